@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box never
+sees the reference, only the .npz files this script writes.  The fixtures are
+data — seeded inputs and the reference's outputs on them — never reference code.
+
+    python tests/golden/make_golden.py [--only geometry|fitters|network|step]
+
+Harness-side shims (the reference files are untouched):
+  * torch.solve was removed from torch>=2        (call site SPFN/geometry_utils.py:140)
+  * Tensor.get_device() is -1 for CPU tensors     (SPFN/geometry_utils.py:11,
+    SPFN/differentiable_tls.py:10) -> return the device instead
+  * F.dropout neutralised for network-level fixtures (PointNet2/pn2_network.py:63
+    applies dropout even in eval mode)
+The reference is always driven with fast=False (its CUDA extension cannot be
+built here).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    torch.solve = lambda B, A: (torch.linalg.solve(A, B), None)
+    _gd = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda t: t.device if not t.is_cuda else _gd(t)
+    from PointNet2 import pn2_network
+    from PointNet2.pointnet2_ops.modules import geometry_utils as pn2_geo
+    from SPFN import fitter_factory, losses_implementation
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        fitter_factory.register_primitives(["sphere", "plane", "cylinder", "cone"])
+    return pn2_network, pn2_geo, fitter_factory, losses_implementation
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (name, os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------- geometry
+def ref_fps(pn2_geo, pos_bcn, S, seed):
+    """Run the reference CPU FPS with a known start: the first randint after
+    manual_seed is the start vector (geometry_utils.py:92)."""
+    B, _, N = pos_bcn.shape
+    torch.manual_seed(seed)
+    start = torch.randint(0, N, (B,), dtype=torch.long)
+    torch.manual_seed(seed)
+    idx = pn2_geo.farthest_point_sample(pos_bcn, S, fast=False)
+    assert torch.equal(idx[:, 0], start)
+    return start, idx
+
+
+def make_geometry(pn2_geo):
+    from cpfn_amd import synthetic
+    from oracle import geometry as og
+
+    out = {}
+    # ---- two 8192-pt clouds: one uniform, one "points on primitives" (dense balls)
+    P = torch.cat([synthetic.uniform_cloud(1, 8192, seed=11),
+                   synthetic.primitive_cloud(1, 8192, seed=12)["P"]], 0)       # [2,8192,3]
+    pos = P.transpose(1, 2).contiguous()                                          # [2,3,8192]
+    start1, idx1 = ref_fps(pn2_geo, pos, 512, seed=101)
+    l1 = pn2_geo.select_point_subset(pos, idx1)                                   # [2,3,512]
+    start2, idx2 = ref_fps(pn2_geo, l1, 128, seed=102)
+    l2 = pn2_geo.select_point_subset(l1, idx2)
+    ball1 = pn2_geo.ball_query(0.2, 64, pos, l1, fast=False)                      # [2,512,64]
+    ball2 = pn2_geo.ball_query(0.4, 64, l1, l2, fast=False)                       # [2,128,64]
+    d3, i3 = pn2_geo.three_nn(point_pos=l1, query_pos=pos, fast=False)            # [2,8192,3]
+    d2, i2 = pn2_geo.three_nn(point_pos=l2, query_pos=l1, fast=False)             # [2,512,3]
+    out.update(xyz=P.numpy(), fps1_start=start1.numpy(), fps1_idx=idx1.numpy().astype(np.int16),
+               fps2_start=start2.numpy(), fps2_idx=idx2.numpy().astype(np.int16),
+               ball1_idx=ball1.numpy().astype(np.int16), ball2_idx=ball2.numpy().astype(np.int16),
+               nn3_dist=d3.numpy(), nn3_idx=i3.numpy().astype(np.int16),
+               nn2_dist=d2.numpy(), nn2_idx=i2.numpy().astype(np.int16))
+    # cross-check the C oracle right here (the CPU test-suite re-checks from the file)
+    l1_np = l1.transpose(1, 2).contiguous().numpy()
+    l2_np = l2.transpose(1, 2).contiguous().numpy()
+    assert np.array_equal(og.farthest_point_sample(P.numpy(), 512, start1.numpy()), idx1.numpy())
+    assert np.array_equal(og.farthest_point_sample(l1_np, 128, start2.numpy()), idx2.numpy())
+    assert np.array_equal(og.ball_query(0.2, 64, P.numpy(), l1_np), ball1.numpy())
+    assert np.array_equal(og.ball_query(0.4, 64, l1_np, l2_np), ball2.numpy())
+    od, oi = og.three_nn(P.numpy(), l1_np)
+    print("3nn sfp3: idx mismatches", int((oi != i3.numpy()).sum()), "dist bit mismatches",
+          int((od.view(np.uint32) != d3.numpy().view(np.uint32)).sum()))
+    save("geometry_8192.npz", **out)
+
+    # ---- ragged / edge sizes: N not a multiple of 64, S small, K small, K > #neighbours,
+    #      duplicate points (ties), a radius whose f32(r**2) rounds UP (r=0.3)
+    g = torch.Generator().manual_seed(5)
+    Pr = torch.rand(3, 1000, 3, generator=g) * 2 - 1
+    Pr[:, 500:520] = Pr[:, 100:120]                      # exact duplicates -> distance ties
+    posr = Pr.transpose(1, 2).contiguous()
+    sr, ir = ref_fps(pn2_geo, posr, 37, seed=7)
+    cr = pn2_geo.select_point_subset(posr, ir)
+    small = {}
+    for r, K in [(0.3, 16), (0.2, 5), (0.7, 128), (0.05, 8)]:
+        small["ball_r%g_k%d" % (r, K)] = pn2_geo.ball_query(r, K, posr, cr, fast=False).numpy().astype(np.int16)
+    dr, inn = pn2_geo.three_nn(point_pos=cr, query_pos=posr, fast=False)
+    dist = pn2_geo.pairwise_squared_distance(cr, posr[:, :, :257])               # [3,37,257]
+    # interpolation forward + adjoint (autograd through the reference's gather)
+    feats = torch.randn(3, 19, 37, generator=g, requires_grad=True)
+    recip = 1.0 / (dr + 1e-8)
+    w = recip / recip.sum(dim=2, keepdim=True)
+    interp = pn2_geo.three_weighted_sum(feats, inn, w, fast=False)                # [3,19,1000]
+    gout = torch.randn(interp.shape, generator=g)
+    interp.backward(gout)
+    # grouping forward + adjoint
+    pts = torch.randn(3, 7, 1000, generator=g, requires_grad=True)
+    bidx = torch.from_numpy(small["ball_r0.3_k16"].astype(np.int64))
+    grouped = pn2_geo.select_point_subset(pts, bidx)                              # [3,7,37,16]
+    gg = torch.randn(grouped.shape, generator=g)
+    grouped.backward(gg)
+    save("geometry_ragged.npz", xyz=Pr.numpy(), fps_start=sr.numpy(), fps_idx=ir.numpy().astype(np.int16),
+         nn_dist=dr.numpy(), nn_idx=inn.numpy().astype(np.int16), pdist=dist.numpy(),
+         feats=feats.detach().numpy(), w=w.numpy(), interp=interp.detach().numpy(), interp_gout=gout.numpy(),
+         interp_gfeats=feats.grad.numpy(), pts=pts.detach().numpy(), grouped=grouped.detach().numpy(),
+         grouped_gout=gg.numpy(), grouped_gpts=pts.grad.numpy(), **small)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    pn2_network, pn2_geo, fitter_factory, losses = import_reference()
+    torch.set_num_threads(8)
+    if args.only in (None, "geometry"):
+        make_geometry(pn2_geo)
+    if args.only in (None, "fitters"):
+        from make_golden_spfn import make_fitters
+        make_fitters(losses)
+    if args.only in (None, "network"):
+        from make_golden_spfn import make_network
+        make_network(pn2_network, pn2_geo)
+    if args.only in (None, "step"):
+        from make_golden_spfn import make_step
+        make_step(pn2_network, pn2_geo, losses)
+
+
+if __name__ == "__main__":
+    main()
