@@ -1,0 +1,83 @@
+"""Builds libcpfn_hip.so in-tree with hipcc for gfx950 (no GPU needed to compile).
+
+    python -m cpfn_amd.build [--force]
+
+One translation unit per kernel family, linked into one shared object whose only
+exported symbols are the `extern "C"` entry points declared in include/cpfn_hip.h.
+Geometry files are compiled with -ffp-contract=off: their index outputs must be
+bit-identical to the reference's CPU arithmetic, so the compiler may not fuse a
+multiply into an add unless the source says fma.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+SO = os.path.join(HERE, "libcpfn_hip.so")
+ARCH = "gfx950"
+
+# file -> extra flags
+SOURCES = {
+    "abi.hip": [],
+    "sampling.hip": ["-ffp-contract=off"],
+    "neighbors.hip": ["-ffp-contract=off"],
+    "gather.hip": ["-ffp-contract=off"],
+    "fitters.hip": ["-ffp-contract=off"],
+    "mlp.hip": [],
+}
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _deps(src):
+    d = [os.path.join(CSRC, src), os.path.join(HERE, "..", "include", "cpfn_hip.h")]
+    d += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return d
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _compile(src, flags, force):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    if force or _stale(obj, _deps(src)):
+        cmd = [_hipcc()] + COMMON + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-4000:]))
+        return obj, True
+    return obj, False
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = {s: f for s, f in SOURCES.items() if os.path.exists(os.path.join(CSRC, s))}
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        res = list(ex.map(lambda kv: _compile(kv[0], kv[1], force), srcs.items()))
+    objs = [o for o, _ in res]
+    if force or any(c for _, c in res) or _stale(SO, objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+        if verbose:
+            print("linked", SO)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,39 @@
+// Shared helpers for the gfx950 kernels of libcpfn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cpfn_hip.h"
+
+#define CPFN_WAVE 64
+
+static inline int cpfn_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+static inline int cpfn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ‖p‖² rounded like torch.sum(p**2, dim=1) on CPU: ((x²+y²)+z²), no contraction.
+__device__ __forceinline__ float cpfn_sqnorm3(float x, float y, float z) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+
+// One entry of the reference's pairwise_squared_distance on CPU
+// (modules/geometry_utils.py:20-22): -2*(fma chain x,y,z) + |src|² + |dst|².
+__device__ __forceinline__ float cpfn_pair_sqdist(float sx, float sy, float sz, float sn,
+                                                  float dx, float dy, float dz, float dn) {
+  float dot = __fmul_rn(sx, dx);
+  dot = __fmaf_rn(sy, dy, dot);
+  dot = __fmaf_rn(sz, dz, dot);
+  float d = __fmul_rn(-2.0f, dot);
+  d = __fadd_rn(d, sn);
+  return __fadd_rn(d, dn);
+}
+
+__device__ __forceinline__ unsigned long long cpfn_shfl_xor_u64(unsigned long long v, int m) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl_xor(lo, m, CPFN_WAVE);
+  hi = __shfl_xor(hi, m, CPFN_WAVE);
+  return ((unsigned long long)hi << 32) | lo;
+}

@@ -1,0 +1,143 @@
+// Ball query and 3-nearest-neighbour search for gfx950.
+//
+// Both evaluate the reference's CPU distance (modules/geometry_utils.py:4-23) bit for
+// bit: D = ((-2*dot) + |q|²) + |p|² with dot an fma chain over x, y, z.
+//
+// ball_query : one 64-lane wave per query.  The wave strides over the cloud 64 points
+//              at a time in index order; `__ballot` + popcount-of-lower-lanes gives each
+//              kept point its output slot, so the first K kept indices land in index
+//              order with no sort, and the wave stops as soon as K are found.
+// three_nn   : one lane per query, candidates broadcast from LDS as float4 (x,y,z,|p|²),
+//              three-deep insertion with strict '<' (ties keep the lower index).
+#include "common.h"
+
+namespace {
+
+constexpr int BQ_WAVES = 4;
+
+__global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz, int B, int N, int S, float thr, int K,
+    int *__restrict__ idx_out) {
+  const int lane = threadIdx.x & (CPFN_WAVE - 1);
+  const long long q = (long long)blockIdx.x * BQ_WAVES + (threadIdx.x / CPFN_WAVE);
+  if (q >= (long long)B * S) return;  // wave-uniform
+  const int b = (int)(q / S);
+  const float *p = xyz + (size_t)b * N * 3;
+  const float *c = new_xyz + (size_t)q * 3;
+  int *out = idx_out + (size_t)q * K;
+  const float qx = c[0], qy = c[1], qz = c[2];
+  const float qn = cpfn_sqnorm3(qx, qy, qz);
+
+  int cnt = 0;
+  int first = N;  // what the reference's sort-based code pads with when nothing is kept
+  for (int base = 0; base < N && cnt < K; base += CPFN_WAVE) {
+    const int n = base + lane;
+    bool keep = false;
+    if (n < N) {
+      const float x = p[3 * n], y = p[3 * n + 1], z = p[3 * n + 2];
+      const float d = cpfn_pair_sqdist(qx, qy, qz, qn, x, y, z, cpfn_sqnorm3(x, y, z));
+      keep = !(d > thr);
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (mask) {
+      if (cnt == 0) first = base + __builtin_ctzll(mask);
+      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (keep && pos < K) out[pos] = n;
+      cnt += __popcll(mask);
+    }
+  }
+  if (cnt > K) cnt = K;
+  for (int k = cnt + lane; k < K; k += CPFN_WAVE) out[k] = first;
+}
+
+constexpr int NN_THREADS = 256;
+constexpr int NN_TILE = 1024;
+
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__restrict__ unknown,
+                                                              const float *__restrict__ known, int N, int M,
+                                                              float *__restrict__ dist2, int *__restrict__ idx) {
+  __shared__ float4 s_known[NN_TILE];
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * NN_THREADS + threadIdx.x;
+  const float *kn = known + (size_t)b * M * 3;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (i < N) {
+    const float *u = unknown + ((size_t)b * N + i) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  const float un = cpfn_sqnorm3(ux, uy, uz);
+  float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+  int i0 = M, i1 = M, i2 = M;
+  for (int base = 0; base < M; base += NN_TILE) {
+    const int cntk = min(NN_TILE, M - base);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cntk; j += NN_THREADS) {
+      const float x = kn[3 * (base + j)], y = kn[3 * (base + j) + 1], z = kn[3 * (base + j) + 2];
+      s_known[j] = make_float4(x, y, z, cpfn_sqnorm3(x, y, z));
+    }
+    __syncthreads();
+    for (int j = 0; j < cntk; ++j) {
+      const float4 k4 = s_known[j];
+      const float d = cpfn_pair_sqdist(ux, uy, uz, un, k4.x, k4.y, k4.z, k4.w);
+      const int jj = base + j;
+      if (d < d2) {
+        if (d < d1) {
+          d2 = d1; i2 = i1;
+          if (d < d0) {
+            d1 = d0; i1 = i0; d0 = d; i0 = jj;
+          } else {
+            d1 = d; i1 = jj;
+          }
+        } else {
+          d2 = d; i2 = jj;
+        }
+      }
+    }
+  }
+  if (i < N) {
+    float *od = dist2 + ((size_t)b * N + i) * 3;
+    int *oi = idx + ((size_t)b * N + i) * 3;
+    od[0] = d0; od[1] = d1; od[2] = d2;
+    oi[0] = i0; oi[1] = i1; oi[2] = i2;
+  }
+}
+
+__global__ void three_weights_kernel(const float *__restrict__ dist, long long R, float *__restrict__ w) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float a = __fdiv_rn(1.0f, __fadd_rn(dist[3 * r], 1e-8f));
+  const float b = __fdiv_rn(1.0f, __fadd_rn(dist[3 * r + 1], 1e-8f));
+  const float c = __fdiv_rn(1.0f, __fadd_rn(dist[3 * r + 2], 1e-8f));
+  const float s = __fadd_rn(__fadd_rn(a, b), c);
+  w[3 * r] = __fdiv_rn(a, s);
+  w[3 * r + 1] = __fdiv_rn(b, s);
+  w[3 * r + 2] = __fdiv_rn(c, s);
+}
+
+}  // namespace
+
+extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float thr, int K,
+                               int *idx_out, void *stream) {
+  if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
+  const long long Q = (long long)B * S;
+  if (Q == 0) return 0;
+  ball_query_kernel<<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+      xyz, new_xyz, B, N, S, thr, K, idx_out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_three_nn(const float *unknown, const float *known, int B, int N, int M, float *dist2,
+                             int *idx, void *stream) {
+  if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist2 || !idx) return CPFN_EINVAL;
+  if (B == 0 || N == 0) return 0;
+  dim3 grid(cpfn_cdiv(N, NN_THREADS), B);
+  three_nn_kernel<<<grid, NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M, dist2, idx);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_three_weights(const float *dist, int64_t R, float *w, void *stream) {
+  if (R < 0 || !dist || !w) return CPFN_EINVAL;
+  if (R == 0) return 0;
+  three_weights_kernel<<<cpfn_cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(dist, R, w);
+  return cpfn_launch_status();
+}

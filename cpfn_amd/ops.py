@@ -1,0 +1,194 @@
+"""Tensor-level front-end of the HIP kernels: argument checks (the reference's
+CHECK_CONTIGUOUS / CHECK_IS_FLOAT / CHECK_IS_INT / CHECK_CUDA macros,
+cuda_ops/include/utils.h:5-25, become RuntimeErrors here), output allocation with
+torch (the C ABI never allocates) and launch on torch's current stream.
+"""
+import numpy as np
+import torch
+
+from . import lib as _l
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA(HIP) tensor: CPU not supported" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be a %s tensor" % (name, str(dtype).replace("torch.", "")))
+    return t
+
+
+def ball_query_threshold(radius):
+    """f32(radius**2 in double): what `sqrdists > radius ** 2` compares against
+    (modules/geometry_utils.py:156)."""
+    return float(np.float32(float(radius) ** 2))
+
+
+def fps(xyz, num_samples, start=None, skip_near_origin=False):
+    """xyz [B,N,3] f32, start [B] i32 or None (-> index 0) -> idx [B,S] i32."""
+    _chk(xyz, "xyz", torch.float32)
+    B, N, _ = xyz.shape
+    if start is not None:
+        _chk(start, "start", torch.int32)
+    out = torch.empty(B, num_samples, dtype=torch.int32, device=xyz.device)
+    scratch = torch.empty(B, N, dtype=torch.float32, device=xyz.device) if N > 8192 else None
+    with torch.cuda.device(xyz.device):
+        _l.check(_l.lib().cpfn_fps(_ptr(xyz), B, N, int(num_samples), _ptr(start),
+                                   1 if skip_near_origin else 0, _ptr(out), _ptr(scratch), _stream()), "cpfn_fps")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """new_xyz [B,S,3], xyz [B,N,3] -> idx [B,S,K] i32 (argument order of the
+    reference's cuda_ops.ball_query, ball_query.cpp)."""
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(xyz, "xyz", torch.float32)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    out = torch.empty(B, S, int(nsample), dtype=torch.int32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _l.check(_l.lib().cpfn_ball_query(_ptr(xyz), _ptr(new_xyz), B, N, S, ball_query_threshold(radius),
+                                          int(nsample), _ptr(out), _stream()), "cpfn_ball_query")
+    return out
+
+
+def three_nn(unknown, known):
+    """unknown [B,N,3] queries, known [B,M,3] -> (dist2 [B,N,3] f32, idx [B,N,3] i32)."""
+    _chk(unknown, "unknown", torch.float32)
+    _chk(known, "known", torch.float32)
+    B, N, _ = unknown.shape
+    M = known.shape[1]
+    d = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
+    i = torch.empty(B, N, 3, dtype=torch.int32, device=unknown.device)
+    with torch.cuda.device(unknown.device):
+        _l.check(_l.lib().cpfn_three_nn(_ptr(unknown), _ptr(known), B, N, M, _ptr(d), _ptr(i), _stream()),
+                 "cpfn_three_nn")
+    return d, i
+
+
+def three_weights(dist):
+    _chk(dist, "dist", torch.float32)
+    w = torch.empty_like(dist)
+    with torch.cuda.device(dist.device):
+        _l.check(_l.lib().cpfn_three_weights(_ptr(dist), dist.numel() // 3, _ptr(w), _stream()), "cpfn_three_weights")
+    return w
+
+
+# ----------------------------------------------------------- channel-major (drop-in) ops
+def three_interp_fwd(feats, idx, w):
+    _chk(feats, "points", torch.float32); _chk(idx, "idx", torch.int32); _chk(w, "weight", torch.float32)
+    B, C, M = feats.shape
+    N = idx.shape[1]
+    out = torch.empty(B, C, N, dtype=torch.float32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        _l.check(_l.lib().cpfn_three_interp_fwd(_ptr(feats), _ptr(idx), _ptr(w), B, C, M, N, _ptr(out), _stream()),
+                 "cpfn_three_interp_fwd")
+    return out
+
+
+def three_interp_bwd(grad_out, idx, w, M):
+    _chk(grad_out, "grad_out", torch.float32); _chk(idx, "idx", torch.int32); _chk(w, "weight", torch.float32)
+    B, C, N = grad_out.shape
+    out = torch.zeros(B, C, int(M), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _l.check(_l.lib().cpfn_three_interp_bwd(_ptr(grad_out), _ptr(idx), _ptr(w), B, C, N, int(M), _ptr(out),
+                                                _stream()), "cpfn_three_interp_bwd")
+    return out
+
+
+def group_fwd(points, idx):
+    """points [B,C,N], idx [B,S,K] or [B,S] -> [B,C,S,K] / [B,C,S]."""
+    _chk(points, "points", torch.float32); _chk(idx, "idx", torch.int32)
+    B, C, N = points.shape
+    S = idx.shape[1]
+    K = idx.shape[2] if idx.dim() == 3 else 1
+    out = torch.empty((B, C, S, K) if idx.dim() == 3 else (B, C, S), dtype=torch.float32, device=points.device)
+    with torch.cuda.device(points.device):
+        _l.check(_l.lib().cpfn_group_fwd(_ptr(points), _ptr(idx), B, C, N, S, K, _ptr(out), _stream()),
+                 "cpfn_group_fwd")
+    return out
+
+
+def group_bwd(grad_out, idx, N):
+    _chk(grad_out, "grad_out", torch.float32); _chk(idx, "idx", torch.int32)
+    B, C = grad_out.shape[:2]
+    S = idx.shape[1]
+    K = idx.shape[2] if idx.dim() == 3 else 1
+    out = torch.zeros(B, C, int(N), dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _l.check(_l.lib().cpfn_group_bwd(_ptr(grad_out), _ptr(idx), B, C, int(N), S, K, _ptr(out), _stream()),
+                 "cpfn_group_bwd")
+    return out
+
+
+# ----------------------------------------------------------- points-major (native) ops
+def gather_rows(rows, idx):
+    """rows [B,N,C] (any 2/4-byte dtype with C*itemsize % 4 == 0), idx [B,...] i32 -> [B,...,C]."""
+    _chk(idx, "idx", torch.int32)
+    if not (rows.is_cuda and rows.is_contiguous()):
+        raise RuntimeError("rows must be a contiguous CUDA(HIP) tensor")
+    B, N, C = rows.shape
+    R = idx[0].numel()
+    out = torch.empty((B,) + tuple(idx.shape[1:]) + (C,), dtype=rows.dtype, device=rows.device)
+    with torch.cuda.device(rows.device):
+        _l.check(_l.lib().cpfn_gather_rows(_ptr(rows), _ptr(idx), B, N, R, C * rows.element_size(), _ptr(out),
+                                           _stream()), "cpfn_gather_rows")
+    return out
+
+
+def scatter_add_rows(grad_out, idx, N):
+    """grad_out [B,...,C] f32, idx [B,...] -> [B,N,C] f32."""
+    _chk(grad_out, "grad_out", torch.float32); _chk(idx, "idx", torch.int32)
+    B = grad_out.shape[0]
+    C = grad_out.shape[-1]
+    R = idx[0].numel()
+    out = torch.zeros(B, int(N), C, dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _l.check(_l.lib().cpfn_scatter_add_rows_f32(_ptr(grad_out), _ptr(idx), B, int(N), R, C, _ptr(out), _stream()),
+                 "cpfn_scatter_add_rows_f32")
+    return out
+
+
+def group_xyz_centered(xyz, new_xyz, idx):
+    """xyz [B,N,3], new_xyz [B,S,3], idx [B,S,K] -> [B,S,K,3]."""
+    _chk(xyz, "xyz", torch.float32); _chk(new_xyz, "new_xyz", torch.float32); _chk(idx, "idx", torch.int32)
+    B, N, _ = xyz.shape
+    S, K = idx.shape[1:]
+    out = torch.empty(B, S, K, 3, dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _l.check(_l.lib().cpfn_group_xyz_centered(_ptr(xyz), _ptr(new_xyz), _ptr(idx), B, N, S, K, _ptr(out),
+                                                  _stream()), "cpfn_group_xyz_centered")
+    return out
+
+
+def interp_rows_fwd(feats, idx, w):
+    """feats [B,M,C] f32, idx/w [B,N,3] -> [B,N,C]."""
+    _chk(feats, "feats", torch.float32); _chk(idx, "idx", torch.int32); _chk(w, "weight", torch.float32)
+    B, M, C = feats.shape
+    N = idx.shape[1]
+    out = torch.empty(B, N, C, dtype=torch.float32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        _l.check(_l.lib().cpfn_interp_rows_fwd(_ptr(feats), _ptr(idx), _ptr(w), B, M, N, C, _ptr(out), _stream()),
+                 "cpfn_interp_rows_fwd")
+    return out
+
+
+def interp_rows_bwd(grad_out, idx, w, M):
+    _chk(grad_out, "grad_out", torch.float32); _chk(idx, "idx", torch.int32); _chk(w, "weight", torch.float32)
+    B, N, C = grad_out.shape
+    out = torch.zeros(B, int(M), C, dtype=torch.float32, device=grad_out.device)
+    with torch.cuda.device(grad_out.device):
+        _l.check(_l.lib().cpfn_interp_rows_bwd(_ptr(grad_out), _ptr(idx), _ptr(w), B, int(M), N, C, _ptr(out),
+                                               _stream()), "cpfn_interp_rows_bwd")
+    return out

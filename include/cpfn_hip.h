@@ -1,0 +1,127 @@
+/*
+ * cpfn_hip.h — C ABI of libcpfn_hip.so, the MI355X (gfx950) replacement for the
+ * reference's `cuda_ops` extension (PointNet2/pointnet2_ops/cuda_ops) plus the
+ * fused kernels behind SPFN.*_fitter.compute_parameters.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch / ATen types; `stream` is a hipStream_t
+ *     passed as void* (NULL = the null stream);
+ *   - nothing is allocated, nothing synchronises, the call only enqueues kernels —
+ *     so a caller may capture it into a hipGraph;
+ *   - return value: 0 on success, otherwise a hipError_t (launch errors) or
+ *     CPFN_EINVAL for bad arguments.  Never exits the process (the reference's
+ *     CUDA_CHECK_ERRORS() does: cuda_ops/include/cuda_utils.h:30-39);
+ *   - indices are int32 (as in the reference's native ops, include/utils.h:17-21);
+ *   - point coordinates are [B, N, 3] fp32 row-major (cuda_ops/src/sampling_gpu.cu:61).
+ *
+ * Each declaration cites the reference interface it replaces.  The Python shim that
+ * re-creates the nine `cuda_ops.*` names on top of these is cpfn_amd/cuda_ops.py;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ */
+#ifndef CPFN_HIP_H
+#define CPFN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define CPFN_API __attribute__((visibility("default")))
+#else
+#define CPFN_API
+#endif
+
+#define CPFN_EINVAL (-22)
+#define CPFN_ABI_VERSION 1
+
+/* Library / build identification (no GPU needed). */
+CPFN_API int cpfn_abi_version(void);
+CPFN_API const char *cpfn_build_info(void);
+
+/* ------------------------------------------------------------------ sampling */
+
+/* Furthest-point sampling.  Replaces farthest_point_sampling()
+ * (cuda_ops/src/sampling.cpp:64-86, kernel sampling_gpu.cu:63-159) with the
+ * semantics of the reference's CPU route (modules/geometry_utils.py:88-101):
+ * sample 0 is start[b] (NULL -> 0), distances are ((dx*dx+dy*dy)+dz*dz) in
+ * unfused fp32, ties go to the lowest index.  idx_out[B,S].
+ * flags bit0 = 1 additionally ignores points with |p|^2 <= 1e-3 like the CUDA
+ * kernel does (sampling_gpu.cu:90-91).
+ * scratch: B*N floats, only touched when N > CPFN_FPS_MAX_RESIDENT (may be NULL
+ * otherwise); the reference allocates the same [B,N] `tmp` itself (sampling.cpp:73). */
+#define CPFN_FPS_MAX_RESIDENT 8192
+#define CPFN_FPS_SKIP_NEAR_ORIGIN 1
+CPFN_API int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, int flags,
+             int *idx_out, float *scratch, void *stream);
+
+/* Ball query.  Replaces ball_query() (cuda_ops/src/ball_query.cpp, kernel
+ * ball_query_gpu.cu:9-44) with the CPU route's arithmetic
+ * (modules/geometry_utils.py:151-161): D = -2 q.p + |q|^2 + |p|^2 with the K=3
+ * inner product as an fma chain, a point is kept iff !(D > thr) where
+ * thr = (float)(radius**2 computed in double); first K kept indices in index
+ * order, padded with the first; a query with no kept point gets K copies of N.
+ * xyz[B,N,3], new_xyz[B,S,3] -> idx_out[B,S,K]. */
+CPFN_API int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S,
+                    float thr, int K, int *idx_out, void *stream);
+
+/* 3 nearest neighbours.  Replaces three_nn() (cuda_ops/src/interpolate.cpp,
+ * kernel interpolate_gpu.cu:9-59) with the CPU route's arithmetic
+ * (modules/geometry_utils.py:212-215): the same expanded D as the ball query,
+ * ascending, ties to the lower index; returns SQUARED distances (can be < 0).
+ * unknown[B,N,3] (queries), known[B,M,3] -> dist2[B,N,3], idx[B,N,3].
+ * M < 3 leaves +inf / M in the unused slots. */
+CPFN_API int cpfn_three_nn(const float *unknown, const float *known, int B, int N, int M,
+                  float *dist2, int *idx, void *stream);
+
+/* Inverse-distance weights of PointsetFeaturePropagation.forward
+ * (modules/pointset_feature_propagation.py:40-42): w = (1/(d+1e-8)) / sum.
+ * dist[R,3] -> w[R,3]. */
+CPFN_API int cpfn_three_weights(const float *dist, int64_t R, float *w, void *stream);
+
+/* ------------------------------------------------- channel-major fp32 ops
+ * Drop-in layouts of the reference's bound functions (bindings.cpp:6-19). */
+
+/* three_weighted_sum (interpolate_gpu.cu:72-101): feats[B,C,M], idx/w[B,N,3] -> out[B,C,N] */
+CPFN_API int cpfn_three_interp_fwd(const float *feats, const int *idx, const float *w, int B,
+                          int C, int M, int N, float *out, void *stream);
+/* three_weighted_sum_grad (interpolate_gpu.cu:116-143): grad_out[B,C,N] -> grad_feats[B,C,M]
+ * (grad_feats must be zero-filled by the caller, as the reference's wrapper does). */
+CPFN_API int cpfn_three_interp_bwd(const float *grad_out, const int *idx, const float *w, int B,
+                          int C, int N, int M, float *grad_feats, void *stream);
+/* group_points (group_points_gpu.cu:8-28): points[B,C,N], idx[B,S,K] -> out[B,C,S,K].
+ * K = 1 is gather_points (sampling_gpu.cu:8-20).  Indices >= N read point N-1. */
+CPFN_API int cpfn_group_fwd(const float *points, const int *idx, int B, int C, int N, int S,
+                   int K, float *out, void *stream);
+/* group_points_grad / gather_points_grad (group_points_gpu.cu:43-64, sampling_gpu.cu:32-45):
+ * grad_out[B,C,S,K] -> grad_points[B,C,N] (zero-filled by the caller). */
+CPFN_API int cpfn_group_bwd(const float *grad_out, const int *idx, int B, int C, int N, int S,
+                   int K, float *grad_points, void *stream);
+
+/* ------------------------------------------------- points-major ops (native layout)
+ * The MI355X path keeps features as [B, N, C] rows so that a neighbour gather is a
+ * contiguous row copy and an MFMA operand fragment is one 16-byte load. */
+
+/* Row gather: rows[B,N,row_bytes], idx[B,R] -> out[B,R,row_bytes].  row_bytes % 4 == 0. */
+CPFN_API int cpfn_gather_rows(const void *rows, const int *idx, int B, int N, int R,
+                     int row_bytes, void *out, void *stream);
+/* Adjoint for fp32 rows: grad_out[B,R,C] scattered-added into grad_rows[B,N,C]
+ * (zero-filled by the caller). */
+CPFN_API int cpfn_scatter_add_rows_f32(const float *grad_out, const int *idx, int B, int N, int R,
+                              int C, float *grad_rows, void *stream);
+/* Grouped, centred coordinates of PointsetAbstraction.forward
+ * (modules/pointset_abstraction.py:62-63): out[b,s,k,:] = xyz[b,idx[b,s,k],:] - new_xyz[b,s,:]. */
+CPFN_API int cpfn_group_xyz_centered(const float *xyz, const float *new_xyz, const int *idx, int B,
+                            int N, int S, int K, float *out, void *stream);
+/* Points-major interpolation: feats[B,M,C], idx/w[B,N,3] -> out[B,N,C] (fp32). */
+CPFN_API int cpfn_interp_rows_fwd(const float *feats, const int *idx, const float *w, int B, int M,
+                         int N, int C, float *out, void *stream);
+/* Adjoint: grad_out[B,N,C] -> grad_feats[B,M,C] (zero-filled by the caller). */
+CPFN_API int cpfn_interp_rows_bwd(const float *grad_out, const int *idx, const float *w, int B,
+                         int M, int N, int C, float *grad_feats, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPFN_HIP_H */

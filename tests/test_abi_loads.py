@@ -1,0 +1,48 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/cpfn_hip.h
+declares (no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cpfn_hip.h")).read()
+    return sorted(set(re.findall(r"CPFN_API\s+[\w\s\*]+?\b(cpfn_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from cpfn_amd import build, lib
+    so = build.build()
+    assert os.path.exists(so)
+    h = ctypes.CDLL(so)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(h, n), "symbol %s declared in cpfn_hip.h but not exported" % n
+        assert n in lib.SIGNATURES, "symbol %s has no ctypes prototype in cpfn_amd/lib.py" % n
+    assert set(lib.SIGNATURES) == set(names)
+    assert lib.lib().cpfn_abi_version() == 1
+    assert b"gfx950" in lib.lib().cpfn_build_info()
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "cpfn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "libcpfn_oracle" not in src, f
+
+
+def test_bad_arguments_raise_runtime_error():
+    import pytest
+    import torch
+    from cpfn_amd import cuda_ops
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        cuda_ops.farthest_point_sampling(torch.zeros(1, 8, 3), 2)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        cuda_ops.ball_query(torch.zeros(1, 2, 3), torch.zeros(1, 8, 3), 0.2, 4)

@@ -1,0 +1,165 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the oracle and the golden fixtures.
+Bit-exact for every integer output and for the fp32 squared distances."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as og
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    return t if dtype is None else t.to(dtype)
+
+
+def _i64(a):
+    return a.astype(np.int64)
+
+
+def test_golden_8192(golden):
+    from cpfn_amd import cuda_ops, ops
+    g = golden("geometry_8192.npz")
+    xyz = T(g["xyz"])
+    idx1 = cuda_ops.farthest_point_sampling(xyz, 512, start_idx=T(g["fps1_start"]))
+    assert idx1.dtype == torch.int32
+    assert np.array_equal(idx1.cpu().numpy(), g["fps1_idx"].astype(np.int32))
+    l1 = ops.gather_rows(xyz, idx1)
+    idx2 = cuda_ops.farthest_point_sampling(l1, 128, start_idx=T(g["fps2_start"]))
+    assert np.array_equal(idx2.cpu().numpy(), g["fps2_idx"].astype(np.int32))
+    l2 = ops.gather_rows(l1, idx2)
+    b1 = cuda_ops.ball_query(l1, xyz, 0.2, 64)
+    assert np.array_equal(b1.cpu().numpy(), g["ball1_idx"].astype(np.int32))
+    b2 = cuda_ops.ball_query(l2, l1, 0.4, 64)
+    assert np.array_equal(b2.cpu().numpy(), g["ball2_idx"].astype(np.int32))
+    d, i = cuda_ops.three_nn(xyz, l1)
+    assert np.array_equal(i.cpu().numpy(), g["nn3_idx"].astype(np.int32))
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), g["nn3_dist"].view(np.uint32))
+    d, i = cuda_ops.three_nn(l1, l2)
+    assert np.array_equal(i.cpu().numpy(), g["nn2_idx"].astype(np.int32))
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), g["nn2_dist"].view(np.uint32))
+
+
+def test_golden_ragged(golden):
+    from cpfn_amd import cuda_ops, ops
+    g = golden("geometry_ragged.npz")
+    xyz = T(g["xyz"])
+    idx = cuda_ops.farthest_point_sampling(xyz, 37, start_idx=T(g["fps_start"]))
+    assert np.array_equal(idx.cpu().numpy(), g["fps_idx"].astype(np.int32))
+    ctr = ops.gather_rows(xyz, idx)
+    for r, K in [(0.3, 16), (0.2, 5), (0.7, 128), (0.05, 8)]:
+        got = cuda_ops.ball_query(ctr, xyz, r, K).cpu().numpy()
+        assert np.array_equal(got, g["ball_r%g_k%d" % (r, K)].astype(np.int32)), (r, K)
+    d, i = cuda_ops.three_nn(xyz, ctr)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), g["nn_dist"].view(np.uint32))
+    od, oi = og.three_nn(g["xyz"], ctr.cpu().numpy())      # ties: compare with the oracle's rule
+    assert np.array_equal(i.cpu().numpy(), oi.astype(np.int32))
+    w = ops.three_weights(d)
+    assert np.array_equal(w.cpu().numpy().view(np.uint32), og.three_weights(od).view(np.uint32))
+    # channel-major drop-in ops
+    nn_idx = T(g["nn_idx"], torch.int32)
+    out = cuda_ops.three_weighted_sum(T(g["feats"]), nn_idx, T(g["w"]))
+    np.testing.assert_allclose(out.cpu().numpy(), g["interp"], rtol=1e-6, atol=1e-6)
+    gf = cuda_ops.three_weighted_sum_grad(T(g["interp_gout"]), nn_idx, T(g["w"]), 37)
+    np.testing.assert_allclose(gf.cpu().numpy(), g["interp_gfeats"], rtol=1e-4, atol=1e-4)
+    bidx = T(g["ball_r0.3_k16"], torch.int32)
+    grouped = cuda_ops.group_points(T(g["pts"]), bidx)
+    assert np.array_equal(grouped.cpu().numpy(), g["grouped"])
+    gp = cuda_ops.group_points_grad(T(g["grouped_gout"]), bidx, 1000)
+    np.testing.assert_allclose(gp.cpu().numpy(), g["grouped_gpts"], rtol=1e-5, atol=1e-5)
+    # gather_points = K==1 grouping
+    gi = T(g["fps_idx"], torch.int32)
+    gpts = cuda_ops.gather_points(T(g["pts"]), gi)
+    assert np.array_equal(gpts.cpu().numpy(), og.group_points(g["pts"], _i64(g["fps_idx"])))
+    gg = cuda_ops.gather_points_grad(gpts, gi, 1000)
+    np.testing.assert_allclose(gg.cpu().numpy(), og.group_points_grad(gpts.cpu().numpy(), _i64(g["fps_idx"]), 1000),
+                               rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,S", [(1, 64, 64), (3, 65, 7), (2, 513, 100), (2, 2049, 33), (1, 8192, 512),
+                                   (2, 10000, 50), (1, 40000, 64)])
+def test_fps_sizes_vs_oracle(B, N, S):
+    from cpfn_amd import cuda_ops
+    rng = np.random.default_rng(N + S)
+    xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    start = rng.integers(0, N, B)
+    got = cuda_ops.farthest_point_sampling(T(xyz), S, start_idx=T(start)).cpu().numpy()
+    assert np.array_equal(got, og.farthest_point_sample(xyz, S, start).astype(np.int32))
+
+
+def test_fps_ties_and_default_start():
+    from cpfn_amd import cuda_ops
+    # a lattice has many exactly equal distances: the lowest index must win each tie
+    ax = np.linspace(-1, 1, 9, dtype=np.float32)
+    xyz = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, -1, 3)
+    got = cuda_ops.farthest_point_sampling(T(xyz), 100).cpu().numpy()
+    assert np.array_equal(got, og.farthest_point_sample(xyz, 100, [0]).astype(np.int32))
+
+
+@pytest.mark.parametrize("B,N,S,K,r", [(2, 100, 10, 4, 0.5), (1, 8192, 512, 64, 0.2), (3, 777, 99, 32, 0.3),
+                                       (2, 4096, 64, 128, 1.5), (1, 300, 300, 1, 0.1)])
+def test_ball_query_vs_oracle(B, N, S, K, r):
+    from cpfn_amd import cuda_ops
+    rng = np.random.default_rng(N + K)
+    xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    q = xyz[:, rng.permutation(N)[:S]]
+    got = cuda_ops.ball_query(T(q), T(xyz), r, K).cpu().numpy()
+    assert np.array_equal(got, og.ball_query(r, K, xyz, q).astype(np.int32))
+
+
+def test_ball_query_no_neighbour_pads_with_N():
+    from cpfn_amd import cuda_ops
+    xyz = np.zeros((1, 10, 3), np.float32)
+    q = np.full((1, 1, 3), 5.0, np.float32)
+    assert np.array_equal(cuda_ops.ball_query(T(q), T(xyz), 0.2, 4).cpu().numpy(), np.full((1, 1, 4), 10))
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 1000, 3), (1, 8192, 512), (2, 333, 1500), (1, 5, 2)])
+def test_three_nn_vs_oracle(B, N, M):
+    from cpfn_amd import cuda_ops
+    rng = np.random.default_rng(N + M)
+    u = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    k = rng.uniform(-1, 1, (B, M, 3)).astype(np.float32)
+    if M >= 3 and N >= M:
+        u[:, :M] = k                      # coincident points -> slightly negative squared distances
+    d, i = cuda_ops.three_nn(T(u), T(k))
+    od, oi = og.three_nn(u, k)
+    assert np.array_equal(i.cpu().numpy(), oi.astype(np.int32))
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_points_major_ops_vs_oracle():
+    from cpfn_amd import ops
+    rng = np.random.default_rng(3)
+    B, N, S, K, C = 2, 500, 40, 16, 20
+    xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    feats = rng.normal(size=(B, N, C)).astype(np.float32)
+    idx = rng.integers(0, N, (B, S, K))
+    new_xyz = xyz[:, :S]
+    # row gather == channel-major grouping transposed
+    got = ops.gather_rows(T(feats), T(idx, torch.int32)).cpu().numpy()
+    want = og.group_points(feats.transpose(0, 2, 1), idx).transpose(0, 2, 3, 1)
+    assert np.array_equal(got, want)
+    got16 = ops.gather_rows(T(feats).to(torch.bfloat16), T(idx, torch.int32))
+    assert torch.equal(got16.cpu(), torch.from_numpy(want).to(torch.bfloat16))
+    c = ops.group_xyz_centered(T(xyz), T(new_xyz), T(idx, torch.int32)).cpu().numpy()
+    wantc = og.group_points(xyz.transpose(0, 2, 1), idx).transpose(0, 2, 3, 1) - new_xyz[:, :, None, :]
+    assert np.array_equal(c, wantc)
+    go = rng.normal(size=(B, S, K, C)).astype(np.float32)
+    gs = ops.scatter_add_rows(T(go), T(idx, torch.int32), N).cpu().numpy()
+    wants = og.group_points_grad(go.transpose(0, 3, 1, 2), idx, N).transpose(0, 2, 1)
+    np.testing.assert_allclose(gs, wants, rtol=1e-5, atol=1e-5)
+    nn = rng.integers(0, S, (B, N, 3))
+    w = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    f2 = rng.normal(size=(B, S, C)).astype(np.float32)
+    o = ops.interp_rows_fwd(T(f2), T(nn, torch.int32), T(w)).cpu().numpy()
+    wo = og.three_weighted_sum(f2.transpose(0, 2, 1), nn, w).transpose(0, 2, 1)
+    assert np.array_equal(o.view(np.uint32), np.ascontiguousarray(wo).view(np.uint32))
+    gb = ops.interp_rows_bwd(T(o), T(nn, torch.int32), T(w), S).cpu().numpy()
+    wb = og.three_weighted_sum_grad(np.ascontiguousarray(o.transpose(0, 2, 1)), nn, w, S).transpose(0, 2, 1)
+    np.testing.assert_allclose(gb, wb, rtol=1e-4, atol=1e-4)
