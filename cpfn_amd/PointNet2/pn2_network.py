@@ -1,0 +1,65 @@
+"""PointNet++ encoder/decoder used by GlobalSPFN, LocalSPFN and PatchSelection — drop-in
+for the reference's PointNet2/pn2_network.py (same constructor arguments, state_dict keys
+and `forward(x [B,N,C]) -> [head_0 [B,N,o0], ..., l3_feats [B,1024,1], output_feat [B,128,N]]`).
+
+Data stay points-major ([B, N, C] rows) from input to heads; the two channel-major
+outputs are transposed views.  Quirk kept on purpose: dropout(p=0.5) is applied in every
+mode, as in the reference (pn2_network.py:63 calls F.dropout with its default
+training=True); set `self.dropout_p = 0.0` to neutralise it for parity tests.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import mlp
+from .pointnet2_ops.modules.pointset_abstraction import PointsetAbstraction
+from .pointnet2_ops.modules.pointset_feature_propagation import PointsetFeaturePropagation
+
+
+class PointNet2(torch.nn.Module):
+    def __init__(self, dim_input=3, dim_pos=3, output_sizes=[16], use_glob_features=False,
+                 use_loc_features=False, features_extractor=False):
+        super().__init__()
+        self.dim_pos = dim_pos
+        self.use_glob_features = use_glob_features
+        self.use_loc_features = use_loc_features
+        self.features_extractor = features_extractor
+        self.dropout_p = 0.5
+        extra = (1024 if use_glob_features else 0) + (128 if use_loc_features else 0)
+        self.sa1 = PointsetAbstraction(512, dim_pos, dim_input - dim_pos, [0.2], [64], [[64, 64, 128]])
+        self.sa2 = PointsetAbstraction(128, dim_pos, 128, [0.4], [64], [[128, 128, 256]])
+        self.sa3 = PointsetAbstraction(None, dim_pos, 256, None, None, [256, 512, 1024], group_all=True)
+        self.sfp1 = PointsetFeaturePropagation(1024 + extra + 256, [256, 256])
+        self.sfp2 = PointsetFeaturePropagation(256 + 128, [256, 128])
+        self.sfp3 = PointsetFeaturePropagation(128 + dim_input - dim_pos, [128, 128, 128])
+        self.fc1 = torch.nn.Conv1d(128, 128, 1)
+        if not features_extractor:
+            self.bn1 = torch.nn.BatchNorm1d(128)
+            self.fc2 = torch.nn.ModuleList(torch.nn.Conv1d(128, o, 1) for o in output_sizes)
+
+    def forward(self, x, glob_features=None, loc_features=None, fast=True, fps_start=None):
+        """`fps_start` = optional (start_sa1 [B], start_sa2 [B]) FPS seeds; by default each SA
+        level draws its own from the CPU generator like the reference's CPU route."""
+        B, N, _ = x.shape
+        xyz = x[:, :, :self.dim_pos].contiguous().float()
+        feats0 = x[:, :, self.dim_pos:].contiguous() if x.shape[2] > self.dim_pos else None
+        s1, s2 = fps_start if fps_start is not None else (None, None)
+        l1_xyz, l1, self.aux_sa1 = self.sa1.forward_rows(xyz, feats0, s1)
+        l2_xyz, l2, self.aux_sa2 = self.sa2.forward_rows(l1_xyz, l1, s2)
+        _, l3, _ = self.sa3.forward_rows(l2_xyz, l2)                       # [B,1,1024]
+        if self.use_glob_features:
+            l3 = torch.cat([l3, glob_features.unsqueeze(1).to(l3.dtype)], dim=2)
+        if self.use_loc_features:
+            l3 = torch.cat([l3, loc_features.unsqueeze(1).to(l3.dtype)], dim=2)
+        l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3)
+        l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4)
+        l6, _ = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5)
+        feat = mlp.conv_as_linear(l6.reshape(B * N, -1), self.fc1).float()
+        l3_out = l3.transpose(1, 2)                                         # [B,1024(+extra),1]
+        if self.features_extractor:
+            return l3_out, feat.reshape(B, N, -1).transpose(1, 2)
+        feat = F.relu(mlp._bn_rows(feat, self.bn1))
+        feat = F.dropout(feat, p=self.dropout_p, training=True)
+        results = [mlp.conv_as_linear(feat, head).float().reshape(B, N, -1) for head in self.fc2]
+        results.append(l3_out)
+        results.append(feat.reshape(B, N, -1).transpose(1, 2))
+        return results

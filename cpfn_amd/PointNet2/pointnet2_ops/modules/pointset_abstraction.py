@@ -1,0 +1,76 @@
+"""Set-abstraction level of PointNet++ (drop-in for the reference module of the same
+name, modules/pointset_abstraction.py:7-77): FPS -> ball query -> neighbourhood gather
+(centred on the sampled point) -> shared MLP -> max over the neighbourhood.
+
+Same constructor signature, parameter names (`conv_blocks.i.j`, `bn_blocks.i.j`) and
+`forward(pos [B,C,N], feats [B,D,N]) -> (new_pos [B,C,S], new_feats [B,D',S])` contract.
+Internally everything is points-major: `forward_rows` is what PointNet2 calls.
+"""
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+
+from .... import autograd_ops, mlp, ops
+
+
+class PointsetAbstraction(nn.Module):
+    def __init__(self, num_points, dim_pos, dim_feats, radius_list, num_samples_list, mlp_list, group_all=False):
+        super().__init__()
+        seq = lambda v: list(v) if isinstance(v, Sequence) else [v]
+        self.num_points = num_points
+        self.group_all = group_all
+        self.radius_list = seq(radius_list)
+        self.num_samples_list = seq(num_samples_list)
+        self.mlp_list = list(mlp_list) if isinstance(mlp_list[0], Sequence) else [list(mlp_list)]
+        if not (len(self.radius_list) == len(self.num_samples_list) == len(self.mlp_list)):
+            raise ValueError('Radius, number of samples and mlps lists must have the same number of entries.')
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for widths in self.mlp_list:
+            convs, bns, c_in = nn.ModuleList(), nn.ModuleList(), dim_pos + dim_feats
+            for c_out in widths:
+                convs.append(nn.Conv2d(c_in, c_out, 1))
+                bns.append(nn.BatchNorm2d(c_out))
+                c_in = c_out
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+    # ---------------------------------------------------------------- native layout
+    def forward_rows(self, xyz, feats, start_idx=None):
+        """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux)."""
+        B, N, _ = xyz.shape
+        aux = {}
+        if self.group_all:
+            new_xyz = None
+            g = xyz if feats is None else torch.cat([xyz, feats.to(xyz.dtype)], dim=2)   # pos FIRST (ref :56)
+            groups = [g.reshape(B, 1, N, -1)] * len(self.mlp_list)
+        else:
+            if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
+                start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+            start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
+            sel = ops.fps(xyz, self.num_points, start_idx)
+            new_xyz = ops.gather_rows(xyz, sel)
+            aux["fps_idx"] = sel
+            groups = []
+            for r, k in zip(self.radius_list, self.num_samples_list):
+                nbr = ops.ball_query(new_xyz, xyz, r, k)                                  # [B,S,K] i32
+                aux["ball_idx"] = nbr
+                rel = ops.group_xyz_centered(xyz, new_xyz, nbr)                           # [B,S,K,3]
+                if feats is not None:
+                    gf = autograd_ops.gather_rows(feats, nbr)                             # [B,S,K,D]
+                    rel = torch.cat([gf.to(rel.dtype), rel], dim=3)                       # feats FIRST (ref :66)
+                groups.append(rel)
+        outs = []
+        for g, convs, bns in zip(groups, self.conv_blocks, self.bn_blocks):
+            Bq, S, K, C = g.shape
+            y = mlp.shared_mlp(g.reshape(Bq * S * K, C), convs, bns)
+            outs.append(y.reshape(Bq, S, K, -1).max(dim=2)[0])
+        return new_xyz, torch.cat(outs, dim=2) if len(outs) > 1 else outs[0], aux
+
+    # ---------------------------------------------------------------- reference layout
+    def forward(self, pos, feats, fast=True):
+        xyz = pos.transpose(1, 2).contiguous()
+        f = None if feats is None else feats.transpose(1, 2).contiguous()
+        new_xyz, new_feats, _ = self.forward_rows(xyz, f)
+        return (None if new_xyz is None else new_xyz.transpose(1, 2)), new_feats.transpose(1, 2)

@@ -1,0 +1,44 @@
+"""Feature-propagation level of PointNet++ (drop-in for the reference module of the same
+name, modules/pointset_feature_propagation.py:6-52): 3-NN inverse-distance interpolation
+of the coarse features onto the dense points, skip concatenation, shared MLP.
+
+Same constructor, parameter names (`mlp_convs.i`, `mlp_bns.i`) and
+`forward(pos1, pos2, feats1, feats2)` contract; `forward_rows` is the native entry.
+"""
+import torch
+import torch.nn as nn
+
+from .... import autograd_ops, mlp, ops
+
+
+class PointsetFeaturePropagation(nn.Module):
+    def __init__(self, dim_feats, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        c_in = dim_feats
+        for c_out in mlp:
+            self.mlp_convs.append(nn.Conv1d(c_in, c_out, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(c_out))
+            c_in = c_out
+
+    def forward_rows(self, xyz1, xyz2, feats1, feats2):
+        """xyz1 [B,N,3] dense, xyz2 [B,S,3] coarse or None, feats1 [B,N,D1] or None,
+        feats2 [B,S,D2] -> [B,N,D']."""
+        B, N, _ = xyz1.shape
+        aux = {}
+        if xyz2 is None:
+            interp = feats2.expand(B, N, feats2.shape[2])                  # broadcast the global vector (ref :33-34)
+        else:
+            d2, nn_idx = ops.three_nn(xyz1, xyz2)                           # squared distances (CPU-route semantics)
+            w = ops.three_weights(d2)                                       # 1/(d+1e-8), normalised (ref :40-42)
+            interp = autograd_ops.interp_rows(feats2, nn_idx, w)
+            aux = {"nn_idx": nn_idx, "nn_w": w}
+        x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
+        y = mlp.shared_mlp(x.reshape(B * N, -1), self.mlp_convs, self.mlp_bns)
+        return y.reshape(B, N, -1), aux
+
+    def forward(self, pos1, pos2, feats1, feats2, fast=True):
+        t = lambda a: None if a is None else a.transpose(1, 2).contiguous()
+        out, _ = self.forward_rows(t(pos1), t(pos2), t(feats1), t(feats2))
+        return out.transpose(1, 2)

@@ -1,0 +1,23 @@
+"""Cylinder fitter (drop-in names for SPFN/cylinder_fitter.py)."""
+import torch
+
+from . import fitters_common as _fc
+from .plane_fitter import compute_parameter_loss  # same loss on the axis (reference lines 91-101)
+
+
+def compute_parameters(P, W, X):
+    """P, X [B,N,3], W [B,N,K] -> axis [B,K,3], centre [B,K,3], radius² [B,K]   (reference lines 10-28)."""
+    n, c, r2 = _fc.cylinder_from_moments(_fc.moments(P, W, X))
+    return n.to(P.dtype), c.to(P.dtype), r2.to(P.dtype)
+
+
+def sqrt_safe(x):
+    return torch.sqrt(torch.abs(x) + 1e-10)
+
+
+def compute_residue_single(axis, center, radius_squared, p):
+    """(dist(p, axis line) − r)²   (reference lines 85-89)."""
+    d = p - center
+    d2 = torch.sum(d ** 2, dim=-1)
+    along = torch.sum(d * axis, dim=-1)
+    return (sqrt_safe(d2 - along ** 2) - sqrt_safe(radius_squared)) ** 2

@@ -1,0 +1,225 @@
+"""Losses of the SPFN training step (drop-in names for SPFN/losses_implementation.py).
+
+`compute_parameters` (reference lines 255-278) is the hot-path entry: it runs ONE fused
+moment pass for all four primitive types instead of four tiled fits.  The remaining
+losses are small stock-PyTorch reductions kept signature-compatible so the reference's
+trainer (Utils/training_utils.py:143-146) can call them unchanged; the only structural
+change is `hungarian_matching`, which builds all B cost matrices on the device and makes
+a single device->host copy for SciPy instead of B round trips (reference lines 19-29).
+"""
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from . import cone_fitter, cylinder_fitter, fitters_common as _fc, plane_fitter, sphere_fitter
+
+
+def hungarian_matching(W_pred, I_gt):
+    """W_pred [B,N,K], I_gt [B,N] (gap-free labels, may hold -1) -> matching [B,K] long:
+    GT instance k of cloud b is matched with prediction matching[b,k]; only the first
+    n_gt entries of a row are meaningful (reference lines 11-30)."""
+    B, N, K = W_pred.shape
+    n_gt = I_gt.max(dim=1)[0] + 1                                         # [B]
+    kmax = K + 1
+    # one-hot with a background column; -1 wraps to the last column like the reference's eye()[I]
+    lab = torch.where(I_gt < 0, n_gt.unsqueeze(1), I_gt).clamp(max=kmax - 1)
+    onehot = torch.zeros(B, N, kmax, dtype=W_pred.dtype, device=W_pred.device)
+    onehot.scatter_(2, lab.unsqueeze(2), 1.0)
+    Wd = W_pred.detach()
+    dot = onehot.transpose(1, 2) @ Wd                                      # [B,kmax,K]
+    den = onehot.sum(1).unsqueeze(2) + Wd.sum(1).unsqueeze(1) - dot
+    cost = (dot / den.clamp(min=1e-10))
+    cost_h = cost.cpu().numpy()                                            # the one host sync
+    n_h = n_gt.cpu().numpy()
+    match = torch.zeros(B, K, dtype=torch.long)
+    for b in range(B):
+        _, col = linear_sum_assignment(-cost_h[b, :n_h[b]])
+        match[b, :n_h[b]] = torch.from_numpy(col)
+    return match.to(W_pred.device)
+
+
+def compute_miou_loss(W, I_gt, matching_indices, div_eps=1e-10):
+    """-> (1 − relaxed IoU [B,K], 1 − intersection/N [B,K])   (reference lines 77-90)."""
+    B, N, K = W.shape
+    n_labels = matching_indices.shape[1]
+    W_reordered = torch.gather(W, 2, matching_indices.unsqueeze(1).expand(B, N, n_labels))
+    lab = torch.where(I_gt < 0, torch.full_like(I_gt, n_labels + 1), I_gt)
+    W_gt = torch.zeros(B, N, n_labels + 2, dtype=W.dtype, device=W.device).scatter_(2, lab.unsqueeze(2), 1.0)
+    W_gt = W_gt[:, :, :n_labels]
+    dot = torch.sum(W_gt * W_reordered, dim=1)
+    den = torch.sum(W_gt, dim=1) + torch.sum(W_reordered, dim=1) - dot
+    return 1.0 - dot / (den + div_eps), 1 - dot / N
+
+
+def acos_safe(x):
+    return torch.acos(torch.clamp(x, min=-1.0 + 1e-6, max=1.0 - 1e-6))
+
+
+def compute_normal_loss(normal, normal_gt, angle_diff):
+    """Unoriented normal loss per cloud [B]   (reference lines 152-159)."""
+    dot_abs = torch.abs(torch.sum(normal * normal_gt, dim=2))
+    return torch.mean(acos_safe(dot_abs), dim=1) if angle_diff else torch.mean(1.0 - dot_abs, dim=1)
+
+
+def compute_per_point_type_loss(per_point_type, I_gt, T_gt, is_eval):
+    """Cross-entropy of the per-point primitive type against the type of the point's GT
+    instance, background points excluded -> [B]   (reference lines 195-210)."""
+    B, N = I_gt.shape
+    tgt = torch.gather(T_gt, 1, torch.clamp(I_gt, min=0))
+    if is_eval:
+        loss = 1.0 - (per_point_type == tgt).float()
+    else:
+        loss = torch.nn.functional.cross_entropy(per_point_type.reshape(B * N, -1), tgt.reshape(B * N),
+                                                 reduction='none').view(B, N)
+    loss = torch.where(I_gt == -1, torch.zeros_like(loss), loss)
+    return torch.sum(loss, dim=1) / torch.sum((I_gt != -1).float(), dim=1)
+
+
+def compute_parameters(P, W, X, classes=['plane', 'sphere', 'cylinder', 'cone']):
+    """P, X [B,N,3], W [B,N,K] -> dict of the ten parameter tensors (reference lines 255-278).
+    One fused pass over (P, X, W) feeds every requested primitive type."""
+    M = _fc.moments(P, W, X)
+    dt = P.dtype
+    out = {}
+    for class_ in classes:
+        if class_ == 'plane':
+            n, c = _fc.plane_from_moments(M)
+            out['plane_normal'], out['plane_center'] = n.to(dt), c.to(dt)
+        elif class_ == 'sphere':
+            c, r2 = _fc.sphere_from_moments(M)
+            out['sphere_center'], out['sphere_radius_squared'] = c.to(dt), r2.to(dt)
+        elif class_ == 'cylinder':
+            a, c, r2 = _fc.cylinder_from_moments(M)
+            out['cylinder_axis'], out['cylinder_center'], out['cylinder_radius_squared'] = a.to(dt), c.to(dt), r2.to(dt)
+        elif class_ == 'cone':
+            apex, axis, half = _fc.cone_from_moments(M, P, W)
+            out['cone_apex'], out['cone_axis'], out['cone_half_angle'] = apex.to(dt), axis.to(dt), half.to(dt)
+        else:
+            raise NotImplementedError
+    return out
+
+
+def _matched(t, matching_indices):
+    """t [B,K,...] -> t[b, matching[b,k], ...]."""
+    idx = matching_indices
+    while idx.dim() < t.dim():
+        idx = idx.unsqueeze(-1)
+    return torch.gather(t, 1, idx.expand(*matching_indices.shape, *t.shape[2:]))
+
+
+def compute_residue_loss(parameters, matching_indices, points_per_instance, T_gt,
+                         classes=['plane', 'sphere', 'cylinder', 'cone']):
+    """points_per_instance [B,K,N',3] -> (residue of the GT type [B,K], per-point residues
+    [B,K,N',T])   (reference lines 351-387)."""
+    g = lambda key: _matched(parameters[key], matching_indices).unsqueeze(2)
+    per_point = []
+    for class_ in classes:
+        if class_ == 'plane':
+            r = plane_fitter.compute_residue_single(g('plane_normal'), g('plane_center'), points_per_instance)
+        elif class_ == 'sphere':
+            r = sphere_fitter.compute_residue_single(g('sphere_center'), g('sphere_radius_squared'), points_per_instance)
+        elif class_ == 'cylinder':
+            r = cylinder_fitter.compute_residue_single(g('cylinder_axis'), g('cylinder_center'),
+                                                       g('cylinder_radius_squared'), points_per_instance)
+        elif class_ == 'cone':
+            r = cone_fitter.compute_residue_single(g('cone_apex'), g('cone_axis'), g('cone_half_angle'),
+                                                   points_per_instance)
+        else:
+            raise NotImplementedError
+        per_point.append(r)
+    means = torch.stack([r.mean(dim=2) for r in per_point], dim=2)
+    residue_loss = torch.gather(means, 2, T_gt.unsqueeze(2)).squeeze(2)
+    return residue_loss, torch.stack(per_point, dim=3)
+
+
+def compute_parameter_loss(predicted_parameters, gt_parameters, matching_indices, T_gt, is_eval=False,
+                           classes=['plane', 'sphere', 'cylinder', 'cone']):
+    """Axis/normal agreement of the matched instances, selected by GT type -> [B,K]   (reference lines 480-497)."""
+    first = predicted_parameters[list(predicted_parameters.keys())[0]]
+    B, K = first.shape[:2]
+    key = {'plane': 'plane_normal', 'cylinder': 'cylinder_axis', 'cone': 'cone_axis'}
+    losses = []
+    for class_ in classes:
+        if class_ == 'sphere':
+            losses.append(torch.zeros(B, K, dtype=torch.float, device=T_gt.device))
+        elif class_ in key:
+            losses.append(plane_fitter.compute_parameter_loss(predicted_parameters[key[class_]],
+                                                              gt_parameters[key[class_]], matching_indices,
+                                                              angle_diff=is_eval))
+        else:
+            raise NotImplementedError
+    return torch.gather(torch.stack(losses, dim=2), 2, T_gt.unsqueeze(2)).squeeze(2)
+
+
+def sequence_mask(lengths, maxlen=None):
+    if maxlen is None:
+        maxlen = lengths.max()
+    return torch.arange(0, maxlen, 1, device=lengths.device) < lengths.unsqueeze(-1)
+
+
+def get_mask_gt(I_gt, n_max_instances):
+    """[B,K] bool: True for the GT instances that exist   (reference lines 603-606)."""
+    return sequence_mask(torch.max(I_gt, dim=1)[0] + 1, maxlen=n_max_instances)
+
+
+def reduce_mean_masked_instance(loss, mask_gt):
+    """Mean over existing instances per cloud [B]   (reference lines 633-638)."""
+    s = torch.where(mask_gt, loss, torch.zeros_like(loss)).sum(dim=1)
+    den = mask_gt.float().sum(dim=1)
+    return torch.where(den > 0, s / den, torch.zeros_like(s))
+
+
+def collect_losses(normal_loss, normal_loss_multiplier, type_loss, type_loss_multiplier, avg_miou_loss, miou_loss,
+                   miou_loss_multiplier, avg_residue_loss, residue_loss, residue_loss_multiplier,
+                   avg_parameter_loss, parameter_loss, parameter_loss_multiplier, total_loss_multiplier):
+    """Weighted sum of the batch means   (reference lines 640-673)."""
+    parts = ((torch.mean(normal_loss), normal_loss_multiplier), (torch.mean(type_loss), type_loss_multiplier),
+             (torch.mean(avg_miou_loss), miou_loss_multiplier), (torch.mean(avg_residue_loss), residue_loss_multiplier),
+             (torch.mean(avg_parameter_loss), parameter_loss_multiplier))
+    total = 0
+    for value, mult in parts:
+        if mult > 0:
+            total = total + mult * value
+    return (total * total_loss_multiplier,) + tuple(v for v, _ in parts)
+
+
+def compute_all_losses(P, W, I_gt, X, X_gt, T, T_gt, gt_parameters, points_per_instance,
+                       normal_loss_multiplier, type_loss_multiplier, miou_loss_multiplier, residue_loss_multiplier,
+                       parameter_loss_multiplier, total_loss_multiplier, is_eval,
+                       mode_seg='mIoU', classes=['plane', 'sphere', 'cylinder', 'cone']):
+    """Same signature and 9-tuple return as the reference (lines 675-720)."""
+    assert mode_seg in ['mIoU', 'intersection']
+    B, _, K = W.size()
+    zeros_bk = lambda: torch.zeros([B, K], device=P.device)
+    zeros_b = lambda: torch.zeros([B], device=P.device)
+    matching_indices = hungarian_matching(W, I_gt)
+    need_params = residue_loss_multiplier > 0 or parameter_loss_multiplier > 0
+    if need_params:
+        predicted_parameters = compute_parameters(P, W, X)
+    mask_gt = get_mask_gt(I_gt, K)
+    normal_loss = compute_normal_loss(X, X_gt, angle_diff=is_eval) if normal_loss_multiplier > 0 else zeros_bk()
+    type_loss = compute_per_point_type_loss(T, I_gt, T_gt, is_eval) if type_loss_multiplier > 0 else zeros_bk()
+    if miou_loss_multiplier > 0:
+        pair = compute_miou_loss(W, I_gt, matching_indices)
+        miou_loss = pair[0] if mode_seg == 'mIoU' else pair[1]
+        avg_miou_loss = reduce_mean_masked_instance(miou_loss, mask_gt)
+    else:
+        miou_loss, avg_miou_loss = zeros_bk(), zeros_b()
+    if residue_loss_multiplier > 0:
+        residue_loss, _ = compute_residue_loss(predicted_parameters, matching_indices, points_per_instance, T_gt,
+                                               classes=classes)
+        avg_residue_loss = reduce_mean_masked_instance(residue_loss, mask_gt)
+    else:
+        residue_loss, avg_residue_loss = zeros_bk(), zeros_b()
+    if parameter_loss_multiplier > 0:
+        parameter_loss = compute_parameter_loss(predicted_parameters, gt_parameters, matching_indices, T_gt, is_eval,
+                                                classes=classes)
+        avg_parameter_loss = reduce_mean_masked_instance(parameter_loss, mask_gt)
+    else:
+        parameter_loss, avg_parameter_loss = zeros_bk(), zeros_b()
+    out = collect_losses(normal_loss, normal_loss_multiplier, type_loss, type_loss_multiplier, avg_miou_loss,
+                         miou_loss, miou_loss_multiplier, avg_residue_loss, residue_loss, residue_loss_multiplier,
+                         avg_parameter_loss, parameter_loss, parameter_loss_multiplier, total_loss_multiplier)
+    if need_params:
+        return out + (predicted_parameters['plane_normal'], predicted_parameters['cylinder_axis'],
+                      predicted_parameters['cone_axis'])
+    return out + (None, None, None)

@@ -25,7 +25,7 @@ SOURCES = {
     "sampling.hip": ["-ffp-contract=off"],
     "neighbors.hip": ["-ffp-contract=off"],
     "gather.hip": ["-ffp-contract=off"],
-    "fitters.hip": ["-ffp-contract=off"],
+    "fitters.hip": [],
     "mlp.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",

@@ -1,0 +1,443 @@
+// Weighted-moment kernels behind the SPFN primitive fitters (plane / sphere / cylinder /
+// cone) for gfx950.
+//
+// The reference tiles P and X to [B*K, N, 3] copies and builds [B*K, N, 3, 3] outer
+// products per fitter (SPFN/plane_fitter.py:12-13, SPFN/differentiable_tls.py:205-207);
+// at B=16, K=28, N=8192 that is ~130 MB per temporary.  Every quantity the four fitters
+// need is a weighted sum over the N points of a low-order polynomial of (p, x), so one
+// pass over P, X, W produces ALL of them for all K instances:
+//
+//   M[b,k,m] = Σ_n  ω_m(W[b,n,k]) · φ_m(P[b,n], X[b,n])          (a [K x N]·[N x 52] product)
+//
+// with ω = w for the "A" slots and ω = max(w, 1e-10) for the "B" slots (the reference's
+// sqrt(clamp(W)) row scaling, SPFN/geometry_utils.py:127).  Sums are accumulated in fp64
+// — raw (uncentred) moments would otherwise lose the thin direction of a plane — per
+// point-chunk, then reduced over chunks in a fixed order (bitwise reproducible, no atomics).
+// The tiny per-instance algebra (3x3 eigenvectors, guarded solves) runs on these
+// [B,K,52] moments (cpfn_amd/SPFN/geometry_utils.py); its adjoint comes back as G = dL/dM
+// and `moments_bwd` expands it to dL/dW [B,N,K] and dL/dX [B,N,3] in one pass.
+//
+// Slot map (FM_SLOTS = 52):
+//   A (ω = w):            0: 1 | 1-3: p | 4-9: p⊗p (xx xy xz yy yz zz) | 10-12: x | 13-18: x⊗x | 19: pad
+//   B (ω = max(w,1e-10)): 20: 1 | 21-23: p | 24-29: p⊗p | 30-39: p⊗p⊗p (xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz)
+//                         40-45: x⊗x | 46-48: x·(p·x) | 49-51: pad
+//
+// The cone's half-angle needs the fitted apex/axis first, so it is a second pass
+// (`cone_pass_*`) over P and W only (SPFN/cone_fitter.py:25-35).
+#include "common.h"
+
+namespace {
+
+constexpr int FM_SLOTS = 52;
+constexpr int FM_A_GROUPS = 5;   // 4-slot groups weighted by w
+constexpr int FM_GROUPS = 13;    // 52 / 4
+constexpr int FM_TILE = 64;      // points staged per iteration
+constexpr int FM_KB = 32;        // instances per k-block
+constexpr int FM_THREADS = 256;
+constexpr float FM_WEPS = 1e-10f;
+
+template <typename T>
+__device__ __forceinline__ void point_features(const float *p, const float *x, T *f) {
+  const T px = p[0], py = p[1], pz = p[2], nx = x[0], ny = x[1], nz = x[2];
+  const T xx = px * px, xy = px * py, xz = px * pz, yy = py * py, yz = py * pz, zz = pz * pz;
+  const T pn = px * nx + py * ny + pz * nz;
+  f[0] = 1; f[1] = px; f[2] = py; f[3] = pz;
+  f[4] = xx; f[5] = xy; f[6] = xz; f[7] = yy; f[8] = yz; f[9] = zz;
+  f[10] = nx; f[11] = ny; f[12] = nz;
+  f[13] = nx * nx; f[14] = nx * ny; f[15] = nx * nz; f[16] = ny * ny; f[17] = ny * nz; f[18] = nz * nz;
+  f[19] = 0;
+  f[20] = 1; f[21] = px; f[22] = py; f[23] = pz;
+  f[24] = xx; f[25] = xy; f[26] = xz; f[27] = yy; f[28] = yz; f[29] = zz;
+  f[30] = xx * px; f[31] = xx * py; f[32] = xx * pz; f[33] = xy * py; f[34] = xy * pz; f[35] = xz * pz;
+  f[36] = yy * py; f[37] = yy * pz; f[38] = yz * pz; f[39] = zz * pz;
+  f[40] = f[13]; f[41] = f[14]; f[42] = f[15]; f[43] = f[16]; f[44] = f[17]; f[45] = f[18];
+  f[46] = nx * pn; f[47] = ny * pn; f[48] = nz * pn;
+  f[49] = 0; f[50] = 0; f[51] = 0;
+}
+
+// grid (chunks, B); partial[b][chunk][K][52]
+__global__ __launch_bounds__(FM_THREADS) void moments_fwd_kernel(const float *__restrict__ P,
+                                                                 const float *__restrict__ X,
+                                                                 const float *__restrict__ W, int N, int K,
+                                                                 int pts_per_block, double *__restrict__ partial) {
+  __shared__ double s_phi[FM_TILE][FM_SLOTS];
+  __shared__ float s_w[FM_TILE][FM_KB];
+  __shared__ float s_wc[FM_TILE][FM_KB];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, t = threadIdx.x;
+  const int n0 = chunk * pts_per_block;
+  const int n1 = min(N, n0 + pts_per_block);
+  const int mg = t % FM_GROUPS;   // slot group: slots 4mg .. 4mg+3
+  const int kg = t / FM_GROUPS;   // instance pair: kb + 2kg, kb + 2kg + 1   (kg < 16 active)
+  const bool active = kg < FM_KB / 2;
+  const float(*wsel)[FM_KB] = mg < FM_A_GROUPS ? s_w : s_wc;
+
+  for (int kb = 0; kb < K; kb += FM_KB) {
+    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int base = n0; base < n1; base += FM_TILE) {
+      __syncthreads();
+      if (t < FM_TILE) {
+        const int n = base + t;
+        if (n < n1) {
+          point_features<double>(P + ((size_t)b * N + n) * 3, X + ((size_t)b * N + n) * 3, s_phi[t]);
+        } else {
+          for (int m = 0; m < FM_SLOTS; ++m) s_phi[t][m] = 0.0;
+        }
+      }
+      for (int e = t; e < FM_TILE * FM_KB; e += FM_THREADS) {
+        const int i = e / FM_KB, kk = e % FM_KB;
+        const int n = base + i, k = kb + kk;
+        float w = 0.f, wc = 0.f;
+        if (n < n1 && k < K) {
+          w = W[((size_t)b * N + n) * K + k];
+          wc = fmaxf(w, FM_WEPS);
+        }
+        s_w[i][kk] = w;
+        s_wc[i][kk] = wc;
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll 4
+        for (int i = 0; i < FM_TILE; ++i) {
+          const double w0 = (double)wsel[i][2 * kg], w1 = (double)wsel[i][2 * kg + 1];
+          const double f0 = s_phi[i][4 * mg], f1 = s_phi[i][4 * mg + 1], f2 = s_phi[i][4 * mg + 2],
+                       f3 = s_phi[i][4 * mg + 3];
+          acc[0][0] += w0 * f0; acc[0][1] += w0 * f1; acc[0][2] += w0 * f2; acc[0][3] += w0 * f3;
+          acc[1][0] += w1 * f0; acc[1][1] += w1 * f1; acc[1][2] += w1 * f2; acc[1][3] += w1 * f3;
+        }
+      }
+    }
+    if (active) {
+      for (int j = 0; j < 2; ++j) {
+        const int k = kb + 2 * kg + j;
+        if (k < K) {
+          double *o = partial + (((size_t)b * nchunks + chunk) * K + k) * FM_SLOTS + 4 * mg;
+          o[0] = acc[j][0]; o[1] = acc[j][1]; o[2] = acc[j][2]; o[3] = acc[j][3];
+        }
+      }
+    }
+  }
+}
+
+// out[r][c] = Σ_chunk partial[b][chunk][r-in-b][c], chunks in ascending order.
+__global__ void chunk_reduce_kernel(const double *__restrict__ partial, int nchunks, int per_b,
+                                    long long total, double *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / per_b, r = e % per_b;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += partial[((size_t)b * nchunks + c) * per_b + r];
+  out[e] = s;
+}
+
+// dW[b,n,k] = Σ_m φ_m G[b,k,m] (B slots only where w >= 1e-10: clamp's adjoint);
+// dX[b,n,:] from the slots that involve the normal.  One lane per point, G[b] in LDS.
+constexpr int FM_MAXK = 64;
+__global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__restrict__ P,
+                                                                 const float *__restrict__ X,
+                                                                 const float *__restrict__ W,
+                                                                 const float *__restrict__ G, int N, int K,
+                                                                 float *__restrict__ dW, float *__restrict__ dX) {
+  __shared__ float s_g[FM_MAXK][FM_SLOTS];
+  const int b = blockIdx.y, t = threadIdx.x;
+  for (int e = t; e < K * FM_SLOTS; e += FM_THREADS) s_g[e / FM_SLOTS][e % FM_SLOTS] = G[(size_t)b * K * FM_SLOTS + e];
+  __syncthreads();
+  const int n = blockIdx.x * FM_THREADS + t;
+  if (n >= N) return;
+  const float *p = P + ((size_t)b * N + n) * 3;
+  const float *x = X + ((size_t)b * N + n) * 3;
+  float f[FM_SLOTS];
+  point_features<float>(p, x, f);
+  float a[3] = {0, 0, 0}, sa[6] = {0, 0, 0, 0, 0, 0}, sb[6] = {0, 0, 0, 0, 0, 0}, gb[3] = {0, 0, 0};
+  const float *wrow = W + ((size_t)b * N + n) * K;
+  float *drow = dW + ((size_t)b * N + n) * K;
+  for (int k = 0; k < K; ++k) {
+    const float *g = s_g[k];
+    float ga = 0.f, gB = 0.f;
+#pragma unroll
+    for (int m = 0; m < 19; ++m) ga = fmaf(f[m], g[m], ga);
+#pragma unroll
+    for (int m = 20; m < 49; ++m) gB = fmaf(f[m], g[m], gB);
+    const float w = wrow[k];
+    const float wc = fmaxf(w, FM_WEPS);
+    drow[k] = ga + (w >= FM_WEPS ? gB : 0.f);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a[j] = fmaf(w, g[10 + j], a[j]); gb[j] = fmaf(wc, g[46 + j], gb[j]); }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { sa[j] = fmaf(w, g[13 + j], sa[j]); sb[j] = fmaf(wc, g[40 + j], sb[j]); }
+  }
+  // d/dx of Σ_{i<=j} S_ij x_i x_j  = Ŝ x with Ŝ_ll = 2 S_ll, Ŝ_lj = S_(lj)
+  float s[6];
+  for (int j = 0; j < 6; ++j) s[j] = sa[j] + sb[j];
+  const float nx = x[0], ny = x[1], nz = x[2], px = p[0], py = p[1], pz = p[2];
+  const float pn = px * nx + py * ny + pz * nz;
+  const float gdotx = gb[0] * nx + gb[1] * ny + gb[2] * nz;
+  float *o = dX + ((size_t)b * N + n) * 3;
+  o[0] = a[0] + 2.f * s[0] * nx + s[1] * ny + s[2] * nz + gb[0] * pn + gdotx * px;
+  o[1] = a[1] + s[1] * nx + 2.f * s[3] * ny + s[4] * nz + gb[1] * pn + gdotx * py;
+  o[2] = a[2] + s[2] * nx + s[4] * ny + 2.f * s[5] * nz + gb[2] * pn + gdotx * pz;
+}
+
+// ---------------------------------------------------------------- cone second pass
+// thread = (instance kk in k-block, point subset); partial[b][chunk][K][NV]
+constexpr int CP_SUB = FM_THREADS / FM_KB;  // 8 point subsets
+constexpr float CP_CLAMP = 1.0f - 1e-6f;
+
+struct ConeTerm {
+  float vx, vy, vz, inv, dot, c;  // v/|v|, 1/max(|v|,eps), axis·vn, clamp(|dot|)
+};
+
+__device__ __forceinline__ ConeTerm cone_term(const float *p, const float *apex, const float *axis) {
+  ConeTerm r;
+  const float vx = p[0] - apex[0], vy = p[1] - apex[1], vz = p[2] - apex[2];
+  const float nv = sqrtf(vx * vx + vy * vy + vz * vz);
+  r.inv = 1.0f / fmaxf(nv, 1e-12f);  // F.normalize(eps=1e-12), cone_fitter.py:26
+  r.vx = vx * r.inv; r.vy = vy * r.inv; r.vz = vz * r.inv;
+  r.dot = axis[0] * r.vx + axis[1] * r.vy + axis[2] * r.vz;
+  r.c = fminf(fabsf(r.dot), CP_CLAMP);  // acos_safe(abs(.)) clamps to [-1+1e-6, 1-1e-6]
+  return r;
+}
+
+template <int NV>
+__device__ __forceinline__ void cone_block_reduce(double (*s_red)[FM_KB][NV], const double *v, int sub, int kk,
+                                                  int k, int K, double *out_row) {
+  for (int j = 0; j < NV; ++j) s_red[sub][kk][j] = v[j];
+  __syncthreads();
+  if (sub == 0 && k < K) {
+    for (int j = 0; j < NV; ++j) {
+      double s = 0.0;
+      for (int q = 0; q < CP_SUB; ++q) s += s_red[q][kk][j];
+      out_row[j] = s;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(FM_THREADS) void cone_fwd_kernel(const float *__restrict__ P,
+                                                              const float *__restrict__ W,
+                                                              const float *__restrict__ apex,
+                                                              const float *__restrict__ axis, int N, int K,
+                                                              int pts_per_block, double *__restrict__ partial) {
+  __shared__ float s_p[FM_TILE][3];
+  __shared__ float s_w[FM_TILE][FM_KB];
+  __shared__ double s_red[CP_SUB][FM_KB][2];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, t = threadIdx.x;
+  const int kk = t % FM_KB, sub = t / FM_KB;
+  const int n0 = chunk * pts_per_block, n1 = min(N, n0 + pts_per_block);
+  for (int kb = 0; kb < K; kb += FM_KB) {
+    const int k = kb + kk;
+    float ap[3] = {0, 0, 0}, ax[3] = {0, 0, 0};
+    if (k < K) {
+      for (int j = 0; j < 3; ++j) { ap[j] = apex[((size_t)b * K + k) * 3 + j]; ax[j] = axis[((size_t)b * K + k) * 3 + j]; }
+    }
+    double acc[2] = {0.0, 0.0};  // Σ w·dot, Σ w·acos(clamp|dot|)
+    for (int base = n0; base < n1; base += FM_TILE) {
+      __syncthreads();
+      if (t < FM_TILE * 3) {
+        const int i = t / 3, c = t % 3;
+        s_p[i][c] = (base + i < n1) ? P[((size_t)b * N + base + i) * 3 + c] : 0.f;
+      }
+      for (int e = t; e < FM_TILE * FM_KB; e += FM_THREADS) {
+        const int i = e / FM_KB, k2 = kb + e % FM_KB;
+        s_w[i][e % FM_KB] = (base + i < n1 && k2 < K) ? W[((size_t)b * N + base + i) * K + k2] : 0.f;
+      }
+      __syncthreads();
+      float a0 = 0.f, a1 = 0.f;
+      for (int i = sub; i < FM_TILE; i += CP_SUB) {
+        const ConeTerm r = cone_term(s_p[i], ap, ax);
+        const float w = s_w[i][kk];
+        a0 = fmaf(w, r.dot, a0);
+        a1 = fmaf(w, acosf(r.c), a1);
+      }
+      acc[0] += (double)a0;
+      acc[1] += (double)a1;
+    }
+    cone_block_reduce<2>(s_red, acc, sub, kk, k, K,
+                         partial + (((size_t)b * nchunks + chunk) * K + (k < K ? k : 0)) * 2);
+  }
+}
+
+// g_acos[b,k] = dL/d(Σ w·acos).  dW[b,n,k] = g·acos(c);  partial adjoints of (apex, axis).
+// (Σ w·dot only feeds a sign(), whose derivative is zero — cone_fitter.py:29.)
+__global__ __launch_bounds__(FM_THREADS) void cone_bwd_kernel(const float *__restrict__ P,
+                                                              const float *__restrict__ W,
+                                                              const float *__restrict__ apex,
+                                                              const float *__restrict__ axis,
+                                                              const float *__restrict__ g_acos, int N, int K,
+                                                              int pts_per_block, float *__restrict__ dW,
+                                                              double *__restrict__ partial) {
+  __shared__ float s_p[FM_TILE][3];
+  __shared__ float s_w[FM_TILE][FM_KB];
+  __shared__ double s_red[CP_SUB][FM_KB][6];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, t = threadIdx.x;
+  const int kk = t % FM_KB, sub = t / FM_KB;
+  const int n0 = chunk * pts_per_block, n1 = min(N, n0 + pts_per_block);
+  for (int kb = 0; kb < K; kb += FM_KB) {
+    const int k = kb + kk;
+    float ap[3] = {0, 0, 0}, ax[3] = {0, 0, 0}, g = 0.f;
+    if (k < K) {
+      for (int j = 0; j < 3; ++j) { ap[j] = apex[((size_t)b * K + k) * 3 + j]; ax[j] = axis[((size_t)b * K + k) * 3 + j]; }
+      g = g_acos[(size_t)b * K + k];
+    }
+    double acc[6] = {0, 0, 0, 0, 0, 0};  // d apex (3), d axis (3)
+    for (int base = n0; base < n1; base += FM_TILE) {
+      __syncthreads();
+      if (t < FM_TILE * 3) {
+        const int i = t / 3, c = t % 3;
+        s_p[i][c] = (base + i < n1) ? P[((size_t)b * N + base + i) * 3 + c] : 0.f;
+      }
+      for (int e = t; e < FM_TILE * FM_KB; e += FM_THREADS) {
+        const int i = e / FM_KB, k2 = kb + e % FM_KB;
+        s_w[i][e % FM_KB] = (base + i < n1 && k2 < K) ? W[((size_t)b * N + base + i) * K + k2] : 0.f;
+      }
+      __syncthreads();
+      float f[6] = {0, 0, 0, 0, 0, 0};
+      for (int i = sub; i < FM_TILE; i += CP_SUB) {
+        const int n = base + i;
+        if (n >= n1) break;
+        const ConeTerm r = cone_term(s_p[i], ap, ax);
+        const float w = s_w[i][kk];
+        if (k < K) dW[((size_t)b * N + n) * K + k] = g * acosf(r.c);
+        // d/d(dot) of w·acos(clamp(|dot|)): zero where the clamp is active
+        float gd = 0.f;
+        if (fabsf(r.dot) < CP_CLAMP) gd = -g * w * rsqrtf(1.f - r.c * r.c) * (r.dot >= 0.f ? 1.f : -1.f);
+        // dot = axis·vn ; vn = v / max(|v|, eps)
+        f[3] = fmaf(gd, r.vx, f[3]); f[4] = fmaf(gd, r.vy, f[4]); f[5] = fmaf(gd, r.vz, f[5]);
+        const float tx = gd * ax[0], ty = gd * ax[1], tz = gd * ax[2];   // d vn
+        const float proj = tx * r.vx + ty * r.vy + tz * r.vz;
+        // d v = (d vn − vn (vn·d vn)) / |v|    (for |v| >= eps);   d apex = −d v
+        f[0] -= (tx - r.vx * proj) * r.inv;
+        f[1] -= (ty - r.vy * proj) * r.inv;
+        f[2] -= (tz - r.vz * proj) * r.inv;
+      }
+      for (int j = 0; j < 6; ++j) acc[j] += (double)f[j];
+    }
+    cone_block_reduce<6>(s_red, acc, sub, kk, k, K,
+                         partial + (((size_t)b * nchunks + chunk) * K + (k < K ? k : 0)) * 6);
+  }
+}
+
+// Batched symmetric 3x3 eigen-decomposition (cyclic Jacobi, fp64), one lane per matrix.
+// S6 = (xx xy xz yy yz zz); eigenvalues ascending; V[g][i][j] = i-th component of eigenvector j.
+__global__ void eigh3_kernel(const double *__restrict__ S6, long long G, double *__restrict__ lam,
+                             double *__restrict__ V) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const double *s = S6 + g * 6;
+  double a[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
+  double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
+    if (off <= 1e-300 || off <= 1e-22 * diag) break;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      const double apq = a[p][q];
+      if (apq == 0.0) continue;
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+      for (int r = 0; r < 3; ++r) {  // A <- A J
+        const double arp = a[r][p], arq = a[r][q];
+        a[r][p] = c * arp - sn * arq;
+        a[r][q] = sn * arp + c * arq;
+      }
+      for (int r = 0; r < 3; ++r) {  // A <- J^T A
+        const double apr = a[p][r], aqr = a[q][r];
+        a[p][r] = c * apr - sn * aqr;
+        a[q][r] = sn * apr + c * aqr;
+      }
+      for (int r = 0; r < 3; ++r) {
+        const double vrp = v[r][p], vrq = v[r][q];
+        v[r][p] = c * vrp - sn * vrq;
+        v[r][q] = sn * vrp + c * vrq;
+      }
+    }
+  }
+  int o0 = 0, o1 = 1, o2 = 2;
+  double e0 = a[0][0], e1 = a[1][1], e2 = a[2][2];
+  if (e0 > e1) { double te = e0; e0 = e1; e1 = te; int ti = o0; o0 = o1; o1 = ti; }
+  if (e1 > e2) { double te = e1; e1 = e2; e2 = te; int ti = o1; o1 = o2; o2 = ti; }
+  if (e0 > e1) { double te = e0; e0 = e1; e1 = te; int ti = o0; o0 = o1; o1 = ti; }
+  lam[g * 3] = e0; lam[g * 3 + 1] = e1; lam[g * 3 + 2] = e2;
+  for (int r = 0; r < 3; ++r) {
+    V[g * 9 + r * 3 + 0] = v[r][o0];
+    V[g * 9 + r * 3 + 1] = v[r][o1];
+    V[g * 9 + r * 3 + 2] = v[r][o2];
+  }
+}
+
+inline int pick_chunks(int B, int N, int *pts_per_block) {
+  // ~2 workgroups per CU over the batch, at least one 64-point tile each, at most 64 chunks
+  int want = (512 + B - 1) / (B > 0 ? B : 1);
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  int ppb = (N + want - 1) / want;
+  ppb = ((ppb + FM_TILE - 1) / FM_TILE) * FM_TILE;
+  *pts_per_block = ppb;
+  return (N + ppb - 1) / ppb;
+}
+
+}  // namespace
+
+extern "C" int cpfn_fit_num_chunks(int B, int N) {
+  int ppb;
+  return pick_chunks(B, N, &ppb);
+}
+
+extern "C" int cpfn_fit_moments_fwd(const float *P, const float *X, const float *W, int B, int N, int K,
+                                    double *workspace, double *M, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || !P || !X || !W || !workspace || !M) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int ppb;
+  const int chunks = pick_chunks(B, N, &ppb);
+  moments_fwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, X, W, N, K, ppb, workspace);
+  const long long total = (long long)B * K * FM_SLOTS;
+  chunk_reduce_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * FM_SLOTS, total, M);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_fit_moments_bwd(const float *P, const float *X, const float *W, const float *G, int B,
+                                    int N, int K, float *dW, float *dX, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || K > FM_MAXK || !P || !X || !W || !G || !dW || !dX) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  moments_bwd_kernel<<<dim3(cpfn_cdiv(N, FM_THREADS), B), FM_THREADS, 0, (hipStream_t)stream>>>(P, X, W, G, N, K,
+                                                                                               dW, dX);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_cone_pass_fwd(const float *P, const float *W, const float *apex, const float *axis, int B,
+                                  int N, int K, double *workspace, double *out, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || !P || !W || !apex || !axis || !workspace || !out) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int ppb;
+  const int chunks = pick_chunks(B, N, &ppb);
+  cone_fwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, W, apex, axis, N, K, ppb, workspace);
+  const long long total = (long long)B * K * 2;
+  chunk_reduce_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * 2, total, out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_cone_pass_bwd(const float *P, const float *W, const float *apex, const float *axis,
+                                  const float *g_acos, int B, int N, int K, float *dW, double *workspace,
+                                  double *d_apex_axis, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || !P || !W || !apex || !axis || !g_acos || !dW || !workspace || !d_apex_axis)
+    return CPFN_EINVAL;
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int ppb;
+  const int chunks = pick_chunks(B, N, &ppb);
+  cone_bwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, W, apex, axis, g_acos, N, K, ppb, dW, workspace);
+  const long long total = (long long)B * K * 6;
+  chunk_reduce_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * 6, total, d_apex_axis);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, void *stream) {
+  if (G < 0 || !S6 || !lam || !V) return CPFN_EINVAL;
+  if (G == 0) return 0;
+  eigh3_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(S6, G, lam, V);
+  return cpfn_launch_status();
+}

@@ -114,6 +114,22 @@ __global__ void three_weights_kernel(const float *__restrict__ dist, long long R
   w[3 * r + 2] = __fdiv_rn(c, s);
 }
 
+// Materialised distance matrix (the reference's pairwise_squared_distance itself); the hot
+// path never needs it — ball_query / three_nn evaluate the same expression on the fly.
+__global__ __launch_bounds__(256) void pairwise_sqdist_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ dst, int N, int M,
+                                                              float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  const float *s = src + ((size_t)b * N + i) * 3;
+  const float *d = dst + ((size_t)b * M + j) * 3;
+  const float sx = s[0], sy = s[1], sz = s[2], dx = d[0], dy = d[1], dz = d[2];
+  out[((size_t)b * N + i) * M + j] =
+      cpfn_pair_sqdist(sx, sy, sz, cpfn_sqnorm3(sx, sy, sz), dx, dy, dz, cpfn_sqnorm3(dx, dy, dz));
+}
+
 }  // namespace
 
 extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float thr, int K,
@@ -139,5 +155,15 @@ extern "C" int cpfn_three_weights(const float *dist, int64_t R, float *w, void *
   if (R < 0 || !dist || !w) return CPFN_EINVAL;
   if (R == 0) return 0;
   three_weights_kernel<<<cpfn_cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(dist, R, w);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_pairwise_sqdist(const float *src, const float *dst, int B, int N, int M, float *out,
+                                    void *stream) {
+  if (B < 0 || N < 0 || M < 0 || !src || !dst || !out) return CPFN_EINVAL;
+  if (B == 0 || N == 0 || M == 0) return 0;
+  if (N > 65535 || B > 65535) return CPFN_EINVAL;
+  dim3 grid(cpfn_cdiv(M, 256), N, B);
+  pairwise_sqdist_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, dst, N, M, out);
   return cpfn_launch_status();
 }

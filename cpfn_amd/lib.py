@@ -19,6 +19,7 @@ SIGNATURES = {
     "cpfn_fps": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "cpfn_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "cpfn_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_pairwise_sqdist": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "cpfn_three_weights": [_vp, _i64, _vp, _vp],
     "cpfn_three_interp_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_three_interp_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
@@ -29,6 +30,12 @@ SIGNATURES = {
     "cpfn_group_xyz_centered": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_interp_rows_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_interp_rows_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "cpfn_fit_num_chunks": [_i, _i],
+    "cpfn_fit_moments_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_fit_moments_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_cone_pass_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_cone_pass_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "cpfn_eigh3": [_vp, _i64, _vp, _vp, _vp],
 }
 _RESTYPES = {"cpfn_build_info": ctypes.c_char_p}
 

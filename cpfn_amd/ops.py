@@ -77,6 +77,18 @@ def three_nn(unknown, known):
     return d, i
 
 
+def pairwise_sqdist(src, dst):
+    """src [B,N,3], dst [B,M,3] -> [B,N,M] f32."""
+    _chk(src, "src", torch.float32); _chk(dst, "dst", torch.float32)
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    out = torch.empty(B, N, M, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _l.check(_l.lib().cpfn_pairwise_sqdist(_ptr(src), _ptr(dst), B, N, M, _ptr(out), _stream()),
+                 "cpfn_pairwise_sqdist")
+    return out
+
+
 def three_weights(dist):
     _chk(dist, "dist", torch.float32)
     w = torch.empty_like(dist)

@@ -75,6 +75,11 @@ CPFN_API int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int 
 CPFN_API int cpfn_three_nn(const float *unknown, const float *known, int B, int N, int M,
                   float *dist2, int *idx, void *stream);
 
+/* pairwise_squared_distance (modules/geometry_utils.py:4-23), materialised:
+ * src[B,N,3], dst[B,M,3] -> out[B,N,M].  API parity only; N, B <= 65535. */
+CPFN_API int cpfn_pairwise_sqdist(const float *src, const float *dst, int B, int N, int M,
+                                  float *out, void *stream);
+
 /* Inverse-distance weights of PointsetFeaturePropagation.forward
  * (modules/pointset_feature_propagation.py:40-42): w = (1/(d+1e-8)) / sum.
  * dist[R,3] -> w[R,3]. */
@@ -120,6 +125,42 @@ CPFN_API int cpfn_interp_rows_fwd(const float *feats, const int *idx, const floa
 /* Adjoint: grad_out[B,N,C] -> grad_feats[B,M,C] (zero-filled by the caller). */
 CPFN_API int cpfn_interp_rows_bwd(const float *grad_out, const int *idx, const float *w, int B,
                          int M, int N, int C, float *grad_feats, void *stream);
+
+/* ------------------------------------------------------------------ SPFN fitters
+ * One pass over P[B,N,3], X[B,N,3] (unit normals), W[B,N,K] (soft memberships) yields every
+ * weighted sum the four primitive fitters need.  Replaces the tiled [B*K,N,3] /
+ * [B*K,N,3,3] temporaries of SPFN/{plane,sphere,cylinder,cone}_fitter.compute_parameters,
+ * SPFN/differentiable_tls.py:200-209 and SPFN/geometry_utils.py:74-84,121-142,209-223.
+ *
+ * M[B,K,52] (fp64) slot map — "A" slots are weighted by w, "B" slots by max(w,1e-10)
+ * (the reference's sqrt(clamp(W,1e-10)) row scaling, geometry_utils.py:127):
+ *   A  0:1  1-3:p  4-9:p(x)p (xx xy xz yy yz zz)  10-12:x  13-18:x(x)x  19:pad
+ *   B  20:1 21-23:p 24-29:p(x)p 30-39:p(x)p(x)p (xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz)
+ *      40-45:x(x)x  46-48:x*(p.x)  49-51:pad
+ * workspace: cpfn_fit_num_chunks(B,N) * B * K * 52 doubles. */
+#define CPFN_FIT_SLOTS 52
+#define CPFN_FIT_MAX_K 64
+CPFN_API int cpfn_fit_num_chunks(int B, int N);
+CPFN_API int cpfn_fit_moments_fwd(const float *P, const float *X, const float *W, int B, int N,
+                                  int K, double *workspace, double *M, void *stream);
+/* Adjoint: G[B,K,52] (fp32) = dL/dM  ->  dW[B,N,K], dX[B,N,3] (both overwritten). K <= 64. */
+CPFN_API int cpfn_fit_moments_bwd(const float *P, const float *X, const float *W, const float *G,
+                                  int B, int N, int K, float *dW, float *dX, void *stream);
+/* Cone second pass (SPFN/cone_fitter.py:25-34) for fitted apex/axis [B,K,3] (fp32):
+ *   out[b,k,0] = sum_n W * (axis . normalize(p - apex)),  out[b,k,1] = sum_n W * acos_safe(|.|)
+ * workspace: chunks * B * K * 2 doubles. */
+CPFN_API int cpfn_cone_pass_fwd(const float *P, const float *W, const float *apex, const float *axis,
+                                int B, int N, int K, double *workspace, double *out, void *stream);
+/* Adjoint w.r.t. out[...,1] (g_acos[B,K] fp32): dW[B,N,K] (overwritten) and
+ * d_apex_axis[B,K,6] (fp64: d apex, d axis).  workspace: chunks * B * K * 6 doubles. */
+CPFN_API int cpfn_cone_pass_bwd(const float *P, const float *W, const float *apex, const float *axis,
+                                const float *g_acos, int B, int N, int K, float *dW,
+                                double *workspace, double *d_apex_axis, void *stream);
+
+/* Batched symmetric 3x3 eigen-decomposition (fp64 Jacobi) replacing the torch.svd call of
+ * Custom_svd_v_colum (SPFN/differentiable_tls.py:126) on the PSD moment matrices.
+ * S6[G,6] = (xx xy xz yy yz zz) -> lam[G,3] ascending, V[G,3,3] with eigenvectors in columns. */
+CPFN_API int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, void *stream);
 
 #ifdef __cplusplus
 }
