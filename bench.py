@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""Headline benchmark: point-clouds/sec of one full GlobalSPFN training step
+(forward, all five losses incl. the fused primitive fitters, backward, gradient
+all-reduce, non-finite guard, Adam) on synthetic 8192-point clouds, 16 clouds per GPU
+(BASELINE.json configs[1]; configs[3] is the same per-GPU work on 8 GPUs -> weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.
+`roofline` is measured live with HIP events around the dominant entry point of
+libcpfn_hip.so; `cpu_baseline` times the oracle (a port of the reference's CPU path) on the
+host cores of this box, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 16
+N_POINTS = 8192
+N_INSTANCES = 28
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# dominant kernel of the step (see DESIGN.md "Measurement") and its algorithmic traffic
+ROOFLINE_SYMBOL = "cpfn_fit_moments_fwd"
+
+
+def roofline_bytes_per_launch(B, N, K):
+    """Algorithmic bytes of one fused-moment launch: read P, X (fp32 xyz) and W once,
+    write the [B,K,52] fp64 moments (SURVEY.md §8d 'fitters fwd': 1,114,112 + 2,464 B / cloud
+    for the reference's 22 outputs; here the 52-slot moment block is what is written)."""
+    return B * (N * 3 * 4 * 2 + N * K * 4 + K * 52 * 8)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Reference CPU path (oracle port) — one GlobalSPFN training step on a bounded sample."""
+    import numpy as np
+    from cpfn_amd import synthetic
+    from oracle import pn2 as opn2
+    Bc = 2
+    torch.manual_seed(0)
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(), seed=0)
+    st = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+          for k, v in state.items()}
+    leaves = [v for v in st.values() if v.requires_grad]
+    opt = torch.optim.Adam(leaves, lr=1e-3)
+    batch = synthetic.training_batch(Bc, N_POINTS, N_INSTANCES, seed=123)
+    times = []
+    t_begin = time.time()
+    it = 0
+    while True:
+        starts = (np.random.RandomState(it).randint(0, N_POINTS, Bc), np.random.RandomState(it + 1).randint(0, 512, Bc))
+        t0 = time.time()
+        opt.zero_grad()
+        out = opn2.training_step_losses(st, batch, starts)
+        out[0].backward()
+        opt.step()
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        it += 1
+        if (len(times) >= 3 and time.time() - t_begin > seconds_budget * 0.6) or len(times) >= 8:
+            break
+    mean = sum(times) / len(times)
+    return {"value": Bc / mean, "unit": "point-clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed GlobalSPFN training steps (fwd+losses+bwd+Adam) of %dx%d pts after 1 warm-up, "
+                      "oracle/ (torch-CPU + C geometry), mean %.3f s/step" % (len(times), Bc, N_POINTS, mean)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from cpfn_amd import lib, synthetic, training
+    from cpfn_amd.PointNet2 import pn2_network
+    from cpfn_amd.SPFN import fitter_factory
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        fitter_factory.register_primitives(training.GLOBAL_SPFN_CLASSES)
+    lib.lib()                                           # fail loudly if the HIP library is missing
+
+    torch.manual_seed(0)                                # default PyTorch init, identical on every rank
+    model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, N_INSTANCES]).to(dev)
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    training.broadcast_parameters(model)
+    trainer = training.SPFNTrainer(model, batch_size=BATCH_PER_GPU * world)
+    batch = {k: v.to(dev) for k, v in
+             synthetic.training_batch(BATCH_PER_GPU, N_POINTS, N_INSTANCES, seed=1000 + rank).items()}
+    torch.manual_seed(1234 + rank)                      # per-rank FPS starts / dropout masks
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.step(batch)
+    lib.time_symbols([ROOFLINE_SYMBOL])
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    calls, kernel_ms = lib.timed_report()[ROOFLINE_SYMBOL]
+    lib.time_symbols([])
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        clouds = BATCH_PER_GPU * world * args.steps
+        per_launch_s = kernel_ms / max(calls, 1) / 1e3
+        achieved = roofline_bytes_per_launch(BATCH_PER_GPU, N_POINTS, N_INSTANCES) / per_launch_s / 1e9
+        line = {
+            "metric": "point-clouds/sec (8192 pts, GlobalSPFN fwd+bwd)",
+            "value": clouds / elapsed, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "GlobalSPFN training step (fwd + 5 losses incl. fitters + bwd + Adam), "
+                                   "%d clouds/GPU x %d pts, %d instances, 4 primitive types"
+                                   % (BATCH_PER_GPU, N_POINTS, N_INSTANCES),
+                       "global_batch": BATCH_PER_GPU * world, "points": N_POINTS,
+                       "parallelism": "dp%d" % world, "loss_last": float(out[0])},
+            "roofline": {"bound": "hbm", "kernel": ROOFLINE_SYMBOL, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": calls, "avg_launch_us": 1e6 * per_launch_s},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

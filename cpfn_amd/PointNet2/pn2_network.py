@@ -36,6 +36,13 @@ class PointNet2(torch.nn.Module):
             self.bn1 = torch.nn.BatchNorm1d(128)
             self.fc2 = torch.nn.ModuleList(torch.nn.Conv1d(128, o, 1) for o in output_sizes)
 
+    def set_compute_dtype(self, dtype):
+        """GEMM operand type of every per-point MLP (torch.bfloat16 on MI355X; fp32 for parity)."""
+        self.compute_dtype = dtype
+        for m in self.modules():
+            m.compute_dtype = dtype
+        return self
+
     def forward(self, x, glob_features=None, loc_features=None, fast=True, fps_start=None):
         """`fps_start` = optional (start_sa1 [B], start_sa2 [B]) FPS seeds; by default each SA
         level draws its own from the CPU generator like the reference's CPU route."""
@@ -53,13 +60,14 @@ class PointNet2(torch.nn.Module):
         l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3)
         l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4)
         l6, _ = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5)
-        feat = mlp.conv_as_linear(l6.reshape(B * N, -1), self.fc1).float()
-        l3_out = l3.transpose(1, 2)                                         # [B,1024(+extra),1]
+        cd = getattr(self, "compute_dtype", torch.float32)
+        l3_out = l3.transpose(1, 2).float()                                 # [B,1024(+extra),1]
         if self.features_extractor:
+            feat = mlp.conv_as_linear(l6.reshape(B * N, -1).to(cd), self.fc1).float()
             return l3_out, feat.reshape(B, N, -1).transpose(1, 2)
-        feat = F.relu(mlp._bn_rows(feat, self.bn1))
-        feat = F.dropout(feat, p=self.dropout_p, training=True)
-        results = [mlp.conv_as_linear(feat, head).float().reshape(B, N, -1) for head in self.fc2]
+        feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd)           # fc1 + bn1 + relu (ref :60-62)
+        feat = F.dropout(feat, p=self.dropout_p, training=True)                            # always on (ref :63)
+        results = [r.reshape(B, N, -1) for r in mlp.heads(feat, self.fc2, cd)]
         results.append(l3_out)
-        results.append(feat.reshape(B, N, -1).transpose(1, 2))
+        results.append(feat.float().reshape(B, N, -1).transpose(1, 2))
         return results

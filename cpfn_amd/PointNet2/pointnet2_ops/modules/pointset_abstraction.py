@@ -41,10 +41,11 @@ class PointsetAbstraction(nn.Module):
         """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux)."""
         B, N, _ = xyz.shape
         aux = {}
+        cd = getattr(self, "compute_dtype", torch.float32)
         if self.group_all:
             new_xyz = None
-            g = xyz if feats is None else torch.cat([xyz, feats.to(xyz.dtype)], dim=2)   # pos FIRST (ref :56)
-            groups = [g.reshape(B, 1, N, -1)] * len(self.mlp_list)
+            g = xyz if feats is None else torch.cat([xyz.to(feats.dtype), feats], dim=2)     # pos FIRST (ref :56)
+            groups = [(g.reshape(B * N, -1), None, 1, N)] * len(self.mlp_list)
         else:
             if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
                 start_idx = torch.randint(0, N, (B,), dtype=torch.long)
@@ -56,16 +57,18 @@ class PointsetAbstraction(nn.Module):
             for r, k in zip(self.radius_list, self.num_samples_list):
                 nbr = ops.ball_query(new_xyz, xyz, r, k)                                  # [B,S,K] i32
                 aux["ball_idx"] = nbr
-                rel = ops.group_xyz_centered(xyz, new_xyz, nbr)                           # [B,S,K,3]
+                rel = ops.group_xyz_centered(xyz, new_xyz, nbr)                           # [B,S,K,3] fp32
+                S = self.num_points
                 if feats is not None:
                     gf = autograd_ops.gather_rows(feats, nbr)                             # [B,S,K,D]
-                    rel = torch.cat([gf.to(rel.dtype), rel], dim=3)                       # feats FIRST (ref :66)
-                groups.append(rel)
+                    x = torch.cat([gf, rel.to(gf.dtype)], dim=3).reshape(B * S * k, -1)   # feats FIRST (ref :66)
+                    groups.append((x, None, S, k))
+                else:
+                    groups.append((None, rel.reshape(B * S * k, 3), S, k))
         outs = []
-        for g, convs, bns in zip(groups, self.conv_blocks, self.bn_blocks):
-            Bq, S, K, C = g.shape
-            y = mlp.shared_mlp(g.reshape(Bq * S * K, C), convs, bns)
-            outs.append(y.reshape(Bq, S, K, -1).max(dim=2)[0])
+        for (x, xyz_rows, S, k), convs, bns in zip(groups, self.conv_blocks, self.bn_blocks):
+            y = mlp.run_stack(x, convs, bns, cd, pool_k=k, xyz_rows=xyz_rows)             # max over the K neighbours (ref :74)
+            outs.append(y.reshape(B, S, -1))
         return new_xyz, torch.cat(outs, dim=2) if len(outs) > 1 else outs[0], aux
 
     # ---------------------------------------------------------------- reference layout

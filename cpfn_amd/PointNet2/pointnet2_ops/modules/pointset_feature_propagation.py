@@ -35,7 +35,7 @@ class PointsetFeaturePropagation(nn.Module):
             interp = autograd_ops.interp_rows(feats2, nn_idx, w)
             aux = {"nn_idx": nn_idx, "nn_w": w}
         x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
-        y = mlp.shared_mlp(x.reshape(B * N, -1), self.mlp_convs, self.mlp_bns)
+        y = mlp.run_stack(x.reshape(B * N, -1), self.mlp_convs, self.mlp_bns, getattr(self, "compute_dtype", torch.float32))
         return y.reshape(B, N, -1), aux
 
     def forward(self, pos1, pos2, feats1, feats2, fast=True):

@@ -1,0 +1,766 @@
+// Per-point MLP stacks (1x1 conv + BatchNorm(batch statistics) + ReLU [+ max-pool]) for gfx950.
+//
+// Data are points-major bf16 rows [P, C] (P = every point / neighbour of the batch), so a
+// 1x1 convolution is Y[P,N] = A[P,K]·W[N,K]ᵀ and both MFMA operands are K-contiguous 16-byte
+// fragments.  bf16 operands, fp32 accumulation (v_mfma_f32_16x16x32_bf16); BatchNorm
+// statistics come out of the fp32 accumulators in the GEMM epilogue, so a layer is
+//     GEMM(+Σy, Σy²) -> [C]-sized finalize -> fused normalise+ReLU(+max-pool)
+// instead of the reference's conv / batch_norm / relu / max chain over fp32 NCHW tensors
+// (modules/pointset_abstraction.py:70-74, modules/pointset_feature_propagation.py:49-51).
+//
+// MFMA orientation: the WEIGHT tile is the A operand (rows = output channels) and the POINT
+// tile the B operand (columns = points), so every lane ends up with 4 consecutive output
+// channels of one point: channels are the contiguous axis of a row, stores are 8-byte
+// pieces that tile a row, and per-channel statistics are per-register sums.
+//
+// All reductions (statistics, weight gradients) go through per-workgroup partial buffers that
+// a second tiny kernel sums in a fixed order: bitwise reproducible, no float atomics.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  return __builtin_bit_cast(unsigned short, (__bf16)f);  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+}
+
+constexpr int G_THREADS = 256;
+constexpr int G_ROWS = 128;   // points per workgroup tile (4 waves x 32)
+constexpr int G_KC = 128;     // K chunk staged in LDS
+constexpr int G_LDW = G_KC + 8;
+
+// Y[P,N] (bf16 or fp32) = A[P,K] (bf16, optional row gather) · W[N,K]ᵀ (bf16) (+ bias)
+// stats_partial[gridDim.x][2][N]: per-workgroup Σy, Σy² over its valid rows (fp32 accumulators).
+template <int BN, bool STATS>
+__global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
+    const unsigned short *__restrict__ A, int lda, const int *__restrict__ gidx,
+    const unsigned short *__restrict__ W, int P, int K, int N, void *__restrict__ Y, int ldy, int y_f32,
+    int n_store, const float *__restrict__ bias, float *__restrict__ stats_partial, int tiles_per_wg) {
+  constexpr int NT = BN / 16;
+  __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
+  __shared__ float s_red[4][2][BN];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+
+  f32x4 s1[NT], s2[NT];
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { s1[i] = (f32x4){0, 0, 0, 0}; s2[i] = (f32x4){0, 0, 0, 0}; }
+  }
+  bool w_loaded = false;
+  const int tile0 = blockIdx.x * tiles_per_wg;
+  for (int tile = tile0; tile < tile0 + tiles_per_wg; ++tile) {
+    const int row0 = tile * G_ROWS;
+    if (row0 >= P) break;
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
+    size_t arow[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      int p = row0 + wave * 32 + tt * 16 + lr;
+      p = p < P ? p : P - 1;
+      arow[tt] = (size_t)(gidx ? gidx[p] : p) * lda;
+    }
+    for (int kc = 0; kc < K; kc += G_KC) {
+      const int kcn = min(G_KC, K - kc);  // multiple of 32
+      bf16x8 af[2][4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks * 32 < kcn) af[tt][ks] = *(const bf16x8 *)(A + arow[tt] + kc + ks * 32 + 8 * lq);
+      if (!(w_loaded && K <= G_KC)) {
+        __syncthreads();
+        const int cpr = kcn / 8;  // 16-byte chunks per row
+        for (int e = t; e < BN * cpr; e += G_THREADS) {
+          const int r = e / cpr, c = e - r * cpr;
+          *(uint4 *)&s_w[r * G_LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + kc + c * 8];
+        }
+        __syncthreads();
+        w_loaded = true;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks * 32 < kcn) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8 wf = *(const bf16x8 *)&s_w[(nt * 16 + lr) * G_LDW + ks * 32 + 8 * lq];
+            acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[nt][0], 0, 0, 0);
+            acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[nt][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // epilogue: lane holds channels n0 + nt*16 + 4*lq + r (r<4) of point row0 + wave*32 + tt*16 + lr
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int p = row0 + wave * 32 + tt * 16 + lr;
+      const bool valid = p < P;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 v = acc[nt][tt];
+        const int n = n0 + nt * 16 + 4 * lq;
+        if (bias) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (n + r < N) ? bias[n + r] : 0.f;
+        }
+        if (STATS && valid) { s1[nt] += v; s2[nt] += v * v; }
+        if (valid) {
+          if (y_f32) {
+            float *o = (float *)Y + (size_t)p * ldy + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < n_store) o[r] = v[r];
+          } else if (n + 3 < n_store) {
+            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *(bf16x4 *)((unsigned short *)Y + (size_t)p * ldy + n) = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < n_store) ((unsigned short *)Y)[(size_t)p * ldy + n + r] = f2bf(v[r]);
+          }
+        }
+      }
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[nt][r], b = s2[nt][r];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (lr == 0) { s_red[wave][0][nt * 16 + 4 * lq + r] = a; s_red[wave][1][nt * 16 + 4 * lq + r] = b; }
+      }
+    }
+    __syncthreads();
+    for (int e = t; e < 2 * BN; e += G_THREADS) {
+      const int which = e / BN, c = e - which * BN;
+      const float s = s_red[0][which][c] + s_red[1][which][c] + s_red[2][which][c] + s_red[3][which][c];
+      if (n0 + c < N) stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm finalize (forward)
+// scale = γ·rstd, shift = β − mean·scale; running statistics updated like torch (unbiased var,
+// the conv bias — dropped from the GEMM because batch-norm cancels it — re-enters the mean).
+__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N, float count,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   const float *__restrict__ conv_bias, float eps, float momentum,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   float *__restrict__ scale, float *__restrict__ shift,
+                                   float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < nblk; ++i) {
+    s1 += (double)partial[((size_t)i * 2 + 0) * N + c];
+    s2 += (double)partial[((size_t)i * 2 + 1) * N + c];
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (running_mean) {
+    const float b = conv_bias ? conv_bias[c] : 0.f;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mean + b);
+    const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// ---------------------------------------------------------------- normalise + ReLU (+ max-pool)
+// out[p,c] = relu(scale[c]·y[p,c] + shift[c]); 8 channels (16 B) per lane.
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const unsigned short *__restrict__ Yr,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, long long total8,
+                                                            int C, unsigned short *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total8) return;
+  const int c0 = (int)((e * 8) % C);
+  const uint4 raw = *(const uint4 *)(Yr + e * 8);
+  const unsigned short *y = (const unsigned short *)&raw;
+  unsigned short o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(fmaxf(fmaf(scale[c0 + j], bf2f(y[j]), shift[c0 + j]), 0.f));
+  *(uint4 *)(out + e * 8) = *(const uint4 *)o;
+}
+
+// One workgroup per group g of Kn consecutive rows: out[g,c] = relu(max_k z), arg[g,c] = first k
+// attaining it, yarg[g,c] = raw y at that k (needed by the backward pass).
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const unsigned short *__restrict__ Yr,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, int Kn, int C,
+                                                              unsigned short *__restrict__ out,
+                                                              unsigned char *__restrict__ arg,
+                                                              unsigned short *__restrict__ yarg) {
+  __shared__ float s_z[32][8 * 33];
+  __shared__ int s_k[32][8 * 33];
+  const int g = blockIdx.x, t = threadIdx.x;
+  const int chunks = C / 8;                 // C in {64,128,256,...}; chunk-tiles of 32 chunks
+  const int rsub = 256 / min(chunks, 32);   // row sub-lanes per chunk
+  for (int cb = 0; cb < chunks; cb += 32) {
+    const int nch = min(32, chunks - cb);
+    const int ch = t % nch, rs = t / nch;
+    float bz[8];
+    int bk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bz[j] = -INFINITY; bk[j] = 0; }
+    const int c0 = (cb + ch) * 8;
+    if (rs < rsub) {
+      float sc[8], sh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+      for (int k = rs; k < Kn; k += rsub) {
+        const uint4 raw = *(const uint4 *)(Yr + ((size_t)g * Kn + k) * C + c0);
+        const unsigned short *y = (const unsigned short *)&raw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float z = fmaf(sc[j], bf2f(y[j]), sh[j]);
+          if (z > bz[j]) { bz[j] = z; bk[j] = k; }
+        }
+      }
+    }
+    __syncthreads();
+    if (rs < 32) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_z[rs][ch * 8 + j + (ch >> 2)] = bz[j]; s_k[rs][ch * 8 + j + (ch >> 2)] = bk[j]; }
+    }
+    __syncthreads();
+    // one thread per channel of this chunk-tile combines the row sub-lanes (ascending k on ties)
+    if (t < nch * 8) {
+      const int ch2 = t / 8, j = t % 8;
+      float z = -INFINITY;
+      int kk = 0;
+      const int nrs = min(rsub, 32);
+      for (int r = 0; r < nrs; ++r) {
+        const float zz = s_z[r][ch2 * 8 + j + (ch2 >> 2)];
+        const int k2 = s_k[r][ch2 * 8 + j + (ch2 >> 2)];
+        if (zz > z || (zz == z && k2 < kk)) { z = zz; kk = k2; }
+      }
+      const int c = (cb + ch2) * 8 + j;
+      out[(size_t)g * C + c] = f2bf(fmaxf(z, 0.f));
+      arg[(size_t)g * C + c] = (unsigned char)kk;
+      yarg[(size_t)g * C + c] = Yr[((size_t)g * Kn + kk) * C + c];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- BatchNorm backward, pass 1
+// g_z = g_a·[z>0]; per-workgroup partial Σ g_z and Σ g_z·y per channel.  Gz may alias Ga.
+constexpr int R_ROWS = 512;  // rows per workgroup
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *__restrict__ Ga,
+                                                          const unsigned short *__restrict__ Yr,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, long long P, int C,
+                                                          unsigned short *__restrict__ Gz,
+                                                          float *__restrict__ partial) {
+  __shared__ float s_red[2][256][8 + 1];
+  const int t = threadIdx.x;
+  const int chunks = C / 8;
+  const long long row0 = (long long)blockIdx.x * R_ROWS;
+  float a1[8], a2[8];
+  for (int cb = 0; cb < chunks; cb += 256) {
+    const int nch = min(256, chunks - cb);
+    const int rsub = 256 / nch;  // nch is a power of two <= 256 for every layer width used
+    const int ch = t % nch, rs = t / nch;
+    const int c0 = (cb + ch) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+    if (rs < rsub) {
+      float sc[8], sh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+      for (long long r = row0 + rs; r < min(P, row0 + R_ROWS); r += rsub) {
+        const uint4 rg = *(const uint4 *)(Ga + r * C + c0);
+        const uint4 ry = *(const uint4 *)(Yr + r * C + c0);
+        const unsigned short *g = (const unsigned short *)&rg, *y = (const unsigned short *)&ry;
+        unsigned short o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float yv = bf2f(y[j]);
+          const float gz = fmaf(sc[j], yv, sh[j]) > 0.f ? bf2f(g[j]) : 0.f;
+          o[j] = f2bf(gz);
+          a1[j] += gz;
+          a2[j] = fmaf(gz, yv, a2[j]);
+        }
+        *(uint4 *)(Gz + r * C + c0) = *(const uint4 *)o;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_red[0][t][j] = a1[j]; s_red[1][t][j] = a2[j]; }
+    __syncthreads();
+    if (t < nch) {
+      for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float s = 0.f;
+          for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + t][j];
+          partial[((size_t)blockIdx.x * 2 + which) * C + (cb + t) * 8 + j] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// pooled variant: only the arg-max row of each group carries gradient.
+// partial[gridDim.x][2][C]; one lane per (group, channel) element, grid-stride over groups.
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned short *__restrict__ Gp,
+                                                                 const unsigned short *__restrict__ yarg,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift, int G, int C,
+                                                                 int groups_per_block,
+                                                                 float *__restrict__ partial) {
+  const int t = threadIdx.x;
+  const int g0 = blockIdx.x * groups_per_block, g1 = min(G, g0 + groups_per_block);
+  for (int c = t; c < C; c += 256) {
+    const float sc = scale[c], sh = shift[c];
+    float a1 = 0.f, a2 = 0.f;
+    for (int g = g0; g < g1; ++g) {
+      const float yv = bf2f(yarg[(size_t)g * C + c]);
+      const float gz = fmaf(sc, yv, sh) > 0.f ? bf2f(Gp[(size_t)g * C + c]) : 0.f;
+      a1 += gz;
+      a2 = fmaf(gz, yv, a2);
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a1;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = a2;
+  }
+}
+
+// dβ = Σg_z, dγ = rstd·(Σg_z·y − mean·Σg_z);  g_y = s·g_z + c2·y + c3 with
+// s = γ·rstd, c2 = −s·dγ·rstd/count, c3 = −s·dβ/count − c2·mean  (training-mode batch norm).
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
+                                       const float *__restrict__ gamma, const float *__restrict__ mean,
+                                       const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < nblk; ++i) {
+    s1 += (double)partial[((size_t)i * 2 + 0) * C + c];
+    s2 += (double)partial[((size_t)i * 2 + 1) * C + c];
+  }
+  const double m = mean[c], rs = rstd[c];
+  const double dg = rs * (s2 - m * s1);
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)s1;
+  const double s = (double)gamma[c] * rs;
+  const double c2 = training ? -s * dg * rs / count : 0.0;
+  const double c3 = training ? -s * s1 / count - c2 * m : 0.0;
+  coef[c] = (float)s;
+  coef[C + c] = (float)c2;
+  coef[2 * C + c] = (float)c3;
+}
+
+// g_y[p,c] = s·g_z + c2·y + c3   (dense).  Gy may alias Gz.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short *__restrict__ Gz,
+                                                           const unsigned short *__restrict__ Yr,
+                                                           const float *__restrict__ coef, long long total8,
+                                                           int C, unsigned short *__restrict__ Gy) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total8) return;
+  const int c0 = (int)((e * 8) % C);
+  const uint4 rg = *(const uint4 *)(Gz + e * 8);
+  const uint4 ry = *(const uint4 *)(Yr + e * 8);
+  const unsigned short *g = (const unsigned short *)&rg, *y = (const unsigned short *)&ry;
+  unsigned short o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    o[j] = f2bf(fmaf(coef[c0 + j], bf2f(g[j]), fmaf(coef[C + c0 + j], bf2f(y[j]), coef[2 * C + c0 + j])));
+  *(uint4 *)(Gy + e * 8) = *(const uint4 *)o;
+}
+
+// pooled: g_z[g,k,c] = (k == arg[g,c]) ? g_pool[g,c]·[z_arg>0] : 0
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned short *__restrict__ Gp,
+                                                                const unsigned char *__restrict__ arg,
+                                                                const unsigned short *__restrict__ yarg,
+                                                                const unsigned short *__restrict__ Yr,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift,
+                                                                const float *__restrict__ coef, long long total8,
+                                                                int Kn, int C, unsigned short *__restrict__ Gy) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total8) return;
+  const int c0 = (int)((e * 8) % C);
+  const long long row = (e * 8) / C;
+  const long long g = row / Kn;
+  const int k = (int)(row - g * Kn);
+  const uint4 ry = *(const uint4 *)(Yr + e * 8);
+  const unsigned short *y = (const unsigned short *)&ry;
+  unsigned short o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    float gz = 0.f;
+    if (arg[g * C + c] == (unsigned char)k) {
+      const float za = fmaf(scale[c], bf2f(yarg[g * C + c]), shift[c]);
+      gz = za > 0.f ? bf2f(Gp[g * C + c]) : 0.f;
+    }
+    o[j] = f2bf(fmaf(coef[c], gz, fmaf(coef[C + c], bf2f(y[j]), coef[2 * C + c])));
+  }
+  *(uint4 *)(Gy + e * 8) = *(const uint4 *)o;
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dW[n,k] = Σ_p Gy[p,n]·A[p,k]: the contraction runs over ROWS, so both MFMA operands are
+// transposed tiles — staged row-major in LDS and read with ds_read_b64_tr_b16.
+// grid (N/64, K/64, splits); partial[split][N][K] fp32.
+constexpr int WG_T = 64;          // output tile 64 x 64
+constexpr int WG_STEP = 32;       // rows per MFMA step
+constexpr int WG_LD = WG_T + 8;   // LDS row stride (elements): 144 B
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short *tile, int col0, int lane) {
+  // fragment F[x = lane&15][k = 8(lane>>4)+j] = tile[row k][col0 + x]  (tile rows = contraction index)
+  const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const unsigned short *a0 = tile + (8 * grp + q) * WG_LD + col0 + 4 * pp;
+  const unsigned short *a1 = a0 + 4 * WG_LD;
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);  // one whole-vector cast: element-wise casts of the tr-read result miscompile
+}
+
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
+                                                        const unsigned short *__restrict__ A, int lda,
+                                                        const int *__restrict__ gidx, long long P, int N, int K,
+                                                        long long rows_per_split, float *__restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) unsigned short s_g[WG_STEP * WG_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[WG_STEP * WG_LD];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n0 = blockIdx.x * WG_T, k0 = blockIdx.y * WG_T;
+  const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
+  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;  // this wave's 32x32 sub-tile
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
+  // staging: 32 rows x 64 cols bf16 = 256 x 16-byte chunks per operand: one chunk per thread
+  const int sr = t >> 3, sc = (t & 7) * 8;
+  for (long long base = p0; base < p1; base += WG_STEP) {
+    const long long p = base + sr;
+    uint4 vg = {0, 0, 0, 0}, va = {0, 0, 0, 0};
+    if (p < p1) {
+      vg = *(const uint4 *)(Gy + p * ldg + n0 + sc);
+      const long long ar = gidx ? (long long)gidx[p] : p;
+      if (k0 + sc < K) va = *(const uint4 *)(A + ar * lda + k0 + sc);
+    }
+    __syncthreads();
+    *(uint4 *)&s_g[sr * WG_LD + sc] = vg;
+    *(uint4 *)&s_a[sr * WG_LD + sc] = va;
+    __syncthreads();
+    bf16x8 fg[2], fa[2];
+    fg[0] = tr_frag(s_g, wn, lane);
+    fg[1] = tr_frag(s_g, wn + 16, lane);
+    fa[0] = tr_frag(s_a, wk, lane);
+    fa[1] = tr_frag(s_a, wk + 16, lane);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
+  }
+  // D[row = n-local 4(lane>>4)+r][col = k-local lane&15]
+  float *o = partial + (size_t)blockIdx.z * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + i * 16 + 4 * (lane >> 4) + r, k = k0 + wk + j * 16 + (lane & 15);
+        if (n < N && k < K) o[(size_t)n * K + k] = acc[i][j][r];
+      }
+}
+
+__global__ void split_reduce_kernel(const float *__restrict__ partial, int splits, long long n,
+                                    float *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int i = 0; i < splits; ++i) s += partial[(size_t)i * n + e];
+  out[e] = s;
+}
+
+// ---------------------------------------------------------------- fp32 small-K first layer (sa1: K = 3)
+// Y[p,c] = Σ_{j<KS} W[c,j]·X[p,j]  (fp32 inputs: relative coordinates are NOT rounded to bf16),
+// bf16 output + Σy, Σy² partials.  One lane per (row-sub, 8-channel chunk).
+constexpr int KS_MAX = 4;
+__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ X, int KS,
+                                                         const float *__restrict__ W, long long P, int C,
+                                                         unsigned short *__restrict__ Y,
+                                                         float *__restrict__ partial) {
+  __shared__ float s_red[2][256][8 + 1];
+  const int t = threadIdx.x;
+  const int nch = C / 8, rsub = 256 / nch;  // C <= 2048, power of two
+  const int ch = t % nch, rs = t / nch, c0 = ch * 8;
+  const long long row0 = (long long)blockIdx.x * R_ROWS;
+  float w[8][KS_MAX];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < KS_MAX; ++q) w[j][q] = q < KS ? W[(c0 + j) * KS + q] : 0.f;
+  float a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+  if (rs < rsub) {
+    for (long long r = row0 + rs; r < min(P, row0 + R_ROWS); r += rsub) {
+      float x[KS_MAX];
+#pragma unroll
+      for (int q = 0; q < KS_MAX; ++q) x[q] = q < KS ? X[r * KS + q] : 0.f;
+      unsigned short o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < KS_MAX; ++q) v = fmaf(w[j][q], x[q], v);
+        o[j] = f2bf(v);
+        a1[j] += v;
+        a2[j] = fmaf(v, v, a2[j]);
+      }
+      *(uint4 *)(Y + r * C + c0) = *(const uint4 *)o;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s_red[0][t][j] = a1[j]; s_red[1][t][j] = a2[j]; }
+  __syncthreads();
+  if (t < nch) {
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = 0.f;
+        for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + t][j];
+        partial[((size_t)blockIdx.x * 2 + which) * C + t * 8 + j] = s;
+      }
+  }
+}
+
+// dW[c,j] = Σ_p Gy[p,c]·X[p,j]: partial[gridDim.x][C][KS]
+__global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short *__restrict__ Gy,
+                                                           const float *__restrict__ X, int KS, long long P,
+                                                           int C, float *__restrict__ partial) {
+  __shared__ float s_red[256][8 * KS_MAX + 1];
+  const int t = threadIdx.x;
+  const int nch = C / 8, rsub = 256 / nch;
+  const int ch = t % nch, rs = t / nch, c0 = ch * 8;
+  const long long row0 = (long long)blockIdx.x * R_ROWS;
+  float a[8][KS_MAX];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < KS_MAX; ++q) a[j][q] = 0.f;
+  if (rs < rsub) {
+    for (long long r = row0 + rs; r < min(P, row0 + R_ROWS); r += rsub) {
+      float x[KS_MAX];
+#pragma unroll
+      for (int q = 0; q < KS_MAX; ++q) x[q] = q < KS ? X[r * KS + q] : 0.f;
+      const uint4 rg = *(const uint4 *)(Gy + r * C + c0);
+      const unsigned short *g = (const unsigned short *)&rg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gv = bf2f(g[j]);
+#pragma unroll
+        for (int q = 0; q < KS_MAX; ++q) a[j][q] = fmaf(gv, x[q], a[j][q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < KS_MAX; ++q) s_red[t][j * KS_MAX + q] = a[j][q];
+  __syncthreads();
+  if (t < nch) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int q = 0; q < KS; ++q) {
+        float s = 0.f;
+        for (int r = 0; r < rsub; ++r) s += s_red[r * nch + t][j * KS_MAX + q];
+        partial[((size_t)blockIdx.x * C + t * 8 + j) * KS + q] = s;
+      }
+  }
+}
+
+inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+// ============================================================================ C ABI
+
+extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
+  // number of row-blocks (gridDim.x) the GEMM will use == rows of its stats-partial buffer
+  const long long tiles = (P + G_ROWS - 1) / G_ROWS;
+  const int ny = (N + 127) / 128 > 0 ? (N + 127) / 128 : 1;
+  long long tpw = tiles * ny / 1024;  // aim for ~1024 workgroups
+  if (tpw < 1) tpw = 1;
+  if (tpw > 16) tpw = 16;
+  return (int)((tiles + tpw - 1) / tpw);
+}
+
+extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, long long P, int K, int N,
+                             void *Y, int ldy, int y_f32, int n_store, const float *bias, float *stats_partial,
+                             void *stream) {
+  if (P < 0 || K <= 0 || (K & 31) || N <= 0 || (N & 63) || !A || !W || !Y || lda < K || (lda & 7)) return CPFN_EINVAL;
+  if (P == 0) return 0;
+  if (P > 2000000000LL) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = cpfn_mlp_gemm_blocks(P, N);
+  const long long tiles = (P + G_ROWS - 1) / G_ROWS;
+  const int tpw = (int)((tiles + gx - 1) / gx);
+  const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
+  if (N % 128 == 0) {
+    dim3 grid(gx, N / 128);
+    if (stats_partial)
+      mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
+    else
+      mlp_gemm_kernel<128, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
+  } else {
+    dim3 grid(gx, N / 64);
+    if (stats_partial)
+      mlp_gemm_kernel<64, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
+    else
+      mlp_gemm_kernel<64, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
+  }
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_finalize(const float *partial, int nblk, int N, float count, const float *gamma,
+                                const float *beta, const float *conv_bias, float eps, float momentum,
+                                float *running_mean, float *running_var, float *scale, float *shift,
+                                float *mean, float *rstd, void *stream) {
+  if (nblk <= 0 || N <= 0 || !partial || !gamma || !beta || !scale || !shift || !mean || !rstd) return CPFN_EINVAL;
+  bn_finalize_kernel<<<cpfn_cdiv(N, 128), 128, 0, (hipStream_t)stream>>>(partial, nblk, N, count, gamma, beta, conv_bias,
+                                                                        eps, momentum, running_mean, running_var,
+                                                                        scale, shift, mean, rstd);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_relu_apply(const void *Y, const float *scale, const float *shift, long long P, int C,
+                                  void *out, void *stream) {
+  if (P < 0 || C <= 0 || (C & 7) || !Y || !scale || !shift || !out) return CPFN_EINVAL;
+  if (P == 0) return 0;
+  const long long total8 = P * C / 8;
+  bn_relu_apply_kernel<<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned short *)Y, scale, shift, total8, C, (unsigned short *)out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const float *shift, int G, int Kn, int C,
+                                    void *out, unsigned char *arg, void *yarg, void *stream) {
+  if (G < 0 || Kn <= 0 || Kn > 256 || C < 64 || (C & 7) || !pow2(C / 8) || !Y || !scale || !shift || !out || !arg || !yarg)
+    return CPFN_EINVAL;
+  if (G == 0) return 0;
+  bn_relu_maxpool_kernel<<<G, 256, 0, (hipStream_t)stream>>>((const unsigned short *)Y, scale, shift, Kn, C,
+                                                             (unsigned short *)out, arg, (unsigned short *)yarg);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_bwd_blocks(long long P) { return (int)((P + R_ROWS - 1) / R_ROWS); }
+
+extern "C" int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift, long long P,
+                                int C, void *Gz, float *partial, void *stream) {
+  if (P <= 0 || C <= 0 || (C & 7) || !pow2(C / 8) || !Ga || !Y || !scale || !shift || !Gz || !partial) return CPFN_EINVAL;
+  bn_relu_bwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_pool_bwd_reduce(const void *Gp, const void *yarg, const float *scale, const float *shift,
+                                       int G, int C, int nblk, float *partial, void *stream) {
+  if (G <= 0 || C <= 0 || nblk <= 0 || !Gp || !yarg || !scale || !shift || !partial) return CPFN_EINVAL;
+  const int gpb = (G + nblk - 1) / nblk;
+  bn_pool_bwd_reduce_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>((const unsigned short *)Gp,
+                                                                   (const unsigned short *)yarg, scale, shift, G, C,
+                                                                   gpb, partial);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float count, const float *gamma,
+                                    const float *mean, const float *rstd, int training, float *dgamma,
+                                    float *dbeta, float *coef, void *stream) {
+  if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef) return CPFN_EINVAL;
+  bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
+                                                                            training, dgamma, dbeta, coef);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, long long P, int C, void *Gy,
+                                 void *stream) {
+  if (P <= 0 || C <= 0 || (C & 7) || !Gz || !Y || !coef || !Gy) return CPFN_EINVAL;
+  const long long total8 = P * C / 8;
+  bn_bwd_apply_kernel<<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned short *)Gz, (const unsigned short *)Y, coef, total8, C, (unsigned short *)Gy);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, const void *yarg, const void *Y,
+                                      const float *scale, const float *shift, const float *coef, int G, int Kn,
+                                      int C, void *Gy, void *stream) {
+  if (G <= 0 || Kn <= 0 || C <= 0 || (C & 7) || !Gp || !arg || !yarg || !Y || !scale || !shift || !coef || !Gy)
+    return CPFN_EINVAL;
+  const long long total8 = (long long)G * Kn * C / 8;
+  bn_pool_bwd_apply_kernel<<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned short *)Gp, arg, (const unsigned short *)yarg, (const unsigned short *)Y, scale, shift, coef,
+      total8, Kn, C, (unsigned short *)Gy);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
+  const long long tiles = (long long)((N + 63) / 64) * ((K + 63) / 64);
+  long long s = (1024 + tiles - 1) / tiles;           // ~1024 workgroups
+  const long long max_s = (P + 255) / 256;            // at least 256 rows per split
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P, int N,
+                              int K, float *workspace, float *dW, void *stream) {
+  if (P <= 0 || N <= 0 || K <= 0 || (N & 63) || (K & 31) || !Gy || !A || !workspace || !dW || (ldg & 7) || (lda & 7))
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = cpfn_mlp_wgrad_splits(P, N, K);
+  long long rps = (P + splits - 1) / splits;
+  rps = ((rps + WG_STEP - 1) / WG_STEP) * WG_STEP;
+  dim3 grid(N / 64, (K + 63) / 64, splits);
+  mlp_wgrad_kernel<<<grid, 256, 0, st>>>((const unsigned short *)Gy, ldg, (const unsigned short *)A, lda, gidx, P, N, K,
+                                         rps, workspace);
+  const long long n = (long long)N * K;
+  split_reduce_kernel<<<cpfn_cdiv(n, 256), 256, 0, st>>>(workspace, splits, n, dW);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P, int C, void *Y, float *partial,
+                               void *stream) {
+  if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || !partial)
+    return CPFN_EINVAL;
+  smallk_fwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(X, KS, W, P, C, (unsigned short *)Y, partial);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C, float *workspace,
+                                 float *dW, void *stream) {
+  if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !Gy || !X || !workspace || !dW)
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = cpfn_bn_bwd_blocks(P);
+  smallk_wgrad_kernel<<<nblk, 256, 0, st>>>((const unsigned short *)Gy, X, KS, P, C, workspace);
+  const long long n = (long long)C * KS;
+  split_reduce_kernel<<<cpfn_cdiv(n, 256), 256, 0, st>>>(workspace, nblk, n, dW);
+  return cpfn_launch_status();
+}

@@ -1,0 +1,286 @@
+"""Fused per-point MLP stacks on the HIP kernels of cpfn_amd/csrc/mlp.hip.
+
+One `torch.autograd.Function` per stack of (1x1 conv -> BatchNorm -> ReLU) layers,
+optionally ending in the max over the K neighbours of a set-abstraction group.  Forward
+and backward are hand-scheduled sequences of kernel launches; PyTorch only owns the
+tensors.  Layer l of a stack (training mode):
+
+  forward   Y_l   = A_{l-1} · W_lᵀ                    MFMA GEMM, epilogue emits Σy, Σy²
+            scale, shift, mean, rstd = finalize        [C]-sized (+ running-stat update)
+            A_l   = relu(scale·Y_l + shift)            fused (+ max-pool on the last layer)
+  backward  G_z   = G_a·[z>0], Σg_z, Σg_z·y            one pass
+            dγ, dβ, coef = finalize                    [C]-sized
+            G_y   = c0·G_z + c1·Y + c2                 one pass (batch-norm adjoint)
+            dW_l  = G_yᵀ · A_{l-1}                     MFMA, transposed LDS reads, split over rows
+            G_a'  = G_y · W_l                          the same MFMA GEMM kernel
+
+The convolution bias is never added: training-mode batch-norm cancels it exactly (it only
+re-enters the running mean), so its gradient is exactly zero rather than the reference's
+rounding noise.
+"""
+import torch
+
+from . import lib as _l
+from .ops import _ptr, _stream
+
+BF16 = torch.bfloat16
+
+
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def _check(status, what):
+    _l.check(status, what)
+
+
+# ------------------------------------------------------------------ thin launch wrappers
+def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_store=None, P=None):
+    """A [P,K] bf16 (row stride = A.stride(0)), Wb [N,K] bf16 -> Y [P, n_store] (bf16 | fp32)."""
+    h = _l.lib()
+    K = Wb.shape[1]
+    N = Wb.shape[0]
+    P = (gidx.numel() if gidx is not None else A.shape[0]) if P is None else P
+    n_store = N if n_store is None else n_store
+    Y = torch.empty(P, n_store, dtype=torch.float32 if out_f32 else BF16, device=A.device)
+    part = None
+    nblk = 0
+    if stats:
+        nblk = h.cpfn_mlp_gemm_blocks(P, N)
+        part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
+    _check(h.cpfn_mlp_gemm(_ptr(A), A.stride(0), _ptr(gidx), _ptr(Wb), P, K, N, _ptr(Y), n_store, 1 if out_f32 else 0,
+                           n_store, _ptr(bias), _ptr(part), _stream()), "cpfn_mlp_gemm")
+    return Y, part, nblk
+
+
+def bn_finalize(part, nblk, N, count, gamma, beta, conv_bias, eps, momentum, rm, rv):
+    dev = part.device
+    out = torch.empty(4, N, dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
+    _check(_l.lib().cpfn_bn_finalize(_ptr(part), nblk, N, float(count), _ptr(gamma), _ptr(beta), _ptr(conv_bias),
+                                     float(eps), float(momentum), _ptr(rm), _ptr(rv), _ptr(out[0]), _ptr(out[1]),
+                                     _ptr(out[2]), _ptr(out[3]), _stream()), "cpfn_bn_finalize")
+    return out
+
+
+def bn_relu_apply(Y, scale, shift):
+    out = torch.empty_like(Y)
+    _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), _stream()),
+           "cpfn_bn_relu_apply")
+    return out
+
+
+def bn_relu_maxpool(Y, scale, shift, Kn):
+    P, C = Y.shape
+    G = P // Kn
+    out = torch.empty(G, C, dtype=BF16, device=Y.device)
+    arg = torch.empty(G, C, dtype=torch.uint8, device=Y.device)
+    yarg = torch.empty(G, C, dtype=BF16, device=Y.device)
+    _check(_l.lib().cpfn_bn_relu_maxpool(_ptr(Y), _ptr(scale), _ptr(shift), G, Kn, C, _ptr(out), _ptr(arg), _ptr(yarg),
+                                         _stream()), "cpfn_bn_relu_maxpool")
+    return out, arg, yarg
+
+
+# ------------------------------------------------------------------ the stack
+class _Layer:
+    """Plain container of one layer's tensors / hyper-parameters (not a module)."""
+    __slots__ = ("weight", "bias", "gamma", "beta", "rm", "rv", "momentum", "eps", "training", "cin", "cout")
+
+
+def _layers_from_modules(convs, bns):
+    out = []
+    for conv, bn in zip(convs, bns):
+        L = _Layer()
+        L.weight, L.bias = conv.weight, conv.bias
+        L.gamma, L.beta = bn.weight, bn.bias
+        L.rm, L.rv = bn.running_mean, bn.running_var
+        L.momentum = 0.0 if bn.momentum is None else bn.momentum
+        L.eps = bn.eps
+        L.training = bn.training
+        L.cout, L.cin = conv.weight.shape[0], conv.weight.shape[1]
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        out.append(L)
+    return out
+
+
+class _FusedStack(torch.autograd.Function):
+    """args: x (bf16 [P,Kpad] or fp32 [P,KS<=4] when cfg.first_fp32), cfg, then per layer W, γ, β."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        h = _l.lib()
+        layers = cfg["layers"]
+        pool_k = cfg.get("pool_k")
+        first_fp32 = cfg.get("first_fp32", False)
+        P = x.shape[0]
+        dev = x.device
+        saved = []
+        a = x
+        out = None
+        with torch.cuda.device(dev):
+            for li, L in enumerate(layers):
+                W = params[3 * li]
+                N = L.cout
+                if li == 0 and first_fp32:
+                    KS = x.shape[1]
+                    w32 = W.detach().reshape(N, -1).float().contiguous()
+                    nblk = h.cpfn_bn_bwd_blocks(P)
+                    Y = torch.empty(P, N, dtype=BF16, device=dev)
+                    part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_smallk_fwd(_ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
+                           "cpfn_smallk_fwd")
+                    Wb = None
+                else:
+                    Kp = a.shape[1]
+                    Wb = torch.zeros(N, Kp, dtype=BF16, device=dev)
+                    Wb[:, :L.cin] = W.detach().reshape(N, -1)
+                    Y, part, nblk = gemm(a, Wb, stats=True)
+                if L.training:
+                    st = bn_finalize(part, nblk, N, P, L.gamma.detach(), L.beta.detach(),
+                                     None if L.bias is None else L.bias.detach(), L.eps, L.momentum, L.rm, L.rv)
+                else:   # running statistics (eval): z = γ (y + b − rm)/sqrt(rv+eps) + β
+                    rstd = torch.rsqrt(L.rv + L.eps)
+                    sc = L.gamma.detach() * rstd
+                    b = 0.0 if L.bias is None else L.bias.detach()
+                    st = torch.stack([sc, L.beta.detach() + (b - L.rm) * sc, L.rm - b, rstd]).float().contiguous()
+                last = li == len(layers) - 1
+                if last and pool_k:
+                    out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)
+                    saved.append((a, Y, st, Wb, arg, yarg))
+                else:
+                    nxt = bn_relu_apply(Y, st[0], st[1])
+                    saved.append((a, Y, st, Wb, None, None))
+                    a = nxt
+                    out = nxt
+        ctx.cfg = cfg
+        ctx.saved = saved
+        ctx.P = P
+        ctx.x_needs_grad = ctx.needs_input_grad[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h = _l.lib()
+        cfg = ctx.cfg
+        layers = cfg["layers"]
+        pool_k = cfg.get("pool_k")
+        first_fp32 = cfg.get("first_fp32", False)
+        P = ctx.P
+        saved = ctx.saved
+        dev = g.device
+        grads = [None] * (3 * len(layers))
+        g = g.contiguous().to(BF16)
+        gx = None
+        with torch.cuda.device(dev):
+            for li in range(len(layers) - 1, -1, -1):
+                L = layers[li]
+                a_in, Y, st, Wb, arg, yarg = saved[li]
+                N = L.cout
+                dgb = torch.empty(2, N, dtype=torch.float32, device=dev)
+                coef = torch.empty(3, N, dtype=torch.float32, device=dev)
+                gamma = L.gamma.detach()
+                if arg is not None:
+                    G = P // pool_k
+                    nblk = min(64, G)
+                    part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_bn_pool_bwd_reduce(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, nblk, _ptr(part),
+                                                     _stream()), "cpfn_bn_pool_bwd_reduce")
+                    _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
+                                                  1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
+                           "cpfn_bn_bwd_finalize")
+                    Gy = torch.empty(P, N, dtype=BF16, device=dev)
+                    _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
+                                                    _ptr(coef), G, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
+                else:
+                    nblk = h.cpfn_bn_bwd_blocks(P)
+                    part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                    Gy = torch.empty(P, N, dtype=BF16, device=dev)
+                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy), _ptr(part), _stream()),
+                           "cpfn_bn_relu_bwd")
+                    _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
+                                                  1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
+                           "cpfn_bn_bwd_finalize")
+                    _check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), P, N, _ptr(Gy), _stream()), "cpfn_bn_bwd_apply")
+                grads[3 * li + 1] = dgb[0]
+                grads[3 * li + 2] = dgb[1]
+                wshape = L.weight.shape
+                if li == 0 and first_fp32:
+                    KS = a_in.shape[1]
+                    nb = h.cpfn_bn_bwd_blocks(P)
+                    ws = torch.empty(nb * N * KS, dtype=torch.float32, device=dev)
+                    dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_smallk_wgrad(_ptr(Gy), _ptr(a_in), KS, P, N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad")
+                    grads[0] = dW.reshape(wshape)
+                else:
+                    Kp = a_in.shape[1]
+                    splits = h.cpfn_mlp_wgrad_splits(P, N, Kp)
+                    ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
+                    dW = torch.empty(N, Kp, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp, _ptr(ws), _ptr(dW), _stream()),
+                           "cpfn_mlp_wgrad")
+                    grads[3 * li] = dW[:, :L.cin].reshape(wshape)
+                    if li > 0 or ctx.x_needs_grad:
+                        WbT = Wb.t().contiguous()                       # [Kp, N]
+                        g, _, _ = gemm(Gy, WbT)
+                        if li == 0:
+                            gx = g
+        return (gx, None) + tuple(grads)
+
+
+def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False):
+    """x: bf16 rows [P, Kpad] (Kpad a multiple of 64, zero-padded beyond the first conv's
+    in_channels) — or fp32 [P, KS<=4] with first_fp32=True.  Returns bf16 [P, C_last], or
+    [P/pool_k, C_last] when pool_k is given (max over each run of pool_k consecutive rows)."""
+    layers = _layers_from_modules(convs, bns)
+    cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32}
+    params = []
+    for L in layers:
+        params += [L.weight, L.gamma, L.beta]
+    return _FusedStack.apply(x, cfg, *params)
+
+
+class _Linear(torch.autograd.Function):
+    """Y = A·Wᵀ + b with bf16 operands and fp32 output (the fc2 heads; no batch-norm)."""
+
+    @staticmethod
+    def forward(ctx, a, W, bias, n_real):
+        N, K = W.shape
+        Np = _pad_to(N, 64)
+        Wb = torch.zeros(Np, K, dtype=BF16, device=a.device)
+        Wb[:N] = W.detach()
+        bp = torch.zeros(Np, dtype=torch.float32, device=a.device)
+        bp[:N] = bias.detach()
+        with torch.cuda.device(a.device):
+            Y, _, _ = gemm(a, Wb, bias=bp, out_f32=True, n_store=N)
+        ctx.save_for_backward(a, Wb)
+        ctx.n = N
+        return Y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, Wb = ctx.saved_tensors
+        h = _l.lib()
+        N, P, K = ctx.n, a.shape[0], a.shape[1]
+        Np = Wb.shape[0]
+        gb = torch.zeros(P, Np, dtype=BF16, device=a.device)
+        gb[:, :N] = g
+        with torch.cuda.device(a.device):
+            splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
+            ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
+            dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
+            _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, _ptr(ws), _ptr(dW), _stream()),
+                   "cpfn_mlp_wgrad")
+            ga, _, _ = gemm(gb, Wb.t().contiguous())
+        return ga, dW[:N], g.sum(0), None
+
+
+def linear_heads(a, weights, biases):
+    """a bf16 [P,K]; several (weight [o_i,K,1], bias [o_i]) heads computed as ONE GEMM."""
+    W = torch.cat([w.reshape(w.shape[0], -1) for w in weights], 0)
+    b = torch.cat(list(biases), 0)
+    Y = _Linear.apply(a, W, b, W.shape[0])
+    outs, o = [], 0
+    for w in weights:
+        outs.append(Y[:, o:o + w.shape[0]])
+        o += w.shape[0]
+    return outs

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcpfn_hip.so")
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+_ll = ctypes.c_longlong
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/cpfn_hip.h
 SIGNATURES = {
@@ -36,10 +37,74 @@ SIGNATURES = {
     "cpfn_cone_pass_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_cone_pass_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_eigh3": [_vp, _i64, _vp, _vp, _vp],
+    "cpfn_mlp_gemm_blocks": [_ll, _i],
+    "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_bn_relu_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp],
+    "cpfn_bn_relu_maxpool": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "cpfn_bn_bwd_blocks": [_ll],
+    "cpfn_bn_relu_bwd": [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp],
+    "cpfn_bn_pool_bwd_reduce": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "cpfn_bn_bwd_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "cpfn_bn_bwd_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp],
+    "cpfn_bn_pool_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "cpfn_mlp_wgrad_splits": [_ll, _i, _i],
+    "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp],
+    "cpfn_smallk_fwd": [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
+    "cpfn_smallk_wgrad": [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
 }
 _RESTYPES = {"cpfn_build_info": ctypes.c_char_p}
 
 _lib = None
+_raw = None
+
+# ---- optional per-entry-point device timing (bench.py's roofline leg) -------------------
+# When a symbol is listed here, every call is bracketed by two events recorded on torch's
+# current stream (the stream the kernels are launched on); nothing synchronises until
+# `timed_report()` is called after the timed region.
+_timed = {}
+
+
+def time_symbols(names):
+    """Enable event timing for the given C-ABI entry points (empty list = off)."""
+    _timed.clear()
+    for n in names:
+        _timed[n] = []
+
+
+def timed_report():
+    """-> {symbol: (calls, total_ms)}; synchronises on the recorded events."""
+    out = {}
+    for n, pairs in _timed.items():
+        total = 0.0
+        for a, b in pairs:
+            b.synchronize()
+            total += a.elapsed_time(b)
+        out[n] = (len(pairs), total)
+    return out
+
+
+class _Proxy:
+    def __init__(self, h):
+        self._h = h
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+
+        def call(*args, _fn=fn, _name=name):
+            rec = _timed.get(_name)
+            if rec is None:
+                return _fn(*args)
+            import torch
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = _fn(*args)
+            b.record()
+            rec.append((a, b))
+            return r
+
+        setattr(self, name, call)
+        return call
 
 
 class CpfnHipError(RuntimeError):
@@ -55,6 +120,13 @@ def lib():
             raise CpfnHipError(
                 "%s not found: the HIP extension is not built. Run `python -m cpfn_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+        # The kernels are launched on torch's streams with torch-allocated pointers, so the
+        # library must bind to the SAME HIP runtime instance torch uses: load torch (and its
+        # bundled libamdhip64) first; our NEEDED libamdhip64.so.7 then resolves to it.
+        import torch  # noqa: F401
+        bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(bundled):
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
         h = ctypes.CDLL(SO_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the .so is stale: loud by design
@@ -62,7 +134,7 @@ def lib():
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
         if h.cpfn_abi_version() != 1:
             raise CpfnHipError("libcpfn_hip.so ABI version mismatch")
-        _lib = h
+        _lib = _Proxy(h)
     return _lib
 
 

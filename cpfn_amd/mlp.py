@@ -29,8 +29,48 @@ def conv_as_linear(x, conv):
     return F.linear(x, w.to(x.dtype), None if conv.bias is None else conv.bias.to(x.dtype))
 
 
-def shared_mlp(x, convs, bns):
-    """x [P, C_in] -> relu(bn(conv(.))) for every (conv, bn) pair."""
+def shared_mlp(x, convs, bns, dtype=torch.float32):
+    """x [P, C_in] -> relu(bn(conv(.))) for every (conv, bn) pair.  `dtype` is the GEMM
+    operand type (bf16 for training on MI355X, fp32 for parity tests); BatchNorm statistics
+    and normalisation are always fp32."""
     for conv, bn in zip(convs, bns):
-        x = F.relu(_bn_rows(conv_as_linear(x, conv).float(), bn))
+        x = F.relu(_bn_rows(conv_as_linear(x.to(dtype), conv).float(), bn))
     return x
+
+
+def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None):
+    """Run a whole (conv, bn, relu)* stack on rows and optionally max-pool every `pool_k`
+    consecutive rows.  `x` [P, C_in] (any float dtype) — or None with `xyz_rows` [P, 3] fp32
+    when the stack's only input is relative coordinates (sa1).
+
+    dtype == torch.bfloat16 on a HIP device: the fused MFMA path (cpfn_amd/fused_mlp.py).
+    dtype == torch.float32: plain PyTorch ops — the fp32 reference the fused path is tested
+    against, and the path used for tight parity against the reference's goldens."""
+    src = x if x is not None else xyz_rows
+    if dtype == torch.bfloat16 and src.is_cuda:
+        from . import fused_mlp
+        if x is None:
+            return fused_mlp.fused_mlp_stack(xyz_rows.float().contiguous(), convs, bns, pool_k=pool_k, first_fp32=True)
+        P, C = x.shape
+        Cp = (C + 63) // 64 * 64
+        if Cp != C or x.dtype != torch.bfloat16 or not x.is_contiguous():
+            xp = torch.zeros(P, Cp, dtype=torch.bfloat16, device=x.device) if Cp != C else None
+            if xp is None:
+                xp = x.to(torch.bfloat16).contiguous()
+            else:
+                xp[:, :C] = x
+            x = xp
+        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k)
+    y = shared_mlp(src, convs, bns, dtype)
+    if pool_k:
+        y = y.reshape(-1, pool_k, y.shape[1]).max(dim=1)[0]
+    return y
+
+
+def heads(feat, head_convs, dtype=torch.float32):
+    """fc2 heads on rows [P,128] -> list of fp32 [P, o_i]."""
+    if dtype == torch.bfloat16 and feat.is_cuda:
+        from . import fused_mlp
+        return fused_mlp.linear_heads(feat.to(torch.bfloat16).contiguous(), [h.weight for h in head_convs],
+                                      [h.bias for h in head_convs])
+    return [conv_as_linear(feat.to(dtype), h).float() for h in head_convs]

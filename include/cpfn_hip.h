@@ -162,6 +162,61 @@ CPFN_API int cpfn_cone_pass_bwd(const float *P, const float *W, const float *ape
  * S6[G,6] = (xx xy xz yy yz zz) -> lam[G,3] ascending, V[G,3,3] with eigenvectors in columns. */
 CPFN_API int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, void *stream);
 
+/* ------------------------------------------------------------------ per-point MLP stacks
+ * Replaces the Conv2d/Conv1d(1x1) + BatchNorm + ReLU (+ max over neighbours) chains of
+ * modules/pointset_abstraction.py:70-74, modules/pointset_feature_propagation.py:49-51 and
+ * PointNet2/pn2_network.py:60-68.  Activations are points-major bf16 rows [P, C]; weights
+ * [N, K] bf16 (row n = output channel); accumulation fp32 (MFMA 16x16x32 bf16). */
+
+/* Y[P,N] = A[P,K] . W[N,K]^T (+bias).  K % 32 == 0, N % 64 == 0, lda % 8 == 0.
+ * gidx (optional): row p of A is A[gidx[p]] (fused neighbour gather).
+ * y_f32 = 0: Y is bf16 with row stride ldy; 1: fp32.  Only channels < n_store are stored.
+ * stats_partial (optional): [cpfn_mlp_gemm_blocks(P,N)][2][N] fp32 per-block sum(y), sum(y^2). */
+CPFN_API int cpfn_mlp_gemm_blocks(long long P, int N);
+CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, long long P, int K,
+                           int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
+                           float *stats_partial, void *stream);
+/* Batch statistics -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update with
+ * torch's momentum / unbiased-variance convention; conv_bias re-enters the running mean). */
+CPFN_API int cpfn_bn_finalize(const float *partial, int nblk, int N, float count, const float *gamma,
+                              const float *beta, const float *conv_bias, float eps, float momentum,
+                              float *running_mean, float *running_var, float *scale, float *shift,
+                              float *mean, float *rstd, void *stream);
+/* out = relu(scale*y + shift), bf16 [P,C]. */
+CPFN_API int cpfn_bn_relu_apply(const void *Y, const float *scale, const float *shift, long long P,
+                                int C, void *out, void *stream);
+/* out[g,c] = max_k relu(scale*y[g,k,c] + shift) over Kn <= 256 consecutive rows; arg = first k
+ * attaining it (u8), yarg = raw y there.  C >= 64, C/8 a power of two. */
+CPFN_API int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const float *shift, int G, int Kn,
+                                  int C, void *out, unsigned char *arg, void *yarg, void *stream);
+/* Backward pass 1: Gz = Ga*[z>0] (may alias Ga); partial[cpfn_bn_bwd_blocks(P)][2][C] = sum(Gz), sum(Gz*y). */
+CPFN_API int cpfn_bn_bwd_blocks(long long P);
+CPFN_API int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift,
+                              long long P, int C, void *Gz, float *partial, void *stream);
+CPFN_API int cpfn_bn_pool_bwd_reduce(const void *Gp, const void *yarg, const float *scale,
+                                     const float *shift, int G, int C, int nblk, float *partial,
+                                     void *stream);
+/* dgamma, dbeta and coef[3][C] with g_y = coef0*g_z + coef1*y + coef2. */
+CPFN_API int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float count, const float *gamma,
+                                  const float *mean, const float *rstd, int training, float *dgamma,
+                                  float *dbeta, float *coef, void *stream);
+CPFN_API int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, long long P, int C,
+                               void *Gy, void *stream);
+CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, const void *yarg,
+                                    const void *Y, const float *scale, const float *shift,
+                                    const float *coef, int G, int Kn, int C, void *Gy, void *stream);
+/* dW[N,K] (fp32) = Gy[P,N]^T . A[P,K]; workspace: cpfn_mlp_wgrad_splits(P,N,K)*N*K floats. */
+CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
+CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
+                            int N, int K, float *workspace, float *dW, void *stream);
+/* fp32 first layer with K = KS <= 4 inputs (sa1: relative xyz stay fp32):
+ * Y[P,C] bf16 = X[P,KS] . W[C,KS]^T, partial[cpfn_bn_bwd_blocks(P)][2][C]; and its weight gradient
+ * (workspace: cpfn_bn_bwd_blocks(P)*C*KS floats). */
+CPFN_API int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P, int C, void *Y,
+                             float *partial, void *stream);
+CPFN_API int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C,
+                               float *workspace, float *dW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,145 @@
+"""GPU numerics of the fused MFMA MLP stacks (bf16 operands, fp32 accumulation) against a
+plain PyTorch fp32 reference of the same op (conv1x1 -> batch_norm(batch stats) -> relu
+[-> max over neighbours]), forward and backward.  Tolerances are bf16-level: activations and
+their gradients are stored as bf16 between layers."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _stack(cin, widths, seed, conv1d=True):
+    torch.manual_seed(seed)
+    convs, bns = nn.ModuleList(), nn.ModuleList()
+    c = cin
+    for w in widths:
+        convs.append(nn.Conv1d(c, w, 1) if conv1d else nn.Conv2d(c, w, 1))
+        bn = nn.BatchNorm1d(w) if conv1d else nn.BatchNorm2d(w)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.weight[::7] *= -1            # negative gammas: the pooling must still take max of z, not of y
+            bn.bias.uniform_(-0.3, 0.3)
+        bns.append(bn)
+        c = w
+    return convs.to(dev()), bns.to(dev())
+
+
+def _rel(a, b):
+    """relative L2 error — the fused path stores activations/gradients as bf16 (8-bit mantissa)
+    between layers and an arg-max can flip on a near-tie, so element-wise max error is noisy."""
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def _emulated_stack(x, convs, bns, pool_k, xyz_rows):
+    """The same op in plain PyTorch fp32 with the fused path's storage roundings made explicit
+    (bf16 operands, bf16-stored pre-activations / activations, fp32 statistics), so ReLU masks and
+    pooling arg-maxes are decided on the same values — otherwise ~0.3 % of the masks flip and the
+    L2 error of a gradient is dominated by those flips (sqrt(0.003) ~ 5 %), not by the kernels."""
+    import torch.nn.functional as F
+    r = lambda t: t.to(torch.bfloat16).float()
+    a = xyz_rows.float() if x is None else r(x)
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        W = conv.weight.reshape(conv.weight.shape[0], -1)
+        W = W.float() if (x is None and i == 0) else r(W)
+        y32 = a @ W.t()
+        mean, var = y32.mean(0), y32.var(0, unbiased=False)
+        with torch.no_grad():
+            n = y32.shape[0]
+            bn.running_mean.mul_(1 - bn.momentum).add_(bn.momentum * (mean + conv.bias))
+            bn.running_var.mul_(1 - bn.momentum).add_(bn.momentum * var * n / (n - 1))
+        y = y32 + (r(y32) - y32).detach()                      # stored as bf16, straight-through
+        z = (y - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+        if pool_k and i == len(convs) - 1:
+            z = z.reshape(-1, pool_k, z.shape[1]).max(dim=1)[0]
+        a = F.relu(z)
+        a = a + (r(a) - a).detach()
+    return a
+
+
+def _run(x, convs, bns, dtype, pool_k, xyz_rows, gout):
+    from cpfn_amd import mlp
+    for p in list(convs.parameters()) + list(bns.parameters()):
+        p.grad = None
+    for bn in bns:
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+    xin = None if x is None else x.clone().requires_grad_(True)
+    if dtype == "emulated":
+        y = _emulated_stack(xin, convs, bns, pool_k, xyz_rows)
+    else:
+        y = mlp.run_stack(xin, convs, bns, dtype, pool_k=pool_k, xyz_rows=xyz_rows)
+    (y.float() * gout).sum().backward()
+    grads = [p.grad.clone() if p.grad is not None else None for p in list(convs.parameters()) + list(bns.parameters())]
+    stats = [(bn.running_mean.clone(), bn.running_var.clone()) for bn in bns]
+    return y.detach().float(), None if xin is None else xin.grad.float(), grads, stats
+
+
+@pytest.mark.parametrize("name,P,cin,widths,pool_k,use_xyz", [
+    ("sa1-like", 2 * 40 * 16, 3, [64, 64, 128], 16, True),
+    ("sa2-like", 2 * 24 * 64, 131, [128, 128, 256], 64, False),
+    ("sa3-like", 3 * 128, 259, [256, 512, 1024], 128, False),
+    ("sfp-like", 1000, 384, [256, 128], None, False),
+    ("sfp3-like", 4096 + 77, 128, [128, 128, 128], None, False),
+])
+def test_fused_stack_matches_fp32_reference(name, P, cin, widths, pool_k, use_xyz):
+    convs, bns = _stack(cin, widths, seed=len(name))
+    g = torch.Generator().manual_seed(P)
+    if use_xyz:
+        xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev())
+        x = None
+    else:
+        xyz = None
+        x = torch.randn(P, cin, generator=g).to(dev())
+    rows_out = P // pool_k if pool_k else P
+    gout = torch.randn(rows_out, widths[-1], generator=g).to(dev())
+    y_32, gx_32, gr_32, _ = _run(x, convs, bns, torch.float32, pool_k, xyz, gout)
+    y_ref, gx_ref, gr_ref, st_ref = _run(x, convs, bns, "emulated", pool_k, xyz, gout)
+    y, gx, gr, st = _run(x, convs, bns, torch.bfloat16, pool_k, xyz, gout)
+    assert y.shape == y_ref.shape
+    # (1) against true fp32: bf16-level agreement of the forward, gradients same direction
+    assert _rel(y, y_32) < 3e-2, ("out vs fp32", _rel(y, y_32))
+    # (2) against the rounding-emulated reference: the kernels themselves
+    assert _rel(y, y_ref) < 1e-2, ("out", _rel(y, y_ref))
+    if gx_ref is not None:
+        assert _rel(gx[:, :cin], gx_ref) < 3e-2, ("gx", _rel(gx[:, :cin], gx_ref))
+        assert _rel(gx[:, :cin], gx_32) < 0.35
+    names = [n for n, _ in list(convs.named_parameters()) + list(bns.named_parameters())]
+    gmax = max(float(t.abs().max()) for t in gr_ref if t is not None)
+    for pos, (n, a, b) in enumerate(zip(names, gr, gr_ref)):
+        is_conv_bias = n.endswith("bias") and pos < 2 * len(widths)
+        if is_conv_bias:
+            # exactly zero under training-mode batch-norm: not produced by the fused path
+            assert a is None and (b is None or float(b.abs().max()) < 1e-3 * gmax), n
+            continue
+        assert _rel(a, b) < 3e-2, (n, _rel(a, b))
+    for (rm, rv), (rm_r, rv_r) in zip(st, st_ref):
+        assert _rel(rm, rm_r) < 1e-2 and _rel(rv, rv_r) < 1e-2
+
+
+def test_heads_linear():
+    from cpfn_amd import mlp
+    torch.manual_seed(0)
+    heads = nn.ModuleList([nn.Conv1d(128, o, 1) for o in (3, 4, 28)]).to(dev())
+    feat = torch.randn(3000, 128, device=dev())
+    f1 = feat.clone().requires_grad_(True)
+    outs = mlp.heads(f1, heads, torch.float32)
+    gouts = [torch.randn_like(o) for o in outs]
+    sum((o * g).sum() for o, g in zip(outs, gouts)).backward()
+    ref = [p.grad.clone() for p in heads.parameters()]
+    gx_ref = f1.grad.clone()
+    for p in heads.parameters():
+        p.grad = None
+    f2 = feat.clone().requires_grad_(True)
+    outs2 = mlp.heads(f2, heads, torch.bfloat16)
+    sum((o * g).sum() for o, g in zip(outs2, gouts)).backward()
+    for o, o2 in zip(outs, outs2):
+        assert o2.dtype == torch.float32 and _rel(o2, o) < 2e-2
+    for p, r in zip(heads.parameters(), ref):
+        assert _rel(p.grad, r) < 3e-2
+    assert _rel(f2.grad, gx_ref) < 3e-2
