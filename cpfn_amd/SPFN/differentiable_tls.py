@@ -13,10 +13,22 @@ from . import moments as _m
 _SYM = ((0, 1, 2), (1, 3, 4), (2, 4, 5))
 
 
+_index_cache = {}
+
+
+def cached_index(name, nested, device):
+    """Small constant index tensors, created once per device (never inside a graph capture)."""
+    key = (name, str(device))
+    t = _index_cache.get(key)
+    if t is None:
+        t = torch.tensor(nested, device=device)
+        _index_cache[key] = t
+    return t
+
+
 def sym3(v6):
     """[...,6] (xx xy xz yy yz zz) -> symmetric [...,3,3]."""
-    idx = torch.tensor(_SYM, device=v6.device)
-    return v6[..., idx]
+    return v6[..., cached_index("sym3", _SYM, v6.device)]
 
 
 def guard_one_over_matrix(M, min_abs_value=1e-10):

@@ -1,11 +1,42 @@
 """The four primitive fits on one shared set of moments."""
 import math
+import os
 
 import torch
 
 from . import geometry_utils as G
 from . import moments as _m
 from .differentiable_tls import smallest_eigvec, sym3
+
+
+# ---------------------------------------------------------------------------------------------
+# The per-instance algebra is ~400 tiny [B,K]-sized fp64 kernels forward and as many backward:
+# launch-bound, not compute-bound.  With static shapes it is captured ONCE into a pair of
+# hipGraphs (forward / backward) per (device, B, K) and replayed every step.
+USE_GRAPH = os.environ.get("CPFN_FIT_GRAPH", "1") == "1"
+_graphed = {}
+
+
+def _algebra(M):
+    """M [B,K,52] -> every fit that needs no second pass over the points."""
+    plane_n, plane_c = plane_from_moments(M)
+    sph_c, sph_r2 = sphere_from_moments(M)
+    cyl_n, cyl_c, cyl_r2 = cylinder_from_moments(M)
+    apex = G.guarded_solve_normal_equations(sym3(M[..., _m.BXX]), M[..., _m.BXPX])   # cone_fitter.py:17-20
+    axis, _ = G.fit_plane(M[..., _m.A0], M[..., _m.AX], sym3(M[..., _m.AXX]))         # cone_fitter.py:23
+    return plane_n, plane_c, sph_c, sph_r2, cyl_n, cyl_c, cyl_r2, apex, axis
+
+
+def algebra(M):
+    if USE_GRAPH and M.is_cuda and M.requires_grad and torch.is_grad_enabled():
+        key = (M.device.index, tuple(M.shape))
+        fn = _graphed.get(key)
+        if fn is None:
+            sample = M.detach().clone().requires_grad_(True)
+            fn = torch.cuda.make_graphed_callables(_algebra, (sample,))
+            _graphed[key] = fn
+        return fn(M)
+    return _algebra(M)
 
 
 def moments(P, W, X=None):
@@ -47,10 +78,11 @@ def cylinder_from_moments(M):
     return n, centre, r2
 
 
-def cone_from_moments(M, P, W, div_eps=1e-10):
+def cone_from_moments(M, P, W, div_eps=1e-10, apex=None, axis=None):
     """SPFN/cone_fitter.py:12-36 -> apex, axis [B,K,3], half_angle [B,K]."""
-    apex = G.guarded_solve_normal_equations(sym3(M[..., _m.BXX]), M[..., _m.BXPX])   # (:17-20)
-    axis, _ = G.fit_plane(M[..., _m.A0], M[..., _m.AX], sym3(M[..., _m.AXX]))         # (:23)
+    if apex is None:
+        apex = G.guarded_solve_normal_equations(sym3(M[..., _m.BXX]), M[..., _m.BXPX])   # (:17-20)
+        axis, _ = G.fit_plane(M[..., _m.A0], M[..., _m.AX], sym3(M[..., _m.AXX]))         # (:23)
     sums = _m.ConePass.apply(P, W, apex, axis)                                        # (:25-34)
     sgn = torch.sign(sums[..., 0])
     sgn = sgn + (sgn == 0).to(sgn.dtype)                                              # (:30)

@@ -9,7 +9,7 @@ singular values detached and ridge 1e-8 (lines 132-139).
 import torch
 
 from . import moments as _m
-from .differentiable_tls import smallest_eigvec, sym3
+from .differentiable_tls import cached_index, smallest_eigvec, sym3
 
 DIV_EPS = 1e-10
 COND_CAP = 1e5
@@ -20,7 +20,7 @@ _T3 = [[[0, 1, 2], [1, 3, 4], [2, 4, 5]], [[1, 3, 4], [3, 6, 7], [4, 7, 8]], [[2
 
 
 def sym3x3x3(v10):
-    return v10[..., torch.tensor(_T3, device=v10.device)]
+    return v10[..., cached_index("sym3x3x3", _T3, v10.device)]
 
 
 def to6(S):

@@ -79,20 +79,19 @@ def compute_parameters(P, W, X, classes=['plane', 'sphere', 'cylinder', 'cone'])
     One fused pass over (P, X, W) feeds every requested primitive type."""
     M = _fc.moments(P, W, X)
     dt = P.dtype
+    (plane_n, plane_c, sph_c, sph_r2, cyl_n, cyl_c, cyl_r2, apex, axis) = _fc.algebra(M)
     out = {}
     for class_ in classes:
         if class_ == 'plane':
-            n, c = _fc.plane_from_moments(M)
-            out['plane_normal'], out['plane_center'] = n.to(dt), c.to(dt)
+            out['plane_normal'], out['plane_center'] = plane_n.to(dt), plane_c.to(dt)
         elif class_ == 'sphere':
-            c, r2 = _fc.sphere_from_moments(M)
-            out['sphere_center'], out['sphere_radius_squared'] = c.to(dt), r2.to(dt)
+            out['sphere_center'], out['sphere_radius_squared'] = sph_c.to(dt), sph_r2.to(dt)
         elif class_ == 'cylinder':
-            a, c, r2 = _fc.cylinder_from_moments(M)
-            out['cylinder_axis'], out['cylinder_center'], out['cylinder_radius_squared'] = a.to(dt), c.to(dt), r2.to(dt)
+            out['cylinder_axis'], out['cylinder_center'], out['cylinder_radius_squared'] = \
+                cyl_n.to(dt), cyl_c.to(dt), cyl_r2.to(dt)
         elif class_ == 'cone':
-            apex, axis, half = _fc.cone_from_moments(M, P, W)
-            out['cone_apex'], out['cone_axis'], out['cone_half_angle'] = apex.to(dt), axis.to(dt), half.to(dt)
+            apex_, axis_, half = _fc.cone_from_moments(M, P, W, apex=apex, axis=axis)
+            out['cone_apex'], out['cone_axis'], out['cone_half_angle'] = apex_.to(dt), axis_.to(dt), half.to(dt)
         else:
             raise NotImplementedError
     return out

@@ -153,19 +153,38 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
 // ---------------------------------------------------------------- BatchNorm finalize (forward)
 // scale = γ·rstd, shift = β − mean·scale; running statistics updated like torch (unbiased var,
 // the conv bias — dropped from the GEMM because batch-norm cancels it — re-enters the mean).
-__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N, float count,
+// Fixed-order two-level sum of per-block partials: 16 channels x 16 block-subsets per workgroup
+// (subset r adds blocks r, r+16, ...; the 16 subset sums are then added in order) — parallel,
+// coalesced, and still bitwise reproducible.
+__device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ partial, int nblk, int N, int c,
+                                                   int r, double (*s_acc)[16][2], double &s1, double &s2) {
+  double a1 = 0.0, a2 = 0.0;
+  if (c < N) {
+    for (int i = r; i < nblk; i += 16) {
+      a1 += (double)partial[((size_t)i * 2 + 0) * N + c];
+      a2 += (double)partial[((size_t)i * 2 + 1) * N + c];
+    }
+  }
+  s_acc[r][threadIdx.x & 15][0] = a1;
+  s_acc[r][threadIdx.x & 15][1] = a2;
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+  if (r == 0) {
+    for (int q = 0; q < 16; ++q) { s1 += s_acc[q][threadIdx.x & 15][0]; s2 += s_acc[q][threadIdx.x & 15][1]; }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N, float count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    const float *__restrict__ conv_bias, float eps, float momentum,
                                    float *__restrict__ running_mean, float *__restrict__ running_var,
                                    float *__restrict__ scale, float *__restrict__ shift,
                                    float *__restrict__ mean_out, float *__restrict__ rstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < nblk; ++i) {
-    s1 += (double)partial[((size_t)i * 2 + 0) * N + c];
-    s2 += (double)partial[((size_t)i * 2 + 1) * N + c];
-  }
+  __shared__ double s_acc[16][16][2];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
+  double s1, s2;
+  partial_sums_16x16(partial, nblk, N, c, r, s_acc, s1, s2);
+  if (r != 0 || c >= N) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   var = var > 0.0 ? var : 0.0;
@@ -346,17 +365,15 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
 
 // dβ = Σg_z, dγ = rstd·(Σg_z·y − mean·Σg_z);  g_y = s·g_z + c2·y + c3 with
 // s = γ·rstd, c2 = −s·dγ·rstd/count, c3 = −s·dβ/count − c2·mean  (training-mode batch norm).
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
                                        const float *__restrict__ gamma, const float *__restrict__ mean,
                                        const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < nblk; ++i) {
-    s1 += (double)partial[((size_t)i * 2 + 0) * C + c];
-    s2 += (double)partial[((size_t)i * 2 + 1) * C + c];
-  }
+  __shared__ double s_acc[16][16][2];
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
+  double s1, s2;
+  partial_sums_16x16(partial, nblk, C, c, r, s_acc, s1, s2);
+  if (r != 0 || c >= C) return;
   const double m = mean[c], rs = rstd[c];
   const double dg = rs * (s2 - m * s1);
   dgamma[c] = (float)dg;
@@ -489,13 +506,21 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
       }
 }
 
-__global__ void split_reduce_kernel(const float *__restrict__ partial, int splits, long long n,
+__global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restrict__ partial, int splits, long long n,
                                     float *__restrict__ out) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float s = 0.f;
-  for (int i = 0; i < splits; ++i) s += partial[(size_t)i * n + e];
-  out[e] = s;
+  __shared__ float s_acc[16][16];
+  const long long e = (long long)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int r = threadIdx.x >> 4;
+  float a = 0.f;
+  if (e < n)
+    for (int i = r; i < splits; i += 16) a += partial[(size_t)i * n + e];
+  s_acc[r][threadIdx.x & 15] = a;
+  __syncthreads();
+  if (r == 0 && e < n) {
+    float s = 0.f;
+    for (int q = 0; q < 16; ++q) s += s_acc[q][threadIdx.x & 15];
+    out[e] = s;
+  }
 }
 
 // ---------------------------------------------------------------- fp32 small-K first layer (sa1: K = 3)
@@ -606,7 +631,7 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   // number of row-blocks (gridDim.x) the GEMM will use == rows of its stats-partial buffer
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
   const int ny = (N + 127) / 128 > 0 ? (N + 127) / 128 : 1;
-  long long tpw = tiles * ny / 1024;  // aim for ~1024 workgroups
+  long long tpw = tiles * ny / 512;  // aim for ~512 workgroups (2 per CU)
   if (tpw < 1) tpw = 1;
   if (tpw > 16) tpw = 16;
   return (int)((tiles + tpw - 1) / tpw);
@@ -644,7 +669,7 @@ extern "C" int cpfn_bn_finalize(const float *partial, int nblk, int N, float cou
                                 float *running_mean, float *running_var, float *scale, float *shift,
                                 float *mean, float *rstd, void *stream) {
   if (nblk <= 0 || N <= 0 || !partial || !gamma || !beta || !scale || !shift || !mean || !rstd) return CPFN_EINVAL;
-  bn_finalize_kernel<<<cpfn_cdiv(N, 128), 128, 0, (hipStream_t)stream>>>(partial, nblk, N, count, gamma, beta, conv_bias,
+  bn_finalize_kernel<<<cpfn_cdiv(N, 16), 256, 0, (hipStream_t)stream>>>(partial, nblk, N, count, gamma, beta, conv_bias,
                                                                         eps, momentum, running_mean, running_var,
                                                                         scale, shift, mean, rstd);
   return cpfn_launch_status();
@@ -694,7 +719,7 @@ extern "C" int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float
                                     const float *mean, const float *rstd, int training, float *dgamma,
                                     float *dbeta, float *coef, void *stream) {
   if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef) return CPFN_EINVAL;
-  bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 128), 128, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
+  bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
                                                                             training, dgamma, dbeta, coef);
   return cpfn_launch_status();
 }
@@ -722,8 +747,9 @@ extern "C" int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, 
 
 extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
   const long long tiles = (long long)((N + 63) / 64) * ((K + 63) / 64);
-  long long s = (1024 + tiles - 1) / tiles;           // ~1024 workgroups
-  const long long max_s = (P + 255) / 256;            // at least 256 rows per split
+  long long s = (512 + tiles - 1) / tiles;            // ~512 workgroups
+  if (s > 128) s = 128;                               // bound the partial buffer / reduce depth
+  const long long max_s = (P + 1023) / 1024;          // at least 1024 rows per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   return (int)s;
@@ -741,7 +767,7 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
   mlp_wgrad_kernel<<<grid, 256, 0, st>>>((const unsigned short *)Gy, ldg, (const unsigned short *)A, lda, gidx, P, N, K,
                                          rps, workspace);
   const long long n = (long long)N * K;
-  split_reduce_kernel<<<cpfn_cdiv(n, 256), 256, 0, st>>>(workspace, splits, n, dW);
+  split_reduce_kernel<<<cpfn_cdiv(n, 16), 256, 0, st>>>(workspace, splits, n, dW);
   return cpfn_launch_status();
 }
 
@@ -761,6 +787,6 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
   const int nblk = cpfn_bn_bwd_blocks(P);
   smallk_wgrad_kernel<<<nblk, 256, 0, st>>>((const unsigned short *)Gy, X, KS, P, C, workspace);
   const long long n = (long long)C * KS;
-  split_reduce_kernel<<<cpfn_cdiv(n, 256), 256, 0, st>>>(workspace, nblk, n, dW);
+  split_reduce_kernel<<<cpfn_cdiv(n, 16), 256, 0, st>>>(workspace, nblk, n, dW);
   return cpfn_launch_status();
 }
