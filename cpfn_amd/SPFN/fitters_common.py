@@ -10,15 +10,14 @@ from .differentiable_tls import smallest_eigvec, sym3
 
 
 # ---------------------------------------------------------------------------------------------
-# The per-instance algebra is ~400 tiny [B,K]-sized fp64 kernels forward and as many backward:
-# launch-bound, not compute-bound.  With static shapes it is captured ONCE into a pair of
-# hipGraphs (forward / backward) per (device, B, K) and replayed every step.
-USE_GRAPH = os.environ.get("CPFN_FIT_GRAPH", "1") == "1"
-_graphed = {}
+# The per-instance algebra ([B,K]-sized: eigenvectors, guarded solves, the cylinder frame) runs
+# in ONE HIP kernel per direction (csrc/fit_algebra.hip).  `_algebra_torch` is the same algebra
+# as ~400 framework ops; it is what the kernel was validated against and can be selected with
+# CPFN_FIT_ALGEBRA=torch for debugging.
+ALGEBRA_IMPL = os.environ.get("CPFN_FIT_ALGEBRA", "hip")
 
 
-def _algebra(M):
-    """M [B,K,52] -> every fit that needs no second pass over the points."""
+def _algebra_torch(M):
     plane_n, plane_c = plane_from_moments(M)
     sph_c, sph_r2 = sphere_from_moments(M)
     cyl_n, cyl_c, cyl_r2 = cylinder_from_moments(M)
@@ -28,15 +27,13 @@ def _algebra(M):
 
 
 def algebra(M):
-    if USE_GRAPH and M.is_cuda and M.requires_grad and torch.is_grad_enabled():
-        key = (M.device.index, tuple(M.shape))
-        fn = _graphed.get(key)
-        if fn is None:
-            sample = M.detach().clone().requires_grad_(True)
-            fn = torch.cuda.make_graphed_callables(_algebra, (sample,))
-            _graphed[key] = fn
-        return fn(M)
-    return _algebra(M)
+    """M [B,K,52] -> (plane_n, plane_c, sphere_c, sphere_r2, cyl_axis, cyl_c, cyl_r2, cone_apex,
+    cone_axis_before_sign_fix)."""
+    if ALGEBRA_IMPL == "torch":
+        return _algebra_torch(M)
+    o = _m.FitAlgebra.apply(M)
+    return (o[..., 0:3], o[..., 3], o[..., 4:7], o[..., 7], o[..., 8:11], o[..., 11:14], o[..., 14],
+            o[..., 15:18], o[..., 18:21])
 
 
 def moments(P, W, X=None):

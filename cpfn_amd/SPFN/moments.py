@@ -92,3 +92,28 @@ def eigh3(S6):
     with torch.cuda.device(S.device):
         _l.check(_l.lib().cpfn_eigh3(_ptr(S), G, _ptr(lam), _ptr(V), _stream()), "cpfn_eigh3")
     return lam, V
+
+
+class FitAlgebra(torch.autograd.Function):
+    """M [B,K,52] float64 -> out [B,K,21] float64 (one lane per instance; backward = Jᵀg by
+    forward-mode AD inside the kernel, 52 lanes per instance)."""
+
+    @staticmethod
+    def forward(ctx, M):
+        Mc = M.detach().contiguous().double()
+        G = Mc.numel() // SLOTS
+        out = torch.empty(Mc.shape[:-1] + (21,), dtype=torch.float64, device=Mc.device)
+        with torch.cuda.device(Mc.device):
+            _l.check(_l.lib().cpfn_fit_algebra_fwd(_ptr(Mc), G, _ptr(out), _stream()), "cpfn_fit_algebra_fwd")
+        ctx.save_for_backward(Mc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (Mc,) = ctx.saved_tensors
+        G = Mc.numel() // SLOTS
+        gc = g.contiguous().double()
+        gM = torch.empty_like(Mc)
+        with torch.cuda.device(Mc.device):
+            _l.check(_l.lib().cpfn_fit_algebra_bwd(_ptr(Mc), _ptr(gc), G, _ptr(gM), _stream()), "cpfn_fit_algebra_bwd")
+        return gM

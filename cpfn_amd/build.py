@@ -26,6 +26,7 @@ SOURCES = {
     "neighbors.hip": ["-ffp-contract=off"],
     "gather.hip": ["-ffp-contract=off"],
     "fitters.hip": [],
+    "fit_algebra.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",

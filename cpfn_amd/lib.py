@@ -36,6 +36,8 @@ SIGNATURES = {
     "cpfn_fit_moments_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_cone_pass_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_cone_pass_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "cpfn_fit_algebra_fwd": [_vp, _i64, _vp, _vp],
+    "cpfn_fit_algebra_bwd": [_vp, _vp, _i64, _vp, _vp],
     "cpfn_eigh3": [_vp, _i64, _vp, _vp, _vp],
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp],

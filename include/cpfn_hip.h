@@ -157,6 +157,17 @@ CPFN_API int cpfn_cone_pass_bwd(const float *P, const float *W, const float *ape
                                 const float *g_acos, int B, int N, int K, float *dW,
                                 double *workspace, double *d_apex_axis, void *stream);
 
+/* Per-instance algebra of all four fitters on the moments (the [B,K]-sized tail of
+ * SPFN/{plane,sphere,cylinder,cone}_fitter.compute_parameters; SPFN/geometry_utils.py:8-27,
+ * 74-84, 121-142, 209-223; SPFN/differentiable_tls.py:123-143):
+ *   M[G,52] -> out[G,21] = plane n(3) c(1) | sphere centre(3) r2(1) | cylinder axis(3) centre(3)
+ *   r2(1) | cone apex(3) | cone axis before the sign fix(3).   G = B*K instances, fp64.
+ * The backward entry returns gM[G,52] = J^T gout by forward-mode AD through the same code. */
+#define CPFN_FIT_OUTPUTS 21
+CPFN_API int cpfn_fit_algebra_fwd(const double *M, int64_t G, double *out, void *stream);
+CPFN_API int cpfn_fit_algebra_bwd(const double *M, const double *gout, int64_t G, double *gM,
+                                  void *stream);
+
 /* Batched symmetric 3x3 eigen-decomposition (fp64 Jacobi) replacing the torch.svd call of
  * Custom_svd_v_colum (SPFN/differentiable_tls.py:126) on the PSD moment matrices.
  * S6[G,6] = (xx xy xz yy yz zz) -> lam[G,3] ascending, V[G,3,3] with eigenvectors in columns. */
