@@ -29,15 +29,13 @@ N_POINTS = 8192
 N_INSTANCES = 28
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
-# dominant kernel of the step (see DESIGN.md "Measurement") and its algorithmic traffic
-ROOFLINE_SYMBOL = "cpfn_fit_moments_fwd"
-
-
-def roofline_bytes_per_launch(B, N, K):
-    """Algorithmic bytes of one fused-moment launch: read P, X (fp32 xyz) and W once,
-    write the [B,K,52] fp64 moments (SURVEY.md §8d 'fitters fwd': 1,114,112 + 2,464 B / cloud
-    for the reference's 22 outputs; here the 52-slot moment block is what is written)."""
-    return B * (N * 3 * 4 * 2 + N * K * 4 + K * 52 * 8)
+# Dominant kernel family of the step (profiles/r01_*_kernel_stats.csv; DESIGN.md "Measurement"):
+# the bf16 MFMA GEMM behind every 1x1 convolution, forward and data-gradient (31 launches per
+# step).  Arithmetic intensity is 32-128 FLOP/B (K, N <= 256 for the layers that carry the
+# bytes), far left of the ~300 FLOP/B bf16 ridge, so the bound is HBM.  The algorithmic bytes
+# of each launch (read A[P,K] and W[N,K] once, write Y[P,N] once) are summed by the caller
+# (cpfn_amd/fused_mlp.py:gemm) while the timed region runs.
+ROOFLINE_SYMBOL = "cpfn_mlp_gemm"
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -128,6 +126,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     calls, kernel_ms = lib.timed_report()[ROOFLINE_SYMBOL]
+    roof_bytes = lib.timed_bytes(ROOFLINE_SYMBOL)
     lib.time_symbols([])
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -137,7 +136,12 @@ def main():
     if rank == 0:
         clouds = BATCH_PER_GPU * world * args.steps
         per_launch_s = kernel_ms / max(calls, 1) / 1e3
-        achieved = roofline_bytes_per_launch(BATCH_PER_GPU, N_POINTS, N_INSTANCES) / per_launch_s / 1e9
+        bytes_per_launch = roof_bytes / max(calls, 1)
+        achieved = bytes_per_launch / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_mlp_gemm_traffic.json")
+        if os.path.exists(tpath):                       # PMC pass (rocprofv3 --pmc), see profiles/README.md
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {
             "metric": "point-clouds/sec (8192 pts, GlobalSPFN fwd+bwd)",
             "value": clouds / elapsed, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps,
@@ -149,8 +153,9 @@ def main():
                        "global_batch": BATCH_PER_GPU * world, "points": N_POINTS,
                        "parallelism": "dp%d" % world, "loss_last": float(out[0])},
             "roofline": {"bound": "hbm", "kernel": ROOFLINE_SYMBOL, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launches": calls, "avg_launch_us": 1e6 * per_launch_s},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches": calls, "avg_launch_us": 1e6 * per_launch_s,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -50,6 +50,8 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
         part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
     _check(h.cpfn_mlp_gemm(_ptr(A), A.stride(0), _ptr(gidx), _ptr(Wb), P, K, N, _ptr(Y), n_store, 1 if out_f32 else 0,
                            n_store, _ptr(bias), _ptr(part), _stream()), "cpfn_mlp_gemm")
+    # algorithmic traffic of this launch: read A and W once, write Y once (+ the stats partials)
+    _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + Y.element_size() * P * n_store + (8 * nblk * N if stats else 0))
     return Y, part, nblk
 
 

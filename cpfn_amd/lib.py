@@ -67,11 +67,26 @@ _raw = None
 _timed = {}
 
 
+_bytes = {}
+
+
 def time_symbols(names):
     """Enable event timing for the given C-ABI entry points (empty list = off)."""
     _timed.clear()
+    _bytes.clear()
     for n in names:
         _timed[n] = []
+        _bytes[n] = 0
+
+
+def add_bytes(name, nbytes):
+    """Callers that know a launch's ALGORITHMIC traffic report it here while timing is on."""
+    if name in _bytes:
+        _bytes[name] += int(nbytes)
+
+
+def timed_bytes(name):
+    return _bytes.get(name, 0)
 
 
 def timed_report():

@@ -1,0 +1,105 @@
+"""CPU, world_size 2, gloo: the data-parallel path of cpfn_amd.training (flat gradient bucket,
+one all-reduce per step, rank-0 broadcast) with the LocalSPFN loss configuration
+(residue / parameter multipliers 0: Configs/config_localSPFN.yml:10-11), whose losses are plain
+torch ops and therefore run without a GPU.  Data parallelism over clouds must reproduce
+single-process training on the concatenated batch (no BatchNorm in the stand-in network)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cpfn_amd import synthetic, training
+
+
+class TinyHeads(torch.nn.Module):
+    """Stand-in with PointNet2's forward contract: P [B,N,3] -> [X, T, W, l3, feat]."""
+
+    def __init__(self, K=21):
+        super().__init__()
+        self.body = torch.nn.Linear(3, 32)
+        self.hx, self.ht, self.hw = torch.nn.Linear(32, 3), torch.nn.Linear(32, 4), torch.nn.Linear(32, K)
+
+    def forward(self, P, fps_start=None):
+        f = torch.tanh(self.body(P))
+        return [self.hx(f), self.ht(f), self.hw(f), None, None]
+
+
+LOCAL_MULT = dict(miou=1.0, normal=1.0, type=1.0, parameter=0.0, residue=0.0, total=1.0)
+
+
+def _batch(B, seed):
+    b = synthetic.training_batch(B, N=256, n_max_instances=21, n_prims=4, n_inst_points=16, seed=seed)
+    return b
+
+
+def _cat(batches):
+    return {k: torch.cat([b[k] for b in batches], 0) for k in batches[0]}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                 # different init per rank: broadcast must fix it
+    model = TinyHeads()
+    training.broadcast_parameters(model)
+    tr = training.SPFNTrainer(model, batch_size=2 * world, multipliers=LOCAL_MULT, fused_adam=False)
+    for step in range(3):
+        out = tr.step(_batch(2, seed=10 * step + rank))
+    assert tr.skipped_steps == 0 and tr.global_step == 3
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_data_parallel_matches_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sd = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    for k in sd[0]:
+        assert torch.equal(sd[0][k], sd[1][k]), "replicas diverged: %s" % k
+    # single process on the concatenated batches, same initial weights as rank 0
+    torch.manual_seed(100)
+    model = TinyHeads()
+    tr = training.SPFNTrainer(model, batch_size=4, multipliers=LOCAL_MULT, fused_adam=False)
+    for step in range(3):
+        tr.step(_cat([_batch(2, seed=10 * step + r) for r in range(world)]))
+    for k, v in model.state_dict().items():
+        torch.testing.assert_close(v, sd[0][k], rtol=2e-4, atol=2e-6)
+
+
+def test_schedules_match_reference_formulas():
+    # Utils/training_utils.py:9-30 with the GlobalSPFN config (bs 16, steps of 200000 samples)
+    assert training.get_batch_norm_decay(0, 16, 200000) == 0.5
+    assert training.get_batch_norm_decay(12500, 16, 200000) == 0.25
+    assert training.get_batch_norm_decay(10 ** 7, 16, 200000) == pytest.approx(0.01)
+    assert training.get_learning_rate(1e-3, 12499, 16, 200000, 0.7) == 1e-3
+    assert training.get_learning_rate(1e-3, 25000, 16, 200000, 0.7) == pytest.approx(1e-3 * 0.49)
+    m = torch.nn.Sequential()
+    m.add_module("bn1", torch.nn.BatchNorm1d(4))
+    m.add_module("fc", torch.nn.Linear(4, 4))
+    training.update_momentum(m, 0.123)
+    assert m.bn1.momentum == 0.123
+
+
+def test_flat_bucket_views_and_finite_check():
+    model = TinyHeads()
+    b = training.FlatGradBucket(model)
+    assert b.flat.numel() == sum(p.numel() for p in model.parameters())
+    model(torch.randn(2, 8, 3))[2].sum().backward()
+    assert float(b.flat.abs().sum()) > 0            # autograd accumulated INTO the flat buffer
+    assert bool(b.finite())
+    b.flat[3] = float("nan")
+    assert not bool(b.finite())
+    b.zero()
+    assert float(b.flat.abs().sum()) == 0 and all(float(p.grad.abs().sum()) == 0 for p in model.parameters())
