@@ -1,0 +1,50 @@
+"""Make the reference's import paths resolve to this package, so that the reference's
+`training_SPFN.py` / `Utils/training_utils.py` run on the MI355X path unchanged:
+
+    import cpfn_amd.dropin; cpfn_amd.dropin.install()
+    from PointNet2 import pn2_network            # -> cpfn_amd.PointNet2.pn2_network
+    from SPFN import fitter_factory, losses_implementation
+
+Call it before the reference's modules are imported (e.g. first line of training_SPFN.py, or a
+`sitecustomize`).  Nothing is copied: the names are aliased in `sys.modules`.
+"""
+import importlib
+import sys
+
+_ALIASES = {
+    "PointNet2": "cpfn_amd.PointNet2",
+    "PointNet2.pn2_network": "cpfn_amd.PointNet2.pn2_network",
+    "PointNet2.pointnet2_ops": "cpfn_amd.PointNet2.pointnet2_ops",
+    "PointNet2.pointnet2_ops.cuda_ops": "cpfn_amd.cuda_ops",
+    "PointNet2.pointnet2_ops.modules": "cpfn_amd.PointNet2.pointnet2_ops.modules",
+    "PointNet2.pointnet2_ops.modules.geometry_utils": "cpfn_amd.PointNet2.pointnet2_ops.modules.geometry_utils",
+    "PointNet2.pointnet2_ops.modules.pointset_abstraction":
+        "cpfn_amd.PointNet2.pointnet2_ops.modules.pointset_abstraction",
+    "PointNet2.pointnet2_ops.modules.pointset_feature_propagation":
+        "cpfn_amd.PointNet2.pointnet2_ops.modules.pointset_feature_propagation",
+    "SPFN": "cpfn_amd.SPFN",
+    "SPFN.fitter_factory": "cpfn_amd.SPFN.fitter_factory",
+    "SPFN.losses_implementation": "cpfn_amd.SPFN.losses_implementation",
+    "SPFN.plane_fitter": "cpfn_amd.SPFN.plane_fitter",
+    "SPFN.sphere_fitter": "cpfn_amd.SPFN.sphere_fitter",
+    "SPFN.cylinder_fitter": "cpfn_amd.SPFN.cylinder_fitter",
+    "SPFN.cone_fitter": "cpfn_amd.SPFN.cone_fitter",
+    "SPFN.geometry_utils": "cpfn_amd.SPFN.geometry_utils",
+    "SPFN.differentiable_tls": "cpfn_amd.SPFN.differentiable_tls",
+}
+
+
+def install(compute_dtype=None):
+    """Alias the reference's module names.  `compute_dtype=torch.bfloat16` additionally makes
+    every PointNet2 built afterwards use the fused bf16 MFMA stacks by default."""
+    for ref_name, ours in _ALIASES.items():
+        sys.modules[ref_name] = importlib.import_module(ours)
+    if compute_dtype is not None:
+        from .PointNet2 import pn2_network
+        orig = pn2_network.PointNet2.__init__
+
+        def patched(self, *a, **k):
+            orig(self, *a, **k)
+            self.set_compute_dtype(compute_dtype)
+        pn2_network.PointNet2.__init__ = patched
+    return sorted(_ALIASES)
