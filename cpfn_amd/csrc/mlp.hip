@@ -36,6 +36,127 @@ constexpr int G_LDW = G_KC + 8;
 
 // Y[P,N] (bf16 or fp32) = A[P,K] (bf16, optional row gather) · W[N,K]ᵀ (bf16) (+ bias)
 // stats_partial[gridDim.x][2][N]: per-workgroup Σy, Σy² over its valid rows (fp32 accumulators).
+//
+// Two kernels share the MFMA tile shape (128 points x BN channels per workgroup, 32 points per wave):
+//  * mlp_gemm_stream_kernel<BN,KS,STATS>: K = 32·KS in {64,128}, bf16 output, N % BN == 0.  These are
+//    the layers that carry the bytes (P >= 131072 rows).  HBM-bound streaming structure: W panel
+//    loaded into LDS once per workgroup; A fragments of tile t+1 are requested BEFORE the MFMAs of
+//    tile t (two register buffers, straight-line loop body so the compiler emits counted
+//    s_waitcnt vmcnt(N) instead of vmcnt(0)); the output tile leaves through a wave-private LDS patch
+//    as 16-byte row-contiguous stores (4 rows x 256 B per wave instruction).
+//  * mlp_gemm_kernel<BN,STATS>: any K % 32 == 0 (chunked through LDS), optional row gather, bias,
+//    fp32 / ragged-N output: the small-P layers (sa3, sfp1, sfp2), K > 128, and the fc2 heads.
+constexpr int G_LDO = 128 + 8;  // output staging row stride (elements): 272 B
+
+template <int KS>
+__device__ __forceinline__ void stream_load_a(bf16x8 (&af)[2][KS], const unsigned short *__restrict__ A, int lda,
+                                              int P, int row0, int wave, int lr, int lq) {
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    int p = row0 + wave * 32 + tt * 16 + lr;
+    p = p < P ? p : P - 1;
+    const unsigned short *src = A + (size_t)p * lda + 8 * lq;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[tt][ks] = *(const bf16x8 *)(src + ks * 32);
+  }
+}
+
+template <int BN, int KS, bool STATS>
+__device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const unsigned short *s_w,
+                                            unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
+                                            int row0, int n0, int wave, int lane, f32x4 (&s1)[BN / 16],
+                                            f32x4 (&s2)[BN / 16]) {
+  constexpr int NT = BN / 16;
+  const int lr = lane & 15, lq = lane >> 4;
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bf16x8 wf = *(const bf16x8 *)&s_w[(nt * 16 + lr) * G_LDW + ks * 32 + 8 * lq];
+      acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[nt][0], 0, 0, 0);
+      acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[nt][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const bool valid = row0 + wave * 32 + tt * 16 + lr < P;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 v = acc[nt][tt];
+      if (STATS && valid) { s1[nt] += v; s2[nt] += v * v; }
+      bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      *(bf16x4 *)&s_o[(tt * 16 + lr) * G_LDO + nt * 16 + 4 * lq] = o;
+    }
+  }
+  constexpr int CPR = BN / 8;  // 16-byte chunks per row
+#pragma unroll
+  for (int i = 0; i < 32 * CPR / 64; ++i) {
+    const int e = i * 64 + lane;
+    const int r = e / CPR, c = e - r * CPR;
+    const int p = row0 + wave * 32 + r;
+    const uint4 vv = *(const uint4 *)&s_o[r * G_LDO + c * 8];
+    if (p < P) *(uint4 *)(Y + (size_t)p * ldy + n0 + c * 8) = vv;
+  }
+}
+
+template <int BN, int KS, bool STATS>
+__global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
+    const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int P, int N,
+    unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg) {
+  constexpr int NT = BN / 16, K = 32 * KS;
+  __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
+  __shared__ __attribute__((aligned(16))) unsigned short s_o[4][32 * G_LDO];
+  __shared__ float s_red[4][2][BN];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.y * BN;
+  f32x4 s1[NT], s2[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) { s1[i] = (f32x4){0, 0, 0, 0}; s2[i] = (f32x4){0, 0, 0, 0}; }
+  const int ntiles = (P + G_ROWS - 1) / G_ROWS;
+  const int tile0 = blockIdx.x * tiles_per_wg;
+  const int tile_end = min(tile0 + tiles_per_wg, ntiles);
+  if (tile0 < tile_end) {
+    bf16x8 a0[2][KS], a1[2][KS];
+    stream_load_a<KS>(a0, A, lda, P, tile0 * G_ROWS, wave, lr, lq);
+    constexpr int cpr = K / 8;
+    for (int e = t; e < BN * cpr; e += G_THREADS) {
+      const int r = e / cpr, c = e - r * cpr;
+      *(uint4 *)&s_w[r * G_LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + c * 8];
+    }
+    __syncthreads();
+    for (int tile = tile0; tile < tile_end; tile += 2) {
+      // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
+      stream_load_a<KS>(a1, A, lda, P, min(tile + 1, ntiles - 1) * G_ROWS, wave, lr, lq);
+      stream_tile<BN, KS, STATS>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, s1, s2);
+      if (tile + 1 >= tile_end) break;
+      stream_load_a<KS>(a0, A, lda, P, min(tile + 2, ntiles - 1) * G_ROWS, wave, lr, lq);
+      stream_tile<BN, KS, STATS>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, s1, s2);
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = s1[nt][r], b = s2[nt][r];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (lr == 0) { s_red[wave][0][nt * 16 + 4 * lq + r] = a; s_red[wave][1][nt * 16 + 4 * lq + r] = b; }
+      }
+    }
+    __syncthreads();
+    for (int e = t; e < 2 * BN; e += G_THREADS) {
+      const int which = e / BN, c = e - which * BN;
+      const float s = s_red[0][which][c] + s_red[1][which][c] + s_red[2][which][c] + s_red[3][which][c];
+      stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c] = s;
+    }
+  }
+}
+
 template <int BN, bool STATS>
 __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const int *__restrict__ gidx,
@@ -405,34 +526,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short 
 }
 
 // pooled: g_z[g,k,c] = (k == arg[g,c]) ? g_pool[g,c]·[z_arg>0] : 0
+// One workgroup per group: the [C]-sized per-group vectors (arg, masked pooled gradient) and the
+// per-channel coefficients are read ONCE per lane (8 channels, 16-byte loads) and reused over the
+// group's Kn rows, so the kernel streams Y -> Gy at one 16-byte load + store per 8 elements.
 __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned short *__restrict__ Gp,
                                                                 const unsigned char *__restrict__ arg,
                                                                 const unsigned short *__restrict__ yarg,
                                                                 const unsigned short *__restrict__ Yr,
                                                                 const float *__restrict__ scale,
                                                                 const float *__restrict__ shift,
-                                                                const float *__restrict__ coef, long long total8,
-                                                                int Kn, int C, unsigned short *__restrict__ Gy) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total8) return;
-  const int c0 = (int)((e * 8) % C);
-  const long long row = (e * 8) / C;
-  const long long g = row / Kn;
-  const int k = (int)(row - g * Kn);
-  const uint4 ry = *(const uint4 *)(Yr + e * 8);
-  const unsigned short *y = (const unsigned short *)&ry;
-  unsigned short o[8];
+                                                                const float *__restrict__ coef, int Kn, int C,
+                                                                unsigned short *__restrict__ Gy) {
+  const long long g = blockIdx.x;
+  const int t = threadIdx.x;
+  const int chunks = C / 8;
+  for (int cb = 0; cb < chunks; cb += 256) {
+    const int nch = min(256, chunks - cb);       // power of two
+    const int rsub = 256 / nch;
+    const int ch = t % nch, rs = t / nch;
+    const int c0 = (cb + ch) * 8;
+    float gz[8], c0v[8], c1v[8], c2v[8];
+    int ak[8];
+    {
+      const uint4 rgp = *(const uint4 *)(Gp + g * C + c0);
+      const uint4 rya = *(const uint4 *)(yarg + g * C + c0);
+      const uint2 rar = *(const uint2 *)(arg + g * C + c0);
+      const unsigned short *gp = (const unsigned short *)&rgp, *ya = (const unsigned short *)&rya;
+      const unsigned char *ar = (const unsigned char *)&rar;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = c0 + j;
-    float gz = 0.f;
-    if (arg[g * C + c] == (unsigned char)k) {
-      const float za = fmaf(scale[c], bf2f(yarg[g * C + c]), shift[c]);
-      gz = za > 0.f ? bf2f(Gp[g * C + c]) : 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const float za = fmaf(scale[c0 + j], bf2f(ya[j]), shift[c0 + j]);
+        gz[j] = za > 0.f ? bf2f(gp[j]) : 0.f;
+        ak[j] = ar[j];
+        c0v[j] = coef[c0 + j]; c1v[j] = coef[C + c0 + j]; c2v[j] = coef[2 * C + c0 + j];
+      }
     }
-    o[j] = f2bf(fmaf(coef[c], gz, fmaf(coef[C + c], bf2f(y[j]), coef[2 * C + c])));
+    for (int k = rs; k < Kn; k += rsub) {
+      const size_t off = ((size_t)g * Kn + k) * C + c0;
+      const uint4 ry = *(const uint4 *)(Yr + off);
+      const unsigned short *y = (const unsigned short *)&ry;
+      unsigned short o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        o[j] = f2bf(fmaf(c0v[j], ak[j] == k ? gz[j] : 0.f, fmaf(c1v[j], bf2f(y[j]), c2v[j])));
+      *(uint4 *)(Gy + off) = *(const uint4 *)o;
+    }
   }
-  *(uint4 *)(Gy + e * 8) = *(const uint4 *)o;
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -648,6 +787,22 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
   const int tpw = (int)((tiles + gx - 1) / gx);
   const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
+  const bool stream_ok = (K == 64 || K == 128) && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0;
+  if (stream_ok) {
+    unsigned short *y = (unsigned short *)Y;
+#define CPFN_STREAM(BN_, KS_)                                                                                        \
+  do {                                                                                                               \
+    dim3 grid(gx, N / BN_);                                                                                          \
+    if (stats_partial)                                                                                               \
+      mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, (int)P, N, y, ldy, stats_partial, tpw); \
+    else                                                                                                             \
+      mlp_gemm_stream_kernel<BN_, KS_, false><<<grid, G_THREADS, 0, st>>>(a, lda, w, (int)P, N, y, ldy, nullptr, tpw);      \
+  } while (0)
+    if (N % 128 == 0) { if (K == 64) CPFN_STREAM(128, 2); else CPFN_STREAM(128, 4); }
+    else              { if (K == 64) CPFN_STREAM(64, 2);  else CPFN_STREAM(64, 4); }
+#undef CPFN_STREAM
+    return cpfn_launch_status();
+  }
   if (N % 128 == 0) {
     dim3 grid(gx, N / 128);
     if (stats_partial)
@@ -738,17 +893,17 @@ extern "C" int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, 
                                       int C, void *Gy, void *stream) {
   if (G <= 0 || Kn <= 0 || C <= 0 || (C & 7) || !Gp || !arg || !yarg || !Y || !scale || !shift || !coef || !Gy)
     return CPFN_EINVAL;
-  const long long total8 = (long long)G * Kn * C / 8;
-  bn_pool_bwd_apply_kernel<<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
+  if (!pow2(C / 8)) return CPFN_EINVAL;
+  bn_pool_bwd_apply_kernel<<<G, 256, 0, (hipStream_t)stream>>>(
       (const unsigned short *)Gp, arg, (const unsigned short *)yarg, (const unsigned short *)Y, scale, shift, coef,
-      total8, Kn, C, (unsigned short *)Gy);
+      Kn, C, (unsigned short *)Gy);
   return cpfn_launch_status();
 }
 
 extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
   const long long tiles = (long long)((N + 63) / 64) * ((K + 63) / 64);
-  long long s = (512 + tiles - 1) / tiles;            // ~512 workgroups
-  if (s > 128) s = 128;                               // bound the partial buffer / reduce depth
+  long long s = (1024 + tiles - 1) / tiles;           // ~1024 workgroups (4 per CU): the kernel is a stream
+  if (s > 256) s = 256;                               // bound the partial buffer / reduce depth
   const long long max_s = (P + 1023) / 1024;          // at least 1024 rows per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
