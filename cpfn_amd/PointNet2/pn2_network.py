@@ -68,6 +68,10 @@ class PointNet2(torch.nn.Module):
         feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd)           # fc1 + bn1 + relu (ref :60-62)
         feat = F.dropout(feat, p=self.dropout_p, training=True)                            # always on (ref :63)
         results = [r.reshape(B, N, -1) for r in mlp.heads(feat, self.fc2, cd)]
+        self.heads_packed = None
+        if cd == torch.bfloat16 and feat.is_cuda:
+            from .. import fused_mlp
+            self.heads_packed = fused_mlp.linear_heads.last_packed.reshape(B, N, -1)       # [B,N,3+4+K] fp32
         results.append(l3_out)
         results.append(feat.float().reshape(B, N, -1).transpose(1, 2))
         return results

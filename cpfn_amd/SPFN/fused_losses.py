@@ -1,0 +1,176 @@
+"""The loss section of the SPFN training step on the fused HIP kernels of csrc/losses.hip.
+
+Same mathematics and return values as `losses_implementation.compute_all_losses`
+(reference: SPFN/losses_implementation.py:675-720 with the normalise / soft-max of
+Utils/training_utils.py:141-142 folded in), organised as four launches instead of ~500 ops:
+
+  heads Y[B,N,7+K] --HeadPost--> X̂, W (soft-max), normal loss[B], type loss[B]
+  W, I_gt          --SegStats--> S[B,K+2,K]  -> Hungarian cost (host SciPy, ONE device->host copy)
+                                             -> relaxed IoU of the matched pairs ([B,K] algebra)
+  P, X̂, W          --fitters---> 22 parameters / instance           (moments + algebra + cone pass)
+  params, match    --Residue---> residue loss[B,K], axis loss[B,K]
+"""
+import ctypes
+
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from .. import lib as _l
+from ..ops import _ptr, _stream
+from . import fitters_common as _fc
+from .losses_implementation import get_mask_gt, reduce_mean_masked_instance
+
+PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
+                ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
+                ("cone_apex", 3), ("cone_axis", 3), ("cone_half_angle", 1))
+
+
+class HeadPost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, X_gt, I_gt, T_gt):
+        B, N, C = Y.shape
+        K = C - 7
+        Yc = Y.detach().contiguous().float()
+        Xg, Ig, Tg = X_gt.contiguous().float(), I_gt.contiguous(), T_gt.contiguous()
+        dev = Y.device
+        Xn = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        W = torch.empty(B, N, K, dtype=torch.float32, device=dev)
+        stats = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        h = _l.lib()
+        ws = torch.empty(B * h.cpfn_head_post_chunks(N) * 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _l.check(h.cpfn_head_post_fwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), B, N, K, _ptr(Xn), _ptr(W), _ptr(ws),
+                                          _ptr(stats), _stream()), "cpfn_head_post_fwd")
+        ctx.save_for_backward(Yc, Xg, Ig, Tg, W, stats)
+        return Xn, W, stats[:, 0], stats[:, 1]
+
+    @staticmethod
+    def backward(ctx, gXn, gW, gnl, gtl):
+        Yc, Xg, Ig, Tg, W, stats = ctx.saved_tensors
+        B, N, C = Yc.shape
+        dev = Yc.device
+        gl = torch.stack([gnl if gnl is not None else torch.zeros(B, device=dev),
+                          gtl if gtl is not None else torch.zeros(B, device=dev)], dim=1).contiguous().float()
+        gXn = None if gXn is None else gXn.contiguous().float()
+        gW = None if gW is None else gW.contiguous().float()
+        gY = torch.empty_like(Yc)
+        with torch.cuda.device(dev):
+            _l.check(_l.lib().cpfn_head_post_bwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), _ptr(W), _ptr(stats), _ptr(gXn),
+                                                 _ptr(gW), _ptr(gl), B, N, C - 7, _ptr(gY), _stream()), "cpfn_head_post_bwd")
+        return gY, None, None, None
+
+
+class SegStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, I_gt):
+        B, N, K = W.shape
+        Wc, Ig = W.detach().contiguous().float(), I_gt.contiguous()
+        h = _l.lib()
+        chunks = h.cpfn_seg_stats_chunks(B, N)
+        ws = torch.empty(B * chunks * (K + 2) * K, dtype=torch.float32, device=W.device)
+        S = torch.empty(B, K + 2, K, dtype=torch.float32, device=W.device)
+        with torch.cuda.device(W.device):
+            _l.check(h.cpfn_seg_stats_fwd(_ptr(Wc), _ptr(Ig), B, N, K, _ptr(ws), _ptr(S), _stream()), "cpfn_seg_stats_fwd")
+        ctx.save_for_backward(Ig)
+        ctx.shape = (B, N, K)
+        return S
+
+    @staticmethod
+    def backward(ctx, gS):
+        (Ig,) = ctx.saved_tensors
+        B, N, K = ctx.shape
+        g = gS.contiguous().float()
+        dW = torch.empty(B, N, K, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _l.check(_l.lib().cpfn_seg_stats_bwd(_ptr(g), _ptr(Ig), B, N, K, _ptr(dW), _stream()), "cpfn_seg_stats_bwd")
+        return dW, None
+
+
+class ResidueLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, params, match, T_gt, pts, gt_axes, type_ids):
+        B, K, _ = params.shape
+        NP = pts.shape[2]
+        pc = params.detach().contiguous().float()
+        mc, tc = match.contiguous(), T_gt.contiguous()
+        out = torch.empty(B, K, 2, dtype=torch.float32, device=pc.device)
+        dout = torch.empty(B, K, 10, dtype=torch.float32, device=pc.device)
+        ids = (ctypes.c_int * 4)(*type_ids)
+        with torch.cuda.device(pc.device):
+            _l.check(_l.lib().cpfn_residue_fwd(_ptr(pc), _ptr(mc), _ptr(tc), _ptr(pts.contiguous().float()),
+                                               _ptr(gt_axes.contiguous().float()), B, K, NP, ids, _ptr(out), _ptr(dout),
+                                               _stream()), "cpfn_residue_fwd")
+        ctx.save_for_backward(dout, mc, tc)
+        ctx.type_ids = tuple(type_ids)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dout, mc, tc = ctx.saved_tensors
+        B, K, _ = dout.shape
+        gp = torch.zeros(B, K, 22, dtype=torch.float32, device=dout.device)
+        ids = (ctypes.c_int * 4)(*ctx.type_ids)
+        with torch.cuda.device(dout.device):
+            _l.check(_l.lib().cpfn_residue_bwd(_ptr(g.contiguous().float()), _ptr(dout), _ptr(mc), _ptr(tc), B, K, ids,
+                                               _ptr(gp), _stream()), "cpfn_residue_bwd")
+        return gp, None, None, None, None, None
+
+
+def hungarian_from_stats(S, I_gt):
+    """Relaxed-IoU cost of every (GT label, prediction) pair from the segmented sums, SciPy
+    assignment on the host (reference lines 11-30) — one device->host copy for the whole batch."""
+    B, K2, K = S.shape
+    D, col, cnt = S[:, :K], S[:, K], S[:, K + 1]
+    den = cnt.unsqueeze(2) + col.unsqueeze(1) - D
+    cost = D / den.clamp(min=1e-10)
+    n_gt = I_gt.max(dim=1)[0] + 1
+    pack = torch.cat([cost.reshape(B, -1), n_gt.unsqueeze(1).to(cost.dtype)], dim=1).cpu().numpy()
+    match = torch.zeros(B, K, dtype=torch.long)
+    for b in range(B):
+        n = int(pack[b, -1])
+        _, c = linear_sum_assignment(-pack[b, :-1].reshape(K, K)[:n])
+        match[b, :n] = torch.from_numpy(c)
+    return match.to(S.device)
+
+
+def fused_losses(P, Y, batch, multipliers, classes):
+    """P [B,N,3]; Y [B,N,7+K] = packed fp32 heads (normal | type logits | membership logits).
+    Returns the reference's (total, normal, type, miou, residue, parameter) scalars."""
+    m = multipliers
+    B, N, _ = P.shape
+    K = Y.shape[2] - 7
+    I_gt, T_gt = batch["I_gt"], batch["T_gt"]
+    Xn, W, nl, tl = HeadPost.apply(Y, batch["X_gt"], I_gt, T_gt)
+    S = SegStats.apply(W, I_gt)
+    match = hungarian_from_stats(S.detach(), I_gt)
+    mask_gt = get_mask_gt(I_gt, K)
+    zero = torch.zeros((), device=P.device)
+    # relaxed IoU of the matched pairs (reference lines 77-90)
+    if m["miou"] > 0:
+        D, col, cnt = S[:, :K], S[:, K], S[:, K + 1]
+        dot = torch.gather(D, 2, match.unsqueeze(2)).squeeze(2)
+        den = cnt + torch.gather(col, 1, match) - dot
+        total_miou = reduce_mean_masked_instance(1.0 - dot / (den + 1e-10), mask_gt).mean()
+    else:
+        total_miou = zero
+    if m["residue"] > 0 or m["parameter"] > 0:
+        Mo = _fc.moments(P, W, Xn)
+        (plane_n, plane_c, sph_c, sph_r2, cyl_n, cyl_c, cyl_r2, apex, axis) = _fc.algebra(Mo)
+        apex_, axis_, half = _fc.cone_from_moments(Mo, P, W, apex=apex, axis=axis)
+        params = torch.cat([plane_n, plane_c.unsqueeze(-1), sph_c, sph_r2.unsqueeze(-1), cyl_n, cyl_c,
+                            cyl_r2.unsqueeze(-1), apex_, axis_, half.unsqueeze(-1)], dim=-1).float()
+        gt_axes = torch.stack([batch["plane_n_gt"], batch["cylinder_axis_gt"], batch["cone_axis_gt"]], 0)
+        ids = [classes.index(c) for c in ("plane", "sphere", "cylinder", "cone")]
+        rp = ResidueLoss.apply(params, match, T_gt, batch["points_per_instance"], gt_axes, ids)
+        total_res = reduce_mean_masked_instance(rp[..., 0], mask_gt).mean() if m["residue"] > 0 else zero
+        total_par = reduce_mean_masked_instance(rp[..., 1], mask_gt).mean() if m["parameter"] > 0 else zero
+    else:
+        total_res, total_par = zero, zero
+    total_normal = nl.mean() if m["normal"] > 0 else zero
+    total_type = tl.mean() if m["type"] > 0 else zero
+    total = 0
+    for key, val in (("normal", total_normal), ("type", total_type), ("miou", total_miou), ("residue", total_res),
+                     ("parameter", total_par)):
+        if m[key] > 0:
+            total = total + m[key] * val
+    return total * m["total"], total_normal, total_type, total_miou, total_res, total_par

@@ -28,6 +28,7 @@ SOURCES = {
     "fitters.hip": [],
     "fit_algebra.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
+    "losses.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]

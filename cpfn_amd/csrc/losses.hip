@@ -1,0 +1,427 @@
+// Fused loss-side kernels of the SPFN training step for gfx950 (the callers
+// on the far side of the fitters).  The reference evaluates these as ~500 small framework ops per
+// step (SPFN/losses_implementation.py); each group below is one streaming pass.
+//
+//  head_post   : heads [P,3+4+K] -> unit normals, soft-max memberships, and the per-cloud normal and
+//                type losses (Utils/training_utils.py:141-142, losses_implementation.py:152-159, 195-210)
+//  seg_stats   : label-segmented sums of the memberships, the one quantity behind both the Hungarian
+//                cost matrix and the relaxed-IoU loss (losses_implementation.py:19-24, 77-90)
+//  residue     : mean residue of the GT points of every instance against the matched prediction of the
+//                instance's GT type, plus the axis-agreement loss (losses_implementation.py:351-387,
+//                480-497; SPFN/*_fitter.compute_residue_single)
+//
+// All reductions use per-block partials summed in a fixed order (no float atomics in forward passes).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = 32;      // instances per cloud supported by the fused kernels (28 global / 21 local)
+constexpr int LP_THREADS = 256;
+
+// ------------------------------------------------------------------------------------ head_post
+// Y[P, 7+K] fp32: cols 0-2 normal, 3-6 type logits, 7.. membership logits.
+// partial[b][chunk][3] = Σ (1-|x̂·x_gt|), Σ CE·[I!=-1], Σ [I!=-1]
+__global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
+    const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
+    const long long *__restrict__ Tgt, int N, int K, float *__restrict__ Xn, float *__restrict__ Wsm,
+    float *__restrict__ partial) {
+  __shared__ float s_red[LP_THREADS / 64][3];
+  const int b = blockIdx.y, t = threadIdx.x, C = 7 + K;
+  const int n = blockIdx.x * LP_THREADS + t;
+  float l_n = 0.f, l_t = 0.f, l_c = 0.f;
+  if (n < N) {
+    const size_t p = (size_t)b * N + n;
+    const float *y = Y + p * C;
+    const float x0 = y[0], x1 = y[1], x2 = y[2];
+    const float inv = 1.0f / fmaxf(sqrtf(x0 * x0 + x1 * x1 + x2 * x2), 1e-12f);   // F.normalize(eps=1e-12)
+    const float u0 = x0 * inv, u1 = x1 * inv, u2 = x2 * inv;
+    Xn[p * 3] = u0; Xn[p * 3 + 1] = u1; Xn[p * 3 + 2] = u2;
+    const float *g = Xgt + p * 3;
+    l_n = 1.0f - fabsf(u0 * g[0] + u1 * g[1] + u2 * g[2]);
+    // soft-max over the K membership logits
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, y[7 + k]);
+    float e[MAXK], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) { e[k] = k < K ? __expf(y[7 + (k < K ? k : 0)] - m) : 0.f; s += e[k]; }
+    const float is = 1.0f / s;
+    float *w = Wsm + p * K;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < K) w[k] = e[k] * is;
+    // per-point type cross-entropy against the type of the point's GT instance
+    const long long lab = Igt[p];
+    if (lab != -1) {
+      const long long tgt = Tgt[(size_t)b * K + (lab < 0 ? 0 : lab)];
+      const float t0 = y[3], t1 = y[4], t2 = y[5], t3 = y[6];
+      const float tm = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+      const float lse = tm + logf(expf(t0 - tm) + expf(t1 - tm) + expf(t2 - tm) + expf(t3 - tm));
+      l_t = lse - y[3 + tgt];
+      l_c = 1.f;
+    }
+  }
+  // block reduce (wave shuffles, then 4 waves)
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    l_n += __shfl_xor(l_n, msk, 64); l_t += __shfl_xor(l_t, msk, 64); l_c += __shfl_xor(l_c, msk, 64);
+  }
+  if ((t & 63) == 0) { s_red[t >> 6][0] = l_n; s_red[t >> 6][1] = l_t; s_red[t >> 6][2] = l_c; }
+  __syncthreads();
+  if (t < 3) {
+    float s = 0.f;
+    for (int w = 0; w < LP_THREADS / 64; ++w) s += s_red[w][t];
+    partial[((size_t)b * gridDim.x + blockIdx.x) * 3 + t] = s;
+  }
+}
+
+// out[b] = (normal_loss, type_loss, count): fixed-order sum over chunks
+__global__ void head_post_reduce_kernel(const float *__restrict__ partial, int chunks, int N, int B,
+                                        float *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double a = 0, c = 0, d = 0;
+  for (int i = 0; i < chunks; ++i) {
+    a += partial[((size_t)b * chunks + i) * 3];
+    c += partial[((size_t)b * chunks + i) * 3 + 1];
+    d += partial[((size_t)b * chunks + i) * 3 + 2];
+  }
+  out[b * 3] = (float)(a / N);
+  out[b * 3 + 1] = (float)(c / d);   // 0/0 -> NaN for a cloud with no labelled point, like the reference
+  out[b * 3 + 2] = (float)d;
+}
+
+// gY[P,7+K] from: gXn[P,3] (may be null), gW[P,K] (may be null), gloss[B,2] = dL/d(normal_loss, type_loss)
+__global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
+    const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
+    const long long *__restrict__ Tgt, const float *__restrict__ Wsm, const float *__restrict__ stats,
+    const float *__restrict__ gXn, const float *__restrict__ gW, const float *__restrict__ gloss, int N, int K,
+    float *__restrict__ gY) {
+  const int b = blockIdx.y, C = 7 + K;
+  const int n = blockIdx.x * LP_THREADS + threadIdx.x;
+  if (n >= N) return;
+  const size_t p = (size_t)b * N + n;
+  const float *y = Y + p * C;
+  float *o = gY + p * C;
+  // normals
+  const float x0 = y[0], x1 = y[1], x2 = y[2];
+  const float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+  const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+  const float u0 = x0 * inv, u1 = x1 * inv, u2 = x2 * inv;
+  const float *g = Xgt + p * 3;
+  const float d = u0 * g[0] + u1 * g[1] + u2 * g[2];
+  const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  const float cn = -gloss[b * 2] * sg / (float)N;
+  float h0 = cn * g[0], h1 = cn * g[1], h2 = cn * g[2];
+  if (gXn) { h0 += gXn[p * 3]; h1 += gXn[p * 3 + 1]; h2 += gXn[p * 3 + 2]; }
+  if (nrm >= 1e-12f) {
+    const float pr = u0 * h0 + u1 * h1 + u2 * h2;
+    o[0] = (h0 - u0 * pr) * inv; o[1] = (h1 - u1 * pr) * inv; o[2] = (h2 - u2 * pr) * inv;
+  } else {
+    o[0] = h0 * inv; o[1] = h1 * inv; o[2] = h2 * inv;
+  }
+  // type logits
+  const long long lab = Igt[p];
+  if (lab != -1) {
+    const long long tgt = Tgt[(size_t)b * K + (lab < 0 ? 0 : lab)];
+    const float t0 = y[3], t1 = y[4], t2 = y[5], t3 = y[6];
+    const float tm = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+    const float e0 = expf(t0 - tm), e1 = expf(t1 - tm), e2 = expf(t2 - tm), e3 = expf(t3 - tm);
+    const float is = 1.0f / (e0 + e1 + e2 + e3);
+    const float c = gloss[b * 2 + 1] / stats[b * 3 + 2];
+    o[3] = c * (e0 * is - (tgt == 0 ? 1.f : 0.f));
+    o[4] = c * (e1 * is - (tgt == 1 ? 1.f : 0.f));
+    o[5] = c * (e2 * is - (tgt == 2 ? 1.f : 0.f));
+    o[6] = c * (e3 * is - (tgt == 3 ? 1.f : 0.f));
+  } else {
+    o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f;
+  }
+  // memberships: soft-max adjoint
+  if (gW) {
+    const float *s = Wsm + p * K, *gw = gW + p * K;
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot = fmaf(gw[k], s[k], dot);
+    for (int k = 0; k < K; ++k) o[7 + k] = s[k] * (gw[k] - dot);
+  } else {
+    for (int k = 0; k < K; ++k) o[7 + k] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------ seg_stats
+// S[b][K+2][K]: rows l<K: Σ_{n: I=l} W[n,:];  row K: Σ_n W[n,:];  row K+1: #points with label l (as float).
+// thread = (column kk, point subset); 32 label accumulators per thread, selected by compare (no atomics).
+constexpr int SS_TILE = 64, SS_SUB = LP_THREADS / MAXK;   // 8 subsets
+__global__ __launch_bounds__(LP_THREADS) void seg_stats_fwd_kernel(const float *__restrict__ W,
+                                                                   const long long *__restrict__ Igt, int N, int K,
+                                                                   int pts_per_block, float *__restrict__ partial) {
+  __shared__ float s_w[SS_TILE][MAXK];
+  __shared__ int s_lab[SS_TILE];
+  __shared__ float s_red[SS_SUB][MAXK + 1][MAXK];
+  __shared__ float s_cnt[MAXK];
+  const int b = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  const int kk = t % MAXK, sub = t / MAXK;
+  const int n0 = chunk * pts_per_block, n1 = min(N, n0 + pts_per_block);
+  float acc[MAXK], all = 0.f, cnt = 0.f;
+#pragma unroll
+  for (int l = 0; l < MAXK; ++l) acc[l] = 0.f;
+  for (int base = n0; base < n1; base += SS_TILE) {
+    __syncthreads();
+    for (int e = t; e < SS_TILE * MAXK; e += LP_THREADS) {
+      const int i = e / MAXK, k = e % MAXK;
+      s_w[i][k] = (base + i < n1 && k < K) ? W[((size_t)b * N + base + i) * K + k] : 0.f;
+    }
+    if (t < SS_TILE) s_lab[t] = (base + t < n1) ? (int)Igt[(size_t)b * N + base + t] : -2;
+    __syncthreads();
+    for (int i = sub; i < SS_TILE; i += SS_SUB) {
+      const int lab = s_lab[i];
+      const float w = s_w[i][kk];
+      all += w;
+#pragma unroll
+      for (int l = 0; l < MAXK; ++l) acc[l] += (lab == l) ? w : 0.f;
+    }
+    if (t < MAXK) {
+      for (int i = 0; i < SS_TILE; ++i) cnt += (s_lab[i] == t) ? 1.f : 0.f;
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < MAXK; ++l) s_red[sub][l][kk] = acc[l];
+  s_red[sub][MAXK][kk] = all;
+  if (t < MAXK) s_cnt[t] = cnt;
+  __syncthreads();
+  float *o = partial + ((size_t)b * gridDim.x + chunk) * (K + 2) * K;
+  for (int e = t; e < (K + 1) * K; e += LP_THREADS) {
+    const int l = e / K, k = e % K;
+    const int row = l < K ? l : MAXK;
+    float s = 0.f;
+    for (int q = 0; q < SS_SUB; ++q) s += s_red[q][row][k];
+    o[l * K + k] = s;
+  }
+  if (t < K) o[(K + 1) * K + t] = s_cnt[t];
+}
+
+__global__ void chunk_sum_f32_kernel(const float *__restrict__ partial, int chunks, int per_b, long long total,
+                                     float *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / per_b, r = e % per_b;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[((size_t)b * chunks + c) * per_b + r];
+  out[e] = s;
+}
+
+// dW[b,n,k] = gS[b, I[b,n], k] (labelled points) + gS[b, K, k]
+__global__ __launch_bounds__(LP_THREADS) void seg_stats_bwd_kernel(const float *__restrict__ gS,
+                                                                   const long long *__restrict__ Igt, int N, int K,
+                                                                   float *__restrict__ dW) {
+  __shared__ float s_g[(MAXK + 2) * MAXK];
+  const int b = blockIdx.y, t = threadIdx.x;
+  for (int e = t; e < (K + 1) * K; e += LP_THREADS) s_g[e] = gS[(size_t)b * (K + 2) * K + e];
+  __syncthreads();
+  const long long e0 = (long long)blockIdx.x * LP_THREADS + t;
+  if (e0 >= (long long)N * K) return;
+  const int n = (int)(e0 / K), k = (int)(e0 % K);
+  const long long lab = Igt[(size_t)b * N + n];
+  float g = s_g[K * K + k];
+  if (lab >= 0 && lab < K) g += s_g[lab * K + k];
+  dW[(size_t)b * N * K + e0] = g;
+}
+
+// ------------------------------------------------------------------------------------ residue
+// params[b][k][22]: plane n(0-2) c(3) | sphere c(4-6) r2(7) | cylinder a(8-10) c(11-13) r2(14) |
+// cone apex(15-17) axis(18-20) half(21).   type ids: tid[4] = id of (plane, sphere, cylinder, cone).
+struct D7 {   // value + 7 tangents (one per parameter of the selected primitive type)
+  float v, d[7];
+};
+__device__ inline D7 mk(float v) { D7 r; r.v = v; for (int i = 0; i < 7; ++i) r.d[i] = 0.f; return r; }
+__device__ inline D7 var(float v, int i) { D7 r = mk(v); r.d[i] = 1.f; return r; }
+__device__ inline D7 operator+(D7 a, D7 b) { D7 r; r.v = a.v + b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ inline D7 operator-(D7 a, D7 b) { D7 r; r.v = a.v - b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ inline D7 operator*(D7 a, D7 b) { D7 r; r.v = a.v * b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ inline D7 scale(D7 a, float s) { D7 r; r.v = a.v * s; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ inline D7 chain(D7 a, float f, float df) { D7 r; r.v = f; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * df; return r; }
+__device__ inline D7 sqrt_safe(D7 a) {   // sqrt(|x| + 1e-10)
+  const float s = sqrtf(fabsf(a.v) + 1e-10f);
+  const float sg = a.v > 0.f ? 1.f : (a.v < 0.f ? -1.f : 0.f);
+  return chain(a, s, sg * 0.5f / s);
+}
+
+__device__ inline D7 residue_of(int kind, const float *q, float px, float py, float pz) {
+  if (kind == 0) {          // plane: (p·n − c)²            params n(0-2), c(3)
+    D7 e = scale(var(q[0], 0), px) + scale(var(q[1], 1), py) + scale(var(q[2], 2), pz) - var(q[3], 3);
+    return e * e;
+  } else if (kind == 1) {   // sphere: (‖p − c‖ − r)²       params c(0-2), r2(3)
+    D7 dx = mk(px) - var(q[0], 0), dy = mk(py) - var(q[1], 1), dz = mk(pz) - var(q[2], 2);
+    D7 e = sqrt_safe(dx * dx + dy * dy + dz * dz) - sqrt_safe(var(q[3], 3));
+    return e * e;
+  } else if (kind == 2) {   // cylinder: (dist to axis − r)² params a(0-2), c(3-5), r2(6)
+    D7 dx = mk(px) - var(q[3], 3), dy = mk(py) - var(q[4], 4), dz = mk(pz) - var(q[5], 5);
+    D7 al = dx * var(q[0], 0) + dy * var(q[1], 1) + dz * var(q[2], 2);
+    D7 e = sqrt_safe(dx * dx + dy * dy + dz * dz - al * al) - sqrt_safe(var(q[6], 6));
+    return e * e;
+  } else {                  // cone                          params apex(0-2), axis(3-5), half(6)
+    D7 vx = mk(px) - var(q[0], 0), vy = mk(py) - var(q[1], 1), vz = mk(pz) - var(q[2], 2);
+    D7 n2 = vx * vx + vy * vy + vz * vz;
+    const float nrm = sqrtf(n2.v);
+    D7 inv;                                    // 1 / max(‖v‖, 1e-12)  (F.normalize)
+    if (nrm >= 1e-12f) inv = chain(n2, 1.f / nrm, -0.5f / (nrm * n2.v));
+    else inv = mk(1e12f);
+    D7 c = (vx * var(q[3], 3) + vy * var(q[4], 4) + vz * var(q[5], 5)) * inv;
+    const float lim = 1.0f - 1e-6f;
+    D7 alpha;                                  // acos_safe: clamp to [-1+1e-6, 1-1e-6] (zero slope when clamped)
+    if (c.v > lim) alpha = mk(acosf(lim));
+    else if (c.v < -lim) alpha = mk(acosf(-lim));
+    else alpha = chain(c, acosf(c.v), -rsqrtf(1.f - c.v * c.v));
+    D7 diff = alpha - var(q[6], 6);
+    const float sg = diff.v > 0.f ? 1.f : (diff.v < 0.f ? -1.f : 0.f);
+    D7 ad = chain(diff, fabsf(diff.v), sg);
+    D7 sn;                                     // sin(min(|·|, π/2))
+    if (ad.v > 1.57079632679f) sn = mk(1.f);
+    else sn = chain(ad, sinf(ad.v), cosf(ad.v));
+    return sn * sn * n2;
+  }
+}
+
+// one workgroup per GT instance (b,k).  out[b][k][0] = mean residue, [1] = axis loss;
+// dout[b][k][0..6] = d residue / d(params of the type), [7..9] = d axis-loss / d(axis or normal)
+__global__ __launch_bounds__(128) void residue_fwd_kernel(const float *__restrict__ params,
+                                                          const long long *__restrict__ match,
+                                                          const long long *__restrict__ Tgt,
+                                                          const float *__restrict__ pts, const float *__restrict__ gt_axes,
+                                                          int K, int NP, int tid_plane, int tid_sphere, int tid_cyl,
+                                                          int tid_cone, float *__restrict__ out, float *__restrict__ dout) {
+  __shared__ float s_red[2][8];
+  const int bk = blockIdx.x, b = bk / K, t = threadIdx.x;
+  const long long m = match[bk], ty = Tgt[bk];
+  const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
+  const float *P22 = params + ((size_t)b * K + m) * 22;
+  float q[7] = {0, 0, 0, 0, 0, 0, 0};
+  const int off = kind == 0 ? 0 : (kind == 1 ? 4 : (kind == 2 ? 8 : 15));
+  const int nq = kind == 0 ? 4 : (kind == 1 ? 4 : 7);
+  for (int i = 0; i < nq; ++i) q[i] = P22[off + i];
+  D7 acc = mk(0.f);
+  const float *pp = pts + (size_t)bk * NP * 3;
+  for (int i = t; i < NP; i += 128) acc = acc + residue_of(kind, q, pp[3 * i], pp[3 * i + 1], pp[3 * i + 2]);
+  float vals[8] = {acc.v, acc.d[0], acc.d[1], acc.d[2], acc.d[3], acc.d[4], acc.d[5], acc.d[6]};
+  for (int j = 0; j < 8; ++j)
+    for (int msk = 32; msk >= 1; msk >>= 1) vals[j] += __shfl_xor(vals[j], msk, 64);
+  if ((t & 63) == 0)
+    for (int j = 0; j < 8; ++j) s_red[t >> 6][j] = vals[j];
+  __syncthreads();
+  if (t == 0) {
+    const float invn = 1.0f / (float)NP;
+    out[bk * 2] = (s_red[0][0] + s_red[1][0]) * invn;
+    for (int j = 0; j < 7; ++j) dout[bk * 10 + j] = (s_red[0][1 + j] + s_red[1][1 + j]) * invn;
+    // axis agreement 1 − |a_pred·a_gt| (plane normal / cylinder axis / cone axis; 0 for spheres)
+    float pl = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (kind != 1) {
+      const int ao = kind == 0 ? 0 : (kind == 2 ? 8 : 18);
+      const float *ga = gt_axes + ((size_t)(kind == 0 ? 0 : (kind == 2 ? 1 : 2)) * gridDim.x + bk) * 3;
+      const float dt = P22[ao] * ga[0] + P22[ao + 1] * ga[1] + P22[ao + 2] * ga[2];
+      const float sg = dt > 0.f ? 1.f : (dt < 0.f ? -1.f : 0.f);
+      pl = 1.0f - fabsf(dt);
+      d0 = -sg * ga[0]; d1 = -sg * ga[1]; d2 = -sg * ga[2];
+    }
+    out[bk * 2 + 1] = pl;
+    dout[bk * 10 + 7] = d0; dout[bk * 10 + 8] = d1; dout[bk * 10 + 9] = d2;
+  }
+}
+
+// gparams[b][match][slots] += g_res·d residue + g_par·d axis-loss   (gparams zero-filled by the caller)
+__global__ void residue_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ dout,
+                                   const long long *__restrict__ match, const long long *__restrict__ Tgt, int K,
+                                   int BK, int tid_plane, int tid_sphere, int tid_cyl, int tid_cone,
+                                   float *__restrict__ gparams) {
+  const int bk = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bk >= BK) return;
+  const int b = bk / K;
+  const long long m = match[bk], ty = Tgt[bk];
+  const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
+  float *gp = gparams + ((size_t)b * K + m) * 22;
+  const float gr = gout[bk * 2], ga = gout[bk * 2 + 1];
+  const int off = kind == 0 ? 0 : (kind == 1 ? 4 : (kind == 2 ? 8 : 15));
+  const int nq = kind == 0 ? 4 : (kind == 1 ? 4 : 7);
+  if (gr != 0.f)
+    for (int i = 0; i < nq; ++i) atomicAdd(gp + off + i, gr * dout[bk * 10 + i]);
+  if (ga != 0.f && kind != 1) {
+    const int ao = kind == 0 ? 0 : (kind == 2 ? 8 : 18);
+    for (int i = 0; i < 3; ++i) atomicAdd(gp + ao + i, ga * dout[bk * 10 + 7 + i]);
+  }
+}
+
+inline int loss_chunks(int B, int N, int *ppb) {
+  int want = (512 + B - 1) / (B > 0 ? B : 1);
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  int p = (N + want - 1) / want;
+  p = ((p + SS_TILE - 1) / SS_TILE) * SS_TILE;
+  *ppb = p;
+  return (N + p - 1) / p;
+}
+
+}  // namespace
+
+extern "C" int cpfn_head_post_chunks(int N) { return cpfn_cdiv(N, LP_THREADS); }
+
+extern "C" int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt, int B,
+                                  int N, int K, float *Xn, float *Wsm, float *workspace, float *stats, void *stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !Y || !Xgt || !Igt || !Tgt || !Xn || !Wsm || !workspace || !stats)
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = cpfn_cdiv(N, LP_THREADS);
+  head_post_fwd_kernel<<<dim3(chunks, B), LP_THREADS, 0, st>>>(Y, Xgt, (const long long *)Igt, (const long long *)Tgt, N, K,
+                                                               Xn, Wsm, workspace);
+  head_post_reduce_kernel<<<cpfn_cdiv(B, 64), 64, 0, st>>>(workspace, chunks, N, B, stats);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
+                                  const float *Wsm, const float *stats, const float *gXn, const float *gW,
+                                  const float *gloss, int B, int N, int K, float *gY, void *stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !Y || !Xgt || !Igt || !Tgt || !Wsm || !stats || !gloss || !gY)
+    return CPFN_EINVAL;
+  head_post_bwd_kernel<<<dim3(cpfn_cdiv(N, LP_THREADS), B), LP_THREADS, 0, (hipStream_t)stream>>>(
+      Y, Xgt, (const long long *)Igt, (const long long *)Tgt, Wsm, stats, gXn, gW, gloss, N, K, gY);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_seg_stats_chunks(int B, int N) {
+  int ppb;
+  return loss_chunks(B, N, &ppb);
+}
+
+extern "C" int cpfn_seg_stats_fwd(const float *W, const int64_t *Igt, int B, int N, int K, float *workspace, float *S,
+                                  void *stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !W || !Igt || !workspace || !S) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int ppb;
+  const int chunks = loss_chunks(B, N, &ppb);
+  seg_stats_fwd_kernel<<<dim3(chunks, B), LP_THREADS, 0, st>>>(W, (const long long *)Igt, N, K, ppb, workspace);
+  const long long total = (long long)B * (K + 2) * K;
+  chunk_sum_f32_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, (K + 2) * K, total, S);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_seg_stats_bwd(const float *gS, const int64_t *Igt, int B, int N, int K, float *dW, void *stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !gS || !Igt || !dW) return CPFN_EINVAL;
+  seg_stats_bwd_kernel<<<dim3(cpfn_cdiv((long long)N * K, LP_THREADS), B), LP_THREADS, 0, (hipStream_t)stream>>>(
+      gS, (const long long *)Igt, N, K, dW);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_residue_fwd(const float *params, const int64_t *match, const int64_t *Tgt, const float *pts,
+                                const float *gt_axes, int B, int K, int NP, const int *type_ids, float *out, float *dout,
+                                void *stream) {
+  if (B <= 0 || K <= 0 || NP <= 0 || !params || !match || !Tgt || !pts || !gt_axes || !type_ids || !out || !dout)
+    return CPFN_EINVAL;
+  residue_fwd_kernel<<<B * K, 128, 0, (hipStream_t)stream>>>(params, (const long long *)match, (const long long *)Tgt, pts,
+                                                             gt_axes, K, NP, type_ids[0], type_ids[1], type_ids[2],
+                                                             type_ids[3], out, dout);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_residue_bwd(const float *gout, const float *dout, const int64_t *match, const int64_t *Tgt, int B,
+                                int K, const int *type_ids, float *gparams, void *stream) {
+  if (B <= 0 || K <= 0 || !gout || !dout || !match || !Tgt || !type_ids || !gparams) return CPFN_EINVAL;
+  residue_bwd_kernel<<<cpfn_cdiv(B * K, 64), 64, 0, (hipStream_t)stream>>>(gout, dout, (const long long *)match,
+                                                                          (const long long *)Tgt, K, B * K, type_ids[0],
+                                                                          type_ids[1], type_ids[2], type_ids[3], gparams);
+  return cpfn_launch_status();
+}

@@ -281,6 +281,7 @@ def linear_heads(a, weights, biases):
     W = torch.cat([w.reshape(w.shape[0], -1) for w in weights], 0)
     b = torch.cat(list(biases), 0)
     Y = _Linear.apply(a, W, b, W.shape[0])
+    linear_heads.last_packed = Y          # [P, sum(o_i)] fp32, for consumers that want the heads fused
     outs, o = [], 0
     for w in weights:
         outs.append(Y[:, o:o + w.shape[0]])

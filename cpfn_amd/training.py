@@ -95,6 +95,7 @@ class SPFNTrainer:
         self._lr = get_learning_rate(init_learning_rate, 0, batch_size, decay_step, decay_rate)
         update_momentum(module, self._bn_momentum)
         self.skipped_steps = 0
+        self.fused_losses = True      # HIP loss kernels when the model exposes its packed fp32 heads
 
     def _schedules(self):
         m = get_batch_norm_decay(self.global_step, self.batch_size, self.bn_decay_step)
@@ -112,6 +113,10 @@ class SPFNTrainer:
         """Forward + losses (training_utils.py:140-146).  Returns the reference's 6 scalars."""
         P = batch["P"]
         X, T, W, _, _ = self.module(P, fps_start=fps_start)
+        packed = getattr(self.module, "heads_packed", None)
+        if self.fused_losses and packed is not None and len(self.classes) == 4 and T.shape[2] == 4:
+            from .SPFN import fused_losses
+            return fused_losses.fused_losses(P, packed, batch, self.mult, self.classes)
         X = torch.nn.functional.normalize(X, p=2, dim=2, eps=1e-12)
         W = torch.softmax(W, dim=2)
         gt = {'plane_normal': batch["plane_n_gt"], 'cylinder_axis': batch["cylinder_axis_gt"],

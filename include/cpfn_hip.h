@@ -228,6 +228,45 @@ CPFN_API int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P
 CPFN_API int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C,
                                float *workspace, float *dW, void *stream);
 
+/* ------------------------------------------------------------------ loss-side fusions
+ * (the callers on the far side of the fitters.)  K <= 32. */
+
+/* Heads post-processing: Y[B,N,7+K] fp32 (3 normal, 4 type logits, K membership logits) ->
+ * Xn[B,N,3] = normalize (Utils/training_utils.py:141), Wsm[B,N,K] = softmax (:142),
+ * stats[B,3] = (normal loss, type loss, #labelled points) per cloud
+ * (SPFN/losses_implementation.py:152-159, 195-210; training forms).  Igt[B,N], Tgt[B,K] int64.
+ * workspace: B * cpfn_head_post_chunks(N) * 3 floats. */
+CPFN_API int cpfn_head_post_chunks(int N);
+CPFN_API int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
+                                int B, int N, int K, float *Xn, float *Wsm, float *workspace, float *stats,
+                                void *stream);
+/* Adjoint: gXn[B,N,3], gW[B,N,K] (either may be NULL), gloss[B,2] = dL/d(normal, type loss) -> gY. */
+CPFN_API int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
+                                const float *Wsm, const float *stats, const float *gXn, const float *gW,
+                                const float *gloss, int B, int N, int K, float *gY, void *stream);
+/* Label-segmented membership sums, shared by the Hungarian cost matrix and the relaxed-IoU loss
+ * (SPFN/losses_implementation.py:19-24, 77-90):  S[B,K+2,K]: rows l<K = sum of W rows with label l,
+ * row K = column sums of W, row K+1 = number of points per label.
+ * workspace: B * cpfn_seg_stats_chunks(B,N) * (K+2)*K floats. */
+CPFN_API int cpfn_seg_stats_chunks(int B, int N);
+CPFN_API int cpfn_seg_stats_fwd(const float *W, const int64_t *Igt, int B, int N, int K, float *workspace,
+                                float *S, void *stream);
+CPFN_API int cpfn_seg_stats_bwd(const float *gS, const int64_t *Igt, int B, int N, int K, float *dW,
+                                void *stream);
+/* Residue + axis losses of every GT instance against its matched prediction, for the instance's GT
+ * type only (SPFN/losses_implementation.py:351-387, 480-497; SPFN/*_fitter.compute_residue_single).
+ * params[B,K,22] = plane n(3) c | sphere c(3) r2 | cylinder a(3) c(3) r2 | cone apex(3) axis(3) half;
+ * pts[B,K,NP,3]; gt_axes[3,B,K,3] = GT plane normal / cylinder axis / cone axis;
+ * type_ids = HOST array of the ids of (plane, sphere, cylinder, cone).
+ * out[B,K,2] = (mean residue, 1-|axis.axis_gt|); dout[B,K,10] = their derivatives (saved for bwd). */
+CPFN_API int cpfn_residue_fwd(const float *params, const int64_t *match, const int64_t *Tgt,
+                              const float *pts, const float *gt_axes, int B, int K, int NP,
+                              const int *type_ids, float *out, float *dout, void *stream);
+/* gparams[B,K,22] (zero-filled by the caller) += gout[B,K,2] . dout, routed through match. */
+CPFN_API int cpfn_residue_bwd(const float *gout, const float *dout, const int64_t *match,
+                              const int64_t *Tgt, int B, int K, const int *type_ids, float *gparams,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif
