@@ -24,7 +24,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH_PER_GPU = 16
+BATCH_PER_GPU = int(os.environ.get("CPFN_BENCH_BATCH", "16"))   # 16 = BASELINE.json configs[1]; override only for experiments
 N_POINTS = 8192
 N_INSTANCES = 28
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,7 +106,7 @@ def main():
     model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, N_INSTANCES]).to(dev)
     model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     training.broadcast_parameters(model)
-    trainer = training.SPFNTrainer(model, batch_size=BATCH_PER_GPU * world)
+    trainer = training.SPFNTrainer(model, batch_size=BATCH_PER_GPU * world, use_graphs=not args.no_graphs)
     batch = {k: v.to(dev) for k, v in
              synthetic.training_batch(BATCH_PER_GPU, N_POINTS, N_INSTANCES, seed=1000 + rank).items()}
     torch.manual_seed(1234 + rank)                      # per-rank FPS starts / dropout masks
@@ -116,17 +117,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Each step also prefetches the NEXT step's geometry (FPS / ball query / 3-NN with fresh random
+    # FPS starts) on a side stream: one geometry pass per step, software-pipelined across steps.
     for _ in range(args.warmup):
-        trainer.step(batch)
+        trainer.step(batch, next_batch=batch)
     lib.time_symbols([ROOFLINE_SYMBOL])
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = trainer.step(batch)
+        out = trainer.step(batch, next_batch=batch)
     sync()
     elapsed = time.perf_counter() - t0
     calls, kernel_ms = lib.timed_report()[ROOFLINE_SYMBOL]
     roof_bytes = lib.timed_bytes(ROOFLINE_SYMBOL)
+    roof_mode = "events around every launch inside the timed region"
+    if calls == 0:
+        # hipGraph replay: the launches of the timed region are graph nodes and cannot be bracketed one
+        # by one, so the same step is re-run eagerly right here (same process, same tensors, same
+        # stream) with an event pair around every launch of the kernel family.  rocprofv3 (which does
+        # see the kernels inside a replay) gives the same per-launch durations: profiles/README.md.
+        lib.time_symbols([ROOFLINE_SYMBOL])
+        for _ in range(3):
+            trainer.step(batch, force_eager=True)
+        sync()
+        calls, kernel_ms = lib.timed_report()[ROOFLINE_SYMBOL]
+        roof_bytes = lib.timed_bytes(ROOFLINE_SYMBOL)
+        roof_mode = "events around every launch in 3 eager re-runs of the step right after the timed region (graph replays are not bracketable)"
     lib.time_symbols([])
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -151,11 +167,12 @@ def main():
                                    "%d clouds/GPU x %d pts, %d instances, 4 primitive types"
                                    % (BATCH_PER_GPU, N_POINTS, N_INSTANCES),
                        "global_batch": BATCH_PER_GPU * world, "points": N_POINTS,
-                       "parallelism": "dp%d" % world, "loss_last": float(out[0])},
+                       "parallelism": "dp%d" % world, "loss_last": float(out[0]),
+                       "launch": "hipGraph replay (2 graphs/step)" if trainer._graph is not None else "eager"},
             "roofline": {"bound": "hbm", "kernel": ROOFLINE_SYMBOL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": calls, "avg_launch_us": 1e6 * per_launch_s,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "measured": roof_mode},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -37,7 +37,23 @@ class PointsetAbstraction(nn.Module):
             self.bn_blocks.append(bns)
 
     # ---------------------------------------------------------------- native layout
-    def forward_rows(self, xyz, feats, start_idx=None):
+    def compute_geometry(self, xyz, start_idx=None):
+        """Everything of this level that depends only on coordinates (no weights, no gradients):
+        FPS indices, sampled centres, ball-query neighbours and the centred neighbour coordinates.
+        Can be run ahead of time on a side stream (PointNet2.compute_geometry)."""
+        B, N, _ = xyz.shape
+        if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
+            start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+        start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
+        sel = ops.fps(xyz, self.num_points, start_idx)
+        new_xyz = ops.gather_rows(xyz, sel)
+        scales = []
+        for r, k in zip(self.radius_list, self.num_samples_list):
+            nbr = ops.ball_query(new_xyz, xyz, r, k)                                      # [B,S,K] i32
+            scales.append((nbr, ops.group_xyz_centered(xyz, new_xyz, nbr)))               # rel [B,S,K,3] fp32
+        return {"fps_idx": sel, "new_xyz": new_xyz, "scales": scales}
+
+    def forward_rows(self, xyz, feats, start_idx=None, geom=None):
         """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux)."""
         B, N, _ = xyz.shape
         aux = {}
@@ -47,18 +63,14 @@ class PointsetAbstraction(nn.Module):
             g = xyz if feats is None else torch.cat([xyz.to(feats.dtype), feats], dim=2)     # pos FIRST (ref :56)
             groups = [(g.reshape(B * N, -1), None, 1, N)] * len(self.mlp_list)
         else:
-            if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
-                start_idx = torch.randint(0, N, (B,), dtype=torch.long)
-            start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
-            sel = ops.fps(xyz, self.num_points, start_idx)
-            new_xyz = ops.gather_rows(xyz, sel)
-            aux["fps_idx"] = sel
+            if geom is None:
+                geom = self.compute_geometry(xyz, start_idx)
+            new_xyz = geom["new_xyz"]
+            aux["fps_idx"] = geom["fps_idx"]
             groups = []
-            for r, k in zip(self.radius_list, self.num_samples_list):
-                nbr = ops.ball_query(new_xyz, xyz, r, k)                                  # [B,S,K] i32
+            S = self.num_points
+            for (nbr, rel), k in zip(geom["scales"], self.num_samples_list):
                 aux["ball_idx"] = nbr
-                rel = ops.group_xyz_centered(xyz, new_xyz, nbr)                           # [B,S,K,3] fp32
-                S = self.num_points
                 if feats is not None:
                     gf = autograd_ops.gather_rows(feats, nbr)                             # [B,S,K,D]
                     x = torch.cat([gf, rel.to(gf.dtype)], dim=3).reshape(B * S * k, -1)   # feats FIRST (ref :66)

@@ -22,7 +22,13 @@ class PointsetFeaturePropagation(nn.Module):
             self.mlp_bns.append(nn.BatchNorm1d(c_out))
             c_in = c_out
 
-    def forward_rows(self, xyz1, xyz2, feats1, feats2):
+    @staticmethod
+    def compute_geometry(xyz1, xyz2):
+        """3-NN indices and inverse-distance weights (coordinates only; prefetchable)."""
+        d2, nn_idx = ops.three_nn(xyz1, xyz2)                               # squared distances (CPU-route semantics)
+        return {"nn_idx": nn_idx, "nn_w": ops.three_weights(d2)}            # 1/(d+1e-8), normalised (ref :40-42)
+
+    def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None):
         """xyz1 [B,N,3] dense, xyz2 [B,S,3] coarse or None, feats1 [B,N,D1] or None,
         feats2 [B,S,D2] -> [B,N,D']."""
         B, N, _ = xyz1.shape
@@ -30,10 +36,10 @@ class PointsetFeaturePropagation(nn.Module):
         if xyz2 is None:
             interp = feats2.expand(B, N, feats2.shape[2])                  # broadcast the global vector (ref :33-34)
         else:
-            d2, nn_idx = ops.three_nn(xyz1, xyz2)                           # squared distances (CPU-route semantics)
-            w = ops.three_weights(d2)                                       # 1/(d+1e-8), normalised (ref :40-42)
-            interp = autograd_ops.interp_rows(feats2, nn_idx, w)
-            aux = {"nn_idx": nn_idx, "nn_w": w}
+            if geom is None:
+                geom = self.compute_geometry(xyz1, xyz2)
+            interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"])
+            aux = geom
         x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
         y = mlp.run_stack(x.reshape(B * N, -1), self.mlp_convs, self.mlp_bns, getattr(self, "compute_dtype", torch.float32))
         return y.reshape(B, N, -1), aux

@@ -133,16 +133,19 @@ def hungarian_from_stats(S, I_gt):
     return match.to(S.device)
 
 
-def fused_losses(P, Y, batch, multipliers, classes):
-    """P [B,N,3]; Y [B,N,7+K] = packed fp32 heads (normal | type logits | membership logits).
-    Returns the reference's (total, normal, type, miou, residue, parameter) scalars."""
+def pre_match(Y, batch):
+    """Everything before the host-side assignment: unit normals, memberships, per-cloud normal /
+    type losses and the label-segmented sums S.  (Capturable: no host synchronisation.)"""
+    Xn, W, nl, tl = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"])
+    return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"])
+
+
+def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes):
+    """Everything after the assignment: relaxed IoU of the matched pairs, the fitters, residue and
+    axis losses, the weighted total.  (Capturable.)"""
     m = multipliers
-    B, N, _ = P.shape
-    K = Y.shape[2] - 7
+    K = W.shape[2]
     I_gt, T_gt = batch["I_gt"], batch["T_gt"]
-    Xn, W, nl, tl = HeadPost.apply(Y, batch["X_gt"], I_gt, T_gt)
-    S = SegStats.apply(W, I_gt)
-    match = hungarian_from_stats(S.detach(), I_gt)
     mask_gt = get_mask_gt(I_gt, K)
     zero = torch.zeros((), device=P.device)
     # relaxed IoU of the matched pairs (reference lines 77-90)
@@ -174,3 +177,11 @@ def fused_losses(P, Y, batch, multipliers, classes):
         if m[key] > 0:
             total = total + m[key] * val
     return total * m["total"], total_normal, total_type, total_miou, total_res, total_par
+
+
+def fused_losses(P, Y, batch, multipliers, classes):
+    """P [B,N,3]; Y [B,N,7+K] = packed fp32 heads (normal | type logits | membership logits).
+    Returns the reference's (total, normal, type, miou, residue, parameter) scalars."""
+    Xn, W, nl, tl, S = pre_match(Y, batch)
+    match = hungarian_from_stats(S.detach(), batch["I_gt"])
+    return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes)

@@ -273,7 +273,9 @@ class _Linear(torch.autograd.Function):
             _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, _ptr(ws), _ptr(dW), _stream()),
                    "cpfn_mlp_wgrad")
             ga, _, _ = gemm(gb, Wb.t().contiguous())
-        return ga, dW[:N], g.sum(0), None
+        # bias gradient = column sums of g: a GEMV, not torch's strided reduce (0.66 ms for [131072,35])
+        gbias = torch.mv(g.t(), torch.ones(P, dtype=g.dtype, device=g.device))
+        return ga, dW[:N], gbias, None
 
 
 def linear_heads(a, weights, biases):

@@ -77,7 +77,7 @@ class SPFNTrainer:
     """Holds the optimizer state and the schedule bookkeeping of the reference's epoch loop."""
 
     def __init__(self, module, batch_size=16, init_learning_rate=1e-3, decay_step=200000, decay_rate=0.7,
-                 bn_decay_step=200000, multipliers=None, classes=None, fused_adam=None):
+                 bn_decay_step=200000, multipliers=None, classes=None, fused_adam=None, use_graphs=False):
         self.module = module
         self.batch_size = batch_size
         self.init_learning_rate, self.decay_step, self.decay_rate = init_learning_rate, decay_step, decay_rate
@@ -88,31 +88,83 @@ class SPFNTrainer:
         self.classes = list(classes) if classes is not None else list(GLOBAL_SPFN_CLASSES)
         self.bucket = FlatGradBucket(module)
         on_gpu = self.bucket.flat.is_cuda
-        self.optimizer = torch.optim.Adam(module.parameters(), lr=init_learning_rate,
-                                          fused=on_gpu if fused_adam is None else fused_adam)
+        self.use_graphs = bool(use_graphs) and on_gpu
+        if self.use_graphs:   # lr lives in a device tensor so the LR staircase needs no re-capture
+            self.optimizer = torch.optim.Adam(module.parameters(), lr=torch.tensor(float(init_learning_rate), device=self.bucket.flat.device),
+                                              fused=True, capturable=True)
+        else:
+            self.optimizer = torch.optim.Adam(module.parameters(), lr=init_learning_rate,
+                                              fused=on_gpu if fused_adam is None else fused_adam)
+        self._graph, self._graph_warm = None, 0
+        self._gstream, self._in_gstream = None, False
         self.global_step = 0
         self._bn_momentum = get_batch_norm_decay(0, batch_size, bn_decay_step)
         self._lr = get_learning_rate(init_learning_rate, 0, batch_size, decay_step, decay_rate)
         update_momentum(module, self._bn_momentum)
         self.skipped_steps = 0
         self.fused_losses = True      # HIP loss kernels when the model exposes its packed fp32 heads
+        self._side, self._prefetched = None, None
 
     def _schedules(self):
         m = get_batch_norm_decay(self.global_step, self.batch_size, self.bn_decay_step)
         if m != self._bn_momentum:
             update_momentum(self.module, m)
             self._bn_momentum = m
+            self._graph = None            # the momentum is a kernel argument baked into the capture
         lr = get_learning_rate(self.init_learning_rate, self.global_step, self.batch_size, self.decay_step,
                                self.decay_rate)
         if lr != self._lr:
             for group in self.optimizer.param_groups:
-                group['lr'] = lr
+                if isinstance(group['lr'], torch.Tensor):
+                    group['lr'].fill_(lr)
+                else:
+                    group['lr'] = lr
             self._lr = lr
+
+    # ---- geometry prefetch: FPS / ball query / 3-NN depend on coordinates only -----------------
+    def prefetch(self, batch, fps_start=None):
+        """Compute the next batch's index tensors on a side stream (overlaps with whatever the
+        main stream is doing, typically the current step's backward pass: FPS alone is 0.7 ms of
+        a 16-workgroup latency chain)."""
+        P = batch["P"]
+        if not (P.is_cuda and hasattr(self.module, "compute_geometry")):
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=P.device)
+        main = torch.cuda.current_stream(P.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            geom = self.module.compute_geometry(P, fps_start)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._prefetched = (P.data_ptr(), geom, ev)
+
+    def _take_prefetched(self, P):
+        pf, self._prefetched = self._prefetched, None
+        if pf is None or pf[0] != P.data_ptr():
+            return None
+        _, geom, ev = pf
+        main = torch.cuda.current_stream(P.device)
+        main.wait_event(ev)
+
+        def mark(o):                    # allocated on the side stream, consumed on the main one
+            if isinstance(o, torch.Tensor):
+                o.record_stream(main)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    mark(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    mark(v)
+        mark(geom)
+        return geom
 
     def losses(self, batch, fps_start=None):
         """Forward + losses (training_utils.py:140-146).  Returns the reference's 6 scalars."""
         P = batch["P"]
-        X, T, W, _, _ = self.module(P, fps_start=fps_start)
+        geom = self._take_prefetched(P) if fps_start is None else None
+        kw = {"geometry": geom} if geom is not None else {}
+        X, T, W, _, _ = self.module(P, fps_start=fps_start, **kw)
         packed = getattr(self.module, "heads_packed", None)
         if self.fused_losses and packed is not None and len(self.classes) == 4 and T.shape[2] == 4:
             from .SPFN import fused_losses
@@ -128,18 +180,109 @@ class SPFNTrainer:
             mode_seg='mIoU', classes=self.classes)
         return out[:6]
 
-    def step(self, batch, fps_start=None):
+    # ---- hipGraph replay of the step -----------------------------------------------------------
+    # At 16 clouds per GPU the step is ~560 launches and host-bound (~7 ms of CPU for ~6.5 ms of GPU
+    # work).  The step is captured once into two graphs split at its single host round trip (the
+    # Hungarian assignment): G1 = geometry + network forward + heads post-processing + segmented
+    # sums; host SciPy; G2 = matched losses, fitters, full backward, finite flag, fused Adam.
+    def _capture(self, batch):
+        from .SPFN import fused_losses as fl
+        dev = batch["P"].device
+        B, N, _ = batch["P"].shape
+        K = batch["T_gt"].shape[1]
+        st = {"batch": {k: v.clone() for k, v in batch.items()},
+              "start1": torch.zeros(B, dtype=torch.int32, device=dev),
+              "start2": torch.zeros(B, dtype=torch.int32, device=dev),
+              "match": torch.zeros(B, K, dtype=torch.long, device=dev),
+              "skipped": torch.zeros((), dtype=torch.float32, device=dev)}
+        sb = st["batch"]
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # capture on the same side stream the eager warm-up steps ran on, so that the parameters'
+        # AccumulateGrad nodes do not belong to the default stream (which cannot take part in a capture)
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=self._gstream):
+            self.bucket.zero()
+            self.module(sb["P"], fps_start=(st["start1"], st["start2"]))
+            st["pre"] = fl.pre_match(self.module.heads_packed, sb)
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=g1.pool(), stream=self._gstream):
+            Xn, W, nl, tl, S = st["pre"]
+            out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes)
+            out[0].backward()
+            if world == 1:
+                st["found_inf"] = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+                self.optimizer.found_inf = st["found_inf"]
+                self.optimizer.step()
+                st["skipped"] += st["found_inf"]
+            st["out"] = tuple(o.detach() for o in out)
+        st["g1"], st["g2"], st["world"] = g1, g2, world
+        return st
+
+    def _graph_step(self, batch):
+        from .SPFN import fused_losses as fl
+        st = self._graph
+        for k, v in batch.items():
+            if v.data_ptr() != st["batch"][k].data_ptr():
+                st["batch"][k].copy_(v, non_blocking=True)
+        B, N, _ = batch["P"].shape
+        # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order
+        st["start1"].copy_(torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32), non_blocking=True)
+        st["start2"].copy_(torch.randint(0, self.module.sa1.num_points, (B,), dtype=torch.long).to(torch.int32),
+                           non_blocking=True)
+        st["g1"].replay()
+        st["match"].copy_(fl.hungarian_from_stats(st["pre"][4].detach(), st["batch"]["I_gt"]))
+        st["g2"].replay()
+        if st["world"] > 1:
+            self.bucket.all_reduce_mean()
+            self.optimizer.found_inf = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+            self.optimizer.step()
+            st["skipped"] += self.optimizer.found_inf
+        self.global_step += 1
+        return st["out"]
+
+    def step(self, batch, fps_start=None, next_batch=None, force_eager=False):
         """One optimisation step; returns the 6 loss tensors (still on the device — the
-        reference's six `.item()` syncs per step, training_utils.py:169-174, are left to the caller)."""
+        reference's six `.item()` syncs per step, training_utils.py:169-174, are left to the caller).
+        `next_batch`: if given, its geometry is prefetched on a side stream during this step's backward."""
         self.module.train()
-        self.bucket.zero()
         self._schedules()
+        if self.use_graphs and not force_eager and fps_start is None and batch["P"].is_cuda and not self._in_gstream:
+            if self._gstream is None:
+                self._gstream = torch.cuda.Stream(device=batch["P"].device)
+            cur = torch.cuda.current_stream(batch["P"].device)
+            self._gstream.wait_stream(cur)
+            self._in_gstream = True
+            try:
+                with torch.cuda.stream(self._gstream):
+                    out = self.step(batch, None, None)
+            finally:
+                self._in_gstream = False
+            cur.wait_stream(self._gstream)
+            return out
+        if self.use_graphs and not force_eager and fps_start is None and batch["P"].is_cuda:
+            if self._graph is None and self._graph_warm >= 2:
+                try:
+                    self._graph = self._capture(batch)
+                except Exception as e:          # capture is an optimisation: fall back to eager launches
+                    import warnings
+                    warnings.warn("hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
+                    self.use_graphs = False
+                    torch.cuda.synchronize()
+            if self._graph is not None:
+                return self._graph_step(batch)
+            self._graph_warm += 1
+        self.bucket.zero()
         out = self.losses(batch, fps_start)
+        if next_batch is not None:
+            self.prefetch(next_batch)
         out[0].backward()
         self.bucket.all_reduce_mean()
-        if bool(self.bucket.finite()):                 # single host sync (reference: 148)
+        if self.use_graphs:                            # capturable optimizer: skip decided on the device
+            self.optimizer.found_inf = (~self.bucket.finite()).float().reshape(())
+            self.optimizer.step()
+        elif bool(self.bucket.finite()):               # single host sync (reference: 148)
             self.optimizer.step()
         else:
             self.skipped_steps += 1
         self.global_step += 1
-        return out
+        return tuple(o.detach() for o in out)     # do not keep the autograd graph alive across steps
