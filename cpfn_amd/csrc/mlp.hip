@@ -760,6 +760,21 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short 
   }
 }
 
+// column sums of a row-major fp32 matrix X[P,C] (C <= 64): partial[gridDim.x][C], then split_reduce.
+// (bias gradient of the heads: torch's strided reduce takes 0.66 ms and rocBLAS gemv 0.8 ms for [131072,35].)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float *__restrict__ X, long long P, int C,
+                                                         float *__restrict__ partial) {
+  __shared__ float s_acc[4][64];
+  const int t = threadIdx.x, c = t & 63, rs = t >> 6;
+  const long long row0 = (long long)blockIdx.x * 1024;
+  float a = 0.f;
+  if (c < C)
+    for (long long r = row0 + rs; r < min(P, row0 + 1024); r += 4) a += X[r * C + c];
+  s_acc[rs][c] = a;
+  __syncthreads();
+  if (t < C) partial[(size_t)blockIdx.x * C + t] = s_acc[0][t] + s_acc[1][t] + s_acc[2][t] + s_acc[3][t];
+}
+
 inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 }  // namespace
@@ -803,7 +818,9 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
 #undef CPFN_STREAM
     return cpfn_launch_status();
   }
-  if (N % 128 == 0) {
+  const long long row_tiles = (P + G_ROWS - 1) / G_ROWS;
+  const bool wide = (N % 128 == 0) && row_tiles * (N / 128) >= 256;   // otherwise 64-wide blocks: 2x the workgroups
+  if (wide) {
     dim3 grid(gx, N / 128);
     if (stats_partial)
       mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
@@ -943,5 +960,14 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
   smallk_wgrad_kernel<<<nblk, 256, 0, st>>>((const unsigned short *)Gy, X, KS, P, C, workspace);
   const long long n = (long long)C * KS;
   split_reduce_kernel<<<cpfn_cdiv(n, 16), 256, 0, st>>>(workspace, nblk, n, dW);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *stream) {
+  if (P <= 0 || C <= 0 || C > 64 || !X || !workspace || !out) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)((P + 1023) / 1024);
+  colsum_f32_kernel<<<nblk, 256, 0, st>>>(X, P, C, workspace);
+  split_reduce_kernel<<<cpfn_cdiv(C, 16), 256, 0, st>>>(workspace, nblk, C, out);
   return cpfn_launch_status();
 }

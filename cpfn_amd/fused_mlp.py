@@ -273,8 +273,12 @@ class _Linear(torch.autograd.Function):
             _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, _ptr(ws), _ptr(dW), _stream()),
                    "cpfn_mlp_wgrad")
             ga, _, _ = gemm(gb, Wb.t().contiguous())
-        # bias gradient = column sums of g: a GEMV, not torch's strided reduce (0.66 ms for [131072,35])
-        gbias = torch.mv(g.t(), torch.ones(P, dtype=g.dtype, device=g.device))
+        # bias gradient = column sums of g (torch's strided reduce: 0.66 ms, rocBLAS gemv: 0.8 ms for [131072,35])
+        gc = g.contiguous().float()
+        gbias = torch.empty(N, dtype=torch.float32, device=a.device)
+        wsb = torch.empty(((P + 1023) // 1024) * N, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), _ptr(gbias), _stream()), "cpfn_colsum_f32")
         return ga, dW[:N], gbias, None
 
 

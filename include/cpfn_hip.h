@@ -220,6 +220,10 @@ CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, co
 CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, float *workspace, float *dW, void *stream);
+/* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
+ * workspace: ceil(P/1024)*C floats. */
+CPFN_API int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out,
+                             void *stream);
 /* fp32 first layer with K = KS <= 4 inputs (sa1: relative xyz stay fp32):
  * Y[P,C] bf16 = X[P,KS] . W[C,KS]^T, partial[cpfn_bn_bwd_blocks(P)][2][C]; and its weight gradient
  * (workspace: cpfn_bn_bwd_blocks(P)*C*KS floats). */
