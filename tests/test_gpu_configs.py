@@ -1,0 +1,87 @@
+"""GPU: the other configurations of BASELINE.json besides the benchmarked one — LocalSPFN training
+(K=21, fitter losses switched off: Configs/config_localSPFN.yml:10-11), evaluation-mode forward on a
+cloud larger than the resident-FPS limit (config 5's high-res clouds use the streaming FPS kernel and
+BatchNorm running statistics), PatchSelection / feature-extractor heads and the glob/loc feature inputs."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from cpfn_amd import synthetic
+from oracle import geometry as og
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_local_spfn_training_step():
+    from cpfn_amd import training
+    from cpfn_amd.PointNet2 import pn2_network
+    from cpfn_amd.SPFN import fitter_factory
+    with contextlib.redirect_stdout(io.StringIO()):
+        fitter_factory.register_primitives(training.GLOBAL_SPFN_CLASSES)
+    torch.manual_seed(0)
+    model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 21]).to(dev())
+    model.set_compute_dtype(torch.bfloat16)
+    mult = dict(miou=1.0, normal=1.0, type=1.0, parameter=0.0, residue=0.0, total=1.0)
+    tr = training.SPFNTrainer(model, batch_size=4, multipliers=mult)
+    batch = {k: v.to(dev()) for k, v in
+             synthetic.training_batch(4, N=2048, n_max_instances=21, n_prims=5, n_inst_points=64, seed=2).items()}
+    first = None
+    for _ in range(4):
+        out = tr.step(batch)
+        first = first if first is not None else float(out[0])
+    assert tr.skipped_steps == 0
+    assert float(out[4]) == 0.0 and float(out[5]) == 0.0          # residue / parameter losses are off
+    assert np.isfinite(float(out[0])) and float(out[0]) < first
+
+
+def test_eval_forward_large_cloud_streaming_fps():
+    from cpfn_amd.PointNet2 import pn2_network
+    torch.manual_seed(1)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev())
+    m.dropout_p = 0.0
+    P = synthetic.primitive_cloud(1, 20000, n_prims=8, seed=3)["P"].to(dev())
+    # a couple of training-mode passes so the running statistics are not the init values
+    m.train()
+    with torch.no_grad():
+        for _ in range(2):
+            m(P[:, :4096].contiguous())
+    m.eval()
+    starts = (torch.tensor([7]), torch.tensor([11]))
+    with torch.no_grad():
+        ref = m(P, fps_start=starts)                                # fp32 PyTorch MLPs, HIP geometry
+        m.set_compute_dtype(torch.bfloat16)
+        out = m(P, fps_start=starts)                                # fused bf16 stacks, running statistics
+    # the 20000-point cloud went through the streaming FPS kernel: check it against the oracle
+    want = og.farthest_point_sample(P.cpu().numpy(), 512, starts[0].numpy())
+    assert np.array_equal(m.aux_sa1["fps_idx"].cpu().numpy(), want.astype(np.int32))
+    for a, b in zip(out[:3], ref[:3]):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert float((a - b).norm() / b.norm()) < 5e-2
+    assert out[3].shape == (1, 1024, 1) and out[4].shape == (1, 128, 20000)
+
+
+def test_patch_selection_and_feature_extractor_variants():
+    from cpfn_amd.PointNet2 import pn2_network
+    torch.manual_seed(2)
+    P = synthetic.uniform_cloud(2, 1024, seed=4).to(dev())
+    ps = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2]).to(dev())       # training_PatchSelection.py
+    ps.set_compute_dtype(torch.bfloat16)
+    heat, l3, feat = ps(P)
+    assert heat.shape == (2, 1024, 2) and l3.shape == (2, 1024, 1) and feat.shape == (2, 128, 1024)
+    fe = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2], features_extractor=True).to(dev())
+    l3, feat = fe(P)
+    assert l3.shape == (2, 1024, 1) and feat.shape == (2, 128, 1024)
+    # LocalSPFN's optional global / local feature inputs widen sfp1 (pn2_network.py:22-27, 51-54)
+    gl = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 21], use_glob_features=True,
+                               use_loc_features=True).to(dev())
+    gl.set_compute_dtype(torch.bfloat16)
+    out = gl(P, glob_features=torch.randn(2, 1024, device=dev()), loc_features=torch.randn(2, 128, device=dev()))
+    assert out[2].shape == (2, 1024, 21) and out[3].shape == (2, 1024 + 1024 + 128, 1)
+    assert gl.sfp1.mlp_convs[0].weight.shape[1] == 1024 + 1024 + 128 + 256
