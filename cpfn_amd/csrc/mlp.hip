@@ -48,6 +48,33 @@ constexpr int G_LDW = G_KC + 8;
 //    fp32 / ragged-N output: the small-P layers (sa3, sfp1, sfp2), K > 128, and the fc2 heads.
 constexpr int G_LDO = 128 + 8;  // output staging row stride (elements): 272 B
 
+// Fill the LDS weight panel s_w[r][k] (r = output channel n0+r, k in [kc, kc+kcn)).
+// w_trans == 0: W is [N,K] row-major (16-byte loads along k).
+// w_trans == 1: W is [K,N] row-major (the FORWARD layer's weight used for the data gradient): 16-byte
+//               loads along n, transposed on the way into LDS with 2-byte writes — the panel is at most
+//               64 KB and filled once per workgroup (or per K chunk), so the slow writes do not matter,
+//               and no transposed weight copy has to be materialised per step.
+template <int BN>
+__device__ __forceinline__ void fill_w_panel(unsigned short *s_w, const unsigned short *__restrict__ W, int K,
+                                             int N, int n0, int kc, int kcn, int w_trans, int t) {
+  if (!w_trans) {
+    const int cpr = kcn / 8;  // 16-byte chunks per row
+    for (int e = t; e < BN * cpr; e += G_THREADS) {
+      const int r = e / cpr, c = e - r * cpr;
+      *(uint4 *)&s_w[r * G_LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + kc + c * 8];
+    }
+  } else {
+    constexpr int cpn = BN / 8;  // 16-byte chunks along n
+    for (int e = t; e < kcn * cpn; e += G_THREADS) {
+      const int k = e / cpn, c = e - k * cpn;
+      const uint4 v = *(const uint4 *)&W[(size_t)(kc + k) * N + n0 + c * 8];
+      const unsigned short *h = (const unsigned short *)&v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_w[(c * 8 + j) * G_LDW + k] = h[j];
+    }
+  }
+}
+
 template <int KS>
 __device__ __forceinline__ void stream_load_a(bf16x8 (&af)[2][KS], const unsigned short *__restrict__ A, int lda,
                                               int P, int row0, int wave, int lr, int lq) {
@@ -104,7 +131,7 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const uns
 
 template <int BN, int KS, bool STATS>
 __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
-    const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int P, int N,
+    const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg) {
   constexpr int NT = BN / 16, K = 32 * KS;
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
@@ -122,11 +149,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   if (tile0 < tile_end) {
     bf16x8 a0[2][KS], a1[2][KS];
     stream_load_a<KS>(a0, A, lda, P, tile0 * G_ROWS, wave, lr, lq);
-    constexpr int cpr = K / 8;
-    for (int e = t; e < BN * cpr; e += G_THREADS) {
-      const int r = e / cpr, c = e - r * cpr;
-      *(uint4 *)&s_w[r * G_LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + c * 8];
-    }
+    fill_w_panel<BN>(s_w, W, K, N, n0, 0, K, w_trans, t);
     __syncthreads();
     for (int tile = tile0; tile < tile_end; tile += 2) {
       // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
 template <int BN, bool STATS>
 __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const int *__restrict__ gidx,
-    const unsigned short *__restrict__ W, int P, int K, int N, void *__restrict__ Y, int ldy, int y_f32,
+    const unsigned short *__restrict__ W, int w_trans, int P, int K, int N, void *__restrict__ Y, int ldy, int y_f32,
     int n_store, const float *__restrict__ bias, float *__restrict__ stats_partial, int tiles_per_wg) {
   constexpr int NT = BN / 16;
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
@@ -199,11 +222,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
           if (ks * 32 < kcn) af[tt][ks] = *(const bf16x8 *)(A + arow[tt] + kc + ks * 32 + 8 * lq);
       if (!(w_loaded && K <= G_KC)) {
         __syncthreads();
-        const int cpr = kcn / 8;  // 16-byte chunks per row
-        for (int e = t; e < BN * cpr; e += G_THREADS) {
-          const int r = e / cpr, c = e - r * cpr;
-          *(uint4 *)&s_w[r * G_LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + kc + c * 8];
-        }
+        fill_w_panel<BN>(s_w, W, K, N, n0, kc, kcn, w_trans, t);
         __syncthreads();
         w_loaded = true;
       }
@@ -791,9 +810,9 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   return (int)((tiles + tpw - 1) / tpw);
 }
 
-extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, long long P, int K, int N,
-                             void *Y, int ldy, int y_f32, int n_store, const float *bias, float *stats_partial,
-                             void *stream) {
+extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P, int K,
+                             int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
+                             float *stats_partial, void *stream) {
   if (P < 0 || K <= 0 || (K & 31) || N <= 0 || (N & 63) || !A || !W || !Y || lda < K || (lda & 7)) return CPFN_EINVAL;
   if (P == 0) return 0;
   if (P > 2000000000LL) return CPFN_EINVAL;
@@ -809,9 +828,9 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   do {                                                                                                               \
     dim3 grid(gx, N / BN_);                                                                                          \
     if (stats_partial)                                                                                               \
-      mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, (int)P, N, y, ldy, stats_partial, tpw); \
+      mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw); \
     else                                                                                                             \
-      mlp_gemm_stream_kernel<BN_, KS_, false><<<grid, G_THREADS, 0, st>>>(a, lda, w, (int)P, N, y, ldy, nullptr, tpw);      \
+      mlp_gemm_stream_kernel<BN_, KS_, false><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, nullptr, tpw);      \
   } while (0)
     if (N % 128 == 0) { if (K == 64) CPFN_STREAM(128, 2); else CPFN_STREAM(128, 4); }
     else              { if (K == 64) CPFN_STREAM(64, 2);  else CPFN_STREAM(64, 4); }
@@ -823,15 +842,15 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   if (wide) {
     dim3 grid(gx, N / 128);
     if (stats_partial)
-      mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
+      mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
     else
-      mlp_gemm_kernel<128, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
+      mlp_gemm_kernel<128, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
   } else {
     dim3 grid(gx, N / 64);
     if (stats_partial)
-      mlp_gemm_kernel<64, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
+      mlp_gemm_kernel<64, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
     else
-      mlp_gemm_kernel<64, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
+      mlp_gemm_kernel<64, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
   }
   return cpfn_launch_status();
 }

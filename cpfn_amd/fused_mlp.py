@@ -18,6 +18,8 @@ The convolution bias is never added: training-mode batch-norm cancels it exactly
 re-enters the running mean), so its gradient is exactly zero rather than the reference's
 rounding noise.
 """
+import weakref
+
 import torch
 
 from . import lib as _l
@@ -35,11 +37,11 @@ def _check(status, what):
 
 
 # ------------------------------------------------------------------ thin launch wrappers
-def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_store=None, P=None):
-    """A [P,K] bf16 (row stride = A.stride(0)), Wb [N,K] bf16 -> Y [P, n_store] (bf16 | fp32)."""
+def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_store=None, P=None, w_trans=False):
+    """A [P,K] bf16 (row stride = A.stride(0)), Wb [N,K] bf16 -> Y [P, n_store] (bf16 | fp32).
+    w_trans: Wb is [K,N] (a forward weight used for the data gradient; transposed inside the kernel)."""
     h = _l.lib()
-    K = Wb.shape[1]
-    N = Wb.shape[0]
+    K, N = (Wb.shape[0], Wb.shape[1]) if w_trans else (Wb.shape[1], Wb.shape[0])
     P = (gidx.numel() if gidx is not None else A.shape[0]) if P is None else P
     n_store = N if n_store is None else n_store
     Y = torch.empty(P, n_store, dtype=torch.float32 if out_f32 else BF16, device=A.device)
@@ -48,7 +50,7 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
     if stats:
         nblk = h.cpfn_mlp_gemm_blocks(P, N)
         part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
-    _check(h.cpfn_mlp_gemm(_ptr(A), A.stride(0), _ptr(gidx), _ptr(Wb), P, K, N, _ptr(Y), n_store, 1 if out_f32 else 0,
+    _check(h.cpfn_mlp_gemm(_ptr(A), A.stride(0), _ptr(gidx), _ptr(Wb), 1 if w_trans else 0, P, K, N, _ptr(Y), n_store, 1 if out_f32 else 0,
                            n_store, _ptr(bias), _ptr(part), _stream()), "cpfn_mlp_gemm")
     # algorithmic traffic of this launch: read A and W once, write Y once (+ the stats partials)
     _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + Y.element_size() * P * n_store + (8 * nblk * N if stats else 0))
@@ -80,6 +82,27 @@ def bn_relu_maxpool(Y, scale, shift, Kn):
     _check(_l.lib().cpfn_bn_relu_maxpool(_ptr(Y), _ptr(scale), _ptr(shift), G, Kn, C, _ptr(out), _ptr(arg), _ptr(yarg),
                                          _stream()), "cpfn_bn_relu_maxpool")
     return out, arg, yarg
+
+
+# ------------------------------------------------------------------ bf16 weight panels
+_wcache = {}
+
+
+def bf16_weight(W, rows, cols):
+    """Persistent zero-padded bf16 panel [rows, cols] of the fp32 weight W (reshaped [n, k]), refreshed
+    with ONE copy kernel per forward pass (instead of zeros + slice-copy, plus a transposed copy for the
+    data gradient).  The refresh is unconditional: fused optimizers update parameters in place without
+    bumping `_version`, so a version check would serve stale weights.  `W` must be the nn.Parameter
+    itself: the entry is tied to that object by a weak reference, so a new model whose parameter happens
+    to reuse a freed id can never hit another model's panel."""
+    key = (id(W), rows, cols)
+    ent = _wcache.get(key)
+    if ent is None or ent[1]() is not W or ent[0].device != W.device:
+        ent = [torch.zeros(rows, cols, dtype=BF16, device=W.device), weakref.ref(W)]
+        _wcache[key] = ent
+    w2 = W.detach().reshape(W.shape[0], -1)
+    ent[0][:w2.shape[0], :w2.shape[1]].copy_(w2)
+    return ent[0]
 
 
 # ------------------------------------------------------------------ the stack
@@ -134,8 +157,7 @@ class _FusedStack(torch.autograd.Function):
                     Wb = None
                 else:
                     Kp = a.shape[1]
-                    Wb = torch.zeros(N, Kp, dtype=BF16, device=dev)
-                    Wb[:, :L.cin] = W.detach().reshape(N, -1)
+                    Wb = bf16_weight(L.weight, N, Kp)
                     Y, part, nblk = gemm(a, Wb, stats=True)
                 if L.training:
                     st = bn_finalize(part, nblk, N, P, L.gamma.detach(), L.beta.detach(),
@@ -222,8 +244,7 @@ class _FusedStack(torch.autograd.Function):
                            "cpfn_mlp_wgrad")
                     grads[3 * li] = dW[:, :L.cin].reshape(wshape)
                     if li > 0 or ctx.x_needs_grad:
-                        WbT = Wb.t().contiguous()                       # [Kp, N]
-                        g, _, _ = gemm(Gy, WbT)
+                        g, _, _ = gemm(Gy, Wb, w_trans=True)            # G_y [P,N] · W [N,Kp]
                         if li == 0:
                             gx = g
         return (gx, None) + tuple(grads)
@@ -272,7 +293,7 @@ class _Linear(torch.autograd.Function):
             dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
             _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, _ptr(ws), _ptr(dW), _stream()),
                    "cpfn_mlp_wgrad")
-            ga, _, _ = gemm(gb, Wb.t().contiguous())
+            ga, _, _ = gemm(gb, Wb, w_trans=True)
         # bias gradient = column sums of g (torch's strided reduce: 0.66 ms, rocBLAS gemv: 0.8 ms for [131072,35])
         gc = g.contiguous().float()
         gbias = torch.empty(N, dtype=torch.float32, device=a.device)

@@ -38,22 +38,44 @@ def get_learning_rate(init_learning_rate, global_step, batch_size, decay_step, d
 
 
 class FlatGradBucket:
-    """All gradients of a module as views into one contiguous fp32 buffer, so the
-    data-parallel exchange is a single all-reduce with no packing copies.  5.6 MB for
-    GlobalSPFN: latency-bound on xGMI, hence one bucket rather than DDP's 25 MB chunks."""
+    """All gradients of a module in one contiguous fp32 buffer, so the data-parallel exchange is a
+    single all-reduce.  5.6 MB for GlobalSPFN: latency-bound on xGMI, hence one bucket rather than
+    DDP's 25 MB chunks.
+
+    Gradients are produced by autograd into fresh tensors (`.grad = None` before the backward pass, so
+    no per-parameter accumulate kernels run), gathered into the flat buffer by ONE multi-tensor copy,
+    and `.grad` is then re-pointed at views of the flat buffer for the all-reduce and the optimizer."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self.zero()
 
     def zero(self):
-        self.flat.zero_()
+        """Call before every backward pass."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        """Call after the backward pass: pack the fresh gradients into the flat buffer.  Parameters that
+        received no gradient (conv biases in front of a training-mode BatchNorm) keep a zero slice and
+        `.grad = None`, which the optimizer skips — identical to a zero update."""
+        src, dst, who = [], [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+                who.append(p)
+        if src:
+            torch._foreach_copy_(dst, src)
+            for p, v in zip(who, dst):
+                p.grad = v
 
     def all_reduce_mean(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -209,6 +231,7 @@ class SPFNTrainer:
             Xn, W, nl, tl, S = st["pre"]
             out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes)
             out[0].backward()
+            self.bucket.collect()
             if world == 1:
                 st["found_inf"] = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
                 self.optimizer.found_inf = st["found_inf"]
@@ -276,6 +299,7 @@ class SPFNTrainer:
         if next_batch is not None:
             self.prefetch(next_batch)
         out[0].backward()
+        self.bucket.collect()
         self.bucket.all_reduce_mean()
         if self.use_graphs:                            # capturable optimizer: skip decided on the device
             self.optimizer.found_inf = (~self.bucket.finite()).float().reshape(())

@@ -180,12 +180,13 @@ CPFN_API int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, voi
  * [N, K] bf16 (row n = output channel); accumulation fp32 (MFMA 16x16x32 bf16). */
 
 /* Y[P,N] = A[P,K] . W[N,K]^T (+bias).  K % 32 == 0, N % 64 == 0, lda % 8 == 0.
+ * w_trans = 1: W is stored [K,N] instead (the forward layer's weight, used as is for the data gradient).
  * gidx (optional): row p of A is A[gidx[p]] (fused neighbour gather).
  * y_f32 = 0: Y is bf16 with row stride ldy; 1: fp32.  Only channels < n_store are stored.
  * stats_partial (optional): [cpfn_mlp_gemm_blocks(P,N)][2][N] fp32 per-block sum(y), sum(y^2). */
 CPFN_API int cpfn_mlp_gemm_blocks(long long P, int N);
-CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, long long P, int K,
-                           int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
+CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
+                           int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
                            float *stats_partial, void *stream);
 /* Batch statistics -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update with
  * torch's momentum / unbiased-variance convention; conv_bias re-enters the running mean). */

@@ -97,9 +97,12 @@ def test_flat_bucket_views_and_finite_check():
     b = training.FlatGradBucket(model)
     assert b.flat.numel() == sum(p.numel() for p in model.parameters())
     model(torch.randn(2, 8, 3))[2].sum().backward()
-    assert float(b.flat.abs().sum()) > 0            # autograd accumulated INTO the flat buffer
+    b.collect()
+    assert float(b.flat.abs().sum()) > 0            # the fresh gradients were packed into the flat buffer
+    used = [p for p in model.parameters() if p.grad is not None]
+    assert used and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(b.params, b.views) if p.grad is not None)
     assert bool(b.finite())
     b.flat[3] = float("nan")
     assert not bool(b.finite())
     b.zero()
-    assert float(b.flat.abs().sum()) == 0 and all(float(p.grad.abs().sum()) == 0 for p in model.parameters())
+    assert all(p.grad is None for p in model.parameters())
