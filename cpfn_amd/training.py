@@ -118,7 +118,7 @@ class SPFNTrainer:
             self.optimizer = torch.optim.Adam(module.parameters(), lr=init_learning_rate,
                                               fused=on_gpu if fused_adam is None else fused_adam)
         self._graph, self._graph_warm = None, 0
-        self._gstream, self._in_gstream = None, False
+        self._gstream, self._in_gstream, self._gside = None, False, None
         self.global_step = 0
         self._bn_momentum = get_batch_norm_decay(0, batch_size, bn_decay_step)
         self._lr = get_learning_rate(init_learning_rate, 0, batch_size, decay_step, decay_rate)
@@ -204,30 +204,82 @@ class SPFNTrainer:
 
     # ---- hipGraph replay of the step -----------------------------------------------------------
     # At 16 clouds per GPU the step is ~560 launches and host-bound (~7 ms of CPU for ~6.5 ms of GPU
-    # work).  The step is captured once into two graphs split at its single host round trip (the
-    # Hungarian assignment): G1 = geometry + network forward + heads post-processing + segmented
-    # sums; host SciPy; G2 = matched losses, fitters, full backward, finite flag, fused Adam.
+    # work).  The step is captured once into graphs split at its single host round trip (the
+    # Hungarian assignment):
+    #   G1 = (geometry buffers B -> A) + network forward + heads post-processing + segmented sums
+    #        host: SciPy assignment
+    #   G2 = matched losses, fitters, full backward, gradient packing, finite flag, fused Adam
+    #        || side branch: FPS / ball query / 3-NN of the NEXT batch into geometry buffers B
+    #   G0 = the geometry pass alone (only replayed when the next batch was not announced)
+    # The geometry of a batch depends on its coordinates only, so computing it one step ahead inside
+    # G2 hides the 0.7 ms FPS latency chain (16 workgroups) behind the backward pass.
+    @staticmethod
+    def _flatten_geom(g):
+        out = []
+        for lvl in ("sa1", "sa2"):
+            out += [g[lvl]["fps_idx"], g[lvl]["new_xyz"]]
+            for nbr, rel in g[lvl]["scales"]:
+                out += [nbr, rel]
+        for lvl in ("sfp2", "sfp3"):
+            out += [g[lvl]["nn_idx"], g[lvl]["nn_w"]]
+        return out
+
+    @staticmethod
+    def _like_geom(g, tensors):
+        it = iter(tensors)
+        out = {}
+        for lvl in ("sa1", "sa2"):
+            d = {"fps_idx": next(it), "new_xyz": next(it), "scales": []}
+            for _ in g[lvl]["scales"]:
+                d["scales"].append((next(it), next(it)))
+            out[lvl] = d
+        for lvl in ("sfp2", "sfp3"):
+            out[lvl] = {"nn_idx": next(it), "nn_w": next(it)}
+        return out
+
     def _capture(self, batch):
         from .SPFN import fused_losses as fl
         dev = batch["P"].device
         B, N, _ = batch["P"].shape
         K = batch["T_gt"].shape[1]
         st = {"batch": {k: v.clone() for k, v in batch.items()},
+              "P_next": batch["P"].clone(),
               "start1": torch.zeros(B, dtype=torch.int32, device=dev),
               "start2": torch.zeros(B, dtype=torch.int32, device=dev),
               "match": torch.zeros(B, K, dtype=torch.long, device=dev),
               "skipped": torch.zeros((), dtype=torch.float32, device=dev)}
         sb = st["batch"]
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        starts = (st["start1"], st["start2"])
+        # static geometry buffers (shapes from one eager pass)
+        g_example = self.module.compute_geometry(sb["P"], starts)
+        geomB = [t.clone() for t in self._flatten_geom(g_example)]
+        geomA = [t.clone() for t in geomB]
+        st["geomA"] = self._like_geom(g_example, geomA)
+        st["geomB"] = geomB
+        if self._gside is None:
+            self._gside = torch.cuda.Stream(device=dev)
+
+        def geometry_into_B(P):
+            fresh = self._flatten_geom(self.module.compute_geometry(P, starts))
+            torch._foreach_copy_(geomB, fresh)
+
         # capture on the same side stream the eager warm-up steps ran on, so that the parameters'
         # AccumulateGrad nodes do not belong to the default stream (which cannot take part in a capture)
+        g0 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g0, stream=self._gstream):
+            geometry_into_B(sb["P"])
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, stream=self._gstream):
+        with torch.cuda.graph(g1, pool=g0.pool(), stream=self._gstream):
+            torch._foreach_copy_(geomA, geomB)
             self.bucket.zero()
-            self.module(sb["P"], fps_start=(st["start1"], st["start2"]))
+            self.module(sb["P"], geometry=st["geomA"])
             st["pre"] = fl.pre_match(self.module.heads_packed, sb)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g1.pool(), stream=self._gstream):
+        with torch.cuda.graph(g2, pool=g0.pool(), stream=self._gstream):
+            self._gside.wait_stream(self._gstream)                  # fork: next batch's geometry
+            with torch.cuda.stream(self._gside):
+                geometry_into_B(st["P_next"])
             Xn, W, nl, tl, S = st["pre"]
             out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes)
             out[0].backward()
@@ -238,21 +290,43 @@ class SPFNTrainer:
                 self.optimizer.step()
                 st["skipped"] += st["found_inf"]
             st["out"] = tuple(o.detach() for o in out)
-        st["g1"], st["g2"], st["world"] = g1, g2, world
+            self._gstream.wait_stream(self._gside)                  # join
+        st["g0"], st["g1"], st["g2"], st["world"] = g0, g1, g2, world
+        st["geom_ready_for"] = None
         return st
 
-    def _graph_step(self, batch):
+    def _draw_starts(self, st, B, N):
+        # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order
+        st["start1"].copy_(torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32), non_blocking=True)
+        st["start2"].copy_(torch.randint(0, self.module.sa1.num_points, (B,), dtype=torch.long).to(torch.int32),
+                           non_blocking=True)
+
+    def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
         st = self._graph
         for k, v in batch.items():
             if v.data_ptr() != st["batch"][k].data_ptr():
                 st["batch"][k].copy_(v, non_blocking=True)
         B, N, _ = batch["P"].shape
-        # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order
-        st["start1"].copy_(torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32), non_blocking=True)
-        st["start2"].copy_(torch.randint(0, self.module.sa1.num_points, (B,), dtype=torch.long).to(torch.int32),
-                           non_blocking=True)
+        if self._prefetched is not None:                       # geometry prefetched by an eager (warm-up) step
+            geom = self._take_prefetched(batch["P"])
+            if geom is not None:
+                torch._foreach_copy_(st["geomB"], self._flatten_geom(geom))
+                st["geom_ready_for"] = batch["P"].data_ptr()
+        if st["geom_ready_for"] != batch["P"].data_ptr():      # not announced one step ahead: do it now
+            self._draw_starts(st, B, N)
+            st["g0"].replay()
         st["g1"].replay()
+        # inputs of the geometry branch inside G2: the NEXT batch's coordinates and FPS seeds
+        # (without an announced next batch the branch recomputes stale inputs; its result is ignored and
+        #  no FPS seeds are drawn, so the CPU generator is consumed exactly as in eager mode)
+        if next_batch is not None:
+            if next_batch["P"].data_ptr() != st["P_next"].data_ptr():
+                st["P_next"].copy_(next_batch["P"], non_blocking=True)
+            self._draw_starts(st, B, N)
+            st["geom_ready_for"] = next_batch["P"].data_ptr()
+        else:
+            st["geom_ready_for"] = None
         st["match"].copy_(fl.hungarian_from_stats(st["pre"][4].detach(), st["batch"]["I_gt"]))
         st["g2"].replay()
         if st["world"] > 1:
@@ -277,7 +351,7 @@ class SPFNTrainer:
             self._in_gstream = True
             try:
                 with torch.cuda.stream(self._gstream):
-                    out = self.step(batch, None, None)
+                    out = self.step(batch, None, next_batch)
             finally:
                 self._in_gstream = False
             cur.wait_stream(self._gstream)
@@ -292,7 +366,7 @@ class SPFNTrainer:
                     self.use_graphs = False
                     torch.cuda.synchronize()
             if self._graph is not None:
-                return self._graph_step(batch)
+                return self._graph_step(batch, next_batch)
             self._graph_warm += 1
         self.bucket.zero()
         out = self.losses(batch, fps_start)
