@@ -72,8 +72,13 @@ class PointsetAbstraction(nn.Module):
             for (nbr, rel), k in zip(geom["scales"], self.num_samples_list):
                 aux["ball_idx"] = nbr
                 if feats is not None:
-                    gf = autograd_ops.gather_rows(feats, nbr)                             # [B,S,K,D]
-                    x = torch.cat([gf, rel.to(gf.dtype)], dim=3).reshape(B * S * k, -1)   # feats FIRST (ref :66)
+                    D = feats.shape[2]
+                    if cd == torch.bfloat16 and feats.is_cuda and feats.dtype == torch.bfloat16 and D % 8 == 0 and N <= 1024:
+                        # gather + centred coordinates + zero padding to the GEMM's K, one kernel (feats FIRST, ref :66)
+                        x = autograd_ops.GroupConcat.apply(feats, rel, nbr, (D + 3 + 63) // 64 * 64)
+                    else:
+                        gf = autograd_ops.gather_rows(feats, nbr)                         # [B,S,K,D]
+                        x = torch.cat([gf, rel.to(gf.dtype)], dim=3).reshape(B * S * k, -1)
                     groups.append((x, None, S, k))
                 else:
                     groups.append((None, rel.reshape(B * S * k, 3), S, k))

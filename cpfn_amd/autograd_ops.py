@@ -1,7 +1,9 @@
 """torch.autograd wrappers around the points-major HIP data movers."""
 import torch
 
+from . import lib as _l
 from . import ops
+from .ops import _ptr, _stream
 
 
 class GatherRows(torch.autograd.Function):
@@ -37,5 +39,68 @@ class InterpRows(torch.autograd.Function):
         return ops.interp_rows_bwd(g.contiguous().float(), idx, w, ctx.m).to(ctx.in_dtype), None, None
 
 
+def _scatter_bf16(g, ldg, idx, w, T, B, R, M, C):
+    """LDS-privatised scatter-add of bf16 rows into a zero-filled fp32 [B,M,C] target (M <= 1024)."""
+    out = torch.zeros(B, M, C, dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _l.check(_l.lib().cpfn_scatter_rows_bf16(_ptr(g), ldg, _ptr(idx), _ptr(w), T, B, R, M, C, _ptr(out), _stream()),
+                 "cpfn_scatter_rows_bf16")
+    return out
+
+
+class InterpRowsBf16(torch.autograd.Function):
+    """bf16 feats [B,M,C] (C % 8 == 0, M <= 1024), idx/w [B,N,3] -> bf16 [B,N,C]."""
+
+    @staticmethod
+    def forward(ctx, feats, idx, w):
+        B, M, C = feats.shape
+        N = idx.shape[1]
+        f = feats.contiguous()
+        out = torch.empty(B, N, C, dtype=torch.bfloat16, device=f.device)
+        with torch.cuda.device(f.device):
+            _l.check(_l.lib().cpfn_interp_rows_bf16(_ptr(f), _ptr(idx), _ptr(w), B, M, N, C, _ptr(out), _stream()),
+                     "cpfn_interp_rows_bf16")
+        ctx.save_for_backward(idx, w)
+        ctx.dims = (B, M, N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, w = ctx.saved_tensors
+        B, M, N, C = ctx.dims
+        g = g.contiguous().to(torch.bfloat16)
+        return _scatter_bf16(g, C, idx, w, 3, B, N, M, C).to(torch.bfloat16), None, None
+
+
+class GroupConcat(torch.autograd.Function):
+    """Grouped set-abstraction input rows in one pass (modules/pointset_abstraction.py:62-66):
+    out[p] = [feats[b, idx[p], :C] | rel[p, :3] | zeros] as bf16 [B*S*K, Cpad]."""
+
+    @staticmethod
+    def forward(ctx, feats, rel, idx, cpad):
+        B, N, C = feats.shape
+        R = idx[0].numel()
+        f = feats.contiguous()
+        out = torch.empty(B * R, cpad, dtype=torch.bfloat16, device=f.device)
+        with torch.cuda.device(f.device):
+            _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
+                                                     _stream()), "cpfn_group_concat_bf16")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, R, C, cpad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, R, C, cpad = ctx.dims
+        g = g.contiguous().to(torch.bfloat16)
+        return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None
+
+
+def interp_rows(feats, idx, w):
+    if feats.dtype == torch.bfloat16 and feats.is_cuda and feats.shape[2] % 8 == 0 and feats.shape[1] <= 1024:
+        return InterpRowsBf16.apply(feats, idx, w)
+    return InterpRows.apply(feats, idx, w)
+
+
 gather_rows = GatherRows.apply
-interp_rows = InterpRows.apply

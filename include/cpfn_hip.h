@@ -126,6 +126,19 @@ CPFN_API int cpfn_interp_rows_fwd(const float *feats, const int *idx, const floa
 CPFN_API int cpfn_interp_rows_bwd(const float *grad_out, const int *idx, const float *w, int B,
                          int M, int N, int C, float *grad_feats, void *stream);
 
+/* bf16 row movers used by the fused MLP path (same semantics as the fp32 entry points above):
+ * interpolation feats[B,M,C] -> out[B,N,C];  its adjoint and the gather adjoint as one LDS-privatised
+ * scatter-add  out[b, idx[b,r,t], :] += w[b,r,t] * g[b,r,:]  (g bf16 with row stride ldg, T in 1..3,
+ * w may be NULL for T = 1, out fp32 [B,M,C] zero-filled by the caller, M <= 1024);
+ * and the grouped sa-level input rows  out[p] = [feats[idx[p]] (C) | rel xyz (3) | zeros] of width Cpad
+ * (modules/pointset_abstraction.py:62-66). */
+CPFN_API int cpfn_interp_rows_bf16(const void *feats, const int *idx, const float *w, int B, int M, int N,
+                                   int C, void *out, void *stream);
+CPFN_API int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, const float *w, int T, int B,
+                                    int R, int M, int C, float *out, void *stream);
+CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const int *idx, int B, int N, int R,
+                                    int C, int Cpad, void *out, void *stream);
+
 /* ------------------------------------------------------------------ SPFN fitters
  * One pass over P[B,N,3], X[B,N,3] (unit normals), W[B,N,K] (soft memberships) yields every
  * weighted sum the four primitive fitters need.  Replaces the tiled [B*K,N,3] /

@@ -163,3 +163,41 @@ def test_points_major_ops_vs_oracle():
     gb = ops.interp_rows_bwd(T(o), T(nn, torch.int32), T(w), S).cpu().numpy()
     wb = og.three_weighted_sum_grad(np.ascontiguousarray(o.transpose(0, 2, 1)), nn, w, S).transpose(0, 2, 1)
     np.testing.assert_allclose(gb, wb, rtol=1e-4, atol=1e-4)
+
+
+def test_bf16_row_movers_vs_oracle():
+    """bf16 interpolation, its LDS-privatised scatter adjoint, and the fused grouped-input rows."""
+    from cpfn_amd import autograd_ops
+    rng = np.random.default_rng(11)
+    B, M, N, C = 2, 300, 2500, 64
+    feats = torch.from_numpy(rng.normal(size=(B, M, C)).astype(np.float32)).to(torch.bfloat16)
+    nn = rng.integers(0, M, (B, N, 3))
+    w = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    f_dev = feats.to(dev()).requires_grad_(True)
+    out = autograd_ops.interp_rows(f_dev, T(nn, torch.int32), T(w))
+    assert out.dtype == torch.bfloat16
+    f32 = feats.float().numpy()
+    want = og.three_weighted_sum(f32.transpose(0, 2, 1), nn, w).transpose(0, 2, 1)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=1e-2, atol=2e-2)
+    g = torch.from_numpy(rng.normal(size=(B, N, C)).astype(np.float32)).to(torch.bfloat16)
+    out.backward(g.to(dev()))
+    wantg = og.three_weighted_sum_grad(np.ascontiguousarray(g.float().numpy().transpose(0, 2, 1)), nn, w, M).transpose(0, 2, 1)
+    got = f_dev.grad.float().cpu().numpy()
+    assert np.abs(got - wantg).max() <= 2e-2 * np.abs(wantg).max()
+    # grouped input rows: [gathered feats | rel xyz | zero pad], and the gather adjoint
+    S, K = 40, 16
+    idx = rng.integers(0, M, (B, S, K))
+    rel = rng.normal(size=(B, S, K, 3)).astype(np.float32)
+    f2 = feats.to(dev()).requires_grad_(True)
+    x = autograd_ops.GroupConcat.apply(f2, T(rel), T(idx, torch.int32), 128)
+    assert x.shape == (B * S * K, 128) and x.dtype == torch.bfloat16
+    xs = x.float().cpu().numpy().reshape(B, S, K, 128)
+    gathered = og.group_points(f32.transpose(0, 2, 1), idx).transpose(0, 2, 3, 1)
+    assert np.array_equal(xs[..., :C], gathered)
+    np.testing.assert_allclose(xs[..., C:C + 3], rel, rtol=1e-2, atol=1e-3)
+    assert not xs[..., C + 3:].any()
+    gx = torch.from_numpy(rng.normal(size=(B * S * K, 128)).astype(np.float32)).to(torch.bfloat16)
+    x.backward(gx.to(dev()))
+    wantgg = og.group_points_grad(np.ascontiguousarray(gx.float().numpy().reshape(B, S, K, 128)[..., :C].transpose(0, 3, 1, 2)), idx, M).transpose(0, 2, 1)
+    gotg = f2.grad.float().cpu().numpy()
+    assert np.abs(gotg - wantgg).max() <= 2e-2 * np.abs(wantgg).max()
