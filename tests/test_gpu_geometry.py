@@ -178,7 +178,7 @@ def test_bf16_row_movers_vs_oracle():
     assert out.dtype == torch.bfloat16
     f32 = feats.float().numpy()
     want = og.three_weighted_sum(f32.transpose(0, 2, 1), nn, w).transpose(0, 2, 1)
-    np.testing.assert_allclose(out.float().cpu().numpy(), want, rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), want, rtol=1e-2, atol=2e-2)
     g = torch.from_numpy(rng.normal(size=(B, N, C)).astype(np.float32)).to(torch.bfloat16)
     out.backward(g.to(dev()))
     wantg = og.three_weighted_sum_grad(np.ascontiguousarray(g.float().numpy().transpose(0, 2, 1)), nn, w, M).transpose(0, 2, 1)
@@ -191,7 +191,7 @@ def test_bf16_row_movers_vs_oracle():
     f2 = feats.to(dev()).requires_grad_(True)
     x = autograd_ops.GroupConcat.apply(f2, T(rel), T(idx, torch.int32), 128)
     assert x.shape == (B * S * K, 128) and x.dtype == torch.bfloat16
-    xs = x.float().cpu().numpy().reshape(B, S, K, 128)
+    xs = x.detach().float().cpu().numpy().reshape(B, S, K, 128)
     gathered = og.group_points(f32.transpose(0, 2, 1), idx).transpose(0, 2, 3, 1)
     assert np.array_equal(xs[..., :C], gathered)
     np.testing.assert_allclose(xs[..., C:C + 3], rel, rtol=1e-2, atol=1e-3)
