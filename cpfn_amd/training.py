@@ -266,17 +266,19 @@ class SPFNTrainer:
 
         # capture on the same side stream the eager warm-up steps ran on, so that the parameters'
         # AccumulateGrad nodes do not belong to the default stream (which cannot take part in a capture)
+        # capture_error_mode="thread_local": other threads (e.g. the RCCL watchdog of a data-parallel job)
+        # may touch the HIP API while this thread captures
         g0 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g0, stream=self._gstream):
+        with torch.cuda.graph(g0, stream=self._gstream, capture_error_mode="thread_local"):
             geometry_into_B(sb["P"])
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, pool=g0.pool(), stream=self._gstream):
+        with torch.cuda.graph(g1, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
             torch._foreach_copy_(geomA, geomB)
             self.bucket.zero()
             self.module(sb["P"], geometry=st["geomA"])
             st["pre"] = fl.pre_match(self.module.heads_packed, sb)
         g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g0.pool(), stream=self._gstream):
+        with torch.cuda.graph(g2, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
             self._gside.wait_stream(self._gstream)                  # fork: next batch's geometry
             with torch.cuda.stream(self._gside):
                 geometry_into_B(st["P_next"])
