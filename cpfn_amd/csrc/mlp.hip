@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
           a1[j] += gz;
           a2[j] = fmaf(gz, yv, a2[j]);
         }
-        *(uint4 *)(Gz + r * C + c0) = *(const uint4 *)o;
+        if (Gz) *(uint4 *)(Gz + r * C + c0) = *(const uint4 *)o;
       }
     }
     __syncthreads();
@@ -527,9 +527,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
 }
 
 // g_y[p,c] = s·g_z + c2·y + c3   (dense).  Gy may alias Gz.
+// With scale/shift given, Gz is really g_a and the ReLU mask [scale·y+shift > 0] is recomputed here, so the
+// reduction pass (bn_relu_bwd) does not have to write the masked gradient at all.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short *__restrict__ Gz,
                                                            const unsigned short *__restrict__ Yr,
-                                                           const float *__restrict__ coef, long long total8,
+                                                           const float *__restrict__ coef,
+                                                           const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, long long total8,
                                                            int C, unsigned short *__restrict__ Gy) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total8) return;
@@ -539,8 +543,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short 
   const unsigned short *g = (const unsigned short *)&rg, *y = (const unsigned short *)&ry;
   unsigned short o[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    o[j] = f2bf(fmaf(coef[c0 + j], bf2f(g[j]), fmaf(coef[C + c0 + j], bf2f(y[j]), coef[2 * C + c0 + j])));
+  for (int j = 0; j < 8; ++j) {
+    const float yv = bf2f(y[j]);
+    float gz = bf2f(g[j]);
+    if (scale) gz = fmaf(scale[c0 + j], yv, shift[c0 + j]) > 0.f ? gz : 0.f;
+    o[j] = f2bf(fmaf(coef[c0 + j], gz, fmaf(coef[C + c0 + j], yv, coef[2 * C + c0 + j])));
+  }
   *(uint4 *)(Gy + e * 8) = *(const uint4 *)o;
 }
 
@@ -890,7 +898,7 @@ extern "C" int cpfn_bn_bwd_blocks(long long P) { return (int)((P + R_ROWS - 1) /
 
 extern "C" int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift, long long P,
                                 int C, void *Gz, float *partial, void *stream) {
-  if (P <= 0 || C <= 0 || (C & 7) || !pow2(C / 8) || !Ga || !Y || !scale || !shift || !Gz || !partial) return CPFN_EINVAL;
+  if (P <= 0 || C <= 0 || (C & 7) || !pow2(C / 8) || !Ga || !Y || !scale || !shift || !partial) return CPFN_EINVAL;
   bn_relu_bwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
       (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial);
   return cpfn_launch_status();
@@ -915,12 +923,12 @@ extern "C" int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, long long P, int C, void *Gy,
-                                 void *stream) {
-  if (P <= 0 || C <= 0 || (C & 7) || !Gz || !Y || !coef || !Gy) return CPFN_EINVAL;
+extern "C" int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, const float *scale,
+                                 const float *shift, long long P, int C, void *Gy, void *stream) {
+  if (P <= 0 || C <= 0 || (C & 7) || !Gz || !Y || !coef || !Gy || (!scale != !shift)) return CPFN_EINVAL;
   const long long total8 = P * C / 8;
   bn_bwd_apply_kernel<<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
-      (const unsigned short *)Gz, (const unsigned short *)Y, coef, total8, C, (unsigned short *)Gy);
+      (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy);
   return cpfn_launch_status();
 }
 

@@ -214,7 +214,8 @@ CPFN_API int cpfn_bn_relu_apply(const void *Y, const float *scale, const float *
  * attaining it (u8), yarg = raw y there.  C >= 64, C/8 a power of two. */
 CPFN_API int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const float *shift, int G, int Kn,
                                   int C, void *out, unsigned char *arg, void *yarg, void *stream);
-/* Backward pass 1: Gz = Ga*[z>0] (may alias Ga); partial[cpfn_bn_bwd_blocks(P)][2][C] = sum(Gz), sum(Gz*y). */
+/* Backward pass 1: partial[cpfn_bn_bwd_blocks(P)][2][C] = sum(Gz), sum(Gz*y) with Gz = Ga*[z>0];
+ * Gz is also stored when the pointer is non-NULL (may alias Ga). */
 CPFN_API int cpfn_bn_bwd_blocks(long long P);
 CPFN_API int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift,
                               long long P, int C, void *Gz, float *partial, void *stream);
@@ -225,8 +226,10 @@ CPFN_API int cpfn_bn_pool_bwd_reduce(const void *Gp, const void *yarg, const flo
 CPFN_API int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float count, const float *gamma,
                                   const float *mean, const float *rstd, int training, float *dgamma,
                                   float *dbeta, float *coef, void *stream);
-CPFN_API int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, long long P, int C,
-                               void *Gy, void *stream);
+/* g_y = coef0*g_z + coef1*y + coef2.  With scale/shift non-NULL the first argument is g_a and the ReLU
+ * mask [scale*y+shift > 0] is recomputed (pass 1 then need not store g_z). */
+CPFN_API int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, const float *scale,
+                               const float *shift, long long P, int C, void *Gy, void *stream);
 CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, const void *yarg,
                                     const void *Y, const float *scale, const float *shift,
                                     const float *coef, int G, int Kn, int C, void *Gy, void *stream);

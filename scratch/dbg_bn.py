@@ -24,5 +24,5 @@ print('Gz', rel(Gy, gz_ref), 'S1', rel(part[:,0].sum(0), gz_ref.sum(0)), 'S2', r
 dgb = torch.empty(2, C, device=dev); coef = torch.empty(3, C, device=dev)
 _l.check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, C, float(P), _ptr(gamma), _ptr(mean), _ptr(rstd), 1, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()), 'b')
 print('dgamma', rel(dgb[0], g_.grad), 'dbeta', rel(dgb[1], b_.grad))
-_l.check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), P, C, _ptr(Gy), _stream()), 'c')
+_l.check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), None, None, P, C, _ptr(Gy), _stream()), "c")
 print('Gy', rel(Gy, y.grad))
