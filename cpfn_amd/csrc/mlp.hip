@@ -88,11 +88,20 @@ __device__ __forceinline__ void stream_load_a(bf16x8 (&af)[2][KS], const unsigne
   }
 }
 
+// Sum over the 16 lanes of a DPP row (lanes that share lane>>4): every lane ends up with the total.
+// quad_perm xor-1, quad_perm xor-2, row_half_mirror, row_mirror — four VALU adds, no LDS traffic.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 template <int BN, int KS, bool STATS>
 __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
-                                            int row0, int n0, int wave, int lane, f32x4 (&s1)[BN / 16],
-                                            f32x4 (&s2)[BN / 16]) {
+                                            int row0, int n0, int wave, int lane, float *s_stat /*[2][BN], this wave's*/) {
   constexpr int NT = BN / 16;
   const int lr = lane & 15, lq = lane >> 4;
   f32x4 acc[NT][2];
@@ -107,13 +116,29 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const uns
       acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[nt][1], 0, 0, 0);
     }
   }
+  if (STATS) {
+    // per-channel Σy, Σy² of this wave's 32 points: per-lane sum over the two point tiles, DPP sum over
+    // the 16 point lanes of a row, then ONE lane per row adds 4 channels to the wave's LDS accumulators
+    // (instead of 2 x BN/4 persistent registers per lane: the stats variant no longer sits at 256 VGPRs)
+    const float m0 = (row0 + wave * 32 + lr < P) ? 1.f : 0.f, m1 = (row0 + wave * 32 + 16 + lr < P) ? 1.f : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 a = acc[nt][0] * m0, b = acc[nt][1] * m1;
+      f32x4 sm = a + b, sq = a * a + b * b;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
+      if (lr == 0) {
+        f32x4 *p0 = (f32x4 *)&s_stat[nt * 16 + 4 * lq], *p1 = (f32x4 *)&s_stat[BN + nt * 16 + 4 * lq];
+        *p0 = *p0 + sm;
+        *p1 = *p1 + sq;
+      }
+    }
+  }
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
-    const bool valid = row0 + wave * 32 + tt * 16 + lr < P;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const f32x4 v = acc[nt][tt];
-      if (STATS && valid) { s1[nt] += v; s2[nt] += v * v; }
       bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
       *(bf16x4 *)&s_o[(tt * 16 + lr) * G_LDO + nt * 16 + 4 * lq] = o;
     }
@@ -140,9 +165,9 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
-  f32x4 s1[NT], s2[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i) { s1[i] = (f32x4){0, 0, 0, 0}; s2[i] = (f32x4){0, 0, 0, 0}; }
+  if (STATS) {
+    for (int e = t; e < 4 * 2 * BN; e += G_THREADS) (&s_red[0][0][0])[e] = 0.f;   // visible after the W-panel barrier
+  }
   const int ntiles = (P + G_ROWS - 1) / G_ROWS;
   const int tile0 = blockIdx.x * tiles_per_wg;
   const int tile_end = min(tile0 + tiles_per_wg, ntiles);
@@ -154,23 +179,13 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
     for (int tile = tile0; tile < tile_end; tile += 2) {
       // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
       stream_load_a<KS>(a1, A, lda, P, min(tile + 1, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, s1, s2);
+      stream_tile<BN, KS, STATS>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, &s_red[wave][0][0]);
       if (tile + 1 >= tile_end) break;
       stream_load_a<KS>(a0, A, lda, P, min(tile + 2, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, s1, s2);
+      stream_tile<BN, KS, STATS>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, &s_red[wave][0][0]);
     }
   }
   if (STATS) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s1[nt][r], b = s2[nt][r];
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-        if (lr == 0) { s_red[wave][0][nt * 16 + 4 * lq + r] = a; s_red[wave][1][nt * 16 + 4 * lq + r] = b; }
-      }
-    }
     __syncthreads();
     for (int e = t; e < 2 * BN; e += G_THREADS) {
       const int which = e / BN, c = e - which * BN;
