@@ -56,6 +56,11 @@ class PointNet2(torch.nn.Module):
                 "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"])}
 
     def forward(self, x, glob_features=None, loc_features=None, fast=True, fps_start=None, geometry=None):
+        from .. import fused_mlp
+        with fused_mlp.deferred_bn_counters():
+            return self._forward(x, glob_features, loc_features, fps_start, geometry)
+
+    def _forward(self, x, glob_features, loc_features, fps_start, geometry):
         """`fps_start` = optional (start_sa1 [B], start_sa2 [B]) FPS seeds; by default each SA
         level draws its own from the CPU generator like the reference's CPU route."""
         B, N, _ = x.shape

@@ -116,21 +116,32 @@ class ResidueLoss(torch.autograd.Function):
         return gp, None, None, None, None, None
 
 
-def hungarian_from_stats(S, I_gt):
-    """Relaxed-IoU cost of every (GT label, prediction) pair from the segmented sums, SciPy
-    assignment on the host (reference lines 11-30) — one device->host copy for the whole batch."""
+def hungarian_cost_pack(S, I_gt):
+    """Device part of the assignment: relaxed-IoU cost of every (GT label, prediction) pair from the
+    segmented sums plus the number of GT labels, packed as one [B, K*K+1] tensor (reference lines 19-25).
+    Capturable; `hungarian_from_pack` is the host part."""
     B, K2, K = S.shape
     D, col, cnt = S[:, :K], S[:, K], S[:, K + 1]
     den = cnt.unsqueeze(2) + col.unsqueeze(1) - D
     cost = D / den.clamp(min=1e-10)
     n_gt = I_gt.max(dim=1)[0] + 1
-    pack = torch.cat([cost.reshape(B, -1), n_gt.unsqueeze(1).to(cost.dtype)], dim=1).cpu().numpy()
+    return torch.cat([cost.reshape(B, -1), n_gt.unsqueeze(1).to(cost.dtype)], dim=1)
+
+
+def hungarian_from_pack(pack, K):
+    """Host part: ONE device->host copy for the whole batch, SciPy assignment per cloud (reference :27)."""
+    h = pack.cpu().numpy()
+    B = h.shape[0]
     match = torch.zeros(B, K, dtype=torch.long)
     for b in range(B):
-        n = int(pack[b, -1])
-        _, c = linear_sum_assignment(-pack[b, :-1].reshape(K, K)[:n])
+        n = int(h[b, -1])
+        _, c = linear_sum_assignment(-h[b, :-1].reshape(K, K)[:n])
         match[b, :n] = torch.from_numpy(c)
-    return match.to(S.device)
+    return match.to(pack.device)
+
+
+def hungarian_from_stats(S, I_gt):
+    return hungarian_from_pack(hungarian_cost_pack(S, I_gt), S.shape[2])
 
 
 def pre_match(Y, batch):

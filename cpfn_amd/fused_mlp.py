@@ -125,9 +125,32 @@ def _layers_from_modules(convs, bns):
         L.training = bn.training
         L.cout, L.cin = conv.weight.shape[0], conv.weight.shape[1]
         if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            if _defer_counters is not None:
+                _defer_counters.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
         out.append(L)
     return out
+
+
+_defer_counters = None
+
+
+class deferred_bn_counters:
+    """Context manager: collect the `num_batches_tracked += 1` of every BatchNorm touched inside and apply
+    them with ONE multi-tensor add on exit (17 tiny kernels -> 1 per forward pass)."""
+
+    def __enter__(self):
+        global _defer_counters
+        self._prev, _defer_counters = _defer_counters, []
+        return self
+
+    def __exit__(self, *exc):
+        global _defer_counters
+        todo, _defer_counters = _defer_counters, self._prev
+        if todo:
+            torch._foreach_add_(todo, 1)
+        return False
 
 
 class _FusedStack(torch.autograd.Function):

@@ -277,6 +277,7 @@ class SPFNTrainer:
             self.bucket.zero()
             self.module(sb["P"], geometry=st["geomA"])
             st["pre"] = fl.pre_match(self.module.heads_packed, sb)
+            st["cost_pack"] = fl.hungarian_cost_pack(st["pre"][4].detach(), sb["I_gt"])   # device part, in-graph
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
             self._gside.wait_stream(self._gstream)                  # fork: next batch's geometry
@@ -329,7 +330,7 @@ class SPFNTrainer:
             st["geom_ready_for"] = next_batch["P"].data_ptr()
         else:
             st["geom_ready_for"] = None
-        st["match"].copy_(fl.hungarian_from_stats(st["pre"][4].detach(), st["batch"]["I_gt"]))
+        st["match"].copy_(fl.hungarian_from_pack(st["cost_pack"], st["match"].shape[1]))   # the step's one host sync
         st["g2"].replay()
         if st["world"] > 1:
             self.bucket.all_reduce_mean()
