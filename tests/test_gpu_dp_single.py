@@ -1,0 +1,25 @@
+"""GPU: the data-parallel launch path of the graph-replayed trainer on ONE device — an RCCL process group
+of size 1 with the world size spoofed to 2, so the 'all-reduce outside the graphs + eager capturable Adam'
+branch of SPFNTrainer runs for real (a true multi-GPU run needs a multi-GPU node; the driver does that
+with bench.py).  Runs in a subprocess so the process group does not leak into other tests."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(600)
+def test_graph_trainer_with_rccl_group():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_graph_smoke.py")], capture_output=True,
+                       text=True, env=env, timeout=540)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("graph captured")][-1]
+    assert "graph captured: True" in line and "world in graph: 2" in line and "skipped 0.0" in line, line
+    first, last = [float(x) for x in line.split("loss")[1].split("skipped")[0].replace("->", " ").split()]
+    assert last < 0.75 * first, line

@@ -1,7 +1,7 @@
 # single-GPU smoke of the data-parallel graph path: NCCL(RCCL) group of size 1, world-size spoofed to 2
-import os, sys, contextlib, io; sys.path.insert(0, '.')
+import os, sys, contextlib, io; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from cpfn_amd import synthetic, training
 from cpfn_amd.PointNet2 import pn2_network
