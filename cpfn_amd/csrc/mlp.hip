@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
 // g_y[p,c] = s·g_z + c2·y + c3   (dense).  Gy may alias Gz.
 // With scale/shift given, Gz is really g_a and the ReLU mask [scale·y+shift > 0] is recomputed here, so the
 // reduction pass (bn_relu_bwd) does not have to write the masked gradient at all.
+template <bool MASK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short *__restrict__ Gz,
                                                            const unsigned short *__restrict__ Yr,
                                                            const float *__restrict__ coef,
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short 
   for (int j = 0; j < 8; ++j) {
     const float yv = bf2f(y[j]);
     float gz = bf2f(g[j]);
-    if (scale) gz = fmaf(scale[c0 + j], yv, shift[c0 + j]) > 0.f ? gz : 0.f;
+    if (MASK) gz = fmaf(scale[c0 + j], yv, shift[c0 + j]) > 0.f ? gz : 0.f;
     o[j] = f2bf(fmaf(coef[c0 + j], gz, fmaf(coef[C + c0 + j], yv, coef[2 * C + c0 + j])));
   }
   *(uint4 *)(Gy + e * 8) = *(const uint4 *)o;
@@ -942,8 +943,12 @@ extern "C" int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coe
                                  const float *shift, long long P, int C, void *Gy, void *stream) {
   if (P <= 0 || C <= 0 || (C & 7) || !Gz || !Y || !coef || !Gy || (!scale != !shift)) return CPFN_EINVAL;
   const long long total8 = P * C / 8;
-  bn_bwd_apply_kernel<<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
-      (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy);
+  if (scale)
+    bn_bwd_apply_kernel<true><<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
+        (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy);
+  else
+    bn_bwd_apply_kernel<false><<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
+        (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy);
   return cpfn_launch_status();
 }
 
