@@ -20,6 +20,7 @@ class PointsetAbstraction(nn.Module):
         seq = lambda v: list(v) if isinstance(v, Sequence) else [v]
         self.num_points = num_points
         self.group_all = group_all
+        self.has_feats = dim_feats > 0
         self.radius_list = seq(radius_list)
         self.num_samples_list = seq(num_samples_list)
         self.mlp_list = list(mlp_list) if isinstance(mlp_list[0], Sequence) else [list(mlp_list)]
@@ -51,7 +52,11 @@ class PointsetAbstraction(nn.Module):
         for r, k in zip(self.radius_list, self.num_samples_list):
             nbr = ops.ball_query(new_xyz, xyz, r, k)                                      # [B,S,K] i32
             scales.append((nbr, ops.group_xyz_centered(xyz, new_xyz, nbr)))               # rel [B,S,K,3] fp32
-        return {"fps_idx": sel, "new_xyz": new_xyz, "scales": scales}
+        out = {"fps_idx": sel, "new_xyz": new_xyz, "scales": scales}
+        if self.has_feats and N <= 2048 and len(scales) == 1:
+            # inverse of the neighbour index: atomic-free, deterministic adjoint of the feature gather
+            out["inv"] = ops.csr_build(scales[0][0], N)
+        return out
 
     def forward_rows(self, xyz, feats, start_idx=None, geom=None):
         """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux)."""
@@ -75,7 +80,8 @@ class PointsetAbstraction(nn.Module):
                     D = feats.shape[2]
                     if cd == torch.bfloat16 and feats.is_cuda and feats.dtype == torch.bfloat16 and D % 8 == 0 and N <= 1024:
                         # gather + centred coordinates + zero padding to the GEMM's K, one kernel (feats FIRST, ref :66)
-                        x = autograd_ops.GroupConcat.apply(feats, rel, nbr, (D + 3 + 63) // 64 * 64)
+                        inv = geom.get("inv") or (None, None)
+                        x = autograd_ops.GroupConcat.apply(feats, rel, nbr, (D + 3 + 63) // 64 * 64, inv[0], inv[1])
                     else:
                         gf = autograd_ops.gather_rows(feats, nbr)                         # [B,S,K,D]
                         x = torch.cat([gf, rel.to(gf.dtype)], dim=3).reshape(B * S * k, -1)

@@ -26,7 +26,10 @@ class PointsetFeaturePropagation(nn.Module):
     def compute_geometry(xyz1, xyz2):
         """3-NN indices and inverse-distance weights (coordinates only; prefetchable)."""
         d2, nn_idx = ops.three_nn(xyz1, xyz2)                               # squared distances (CPU-route semantics)
-        return {"nn_idx": nn_idx, "nn_w": ops.three_weights(d2)}            # 1/(d+1e-8), normalised (ref :40-42)
+        out = {"nn_idx": nn_idx, "nn_w": ops.three_weights(d2)}             # 1/(d+1e-8), normalised (ref :40-42)
+        if xyz2.shape[1] <= 2048:
+            out["inv"] = ops.csr_build(nn_idx, xyz2.shape[1])               # for the atomic-free interpolation adjoint
+        return out
 
     def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None):
         """xyz1 [B,N,3] dense, xyz2 [B,S,3] coarse or None, feats1 [B,N,D1] or None,
@@ -38,7 +41,7 @@ class PointsetFeaturePropagation(nn.Module):
         else:
             if geom is None:
                 geom = self.compute_geometry(xyz1, xyz2)
-            interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"])
+            interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"], geom.get("inv"))
             aux = geom
         x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
         y = mlp.run_stack(x.reshape(B * N, -1), self.mlp_convs, self.mlp_bns, getattr(self, "compute_dtype", torch.float32))

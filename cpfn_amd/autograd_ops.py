@@ -48,11 +48,21 @@ def _scatter_bf16(g, ldg, idx, w, T, B, R, M, C):
     return out
 
 
+def _csr_sum_bf16(g, ldg, inv, w, T, B, R, M, C):
+    """Atomic-free adjoint through the inverse index `inv` = (offsets, entries): bf16 [B,M,C]."""
+    out = torch.empty(B, M, C, dtype=torch.bfloat16, device=g.device)
+    with torch.cuda.device(g.device):
+        _l.check(_l.lib().cpfn_csr_gather_sum_bf16(_ptr(g), ldg, _ptr(inv[0]), _ptr(inv[1]), _ptr(w), T, B, R, M, C, _ptr(out),
+                                                   _stream()), "cpfn_csr_gather_sum_bf16")
+    return out
+
+
 class InterpRowsBf16(torch.autograd.Function):
-    """bf16 feats [B,M,C] (C % 8 == 0, M <= 1024), idx/w [B,N,3] -> bf16 [B,N,C]."""
+    """bf16 feats [B,M,C] (C % 8 == 0, M <= 1024), idx/w [B,N,3] -> bf16 [B,N,C].
+    `inv` = optional inverse index of idx (ops.csr_build): deterministic, atomic-free adjoint."""
 
     @staticmethod
-    def forward(ctx, feats, idx, w):
+    def forward(ctx, feats, idx, w, inv_off=None, inv_ent=None):
         B, M, C = feats.shape
         N = idx.shape[1]
         f = feats.contiguous()
@@ -61,6 +71,7 @@ class InterpRowsBf16(torch.autograd.Function):
             _l.check(_l.lib().cpfn_interp_rows_bf16(_ptr(f), _ptr(idx), _ptr(w), B, M, N, C, _ptr(out), _stream()),
                      "cpfn_interp_rows_bf16")
         ctx.save_for_backward(idx, w)
+        ctx.inv = None if inv_off is None else (inv_off, inv_ent)
         ctx.dims = (B, M, N, C)
         return out
 
@@ -69,7 +80,9 @@ class InterpRowsBf16(torch.autograd.Function):
         idx, w = ctx.saved_tensors
         B, M, N, C = ctx.dims
         g = g.contiguous().to(torch.bfloat16)
-        return _scatter_bf16(g, C, idx, w, 3, B, N, M, C).to(torch.bfloat16), None, None
+        if ctx.inv is not None:
+            return _csr_sum_bf16(g, C, ctx.inv, w, 3, B, N, M, C), None, None, None, None
+        return _scatter_bf16(g, C, idx, w, 3, B, N, M, C).to(torch.bfloat16), None, None, None, None
 
 
 class GroupConcat(torch.autograd.Function):
@@ -77,7 +90,7 @@ class GroupConcat(torch.autograd.Function):
     out[p] = [feats[b, idx[p], :C] | rel[p, :3] | zeros] as bf16 [B*S*K, Cpad]."""
 
     @staticmethod
-    def forward(ctx, feats, rel, idx, cpad):
+    def forward(ctx, feats, rel, idx, cpad, inv_off=None, inv_ent=None):
         B, N, C = feats.shape
         R = idx[0].numel()
         f = feats.contiguous()
@@ -86,6 +99,7 @@ class GroupConcat(torch.autograd.Function):
             _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
                                                      _stream()), "cpfn_group_concat_bf16")
         ctx.save_for_backward(idx)
+        ctx.inv = None if inv_off is None else (inv_off, inv_ent)
         ctx.dims = (B, N, R, C, cpad)
         return out
 
@@ -94,11 +108,15 @@ class GroupConcat(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, R, C, cpad = ctx.dims
         g = g.contiguous().to(torch.bfloat16)
-        return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None
+        if ctx.inv is not None:
+            return _csr_sum_bf16(g, cpad, ctx.inv, None, 1, B, R, N, C), None, None, None, None, None
+        return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None, None, None
 
 
-def interp_rows(feats, idx, w):
+def interp_rows(feats, idx, w, inv=None):
     if feats.dtype == torch.bfloat16 and feats.is_cuda and feats.shape[2] % 8 == 0 and feats.shape[1] <= 1024:
+        if inv is not None:
+            return InterpRowsBf16.apply(feats, idx, w, inv[0], inv[1])
         return InterpRowsBf16.apply(feats, idx, w)
     return InterpRows.apply(feats, idx, w)
 

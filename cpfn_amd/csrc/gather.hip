@@ -200,32 +200,159 @@ __global__ __launch_bounds__(TPB) void interp_rows_bf16_kernel(const unsigned sh
 // LDS atomic (64 lanes of one instruction hit 64 different banks), and the slab is flushed with one
 // global atomic per element per workgroup: ~50x fewer global atomics than scattering row by row.
 constexpr int SC_CH = 32;
+constexpr int SC_LD = SC_CH + 1;   // padded slab row: with a 32-float stride every lane of an atomic hits bank (cg*8+j)%32 -> 16-way conflicts
 __global__ __launch_bounds__(TPB) void scatter_rows_lds_kernel(const unsigned short *__restrict__ g, int ldg,
                                                                const int *__restrict__ idx,
                                                                const float *__restrict__ w, int T, int R, int M,
                                                                int C, int rows_per_block, float *__restrict__ out) {
-  extern __shared__ float s_acc[];  // [M][SC_CH]
+  extern __shared__ float s_acc[];  // [M][SC_LD]
   const int b = blockIdx.z, c0 = blockIdx.y * SC_CH;
-  const int t = threadIdx.x, cl = t % SC_CH, rs = t / SC_CH;  // 8 row sub-lanes
-  for (int e = t; e < M * SC_CH; e += TPB) s_acc[e] = 0.f;
+  const int t = threadIdx.x, cg = t % (SC_CH / 8), rs = t / (SC_CH / 8);  // 4 channel groups x 64 row lanes
+  for (int e = t; e < M * SC_LD; e += TPB) s_acc[e] = 0.f;
   __syncthreads();
   const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  if (c0 + cl < C) {
-    for (int r = r0 + rs; r < r1; r += TPB / SC_CH) {
-      const float gv = bf2f_(g[((size_t)b * R + r) * ldg + c0 + cl]);
+  const int cbase = c0 + cg * 8;
+  if (cbase < C) {   // C % 8 == 0: a group is either fully inside or fully outside
+    for (int r = r0 + rs; r < r1; r += TPB / (SC_CH / 8)) {
+      const uint4 raw = *(const uint4 *)(g + ((size_t)b * R + r) * ldg + cbase);   // 8 channels, one 16-byte load
+      const unsigned short *h = (const unsigned short *)&raw;
+      float gv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = bf2f_(h[j]);
       for (int tt = 0; tt < T; ++tt) {
         int m = idx[((size_t)b * R + r) * T + tt];
         m = m < 0 ? 0 : (m >= M ? M - 1 : m);
         const float wt = w ? w[((size_t)b * R + r) * T + tt] : 1.f;
-        atomicAdd(&s_acc[m * SC_CH + cl], wt * gv);
+        float *dst = &s_acc[m * SC_LD + cg * 8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(dst + j, wt * gv[j]);
       }
     }
   }
   __syncthreads();
   for (int e = t; e < M * SC_CH; e += TPB) {
     const int m = e / SC_CH, c = e % SC_CH;
-    const float v = s_acc[e];
+    const float v = s_acc[m * SC_LD + c];
     if (v != 0.f && c0 + c < C) atomicAdd(out + ((size_t)b * M + m) * C + c0 + c, v);
+  }
+}
+
+// ---------------------------------------------------------------- inverse index (CSR) adjoints
+// A gather's adjoint is a scatter-add; with float atomics it is slow (LDS float atomics retire about one
+// lane per cycle on gfx950: 265 us for the sfp3 interpolation adjoint) and its summation order changes
+// from run to run.  The index tensors depend on coordinates only, so the geometry stage (which runs one
+// step ahead on a side stream) also builds their INVERSE: for every target row m the ascending list of
+// source entries e = r*T + t that reference it.  The adjoint is then a gather-and-sum per target row:
+// no atomics, fixed order, bitwise reproducible.
+constexpr int CSR_MAXM = 2048;
+constexpr int CSR_LDS_E = 32768;   // entries per cloud that fit the LDS staging slab (128 KB)
+template <bool LDS_SLAB>
+__global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ idx, int E, int M,
+                                                        int *__restrict__ offsets, int *__restrict__ entries) {
+  __shared__ int s_cnt[CSR_MAXM + 1];
+  __shared__ int s_cur[CSR_MAXM];
+  extern __shared__ int s_ent[];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int *ii = idx + (size_t)b * E;
+  int *off = offsets + (size_t)b * (M + 1), *gent = entries + (size_t)b * E;
+  int *ent = LDS_SLAB ? s_ent : gent;
+  for (int m = t; m <= M; m += TPB) s_cnt[m] = 0;
+  __syncthreads();
+  for (int e = t; e < E; e += TPB) {
+    int m = ii[e];
+    m = m < 0 ? 0 : (m >= M ? M - 1 : m);
+    atomicAdd(&s_cnt[m], 1);
+  }
+  __syncthreads();
+  if (t < 64) {   // exclusive scan by one wave: 64 lanes x (M/64) consecutive counters
+    const int per = (M + 63) / 64, m0 = t * per, m1 = min(M, m0 + per);
+    int sum = 0;
+    for (int m = m0; m < m1; ++m) sum += s_cnt[m];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (t >= d) incl += o;
+    }
+    int run = incl - sum;
+    for (int m = m0; m < m1; ++m) { const int c = s_cnt[m]; s_cnt[m] = run; run += c; }
+    if (t == 63) s_cnt[M] = incl;
+  }
+  __syncthreads();
+  for (int m = t; m <= M; m += TPB) { off[m] = s_cnt[m]; if (m < M) s_cur[m] = s_cnt[m]; }
+  __syncthreads();
+  for (int e = t; e < E; e += TPB) {
+    int m = ii[e];
+    m = m < 0 ? 0 : (m >= M ? M - 1 : m);
+    ent[atomicAdd(&s_cur[m], 1)] = e;
+  }
+  __syncthreads();
+  // the fill order above depends on scheduling: sort every list ascending (insertion sort; the lists are
+  // short and arrive nearly sorted)
+  for (int m = t; m < M; m += TPB) {
+    const int a = s_cnt[m], z = s_cnt[m + 1];
+    for (int i = a + 1; i < z; ++i) {
+      const int v = ent[i];
+      int j = i - 1;
+      while (j >= a && ent[j] > v) { ent[j + 1] = ent[j]; --j; }
+      ent[j + 1] = v;
+    }
+  }
+  if (LDS_SLAB) {
+    __syncthreads();
+    for (int e = t; e < E; e += TPB) gent[e] = s_ent[e];
+  }
+}
+
+// out[b,m,:] = Σ_{e in list(m)} w[b,e] · g[b, e / T, :]      (w may be NULL), bf16 in / bf16 out.
+// Four lanes share one (target row, 8-channel chunk): lane q takes entries q, q+4, ... of the list, two at a
+// time, and the four partial sums are combined in a fixed order.
+__global__ __launch_bounds__(TPB) void csr_gather_sum_kernel(const unsigned short *__restrict__ g, int ldg,
+                                                             const int *__restrict__ offsets,
+                                                             const int *__restrict__ entries,
+                                                             const float *__restrict__ w, int T, int R, int M, int C,
+                                                             unsigned short *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int cpr = C / 8;
+  const long long x4 = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long x = x4 >> 2;
+  const int q = (int)(x4 & 3);
+  const bool live = x < (long long)M * cpr;
+  const int m = live ? (int)(x / cpr) : 0, c0 = live ? (int)(x - (long long)m * cpr) * 8 : 0;
+  const int *off = offsets + (size_t)b * (M + 1);
+  const int *ent = entries + (size_t)b * R * T;
+  const float *wb = w ? w + (size_t)b * R * T : nullptr;
+  const unsigned short *gb = g + (size_t)b * R * ldg + c0;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int i1 = live ? off[m + 1] : 0;
+  int i = (live ? off[m] : 0) + q;
+  for (; i + 4 < i1; i += 8) {
+    const int e0 = ent[i], e1 = ent[i + 4];
+    const float w0 = wb ? wb[e0] : 1.f, w1 = wb ? wb[e1] : 1.f;
+    const uint4 r0 = *(const uint4 *)(gb + (size_t)(e0 / T) * ldg);
+    const uint4 r1 = *(const uint4 *)(gb + (size_t)(e1 / T) * ldg);
+    const unsigned short *h0 = (const unsigned short *)&r0, *h1 = (const unsigned short *)&r1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w1, bf2f_(h1[j]), fmaf(w0, bf2f_(h0[j]), acc[j]));
+  }
+  if (i < i1) {
+    const int e0 = ent[i];
+    const float w0 = wb ? wb[e0] : 1.f;
+    const uint4 r0 = *(const uint4 *)(gb + (size_t)(e0 / T) * ldg);
+    const unsigned short *h0 = (const unsigned short *)&r0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w0, bf2f_(h0[j]), acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    acc[j] += __shfl_xor(acc[j], 1);
+    acc[j] += __shfl_xor(acc[j], 2);
+  }
+  if (live && q == 0) {
+    unsigned short o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf_(acc[j]);
+    *(uint4 *)(out + ((size_t)b * M + m) * C + c0) = *(const uint4 *)o;
   }
 }
 
@@ -383,11 +510,11 @@ extern "C" int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, co
   if (B < 0 || R < 0 || M <= 0 || M > 1024 || C <= 0 || T < 1 || T > 3 || ldg < C || !g || !idx || !out)
     return CPFN_EINVAL;
   if (B == 0 || R == 0) return 0;
-  const size_t lds = (size_t)M * SC_CH * sizeof(float);
+  const size_t lds = (size_t)M * SC_LD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)scatter_rows_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       1024 * SC_CH * (int)sizeof(float));
+                                       1024 * SC_LD * (int)sizeof(float));
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -411,5 +538,34 @@ extern "C" int cpfn_group_concat_bf16(const void *feats, const float *rel, const
   dim3 grid(cpfn_cdiv((long long)R * (Cpad / 8), TPB), B);
   group_concat_bf16_kernel<<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)feats, rel, idx, N, R, C, Cpad,
                                                                   (unsigned short *)out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets, int *entries, void *stream) {
+  if (B < 0 || E < 0 || M <= 0 || M > CSR_MAXM || !idx || !offsets || !entries) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  if (E <= CSR_LDS_E) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void *)csr_build_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         CSR_LDS_E * (int)sizeof(int));
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    csr_build_kernel<true><<<B, TPB, (size_t)E * sizeof(int), (hipStream_t)stream>>>(idx, E, M, offsets, entries);
+  } else {
+    csr_build_kernel<false><<<B, TPB, 0, (hipStream_t)stream>>>(idx, E, M, offsets, entries);
+  }
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets, const int *entries, const float *w,
+                                        int T, int B, int R, int M, int C, void *out, void *stream) {
+  if (B < 0 || R < 0 || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || ldg < C || T < 1 || !g || !offsets || !entries || !out)
+    return CPFN_EINVAL;
+  if (B == 0) return 0;
+  dim3 grid(cpfn_cdiv((long long)M * (C / 8) * 4, TPB), B);
+  csr_gather_sum_kernel<<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, offsets, entries, w, T, R, M,
+                                                               C, (unsigned short *)out);
   return cpfn_launch_status();
 }

@@ -437,17 +437,23 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const unsigned sho
 
 // ---------------------------------------------------------------- BatchNorm backward, pass 1
 // g_z = g_a·[z>0]; per-workgroup partial Σ g_z and Σ g_z·y per channel.  Gz may alias Ga.
-constexpr int R_ROWS = 512;  // rows per workgroup
+// Rows per workgroup of the column-reduction passes: ~1024 workgroups when P allows (a 4-workgroup launch
+// on the 2048-row sa4 layers was a 70 us latency chain), between 16 and 512 rows each.
+static inline int bn_rows_per_block(long long P) {
+  int r = 16;
+  while (r < 512 && (P + r - 1) / r > 1024) r *= 2;
+  return r;
+}
 __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *__restrict__ Ga,
                                                           const unsigned short *__restrict__ Yr,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, long long P, int C,
                                                           unsigned short *__restrict__ Gz,
-                                                          float *__restrict__ partial) {
+                                                          float *__restrict__ partial, int rpb) {
   __shared__ float s_red[2][256][8 + 1];
   const int t = threadIdx.x;
   const int chunks = C / 8;
-  const long long row0 = (long long)blockIdx.x * R_ROWS;
+  const long long row0 = (long long)blockIdx.x * rpb;
   float a1[8], a2[8];
   for (int cb = 0; cb < chunks; cb += 256) {
     const int nch = min(256, chunks - cb);
@@ -460,7 +466,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
       float sc[8], sh[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
-      for (long long r = row0 + rs; r < min(P, row0 + R_ROWS); r += rsub) {
+#pragma unroll 4
+      for (long long r = row0 + rs; r < min(P, row0 + rpb); r += rsub) {
         const uint4 rg = *(const uint4 *)(Ga + r * C + c0);
         const uint4 ry = *(const uint4 *)(Yr + r * C + c0);
         const unsigned short *g = (const unsigned short *)&rg, *y = (const unsigned short *)&ry;
@@ -712,12 +719,12 @@ constexpr int KS_MAX = 4;
 __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ X, int KS,
                                                          const float *__restrict__ W, long long P, int C,
                                                          unsigned short *__restrict__ Y,
-                                                         float *__restrict__ partial) {
+                                                         float *__restrict__ partial, int rpb) {
   __shared__ float s_red[2][256][8 + 1];
   const int t = threadIdx.x;
   const int nch = C / 8, rsub = 256 / nch;  // C <= 2048, power of two
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
-  const long long row0 = (long long)blockIdx.x * R_ROWS;
+  const long long row0 = (long long)blockIdx.x * rpb;
   float w[8][KS_MAX];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
   if (rs < rsub) {
-    for (long long r = row0 + rs; r < min(P, row0 + R_ROWS); r += rsub) {
+    for (long long r = row0 + rs; r < min(P, row0 + rpb); r += rsub) {
       float x[KS_MAX];
 #pragma unroll
       for (int q = 0; q < KS_MAX; ++q) x[q] = q < KS ? X[r * KS + q] : 0.f;
@@ -761,19 +768,19 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 // dW[c,j] = Σ_p Gy[p,c]·X[p,j]: partial[gridDim.x][C][KS]
 __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short *__restrict__ Gy,
                                                            const float *__restrict__ X, int KS, long long P,
-                                                           int C, float *__restrict__ partial) {
+                                                           int C, float *__restrict__ partial, int rpb) {
   __shared__ float s_red[256][8 * KS_MAX + 1];
   const int t = threadIdx.x;
   const int nch = C / 8, rsub = 256 / nch;
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
-  const long long row0 = (long long)blockIdx.x * R_ROWS;
+  const long long row0 = (long long)blockIdx.x * rpb;
   float a[8][KS_MAX];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
     for (int q = 0; q < KS_MAX; ++q) a[j][q] = 0.f;
   if (rs < rsub) {
-    for (long long r = row0 + rs; r < min(P, row0 + R_ROWS); r += rsub) {
+    for (long long r = row0 + rs; r < min(P, row0 + rpb); r += rsub) {
       float x[KS_MAX];
 #pragma unroll
       for (int q = 0; q < KS_MAX; ++q) x[q] = q < KS ? X[r * KS + q] : 0.f;
@@ -910,13 +917,17 @@ extern "C" int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const flo
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_bn_bwd_blocks(long long P) { return (int)((P + R_ROWS - 1) / R_ROWS); }
+extern "C" int cpfn_bn_bwd_blocks(long long P) {
+  const int r = bn_rows_per_block(P);
+  return (int)((P + r - 1) / r);
+}
 
 extern "C" int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift, long long P,
                                 int C, void *Gz, float *partial, void *stream) {
   if (P <= 0 || C <= 0 || (C & 7) || !pow2(C / 8) || !Ga || !Y || !scale || !shift || !partial) return CPFN_EINVAL;
   bn_relu_bwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
-      (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial);
+      (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial,
+      bn_rows_per_block(P));
   return cpfn_launch_status();
 }
 
@@ -994,7 +1005,8 @@ extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long
                                void *stream) {
   if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || !partial)
     return CPFN_EINVAL;
-  smallk_fwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(X, KS, W, P, C, (unsigned short *)Y, partial);
+  smallk_fwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(X, KS, W, P, C, (unsigned short *)Y, partial,
+                                                                             bn_rows_per_block(P));
   return cpfn_launch_status();
 }
 
@@ -1004,7 +1016,7 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = cpfn_bn_bwd_blocks(P);
-  smallk_wgrad_kernel<<<nblk, 256, 0, st>>>((const unsigned short *)Gy, X, KS, P, C, workspace);
+  smallk_wgrad_kernel<<<nblk, 256, 0, st>>>((const unsigned short *)Gy, X, KS, P, C, workspace, bn_rows_per_block(P));
   const long long n = (long long)C * KS;
   split_reduce_kernel<<<cpfn_cdiv(n, 16), 256, 0, st>>>(workspace, nblk, n, dW);
   return cpfn_launch_status();

@@ -204,3 +204,16 @@ def interp_rows_bwd(grad_out, idx, w, M):
         _l.check(_l.lib().cpfn_interp_rows_bwd(_ptr(grad_out), _ptr(idx), _ptr(w), B, int(M), N, C, _ptr(out),
                                                _stream()), "cpfn_interp_rows_bwd")
     return out
+
+
+def csr_build(idx, M):
+    """idx [B, ...] i32 with values in [0, M) -> (offsets [B, M+1] i32, entries [B, E] i32): for every
+    target m the ascending list of flattened source positions that reference it."""
+    _chk(idx, "idx", torch.int32)
+    B = idx.shape[0]
+    E = idx[0].numel()
+    off = torch.empty(B, M + 1, dtype=torch.int32, device=idx.device)
+    ent = torch.empty(B, E, dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _l.check(_l.lib().cpfn_csr_build(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _stream()), "cpfn_csr_build")
+    return off, ent

@@ -220,8 +220,12 @@ class SPFNTrainer:
             out += [g[lvl]["fps_idx"], g[lvl]["new_xyz"]]
             for nbr, rel in g[lvl]["scales"]:
                 out += [nbr, rel]
+            if "inv" in g[lvl]:
+                out += list(g[lvl]["inv"])
         for lvl in ("sfp2", "sfp3"):
             out += [g[lvl]["nn_idx"], g[lvl]["nn_w"]]
+            if "inv" in g[lvl]:
+                out += list(g[lvl]["inv"])
         return out
 
     @staticmethod
@@ -232,9 +236,14 @@ class SPFNTrainer:
             d = {"fps_idx": next(it), "new_xyz": next(it), "scales": []}
             for _ in g[lvl]["scales"]:
                 d["scales"].append((next(it), next(it)))
+            if "inv" in g[lvl]:
+                d["inv"] = (next(it), next(it))
             out[lvl] = d
         for lvl in ("sfp2", "sfp3"):
-            out[lvl] = {"nn_idx": next(it), "nn_w": next(it)}
+            d = {"nn_idx": next(it), "nn_w": next(it)}
+            if "inv" in g[lvl]:
+                d["inv"] = (next(it), next(it))
+            out[lvl] = d
         return out
 
     def _capture(self, batch):

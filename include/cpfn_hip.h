@@ -139,6 +139,16 @@ CPFN_API int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, cons
 CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const int *idx, int B, int N, int R,
                                     int C, int Cpad, void *out, void *stream);
 
+/* Inverse index of a gather (geometry stage): for idx[B,E] with values in [0,M) (M <= 2048) build, per
+ * cloud, offsets[M+1] and the ASCENDING list entries[E] of source positions e that reference each target.
+ * The adjoint of the gather is then cpfn_csr_gather_sum_bf16: out[b,m,:] = sum over list(m) of
+ * w[b,e] * g[b, e/T, :] (w may be NULL; g bf16 with row stride ldg; out bf16 [B,M,C]) — no atomics,
+ * fixed summation order. */
+CPFN_API int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets, int *entries, void *stream);
+CPFN_API int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets, const int *entries,
+                                      const float *w, int T, int B, int R, int M, int C, void *out,
+                                      void *stream);
+
 /* ------------------------------------------------------------------ SPFN fitters
  * One pass over P[B,N,3], X[B,N,3] (unit normals), W[B,N,K] (soft memberships) yields every
  * weighted sum the four primitive fitters need.  Replaces the tiled [B*K,N,3] /

@@ -201,3 +201,46 @@ def test_bf16_row_movers_vs_oracle():
     wantgg = og.group_points_grad(np.ascontiguousarray(gx.float().numpy().reshape(B, S, K, 128)[..., :C].transpose(0, 3, 1, 2)), idx, M).transpose(0, 2, 1)
     gotg = f2.grad.float().cpu().numpy()
     assert np.abs(gotg - wantgg).max() <= 2e-2 * np.abs(wantgg).max()
+
+
+def test_inverse_index_adjoints_vs_oracle():
+    """cpfn_csr_build gives, per target, the ascending list of referencing entries; the atomic-free adjoints
+    through it match the oracle's scatter-adds and are bitwise reproducible."""
+    from cpfn_amd import autograd_ops, ops
+    rng = np.random.default_rng(12)
+    B, M, N, C = 2, 300, 2500, 64
+    nn = rng.integers(0, M, (B, N, 3))
+    nn[0, :200] = 7                                     # one very long list
+    nn[1][nn[1] == 5] = 6                               # and an empty one
+    off, ent = ops.csr_build(T(nn, torch.int32), M)
+    off, ent = off.cpu().numpy(), ent.cpu().numpy()
+    for b in range(B):
+        flat = nn[b].reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        assert np.array_equal(ent[b], order)
+        assert np.array_equal(off[b], np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=M))]))
+    feats = torch.from_numpy(rng.normal(size=(B, M, C)).astype(np.float32)).to(torch.bfloat16)
+    w = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    g = torch.from_numpy(rng.normal(size=(B, N, C)).astype(np.float32)).to(torch.bfloat16)
+    grads = []
+    for _ in range(2):
+        f_dev = feats.to(dev()).requires_grad_(True)
+        idx_d = T(nn, torch.int32)
+        out = autograd_ops.interp_rows(f_dev, idx_d, T(w), ops.csr_build(idx_d, M))
+        out.backward(g.to(dev()))
+        grads.append(f_dev.grad.float().cpu().numpy())
+    assert np.array_equal(grads[0], grads[1])
+    wantg = og.three_weighted_sum_grad(np.ascontiguousarray(g.float().numpy().transpose(0, 2, 1)), nn, w, M).transpose(0, 2, 1)
+    assert np.abs(grads[0] - wantg).max() <= 1e-2 * np.abs(wantg).max()
+    S, K = 40, 16
+    idx = rng.integers(0, M, (B, S, K))
+    rel = rng.normal(size=(B, S, K, 3)).astype(np.float32)
+    f2 = feats.to(dev()).requires_grad_(True)
+    idx_d = T(idx, torch.int32)
+    inv = ops.csr_build(idx_d, M)
+    x = autograd_ops.GroupConcat.apply(f2, T(rel), idx_d, 128, inv[0], inv[1])
+    gx = torch.from_numpy(rng.normal(size=(B * S * K, 128)).astype(np.float32)).to(torch.bfloat16)
+    x.backward(gx.to(dev()))
+    wantgg = og.group_points_grad(np.ascontiguousarray(gx.float().numpy().reshape(B, S, K, 128)[..., :C].transpose(0, 3, 1, 2)), idx, M).transpose(0, 2, 1)
+    gotg = f2.grad.float().cpu().numpy()
+    assert np.abs(gotg - wantgg).max() <= 1e-2 * np.abs(wantgg).max()
