@@ -308,14 +308,17 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
 // ---------------------------------------------------------------- BatchNorm finalize (forward)
 // scale = γ·rstd, shift = β − mean·scale; running statistics updated like torch (unbiased var,
 // the conv bias — dropped from the GEMM because batch-norm cancels it — re-enters the mean).
-// Fixed-order two-level sum of per-block partials: 16 channels x 16 block-subsets per workgroup
-// (subset r adds blocks r, r+16, ...; the 16 subset sums are then added in order) — parallel,
+// Fixed-order two-level sum of per-block partials: 16 channels x RSUB block-subsets per workgroup
+// (subset r adds blocks r, r+RSUB, ...; the RSUB subset sums are then added in order) — parallel,
 // coalesced, and still bitwise reproducible.
+constexpr int RSUB = 64;
+constexpr int RTPB = 16 * RSUB;
 __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ partial, int nblk, int N, int c,
                                                    int r, double (*s_acc)[16][2], double &s1, double &s2) {
   double a1 = 0.0, a2 = 0.0;
   if (c < N) {
-    for (int i = r; i < nblk; i += 16) {
+#pragma unroll 4
+    for (int i = r; i < nblk; i += RSUB) {
       a1 += (double)partial[((size_t)i * 2 + 0) * N + c];
       a2 += (double)partial[((size_t)i * 2 + 1) * N + c];
     }
@@ -325,17 +328,17 @@ __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ par
   __syncthreads();
   s1 = 0.0; s2 = 0.0;
   if (r == 0) {
-    for (int q = 0; q < 16; ++q) { s1 += s_acc[q][threadIdx.x & 15][0]; s2 += s_acc[q][threadIdx.x & 15][1]; }
+    for (int q = 0; q < RSUB; ++q) { s1 += s_acc[q][threadIdx.x & 15][0]; s2 += s_acc[q][threadIdx.x & 15][1]; }
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N, float count,
+__global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N, float count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    const float *__restrict__ conv_bias, float eps, float momentum,
                                    float *__restrict__ running_mean, float *__restrict__ running_var,
                                    float *__restrict__ scale, float *__restrict__ shift,
                                    float *__restrict__ mean_out, float *__restrict__ rstd_out) {
-  __shared__ double s_acc[16][16][2];
+  __shared__ double s_acc[RSUB][16][2];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
   double s1, s2;
   partial_sums_16x16(partial, nblk, N, c, r, s_acc, s1, s2);
@@ -527,11 +530,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned 
 
 // dβ = Σg_z, dγ = rstd·(Σg_z·y − mean·Σg_z);  g_y = s·g_z + c2·y + c3 with
 // s = γ·rstd, c2 = −s·dγ·rstd/count, c3 = −s·dβ/count − c2·mean  (training-mode batch norm).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
+__global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
                                        const float *__restrict__ gamma, const float *__restrict__ mean,
                                        const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
-  __shared__ double s_acc[16][16][2];
+  __shared__ double s_acc[RSUB][16][2];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
   double s1, s2;
   partial_sums_16x16(partial, nblk, C, c, r, s_acc, s1, s2);
@@ -628,15 +631,19 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
 // dW[n,k] = Σ_p Gy[p,n]·A[p,k]: the contraction runs over ROWS, so both MFMA operands are
 // transposed tiles — staged row-major in LDS and read with ds_read_b64_tr_b16.
 // grid (N/64, K/64, splits); partial[split][N][K] fp32.
-constexpr int WG_T = 64;          // output tile 64 x 64
+// grid (N/TN, ceil(K/TK), splits); partial[split][N][K] fp32.  The row loop is a 4-deep register pipeline:
+// the 16-byte chunks of step i+4 are in flight while step i goes registers -> LDS -> transposed fragments ->
+// MFMA, so a workgroup's time is its bytes, not (steps x memory latency) as in the first version (which
+// had a 25 us floor on every layer).  128x128 tiles read each operand once for the 128-wide layers.
 constexpr int WG_STEP = 32;       // rows per MFMA step
-constexpr int WG_LD = WG_T + 8;   // LDS row stride (elements): 144 B
+constexpr int WG_DEPTH = 4;       // steps in flight
 
+template <int LD>
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *tile, int col0, int lane) {
   // fragment F[x = lane&15][k = 8(lane>>4)+j] = tile[row k][col0 + x]  (tile rows = contraction index)
   const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const unsigned short *a0 = tile + (8 * grp + q) * WG_LD + col0 + 4 * pp;
-  const unsigned short *a1 = a0 + 4 * WG_LD;
+  const unsigned short *a0 = tile + (8 * grp + q) * LD + col0 + 4 * pp;
+  const unsigned short *a1 = a0 + 4 * LD;
   typedef s16x4 __attribute__((address_space(3))) * lds_p;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
@@ -645,49 +652,98 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *tile, int col0, 
   return __builtin_bit_cast(bf16x8, v);  // one whole-vector cast: element-wise casts of the tr-read result miscompile
 }
 
+template <int TN, int TK>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
                                                         const unsigned short *__restrict__ A, int lda,
                                                         const int *__restrict__ gidx, long long P, int N, int K,
                                                         long long rows_per_split, float *__restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) unsigned short s_g[WG_STEP * WG_LD];
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[WG_STEP * WG_LD];
+  constexpr int LDN = TN + 8, LDK = TK + 8;       // LDS row strides (elements)
+  constexpr int CG = TN / 64, CA = TK / 64;       // 16-byte chunks per thread and step
+  constexpr int MI = TN / 32, MJ = TK / 32;       // MFMA tiles per wave (wave sub-tile = TN/2 x TK/2)
+  __shared__ __attribute__((aligned(16))) unsigned short s_g[WG_STEP * LDN];
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[WG_STEP * LDK];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int n0 = blockIdx.x * WG_T, k0 = blockIdx.y * WG_T;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
   const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
-  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;  // this wave's 32x32 sub-tile
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
-  // staging: 32 rows x 64 cols bf16 = 256 x 16-byte chunks per operand: one chunk per thread
-  const int sr = t >> 3, sc = (t & 7) * 8;
-  for (long long base = p0; base < p1; base += WG_STEP) {
-    const long long p = base + sr;
-    uint4 vg = {0, 0, 0, 0}, va = {0, 0, 0, 0};
-    if (p < p1) {
-      vg = *(const uint4 *)(Gy + p * ldg + n0 + sc);
-      const long long ar = gidx ? (long long)gidx[p] : p;
-      if (k0 + sc < K) va = *(const uint4 *)(A + ar * lda + k0 + sc);
+  if (p0 >= p1) {   // empty split: its partial slab must still be zero
+    float *o = partial + (size_t)blockIdx.z * N * K;
+    for (int e = t; e < TN * TK; e += 256) {
+      const int n = n0 + e / TK, k = k0 + e % TK;
+      if (n < N && k < K) o[(size_t)n * K + k] = 0.f;
     }
-    __syncthreads();
-    *(uint4 *)&s_g[sr * WG_LD + sc] = vg;
-    *(uint4 *)&s_a[sr * WG_LD + sc] = va;
-    __syncthreads();
-    bf16x8 fg[2], fa[2];
-    fg[0] = tr_frag(s_g, wn, lane);
-    fg[1] = tr_frag(s_g, wn + 16, lane);
-    fa[0] = tr_frag(s_a, wk, lane);
-    fa[1] = tr_frag(s_a, wk + 16, lane);
+    return;
+  }
+  const int wn = (wave >> 1) * (TN / 2), wk = (wave & 1) * (TK / 2);
+  f32x4 acc[MI][MJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  // chunk c = t + 256 i of a step: row c / (T/8), column 8 (c % (T/8))
+  uint4 vg[WG_DEPTH][CG], va[WG_DEPTH][CA];
+  auto issue = [&](int sidx, long long base) {
+#pragma unroll
+    for (int i = 0; i < CG; ++i) {
+      const int c = t + 256 * i;
+      const long long p = min(base + c / (TN / 8), p1 - 1);      // clamped: always a valid row, zeroed at store time
+      vg[sidx][i] = *(const uint4 *)(Gy + p * ldg + n0 + (c % (TN / 8)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = t + 256 * i;
+      const long long p = min(base + c / (TK / 8), p1 - 1);
+      const long long ar = gidx ? (long long)gidx[p] : p;
+      const int col = min(k0 + (c % (TK / 8)) * 8, K - 8);
+      va[sidx][i] = *(const uint4 *)(A + ar * lda + col);
+    }
+  };
+  auto stage = [&](int sidx, long long base) {
+#pragma unroll
+    for (int i = 0; i < CG; ++i) {
+      const int c = t + 256 * i, r = c / (TN / 8);
+      uint4 v = vg[sidx][i];
+      if (base + r >= p1) v = (uint4){0, 0, 0, 0};
+      *(uint4 *)&s_g[r * LDN + (c % (TN / 8)) * 8] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int c = t + 256 * i, r = c / (TK / 8), col = (c % (TK / 8)) * 8;
+      uint4 v = va[sidx][i];
+      if (base + r >= p1 || k0 + col >= K) v = (uint4){0, 0, 0, 0};
+      *(uint4 *)&s_a[r * LDK + col] = v;
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < WG_DEPTH; ++d) issue(d, p0 + (long long)d * WG_STEP);
+  for (long long base0 = p0; base0 < p1; base0 += WG_STEP * WG_DEPTH) {
+#pragma unroll
+    for (int d = 0; d < WG_DEPTH; ++d) {
+      // no "if (base < p1)" here: a skipped stage would make the number of loads in flight path-dependent and
+      // the compiler falls back to vmcnt(0) drains; steps past the end stage zeros instead (rows_per_split is
+      // a multiple of WG_STEP*WG_DEPTH, so only the last split of a ragged P ever does that)
+      const long long base = base0 + (long long)d * WG_STEP;
+      __syncthreads();
+      stage(d, base);
+      __syncthreads();
+      issue(d, base + WG_STEP * WG_DEPTH);
+      bf16x8 fg[MI], fa[MJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fg[i] = tr_frag<LDN>(s_g, wn + 16 * i, lane);
+#pragma unroll
+      for (int j = 0; j < MJ; ++j) fa[j] = tr_frag<LDK>(s_a, wk + 16 * j, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
+    }
   }
   // D[row = n-local 4(lane>>4)+r][col = k-local lane&15]
   float *o = partial + (size_t)blockIdx.z * N * K;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn + i * 16 + 4 * (lane >> 4) + r, k = k0 + wk + j * 16 + (lane & 15);
@@ -695,19 +751,22 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
       }
 }
 
-__global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restrict__ partial, int splits, long long n,
+template <int RS>
+__global__ __launch_bounds__(16 * RS) void split_reduce_kernel(const float *__restrict__ partial, int splits, long long n,
                                     float *__restrict__ out) {
-  __shared__ float s_acc[16][16];
+  __shared__ float s_acc[RS][16];
   const long long e = (long long)blockIdx.x * 16 + (threadIdx.x & 15);
   const int r = threadIdx.x >> 4;
   float a = 0.f;
-  if (e < n)
-    for (int i = r; i < splits; i += 16) a += partial[(size_t)i * n + e];
+  if (e < n) {
+#pragma unroll 4
+    for (int i = r; i < splits; i += RS) a += partial[(size_t)i * n + e];
+  }
   s_acc[r][threadIdx.x & 15] = a;
   __syncthreads();
   if (r == 0 && e < n) {
     float s = 0.f;
-    for (int q = 0; q < 16; ++q) s += s_acc[q][threadIdx.x & 15];
+    for (int q = 0; q < RS; ++q) s += s_acc[q][threadIdx.x & 15];
     out[e] = s;
   }
 }
@@ -891,7 +950,7 @@ extern "C" int cpfn_bn_finalize(const float *partial, int nblk, int N, float cou
                                 float *running_mean, float *running_var, float *scale, float *shift,
                                 float *mean, float *rstd, void *stream) {
   if (nblk <= 0 || N <= 0 || !partial || !gamma || !beta || !scale || !shift || !mean || !rstd) return CPFN_EINVAL;
-  bn_finalize_kernel<<<cpfn_cdiv(N, 16), 256, 0, (hipStream_t)stream>>>(partial, nblk, N, count, gamma, beta, conv_bias,
+  bn_finalize_kernel<<<cpfn_cdiv(N, 16), RTPB, 0, (hipStream_t)stream>>>(partial, nblk, N, count, gamma, beta, conv_bias,
                                                                         eps, momentum, running_mean, running_var,
                                                                         scale, shift, mean, rstd);
   return cpfn_launch_status();
@@ -915,6 +974,13 @@ extern "C" int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const flo
   bn_relu_maxpool_kernel<<<G, 256, 0, (hipStream_t)stream>>>((const unsigned short *)Y, scale, shift, Kn, C,
                                                              (unsigned short *)out, arg, (unsigned short *)yarg);
   return cpfn_launch_status();
+}
+
+static inline void launch_split_reduce(const float *ws, int splits, long long n, float *out, hipStream_t st) {
+  if (splits > 64)
+    split_reduce_kernel<64><<<cpfn_cdiv(n, 16), 1024, 0, st>>>(ws, splits, n, out);
+  else
+    split_reduce_kernel<16><<<cpfn_cdiv(n, 16), 256, 0, st>>>(ws, splits, n, out);
 }
 
 extern "C" int cpfn_bn_bwd_blocks(long long P) {
@@ -945,7 +1011,7 @@ extern "C" int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float
                                     const float *mean, const float *rstd, int training, float *dgamma,
                                     float *dbeta, float *coef, void *stream) {
   if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef) return CPFN_EINVAL;
-  bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
+  bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 16), RTPB, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
                                                                             training, dgamma, dbeta, coef);
   return cpfn_launch_status();
 }
@@ -975,11 +1041,16 @@ extern "C" int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, 
   return cpfn_launch_status();
 }
 
+// tile edge for one (P, N, K): 128 where the layer is wide and long enough to fill the chip with 128-tiles
+static inline int wgrad_tile(long long P, int N, int K) { return (P >= 32768 && N % 128 == 0 && K >= 128) ? 128 : 64; }
+
 extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
-  const long long tiles = (long long)((N + 63) / 64) * ((K + 63) / 64);
-  long long s = (1024 + tiles - 1) / tiles;           // ~1024 workgroups (4 per CU): the kernel is a stream
+  const int T = wgrad_tile(P, N, K);
+  const long long tiles = (long long)((N + T - 1) / T) * ((K + T - 1) / T);
+  const long long target = T == 128 ? 512 : 1024;     // workgroups
+  long long s = (target + tiles - 1) / tiles;
   if (s > 256) s = 256;                               // bound the partial buffer / reduce depth
-  const long long max_s = (P + 1023) / 1024;          // at least 1024 rows per split
+  const long long max_s = (P + 127) / 128;            // at least 128 rows (one pipeline depth) per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   return (int)s;
@@ -987,17 +1058,22 @@ extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
 
 extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P, int N,
                               int K, float *workspace, float *dW, void *stream) {
-  if (P <= 0 || N <= 0 || K <= 0 || (N & 63) || (K & 31) || !Gy || !A || !workspace || !dW || (ldg & 7) || (lda & 7))
+  if (P <= 0 || N <= 0 || K < 8 || (N & 63) || (K & 31) || !Gy || !A || !workspace || !dW || (ldg & 7) || (lda & 7))
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int splits = cpfn_mlp_wgrad_splits(P, N, K);
   long long rps = (P + splits - 1) / splits;
-  rps = ((rps + WG_STEP - 1) / WG_STEP) * WG_STEP;
-  dim3 grid(N / 64, (K + 63) / 64, splits);
-  mlp_wgrad_kernel<<<grid, 256, 0, st>>>((const unsigned short *)Gy, ldg, (const unsigned short *)A, lda, gidx, P, N, K,
-                                         rps, workspace);
+  rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
+  const unsigned short *g = (const unsigned short *)Gy, *a = (const unsigned short *)A;
+  if (wgrad_tile(P, N, K) == 128) {
+    dim3 grid(N / 128, (K + 127) / 128, splits);
+    mlp_wgrad_kernel<128, 128><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace);
+  } else {
+    dim3 grid(N / 64, (K + 63) / 64, splits);
+    mlp_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace);
+  }
   const long long n = (long long)N * K;
-  split_reduce_kernel<<<cpfn_cdiv(n, 16), 256, 0, st>>>(workspace, splits, n, dW);
+  launch_split_reduce(workspace, splits, n, dW, st);
   return cpfn_launch_status();
 }
 
@@ -1018,7 +1094,7 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
   const int nblk = cpfn_bn_bwd_blocks(P);
   smallk_wgrad_kernel<<<nblk, 256, 0, st>>>((const unsigned short *)Gy, X, KS, P, C, workspace, bn_rows_per_block(P));
   const long long n = (long long)C * KS;
-  split_reduce_kernel<<<cpfn_cdiv(n, 16), 256, 0, st>>>(workspace, nblk, n, dW);
+  launch_split_reduce(workspace, nblk, n, dW, st);
   return cpfn_launch_status();
 }
 
@@ -1027,6 +1103,6 @@ extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *worksp
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (int)((P + 1023) / 1024);
   colsum_f32_kernel<<<nblk, 256, 0, st>>>(X, P, C, workspace);
-  split_reduce_kernel<<<cpfn_cdiv(C, 16), 256, 0, st>>>(workspace, nblk, C, out);
+  launch_split_reduce(workspace, nblk, C, out, st);
   return cpfn_launch_status();
 }

@@ -229,6 +229,14 @@ class SPFNTrainer:
         return out
 
     @staticmethod
+    def _copy_all(dst, src):
+        """One multi-tensor copy for the whole geometry set: the int32 and fp32 tensors are viewed as one
+        4-byte dtype so that _foreach_copy_ takes its single-kernel route (mixed dtypes fall back to one
+        memcpy node per tensor: 48 of them per step)."""
+        torch._foreach_copy_([d.view(torch.int32) if d.element_size() == 4 else d for d in dst],
+                             [t.view(torch.int32) if t.element_size() == 4 else t for t in src])
+
+    @staticmethod
     def _like_geom(g, tensors):
         it = iter(tensors)
         out = {}
@@ -271,7 +279,7 @@ class SPFNTrainer:
 
         def geometry_into_B(P):
             fresh = self._flatten_geom(self.module.compute_geometry(P, starts))
-            torch._foreach_copy_(geomB, fresh)
+            self._copy_all(geomB, fresh)
 
         # capture on the same side stream the eager warm-up steps ran on, so that the parameters'
         # AccumulateGrad nodes do not belong to the default stream (which cannot take part in a capture)
@@ -282,7 +290,7 @@ class SPFNTrainer:
             geometry_into_B(sb["P"])
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
-            torch._foreach_copy_(geomA, geomB)
+            self._copy_all(geomA, geomB)
             self.bucket.zero()
             self.module(sb["P"], geometry=st["geomA"])
             st["pre"] = fl.pre_match(self.module.heads_packed, sb)
@@ -323,7 +331,7 @@ class SPFNTrainer:
         if self._prefetched is not None:                       # geometry prefetched by an eager (warm-up) step
             geom = self._take_prefetched(batch["P"])
             if geom is not None:
-                torch._foreach_copy_(st["geomB"], self._flatten_geom(geom))
+                self._copy_all(st["geomB"], self._flatten_geom(geom))
                 st["geom_ready_for"] = batch["P"].data_ptr()
         if st["geom_ready_for"] != batch["P"].data_ptr():      # not announced one step ahead: do it now
             self._draw_starts(st, B, N)
