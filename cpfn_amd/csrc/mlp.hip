@@ -377,64 +377,75 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const unsigned short
   *(uint4 *)(out + e * 8) = *(const uint4 *)o;
 }
 
-// One workgroup per group g of Kn consecutive rows: out[g,c] = relu(max_k z), arg[g,c] = first k
-// attaining it, yarg[g,c] = raw y at that k (needed by the backward pass).
+// One workgroup per (group g of Kn consecutive rows, tile of 256 channels): out[g,c] = relu(max_k z),
+// arg[g,c] = first k attaining it, yarg[g,c] = raw y at that k (needed by the backward pass).
+// Lane layout: chunk ch = t % nch (8 channels, 16-byte loads), row sub-lane rs = t / nch.  The row sub-lanes
+// of one wave are combined with shuffles, the four waves through 8 KB of LDS (the first version staged every
+// sub-lane through 67 KB of LDS: two workgroups per CU, 2 TB/s).
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const unsigned short *__restrict__ Yr,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift, int Kn, int C,
                                                               unsigned short *__restrict__ out,
                                                               unsigned char *__restrict__ arg,
                                                               unsigned short *__restrict__ yarg) {
-  __shared__ float s_z[32][8 * 33];
-  __shared__ int s_k[32][8 * 33];
-  const int g = blockIdx.x, t = threadIdx.x;
-  const int chunks = C / 8;                 // C in {64,128,256,...}; chunk-tiles of 32 chunks
-  const int rsub = 256 / min(chunks, 32);   // row sub-lanes per chunk
-  for (int cb = 0; cb < chunks; cb += 32) {
-    const int nch = min(32, chunks - cb);
-    const int ch = t % nch, rs = t / nch;
-    float bz[8];
-    int bk[8];
+  __shared__ float s_z[4][8 * 33];
+  __shared__ int s_k[4][8 * 33];
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int chunks = C / 8;                 // C in {64,128,256,...}: a power of two >= 8 chunks
+  const int cb = blockIdx.y * 32;
+  const int nch = min(32, chunks - cb);     // 8, 16 or 32
+  const int rsub = 256 / nch;               // row sub-lanes
+  const int ch = t % nch, rs = t / nch;
+  float bz[8];
+  int bk[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { bz[j] = -INFINITY; bk[j] = 0; }
-    const int c0 = (cb + ch) * 8;
-    if (rs < rsub) {
-      float sc[8], sh[8];
+  for (int j = 0; j < 8; ++j) { bz[j] = -INFINITY; bk[j] = 0x7fffffff; }
+  const int c0 = (cb + ch) * 8;
+  {
+    float sc[8], sh[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
-      for (int k = rs; k < Kn; k += rsub) {
-        const uint4 raw = *(const uint4 *)(Yr + ((size_t)g * Kn + k) * C + c0);
-        const unsigned short *y = (const unsigned short *)&raw;
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+    const unsigned short *base = Yr + (size_t)g * Kn * C + c0;
+#pragma unroll 4
+    for (int k = rs; k < Kn; k += rsub) {
+      const uint4 raw = *(const uint4 *)(base + (size_t)k * C);
+      const unsigned short *y = (const unsigned short *)&raw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float z = fmaf(sc[j], bf2f(y[j]), sh[j]);
-          if (z > bz[j]) { bz[j] = z; bk[j] = k; }
-        }
+      for (int j = 0; j < 8; ++j) {
+        const float z = fmaf(sc[j], bf2f(y[j]), sh[j]);
+        if (z > bz[j]) { bz[j] = z; bk[j] = k; }
       }
     }
-    __syncthreads();
-    if (rs < 32) {
+  }
+  // combine the row sub-lanes that live in this wave (lowest k wins ties: "first k attaining the max")
+  for (int off = nch; off < 64; off <<= 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s_z[rs][ch * 8 + j + (ch >> 2)] = bz[j]; s_k[rs][ch * 8 + j + (ch >> 2)] = bk[j]; }
+    for (int j = 0; j < 8; ++j) {
+      const float z2 = __shfl_xor(bz[j], off);
+      const int k2 = __shfl_xor(bk[j], off);
+      if (z2 > bz[j] || (z2 == bz[j] && k2 < bk[j])) { bz[j] = z2; bk[j] = k2; }
     }
-    __syncthreads();
-    // one thread per channel of this chunk-tile combines the row sub-lanes (ascending k on ties)
-    if (t < nch * 8) {
-      const int ch2 = t / 8, j = t % 8;
-      float z = -INFINITY;
-      int kk = 0;
-      const int nrs = min(rsub, 32);
-      for (int r = 0; r < nrs; ++r) {
-        const float zz = s_z[r][ch2 * 8 + j + (ch2 >> 2)];
-        const int k2 = s_k[r][ch2 * 8 + j + (ch2 >> 2)];
-        if (zz > z || (zz == z && k2 < kk)) { z = zz; kk = k2; }
-      }
-      const int c = (cb + ch2) * 8 + j;
-      out[(size_t)g * C + c] = f2bf(fmaxf(z, 0.f));
-      arg[(size_t)g * C + c] = (unsigned char)kk;
-      yarg[(size_t)g * C + c] = Yr[((size_t)g * Kn + kk) * C + c];
+  }
+  if (lane < nch) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_z[wave][ch * 8 + j + (ch >> 2)] = bz[j]; s_k[wave][ch * 8 + j + (ch >> 2)] = bk[j]; }
+  }
+  __syncthreads();
+  if (t < nch * 8) {
+    const int ch2 = t / 8, j = t % 8;
+    float z = -INFINITY;
+    int kk = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float zz = s_z[r][ch2 * 8 + j + (ch2 >> 2)];
+      const int k2 = s_k[r][ch2 * 8 + j + (ch2 >> 2)];
+      if (zz > z || (zz == z && k2 < kk)) { z = zz; kk = k2; }
     }
-    __syncthreads();
+    if (kk >= Kn) kk = 0;                   // all-NaN column: keep row 0 like the first version
+    const int c = (cb + ch2) * 8 + j;
+    out[(size_t)g * C + c] = f2bf(fmaxf(z, 0.f));
+    arg[(size_t)g * C + c] = (unsigned char)kk;
+    yarg[(size_t)g * C + c] = Yr[((size_t)g * Kn + kk) * C + c];
   }
 }
 
@@ -490,41 +501,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s_red[0][t][j] = a1[j]; s_red[1][t][j] = a2[j]; }
     __syncthreads();
-    if (t < nch) {
-      for (int which = 0; which < 2; ++which) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float s = 0.f;
-          for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + t][j];
-          partial[((size_t)blockIdx.x * 2 + which) * C + (cb + t) * 8 + j] = s;
-        }
-      }
+    // 16*nch outputs (2 sums x nch chunks x 8 channels) spread over all 256 lanes, each adding its rsub
+    // row-subset values in a fixed order (the first version left this to nch lanes: a 7 us serial tail)
+    for (int o = t; o < 16 * nch; o += 256) {
+      const int which = o / (8 * nch), rem = o - which * 8 * nch, chn = rem >> 3, j = rem & 7;
+      float s = 0.f;
+      for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + chn][j];
+      partial[((size_t)blockIdx.x * 2 + which) * C + cb * 8 + rem] = s;
     }
     __syncthreads();
-  }
-}
-
-// pooled variant: only the arg-max row of each group carries gradient.
-// partial[gridDim.x][2][C]; one lane per (group, channel) element, grid-stride over groups.
-__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const unsigned short *__restrict__ Gp,
-                                                                 const unsigned short *__restrict__ yarg,
-                                                                 const float *__restrict__ scale,
-                                                                 const float *__restrict__ shift, int G, int C,
-                                                                 int groups_per_block,
-                                                                 float *__restrict__ partial) {
-  const int t = threadIdx.x;
-  const int g0 = blockIdx.x * groups_per_block, g1 = min(G, g0 + groups_per_block);
-  for (int c = t; c < C; c += 256) {
-    const float sc = scale[c], sh = shift[c];
-    float a1 = 0.f, a2 = 0.f;
-    for (int g = g0; g < g1; ++g) {
-      const float yv = bf2f(yarg[(size_t)g * C + c]);
-      const float gz = fmaf(sc, yv, sh) > 0.f ? bf2f(Gp[(size_t)g * C + c]) : 0.f;
-      a1 += gz;
-      a2 = fmaf(gz, yv, a2);
-    }
-    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = a1;
-    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = a2;
   }
 }
 
@@ -589,8 +574,9 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
                                                                 const float *__restrict__ scale,
                                                                 const float *__restrict__ shift,
                                                                 const float *__restrict__ coef, int Kn, int C,
-                                                                unsigned short *__restrict__ Gy) {
+                                                                int kper, unsigned short *__restrict__ Gy) {
   const long long g = blockIdx.x;
+  const int kbeg = blockIdx.y * kper, kend = min(Kn, kbeg + kper);   // row range of this workgroup
   const int t = threadIdx.x;
   const int chunks = C / 8;
   for (int cb = 0; cb < chunks; cb += 256) {
@@ -614,7 +600,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
         c0v[j] = coef[c0 + j]; c1v[j] = coef[C + c0 + j]; c2v[j] = coef[2 * C + c0 + j];
       }
     }
-    for (int k = rs; k < Kn; k += rsub) {
+#pragma unroll 4
+    for (int k = kbeg + rs; k < kend; k += rsub) {
       const size_t off = ((size_t)g * Kn + k) * C + c0;
       const uint4 ry = *(const uint4 *)(Yr + off);
       const unsigned short *y = (const unsigned short *)&ry;
@@ -630,7 +617,6 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
 // ---------------------------------------------------------------- weight gradient
 // dW[n,k] = Σ_p Gy[p,n]·A[p,k]: the contraction runs over ROWS, so both MFMA operands are
 // transposed tiles — staged row-major in LDS and read with ds_read_b64_tr_b16.
-// grid (N/64, K/64, splits); partial[split][N][K] fp32.
 // grid (N/TN, ceil(K/TK), splits); partial[split][N][K] fp32.  The row loop is a 4-deep register pipeline:
 // the 16-byte chunks of step i+4 are in flight while step i goes registers -> LDS -> transposed fragments ->
 // MFMA, so a workgroup's time is its bytes, not (steps x memory latency) as in the first version (which
@@ -813,14 +799,11 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s_red[0][t][j] = a1[j]; s_red[1][t][j] = a2[j]; }
   __syncthreads();
-  if (t < nch) {
-    for (int which = 0; which < 2; ++which)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float s = 0.f;
-        for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + t][j];
-        partial[((size_t)blockIdx.x * 2 + which) * C + t * 8 + j] = s;
-      }
+  for (int o = t; o < 16 * nch; o += 256) {
+    const int which = o / (8 * nch), rem = o - which * 8 * nch, chn = rem >> 3, j = rem & 7;
+    float s = 0.f;
+    for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + chn][j];
+    partial[((size_t)blockIdx.x * 2 + which) * C + rem] = s;
   }
 }
 
@@ -858,14 +841,11 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short 
 #pragma unroll
     for (int q = 0; q < KS_MAX; ++q) s_red[t][j * KS_MAX + q] = a[j][q];
   __syncthreads();
-  if (t < nch) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      for (int q = 0; q < KS; ++q) {
-        float s = 0.f;
-        for (int r = 0; r < rsub; ++r) s += s_red[r * nch + t][j * KS_MAX + q];
-        partial[((size_t)blockIdx.x * C + t * 8 + j) * KS + q] = s;
-      }
+  for (int o = t; o < C * KS; o += 256) {          // output (channel c, tap q), all lanes busy
+    const int c = o / KS, q = o - c * KS;
+    float s = 0.f;
+    for (int r = 0; r < rsub; ++r) s += s_red[r * nch + (c >> 3)][(c & 7) * KS_MAX + q];
+    partial[(size_t)blockIdx.x * C * KS + o] = s;
   }
 }
 
@@ -971,7 +951,7 @@ extern "C" int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const flo
   if (G < 0 || Kn <= 0 || Kn > 256 || C < 64 || (C & 7) || !pow2(C / 8) || !Y || !scale || !shift || !out || !arg || !yarg)
     return CPFN_EINVAL;
   if (G == 0) return 0;
-  bn_relu_maxpool_kernel<<<G, 256, 0, (hipStream_t)stream>>>((const unsigned short *)Y, scale, shift, Kn, C,
+  bn_relu_maxpool_kernel<<<dim3(G, cpfn_cdiv(C / 8, 32)), 256, 0, (hipStream_t)stream>>>((const unsigned short *)Y, scale, shift, Kn, C,
                                                              (unsigned short *)out, arg, (unsigned short *)yarg);
   return cpfn_launch_status();
 }
@@ -994,16 +974,6 @@ extern "C" int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scal
   bn_relu_bwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
       (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial,
       bn_rows_per_block(P));
-  return cpfn_launch_status();
-}
-
-extern "C" int cpfn_bn_pool_bwd_reduce(const void *Gp, const void *yarg, const float *scale, const float *shift,
-                                       int G, int C, int nblk, float *partial, void *stream) {
-  if (G <= 0 || C <= 0 || nblk <= 0 || !Gp || !yarg || !scale || !shift || !partial) return CPFN_EINVAL;
-  const int gpb = (G + nblk - 1) / nblk;
-  bn_pool_bwd_reduce_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>((const unsigned short *)Gp,
-                                                                   (const unsigned short *)yarg, scale, shift, G, C,
-                                                                   gpb, partial);
   return cpfn_launch_status();
 }
 
@@ -1035,9 +1005,15 @@ extern "C" int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, 
   if (G <= 0 || Kn <= 0 || C <= 0 || (C & 7) || !Gp || !arg || !yarg || !Y || !scale || !shift || !coef || !Gy)
     return CPFN_EINVAL;
   if (!pow2(C / 8)) return CPFN_EINVAL;
-  bn_pool_bwd_apply_kernel<<<G, 256, 0, (hipStream_t)stream>>>(
+  // few groups (sa4: 16 groups of 128 rows x 1024 channels): split the rows of a group over workgroups
+  const int rsub = 256 / (C / 8 < 256 ? C / 8 : 256);
+  int ys = G >= 1024 ? 1 : (1024 + G - 1) / G;
+  int kper = cpfn_cdiv(cpfn_cdiv(Kn, ys), rsub) * rsub;        // multiple of the row sub-lane count
+  if (kper < rsub) kper = rsub;
+  ys = cpfn_cdiv(Kn, kper);
+  bn_pool_bwd_apply_kernel<<<dim3(G, ys), 256, 0, (hipStream_t)stream>>>(
       (const unsigned short *)Gp, arg, (const unsigned short *)yarg, (const unsigned short *)Y, scale, shift, coef,
-      Kn, C, (unsigned short *)Gy);
+      Kn, C, kper, (unsigned short *)Gy);
   return cpfn_launch_status();
 }
 

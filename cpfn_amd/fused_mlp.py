@@ -230,10 +230,12 @@ class _FusedStack(torch.autograd.Function):
                 gamma = L.gamma.detach()
                 if arg is not None:
                     G = P // pool_k
-                    nblk = min(64, G)
+                    # only the arg-max row of each group carries gradient: the reduction is the dense one over
+                    # the [G, N] pooled gradient and the pre-BN values at the arg-max rows
+                    nblk = h.cpfn_bn_bwd_blocks(G)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
-                    _check(h.cpfn_bn_pool_bwd_reduce(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, nblk, _ptr(part),
-                                                     _stream()), "cpfn_bn_pool_bwd_reduce")
+                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, None, _ptr(part),
+                                              _stream()), "cpfn_bn_relu_bwd")
                     _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")

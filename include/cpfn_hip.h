@@ -225,13 +225,11 @@ CPFN_API int cpfn_bn_relu_apply(const void *Y, const float *scale, const float *
 CPFN_API int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const float *shift, int G, int Kn,
                                   int C, void *out, unsigned char *arg, void *yarg, void *stream);
 /* Backward pass 1: partial[cpfn_bn_bwd_blocks(P)][2][C] = sum(Gz), sum(Gz*y) with Gz = Ga*[z>0];
- * Gz is also stored when the pointer is non-NULL (may alias Ga). */
+ * Gz is also stored when the pointer is non-NULL (may alias Ga).  The pooled layers call it on the
+ * [G,C] pooled gradient and the pre-BN values at the arg-max rows (only those rows carry gradient). */
 CPFN_API int cpfn_bn_bwd_blocks(long long P);
 CPFN_API int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift,
                               long long P, int C, void *Gz, float *partial, void *stream);
-CPFN_API int cpfn_bn_pool_bwd_reduce(const void *Gp, const void *yarg, const float *scale,
-                                     const float *shift, int G, int C, int nblk, float *partial,
-                                     void *stream);
 /* dgamma, dbeta and coef[3][C] with g_y = coef0*g_z + coef1*y + coef2. */
 CPFN_API int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float count, const float *gamma,
                                   const float *mean, const float *rstd, int training, float *dgamma,
