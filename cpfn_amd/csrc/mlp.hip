@@ -406,14 +406,19 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const unsigned sho
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
     const unsigned short *base = Yr + (size_t)g * Kn * C + c0;
-#pragma unroll 4
-    for (int k = rs; k < Kn; k += rsub) {
-      const uint4 raw = *(const uint4 *)(base + (size_t)k * C);
-      const unsigned short *y = (const unsigned short *)&raw;
+    for (int k = rs; k < Kn; k += 4 * rsub) {      // four rows in flight per lane (see bn_relu_bwd_kernel)
+      uint4 raw[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float z = fmaf(sc[j], bf2f(y[j]), sh[j]);
-        if (z > bz[j]) { bz[j] = z; bk[j] = k; }
+      for (int u = 0; u < 4; ++u) raw[u] = *(const uint4 *)(base + (size_t)min(k + u * rsub, Kn - 1) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k + u * rsub;
+        const unsigned short *y = (const unsigned short *)&raw[u];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float z = fmaf(sc[j], bf2f(y[j]), sh[j]);
+          if (kk < Kn && z > bz[j]) { bz[j] = z; bk[j] = kk; }
+        }
       }
     }
   }
@@ -480,21 +485,33 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
       float sc[8], sh[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
-#pragma unroll 4
-      for (long long r = row0 + rs; r < min(P, row0 + rpb); r += rsub) {
-        const uint4 rg = *(const uint4 *)(Ga + r * C + c0);
-        const uint4 ry = *(const uint4 *)(Yr + r * C + c0);
-        const unsigned short *g = (const unsigned short *)&rg, *y = (const unsigned short *)&ry;
-        unsigned short o[8];
+      // four rows per trip, all eight 16-byte loads issued before the first use (the compiler serialises a
+      // plain row loop: load, wait, store, load, ...); rows past the end are clamped and masked out
+      const long long rend = min(P, row0 + rpb);
+      for (long long r = row0 + rs; r < rend; r += 4 * rsub) {
+        uint4 rg[4], ry[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float yv = bf2f(y[j]);
-          const float gz = fmaf(sc[j], yv, sh[j]) > 0.f ? bf2f(g[j]) : 0.f;
-          o[j] = f2bf(gz);
-          a1[j] += gz;
-          a2[j] = fmaf(gz, yv, a2[j]);
+        for (int u = 0; u < 4; ++u) {
+          const long long rr = min(r + (long long)u * rsub, rend - 1);
+          rg[u] = *(const uint4 *)(Ga + rr * C + c0);
+          ry[u] = *(const uint4 *)(Yr + rr * C + c0);
         }
-        if (Gz) *(uint4 *)(Gz + r * C + c0) = *(const uint4 *)o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long rr = r + (long long)u * rsub;
+          const bool live = rr < rend;
+          const unsigned short *g = (const unsigned short *)&rg[u], *y = (const unsigned short *)&ry[u];
+          unsigned short o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float yv = bf2f(y[j]);
+            const float gz = (live && fmaf(sc[j], yv, sh[j]) > 0.f) ? bf2f(g[j]) : 0.f;
+            o[j] = f2bf(gz);
+            a1[j] += gz;
+            a2[j] = fmaf(gz, yv, a2[j]);
+          }
+          if (Gz && live) *(uint4 *)(Gz + rr * C + c0) = *(const uint4 *)o;
+        }
       }
     }
     __syncthreads();
@@ -600,16 +617,21 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
         c0v[j] = coef[c0 + j]; c1v[j] = coef[C + c0 + j]; c2v[j] = coef[2 * C + c0 + j];
       }
     }
-#pragma unroll 4
-    for (int k = kbeg + rs; k < kend; k += rsub) {
-      const size_t off = ((size_t)g * Kn + k) * C + c0;
-      const uint4 ry = *(const uint4 *)(Yr + off);
-      const unsigned short *y = (const unsigned short *)&ry;
-      unsigned short o[8];
+    for (int k = kbeg + rs; k < kend; k += 4 * rsub) {   // four rows in flight per lane
+      uint4 ry[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        o[j] = f2bf(fmaf(c0v[j], ak[j] == k ? gz[j] : 0.f, fmaf(c1v[j], bf2f(y[j]), c2v[j])));
-      *(uint4 *)(Gy + off) = *(const uint4 *)o;
+      for (int u = 0; u < 4; ++u)
+        ry[u] = *(const uint4 *)(Yr + ((size_t)g * Kn + min(k + u * rsub, kend - 1)) * C + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kk = k + u * rsub;
+        const unsigned short *y = (const unsigned short *)&ry[u];
+        unsigned short o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o[j] = f2bf(fmaf(c0v[j], ak[j] == kk ? gz[j] : 0.f, fmaf(c1v[j], bf2f(y[j]), c2v[j])));
+        if (kk < kend) *(uint4 *)(Gy + ((size_t)g * Kn + kk) * C + c0) = *(const uint4 *)o;
+      }
     }
   }
 }
@@ -761,7 +783,8 @@ __global__ __launch_bounds__(16 * RS) void split_reduce_kernel(const float *__re
 // Y[p,c] = Σ_{j<KS} W[c,j]·X[p,j]  (fp32 inputs: relative coordinates are NOT rounded to bf16),
 // bf16 output + Σy, Σy² partials.  One lane per (row-sub, 8-channel chunk).
 constexpr int KS_MAX = 4;
-__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ X, int KS,
+template <int KS>
+__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ X,
                                                          const float *__restrict__ W, long long P, int C,
                                                          unsigned short *__restrict__ Y,
                                                          float *__restrict__ partial, int rpb) {
@@ -770,30 +793,41 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
   const int nch = C / 8, rsub = 256 / nch;  // C <= 2048, power of two
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
   const long long row0 = (long long)blockIdx.x * rpb;
-  float w[8][KS_MAX];
+  float w[8][KS];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int q = 0; q < KS_MAX; ++q) w[j][q] = q < KS ? W[(c0 + j) * KS + q] : 0.f;
+    for (int q = 0; q < KS; ++q) w[j][q] = W[(c0 + j) * KS + q];
   float a1[8], a2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
   if (rs < rsub) {
-    for (long long r = row0 + rs; r < min(P, row0 + rpb); r += rsub) {
-      float x[KS_MAX];
+    const long long rend = min(P, row0 + rpb);
+    for (long long r = row0 + rs; r < rend; r += 4 * rsub) {      // four rows in flight per lane
+      float x[4][KS];
 #pragma unroll
-      for (int q = 0; q < KS_MAX; ++q) x[q] = q < KS ? X[r * KS + q] : 0.f;
-      unsigned short o[8];
+      for (int u = 0; u < 4; ++u) {
+        const long long rr = min(r + (long long)u * rsub, rend - 1);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < KS_MAX; ++q) v = fmaf(w[j][q], x[q], v);
-        o[j] = f2bf(v);
-        a1[j] += v;
-        a2[j] = fmaf(v, v, a2[j]);
+        for (int q = 0; q < KS; ++q) x[u][q] = X[rr * KS + q];
       }
-      *(uint4 *)(Y + r * C + c0) = *(const uint4 *)o;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long rr = r + (long long)u * rsub;
+        if (rr < rend) {
+          unsigned short o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < KS; ++q) v = fmaf(w[j][q], x[u][q], v);
+            o[j] = f2bf(v);
+            a1[j] += v;
+            a2[j] = fmaf(v, v, a2[j]);
+          }
+          *(uint4 *)(Y + rr * C + c0) = *(const uint4 *)o;
+        }
+      }
     }
   }
 #pragma unroll
@@ -808,57 +842,75 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 }
 
 // dW[c,j] = Σ_p Gy[p,c]·X[p,j]: partial[gridDim.x][C][KS]
+template <int KS>
 __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short *__restrict__ Gy,
-                                                           const float *__restrict__ X, int KS, long long P,
+                                                           const float *__restrict__ X, long long P,
                                                            int C, float *__restrict__ partial, int rpb) {
-  __shared__ float s_red[256][8 * KS_MAX + 1];
+  __shared__ float s_red[256][8 * KS + 1];
   const int t = threadIdx.x;
   const int nch = C / 8, rsub = 256 / nch;
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
   const long long row0 = (long long)blockIdx.x * rpb;
-  float a[8][KS_MAX];
+  float a[8][KS];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int q = 0; q < KS_MAX; ++q) a[j][q] = 0.f;
+    for (int q = 0; q < KS; ++q) a[j][q] = 0.f;
   if (rs < rsub) {
-    for (long long r = row0 + rs; r < min(P, row0 + rpb); r += rsub) {
-      float x[KS_MAX];
+    const long long rend = min(P, row0 + rpb);
+    for (long long r = row0 + rs; r < rend; r += 4 * rsub) {      // four rows in flight per lane
+      float x[4][KS];
+      uint4 rg[4];
 #pragma unroll
-      for (int q = 0; q < KS_MAX; ++q) x[q] = q < KS ? X[r * KS + q] : 0.f;
-      const uint4 rg = *(const uint4 *)(Gy + r * C + c0);
-      const unsigned short *g = (const unsigned short *)&rg;
+      for (int u = 0; u < 4; ++u) {
+        const long long rr = min(r + (long long)u * rsub, rend - 1);
+        rg[u] = *(const uint4 *)(Gy + rr * C + c0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float gv = bf2f(g[j]);
+        for (int q = 0; q < KS; ++q) x[u][q] = X[rr * KS + q];
+      }
 #pragma unroll
-        for (int q = 0; q < KS_MAX; ++q) a[j][q] = fmaf(gv, x[q], a[j][q]);
+      for (int u = 0; u < 4; ++u) {
+        const bool live = r + (long long)u * rsub < rend;
+        const unsigned short *g = (const unsigned short *)&rg[u];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gv = live ? bf2f(g[j]) : 0.f;
+#pragma unroll
+          for (int q = 0; q < KS; ++q) a[j][q] = fmaf(gv, x[u][q], a[j][q]);
+        }
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int q = 0; q < KS_MAX; ++q) s_red[t][j * KS_MAX + q] = a[j][q];
+    for (int q = 0; q < KS; ++q) s_red[t][j * KS + q] = a[j][q];
   __syncthreads();
   for (int o = t; o < C * KS; o += 256) {          // output (channel c, tap q), all lanes busy
     const int c = o / KS, q = o - c * KS;
     float s = 0.f;
-    for (int r = 0; r < rsub; ++r) s += s_red[r * nch + (c >> 3)][(c & 7) * KS_MAX + q];
+    for (int r = 0; r < rsub; ++r) s += s_red[r * nch + (c >> 3)][(c & 7) * KS + q];
     partial[(size_t)blockIdx.x * C * KS + o] = s;
   }
 }
 
 // column sums of a row-major fp32 matrix X[P,C] (C <= 64): partial[gridDim.x][C], then split_reduce.
 // (bias gradient of the heads: torch's strided reduce takes 0.66 ms and rocBLAS gemv 0.8 ms for [131072,35].)
+constexpr int CS_ROWS = 256;   // rows per workgroup
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float *__restrict__ X, long long P, int C,
                                                          float *__restrict__ partial) {
   __shared__ float s_acc[4][64];
   const int t = threadIdx.x, c = t & 63, rs = t >> 6;
-  const long long row0 = (long long)blockIdx.x * 1024;
+  const long long row0 = (long long)blockIdx.x * CS_ROWS, rend = min(P, row0 + CS_ROWS);
   float a = 0.f;
   if (c < C)
-    for (long long r = row0 + rs; r < min(P, row0 + 1024); r += 4) a += X[r * C + c];
+    for (long long r = row0 + rs; r < rend; r += 32) {          // eight rows in flight per lane
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = X[min(r + 4 * u, rend - 1) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (r + 4 * u < rend) ? v[u] : 0.f;
+    }
   s_acc[rs][c] = a;
   __syncthreads();
   if (t < C) partial[(size_t)blockIdx.x * C + t] = s_acc[0][t] + s_acc[1][t] + s_acc[2][t] + s_acc[3][t];
@@ -1057,8 +1109,15 @@ extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long
                                void *stream) {
   if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || !partial)
     return CPFN_EINVAL;
-  smallk_fwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(X, KS, W, P, C, (unsigned short *)Y, partial,
-                                                                             bn_rows_per_block(P));
+  const int nblk = cpfn_bn_bwd_blocks(P), rpb = bn_rows_per_block(P);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short *y = (unsigned short *)Y;
+  switch (KS) {
+    case 1: smallk_fwd_kernel<1><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
+    case 2: smallk_fwd_kernel<2><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
+    case 3: smallk_fwd_kernel<3><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
+    default: smallk_fwd_kernel<4><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
+  }
   return cpfn_launch_status();
 }
 
@@ -1068,7 +1127,14 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = cpfn_bn_bwd_blocks(P);
-  smallk_wgrad_kernel<<<nblk, 256, 0, st>>>((const unsigned short *)Gy, X, KS, P, C, workspace, bn_rows_per_block(P));
+  const unsigned short *g = (const unsigned short *)Gy;
+  const int rpb = bn_rows_per_block(P);
+  switch (KS) {
+    case 1: smallk_wgrad_kernel<1><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
+    case 2: smallk_wgrad_kernel<2><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
+    case 3: smallk_wgrad_kernel<3><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
+    default: smallk_wgrad_kernel<4><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
+  }
   const long long n = (long long)C * KS;
   launch_split_reduce(workspace, nblk, n, dW, st);
   return cpfn_launch_status();
@@ -1077,7 +1143,7 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
 extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *stream) {
   if (P <= 0 || C <= 0 || C > 64 || !X || !workspace || !out) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)((P + 1023) / 1024);
+  const int nblk = (int)((P + CS_ROWS - 1) / CS_ROWS);
   colsum_f32_kernel<<<nblk, 256, 0, st>>>(X, P, C, workspace);
   launch_split_reduce(workspace, nblk, C, out, st);
   return cpfn_launch_status();

@@ -246,7 +246,7 @@ CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, float *workspace, float *dW, void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
- * workspace: ceil(P/1024)*C floats. */
+ * workspace: ceil(P/256)*C floats. */
 CPFN_API int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out,
                              void *stream);
 /* fp32 first layer with K = KS <= 4 inputs (sa1: relative xyz stay fp32):
