@@ -36,6 +36,11 @@ def algebra(M):
             o[..., 15:18], o[..., 18:21])
 
 
+def fit_params(P, W, X):
+    """All four fits in the packed 22-column layout (moments.FitParams): the training path."""
+    return _m.FitParams.apply(P, X, W)
+
+
 def moments(P, W, X=None):
     """One fused pass: M [B,K,52] float64 (X defaults to P for the fits that ignore normals)."""
     return _m.FitMoments.apply(P, P if X is None else X, W)

@@ -18,7 +18,6 @@ from scipy.optimize import linear_sum_assignment
 from .. import lib as _l
 from ..ops import _ptr, _stream
 from . import fitters_common as _fc
-from .losses_implementation import get_mask_gt, reduce_mean_masked_instance
 
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
                 ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
@@ -116,7 +115,49 @@ class ResidueLoss(torch.autograd.Function):
         return gp, None, None, None, None, None
 
 
-def hungarian_cost_pack(S, I_gt):
+class LossTail(torch.autograd.Function):
+    """(S, rp, nl, tl, match, n_gt) -> total [] and parts [5] = normal, type, miou, residue, parameter
+    (cpfn_loss_tail: one launch; the gradients of the total are produced by the same launch)."""
+
+    @staticmethod
+    def forward(ctx, S, rp, nl, tl, match, n_gt, mult6):
+        B, K2, K = S.shape
+        dev = S.device
+        Sc = S.detach().contiguous().float()
+        rpc = None if rp is None else rp.detach().contiguous().float()
+        assert nl.stride(0) == tl.stride(0) and nl.dtype == tl.dtype == torch.float32
+        out = torch.empty(6, dtype=torch.float32, device=dev)
+        nS, nR = B * K2 * K, B * K * 2
+        flat = torch.empty(nS + nR + 2 * B, dtype=torch.float32, device=dev)
+        gS, grp = flat[:nS].view(B, K2, K), flat[nS:nS + nR].view(B, K, 2)
+        gnl, gtl = flat[nS + nR:nS + nR + B], flat[nS + nR + B:]
+        mu = (ctypes.c_float * 6)(*[float(v) for v in mult6])
+        with torch.cuda.device(dev):
+            _l.check(_l.lib().cpfn_loss_tail(_ptr(Sc), _ptr(rpc), _ptr(nl), _ptr(tl), nl.stride(0), _ptr(match.contiguous()),
+                                             _ptr(n_gt.contiguous()), B, K, mu, _ptr(out), _ptr(gS), _ptr(grp), _ptr(gnl),
+                                             _ptr(gtl), _stream()), "cpfn_loss_tail")
+        ctx.save_for_backward(flat)
+        ctx.dims = (B, K2, K, rp is not None)
+        parts = out[1:]
+        ctx.mark_non_differentiable(parts)
+        return out[0], parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        (flat,) = ctx.saved_tensors
+        B, K2, K, has_rp = ctx.dims
+        nS, nR = B * K2 * K, B * K * 2
+        f = flat * g_total
+        return (f[:nS].view(B, K2, K), f[nS:nS + nR].view(B, K, 2) if has_rp else None, f[nS + nR:nS + nR + B],
+                f[nS + nR + B:], None, None, None)
+
+
+def count_gt(I_gt):
+    """[B] int64: number of GT instances per cloud (max label + 1; reference lines 603-606)."""
+    return I_gt.max(dim=1)[0] + 1
+
+
+def hungarian_cost_pack(S, I_gt, n_gt=None):
     """Device part of the assignment: relaxed-IoU cost of every (GT label, prediction) pair from the
     segmented sums plus the number of GT labels, packed as one [B, K*K+1] tensor (reference lines 19-25).
     Capturable; `hungarian_from_pack` is the host part."""
@@ -124,7 +165,8 @@ def hungarian_cost_pack(S, I_gt):
     D, col, cnt = S[:, :K], S[:, K], S[:, K + 1]
     den = cnt.unsqueeze(2) + col.unsqueeze(1) - D
     cost = D / den.clamp(min=1e-10)
-    n_gt = I_gt.max(dim=1)[0] + 1
+    if n_gt is None:
+        n_gt = count_gt(I_gt)
     return torch.cat([cost.reshape(B, -1), n_gt.unsqueeze(1).to(cost.dtype)], dim=1)
 
 
@@ -151,48 +193,29 @@ def pre_match(Y, batch):
     return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"])
 
 
-def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes):
+def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=None):
     """Everything after the assignment: relaxed IoU of the matched pairs, the fitters, residue and
-    axis losses, the weighted total.  (Capturable.)"""
+    axis losses, the weighted total.  (Capturable.)  Four autograd nodes: FitParams -> ResidueLoss ->
+    LossTail (<- SegStats, HeadPost)."""
     m = multipliers
-    K = W.shape[2]
-    I_gt, T_gt = batch["I_gt"], batch["T_gt"]
-    mask_gt = get_mask_gt(I_gt, K)
-    zero = torch.zeros((), device=P.device)
-    # relaxed IoU of the matched pairs (reference lines 77-90)
-    if m["miou"] > 0:
-        D, col, cnt = S[:, :K], S[:, K], S[:, K + 1]
-        dot = torch.gather(D, 2, match.unsqueeze(2)).squeeze(2)
-        den = cnt + torch.gather(col, 1, match) - dot
-        total_miou = reduce_mean_masked_instance(1.0 - dot / (den + 1e-10), mask_gt).mean()
-    else:
-        total_miou = zero
+    T_gt = batch["T_gt"]
+    if n_gt is None:
+        n_gt = count_gt(batch["I_gt"])
+    rp = None
     if m["residue"] > 0 or m["parameter"] > 0:
-        Mo = _fc.moments(P, W, Xn)
-        (plane_n, plane_c, sph_c, sph_r2, cyl_n, cyl_c, cyl_r2, apex, axis) = _fc.algebra(Mo)
-        apex_, axis_, half = _fc.cone_from_moments(Mo, P, W, apex=apex, axis=axis)
-        params = torch.cat([plane_n, plane_c.unsqueeze(-1), sph_c, sph_r2.unsqueeze(-1), cyl_n, cyl_c,
-                            cyl_r2.unsqueeze(-1), apex_, axis_, half.unsqueeze(-1)], dim=-1).float()
+        params = _fc.fit_params(P, W, Xn)
         gt_axes = torch.stack([batch["plane_n_gt"], batch["cylinder_axis_gt"], batch["cone_axis_gt"]], 0)
         ids = [classes.index(c) for c in ("plane", "sphere", "cylinder", "cone")]
         rp = ResidueLoss.apply(params, match, T_gt, batch["points_per_instance"], gt_axes, ids)
-        total_res = reduce_mean_masked_instance(rp[..., 0], mask_gt).mean() if m["residue"] > 0 else zero
-        total_par = reduce_mean_masked_instance(rp[..., 1], mask_gt).mean() if m["parameter"] > 0 else zero
-    else:
-        total_res, total_par = zero, zero
-    total_normal = nl.mean() if m["normal"] > 0 else zero
-    total_type = tl.mean() if m["type"] > 0 else zero
-    total = 0
-    for key, val in (("normal", total_normal), ("type", total_type), ("miou", total_miou), ("residue", total_res),
-                     ("parameter", total_par)):
-        if m[key] > 0:
-            total = total + m[key] * val
-    return total * m["total"], total_normal, total_type, total_miou, total_res, total_par
+    mult6 = [m["normal"], m["type"], m["miou"], m["residue"], m["parameter"], m["total"]]
+    total, parts = LossTail.apply(S, rp, nl, tl, match, n_gt, mult6)
+    return total, parts[0], parts[1], parts[2], parts[3], parts[4]
 
 
 def fused_losses(P, Y, batch, multipliers, classes):
     """P [B,N,3]; Y [B,N,7+K] = packed fp32 heads (normal | type logits | membership logits).
     Returns the reference's (total, normal, type, miou, residue, parameter) scalars."""
     Xn, W, nl, tl, S = pre_match(Y, batch)
-    match = hungarian_from_stats(S.detach(), batch["I_gt"])
-    return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes)
+    n_gt = count_gt(batch["I_gt"])
+    match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
+    return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt)

@@ -42,7 +42,7 @@ class FitMoments(torch.autograd.Function):
         dW = torch.empty_like(W)
         dX = torch.empty_like(X)
         with torch.cuda.device(W.device):
-            _l.check(_l.lib().cpfn_fit_moments_bwd(_ptr(P), _ptr(X), _ptr(W), _ptr(G32), B, N, K, _ptr(dW), _ptr(dX),
+            _l.check(_l.lib().cpfn_fit_moments_bwd(_ptr(P), _ptr(X), _ptr(W), _ptr(G32), B, N, K, None, _ptr(dW), _ptr(dX),
                                                    _stream()), "cpfn_fit_moments_bwd")
         return None, dX, dW
 
@@ -79,7 +79,7 @@ class ConePass(torch.autograd.Function):
         d6 = torch.empty(B, K, 6, dtype=torch.float64, device=W.device)
         with torch.cuda.device(W.device):
             _l.check(h.cpfn_cone_pass_bwd(_ptr(P), _ptr(W), _ptr(ap32), _ptr(ax32), _ptr(g_acos), B, N, K, _ptr(dW),
-                                          _ptr(ws), _ptr(d6), _stream()), "cpfn_cone_pass_bwd")
+                                          _ptr(ws), _ptr(d6), 6, 0, _stream()), "cpfn_cone_pass_bwd")
         return None, dW, d6[..., :3].to(ctx.out_dtypes[0]), d6[..., 3:].to(ctx.out_dtypes[1])
 
 
@@ -104,7 +104,7 @@ class FitAlgebra(torch.autograd.Function):
         G = Mc.numel() // SLOTS
         out = torch.empty(Mc.shape[:-1] + (21,), dtype=torch.float64, device=Mc.device)
         with torch.cuda.device(Mc.device):
-            _l.check(_l.lib().cpfn_fit_algebra_fwd(_ptr(Mc), G, _ptr(out), _stream()), "cpfn_fit_algebra_fwd")
+            _l.check(_l.lib().cpfn_fit_algebra_fwd(_ptr(Mc), G, _ptr(out), None, _stream()), "cpfn_fit_algebra_fwd")
         ctx.save_for_backward(Mc)
         return out
 
@@ -115,5 +115,69 @@ class FitAlgebra(torch.autograd.Function):
         gc = g.contiguous().double()
         gM = torch.empty_like(Mc)
         with torch.cuda.device(Mc.device):
-            _l.check(_l.lib().cpfn_fit_algebra_bwd(_ptr(Mc), _ptr(gc), G, _ptr(gM), _stream()), "cpfn_fit_algebra_bwd")
+            _l.check(_l.lib().cpfn_fit_algebra_bwd(_ptr(Mc), _ptr(gc), None, G, _ptr(gM), None, _stream()),
+                     "cpfn_fit_algebra_bwd")
         return gM
+
+
+class FitParams(torch.autograd.Function):
+    """(P [B,N,3], X [B,N,3] unit normals, W [B,N,K]) -> params [B,K,22] fp32: all four fits of every instance
+    in the layout of include/cpfn_hip.h (cpfn_fit_pack_fwd).  The same kernels as FitMoments -> FitAlgebra ->
+    ConePass -> (sign fix, half angle, concatenation) chained by hand in both directions, so no framework op
+    runs between them: 6 launches forward, 6 backward (the autograd-glued chain was ~60).
+    Differentiable in W and X (SPFN/{plane,sphere,cylinder,cone}_fitter.compute_parameters)."""
+
+    @staticmethod
+    def forward(ctx, P, X, W):
+        P, X, W = _f32c(P), _f32c(X), _f32c(W)
+        for t, n in ((P, "P"), (X, "X"), (W, "W")):
+            _chk(t, n, torch.float32)
+        B, N, K = W.shape
+        dev = W.device
+        h = _l.lib()
+        chunks = h.cpfn_fit_num_chunks(B, N)
+        ws = torch.empty(chunks * B * K * SLOTS, dtype=torch.float64, device=dev)
+        M = torch.empty(B, K, SLOTS, dtype=torch.float64, device=dev)
+        alg = torch.empty(B, K, 21, dtype=torch.float64, device=dev)
+        cone_in = torch.empty(2, B, K, 3, dtype=torch.float32, device=dev)      # apex, axis (fp32) for the cone pass
+        sums = torch.empty(B, K, 2, dtype=torch.float64, device=dev)
+        params = torch.empty(B, K, 22, dtype=torch.float32, device=dev)
+        G = B * K
+        with torch.cuda.device(dev):
+            st = _stream()
+            _l.check(h.cpfn_fit_moments_fwd(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), st), "cpfn_fit_moments_fwd")
+            _l.check(h.cpfn_fit_algebra_fwd(_ptr(M), G, _ptr(alg), _ptr(cone_in), st), "cpfn_fit_algebra_fwd")
+            _l.check(h.cpfn_cone_pass_fwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), B, N, K, _ptr(ws), _ptr(sums),
+                                          st), "cpfn_cone_pass_fwd")
+            _l.check(h.cpfn_fit_pack_fwd(_ptr(alg), _ptr(sums), _ptr(M), G, _ptr(params), st), "cpfn_fit_pack_fwd")
+        ctx.save_for_backward(P, X, W, M, cone_in, sums)
+        return params
+
+    @staticmethod
+    def backward(ctx, g):
+        P, X, W, M, cone_in, sums = ctx.saved_tensors
+        B, N, K = W.shape
+        dev = W.device
+        G = B * K
+        h = _l.lib()
+        gp = g.contiguous().float()
+        g_alg = torch.empty(B, K, 21, dtype=torch.float64, device=dev)
+        g_acos = torch.empty(B, K, dtype=torch.float32, device=dev)
+        gA0 = torch.empty(B, K, dtype=torch.float64, device=dev)
+        chunks = h.cpfn_fit_num_chunks(B, N)
+        ws = torch.empty(chunks * B * K * 6, dtype=torch.float64, device=dev)
+        dWc = torch.empty_like(W)
+        gM32 = torch.empty(B, K, SLOTS, dtype=torch.float32, device=dev)
+        dW = torch.empty_like(W)
+        dX = torch.empty_like(X)
+        with torch.cuda.device(dev):
+            st = _stream()
+            _l.check(h.cpfn_fit_pack_bwd(_ptr(gp), _ptr(sums), _ptr(M), G, _ptr(g_alg), _ptr(g_acos), _ptr(gA0), st),
+                     "cpfn_fit_pack_bwd")
+            # cone pass adjoint: dW term, and d(apex, axis) accumulated into columns 15..20 of g_alg
+            _l.check(h.cpfn_cone_pass_bwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), _ptr(g_acos), B, N, K, _ptr(dWc),
+                                          _ptr(ws), g_alg.data_ptr() + 15 * 8, 21, 1, st), "cpfn_cone_pass_bwd")
+            _l.check(h.cpfn_fit_algebra_bwd(_ptr(M), _ptr(g_alg), _ptr(gA0), G, None, _ptr(gM32), st), "cpfn_fit_algebra_bwd")
+            _l.check(h.cpfn_fit_moments_bwd(_ptr(P), _ptr(X), _ptr(W), _ptr(gM32), B, N, K, _ptr(dWc), _ptr(dW), _ptr(dX), st),
+                     "cpfn_fit_moments_bwd")
+        return None, dX, dW

@@ -265,19 +265,23 @@ __device__ void fit_all(const T *M, T *out) {
   }
 }
 
-__global__ void fit_algebra_fwd_kernel(const double *__restrict__ M, long long G, double *__restrict__ out) {
+__global__ void fit_algebra_fwd_kernel(const double *__restrict__ M, long long G, double *__restrict__ out,
+                                       float *__restrict__ apex_axis32) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   double m[NM], o[NO];
   for (int i = 0; i < NM; ++i) m[i] = M[g * NM + i];
   fit_all<double>(m, o);
   for (int i = 0; i < NO; ++i) out[g * NO + i] = o[i];
+  if (apex_axis32)   // fp32 copy of the cone pass's inputs: apex[G,3] then axis[G,3]
+    for (int i = 0; i < 3; ++i) { apex_axis32[g * 3 + i] = (float)o[15 + i]; apex_axis32[(G + g) * 3 + i] = (float)o[18 + i]; }
 }
 
 // one workgroup of 64 lanes per instance; lane d < 52 computes dL/dM[g,d]
 __global__ __launch_bounds__(64) void fit_algebra_bwd_kernel(const double *__restrict__ M,
-                                                             const double *__restrict__ gout, long long G,
-                                                             double *__restrict__ gM) {
+                                                             const double *__restrict__ gout,
+                                                             const double *__restrict__ gA0, long long G,
+                                                             double *__restrict__ gM, float *__restrict__ gM32) {
   const long long g = blockIdx.x;
   const int d = threadIdx.x;
   if (d >= NM) return;
@@ -286,21 +290,24 @@ __global__ __launch_bounds__(64) void fit_algebra_bwd_kernel(const double *__res
   fit_all<Dual>(m, o);
   double acc = 0.0;
   for (int i = 0; i < NO; ++i) acc += gout[g * NO + i] * o[i].d;
-  gM[g * NM + d] = acc;
+  if (gA0 && d == 0) acc += gA0[g];   // direct dependence of the caller on slot 0 (Σ W), e.g. the cone half angle
+  if (gM) gM[g * NM + d] = acc;
+  if (gM32) gM32[g * NM + d] = (float)acc;
 }
 
 }  // namespace
 
-extern "C" int cpfn_fit_algebra_fwd(const double *M, int64_t G, double *out, void *stream) {
+extern "C" int cpfn_fit_algebra_fwd(const double *M, int64_t G, double *out, float *apex_axis32, void *stream) {
   if (G < 0 || !M || !out) return CPFN_EINVAL;
   if (G == 0) return 0;
-  fit_algebra_fwd_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(M, G, out);
+  fit_algebra_fwd_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(M, G, out, apex_axis32);
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_fit_algebra_bwd(const double *M, const double *gout, int64_t G, double *gM, void *stream) {
-  if (G < 0 || !M || !gout || !gM) return CPFN_EINVAL;
+extern "C" int cpfn_fit_algebra_bwd(const double *M, const double *gout, const double *gA0, int64_t G, double *gM,
+                                    float *gM32, void *stream) {
+  if (G < 0 || !M || !gout || (!gM && !gM32)) return CPFN_EINVAL;
   if (G == 0) return 0;
-  fit_algebra_bwd_kernel<<<(unsigned)G, 64, 0, (hipStream_t)stream>>>(M, gout, G, gM);
+  fit_algebra_bwd_kernel<<<(unsigned)G, 64, 0, (hipStream_t)stream>>>(M, gout, gA0, G, gM, gM32);
   return cpfn_launch_status();
 }

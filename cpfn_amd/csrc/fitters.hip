@@ -129,6 +129,20 @@ __global__ void chunk_reduce_kernel(const double *__restrict__ partial, int nchu
   out[e] = s;
 }
 
+// same sum, written as rows of `width` values into a wider row-major matrix (row stride ld), optionally
+// accumulating: lets the cone adjoint land directly in columns 15..20 of the [G,21] algebra adjoint.
+__global__ void chunk_reduce_strided_kernel(const double *__restrict__ partial, int nchunks, int per_b,
+                                            long long total, int width, int ld, int accumulate,
+                                            double *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / per_b, r = e % per_b;
+  double s = 0.0;
+  for (int c = 0; c < nchunks; ++c) s += partial[((size_t)b * nchunks + c) * per_b + r];
+  double *dst = out + (e / width) * ld + (e % width);
+  *dst = accumulate ? *dst + s : s;
+}
+
 // dW[b,n,k] = Σ_m φ_m G[b,k,m] (B slots only where w >= 1e-10: clamp's adjoint);
 // dX[b,n,:] from the slots that involve the normal.  One lane per point, G[b] in LDS.
 constexpr int FM_MAXK = 64;
@@ -136,6 +150,7 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
                                                                  const float *__restrict__ X,
                                                                  const float *__restrict__ W,
                                                                  const float *__restrict__ G, int N, int K,
+                                                                 const float *__restrict__ dW_add,
                                                                  float *__restrict__ dW, float *__restrict__ dX) {
   __shared__ float s_g[FM_MAXK][FM_SLOTS];
   const int b = blockIdx.y, t = threadIdx.x;
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
   float a[3] = {0, 0, 0}, sa[6] = {0, 0, 0, 0, 0, 0}, sb[6] = {0, 0, 0, 0, 0, 0}, gb[3] = {0, 0, 0};
   const float *wrow = W + ((size_t)b * N + n) * K;
   float *drow = dW + ((size_t)b * N + n) * K;
+  const float *arow = dW_add ? dW_add + ((size_t)b * N + n) * K : nullptr;   // e.g. the cone pass's dW
   for (int k = 0; k < K; ++k) {
     const float *g = s_g[k];
     float ga = 0.f, gB = 0.f;
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
     for (int m = 20; m < 49; ++m) gB = fmaf(f[m], g[m], gB);
     const float w = wrow[k];
     const float wc = fmaxf(w, FM_WEPS);
-    drow[k] = ga + (w >= FM_WEPS ? gB : 0.f);
+    drow[k] = ga + (w >= FM_WEPS ? gB : 0.f) + (arow ? arow[k] : 0.f);
 #pragma unroll
     for (int j = 0; j < 3; ++j) { a[j] = fmaf(w, g[10 + j], a[j]); gb[j] = fmaf(wc, g[46 + j], gb[j]); }
 #pragma unroll
@@ -378,6 +394,46 @@ inline int pick_chunks(int B, int N, int *pts_per_block) {
   return (N + ppb - 1) / ppb;
 }
 
+// ---------------------------------------------------------------- parameter pack (the [B,K]-sized glue)
+// params[g, 0:22] (fp32) = plane n(3) c | sphere centre(3) r² | cylinder axis(3) centre(3) r² | cone apex(3)
+// axis(3) half-angle — the layout the residue / axis losses read.  Columns 0..17 are the algebra's;
+// the cone axis is flipped to sgn = sign(Σ W·(axis·v̂)) with sign(0) -> +1 (cone_fitter.py:28-31) and the
+// half angle is Σ W·acos / (Σ W + 1e-10) clamped to [1e-3, π/2 − 1e-3] (cone_fitter.py:33-35).
+constexpr double PK_LO = 1e-3, PK_HI = 1.5707963267948966 - 1e-3, PK_EPS = 1e-10;
+
+__device__ __forceinline__ double cone_sign(double s0) { return s0 > 0.0 ? 1.0 : (s0 < 0.0 ? -1.0 : (s0 == 0.0 ? 1.0 : s0)); }
+
+__global__ void fit_pack_fwd_kernel(const double *__restrict__ alg, const double *__restrict__ sums,
+                                    const double *__restrict__ M, long long G, float *__restrict__ params) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const double *a = alg + g * 21;
+  float *p = params + g * 22;
+  for (int i = 0; i < 18; ++i) p[i] = (float)a[i];
+  const double sgn = cone_sign(sums[g * 2]);
+  for (int i = 18; i < 21; ++i) p[i] = (float)(a[i] * sgn);
+  const double h = sums[g * 2 + 1] / (M[g * FM_SLOTS] + PK_EPS);
+  p[21] = (float)(h < PK_LO ? PK_LO : (h > PK_HI ? PK_HI : h));   // NaN stays NaN, like torch.clamp
+}
+
+// adjoint: g_alg[G,21] (all columns written), g_acos[G] (fp32, feeds the cone pass adjoint), gA0[G] (slot 0 of M)
+__global__ void fit_pack_bwd_kernel(const float *__restrict__ gparams, const double *__restrict__ sums,
+                                    const double *__restrict__ M, long long G, double *__restrict__ g_alg,
+                                    float *__restrict__ g_acos, double *__restrict__ gA0) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const float *gp = gparams + g * 22;
+  double *ga = g_alg + g * 21;
+  for (int i = 0; i < 18; ++i) ga[i] = (double)gp[i];
+  const double sgn = cone_sign(sums[g * 2]);
+  for (int i = 18; i < 21; ++i) ga[i] = (double)gp[i] * sgn;
+  const double den = M[g * FM_SLOTS] + PK_EPS, s1 = sums[g * 2 + 1];
+  const double h = s1 / den;
+  const double gh = (h >= PK_LO && h <= PK_HI) ? (double)gp[21] : 0.0;   // clamp's adjoint
+  g_acos[g] = (float)(gh / den);
+  gA0[g] = -gh * s1 / (den * den);
+}
+
 }  // namespace
 
 extern "C" int cpfn_fit_num_chunks(int B, int N) {
@@ -399,11 +455,11 @@ extern "C" int cpfn_fit_moments_fwd(const float *P, const float *X, const float 
 }
 
 extern "C" int cpfn_fit_moments_bwd(const float *P, const float *X, const float *W, const float *G, int B,
-                                    int N, int K, float *dW, float *dX, void *stream) {
+                                    int N, int K, const float *dW_add, float *dW, float *dX, void *stream) {
   if (B < 0 || N <= 0 || K <= 0 || K > FM_MAXK || !P || !X || !W || !G || !dW || !dX) return CPFN_EINVAL;
   if (B == 0) return 0;
   moments_bwd_kernel<<<dim3(cpfn_cdiv(N, FM_THREADS), B), FM_THREADS, 0, (hipStream_t)stream>>>(P, X, W, G, N, K,
-                                                                                               dW, dX);
+                                                                                               dW_add, dW, dX);
   return cpfn_launch_status();
 }
 
@@ -422,8 +478,8 @@ extern "C" int cpfn_cone_pass_fwd(const float *P, const float *W, const float *a
 
 extern "C" int cpfn_cone_pass_bwd(const float *P, const float *W, const float *apex, const float *axis,
                                   const float *g_acos, int B, int N, int K, float *dW, double *workspace,
-                                  double *d_apex_axis, void *stream) {
-  if (B < 0 || N <= 0 || K <= 0 || !P || !W || !apex || !axis || !g_acos || !dW || !workspace || !d_apex_axis)
+                                  double *d_apex_axis, int ld, int accumulate, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || ld < 6 || !P || !W || !apex || !axis || !g_acos || !dW || !workspace || !d_apex_axis)
     return CPFN_EINVAL;
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -431,7 +487,8 @@ extern "C" int cpfn_cone_pass_bwd(const float *P, const float *W, const float *a
   const int chunks = pick_chunks(B, N, &ppb);
   cone_bwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, W, apex, axis, g_acos, N, K, ppb, dW, workspace);
   const long long total = (long long)B * K * 6;
-  chunk_reduce_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * 6, total, d_apex_axis);
+  chunk_reduce_strided_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * 6, total, 6, ld, accumulate,
+                                                                     d_apex_axis);
   return cpfn_launch_status();
 }
 
@@ -439,5 +496,21 @@ extern "C" int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, v
   if (G < 0 || !S6 || !lam || !V) return CPFN_EINVAL;
   if (G == 0) return 0;
   eigh3_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(S6, G, lam, V);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_fit_pack_fwd(const double *alg, const double *sums, const double *M, int64_t G, float *params,
+                                 void *stream) {
+  if (G < 0 || !alg || !sums || !M || !params) return CPFN_EINVAL;
+  if (G == 0) return 0;
+  fit_pack_fwd_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(alg, sums, M, G, params);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_fit_pack_bwd(const float *gparams, const double *sums, const double *M, int64_t G, double *g_alg,
+                                 float *g_acos, double *gA0, void *stream) {
+  if (G < 0 || !gparams || !sums || !M || !g_alg || !g_acos || !gA0) return CPFN_EINVAL;
+  if (G == 0) return 0;
+  fit_pack_bwd_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(gparams, sums, M, G, g_alg, g_acos, gA0);
   return cpfn_launch_status();
 }

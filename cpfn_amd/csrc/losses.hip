@@ -356,6 +356,81 @@ inline int loss_chunks(int B, int N, int *ppb) {
   return (N + p - 1) / p;
 }
 
+// ------------------------------------------------------------------------------------ loss tail
+// Everything after the fitters that is [B,K]-sized (losses_implementation.py:77-90, 603-606, 633-673):
+// relaxed IoU of the matched pairs from the segmented sums S, the per-cloud masked means of the IoU /
+// residue / axis losses over the n_gt existing instances, the batch means and the weighted total — and, in the
+// same pass, d total / d (S, rp, nl, tl), which are closed-form.  One workgroup; one lane per cloud.
+//   out[6] = total, normal, type, miou, residue, parameter      mult[6] = normal, type, miou, residue, parameter, total
+constexpr int LT_MAXB = 1024;
+struct LossMult { float m[6]; };
+__global__ __launch_bounds__(256) void loss_tail_kernel(const float *__restrict__ S, const float *__restrict__ rp,
+                                                        const float *__restrict__ nl, const float *__restrict__ tl,
+                                                        int nl_stride, const long long *__restrict__ match,
+                                                        const long long *__restrict__ n_gt, int B, int K, LossMult mu,
+                                                        float *__restrict__ out, float *__restrict__ gS,
+                                                        float *__restrict__ grp, float *__restrict__ gnl,
+                                                        float *__restrict__ gtl) {
+  __shared__ float s_v[5][LT_MAXB];
+  const int t = threadIdx.x;
+  const bool on_miou = mu.m[2] > 0.f, on_res = mu.m[3] > 0.f && rp, on_par = mu.m[4] > 0.f && rp;
+  const float invB = 1.f / (float)B, mt = mu.m[5];
+  for (long long e = t; e < (long long)B * (K + 2) * K; e += 256) gS[e] = 0.f;
+  __syncthreads();
+  for (int b = t; b < B; b += 256) {
+    long long nn = n_gt[b];
+    const int n = (int)(nn < 0 ? 0 : (nn > K ? K : nn));
+    const float *Sb = S + (size_t)b * (K + 2) * K;
+    float *gSb = gS + (size_t)b * (K + 2) * K;
+    const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+    const float c_miou = on_miou ? mt * mu.m[2] * invB * inv_n : 0.f;
+    float miou = 0.f, res = 0.f, par = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const bool live = k < n;
+      if (live && on_miou) {
+        long long m = match[(size_t)b * K + k];
+        m = m < 0 ? 0 : (m >= K ? K - 1 : m);
+        const float dot = Sb[k * K + m], colv = Sb[K * K + m], cntv = Sb[(K + 1) * K + k];
+        const float q = cntv + colv - dot + 1e-10f;
+        miou += 1.f - dot / q;
+        const float dq = dot / (q * q);
+        gSb[k * K + m] += -c_miou * (1.f / q + dq);
+        gSb[K * K + m] += c_miou * dq;
+        gSb[(K + 1) * K + k] += c_miou * dq;
+      }
+      if (rp) {
+        if (live) { res += rp[((size_t)b * K + k) * 2]; par += rp[((size_t)b * K + k) * 2 + 1]; }
+        grp[((size_t)b * K + k) * 2] = (live && on_res) ? mt * mu.m[3] * invB * inv_n : 0.f;
+        grp[((size_t)b * K + k) * 2 + 1] = (live && on_par) ? mt * mu.m[4] * invB * inv_n : 0.f;
+      }
+    }
+    s_v[0][b] = nl[(size_t)b * nl_stride];
+    s_v[1][b] = tl[(size_t)b * nl_stride];
+    s_v[2][b] = miou * inv_n;
+    s_v[3][b] = res * inv_n;
+    s_v[4][b] = par * inv_n;
+    gnl[b] = mu.m[0] > 0.f ? mt * mu.m[0] * invB : 0.f;
+    gtl[b] = mu.m[1] > 0.f ? mt * mu.m[1] * invB : 0.f;
+  }
+  __syncthreads();
+  if (t < 5) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += s_v[t][b];
+    s *= invB;
+    const bool on = t == 3 ? on_res : (t == 4 ? on_par : mu.m[t] > 0.f);
+    s_v[t][0] = on ? s : 0.f;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float total = 0.f;
+    for (int i = 0; i < 5; ++i) {
+      out[1 + i] = s_v[i][0];
+      if (mu.m[i] > 0.f) total += mu.m[i] * s_v[i][0];
+    }
+    out[0] = total * mt;
+  }
+}
+
 }  // namespace
 
 extern "C" int cpfn_head_post_chunks(int N) { return cpfn_cdiv(N, LP_THREADS); }
@@ -423,5 +498,18 @@ extern "C" int cpfn_residue_bwd(const float *gout, const float *dout, const int6
   residue_bwd_kernel<<<cpfn_cdiv(B * K, 64), 64, 0, (hipStream_t)stream>>>(gout, dout, (const long long *)match,
                                                                           (const long long *)Tgt, K, B * K, type_ids[0],
                                                                           type_ids[1], type_ids[2], type_ids[3], gparams);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_loss_tail(const float *S, const float *rp, const float *nl, const float *tl, int nl_stride,
+                              const int64_t *match, const int64_t *n_gt, int B, int K, const float *mult6, float *out6,
+                              float *gS, float *grp, float *gnl, float *gtl, void *stream) {
+  if (B <= 0 || B > LT_MAXB || K <= 0 || nl_stride < 1 || !S || !nl || !tl || !match || !n_gt || !mult6 || !out6 || !gS ||
+      !gnl || !gtl || (rp && !grp))
+    return CPFN_EINVAL;
+  LossMult mu;
+  for (int i = 0; i < 6; ++i) mu.m[i] = mult6[i];   // host array, passed by value
+  loss_tail_kernel<<<1, 256, 0, (hipStream_t)stream>>>(S, rp, nl, tl, nl_stride, (const long long *)match,
+                                                       (const long long *)n_gt, B, K, mu, out6, gS, grp, gnl, gtl);
   return cpfn_launch_status();
 }

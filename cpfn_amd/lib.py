@@ -38,11 +38,14 @@ SIGNATURES = {
     "cpfn_csr_gather_sum_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_fit_num_chunks": [_i, _i],
     "cpfn_fit_moments_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
-    "cpfn_fit_moments_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_fit_moments_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_cone_pass_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
-    "cpfn_cone_pass_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "cpfn_fit_algebra_fwd": [_vp, _i64, _vp, _vp],
-    "cpfn_fit_algebra_bwd": [_vp, _vp, _i64, _vp, _vp],
+    "cpfn_cone_pass_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "cpfn_fit_algebra_fwd": [_vp, _i64, _vp, _vp, _vp],
+    "cpfn_fit_algebra_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "cpfn_fit_pack_fwd": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "cpfn_fit_pack_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
+    "cpfn_loss_tail": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_eigh3": [_vp, _i64, _vp, _vp, _vp],
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp],

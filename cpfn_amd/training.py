@@ -294,14 +294,15 @@ class SPFNTrainer:
             self.bucket.zero()
             self.module(sb["P"], geometry=st["geomA"])
             st["pre"] = fl.pre_match(self.module.heads_packed, sb)
-            st["cost_pack"] = fl.hungarian_cost_pack(st["pre"][4].detach(), sb["I_gt"])   # device part, in-graph
+            st["n_gt"] = fl.count_gt(sb["I_gt"])
+            st["cost_pack"] = fl.hungarian_cost_pack(st["pre"][4].detach(), sb["I_gt"], st["n_gt"])   # device part, in-graph
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
             self._gside.wait_stream(self._gstream)                  # fork: next batch's geometry
             with torch.cuda.stream(self._gside):
                 geometry_into_B(st["P_next"])
             Xn, W, nl, tl, S = st["pre"]
-            out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes)
+            out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, st["n_gt"])
             out[0].backward()
             self.bucket.collect()
             if world == 1:

@@ -166,19 +166,24 @@ CPFN_API int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets
 CPFN_API int cpfn_fit_num_chunks(int B, int N);
 CPFN_API int cpfn_fit_moments_fwd(const float *P, const float *X, const float *W, int B, int N,
                                   int K, double *workspace, double *M, void *stream);
-/* Adjoint: G[B,K,52] (fp32) = dL/dM  ->  dW[B,N,K], dX[B,N,3] (both overwritten). K <= 64. */
+/* Adjoint: G[B,K,52] (fp32) = dL/dM  ->  dW[B,N,K], dX[B,N,3] (both overwritten). K <= 64.
+ * dW_add (may be NULL): a [B,N,K] term added into dW (the cone pass's dW), saving a separate pass. */
 CPFN_API int cpfn_fit_moments_bwd(const float *P, const float *X, const float *W, const float *G,
-                                  int B, int N, int K, float *dW, float *dX, void *stream);
+                                  int B, int N, int K, const float *dW_add, float *dW, float *dX,
+                                  void *stream);
 /* Cone second pass (SPFN/cone_fitter.py:25-34) for fitted apex/axis [B,K,3] (fp32):
  *   out[b,k,0] = sum_n W * (axis . normalize(p - apex)),  out[b,k,1] = sum_n W * acos_safe(|.|)
  * workspace: chunks * B * K * 2 doubles. */
 CPFN_API int cpfn_cone_pass_fwd(const float *P, const float *W, const float *apex, const float *axis,
                                 int B, int N, int K, double *workspace, double *out, void *stream);
-/* Adjoint w.r.t. out[...,1] (g_acos[B,K] fp32): dW[B,N,K] (overwritten) and
- * d_apex_axis[B,K,6] (fp64: d apex, d axis).  workspace: chunks * B * K * 6 doubles. */
+/* Adjoint w.r.t. out[...,1] (g_acos[B,K] fp32): dW[B,N,K] (overwritten) and the fp64 adjoint of
+ * (apex, axis): 6 values per instance written at d_apex_axis + (b*K+k)*ld (ld >= 6; ld = 6 for a dense
+ * [B,K,6]; ld = 21 with the pointer at column 15 lands in the algebra adjoint), added to what is
+ * there when `accumulate`.  workspace: chunks * B * K * 6 doubles. */
 CPFN_API int cpfn_cone_pass_bwd(const float *P, const float *W, const float *apex, const float *axis,
                                 const float *g_acos, int B, int N, int K, float *dW,
-                                double *workspace, double *d_apex_axis, void *stream);
+                                double *workspace, double *d_apex_axis, int ld, int accumulate,
+                                void *stream);
 
 /* Per-instance algebra of all four fitters on the moments (the [B,K]-sized tail of
  * SPFN/{plane,sphere,cylinder,cone}_fitter.compute_parameters; SPFN/geometry_utils.py:8-27,
@@ -187,9 +192,22 @@ CPFN_API int cpfn_cone_pass_bwd(const float *P, const float *W, const float *ape
  *   r2(1) | cone apex(3) | cone axis before the sign fix(3).   G = B*K instances, fp64.
  * The backward entry returns gM[G,52] = J^T gout by forward-mode AD through the same code. */
 #define CPFN_FIT_OUTPUTS 21
-CPFN_API int cpfn_fit_algebra_fwd(const double *M, int64_t G, double *out, void *stream);
-CPFN_API int cpfn_fit_algebra_bwd(const double *M, const double *gout, int64_t G, double *gM,
+/* apex_axis32 (may be NULL): fp32 copy of the cone columns as apex[G,3] followed by axis[G,3] — the
+ * inputs of cpfn_cone_pass_*.  Backward: gA0[G] (may be NULL) is added to slot 0 of the result (a
+ * direct dependence on sum(W)); the result goes to gM (fp64) and/or gM32 (fp32), either may be NULL. */
+CPFN_API int cpfn_fit_algebra_fwd(const double *M, int64_t G, double *out, float *apex_axis32,
                                   void *stream);
+CPFN_API int cpfn_fit_algebra_bwd(const double *M, const double *gout, const double *gA0, int64_t G,
+                                  double *gM, float *gM32, void *stream);
+/* The 22 fp32 parameters per instance the residue / axis losses read, from the algebra's out[G,21],
+ * the cone pass's sums[G,2] and M (slot 0): columns 0..17 as they are, cone axis flipped to
+ * sign(sums0) (sign(0) = +1, SPFN/cone_fitter.py:28-31), half angle = sums1 / (M0 + 1e-10) clamped to
+ * [1e-3, pi/2 - 1e-3] (cone_fitter.py:33-35).  Adjoint: g_alg[G,21] (every column written),
+ * g_acos[G] fp32 (for cpfn_cone_pass_bwd) and gA0[G] (for cpfn_fit_algebra_bwd). */
+CPFN_API int cpfn_fit_pack_fwd(const double *alg, const double *sums, const double *M, int64_t G,
+                               float *params, void *stream);
+CPFN_API int cpfn_fit_pack_bwd(const float *gparams, const double *sums, const double *M, int64_t G,
+                               double *g_alg, float *g_acos, double *gA0, void *stream);
 
 /* Batched symmetric 3x3 eigen-decomposition (fp64 Jacobi) replacing the torch.svd call of
  * Custom_svd_v_colum (SPFN/differentiable_tls.py:126) on the PSD moment matrices.
@@ -295,6 +313,18 @@ CPFN_API int cpfn_residue_fwd(const float *params, const int64_t *match, const i
 CPFN_API int cpfn_residue_bwd(const float *gout, const float *dout, const int64_t *match,
                               const int64_t *Tgt, int B, int K, const int *type_ids, float *gparams,
                               void *stream);
+
+/* The [B,K]-sized tail of compute_all_losses (SPFN/losses_implementation.py:77-90, 603-606, 633-673)
+ * in one launch: relaxed IoU of the matched pairs from S[B,K+2,K] (cpfn_seg_stats_fwd), masked means
+ * over the n_gt[b] existing instances of that and of rp[B,K,2] (cpfn_residue_fwd; may be NULL), batch
+ * means of those and of nl/tl (element stride nl_stride), the weighted total.  mult6 (HOST array) =
+ * normal, type, miou, residue, parameter, total multipliers; a part with multiplier <= 0 is reported
+ * as 0 and gets no gradient.  out6 = total, normal, type, miou, residue, parameter.  Also written:
+ * d total / d S, rp, nl, tl (gS[B,K+2,K], grp[B,K,2], gnl[B], gtl[B]).  B <= 1024. */
+CPFN_API int cpfn_loss_tail(const float *S, const float *rp, const float *nl, const float *tl,
+                            int nl_stride, const int64_t *match, const int64_t *n_gt, int B, int K,
+                            const float *mult6, float *out6, float *gS, float *grp, float *gnl,
+                            float *gtl, void *stream);
 
 #ifdef __cplusplus
 }

@@ -103,3 +103,32 @@ def test_fused_losses_match_reference_shaped_losses():
     assert err < 2e-3, err
     m1 = fused_losses.hungarian_from_stats(fused_losses.SegStats.apply(W.detach(), batch["I_gt"]), batch["I_gt"])
     assert torch.equal(m1, li.hungarian_matching(W.detach(), batch["I_gt"]))
+
+
+@pytest.mark.parametrize("mult", [dict(miou=0.7, normal=1.3, type=0.5, parameter=2.0, residue=1.5, total=0.9),
+                                  dict(miou=1.0, normal=0.0, type=1.0, parameter=0.0, residue=1.0, total=1.0)])
+def test_loss_tail_multipliers(mult):
+    """cpfn_loss_tail / FitParams with non-unit and zero multipliers against the op-by-op losses."""
+    from cpfn_amd.SPFN import fused_losses, losses_implementation as li
+    B, N, K = 2, 2048, 28
+    batch = {k: v.to(dev()) for k, v in synthetic.training_batch(B, N=N, n_prims=6, n_inst_points=128, seed=21).items()}
+    g = torch.Generator().manual_seed(5)
+    Y0 = torch.randn(B, N, 7 + K, generator=g)
+    Y0[:, :, 7:].scatter_add_(2, batch["I_gt"].cpu().unsqueeze(2), torch.full((B, N, 1), 4.0))
+    Y0[:, :, :3] += 2 * batch["X_gt"].cpu()
+    classes = ["sphere", "plane", "cylinder", "cone"]
+    Ya = Y0.to(dev()).requires_grad_(True)
+    out_f = fused_losses.fused_losses(batch["P"], Ya, batch, mult, classes)
+    out_f[0].backward()
+    Yb = Y0.to(dev()).requires_grad_(True)
+    X = torch.nn.functional.normalize(Yb[..., :3], p=2, dim=2, eps=1e-12)
+    W = torch.softmax(Yb[..., 7:], dim=2)
+    gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"], "cone_axis": batch["cone_axis_gt"]}
+    out_r = li.compute_all_losses(batch["P"], W, batch["I_gt"], X, batch["X_gt"], Yb[..., 3:7], batch["T_gt"], gt,
+                                  batch["points_per_instance"], mult["normal"], mult["type"], mult["miou"], mult["residue"],
+                                  mult["parameter"], mult["total"], False, mode_seg="mIoU", classes=classes)
+    out_r[0].backward()
+    for a, b in zip(out_f[:6], out_r[:6]):
+        assert abs(float(a) - float(b)) <= 2e-4 * abs(float(b)) + 1e-6, (float(a), float(b))
+    err = float((Ya.grad - Yb.grad).norm() / Yb.grad.norm())
+    assert err < 2e-3, err
