@@ -57,6 +57,8 @@ class PointNet2(torch.nn.Module):
 
     def forward(self, x, glob_features=None, loc_features=None, fast=True, fps_start=None, geometry=None):
         from .. import fused_mlp
+        if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda:
+            fused_mlp.refresh_weight_panels(self.parameters())     # one multi-tensor fp32 -> bf16 conversion
         with fused_mlp.deferred_bn_counters():
             return self._forward(x, glob_features, loc_features, fps_start, geometry)
 

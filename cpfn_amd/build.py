@@ -9,6 +9,7 @@ bit-identical to the reference's CPU arithmetic, so the compiler may not fuse a
 multiply into an add unless the source says fma.
 """
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -57,12 +58,38 @@ def _stale(target, deps):
 def _compile(src, flags, force):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     if force or _stale(obj, _deps(src)):
-        cmd = [_hipcc()] + COMMON + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc()] + COMMON + flags + ["-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-4000:]))
+        _check_isa(src)
         return obj, True
     return obj, False
+
+
+# 96-bit DS instructions are banned: ds_read_b96 was measured to return wrong data on gfx950 while another
+# kernel's workgroup on the same CU writes LDS heavily (csrc/common.h: cpfn_lds_read4).  The compiler emits
+# them when three of four floats of a 16-byte LDS element are used; the device assembly kept by
+# -save-temps is scanned after every compile so that a new one cannot slip in.
+_BANNED_ISA = re.compile(r"\bds_(read|write|load|store)_b96\b")
+
+
+def _check_isa(src):
+    stem = src.replace(".hip", "")
+    temps = [f for f in os.listdir(OBJ) if (f.startswith(stem + "-hip-") or f.startswith(stem + "-host-") or
+                                            f.startswith(src + "-hip-")) and f != stem + ".o"]
+    asm = [f for f in temps if f.startswith(stem + "-hip-amdgcn") and f.endswith(".s")]
+    try:
+        if not asm:
+            raise RuntimeError("device assembly of %s not found under %s (needed for the ISA check)" % (src, OBJ))
+        hits = _BANNED_ISA.findall(open(os.path.join(OBJ, asm[0])).read())
+        if hits:
+            os.remove(os.path.join(OBJ, stem + ".o"))
+            raise RuntimeError("%s: %d banned 96-bit DS instruction(s) in the gfx950 code (see csrc/common.h, "
+                               "cpfn_lds_read4)" % (src, len(hits)))
+    finally:
+        for f in temps:                      # -save-temps leaves ~8 MB per source; only the object is kept
+            os.remove(os.path.join(OBJ, f))
 
 
 def build(force=False, verbose=False):

@@ -31,6 +31,15 @@ __device__ __forceinline__ float cpfn_pair_sqdist(float sx, float sy, float sz, 
   return __fadd_rn(d, dn);
 }
 
+// 16-byte LDS read that the compiler may neither narrow nor merge.  Why it exists: when only three of the four
+// floats are used the compiler narrows the access to ds_read_b96, and on gfx950 that instruction was measured to
+// return wrong data now and then while a workgroup of ANOTHER kernel on the same CU is writing LDS heavily
+// (furthest-point sampling next to the weight-gradient kernel: 195 of 200 runs picked a spurious point; three
+// ds_read_b32 or one ds_read_b128: 0 of 200 — tools/debug_fps_eager.py).  build.py rejects any object that
+// contains a 96-bit DS instruction.
+typedef float cpfn_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cpfn_f32x4 cpfn_lds_read4(const float *p) { return *(const volatile cpfn_f32x4 *)p; }
+
 __device__ __forceinline__ unsigned long long cpfn_shfl_xor_u64(unsigned long long v, int m) {
   unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
   lo = __shfl_xor(lo, m, CPFN_WAVE);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
                                                                  const float *__restrict__ G, int N, int K,
                                                                  const float *__restrict__ dW_add,
                                                                  float *__restrict__ dW, float *__restrict__ dX) {
-  __shared__ float s_g[FM_MAXK][FM_SLOTS];
+  __shared__ __attribute__((aligned(16))) float s_g[FM_MAXK][FM_SLOTS];   // rows are 208 B: 16-byte aligned
   const int b = blockIdx.y, t = threadIdx.x;
   for (int e = t; e < K * FM_SLOTS; e += FM_THREADS) s_g[e / FM_SLOTS][e % FM_SLOTS] = G[(size_t)b * K * FM_SLOTS + e];
   __syncthreads();
@@ -167,7 +167,13 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
   float *drow = dW + ((size_t)b * N + n) * K;
   const float *arow = dW_add ? dW_add + ((size_t)b * N + n) * K : nullptr;   // e.g. the cone pass's dW
   for (int k = 0; k < K; ++k) {
-    const float *g = s_g[k];
+    // the whole 52-slot row as 13 un-narrowable 16-byte LDS reads (cpfn_lds_read4: no ds_read_b96)
+    float g[FM_SLOTS];
+#pragma unroll
+    for (int q = 0; q < FM_SLOTS / 4; ++q) {
+      const cpfn_f32x4 v = cpfn_lds_read4(&s_g[k][4 * q]);
+      g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+    }
     float ga = 0.f, gB = 0.f;
 #pragma unroll
     for (int m = 0; m < 19; ++m) ga = fmaf(f[m], g[m], ga);

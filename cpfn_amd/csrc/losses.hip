@@ -287,7 +287,7 @@ __global__ __launch_bounds__(128) void residue_fwd_kernel(const float *__restric
                                                           const float *__restrict__ pts, const float *__restrict__ gt_axes,
                                                           int K, int NP, int tid_plane, int tid_sphere, int tid_cyl,
                                                           int tid_cone, float *__restrict__ out, float *__restrict__ dout) {
-  __shared__ float s_red[2][8];
+  __shared__ __attribute__((aligned(16))) float s_red[2][8];
   const int bk = blockIdx.x, b = bk / K, t = threadIdx.x;
   const long long m = match[bk], ty = Tgt[bk];
   const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
@@ -307,8 +307,13 @@ __global__ __launch_bounds__(128) void residue_fwd_kernel(const float *__restric
   __syncthreads();
   if (t == 0) {
     const float invn = 1.0f / (float)NP;
-    out[bk * 2] = (s_red[0][0] + s_red[1][0]) * invn;
-    for (int j = 0; j < 7; ++j) dout[bk * 10 + j] = (s_red[0][1 + j] + s_red[1][1 + j]) * invn;
+    float r[8];   // both rows through un-narrowable 16-byte reads (cpfn_lds_read4: no ds_read_b96)
+    for (int h = 0; h < 2; ++h) {
+      const cpfn_f32x4 u = cpfn_lds_read4(&s_red[0][4 * h]), v = cpfn_lds_read4(&s_red[1][4 * h]);
+      r[4 * h] = u.x + v.x; r[4 * h + 1] = u.y + v.y; r[4 * h + 2] = u.z + v.z; r[4 * h + 3] = u.w + v.w;
+    }
+    out[bk * 2] = r[0] * invn;
+    for (int j = 0; j < 7; ++j) dout[bk * 10 + j] = r[1 + j] * invn;
     // axis agreement 1 − |a_pred·a_gt| (plane normal / cylinder axis / cone axis; 0 for spheres)
     float pl = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
     if (kind != 1) {

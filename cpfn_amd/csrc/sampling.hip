@@ -1,8 +1,8 @@
 // Furthest-point sampling for gfx950.
 //
 // One workgroup per cloud.  The running min-distance of every point lives in
-// registers (PPT points per lane), the cloud itself is mirrored in LDS as float4 so
-// that the coordinates of the newly selected point are one broadcast ds_read_b128
+// registers (PPT points per lane), the cloud itself is mirrored in LDS (x, y, z planes) so
+// that the coordinates of the newly selected point are three broadcast ds_read_b32
 // away, and the arg-max is a 64-bit key max-reduction:
 //     key = (fp32 bits of distance) << 32 | ~index
 // (distances are >= 0 so their bit patterns order like the floats; ~index makes the
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
                                                           const int *__restrict__ start, int flags,
                                                           int *__restrict__ idx_out) {
   constexpr int NW = NT / CPFN_WAVE;
-  __shared__ float4 s_xyz[NT * PPT];
+  __shared__ float s_x[NT * PPT], s_y[NT * PPT], s_z[NT * PPT];   // three b32 broadcasts per sample, NOT one float4:
+                                                                   // see cpfn_lds_read4 in common.h (ds_read_b96)
   __shared__ unsigned long long s_key[2][NW > 1 ? NW : 1];
 
   const int b = blockIdx.x;
@@ -54,19 +55,19 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       if ((flags & CPFN_FPS_SKIP_NEAR_ORIGIN) && cpfn_sqnorm3(x, y, z) <= 1e-3f) m = -1.0f;
     }
     px[j] = x; py[j] = y; pz[j] = z; md[j] = m;
-    s_xyz[k] = make_float4(x, y, z, 0.f);
+    s_x[k] = x; s_y[k] = y; s_z[k] = z;
   }
   __syncthreads();
 
   unsigned far = start ? (unsigned)start[b] : 0u;
   for (int i = 0; i < S; ++i) {
     if (t == 0) out[i] = (int)far;
-    const float4 f = s_xyz[far];
+    const float fx = s_x[far], fy = s_y[far], fz = s_z[far];
     float best = -1.0f;
     unsigned besti = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-      const float dx = __fsub_rn(px[j], f.x), dy = __fsub_rn(py[j], f.y), dz = __fsub_rn(pz[j], f.z);
+      const float dx = __fsub_rn(px[j], fx), dy = __fsub_rn(py[j], fy), dz = __fsub_rn(pz[j], fz);
       const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
       float m = md[j];
       m = d < m ? d : m;  // never true for m = -1 (d >= 0)

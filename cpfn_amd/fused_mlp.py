@@ -100,11 +100,38 @@ def bf16_weight(W, rows, cols):
     key = (id(W), rows, cols)
     ent = _wcache.get(key)
     if ent is None or ent[1]() is not W or ent[0].device != W.device:
-        ent = [torch.zeros(rows, cols, dtype=BF16, device=W.device), weakref.ref(W)]
+        ent = [torch.zeros(rows, cols, dtype=BF16, device=W.device), weakref.ref(W), -1]
         _wcache[key] = ent
-    w2 = W.detach().reshape(W.shape[0], -1)
-    ent[0][:w2.shape[0], :w2.shape[1]].copy_(w2)
+    if ent[2] != _refresh_epoch[0]:          # not covered by this forward pass's refresh_weight_panels()
+        w2 = W.detach().reshape(W.shape[0], -1)
+        ent[0][:w2.shape[0], :w2.shape[1]].copy_(w2)
     return ent[0]
+
+
+_refresh_epoch = [0]
+
+
+def refresh_weight_panels(params):
+    """Refresh the bf16 panels of all `params` (nn.Parameters that already have one) with ONE multi-tensor
+    copy instead of one conversion kernel per layer (~20 launches, 0.1 ms per step).  Called at the start of a
+    forward pass; bf16_weight() then returns the panels as they are until the next call.  Panels that are
+    zero-padded views, or do not exist yet, are left to bf16_weight()."""
+    _refresh_epoch[0] += 1
+    want = {id(p): p for p in params}
+    dst, src, ents = [], [], []
+    for (pid, rows, cols), ent in _wcache.items():
+        W = want.get(pid)
+        if W is None or ent[1]() is not W or ent[0].device != W.device:
+            continue
+        w2 = W.detach().reshape(W.shape[0], -1)
+        if tuple(w2.shape) == (rows, cols):
+            dst.append(ent[0])
+            src.append(w2)
+            ents.append(ent)
+    if dst:
+        torch._foreach_copy_(dst, src)
+        for ent in ents:
+            ent[2] = _refresh_epoch[0]
 
 
 # ------------------------------------------------------------------ the stack

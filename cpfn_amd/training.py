@@ -6,6 +6,7 @@ data-parallel training, one process per GPU, with ONE flat fp32 gradient bucket
 all-reduced over RCCL (xGMI) per step.
 """
 import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -261,10 +262,11 @@ class SPFNTrainer:
         K = batch["T_gt"].shape[1]
         st = {"batch": {k: v.clone() for k, v in batch.items()},
               "P_next": batch["P"].clone(),
-              "start1": torch.zeros(B, dtype=torch.int32, device=dev),
-              "start2": torch.zeros(B, dtype=torch.int32, device=dev),
+              "start_dev": torch.zeros(2, B, dtype=torch.int32, device=dev),
+              "start_host": torch.zeros(2, B, dtype=torch.int32).pin_memory(),
               "match": torch.zeros(B, K, dtype=torch.long, device=dev),
               "skipped": torch.zeros((), dtype=torch.float32, device=dev)}
+        st["start1"], st["start2"] = st["start_dev"][0], st["start_dev"][1]
         sb = st["batch"]
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         starts = (st["start1"], st["start2"])
@@ -317,10 +319,15 @@ class SPFNTrainer:
         return st
 
     def _draw_starts(self, st, B, N):
-        # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order
-        st["start1"].copy_(torch.randint(0, N, (B,), dtype=torch.long).to(torch.int32), non_blocking=True)
-        st["start2"].copy_(torch.randint(0, self.module.sa1.num_points, (B,), dtype=torch.long).to(torch.int32),
-                           non_blocking=True)
+        # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order.
+        # They go through a PINNED staging buffer that lives as long as the graphs: an asynchronous copy from a
+        # temporary pageable tensor may still be pending on a busy stream when the host frees and reuses that
+        # memory (seen as occasional wrong FPS seeds in graph+prefetch mode).  The buffer is rewritten only
+        # after the next step's host sync (the Hungarian round trip), i.e. after this copy has executed.
+        host = st["start_host"]
+        host[0].copy_(torch.randint(0, N, (B,), dtype=torch.long))
+        host[1].copy_(torch.randint(0, self.module.sa1.num_points, (B,), dtype=torch.long))
+        st["start_dev"].copy_(host, non_blocking=True)
 
     def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
