@@ -144,7 +144,7 @@ __global__ void chunk_reduce_strided_kernel(const double *__restrict__ partial, 
 }
 
 // dW[b,n,k] = Σ_m φ_m G[b,k,m] (B slots only where w >= 1e-10: clamp's adjoint);
-// dX[b,n,:] from the slots that involve the normal.  One lane per point, G[b] in LDS.
+// dX[b,n,:] from the slots that involve the normal.  One lane per point, G[b] through the scalar cache.
 constexpr int FM_MAXK = 64;
 __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__restrict__ P,
                                                                  const float *__restrict__ X,
@@ -152,10 +152,7 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
                                                                  const float *__restrict__ G, int N, int K,
                                                                  const float *__restrict__ dW_add,
                                                                  float *__restrict__ dW, float *__restrict__ dX) {
-  __shared__ __attribute__((aligned(16))) float s_g[FM_MAXK][FM_SLOTS];   // rows are 208 B: 16-byte aligned
   const int b = blockIdx.y, t = threadIdx.x;
-  for (int e = t; e < K * FM_SLOTS; e += FM_THREADS) s_g[e / FM_SLOTS][e % FM_SLOTS] = G[(size_t)b * K * FM_SLOTS + e];
-  __syncthreads();
   const int n = blockIdx.x * FM_THREADS + t;
   if (n >= N) return;
   const float *p = P + ((size_t)b * N + n) * 3;
@@ -167,13 +164,9 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
   float *drow = dW + ((size_t)b * N + n) * K;
   const float *arow = dW_add ? dW_add + ((size_t)b * N + n) * K : nullptr;   // e.g. the cone pass's dW
   for (int k = 0; k < K; ++k) {
-    // the whole 52-slot row as 13 un-narrowable 16-byte LDS reads (cpfn_lds_read4: no ds_read_b96)
-    float g[FM_SLOTS];
-#pragma unroll
-    for (int q = 0; q < FM_SLOTS / 4; ++q) {
-      const cpfn_f32x4 v = cpfn_lds_read4(&s_g[k][4 * q]);
-      g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
-    }
+    // G[b,k,:] is the same for every lane: read it straight from global memory with a wave-uniform address, which
+    // the compiler turns into scalar loads (s_load_dwordx*) — no LDS staging, no vector loads
+    const float *g = G + ((size_t)b * K + k) * FM_SLOTS;
     float ga = 0.f, gB = 0.f;
 #pragma unroll
     for (int m = 0; m < 19; ++m) ga = fmaf(f[m], g[m], ga);

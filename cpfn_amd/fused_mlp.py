@@ -27,7 +27,7 @@ from . import lib as _l
 from .ops import _ptr, _stream
 
 BF16 = torch.bfloat16
-BN_NOSTORE = os.environ.get("CPFN_BN_NOSTORE", "0") == "1"
+BN_NOSTORE = os.environ.get("CPFN_BN_NOSTORE", "1") == "1"
 
 
 def _pad_to(n, m):
@@ -273,9 +273,9 @@ class _FusedStack(torch.autograd.Function):
                     nblk = h.cpfn_bn_bwd_blocks(P)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                     Gy = torch.empty(P, N, dtype=BF16, device=dev)
-                    # BN_NOSTORE: reduction without the masked-gradient store + mask recomputed in the apply pass.
-                    # Measured SLOWER on MI355X (6.6 vs 6.15 ms/step, same box): the in-place second pass over
-                    # the freshly written g_z is served from the 256 MB Infinity Cache.  Kept selectable.
+                    # BN_NOSTORE (default): the reduction pass does not store the masked gradient; the apply pass
+                    # recomputes the ReLU mask from y.  3.57 vs 3.65 ms/step (same box, A/B/A/B); CPFN_BN_NOSTORE=0
+                    # selects the two-pass-over-g_z variant.
                     nostore = BN_NOSTORE
                     _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None if nostore else _ptr(Gy), _ptr(part), _stream()),
                            "cpfn_bn_relu_bwd")
