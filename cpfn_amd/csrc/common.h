@@ -38,7 +38,30 @@ __device__ __forceinline__ float cpfn_pair_sqdist(float sx, float sy, float sz, 
 // ds_read_b32 or one ds_read_b128: 0 of 200 — tools/debug_fps_eager.py).  build.py rejects any object that
 // contains a 96-bit DS instruction.
 typedef float cpfn_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ cpfn_f32x4 cpfn_lds_read4(const float *p) { return *(const volatile cpfn_f32x4 *)p; }
+__device__ __forceinline__ cpfn_f32x4 cpfn_lds_read4(const float *p) {
+  cpfn_f32x4 v = *(const cpfn_f32x4 *)p;
+  asm volatile("" : "+v"(v));   // all four lanes "used": the load cannot be narrowed to 96 bits (it can still be scheduled freely)
+  return v;
+}
+
+// Row tiles between global memory and LDS with fully coalesced accesses: `rows` consecutive rows of `width`
+// floats are contiguous in memory; in LDS they sit at row stride `ld` (odd: a lane-per-row reader is
+// conflict-free).  A lane that walks its own row in GLOBAL memory instead (width*4-byte stride between lanes)
+// touches 64 cache lines per load instruction and ran the per-point loss / fitter kernels at ~1 TB/s.
+template <int THREADS>
+__device__ __forceinline__ void cpfn_rows_to_lds(float *s, int ld, const float *__restrict__ src, int rows, int width, int t) {
+  for (int e = t; e < rows * width; e += THREADS) {
+    const int r = e / width;
+    s[r * ld + (e - r * width)] = src[e];
+  }
+}
+template <int THREADS>
+__device__ __forceinline__ void cpfn_rows_from_lds(const float *s, int ld, float *__restrict__ dst, int rows, int width, int t) {
+  for (int e = t; e < rows * width; e += THREADS) {
+    const int r = e / width;
+    dst[e] = s[r * ld + (e - r * width)];
+  }
+}
 
 __device__ __forceinline__ unsigned long long cpfn_shfl_xor_u64(unsigned long long v, int m) {
   unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);

@@ -144,7 +144,7 @@ __global__ void chunk_reduce_strided_kernel(const double *__restrict__ partial, 
 }
 
 // dW[b,n,k] = Σ_m φ_m G[b,k,m] (B slots only where w >= 1e-10: clamp's adjoint);
-// dX[b,n,:] from the slots that involve the normal.  One lane per point, G[b] through the scalar cache.
+// dX[b,n,:] from the slots that involve the normal.  One lane per point, G[b] in LDS.
 constexpr int FM_MAXK = 64;
 __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__restrict__ P,
                                                                  const float *__restrict__ X,
@@ -152,44 +152,63 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
                                                                  const float *__restrict__ G, int N, int K,
                                                                  const float *__restrict__ dW_add,
                                                                  float *__restrict__ dW, float *__restrict__ dX) {
+  __shared__ __attribute__((aligned(16))) float s_g[FM_MAXK][FM_SLOTS];   // rows are 208 B: 16-byte aligned
+  __shared__ float s_p[FM_THREADS * 3], s_x[FM_THREADS * 3];
+  extern __shared__ float s_dyn[];                   // W tile, then (in place) the dW tile; dW_add tile
   const int b = blockIdx.y, t = threadIdx.x;
-  const int n = blockIdx.x * FM_THREADS + t;
-  if (n >= N) return;
-  const float *p = P + ((size_t)b * N + n) * 3;
-  const float *x = X + ((size_t)b * N + n) * 3;
-  float f[FM_SLOTS];
-  point_features<float>(p, x, f);
-  float a[3] = {0, 0, 0}, sa[6] = {0, 0, 0, 0, 0, 0}, sb[6] = {0, 0, 0, 0, 0, 0}, gb[3] = {0, 0, 0};
-  const float *wrow = W + ((size_t)b * N + n) * K;
-  float *drow = dW + ((size_t)b * N + n) * K;
-  const float *arow = dW_add ? dW_add + ((size_t)b * N + n) * K : nullptr;   // e.g. the cone pass's dW
-  for (int k = 0; k < K; ++k) {
-    // G[b,k,:] is the same for every lane: read it straight from global memory with a wave-uniform address, which
-    // the compiler turns into scalar loads (s_load_dwordx*) — no LDS staging, no vector loads
-    const float *g = G + ((size_t)b * K + k) * FM_SLOTS;
-    float ga = 0.f, gB = 0.f;
+  const int n0 = blockIdx.x * FM_THREADS, rows = min(FM_THREADS, N - n0);
+  const size_t p0 = (size_t)b * N + n0;
+  const int ld = K | 1;
+  float *s_w = s_dyn, *s_add = s_dyn + FM_THREADS * ld;
+  for (int e = t; e < K * FM_SLOTS; e += FM_THREADS) s_g[e / FM_SLOTS][e % FM_SLOTS] = G[(size_t)b * K * FM_SLOTS + e];
+  cpfn_rows_to_lds<FM_THREADS>(s_p, 3, P + p0 * 3, rows, 3, t);
+  cpfn_rows_to_lds<FM_THREADS>(s_x, 3, X + p0 * 3, rows, 3, t);
+  cpfn_rows_to_lds<FM_THREADS>(s_w, ld, W + p0 * K, rows, K, t);
+  if (dW_add) cpfn_rows_to_lds<FM_THREADS>(s_add, ld, dW_add + p0 * K, rows, K, t);
+  __syncthreads();
+  if (t < rows) {
+    const float p[3] = {s_p[t * 3], s_p[t * 3 + 1], s_p[t * 3 + 2]}, x[3] = {s_x[t * 3], s_x[t * 3 + 1], s_x[t * 3 + 2]};
+    float f[FM_SLOTS];
+    point_features<float>(p, x, f);
+    float a[3] = {0, 0, 0}, sa[6] = {0, 0, 0, 0, 0, 0}, sb[6] = {0, 0, 0, 0, 0, 0}, gb[3] = {0, 0, 0};
+    float *wrow = s_w + t * ld;
+    const float *arow = s_add + t * ld;
+    for (int k = 0; k < K; ++k) {
+      // the 52-slot row as 13 un-narrowable 16-byte LDS reads (cpfn_lds_read4: the compiler would turn two of them
+      // into the banned ds_read_b96 because slots 19 and 49..51 are padding)
+      float g[FM_SLOTS];
 #pragma unroll
-    for (int m = 0; m < 19; ++m) ga = fmaf(f[m], g[m], ga);
+      for (int q = 0; q < FM_SLOTS / 4; ++q) {
+        const cpfn_f32x4 v = cpfn_lds_read4(&s_g[k][4 * q]);
+        g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+      }
+      float ga = 0.f, gB = 0.f;
 #pragma unroll
-    for (int m = 20; m < 49; ++m) gB = fmaf(f[m], g[m], gB);
-    const float w = wrow[k];
-    const float wc = fmaxf(w, FM_WEPS);
-    drow[k] = ga + (w >= FM_WEPS ? gB : 0.f) + (arow ? arow[k] : 0.f);
+      for (int m = 0; m < 19; ++m) ga = fmaf(f[m], g[m], ga);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { a[j] = fmaf(w, g[10 + j], a[j]); gb[j] = fmaf(wc, g[46 + j], gb[j]); }
+      for (int m = 20; m < 49; ++m) gB = fmaf(f[m], g[m], gB);
+      const float w = wrow[k];
+      const float wc = fmaxf(w, FM_WEPS);
+      wrow[k] = ga + (w >= FM_WEPS ? gB : 0.f) + (dW_add ? arow[k] : 0.f);     // the dW row replaces the W row
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { sa[j] = fmaf(w, g[13 + j], sa[j]); sb[j] = fmaf(wc, g[40 + j], sb[j]); }
+      for (int j = 0; j < 3; ++j) { a[j] = fmaf(w, g[10 + j], a[j]); gb[j] = fmaf(wc, g[46 + j], gb[j]); }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { sa[j] = fmaf(w, g[13 + j], sa[j]); sb[j] = fmaf(wc, g[40 + j], sb[j]); }
+    }
+    // d/dx of Σ_{i<=j} S_ij x_i x_j  = Ŝ x with Ŝ_ll = 2 S_ll, Ŝ_lj = S_(lj)
+    float s[6];
+    for (int j = 0; j < 6; ++j) s[j] = sa[j] + sb[j];
+    const float nx = x[0], ny = x[1], nz = x[2], px = p[0], py = p[1], pz = p[2];
+    const float pn = px * nx + py * ny + pz * nz;
+    const float gdotx = gb[0] * nx + gb[1] * ny + gb[2] * nz;
+    float *o = s_x + t * 3;                               // the dX row replaces the X row
+    o[0] = a[0] + 2.f * s[0] * nx + s[1] * ny + s[2] * nz + gb[0] * pn + gdotx * px;
+    o[1] = a[1] + s[1] * nx + 2.f * s[3] * ny + s[4] * nz + gb[1] * pn + gdotx * py;
+    o[2] = a[2] + s[2] * nx + s[4] * ny + 2.f * s[5] * nz + gb[2] * pn + gdotx * pz;
   }
-  // d/dx of Σ_{i<=j} S_ij x_i x_j  = Ŝ x with Ŝ_ll = 2 S_ll, Ŝ_lj = S_(lj)
-  float s[6];
-  for (int j = 0; j < 6; ++j) s[j] = sa[j] + sb[j];
-  const float nx = x[0], ny = x[1], nz = x[2], px = p[0], py = p[1], pz = p[2];
-  const float pn = px * nx + py * ny + pz * nz;
-  const float gdotx = gb[0] * nx + gb[1] * ny + gb[2] * nz;
-  float *o = dX + ((size_t)b * N + n) * 3;
-  o[0] = a[0] + 2.f * s[0] * nx + s[1] * ny + s[2] * nz + gb[0] * pn + gdotx * px;
-  o[1] = a[1] + s[1] * nx + 2.f * s[3] * ny + s[4] * nz + gb[1] * pn + gdotx * py;
-  o[2] = a[2] + s[2] * nx + s[4] * ny + 2.f * s[5] * nz + gb[2] * pn + gdotx * pz;
+  __syncthreads();
+  cpfn_rows_from_lds<FM_THREADS>(s_w, ld, dW + p0 * K, rows, K, t);
+  cpfn_rows_from_lds<FM_THREADS>(s_x, 3, dX + p0 * 3, rows, 3, t);
 }
 
 // ---------------------------------------------------------------- cone second pass
@@ -457,8 +476,16 @@ extern "C" int cpfn_fit_moments_bwd(const float *P, const float *X, const float 
                                     int N, int K, const float *dW_add, float *dW, float *dX, void *stream) {
   if (B < 0 || N <= 0 || K <= 0 || K > FM_MAXK || !P || !X || !W || !G || !dW || !dX) return CPFN_EINVAL;
   if (B == 0) return 0;
-  moments_bwd_kernel<<<dim3(cpfn_cdiv(N, FM_THREADS), B), FM_THREADS, 0, (hipStream_t)stream>>>(P, X, W, G, N, K,
-                                                                                               dW_add, dW, dX);
+  const size_t lds = (size_t)2 * FM_THREADS * (K | 1) * sizeof(float);            // <= 130 KB at K = 64
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)moments_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * FM_THREADS * (FM_MAXK | 1) * (int)sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  moments_bwd_kernel<<<dim3(cpfn_cdiv(N, FM_THREADS), B), FM_THREADS, lds, (hipStream_t)stream>>>(P, X, W, G, N, K,
+                                                                                                 dW_add, dW, dX);
   return cpfn_launch_status();
 }
 

@@ -21,36 +21,46 @@ constexpr int LP_THREADS = 256;
 // ------------------------------------------------------------------------------------ head_post
 // Y[P, 7+K] fp32: cols 0-2 normal, 3-6 type logits, 7.. membership logits.
 // partial[b][chunk][3] = Σ (1-|x̂·x_gt|), Σ CE·[I!=-1], Σ [I!=-1]
+//
+// One lane per point, but the lanes never touch global memory row by row (35 floats at a 140-byte stride: 64
+// cache lines per load instruction, ~1 TB/s): the workgroup's 256 rows are contiguous, so they are copied
+// into LDS with fully coalesced loads, each lane then owns LDS row t (odd row stride: conflict-free), and the
+// result rows go back the same way.
+constexpr int LP_LD = 7 + MAXK;   // LDS row stride for the [*, 7+K] rows: 39 floats, odd
+#define lp_stage_in cpfn_rows_to_lds<LP_THREADS>
+#define lp_stage_out cpfn_rows_from_lds<LP_THREADS>
+
 __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
     const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
     const long long *__restrict__ Tgt, int N, int K, float *__restrict__ Xn, float *__restrict__ Wsm,
     float *__restrict__ partial) {
+  __shared__ float s_row[LP_THREADS * LP_LD];
+  __shared__ float s_x[LP_THREADS * 3];
   __shared__ float s_red[LP_THREADS / 64][3];
   const int b = blockIdx.y, t = threadIdx.x, C = 7 + K;
-  const int n = blockIdx.x * LP_THREADS + t;
+  const int n0 = blockIdx.x * LP_THREADS;
+  const int rows = min(LP_THREADS, N - n0);
+  const size_t p0 = (size_t)b * N + n0;
+  lp_stage_in(s_row, LP_LD, Y + p0 * C, rows, C, t);
+  lp_stage_in(s_x, 3, Xgt + p0 * 3, rows, 3, t);
+  __syncthreads();
   float l_n = 0.f, l_t = 0.f, l_c = 0.f;
-  if (n < N) {
-    const size_t p = (size_t)b * N + n;
-    const float *y = Y + p * C;
+  float e[MAXK], u0 = 0.f, u1 = 0.f, u2 = 0.f, is = 0.f;
+  if (t < rows) {
+    const float *y = s_row + t * LP_LD;
     const float x0 = y[0], x1 = y[1], x2 = y[2];
     const float inv = 1.0f / fmaxf(sqrtf(x0 * x0 + x1 * x1 + x2 * x2), 1e-12f);   // F.normalize(eps=1e-12)
-    const float u0 = x0 * inv, u1 = x1 * inv, u2 = x2 * inv;
-    Xn[p * 3] = u0; Xn[p * 3 + 1] = u1; Xn[p * 3 + 2] = u2;
-    const float *g = Xgt + p * 3;
-    l_n = 1.0f - fabsf(u0 * g[0] + u1 * g[1] + u2 * g[2]);
+    u0 = x0 * inv; u1 = x1 * inv; u2 = x2 * inv;
+    l_n = 1.0f - fabsf(u0 * s_x[t * 3] + u1 * s_x[t * 3 + 1] + u2 * s_x[t * 3 + 2]);
     // soft-max over the K membership logits
     float m = -INFINITY;
     for (int k = 0; k < K; ++k) m = fmaxf(m, y[7 + k]);
-    float e[MAXK], s = 0.f;
+    float s = 0.f;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) { e[k] = k < K ? __expf(y[7 + (k < K ? k : 0)] - m) : 0.f; s += e[k]; }
-    const float is = 1.0f / s;
-    float *w = Wsm + p * K;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-      if (k < K) w[k] = e[k] * is;
+    is = 1.0f / s;
     // per-point type cross-entropy against the type of the point's GT instance
-    const long long lab = Igt[p];
+    const long long lab = Igt[p0 + t];
     if (lab != -1) {
       const long long tgt = Tgt[(size_t)b * K + (lab < 0 ? 0 : lab)];
       const float t0 = y[3], t1 = y[4], t2 = y[5], t3 = y[6];
@@ -60,12 +70,22 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
       l_c = 1.f;
     }
   }
+  __syncthreads();                       // every lane has read its row: reuse the slab for the outputs
+  if (t < rows) {
+    float *w = s_row + t * LP_LD;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < K) w[k] = e[k] * is;
+    s_x[t * 3] = u0; s_x[t * 3 + 1] = u1; s_x[t * 3 + 2] = u2;
+  }
   // block reduce (wave shuffles, then 4 waves)
   for (int msk = 32; msk >= 1; msk >>= 1) {
     l_n += __shfl_xor(l_n, msk, 64); l_t += __shfl_xor(l_t, msk, 64); l_c += __shfl_xor(l_c, msk, 64);
   }
   if ((t & 63) == 0) { s_red[t >> 6][0] = l_n; s_red[t >> 6][1] = l_t; s_red[t >> 6][2] = l_c; }
   __syncthreads();
+  lp_stage_out(s_row, LP_LD, Wsm + p0 * K, rows, K, t);
+  lp_stage_out(s_x, 3, Xn + p0 * 3, rows, 3, t);
   if (t < 3) {
     float s = 0.f;
     for (int w = 0; w < LP_THREADS / 64; ++w) s += s_red[w][t];
@@ -90,59 +110,91 @@ __global__ void head_post_reduce_kernel(const float *__restrict__ partial, int c
 }
 
 // gY[P,7+K] from: gXn[P,3] (may be null), gW[P,K] (may be null), gloss[B,2] = dL/d(normal_loss, type_loss)
+// Same LDS-staged row movement as the forward kernel; the slab is reused for Y, W, gW in turn and for gY.
 __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
     const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
     const long long *__restrict__ Tgt, const float *__restrict__ Wsm, const float *__restrict__ stats,
     const float *__restrict__ gXn, const float *__restrict__ gW, const float *__restrict__ gloss, int N, int K,
     float *__restrict__ gY) {
-  const int b = blockIdx.y, C = 7 + K;
-  const int n = blockIdx.x * LP_THREADS + threadIdx.x;
-  if (n >= N) return;
-  const size_t p = (size_t)b * N + n;
-  const float *y = Y + p * C;
-  float *o = gY + p * C;
-  // normals
-  const float x0 = y[0], x1 = y[1], x2 = y[2];
-  const float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
-  const float inv = 1.0f / fmaxf(nrm, 1e-12f);
-  const float u0 = x0 * inv, u1 = x1 * inv, u2 = x2 * inv;
-  const float *g = Xgt + p * 3;
-  const float d = u0 * g[0] + u1 * g[1] + u2 * g[2];
-  const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-  const float cn = -gloss[b * 2] * sg / (float)N;
-  float h0 = cn * g[0], h1 = cn * g[1], h2 = cn * g[2];
-  if (gXn) { h0 += gXn[p * 3]; h1 += gXn[p * 3 + 1]; h2 += gXn[p * 3 + 2]; }
-  if (nrm >= 1e-12f) {
-    const float pr = u0 * h0 + u1 * h1 + u2 * h2;
-    o[0] = (h0 - u0 * pr) * inv; o[1] = (h1 - u1 * pr) * inv; o[2] = (h2 - u2 * pr) * inv;
-  } else {
-    o[0] = h0 * inv; o[1] = h1 * inv; o[2] = h2 * inv;
+  __shared__ float s_row[LP_THREADS * LP_LD];
+  __shared__ float s_x[LP_THREADS * 3], s_gx[LP_THREADS * 3];
+  const int b = blockIdx.y, t = threadIdx.x, C = 7 + K;
+  const int n0 = blockIdx.x * LP_THREADS;
+  const int rows = min(LP_THREADS, N - n0);
+  const size_t p0 = (size_t)b * N + n0;
+  const bool live = t < rows;
+  lp_stage_in(s_row, LP_LD, Y + p0 * C, rows, C, t);
+  lp_stage_in(s_x, 3, Xgt + p0 * 3, rows, 3, t);
+  if (gXn) lp_stage_in(s_gx, 3, gXn + p0 * 3, rows, 3, t);
+  __syncthreads();
+  float y7[7] = {0, 0, 0, 0, 0, 0, 0}, sm[MAXK], o7[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (live)
+    for (int j = 0; j < 7; ++j) y7[j] = s_row[t * LP_LD + j];
+  __syncthreads();
+  if (gW) {                                              // soft-max adjoint needs W and gW rows
+    lp_stage_in(s_row, LP_LD, Wsm + p0 * K, rows, K, t);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) sm[k] = (live && k < K) ? s_row[t * LP_LD + k] : 0.f;
+    __syncthreads();
+    lp_stage_in(s_row, LP_LD, gW + p0 * K, rows, K, t);
+    __syncthreads();
   }
-  // type logits
-  const long long lab = Igt[p];
-  if (lab != -1) {
-    const long long tgt = Tgt[(size_t)b * K + (lab < 0 ? 0 : lab)];
-    const float t0 = y[3], t1 = y[4], t2 = y[5], t3 = y[6];
-    const float tm = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
-    const float e0 = expf(t0 - tm), e1 = expf(t1 - tm), e2 = expf(t2 - tm), e3 = expf(t3 - tm);
-    const float is = 1.0f / (e0 + e1 + e2 + e3);
-    const float c = gloss[b * 2 + 1] / stats[b * 3 + 2];
-    o[3] = c * (e0 * is - (tgt == 0 ? 1.f : 0.f));
-    o[4] = c * (e1 * is - (tgt == 1 ? 1.f : 0.f));
-    o[5] = c * (e2 * is - (tgt == 2 ? 1.f : 0.f));
-    o[6] = c * (e3 * is - (tgt == 3 ? 1.f : 0.f));
-  } else {
-    o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = 0.f;
+  if (live) {
+    // normals
+    const float x0 = y7[0], x1 = y7[1], x2 = y7[2];
+    const float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+    const float u0 = x0 * inv, u1 = x1 * inv, u2 = x2 * inv;
+    const float g0 = s_x[t * 3], g1 = s_x[t * 3 + 1], g2 = s_x[t * 3 + 2];
+    const float d = u0 * g0 + u1 * g1 + u2 * g2;
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    const float cn = -gloss[b * 2] * sg / (float)N;
+    float h0 = cn * g0, h1 = cn * g1, h2 = cn * g2;
+    if (gXn) { h0 += s_gx[t * 3]; h1 += s_gx[t * 3 + 1]; h2 += s_gx[t * 3 + 2]; }
+    if (nrm >= 1e-12f) {
+      const float pr = u0 * h0 + u1 * h1 + u2 * h2;
+      o7[0] = (h0 - u0 * pr) * inv; o7[1] = (h1 - u1 * pr) * inv; o7[2] = (h2 - u2 * pr) * inv;
+    } else {
+      o7[0] = h0 * inv; o7[1] = h1 * inv; o7[2] = h2 * inv;
+    }
+    // type logits
+    const long long lab = Igt[p0 + t];
+    if (lab != -1) {
+      const long long tgt = Tgt[(size_t)b * K + (lab < 0 ? 0 : lab)];
+      const float t0 = y7[3], t1 = y7[4], t2 = y7[5], t3 = y7[6];
+      const float tm = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+      const float e0 = expf(t0 - tm), e1 = expf(t1 - tm), e2 = expf(t2 - tm), e3 = expf(t3 - tm);
+      const float is = 1.0f / (e0 + e1 + e2 + e3);
+      const float c = gloss[b * 2 + 1] / stats[b * 3 + 2];
+      o7[3] = c * (e0 * is - (tgt == 0 ? 1.f : 0.f));
+      o7[4] = c * (e1 * is - (tgt == 1 ? 1.f : 0.f));
+      o7[5] = c * (e2 * is - (tgt == 2 ? 1.f : 0.f));
+      o7[6] = c * (e3 * is - (tgt == 3 ? 1.f : 0.f));
+    }
   }
-  // memberships: soft-max adjoint
+  // memberships: soft-max adjoint, written over the gW row in place (columns shift by 7)
+  float om[MAXK];
   if (gW) {
-    const float *s = Wsm + p * K, *gw = gW + p * K;
     float dot = 0.f;
-    for (int k = 0; k < K; ++k) dot = fmaf(gw[k], s[k], dot);
-    for (int k = 0; k < K; ++k) o[7 + k] = s[k] * (gw[k] - dot);
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) { om[k] = (live && k < K) ? s_row[t * LP_LD + k] : 0.f; dot = fmaf(om[k], sm[k], dot); }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) om[k] = sm[k] * (om[k] - dot);
   } else {
-    for (int k = 0; k < K; ++k) o[7 + k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) om[k] = 0.f;
   }
+  __syncthreads();
+  if (live) {
+    float *o = s_row + t * LP_LD;
+    for (int j = 0; j < 7; ++j) o[j] = o7[j];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < K) o[7 + k] = om[k];
+  }
+  __syncthreads();
+  lp_stage_out(s_row, LP_LD, gY + p0 * C, rows, C, t);
 }
 
 // ------------------------------------------------------------------------------------ seg_stats
