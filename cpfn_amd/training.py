@@ -320,9 +320,8 @@ class SPFNTrainer:
 
     def _draw_starts(self, st, B, N):
         # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order.
-        # They go through a PINNED staging buffer that lives as long as the graphs: an asynchronous copy from a
-        # temporary pageable tensor may still be pending on a busy stream when the host frees and reuses that
-        # memory (seen as occasional wrong FPS seeds in graph+prefetch mode).  The buffer is rewritten only
+        # They go through a PINNED staging buffer that lives as long as the graphs, so the asynchronous copy never
+        # reads from a temporary pageable tensor the host may already have reused.  The buffer is rewritten only
         # after the next step's host sync (the Hungarian round trip), i.e. after this copy has executed.
         host = st["start_host"]
         host[0].copy_(torch.randint(0, N, (B,), dtype=torch.long))
