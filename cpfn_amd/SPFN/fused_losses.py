@@ -170,16 +170,22 @@ def hungarian_cost_pack(S, I_gt, n_gt=None):
     return torch.cat([cost.reshape(B, -1), n_gt.unsqueeze(1).to(cost.dtype)], dim=1)
 
 
-def hungarian_from_pack(pack, K):
-    """Host part: ONE device->host copy for the whole batch, SciPy assignment per cloud (reference :27)."""
-    h = pack.cpu().numpy()
+def hungarian_host(h, K, out=None):
+    """Host part on a host array h [B, K*K+1] (numpy or CPU tensor): SciPy assignment per cloud (reference :27).
+    Returns (or fills `out`, e.g. a pinned buffer) the [B, K] int64 matching."""
+    h = h.numpy() if isinstance(h, torch.Tensor) else h
     B = h.shape[0]
-    match = torch.zeros(B, K, dtype=torch.long)
+    match = torch.zeros(B, K, dtype=torch.long) if out is None else out.zero_()
     for b in range(B):
         n = int(h[b, -1])
         _, c = linear_sum_assignment(-h[b, :-1].reshape(K, K)[:n])
         match[b, :n] = torch.from_numpy(c)
-    return match.to(pack.device)
+    return match
+
+
+def hungarian_from_pack(pack, K):
+    """Host part: ONE device->host copy for the whole batch, SciPy assignment per cloud (reference :27)."""
+    return hungarian_host(pack.cpu(), K).to(pack.device)
 
 
 def hungarian_from_stats(S, I_gt):
@@ -193,7 +199,16 @@ def pre_match(Y, batch):
     return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"])
 
 
-def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=None):
+def fit_params(P, W, Xn, multipliers):
+    """The match-independent part of the post-assignment work (all four fits of every instance); None when
+    neither the residue nor the parameter loss is switched on.  A trainer can run it while the host solves the
+    assignment."""
+    if multipliers["residue"] > 0 or multipliers["parameter"] > 0:
+        return _fc.fit_params(P, W, Xn)
+    return None
+
+
+def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=None, params=None):
     """Everything after the assignment: relaxed IoU of the matched pairs, the fitters, residue and
     axis losses, the weighted total.  (Capturable.)  Four autograd nodes: FitParams -> ResidueLoss ->
     LossTail (<- SegStats, HeadPost)."""
@@ -203,7 +218,8 @@ def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=Non
         n_gt = count_gt(batch["I_gt"])
     rp = None
     if m["residue"] > 0 or m["parameter"] > 0:
-        params = _fc.fit_params(P, W, Xn)
+        if params is None:
+            params = _fc.fit_params(P, W, Xn)
         gt_axes = torch.stack([batch["plane_n_gt"], batch["cylinder_axis_gt"], batch["cone_axis_gt"]], 0)
         ids = [classes.index(c) for c in ("plane", "sphere", "cylinder", "cone")]
         rp = ResidueLoss.apply(params, match, T_gt, batch["points_per_instance"], gt_axes, ids)

@@ -207,9 +207,11 @@ class SPFNTrainer:
     # At 16 clouds per GPU the step is ~560 launches and host-bound (~7 ms of CPU for ~6.5 ms of GPU
     # work).  The step is captured once into graphs split at its single host round trip (the
     # Hungarian assignment):
-    #   G1 = (geometry buffers B -> A) + network forward + heads post-processing + segmented sums
-    #        host: SciPy assignment
-    #   G2 = matched losses, fitters, full backward, gradient packing, finite flag, fused Adam
+    #   G1  = (geometry buffers B -> A) + network forward + heads post-processing + segmented sums
+    #         + cost matrices copied to pinned host memory; an event marks its end
+    #   G1b = the four fits of every instance (they do not depend on the assignment)
+    #         || host: waits for the event (not for G1b), SciPy assignment, matching back to the device
+    #   G2  = matched losses, full backward, gradient packing, finite flag, fused Adam
     #        || side branch: FPS / ball query / 3-NN of the NEXT batch into geometry buffers B
     #   G0 = the geometry pass alone (only replayed when the next batch was not announced)
     # The geometry of a batch depends on its coordinates only, so computing it one step ahead inside
@@ -231,11 +233,12 @@ class SPFNTrainer:
 
     @staticmethod
     def _copy_all(dst, src):
-        """One multi-tensor copy for the whole geometry set: the int32 and fp32 tensors are viewed as one
-        4-byte dtype so that _foreach_copy_ takes its single-kernel route (mixed dtypes fall back to one
-        memcpy node per tensor: 48 of them per step)."""
-        torch._foreach_copy_([d.view(torch.int32) if d.element_size() == 4 else d for d in dst],
-                             [t.view(torch.int32) if t.element_size() == 4 else t for t in src])
+        """One multi-tensor copy for a whole tensor set: int32 / fp32 / int64 tensors are viewed as int32 so that
+        _foreach_copy_ takes its single-kernel route (mixed dtypes fall back to one memcpy node per tensor:
+        48 of them per step for the geometry set)."""
+        def v32(t):
+            return t.view(torch.int32) if t.element_size() in (4, 8) and t.is_contiguous() else t
+        torch._foreach_copy_([v32(d) for d in dst], [v32(t) for t in src])
 
     @staticmethod
     def _like_geom(g, tensors):
@@ -290,6 +293,8 @@ class SPFNTrainer:
         g0 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g0, stream=self._gstream, capture_error_mode="thread_local"):
             geometry_into_B(sb["P"])
+        st["cost_host"] = torch.empty(B, K * K + 1, dtype=torch.float32).pin_memory()   # (not inside a capture)
+        st["match_host"] = torch.zeros(B, K, dtype=torch.long).pin_memory()
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
             self._copy_all(geomA, geomB)
@@ -298,13 +303,20 @@ class SPFNTrainer:
             st["pre"] = fl.pre_match(self.module.heads_packed, sb)
             st["n_gt"] = fl.count_gt(sb["I_gt"])
             st["cost_pack"] = fl.hungarian_cost_pack(st["pre"][4].detach(), sb["I_gt"], st["n_gt"])   # device part, in-graph
+            st["cost_host"].copy_(st["cost_pack"], non_blocking=True)          # D2H node at the end of G1
+        # G1b: the fits do not depend on the assignment: they run while the host solves it
+        g1b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1b, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
+            Xn, W, nl, tl, S = st["pre"]
+            st["params"] = fl.fit_params(sb["P"], W, Xn, self.mult)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
             self._gside.wait_stream(self._gstream)                  # fork: next batch's geometry
             with torch.cuda.stream(self._gside):
                 geometry_into_B(st["P_next"])
             Xn, W, nl, tl, S = st["pre"]
-            out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, st["n_gt"])
+            out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, st["n_gt"],
+                                st["params"])
             out[0].backward()
             self.bucket.collect()
             if world == 1:
@@ -314,7 +326,8 @@ class SPFNTrainer:
                 st["skipped"] += st["found_inf"]
             st["out"] = tuple(o.detach() for o in out)
             self._gstream.wait_stream(self._gside)                  # join
-        st["g0"], st["g1"], st["g2"], st["world"] = g0, g1, g2, world
+        st["g0"], st["g1"], st["g1b"], st["g2"], st["world"] = g0, g1, g1b, g2, world
+        st["cost_ready"] = torch.cuda.Event()
         st["geom_ready_for"] = None
         return st
 
@@ -331,9 +344,18 @@ class SPFNTrainer:
     def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
         st = self._graph
+        # inputs into the static buffers: ONE multi-tensor copy (the batch tensors that are not already the
+        # static ones + the next batch's coordinates for the geometry branch of G2)
+        dst, src = [], []
         for k, v in batch.items():
             if v.data_ptr() != st["batch"][k].data_ptr():
-                st["batch"][k].copy_(v, non_blocking=True)
+                dst.append(st["batch"][k])
+                src.append(v)
+        if next_batch is not None and next_batch["P"].data_ptr() != st["P_next"].data_ptr():
+            dst.append(st["P_next"])
+            src.append(next_batch["P"])
+        if dst:
+            self._copy_all(dst, src)
         B, N, _ = batch["P"].shape
         if self._prefetched is not None:                       # geometry prefetched by an eager (warm-up) step
             geom = self._take_prefetched(batch["P"])
@@ -344,17 +366,19 @@ class SPFNTrainer:
             self._draw_starts(st, B, N)
             st["g0"].replay()
         st["g1"].replay()
-        # inputs of the geometry branch inside G2: the NEXT batch's coordinates and FPS seeds
+        st["cost_ready"].record()                              # the cost matrices are in pinned host memory after this
+        st["g1b"].replay()                                     # fits: GPU work for the time of the host round trip
+        # inputs of the geometry branch inside G2: the NEXT batch's FPS seeds
         # (without an announced next batch the branch recomputes stale inputs; its result is ignored and
         #  no FPS seeds are drawn, so the CPU generator is consumed exactly as in eager mode)
         if next_batch is not None:
-            if next_batch["P"].data_ptr() != st["P_next"].data_ptr():
-                st["P_next"].copy_(next_batch["P"], non_blocking=True)
             self._draw_starts(st, B, N)
             st["geom_ready_for"] = next_batch["P"].data_ptr()
         else:
             st["geom_ready_for"] = None
-        st["match"].copy_(fl.hungarian_from_pack(st["cost_pack"], st["match"].shape[1]))   # the step's one host sync
+        st["cost_ready"].synchronize()                         # the step's one host sync (waits for G1, not G1b)
+        fl.hungarian_host(st["cost_host"], st["match"].shape[1], out=st["match_host"])
+        st["match"].copy_(st["match_host"], non_blocking=True)
         st["g2"].replay()
         if st["world"] > 1:
             self.bucket.all_reduce_mean()
