@@ -178,7 +178,9 @@ def main():
                                    % (BATCH_PER_GPU, N_POINTS, N_INSTANCES),
                        "global_batch": BATCH_PER_GPU * world, "points": N_POINTS,
                        "parallelism": "dp%d" % world, "loss_last": float(out[0]),
-                       "launch": "hipGraph replay (2 graphs/step)" if trainer._graph is not None else "eager"},
+                       "launch": ("eager" if trainer._graph is None else
+                                  "hipGraph replay (1 graph/step, device-side assignment)" if trainer._graph.get("single")
+                                  else "hipGraph replay (3 graphs/step around the host-side assignment)")},
             "roofline": {"bound": "hbm", "kernel": ROOFLINE_SYMBOL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": calls, "avg_launch_us": 1e6 * per_launch_s,

@@ -11,6 +11,7 @@ Utils/training_utils.py:141-142 folded in), organised as four launches instead o
   params, match    --Residue---> residue loss[B,K], axis loss[B,K]
 """
 import ctypes
+import os
 
 import torch
 from scipy.optimize import linear_sum_assignment
@@ -18,6 +19,10 @@ from scipy.optimize import linear_sum_assignment
 from .. import lib as _l
 from ..ops import _ptr, _stream
 from . import fitters_common as _fc
+
+# CPFN_HOST_ASSIGNMENT=1: solve the assignment with SciPy on the host like the reference (one device->host->device
+# round trip per step) instead of cpfn_hungarian_match.
+HOST_ASSIGNMENT = os.environ.get("CPFN_HOST_ASSIGNMENT", "0") == "1"
 
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
                 ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
@@ -188,6 +193,19 @@ def hungarian_from_pack(pack, K):
     return hungarian_host(pack.cpu(), K).to(pack.device)
 
 
+def hungarian_device(S, n_gt):
+    """The assignment on the device (cpfn_hungarian_match): S [B,K+2,K] from SegStats, n_gt [B] int64 ->
+    match [B,K] int64.  Same solver and tie-breaking as the SciPy call of the reference
+    (losses_implementation.py:27), no host round trip, capturable."""
+    B, K2, K = S.shape
+    Sc = S.detach().contiguous().float()
+    match = torch.empty(B, K, dtype=torch.long, device=S.device)
+    with torch.cuda.device(S.device):
+        _l.check(_l.lib().cpfn_hungarian_match(_ptr(Sc), _ptr(n_gt.contiguous()), B, K, _ptr(match), _stream()),
+                 "cpfn_hungarian_match")
+    return match
+
+
 def hungarian_from_stats(S, I_gt):
     return hungarian_from_pack(hungarian_cost_pack(S, I_gt), S.shape[2])
 
@@ -233,5 +251,8 @@ def fused_losses(P, Y, batch, multipliers, classes):
     Returns the reference's (total, normal, type, miou, residue, parameter) scalars."""
     Xn, W, nl, tl, S = pre_match(Y, batch)
     n_gt = count_gt(batch["I_gt"])
-    match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
+    if HOST_ASSIGNMENT or S.shape[2] > 32:
+        match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
+    else:
+        match = hungarian_device(S, n_gt)
     return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt)

@@ -99,10 +99,11 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int BN, int KS, bool STATS>
+template <int BN, int KS, bool STATS, bool PER_TILE_DPP>
 __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
-                                            int row0, int n0, int wave, int lane, float *s_stat /*[2][BN], this wave's*/) {
+                                            int row0, int n0, int wave, int lane, f32x4 (&st_s)[BN / 16],
+                                            f32x4 (&st_q)[BN / 16]) {
   constexpr int NT = BN / 16;
   const int lr = lane & 15, lq = lane >> 4;
   f32x4 acc[NT][2];
@@ -118,21 +119,22 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const uns
     }
   }
   if (STATS) {
-    // per-channel Σy, Σy² of this wave's 32 points: per-lane sum over the two point tiles, DPP sum over
-    // the 16 point lanes of a row, then ONE lane per row adds 4 channels to the wave's LDS accumulators
-    // (instead of 2 x BN/4 persistent registers per lane: the stats variant no longer sits at 256 VGPRs)
+    // per-channel Σy, Σy² of this wave's points, kept in registers over all row tiles of the workgroup and written
+    // to LDS once at the end.  Measured (us per launch, 128->128 @131072 rows | sa1 64->128 @524288 rows):
+    //   per-tile DPP sum + per-tile LDS read-modify-write     22.5 | 56.4   (the LDS round trips serialise)
+    //   per-lane sums, ONE DPP reduction after the tile loop  29.0 | 38.3
+    //   per-tile DPP sum, register accumulation (this)        21.9 | 37.9
     const float m0 = (row0 + wave * 32 + lr < P) ? 1.f : 0.f, m1 = (row0 + wave * 32 + 16 + lr < P) ? 1.f : 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      f32x4 a = acc[nt][0] * m0, b = acc[nt][1] * m1;
+      const f32x4 a = acc[nt][0] * m0, b = acc[nt][1] * m1;
       f32x4 sm = a + b, sq = a * a + b * b;
+      if (PER_TILE_DPP) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
-      if (lr == 0) {
-        f32x4 *p0 = (f32x4 *)&s_stat[nt * 16 + 4 * lq], *p1 = (f32x4 *)&s_stat[BN + nt * 16 + 4 * lq];
-        *p0 = *p0 + sm;
-        *p1 = *p1 + sq;
+        for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
       }
+      st_s[nt] += sm;
+      st_q[nt] += sq;
     }
   }
 #pragma unroll
@@ -162,13 +164,14 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   constexpr int NT = BN / 16, K = 32 * KS;
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
   __shared__ __attribute__((aligned(16))) unsigned short s_o[4][32 * G_LDO];
-  __shared__ float s_red[4][2][BN];
+  __shared__ __attribute__((aligned(16))) float s_red[4][2][BN];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
-  if (STATS) {
-    for (int e = t; e < 4 * 2 * BN; e += G_THREADS) (&s_red[0][0][0])[e] = 0.f;   // visible after the W-panel barrier
-  }
+  constexpr bool PTD = true;    // per-tile DPP row sums (see stream_tile)
+  f32x4 st_s[NT], st_q[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) { st_s[i] = (f32x4){0, 0, 0, 0}; st_q[i] = (f32x4){0, 0, 0, 0}; }
   const int ntiles = (P + G_ROWS - 1) / G_ROWS;
   const int tile0 = blockIdx.x * tiles_per_wg;
   const int tile_end = min(tile0 + tiles_per_wg, ntiles);
@@ -180,13 +183,24 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
     for (int tile = tile0; tile < tile_end; tile += 2) {
       // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
       stream_load_a<KS>(a1, A, lda, P, min(tile + 1, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, &s_red[wave][0][0]);
+      stream_tile<BN, KS, STATS, PTD>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q);
       if (tile + 1 >= tile_end) break;
       stream_load_a<KS>(a0, A, lda, P, min(tile + 2, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, &s_red[wave][0][0]);
+      stream_tile<BN, KS, STATS, PTD>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q);
     }
   }
   if (STATS) {
+    // once per workgroup: DPP sum over the 16 point lanes of a row, one lane per row writes 4 channels
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      if (!PTD)
+        for (int r = 0; r < 4; ++r) { st_s[nt][r] = row16_sum(st_s[nt][r]); st_q[nt][r] = row16_sum(st_q[nt][r]); }
+      if (lr == 0) {
+        *(f32x4 *)&s_red[wave][0][nt * 16 + 4 * lq] = st_s[nt];
+        *(f32x4 *)&s_red[wave][1][nt * 16 + 4 * lq] = st_q[nt];
+      }
+    }
     __syncthreads();
     for (int e = t; e < 2 * BN; e += G_THREADS) {
       const int which = e / BN, c = e - which * BN;

@@ -1,0 +1,67 @@
+// Adam on flat buffers for gfx950: all parameters, gradients and both moments are single contiguous fp32
+// buffers (training.FlatGradBucket / optim.FlatAdam), so the optimizer step is ONE streaming kernel instead of
+// a multi-tensor launch over ~100 small tensors (62 us -> a few us for the 1.4 M parameters of GlobalSPFN).
+// Same arithmetic as torch.optim.Adam (reference: the optimizer of Utils/training_utils.py's epoch loop;
+// torch/optim/adam.py, non-amsgrad, maximize=False), capturable: learning rate, step count and the
+// "skip this step" flag live in device memory.
+#include "common.h"
+
+namespace {
+
+// coef[0] = lr / (1 - beta1^t), coef[1] = sqrt(1 - beta2^t), coef[2] = 1 when the step is skipped; t = step + 1.
+// One lane: the two fp64 pow() calls cost more than the whole streaming pass when every lane repeats them.
+__global__ void adam_prepare_kernel(const float *__restrict__ lr, float beta1, float beta2, float *__restrict__ step,
+                                    const float *__restrict__ found_inf, float *__restrict__ coef) {
+  const bool skip = found_inf && *found_inf != 0.f;
+  const double t = (double)*step + 1.0;
+  coef[0] = *lr / (float)(1.0 - pow((double)beta1, t));
+  coef[1] = sqrtf((float)(1.0 - pow((double)beta2, t)));
+  coef[2] = skip ? 1.f : 0.f;
+  if (!skip) *step += 1.f;
+}
+
+__global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                        float *__restrict__ m, float *__restrict__ v, long long n,
+                                                        float beta1, float beta2, float eps, float weight_decay,
+                                                        const float *__restrict__ coef) {
+  if (coef[2] != 0.f) return;                                       // non-finite gradients: the step is skipped
+  const float step_size = coef[0], bc2_sqrt = coef[1];
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  float pv[4], gv[4], mv[4], vv[4];
+  const int cnt = (int)min(4LL, n - i0);
+  if (cnt == 4) {
+    *(float4 *)pv = *(const float4 *)(p + i0); *(float4 *)gv = *(const float4 *)(g + i0);
+    *(float4 *)mv = *(const float4 *)(m + i0); *(float4 *)vv = *(const float4 *)(v + i0);
+  } else {
+    for (int j = 0; j < cnt; ++j) { pv[j] = p[i0 + j]; gv[j] = g[i0 + j]; mv[j] = m[i0 + j]; vv[j] = v[i0 + j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float gr = gv[j];
+    if (weight_decay != 0.f) gr = fmaf(weight_decay, pv[j], gr);
+    mv[j] = mv[j] + (gr - mv[j]) * (1.f - beta1);                   // exp_avg.lerp_(grad, 1 - beta1)
+    vv[j] = beta2 * vv[j] + (1.f - beta2) * gr * gr;                // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+    pv[j] = pv[j] - step_size * (mv[j] / denom);
+  }
+  if (cnt == 4) {
+    *(float4 *)(p + i0) = *(const float4 *)pv; *(float4 *)(m + i0) = *(const float4 *)mv; *(float4 *)(v + i0) = *(const float4 *)vv;
+  } else {
+    for (int j = 0; j < cnt; ++j) { p[i0 + j] = pv[j]; m[i0 + j] = mv[j]; v[i0 + j] = vv[j]; }
+  }
+}
+
+}  // namespace
+
+extern "C" int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
+                              float beta2, float eps, float weight_decay, float *step, const float *found_inf,
+                              float *coef3, void *stream) {
+  if (n < 0 || !p || !g || !m || !v || !lr || !step || !coef3) return CPFN_EINVAL;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CPFN_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  adam_prepare_kernel<<<1, 1, 0, st>>>(lr, beta1, beta2, step, found_inf, coef3);
+  adam_flat_kernel<<<cpfn_cdiv(cpfn_cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, coef3);
+  return cpfn_launch_status();
+}

@@ -1,0 +1,76 @@
+"""Adam on flat buffers (cpfn_adam_flat): the optimizer of the training step as one streaming kernel.
+
+`FlatAdam` is a torch.optim.Optimizer with torch.optim.Adam's arithmetic and hyper-parameters (the reference
+builds `optim.Adam(spfn_module.parameters(), lr=...)`, training_SPFN.py; torch/optim/adam.py).  It re-points
+every parameter at a view of ONE contiguous fp32 buffer and reads the gradients from the trainer's
+FlatGradBucket, so a step is a single launch over 1.4 M elements instead of a multi-tensor launch over ~100
+tensors.  Capturable: learning rate, step count and `found_inf` (set it before `step()` to skip on non-finite
+gradients) are device scalars.  GPU only — on CPU the trainer keeps torch.optim.Adam."""
+import torch
+
+from . import lib as _l
+from .ops import _ptr, _stream
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = list(bucket.params)
+        dev = bucket.flat.device
+        if not bucket.flat.is_cuda:
+            raise RuntimeError("FlatAdam runs on the GPU only (CPU not supported)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.bucket = bucket
+        n = bucket.flat.numel()
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                if p.dtype != torch.float32:
+                    raise RuntimeError("FlatAdam expects fp32 master parameters")
+                k = p.numel()
+                view = self.flat_p[off:off + k].view_as(p)
+                view.copy_(p.data)
+                p.data = view                      # same nn.Parameter object, storage inside the flat buffer
+                off += k
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros((), dtype=torch.float32, device=dev)
+        self.lr_dev = torch.zeros((), dtype=torch.float32, device=dev)
+        self._coef = torch.zeros(3, dtype=torch.float32, device=dev)
+        self._lr_host = None
+        self.found_inf = None
+        g = self.param_groups[0]
+        g["lr"] = self.lr_dev                      # the trainer's staircase does `group['lr'].fill_(lr)`
+        self.lr_dev.fill_(float(lr))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        lr = g["lr"]
+        if not isinstance(lr, torch.Tensor):       # someone assigned a float: mirror it into the device scalar
+            if lr != self._lr_host:
+                self.lr_dev.fill_(float(lr))
+                self._lr_host = lr
+            lr = self.lr_dev
+        b1, b2 = g["betas"]
+        with torch.cuda.device(self.flat_p.device):
+            _l.check(_l.lib().cpfn_adam_flat(_ptr(self.flat_p), _ptr(self.bucket.flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                             self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
+                                             float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.found_inf), _ptr(self._coef),
+                                             _stream()),
+                     "cpfn_adam_flat")
+
+    def state_dict(self):
+        return {"flat": {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count},
+                "hyper": {k: (float(v) if isinstance(v, torch.Tensor) else v) for k, v in self.param_groups[0].items()
+                          if k != "params"}}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["flat"]["exp_avg"])
+        self.exp_avg_sq.copy_(sd["flat"]["exp_avg_sq"])
+        self.step_count.copy_(sd["flat"]["step"])
+        for k, v in sd.get("hyper", {}).items():
+            if k == "lr":
+                self.lr_dev.fill_(float(v))
+            else:
+                self.param_groups[0][k] = v

@@ -112,12 +112,13 @@ class SPFNTrainer:
         self.bucket = FlatGradBucket(module)
         on_gpu = self.bucket.flat.is_cuda
         self.use_graphs = bool(use_graphs) and on_gpu
-        if self.use_graphs:   # lr lives in a device tensor so the LR staircase needs no re-capture
-            self.optimizer = torch.optim.Adam(module.parameters(), lr=torch.tensor(float(init_learning_rate), device=self.bucket.flat.device),
-                                              fused=True, capturable=True)
+        # GPU: Adam as one kernel over flat buffers (optim.FlatAdam; lr / step count / skip flag on the device, so
+        # the LR staircase needs no re-capture).  `fused_adam=False` keeps torch.optim.Adam (also used on CPU).
+        if on_gpu and fused_adam is not False:
+            from .optim import FlatAdam
+            self.optimizer = FlatAdam(self.bucket, lr=init_learning_rate)
         else:
-            self.optimizer = torch.optim.Adam(module.parameters(), lr=init_learning_rate,
-                                              fused=on_gpu if fused_adam is None else fused_adam)
+            self.optimizer = torch.optim.Adam(module.parameters(), lr=init_learning_rate)
         self._graph, self._graph_warm = None, 0
         self._gstream, self._in_gstream, self._gside = None, False, None
         self.global_step = 0
@@ -204,18 +205,18 @@ class SPFNTrainer:
         return out[:6]
 
     # ---- hipGraph replay of the step -----------------------------------------------------------
-    # At 16 clouds per GPU the step is ~560 launches and host-bound (~7 ms of CPU for ~6.5 ms of GPU
-    # work).  The step is captured once into graphs split at its single host round trip (the
-    # Hungarian assignment):
-    #   G1  = (geometry buffers B -> A) + network forward + heads post-processing + segmented sums
-    #         + cost matrices copied to pinned host memory; an event marks its end
-    #   G1b = the four fits of every instance (they do not depend on the assignment)
-    #         || host: waits for the event (not for G1b), SciPy assignment, matching back to the device
-    #   G2  = matched losses, full backward, gradient packing, finite flag, fused Adam
-    #        || side branch: FPS / ball query / 3-NN of the NEXT batch into geometry buffers B
+    # At 16 clouds per GPU the step is ~330 launches and host-bound when launched one by one.  With the
+    # assignment solved on the device (cpfn_hungarian_match) nothing in the step needs the host, so it is
+    # captured ONCE as a single graph:
+    #   G  = (geometry buffers B -> A) + network forward + heads post-processing + segmented sums + assignment
+    #        + fits + matched losses + full backward + gradient packing + finite flag + Adam
+    #        || forked branch: FPS / ball query / 3-NN / inverse indices of the NEXT batch into buffers B
     #   G0 = the geometry pass alone (only replayed when the next batch was not announced)
-    # The geometry of a batch depends on its coordinates only, so computing it one step ahead inside
-    # G2 hides the 0.7 ms FPS latency chain (16 workgroups) behind the backward pass.
+    # The geometry of a batch depends on its coordinates only, so computing it one step ahead inside G hides
+    # the 0.7 ms FPS latency chain (16 workgroups) behind the forward and backward passes.
+    # CPFN_HOST_ASSIGNMENT=1 solves the assignment with SciPy on the host like the reference; the step is then
+    # split at that round trip: G1 (forward .. cost matrices -> pinned host memory, event), G1b (the fits, which
+    # do not depend on the assignment, run while the host works), G2 (the rest).
     @staticmethod
     def _flatten_geom(g):
         out = []
@@ -266,7 +267,8 @@ class SPFNTrainer:
         st = {"batch": {k: v.clone() for k, v in batch.items()},
               "P_next": batch["P"].clone(),
               "start_dev": torch.zeros(2, B, dtype=torch.int32, device=dev),
-              "start_host": torch.zeros(2, B, dtype=torch.int32).pin_memory(),
+              "start_host": [torch.zeros(2, B, dtype=torch.int32).pin_memory() for _ in range(2)],
+              "start_done": [torch.cuda.Event(), torch.cuda.Event()], "start_turn": 0,
               "match": torch.zeros(B, K, dtype=torch.long, device=dev),
               "skipped": torch.zeros((), dtype=torch.float32, device=dev)}
         st["start1"], st["start2"] = st["start_dev"][0], st["start_dev"][1]
@@ -293,6 +295,36 @@ class SPFNTrainer:
         g0 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g0, stream=self._gstream, capture_error_mode="thread_local"):
             geometry_into_B(sb["P"])
+        st["world"], st["g0"] = world, g0
+        st["single"] = not fl.HOST_ASSIGNMENT and K <= 32
+        if st["single"]:
+            # Device-side assignment (cpfn_hungarian_match): the step has no host round trip and is ONE graph.
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
+                self._copy_all(geomA, geomB)
+                self._gside.wait_stream(self._gstream)              # fork (after B was read): next batch's geometry
+                with torch.cuda.stream(self._gside):
+                    geometry_into_B(st["P_next"])
+                self.bucket.zero()
+                self.module(sb["P"], geometry=st["geomA"])
+                Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
+                n_gt = fl.count_gt(sb["I_gt"])
+                st["match"] = fl.hungarian_device(S, n_gt)
+                params = fl.fit_params(sb["P"], W, Xn, self.mult)
+                out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
+                out[0].backward()
+                self.bucket.collect()
+                if world == 1:
+                    st["found_inf"] = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+                    self.optimizer.found_inf = st["found_inf"]
+                    self.optimizer.step()
+                    st["skipped"] += st["found_inf"]
+                st["out"] = tuple(o.detach() for o in out)
+                self._gstream.wait_stream(self._gside)              # join
+            st["g"] = g
+            st["geom_ready_for"] = None
+            return st
+        # ---- CPFN_HOST_ASSIGNMENT=1: SciPy on the host like the reference; graphs split at that round trip
         st["cost_host"] = torch.empty(B, K * K + 1, dtype=torch.float32).pin_memory()   # (not inside a capture)
         st["match_host"] = torch.zeros(B, K, dtype=torch.long).pin_memory()
         g1 = torch.cuda.CUDAGraph()
@@ -326,20 +358,25 @@ class SPFNTrainer:
                 st["skipped"] += st["found_inf"]
             st["out"] = tuple(o.detach() for o in out)
             self._gstream.wait_stream(self._gside)                  # join
-        st["g0"], st["g1"], st["g1b"], st["g2"], st["world"] = g0, g1, g1b, g2, world
+        st["g1"], st["g1b"], st["g2"] = g1, g1b, g2
         st["cost_ready"] = torch.cuda.Event()
         st["geom_ready_for"] = None
         return st
 
     def _draw_starts(self, st, B, N):
         # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order.
-        # They go through a PINNED staging buffer that lives as long as the graphs, so the asynchronous copy never
-        # reads from a temporary pageable tensor the host may already have reused.  The buffer is rewritten only
-        # after the next step's host sync (the Hungarian round trip), i.e. after this copy has executed.
-        host = st["start_host"]
+        # They go through PINNED staging buffers that live as long as the graphs, so the asynchronous copy never
+        # reads from a temporary pageable tensor the host may already have reused.  Two buffers take turns and
+        # each is rewritten only after the copy that last read it has executed (its event): without a host
+        # sync in the step the host may run ahead of the device.
+        k = st["start_turn"]
+        st["start_turn"] = 1 - k
+        host, done = st["start_host"][k], st["start_done"][k]
+        done.synchronize()
         host[0].copy_(torch.randint(0, N, (B,), dtype=torch.long))
         host[1].copy_(torch.randint(0, self.module.sa1.num_points, (B,), dtype=torch.long))
         st["start_dev"].copy_(host, non_blocking=True)
+        done.record()
 
     def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
@@ -365,17 +402,28 @@ class SPFNTrainer:
         if st["geom_ready_for"] != batch["P"].data_ptr():      # not announced one step ahead: do it now
             self._draw_starts(st, B, N)
             st["g0"].replay()
+        # inputs of the geometry branch: the NEXT batch's FPS seeds (its coordinates were copied above)
+        # (without an announced next batch the branch recomputes stale inputs; its result is ignored and
+        #  no FPS seeds are drawn, so the CPU generator is consumed exactly as in eager mode)
+        announce = next_batch is not None
+        if st["single"]:
+            if announce:
+                self._draw_starts(st, B, N)
+            st["geom_ready_for"] = next_batch["P"].data_ptr() if announce else None
+            st["g"].replay()                                   # the whole step: no host synchronisation
+            if st["world"] > 1:
+                self.bucket.all_reduce_mean()
+                self.optimizer.found_inf = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+                self.optimizer.step()
+                st["skipped"] += self.optimizer.found_inf
+            self.global_step += 1
+            return st["out"]
         st["g1"].replay()
         st["cost_ready"].record()                              # the cost matrices are in pinned host memory after this
         st["g1b"].replay()                                     # fits: GPU work for the time of the host round trip
-        # inputs of the geometry branch inside G2: the NEXT batch's FPS seeds
-        # (without an announced next batch the branch recomputes stale inputs; its result is ignored and
-        #  no FPS seeds are drawn, so the CPU generator is consumed exactly as in eager mode)
-        if next_batch is not None:
+        if announce:
             self._draw_starts(st, B, N)
-            st["geom_ready_for"] = next_batch["P"].data_ptr()
-        else:
-            st["geom_ready_for"] = None
+        st["geom_ready_for"] = next_batch["P"].data_ptr() if announce else None
         st["cost_ready"].synchronize()                         # the step's one host sync (waits for G1, not G1b)
         fl.hungarian_host(st["cost_host"], st["match"].shape[1], out=st["match_host"])
         st["match"].copy_(st["match_host"], non_blocking=True)

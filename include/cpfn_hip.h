@@ -314,6 +314,13 @@ CPFN_API int cpfn_residue_bwd(const float *gout, const float *dout, const int64_
                               const int64_t *Tgt, int B, int K, const int *type_ids, float *gparams,
                               void *stream);
 
+/* The assignment of GT instances to predictions on the device (the reference does it on the host:
+ * SPFN/losses_implementation.py:10-30, scipy.optimize.linear_sum_assignment(-cost) per cloud):
+ * S[B,K+2,K] from cpfn_seg_stats_fwd, n_gt[B] = number of GT instances -> match[B,K] int64 (zeros
+ * beyond n_gt).  Same solver as SciPy 1.15 (Crouse's shortest augmenting path, fp64), same tie
+ * breaking, hence the same matching.  K <= 32.  Costs must be finite (SciPy raises on NaN/inf). */
+CPFN_API int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, int K, int64_t *match,
+                                  void *stream);
 /* The [B,K]-sized tail of compute_all_losses (SPFN/losses_implementation.py:77-90, 603-606, 633-673)
  * in one launch: relaxed IoU of the matched pairs from S[B,K+2,K] (cpfn_seg_stats_fwd), masked means
  * over the n_gt[b] existing instances of that and of rp[B,K,2] (cpfn_residue_fwd; may be NULL), batch
@@ -325,6 +332,14 @@ CPFN_API int cpfn_loss_tail(const float *S, const float *rp, const float *nl, co
                             int nl_stride, const int64_t *match, const int64_t *n_gt, int B, int K,
                             const float *mult6, float *out6, float *gS, float *grp, float *gnl,
                             float *gtl, void *stream);
+
+/* Adam step on flat fp32 buffers p, g, m, v [n] (16-byte aligned), torch.optim.Adam arithmetic
+ * (non-amsgrad; the optimizer of the reference's epoch loop, Utils/training_utils.py).  Capturable:
+ * lr, step (count of steps taken so far, incremented here) and found_inf (may be NULL; non-zero =
+ * skip the whole step) are device scalars; coef3 = 3 floats of device scratch (bias-correction terms). */
+CPFN_API int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr,
+                            float beta1, float beta2, float eps, float weight_decay, float *step,
+                            const float *found_inf, float *coef3, void *stream);
 
 #ifdef __cplusplus
 }

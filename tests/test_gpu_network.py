@@ -132,3 +132,34 @@ def test_loss_tail_multipliers(mult):
         assert abs(float(a) - float(b)) <= 2e-4 * abs(float(b)) + 1e-6, (float(a), float(b))
     err = float((Ya.grad - Yb.grad).norm() / Yb.grad.norm())
     assert err < 2e-3, err
+
+
+def test_device_assignment_matches_scipy():
+    """cpfn_hungarian_match against the reference's host-side SciPy call on the same segmented sums: random soft
+    memberships, peaky ones, clouds with few / all instances, exact ties (identical prediction columns, empty
+    GT instances)."""
+    from scipy.optimize import linear_sum_assignment
+    from cpfn_amd.SPFN import fused_losses as fl
+    from oracle import lsap
+    rng = np.random.default_rng(5)
+    B, N, K = 24, 1024, 28
+    I = np.zeros((B, N), dtype=np.int64)
+    W = np.zeros((B, N, K), dtype=np.float32)
+    for b in range(B):
+        n = int(rng.integers(1, K + 1)) if b % 5 else K
+        I[b] = rng.integers(-1, n, N)
+        I[b, :n] = np.arange(n)                                   # every label < n present (no gaps)
+        logits = rng.normal(size=(N, K)) * (0.2 if b % 3 == 0 else 3.0)
+        if b % 4 == 1:
+            logits[:, 5] = logits[:, 9]                            # two identical prediction columns: exact ties
+        if b % 4 == 2:
+            logits[:] = 0.0                                        # uniform memberships: everything ties
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        W[b] = e / e.sum(1, keepdims=True)
+    Wd, Id = torch.from_numpy(W).to(dev()), torch.from_numpy(I).to(dev())
+    S = fl.SegStats.apply(Wd, Id)
+    n_gt = fl.count_gt(Id)
+    got = fl.hungarian_device(S, n_gt).cpu().numpy()
+    want_host = fl.hungarian_from_pack(fl.hungarian_cost_pack(S, Id, n_gt), K).cpu().numpy()       # SciPy
+    assert np.array_equal(got, want_host)
+    assert np.array_equal(got, lsap.hungarian_from_stats(S.cpu().numpy(), n_gt.cpu().numpy()))     # the oracle restatement

@@ -1,0 +1,49 @@
+"""cpfn_adam_flat / optim.FlatAdam against torch.optim.Adam (the reference's optimizer): same trajectory over
+several steps, the skip-on-non-finite flag, a learning-rate change through the device scalar."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev):
+    torch.manual_seed(3)
+    return torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.ReLU(), torch.nn.Linear(13, 5), torch.nn.Linear(5, 3)).to(dev)
+
+
+def test_flat_adam_matches_torch_adam():
+    from cpfn_amd import training
+    from cpfn_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    ma = _model(dev)
+    mb = copy.deepcopy(ma)
+    bucket = training.FlatGradBucket(ma)
+    oa = FlatAdam(bucket, lr=1e-2)
+    ob = torch.optim.Adam(mb.parameters(), lr=1e-2)
+    assert all(p.data_ptr() >= oa.flat_p.data_ptr() for p in ma.parameters())          # parameters live in the flat buffer
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for step in range(12):
+        x = torch.randn(32, 7, generator=g).to(dev)
+        if step == 6:                                  # staircase: new learning rate through the device scalar
+            oa.param_groups[0]["lr"].fill_(3e-3)
+            ob.param_groups[0]["lr"] = 3e-3
+        for m, o in ((ma, oa), (mb, ob)):
+            for p in m.parameters():
+                p.grad = None
+            (m(x) ** 2).sum().backward()
+        bucket.collect()
+        if step == 4:                                  # non-finite gradients: the whole step is skipped, count included
+            oa.found_inf = torch.ones((), device=dev)
+            oa.step()
+            oa.found_inf = torch.zeros((), device=dev)
+            assert float(oa.step_count) == 4.0
+            continue
+        oa.step()
+        ob.step()
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            torch.testing.assert_close(pa, pb, rtol=2e-6, atol=1e-7)
+    assert float(oa.step_count) == 11.0
+    sd = oa.state_dict()
+    assert sd["flat"]["exp_avg"].numel() == bucket.flat.numel()

@@ -138,3 +138,31 @@ def test_training_step_losses_and_grads(golden):
     gn = np.array([float(st[n].grad.norm()) for n in names])
     scale = g["grad_norm"].max()
     assert np.all(np.abs(gn - g["grad_norm"]) <= 1e-3 * g["grad_norm"] + 1e-6 * scale)
+
+
+def test_lsap_matches_scipy():
+    """The restated assignment solver (oracle/lsap.py) picks the SAME optimal assignment as SciPy, ties
+    included: random fp32 costs, small-integer costs (many ties), constant matrices, rectangular shapes."""
+    from scipy.optimize import linear_sum_assignment
+    from oracle import lsap
+    rng = np.random.default_rng(0)
+    n_checked = 0
+    for trial in range(600):
+        nc = int(rng.integers(1, 29))
+        nr = int(rng.integers(1, nc + 1))
+        kind = trial % 4
+        if kind == 0:
+            c = rng.random((nr, nc)).astype(np.float32).astype(np.float64)
+        elif kind == 1:
+            c = rng.integers(0, 4, (nr, nc)).astype(np.float64)              # heavy ties
+        elif kind == 2:
+            c = np.full((nr, nc), float(rng.integers(0, 3)))                  # constant: identity expected
+        else:
+            c = np.round(rng.random((nr, nc)), 1)                             # ties at one decimal
+            c[rng.random((nr, nc)) < 0.3] = 0.0                               # zero rows / columns like empty instances
+        for sign in (1.0, -1.0):
+            _, want = linear_sum_assignment(sign * c)
+            got = lsap.linear_sum_assignment_min(sign * c)
+            assert np.array_equal(got, want), (trial, sign, c, got, want)
+            n_checked += 1
+    assert n_checked == 1200
