@@ -99,7 +99,7 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int BN, int KS, bool STATS, bool PER_TILE_DPP>
+template <int BN, int KS, bool STATS>
 __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
                                             int row0, int n0, int wave, int lane, f32x4 (&st_s)[BN / 16],
@@ -119,22 +119,18 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const uns
     }
   }
   if (STATS) {
-    // per-channel Σy, Σy² of this wave's points, kept in registers over all row tiles of the workgroup and written
-    // to LDS once at the end.  Measured (us per launch, 128->128 @131072 rows | sa1 64->128 @524288 rows):
-    //   per-tile DPP sum + per-tile LDS read-modify-write     22.5 | 56.4   (the LDS round trips serialise)
-    //   per-lane sums, ONE DPP reduction after the tile loop  29.0 | 38.3
-    //   per-tile DPP sum, register accumulation (this)        21.9 | 37.9
+    // per-channel Σy, Σy² of this wave's points: per-lane running sums over all row tiles of the workgroup; the
+    // cross-lane (DPP) reduction and the LDS hand-over happen once, after the tile loop.
+    // Measured (us per launch, 128->128 @131072 rows | sa1 64->128 @524288 rows):
+    //   per-tile DPP sum + per-tile LDS read-modify-write   22.5 | 56.4   (the LDS round trips serialise)
+    //   per-tile DPP sum, register accumulation             23.3 | 48.0
+    //   per-lane sums, one DPP reduction at the end (this)  22.1 | 37.8
     const float m0 = (row0 + wave * 32 + lr < P) ? 1.f : 0.f, m1 = (row0 + wave * 32 + 16 + lr < P) ? 1.f : 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const f32x4 a = acc[nt][0] * m0, b = acc[nt][1] * m1;
-      f32x4 sm = a + b, sq = a * a + b * b;
-      if (PER_TILE_DPP) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
-      }
-      st_s[nt] += sm;
-      st_q[nt] += sq;
+      st_s[nt] += a + b;
+      st_q[nt] += a * a + b * b;
     }
   }
 #pragma unroll
@@ -168,7 +164,6 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
-  constexpr bool PTD = true;    // per-tile DPP row sums (see stream_tile)
   f32x4 st_s[NT], st_q[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { st_s[i] = (f32x4){0, 0, 0, 0}; st_q[i] = (f32x4){0, 0, 0, 0}; }
@@ -183,10 +178,10 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
     for (int tile = tile0; tile < tile_end; tile += 2) {
       // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
       stream_load_a<KS>(a1, A, lda, P, min(tile + 1, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS, PTD>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q);
+      stream_tile<BN, KS, STATS>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q);
       if (tile + 1 >= tile_end) break;
       stream_load_a<KS>(a0, A, lda, P, min(tile + 2, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS, PTD>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q);
+      stream_tile<BN, KS, STATS>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q);
     }
   }
   if (STATS) {
@@ -194,8 +189,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-      if (!PTD)
-        for (int r = 0; r < 4; ++r) { st_s[nt][r] = row16_sum(st_s[nt][r]); st_q[nt][r] = row16_sum(st_q[nt][r]); }
+      for (int r = 0; r < 4; ++r) { st_s[nt][r] = row16_sum(st_s[nt][r]); st_q[nt][r] = row16_sum(st_q[nt][r]); }
       if (lr == 0) {
         *(f32x4 *)&s_red[wave][0][nt * 16 + 4 * lq] = st_s[nt];
         *(f32x4 *)&s_red[wave][1][nt * 16 + 4 * lq] = st_q[nt];

@@ -9,15 +9,17 @@
 namespace {
 
 // coef[0] = lr / (1 - beta1^t), coef[1] = sqrt(1 - beta2^t), coef[2] = 1 when the step is skipped; t = step + 1.
-// One lane: the two fp64 pow() calls cost more than the whole streaming pass when every lane repeats them.
+// One lane.  beta^t is carried as a running fp64 product in pows[2] (beta1^step, beta2^step): calling pow() here
+// costs 25 us of single-lane fp64 software — more than the streaming pass over the parameters.
 __global__ void adam_prepare_kernel(const float *__restrict__ lr, float beta1, float beta2, float *__restrict__ step,
-                                    const float *__restrict__ found_inf, float *__restrict__ coef) {
+                                    double *__restrict__ pows, const float *__restrict__ found_inf,
+                                    float *__restrict__ coef) {
   const bool skip = found_inf && *found_inf != 0.f;
-  const double t = (double)*step + 1.0;
-  coef[0] = *lr / (float)(1.0 - pow((double)beta1, t));
-  coef[1] = sqrtf((float)(1.0 - pow((double)beta2, t)));
+  const double b1t = pows[0] * (double)beta1, b2t = pows[1] * (double)beta2;
+  coef[0] = *lr / (float)(1.0 - b1t);
+  coef[1] = sqrtf((float)(1.0 - b2t));
   coef[2] = skip ? 1.f : 0.f;
-  if (!skip) *step += 1.f;
+  if (!skip) { *step += 1.f; pows[0] = b1t; pows[1] = b2t; }
 }
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g,
@@ -55,13 +57,13 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
 }  // namespace
 
 extern "C" int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
-                              float beta2, float eps, float weight_decay, float *step, const float *found_inf,
-                              float *coef3, void *stream) {
-  if (n < 0 || !p || !g || !m || !v || !lr || !step || !coef3) return CPFN_EINVAL;
+                              float beta2, float eps, float weight_decay, float *step, double *pows,
+                              const float *found_inf, float *coef3, void *stream) {
+  if (n < 0 || !p || !g || !m || !v || !lr || !step || !pows || !coef3) return CPFN_EINVAL;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CPFN_EINVAL;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  adam_prepare_kernel<<<1, 1, 0, st>>>(lr, beta1, beta2, step, found_inf, coef3);
+  adam_prepare_kernel<<<1, 1, 0, st>>>(lr, beta1, beta2, step, pows, found_inf, coef3);
   adam_flat_kernel<<<cpfn_cdiv(cpfn_cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, coef3);
   return cpfn_launch_status();
 }

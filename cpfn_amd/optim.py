@@ -37,6 +37,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = torch.zeros((), dtype=torch.float32, device=dev)
         self.lr_dev = torch.zeros((), dtype=torch.float32, device=dev)
         self._coef = torch.zeros(3, dtype=torch.float32, device=dev)
+        self.beta_pows = torch.ones(2, dtype=torch.float64, device=dev)      # beta1^step, beta2^step
         self._lr_host = None
         self.found_inf = None
         g = self.param_groups[0]
@@ -56,12 +57,14 @@ class FlatAdam(torch.optim.Optimizer):
         with torch.cuda.device(self.flat_p.device):
             _l.check(_l.lib().cpfn_adam_flat(_ptr(self.flat_p), _ptr(self.bucket.flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                              self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
-                                             float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.found_inf), _ptr(self._coef),
+                                             float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows), _ptr(self.found_inf),
+                                             _ptr(self._coef),
                                              _stream()),
                      "cpfn_adam_flat")
 
     def state_dict(self):
-        return {"flat": {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count},
+        return {"flat": {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
+                         "beta_pows": self.beta_pows},
                 "hyper": {k: (float(v) if isinstance(v, torch.Tensor) else v) for k, v in self.param_groups[0].items()
                           if k != "params"}}
 
@@ -69,6 +72,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg.copy_(sd["flat"]["exp_avg"])
         self.exp_avg_sq.copy_(sd["flat"]["exp_avg_sq"])
         self.step_count.copy_(sd["flat"]["step"])
+        self.beta_pows.copy_(sd["flat"]["beta_pows"])
         for k, v in sd.get("hyper", {}).items():
             if k == "lr":
                 self.lr_dev.fill_(float(v))

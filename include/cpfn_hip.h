@@ -335,11 +335,12 @@ CPFN_API int cpfn_loss_tail(const float *S, const float *rp, const float *nl, co
 
 /* Adam step on flat fp32 buffers p, g, m, v [n] (16-byte aligned), torch.optim.Adam arithmetic
  * (non-amsgrad; the optimizer of the reference's epoch loop, Utils/training_utils.py).  Capturable:
- * lr, step (count of steps taken so far, incremented here) and found_inf (may be NULL; non-zero =
- * skip the whole step) are device scalars; coef3 = 3 floats of device scratch (bias-correction terms). */
+ * lr, step (count of steps taken so far, incremented here), pows (fp64 {beta1^step, beta2^step},
+ * start at {1, 1}, advanced here) and found_inf (may be NULL; non-zero = skip the whole step) are
+ * device scalars; coef3 = 3 floats of device scratch (bias-correction terms). */
 CPFN_API int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr,
                             float beta1, float beta2, float eps, float weight_decay, float *step,
-                            const float *found_inf, float *coef3, void *stream);
+                            double *pows, const float *found_inf, float *coef3, void *stream);
 
 #ifdef __cplusplus
 }
