@@ -55,23 +55,37 @@ constexpr int G_LDO = 128 + 8;  // output staging row stride (elements): 272 B
 //               loads along n, transposed on the way into LDS with 2-byte writes — the panel is at most
 //               64 KB and filled once per workgroup (or per K chunk), so the slow writes do not matter,
 //               and no transposed weight copy has to be materialised per step.
-template <int BN>
+template <int BN, int LDW = G_LDW>
 __device__ __forceinline__ void fill_w_panel(unsigned short *s_w, const unsigned short *__restrict__ W, int K,
                                              int N, int n0, int kc, int kcn, int w_trans, int t) {
   if (!w_trans) {
     const int cpr = kcn / 8;  // 16-byte chunks per row
     for (int e = t; e < BN * cpr; e += G_THREADS) {
       const int r = e / cpr, c = e - r * cpr;
-      *(uint4 *)&s_w[r * G_LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + kc + c * 8];
+      *(uint4 *)&s_w[r * LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + kc + c * 8];
     }
   } else {
+    // W is [K, N] (a forward weight used for the data gradient): transpose on the way into LDS.  A lane takes
+    // FOUR consecutive k rows of one 8-column chunk and writes 8-byte pieces (4 k values of one column); the
+    // column order is rotated by the chunk index, otherwise the 16 lanes of a k-row hit one LDS bank (a panel row
+    // is 272 B, so 8 rows apart = 2176 B = 17 x 128 B).  The first version wrote single bf16s with that 16-way
+    // conflict: the transposed launches ran 25 us against 17.5 us for the plain ones.
     constexpr int cpn = BN / 8;  // 16-byte chunks along n
-    for (int e = t; e < kcn * cpn; e += G_THREADS) {
-      const int k = e / cpn, c = e - k * cpn;
-      const uint4 v = *(const uint4 *)&W[(size_t)(kc + k) * N + n0 + c * 8];
-      const unsigned short *h = (const unsigned short *)&v;
+    for (int e = t; e < (kcn / 4) * cpn; e += G_THREADS) {
+      const int k4 = e / cpn, c = e - k4 * cpn;
+      uint4 v[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s_w[(c * 8 + j) * G_LDW + k] = h[j];
+      for (int r = 0; r < 4; ++r) v[r] = *(const uint4 *)&W[(size_t)(kc + 4 * k4 + r) * N + n0 + c * 8];
+      const unsigned short *h0 = (const unsigned short *)&v[0], *h1 = (const unsigned short *)&v[1],
+                           *h2 = (const unsigned short *)&v[2], *h3 = (const unsigned short *)&v[3];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int j = (jj + c) & 7;
+        uint2 o;
+        o.x = (unsigned)h0[j] | ((unsigned)h1[j] << 16);
+        o.y = (unsigned)h2[j] | ((unsigned)h3[j] << 16);
+        *(uint2 *)&s_w[(c * 8 + j) * LDW + 4 * k4] = o;
+      }
     }
   }
 }
@@ -113,7 +127,7 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const uns
   for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const bf16x8 wf = *(const bf16x8 *)&s_w[(nt * 16 + lr) * G_LDW + ks * 32 + 8 * lq];
+      const bf16x8 wf = *(const bf16x8 *)&s_w[(nt * 16 + lr) * (32 * KS + 8) + ks * 32 + 8 * lq];
       acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[nt][0], 0, 0, 0);
       acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[nt][1], 0, 0, 0);
     }
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg) {
   constexpr int NT = BN / 16, K = 32 * KS;
-  __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
+  __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
   __shared__ __attribute__((aligned(16))) unsigned short s_o[4][32 * G_LDO];
   __shared__ __attribute__((aligned(16))) float s_red[4][2][BN];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   if (tile0 < tile_end) {
     bf16x8 a0[2][KS], a1[2][KS];
     stream_load_a<KS>(a0, A, lda, P, tile0 * G_ROWS, wave, lr, lq);
-    fill_w_panel<BN>(s_w, W, K, N, n0, 0, K, w_trans, t);
+    fill_w_panel<BN, 32 * KS + 8>(s_w, W, K, N, n0, 0, K, w_trans, t);
     __syncthreads();
     for (int tile = tile0; tile < tile_end; tile += 2) {
       // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
@@ -954,7 +968,10 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
   const int tpw = (int)((tiles + gx - 1) / gx);
   const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
-  const bool stream_ok = (K == 64 || K == 128) && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0;
+  // whole-K panel in LDS: K <= 256.  K = 192 / 256 only for the long layers: with few row tiles the 50-68 KB panel
+  // (cold in a real step, unlike in a micro-benchmark loop) costs more than the generic kernel's 128-wide K chunks
+  const bool stream_k = K == 64 || K == 128 || ((K == 192 || K == 256) && P >= 32768);
+  const bool stream_ok = stream_k && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0;
   if (stream_ok) {
     unsigned short *y = (unsigned short *)Y;
 #define CPFN_STREAM(BN_, KS_)                                                                                        \
@@ -965,8 +982,13 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
     else                                                                                                             \
       mlp_gemm_stream_kernel<BN_, KS_, false><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, nullptr, tpw);      \
   } while (0)
-    if (N % 128 == 0) { if (K == 64) CPFN_STREAM(128, 2); else CPFN_STREAM(128, 4); }
-    else              { if (K == 64) CPFN_STREAM(64, 2);  else CPFN_STREAM(64, 4); }
+    if (N % 128 == 0) {
+      switch (K) { case 64: CPFN_STREAM(128, 2); break; case 128: CPFN_STREAM(128, 4); break;
+                   case 192: CPFN_STREAM(128, 6); break; default: CPFN_STREAM(128, 8); }
+    } else {
+      switch (K) { case 64: CPFN_STREAM(64, 2); break; case 128: CPFN_STREAM(64, 4); break;
+                   case 192: CPFN_STREAM(64, 6); break; default: CPFN_STREAM(64, 8); }
+    }
 #undef CPFN_STREAM
     return cpfn_launch_status();
   }

@@ -19,3 +19,14 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / reps
 print("P=%d K=%d N=%d stats=%d: %.1f us/launch, %.2f TB/s algorithmic" % (P, K, N, stats, us, (P * K + P * N + N * K) * 2 / us / 1e6))
+if len(sys.argv) > 6 and sys.argv[6] == "trans":
+    Wt = torch.randn(K, N, device=dev).to(torch.bfloat16)
+    for _ in range(5):
+        fused_mlp.gemm(A, Wt, w_trans=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fused_mlp.gemm(A, Wt, w_trans=True)
+    e1.record()
+    torch.cuda.synchronize()
+    print("   w_trans: %.1f us/launch" % (e0.elapsed_time(e1) * 1e3 / reps))
