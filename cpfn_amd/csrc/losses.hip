@@ -413,6 +413,93 @@ inline int loss_chunks(int B, int N, int *ppb) {
   return (N + p - 1) / p;
 }
 
+// ------------------------------------------------------------------------------------ P coverage (evaluation)
+// compute_P_coverage (SPFN/metric_implementation.py:409-415): for every point of the cloud the residue against
+// EVERY instance slot k (prediction matching[b,k], evaluated as the primitive type type_of_slot[b,k]), the minimum
+// over k, and the fraction of points below each epsilon.  The reference expands P to [B,K,N,3] and evaluates all
+// four residue formulas for every (k, n) ([B,K,N,4]: 77 MB at one 131072-point cloud with K = 49); here one lane
+// per point walks the K slots with the slot parameters in LDS.
+// residue value only (no tangents): the same formulas as residue_of above
+__device__ inline float sqrt_safe_f(float x) { return sqrtf(fabsf(x) + 1e-10f); }   // metric_implementation.py:65-66
+__device__ inline float residue_value(int kind, const float *q, float px, float py, float pz) {
+  if (kind == 0) {
+    const float e = px * q[0] + py * q[1] + pz * q[2] - q[3];
+    return e * e;
+  } else if (kind == 1) {
+    const float dx = px - q[0], dy = py - q[1], dz = pz - q[2];
+    const float e = sqrt_safe_f(dx * dx + dy * dy + dz * dz) - sqrt_safe_f(q[3]);
+    return e * e;
+  } else if (kind == 2) {
+    const float dx = px - q[3], dy = py - q[4], dz = pz - q[5];
+    const float al = dx * q[0] + dy * q[1] + dz * q[2];
+    const float e = sqrt_safe_f(dx * dx + dy * dy + dz * dz - al * al) - sqrt_safe_f(q[6]);
+    return e * e;
+  } else {
+    const float vx = px - q[0], vy = py - q[1], vz = pz - q[2];
+    const float n2 = vx * vx + vy * vy + vz * vz;
+    const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
+    float c = (vx * q[3] + vy * q[4] + vz * q[5]) * inv;
+    const float lim = 1.0f - 1e-6f;
+    c = fminf(fmaxf(c, -lim), lim);
+    const float ad = fabsf(acosf(c) - q[6]);
+    const float sn = sinf(fminf(ad, 1.57079632679f));
+    return sn * sn * n2;
+  }
+}
+
+constexpr int PC_MAXEPS = 4;
+struct PcEps { float e[PC_MAXEPS]; };
+// partial[b][chunk][n_eps] = number of points of the chunk with min_k sqrt_safe(residue) < eps
+__global__ __launch_bounds__(256) void p_coverage_kernel(const float *__restrict__ P, const float *__restrict__ params,
+                                                         const long long *__restrict__ match,
+                                                         const long long *__restrict__ slot_type, int N, int K,
+                                                         int tid_plane, int tid_sphere, int tid_cyl, PcEps eps, int n_eps,
+                                                         float *__restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float s_q[64][8];
+  __shared__ int s_kind[64];
+  __shared__ float s_cnt[4][PC_MAXEPS];
+  const int b = blockIdx.y, t = threadIdx.x;
+  for (int k = t; k < K; k += 256) {
+    const long long m = match[(size_t)b * K + k], ty = slot_type[(size_t)b * K + k];
+    const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
+    const float *P22 = params + ((size_t)b * K + m) * 22;
+    const int off = kind == 0 ? 0 : (kind == 1 ? 4 : (kind == 2 ? 8 : 15));
+    const int nq = kind == 0 ? 4 : (kind == 1 ? 4 : 7);
+    for (int i = 0; i < 8; ++i) s_q[k][i] = i < nq ? P22[off + i] : 0.f;
+    s_kind[k] = kind;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + t;
+  float cnt[PC_MAXEPS] = {0, 0, 0, 0};
+  if (n < N) {
+    const float *p = P + ((size_t)b * N + n) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    float best = INFINITY;
+    for (int k = 0; k < K; ++k) {
+      const cpfn_f32x4 q0 = cpfn_lds_read4(&s_q[k][0]), q1 = cpfn_lds_read4(&s_q[k][4]);   // never a 96-bit LDS read
+      const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      best = fminf(best, sqrt_safe_f(residue_value(s_kind[k], q, px, py, pz)));
+    }
+    for (int i = 0; i < PC_MAXEPS; ++i) cnt[i] = (i < n_eps && best < eps.e[i]) ? 1.f : 0.f;
+  }
+  for (int i = 0; i < PC_MAXEPS; ++i)
+    for (int msk = 32; msk >= 1; msk >>= 1) cnt[i] += __shfl_xor(cnt[i], msk, 64);
+  if ((t & 63) == 0)
+    for (int i = 0; i < PC_MAXEPS; ++i) s_cnt[t >> 6][i] = cnt[i];
+  __syncthreads();
+  if (t < n_eps) partial[((size_t)b * gridDim.x + blockIdx.x) * n_eps + t] = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+}
+
+__global__ void p_coverage_reduce_kernel(const float *__restrict__ partial, int chunks, int n_eps, int N, int total,
+                                         float *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // (b, eps)
+  if (e >= total) return;
+  const int b = e / n_eps, i = e - b * n_eps;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += partial[((size_t)b * chunks + c) * n_eps + i];
+  out[e] = (float)(s / (double)N);
+}
+
 // ------------------------------------------------------------------------------------ assignment
 // The reference solves one linear assignment per cloud on the HOST (losses_implementation.py:19-29:
 // scipy.optimize.linear_sum_assignment(-cost) on the relaxed-IoU matrix of the n_gt GT instances against the K
@@ -673,5 +760,21 @@ extern "C" int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, 
   if (B < 0 || K <= 0 || K > MAXK || !S || !n_gt || !match) return CPFN_EINVAL;
   if (B == 0) return 0;
   lsap_kernel<<<B, 64, 0, (hipStream_t)stream>>>(S, (const long long *)n_gt, K, (long long *)match);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_p_coverage(const float *P, const float *params22, const int64_t *match, const int64_t *slot_type, int B,
+                               int N, int K, const int *type_ids, const float *eps, int n_eps, float *workspace, float *out,
+                               void *stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || K > 64 || n_eps <= 0 || n_eps > PC_MAXEPS || !P || !params22 || !match || !slot_type ||
+      !type_ids || !eps || !workspace || !out)
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  PcEps pe;
+  for (int i = 0; i < PC_MAXEPS; ++i) pe.e[i] = i < n_eps ? eps[i] : 0.f;
+  const int chunks = cpfn_cdiv(N, 256);
+  p_coverage_kernel<<<dim3(chunks, B), 256, 0, st>>>(P, params22, (const long long *)match, (const long long *)slot_type, N, K,
+                                                     type_ids[0], type_ids[1], type_ids[2], pe, n_eps, workspace);
+  p_coverage_reduce_kernel<<<cpfn_cdiv(B * n_eps, 64), 64, 0, st>>>(workspace, chunks, n_eps, N, B * n_eps, out);
   return cpfn_launch_status();
 }

@@ -29,6 +29,7 @@ _ALIASES = {
     "SPFN.sphere_fitter": "cpfn_amd.SPFN.sphere_fitter",
     "SPFN.cylinder_fitter": "cpfn_amd.SPFN.cylinder_fitter",
     "SPFN.cone_fitter": "cpfn_amd.SPFN.cone_fitter",
+    "SPFN.metric_implementation": "cpfn_amd.SPFN.metric_implementation",
     "SPFN.geometry_utils": "cpfn_amd.SPFN.geometry_utils",
     "SPFN.differentiable_tls": "cpfn_amd.SPFN.differentiable_tls",
 }

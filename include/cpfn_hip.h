@@ -321,6 +321,15 @@ CPFN_API int cpfn_residue_bwd(const float *gout, const float *dout, const int64_
  * breaking, hence the same matching.  K <= 32.  Costs must be finite (SciPy raises on NaN/inf). */
 CPFN_API int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, int K, int64_t *match,
                                   void *stream);
+/* Evaluation metric "P coverage" (SPFN/metric_implementation.py:409-415): out[b, i] = fraction of the N
+ * points of cloud b whose smallest residue over the K instance slots is below eps[i]; slot k uses the
+ * parameters of prediction match[b,k] (params22 in the cpfn_fit_pack_fwd layout) evaluated as primitive
+ * type slot_type[b,k]; residue = sqrt(|r| + 1e-10) of the fitters' compute_residue_single.
+ * type_ids (HOST, 4 ints) = ids of plane, sphere, cylinder, cone; eps (HOST) n_eps <= 4 thresholds; K <= 64.
+ * workspace: B * ceil(N/256) * n_eps floats. */
+CPFN_API int cpfn_p_coverage(const float *P, const float *params22, const int64_t *match,
+                             const int64_t *slot_type, int B, int N, int K, const int *type_ids,
+                             const float *eps, int n_eps, float *workspace, float *out, void *stream);
 /* The [B,K]-sized tail of compute_all_losses (SPFN/losses_implementation.py:77-90, 603-606, 633-673)
  * in one launch: relaxed IoU of the matched pairs from S[B,K+2,K] (cpfn_seg_stats_fwd), masked means
  * over the n_gt[b] existing instances of that and of rp[B,K,2] (cpfn_residue_fwd; may be NULL), batch

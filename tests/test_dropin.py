@@ -11,7 +11,7 @@ def test_install_aliases_reference_import_paths():
         from PointNet2 import pn2_network
         from PointNet2.pointnet2_ops import cuda_ops
         from PointNet2.pointnet2_ops.modules import geometry_utils
-        from SPFN import fitter_factory, losses_implementation, plane_fitter
+        from SPFN import fitter_factory, losses_implementation, metric_implementation, plane_fitter
         assert pn2_network.__name__ == "cpfn_amd.PointNet2.pn2_network"
         # the nine bound functions of cuda_ops/src/bindings.cpp:6-19
         for name in ("gather_points", "gather_points_grad", "farthest_point_sampling", "three_nn",
@@ -24,6 +24,12 @@ def test_install_aliases_reference_import_paths():
         assert "fast" in inspect.signature(geometry_utils.ball_query).parameters
         assert list(inspect.signature(losses_implementation.compute_all_losses).parameters)[:9] == [
             "P", "W", "I_gt", "X", "X_gt", "T", "T_gt", "gt_parameters", "points_per_instance"]
+        assert list(inspect.signature(metric_implementation.compute_all_metrics).parameters) == [
+            "P", "X", "X_gt", "W", "I_gt", "T", "T_gt", "points_per_instance", "gt_parameters", "list_epsilon", "classes"]
+        for fn in ("hungarian_matching", "hard_W_encoding", "get_instance_type", "get_residual_loss", "compute_segmentation_iou",
+                   "compute_type_accuracy", "compute_normal_difference", "compute_axis_difference",
+                   "compute_meanstd_Sk_residual", "compute_Sk_coverage", "compute_P_coverage"):
+            assert callable(getattr(metric_implementation, fn)), fn
         for fn in ("compute_parameters", "compute_residue_single", "compute_parameter_loss"):
             assert callable(getattr(plane_fitter, fn))
         fitter_factory.register_primitives(["sphere", "plane", "cylinder", "cone"])

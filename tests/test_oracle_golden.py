@@ -166,3 +166,20 @@ def test_lsap_matches_scipy():
             assert np.array_equal(got, want), (trial, sign, c, got, want)
             n_checked += 1
     assert n_checked == 1200
+
+
+def test_metrics_oracle_matches_reference_fixture(golden):
+    """oracle/metrics.py against the reference's compute_all_metrics (fixture generated by importing it)."""
+    from oracle import metrics as om
+    g = golden("metrics_2x2048.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    gt = {k: t("gt_" + k) for k in ("plane_normal", "cylinder_axis", "cone_axis")}
+    out = om.compute_all_metrics(t("P"), t("X"), t("X_gt"), t("W"), t("I_gt"), t("T"), t("T_gt"), t("points_per_instance"),
+                                 gt, list_epsilon=[float(e) for e in g["epsilons"]])
+    assert np.array_equal(out["matching"].numpy(), g["matching"])
+    assert np.array_equal(out["T_instance"].numpy(), g["T_instance"])
+    for k in ("mIoU", "type_accuracy", "normal_difference", "axis_difference", "mean_residual", "std_residual"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=2e-4, atol=1e-6, err_msg=k)
+    # coverages are counts of points under a threshold: allow a handful of points to sit on the boundary
+    np.testing.assert_allclose(out["Sk_coverage"].numpy(), g["Sk_coverage"], atol=3.0 / 512)
+    np.testing.assert_allclose(out["P_coverage"].numpy(), g["P_coverage"], atol=3.0 / 2048)
