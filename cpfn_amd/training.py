@@ -117,6 +117,9 @@ class SPFNTrainer:
         if on_gpu and fused_adam is not False:
             from .optim import FlatAdam
             self.optimizer = FlatAdam(self.bucket, lr=init_learning_rate)
+        elif self.use_graphs:     # torch's optimizer inside a capture: fused + capturable, lr as a device tensor
+            self.optimizer = torch.optim.Adam(module.parameters(), lr=torch.tensor(float(init_learning_rate), device=self.bucket.flat.device),
+                                              fused=True, capturable=True)
         else:
             self.optimizer = torch.optim.Adam(module.parameters(), lr=init_learning_rate)
         self._graph, self._graph_warm = None, 0
