@@ -29,6 +29,18 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   return __builtin_bit_cast(unsigned short, (__bf16)f);  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 }
 
+// a' = relu(scale·a + shift) on eight consecutive channels of one point, rounded to bf16 exactly like
+// bn_relu_apply_kernel: lets a GEMM / weight-gradient kernel consume the PREVIOUS layer's pre-BN output directly
+// (the activated tensor is then never written or read).
+__device__ __forceinline__ bf16x8 bn_relu_frag(bf16x8 v, const float *sc, const float *sh) {
+  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+  const u16x8 u = __builtin_bit_cast(u16x8, v);
+  u16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(fmaxf(fmaf(sc[j], bf2f(u[j]), sh[j]), 0.f));
+  return __builtin_bit_cast(bf16x8, o);
+}
+
 constexpr int G_THREADS = 256;
 constexpr int G_ROWS = 128;   // points per workgroup tile (4 waves x 32)
 constexpr int G_KC = 128;     // K chunk staged in LDS
@@ -51,9 +63,8 @@ constexpr int G_LDO = 128 + 8;  // output staging row stride (elements): 272 B
 // Fill the LDS weight panel s_w[r][k] (r = output channel n0+r, k in [kc, kc+kcn)).
 // w_trans == 0: W is [N,K] row-major (16-byte loads along k).
 // w_trans == 1: W is [K,N] row-major (the FORWARD layer's weight used for the data gradient): 16-byte
-//               loads along n, transposed on the way into LDS with 2-byte writes — the panel is at most
-//               64 KB and filled once per workgroup (or per K chunk), so the slow writes do not matter,
-//               and no transposed weight copy has to be materialised per step.
+//               loads along n, transposed on the way into LDS (8-byte pieces, see below), so no transposed
+//               weight copy has to be materialised per step.
 template <int BN, int LDW = G_LDW>
 __device__ __forceinline__ void fill_w_panel(unsigned short *s_w, const unsigned short *__restrict__ W, int K,
                                              int N, int n0, int kc, int kcn, int w_trans, int t) {
@@ -112,13 +123,29 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int BN, int KS, bool STATS>
-__device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const unsigned short *s_w,
+template <int BN, int KS, bool STATS, bool ATR>
+__device__ __forceinline__ void stream_tile(const bf16x8 (&af_raw)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
                                             int row0, int n0, int wave, int lane, f32x4 (&st_s)[BN / 16],
-                                            f32x4 (&st_q)[BN / 16]) {
+                                            f32x4 (&st_q)[BN / 16], const float *s_ss /*[2][32*KS]: scale, shift*/) {
   constexpr int NT = BN / 16;
   const int lr = lane & 15, lq = lane >> 4;
+  bf16x8 af[2][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ATR) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
+      float sc[8], sh[8];
+      *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[ks * 32 + 8 * lq];
+      *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[ks * 32 + 8 * lq + 4];
+      *(cpfn_f32x4 *)&sh[0] = *(const cpfn_f32x4 *)&s_ss[32 * KS + ks * 32 + 8 * lq];
+      *(cpfn_f32x4 *)&sh[4] = *(const cpfn_f32x4 *)&s_ss[32 * KS + ks * 32 + 8 * lq + 4];
+      af[0][ks] = bn_relu_frag(af_raw[0][ks], sc, sh);
+      af[1][ks] = bn_relu_frag(af_raw[1][ks], sc, sh);
+    } else {
+      af[0][ks] = af_raw[0][ks];
+      af[1][ks] = af_raw[1][ks];
+    }
+  }
   f32x4 acc[NT][2];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
@@ -166,17 +193,22 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af)[2][KS], const uns
   }
 }
 
-template <int BN, int KS, bool STATS>
+template <int BN, int KS, bool STATS, bool ATR = false>
 __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
-    unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg) {
+    unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
+    const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr) {
   constexpr int NT = BN / 16, K = 32 * KS;
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
   __shared__ __attribute__((aligned(16))) unsigned short s_o[4][32 * G_LDO];
   __shared__ __attribute__((aligned(16))) float s_red[4][2][BN];
+  __shared__ __attribute__((aligned(16))) float s_ss[ATR ? 2 * K : 4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
+  if (ATR) {   // visible after the W-panel barrier
+    for (int e = t; e < K; e += G_THREADS) { s_ss[e] = a_scale[e]; s_ss[K + e] = a_shift[e]; }
+  }
   f32x4 st_s[NT], st_q[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { st_s[i] = (f32x4){0, 0, 0, 0}; st_q[i] = (f32x4){0, 0, 0, 0}; }
@@ -191,10 +223,10 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
     for (int tile = tile0; tile < tile_end; tile += 2) {
       // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
       stream_load_a<KS>(a1, A, lda, P, min(tile + 1, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q);
+      stream_tile<BN, KS, STATS, ATR>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss);
       if (tile + 1 >= tile_end) break;
       stream_load_a<KS>(a0, A, lda, P, min(tile + 2, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q);
+      stream_tile<BN, KS, STATS, ATR>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q, s_ss);
     }
   }
   if (STATS) {
@@ -221,7 +253,8 @@ template <int BN, bool STATS>
 __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const int *__restrict__ gidx,
     const unsigned short *__restrict__ W, int w_trans, int P, int K, int N, void *__restrict__ Y, int ldy, int y_f32,
-    int n_store, const float *__restrict__ bias, float *__restrict__ stats_partial, int tiles_per_wg) {
+    int n_store, const float *__restrict__ bias, float *__restrict__ stats_partial, int tiles_per_wg,
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift) {
   constexpr int NT = BN / 16;
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
   __shared__ float s_red[4][2][BN];
@@ -262,6 +295,18 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
         fill_w_panel<BN>(s_w, W, K, N, n0, kc, kcn, w_trans, t);
         __syncthreads();
         w_loaded = true;
+      }
+      if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          if (ks * 32 < kcn) {
+            float sc[8], sh[8];
+            const int k0 = kc + ks * 32 + 8 * lq;
+            *(float4 *)&sc[0] = *(const float4 *)(a_scale + k0); *(float4 *)&sc[4] = *(const float4 *)(a_scale + k0 + 4);
+            *(float4 *)&sh[0] = *(const float4 *)(a_shift + k0); *(float4 *)&sh[4] = *(const float4 *)(a_shift + k0 + 4);
+            af[0][ks] = bn_relu_frag(af[0][ks], sc, sh);
+            af[1][ks] = bn_relu_frag(af[1][ks], sc, sh);
+          }
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -686,7 +731,9 @@ template <int TN, int TK>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
                                                         const unsigned short *__restrict__ A, int lda,
                                                         const int *__restrict__ gidx, long long P, int N, int K,
-                                                        long long rows_per_split, float *__restrict__ partial) {
+                                                        long long rows_per_split, float *__restrict__ partial,
+                                                        const float *__restrict__ a_scale,
+                                                        const float *__restrict__ a_shift) {
   constexpr int LDN = TN + 8, LDK = TK + 8;       // LDS row strides (elements)
   constexpr int CG = TN / 64, CA = TK / 64;       // 16-byte chunks per thread and step
   constexpr int MI = TN / 32, MJ = TK / 32;       // MFMA tiles per wave (wave sub-tile = TN/2 x TK/2)
@@ -711,6 +758,16 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
   // chunk c = t + 256 i of a step: row c / (T/8), column 8 (c % (T/8))
   uint4 vg[WG_DEPTH][CG], va[WG_DEPTH][CA];
+  // optional BatchNorm + ReLU of the PREVIOUS layer on the A operand (a lane's chunk columns never change)
+  float asc[CA][8], ash[CA][8];
+  if (a_scale) {
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int col = min(k0 + ((t + 256 * i) % (TK / 8)) * 8, K - 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { asc[i][j] = a_scale[col + j]; ash[i][j] = a_shift[col + j]; }
+    }
+  }
   auto issue = [&](int sidx, long long base) {
 #pragma unroll
     for (int i = 0; i < CG; ++i) {
@@ -739,6 +796,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
     for (int i = 0; i < CA; ++i) {
       const int c = t + 256 * i, r = c / (TK / 8), col = (c % (TK / 8)) * 8;
       uint4 v = va[sidx][i];
+      if (a_scale) v = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, v), asc[i], ash[i]));
       if (base + r >= p1 || k0 + col >= K) v = (uint4){0, 0, 0, 0};
       *(uint4 *)&s_a[r * LDK + col] = v;
     }
@@ -956,8 +1014,9 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
 
 extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P, int K,
                              int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
-                             float *stats_partial, void *stream) {
-  if (P < 0 || K <= 0 || (K & 31) || N <= 0 || (N & 63) || !A || !W || !Y || lda < K || (lda & 7)) return CPFN_EINVAL;
+                             float *stats_partial, const float *a_scale, const float *a_shift, void *stream) {
+  if (P < 0 || K <= 0 || (K & 31) || N <= 0 || (N & 63) || !A || !W || !Y || lda < K || (lda & 7) || (!a_scale != !a_shift))
+    return CPFN_EINVAL;
   if (P == 0) return 0;
   if (P > 2000000000LL) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -968,13 +1027,16 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   // whole-K panel in LDS: K <= 256.  K = 192 / 256 only for the long layers: with few row tiles the 50-68 KB panel
   // (cold in a real step, unlike in a micro-benchmark loop) costs more than the generic kernel's 128-wide K chunks
   const bool stream_k = K == 64 || K == 128 || ((K == 192 || K == 256) && P >= 32768);
-  const bool stream_ok = stream_k && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0;
+  // (the operand transform exists in the stream kernel only next to the BN statistics: forward layers)
+  const bool stream_ok = stream_k && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0 && (!a_scale || stats_partial);
   if (stream_ok) {
     unsigned short *y = (unsigned short *)Y;
 #define CPFN_STREAM(BN_, KS_)                                                                                        \
   do {                                                                                                               \
     dim3 grid(gx, N / BN_);                                                                                          \
-    if (stats_partial)                                                                                               \
+    if (stats_partial && a_scale)                                                                                    \
+      mlp_gemm_stream_kernel<BN_, KS_, true, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift); \
+    else if (stats_partial)                                                                                          \
       mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw); \
     else                                                                                                             \
       mlp_gemm_stream_kernel<BN_, KS_, false><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, nullptr, tpw);      \
@@ -994,15 +1056,15 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   if (wide) {
     dim3 grid(gx, N / 128);
     if (stats_partial)
-      mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
+      mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw, a_scale, a_shift);
     else
-      mlp_gemm_kernel<128, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
+      mlp_gemm_kernel<128, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw, a_scale, a_shift);
   } else {
     dim3 grid(gx, N / 64);
     if (stats_partial)
-      mlp_gemm_kernel<64, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw);
+      mlp_gemm_kernel<64, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw, a_scale, a_shift);
     else
-      mlp_gemm_kernel<64, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw);
+      mlp_gemm_kernel<64, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw, a_scale, a_shift);
   }
   return cpfn_launch_status();
 }
@@ -1115,8 +1177,10 @@ extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
 }
 
 extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P, int N,
-                              int K, float *workspace, float *dW, void *stream) {
-  if (P <= 0 || N <= 0 || K < 8 || (N & 63) || (K & 31) || !Gy || !A || !workspace || !dW || (ldg & 7) || (lda & 7))
+                              int K, const float *a_scale, const float *a_shift, float *workspace, float *dW,
+                              void *stream) {
+  if (P <= 0 || N <= 0 || K < 8 || (N & 63) || (K & 31) || !Gy || !A || !workspace || !dW || (ldg & 7) || (lda & 7) ||
+      (!a_scale != !a_shift))
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int splits = cpfn_mlp_wgrad_splits(P, N, K);
@@ -1125,10 +1189,10 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
   const unsigned short *g = (const unsigned short *)Gy, *a = (const unsigned short *)A;
   if (wgrad_tile(P, N, K) == 128) {
     dim3 grid(N / 128, (K + 127) / 128, splits);
-    mlp_wgrad_kernel<128, 128><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace);
+    mlp_wgrad_kernel<128, 128><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
   } else {
     dim3 grid(N / 64, (K + 63) / 64, splits);
-    mlp_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace);
+    mlp_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
   }
   const long long n = (long long)N * K;
   launch_split_reduce(workspace, splits, n, dW, st);

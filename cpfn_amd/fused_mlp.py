@@ -28,6 +28,9 @@ from .ops import _ptr, _stream
 
 BF16 = torch.bfloat16
 BN_NOSTORE = os.environ.get("CPFN_BN_NOSTORE", "1") == "1"
+# BN + ReLU of a hidden layer applied on the operand load of the NEXT layer's GEMM and of its weight gradient
+# (the activated tensor of a hidden layer is then never written or read).  CPFN_BN_APPLY_FUSED=0 materialises it.
+BN_APPLY_FUSED = os.environ.get("CPFN_BN_APPLY_FUSED", "1") == "1"
 
 
 def _pad_to(n, m):
@@ -39,9 +42,12 @@ def _check(status, what):
 
 
 # ------------------------------------------------------------------ thin launch wrappers
-def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_store=None, P=None, w_trans=False):
+def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_store=None, P=None, w_trans=False,
+         a_scale=None, a_shift=None):
     """A [P,K] bf16 (row stride = A.stride(0)), Wb [N,K] bf16 -> Y [P, n_store] (bf16 | fp32).
-    w_trans: Wb is [K,N] (a forward weight used for the data gradient; transposed inside the kernel)."""
+    w_trans: Wb is [K,N] (a forward weight used for the data gradient; transposed inside the kernel).
+    a_scale / a_shift [K] fp32: A is the previous layer's pre-BN output; relu(a_scale*A + a_shift) is applied to
+    the operand on the fly."""
     h = _l.lib()
     K, N = (Wb.shape[0], Wb.shape[1]) if w_trans else (Wb.shape[1], Wb.shape[0])
     P = (gidx.numel() if gidx is not None else A.shape[0]) if P is None else P
@@ -53,7 +59,7 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
         nblk = h.cpfn_mlp_gemm_blocks(P, N)
         part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
     _check(h.cpfn_mlp_gemm(_ptr(A), A.stride(0), _ptr(gidx), _ptr(Wb), 1 if w_trans else 0, P, K, N, _ptr(Y), n_store, 1 if out_f32 else 0,
-                           n_store, _ptr(bias), _ptr(part), _stream()), "cpfn_mlp_gemm")
+                           n_store, _ptr(bias), _ptr(part), _ptr(a_scale), _ptr(a_shift), _stream()), "cpfn_mlp_gemm")
     # algorithmic traffic of this launch: read A and W once, write Y once (+ the stats partials)
     _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + Y.element_size() * P * n_store + (8 * nblk * N if stats else 0))
     return Y, part, nblk
@@ -193,6 +199,7 @@ class _FusedStack(torch.autograd.Function):
         dev = x.device
         saved = []
         a = x
+        a_ss = None                      # (scale, shift) when `a` is the previous layer's raw pre-BN output
         out = None
         with torch.cuda.device(dev):
             for li, L in enumerate(layers):
@@ -210,7 +217,10 @@ class _FusedStack(torch.autograd.Function):
                 else:
                     Kp = a.shape[1]
                     Wb = bf16_weight(L.weight, N, Kp)
-                    Y, part, nblk = gemm(a, Wb, stats=True)
+                    if a_ss is None:
+                        Y, part, nblk = gemm(a, Wb, stats=True)
+                    else:
+                        Y, part, nblk = gemm(a, Wb, stats=True, a_scale=a_ss[0], a_shift=a_ss[1])
                 if L.training:
                     st = bn_finalize(part, nblk, N, P, L.gamma.detach(), L.beta.detach(),
                                      None if L.bias is None else L.bias.detach(), L.eps, L.momentum, L.rm, L.rv)
@@ -222,12 +232,15 @@ class _FusedStack(torch.autograd.Function):
                 last = li == len(layers) - 1
                 if last and pool_k:
                     out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)
-                    saved.append((a, Y, st, Wb, arg, yarg))
-                else:
+                    saved.append((a, a_ss, Y, st, Wb, arg, yarg))
+                elif last or not BN_APPLY_FUSED:
                     nxt = bn_relu_apply(Y, st[0], st[1])
-                    saved.append((a, Y, st, Wb, None, None))
-                    a = nxt
+                    saved.append((a, a_ss, Y, st, Wb, None, None))
+                    a, a_ss = nxt, None
                     out = nxt
+                else:       # hidden layer: the next GEMM (and its weight gradient) apply BN + ReLU while loading Y
+                    saved.append((a, a_ss, Y, st, Wb, None, None))
+                    a, a_ss = Y, (st[0], st[1])
         ctx.cfg = cfg
         ctx.saved = saved
         ctx.P = P
@@ -250,7 +263,7 @@ class _FusedStack(torch.autograd.Function):
         with torch.cuda.device(dev):
             for li in range(len(layers) - 1, -1, -1):
                 L = layers[li]
-                a_in, Y, st, Wb, arg, yarg = saved[li]
+                a_in, a_ss, Y, st, Wb, arg, yarg = saved[li]
                 N = L.cout
                 dgb = torch.empty(2, N, dtype=torch.float32, device=dev)
                 coef = torch.empty(3, N, dtype=torch.float32, device=dev)
@@ -303,8 +316,9 @@ class _FusedStack(torch.autograd.Function):
                     splits = h.cpfn_mlp_wgrad_splits(P, N, Kp)
                     ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
                     dW = torch.empty(N, Kp, dtype=torch.float32, device=dev)
-                    _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp, _ptr(ws), _ptr(dW), _stream()),
-                           "cpfn_mlp_wgrad")
+                    _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
+                                            None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
+                                            _ptr(ws), _ptr(dW), _stream()), "cpfn_mlp_wgrad")
                     grads[3 * li] = dW[:, :L.cin].reshape(wshape)
                     if li > 0 or ctx.x_needs_grad:
                         g, _, _ = gemm(Gy, Wb, w_trans=True)            # G_y [P,N] · W [N,Kp]
@@ -354,7 +368,7 @@ class _Linear(torch.autograd.Function):
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
             dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
-            _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, _ptr(ws), _ptr(dW), _stream()),
+            _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), _ptr(dW), _stream()),
                    "cpfn_mlp_wgrad")
             ga, _, _ = gemm(gb, Wb, w_trans=True)
         # bias gradient = column sums of g (torch's strided reduce: 0.66 ms, rocBLAS gemv: 0.8 ms for [131072,35])

@@ -51,7 +51,7 @@ SIGNATURES = {
     "cpfn_loss_tail": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_eigh3": [_vp, _i64, _vp, _vp, _vp],
     "cpfn_mlp_gemm_blocks": [_ll, _i],
-    "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_bn_relu_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp],
     "cpfn_bn_relu_maxpool": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -61,7 +61,7 @@ SIGNATURES = {
     "cpfn_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp],
     "cpfn_bn_pool_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "cpfn_mlp_wgrad_splits": [_ll, _i, _i],
-    "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp],
+    "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_colsum_f32": [_vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_fwd": [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad": [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp],

@@ -224,11 +224,14 @@ CPFN_API int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, voi
  * w_trans = 1: W is stored [K,N] instead (the forward layer's weight, used as is for the data gradient).
  * gidx (optional): row p of A is A[gidx[p]] (fused neighbour gather).
  * y_f32 = 0: Y is bf16 with row stride ldy; 1: fp32.  Only channels < n_store are stored.
- * stats_partial (optional): [cpfn_mlp_gemm_blocks(P,N)][2][N] fp32 per-block sum(y), sum(y^2). */
+ * stats_partial (optional): [cpfn_mlp_gemm_blocks(P,N)][2][N] fp32 per-block sum(y), sum(y^2).
+ * a_scale, a_shift (optional, [K] fp32, both or neither): A holds the PREVIOUS layer's pre-BN output and
+ * the operand is relu(a_scale*A + a_shift) rounded to bf16, applied on the fly (bit-identical to
+ * cpfn_bn_relu_apply followed by a plain call; the activated tensor is never materialised). */
 CPFN_API int cpfn_mlp_gemm_blocks(long long P, int N);
 CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
-                           float *stats_partial, void *stream);
+                           float *stats_partial, const float *a_scale, const float *a_shift, void *stream);
 /* Batch statistics -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update with
  * torch's momentum / unbiased-variance convention; conv_bias re-enters the running mean). */
 CPFN_API int cpfn_bn_finalize(const float *partial, int nblk, int N, float count, const float *gamma,
@@ -259,10 +262,12 @@ CPFN_API int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef,
 CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, const void *yarg,
                                     const void *Y, const float *scale, const float *shift,
                                     const float *coef, int G, int Kn, int C, void *Gy, void *stream);
-/* dW[N,K] (fp32) = Gy[P,N]^T . A[P,K]; workspace: cpfn_mlp_wgrad_splits(P,N,K)*N*K floats. */
+/* dW[N,K] (fp32) = Gy[P,N]^T . A[P,K]; workspace: cpfn_mlp_wgrad_splits(P,N,K)*N*K floats.
+ * a_scale, a_shift (optional): as in cpfn_mlp_gemm, A = relu(a_scale*A + a_shift) on the fly. */
 CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
-                            int N, int K, float *workspace, float *dW, void *stream);
+                            int N, int K, const float *a_scale, const float *a_shift, float *workspace,
+                            float *dW, void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
  * workspace: ceil(P/256)*C floats. */
 CPFN_API int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out,

@@ -28,7 +28,7 @@ def _setup():
 
     def wgrad(n):
         for _ in range(n):
-            rc = h.cpfn_mlp_wgrad(Y.data_ptr(), 128, Y.data_ptr(), 128, None, 131072, 128, 128, ws.data_ptr(), dW.data_ptr(),
+            rc = h.cpfn_mlp_wgrad(Y.data_ptr(), 128, Y.data_ptr(), 128, None, 131072, 128, 128, None, None, ws.data_ptr(), dW.data_ptr(),
                                   torch.cuda.current_stream().cuda_stream)
             assert rc == 0
     return ops, P1, P2, start, wgrad

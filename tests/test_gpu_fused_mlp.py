@@ -122,6 +122,34 @@ def test_fused_stack_matches_fp32_reference(name, P, cin, widths, pool_k, use_xy
         assert _rel(rm, rm_r) < 1e-2 and _rel(rv, rv_r) < 1e-2
 
 
+@pytest.mark.parametrize("name,P,cin,widths,pool_k,use_xyz", [
+    ("sa1-like", 2 * 40 * 16, 3, [64, 64, 128], 16, True),
+    ("sa3-like", 3 * 128, 259, [256, 512, 1024], 128, False),
+    ("sfp3-like", 40000 + 77, 128, [128, 128, 128], None, False),
+    ("k192-k256", 33000, 192, [256, 128], None, False),
+])
+def test_bn_apply_on_operand_load_is_bit_identical(name, P, cin, widths, pool_k, use_xyz, monkeypatch):
+    """BN + ReLU of a hidden layer applied on the operand load of the next GEMM and of its weight gradient
+    (default) against the variant that materialises the activated tensor: same bits, forward and backward."""
+    from cpfn_amd import fused_mlp
+    convs, bns = _stack(cin, widths, seed=7)
+    g = torch.Generator().manual_seed(P)
+    xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev()) if use_xyz else None
+    x = None if use_xyz else torch.randn(P, cin, generator=g).to(dev())
+    gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(fused_mlp, "BN_APPLY_FUSED", fused)
+        res[fused] = _run(x, convs, bns, torch.bfloat16, pool_k, xyz, gout)
+    (ya, gxa, gra, sta), (yb, gxb, grb, stb) = res[True], res[False]
+    assert torch.equal(ya, yb)
+    assert (gxa is None and gxb is None) or torch.equal(gxa, gxb)
+    for a, b in zip(gra, grb):
+        assert (a is None and b is None) or torch.equal(a, b)
+    for (rm, rv), (rm_r, rv_r) in zip(sta, stb):
+        assert torch.equal(rm, rm_r) and torch.equal(rv, rv_r)
+
+
 def test_heads_linear():
     from cpfn_amd import mlp
     torch.manual_seed(0)
