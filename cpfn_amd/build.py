@@ -73,6 +73,10 @@ def _compile(src, flags, force):
 # them when three of four floats of a 16-byte LDS element are used; the device assembly kept by
 # -save-temps is scanned after every compile so that a new one cannot slip in.
 _BANNED_ISA = re.compile(r"\bds_(read|write|load|store)_b96\b")
+# Scratch (private segment) is banned too, except where it is known and accepted: a dynamically indexed local
+# array silently moves to scratch memory and cost the Adam kernel 25 us per launch.
+_SCRATCH_OK = ("fit_algebra_fwd_kernel", "fit_algebra_bwd_kernel")
+_KERNEL_META = re.compile(r"\.name:\s+(\S+)\s*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)")
 
 
 def _check_isa(src):
@@ -83,11 +87,17 @@ def _check_isa(src):
     try:
         if not asm:
             raise RuntimeError("device assembly of %s not found under %s (needed for the ISA check)" % (src, OBJ))
-        hits = _BANNED_ISA.findall(open(os.path.join(OBJ, asm[0])).read())
+        text = open(os.path.join(OBJ, asm[0])).read()
+        hits = _BANNED_ISA.findall(text)
         if hits:
             os.remove(os.path.join(OBJ, stem + ".o"))
             raise RuntimeError("%s: %d banned 96-bit DS instruction(s) in the gfx950 code (see csrc/common.h, "
                                "cpfn_lds_read4)" % (src, len(hits)))
+        spilled = [(n, int(b)) for n, b in _KERNEL_META.findall(text) if int(b) > 0 and not any(k in n for k in _SCRATCH_OK)]
+        if spilled:
+            os.remove(os.path.join(OBJ, stem + ".o"))
+            raise RuntimeError("%s: kernels using scratch memory: %s (dynamically indexed local array or register "
+                               "spill; restructure, or add to _SCRATCH_OK with a reason)" % (src, spilled))
     finally:
         for f in temps:                      # -save-temps leaves ~8 MB per source; only the object is kept
             os.remove(os.path.join(OBJ, f))

@@ -60,6 +60,14 @@ constexpr int G_LDW = G_KC + 8;
 //    fp32 / ragged-N output: the small-P layers (sa3, sfp1, sfp2), K > 128, and the fc2 heads.
 constexpr int G_LDO = 128 + 8;  // output staging row stride (elements): 272 B
 
+// eight 16-bit elements rotated left by r positions (result[i] = v[(i + r) & 7]) without register indexing
+__device__ __forceinline__ uint4 rot_u16x8(uint4 v, int r) {
+  if (r & 4) v = (uint4){v.z, v.w, v.x, v.y};
+  if (r & 2) v = (uint4){v.y, v.z, v.w, v.x};
+  if (r & 1) v = (uint4){(v.x >> 16) | (v.y << 16), (v.y >> 16) | (v.z << 16), (v.z >> 16) | (v.w << 16), (v.w >> 16) | (v.x << 16)};
+  return v;
+}
+
 // Fill the LDS weight panel s_w[r][k] (r = output channel n0+r, k in [kc, kc+kcn)).
 // w_trans == 0: W is [N,K] row-major (16-byte loads along k).
 // w_trans == 1: W is [K,N] row-major (the FORWARD layer's weight used for the data gradient): 16-byte
@@ -86,14 +94,18 @@ __device__ __forceinline__ void fill_w_panel(unsigned short *s_w, const unsigned
       uint4 v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = *(const uint4 *)&W[(size_t)(kc + 4 * k4 + r) * N + n0 + c * 8];
+      // rotate the eight columns of every row vector by (c & 7) positions with whole-register selects — indexing
+      // the registers with a lane-dependent j would push them to scratch memory
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rot_u16x8(v[r], c & 7);
       const unsigned short *h0 = (const unsigned short *)&v[0], *h1 = (const unsigned short *)&v[1],
                            *h2 = (const unsigned short *)&v[2], *h3 = (const unsigned short *)&v[3];
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
-        const int j = (jj + c) & 7;
+        const int j = (jj + c) & 7;      // rotated position jj holds column j
         uint2 o;
-        o.x = (unsigned)h0[j] | ((unsigned)h1[j] << 16);
-        o.y = (unsigned)h2[j] | ((unsigned)h3[j] << 16);
+        o.x = (unsigned)h0[jj] | ((unsigned)h1[jj] << 16);
+        o.y = (unsigned)h2[jj] | ((unsigned)h3[jj] << 16);
         *(uint2 *)&s_w[(c * 8 + j) * LDW + 4 * k4] = o;
       }
     }
@@ -127,7 +139,8 @@ template <int BN, int KS, bool STATS, bool ATR>
 __device__ __forceinline__ void stream_tile(const bf16x8 (&af_raw)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
                                             int row0, int n0, int wave, int lane, f32x4 (&st_s)[BN / 16],
-                                            f32x4 (&st_q)[BN / 16], const float *s_ss /*[2][32*KS]: scale, shift*/) {
+                                            f32x4 (&st_q)[BN / 16], const float *s_ss /*[2][32*KS]: scale, shift*/,
+                                            float *s_stat /*[2][BN], this wave's (KS >= 6 only)*/) {
   constexpr int NT = BN / 16;
   const int lr = lane & 15, lq = lane >> 4;
   bf16x8 af[2][KS];
@@ -165,12 +178,25 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af_raw)[2][KS], const
     //   per-tile DPP sum + per-tile LDS read-modify-write   22.5 | 56.4   (the LDS round trips serialise)
     //   per-tile DPP sum, register accumulation             23.3 | 48.0
     //   per-lane sums, one DPP reduction at the end (this)  22.1 | 37.8
+    // (K = 192 / 256 variants: the two A-fragment buffers already take 96 / 128 registers and 64 more running sums
+    //  spill to scratch, so those reduce per tile into the wave's LDS accumulators instead.)
     const float m0 = (row0 + wave * 32 + lr < P) ? 1.f : 0.f, m1 = (row0 + wave * 32 + 16 + lr < P) ? 1.f : 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const f32x4 a = acc[nt][0] * m0, b = acc[nt][1] * m1;
-      st_s[nt] += a + b;
-      st_q[nt] += a * a + b * b;
+      if (KS <= 4) {
+        st_s[nt] += a + b;
+        st_q[nt] += a * a + b * b;
+      } else {
+        f32x4 sm = a + b, sq = a * a + b * b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
+        if (lr == 0) {
+          f32x4 *p0 = (f32x4 *)&s_stat[nt * 16 + 4 * lq], *p1 = (f32x4 *)&s_stat[BN + nt * 16 + 4 * lq];
+          *p0 = *p0 + sm;
+          *p1 = *p1 + sq;
+        }
+      }
     }
   }
 #pragma unroll
@@ -209,6 +235,9 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   if (ATR) {   // visible after the W-panel barrier
     for (int e = t; e < K; e += G_THREADS) { s_ss[e] = a_scale[e]; s_ss[K + e] = a_shift[e]; }
   }
+  if (STATS && KS > 4) {
+    for (int e = t; e < 4 * 2 * BN; e += G_THREADS) (&s_red[0][0][0])[e] = 0.f;   // visible after the W-panel barrier
+  }
   f32x4 st_s[NT], st_q[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { st_s[i] = (f32x4){0, 0, 0, 0}; st_q[i] = (f32x4){0, 0, 0, 0}; }
@@ -223,16 +252,16 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
     for (int tile = tile0; tile < tile_end; tile += 2) {
       // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
       stream_load_a<KS>(a1, A, lda, P, min(tile + 1, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS, ATR>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss);
+      stream_tile<BN, KS, STATS, ATR>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, &s_red[wave][0][0]);
       if (tile + 1 >= tile_end) break;
       stream_load_a<KS>(a0, A, lda, P, min(tile + 2, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS, ATR>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q, s_ss);
+      stream_tile<BN, KS, STATS, ATR>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, &s_red[wave][0][0]);
     }
   }
   if (STATS) {
     // once per workgroup: DPP sum over the 16 point lanes of a row, one lane per row writes 4 channels
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < (KS <= 4 ? NT : 0); ++nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { st_s[nt][r] = row16_sum(st_s[nt][r]); st_q[nt][r] = row16_sum(st_q[nt][r]); }
       if (lr == 0) {
@@ -859,6 +888,38 @@ __global__ __launch_bounds__(16 * RS) void split_reduce_kernel(const float *__re
   }
 }
 
+// The same fixed-order reduction for up to MSR_MAX partial buffers in ONE launch: the weight-gradient kernels of a
+// whole backward pass leave their split partials behind and are finished together at its end (19 launches of
+// ~7 us each, all latency, become one).  blockIdx -> (buffer, 64-element group) through prefix sums.
+constexpr int MSR_MAX = 32;
+struct MsrArgs {
+  const float *partial[MSR_MAX];
+  float *out[MSR_MAX];
+  long long n[MSR_MAX];
+  int splits[MSR_MAX];
+  int block0[MSR_MAX + 1];     // first workgroup of buffer i
+  int count;
+};
+__global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
+  // 64 consecutive elements x 4 split-subsets per workgroup: 256-byte coalesced rows of the partial buffers
+  __shared__ float s_acc[4][64];
+  int d = 0;
+  while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
+  const float *__restrict__ partial = a.partial[d];
+  const long long n = a.n[d];
+  const int splits = a.splits[d];
+  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+  const long long e = (long long)(blockIdx.x - a.block0[d]) * 64 + lane;
+  float acc = 0.f;
+  if (e < n) {
+#pragma unroll 4
+    for (int i = r; i < splits; i += 4) acc += partial[(size_t)i * n + e];
+  }
+  s_acc[r][lane] = acc;
+  __syncthreads();
+  if (r == 0 && e < n) a.out[d][e] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+}
+
 // ---------------------------------------------------------------- fp32 small-K first layer (sa1: K = 3)
 // Y[p,c] = Σ_{j<KS} W[c,j]·X[p,j]  (fp32 inputs: relative coordinates are NOT rounded to bf16),
 // bf16 output + Σy, Σy² partials.  One lane per (row-sub, 8-channel chunk).
@@ -1028,14 +1089,15 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   // (cold in a real step, unlike in a micro-benchmark loop) costs more than the generic kernel's 128-wide K chunks
   const bool stream_k = K == 64 || K == 128 || ((K == 192 || K == 256) && P >= 32768);
   // (the operand transform exists in the stream kernel only next to the BN statistics: forward layers)
-  const bool stream_ok = stream_k && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0 && (!a_scale || stats_partial);
+  const bool stream_ok = stream_k && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0 &&
+                         (!a_scale || (stats_partial && K <= 128));
   if (stream_ok) {
     unsigned short *y = (unsigned short *)Y;
 #define CPFN_STREAM(BN_, KS_)                                                                                        \
   do {                                                                                                               \
     dim3 grid(gx, N / BN_);                                                                                          \
     if (stats_partial && a_scale)                                                                                    \
-      mlp_gemm_stream_kernel<BN_, KS_, true, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift); \
+      mlp_gemm_stream_kernel<BN_, (KS_ <= 4 ? KS_ : 4), true, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift); \
     else if (stats_partial)                                                                                          \
       mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw); \
     else                                                                                                             \
@@ -1179,7 +1241,7 @@ extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
 extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P, int N,
                               int K, const float *a_scale, const float *a_shift, float *workspace, float *dW,
                               void *stream) {
-  if (P <= 0 || N <= 0 || K < 8 || (N & 63) || (K & 31) || !Gy || !A || !workspace || !dW || (ldg & 7) || (lda & 7) ||
+  if (P <= 0 || N <= 0 || K < 8 || (N & 63) || (K & 31) || !Gy || !A || !workspace || (ldg & 7) || (lda & 7) ||
       (!a_scale != !a_shift))
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1195,7 +1257,7 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
     mlp_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
   }
   const long long n = (long long)N * K;
-  launch_split_reduce(workspace, splits, n, dW, st);
+  if (dW) launch_split_reduce(workspace, splits, n, dW, st);    // NULL: the caller batches it (cpfn_multi_split_reduce)
   return cpfn_launch_status();
 }
 
@@ -1240,5 +1302,25 @@ extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *worksp
   const int nblk = (int)((P + CS_ROWS - 1) / CS_ROWS);
   colsum_f32_kernel<<<nblk, 256, 0, st>>>(X, P, C, workspace);
   launch_split_reduce(workspace, nblk, C, out, st);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count, void *stream) {
+  if (count < 0 || (count > 0 && !descs)) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < count; base += MSR_MAX) {
+    MsrArgs a;
+    a.count = count - base < MSR_MAX ? count - base : MSR_MAX;
+    int blocks = 0;
+    for (int i = 0; i < a.count; ++i) {
+      const cpfn_reduce_desc &d = descs[base + i];
+      if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0) return CPFN_EINVAL;
+      a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
+      a.block0[i] = blocks;
+      blocks += cpfn_cdiv(d.n, 64);
+    }
+    a.block0[a.count] = blocks;
+    if (blocks) multi_split_reduce_kernel<<<blocks, 256, 0, st>>>(a);
+  }
   return cpfn_launch_status();
 }

@@ -30,14 +30,20 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
   const float step_size = coef[0], bc2_sqrt = coef[1];
   const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= n) return;
-  float pv[4], gv[4], mv[4], vv[4];
-  const int cnt = (int)min(4LL, n - i0);
-  if (cnt == 4) {
-    *(float4 *)pv = *(const float4 *)(p + i0); *(float4 *)gv = *(const float4 *)(g + i0);
-    *(float4 *)mv = *(const float4 *)(m + i0); *(float4 *)vv = *(const float4 *)(v + i0);
+  // (no dynamically indexed local arrays: they would live in scratch memory and cost ~25 us per launch)
+  const bool full = i0 + 4 <= n;
+  float4 p4, g4, m4, v4;
+  if (full) {
+    p4 = *(const float4 *)(p + i0); g4 = *(const float4 *)(g + i0); m4 = *(const float4 *)(m + i0); v4 = *(const float4 *)(v + i0);
   } else {
-    for (int j = 0; j < cnt; ++j) { pv[j] = p[i0 + j]; gv[j] = g[i0 + j]; mv[j] = m[i0 + j]; vv[j] = v[i0 + j]; }
+    const long long i1 = i0 + 1, i2 = i0 + 2;
+    p4 = make_float4(p[i0], i1 < n ? p[i1] : 0.f, i2 < n ? p[i2] : 0.f, 0.f);
+    g4 = make_float4(g[i0], i1 < n ? g[i1] : 0.f, i2 < n ? g[i2] : 0.f, 0.f);
+    m4 = make_float4(m[i0], i1 < n ? m[i1] : 0.f, i2 < n ? m[i2] : 0.f, 0.f);
+    v4 = make_float4(v[i0], i1 < n ? v[i1] : 0.f, i2 < n ? v[i2] : 0.f, 0.f);
   }
+  float pv[4] = {p4.x, p4.y, p4.z, p4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w},
+        vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float gr = gv[j];
@@ -47,10 +53,14 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
     const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
     pv[j] = pv[j] - step_size * (mv[j] / denom);
   }
-  if (cnt == 4) {
-    *(float4 *)(p + i0) = *(const float4 *)pv; *(float4 *)(m + i0) = *(const float4 *)mv; *(float4 *)(v + i0) = *(const float4 *)vv;
+  if (full) {
+    *(float4 *)(p + i0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    *(float4 *)(m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *(float4 *)(v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
   } else {
-    for (int j = 0; j < cnt; ++j) { p[i0 + j] = pv[j]; m[i0 + j] = mv[j]; v[i0 + j] = vv[j]; }
+    p[i0] = pv[0]; m[i0] = mv[0]; v[i0] = vv[0];
+    if (i0 + 1 < n) { p[i0 + 1] = pv[1]; m[i0 + 1] = mv[1]; v[i0 + 1] = vv[1]; }
+    if (i0 + 2 < n) { p[i0 + 2] = pv[2]; m[i0 + 2] = mv[2]; v[i0 + 2] = vv[2]; }
   }
 }
 

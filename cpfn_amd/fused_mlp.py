@@ -18,6 +18,7 @@ The convolution bias is never added: training-mode batch-norm cancels it exactly
 re-enters the running mean), so its gradient is exactly zero rather than the reference's
 rounding noise.
 """
+import ctypes
 import os
 import weakref
 
@@ -90,6 +91,35 @@ def bn_relu_maxpool(Y, scale, shift, Kn):
     _check(_l.lib().cpfn_bn_relu_maxpool(_ptr(Y), _ptr(scale), _ptr(shift), G, Kn, C, _ptr(out), _ptr(arg), _ptr(yarg),
                                          _stream()), "cpfn_bn_relu_maxpool")
     return out, arg, yarg
+
+
+# ------------------------------------------------------------------ deferred split reductions
+# The weight-gradient kernels leave [splits][N*K] partials; finishing each with its own launch costs ~7 us of
+# pure latency, 19 times per backward pass.  They are queued instead and finished by ONE launch when the autograd
+# engine reaches the end of the backward pass (queue_callback), before anybody can read the gradients.
+class _ReduceDesc(ctypes.Structure):
+    _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_longlong), ("splits", ctypes.c_int)]
+
+
+_pending_reduce = []
+
+
+def _flush_reductions():
+    global _pending_reduce
+    todo, _pending_reduce = _pending_reduce, []
+    if not todo:
+        return
+    arr = (_ReduceDesc * len(todo))(*[_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits) for ws, out, n, splits in todo])
+    dev = todo[0][0].device
+    with torch.cuda.device(dev):
+        _check(_l.lib().cpfn_multi_split_reduce(arr, len(todo), _stream()), "cpfn_multi_split_reduce")
+
+
+def _defer_reduction(ws, out, n, splits):
+    """Queue `out[n] = sum over splits of ws[splits][n]`; runs at the end of the current backward pass."""
+    if not _pending_reduce:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
+    _pending_reduce.append((ws, out, n, splits))
 
 
 # ------------------------------------------------------------------ bf16 weight panels
@@ -318,7 +348,9 @@ class _FusedStack(torch.autograd.Function):
                     dW = torch.empty(N, Kp, dtype=torch.float32, device=dev)
                     _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
                                             None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
-                                            _ptr(ws), _ptr(dW), _stream()), "cpfn_mlp_wgrad")
+                                            _ptr(ws), _ptr(dW) if Kp != L.cin else None, _stream()), "cpfn_mlp_wgrad")
+                    if Kp == L.cin:       # (a zero-padded K needs dW right away: the slice below is a copy)
+                        _defer_reduction(ws, dW, N * Kp, splits)
                     grads[3 * li] = dW[:, :L.cin].reshape(wshape)
                     if li > 0 or ctx.x_needs_grad:
                         g, _, _ = gemm(Gy, Wb, w_trans=True)            # G_y [P,N] · W [N,Kp]

@@ -263,7 +263,11 @@ CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, co
                                     const void *Y, const float *scale, const float *shift,
                                     const float *coef, int G, int Kn, int C, void *Gy, void *stream);
 /* dW[N,K] (fp32) = Gy[P,N]^T . A[P,K]; workspace: cpfn_mlp_wgrad_splits(P,N,K)*N*K floats.
- * a_scale, a_shift (optional): as in cpfn_mlp_gemm, A = relu(a_scale*A + a_shift) on the fly. */
+ * a_scale, a_shift (optional): as in cpfn_mlp_gemm, A = relu(a_scale*A + a_shift) on the fly.
+ * dW may be NULL: only the split partials [splits][N*K] are left in `workspace`, to be finished later,
+ * together with those of other layers, by ONE cpfn_multi_split_reduce launch (same fixed summation order). */
+typedef struct { const float *partial; float *out; long long n; int splits; } cpfn_reduce_desc;
+CPFN_API int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs /* HOST array */, int count, void *stream);
 CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,

@@ -8,7 +8,8 @@ v.abs_()
 lr = torch.tensor(1e-3, device=dev); step = torch.zeros((), device=dev); coef = torch.zeros(3, device=dev); pows = torch.ones(2, dtype=torch.float64, device=dev)
 h = _l.lib()
 def run():
-    h.cpfn_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr.data_ptr(), 0.9, 0.999, 1e-8, 0.0, step.data_ptr(), pows.data_ptr(), None, coef.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rc = h.cpfn_adam_flat(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr.data_ptr(), 0.9, 0.999, 1e-8, 0.0, step.data_ptr(), pows.data_ptr(), None, coef.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
 for _ in range(5): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
