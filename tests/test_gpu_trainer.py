@@ -52,6 +52,22 @@ def test_modes_agree_with_frozen_weights():
             assert err < 2e-2, (mode, step, err)
 
 
+def test_host_assignment_mode_matches_device_assignment(monkeypatch):
+    """CPFN_HOST_ASSIGNMENT=1 (SciPy on the host like the reference; three graphs with the fits overlapping the host
+    round trip) against the default single-graph step with cpfn_hungarian_match: same losses and gradients."""
+    from cpfn_amd.SPFN import fused_losses as fl
+    l_d, g_d, tr_d = _run("graph+prefetch", 0.0, steps=6)
+    assert tr_d._graph is not None and tr_d._graph["single"]
+    monkeypatch.setattr(fl, "HOST_ASSIGNMENT", True)
+    l_h, g_h, tr_h = _run("graph+prefetch", 0.0, steps=6)
+    assert tr_h._graph is not None and not tr_h._graph["single"]
+    for a, b in zip(l_h, l_d):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 1e-3 * abs(y) + 1e-5, (a, b)
+    for a, b in zip(g_h, g_d):
+        assert float((a - b).norm() / b.norm()) < 2e-2
+
+
 def _train(dtype, fused_losses, graphs, steps=64):
     from cpfn_amd import training
     from cpfn_amd.PointNet2 import pn2_network
