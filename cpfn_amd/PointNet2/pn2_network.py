@@ -93,5 +93,10 @@ class PointNet2(torch.nn.Module):
             from .. import fused_mlp
             self.heads_packed = fused_mlp.linear_heads.last_packed.reshape(B, N, -1)       # [B,N,3+4+K] fp32
         results.append(l3_out)
-        results.append(feat.float().reshape(B, N, -1).transpose(1, 2))
+        # per-point features [B,128,N] fp32 like the reference's fifth output; a trainer that only consumes the heads
+        # sets `return_point_features = False` and gets the bf16 rows as a view instead (saves a 100 MB conversion)
+        if getattr(self, "return_point_features", True):
+            results.append(feat.float().reshape(B, N, -1).transpose(1, 2))
+        else:
+            results.append(feat.reshape(B, N, -1).transpose(1, 2))
         return results

@@ -64,7 +64,44 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
   }
 }
 
+// flag[0] = 1.0 if any of x[0..n) is NaN or +-inf, else 0.0 (the reference scans every parameter gradient with
+// isinf/isnan and two host syncs per tensor, Utils/training_utils.py:151-156; torch needs five kernels for
+// `(~isfinite(x).all()).float()`).  Two tiny passes so that the flag is always written (no memset needed).
+__global__ __launch_bounds__(256) void nonfinite_partial_kernel(const float *__restrict__ x, long long n,
+                                                                unsigned *__restrict__ partial) {
+  __shared__ unsigned s_any[4];
+  unsigned bad = 0;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      const uint4 v = *(const uint4 *)(x + i);
+      bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) |
+             ((v.z & 0x7f800000u) == 0x7f800000u) | ((v.w & 0x7f800000u) == 0x7f800000u);
+    } else {
+      for (long long j = i; j < n; ++j) bad |= (__float_as_uint(x[j]) & 0x7f800000u) == 0x7f800000u;
+    }
+  }
+  const unsigned long long m = __ballot(bad != 0);
+  if ((threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = m != 0;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_any[0] | s_any[1] | s_any[2] | s_any[3];
+}
+__global__ void nonfinite_final_kernel(const unsigned *__restrict__ partial, int nblk, float *__restrict__ flag) {
+  unsigned bad = 0;
+  for (int i = threadIdx.x; i < nblk; i += 64) bad |= partial[i];
+  const unsigned long long m = __ballot(bad != 0);
+  if (threadIdx.x == 0) *flag = m != 0 ? 1.f : 0.f;
+}
+
 }  // namespace
+
+extern "C" int cpfn_nonfinite_flag(const float *x, long long n, unsigned *workspace256, float *flag, void *stream) {
+  if (n < 0 || !x || !workspace256 || !flag || ((uintptr_t)x & 15)) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)(n / 4096 + 1 < 256 ? n / 4096 + 1 : 256);
+  nonfinite_partial_kernel<<<nblk, 256, 0, st>>>(x, n, workspace256);
+  nonfinite_final_kernel<<<1, 64, 0, st>>>(workspace256, nblk, flag);
+  return cpfn_launch_status();
+}
 
 extern "C" int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
                               float beta2, float eps, float weight_decay, float *step, double *pows,

@@ -88,6 +88,20 @@ class FlatGradBucket:
         (training_utils.py:151-156: two host syncs per tensor)."""
         return torch.isfinite(self.flat).all()
 
+    def nonfinite_flag(self):
+        """0-dim fp32 tensor: 1.0 if any gradient is NaN / inf, else 0.0 — one streaming kernel on the GPU
+        (cpfn_nonfinite_flag), capturable; the optimizer skips its step when it is set."""
+        if not self.flat.is_cuda:
+            return (~torch.isfinite(self.flat).all()).float().reshape(())
+        from . import lib as _l
+        if getattr(self, "_nf_ws", None) is None:
+            self._nf_ws = torch.empty(256, dtype=torch.int32, device=self.flat.device)
+        flag = torch.empty((), dtype=torch.float32, device=self.flat.device)
+        with torch.cuda.device(self.flat.device):
+            _l.check(_l.lib().cpfn_nonfinite_flag(self.flat.data_ptr(), self.flat.numel(), self._nf_ws.data_ptr(), flag.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "cpfn_nonfinite_flag")
+        return flag
+
 
 def broadcast_parameters(module, src=0):
     """Identical replicas at start: rank-0 state to everyone (parameters and BN buffers)."""
@@ -130,6 +144,7 @@ class SPFNTrainer:
         update_momentum(module, self._bn_momentum)
         self.skipped_steps = 0
         self.fused_losses = True      # HIP loss kernels when the model exposes its packed fp32 heads
+        module.return_point_features = False    # the step consumes the heads only (no [B,128,N] fp32 conversion)
         self._side, self._prefetched = None, None
 
     def _schedules(self):
@@ -318,7 +333,7 @@ class SPFNTrainer:
                 out[0].backward()
                 self.bucket.collect()
                 if world == 1:
-                    st["found_inf"] = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+                    st["found_inf"] = self.bucket.nonfinite_flag()
                     self.optimizer.found_inf = st["found_inf"]
                     self.optimizer.step()
                     st["skipped"] += st["found_inf"]
@@ -355,7 +370,7 @@ class SPFNTrainer:
             out[0].backward()
             self.bucket.collect()
             if world == 1:
-                st["found_inf"] = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+                st["found_inf"] = self.bucket.nonfinite_flag()
                 self.optimizer.found_inf = st["found_inf"]
                 self.optimizer.step()
                 st["skipped"] += st["found_inf"]
@@ -416,7 +431,7 @@ class SPFNTrainer:
             st["g"].replay()                                   # the whole step: no host synchronisation
             if st["world"] > 1:
                 self.bucket.all_reduce_mean()
-                self.optimizer.found_inf = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+                self.optimizer.found_inf = self.bucket.nonfinite_flag()
                 self.optimizer.step()
                 st["skipped"] += self.optimizer.found_inf
             self.global_step += 1
@@ -433,7 +448,7 @@ class SPFNTrainer:
         st["g2"].replay()
         if st["world"] > 1:
             self.bucket.all_reduce_mean()
-            self.optimizer.found_inf = (~torch.isfinite(self.bucket.flat).all()).float().reshape(())
+            self.optimizer.found_inf = self.bucket.nonfinite_flag()
             self.optimizer.step()
             st["skipped"] += self.optimizer.found_inf
         self.global_step += 1
@@ -478,7 +493,7 @@ class SPFNTrainer:
         self.bucket.collect()
         self.bucket.all_reduce_mean()
         if self.use_graphs:                            # capturable optimizer: skip decided on the device
-            self.optimizer.found_inf = (~self.bucket.finite()).float().reshape(())
+            self.optimizer.found_inf = self.bucket.nonfinite_flag()
             self.optimizer.step()
         elif bool(self.bucket.finite()):               # single host sync (reference: 148)
             self.optimizer.step()

@@ -351,6 +351,11 @@ CPFN_API int cpfn_loss_tail(const float *S, const float *rp, const float *nl, co
                             const float *mult6, float *out6, float *gS, float *grp, float *gnl,
                             float *gtl, void *stream);
 
+/* flag[0] = 1.0f if any of x[0..n) (fp32, 16-byte aligned) is NaN or +-inf, else 0.0f: the finite
+ * check of the gradients (Utils/training_utils.py:151-156) as one streaming pass.  workspace256: 256 uints. */
+CPFN_API int cpfn_nonfinite_flag(const float *x, long long n, unsigned *workspace256, float *flag,
+                                 void *stream);
+
 /* Adam step on flat fp32 buffers p, g, m, v [n] (16-byte aligned), torch.optim.Adam arithmetic
  * (non-amsgrad; the optimizer of the reference's epoch loop, Utils/training_utils.py).  Capturable:
  * lr, step (count of steps taken so far, incremented here), pows (fp64 {beta1^step, beta2^step},

@@ -47,3 +47,19 @@ def test_flat_adam_matches_torch_adam():
     assert float(oa.step_count) == 11.0
     sd = oa.state_dict()
     assert sd["flat"]["exp_avg"].numel() == bucket.flat.numel()
+
+
+def test_nonfinite_flag():
+    from cpfn_amd import training
+    dev = torch.device("cuda:0")
+    m = torch.nn.Linear(1000, 37).to(dev)            # 37037 gradients: ragged tail
+    b = training.FlatGradBucket(m)
+    b.flat.normal_()
+    assert float(b.nonfinite_flag()) == 0.0
+    for pos, val in ((0, float("nan")), (b.flat.numel() - 1, float("inf")), (12345, -float("inf"))):
+        b.flat.normal_()
+        b.flat[pos] = val
+        assert float(b.nonfinite_flag()) == 1.0
+    b.flat.normal_()
+    b.flat[5] = 3.0e38                               # large but finite
+    assert float(b.nonfinite_flag()) == 0.0
