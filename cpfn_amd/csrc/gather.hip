@@ -402,6 +402,28 @@ __global__ __launch_bounds__(TPB) void group_concat_bf16_kernel(const unsigned s
   }
 }
 
+// Up to MC_MAX contiguous buffers copied by ONE launch (16-byte pieces, grid-stride inside each buffer's block
+// range): the trainer's static-buffer hand-overs (geometry set B -> A, a new batch into the input buffers) are
+// ~20 tensors of a few MB each; torch's multi-tensor copy takes ~25 us for them, a memcpy node per tensor more.
+constexpr int MC_MAX = 40;
+struct McArgs {
+  const void *src[MC_MAX];
+  void *dst[MC_MAX];
+  long long bytes[MC_MAX];
+  int block0[MC_MAX + 1];
+  int count;
+};
+__global__ __launch_bounds__(TPB) void multi_copy_kernel(McArgs a) {
+  int d = 0;
+  while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
+  const long long n16 = a.bytes[d] / 16, nb = a.block0[d + 1] - a.block0[d];
+  const uint4 *__restrict__ s = (const uint4 *)a.src[d];
+  uint4 *__restrict__ o = (uint4 *)a.dst[d];
+  for (long long i = (long long)(blockIdx.x - a.block0[d]) * TPB + threadIdx.x; i < n16; i += nb * TPB) o[i] = s[i];
+  if (blockIdx.x == a.block0[d] && threadIdx.x < (a.bytes[d] & 15))       // ragged tail, byte by byte
+    ((unsigned char *)a.dst[d])[n16 * 16 + threadIdx.x] = ((const unsigned char *)a.src[d])[n16 * 16 + threadIdx.x];
+}
+
 inline int channel_chunk(int C, int blocks_x, int B) {
   // enough blocks to fill 256 CUs a few times over, but at least 8 channels per block
   // so the index / weight loads are amortised
@@ -588,5 +610,28 @@ extern "C" int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offse
   dim3 grid(cpfn_cdiv((long long)M * (C / 8) * CS_LANES, TPB), B);
   csr_gather_sum_kernel<<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, offsets, entries, w, T, R, M,
                                                                C, (unsigned short *)out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_multi_copy(const cpfn_copy_desc *descs, int count, void *stream) {
+  if (count < 0 || (count > 0 && !descs)) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < count; base += MC_MAX) {
+    McArgs a;
+    a.count = count - base < MC_MAX ? count - base : MC_MAX;
+    int blocks = 0;
+    for (int i = 0; i < a.count; ++i) {
+      const cpfn_copy_desc &d = descs[base + i];
+      if (!d.src || !d.dst || d.bytes < 0 || (((uintptr_t)d.src | (uintptr_t)d.dst) & 15)) return CPFN_EINVAL;
+      a.src[i] = d.src; a.dst[i] = d.dst; a.bytes[i] = d.bytes;
+      a.block0[i] = blocks;
+      long long nb = (d.bytes / 16 + TPB * 4 - 1) / (TPB * 4);            // ~4 pieces per lane
+      if (nb < 1) nb = 1;
+      if (nb > 1024) nb = 1024;
+      blocks += (int)nb;
+    }
+    a.block0[a.count] = blocks;
+    if (blocks) multi_copy_kernel<<<blocks, TPB, 0, st>>>(a);
+  }
   return cpfn_launch_status();
 }

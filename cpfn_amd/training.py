@@ -252,12 +252,24 @@ class SPFNTrainer:
 
     @staticmethod
     def _copy_all(dst, src):
-        """One multi-tensor copy for a whole tensor set: int32 / fp32 / int64 tensors are viewed as int32 so that
-        _foreach_copy_ takes its single-kernel route (mixed dtypes fall back to one memcpy node per tensor:
-        48 of them per step for the geometry set)."""
-        def v32(t):
-            return t.view(torch.int32) if t.element_size() in (4, 8) and t.is_contiguous() else t
-        torch._foreach_copy_([v32(d) for d in dst], [v32(t) for t in src])
+        """One launch for a whole set of device-to-device copies (cpfn_multi_copy); tensors that are not contiguous
+        or not 16-byte aligned go through torch."""
+        import ctypes
+        from . import lib as _l
+
+        class _D(ctypes.Structure):
+            _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
+        fast = []
+        for d, t in zip(dst, src):
+            if (d.is_cuda and t.is_cuda and d.is_contiguous() and t.is_contiguous() and d.dtype == t.dtype
+                    and d.numel() == t.numel() and (d.data_ptr() | t.data_ptr()) % 16 == 0):
+                fast.append(_D(t.data_ptr(), d.data_ptr(), d.numel() * d.element_size()))
+            else:
+                d.copy_(t, non_blocking=True)
+        if fast:
+            arr = (_D * len(fast))(*fast)
+            with torch.cuda.device(dst[0].device):
+                _l.check(_l.lib().cpfn_multi_copy(arr, len(fast), torch.cuda.current_stream().cuda_stream), "cpfn_multi_copy")
 
     @staticmethod
     def _like_geom(g, tensors):

@@ -139,6 +139,10 @@ CPFN_API int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, cons
 CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const int *idx, int B, int N, int R,
                                     int C, int Cpad, void *out, void *stream);
 
+/* count device-to-device copies (16-byte aligned pointers, any byte length) in ONE launch. */
+typedef struct { const void *src; void *dst; long long bytes; } cpfn_copy_desc;
+CPFN_API int cpfn_multi_copy(const cpfn_copy_desc *descs /* HOST array */, int count, void *stream);
+
 /* Inverse index of a gather (geometry stage): for idx[B,E] with values in [0,M) (M <= 2048) build, per
  * cloud, offsets[M+1] and the ASCENDING list entries[E] of source positions e that reference each target.
  * The adjoint of the gather is then cpfn_csr_gather_sum_bf16: out[b,m,:] = sum over list(m) of
