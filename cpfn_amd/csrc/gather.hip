@@ -416,12 +416,22 @@ struct McArgs {
 __global__ __launch_bounds__(TPB) void multi_copy_kernel(McArgs a) {
   int d = 0;
   while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
-  const long long n16 = a.bytes[d] / 16, nb = a.block0[d + 1] - a.block0[d];
-  const uint4 *__restrict__ s = (const uint4 *)a.src[d];
-  uint4 *__restrict__ o = (uint4 *)a.dst[d];
-  for (long long i = (long long)(blockIdx.x - a.block0[d]) * TPB + threadIdx.x; i < n16; i += nb * TPB) o[i] = s[i];
-  if (blockIdx.x == a.block0[d] && threadIdx.x < (a.bytes[d] & 15))       // ragged tail, byte by byte
-    ((unsigned char *)a.dst[d])[n16 * 16 + threadIdx.x] = ((const unsigned char *)a.src[d])[n16 * 16 + threadIdx.x];
+  const long long nb = a.block0[d + 1] - a.block0[d];
+  const long long first = (long long)(blockIdx.x - a.block0[d]) * TPB + threadIdx.x;
+  const unsigned long long both = (unsigned long long)a.src[d] | (unsigned long long)a.dst[d];
+  if ((both & 15) == 0) {
+    const long long n16 = a.bytes[d] / 16;
+    const uint4 *__restrict__ s = (const uint4 *)a.src[d];
+    uint4 *__restrict__ o = (uint4 *)a.dst[d];
+    for (long long i = first; i < n16; i += nb * TPB) o[i] = s[i];
+    if (blockIdx.x == a.block0[d] && threadIdx.x < (a.bytes[d] & 15))     // ragged tail, byte by byte
+      ((unsigned char *)a.dst[d])[n16 * 16 + threadIdx.x] = ((const unsigned char *)a.src[d])[n16 * 16 + threadIdx.x];
+  } else {                                                                // 4-byte aligned views (slices of a flat buffer)
+    const long long n4 = a.bytes[d] / 4;
+    const unsigned *__restrict__ s = (const unsigned *)a.src[d];
+    unsigned *__restrict__ o = (unsigned *)a.dst[d];
+    for (long long i = first; i < n4; i += nb * TPB) o[i] = s[i];
+  }
 }
 
 inline int channel_chunk(int C, int blocks_x, int B) {
@@ -622,7 +632,8 @@ extern "C" int cpfn_multi_copy(const cpfn_copy_desc *descs, int count, void *str
     int blocks = 0;
     for (int i = 0; i < a.count; ++i) {
       const cpfn_copy_desc &d = descs[base + i];
-      if (!d.src || !d.dst || d.bytes < 0 || (((uintptr_t)d.src | (uintptr_t)d.dst) & 15)) return CPFN_EINVAL;
+      const uintptr_t both = (uintptr_t)d.src | (uintptr_t)d.dst;
+      if (!d.src || !d.dst || d.bytes < 0 || (both & 3) || ((both & 15) && (d.bytes & 3))) return CPFN_EINVAL;
       a.src[i] = d.src; a.dst[i] = d.dst; a.bytes[i] = d.bytes;
       a.block0[i] = blocks;
       long long nb = (d.bytes / 16 + TPB * 4 - 1) / (TPB * 4);            // ~4 pieces per lane

@@ -74,7 +74,10 @@ class FlatGradBucket:
                 dst.append(v)
                 who.append(p)
         if src:
-            torch._foreach_copy_(dst, src)
+            if self.flat.is_cuda:
+                SPFNTrainer._copy_all(dst, src)            # one launch (cpfn_multi_copy)
+            else:
+                torch._foreach_copy_(dst, src)
             for p, v in zip(who, dst):
                 p.grad = v
 
@@ -253,7 +256,7 @@ class SPFNTrainer:
     @staticmethod
     def _copy_all(dst, src):
         """One launch for a whole set of device-to-device copies (cpfn_multi_copy); tensors that are not contiguous
-        or not 16-byte aligned go through torch."""
+        (or oddly aligned) go through torch."""
         import ctypes
         from . import lib as _l
 
@@ -262,7 +265,8 @@ class SPFNTrainer:
         fast = []
         for d, t in zip(dst, src):
             if (d.is_cuda and t.is_cuda and d.is_contiguous() and t.is_contiguous() and d.dtype == t.dtype
-                    and d.numel() == t.numel() and (d.data_ptr() | t.data_ptr()) % 16 == 0):
+                    and d.numel() == t.numel() and ((d.data_ptr() | t.data_ptr()) % 16 == 0 or
+                                                    ((d.data_ptr() | t.data_ptr()) % 4 == 0 and d.element_size() % 4 == 0))):
                 fast.append(_D(t.data_ptr(), d.data_ptr(), d.numel() * d.element_size()))
             else:
                 d.copy_(t, non_blocking=True)

@@ -139,7 +139,8 @@ CPFN_API int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, cons
 CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const int *idx, int B, int N, int R,
                                     int C, int Cpad, void *out, void *stream);
 
-/* count device-to-device copies (16-byte aligned pointers, any byte length) in ONE launch. */
+/* count device-to-device copies in ONE launch: pointers 16-byte aligned (any byte length), or 4-byte aligned
+ * with a length that is a multiple of 4 (slices of a flat fp32 buffer). */
 typedef struct { const void *src; void *dst; long long bytes; } cpfn_copy_desc;
 CPFN_API int cpfn_multi_copy(const cpfn_copy_desc *descs /* HOST array */, int count, void *stream);
 
