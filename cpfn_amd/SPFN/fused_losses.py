@@ -23,6 +23,8 @@ from . import fitters_common as _fc
 # CPFN_HOST_ASSIGNMENT=1: solve the assignment with SciPy on the host like the reference (one device->host->device
 # round trip per step) instead of cpfn_hungarian_match.
 HOST_ASSIGNMENT = os.environ.get("CPFN_HOST_ASSIGNMENT", "0") == "1"
+# the assignment branch and the fitter branch of the loss section on two streams (CPFN_PARALLEL_BRANCHES=0: one)
+PARALLEL_BRANCHES = os.environ.get("CPFN_PARALLEL_BRANCHES", "1") == "1"
 
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
                 ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
@@ -217,6 +219,34 @@ def pre_match(Y, batch):
     return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"])
 
 
+_branch_streams = {}
+
+
+def match_and_fit(P, Y, batch, multipliers):
+    """Heads post-processing, then TWO independent branches run side by side: (segmented sums -> assignment) on a
+    forked stream and (the four fits) on the current one — both are a handful of low-occupancy, latency-bound
+    kernels (one wave per cloud / one lane per instance), so they overlap almost for free.  Returns
+    (Xn, W, nl, tl, S, n_gt, match, params).  Capturable (the fork becomes a parallel branch of the graph)."""
+    Xn, W, nl, tl = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"])
+    dev = W.device
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream)
+    side = _branch_streams.get(key)
+    if side is None:
+        side = _branch_streams[key] = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        S = SegStats.apply(W, batch["I_gt"])
+        n_gt = count_gt(batch["I_gt"])
+        match = hungarian_device(S, n_gt)
+    W.record_stream(side)                       # produced here, read on the side stream
+    params = fit_params(P, W, Xn, multipliers)
+    cur.wait_stream(side)
+    for t in (S, n_gt, match):                  # produced on the side stream, read here from now on
+        t.record_stream(cur)
+    return Xn, W, nl, tl, S, n_gt, match, params
+
+
 def fit_params(P, W, Xn, multipliers):
     """The match-independent part of the post-assignment work (all four fits of every instance); None when
     neither the residue nor the parameter loss is switched on.  A trainer can run it while the host solves the
@@ -249,10 +279,13 @@ def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=Non
 def fused_losses(P, Y, batch, multipliers, classes):
     """P [B,N,3]; Y [B,N,7+K] = packed fp32 heads (normal | type logits | membership logits).
     Returns the reference's (total, normal, type, miou, residue, parameter) scalars."""
-    Xn, W, nl, tl, S = pre_match(Y, batch)
-    n_gt = count_gt(batch["I_gt"])
-    if HOST_ASSIGNMENT or S.shape[2] > 32:
-        match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
-    else:
-        match = hungarian_device(S, n_gt)
-    return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt)
+    if HOST_ASSIGNMENT or Y.shape[2] - 7 > 32 or not PARALLEL_BRANCHES:
+        Xn, W, nl, tl, S = pre_match(Y, batch)
+        n_gt = count_gt(batch["I_gt"])
+        if HOST_ASSIGNMENT or S.shape[2] > 32:
+            match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
+        else:
+            match = hungarian_device(S, n_gt)
+        return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt)
+    Xn, W, nl, tl, S, n_gt, match, params = match_and_fit(P, Y, batch, multipliers)
+    return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt, params)

@@ -341,10 +341,13 @@ class SPFNTrainer:
                     geometry_into_B(st["P_next"])
                 self.bucket.zero()
                 self.module(sb["P"], geometry=st["geomA"])
-                Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
-                n_gt = fl.count_gt(sb["I_gt"])
-                st["match"] = fl.hungarian_device(S, n_gt)
-                params = fl.fit_params(sb["P"], W, Xn, self.mult)
+                if fl.PARALLEL_BRANCHES:
+                    Xn, W, nl, tl, S, n_gt, st["match"], params = fl.match_and_fit(sb["P"], self.module.heads_packed, sb, self.mult)
+                else:
+                    Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
+                    n_gt = fl.count_gt(sb["I_gt"])
+                    st["match"] = fl.hungarian_device(S, n_gt)
+                    params = fl.fit_params(sb["P"], W, Xn, self.mult)
                 out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
                 out[0].backward()
                 self.bucket.collect()
