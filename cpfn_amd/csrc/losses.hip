@@ -200,53 +200,54 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
 // ------------------------------------------------------------------------------------ seg_stats
 // S[b][K+2][K]: rows l<K: Σ_{n: I=l} W[n,:];  row K: Σ_n W[n,:];  row K+1: #points with label l (as float).
 // thread = (column kk, point subset); 32 label accumulators per thread, selected by compare (no atomics).
-constexpr int SS_TILE = 64, SS_SUB = LP_THREADS / MAXK;   // 8 subsets
+constexpr int SS_TILE = 256, SS_SUB = LP_THREADS / MAXK;   // 8 subsets; a tile = one latency: the whole 256-point chunk
 __global__ __launch_bounds__(LP_THREADS) void seg_stats_fwd_kernel(const float *__restrict__ W,
                                                                    const long long *__restrict__ Igt, int N, int K,
                                                                    int pts_per_block, float *__restrict__ partial) {
   __shared__ float s_w[SS_TILE][MAXK];
   __shared__ int s_lab[SS_TILE];
-  __shared__ float s_red[SS_SUB][MAXK + 1][MAXK];
-  __shared__ float s_cnt[MAXK];
+  // accumulators [point sub-lane][label row (row MAXK = all points)][column], rows padded to 33 floats.  A lane owns
+  // column kk of its sub-lane's slab, so `slab[label][kk] += w` is a private read-modify-write in LDS (DS ops of a
+  // wave execute in order) — one ds_read + add + ds_write per point instead of 32 compare-select-adds into 32
+  // register accumulators (26 us -> a few us: that loop was the kernel).
+  __shared__ float s_acc[SS_SUB][MAXK + 1][MAXK + 1];
+  __shared__ int s_cnt[MAXK];                       // points per label: integer LDS atomics (exact, order-free)
   const int b = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
   const int kk = t % MAXK, sub = t / MAXK;
   const int n0 = chunk * pts_per_block, n1 = min(N, n0 + pts_per_block);
-  float acc[MAXK], all = 0.f, cnt = 0.f;
-#pragma unroll
-  for (int l = 0; l < MAXK; ++l) acc[l] = 0.f;
+  float all = 0.f;
+  for (int l = 0; l <= MAXK; ++l) s_acc[sub][l][kk] = 0.f;
+  if (t < MAXK) s_cnt[t] = 0;
   for (int base = n0; base < n1; base += SS_TILE) {
     __syncthreads();
     for (int e = t; e < SS_TILE * MAXK; e += LP_THREADS) {
       const int i = e / MAXK, k = e % MAXK;
       s_w[i][k] = (base + i < n1 && k < K) ? W[((size_t)b * N + base + i) * K + k] : 0.f;
     }
-    if (t < SS_TILE) s_lab[t] = (base + t < n1) ? (int)Igt[(size_t)b * N + base + t] : -2;
+    if (t < SS_TILE) {
+      const int lab = (base + t < n1) ? (int)Igt[(size_t)b * N + base + t] : -2;
+      s_lab[t] = lab;
+      if (lab >= 0 && lab < MAXK) atomicAdd(&s_cnt[lab], 1);
+    }
     __syncthreads();
     for (int i = sub; i < SS_TILE; i += SS_SUB) {
       const int lab = s_lab[i];
       const float w = s_w[i][kk];
       all += w;
-#pragma unroll
-      for (int l = 0; l < MAXK; ++l) acc[l] += (lab == l) ? w : 0.f;
-    }
-    if (t < MAXK) {
-      for (int i = 0; i < SS_TILE; ++i) cnt += (s_lab[i] == t) ? 1.f : 0.f;
+      if (lab >= 0 && lab < MAXK) s_acc[sub][lab][kk] += w;
     }
   }
-#pragma unroll
-  for (int l = 0; l < MAXK; ++l) s_red[sub][l][kk] = acc[l];
-  s_red[sub][MAXK][kk] = all;
-  if (t < MAXK) s_cnt[t] = cnt;
+  s_acc[sub][MAXK][kk] = all;
   __syncthreads();
   float *o = partial + ((size_t)b * gridDim.x + chunk) * (K + 2) * K;
   for (int e = t; e < (K + 1) * K; e += LP_THREADS) {
     const int l = e / K, k = e % K;
     const int row = l < K ? l : MAXK;
     float s = 0.f;
-    for (int q = 0; q < SS_SUB; ++q) s += s_red[q][row][k];
+    for (int q = 0; q < SS_SUB; ++q) s += s_acc[q][row][k];
     o[l * K + k] = s;
   }
-  if (t < K) o[(K + 1) * K + t] = s_cnt[t];
+  if (t < K) o[(K + 1) * K + t] = (float)s_cnt[t];
 }
 
 __global__ void chunk_sum_f32_kernel(const float *__restrict__ partial, int chunks, int per_b, long long total,
@@ -260,20 +261,26 @@ __global__ void chunk_sum_f32_kernel(const float *__restrict__ partial, int chun
 }
 
 // dW[b,n,k] = gS[b, I[b,n], k] (labelled points) + gS[b, K, k]
+// One lane per point builds its row in LDS (odd stride), the tile leaves with coalesced stores
+// (the first version: one lane per element with two integer divisions by K and a redundant label load, 0.7 TB/s).
 __global__ __launch_bounds__(LP_THREADS) void seg_stats_bwd_kernel(const float *__restrict__ gS,
                                                                    const long long *__restrict__ Igt, int N, int K,
                                                                    float *__restrict__ dW) {
   __shared__ float s_g[(MAXK + 2) * MAXK];
+  __shared__ float s_row[LP_THREADS * (MAXK + 1)];
   const int b = blockIdx.y, t = threadIdx.x;
   for (int e = t; e < (K + 1) * K; e += LP_THREADS) s_g[e] = gS[(size_t)b * (K + 2) * K + e];
   __syncthreads();
-  const long long e0 = (long long)blockIdx.x * LP_THREADS + t;
-  if (e0 >= (long long)N * K) return;
-  const int n = (int)(e0 / K), k = (int)(e0 % K);
-  const long long lab = Igt[(size_t)b * N + n];
-  float g = s_g[K * K + k];
-  if (lab >= 0 && lab < K) g += s_g[lab * K + k];
-  dW[(size_t)b * N * K + e0] = g;
+  const int n0 = blockIdx.x * LP_THREADS, rows = min(LP_THREADS, N - n0);
+  if (t < rows) {
+    const long long lab = Igt[(size_t)b * N + n0 + t];
+    const bool has = lab >= 0 && lab < K;
+    const float *gl = s_g + (has ? (int)lab : 0) * K, *ga = s_g + K * K;
+    float *o = s_row + t * (MAXK + 1);
+    for (int k = 0; k < K; ++k) o[k] = ga[k] + (has ? gl[k] : 0.f);
+  }
+  __syncthreads();
+  cpfn_rows_from_lds<LP_THREADS>(s_row, MAXK + 1, dW + ((size_t)b * N + n0) * K, rows, K, t);
 }
 
 // ------------------------------------------------------------------------------------ residue
@@ -718,7 +725,7 @@ extern "C" int cpfn_seg_stats_fwd(const float *W, const int64_t *Igt, int B, int
 
 extern "C" int cpfn_seg_stats_bwd(const float *gS, const int64_t *Igt, int B, int N, int K, float *dW, void *stream) {
   if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !gS || !Igt || !dW) return CPFN_EINVAL;
-  seg_stats_bwd_kernel<<<dim3(cpfn_cdiv((long long)N * K, LP_THREADS), B), LP_THREADS, 0, (hipStream_t)stream>>>(
+  seg_stats_bwd_kernel<<<dim3(cpfn_cdiv(N, LP_THREADS), B), LP_THREADS, 0, (hipStream_t)stream>>>(
       gS, (const long long *)Igt, N, K, dW);
   return cpfn_launch_status();
 }
