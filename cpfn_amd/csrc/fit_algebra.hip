@@ -189,15 +189,18 @@ __device__ void fit_sphere(T S0, const T S1[D], const T S2[D][D], T T0, const T 
 // index of (i,j,k) in the 10 unique third-order moments (xxx xxy xxz xyy xyz xzz yyy yyz yzz zzz)
 __device__ __constant__ int T3IDX[3][3][3] = {{{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}, {{1, 3, 4}, {3, 6, 7}, {4, 7, 8}}, {{2, 4, 5}, {4, 7, 8}, {5, 8, 9}}};
 
-template <typename T>
+// PART = -1: all four fits; 0 plane, 1 sphere, 2 cylinder, 3 cone first pass (each writes only its own columns of
+// out: 0..3 | 4..7 | 8..14 | 15..20).  The kernels give every part its own WAVE, so the four fits of an instance
+// run side by side on four SIMDs instead of one after the other in one lane.
+template <typename T, int PART = -1>
 __device__ void fit_all(const T *M, T *out) {
   const T S0 = M[0], T0 = M[20];
   const T *S1 = M + 1, *S2 = M + 4, *Sx = M + 10, *Sxx = M + 13;
   const T *T1 = M + 21, *T2 = M + 24, *T3 = M + 30, *Tnn = M + 40, *Tnpn = M + 46;
   // ---- plane (plane_fitter.py:9-17)
-  fit_plane(S0, S1, S2, out + 0, out[3]);
+  if (PART < 0 || PART == 0) fit_plane(S0, S1, S2, out + 0, out[3]);
   // ---- sphere (sphere_fitter.py:9-19)
-  {
+  if (PART < 0 || PART == 1) {
     T S2m[3][3], T2m[3][3], T3c[3];
     sym_from6(S2, S2m);
     sym_from6(T2, T2m);
@@ -205,7 +208,7 @@ __device__ void fit_all(const T *M, T *out) {
     fit_sphere<T, 3>(S0, S1, S2m, T0, T1, T2m, T3c, out + 4, out[7]);
   }
   // ---- cylinder (cylinder_fitter.py:10-28)
-  {
+  if (PART < 0 || PART == 2) {
     T n[3];
     smallest_eigvec(Sxx, n);
     // compute_consistent_plane_frame (geometry_utils.py:8-27): y = normalise(n x e_i) of largest norm
@@ -256,7 +259,7 @@ __device__ void fit_all(const T *M, T *out) {
     out[14] = r2;
   }
   // ---- cone, first pass (cone_fitter.py:17-23): apex = guarded LS(Σω' x xᵀ, Σω' x (p·x)); axis = plane fit of X
-  {
+  if (PART < 0 || PART == 3) {
     T A[3][3], b[3] = {Tnpn[0], Tnpn[1], Tnpn[2]};
     sym_from6(Tnn, A);
     guarded_solve3(A, b, out + 15);
@@ -265,34 +268,56 @@ __device__ void fit_all(const T *M, T *out) {
   }
 }
 
-__global__ void fit_algebra_fwd_kernel(const double *__restrict__ M, long long G, double *__restrict__ out,
-                                       float *__restrict__ apex_axis32) {
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+constexpr int PART_LO[4] = {0, 4, 8, 15}, PART_HI[4] = {4, 8, 15, 21};
+
+template <typename T>
+__device__ __forceinline__ void fit_part(int part, const T *m, T *o) {   // wave-uniform `part`
+  switch (part) {
+    case 0: fit_all<T, 0>(m, o); break;
+    case 1: fit_all<T, 1>(m, o); break;
+    case 2: fit_all<T, 2>(m, o); break;
+    default: fit_all<T, 3>(m, o); break;
+  }
+}
+
+// 256 lanes = 4 waves: wave p fits primitive type p for 64 instances
+__global__ __launch_bounds__(256) void fit_algebra_fwd_kernel(const double *__restrict__ M, long long G,
+                                                              double *__restrict__ out, float *__restrict__ apex_axis32) {
+  const int part = threadIdx.x >> 6;
+  const long long g = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
   if (g >= G) return;
   double m[NM], o[NO];
   for (int i = 0; i < NM; ++i) m[i] = M[g * NM + i];
-  fit_all<double>(m, o);
-  for (int i = 0; i < NO; ++i) out[g * NO + i] = o[i];
-  if (apex_axis32)   // fp32 copy of the cone pass's inputs: apex[G,3] then axis[G,3]
+  fit_part<double>(part, m, o);
+  for (int i = PART_LO[part]; i < PART_HI[part]; ++i) out[g * NO + i] = o[i];
+  if (apex_axis32 && part == 3)   // fp32 copy of the cone pass's inputs: apex[G,3] then axis[G,3]
     for (int i = 0; i < 3; ++i) { apex_axis32[g * 3 + i] = (float)o[15 + i]; apex_axis32[(G + g) * 3 + i] = (float)o[18 + i]; }
 }
 
-// one workgroup of 64 lanes per instance; lane d < 52 computes dL/dM[g,d]
-__global__ __launch_bounds__(64) void fit_algebra_bwd_kernel(const double *__restrict__ M,
-                                                             const double *__restrict__ gout,
-                                                             const double *__restrict__ gA0, long long G,
-                                                             double *__restrict__ gM, float *__restrict__ gM32) {
+// one workgroup per instance, 4 waves: wave p, lane d < 52 computes the part-p share of dL/dM[g,d] by forward-mode
+// AD through fit p; the four shares are added in a fixed order
+__global__ __launch_bounds__(256) void fit_algebra_bwd_kernel(const double *__restrict__ M,
+                                                              const double *__restrict__ gout,
+                                                              const double *__restrict__ gA0, long long G,
+                                                              double *__restrict__ gM, float *__restrict__ gM32) {
+  __shared__ double s_share[4][64];
   const long long g = blockIdx.x;
-  const int d = threadIdx.x;
-  if (d >= NM) return;
-  Dual m[NM], o[NO];
-  for (int i = 0; i < NM; ++i) m[i] = Dual(M[g * NM + i], i == d ? 1.0 : 0.0);
-  fit_all<Dual>(m, o);
+  const int part = threadIdx.x >> 6, d = threadIdx.x & 63;
   double acc = 0.0;
-  for (int i = 0; i < NO; ++i) acc += gout[g * NO + i] * o[i].d;
-  if (gA0 && d == 0) acc += gA0[g];   // direct dependence of the caller on slot 0 (Σ W), e.g. the cone half angle
-  if (gM) gM[g * NM + d] = acc;
-  if (gM32) gM32[g * NM + d] = (float)acc;
+  if (d < NM) {
+    Dual m[NM], o[NO];
+    for (int i = 0; i < NM; ++i) m[i] = Dual(M[g * NM + i], i == d ? 1.0 : 0.0);
+    fit_part<Dual>(part, m, o);
+    for (int i = PART_LO[part]; i < PART_HI[part]; ++i) acc += gout[g * NO + i] * o[i].d;
+  }
+  s_share[part][d] = acc;
+  __syncthreads();
+  if (part == 0 && d < NM) {
+    double tot = ((s_share[0][d] + s_share[1][d]) + s_share[2][d]) + s_share[3][d];
+    if (gA0 && d == 0) tot += gA0[g];   // direct dependence of the caller on slot 0 (Σ W), e.g. the cone half angle
+    if (gM) gM[g * NM + d] = tot;
+    if (gM32) gM32[g * NM + d] = (float)tot;
+  }
 }
 
 }  // namespace
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(64) void fit_algebra_bwd_kernel(const double *__res
 extern "C" int cpfn_fit_algebra_fwd(const double *M, int64_t G, double *out, float *apex_axis32, void *stream) {
   if (G < 0 || !M || !out) return CPFN_EINVAL;
   if (G == 0) return 0;
-  fit_algebra_fwd_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(M, G, out, apex_axis32);
+  fit_algebra_fwd_kernel<<<cpfn_cdiv(G, 64), 256, 0, (hipStream_t)stream>>>(M, G, out, apex_axis32);
   return cpfn_launch_status();
 }
 
@@ -308,6 +333,6 @@ extern "C" int cpfn_fit_algebra_bwd(const double *M, const double *gout, const d
                                     float *gM32, void *stream) {
   if (G < 0 || !M || !gout || (!gM && !gM32)) return CPFN_EINVAL;
   if (G == 0) return 0;
-  fit_algebra_bwd_kernel<<<(unsigned)G, 64, 0, (hipStream_t)stream>>>(M, gout, gA0, G, gM, gM32);
+  fit_algebra_bwd_kernel<<<(unsigned)G, 256, 0, (hipStream_t)stream>>>(M, gout, gA0, G, gM, gM32);
   return cpfn_launch_status();
 }
