@@ -16,6 +16,7 @@
 // All reductions (statistics, weight gradients) go through per-workgroup partial buffers that
 // a second tiny kernel sums in a fixed order: bitwise reproducible, no float atomics.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -278,6 +279,85 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   }
 }
 
+// ---- generic kernel: K chunks of 128 through a DOUBLE-BUFFERED LDS weight panel.
+// The small-P layers (sa3, sfp1, sfp2: 2048-8192 rows, K up to 1280) are pure latency: 64-128 workgroups, each
+// walking its K chunks one after the other.  The first version did load -> wait -> LDS store -> barrier -> MFMA
+// per chunk (~3 us per chunk: 43 us for 2048 x 1280 -> 256).  Now chunk c+1's weight pieces and A fragments are
+// requested into registers BEFORE the MFMAs of chunk c and stored to the other panel buffer after them, so a chunk
+// costs one barrier and the global latency hides behind the MFMAs of the previous chunk; the (tile, chunk) sequence
+// is flattened, so the first chunk of the next row tile is also in flight during the epilogue of the current one.
+constexpr int G_SS_MAX = 512;   // operand-transform scale/shift staged in LDS up to this K
+
+template <int BN>
+__device__ __forceinline__ void w_chunk_load(uint4 (&v)[BN / 16], const unsigned short *__restrict__ W, int K, int N,
+                                             int n0, int kc, int kcn, int w_trans, int t) {
+  constexpr int NV = BN / 16;
+  if (!w_trans) {
+    // the chunk is addressed as 16 16-byte columns per row whatever kcn is: no runtime division, idle lanes load 0
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = t + i * G_THREADS, r = e >> 4, c = e & 15;
+      v[i] = (c * 8 < kcn) ? *(const uint4 *)&W[(size_t)(n0 + r) * K + kc + c * 8] : (uint4){0, 0, 0, 0};
+    }
+  } else {
+    constexpr int cpn = BN / 8;
+#pragma unroll
+    for (int j = 0; j < NV / 4; ++j) {
+      const int e = t + j * G_THREADS, k4 = e / cpn, c = e - k4 * cpn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        v[j * 4 + r] = (4 * k4 < kcn) ? *(const uint4 *)&W[(size_t)(kc + 4 * k4 + r) * N + n0 + c * 8] : (uint4){0, 0, 0, 0};
+    }
+  }
+}
+
+template <int BN>
+__device__ __forceinline__ void w_chunk_store(unsigned short *s_w, uint4 (&v)[BN / 16], int w_trans, int t) {
+  constexpr int NV = BN / 16;
+  if (!w_trans) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = t + i * G_THREADS, r = e >> 4, c = e & 15;
+      *(uint4 *)&s_w[r * G_LDW + c * 8] = v[i];
+    }
+  } else {
+    // transposed on the way in: 8-byte pieces (4 k values of one column), column order rotated by the chunk index
+    // (see fill_w_panel)
+    constexpr int cpn = BN / 8;
+#pragma unroll
+    for (int j = 0; j < NV / 4; ++j) {
+      const int e = t + j * G_THREADS, k4 = e / cpn, c = e - k4 * cpn;
+      uint4 w4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w4[r] = rot_u16x8(v[j * 4 + r], c & 7);
+      const unsigned short *h0 = (const unsigned short *)&w4[0], *h1 = (const unsigned short *)&w4[1],
+                           *h2 = (const unsigned short *)&w4[2], *h3 = (const unsigned short *)&w4[3];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int col = (jj + c) & 7;
+        uint2 o;
+        o.x = (unsigned)h0[jj] | ((unsigned)h1[jj] << 16);
+        o.y = (unsigned)h2[jj] | ((unsigned)h3[jj] << 16);
+        *(uint2 *)&s_w[(c * 8 + col) * G_LDW + 4 * k4] = o;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void a_chunk_load(bf16x8 (&af)[2][4], const unsigned short *__restrict__ A, int lda,
+                                             const int *__restrict__ gidx, int P, int row0, int kc, int kcn, int wave,
+                                             int lr, int lq) {
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    int p = row0 + wave * 32 + tt * 16 + lr;
+    p = p < P ? p : P - 1;
+    const unsigned short *src = A + (size_t)(gidx ? gidx[p] : p) * lda + kc + 8 * lq;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      if (ks * 32 < kcn) af[tt][ks] = *(const bf16x8 *)(src + ks * 32);
+  }
+}
+
 template <int BN, bool STATS>
 __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const int *__restrict__ gidx,
@@ -285,8 +365,9 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
     int n_store, const float *__restrict__ bias, float *__restrict__ stats_partial, int tiles_per_wg,
     const float *__restrict__ a_scale, const float *__restrict__ a_shift) {
   constexpr int NT = BN / 16;
-  __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * G_LDW];
+  __shared__ __attribute__((aligned(16))) unsigned short s_w[2][BN * G_LDW];
   __shared__ float s_red[4][2][BN];
+  __shared__ __attribute__((aligned(16))) float s_ss[2][G_SS_MAX];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
@@ -296,90 +377,111 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
 #pragma unroll
     for (int i = 0; i < NT; ++i) { s1[i] = (f32x4){0, 0, 0, 0}; s2[i] = (f32x4){0, 0, 0, 0}; }
   }
-  bool w_loaded = false;
+  const bool ss_lds = a_scale && K <= G_SS_MAX;
+  if (ss_lds) {   // visible after the first panel barrier
+    for (int e = t; e < K; e += G_THREADS) { s_ss[0][e] = a_scale[e]; s_ss[1][e] = a_shift[e]; }
+  }
+  const int nchunks = (K + G_KC - 1) / G_KC;
+  const bool single = nchunks == 1;   // whole K in one panel: filled once per workgroup
+  const int ntiles = (P + G_ROWS - 1) / G_ROWS;
   const int tile0 = blockIdx.x * tiles_per_wg;
-  for (int tile = tile0; tile < tile0 + tiles_per_wg; ++tile) {
-    const int row0 = tile * G_ROWS;
-    if (row0 >= P) break;
-    f32x4 acc[NT][2];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
-    size_t arow[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      int p = row0 + wave * 32 + tt * 16 + lr;
-      p = p < P ? p : P - 1;
-      arow[tt] = (size_t)(gidx ? gidx[p] : p) * lda;
+  const int tile_end = min(tile0 + tiles_per_wg, ntiles);
+  const int total = tile_end > tile0 ? (tile_end - tile0) * nchunks : 0;
+
+  uint4 wv[BN / 16];
+  bf16x8 an[2][4];
+  if (total > 0) {
+    const int kcn = min(G_KC, K);
+    a_chunk_load(an, A, lda, gidx, P, tile0 * G_ROWS, 0, kcn, wave, lr, lq);
+    w_chunk_load<BN>(wv, W, K, N, n0, 0, kcn, w_trans, t);
+  }
+  f32x4 acc[NT][2];
+  int tile = tile0, c = 0;
+  for (int q = 0; q < total; ++q) {
+    const int kc = c * G_KC, kcn = min(G_KC, K - kc);   // multiple of 32
+    const unsigned short *sw = s_w[single ? 0 : (q & 1)];
+    if (!single || q == 0) {
+      w_chunk_store<BN>(s_w[single ? 0 : (q & 1)], wv, w_trans, t);
+      __syncthreads();   // the only barrier of a chunk: the other buffer was last read before the previous one
     }
-    for (int kc = 0; kc < K; kc += G_KC) {
-      const int kcn = min(G_KC, K - kc);  // multiple of 32
-      bf16x8 af[2][4];
+    bf16x8 af[2][4];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+    for (int ks = 0; ks < 4; ++ks) { af[0][ks] = an[0][ks]; af[1][ks] = an[1][ks]; }
+    int nc = c + 1, ntile = tile;
+    if (nc == nchunks) { nc = 0; ++ntile; }
+    if (q + 1 < total) {   // next chunk in flight during this chunk's MFMAs
+      const int nkc = nc * G_KC, nkcn = min(G_KC, K - nkc);
+      a_chunk_load(an, A, lda, gidx, P, ntile * G_ROWS, nkc, nkcn, wave, lr, lq);
+      if (!single) w_chunk_load<BN>(wv, W, K, N, n0, nkc, nkcn, w_trans, t);
+    }
+    if (c == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          if (ks * 32 < kcn) af[tt][ks] = *(const bf16x8 *)(A + arow[tt] + kc + ks * 32 + 8 * lq);
-      if (!(w_loaded && K <= G_KC)) {
-        __syncthreads();
-        fill_w_panel<BN>(s_w, W, K, N, n0, kc, kcn, w_trans, t);
-        __syncthreads();
-        w_loaded = true;
-      }
-      if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
+      for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
+    }
+    if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          if (ks * 32 < kcn) {
-            float sc[8], sh[8];
-            const int k0 = kc + ks * 32 + 8 * lq;
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks * 32 < kcn) {
+          float sc[8], sh[8];
+          const int k0 = kc + ks * 32 + 8 * lq;
+          if (ss_lds) {
+            *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[0][k0]; *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[0][k0 + 4];
+            *(cpfn_f32x4 *)&sh[0] = *(const cpfn_f32x4 *)&s_ss[1][k0]; *(cpfn_f32x4 *)&sh[4] = *(const cpfn_f32x4 *)&s_ss[1][k0 + 4];
+          } else {
             *(float4 *)&sc[0] = *(const float4 *)(a_scale + k0); *(float4 *)&sc[4] = *(const float4 *)(a_scale + k0 + 4);
             *(float4 *)&sh[0] = *(const float4 *)(a_shift + k0); *(float4 *)&sh[4] = *(const float4 *)(a_shift + k0 + 4);
-            af[0][ks] = bn_relu_frag(af[0][ks], sc, sh);
-            af[1][ks] = bn_relu_frag(af[1][ks], sc, sh);
           }
+          af[0][ks] = bn_relu_frag(af[0][ks], sc, sh);
+          af[1][ks] = bn_relu_frag(af[1][ks], sc, sh);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks * 32 < kcn) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8 wf = *(const bf16x8 *)&sw[(nt * 16 + lr) * G_LDW + ks * 32 + 8 * lq];
+          acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[nt][0], 0, 0, 0);
+          acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[nt][1], 0, 0, 0);
+        }
       }
+    }
+    if (c == nchunks - 1) {
+      // epilogue: lane holds channels n0 + nt*16 + 4*lq + r (r<4) of point row0 + wave*32 + tt*16 + lr
+      const int row0 = tile * G_ROWS;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks * 32 < kcn) {
+      for (int tt = 0; tt < 2; ++tt) {
+        const int p = row0 + wave * 32 + tt * 16 + lr;
+        const bool valid = p < P;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const bf16x8 wf = *(const bf16x8 *)&s_w[(nt * 16 + lr) * G_LDW + ks * 32 + 8 * lq];
-            acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[nt][0], 0, 0, 0);
-            acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[nt][1], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4 v = acc[nt][tt];
+          const int n = n0 + nt * 16 + 4 * lq;
+          if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (n + r < N) ? bias[n + r] : 0.f;
+          }
+          if (STATS && valid) { s1[nt] += v; s2[nt] += v * v; }
+          if (valid) {
+            if (y_f32) {
+              float *o = (float *)Y + (size_t)p * ldy + n;
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (n + r < n_store) o[r] = v[r];
+            } else if (n + 3 < n_store) {
+              bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+              *(bf16x4 *)((unsigned short *)Y + (size_t)p * ldy + n) = o;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (n + r < n_store) ((unsigned short *)Y)[(size_t)p * ldy + n + r] = f2bf(v[r]);
+            }
           }
         }
       }
     }
-    // epilogue: lane holds channels n0 + nt*16 + 4*lq + r (r<4) of point row0 + wave*32 + tt*16 + lr
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int p = row0 + wave * 32 + tt * 16 + lr;
-      const bool valid = p < P;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x4 v = acc[nt][tt];
-        const int n = n0 + nt * 16 + 4 * lq;
-        if (bias) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (n + r < N) ? bias[n + r] : 0.f;
-        }
-        if (STATS && valid) { s1[nt] += v; s2[nt] += v * v; }
-        if (valid) {
-          if (y_f32) {
-            float *o = (float *)Y + (size_t)p * ldy + n;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < n_store) o[r] = v[r];
-          } else if (n + 3 < n_store) {
-            bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            *(bf16x4 *)((unsigned short *)Y + (size_t)p * ldy + n) = o;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < n_store) ((unsigned short *)Y)[(size_t)p * ldy + n + r] = f2bf(v[r]);
-          }
-        }
-      }
-    }
+    c = nc;
+    tile = ntile;
   }
   if (STATS) {
 #pragma unroll
@@ -394,9 +496,179 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
     }
     __syncthreads();
     for (int e = t; e < 2 * BN; e += G_THREADS) {
-      const int which = e / BN, c = e - which * BN;
-      const float s = s_red[0][which][c] + s_red[1][which][c] + s_red[2][which][c] + s_red[3][which][c];
-      if (n0 + c < N) stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c] = s;
+      const int which = e / BN, c2 = e - which * BN;
+      const float s = s_red[0][which][c2] + s_red[1][which][c2] + s_red[2][which][c2] + s_red[3][which][c2];
+      if (n0 + c2 < N) stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c2] = s;
+    }
+  }
+}
+
+template <int LD>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned short *tile, int col0, int lane) {
+  // fragment F[x = lane&15][k = 8(lane>>4)+j] = tile[row k][col0 + x]  (tile rows = contraction index)
+  const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const unsigned short *a0 = tile + (8 * grp + q) * LD + col0 + 4 * pp;
+  const unsigned short *a1 = a0 + 4 * LD;
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);  // one whole-vector cast: element-wise casts of the tr-read result miscompile
+}
+
+// ---- small-P kernel (P <= 16384 rows: sa3, sfp1, sfp2 and their data gradients).
+// These layers move a few MB and are pure latency: with 128-row tiles they fill 16-128 workgroups and walk K
+// (up to 1280) chunk by chunk, 2-3 us of exposed memory latency per chunk.  Here a workgroup owns RT (32|64) rows x
+// 64 channels and its four waves SPLIT K (wave w takes the 32-wide k-steps w, w+4, ...): 4x-16x more workgroups,
+// a 4x shorter serial chain per wave, no LDS panel and no barrier inside the K loop.  A and W fragments go straight
+// from global memory (L2-resident after the first touch) into MFMA operand registers through a 2-slot register
+// pipeline of bounds-checked buffer loads (counted vmcnt waits).  For the data gradient (W stored [K,N]) a wave
+// bounces its 32 x 64 weight slice through a wave-private LDS tile and reads it back with ds_read_b64_tr_b16.
+// The four K-partial accumulators are summed through LDS in a fixed order; wave w finishes channels 16w..16w+15:
+// BatchNorm statistics by DPP row sums straight into the partial buffer, bf16 rows to Y.
+// Measured (rocprofv3, tools/smallp_probe.py: the 14 small-P launches of one GlobalSPFN step, operands cold):
+//   first version (128-row tiles, chunk-serial)   ~220 us     same with double-buffered panel   174 us
+//   this kernel                                    112 us     (2048 x 1280 -> 256: 43 -> 9.8 us)
+// What is left is launch + two memory round trips per workgroup: with stores, statistics and MFMAs removed the
+// sum only drops to 98 us.
+constexpr int SP_MAX_ROWS = 16384;
+constexpr int SP_SS_MAX = 512;
+constexpr int SP_DEPTH = 2;   // slots in flight per wave (4 measured slower on every shape: registers -> occupancy)
+// 64-row tiles halve the weight re-reads; 32-row tiles when that would leave fewer than 256 workgroups
+static inline int sp_rows(long long P, int N) { return ((P + 63) / 64) * (N / 64 > 0 ? N / 64 : 1) >= 256 ? 64 : 32; }
+
+template <int RT, bool STATS, bool WT>
+__global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
+    const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
+    int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift) {
+  constexpr int TT = RT / 16, D = SP_DEPTH, LDT = 64 + 8;
+  constexpr int RAW_TILE = 4 * 32 * LDT * 2, RAW_RED = 4 * 4 * TT * 64 * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW_TILE > RAW_RED ? RAW_TILE : RAW_RED];
+  __shared__ __attribute__((aligned(16))) float s_ss[2][SP_SS_MAX];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int n0 = blockIdx.y * 64, row0 = blockIdx.x * RT;
+  if (a_scale) {
+    for (int e = t; e < K; e += 256) { s_ss[0][e] = a_scale[e]; s_ss[1][e] = a_shift[e]; }
+    __syncthreads();
+  }
+  const int S = K / 32;
+  // Buffer loads (SGPR base + 32-bit lane offset, hardware bounds check): a pipeline slot past the end of K gets an
+  // out-of-range offset, which returns zeros WITHOUT touching memory — the loop body stays straight-line (counted
+  // vmcnt waits) and the tail slots cost nothing.  (Plain loads with clamped addresses re-read real data there:
+  // with K = 256 that was 4x the traffic, and the kernel was slower than the one it replaces.)
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, N * K * 2, 0x00020000);
+  unsigned aoff[TT];   // byte offsets
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    int p = row0 + tt * 16 + lr;
+    p = p < P ? p : P - 1;
+    aoff[tt] = ((unsigned)p * lda + 8 * lq) * 2;
+  }
+  unsigned woff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = lane + 64 * i;   // WT: 16-byte piece e of the [32 k][64 n] slice: k row e>>3, columns 8(e&7)..
+    woff[i] = WT ? ((unsigned)(e >> 3) * N + n0 + (e & 7) * 8) * 2 : ((unsigned)(n0 + i * 16 + lr) * K + 8 * lq) * 2;
+  }
+  const unsigned wstep = WT ? 32u * N * 2 : 64u;
+  unsigned short *tile = (unsigned short *)s_raw + wave * 32 * LDT;   // this wave's [32 k][64 n] slice (WT only)
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (a plain vector type: HIP's uint4 struct blocks SROA here)
+  u32x4 ra[D][TT];
+  u32x4 rw[D][4];
+  auto issue = [&](int d, int s) __attribute__((always_inline)) {
+    const unsigned oob = s < S ? 0u : 0x80000000u;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) ra[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (aoff[tt] + s * 64) | oob, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rw[d][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (woff[i] + s * wstep) | oob, 0, 0);
+  };
+  f32x4 acc[4][TT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[i][tt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d, wave + 4 * d);
+  const int cnt = (S + 3) / 4;
+  // (one instantiation of the stage body per pipeline slot: the slot index must be a compile-time constant so that
+  //  ra / rw stay in registers)
+  auto stage = [&](auto slot, int i0) __attribute__((always_inline)) {
+      constexpr int d = decltype(slot)::value;
+      const int s = wave + 4 * (i0 + d);
+      if (s < S) {
+        bf16x8 af[TT], wf[4];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) af[tt] = __builtin_bit_cast(bf16x8, ra[d][tt]);
+        if (WT) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = lane + 64 * i;
+            *(u32x4 *)&tile[(e >> 3) * LDT + (e & 7) * 8] = rw[d][i];
+          }
+          // (wave-private tile: LDS executes one wave's instructions in order, and the compiler keeps the
+          //  may-alias write -> transposing read -> next write order: no barrier of any kind is needed)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wf[i] = tr_frag<LDT>(tile, i * 16, lane);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(bf16x8, rw[d][i]);
+        }
+        if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
+          float sc[8], sh[8];
+          const int k0 = s * 32 + 8 * lq;
+          *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[0][k0]; *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[0][k0 + 4];
+          *(cpfn_f32x4 *)&sh[0] = *(const cpfn_f32x4 *)&s_ss[1][k0]; *(cpfn_f32x4 *)&sh[4] = *(const cpfn_f32x4 *)&s_ss[1][k0 + 4];
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) af[tt] = bn_relu_frag(af[tt], sc, sh);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt)
+            acc[i][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[tt], acc[i][tt], 0, 0, 0);
+      }
+      // the slot is refilled AFTER its operands were consumed (no register copies: occupancy, not per-wave depth,
+      // is what hides the latency here — measured: depth 2 beats depth 4 on every shape)
+      issue(d, wave + 4 * (i0 + d + D));
+  };
+  static_assert(D == 2, "the pipeline slots are spelled out below");
+  for (int i0 = 0; i0 < cnt; i0 += D) {
+    stage(std::integral_constant<int, 0>{}, i0);
+    stage(std::integral_constant<int, 1>{}, i0);
+  }
+  // K-partials of the four waves -> LDS in register layout [src wave][nt][tt][lane] (conflict-free 16-byte stores);
+  // wave w then owns channel block nt = w and adds the four partials in wave order (fixed: reproducible)
+  __syncthreads();   // the tiles are dead (s_raw is reused)
+  f32x4 *s_part = (f32x4 *)s_raw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) s_part[((wave * 4 + i) * TT + tt) * 64 + lane] = acc[i][tt];
+  __syncthreads();
+  const int n = n0 + wave * 16 + 4 * lq;
+  f32x4 sm = {0, 0, 0, 0}, sq = {0, 0, 0, 0};
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    f32x4 v = s_part[((0 * 4 + wave) * TT + tt) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += s_part[((w * 4 + wave) * TT + tt) * 64 + lane];
+    const int p = row0 + tt * 16 + lr;
+    if (p < P) {
+      if (STATS) { sm += v; sq += v * v; }
+      bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      *(bf16x4 *)(Y + (size_t)p * ldy + n) = o;
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
+    if (lr == 0) {
+      *(f32x4 *)&stats_partial[((size_t)blockIdx.x * 2 + 0) * N + n] = sm;
+      *(f32x4 *)&stats_partial[((size_t)blockIdx.x * 2 + 1) * N + n] = sq;
     }
   }
 }
@@ -742,20 +1014,6 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
 constexpr int WG_STEP = 32;       // rows per MFMA step
 constexpr int WG_DEPTH = 4;       // steps in flight
 
-template <int LD>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned short *tile, int col0, int lane) {
-  // fragment F[x = lane&15][k = 8(lane>>4)+j] = tile[row k][col0 + x]  (tile rows = contraction index)
-  const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const unsigned short *a0 = tile + (8 * grp + q) * LD + col0 + 4 * pp;
-  const unsigned short *a1 = a0 + 4 * LD;
-  typedef s16x4 __attribute__((address_space(3))) * lds_p;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);  // one whole-vector cast: element-wise casts of the tr-read result miscompile
-}
-
 template <int TN, int TK>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
                                                         const unsigned short *__restrict__ A, int lda,
@@ -1065,6 +1323,7 @@ inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   // number of row-blocks (gridDim.x) the GEMM will use == rows of its stats-partial buffer
+  if (P > 0 && P <= SP_MAX_ROWS) return (int)((P + sp_rows(P, N) - 1) / sp_rows(P, N));   // small-P kernel: one per row tile
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
   const int ny = (N + 127) / 128 > 0 ? (N + 127) / 128 : 1;
   long long tpw = tiles * ny / 512;  // aim for ~512 workgroups (256 and 1024 measured: within 4 % / 10 % slower)
@@ -1083,8 +1342,24 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   hipStream_t st = (hipStream_t)stream;
   const int gx = cpfn_mlp_gemm_blocks(P, N);
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
-  const int tpw = (int)((tiles + gx - 1) / gx);
+  const int tpw = (int)((tiles + gx - 1) / gx);   // (gx > tiles for small P: the surplus workgroups write zero statistics)
   const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
+  if (P <= SP_MAX_ROWS && !gidx && !bias && !y_f32 && n_store == N && (ldy & 3) == 0 && (!a_scale || K <= SP_SS_MAX) &&
+      P * lda * 2 < (1LL << 31) && (long long)N * K * 2 < (1LL << 31)) {
+    unsigned short *y = (unsigned short *)Y;
+    dim3 grid(gx, N / 64);
+    const int a_bytes = (int)(((P - 1) * lda + K) * 2);
+#define CPFN_SMALLP(RT_)                                                                                              \
+  do {                                                                                                                \
+    if (stats_partial && w_trans) mlp_gemm_smallp_kernel<RT_, true, true><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift);  \
+    else if (stats_partial) mlp_gemm_smallp_kernel<RT_, true, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift);       \
+    else if (w_trans) mlp_gemm_smallp_kernel<RT_, false, true><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, nullptr, a_scale, a_shift);                  \
+    else mlp_gemm_smallp_kernel<RT_, false, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, nullptr, a_scale, a_shift);                             \
+  } while (0)
+    if (sp_rows(P, N) == 32) CPFN_SMALLP(32); else CPFN_SMALLP(64);
+#undef CPFN_SMALLP
+    return cpfn_launch_status();
+  }
   // whole-K panel in LDS: K <= 256.  K = 192 / 256 only for the long layers: with few row tiles the 50-68 KB panel
   // (cold in a real step, unlike in a micro-benchmark loop) costs more than the generic kernel's 128-wide K chunks
   const bool stream_k = K == 64 || K == 128 || ((K == 192 || K == 256) && P >= 32768);

@@ -232,7 +232,10 @@ CPFN_API int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, voi
  * stats_partial (optional): [cpfn_mlp_gemm_blocks(P,N)][2][N] fp32 per-block sum(y), sum(y^2).
  * a_scale, a_shift (optional, [K] fp32, both or neither): A holds the PREVIOUS layer's pre-BN output and
  * the operand is relu(a_scale*A + a_shift) rounded to bf16, applied on the fly (bit-identical to
- * cpfn_bn_relu_apply followed by a plain call; the activated tensor is never materialised). */
+ * cpfn_bn_relu_apply followed by a plain call; the activated tensor is never materialised).
+ * Three kernels behind the one entry point: P <= 16384 rows -> split-K small-P kernel (32|64 rows x 64 channels per
+ * workgroup); K in {64,128} (and {192,256} for P >= 32768) -> whole-K streaming kernel; everything else (bias, fp32
+ * or ragged output, gather, other K) -> 128-wide K chunks through a double-buffered LDS panel. */
 CPFN_API int cpfn_mlp_gemm_blocks(long long P, int N);
 CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,

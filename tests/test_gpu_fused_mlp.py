@@ -174,3 +174,42 @@ def test_heads_linear():
     for p, r in zip(heads.parameters(), ref):
         assert _rel(p.grad, r) < 3e-2
     assert _rel(f2.grad, gx_ref) < 3e-2
+
+
+@pytest.mark.parametrize("P,K,N", [
+    (1, 32, 64), (31, 96, 64), (33, 320, 320), (2048, 1280, 256), (2048, 512, 1024), (4096, 64, 128), (4097, 256, 128),
+    (8192, 384, 256), (16384, 128, 64), (16385, 128, 128), (5000, 1056, 192), (40000, 320, 128), (33000, 256, 256),
+])
+@pytest.mark.parametrize("w_trans", [False, True])
+@pytest.mark.parametrize("mode", ["plain", "stats", "stats+atr", "gather"])
+def test_gemm_every_dispatch_path(P, K, N, w_trans, mode):
+    """cpfn_mlp_gemm through all of its kernels (small-P split-K, whole-K stream, generic chunked) against an fp32
+    matmul of the same bf16 operands: output within one bf16 rounding, BatchNorm partial sums within fp32 noise."""
+    from cpfn_amd import fused_mlp
+    g = torch.Generator().manual_seed(P * 7 + K + N)
+    rows = P + 50 if mode == "gather" else P
+    A = torch.randn(rows, K, generator=g).to(dev()).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev()).to(torch.bfloat16)
+    kw = {}
+    a_eff = A.float()
+    if mode == "gather":
+        idx = torch.randint(0, rows, (P,), generator=g).to(dev()).int()
+        kw["gidx"] = idx
+        a_eff = a_eff[idx.long()]
+    if mode == "stats+atr":
+        sc = (torch.rand(K, generator=g) + 0.5).to(dev())
+        sh = (torch.rand(K, generator=g) - 0.5).to(dev())
+        kw.update(a_scale=sc, a_shift=sh)
+        a_eff = torch.relu(a_eff * sc + sh).to(torch.bfloat16).float()
+    Wk = W.t().contiguous() if w_trans else W
+    Y, part, nblk = fused_mlp.gemm(A, Wk, stats=mode.startswith("stats"), w_trans=w_trans, **kw)
+    ref = a_eff @ W.float().t()
+    assert Y.shape == (P, N) and Y.dtype == torch.bfloat16
+    err = (Y.float() - ref).abs()
+    assert float((err - ref.abs() * 2.0 ** -8).max()) <= 1e-3 * float(ref.abs().max()), float(err.max())
+    if mode.startswith("stats"):
+        assert part.shape == (nblk, 2, N)
+        s = part.double().sum(0)
+        scale = float(ref.abs().max())
+        assert float((s[0] - ref.double().sum(0)).abs().max()) <= 2e-4 * scale * P ** 0.5 + 1e-3
+        assert float((s[1] - (ref.double() ** 2).sum(0)).abs().max()) <= 1e-3 * float((ref.double() ** 2).sum(0).max())
