@@ -30,6 +30,7 @@ SOURCES = {
     "fit_algebra.hip": ["-ffp-contract=off"],
     "mlp.hip": [],
     "losses.hip": [],
+    "merging.hip": [],
     "optim.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",

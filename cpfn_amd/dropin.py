@@ -32,6 +32,7 @@ _ALIASES = {
     "SPFN.metric_implementation": "cpfn_amd.SPFN.metric_implementation",
     "SPFN.geometry_utils": "cpfn_amd.SPFN.geometry_utils",
     "SPFN.differentiable_tls": "cpfn_amd.SPFN.differentiable_tls",
+    "Utils.merging_utils": "cpfn_amd.Utils.merging_utils",
 }
 
 

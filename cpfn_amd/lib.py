@@ -52,6 +52,9 @@ SIGNATURES = {
     "cpfn_p_coverage": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cpfn_loss_tail": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_eigh3": [_vp, _i64, _vp, _vp, _vp],
+    "cpfn_similarity_soft_workspace": [_i, _i, _i, _i, _i],
+    "cpfn_similarity_soft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_label_pool": [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp],
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -77,7 +80,7 @@ SIGNATURES = {
     "cpfn_residue_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_residue_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
 }
-_RESTYPES = {"cpfn_build_info": ctypes.c_char_p}
+_RESTYPES = {"cpfn_build_info": ctypes.c_char_p, "cpfn_similarity_soft_workspace": ctypes.c_longlong}
 
 _lib = None
 _raw = None

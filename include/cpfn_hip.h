@@ -373,6 +373,26 @@ CPFN_API int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long l
                             float beta1, float beta2, float eps, float weight_decay, float *step,
                             double *pows, const float *found_inf, float *coef3, void *stream);
 
+/* ------------------------------------------------------------------ patch merging (evaluation, config 5)
+ * Replaces the two tensor functions of Utils/merging_utils.py that evaluation_localSPFN.py:101-110 runs on
+ * the device.
+ *
+ * cpfn_similarity_soft (merging_utils.py:6-15): Gram matrix out[C,C] (C = nb*Lp + Lo, fp32) of the
+ * point-to-primitive matrix whose columns b*Lp..(b+1)*Lp hold predicted_labels[b] [npp, Lp] scattered to the rows
+ * point_indices[b] [npp] (int64, values in [0,N), no repeats inside a patch) and whose last Lo columns hold
+ * spfn_labels [N, Lo] (fp32).  The dense matrix is never built.  Lp, Lo <= 32.  workspace: device memory of
+ * cpfn_similarity_soft_workspace(...) bytes (256-byte aligned).
+ *
+ * cpfn_label_pool (merging_utils.py:56-60, get_point_final): out[N,G] with out[p][g] = (sum of M[p][c] over the
+ * columns c with labels[c] == g, ascending c) / (number of such columns + 1e-10).  labels: C int64 values (those
+ * outside [0,G) are ignored).  workspace: (C + 2*G + 2) * 4 bytes of device scratch.  C <= 12288, G <= 16384. */
+CPFN_API long long cpfn_similarity_soft_workspace(int N, int nb, int npp, int Lp, int Lo);
+CPFN_API int cpfn_similarity_soft(const float *spfn_labels, const float *predicted_labels,
+                                  const int64_t *point_indices, int N, int nb, int npp, int Lp, int Lo,
+                                  void *workspace, float *out, void *stream);
+CPFN_API int cpfn_label_pool(const float *M, const int64_t *labels, long long N, int C, int G, void *workspace,
+                             float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,3 +53,35 @@ def test_state_dict_keys_match_reference_layout():
         assert list(sd.keys()) == list(shapes.keys())
         assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in sd)
     assert sum(p.numel() for p in pn2_network.PointNet2(3, 3, [3, 4, 28]).parameters()) == 1406307
+
+
+def test_merging_utils_alias_keeps_the_host_solver_of_the_reference(tmp_path):
+    """`Utils.merging_utils` resolves to the HIP-backed module; names it does not define (the greedy host solver)
+    come from the reference's own file found on sys.path."""
+    import cpfn_amd.dropin as d
+    (tmp_path / "Utils").mkdir()
+    (tmp_path / "Utils" / "__init__.py").write_text("")
+    (tmp_path / "Utils" / "merging_utils.py").write_text(
+        "def run_heuristic_solver(*a, **k):\n    return 'host solver of the reference'\n"
+        "def similarity_soft(*a):\n    raise AssertionError('must not be reached')\n")
+    saved = {k: sys.modules.get(k) for k in list(d._ALIASES) + ["Utils"]}
+    sys.path.insert(0, str(tmp_path))
+    try:
+        d.install()
+        import cpfn_amd.Utils.merging_utils as mine
+        mine._reference_module = None
+        from Utils import merging_utils
+        assert merging_utils is mine
+        assert merging_utils.similarity_soft.__module__ == "cpfn_amd.Utils.merging_utils"
+        assert merging_utils.get_point_final.__module__ == "cpfn_amd.Utils.merging_utils"
+        assert merging_utils.run_heuristic_solver() == "host solver of the reference"
+        assert list(inspect.signature(merging_utils.similarity_soft).parameters) == ["spfn_labels", "predicted_labels", "point_indices"]
+        assert list(inspect.signature(merging_utils.get_point_final).parameters) == ["point2primitive_prediction", "output_labels_heuristic"]
+    finally:
+        sys.path.remove(str(tmp_path))
+        mine._reference_module = None
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

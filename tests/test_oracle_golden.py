@@ -186,3 +186,20 @@ def test_metrics_oracle_matches_reference_fixture(golden):
     # coverages are counts of points under a threshold: allow a handful of points to sit on the boundary
     np.testing.assert_allclose(out["Sk_coverage"].numpy(), g["Sk_coverage"], atol=3.0 / 512)
     np.testing.assert_allclose(out["P_coverage"].numpy(), g["P_coverage"], atol=3.0 / 2048)
+
+
+def test_merging_oracle_matches_reference_fixture(golden):
+    """oracle/merging.py against the reference's similarity_soft / get_point_final (fixture generated by running
+    those two functions of Utils/merging_utils.py)."""
+    from oracle import merging as om
+    g = golden("merging_small.npz")
+    sim = om.similarity_soft(g["spfn_labels"], g["predicted_labels"], g["point_indices"])
+    np.testing.assert_allclose(sim, g["similarity"], rtol=2e-5, atol=1e-5)
+    sim32 = om.similarity_soft(g["spfn_labels"], g["predicted_labels"], g["point_indices"], dtype=np.float32)
+    np.testing.assert_allclose(sim32, g["similarity"], rtol=2e-5, atol=1e-5)
+    M = om.point2primitive(g["spfn_labels"], g["predicted_labels"], g["point_indices"])
+    covered = M[:, :-g["spfn_labels"].shape[1]].sum(1) > 0              # the caller zeroes the global labels there
+    M[covered, -g["spfn_labels"].shape[1]:] = 0
+    np.testing.assert_array_equal(M, g["point2primitive"])
+    fin = om.get_point_final(g["point2primitive"], g["merged_labels"])
+    np.testing.assert_allclose(fin, g["point_final"], rtol=1e-5, atol=1e-7)
