@@ -1296,20 +1296,27 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short 
 // column sums of a row-major fp32 matrix X[P,C] (C <= 64): partial[gridDim.x][C], then split_reduce.
 // (bias gradient of the heads: torch's strided reduce takes 0.66 ms and rocBLAS gemv 0.8 ms for [131072,35].)
 constexpr int CS_ROWS = 256;   // rows per workgroup
+// pad_bf16 (optional): the same pass also writes the rows as bf16 with 64 columns (X | zeros) — the padded
+// gradient operand of the heads' weight / data gradient GEMMs (was torch.zeros [P,64] + a strided slice copy).
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float *__restrict__ X, long long P, int C,
-                                                         float *__restrict__ partial) {
+                                                         float *__restrict__ partial,
+                                                         unsigned short *__restrict__ pad_bf16) {
   __shared__ float s_acc[4][64];
   const int t = threadIdx.x, c = t & 63, rs = t >> 6;
   const long long row0 = (long long)blockIdx.x * CS_ROWS, rend = min(P, row0 + CS_ROWS);
+  const int cc = c < C ? c : C - 1;
   float a = 0.f;
-  if (c < C)
-    for (long long r = row0 + rs; r < rend; r += 32) {          // eight rows in flight per lane
-      float v[8];
+  for (long long r = row0 + rs; r < rend; r += 32) {          // eight rows in flight per lane
+    float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = X[min(r + 4 * u, rend - 1) * C + c];
+    for (int u = 0; u < 8; ++u) v[u] = X[min(r + 4 * u, rend - 1) * C + cc];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += (r + 4 * u < rend) ? v[u] : 0.f;
+    for (int u = 0; u < 8; ++u) {
+      const float x = (c < C && r + 4 * u < rend) ? v[u] : 0.f;
+      a += x;
+      if (pad_bf16 && r + 4 * u < rend) pad_bf16[(r + 4 * u) * 64 + c] = f2bf(x);
     }
+  }
   s_acc[rs][c] = a;
   __syncthreads();
   if (t < C) partial[(size_t)blockIdx.x * C + t] = s_acc[0][t] + s_acc[1][t] + s_acc[2][t] + s_acc[3][t];
@@ -1571,11 +1578,12 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *stream) {
+extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *pad_bf16,
+                               void *stream) {
   if (P <= 0 || C <= 0 || C > 64 || !X || !workspace || !out) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (int)((P + CS_ROWS - 1) / CS_ROWS);
-  colsum_f32_kernel<<<nblk, 256, 0, st>>>(X, P, C, workspace);
+  colsum_f32_kernel<<<nblk, 256, 0, st>>>(X, P, C, workspace, (unsigned short *)pad_bf16);
   launch_split_reduce(workspace, nblk, C, out, st);
   return cpfn_launch_status();
 }

@@ -147,6 +147,19 @@ def bf16_weight(W, rows, cols):
 _refresh_epoch = [0]
 
 
+def _foreach_copy_by_dtype(dst, src):
+    """torch._foreach_copy_ per destination dtype: with bf16 and fp32 destinations in ONE list the multi-tensor
+    kernel is instantiated for the first pair's dtypes and writes garbage into the others (seen on ROCm 7.0 /
+    torch 2.10: the fp32 bias slices of the packed heads panel)."""
+    groups = {}
+    for d, s_ in zip(dst, src):
+        groups.setdefault((d.dtype, s_.dtype), ([], []))
+        groups[(d.dtype, s_.dtype)][0].append(d)
+        groups[(d.dtype, s_.dtype)][1].append(s_)
+    for d, s_ in groups.values():
+        torch._foreach_copy_(d, s_)
+
+
 def refresh_weight_panels(params):
     """Refresh the bf16 panels of all `params` (nn.Parameters that already have one) with ONE multi-tensor
     copy instead of one conversion kernel per layer (~20 launches, 0.1 ms per step).  Called at the start of a
@@ -164,10 +177,20 @@ def refresh_weight_panels(params):
             dst.append(ent[0])
             src.append(w2)
             ents.append(ent)
+    packed = []
+    for ent in _packed.values():                 # the packed panels of the heads ride along
+        ts = [r() for r in ent["refs"]]
+        if any(t is None or id(t) not in want for t in ts) or ent["Wb"].device != ts[0].device:
+            continue
+        dst += ent["dst"]
+        src += [t.detach().reshape(t.shape[0], -1) if t.dim() > 1 else t.detach() for t in ts]
+        packed.append(ent)
     if dst:
-        torch._foreach_copy_(dst, src)
+        _foreach_copy_by_dtype(dst, src)
         for ent in ents:
             ent[2] = _refresh_epoch[0]
+        for ent in packed:
+            ent["epoch"] = _refresh_epoch[0]
 
 
 # ------------------------------------------------------------------ the stack
@@ -371,21 +394,50 @@ def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False):
     return _FusedStack.apply(x, cfg, *params)
 
 
+# Packed, zero-padded bf16 panel of several heads' weights ([sum(o_i) -> 64k rows, K]) + fp32 bias vector, kept across
+# steps and refreshed by refresh_weight_panels() in its one multi-tensor copy (was: 2 cats + 2 zeros + 2 slice copies
+# per forward pass).
+_packed = {}
+
+
+def _packed_heads(weights, biases):
+    key = tuple(id(w) for w in weights) + tuple(id(b) for b in biases)
+    ent = _packed.get(key)
+    dev = weights[0].device
+    if ent is None or any(r() is not t for r, t in zip(ent["refs"], list(weights) + list(biases))) or ent["Wb"].device != dev:
+        N = sum(w.shape[0] for w in weights)
+        K = weights[0].reshape(weights[0].shape[0], -1).shape[1]
+        Wb = torch.zeros(_pad_to(N, 64), K, dtype=BF16, device=dev)
+        bp = torch.zeros(_pad_to(N, 64), dtype=torch.float32, device=dev)
+        dst, o = [], 0
+        for w in weights:
+            dst.append(Wb[o:o + w.shape[0]])
+            o += w.shape[0]
+        o = 0
+        for b in biases:
+            dst.append(bp[o:o + b.shape[0]])
+            o += b.shape[0]
+        ent = {"Wb": Wb, "bp": bp, "dst": dst, "refs": [weakref.ref(t) for t in list(weights) + list(biases)], "epoch": -1,
+               "N": N}
+        _packed[key] = ent
+    if ent["epoch"] != _refresh_epoch[0]:        # not covered by this forward pass's refresh_weight_panels()
+        src = [w.detach().reshape(w.shape[0], -1) for w in weights] + [b.detach() for b in biases]
+        _foreach_copy_by_dtype(ent["dst"], src)
+    return ent["Wb"], ent["bp"], ent["N"]
+
+
 class _Linear(torch.autograd.Function):
-    """Y = A·Wᵀ + b with bf16 operands and fp32 output (the fc2 heads; no batch-norm)."""
+    """Y = A·Wᵀ + b with bf16 operands and fp32 output (the fc2 heads; no batch-norm).  Wb / bp: the packed padded
+    panel of _packed_heads; the heads' own parameters come in as *wb so that their gradients are routed back."""
 
     @staticmethod
-    def forward(ctx, a, W, bias, n_real):
-        N, K = W.shape
-        Np = _pad_to(N, 64)
-        Wb = torch.zeros(Np, K, dtype=BF16, device=a.device)
-        Wb[:N] = W.detach()
-        bp = torch.zeros(Np, dtype=torch.float32, device=a.device)
-        bp[:N] = bias.detach()
+    def forward(ctx, a, Wb, bp, N, nheads, *wb):
         with torch.cuda.device(a.device):
             Y, _, _ = gemm(a, Wb, bias=bp, out_f32=True, n_store=N)
         ctx.save_for_backward(a, Wb)
         ctx.n = N
+        ctx.sizes = [t.shape[0] for t in wb[:nheads]]
+        ctx.wshapes = [tuple(t.shape) for t in wb[:nheads]]
         return Y
 
     @staticmethod
@@ -394,29 +446,37 @@ class _Linear(torch.autograd.Function):
         h = _l.lib()
         N, P, K = ctx.n, a.shape[0], a.shape[1]
         Np = Wb.shape[0]
-        gb = torch.zeros(P, Np, dtype=BF16, device=a.device)
-        gb[:, :N] = g
+        gc = g.contiguous().float()
+        fused_pad = Np == 64
+        gb = torch.empty(P, Np, dtype=BF16, device=a.device) if fused_pad else torch.zeros(P, Np, dtype=BF16, device=a.device)
+        if not fused_pad:
+            gb[:, :N] = g
+        # bias gradient = column sums of g (torch's strided reduce: 0.66 ms, rocBLAS gemv: 0.8 ms for [131072,35]);
+        # the same pass writes the padded bf16 operand of the two GEMMs below
+        gbias = torch.empty(N, dtype=torch.float32, device=a.device)
+        wsb = torch.empty(((P + 255) // 256) * N, dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device):
+            _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), _ptr(gbias), _ptr(gb) if fused_pad else None, _stream()),
+                   "cpfn_colsum_f32")
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
             dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
             _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), _ptr(dW), _stream()),
                    "cpfn_mlp_wgrad")
             ga, _, _ = gemm(gb, Wb, w_trans=True)
-        # bias gradient = column sums of g (torch's strided reduce: 0.66 ms, rocBLAS gemv: 0.8 ms for [131072,35])
-        gc = g.contiguous().float()
-        gbias = torch.empty(N, dtype=torch.float32, device=a.device)
-        wsb = torch.empty(((P + 255) // 256) * N, dtype=torch.float32, device=a.device)
-        with torch.cuda.device(a.device):
-            _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), _ptr(gbias), _stream()), "cpfn_colsum_f32")
-        return ga, dW[:N], gbias, None
+        gw, gbs, o = [], [], 0
+        for n, shp in zip(ctx.sizes, ctx.wshapes):
+            gw.append(dW[o:o + n].reshape(shp))
+            gbs.append(gbias[o:o + n])
+            o += n
+        return (ga, None, None, None, None) + tuple(gw) + tuple(gbs)
 
 
 def linear_heads(a, weights, biases):
     """a bf16 [P,K]; several (weight [o_i,K,1], bias [o_i]) heads computed as ONE GEMM."""
-    W = torch.cat([w.reshape(w.shape[0], -1) for w in weights], 0)
-    b = torch.cat(list(biases), 0)
-    Y = _Linear.apply(a, W, b, W.shape[0])
+    weights, biases = list(weights), list(biases)
+    Wb, bp, N = _packed_heads(weights, biases)
+    Y = _Linear.apply(a, Wb, bp, N, len(weights), *weights, *biases)
     linear_heads.last_packed = Y          # [P, sum(o_i)] fp32, for consumers that want the heads fused
     outs, o = [], 0
     for w in weights:

@@ -281,8 +281,9 @@ CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, con
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,
                             float *dW, void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
- * workspace: ceil(P/256)*C floats. */
-CPFN_API int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out,
+ * workspace: ceil(P/256)*C floats.  pad_bf16 (optional): [P,64] bf16, receives the rows of X converted to bf16
+ * and zero-padded to 64 columns in the same pass (the gradient operand of the heads' GEMMs). */
+CPFN_API int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *pad_bf16,
                              void *stream);
 /* fp32 first layer with K = KS <= 4 inputs (sa1: relative xyz stay fp32):
  * Y[P,C] bf16 = X[P,KS] . W[C,KS]^T, partial[cpfn_bn_bwd_blocks(P)][2][C]; and its weight gradient
