@@ -7,12 +7,19 @@ outputs are transposed views.  Quirk kept on purpose: dropout(p=0.5) is applied 
 mode, as in the reference (pn2_network.py:63 calls F.dropout with its default
 training=True); set `self.dropout_p = 0.0` to neutralise it for parity tests.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 from .. import mlp
 from .pointnet2_ops.modules.pointset_abstraction import PointsetAbstraction
 from .pointnet2_ops.modules.pointset_feature_propagation import PointsetFeaturePropagation
+
+
+# CPFN_FUSED_DROPOUT=0: F.dropout as separate PyTorch kernels (mask tensor) instead of the mask generated inside the
+# BatchNorm apply / backward kernels
+FUSED_DROPOUT = os.environ.get("CPFN_FUSED_DROPOUT", "1") != "0"
 
 
 class PointNet2(torch.nn.Module):
@@ -24,6 +31,8 @@ class PointNet2(torch.nn.Module):
         self.use_loc_features = use_loc_features
         self.features_extractor = features_extractor
         self.dropout_p = 0.5
+        self._dropout_counter = None          # device step counter of the fused dropout (bf16 HIP path)
+        self._dropout_base = 0
         extra = (1024 if use_glob_features else 0) + (128 if use_loc_features else 0)
         self.sa1 = PointsetAbstraction(512, dim_pos, dim_input - dim_pos, [0.2], [64], [[64, 64, 128]])
         self.sa2 = PointsetAbstraction(128, dim_pos, 128, [0.4], [64], [[128, 128, 256]])
@@ -85,8 +94,20 @@ class PointNet2(torch.nn.Module):
         if self.features_extractor:
             feat = mlp.conv_as_linear(l6.reshape(B * N, -1).to(cd), self.fc1).float()
             return l3_out, feat.reshape(B, N, -1).transpose(1, 2)
-        feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd)           # fc1 + bn1 + relu (ref :60-62)
-        feat = F.dropout(feat, p=self.dropout_p, training=True)                            # always on (ref :63)
+        if cd == torch.bfloat16 and l6.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT:
+            # fc1 + bn1 + relu + the always-on dropout (ref :60-63) with the mask generated inside the BN apply kernel
+            # and regenerated in the backward passes (no mask tensor, no separate dropout kernels)
+            if self._dropout_counter is None or self._dropout_counter.device != l6.device:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("run one eager forward pass before capturing a graph (the dropout step counter "
+                                       "must exist outside the captured region)")
+                self._dropout_counter = torch.zeros(1, dtype=torch.int64, device=l6.device)
+                self._dropout_base = torch.initial_seed() ^ 0x5DEECE66D
+            feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd,
+                                 dropout=(self.dropout_p, self._dropout_counter, self._dropout_base))
+        else:
+            feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd)       # fc1 + bn1 + relu (ref :60-62)
+            feat = F.dropout(feat, p=self.dropout_p, training=True)                        # always on (ref :63)
         results = [r.reshape(B, N, -1) for r in mlp.heads(feat, self.fc2, cd)]
         self.heads_packed = None
         if cd == torch.bfloat16 and feat.is_cuda:

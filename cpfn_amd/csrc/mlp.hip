@@ -730,18 +730,58 @@ __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restri
 
 // ---------------------------------------------------------------- normalise + ReLU (+ max-pool)
 // out[p,c] = relu(scale[c]·y[p,c] + shift[c]); 8 channels (16 B) per lane.
+// ---- dropout fused into the BatchNorm apply passes (the reference applies F.dropout(p = 0.5) to the fc1
+// features in every mode, PointNet2/pn2_network.py:63; as PyTorch ops that is a mask-producing kernel in the forward
+// pass and a masked-scale kernel in the backward pass over [B*N, 128]).  Counter-based: element chunk e (8 consecutive
+// channels of one point) keeps element j iff the j-th 16-bit field of splitmix64(seed, e) is >= p * 65536, so the
+// backward passes recompute the mask from the 8-byte seed instead of reading a stored one.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// keep[j] for the 8 elements of chunk e: scale factor (1/(1-p)) or 0
+__device__ __forceinline__ void dropout_factors(unsigned long long seed, unsigned long long e, unsigned thresh16,
+                                                float inv_keep, float (&f)[8]) {
+  const unsigned long long h0 = splitmix64(seed ^ (2 * e)), h1 = splitmix64(seed ^ (2 * e + 1));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[j] = ((unsigned)(h0 >> (16 * j)) & 0xffffu) >= thresh16 ? inv_keep : 0.f;
+    f[4 + j] = ((unsigned)(h1 >> (16 * j)) & 0xffffu) >= thresh16 ? inv_keep : 0.f;
+  }
+}
+__host__ __device__ inline unsigned dropout_thresh16(float p) {
+  const float t = p * 65536.f + 0.5f;
+  return t <= 0.f ? 0u : (t >= 65536.f ? 65536u : (unsigned)t);
+}
+
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const unsigned short *__restrict__ Yr,
                                                             const float *__restrict__ scale,
                                                             const float *__restrict__ shift, long long total8,
-                                                            int C, unsigned short *__restrict__ out) {
+                                                            int C, unsigned short *__restrict__ out,
+                                                            const long long *__restrict__ drop_counter,
+                                                            unsigned long long drop_base, unsigned thresh16,
+                                                            float inv_keep, unsigned long long *__restrict__ drop_seed_out) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long seed = 0;
+  if (drop_counter) {
+    seed = splitmix64(drop_base + 0xD1B54A32D192ED03ull * (unsigned long long)*drop_counter);
+    if (e == 0) *drop_seed_out = seed;            // the backward passes of THIS forward pass read it from here
+  }
   if (e >= total8) return;
   const int c0 = (int)((e * 8) % C);
   const uint4 raw = *(const uint4 *)(Yr + e * 8);
   const unsigned short *y = (const unsigned short *)&raw;
+  float f[8];
+  if (drop_counter) dropout_factors(seed, (unsigned long long)e, thresh16, inv_keep, f);
   unsigned short o[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = f2bf(fmaxf(fmaf(scale[c0 + j], bf2f(y[j]), shift[c0 + j]), 0.f));
+  for (int j = 0; j < 8; ++j) {
+    float v = fmaxf(fmaf(scale[c0 + j], bf2f(y[j]), shift[c0 + j]), 0.f);
+    if (drop_counter) v *= f[j];
+    o[j] = f2bf(v);
+  }
   *(uint4 *)(out + e * 8) = *(const uint4 *)o;
 }
 
@@ -836,8 +876,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, long long P, int C,
                                                           unsigned short *__restrict__ Gz,
-                                                          float *__restrict__ partial, int rpb) {
+                                                          float *__restrict__ partial, int rpb,
+                                                          const unsigned long long *__restrict__ drop_seed,
+                                                          unsigned thresh16, float inv_keep) {
   __shared__ float s_red[2][256][8 + 1];
+  const unsigned long long seed = drop_seed ? *drop_seed : 0ull;
   const int t = threadIdx.x;
   const int chunks = C / 8;
   const long long row0 = (long long)blockIdx.x * rpb;
@@ -870,10 +913,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
           const bool live = rr < rend;
           const unsigned short *g = (const unsigned short *)&rg[u], *y = (const unsigned short *)&ry[u];
           unsigned short o[8];
+          float f[8];
+          if (drop_seed) dropout_factors(seed, (unsigned long long)((min(rr, rend - 1) * C + c0) >> 3), thresh16, inv_keep, f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float yv = bf2f(y[j]);
-            const float gz = (live && fmaf(sc[j], yv, sh[j]) > 0.f) ? bf2f(g[j]) : 0.f;
+            float ga = bf2f(g[j]);
+            if (drop_seed) ga *= f[j];              // incoming gradient is w.r.t. the dropped activation
+            const float gz = (live && fmaf(sc[j], yv, sh[j]) > 0.f) ? ga : 0.f;
             o[j] = f2bf(gz);
             a1[j] += gz;
             a2[j] = fmaf(gz, yv, a2[j]);
@@ -930,10 +977,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short 
                                                            const float *__restrict__ coef,
                                                            const float *__restrict__ scale,
                                                            const float *__restrict__ shift, long long total8,
-                                                           int C, unsigned short *__restrict__ Gy) {
+                                                           int C, unsigned short *__restrict__ Gy,
+                                                           const unsigned long long *__restrict__ drop_seed,
+                                                           unsigned thresh16, float inv_keep) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total8) return;
   const int c0 = (int)((e * 8) % C);
+  float f[8];
+  if (drop_seed) dropout_factors(*drop_seed, (unsigned long long)e, thresh16, inv_keep, f);
   const uint4 rg = *(const uint4 *)(Gz + e * 8);
   const uint4 ry = *(const uint4 *)(Yr + e * 8);
   const unsigned short *g = (const unsigned short *)&rg, *y = (const unsigned short *)&ry;
@@ -942,6 +993,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short 
   for (int j = 0; j < 8; ++j) {
     const float yv = bf2f(y[j]);
     float gz = bf2f(g[j]);
+    if (drop_seed) gz *= f[j];
     if (MASK) gz = fmaf(scale[c0 + j], yv, shift[c0 + j]) > 0.f ? gz : 0.f;
     o[j] = f2bf(fmaf(coef[c0 + j], gz, fmaf(coef[C + c0 + j], yv, coef[2 * C + c0 + j])));
   }
@@ -1425,12 +1477,15 @@ extern "C" int cpfn_bn_finalize(const float *partial, int nblk, int N, float cou
 }
 
 extern "C" int cpfn_bn_relu_apply(const void *Y, const float *scale, const float *shift, long long P, int C,
-                                  void *out, void *stream) {
+                                  void *out, const long long *drop_counter, unsigned long long drop_base, float drop_p,
+                                  unsigned long long *drop_seed_out, void *stream) {
   if (P < 0 || C <= 0 || (C & 7) || !Y || !scale || !shift || !out) return CPFN_EINVAL;
+  if (drop_counter && (!drop_seed_out || !(drop_p >= 0.f && drop_p < 1.f))) return CPFN_EINVAL;
   if (P == 0) return 0;
   const long long total8 = P * C / 8;
   bn_relu_apply_kernel<<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
-      (const unsigned short *)Y, scale, shift, total8, C, (unsigned short *)out);
+      (const unsigned short *)Y, scale, shift, total8, C, (unsigned short *)out, drop_counter, drop_base,
+      dropout_thresh16(drop_p), 1.f / (1.f - drop_p), drop_seed_out);
   return cpfn_launch_status();
 }
 
@@ -1457,11 +1512,13 @@ extern "C" int cpfn_bn_bwd_blocks(long long P) {
 }
 
 extern "C" int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift, long long P,
-                                int C, void *Gz, float *partial, void *stream) {
+                                int C, void *Gz, float *partial, const unsigned long long *drop_seed, float drop_p,
+                                void *stream) {
   if (P <= 0 || C <= 0 || (C & 7) || !pow2(C / 8) || !Ga || !Y || !scale || !shift || !partial) return CPFN_EINVAL;
+  if (drop_seed && !(drop_p >= 0.f && drop_p < 1.f)) return CPFN_EINVAL;
   bn_relu_bwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
       (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial,
-      bn_rows_per_block(P));
+      bn_rows_per_block(P), drop_seed, dropout_thresh16(drop_p), 1.f / (1.f - drop_p));
   return cpfn_launch_status();
 }
 
@@ -1475,15 +1532,19 @@ extern "C" int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float
 }
 
 extern "C" int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, const float *scale,
-                                 const float *shift, long long P, int C, void *Gy, void *stream) {
+                                 const float *shift, long long P, int C, void *Gy,
+                                 const unsigned long long *drop_seed, float drop_p, void *stream) {
   if (P <= 0 || C <= 0 || (C & 7) || !Gz || !Y || !coef || !Gy || (!scale != !shift)) return CPFN_EINVAL;
+  if (drop_seed && !(drop_p >= 0.f && drop_p < 1.f)) return CPFN_EINVAL;
   const long long total8 = P * C / 8;
+  const unsigned th = dropout_thresh16(drop_p);
+  const float ik = 1.f / (1.f - drop_p);
   if (scale)
     bn_bwd_apply_kernel<true><<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
-        (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy);
+        (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy, drop_seed, th, ik);
   else
     bn_bwd_apply_kernel<false><<<cpfn_cdiv(total8, 256), 256, 0, (hipStream_t)stream>>>(
-        (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy);
+        (const unsigned short *)Gz, (const unsigned short *)Y, coef, scale, shift, total8, C, (unsigned short *)Gy, drop_seed, th, ik);
   return cpfn_launch_status();
 }
 

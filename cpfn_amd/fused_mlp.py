@@ -75,11 +75,22 @@ def bn_finalize(part, nblk, N, count, gamma, beta, conv_bias, eps, momentum, rm,
     return out
 
 
-def bn_relu_apply(Y, scale, shift):
+def bn_relu_apply(Y, scale, shift, dropout=None):
+    """dropout = (p, counter int64 device scalar, base seed): fused mask; returns (out, seed tensor for backward)."""
     out = torch.empty_like(Y)
-    _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), _stream()),
-           "cpfn_bn_relu_apply")
-    return out
+    if dropout is None:
+        _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), None, 0, 0.0,
+                                           None, _stream()), "cpfn_bn_relu_apply")
+        return out
+    p, counter, base = dropout
+    seed = torch.empty(1, dtype=torch.int64, device=Y.device)
+    _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), _ptr(counter),
+                                       int(base) & 0xFFFFFFFFFFFFFFFF, float(p), _ptr(seed), _stream()), "cpfn_bn_relu_apply")
+    if _defer_counters is not None:
+        _defer_counters.append(counter)      # advanced with the BatchNorm counters at the end of the forward pass
+    else:
+        counter.add_(1)
+    return out, seed
 
 
 def bn_relu_maxpool(Y, scale, shift, Kn):
@@ -254,6 +265,7 @@ class _FusedStack(torch.autograd.Function):
         a = x
         a_ss = None                      # (scale, shift) when `a` is the previous layer's raw pre-BN output
         out = None
+        drop_seed = None
         with torch.cuda.device(dev):
             for li, L in enumerate(layers):
                 W = params[3 * li]
@@ -287,7 +299,10 @@ class _FusedStack(torch.autograd.Function):
                     out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)
                     saved.append((a, a_ss, Y, st, Wb, arg, yarg))
                 elif last or not BN_APPLY_FUSED:
-                    nxt = bn_relu_apply(Y, st[0], st[1])
+                    if last and cfg.get("dropout") is not None:
+                        nxt, drop_seed = bn_relu_apply(Y, st[0], st[1], cfg["dropout"])
+                    else:
+                        nxt = bn_relu_apply(Y, st[0], st[1])
                     saved.append((a, a_ss, Y, st, Wb, None, None))
                     a, a_ss = nxt, None
                     out = nxt
@@ -297,6 +312,7 @@ class _FusedStack(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.saved = saved
         ctx.P = P
+        ctx.drop_seed = drop_seed
         ctx.x_needs_grad = ctx.needs_input_grad[0]
         return out
 
@@ -328,7 +344,7 @@ class _FusedStack(torch.autograd.Function):
                     nblk = h.cpfn_bn_bwd_blocks(G)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                     _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, None, _ptr(part),
-                                              _stream()), "cpfn_bn_relu_bwd")
+                                              None, 0.0, _stream()), "cpfn_bn_relu_bwd")
                     _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
@@ -343,16 +359,19 @@ class _FusedStack(torch.autograd.Function):
                     # recomputes the ReLU mask from y.  3.57 vs 3.65 ms/step (same box, A/B/A/B); CPFN_BN_NOSTORE=0
                     # selects the two-pass-over-g_z variant.
                     nostore = BN_NOSTORE
-                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None if nostore else _ptr(Gy), _ptr(part), _stream()),
-                           "cpfn_bn_relu_bwd")
+                    # fused dropout: the gradient of the stack's output is masked on load (top layer only)
+                    dseed = ctx.drop_seed if li == len(layers) - 1 else None
+                    dp = float(cfg["dropout"][0]) if dseed is not None else 0.0
+                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None if nostore else _ptr(Gy), _ptr(part),
+                                              _ptr(dseed), dp, _stream()), "cpfn_bn_relu_bwd")
                     _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
                     if nostore:
-                        _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy), _stream()),
-                               "cpfn_bn_bwd_apply")
-                    else:
-                        _check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), None, None, P, N, _ptr(Gy), _stream()),
+                        _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
+                                                   _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
+                    else:       # (the stored g_z already carries the dropout mask)
+                        _check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), None, None, P, N, _ptr(Gy), None, 0.0, _stream()),
                                "cpfn_bn_bwd_apply")
                 grads[3 * li + 1] = dgb[0]
                 grads[3 * li + 2] = dgb[1]
@@ -382,12 +401,17 @@ class _FusedStack(torch.autograd.Function):
         return (gx, None) + tuple(grads)
 
 
-def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False):
+def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None):
     """x: bf16 rows [P, Kpad] (Kpad a multiple of 64, zero-padded beyond the first conv's
     in_channels) — or fp32 [P, KS<=4] with first_fp32=True.  Returns bf16 [P, C_last], or
-    [P/pool_k, C_last] when pool_k is given (max over each run of pool_k consecutive rows)."""
+    [P/pool_k, C_last] when pool_k is given (max over each run of pool_k consecutive rows).
+    dropout = (p, counter, base_seed): dropout on the stack's output, fused into the last BN apply (no pooling)."""
     layers = _layers_from_modules(convs, bns)
-    cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32}
+    if dropout is not None and pool_k:
+        raise ValueError("dropout cannot be fused into a pooled stack")
+    if dropout is not None and not dropout[0] > 0.0:
+        dropout = None
+    cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout}
     params = []
     for L in layers:
         params += [L.weight, L.gamma, L.beta]

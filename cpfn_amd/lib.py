@@ -58,12 +58,12 @@ SIGNATURES = {
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "cpfn_bn_relu_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp],
+    "cpfn_bn_relu_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp, ctypes.c_uint64, _f, _vp, _vp],
     "cpfn_bn_relu_maxpool": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_bn_bwd_blocks": [_ll],
-    "cpfn_bn_relu_bwd": [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp],
+    "cpfn_bn_relu_bwd": [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _f, _vp],
     "cpfn_bn_bwd_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
-    "cpfn_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp],
+    "cpfn_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _f, _vp],
     "cpfn_bn_pool_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "cpfn_mlp_wgrad_splits": [_ll, _i, _i],
     "cpfn_multi_split_reduce": [_vp, _i, _vp],

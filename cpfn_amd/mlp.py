@@ -38,7 +38,7 @@ def shared_mlp(x, convs, bns, dtype=torch.float32):
     return x
 
 
-def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None):
+def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None):
     """Run a whole (conv, bn, relu)* stack on rows and optionally max-pool every `pool_k`
     consecutive rows.  `x` [P, C_in] (any float dtype) — or None with `xyz_rows` [P, 3] fp32
     when the stack's only input is relative coordinates (sa1).
@@ -60,7 +60,9 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None):
             else:
                 xp[:, :C] = x
             x = xp
-        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k)
+        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout)
+    if dropout is not None:
+        raise ValueError("fused dropout exists on the bf16 HIP path only")
     y = shared_mlp(src, convs, bns, dtype)
     if pool_k:
         y = y.reshape(-1, pool_k, y.shape[1]).max(dim=1)[0]

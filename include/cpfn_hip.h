@@ -246,9 +246,16 @@ CPFN_API int cpfn_bn_finalize(const float *partial, int nblk, int N, float count
                               const float *beta, const float *conv_bias, float eps, float momentum,
                               float *running_mean, float *running_var, float *scale, float *shift,
                               float *mean, float *rstd, void *stream);
-/* out = relu(scale*y + shift), bf16 [P,C]. */
+/* out = relu(scale*y + shift), bf16 [P,C].
+ * Fused dropout (optional; the reference's always-on F.dropout on the fc1 features, PointNet2/pn2_network.py:63):
+ * with drop_counter non-NULL (a device int64 the caller advances once per forward pass) the output is multiplied by
+ * a Bernoulli(1-drop_p) mask / (1-drop_p) generated from splitmix64(drop_base, *drop_counter, element index), and
+ * the 8-byte seed is written to drop_seed_out; cpfn_bn_relu_bwd / cpfn_bn_bwd_apply given that seed (and the same
+ * drop_p) apply the same mask to the incoming gradient, so no mask tensor exists.  0 <= drop_p < 1 (quantised to
+ * 1/65536). */
 CPFN_API int cpfn_bn_relu_apply(const void *Y, const float *scale, const float *shift, long long P,
-                                int C, void *out, void *stream);
+                                int C, void *out, const long long *drop_counter, unsigned long long drop_base,
+                                float drop_p, unsigned long long *drop_seed_out, void *stream);
 /* out[g,c] = max_k relu(scale*y[g,k,c] + shift) over Kn <= 256 consecutive rows; arg = first k
  * attaining it (u8), yarg = raw y there.  C >= 64, C/8 a power of two. */
 CPFN_API int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const float *shift, int G, int Kn,
@@ -258,7 +265,8 @@ CPFN_API int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const float
  * [G,C] pooled gradient and the pre-BN values at the arg-max rows (only those rows carry gradient). */
 CPFN_API int cpfn_bn_bwd_blocks(long long P);
 CPFN_API int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift,
-                              long long P, int C, void *Gz, float *partial, void *stream);
+                              long long P, int C, void *Gz, float *partial,
+                              const unsigned long long *drop_seed /* NULL: no dropout */, float drop_p, void *stream);
 /* dgamma, dbeta and coef[3][C] with g_y = coef0*g_z + coef1*y + coef2. */
 CPFN_API int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float count, const float *gamma,
                                   const float *mean, const float *rstd, int training, float *dgamma,
@@ -266,7 +274,8 @@ CPFN_API int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float c
 /* g_y = coef0*g_z + coef1*y + coef2.  With scale/shift non-NULL the first argument is g_a and the ReLU
  * mask [scale*y+shift > 0] is recomputed (pass 1 then need not store g_z). */
 CPFN_API int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, const float *scale,
-                               const float *shift, long long P, int C, void *Gy, void *stream);
+                               const float *shift, long long P, int C, void *Gy,
+                               const unsigned long long *drop_seed /* NULL: no dropout */, float drop_p, void *stream);
 CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, const void *yarg,
                                     const void *Y, const float *scale, const float *shift,
                                     const float *coef, int G, int Kn, int C, void *Gy, void *stream);

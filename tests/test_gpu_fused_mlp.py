@@ -213,3 +213,52 @@ def test_gemm_every_dispatch_path(P, K, N, w_trans, mode):
         scale = float(ref.abs().max())
         assert float((s[0] - ref.double().sum(0)).abs().max()) <= 2e-4 * scale * P ** 0.5 + 1e-3
         assert float((s[1] - (ref.double() ** 2).sum(0)).abs().max()) <= 1e-3 * float((ref.double() ** 2).sum(0).max())
+
+
+def test_fused_dropout_mask_statistics_and_backward():
+    """Dropout fused into the last BatchNorm apply (fc1 of the network): Bernoulli(1-p) mask with 1/(1-p) scaling,
+    a fresh mask per forward pass, and a backward pass that applies exactly the forward mask (the mask is
+    regenerated from an 8-byte seed, never stored)."""
+    from cpfn_amd import fused_mlp
+    P, C = 20000, 128
+    convs, bns = _stack(C, [128], seed=3)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(P, C, generator=g).to(dev()).to(torch.bfloat16)
+    gout = torch.randn(P, 128, generator=g).to(dev())
+    counter = torch.zeros(1, dtype=torch.int64, device=dev())
+
+    def run(dropout, grad_out):
+        for p in list(convs.parameters()) + list(bns.parameters()):
+            p.grad = None
+        xin = x.clone().requires_grad_(True)
+        y = fused_mlp.fused_mlp_stack(xin, convs, bns, dropout=dropout)
+        (y.float() * grad_out).sum().backward()
+        return y.detach().float(), xin.grad.float(), [p.grad.clone() for p in convs.parameters() if p.grad is not None] + \
+            [p.grad.clone() for p in bns.parameters()]
+
+    for p in (0.5, 0.2):
+        y0, _, _ = run(None, gout)
+        y1, gx1, gp1 = run((p, counter, 1234), gout)
+        y2, _, _ = run((p, counter, 1234), gout)
+        assert int(counter) == 2 + (0 if p == 0.5 else 2)
+        live = y0 > 0
+        keep1 = (y1 != 0) & live
+        n = int(live.sum())
+        frac = float(keep1.sum()) / n
+        assert abs(frac - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5, frac
+        # kept values are the undropped ones scaled by 1/(1-p) (one bf16 rounding apart)
+        ratio = (y1[keep1] / y0[keep1])
+        assert float((ratio - 1 / (1 - p)).abs().max()) < 2e-2
+        # a new mask every forward pass; no structure along rows or channels
+        keep2 = (y2 != 0) & live
+        agree = float((keep1 == keep2)[live].float().mean())
+        assert abs(agree - (p * p + (1 - p) * (1 - p))) < 0.01
+        per_ch = keep1.float().sum(0) / live.float().sum(0).clamp_min(1)
+        assert float((per_ch - (1 - p)).abs().max()) < 0.03
+        # backward: identical to the undropped stack fed with the masked, rescaled output gradient
+        mask = torch.where(live, keep1.float() / (1 - p), torch.zeros_like(y0))
+        # (elements with y0 == 0 have zero gradient through the ReLU either way)
+        _, gx_ref, gp_ref = run(None, (gout * mask).to(torch.bfloat16).float())
+        assert _rel(gx1, gx_ref) < 2e-2, _rel(gx1, gx_ref)
+        for a, b in zip(gp1, gp_ref):
+            assert _rel(a, b) < 2e-2
