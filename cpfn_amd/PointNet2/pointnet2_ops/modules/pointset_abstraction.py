@@ -65,7 +65,12 @@ class PointsetAbstraction(nn.Module):
         cd = getattr(self, "compute_dtype", torch.float32)
         if self.group_all:
             new_xyz = None
-            g = xyz if feats is None else torch.cat([xyz.to(feats.dtype), feats], dim=2)     # pos FIRST (ref :56)
+            if feats is not None and cd == torch.bfloat16 and feats.is_cuda and feats.dtype == torch.bfloat16:
+                # positions + features + zero padding to the GEMM's K, one kernel (pos FIRST, ref :56)
+                D = feats.shape[2]
+                g = autograd_ops.ConcatPosFeats.apply(xyz.reshape(B * N, 3), feats.reshape(B * N, D), (D + 3 + 63) // 64 * 64)
+            else:
+                g = xyz if feats is None else torch.cat([xyz.to(feats.dtype), feats], dim=2)  # pos FIRST (ref :56)
             groups = [(g.reshape(B * N, -1), None, 1, N)] * len(self.mlp_list)
         else:
             if geom is None:

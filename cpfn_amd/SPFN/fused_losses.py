@@ -125,6 +125,7 @@ class ResidueLoss(torch.autograd.Function):
 class LossTail(torch.autograd.Function):
     """(S, rp, nl, tl, match, n_gt) -> total [] and parts [5] = normal, type, miou, residue, parameter
     (cpfn_loss_tail: one launch; the gradients of the total are produced by the same launch)."""
+    unit_grad = False      # set by a trainer that always back-propagates the plain total (saves one scaling kernel)
 
     @staticmethod
     def forward(ctx, S, rp, nl, tl, match, n_gt, mult6):
@@ -145,8 +146,10 @@ class LossTail(torch.autograd.Function):
                                              _ptr(gtl), _stream()), "cpfn_loss_tail")
         ctx.save_for_backward(flat)
         ctx.dims = (B, K2, K, rp is not None)
+        ctx.unit_grad = LossTail.unit_grad
         parts = out[1:]
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)
         return out[0], parts
 
     @staticmethod
@@ -154,14 +157,33 @@ class LossTail(torch.autograd.Function):
         (flat,) = ctx.saved_tensors
         B, K2, K, has_rp = ctx.dims
         nS, nR = B * K2 * K, B * K * 2
-        f = flat * g_total
+        # (unit_grad: the caller promises to call total.backward() with the default gradient 1 — the trainer does)
+        f = flat if ctx.unit_grad else flat * g_total
         return (f[:nS].view(B, K2, K), f[nS:nS + nR].view(B, K, 2) if has_rp else None, f[nS + nR:nS + nR + B],
                 f[nS + nR + B:], None, None, None)
 
 
+class unit_loss_gradient:
+    """Context manager for a trainer that back-propagates the plain total (`total.backward()`): LossTail then
+    hands its stored gradients on as they are instead of multiplying them by the incoming 1.0."""
+
+    def __enter__(self):
+        self._prev, LossTail.unit_grad = LossTail.unit_grad, True
+
+    def __exit__(self, *exc):
+        LossTail.unit_grad = self._prev
+        return False
+
+
 def count_gt(I_gt):
     """[B] int64: number of GT instances per cloud (max label + 1; reference lines 603-606)."""
-    return I_gt.max(dim=1)[0] + 1
+    if not I_gt.is_cuda:
+        return I_gt.max(dim=1)[0] + 1
+    Ig = I_gt.contiguous()
+    n_gt = torch.empty(Ig.shape[0], dtype=torch.int64, device=Ig.device)
+    with torch.cuda.device(Ig.device):
+        _l.check(_l.lib().cpfn_count_labels(_ptr(Ig), Ig.shape[0], Ig.shape[1], _ptr(n_gt), _stream()), "cpfn_count_labels")
+    return n_gt
 
 
 def hungarian_cost_pack(S, I_gt, n_gt=None):
@@ -268,7 +290,9 @@ def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=Non
     if m["residue"] > 0 or m["parameter"] > 0:
         if params is None:
             params = _fc.fit_params(P, W, Xn)
-        gt_axes = torch.stack([batch["plane_n_gt"], batch["cylinder_axis_gt"], batch["cone_axis_gt"]], 0)
+        gt_axes = batch.get("gt_axes")          # [3,B,K,3]; a trainer with static input buffers keeps them stacked
+        if gt_axes is None:
+            gt_axes = torch.stack([batch["plane_n_gt"], batch["cylinder_axis_gt"], batch["cone_axis_gt"]], 0)
         ids = [classes.index(c) for c in ("plane", "sphere", "cylinder", "cone")]
         rp = ResidueLoss.apply(params, match, T_gt, batch["points_per_instance"], gt_axes, ids)
     mult6 = [m["normal"], m["type"], m["miou"], m["residue"], m["parameter"], m["total"]]

@@ -113,6 +113,25 @@ class GroupConcat(torch.autograd.Function):
         return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None, None, None
 
 
+class ConcatPosFeats(torch.autograd.Function):
+    """Group-all set-abstraction input rows in one pass (modules/pointset_abstraction.py:56, positions FIRST):
+    out = [bf16(xyz) | feats | zeros] as bf16 [R, Cpad]; the positions carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, xyz_rows, feats_rows, cpad):
+        R, C = feats_rows.shape
+        out = torch.empty(R, cpad, dtype=torch.bfloat16, device=feats_rows.device)
+        with torch.cuda.device(feats_rows.device):
+            _l.check(_l.lib().cpfn_concat_pos_feats_bf16(_ptr(xyz_rows.contiguous().float()), _ptr(feats_rows.contiguous()),
+                                                         R, C, cpad, _ptr(out), _stream()), "cpfn_concat_pos_feats_bf16")
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, g[:, 3:3 + ctx.C], None
+
+
 def interp_rows(feats, idx, w, inv=None):
     if feats.dtype == torch.bfloat16 and feats.is_cuda and feats.shape[2] % 8 == 0 and feats.shape[1] <= 1024:
         if inv is not None:

@@ -434,6 +434,80 @@ __global__ __launch_bounds__(TPB) void multi_copy_kernel(McArgs a) {
   }
 }
 
+// fp32 matrices -> bf16 (or fp32) panels with a row stride, up to MCV_MAX of them in ONE launch: the per-step refresh
+// of every bf16 weight panel of the network (plain, zero-padded-K and the packed heads panel with its fp32 bias
+// vector).  torch._foreach_copy_ took 16 us for the ~20 plain panels and the padded ones were one strided copy each.
+constexpr int MCV_MAX = 64;
+struct McvArgs {
+  const float *src[MCV_MAX];
+  void *dst[MCV_MAX];
+  int rows[MCV_MAX], cols[MCV_MAX], ld[MCV_MAX], f32[MCV_MAX];
+  int block0[MCV_MAX + 1];
+  int count;
+};
+__global__ __launch_bounds__(TPB) void multi_cast_kernel(McvArgs a) {
+  int d = 0;
+  while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
+  const int cols = a.cols[d], ld = a.ld[d];
+  const long long n = (long long)a.rows[d] * cols;
+  const long long nb = a.block0[d + 1] - a.block0[d];
+  const float *__restrict__ s = a.src[d];
+  for (long long e = ((long long)(blockIdx.x - a.block0[d]) * TPB + threadIdx.x) * 4; e < n; e += nb * TPB * 4) {
+    float v[4];
+    if (e + 4 <= n && (((uintptr_t)(s + e)) & 15) == 0) {
+      const float4 q = *(const float4 *)(s + e);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = e + j < n ? s[e + j] : 0.f;
+    }
+    const long long r = e / cols;
+    int c = (int)(e - r * cols);
+    long long o = r * ld + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (e + j < n) {
+        if (a.f32[d]) ((float *)a.dst[d])[o] = v[j];
+        else ((unsigned short *)a.dst[d])[o] = __builtin_bit_cast(unsigned short, (__bf16)v[j]);
+      }
+      ++o;
+      if (++c == cols) { c = 0; o += ld - cols; }
+    }
+  }
+}
+
+// group_all set abstraction (sa3): rows [xyz(3) as bf16 | feats(C) bf16 | zeros] with the row length padded to the
+// GEMM's K (modules/pointset_abstraction.py:56: pos FIRST).  Was: a dtype cast, torch.cat, torch.zeros and a strided
+// slice copy.
+__global__ __launch_bounds__(TPB) void concat_pos_feats_kernel(const float *__restrict__ xyz,
+                                                               const unsigned short *__restrict__ feats, long long R,
+                                                               int C, int Cpad, unsigned short *__restrict__ out) {
+  const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (e >= R * Cpad) return;
+  const long long r = e / Cpad;
+  const int c = (int)(e - r * Cpad);
+  unsigned short v = 0;
+  if (c < 3) v = __builtin_bit_cast(unsigned short, (__bf16)xyz[r * 3 + c]);
+  else if (c < 3 + C) v = feats[r * C + c - 3];
+  out[e] = v;
+}
+
+// n_gt[b] = max label of cloud b + 1 (SPFN/losses_implementation.py:603-606 via `.max()`): one workgroup per cloud.
+__global__ __launch_bounds__(1024) void count_labels_kernel(const long long *__restrict__ labels, int N,
+                                                            long long *__restrict__ n_gt) {
+  __shared__ long long s_max[16];
+  const long long *__restrict__ row = labels + (size_t)blockIdx.x * N;
+  long long m = -1;
+  for (int i = threadIdx.x; i < N; i += 1024) m = max(m, row[i]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = max(m, s_max[w]);
+    n_gt[blockIdx.x] = m + 1;
+  }
+}
+
 inline int channel_chunk(int C, int blocks_x, int B) {
   // enough blocks to fill 256 CUs a few times over, but at least 8 channels per block
   // so the index / weight loads are amortised
@@ -644,5 +718,44 @@ extern "C" int cpfn_multi_copy(const cpfn_copy_desc *descs, int count, void *str
     a.block0[a.count] = blocks;
     if (blocks) multi_copy_kernel<<<blocks, TPB, 0, st>>>(a);
   }
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_multi_cast(const cpfn_cast_desc *descs, int count, void *stream) {
+  if (count < 0 || (count > 0 && !descs)) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < count; base += MCV_MAX) {
+    McvArgs a;
+    a.count = count - base < MCV_MAX ? count - base : MCV_MAX;
+    int blocks = 0;
+    for (int i = 0; i < a.count; ++i) {
+      const cpfn_cast_desc &d = descs[base + i];
+      if (!d.src || !d.dst || d.rows < 0 || d.cols <= 0 || d.dst_ld < d.cols || ((uintptr_t)d.src & 3)) return CPFN_EINVAL;
+      a.src[i] = d.src; a.dst[i] = d.dst; a.rows[i] = d.rows; a.cols[i] = d.cols; a.ld[i] = d.dst_ld; a.f32[i] = d.dst_f32;
+      a.block0[i] = blocks;
+      long long nb = ((long long)d.rows * d.cols + TPB * 4 - 1) / (TPB * 4);
+      if (nb < 1) nb = 1;
+      if (nb > 512) nb = 512;
+      blocks += (int)nb;
+    }
+    a.block0[a.count] = blocks;
+    if (blocks) multi_cast_kernel<<<blocks, TPB, 0, st>>>(a);
+  }
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_concat_pos_feats_bf16(const float *xyz, const void *feats, long long R, int C, int Cpad, void *out,
+                                          void *stream) {
+  if (R < 0 || C < 0 || Cpad < C + 3 || !xyz || (C > 0 && !feats) || !out) return CPFN_EINVAL;
+  if (R == 0) return 0;
+  concat_pos_feats_kernel<<<(unsigned)cpfn_cdiv(R * Cpad, TPB), TPB, 0, (hipStream_t)stream>>>(
+      xyz, (const unsigned short *)feats, R, C, Cpad, (unsigned short *)out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_count_labels(const int64_t *labels, int B, int N, int64_t *n_gt, void *stream) {
+  if (B < 0 || N <= 0 || !labels || !n_gt) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  count_labels_kernel<<<B, 1024, 0, (hipStream_t)stream>>>((const long long *)labels, N, (long long *)n_gt);
   return cpfn_launch_status();
 }

@@ -1207,6 +1207,7 @@ struct MsrArgs {
   float *out[MSR_MAX];
   long long n[MSR_MAX];
   int splits[MSR_MAX];
+  int row_in[MSR_MAX], row_out[MSR_MAX];   // 0, 0: flat; else only the first row_out of every row_in elements are kept
   int block0[MSR_MAX + 1];     // first workgroup of buffer i
   int count;
 };
@@ -1227,7 +1228,17 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
   }
   s_acc[r][lane] = acc;
   __syncthreads();
-  if (r == 0 && e < n) a.out[d][e] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+  if (r == 0 && e < n) {
+    const float v = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+    const int ri = a.row_in[d];
+    if (ri == 0) {
+      a.out[d][e] = v;
+    } else {           // zero-padded K: drop the padding columns (the caller gets a compact [N, row_out] matrix)
+      const long long row = e / ri;
+      const int col = (int)(e - row * ri);
+      if (col < a.row_out[d]) a.out[d][row * a.row_out[d] + col] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- fp32 small-K first layer (sa1: K = 3)
@@ -1658,8 +1669,10 @@ extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count,
     int blocks = 0;
     for (int i = 0; i < a.count; ++i) {
       const cpfn_reduce_desc &d = descs[base + i];
-      if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0) return CPFN_EINVAL;
+      if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0 || d.row_in < 0 || d.row_out < 0 || d.row_out > d.row_in ||
+          (d.row_in > 0 && (d.row_out == 0 || d.n % d.row_in))) return CPFN_EINVAL;
       a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
+      a.row_in[i] = d.row_in; a.row_out[i] = d.row_out;
       a.block0[i] = blocks;
       blocks += cpfn_cdiv(d.n, 64);
     }

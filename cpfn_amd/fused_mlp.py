@@ -109,7 +109,8 @@ def bn_relu_maxpool(Y, scale, shift, Kn):
 # pure latency, 19 times per backward pass.  They are queued instead and finished by ONE launch when the autograd
 # engine reaches the end of the backward pass (queue_callback), before anybody can read the gradients.
 class _ReduceDesc(ctypes.Structure):
-    _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_longlong), ("splits", ctypes.c_int)]
+    _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_longlong), ("splits", ctypes.c_int),
+                ("row_in", ctypes.c_int), ("row_out", ctypes.c_int)]
 
 
 _pending_reduce = []
@@ -120,17 +121,19 @@ def _flush_reductions():
     todo, _pending_reduce = _pending_reduce, []
     if not todo:
         return
-    arr = (_ReduceDesc * len(todo))(*[_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits) for ws, out, n, splits in todo])
+    arr = (_ReduceDesc * len(todo))(*[_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits, ri, ro)
+                                      for ws, out, n, splits, ri, ro in todo])
     dev = todo[0][0].device
     with torch.cuda.device(dev):
         _check(_l.lib().cpfn_multi_split_reduce(arr, len(todo), _stream()), "cpfn_multi_split_reduce")
 
 
-def _defer_reduction(ws, out, n, splits):
-    """Queue `out[n] = sum over splits of ws[splits][n]`; runs at the end of the current backward pass."""
+def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0):
+    """Queue `out[n] = sum over splits of ws[splits][n]`; runs at the end of the current backward pass.
+    row_in / row_out: the partial rows have row_in elements of which `out` (compact) keeps the first row_out."""
     if not _pending_reduce:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
-    _pending_reduce.append((ws, out, n, splits))
+    _pending_reduce.append((ws, out, n, splits, row_in, row_out))
 
 
 # ------------------------------------------------------------------ bf16 weight panels
@@ -171,37 +174,61 @@ def _foreach_copy_by_dtype(dst, src):
         torch._foreach_copy_(d, s_)
 
 
+class _CastDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
+                ("dst_ld", ctypes.c_int), ("dst_f32", ctypes.c_int)]
+
+
+_cast_cache = {}
+
+
 def refresh_weight_panels(params):
-    """Refresh the bf16 panels of all `params` (nn.Parameters that already have one) with ONE multi-tensor
-    copy instead of one conversion kernel per layer (~20 launches, 0.1 ms per step).  Called at the start of a
-    forward pass; bf16_weight() then returns the panels as they are until the next call.  Panels that are
-    zero-padded views, or do not exist yet, are left to bf16_weight()."""
+    """Refresh the bf16 panels of all `params` (nn.Parameters that already have one) — plain, zero-padded and the
+    packed heads panel with its fp32 bias vector — with ONE launch (cpfn_multi_cast) instead of one conversion
+    kernel per layer (~25 launches, 0.1 ms per step).  Called at the start of a forward pass; bf16_weight() and
+    _packed_heads() then return the panels as they are until the next call.  Panels that do not exist yet are left
+    to their first use."""
     _refresh_epoch[0] += 1
     want = {id(p): p for p in params}
-    dst, src, ents = [], [], []
+    jobs, ents, packed, dev = [], [], [], None
     for (pid, rows, cols), ent in _wcache.items():
         W = want.get(pid)
-        if W is None or ent[1]() is not W or ent[0].device != W.device:
+        if W is None or ent[1]() is not W or ent[0].device != W.device or not W.is_cuda or W.dtype != torch.float32:
             continue
         w2 = W.detach().reshape(W.shape[0], -1)
-        if tuple(w2.shape) == (rows, cols):
-            dst.append(ent[0])
-            src.append(w2)
-            ents.append(ent)
-    packed = []
+        if not w2.is_contiguous() or w2.shape[0] > rows or w2.shape[1] > cols:
+            continue
+        jobs.append((w2, ent[0], w2.shape[0], w2.shape[1], cols, 0))
+        ents.append(ent)
+        dev = W.device
     for ent in _packed.values():                 # the packed panels of the heads ride along
         ts = [r() for r in ent["refs"]]
-        if any(t is None or id(t) not in want for t in ts) or ent["Wb"].device != ts[0].device:
+        if any(t is None or id(t) not in want or not t.is_cuda or t.dtype != torch.float32 for t in ts) or \
+                ent["Wb"].device != ts[0].device:
             continue
-        dst += ent["dst"]
-        src += [t.detach().reshape(t.shape[0], -1) if t.dim() > 1 else t.detach() for t in ts]
+        for t, d in zip(ts, ent["dst"]):
+            t2 = t.detach().reshape(t.shape[0], -1)
+            if t.dim() > 1:
+                jobs.append((t2, d, t2.shape[0], t2.shape[1], ent["Wb"].shape[1], 0))
+            else:
+                jobs.append((t2, d, 1, t2.shape[0], t2.shape[0], 1))
         packed.append(ent)
-    if dst:
-        _foreach_copy_by_dtype(dst, src)
-        for ent in ents:
-            ent[2] = _refresh_epoch[0]
-        for ent in packed:
-            ent["epoch"] = _refresh_epoch[0]
+        dev = ts[0].device
+    if not jobs:
+        return
+    key = tuple((s_.data_ptr(), d.data_ptr(), r, c, ld, f) for s_, d, r, c, ld, f in jobs)
+    arr = _cast_cache.get(key)
+    if arr is None:
+        if len(_cast_cache) > 64:
+            _cast_cache.clear()
+        arr = (_CastDesc * len(jobs))(*[_CastDesc(s_.data_ptr(), d.data_ptr(), r, c, ld, f) for s_, d, r, c, ld, f in jobs])
+        _cast_cache[key] = arr
+    with torch.cuda.device(dev):
+        _check(_l.lib().cpfn_multi_cast(arr, len(jobs), _stream()), "cpfn_multi_cast")
+    for ent in ents:
+        ent[2] = _refresh_epoch[0]
+    for ent in packed:
+        ent["epoch"] = _refresh_epoch[0]
 
 
 # ------------------------------------------------------------------ the stack
@@ -387,13 +414,17 @@ class _FusedStack(torch.autograd.Function):
                     Kp = a_in.shape[1]
                     splits = h.cpfn_mlp_wgrad_splits(P, N, Kp)
                     ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
-                    dW = torch.empty(N, Kp, dtype=torch.float32, device=dev)
                     _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
                                             None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
-                                            _ptr(ws), _ptr(dW) if Kp != L.cin else None, _stream()), "cpfn_mlp_wgrad")
-                    if Kp == L.cin:       # (a zero-padded K needs dW right away: the slice below is a copy)
+                                            _ptr(ws), None, _stream()), "cpfn_mlp_wgrad")
+                    # the split partials are finished by ONE launch at the end of the backward pass; a zero-padded K
+                    # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
+                    dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
+                    if Kp == L.cin:
                         _defer_reduction(ws, dW, N * Kp, splits)
-                    grads[3 * li] = dW[:, :L.cin].reshape(wshape)
+                    else:
+                        _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin)
+                    grads[3 * li] = dW.reshape(wshape)
                     if li > 0 or ctx.x_needs_grad:
                         g, _, _ = gemm(Gy, Wb, w_trans=True)            # G_y [P,N] · W [N,Kp]
                         if li == 0:

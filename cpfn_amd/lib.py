@@ -35,6 +35,9 @@ SIGNATURES = {
     "cpfn_scatter_rows_bf16": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_group_concat_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_multi_copy": [_vp, _i, _vp],
+    "cpfn_multi_cast": [_vp, _i, _vp],
+    "cpfn_concat_pos_feats_bf16": [_vp, _vp, _ll, _i, _i, _vp, _vp],
+    "cpfn_count_labels": [_vp, _i, _i, _vp, _vp],
     "cpfn_csr_build": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_csr_gather_sum_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_fit_num_chunks": [_i, _i],

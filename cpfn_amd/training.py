@@ -307,6 +307,15 @@ class SPFNTrainer:
               "skipped": torch.zeros((), dtype=torch.float32, device=dev)}
         st["start1"], st["start2"] = st["start_dev"][0], st["start_dev"][1]
         sb = st["batch"]
+        # the three GT axis tensors live stacked ([3,B,K,3], what the residue kernel reads): the per-key static
+        # buffers are views of it, so staging a batch fills the stacked tensor without a torch.stack per step
+        axes = ("plane_n_gt", "cylinder_axis_gt", "cone_axis_gt")
+        if all(k in sb for k in axes) and len({(tuple(sb[k].shape), sb[k].dtype) for k in axes}) == 1 and \
+                sb[axes[0]].dtype == torch.float32:
+            stacked = torch.stack([sb[k] for k in axes], 0).contiguous()
+            for i, k in enumerate(axes):
+                sb[k] = stacked[i]
+            sb["gt_axes"] = stacked
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         starts = (st["start1"], st["start2"])
         # static geometry buffers (shapes from one eager pass)
@@ -348,7 +357,8 @@ class SPFNTrainer:
                     n_gt = fl.count_gt(sb["I_gt"])
                     st["match"] = fl.hungarian_device(S, n_gt)
                     params = fl.fit_params(sb["P"], W, Xn, self.mult)
-                out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
+                with fl.unit_loss_gradient():
+                    out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
                 out[0].backward()
                 self.bucket.collect()
                 if world == 1:
@@ -384,8 +394,9 @@ class SPFNTrainer:
             with torch.cuda.stream(self._gside):
                 geometry_into_B(st["P_next"])
             Xn, W, nl, tl, S = st["pre"]
-            out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, st["n_gt"],
-                                st["params"])
+            with fl.unit_loss_gradient():
+                out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, st["n_gt"],
+                                    st["params"])
             out[0].backward()
             self.bucket.collect()
             if world == 1:

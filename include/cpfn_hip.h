@@ -143,6 +143,17 @@ CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const i
  * with a length that is a multiple of 4 (slices of a flat fp32 buffer). */
 typedef struct { const void *src; void *dst; long long bytes; } cpfn_copy_desc;
 CPFN_API int cpfn_multi_copy(const cpfn_copy_desc *descs /* HOST array */, int count, void *stream);
+/* count fp32 matrices src[rows, cols] (contiguous) converted to bf16 (dst_f32 = 0) or copied as fp32 (dst_f32 = 1)
+ * into dst with row stride dst_ld >= cols (elements; padding columns are left untouched), in ONE launch: the
+ * per-step refresh of all bf16 weight panels of the network. */
+/* out[R, Cpad] bf16 = [ bf16(xyz[R,3]) | feats[R,C] (bf16) | zeros ]: the input rows of the group-all set
+ * abstraction (modules/pointset_abstraction.py:56, positions first), padded to the GEMM's K. */
+CPFN_API int cpfn_concat_pos_feats_bf16(const float *xyz, const void *feats, long long R, int C, int Cpad, void *out,
+                                        void *stream);
+/* n_gt[b] = max(labels[b, :]) + 1 (SPFN/losses_implementation.py:603-606). */
+CPFN_API int cpfn_count_labels(const int64_t *labels, int B, int N, int64_t *n_gt, void *stream);
+typedef struct { const float *src; void *dst; int rows, cols, dst_ld, dst_f32; } cpfn_cast_desc;
+CPFN_API int cpfn_multi_cast(const cpfn_cast_desc *descs /* HOST array */, int count, void *stream);
 
 /* Inverse index of a gather (geometry stage): for idx[B,E] with values in [0,M) (M <= 2048) build, per
  * cloud, offsets[M+1] and the ASCENDING list entries[E] of source positions e that reference each target.
@@ -283,7 +294,10 @@ CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, co
  * a_scale, a_shift (optional): as in cpfn_mlp_gemm, A = relu(a_scale*A + a_shift) on the fly.
  * dW may be NULL: only the split partials [splits][N*K] are left in `workspace`, to be finished later,
  * together with those of other layers, by ONE cpfn_multi_split_reduce launch (same fixed summation order). */
-typedef struct { const float *partial; float *out; long long n; int splits; } cpfn_reduce_desc;
+typedef struct { const float *partial; float *out; long long n; int splits;
+                 int row_in, row_out; /* 0,0: out[n] flat; else partial rows have row_in elements of which the first
+                                         row_out are kept: out is compact [n/row_in, row_out] (zero-padded K) */
+} cpfn_reduce_desc;
 CPFN_API int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs /* HOST array */, int count, void *stream);
 CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
