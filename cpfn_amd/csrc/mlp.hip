@@ -137,69 +137,43 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 template <int BN, int KS, bool STATS, bool ATR>
-__device__ __forceinline__ void stream_tile(const bf16x8 (&af_raw)[2][KS], const unsigned short *s_w,
+__device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
-                                            int row0, int n0, int wave, int lane, f32x4 (&st_s)[BN / 16],
-                                            f32x4 (&st_q)[BN / 16], const float *s_ss /*[2][32*KS]: scale, shift*/,
-                                            float *s_stat /*[2][BN], this wave's (KS >= 6 only)*/) {
+                                            int row0, int n0, int wave, int lane, float (&st_s)[8],
+                                            float (&st_q)[8], const float *s_ss /*[2][32*KS]: scale, shift*/,
+                                            const unsigned short *__restrict__ A, int lda, int next_row0) {
   constexpr int NT = BN / 16;
   const int lr = lane & 15, lq = lane >> 4;
-  bf16x8 af[2][KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ATR) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
-      float sc[8], sh[8];
-      *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[ks * 32 + 8 * lq];
-      *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[ks * 32 + 8 * lq + 4];
-      *(cpfn_f32x4 *)&sh[0] = *(const cpfn_f32x4 *)&s_ss[32 * KS + ks * 32 + 8 * lq];
-      *(cpfn_f32x4 *)&sh[4] = *(const cpfn_f32x4 *)&s_ss[32 * KS + ks * 32 + 8 * lq + 4];
-      af[0][ks] = bn_relu_frag(af_raw[0][ks], sc, sh);
-      af[1][ks] = bn_relu_frag(af_raw[1][ks], sc, sh);
-    } else {
-      af[0][ks] = af_raw[0][ks];
-      af[1][ks] = af_raw[1][ks];
-    }
-  }
   f32x4 acc[NT][2];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
+    if (ATR) {   // BatchNorm + ReLU of the previous layer applied to the operand in place, one k-step at a time
+      float sc[8], sh[8];
+      *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[ks * 32 + 8 * lq];
+      *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[ks * 32 + 8 * lq + 4];
+      *(cpfn_f32x4 *)&sh[0] = *(const cpfn_f32x4 *)&s_ss[32 * KS + ks * 32 + 8 * lq];
+      *(cpfn_f32x4 *)&sh[4] = *(const cpfn_f32x4 *)&s_ss[32 * KS + ks * 32 + 8 * lq + 4];
+      af[0][ks] = bn_relu_frag(af[0][ks], sc, sh);
+      af[1][ks] = bn_relu_frag(af[1][ks], sc, sh);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const bf16x8 wf = *(const bf16x8 *)&s_w[(nt * 16 + lr) * (32 * KS + 8) + ks * 32 + 8 * lq];
       acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[nt][0], 0, 0, 0);
       acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[nt][1], 0, 0, 0);
     }
+    // keep the k-steps apart: left alone the scheduler hoists all 32 weight-fragment reads (and the operand
+    // transform of every k-step) in front of the first MFMA, which costs >100 registers
+    if (ATR) __builtin_amdgcn_sched_barrier(0);
   }
-  if (STATS) {
-    // per-channel Σy, Σy² of this wave's points: per-lane running sums over all row tiles of the workgroup; the
-    // cross-lane (DPP) reduction and the LDS hand-over happen once, after the tile loop.
-    // Measured (us per launch, 128->128 @131072 rows | sa1 64->128 @524288 rows):
-    //   per-tile DPP sum + per-tile LDS read-modify-write   22.5 | 56.4   (the LDS round trips serialise)
-    //   per-tile DPP sum, register accumulation             23.3 | 48.0
-    //   per-lane sums, one DPP reduction at the end (this)  22.1 | 37.8
-    // (K = 192 / 256 variants: the two A-fragment buffers already take 96 / 128 registers and 64 more running sums
-    //  spill to scratch, so those reduce per tile into the wave's LDS accumulators instead.)
-    const float m0 = (row0 + wave * 32 + lr < P) ? 1.f : 0.f, m1 = (row0 + wave * 32 + 16 + lr < P) ? 1.f : 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const f32x4 a = acc[nt][0] * m0, b = acc[nt][1] * m1;
-      if (KS <= 4) {
-        st_s[nt] += a + b;
-        st_q[nt] += a * a + b * b;
-      } else {
-        f32x4 sm = a + b, sq = a * a + b * b;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
-        if (lr == 0) {
-          f32x4 *p0 = (f32x4 *)&s_stat[nt * 16 + 4 * lq], *p1 = (f32x4 *)&s_stat[BN + nt * 16 + 4 * lq];
-          *p0 = *p0 + sm;
-          *p1 = *p1 + sq;
-        }
-      }
-    }
-  }
+  // ONE operand buffer: the next tile's rows are requested as soon as the MFMAs have consumed this one's, and fly
+  // during the epilogue below (statistics, LDS staging, stores).  The first version kept two buffers (tile t+1
+  // requested before the MFMAs of tile t): 268 registers for the plain 128-wide variant and 454-490 with the
+  // statistics — one wave per SIMD, so a CU held ONE workgroup and its load / compute / store phases overlapped
+  // with nothing.  Occupancy, not a deeper per-wave pipeline, is what hides the latency here.
+  stream_load_a<KS>(af, A, lda, P, next_row0, wave, lr, lq);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
@@ -209,6 +183,11 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af_raw)[2][KS], const
       *(bf16x4 *)&s_o[(tt * 16 + lr) * G_LDO + nt * 16 + 4 * lq] = o;
     }
   }
+  // The tile leaves through the wave's LDS patch as 16-byte row-contiguous pieces; a lane always carries the SAME
+  // 8-channel chunk (c = lane % CPR), so the BatchNorm statistics are 16 per-lane running sums over the pieces it
+  // stores (Σy, Σy² of the bf16 values BatchNorm will actually normalise), reduced across lanes once after the
+  // tile loop.  The first version summed the fp32 accumulators: 64 running sums per lane (all channels of the
+  // lane's MFMA rows) — with them the 128-wide variants needed 380-490 registers and ran one workgroup per CU.
   constexpr int CPR = BN / 8;  // 16-byte chunks per row
 #pragma unroll
   for (int i = 0; i < 32 * CPR / 64; ++i) {
@@ -216,12 +195,25 @@ __device__ __forceinline__ void stream_tile(const bf16x8 (&af_raw)[2][KS], const
     const int r = e / CPR, c = e - r * CPR;
     const int p = row0 + wave * 32 + r;
     const uint4 vv = *(const uint4 *)&s_o[r * G_LDO + c * 8];
-    if (p < P) *(uint4 *)(Y + (size_t)p * ldy + n0 + c * 8) = vv;
+    if (p < P) {
+      *(uint4 *)(Y + (size_t)p * ldy + n0 + c * 8) = vv;
+      if (STATS) {
+        const unsigned w4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = __uint_as_float(w4[j] << 16), hi = __uint_as_float(w4[j] & 0xffff0000u);
+          st_s[2 * j] += lo;
+          st_s[2 * j + 1] += hi;
+          st_q[2 * j] = fmaf(lo, lo, st_q[2 * j]);
+          st_q[2 * j + 1] = fmaf(hi, hi, st_q[2 * j + 1]);
+        }
+      }
+    }
   }
 }
 
 template <int BN, int KS, bool STATS, bool ATR = false>
-__global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
+__global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void mlp_gemm_stream_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
     const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr) {
@@ -236,39 +228,35 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_stream_kernel(
   if (ATR) {   // visible after the W-panel barrier
     for (int e = t; e < K; e += G_THREADS) { s_ss[e] = a_scale[e]; s_ss[K + e] = a_shift[e]; }
   }
-  if (STATS && KS > 4) {
-    for (int e = t; e < 4 * 2 * BN; e += G_THREADS) (&s_red[0][0][0])[e] = 0.f;   // visible after the W-panel barrier
-  }
-  f32x4 st_s[NT], st_q[NT];
+  float st_s[8], st_q[8];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) { st_s[i] = (f32x4){0, 0, 0, 0}; st_q[i] = (f32x4){0, 0, 0, 0}; }
+  for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
   const int ntiles = (P + G_ROWS - 1) / G_ROWS;
   const int tile0 = blockIdx.x * tiles_per_wg;
   const int tile_end = min(tile0 + tiles_per_wg, ntiles);
   if (tile0 < tile_end) {
-    bf16x8 a0[2][KS], a1[2][KS];
-    stream_load_a<KS>(a0, A, lda, P, tile0 * G_ROWS, wave, lr, lq);
+    bf16x8 a[2][KS];
+    stream_load_a<KS>(a, A, lda, P, tile0 * G_ROWS, wave, lr, lq);
     fill_w_panel<BN, 32 * KS + 8>(s_w, W, K, N, n0, 0, K, w_trans, t);
     __syncthreads();
-    for (int tile = tile0; tile < tile_end; tile += 2) {
-      // prefetch is unconditional (row indices are clamped), so the loop body is straight-line
-      stream_load_a<KS>(a1, A, lda, P, min(tile + 1, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS, ATR>(a0, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, &s_red[wave][0][0]);
-      if (tile + 1 >= tile_end) break;
-      stream_load_a<KS>(a0, A, lda, P, min(tile + 2, ntiles - 1) * G_ROWS, wave, lr, lq);
-      stream_tile<BN, KS, STATS, ATR>(a1, s_w, s_o[wave], Y, ldy, P, (tile + 1) * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, &s_red[wave][0][0]);
+    for (int tile = tile0; tile < tile_end; ++tile) {
+      // the reload inside is unconditional (row indices are clamped), so the loop body is straight-line
+      stream_tile<BN, KS, STATS, ATR>(a, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, A, lda,
+                                      min(tile + 1, ntiles - 1) * G_ROWS);
     }
   }
   if (STATS) {
-    // once per workgroup: DPP sum over the 16 point lanes of a row, one lane per row writes 4 channels
+    // once per workgroup: lanes that carry the same 8-channel chunk (lane % CPR) are summed by xor-shuffles, the
+    // first CPR lanes of every wave hand their 8 channels over through LDS
+    constexpr int CPR = BN / 8;
 #pragma unroll
-    for (int nt = 0; nt < (KS <= 4 ? NT : 0); ++nt) {
+    for (int j = 0; j < 8; ++j) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { st_s[nt][r] = row16_sum(st_s[nt][r]); st_q[nt][r] = row16_sum(st_q[nt][r]); }
-      if (lr == 0) {
-        *(f32x4 *)&s_red[wave][0][nt * 16 + 4 * lq] = st_s[nt];
-        *(f32x4 *)&s_red[wave][1][nt * 16 + 4 * lq] = st_q[nt];
-      }
+      for (int m = CPR; m < 64; m <<= 1) { st_s[j] += __shfl_xor(st_s[j], m, 64); st_q[j] += __shfl_xor(st_q[j], m, 64); }
+    }
+    if (lane < CPR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_red[wave][0][lane * 8 + j] = st_s[j]; s_red[wave][1][lane * 8 + j] = st_q[j]; }
     }
     __syncthreads();
     for (int e = t; e < 2 * BN; e += G_THREADS) {

@@ -211,8 +211,13 @@ def test_gemm_every_dispatch_path(P, K, N, w_trans, mode):
         assert part.shape == (nblk, 2, N)
         s = part.double().sum(0)
         scale = float(ref.abs().max())
-        assert float((s[0] - ref.double().sum(0)).abs().max()) <= 2e-4 * scale * P ** 0.5 + 1e-3
-        assert float((s[1] - (ref.double() ** 2).sum(0)).abs().max()) <= 1e-3 * float((ref.double() ** 2).sum(0).max())
+        # the statistics are those of the fp32 accumulators (small-P and generic kernels) or of the bf16 values that
+        # were stored (stream kernel: what BatchNorm will normalise) — the test accepts either, each at fp32 noise
+        yd = Y.double()
+        e1 = min(float((s[0] - ref.double().sum(0)).abs().max()), float((s[0] - yd.sum(0)).abs().max()))
+        e2 = min(float((s[1] - (ref.double() ** 2).sum(0)).abs().max()), float((s[1] - (yd ** 2).sum(0)).abs().max()))
+        assert e1 <= 4e-6 * float(ref.abs().double().sum(0).max()) + 1e-3, e1          # fp32 summation noise
+        assert e2 <= 2e-5 * float((ref.double() ** 2).sum(0).max()) + 1e-3, e2
 
 
 def test_fused_dropout_mask_statistics_and_backward():
