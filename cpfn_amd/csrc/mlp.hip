@@ -859,7 +859,8 @@ static inline int bn_rows_per_block(long long P) {
   while (r < 512 && (P + r - 1) / r > 1024) r *= 2;
   return r;
 }
-__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *__restrict__ Ga,
+template <bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DROP ? 3 : 4))) void bn_relu_bwd_kernel(const unsigned short *__restrict__ Ga,
                                                           const unsigned short *__restrict__ Yr,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, long long P, int C,
@@ -868,7 +869,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
                                                           const unsigned long long *__restrict__ drop_seed,
                                                           unsigned thresh16, float inv_keep) {
   __shared__ float s_red[2][256][8 + 1];
-  const unsigned long long seed = drop_seed ? *drop_seed : 0ull;
+  const unsigned long long seed = DROP ? *drop_seed : 0ull;
   const int t = threadIdx.x;
   const int chunks = C / 8;
   const long long row0 = (long long)blockIdx.x * rpb;
@@ -902,12 +903,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const unsigned short *
           const unsigned short *g = (const unsigned short *)&rg[u], *y = (const unsigned short *)&ry[u];
           unsigned short o[8];
           float f[8];
-          if (drop_seed) dropout_factors(seed, (unsigned long long)((min(rr, rend - 1) * C + c0) >> 3), thresh16, inv_keep, f);
+          if (DROP) dropout_factors(seed, (unsigned long long)((min(rr, rend - 1) * C + c0) >> 3), thresh16, inv_keep, f);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float yv = bf2f(y[j]);
             float ga = bf2f(g[j]);
-            if (drop_seed) ga *= f[j];              // incoming gradient is w.r.t. the dropped activation
+            if (DROP) ga *= f[j];                   // incoming gradient is w.r.t. the dropped activation
             const float gz = (live && fmaf(sc[j], yv, sh[j]) > 0.f) ? ga : 0.f;
             o[j] = f2bf(gz);
             a1[j] += gz;
@@ -1515,9 +1516,14 @@ extern "C" int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scal
                                 void *stream) {
   if (P <= 0 || C <= 0 || (C & 7) || !pow2(C / 8) || !Ga || !Y || !scale || !shift || !partial) return CPFN_EINVAL;
   if (drop_seed && !(drop_p >= 0.f && drop_p < 1.f)) return CPFN_EINVAL;
-  bn_relu_bwd_kernel<<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
-      (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial,
-      bn_rows_per_block(P), drop_seed, dropout_thresh16(drop_p), 1.f / (1.f - drop_p));
+  if (drop_seed)
+    bn_relu_bwd_kernel<true><<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
+        (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial,
+        bn_rows_per_block(P), drop_seed, dropout_thresh16(drop_p), 1.f / (1.f - drop_p));
+  else
+    bn_relu_bwd_kernel<false><<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
+        (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial,
+        bn_rows_per_block(P), nullptr, 0u, 1.f);
   return cpfn_launch_status();
 }
 
