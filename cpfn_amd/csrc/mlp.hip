@@ -136,14 +136,32 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int BN, int KS, bool STATS, bool ATR>
+template <int BN, int KS, bool STATS, bool ATR, bool BST>
 __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
                                             int row0, int n0, int wave, int lane, float (&st_s)[8],
                                             float (&st_q)[8], const float *s_ss /*[2][32*KS]: scale, shift*/,
-                                            const unsigned short *__restrict__ A, int lda, int next_row0) {
+                                            const unsigned short *__restrict__ A, int lda, int next_row0,
+                                            const unsigned short *__restrict__ Yb,
+                                            const float *s_bs /*[2][BN]: scale, shift of the layer below (BST)*/) {
   constexpr int NT = BN / 16;
+  constexpr int CPR = BN / 8;  // 16-byte chunks per row
+  // the 64-wide variants have the registers to request the pieces of Yb before the MFMAs (the two sa1 data gradients,
+  // 524288 rows: 47 / 36 us with the loads issued at the epilogue, where their latency is exposed); the 128-wide ones
+  // request them at the start of the epilogue
+  constexpr bool YB_EARLY = BST && BN == 64;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (arrays of HIP's uint4 struct end up in scratch memory)
+  u32x4 yb[BST ? 32 * CPR / 64 : 1];
   const int lr = lane & 15, lq = lane >> 4;
+  if (YB_EARLY) {
+#pragma unroll
+    for (int i = 0; i < 32 * CPR / 64; ++i) {
+      const int e = i * 64 + lane;
+      const int r = e / CPR, c = e - r * CPR;
+      const int p = min(row0 + wave * 32 + r, P - 1);
+      yb[i] = *(const u32x4 *)(Yb + (size_t)p * ldy + n0 + c * 8);
+    }
+  }
   f32x4 acc[NT][2];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
@@ -188,7 +206,19 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   // stores (Σy, Σy² of the bf16 values BatchNorm will actually normalise), reduced across lanes once after the
   // tile loop.  The first version summed the fp32 accumulators: 64 running sums per lane (all channels of the
   // lane's MFMA rows) — with them the 128-wide variants needed 380-490 registers and ran one workgroup per CU.
-  constexpr int CPR = BN / 8;  // 16-byte chunks per row
+  // BST (data-gradient launches): the output IS the gradient g_a of the layer below, so BatchNorm-backward pass 1 of
+  // that layer — Σ g_z and Σ g_z·y with g_z = g_a·[scale·y + shift > 0] — is taken here from the pieces being
+  // stored and the matching pieces of that layer's pre-BN output Yb (same rows, same 8-channel chunk, loaded just
+  // ahead of the store loop).  The separate bn_relu_bwd pass (which re-read g_a and y) is then not launched.
+  if (BST && !YB_EARLY) {
+#pragma unroll
+    for (int i = 0; i < 32 * CPR / 64; ++i) {
+      const int e = i * 64 + lane;
+      const int r = e / CPR, c = e - r * CPR;
+      const int p = min(row0 + wave * 32 + r, P - 1);
+      yb[i] = *(const u32x4 *)(Yb + (size_t)p * ldy + n0 + c * 8);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 32 * CPR / 64; ++i) {
     const int e = i * 64 + lane;
@@ -197,6 +227,35 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
     const uint4 vv = *(const uint4 *)&s_o[r * G_LDO + c * 8];
     if (p < P) {
       *(uint4 *)(Y + (size_t)p * ldy + n0 + c * 8) = vv;
+      if (BST) {
+        // (scale / shift of the lane's chunk come from LDS for every piece: as 16 more live registers they pushed
+        //  the 128-wide K = 128 variant over 256 and back to one workgroup per CU)
+        float bsc[8], bsh[8];
+        if (BN == 64 && KS <= 4) {   // (these variants have the registers: read once per tile, the compiler hoists it)
+          *(cpfn_f32x4 *)&bsc[0] = *(const cpfn_f32x4 *)&s_bs[c * 8];
+          *(cpfn_f32x4 *)&bsc[4] = *(const cpfn_f32x4 *)&s_bs[c * 8 + 4];
+          *(cpfn_f32x4 *)&bsh[0] = *(const cpfn_f32x4 *)&s_bs[BN + c * 8];
+          *(cpfn_f32x4 *)&bsh[4] = *(const cpfn_f32x4 *)&s_bs[BN + c * 8 + 4];
+        } else {
+          *(cpfn_f32x4 *)&bsc[0] = cpfn_lds_read4(&s_bs[c * 8]);
+          *(cpfn_f32x4 *)&bsc[4] = cpfn_lds_read4(&s_bs[c * 8 + 4]);
+          *(cpfn_f32x4 *)&bsh[0] = cpfn_lds_read4(&s_bs[BN + c * 8]);
+          *(cpfn_f32x4 *)&bsh[4] = cpfn_lds_read4(&s_bs[BN + c * 8 + 4]);
+        }
+        const unsigned g4[4] = {vv.x, vv.y, vv.z, vv.w};
+        const unsigned y4[4] = {yb[i][0], yb[i][1], yb[i][2], yb[i][3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g0 = __uint_as_float(g4[j] << 16), g1 = __uint_as_float(g4[j] & 0xffff0000u);
+          const float y0 = __uint_as_float(y4[j] << 16), y1 = __uint_as_float(y4[j] & 0xffff0000u);
+          const float z0 = fmaf(bsc[2 * j], y0, bsh[2 * j]) > 0.f ? g0 : 0.f;
+          const float z1 = fmaf(bsc[2 * j + 1], y1, bsh[2 * j + 1]) > 0.f ? g1 : 0.f;
+          st_s[2 * j] += z0;
+          st_s[2 * j + 1] += z1;
+          st_q[2 * j] = fmaf(z0, y0, st_q[2 * j]);
+          st_q[2 * j + 1] = fmaf(z1, y1, st_q[2 * j + 1]);
+        }
+      }
       if (STATS) {
         const unsigned w4[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -212,11 +271,12 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   }
 }
 
-template <int BN, int KS, bool STATS, bool ATR = false>
+template <int BN, int KS, bool STATS, bool ATR = false, bool BST = false>
 __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void mlp_gemm_stream_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
-    const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr) {
+    const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr,
+    const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */) {
   constexpr int NT = BN / 16, K = 32 * KS;
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
   __shared__ __attribute__((aligned(16))) unsigned short s_o[4][32 * G_LDO];
@@ -228,9 +288,13 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   if (ATR) {   // visible after the W-panel barrier
     for (int e = t; e < K; e += G_THREADS) { s_ss[e] = a_scale[e]; s_ss[K + e] = a_shift[e]; }
   }
+  __shared__ __attribute__((aligned(16))) float s_bs[BST ? 2 * BN : 4];
   float st_s[8], st_q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+  if (BST) {   // scale / shift of the layer below for this column block (visible after the W-panel barrier)
+    for (int e = t; e < BN; e += G_THREADS) { s_bs[e] = a_scale[n0 + e]; s_bs[BN + e] = a_shift[n0 + e]; }
+  }
   const int ntiles = (P + G_ROWS - 1) / G_ROWS;
   const int tile0 = blockIdx.x * tiles_per_wg;
   const int tile_end = min(tile0 + tiles_per_wg, ntiles);
@@ -241,11 +305,11 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     __syncthreads();
     for (int tile = tile0; tile < tile_end; ++tile) {
       // the reload inside is unconditional (row indices are clamped), so the loop body is straight-line
-      stream_tile<BN, KS, STATS, ATR>(a, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, A, lda,
-                                      min(tile + 1, ntiles - 1) * G_ROWS);
+      stream_tile<BN, KS, STATS, ATR, BST>(a, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, A,
+                                           lda, min(tile + 1, ntiles - 1) * G_ROWS, Yb, s_bs);
     }
   }
-  if (STATS) {
+  if (STATS || BST) {
     // once per workgroup: lanes that carry the same 8-channel chunk (lane % CPR) are summed by xor-shuffles, the
     // first CPR lanes of every wave hand their 8 channels over through LDS
     constexpr int CPR = BN / 8;
@@ -1391,10 +1455,24 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   return (int)((tiles + tpw - 1) / tpw);
 }
 
+static inline bool gemm_stream_k(long long P, int K) {
+  // whole-K panel in LDS: K <= 256.  K = 192 / 256 only for the long layers: with few row tiles the 50-68 KB panel
+  // (cold in a real step, unlike in a micro-benchmark loop) costs more than the generic kernel's 128-wide K chunks
+  return K == 64 || K == 128 || ((K == 192 || K == 256) && P >= 32768);
+}
+
+extern "C" int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N) {
+  return P > SP_MAX_ROWS && P <= 2000000000LL && gemm_stream_k(P, K) && N > 0 && (N & 63) == 0;
+}
+
 extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P, int K,
                              int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
-                             float *stats_partial, const float *a_scale, const float *a_shift, void *stream) {
+                             float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,
+                             void *stream) {
   if (P < 0 || K <= 0 || (K & 31) || N <= 0 || (N & 63) || !A || !W || !Y || lda < K || (lda & 7) || (!a_scale != !a_shift))
+    return CPFN_EINVAL;
+  if (bwd_y && (!stats_partial || !a_scale || gidx || bias || y_f32 || n_store != N || (ldy & 7) ||
+                !cpfn_mlp_gemm_can_fuse_bwd_stats(P, K, N)))
     return CPFN_EINVAL;
   if (P == 0) return 0;
   if (P > 2000000000LL) return CPFN_EINVAL;
@@ -1419,18 +1497,18 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
 #undef CPFN_SMALLP
     return cpfn_launch_status();
   }
-  // whole-K panel in LDS: K <= 256.  K = 192 / 256 only for the long layers: with few row tiles the 50-68 KB panel
-  // (cold in a real step, unlike in a micro-benchmark loop) costs more than the generic kernel's 128-wide K chunks
-  const bool stream_k = K == 64 || K == 128 || ((K == 192 || K == 256) && P >= 32768);
+  const bool stream_k = gemm_stream_k(P, K);
   // (the operand transform exists in the stream kernel only next to the BN statistics: forward layers)
   const bool stream_ok = stream_k && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0 &&
-                         (!a_scale || (stats_partial && K <= 128));
+                         (bwd_y || !a_scale || (stats_partial && K <= 128));
   if (stream_ok) {
     unsigned short *y = (unsigned short *)Y;
 #define CPFN_STREAM(BN_, KS_)                                                                                        \
   do {                                                                                                               \
     dim3 grid(gx, N / BN_);                                                                                          \
-    if (stats_partial && a_scale)                                                                                    \
+    if (bwd_y)                                                                                                       \
+      mlp_gemm_stream_kernel<BN_, KS_, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift, (const unsigned short *)bwd_y); \
+    else if (stats_partial && a_scale)                                                                               \
       mlp_gemm_stream_kernel<BN_, (KS_ <= 4 ? KS_ : 4), true, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift); \
     else if (stats_partial)                                                                                          \
       mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw); \

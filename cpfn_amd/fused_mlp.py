@@ -31,6 +31,9 @@ BF16 = torch.bfloat16
 BN_NOSTORE = os.environ.get("CPFN_BN_NOSTORE", "1") == "1"
 # BN + ReLU of a hidden layer applied on the operand load of the NEXT layer's GEMM and of its weight gradient
 # (the activated tensor of a hidden layer is then never written or read).  CPFN_BN_APPLY_FUSED=0 materialises it.
+# CPFN_BWD_STATS_FUSED=0: BatchNorm-backward pass 1 always as its own kernel (cpfn_bn_relu_bwd) instead of riding on
+# the data-gradient GEMM that produces the gradient
+BWD_STATS_FUSED = os.environ.get("CPFN_BWD_STATS_FUSED", "1") != "0"
 BN_APPLY_FUSED = os.environ.get("CPFN_BN_APPLY_FUSED", "1") == "1"
 
 
@@ -44,11 +47,13 @@ def _check(status, what):
 
 # ------------------------------------------------------------------ thin launch wrappers
 def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_store=None, P=None, w_trans=False,
-         a_scale=None, a_shift=None):
+         a_scale=None, a_shift=None, bwd_stats=None):
     """A [P,K] bf16 (row stride = A.stride(0)), Wb [N,K] bf16 -> Y [P, n_store] (bf16 | fp32).
     w_trans: Wb is [K,N] (a forward weight used for the data gradient; transposed inside the kernel).
     a_scale / a_shift [K] fp32: A is the previous layer's pre-BN output; relu(a_scale*A + a_shift) is applied to
-    the operand on the fly."""
+    the operand on the fly.
+    bwd_stats = (Y_below [P,N] bf16, scale [N], shift [N]) on a data-gradient launch: the kernel also leaves pass 1 of
+    the BatchNorm backward of the layer below (what cpfn_bn_relu_bwd computes) in the returned partial buffer."""
     h = _l.lib()
     K, N = (Wb.shape[0], Wb.shape[1]) if w_trans else (Wb.shape[1], Wb.shape[0])
     P = (gidx.numel() if gidx is not None else A.shape[0]) if P is None else P
@@ -56,14 +61,24 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
     Y = torch.empty(P, n_store, dtype=torch.float32 if out_f32 else BF16, device=A.device)
     part = None
     nblk = 0
+    yb = None
+    if bwd_stats is not None:
+        yb, a_scale, a_shift = bwd_stats
+        stats = True
     if stats:
         nblk = h.cpfn_mlp_gemm_blocks(P, N)
         part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
     _check(h.cpfn_mlp_gemm(_ptr(A), A.stride(0), _ptr(gidx), _ptr(Wb), 1 if w_trans else 0, P, K, N, _ptr(Y), n_store, 1 if out_f32 else 0,
-                           n_store, _ptr(bias), _ptr(part), _ptr(a_scale), _ptr(a_shift), _stream()), "cpfn_mlp_gemm")
-    # algorithmic traffic of this launch: read A and W once, write Y once (+ the stats partials)
-    _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + Y.element_size() * P * n_store + (8 * nblk * N if stats else 0))
+                           n_store, _ptr(bias), _ptr(part), _ptr(a_scale), _ptr(a_shift), _ptr(yb), _stream()), "cpfn_mlp_gemm")
+    # algorithmic traffic of this launch: read A and W once, write Y once (+ the stats partials; + Y_below when the
+    # BatchNorm-backward reduction of the layer below rides along)
+    _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + Y.element_size() * P * n_store + (8 * nblk * N if stats else 0)
+                 + (2 * P * N if yb is not None else 0))
     return Y, part, nblk
+
+
+def can_fuse_bwd_stats(P, K, N):
+    return BWD_STATS_FUSED and bool(_l.lib().cpfn_mlp_gemm_can_fuse_bwd_stats(P, K, N))
 
 
 def bn_finalize(part, nblk, N, count, gamma, beta, conv_bias, eps, momentum, rm, rv):
@@ -356,6 +371,7 @@ class _FusedStack(torch.autograd.Function):
         grads = [None] * (3 * len(layers))
         g = g.contiguous().to(BF16)
         gx = None
+        fused_part = None
         with torch.cuda.device(dev):
             for li in range(len(layers) - 1, -1, -1):
                 L = layers[li]
@@ -389,8 +405,12 @@ class _FusedStack(torch.autograd.Function):
                     # fused dropout: the gradient of the stack's output is masked on load (top layer only)
                     dseed = ctx.drop_seed if li == len(layers) - 1 else None
                     dp = float(cfg["dropout"][0]) if dseed is not None else 0.0
-                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None if nostore else _ptr(Gy), _ptr(part),
-                                              _ptr(dseed), dp, _stream()), "cpfn_bn_relu_bwd")
+                    if fused_part is not None:      # pass 1 rode on the data-gradient GEMM of the layer above
+                        part, nblk = fused_part
+                        fused_part = None
+                    else:
+                        _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None if nostore else _ptr(Gy),
+                                                  _ptr(part), _ptr(dseed), dp, _stream()), "cpfn_bn_relu_bwd")
                     _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
@@ -426,7 +446,14 @@ class _FusedStack(torch.autograd.Function):
                         _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin)
                     grads[3 * li] = dW.reshape(wshape)
                     if li > 0 or ctx.x_needs_grad:
-                        g, _, _ = gemm(Gy, Wb, w_trans=True)            # G_y [P,N] · W [N,Kp]
+                        # G_y [P,N] · W [N,Kp]; where the streaming kernel runs, it also reduces the BatchNorm backward
+                        # of the layer below from the gradient it is writing
+                        if li > 0 and BN_NOSTORE and can_fuse_bwd_stats(P, N, Kp) and saved[li - 1][5] is None:
+                            Yp, stp = saved[li - 1][2], saved[li - 1][3]
+                            g, fp_, nb_ = gemm(Gy, Wb, w_trans=True, bwd_stats=(Yp, stp[0], stp[1]))
+                            fused_part = (fp_, nb_)
+                        else:
+                            g, _, _ = gemm(Gy, Wb, w_trans=True)
                         if li == 0:
                             gx = g
         return (gx, None) + tuple(grads)

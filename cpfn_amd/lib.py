@@ -59,7 +59,8 @@ SIGNATURES = {
     "cpfn_similarity_soft": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_label_pool": [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp],
     "cpfn_mlp_gemm_blocks": [_ll, _i],
-    "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
     "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_bn_relu_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp, ctypes.c_uint64, _f, _vp, _vp],
     "cpfn_bn_relu_maxpool": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -248,9 +248,16 @@ CPFN_API int cpfn_eigh3(const double *S6, int64_t G, double *lam, double *V, voi
  * workgroup); K in {64,128} (and {192,256} for P >= 32768) -> whole-K streaming kernel; everything else (bias, fp32
  * or ragged output, gather, other K) -> 128-wide K chunks through a double-buffered LDS panel. */
 CPFN_API int cpfn_mlp_gemm_blocks(long long P, int N);
+/* bwd_y (optional; data-gradient launches, w_trans = 1): Y is then the gradient g_a of the layer BELOW, bwd_y that
+ * layer's pre-BN output [P,N] bf16 (row stride ldy) and a_scale / a_shift ITS BatchNorm scale / shift [N]; the launch
+ * also leaves pass 1 of that layer's BatchNorm backward in stats_partial — per-block sum(g_z), sum(g_z*y) with
+ * g_z = g_a*[a_scale*y + a_shift > 0], the layout cpfn_bn_relu_bwd writes — so cpfn_bn_relu_bwd is not needed for
+ * it.  Only where cpfn_mlp_gemm_can_fuse_bwd_stats(P,K,N) returns 1 (the streaming kernel). */
+CPFN_API int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N);
 CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
-                           float *stats_partial, const float *a_scale, const float *a_shift, void *stream);
+                           float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,
+                           void *stream);
 /* Batch statistics -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update with
  * torch's momentum / unbiased-variance convention; conv_bias re-enters the running mean). */
 CPFN_API int cpfn_bn_finalize(const float *partial, int nblk, int N, float count, const float *gamma,

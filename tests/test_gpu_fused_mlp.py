@@ -267,3 +267,28 @@ def test_fused_dropout_mask_statistics_and_backward():
         assert _rel(gx1, gx_ref) < 2e-2, _rel(gx1, gx_ref)
         for a, b in zip(gp1, gp_ref):
             assert _rel(a, b) < 2e-2
+
+
+@pytest.mark.parametrize("name,P,cin,widths,pool_k", [
+    ("sfp3-like", 40000 + 77, 128, [128, 128, 128], None),
+    ("sa2-like", 2 * 300 * 64, 131, [128, 128, 256], 64),
+    ("sa1-like", 40 * 1024, 64, [64, 64, 128], 16),
+])
+def test_bn_backward_reduction_on_the_data_gradient_gemm(name, P, cin, widths, pool_k, monkeypatch):
+    """BatchNorm-backward pass 1 of a hidden layer taken by the data-gradient GEMM that produces its gradient
+    (default where the streaming kernel runs) against the separate cpfn_bn_relu_bwd pass: the same sums in a
+    different order."""
+    from cpfn_amd import fused_mlp
+    convs, bns = _stack(cin, widths, seed=11)
+    g = torch.Generator().manual_seed(P)
+    x = torch.randn(P, cin, generator=g).to(dev())
+    gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(fused_mlp, "BWD_STATS_FUSED", fused)
+        res[fused] = _run(x, convs, bns, torch.bfloat16, pool_k, None, gout)
+    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
+    assert torch.equal(ya, yb)
+    assert _rel(gxa, gxb) < 2e-3, _rel(gxa, gxb)
+    for a, b in zip(gra, grb):
+        assert (a is None and b is None) or _rel(a, b) < 2e-3
