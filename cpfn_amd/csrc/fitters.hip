@@ -56,62 +56,153 @@ __device__ __forceinline__ void point_features(const float *p, const float *x, T
 }
 
 // grid (chunks, B); partial[b][chunk][K][52]
+// Staging is software-pipelined and spread over the whole workgroup: the next tile's coordinates, normals and
+// memberships are requested into registers before the FMA loop of the current tile; four lanes share a point and
+// each stores a quarter of its 52 features (the first version let 64 lanes compute and store all 52 doubles of a
+// point each — 52 stores with a 416-byte lane stride = 16-way bank conflicts — while three waves waited, and loaded
+// every tile synchronously: 48 us for 18 MB).
+constexpr int FM_LDP = FM_SLOTS + 2;   // row stride of the feature tile in doubles: 432 B keeps the rows 16-byte aligned
+                                       // (ds_read_b128 in the FMA loop) and spreads the staging stores (2-way, was 16-way)
+constexpr int FM_SUB = 4;              // point subsets of a tile (each handled by 52 lanes)
+// The FMA loop is bound by LDS bandwidth, not by fp64 FMAs: with a 2-instance x 4-slot register tile a lane read 40 B
+// of LDS per 8 FMAs (1.09 GB of LDS reads per launch = 14 us at the chip's LDS peak, 45 us measured).  Now a lane owns
+// 8 instances x 4 slots (64 B per 32 FMAs) and the 64 points of a tile are split over four lane groups whose partial
+// sums are added in a fixed order at the end.
 __global__ __launch_bounds__(FM_THREADS) void moments_fwd_kernel(const float *__restrict__ P,
                                                                  const float *__restrict__ X,
                                                                  const float *__restrict__ W, int N, int K,
                                                                  int pts_per_block, double *__restrict__ partial) {
-  __shared__ double s_phi[FM_TILE][FM_SLOTS];
-  __shared__ float s_w[FM_TILE][FM_KB];
-  __shared__ float s_wc[FM_TILE][FM_KB];
+  __shared__ __attribute__((aligned(16))) double s_phi[FM_TILE][FM_LDP];     // 27.6 KB; reused for the final combine
+  __shared__ __attribute__((aligned(16))) float s_w[FM_TILE][FM_KB];
+  __shared__ __attribute__((aligned(16))) float s_wc[FM_TILE][FM_KB];
+  static_assert(FM_THREADS == 4 * FM_TILE && FM_TILE * FM_KB == 8 * FM_THREADS, "staging maps below");
+  static_assert(FM_SUB * 16 * FM_SLOTS <= FM_TILE * FM_LDP, "combine buffer (half of the instances at a time)");
   const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, t = threadIdx.x;
   const int n0 = chunk * pts_per_block;
   const int n1 = min(N, n0 + pts_per_block);
-  const int mg = t % FM_GROUPS;   // slot group: slots 4mg .. 4mg+3
-  const int kg = t / FM_GROUPS;   // instance pair: kb + 2kg, kb + 2kg + 1   (kg < 16 active)
-  const bool active = kg < FM_KB / 2;
+  const int sub = t / 52, r52 = t % 52;       // lane group (points sub, sub+4, ... of a tile) and position in it
+  const int mg = r52 % FM_GROUPS;             // slot group: slots 4mg .. 4mg+3
+  const int kq = r52 / FM_GROUPS;             // instance octet: kb + 8kq .. kb + 8kq + 7
+  const bool active = sub < FM_SUB;
   const float(*wsel)[FM_KB] = mg < FM_A_GROUPS ? s_w : s_wc;
+  const int pi = t & 63, pq = t >> 6;         // staging: lane = point of the tile, wave = quarter of the feature rows
+                                              // (full-wave stores of ONE feature of 64 points: 13 per wave and tile)
 
   for (int kb = 0; kb < K; kb += FM_KB) {
-    double acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    double acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[j][0] = 0; acc[j][1] = 0; acc[j][2] = 0; acc[j][3] = 0; }
+    float rp[3], rx[3], rw[8];
+    // memberships of a tile: rows of K floats, contiguous in memory.  K % 4 == 0 (and a whole K block): float4 pieces
+    // (2 per lane for K = 28 instead of 8 scalar loads and 16 scalar LDS stores); otherwise element by element.
+    const bool wvec = (K & 3) == 0 && kb == 0 && K <= FM_KB && ((uintptr_t)W & 15) == 0;
+    const int k4 = K >> 2;                      // float4 pieces per row
+    auto fetch = [&](int base) __attribute__((always_inline)) {
+      const int n = min(base + pi, n1 - 1);
+      const float *pp = P + ((size_t)b * N + n) * 3, *xx = X + ((size_t)b * N + n) * 3;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { rp[j] = pp[j]; rx[j] = xx[j]; }
+      if (wvec) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = t + u * FM_THREADS, i = min(e / k4, FM_TILE - 1), q = e % k4;
+          const int nn = min(base + i, n1 - 1);
+          *(cpfn_f32x4 *)&rw[4 * u] = *(const cpfn_f32x4 *)(W + ((size_t)b * N + nn) * K + 4 * q);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = t + u * FM_THREADS, i = e / FM_KB, kk = e % FM_KB;
+          const int nn = min(base + i, n1 - 1), k = min(kb + kk, K - 1);
+          rw[u] = W[((size_t)b * N + nn) * K + k];
+        }
+      }
+    };
+    if (wvec) {   // the columns K..31 of the membership tiles are never written by the float4 path
+      for (int e = t; e < FM_TILE * FM_KB; e += FM_THREADS) { (&s_w[0][0])[e] = 0.f; (&s_wc[0][0])[e] = 0.f; }
+    }
+    fetch(n0);
     for (int base = n0; base < n1; base += FM_TILE) {
-      __syncthreads();
-      if (t < FM_TILE) {
-        const int n = base + t;
-        if (n < n1) {
-          point_features<double>(P + ((size_t)b * N + n) * 3, X + ((size_t)b * N + n) * 3, s_phi[t]);
+      __syncthreads();                       // the previous tile's FMA loop is done with the LDS tiles
+      {
+        double f[FM_SLOTS];
+        point_features<double>(rp, rx, f);
+        const double live = base + pi < n1 ? 1.0 : 0.0;
+        double *row = s_phi[pi];
+        if (pq == 0) {
+#pragma unroll
+          for (int j = 0; j < 13; ++j) row[j] = f[j] * live;
+        } else if (pq == 1) {
+#pragma unroll
+          for (int j = 13; j < 26; ++j) row[j] = f[j] * live;
+        } else if (pq == 2) {
+#pragma unroll
+          for (int j = 26; j < 39; ++j) row[j] = f[j] * live;
         } else {
-          for (int m = 0; m < FM_SLOTS; ++m) s_phi[t][m] = 0.0;
+#pragma unroll
+          for (int j = 39; j < 52; ++j) row[j] = f[j] * live;
         }
       }
-      for (int e = t; e < FM_TILE * FM_KB; e += FM_THREADS) {
-        const int i = e / FM_KB, kk = e % FM_KB;
-        const int n = base + i, k = kb + kk;
-        float w = 0.f, wc = 0.f;
-        if (n < n1 && k < K) {
-          w = W[((size_t)b * N + n) * K + k];
-          wc = fmaxf(w, FM_WEPS);
+      if (wvec) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = t + u * FM_THREADS, i = e / k4, q = e % k4;
+          if (i < FM_TILE) {
+            const bool ok = base + i < n1;
+            cpfn_f32x4 w = *(const cpfn_f32x4 *)&rw[4 * u], wc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = ok ? w[j] : 0.f; wc[j] = ok ? fmaxf(w[j], FM_WEPS) : 0.f; }
+            *(cpfn_f32x4 *)&s_w[i][4 * q] = w;
+            *(cpfn_f32x4 *)&s_wc[i][4 * q] = wc;
+          }
         }
-        s_w[i][kk] = w;
-        s_wc[i][kk] = wc;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = t + u * FM_THREADS, i = e / FM_KB, kk = e % FM_KB;
+          const bool ok = base + i < n1 && kb + kk < K;
+          const float w = ok ? rw[u] : 0.f;
+          s_w[i][kk] = w;
+          s_wc[i][kk] = ok ? fmaxf(w, FM_WEPS) : 0.f;
+        }
       }
       __syncthreads();
+      fetch(base + FM_TILE);                 // in flight during the FMA loop (clamped past the end)
       if (active) {
-#pragma unroll 4
-        for (int i = 0; i < FM_TILE; ++i) {
-          const double w0 = (double)wsel[i][2 * kg], w1 = (double)wsel[i][2 * kg + 1];
+#pragma unroll 2
+        for (int i = sub; i < FM_TILE; i += FM_SUB) {
+          const cpfn_f32x4 wa = *(const cpfn_f32x4 *)&wsel[i][8 * kq], wb = *(const cpfn_f32x4 *)&wsel[i][8 * kq + 4];
           const double f0 = s_phi[i][4 * mg], f1 = s_phi[i][4 * mg + 1], f2 = s_phi[i][4 * mg + 2],
                        f3 = s_phi[i][4 * mg + 3];
-          acc[0][0] += w0 * f0; acc[0][1] += w0 * f1; acc[0][2] += w0 * f2; acc[0][3] += w0 * f3;
-          acc[1][0] += w1 * f0; acc[1][1] += w1 * f1; acc[1][2] += w1 * f2; acc[1][3] += w1 * f3;
+          const float w8[8] = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const double w = (double)w8[j];
+            acc[j][0] += w * f0; acc[j][1] += w * f1; acc[j][2] += w * f2; acc[j][3] += w * f3;
+          }
         }
       }
     }
-    if (active) {
-      for (int j = 0; j < 2; ++j) {
-        const int k = kb + 2 * kg + j;
-        if (k < K) {
-          double *o = partial + (((size_t)b * nchunks + chunk) * K + k) * FM_SLOTS + 4 * mg;
+    // the four lane groups' partial sums, added in group order: half of the instances at a time through the
+    // (now idle) feature tile
+    double *s_cmb = &s_phi[0][0];              // [FM_SUB][16][52]
+    for (int h = 0; h < 2; ++h) {
+      __syncthreads();
+      if (active && (kq >> 1) == h) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          double *o = s_cmb + ((size_t)sub * 16 + (kq & 1) * 8 + j) * FM_SLOTS + 4 * mg;
           o[0] = acc[j][0]; o[1] = acc[j][1]; o[2] = acc[j][2]; o[3] = acc[j][3];
+        }
+      }
+      __syncthreads();
+      for (int e = t; e < 16 * FM_SLOTS; e += FM_THREADS) {
+        const int kl = e / FM_SLOTS, m = e - kl * FM_SLOTS;
+        const int k = kb + 16 * h + kl;
+        if (k < K) {
+          const double v = ((s_cmb[(0 * 16 + kl) * FM_SLOTS + m] + s_cmb[(1 * 16 + kl) * FM_SLOTS + m]) +
+                            s_cmb[(2 * 16 + kl) * FM_SLOTS + m]) + s_cmb[(3 * 16 + kl) * FM_SLOTS + m];
+          partial[(((size_t)b * nchunks + chunk) * K + k) * FM_SLOTS + m] = v;
         }
       }
     }
@@ -403,6 +494,8 @@ __global__ void eigh3_kernel(const double *__restrict__ S6, long long G, double 
 
 inline int pick_chunks(int B, int N, int *pts_per_block) {
   // ~2 workgroups per CU over the batch, at least one 64-point tile each, at most 64 chunks
+  // (256 / 1024 / 2048 workgroups measured: the moments pass 77 / 45 / 41 us against 48 at 512, but the ordered chunk
+  //  reduction behind each pass grows by 10 us per doubling)
   int want = (512 + B - 1) / (B > 0 ? B : 1);
   if (want < 1) want = 1;
   if (want > 64) want = 64;
