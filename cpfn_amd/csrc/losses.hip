@@ -99,6 +99,7 @@ __global__ void head_post_reduce_kernel(const float *__restrict__ partial, int c
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double a = 0, c = 0, d = 0;
+#pragma unroll 8
   for (int i = 0; i < chunks; ++i) {
     a += partial[((size_t)b * chunks + i) * 3];
     c += partial[((size_t)b * chunks + i) * 3 + 1];
@@ -256,6 +257,7 @@ __global__ void chunk_sum_f32_kernel(const float *__restrict__ partial, int chun
   if (e >= total) return;
   const long long b = e / per_b, r = e % per_b;
   float s = 0.f;
+#pragma unroll 8
   for (int c = 0; c < chunks; ++c) s += partial[((size_t)b * chunks + c) * per_b + r];
   out[e] = s;
 }
