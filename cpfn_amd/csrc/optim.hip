@@ -9,17 +9,26 @@
 namespace {
 
 // coef[0] = lr / (1 - beta1^t), coef[1] = sqrt(1 - beta2^t), coef[2] = 1 when the step is skipped; t = step + 1.
-// One lane.  beta^t is carried as a running fp64 product in pows[2] (beta1^step, beta2^step): calling pow() here
+// One wave.  beta^t is carried as a running fp64 product in pows[2] (beta1^step, beta2^step): calling pow() here
 // costs 25 us of single-lane fp64 software — more than the streaming pass over the parameters.
-__global__ void adam_prepare_kernel(const float *__restrict__ lr, float beta1, float beta2, float *__restrict__ step,
-                                    double *__restrict__ pows, const float *__restrict__ found_inf,
-                                    float *__restrict__ coef) {
-  const bool skip = found_inf && *found_inf != 0.f;
+// The step is skipped when *found_inf != 0 or any of the nf_count per-block flags of the gradient scan
+// (nonfinite_partial_kernel) is set — the scan's final reduction and the trainer's skipped-step counter ride here
+// instead of being two more launches.
+__global__ __launch_bounds__(64) void adam_prepare_kernel(const float *__restrict__ lr, float beta1, float beta2,
+                                                         float *__restrict__ step, double *__restrict__ pows,
+                                                         const float *__restrict__ found_inf, float *__restrict__ coef,
+                                                         const unsigned *__restrict__ nf_partial, int nf_count,
+                                                         float *__restrict__ skipped) {
+  unsigned bad = 0;
+  for (int i = threadIdx.x; i < nf_count; i += 64) bad |= nf_partial[i];
+  const bool skip = __ballot(bad != 0) != 0ull || (found_inf && *found_inf != 0.f);
+  if (threadIdx.x != 0) return;
   const double b1t = pows[0] * (double)beta1, b2t = pows[1] * (double)beta2;
   coef[0] = *lr / (float)(1.0 - b1t);
   coef[1] = sqrtf((float)(1.0 - b2t));
   coef[2] = skip ? 1.f : 0.f;
   if (!skip) { *step += 1.f; pows[0] = b1t; pows[1] = b2t; }
+  else if (skipped) *skipped += 1.f;
 }
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g,
@@ -94,10 +103,20 @@ __global__ void nonfinite_final_kernel(const unsigned *__restrict__ partial, int
 
 }  // namespace
 
+static inline int nonfinite_blocks(long long n) { return (int)(n / 4096 + 1 < 256 ? n / 4096 + 1 : 256); }
+
+extern "C" int cpfn_nonfinite_blocks(long long n) { return n < 0 ? 0 : nonfinite_blocks(n); }
+
+extern "C" int cpfn_nonfinite_partial(const float *x, long long n, unsigned *workspace256, void *stream) {
+  if (n < 0 || !x || !workspace256 || ((uintptr_t)x & 15)) return CPFN_EINVAL;
+  nonfinite_partial_kernel<<<nonfinite_blocks(n), 256, 0, (hipStream_t)stream>>>(x, n, workspace256);
+  return cpfn_launch_status();
+}
+
 extern "C" int cpfn_nonfinite_flag(const float *x, long long n, unsigned *workspace256, float *flag, void *stream) {
   if (n < 0 || !x || !workspace256 || !flag || ((uintptr_t)x & 15)) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)(n / 4096 + 1 < 256 ? n / 4096 + 1 : 256);
+  const int nblk = nonfinite_blocks(n);
   nonfinite_partial_kernel<<<nblk, 256, 0, st>>>(x, n, workspace256);
   nonfinite_final_kernel<<<1, 64, 0, st>>>(workspace256, nblk, flag);
   return cpfn_launch_status();
@@ -105,12 +124,14 @@ extern "C" int cpfn_nonfinite_flag(const float *x, long long n, unsigned *worksp
 
 extern "C" int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
                               float beta2, float eps, float weight_decay, float *step, double *pows,
-                              const float *found_inf, float *coef3, void *stream) {
-  if (n < 0 || !p || !g || !m || !v || !lr || !step || !pows || !coef3) return CPFN_EINVAL;
+                              const float *found_inf, float *coef3, const unsigned *nf_partial, int nf_count,
+                              float *skipped, void *stream) {
+  if (n < 0 || !p || !g || !m || !v || !lr || !step || !pows || !coef3 || nf_count < 0 || (nf_count > 0 && !nf_partial))
+    return CPFN_EINVAL;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CPFN_EINVAL;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  adam_prepare_kernel<<<1, 1, 0, st>>>(lr, beta1, beta2, step, pows, found_inf, coef3);
+  adam_prepare_kernel<<<1, 64, 0, st>>>(lr, beta1, beta2, step, pows, found_inf, coef3, nf_partial, nf_count, skipped);
   adam_flat_kernel<<<cpfn_cdiv(cpfn_cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, coef3);
   return cpfn_launch_status();
 }

@@ -50,7 +50,9 @@ SIGNATURES = {
     "cpfn_fit_pack_fwd": [_vp, _vp, _vp, _i64, _vp, _vp],
     "cpfn_fit_pack_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "cpfn_nonfinite_flag": [_vp, _ll, _vp, _vp, _vp],
-    "cpfn_adam_flat": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_adam_flat": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "cpfn_nonfinite_blocks": [_ll],
+    "cpfn_nonfinite_partial": [_vp, _ll, _vp, _vp],
     "cpfn_hungarian_match": [_vp, _vp, _i, _i, _vp, _vp],
     "cpfn_p_coverage": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cpfn_loss_tail": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

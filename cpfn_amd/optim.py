@@ -40,12 +40,16 @@ class FlatAdam(torch.optim.Optimizer):
         self.beta_pows = torch.ones(2, dtype=torch.float64, device=dev)      # beta1^step, beta2^step
         self._lr_host = None
         self.found_inf = None
+        self._nf_ws = None
         g = self.param_groups[0]
         g["lr"] = self.lr_dev                      # the trainer's staircase does `group['lr'].fill_(lr)`
         self.lr_dev.fill_(float(lr))
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, check_gradients=False, skipped=None):
+        """check_gradients: scan the flat gradient for NaN / inf in the same launch sequence and skip the step if any
+        is found (the reference's per-parameter isinf/isnan scan, Utils/training_utils.py:151-156) — the scan's final
+        reduction and the optional `skipped` device counter (+1 per skipped step) live in the 1-wave prepare kernel."""
         g = self.param_groups[0]
         lr = g["lr"]
         if not isinstance(lr, torch.Tensor):       # someone assigned a float: mirror it into the device scalar
@@ -54,12 +58,19 @@ class FlatAdam(torch.optim.Optimizer):
                 self._lr_host = lr
             lr = self.lr_dev
         b1, b2 = g["betas"]
+        h = _l.lib()
+        grads = self.bucket.flat
         with torch.cuda.device(self.flat_p.device):
-            _l.check(_l.lib().cpfn_adam_flat(_ptr(self.flat_p), _ptr(self.bucket.flat), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                             self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
-                                             float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows), _ptr(self.found_inf),
-                                             _ptr(self._coef),
-                                             _stream()),
+            nf_ws, nf_count = None, 0
+            if check_gradients:
+                if self._nf_ws is None:
+                    self._nf_ws = torch.empty(256, dtype=torch.int32, device=self.flat_p.device)
+                nf_ws, nf_count = self._nf_ws, h.cpfn_nonfinite_blocks(grads.numel())
+                _l.check(h.cpfn_nonfinite_partial(_ptr(grads), grads.numel(), _ptr(nf_ws), _stream()), "cpfn_nonfinite_partial")
+            _l.check(h.cpfn_adam_flat(_ptr(self.flat_p), _ptr(grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                      self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
+                                      float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows), _ptr(self.found_inf),
+                                      _ptr(self._coef), _ptr(nf_ws), nf_count, _ptr(skipped), _stream()),
                      "cpfn_adam_flat")
 
     def state_dict(self):

@@ -204,6 +204,18 @@ class SPFNTrainer:
         mark(geom)
         return geom
 
+    def _checked_optimizer_step(self, skipped):
+        """Finite check of the flat gradient + optimizer step (skipped on the device when a NaN / inf is found) +
+        `skipped` counter.  FlatAdam does all of it in three launches; other optimizers get the flag tensor."""
+        from .optim import FlatAdam
+        if isinstance(self.optimizer, FlatAdam):
+            self.optimizer.found_inf = None
+            self.optimizer.step(check_gradients=True, skipped=skipped)
+        else:
+            self.optimizer.found_inf = self.bucket.nonfinite_flag()
+            self.optimizer.step()
+            skipped += self.optimizer.found_inf
+
     def losses(self, batch, fps_start=None):
         """Forward + losses (training_utils.py:140-146).  Returns the reference's 6 scalars."""
         P = batch["P"]
@@ -362,10 +374,7 @@ class SPFNTrainer:
                 out[0].backward()
                 self.bucket.collect()
                 if world == 1:
-                    st["found_inf"] = self.bucket.nonfinite_flag()
-                    self.optimizer.found_inf = st["found_inf"]
-                    self.optimizer.step()
-                    st["skipped"] += st["found_inf"]
+                    self._checked_optimizer_step(st["skipped"])
                 st["out"] = tuple(o.detach() for o in out)
                 self._gstream.wait_stream(self._gside)              # join
             st["g"] = g
@@ -400,10 +409,7 @@ class SPFNTrainer:
             out[0].backward()
             self.bucket.collect()
             if world == 1:
-                st["found_inf"] = self.bucket.nonfinite_flag()
-                self.optimizer.found_inf = st["found_inf"]
-                self.optimizer.step()
-                st["skipped"] += st["found_inf"]
+                self._checked_optimizer_step(st["skipped"])
             st["out"] = tuple(o.detach() for o in out)
             self._gstream.wait_stream(self._gside)                  # join
         st["g1"], st["g1b"], st["g2"] = g1, g1b, g2
@@ -461,9 +467,7 @@ class SPFNTrainer:
             st["g"].replay()                                   # the whole step: no host synchronisation
             if st["world"] > 1:
                 self.bucket.all_reduce_mean()
-                self.optimizer.found_inf = self.bucket.nonfinite_flag()
-                self.optimizer.step()
-                st["skipped"] += self.optimizer.found_inf
+                self._checked_optimizer_step(st["skipped"])
             self.global_step += 1
             return st["out"]
         st["g1"].replay()
@@ -478,9 +482,7 @@ class SPFNTrainer:
         st["g2"].replay()
         if st["world"] > 1:
             self.bucket.all_reduce_mean()
-            self.optimizer.found_inf = self.bucket.nonfinite_flag()
-            self.optimizer.step()
-            st["skipped"] += self.optimizer.found_inf
+            self._checked_optimizer_step(st["skipped"])
         self.global_step += 1
         return st["out"]
 

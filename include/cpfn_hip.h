@@ -402,7 +402,14 @@ CPFN_API int cpfn_nonfinite_flag(const float *x, long long n, unsigned *workspac
  * device scalars; coef3 = 3 floats of device scratch (bias-correction terms). */
 CPFN_API int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr,
                             float beta1, float beta2, float eps, float weight_decay, float *step,
-                            double *pows, const float *found_inf, float *coef3, void *stream);
+                            double *pows, const float *found_inf, float *coef3,
+                            const unsigned *nf_partial /* optional: the nf_count per-block flags left by
+                            cpfn_nonfinite_partial over g; any set flag skips the step */, int nf_count,
+                            float *skipped /* optional device counter, +1 for a skipped step */, void *stream);
+/* First half of cpfn_nonfinite_flag: workspace256[i] = 1 if block i of x holds a NaN / inf, for
+ * i < cpfn_nonfinite_blocks(n) (<= 256); the reduction is then done by cpfn_adam_flat's prepare kernel. */
+CPFN_API int cpfn_nonfinite_blocks(long long n);
+CPFN_API int cpfn_nonfinite_partial(const float *x, long long n, unsigned *workspace256, void *stream);
 
 /* ------------------------------------------------------------------ patch merging (evaluation, config 5)
  * Replaces the two tensor functions of Utils/merging_utils.py that evaluation_localSPFN.py:101-110 runs on

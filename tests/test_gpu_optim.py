@@ -63,3 +63,26 @@ def test_nonfinite_flag():
     b.flat.normal_()
     b.flat[5] = 3.0e38                               # large but finite
     assert float(b.nonfinite_flag()) == 0.0
+
+
+def test_checked_step_scans_gradients_and_counts_skips():
+    """FlatAdam.step(check_gradients=True): the finite scan of the flat gradient, the skip decision and the
+    skipped-step counter in the optimizer's own launches (what the graph-replayed trainer uses)."""
+    from cpfn_amd import training
+    from cpfn_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    m = torch.nn.Linear(1000, 37).to(dev)
+    bucket = training.FlatGradBucket(m)
+    opt = FlatAdam(bucket, lr=1e-2)
+    skipped = torch.zeros((), device=dev)
+    for pos, val, skip in ((None, 0.0, False), (0, float("nan"), True), (bucket.flat.numel() - 1, float("inf"), True),
+                           (777, 3.0e38, False), (12345, -float("inf"), True)):
+        bucket.flat.normal_()
+        if pos is not None:
+            bucket.flat[pos] = val
+        before, steps, sk = opt.flat_p.clone(), float(opt.step_count), float(skipped)
+        opt.step(check_gradients=True, skipped=skipped)
+        assert (float(opt.step_count) == steps) == skip
+        assert float(skipped) == sk + (1.0 if skip else 0.0)
+        assert torch.equal(opt.flat_p, before) == skip
+    assert float(skipped) == 3.0 and float(opt.step_count) == 2.0
