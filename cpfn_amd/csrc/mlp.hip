@@ -517,9 +517,16 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
           if (valid) {
             if (y_f32) {
               float *o = (float *)Y + (size_t)p * ldy + n;
+              if (n + 3 < n_store) {
+                // one 16-byte store (dword-aligned: the row stride of the packed heads is 35 floats) instead of four
+                // guarded dword stores — the fc2 launch issued 32 scalar stores per lane and tile
+                typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                *(f32x4_a4 *)o = (f32x4_a4){v[0], v[1], v[2], v[3]};
+              } else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (n + r < n_store) o[r] = v[r];
+                for (int r = 0; r < 4; ++r)
+                  if (n + r < n_store) o[r] = v[r];
+              }
             } else if (n + 3 < n_store) {
               bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
               *(bf16x4 *)((unsigned short *)Y + (size_t)p * ldy + n) = o;
