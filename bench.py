@@ -91,7 +91,16 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    ap.add_argument("--workload", default="global", choices=["global", "local"],
+                    help="global (default) = BASELINE.json configs[1], the config the metric is quoted on; local = "
+                         "configs[2] (LocalSPFN: 32 patches/GPU, 21 instances, fitter losses off) as an extra data point")
     args = ap.parse_args()
+    global BATCH_PER_GPU, N_INSTANCES
+    mult = None
+    if args.workload == "local":                        # Configs/config_localSPFN.yml:10-11, training_SPFN.py:69-71
+        BATCH_PER_GPU, N_INSTANCES = 32, 21
+        mult = dict(miou=1.0, normal=1.0, type=1.0, parameter=0.0, residue=0.0, total=1.0)
+        args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,7 +125,7 @@ def main():
     model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, N_INSTANCES]).to(dev)
     model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     training.broadcast_parameters(model)
-    trainer = training.SPFNTrainer(model, batch_size=BATCH_PER_GPU * world, use_graphs=not args.no_graphs)
+    trainer = training.SPFNTrainer(model, batch_size=BATCH_PER_GPU * world, use_graphs=not args.no_graphs, multipliers=mult)
     batch = {k: v.to(dev) for k, v in
              synthetic.training_batch(BATCH_PER_GPU, N_POINTS, N_INSTANCES, seed=1000 + rank).items()}
     torch.manual_seed(1234 + rank)                      # per-rank FPS starts / dropout masks
@@ -169,13 +178,15 @@ def main():
         if os.path.exists(tpath):                       # PMC pass (rocprofv3 --pmc), see profiles/README.md
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {
-            "metric": "point-clouds/sec (8192 pts, GlobalSPFN fwd+bwd)",
+            "metric": "point-clouds/sec (8192 pts, %sSPFN fwd+bwd)" % ("Global" if args.workload == "global" else "Local"),
             "value": clouds / elapsed, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "GlobalSPFN training step (fwd + 5 losses incl. fitters + bwd + Adam), "
-                                   "%d clouds/GPU x %d pts, %d instances, 4 primitive types"
-                                   % (BATCH_PER_GPU, N_POINTS, N_INSTANCES),
+            "config": {"workload": ("GlobalSPFN training step (fwd + 5 losses incl. fitters + bwd + Adam), "
+                                    "%d clouds/GPU x %d pts, %d instances, 4 primitive types" if args.workload == "global" else
+                                    "LocalSPFN training step (fwd + normal/type/mIoU losses + bwd + Adam; fitter losses "
+                                    "switched off as in config_localSPFN.yml), %d patches/GPU x %d pts, %d instances, "
+                                    "4 primitive types") % (BATCH_PER_GPU, N_POINTS, N_INSTANCES),
                        "global_batch": BATCH_PER_GPU * world, "points": N_POINTS,
                        "parallelism": "dp%d" % world, "loss_last": float(out[0]),
                        "launch": ("eager" if trainer._graph is None else

@@ -307,6 +307,11 @@ class SPFNTrainer:
 
     def _capture(self, batch):
         from .SPFN import fused_losses as fl
+        # The parameters' AccumulateGrad nodes were created by the eager warm-up steps on the default stream and are
+        # reused while capturing on the capture stream: autograd warns about that on every backward pass although the
+        # capture is self-contained (every gradient is produced and consumed on the capture stream).
+        if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dev = batch["P"].device
         B, N, _ = batch["P"].shape
         K = batch["T_gt"].shape[1]
