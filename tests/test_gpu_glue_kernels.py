@@ -1,0 +1,92 @@
+"""GPU: the small bookkeeping kernels behind the C ABI that replaced framework glue ops, each against the PyTorch
+expression it replaced (ragged sizes, padding, alignment cases)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _call(name, *args):
+    from cpfn_amd import lib as _l
+    _l.check(getattr(_l.lib(), name)(*args), name)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_multi_cast_matches_per_tensor_copies():
+    from cpfn_amd import fused_mlp
+    g = torch.Generator().manual_seed(0)
+    jobs = []
+    for rows, cols, ld, f32 in [(64, 3, 64, 0), (128, 131, 192, 0), (1, 1, 8, 0), (256, 259, 320, 0), (1, 35, 35, 1),
+                                (37, 128, 128, 0), (1000, 129, 136, 1)]:
+        src = torch.randn(rows, cols, generator=g).to(dev())
+        dst = torch.full((rows, ld), 7.0, dtype=torch.float32 if f32 else torch.bfloat16, device=dev())
+        jobs.append((src, dst, rows, cols, ld, f32))
+    arr = (fused_mlp._CastDesc * len(jobs))(*[fused_mlp._CastDesc(s.data_ptr(), d.data_ptr(), r, c, ld, f) for s, d, r, c, ld, f in jobs])
+    _call("cpfn_multi_cast", arr, len(jobs), _stream())
+    for src, dst, rows, cols, ld, f32 in jobs:
+        want = src if f32 else src.to(torch.bfloat16)
+        assert torch.equal(dst[:, :cols], want)
+        assert bool((dst[:, cols:] == 7.0).all())               # padding columns untouched
+
+
+def test_count_labels():
+    from cpfn_amd.SPFN import fused_losses as fl
+    g = torch.Generator().manual_seed(1)
+    for B, N, hi in [(1, 1, 1), (3, 1000, 28), (16, 8192, 21), (5, 4097, 200)]:
+        I = torch.randint(0, hi, (B, N), generator=g)
+        I[0, -1] = hi - 1
+        got = fl.count_gt(I.to(dev()))
+        assert torch.equal(got.cpu(), I.max(dim=1)[0] + 1)
+
+
+def test_concat_pos_feats_forward_and_backward():
+    from cpfn_amd import autograd_ops
+    g = torch.Generator().manual_seed(2)
+    for R, C, cpad in [(1, 8, 64), (2048, 256, 320), (77, 128, 192)]:
+        xyz = torch.randn(R, 3, generator=g).to(dev())
+        feats = torch.randn(R, C, generator=g).to(dev()).to(torch.bfloat16).requires_grad_(True)
+        out = autograd_ops.ConcatPosFeats.apply(xyz, feats, cpad)
+        want = torch.cat([xyz.to(torch.bfloat16), feats.detach(), torch.zeros(R, cpad - C - 3, dtype=torch.bfloat16, device=dev())], 1)
+        assert torch.equal(out, want)
+        gout = torch.randn(R, cpad, generator=g).to(dev()).to(torch.bfloat16)
+        out.backward(gout)
+        assert torch.equal(feats.grad, gout[:, 3:3 + C])
+
+
+def test_compacting_split_reduce():
+    """cpfn_multi_split_reduce with row_in / row_out: the weight gradient of a zero-padded K, summed over the splits
+    in subset order and compacted to [N, cin] by the same launch."""
+    from cpfn_amd import fused_mlp
+    g = torch.Generator().manual_seed(3)
+    N, Kp, cin, splits = 96, 192, 131, 7
+    ws = torch.randn(splits, N, Kp, generator=g).to(dev())
+    flat = torch.randn(5, 1000, generator=g).to(dev())
+    out_c = torch.empty(N, cin, device=dev())
+    out_f = torch.empty(1000, device=dev())
+    arr = (fused_mlp._ReduceDesc * 2)(fused_mlp._ReduceDesc(ws.data_ptr(), out_c.data_ptr(), N * Kp, splits, Kp, cin),
+                                      fused_mlp._ReduceDesc(flat.data_ptr(), out_f.data_ptr(), 1000, 5, 0, 0))
+    _call("cpfn_multi_split_reduce", arr, 2, _stream())
+    torch.testing.assert_close(out_c, ws.sum(0)[:, :cin], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out_f, flat.sum(0), rtol=1e-5, atol=1e-5)
+
+
+def test_colsum_with_padded_bf16_copy():
+    g = torch.Generator().manual_seed(4)
+    for P, C in [(1, 35), (131072, 35), (5000, 64), (257, 3)]:
+        X = torch.randn(P, C, generator=g).to(dev())
+        ws = torch.empty(((P + 255) // 256) * C, device=dev())
+        out = torch.empty(C, device=dev())
+        pad = torch.full((P, 64), 5.0, dtype=torch.bfloat16, device=dev())
+        _call("cpfn_colsum_f32", X.data_ptr(), P, C, ws.data_ptr(), out.data_ptr(), pad.data_ptr(), _stream())
+        torch.testing.assert_close(out, X.sum(0), rtol=1e-4, atol=1e-3)
+        assert torch.equal(pad[:, :C], X.to(torch.bfloat16)) and bool((pad[:, C:] == 0).all())
