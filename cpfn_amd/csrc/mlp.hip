@@ -113,17 +113,21 @@ __device__ __forceinline__ void fill_w_panel(unsigned short *s_w, const unsigned
   }
 }
 
+// Buffer addressing for the streaming kernel: SGPR base, ONE lane offset per operand row computed once per kernel,
+// the tile position added as one 32-bit value (in the lane offset: the scalar offset of a buffer instruction is not
+// bounds-checked).  Rows past P are out of range for the hardware bounds check (loads return zeros, stores are
+// dropped), so there is no per-tile 64-bit address arithmetic, clamping or exec masking: ~140 of
+// the ~750 vector instructions per tile of the first version were address arithmetic (a wave64 VALU instruction costs
+// 4 cycles; with BatchNorm statistics and operand transform these kernels are VALU-limited, not MFMA-limited).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 template <int KS>
-__device__ __forceinline__ void stream_load_a(bf16x8 (&af)[2][KS], const unsigned short *__restrict__ A, int lda,
-                                              int P, int row0, int wave, int lr, int lq) {
+__device__ __forceinline__ void stream_load_a(bf16x8 (&af)[2][KS], __amdgpu_buffer_rsrc_t rs_a, const unsigned (&aoff)[2],
+                                              unsigned tile_off /* bytes, wave-uniform */) {
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt) {
-    int p = row0 + wave * 32 + tt * 16 + lr;
-    p = p < P ? p : P - 1;
-    const unsigned short *src = A + (size_t)p * lda + 8 * lq;
+  for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) af[tt][ks] = *(const bf16x8 *)(src + ks * 32);
-  }
+    for (int ks = 0; ks < KS; ++ks)
+      af[tt][ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, aoff[tt] + tile_off + ks * 64, 0, 0));
 }
 
 // Sum over the 16 lanes of a DPP row (lanes that share lane>>4): every lane ends up with the total.
@@ -136,13 +140,18 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+struct StreamBufs {
+  __amdgpu_buffer_rsrc_t a, y, yb;       // operand rows, output rows, (BST) pre-BN output of the layer below
+  unsigned aoff[2];                      // lane byte offset of its two operand rows inside a tile
+  unsigned yoff;                         // lane byte offset of its first output piece inside a tile
+  unsigned a_tile, y_tile, y_step;       // bytes per 128-row tile of A / Y, bytes between a lane's output pieces
+};
+
 template <int BN, int KS, bool STATS, bool ATR, bool BST>
 __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned short *s_w,
-                                            unsigned short *s_o, unsigned short *__restrict__ Y, int ldy, int P,
-                                            int row0, int n0, int wave, int lane, float (&st_s)[8],
-                                            float (&st_q)[8], const float *s_ss /*[2][32*KS]: scale, shift*/,
-                                            const unsigned short *__restrict__ A, int lda, int next_row0,
-                                            const unsigned short *__restrict__ Yb,
+                                            unsigned short *s_o, const StreamBufs &sb, int P, int row0, int next_tile,
+                                            int wave, int lane, float (&st_s)[8], float (&st_q)[8],
+                                            const float *s_ss /*[2][32*KS]: scale, shift*/,
                                             const float *s_bs /*[2][BN]: scale, shift of the layer below (BST)*/) {
   constexpr int NT = BN / 16;
   constexpr int CPR = BN / 8;  // 16-byte chunks per row
@@ -150,17 +159,12 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   // 524288 rows: 47 / 36 us with the loads issued at the epilogue, where their latency is exposed); the 128-wide ones
   // request them at the start of the epilogue
   constexpr bool YB_EARLY = BST && BN == 64;
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (arrays of HIP's uint4 struct end up in scratch memory)
-  u32x4 yb[BST ? 32 * CPR / 64 : 1];
+  u32x4_t yb[BST ? 32 * CPR / 64 : 1];   // (a plain vector type: arrays of HIP's uint4 struct end up in scratch memory)
   const int lr = lane & 15, lq = lane >> 4;
+  const unsigned y_tile_off = (unsigned)(row0 / G_ROWS) * sb.y_tile;
   if (YB_EARLY) {
 #pragma unroll
-    for (int i = 0; i < 32 * CPR / 64; ++i) {
-      const int e = i * 64 + lane;
-      const int r = e / CPR, c = e - r * CPR;
-      const int p = min(row0 + wave * 32 + r, P - 1);
-      yb[i] = *(const u32x4 *)(Yb + (size_t)p * ldy + n0 + c * 8);
-    }
+    for (int i = 0; i < 32 * CPR / 64; ++i) yb[i] = __builtin_amdgcn_raw_buffer_load_b128(sb.yb, sb.yoff + y_tile_off + i * sb.y_step, 0, 0);
   }
   f32x4 acc[NT][2];
 #pragma unroll
@@ -191,7 +195,7 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   // requested before the MFMAs of tile t): 268 registers for the plain 128-wide variant and 454-490 with the
   // statistics — one wave per SIMD, so a CU held ONE workgroup and its load / compute / store phases overlapped
   // with nothing.  Occupancy, not a deeper per-wave pipeline, is what hides the latency here.
-  stream_load_a<KS>(af, A, lda, P, next_row0, wave, lr, lq);
+  stream_load_a<KS>(af, sb.a, sb.aoff, (unsigned)next_tile * sb.a_tile);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
@@ -212,12 +216,7 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   // ahead of the store loop).  The separate bn_relu_bwd pass (which re-read g_a and y) is then not launched.
   if (BST && !YB_EARLY) {
 #pragma unroll
-    for (int i = 0; i < 32 * CPR / 64; ++i) {
-      const int e = i * 64 + lane;
-      const int r = e / CPR, c = e - r * CPR;
-      const int p = min(row0 + wave * 32 + r, P - 1);
-      yb[i] = *(const u32x4 *)(Yb + (size_t)p * ldy + n0 + c * 8);
-    }
+    for (int i = 0; i < 32 * CPR / 64; ++i) yb[i] = __builtin_amdgcn_raw_buffer_load_b128(sb.yb, sb.yoff + y_tile_off + i * sb.y_step, 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < 32 * CPR / 64; ++i) {
@@ -225,8 +224,8 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
     const int r = e / CPR, c = e - r * CPR;
     const int p = row0 + wave * 32 + r;
     const uint4 vv = *(const uint4 *)&s_o[r * G_LDO + c * 8];
-    if (p < P) {
-      *(uint4 *)(Y + (size_t)p * ldy + n0 + c * 8) = vv;
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){vv.x, vv.y, vv.z, vv.w}, sb.y, sb.yoff + y_tile_off + i * sb.y_step, 0, 0);
+    if (p < P) {      // (the store needs no guard: rows past P are out of the buffer's range; the sums do)
       if (BST) {
         // (scale / shift of the lane's chunk come from LDS for every piece: as 16 more live registers they pushed
         //  the 128-wide K = 128 variant over 256 and back to one workgroup per CU)
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
     const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr,
     const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */) {
-  constexpr int NT = BN / 16, K = 32 * KS;
+  constexpr int NT = BN / 16, K = 32 * KS, CPR = BN / 8;
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
   __shared__ __attribute__((aligned(16))) unsigned short s_o[4][32 * G_LDO];
   __shared__ __attribute__((aligned(16))) float s_red[4][2][BN];
@@ -295,18 +294,30 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   if (BST) {   // scale / shift of the layer below for this column block (visible after the W-panel barrier)
     for (int e = t; e < BN; e += G_THREADS) { s_bs[e] = a_scale[n0 + e]; s_bs[BN + e] = a_shift[n0 + e]; }
   }
+  // buffer descriptors: the host guarantees P * max(lda, ldy) * 2 < 2^32
+  StreamBufs sb;
+  const unsigned y_bytes = ((unsigned)(P - 1) * ldy + N) * 2u;
+  sb.a = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, ((unsigned)(P - 1) * lda + K) * 2u, 0x00020000);
+  sb.y = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, y_bytes, 0x00020000);
+  sb.yb = __builtin_amdgcn_make_buffer_rsrc(BST ? (void *)Yb : (void *)Y, 0, y_bytes, 0x00020000);
+  sb.aoff[0] = ((unsigned)(wave * 32 + lr) * lda + 8 * lq) * 2u;
+  sb.aoff[1] = sb.aoff[0] + 16u * lda * 2u;
+  sb.yoff = ((unsigned)(wave * 32 + lane / CPR) * ldy + n0 + (lane % CPR) * 8) * 2u;
+  sb.a_tile = (unsigned)G_ROWS * lda * 2u;
+  sb.y_tile = (unsigned)G_ROWS * ldy * 2u;
+  sb.y_step = (unsigned)(64 / CPR) * ldy * 2u;
   const int ntiles = (P + G_ROWS - 1) / G_ROWS;
   const int tile0 = blockIdx.x * tiles_per_wg;
   const int tile_end = min(tile0 + tiles_per_wg, ntiles);
   if (tile0 < tile_end) {
     bf16x8 a[2][KS];
-    stream_load_a<KS>(a, A, lda, P, tile0 * G_ROWS, wave, lr, lq);
+    stream_load_a<KS>(a, sb.a, sb.aoff, (unsigned)tile0 * sb.a_tile);
     fill_w_panel<BN, 32 * KS + 8>(s_w, W, K, N, n0, 0, K, w_trans, t);
     __syncthreads();
     for (int tile = tile0; tile < tile_end; ++tile) {
-      // the reload inside is unconditional (row indices are clamped), so the loop body is straight-line
-      stream_tile<BN, KS, STATS, ATR, BST>(a, s_w, s_o[wave], Y, ldy, P, tile * G_ROWS, n0, wave, lane, st_s, st_q, s_ss, A,
-                                           lda, min(tile + 1, ntiles - 1) * G_ROWS, Yb, s_bs);
+      // the reload inside is unconditional (a tile past the end is out of the buffer's range: zeros, no traffic), so
+      // the loop body is straight-line
+      stream_tile<BN, KS, STATS, ATR, BST>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1, wave, lane, st_s, st_q, s_ss, s_bs);
     }
   }
   if (STATS || BST) {
@@ -1469,7 +1480,8 @@ static inline bool gemm_stream_k(long long P, int K) {
 }
 
 extern "C" int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N) {
-  return P > SP_MAX_ROWS && P <= 2000000000LL && gemm_stream_k(P, K) && N > 0 && (N & 63) == 0;
+  return P > SP_MAX_ROWS && (P + G_ROWS) * (long long)(K > N ? K : N) * 2 < (1LL << 32) && gemm_stream_k(P, K) && N > 0 &&
+         (N & 63) == 0;   // (contiguous operands: lda = K, ldy = N; 32-bit buffer offsets)
 }
 
 extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P, int K,
@@ -1507,7 +1519,8 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   const bool stream_k = gemm_stream_k(P, K);
   // (the operand transform exists in the stream kernel only next to the BN statistics: forward layers)
   const bool stream_ok = stream_k && !gidx && !bias && !y_f32 && n_store == N && (ldy & 7) == 0 &&
-                         (bwd_y || !a_scale || (stats_partial && K <= 128));
+                         (bwd_y || !a_scale || (stats_partial && K <= 128)) &&
+                         (P + G_ROWS) * (long long)(lda > ldy ? lda : ldy) * 2 < (1LL << 32);   // 32-bit buffer offsets
   if (stream_ok) {
     unsigned short *y = (unsigned short *)Y;
 #define CPFN_STREAM(BN_, KS_)                                                                                        \
