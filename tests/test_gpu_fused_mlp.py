@@ -274,12 +274,19 @@ def test_fused_dropout_mask_statistics_and_backward():
     ("sa2-like", 2 * 300 * 64, 131, [128, 128, 256], 64),
     ("sa1-like", 40 * 1024, 64, [64, 64, 128], 16),
 ])
-def test_bn_backward_reduction_on_the_data_gradient_gemm(name, P, cin, widths, pool_k, monkeypatch):
+@pytest.mark.parametrize("bn_eval", [False, True])
+def test_bn_backward_reduction_on_the_data_gradient_gemm(name, P, cin, widths, pool_k, bn_eval, monkeypatch):
     """BatchNorm-backward pass 1 of a hidden layer taken by the data-gradient GEMM that produces its gradient
     (default where the streaming kernel runs) against the separate cpfn_bn_relu_bwd pass: the same sums in a
     different order."""
     from cpfn_amd import fused_mlp
     convs, bns = _stack(cin, widths, seed=11)
+    if bn_eval:                                        # running statistics: the gradient has no batch-statistics terms
+        for bn in bns:
+            bn.eval()
+            with torch.no_grad():
+                bn.running_var.uniform_(0.5, 2.0)
+                bn.running_mean.normal_(0, 0.2)
     g = torch.Generator().manual_seed(P)
     x = torch.randn(P, cin, generator=g).to(dev())
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
