@@ -623,45 +623,62 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(const float *__restrict_
                                                         float *__restrict__ grp, float *__restrict__ gnl,
                                                         float *__restrict__ gtl) {
   __shared__ float s_v[5][LT_MAXB];
+  __shared__ float s_k[3][256];            // per-(cloud, instance) terms of the clouds in flight
   const int t = threadIdx.x;
   const bool on_miou = mu.m[2] > 0.f, on_res = mu.m[3] > 0.f && rp, on_par = mu.m[4] > 0.f && rp;
   const float invB = 1.f / (float)B, mt = mu.m[5];
   for (long long e = t; e < (long long)B * (K + 2) * K; e += 256) gS[e] = 0.f;
   __syncthreads();
-  for (int b = t; b < B; b += 256) {
-    long long nn = n_gt[b];
-    const int n = (int)(nn < 0 ? 0 : (nn > K ? K : nn));
-    const float *Sb = S + (size_t)b * (K + 2) * K;
-    float *gSb = gS + (size_t)b * (K + 2) * K;
-    const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
-    const float c_miou = on_miou ? mt * mu.m[2] * invB * inv_n : 0.f;
-    float miou = 0.f, res = 0.f, par = 0.f;
-    for (int k = 0; k < K; ++k) {
+  // One lane per (cloud, instance) — the first version walked the K instances of a cloud serially in one lane, a chain
+  // of K dependent (match -> S gather) round trips: 20 us for a few KB.  The assignment is a permutation, so every
+  // gS entry is written by exactly one lane; the per-cloud sums are taken from LDS in instance order.
+  const int cpb = K <= 256 ? 256 / K : 0;      // clouds per pass (K <= MAXK = 64)
+  for (int b0 = 0; b0 < B; b0 += cpb) {
+    const int bl = t / K, k = t - bl * K, b = b0 + bl;
+    float v_miou = 0.f, v_res = 0.f, v_par = 0.f;
+    if (bl < cpb && b < B) {
+      long long nn = n_gt[b];
+      const int n = (int)(nn < 0 ? 0 : (nn > K ? K : nn));
+      const float *Sb = S + (size_t)b * (K + 2) * K;
+      float *gSb = gS + (size_t)b * (K + 2) * K;
+      const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+      const float c_miou = on_miou ? mt * mu.m[2] * invB * inv_n : 0.f;
       const bool live = k < n;
       if (live && on_miou) {
         long long m = match[(size_t)b * K + k];
         m = m < 0 ? 0 : (m >= K ? K - 1 : m);
         const float dot = Sb[k * K + m], colv = Sb[K * K + m], cntv = Sb[(K + 1) * K + k];
         const float q = cntv + colv - dot + 1e-10f;
-        miou += 1.f - dot / q;
+        v_miou = 1.f - dot / q;
         const float dq = dot / (q * q);
-        gSb[k * K + m] += -c_miou * (1.f / q + dq);
-        gSb[K * K + m] += c_miou * dq;
-        gSb[(K + 1) * K + k] += c_miou * dq;
+        gSb[k * K + m] = -c_miou * (1.f / q + dq);
+        gSb[K * K + m] = c_miou * dq;
+        gSb[(K + 1) * K + k] = c_miou * dq;
       }
       if (rp) {
-        if (live) { res += rp[((size_t)b * K + k) * 2]; par += rp[((size_t)b * K + k) * 2 + 1]; }
+        if (live) { v_res = rp[((size_t)b * K + k) * 2]; v_par = rp[((size_t)b * K + k) * 2 + 1]; }
         grp[((size_t)b * K + k) * 2] = (live && on_res) ? mt * mu.m[3] * invB * inv_n : 0.f;
         grp[((size_t)b * K + k) * 2 + 1] = (live && on_par) ? mt * mu.m[4] * invB * inv_n : 0.f;
       }
     }
-    s_v[0][b] = nl[(size_t)b * nl_stride];
-    s_v[1][b] = tl[(size_t)b * nl_stride];
-    s_v[2][b] = miou * inv_n;
-    s_v[3][b] = res * inv_n;
-    s_v[4][b] = par * inv_n;
-    gnl[b] = mu.m[0] > 0.f ? mt * mu.m[0] * invB : 0.f;
-    gtl[b] = mu.m[1] > 0.f ? mt * mu.m[1] * invB : 0.f;
+    s_k[0][t] = v_miou; s_k[1][t] = v_res; s_k[2][t] = v_par;
+    __syncthreads();
+    if (t < cpb && b0 + t < B) {
+      const int bb = b0 + t;
+      long long nn = n_gt[bb];
+      const int n = (int)(nn < 0 ? 0 : (nn > K ? K : nn));
+      const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+      float miou = 0.f, res = 0.f, par = 0.f;
+      for (int kk = 0; kk < K; ++kk) { miou += s_k[0][t * K + kk]; res += s_k[1][t * K + kk]; par += s_k[2][t * K + kk]; }
+      s_v[0][bb] = nl[(size_t)bb * nl_stride];
+      s_v[1][bb] = tl[(size_t)bb * nl_stride];
+      s_v[2][bb] = miou * inv_n;
+      s_v[3][bb] = res * inv_n;
+      s_v[4][bb] = par * inv_n;
+      gnl[bb] = mu.m[0] > 0.f ? mt * mu.m[0] * invB : 0.f;
+      gtl[bb] = mu.m[1] > 0.f ? mt * mu.m[1] * invB : 0.f;
+    }
+    __syncthreads();
   }
   __syncthreads();
   if (t < 5) {
