@@ -412,25 +412,57 @@ struct McArgs {
   long long bytes[MC_MAX];
   int block0[MC_MAX + 1];
   int count;
+  unsigned *flags;     // CHECK: flags[flag_base + blockIdx.x] = 1 if the block copied an fp32 NaN / inf
+  int flag_base;
 };
+// CHECK: the buffers are fp32 and every copied word is also tested for NaN / inf (exponent all ones) — the finite
+// scan of the gradients rides on the copy that packs them into the flat bucket instead of being one more pass.
+template <bool CHECK>
 __global__ __launch_bounds__(TPB) void multi_copy_kernel(McArgs a) {
   int d = 0;
   while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
   const long long nb = a.block0[d + 1] - a.block0[d];
   const long long first = (long long)(blockIdx.x - a.block0[d]) * TPB + threadIdx.x;
   const unsigned long long both = (unsigned long long)a.src[d] | (unsigned long long)a.dst[d];
+  unsigned bad = 0;
   if ((both & 15) == 0) {
     const long long n16 = a.bytes[d] / 16;
     const uint4 *__restrict__ s = (const uint4 *)a.src[d];
     uint4 *__restrict__ o = (uint4 *)a.dst[d];
-    for (long long i = first; i < n16; i += nb * TPB) o[i] = s[i];
-    if (blockIdx.x == a.block0[d] && threadIdx.x < (a.bytes[d] & 15))     // ragged tail, byte by byte
+    for (long long i = first; i < n16; i += nb * TPB) {
+      const uint4 v = s[i];
+      o[i] = v;
+      if (CHECK)
+        bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) |
+               ((v.z & 0x7f800000u) == 0x7f800000u) | ((v.w & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == a.block0[d] && threadIdx.x < (a.bytes[d] & 15)) {   // ragged tail, byte by byte
       ((unsigned char *)a.dst[d])[n16 * 16 + threadIdx.x] = ((const unsigned char *)a.src[d])[n16 * 16 + threadIdx.x];
+      if (CHECK && (threadIdx.x & 3) == 0 && threadIdx.x + 4 <= (a.bytes[d] & 15)) {
+        const unsigned w = *(const unsigned *)((const unsigned char *)a.src[d] + n16 * 16 + threadIdx.x);
+        bad |= (w & 0x7f800000u) == 0x7f800000u;
+      }
+    }
   } else {                                                                // 4-byte aligned views (slices of a flat buffer)
     const long long n4 = a.bytes[d] / 4;
     const unsigned *__restrict__ s = (const unsigned *)a.src[d];
     unsigned *__restrict__ o = (unsigned *)a.dst[d];
-    for (long long i = first; i < n4; i += nb * TPB) o[i] = s[i];
+    for (long long i = first; i < n4; i += nb * TPB) {
+      const unsigned v = s[i];
+      o[i] = v;
+      if (CHECK) bad |= (v & 0x7f800000u) == 0x7f800000u;
+    }
+  }
+  if (CHECK) {
+    __shared__ unsigned s_bad[TPB / 64];
+    const unsigned long long m = __ballot(bad != 0);
+    if ((threadIdx.x & 63) == 0) s_bad[threadIdx.x >> 6] = m != 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned any = 0;
+      for (int w = 0; w < TPB / 64; ++w) any |= s_bad[w];
+      a.flags[a.flag_base + blockIdx.x] = any;
+    }
   }
 }
 
@@ -697,9 +729,9 @@ extern "C" int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offse
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_multi_copy(const cpfn_copy_desc *descs, int count, void *stream) {
-  if (count < 0 || (count > 0 && !descs)) return CPFN_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
+static int multi_copy_impl(const cpfn_copy_desc *descs, int count, unsigned *flags, int flags_capacity, bool launch,
+                           hipStream_t st, int *blocks_total) {
+  int total = 0;
   for (int base = 0; base < count; base += MC_MAX) {
     McArgs a;
     a.count = count - base < MC_MAX ? count - base : MC_MAX;
@@ -708,6 +740,7 @@ extern "C" int cpfn_multi_copy(const cpfn_copy_desc *descs, int count, void *str
       const cpfn_copy_desc &d = descs[base + i];
       const uintptr_t both = (uintptr_t)d.src | (uintptr_t)d.dst;
       if (!d.src || !d.dst || d.bytes < 0 || (both & 3) || ((both & 15) && (d.bytes & 3))) return CPFN_EINVAL;
+      if (flags && (d.bytes & 3)) return CPFN_EINVAL;                       // checked copies are whole fp32 words
       a.src[i] = d.src; a.dst[i] = d.dst; a.bytes[i] = d.bytes;
       a.block0[i] = blocks;
       long long nb = (d.bytes / 16 + TPB * 4 - 1) / (TPB * 4);            // ~4 pieces per lane
@@ -716,9 +749,39 @@ extern "C" int cpfn_multi_copy(const cpfn_copy_desc *descs, int count, void *str
       blocks += (int)nb;
     }
     a.block0[a.count] = blocks;
-    if (blocks) multi_copy_kernel<<<blocks, TPB, 0, st>>>(a);
+    a.flags = flags;
+    a.flag_base = total;
+    if (launch && blocks) {
+      if (flags) {
+        if (total + blocks > flags_capacity) return CPFN_EINVAL;
+        multi_copy_kernel<true><<<blocks, TPB, 0, st>>>(a);
+      } else {
+        multi_copy_kernel<false><<<blocks, TPB, 0, st>>>(a);
+      }
+    }
+    total += blocks;
   }
-  return cpfn_launch_status();
+  if (blocks_total) *blocks_total = total;
+  return 0;
+}
+
+extern "C" int cpfn_multi_copy(const cpfn_copy_desc *descs, int count, void *stream) {
+  if (count < 0 || (count > 0 && !descs)) return CPFN_EINVAL;
+  const int e = multi_copy_impl(descs, count, nullptr, 0, true, (hipStream_t)stream, nullptr);
+  return e ? e : cpfn_launch_status();
+}
+
+extern "C" int cpfn_multi_copy_blocks(const cpfn_copy_desc *descs, int count) {
+  if (count < 0 || (count > 0 && !descs)) return -1;
+  int total = 0;
+  return multi_copy_impl(descs, count, nullptr, 0, false, nullptr, &total) ? -1 : total;
+}
+
+extern "C" int cpfn_multi_copy_checked(const cpfn_copy_desc *descs, int count, unsigned *flags, int flags_capacity,
+                                       void *stream) {
+  if (count < 0 || (count > 0 && !descs) || !flags || flags_capacity < 0) return CPFN_EINVAL;
+  const int e = multi_copy_impl(descs, count, flags, flags_capacity, true, (hipStream_t)stream, nullptr);
+  return e ? e : cpfn_launch_status();
 }
 
 extern "C" int cpfn_multi_cast(const cpfn_cast_desc *descs, int count, void *stream) {

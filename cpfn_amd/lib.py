@@ -35,6 +35,8 @@ SIGNATURES = {
     "cpfn_scatter_rows_bf16": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_group_concat_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_multi_copy": [_vp, _i, _vp],
+    "cpfn_multi_copy_blocks": [_vp, _i],
+    "cpfn_multi_copy_checked": [_vp, _i, _vp, _i, _vp],
     "cpfn_multi_cast": [_vp, _i, _vp],
     "cpfn_concat_pos_feats_bf16": [_vp, _vp, _ll, _i, _i, _vp, _vp],
     "cpfn_count_labels": [_vp, _i, _i, _vp, _vp],

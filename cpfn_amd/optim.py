@@ -46,10 +46,12 @@ class FlatAdam(torch.optim.Optimizer):
         self.lr_dev.fill_(float(lr))
 
     @torch.no_grad()
-    def step(self, closure=None, check_gradients=False, skipped=None):
+    def step(self, closure=None, check_gradients=False, skipped=None, nf_flags=None):
         """check_gradients: scan the flat gradient for NaN / inf in the same launch sequence and skip the step if any
         is found (the reference's per-parameter isinf/isnan scan, Utils/training_utils.py:151-156) — the scan's final
-        reduction and the optional `skipped` device counter (+1 per skipped step) live in the 1-wave prepare kernel."""
+        reduction and the optional `skipped` device counter (+1 per skipped step) live in the 1-wave prepare kernel.
+        nf_flags = (int32 flags tensor, count): per-workgroup flags of a scan that already happened (the checked packing
+        copy of FlatGradBucket.collect); the step is skipped if any of them is set."""
         g = self.param_groups[0]
         lr = g["lr"]
         if not isinstance(lr, torch.Tensor):       # someone assigned a float: mirror it into the device scalar
@@ -62,7 +64,9 @@ class FlatAdam(torch.optim.Optimizer):
         grads = self.bucket.flat
         with torch.cuda.device(self.flat_p.device):
             nf_ws, nf_count = None, 0
-            if check_gradients:
+            if nf_flags is not None:
+                nf_ws, nf_count = nf_flags
+            elif check_gradients:
                 if self._nf_ws is None:
                     self._nf_ws = torch.empty(256, dtype=torch.int32, device=self.flat_p.device)
                 nf_ws, nf_count = self._nf_ws, h.cpfn_nonfinite_blocks(grads.numel())

@@ -63,23 +63,33 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
-    def collect(self):
+    def collect(self, check=False):
         """Call after the backward pass: pack the fresh gradients into the flat buffer.  Parameters that
         received no gradient (conv biases in front of a training-mode BatchNorm) keep a zero slice and
-        `.grad = None`, which the optimizer skips — identical to a zero update."""
+        `.grad = None`, which the optimizer skips — identical to a zero update.
+        check=True (GPU): the packing copy also scans what it copies for NaN / inf (cpfn_multi_copy_checked) and the
+        per-workgroup flags are returned as (flags int32 tensor, count) for FlatAdam.step(nf_flags=...); None when
+        nothing had to be copied or the scan could not ride along."""
         src, dst, who = [], [], []
         for p, v in zip(self.params, self.views):
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
                 who.append(p)
+        flags = None
         if src:
             if self.flat.is_cuda:
-                SPFNTrainer._copy_all(dst, src)            # one launch (cpfn_multi_copy)
+                if check:
+                    if getattr(self, "_copy_flags", None) is None:
+                        self._copy_flags = torch.empty(4096, dtype=torch.int32, device=self.flat.device)
+                    flags = SPFNTrainer._copy_all(dst, src, flags=self._copy_flags)
+                else:
+                    SPFNTrainer._copy_all(dst, src)            # one launch (cpfn_multi_copy)
             else:
                 torch._foreach_copy_(dst, src)
             for p, v in zip(who, dst):
                 p.grad = v
+        return flags
 
     def all_reduce_mean(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -204,13 +214,14 @@ class SPFNTrainer:
         mark(geom)
         return geom
 
-    def _checked_optimizer_step(self, skipped):
+    def _checked_optimizer_step(self, skipped, nf_flags=None):
         """Finite check of the flat gradient + optimizer step (skipped on the device when a NaN / inf is found) +
-        `skipped` counter.  FlatAdam does all of it in three launches; other optimizers get the flag tensor."""
+        `skipped` counter.  FlatAdam does all of it in its own launches — two when the scan already rode on the
+        packing copy (nf_flags from FlatGradBucket.collect(check=True)); other optimizers get the flag tensor."""
         from .optim import FlatAdam
         if isinstance(self.optimizer, FlatAdam):
             self.optimizer.found_inf = None
-            self.optimizer.step(check_gradients=True, skipped=skipped)
+            self.optimizer.step(check_gradients=nf_flags is None, skipped=skipped, nf_flags=nf_flags)
         else:
             self.optimizer.found_inf = self.bucket.nonfinite_flag()
             self.optimizer.step()
@@ -266,15 +277,16 @@ class SPFNTrainer:
         return out
 
     @staticmethod
-    def _copy_all(dst, src):
+    def _copy_all(dst, src, flags=None):
         """One launch for a whole set of device-to-device copies (cpfn_multi_copy); tensors that are not contiguous
-        (or oddly aligned) go through torch."""
+        (or oddly aligned) go through torch.  flags (int32 device tensor): fp32 copies with the finite scan riding
+        along; returns (flags, count) when every tensor went through the checked launch, else None."""
         import ctypes
         from . import lib as _l
 
         class _D(ctypes.Structure):
             _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
-        fast = []
+        fast, slow = [], 0
         for d, t in zip(dst, src):
             if (d.is_cuda and t.is_cuda and d.is_contiguous() and t.is_contiguous() and d.dtype == t.dtype
                     and d.numel() == t.numel() and ((d.data_ptr() | t.data_ptr()) % 16 == 0 or
@@ -282,10 +294,21 @@ class SPFNTrainer:
                 fast.append(_D(t.data_ptr(), d.data_ptr(), d.numel() * d.element_size()))
             else:
                 d.copy_(t, non_blocking=True)
-        if fast:
-            arr = (_D * len(fast))(*fast)
-            with torch.cuda.device(dst[0].device):
-                _l.check(_l.lib().cpfn_multi_copy(arr, len(fast), torch.cuda.current_stream().cuda_stream), "cpfn_multi_copy")
+                slow += 1
+        if not fast:
+            return None
+        arr = (_D * len(fast))(*fast)
+        h = _l.lib()
+        with torch.cuda.device(dst[0].device):
+            stream = torch.cuda.current_stream().cuda_stream
+            if flags is not None and slow == 0 and all(t.dtype == torch.float32 for t in src):
+                count = h.cpfn_multi_copy_blocks(arr, len(fast))
+                if 0 < count <= flags.numel():
+                    _l.check(h.cpfn_multi_copy_checked(arr, len(fast), flags.data_ptr(), flags.numel(), stream),
+                             "cpfn_multi_copy_checked")
+                    return flags, count
+            _l.check(h.cpfn_multi_copy(arr, len(fast), stream), "cpfn_multi_copy")
+        return None
 
     @staticmethod
     def _like_geom(g, tensors):
@@ -377,9 +400,9 @@ class SPFNTrainer:
                 with fl.unit_loss_gradient():
                     out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
                 out[0].backward()
-                self.bucket.collect()
+                nf = self.bucket.collect(check=world == 1)
                 if world == 1:
-                    self._checked_optimizer_step(st["skipped"])
+                    self._checked_optimizer_step(st["skipped"], nf)
                 st["out"] = tuple(o.detach() for o in out)
                 self._gstream.wait_stream(self._gside)              # join
             st["g"] = g
@@ -412,9 +435,9 @@ class SPFNTrainer:
                 out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, st["n_gt"],
                                     st["params"])
             out[0].backward()
-            self.bucket.collect()
+            nf = self.bucket.collect(check=world == 1)
             if world == 1:
-                self._checked_optimizer_step(st["skipped"])
+                self._checked_optimizer_step(st["skipped"], nf)
             st["out"] = tuple(o.detach() for o in out)
             self._gstream.wait_stream(self._gside)                  # join
         st["g1"], st["g1b"], st["g2"] = g1, g1b, g2

@@ -143,6 +143,12 @@ CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const i
  * with a length that is a multiple of 4 (slices of a flat fp32 buffer). */
 typedef struct { const void *src; void *dst; long long bytes; } cpfn_copy_desc;
 CPFN_API int cpfn_multi_copy(const cpfn_copy_desc *descs /* HOST array */, int count, void *stream);
+/* The same copies of fp32 buffers (bytes % 4 == 0) with a finite scan riding along: flags[i] = 1 if workgroup i copied
+ * a NaN / inf, for i < cpfn_multi_copy_blocks(descs, count) <= flags_capacity.  The trainer packs the gradients into
+ * the flat bucket with it and hands the flags to cpfn_adam_flat (nf_partial): no separate scan of the gradients. */
+CPFN_API int cpfn_multi_copy_blocks(const cpfn_copy_desc *descs /* HOST array */, int count);
+CPFN_API int cpfn_multi_copy_checked(const cpfn_copy_desc *descs /* HOST array */, int count, unsigned *flags,
+                                     int flags_capacity, void *stream);
 /* count fp32 matrices src[rows, cols] (contiguous) converted to bf16 (dst_f32 = 0) or copied as fp32 (dst_f32 = 1)
  * into dst with row stride dst_ld >= cols (elements; padding columns are left untouched), in ONE launch: the
  * per-step refresh of all bf16 weight panels of the network. */

@@ -86,3 +86,31 @@ def test_checked_step_scans_gradients_and_counts_skips():
         assert float(skipped) == sk + (1.0 if skip else 0.0)
         assert torch.equal(opt.flat_p, before) == skip
     assert float(skipped) == 3.0 and float(opt.step_count) == 2.0
+
+
+def test_checked_packing_copy_feeds_the_optimizer():
+    """FlatGradBucket.collect(check=True): the finite scan rides on the copy that packs the gradients; its flags make
+    FlatAdam skip the step exactly when a gradient holds a NaN / inf (ragged sizes, unaligned slices)."""
+    from cpfn_amd import training
+    from cpfn_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    m = torch.nn.Sequential(torch.nn.Linear(1000, 37), torch.nn.Linear(37, 3), torch.nn.Linear(3, 129)).to(dev)
+    bucket = training.FlatGradBucket(m)
+    opt = FlatAdam(bucket, lr=1e-2)
+    skipped = torch.zeros((), device=dev)
+    params = list(m.parameters())
+    for which, pos, val, skip in ((None, 0, 0.0, False), (0, 36999, float("nan"), True), (3, 2, float("inf"), True),
+                                  (4, 100, 3.0e38, False), (5, 128, -float("inf"), True)):
+        for p in params:
+            p.grad = torch.randn_like(p)
+        if which is not None:
+            params[which].grad.view(-1)[pos] = val
+        nf = bucket.collect(check=True)
+        assert nf is not None and nf[1] > 0
+        before, steps = opt.flat_p.clone(), float(opt.step_count)
+        opt.step(skipped=skipped, nf_flags=nf)
+        assert (float(opt.step_count) == steps) == skip
+        assert torch.equal(opt.flat_p, before) == skip
+        for p, v in zip(bucket.params, bucket.views):
+            assert p.grad.data_ptr() == v.data_ptr()
+    assert float(skipped) == 3.0
