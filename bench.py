@@ -155,13 +155,21 @@ def main():
         # by one, so the same step is re-run eagerly right here (same process, same tensors, same
         # stream) with an event pair around every launch of the kernel family.  rocprofv3 (which does
         # see the kernels inside a replay) gives the same per-launch durations: profiles/README.md.
+        # Launched one by one the host is slower than the GPU (5.5 ms vs 2.5 ms per step), and an event pair would
+        # also time the GPU waiting for the next launch.  A spin kernel queued first holds the stream back until the
+        # host has queued the whole step, so every pair brackets a kernel executing back to back like in the replay.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(2_000_000); e1.record(); sync()
+        spin = int(2_000_000 * 8.0 / max(e0.elapsed_time(e1), 1e-3))      # ~8 ms of spinning
         lib.time_symbols([ROOFLINE_SYMBOL])
         for _ in range(3):
+            torch.cuda._sleep(spin)
             trainer.step(batch, force_eager=True)
         sync()
         calls, kernel_ms = lib.timed_report()[ROOFLINE_SYMBOL]
         roof_bytes = lib.timed_bytes(ROOFLINE_SYMBOL)
-        roof_mode = "events around every launch in 3 eager re-runs of the step right after the timed region (graph replays are not bracketable)"
+        roof_mode = ("events around every launch in 3 eager re-runs of the step right after the timed region, each queued "
+                     "behind a spin kernel so that the launches execute back to back (graph replays are not bracketable)")
     lib.time_symbols([])
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
