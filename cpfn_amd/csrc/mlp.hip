@@ -1669,13 +1669,19 @@ extern "C" int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, 
   return cpfn_launch_status();
 }
 
-// tile edge for one (P, N, K): 128 where the layer is wide and long enough to fill the chip with 128-tiles
-static inline int wgrad_tile(long long P, int N, int K) { return (P >= 32768 && N % 128 == 0 && K >= 128) ? 128 : 64; }
+// output tile for one (P, N, K): 128 x 128 where the layer is wide and long enough to fill the chip with 128-tiles,
+// 128 x 64 for the long 64 -> 128 layer (sa1: both operands read once instead of the input twice), 64 x 64 otherwise
+static inline void wgrad_tile(long long P, int N, int K, int *TN, int *TK) {
+  if (P >= 32768 && N % 128 == 0 && K >= 128) { *TN = 128; *TK = 128; }
+  else if (P >= 32768 && N % 128 == 0 && K == 64) { *TN = 128; *TK = 64; }
+  else { *TN = 64; *TK = 64; }
+}
 
 extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
-  const int T = wgrad_tile(P, N, K);
-  const long long tiles = (long long)((N + T - 1) / T) * ((K + T - 1) / T);
-  const long long target = T == 128 ? 512 : 1024;     // workgroups
+  int TN, TK;
+  wgrad_tile(P, N, K, &TN, &TK);
+  const long long tiles = (long long)((N + TN - 1) / TN) * ((K + TK - 1) / TK);
+  const long long target = TN == 128 ? 512 : 1024;     // workgroups
   long long s = (target + tiles - 1) / tiles;
   if (s > 256) s = 256;   // bound the partial buffer / reduce depth (128 and 512 measured: +40 us per step each)
   const long long max_s = (P + 127) / 128;            // at least 128 rows (one pipeline depth) per split
@@ -1695,9 +1701,14 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
   long long rps = (P + splits - 1) / splits;
   rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
   const unsigned short *g = (const unsigned short *)Gy, *a = (const unsigned short *)A;
-  if (wgrad_tile(P, N, K) == 128) {
+  int TN, TK;
+  wgrad_tile(P, N, K, &TN, &TK);
+  if (TN == 128 && TK == 128) {
     dim3 grid(N / 128, (K + 127) / 128, splits);
     mlp_wgrad_kernel<128, 128><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
+  } else if (TN == 128) {
+    dim3 grid(N / 128, (K + 63) / 64, splits);
+    mlp_wgrad_kernel<128, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
   } else {
     dim3 grid(N / 64, (K + 63) / 64, splits);
     mlp_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
