@@ -1681,7 +1681,7 @@ extern "C" int cpfn_mlp_wgrad_splits(long long P, int N, int K) {
   int TN, TK;
   wgrad_tile(P, N, K, &TN, &TK);
   const long long tiles = (long long)((N + TN - 1) / TN) * ((K + TK - 1) / TK);
-  const long long target = TN == 128 ? 512 : 1024;     // workgroups
+  const long long target = TN == 128 ? 512 : 1024;     // workgroups (256 / 512 / 2048 for the 64-tiles: no measurable difference)
   long long s = (target + tiles - 1) / tiles;
   if (s > 256) s = 256;   // bound the partial buffer / reduce depth (128 and 512 measured: +40 us per step each)
   const long long max_s = (P + 127) / 128;            // at least 128 rows (one pipeline depth) per split
