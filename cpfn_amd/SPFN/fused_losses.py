@@ -25,6 +25,9 @@ from . import fitters_common as _fc
 HOST_ASSIGNMENT = os.environ.get("CPFN_HOST_ASSIGNMENT", "0") == "1"
 # the assignment branch and the fitter branch of the loss section on two streams (CPFN_PARALLEL_BRANCHES=0: one)
 PARALLEL_BRANCHES = os.environ.get("CPFN_PARALLEL_BRANCHES", "1") == "1"
+# CPFN_SEG_FUSED=0: the label-segmented membership sums as their own pass over W (cpfn_seg_stats_fwd) instead of riding
+# on the heads post-processing launch
+SEG_FUSED = os.environ.get("CPFN_SEG_FUSED", "1") != "0"
 
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
                 ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
@@ -33,7 +36,7 @@ PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), 
 
 class HeadPost(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, Y, X_gt, I_gt, T_gt):
+    def forward(ctx, Y, X_gt, I_gt, T_gt, with_seg=False):
         B, N, C = Y.shape
         K = C - 7
         Yc = Y.detach().contiguous().float()
@@ -43,15 +46,27 @@ class HeadPost(torch.autograd.Function):
         W = torch.empty(B, N, K, dtype=torch.float32, device=dev)
         stats = torch.empty(B, 3, dtype=torch.float32, device=dev)
         h = _l.lib()
-        ws = torch.empty(B * h.cpfn_head_post_chunks(N) * 3, dtype=torch.float32, device=dev)
+        chunks = h.cpfn_head_post_chunks(N)
+        ws = torch.empty(B * chunks * 3, dtype=torch.float32, device=dev)
+        # the label-segmented membership sums ride on this launch (SEG_FUSED, K <= 31): SegStats then has nothing to
+        # compute in its forward pass
+        seg_ws = S = None
+        if with_seg and SEG_FUSED and K <= 31:
+            seg_ws = torch.empty(B * chunks * (K + 2) * K, dtype=torch.float32, device=dev)
+            S = torch.empty(B, K + 2, K, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _l.check(h.cpfn_head_post_fwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), B, N, K, _ptr(Xn), _ptr(W), _ptr(ws),
-                                          _ptr(stats), _stream()), "cpfn_head_post_fwd")
+                                          _ptr(stats), _ptr(seg_ws), _ptr(S), _stream()), "cpfn_head_post_fwd")
         ctx.save_for_backward(Yc, Xg, Ig, Tg, W, stats)
+        if with_seg:
+            if S is None:
+                S = torch.empty(0, device=dev)
+            ctx.mark_non_differentiable(S)
+            return Xn, W, stats[:, 0], stats[:, 1], S
         return Xn, W, stats[:, 0], stats[:, 1]
 
     @staticmethod
-    def backward(ctx, gXn, gW, gnl, gtl):
+    def backward(ctx, gXn, gW, gnl, gtl, _gS=None):
         Yc, Xg, Ig, Tg, W, stats = ctx.saved_tensors
         B, N, C = Yc.shape
         dev = Yc.device
@@ -63,22 +78,25 @@ class HeadPost(torch.autograd.Function):
         with torch.cuda.device(dev):
             _l.check(_l.lib().cpfn_head_post_bwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), _ptr(W), _ptr(stats), _ptr(gXn),
                                                  _ptr(gW), _ptr(gl), B, N, C - 7, _ptr(gY), _stream()), "cpfn_head_post_bwd")
-        return gY, None, None, None
+        return gY, None, None, None, None
 
 
 class SegStats(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, W, I_gt):
+    def forward(ctx, W, I_gt, S_pre=None):
         B, N, K = W.shape
-        Wc, Ig = W.detach().contiguous().float(), I_gt.contiguous()
+        Ig = I_gt.contiguous()
+        ctx.save_for_backward(Ig)
+        ctx.shape = (B, N, K)
+        if S_pre is not None and S_pre.numel() == B * (K + 2) * K:
+            return S_pre.view(B, K + 2, K)          # computed by the heads post-processing launch (HeadPost)
+        Wc = W.detach().contiguous().float()
         h = _l.lib()
         chunks = h.cpfn_seg_stats_chunks(B, N)
         ws = torch.empty(B * chunks * (K + 2) * K, dtype=torch.float32, device=W.device)
         S = torch.empty(B, K + 2, K, dtype=torch.float32, device=W.device)
         with torch.cuda.device(W.device):
             _l.check(h.cpfn_seg_stats_fwd(_ptr(Wc), _ptr(Ig), B, N, K, _ptr(ws), _ptr(S), _stream()), "cpfn_seg_stats_fwd")
-        ctx.save_for_backward(Ig)
-        ctx.shape = (B, N, K)
         return S
 
     @staticmethod
@@ -89,7 +107,7 @@ class SegStats(torch.autograd.Function):
         dW = torch.empty(B, N, K, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _l.check(_l.lib().cpfn_seg_stats_bwd(_ptr(g), _ptr(Ig), B, N, K, _ptr(dW), _stream()), "cpfn_seg_stats_bwd")
-        return dW, None
+        return dW, None, None
 
 
 class ResidueLoss(torch.autograd.Function):
@@ -237,8 +255,8 @@ def hungarian_from_stats(S, I_gt):
 def pre_match(Y, batch):
     """Everything before the host-side assignment: unit normals, memberships, per-cloud normal /
     type losses and the label-segmented sums S.  (Capturable: no host synchronisation.)"""
-    Xn, W, nl, tl = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"])
-    return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"])
+    Xn, W, nl, tl, S_pre = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"], True)
+    return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"], S_pre)
 
 
 _branch_streams = {}
@@ -249,7 +267,7 @@ def match_and_fit(P, Y, batch, multipliers):
     forked stream and (the four fits) on the current one — both are a handful of low-occupancy, latency-bound
     kernels (one wave per cloud / one lane per instance), so they overlap almost for free.  Returns
     (Xn, W, nl, tl, S, n_gt, match, params).  Capturable (the fork becomes a parallel branch of the graph)."""
-    Xn, W, nl, tl = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"])
+    Xn, W, nl, tl, S_pre = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"], True)
     dev = W.device
     cur = torch.cuda.current_stream(dev)
     key = (dev.index, cur.cuda_stream)
@@ -258,7 +276,7 @@ def match_and_fit(P, Y, batch, multipliers):
         side = _branch_streams[key] = torch.cuda.Stream(device=dev)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        S = SegStats.apply(W, batch["I_gt"])
+        S = SegStats.apply(W, batch["I_gt"], S_pre)
         n_gt = count_gt(batch["I_gt"])
         match = hungarian_device(S, n_gt)
     W.record_stream(side)                       # produced here, read on the side stream

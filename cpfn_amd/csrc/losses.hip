@@ -33,10 +33,12 @@ constexpr int LP_LD = 7 + MAXK;   // LDS row stride for the [*, 7+K] rows: 39 fl
 __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
     const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
     const long long *__restrict__ Tgt, int N, int K, float *__restrict__ Xn, float *__restrict__ Wsm,
-    float *__restrict__ partial) {
+    float *__restrict__ partial, float *__restrict__ seg_partial /* optional: [B][chunks][(K+2)*K] */) {
   __shared__ float s_row[LP_THREADS * LP_LD];
   __shared__ float s_x[LP_THREADS * 3];
   __shared__ float s_red[LP_THREADS / 64][3];
+  __shared__ float s_seg[LP_THREADS / 64][MAXK][MAXK + 1];     // per-wave segmented sums (seg_partial only)
+  __shared__ int s_cnt[MAXK];
   const int b = blockIdx.y, t = threadIdx.x, C = 7 + K;
   const int n0 = blockIdx.x * LP_THREADS;
   const int rows = min(LP_THREADS, N - n0);
@@ -46,6 +48,8 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
   __syncthreads();
   float l_n = 0.f, l_t = 0.f, l_c = 0.f;
   float e[MAXK], u0 = 0.f, u1 = 0.f, u2 = 0.f, is = 0.f;
+  int seg_lab = -2;                       // this lane's label (-1 unlabelled, -2 past the end of the cloud)
+  if (t < MAXK) s_cnt[t] = 0;
   if (t < rows) {
     const float *y = s_row + t * LP_LD;
     const float x0 = y[0], x1 = y[1], x2 = y[2];
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
     is = 1.0f / s;
     // per-point type cross-entropy against the type of the point's GT instance
     const long long lab = Igt[p0 + t];
+    seg_lab = (int)lab;
     if (lab != -1) {
       const long long tgt = Tgt[(size_t)b * K + (lab < 0 ? 0 : lab)];
       const float t0 = y[3], t1 = y[4], t2 = y[5], t3 = y[6];
@@ -83,7 +88,40 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
     l_n += __shfl_xor(l_n, msk, 64); l_t += __shfl_xor(l_t, msk, 64); l_c += __shfl_xor(l_c, msk, 64);
   }
   if ((t & 63) == 0) { s_red[t >> 6][0] = l_n; s_red[t >> 6][1] = l_t; s_red[t >> 6][2] = l_c; }
+  if (seg_partial && seg_lab >= 0 && seg_lab < MAXK) atomicAdd(&s_cnt[seg_lab], 1);   // integer: exact, order-free
   __syncthreads();
+  if (seg_partial) {
+    // Label-segmented sums of the memberships (what seg_stats_fwd_kernel computes: rows l < K: Σ_{I=l} w, row K: Σ w,
+    // row K+1: label counts) taken from the soft-max rows while they are in LDS — the separate pass re-read all of W
+    // and cost 25-34 us.  Per wave a [32 labels+1] x [32 columns] fp32 MFMA contraction over its 64 points, two points
+    // per v_mfma_f32_32x32x2_f32: A = one-hot(label) with an all-ones row K, B = the membership row.
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    const int lane = t & 63, wave = t >> 6, x = lane & 31, hk = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll 8
+    for (int tt = 0; tt < 32; ++tt) {
+      const int r = 2 * tt + hk, row = wave * 64 + r;
+      const int lab_r = __shfl(seg_lab, r, 64);                         // lane r of this wave owns that row
+      const float a = (x < K) ? (lab_r == x ? 1.f : 0.f) : ((x == K && lab_r != -2) ? 1.f : 0.f);
+      const float bv = (x < K && lab_r != -2) ? s_row[row * LP_LD + x] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    // D[i][j]: j = lane & 31, i = 8 (v / 4) + 4 (lane >> 5) + (v % 4)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int i = 8 * (v >> 2) + 4 * hk + (v & 3);
+      s_seg[wave][i][x] = acc[v];
+    }
+    __syncthreads();
+    float *o = seg_partial + ((size_t)b * gridDim.x + blockIdx.x) * (K + 2) * K;
+    for (int e2 = t; e2 < (K + 1) * K; e2 += LP_THREADS) {
+      const int l = e2 / K, k = e2 - l * K;
+      o[e2] = ((s_seg[0][l][k] + s_seg[1][l][k]) + s_seg[2][l][k]) + s_seg[3][l][k];
+    }
+    if (t < K) o[(K + 1) * K + t] = (float)s_cnt[t];
+  }
   lp_stage_out(s_row, LP_LD, Wsm + p0 * K, rows, K, t);
   lp_stage_out(s_x, 3, Xn + p0 * 3, rows, 3, t);
   if (t < 3) {
@@ -704,14 +742,20 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(const float *__restrict_
 extern "C" int cpfn_head_post_chunks(int N) { return cpfn_cdiv(N, LP_THREADS); }
 
 extern "C" int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt, int B,
-                                  int N, int K, float *Xn, float *Wsm, float *workspace, float *stats, void *stream) {
+                                  int N, int K, float *Xn, float *Wsm, float *workspace, float *stats,
+                                  float *seg_workspace, float *S, void *stream) {
   if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !Y || !Xgt || !Igt || !Tgt || !Xn || !Wsm || !workspace || !stats)
     return CPFN_EINVAL;
+  if ((seg_workspace != nullptr) != (S != nullptr) || (S && K >= MAXK)) return CPFN_EINVAL;   // the ones row needs K < 32
   hipStream_t st = (hipStream_t)stream;
   const int chunks = cpfn_cdiv(N, LP_THREADS);
   head_post_fwd_kernel<<<dim3(chunks, B), LP_THREADS, 0, st>>>(Y, Xgt, (const long long *)Igt, (const long long *)Tgt, N, K,
-                                                               Xn, Wsm, workspace);
+                                                               Xn, Wsm, workspace, seg_workspace);
   head_post_reduce_kernel<<<cpfn_cdiv(B, 64), 64, 0, st>>>(workspace, chunks, N, B, stats);
+  if (S) {
+    const long long total = (long long)B * (K + 2) * K;
+    chunk_sum_f32_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(seg_workspace, chunks, (K + 2) * K, total, S);
+  }
   return cpfn_launch_status();
 }
 

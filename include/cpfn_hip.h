@@ -336,11 +336,14 @@ CPFN_API int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long
  * Xn[B,N,3] = normalize (Utils/training_utils.py:141), Wsm[B,N,K] = softmax (:142),
  * stats[B,3] = (normal loss, type loss, #labelled points) per cloud
  * (SPFN/losses_implementation.py:152-159, 195-210; training forms).  Igt[B,N], Tgt[B,K] int64.
- * workspace: B * cpfn_head_post_chunks(N) * 3 floats. */
+ * workspace: B * cpfn_head_post_chunks(N) * 3 floats.
+ * seg_workspace + S (optional, both or neither; K <= 31): the same launch also leaves the label-segmented sums
+ * S[B,K+2,K] of cpfn_seg_stats_fwd, taken from the soft-max rows while they are on chip (fp32 MFMA contraction
+ * one-hot(label) x memberships); seg_workspace: B * cpfn_head_post_chunks(N) * (K+2)*K floats. */
 CPFN_API int cpfn_head_post_chunks(int N);
 CPFN_API int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                 int B, int N, int K, float *Xn, float *Wsm, float *workspace, float *stats,
-                                void *stream);
+                                float *seg_workspace, float *S, void *stream);
 /* Adjoint: gXn[B,N,3], gW[B,N,K] (either may be NULL), gloss[B,2] = dL/d(normal, type loss) -> gY. */
 CPFN_API int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                 const float *Wsm, const float *stats, const float *gXn, const float *gW,
