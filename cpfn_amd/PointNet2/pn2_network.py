@@ -90,7 +90,9 @@ class PointNet2(torch.nn.Module):
         l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"))
         l6, _ = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5, gm.get("sfp3"))
         cd = getattr(self, "compute_dtype", torch.float32)
-        l3_out = l3.transpose(1, 2).float()                                 # [B,1024(+extra),1]
+        l3_out = l3.transpose(1, 2)                                         # [B,1024(+extra),1]
+        if getattr(self, "return_point_features", True) or self.features_extractor:
+            l3_out = l3_out.float()            # (a trainer that only consumes the heads skips this conversion too)
         if self.features_extractor:
             feat = mlp.conv_as_linear(l6.reshape(B * N, -1).to(cd), self.fc1).float()
             return l3_out, feat.reshape(B, N, -1).transpose(1, 2)

@@ -70,14 +70,22 @@ class HeadPost(torch.autograd.Function):
         Yc, Xg, Ig, Tg, W, stats = ctx.saved_tensors
         B, N, C = Yc.shape
         dev = Yc.device
-        gl = torch.stack([gnl if gnl is not None else torch.zeros(B, device=dev),
-                          gtl if gtl is not None else torch.zeros(B, device=dev)], dim=1).contiguous().float()
+        # dL/d(normal loss), dL/d(type loss): LossTail leaves them one after the other in one buffer ([2,B] planar),
+        # which the kernel reads as is; anything else is interleaved into [B,2] first
+        planar = (gnl is not None and gtl is not None and gnl.dtype == gtl.dtype == torch.float32 and gnl.is_contiguous()
+                  and gtl.is_contiguous() and gtl.data_ptr() == gnl.data_ptr() + 4 * B)
+        if planar:
+            gl = gnl
+        else:
+            gl = torch.stack([gnl if gnl is not None else torch.zeros(B, device=dev),
+                              gtl if gtl is not None else torch.zeros(B, device=dev)], dim=1).contiguous().float()
         gXn = None if gXn is None else gXn.contiguous().float()
         gW = None if gW is None else gW.contiguous().float()
         gY = torch.empty_like(Yc)
         with torch.cuda.device(dev):
             _l.check(_l.lib().cpfn_head_post_bwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), _ptr(W), _ptr(stats), _ptr(gXn),
-                                                 _ptr(gW), _ptr(gl), B, N, C - 7, _ptr(gY), _stream()), "cpfn_head_post_bwd")
+                                                 _ptr(gW), _ptr(gl), 1 if planar else 0, B, N, C - 7, _ptr(gY), _stream()),
+                     "cpfn_head_post_bwd")
         return gY, None, None, None, None
 
 

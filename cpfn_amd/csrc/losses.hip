@@ -153,8 +153,8 @@ __global__ void head_post_reduce_kernel(const float *__restrict__ partial, int c
 __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
     const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
     const long long *__restrict__ Tgt, const float *__restrict__ Wsm, const float *__restrict__ stats,
-    const float *__restrict__ gXn, const float *__restrict__ gW, const float *__restrict__ gloss, int N, int K,
-    float *__restrict__ gY) {
+    const float *__restrict__ gXn, const float *__restrict__ gW, const float *__restrict__ gloss, int gl_planar, int N,
+    int K, float *__restrict__ gY) {
   __shared__ float s_row[LP_THREADS * LP_LD];
   __shared__ float s_x[LP_THREADS * 3], s_gx[LP_THREADS * 3];
   const int b = blockIdx.y, t = threadIdx.x, C = 7 + K;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
     const float g0 = s_x[t * 3], g1 = s_x[t * 3 + 1], g2 = s_x[t * 3 + 2];
     const float d = u0 * g0 + u1 * g1 + u2 * g2;
     const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    const float cn = -gloss[b * 2] * sg / (float)N;
+    const float cn = -gloss[gl_planar ? b : b * 2] * sg / (float)N;
     float h0 = cn * g0, h1 = cn * g1, h2 = cn * g2;
     if (gXn) { h0 += s_gx[t * 3]; h1 += s_gx[t * 3 + 1]; h2 += s_gx[t * 3 + 2]; }
     if (nrm >= 1e-12f) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
       const float tm = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
       const float e0 = expf(t0 - tm), e1 = expf(t1 - tm), e2 = expf(t2 - tm), e3 = expf(t3 - tm);
       const float is = 1.0f / (e0 + e1 + e2 + e3);
-      const float c = gloss[b * 2 + 1] / stats[b * 3 + 2];
+      const float c = gloss[gl_planar ? gridDim.y + b : b * 2 + 1] / stats[b * 3 + 2];
       o7[3] = c * (e0 * is - (tgt == 0 ? 1.f : 0.f));
       o7[4] = c * (e1 * is - (tgt == 1 ? 1.f : 0.f));
       o7[5] = c * (e2 * is - (tgt == 2 ? 1.f : 0.f));
@@ -761,11 +761,11 @@ extern "C" int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_
 
 extern "C" int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                   const float *Wsm, const float *stats, const float *gXn, const float *gW,
-                                  const float *gloss, int B, int N, int K, float *gY, void *stream) {
+                                  const float *gloss, int gloss_planar, int B, int N, int K, float *gY, void *stream) {
   if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !Y || !Xgt || !Igt || !Tgt || !Wsm || !stats || !gloss || !gY)
     return CPFN_EINVAL;
   head_post_bwd_kernel<<<dim3(cpfn_cdiv(N, LP_THREADS), B), LP_THREADS, 0, (hipStream_t)stream>>>(
-      Y, Xgt, (const long long *)Igt, (const long long *)Tgt, Wsm, stats, gXn, gW, gloss, N, K, gY);
+      Y, Xgt, (const long long *)Igt, (const long long *)Tgt, Wsm, stats, gXn, gW, gloss, gloss_planar, N, K, gY);
   return cpfn_launch_status();
 }
 

@@ -346,6 +346,7 @@ class SPFNTrainer:
               "match": torch.zeros(B, K, dtype=torch.long, device=dev),
               "skipped": torch.zeros((), dtype=torch.float32, device=dev)}
         st["start1"], st["start2"] = st["start_dev"][0], st["start_dev"][1]
+        st["unit"] = torch.ones((), dtype=torch.float32, device=dev)      # d total / d total, allocated outside the graph
         sb = st["batch"]
         # the three GT axis tensors live stacked ([3,B,K,3], what the residue kernel reads): the per-key static
         # buffers are views of it, so staging a batch fills the stacked tensor without a torch.stack per step
@@ -399,7 +400,7 @@ class SPFNTrainer:
                     params = fl.fit_params(sb["P"], W, Xn, self.mult)
                 with fl.unit_loss_gradient():
                     out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
-                out[0].backward()
+                out[0].backward(st["unit"])              # (no ones_like fill inside the graph)
                 nf = self.bucket.collect(check=world == 1)
                 if world == 1:
                     self._checked_optimizer_step(st["skipped"], nf)
@@ -434,7 +435,7 @@ class SPFNTrainer:
             with fl.unit_loss_gradient():
                 out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, st["n_gt"],
                                     st["params"])
-            out[0].backward()
+            out[0].backward(st["unit"])
             nf = self.bucket.collect(check=world == 1)
             if world == 1:
                 self._checked_optimizer_step(st["skipped"], nf)

@@ -344,10 +344,12 @@ CPFN_API int cpfn_head_post_chunks(int N);
 CPFN_API int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                 int B, int N, int K, float *Xn, float *Wsm, float *workspace, float *stats,
                                 float *seg_workspace, float *S, void *stream);
-/* Adjoint: gXn[B,N,3], gW[B,N,K] (either may be NULL), gloss[B,2] = dL/d(normal, type loss) -> gY. */
+/* Adjoint: gXn[B,N,3], gW[B,N,K] (either may be NULL), gloss = dL/d(normal, type loss) -> gY.
+ * gloss_planar = 0: gloss is [B,2]; 1: [2,B] (the two gradient vectors one after the other, as cpfn_loss_tail leaves
+ * them: no interleaving copy). */
 CPFN_API int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                 const float *Wsm, const float *stats, const float *gXn, const float *gW,
-                                const float *gloss, int B, int N, int K, float *gY, void *stream);
+                                const float *gloss, int gloss_planar, int B, int N, int K, float *gY, void *stream);
 /* Label-segmented membership sums, shared by the Hungarian cost matrix and the relaxed-IoU loss
  * (SPFN/losses_implementation.py:19-24, 77-90):  S[B,K+2,K]: rows l<K = sum of W rows with label l,
  * row K = column sums of W, row K+1 = number of points per label.
