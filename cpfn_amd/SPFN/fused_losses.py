@@ -23,8 +23,11 @@ from . import fitters_common as _fc
 # CPFN_HOST_ASSIGNMENT=1: solve the assignment with SciPy on the host like the reference (one device->host->device
 # round trip per step) instead of cpfn_hungarian_match.
 HOST_ASSIGNMENT = os.environ.get("CPFN_HOST_ASSIGNMENT", "0") == "1"
-# the assignment branch and the fitter branch of the loss section on two streams (CPFN_PARALLEL_BRANCHES=0: one)
-PARALLEL_BRANCHES = os.environ.get("CPFN_PARALLEL_BRANCHES", "1") == "1"
+# CPFN_PARALLEL_BRANCHES=1: the assignment branch and the fitter branch of the loss section on two streams.  Default off
+# since the segmented sums moved into the heads post-processing launch: the assignment branch is then 45 us of kernels
+# and the fork/join pair (forward AND backward, which autograd replays on the forward's streams) costs more than it
+# hides — 2.40 ms serial against 2.51 ms forked on the same box.  (It paid while seg_stats_fwd, 25-34 us, ran there.)
+PARALLEL_BRANCHES = os.environ.get("CPFN_PARALLEL_BRANCHES", "0") == "1"
 # CPFN_SEG_FUSED=0: the label-segmented membership sums as their own pass over W (cpfn_seg_stats_fwd) instead of riding
 # on the heads post-processing launch
 SEG_FUSED = os.environ.get("CPFN_SEG_FUSED", "1") != "0"
