@@ -53,25 +53,32 @@ class PointNet2(torch.nn.Module):
         return self
 
     @torch.no_grad()
-    def compute_geometry(self, x, fps_start=None):
+    def compute_geometry(self, x, fps_start=None, cuda_route=None):
         """All index tensors of a forward pass (FPS / ball query of sa1, sa2; 3-NN of sfp2, sfp3).
         They depend on the input coordinates only, so a trainer can compute them for batch t+1 on a
         side stream while batch t is still in its backward pass (training.SPFNTrainer.prefetch)."""
+        from .. import cuda_ops as _co
+        cr = bool(_co.CUDA_ROUTE) if cuda_route is None else bool(cuda_route)
         xyz = x[:, :, :self.dim_pos].contiguous().float()
         s1, s2 = fps_start if fps_start is not None else (None, None)
-        g1 = self.sa1.compute_geometry(xyz, s1)
-        g2 = self.sa2.compute_geometry(g1["new_xyz"], s2)
-        return {"sa1": g1, "sa2": g2, "sfp2": self.sfp2.compute_geometry(g1["new_xyz"], g2["new_xyz"]),
-                "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"])}
+        g1 = self.sa1.compute_geometry(xyz, s1, cr)
+        g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr)
+        return {"sa1": g1, "sa2": g2, "sfp2": self.sfp2.compute_geometry(g1["new_xyz"], g2["new_xyz"], cr),
+                "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"], cr)}
 
     def forward(self, x, glob_features=None, loc_features=None, fast=True, fps_start=None, geometry=None):
-        from .. import fused_mlp
+        """`fast`: the reference switches between its compiled CUDA ops (default) and its PyTorch CPU route, which
+        give DIFFERENT results (FPS start / near-origin skip, ball-query distance, sqrt vs squared 3-NN distances in
+        the interpolation weights).  Here the CPU route's results are the default for both values (BASELINE.json's
+        parity target); with the process-wide opt-in `cuda_ops.CUDA_ROUTE` (CPFN_CUDA_ROUTE=1) `fast=True` selects
+        the CUDA route's semantics — what a checkpoint trained by the reference on a GPU saw."""
+        from .. import cuda_ops as _co, fused_mlp
         if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda:
             fused_mlp.refresh_weight_panels(self.parameters())     # one multi-tensor fp32 -> bf16 conversion
         with fused_mlp.deferred_bn_counters():
-            return self._forward(x, glob_features, loc_features, fps_start, geometry)
+            return self._forward(x, glob_features, loc_features, fps_start, geometry, bool(_co.CUDA_ROUTE and fast))
 
-    def _forward(self, x, glob_features, loc_features, fps_start, geometry):
+    def _forward(self, x, glob_features, loc_features, fps_start, geometry, cuda_route=False):
         """`fps_start` = optional (start_sa1 [B], start_sa2 [B]) FPS seeds; by default each SA
         level draws its own from the CPU generator like the reference's CPU route."""
         B, N, _ = x.shape
@@ -79,16 +86,17 @@ class PointNet2(torch.nn.Module):
         feats0 = x[:, :, self.dim_pos:].contiguous() if x.shape[2] > self.dim_pos else None
         s1, s2 = fps_start if fps_start is not None else (None, None)
         gm = geometry if geometry is not None else {}
-        l1_xyz, l1, self.aux_sa1 = self.sa1.forward_rows(xyz, feats0, s1, gm.get("sa1"))
-        l2_xyz, l2, self.aux_sa2 = self.sa2.forward_rows(l1_xyz, l1, s2, gm.get("sa2"))
+        cr = cuda_route
+        l1_xyz, l1, self.aux_sa1 = self.sa1.forward_rows(xyz, feats0, s1, gm.get("sa1"), cr)
+        l2_xyz, l2, self.aux_sa2 = self.sa2.forward_rows(l1_xyz, l1, s2, gm.get("sa2"), cr)
         _, l3, _ = self.sa3.forward_rows(l2_xyz, l2)                       # [B,1,1024]
         if self.use_glob_features:
             l3 = torch.cat([l3, glob_features.unsqueeze(1).to(l3.dtype)], dim=2)
         if self.use_loc_features:
             l3 = torch.cat([l3, loc_features.unsqueeze(1).to(l3.dtype)], dim=2)
         l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3)
-        l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"))
-        l6, _ = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5, gm.get("sfp3"))
+        l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"), cr)
+        l6, self.aux_sfp3 = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5, gm.get("sfp3"), cr)
         cd = getattr(self, "compute_dtype", torch.float32)
         l3_out = l3.transpose(1, 2)                                         # [B,1024(+extra),1]
         if getattr(self, "return_point_features", True) or self.features_extractor:

@@ -1,11 +1,13 @@
 """Drop-in for PointNet2/pointnet2_ops/modules/geometry_utils.py: same function names,
 argument order and channel-major [B, C, N] tensor conventions.
 
-Every function runs a HIP kernel from libcpfn_hip.so.  The kernels reproduce the
-arithmetic of the reference's `fast=False` (CPU) route bit for bit, so the `fast`
-switch no longer selects between two different results: it is accepted for source
-compatibility and ignored.  CPU tensors raise "CPU not supported" like the
-reference's native ops (cuda_ops/src/sampling.cpp:33-35); there is no fallback.
+Every function runs a HIP kernel from libcpfn_hip.so.  By default the kernels reproduce the
+arithmetic of the reference's `fast=False` (CPU) route bit for bit whatever `fast` says
+(BASELINE.json's parity target).  With the process-wide opt-in `cuda_ops.CUDA_ROUTE`
+(CPFN_CUDA_ROUTE=1), `fast=True` selects what the reference's compiled CUDA ops return instead:
+FPS from index 0 skipping near-origin points, direct-distance ball query and 3-NN, and the
+SQUARE ROOTS of the 3-NN distances (reference line 184).  CPU tensors raise "CPU not supported"
+like the reference's native ops (cuda_ops/src/sampling.cpp:33-35); there is no fallback.
 """
 import torch
 
@@ -53,24 +55,31 @@ def farthest_point_sample(point_pos, num_point, fast=True, start_idx=None):
     if point_pos.shape[1] != 3:
         raise ValueError('Points must have exactly three position dimensions when using the fast method.')
     B, _, N = point_pos.shape
+    if cuda_ops.CUDA_ROUTE and fast:
+        return cuda_ops.farthest_point_sampling(_rows(point_pos), num_point, start_idx=start_idx,
+                                                cuda_compat=True).to(dtype=torch.long)
     if start_idx is None:
         start_idx = torch.randint(0, N, (B,), dtype=torch.long)
-    return cuda_ops.farthest_point_sampling(_rows(point_pos), num_point, start_idx=start_idx).to(dtype=torch.long)
+    return cuda_ops.farthest_point_sampling(_rows(point_pos), num_point, start_idx=start_idx,
+                                            cuda_compat=False).to(dtype=torch.long)
 
 
 def ball_query(radius, num_samples, point_pos, query_pos, fast=True):
     """point_pos [B,3,N], query_pos [B,3,S] -> [B,S,num_samples] (long)   (reference lines 133-161)."""
     if point_pos.shape[1] != 3:
         raise ValueError('Points must have exactly three position dimensions when using the fast method.')
-    return cuda_ops.ball_query(_rows(query_pos), _rows(point_pos), radius, num_samples).to(dtype=torch.long)
+    return cuda_ops.ball_query(_rows(query_pos), _rows(point_pos), radius, num_samples,
+                               cuda_compat=bool(cuda_ops.CUDA_ROUTE and fast)).to(dtype=torch.long)
 
 
 def three_nn(point_pos, query_pos, fast=True):
     """point_pos [B,3,N] (known), query_pos [B,3,S] -> (squared dists [B,S,3], idx [B,S,3] long).
-    Squared distances, as the reference's CPU route returns (lines 212-215)."""
+    Squared distances, as the reference's CPU route returns (lines 212-215); on the opt-in CUDA route their
+    square roots, as `_FastThreeNN` returns (line 184)."""
     if point_pos.shape[1] != 3:
         raise ValueError('Points must have exactly three position dimensions when using the fast method.')
-    d, i = cuda_ops.three_nn(_rows(query_pos), _rows(point_pos))
+    cr = bool(cuda_ops.CUDA_ROUTE and fast)
+    d, i = _ops.three_nn(_rows(query_pos), _rows(point_pos), cuda_route=cr, sqrt=cr)
     return d, i.to(dtype=torch.long)
 
 

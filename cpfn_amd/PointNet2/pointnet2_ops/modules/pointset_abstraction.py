@@ -38,19 +38,24 @@ class PointsetAbstraction(nn.Module):
             self.bn_blocks.append(bns)
 
     # ---------------------------------------------------------------- native layout
-    def compute_geometry(self, xyz, start_idx=None):
+    def compute_geometry(self, xyz, start_idx=None, cuda_route=False):
         """Everything of this level that depends only on coordinates (no weights, no gradients):
         FPS indices, sampled centres, ball-query neighbours and the centred neighbour coordinates.
-        Can be run ahead of time on a side stream (PointNet2.compute_geometry)."""
+        Can be run ahead of time on a side stream (PointNet2.compute_geometry).
+        cuda_route: the semantics of the reference's compiled CUDA ops (`fast=True`): FPS from index 0 skipping
+        near-origin points (sampling_gpu.cu:76-91), direct-distance ball query (ball_query_gpu.cu:21-31)."""
         B, N, _ = xyz.shape
-        if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
-            start_idx = torch.randint(0, N, (B,), dtype=torch.long)
-        start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
-        sel = ops.fps(xyz, self.num_points, start_idx)
+        if cuda_route:          # always from index 0 (sampling_gpu.cu:76-77); a caller's start indices do not apply
+            sel = ops.fps(xyz, self.num_points, None, skip_near_origin=True)
+        else:
+            if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
+                start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+            start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
+            sel = ops.fps(xyz, self.num_points, start_idx)
         new_xyz = ops.gather_rows(xyz, sel)
         scales = []
         for r, k in zip(self.radius_list, self.num_samples_list):
-            nbr = ops.ball_query(new_xyz, xyz, r, k)                                      # [B,S,K] i32
+            nbr = ops.ball_query(new_xyz, xyz, r, k, cuda_route=cuda_route)               # [B,S,K] i32
             scales.append((nbr, ops.group_xyz_centered(xyz, new_xyz, nbr)))               # rel [B,S,K,3] fp32
         out = {"fps_idx": sel, "new_xyz": new_xyz, "scales": scales}
         if self.has_feats and N <= 2048 and len(scales) == 1:
@@ -58,7 +63,7 @@ class PointsetAbstraction(nn.Module):
             out["inv"] = ops.csr_build(scales[0][0], N)
         return out
 
-    def forward_rows(self, xyz, feats, start_idx=None, geom=None):
+    def forward_rows(self, xyz, feats, start_idx=None, geom=None, cuda_route=False):
         """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux)."""
         B, N, _ = xyz.shape
         aux = {}
@@ -74,7 +79,7 @@ class PointsetAbstraction(nn.Module):
             groups = [(g.reshape(B * N, -1), None, 1, N)] * len(self.mlp_list)
         else:
             if geom is None:
-                geom = self.compute_geometry(xyz, start_idx)
+                geom = self.compute_geometry(xyz, start_idx, cuda_route)
             new_xyz = geom["new_xyz"]
             aux["fps_idx"] = geom["fps_idx"]
             groups = []
@@ -101,7 +106,10 @@ class PointsetAbstraction(nn.Module):
 
     # ---------------------------------------------------------------- reference layout
     def forward(self, pos, feats, fast=True):
+        """`fast` selects the CUDA-route semantics only when the process-wide switch cuda_ops.CUDA_ROUTE is on;
+        by default both values give the reference's CPU-route results."""
+        from .... import cuda_ops as _co
         xyz = pos.transpose(1, 2).contiguous()
         f = None if feats is None else feats.transpose(1, 2).contiguous()
-        new_xyz, new_feats, _ = self.forward_rows(xyz, f)
+        new_xyz, new_feats, _ = self.forward_rows(xyz, f, cuda_route=bool(_co.CUDA_ROUTE and fast))
         return (None if new_xyz is None else new_xyz.transpose(1, 2)), new_feats.transpose(1, 2)

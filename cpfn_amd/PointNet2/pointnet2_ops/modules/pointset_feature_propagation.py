@@ -23,15 +23,17 @@ class PointsetFeaturePropagation(nn.Module):
             c_in = c_out
 
     @staticmethod
-    def compute_geometry(xyz1, xyz2):
-        """3-NN indices and inverse-distance weights (coordinates only; prefetchable)."""
-        d2, nn_idx = ops.three_nn(xyz1, xyz2)                               # squared distances (CPU-route semantics)
+    def compute_geometry(xyz1, xyz2, cuda_route=False):
+        """3-NN indices and inverse-distance weights (coordinates only; prefetchable).
+        cuda_route: what the reference's `fast=True` gives — direct distances and their SQUARE ROOTS
+        (geometry_utils.py:184), so the weights are 1/(d + 1e-8) instead of the CPU route's 1/(d² + 1e-8)."""
+        d2, nn_idx = ops.three_nn(xyz1, xyz2, cuda_route=cuda_route, sqrt=cuda_route)   # CPU route: squared distances
         out = {"nn_idx": nn_idx, "nn_w": ops.three_weights(d2)}             # 1/(d+1e-8), normalised (ref :40-42)
         if xyz2.shape[1] <= 2048:
             out["inv"] = ops.csr_build(nn_idx, xyz2.shape[1])               # for the atomic-free interpolation adjoint
         return out
 
-    def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None):
+    def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None, cuda_route=False):
         """xyz1 [B,N,3] dense, xyz2 [B,S,3] coarse or None, feats1 [B,N,D1] or None,
         feats2 [B,S,D2] -> [B,N,D']."""
         B, N, _ = xyz1.shape
@@ -40,7 +42,7 @@ class PointsetFeaturePropagation(nn.Module):
             interp = feats2.expand(B, N, feats2.shape[2])                  # broadcast the global vector (ref :33-34)
         else:
             if geom is None:
-                geom = self.compute_geometry(xyz1, xyz2)
+                geom = self.compute_geometry(xyz1, xyz2, cuda_route)
             interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"], geom.get("inv"))
             aux = geom
         x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
@@ -48,6 +50,7 @@ class PointsetFeaturePropagation(nn.Module):
         return y.reshape(B, N, -1), aux
 
     def forward(self, pos1, pos2, feats1, feats2, fast=True):
+        from .... import cuda_ops as _co
         t = lambda a: None if a is None else a.transpose(1, 2).contiguous()
-        out, _ = self.forward_rows(t(pos1), t(pos2), t(feats1), t(feats2))
+        out, _ = self.forward_rows(t(pos1), t(pos2), t(feats1), t(feats2), cuda_route=bool(_co.CUDA_ROUTE and fast))
         return out.transpose(1, 2)

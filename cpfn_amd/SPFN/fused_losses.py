@@ -331,11 +331,22 @@ def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=Non
 
 def fused_losses(P, Y, batch, multipliers, classes):
     """P [B,N,3]; Y [B,N,7+K] = packed fp32 heads (normal | type logits | membership logits).
-    Returns the reference's (total, normal, type, miou, residue, parameter) scalars."""
-    if HOST_ASSIGNMENT or Y.shape[2] - 7 > 32 or not PARALLEL_BRANCHES:
+    Returns the reference's (total, normal, type, miou, residue, parameter) scalars.
+    More than 32 instance columns (beyond the fused kernels' tile): the op-by-op twin
+    `losses_implementation.compute_all_losses` on the same heads (HIP fitters, stock reductions)."""
+    if Y.shape[2] - 7 > 32:
+        from . import losses_implementation as li
+        X = torch.nn.functional.normalize(Y[..., :3], p=2, dim=2, eps=1e-12)
+        W = torch.softmax(Y[..., 7:], dim=2)
+        gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"], "cone_axis": batch["cone_axis_gt"]}
+        m = multipliers
+        return li.compute_all_losses(P, W, batch["I_gt"], X, batch["X_gt"], Y[..., 3:7], batch["T_gt"], gt,
+                                     batch["points_per_instance"], m["normal"], m["type"], m["miou"], m["residue"],
+                                     m["parameter"], m["total"], False, mode_seg='mIoU', classes=classes)[:6]
+    if HOST_ASSIGNMENT or not PARALLEL_BRANCHES:
         Xn, W, nl, tl, S = pre_match(Y, batch)
         n_gt = count_gt(batch["I_gt"])
-        if HOST_ASSIGNMENT or S.shape[2] > 32:
+        if HOST_ASSIGNMENT:
             match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
         else:
             match = hungarian_device(S, n_gt)

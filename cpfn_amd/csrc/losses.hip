@@ -240,6 +240,9 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
 // S[b][K+2][K]: rows l<K: Σ_{n: I=l} W[n,:];  row K: Σ_n W[n,:];  row K+1: #points with label l (as float).
 // thread = (column kk, point subset); 32 label accumulators per thread, selected by compare (no atomics).
 constexpr int SS_TILE = 256, SS_SUB = LP_THREADS / MAXK;   // 8 subsets; a tile = one latency: the whole 256-point chunk
+// WIDE (K > 32, evaluation only: merged label sets of evaluation_localSPFN.py:129-131 have no upper bound): blockIdx.z
+// enumerates (label tile, column tile) pairs of 32 x 32 and the same code accumulates one tile of S per workgroup.
+template <bool WIDE>
 __global__ __launch_bounds__(LP_THREADS) void seg_stats_fwd_kernel(const float *__restrict__ W,
                                                                    const long long *__restrict__ Igt, int N, int K,
                                                                    int pts_per_block, float *__restrict__ partial) {
@@ -252,6 +255,8 @@ __global__ __launch_bounds__(LP_THREADS) void seg_stats_fwd_kernel(const float *
   __shared__ float s_acc[SS_SUB][MAXK + 1][MAXK + 1];
   __shared__ int s_cnt[MAXK];                       // points per label: integer LDS atomics (exact, order-free)
   const int b = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+  const int kt_n = WIDE ? (K + MAXK - 1) / MAXK : 1;
+  const int l0 = WIDE ? (int)(blockIdx.z / kt_n) * MAXK : 0, k0 = WIDE ? (int)(blockIdx.z % kt_n) * MAXK : 0;
   const int kk = t % MAXK, sub = t / MAXK;
   const int n0 = chunk * pts_per_block, n1 = min(N, n0 + pts_per_block);
   float all = 0.f;
@@ -261,10 +266,10 @@ __global__ __launch_bounds__(LP_THREADS) void seg_stats_fwd_kernel(const float *
     __syncthreads();
     for (int e = t; e < SS_TILE * MAXK; e += LP_THREADS) {
       const int i = e / MAXK, k = e % MAXK;
-      s_w[i][k] = (base + i < n1 && k < K) ? W[((size_t)b * N + base + i) * K + k] : 0.f;
+      s_w[i][k] = (base + i < n1 && k0 + k < K) ? W[((size_t)b * N + base + i) * K + k0 + k] : 0.f;
     }
     if (t < SS_TILE) {
-      const int lab = (base + t < n1) ? (int)Igt[(size_t)b * N + base + t] : -2;
+      const int lab = (base + t < n1) ? (int)Igt[(size_t)b * N + base + t] - l0 : -2;
       s_lab[t] = lab;
       if (lab >= 0 && lab < MAXK) atomicAdd(&s_cnt[lab], 1);
     }
@@ -279,14 +284,26 @@ __global__ __launch_bounds__(LP_THREADS) void seg_stats_fwd_kernel(const float *
   s_acc[sub][MAXK][kk] = all;
   __syncthreads();
   float *o = partial + ((size_t)b * gridDim.x + chunk) * (K + 2) * K;
-  for (int e = t; e < (K + 1) * K; e += LP_THREADS) {
-    const int l = e / K, k = e % K;
-    const int row = l < K ? l : MAXK;
-    float s = 0.f;
-    for (int q = 0; q < SS_SUB; ++q) s += s_acc[q][row][k];
-    o[l * K + k] = s;
+  if (!WIDE) {
+    for (int e = t; e < (K + 1) * K; e += LP_THREADS) {
+      const int l = e / K, k = e % K;
+      const int row = l < K ? l : MAXK;
+      float s = 0.f;
+      for (int q = 0; q < SS_SUB; ++q) s += s_acc[q][row][k];
+      o[l * K + k] = s;
+    }
+    if (t < K) o[(K + 1) * K + t] = (float)s_cnt[t];
+  } else {
+    const int kw = min(MAXK, K - k0), lw = min(MAXK, K - l0);
+    for (int e = t; e < (MAXK + 1) * MAXK; e += LP_THREADS) {
+      const int l = e / MAXK, k = e % MAXK;          // l == MAXK: the all-points row (written by label tile 0 only)
+      if (k >= kw || (l < MAXK ? l >= lw : l0 != 0)) continue;
+      float s = 0.f;
+      for (int q = 0; q < SS_SUB; ++q) s += s_acc[q][l][k];
+      o[(l < MAXK ? l0 + l : K) * K + k0 + k] = s;
+    }
+    if (k0 == 0 && t < lw) o[(K + 1) * K + l0 + t] = (float)s_cnt[t];
   }
-  if (t < K) o[(K + 1) * K + t] = (float)s_cnt[t];
 }
 
 __global__ void chunk_sum_f32_kernel(const float *__restrict__ partial, int chunks, int per_b, long long total,
@@ -506,29 +523,37 @@ __global__ __launch_bounds__(256) void p_coverage_kernel(const float *__restrict
   __shared__ int s_kind[64];
   __shared__ float s_cnt[4][PC_MAXEPS];
   const int b = blockIdx.y, t = threadIdx.x;
-  for (int k = t; k < K; k += 256) {
-    const long long m = match[(size_t)b * K + k], ty = slot_type[(size_t)b * K + k];
-    const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
-    const float *P22 = params + ((size_t)b * K + m) * 22;
-    const int off = kind == 0 ? 0 : (kind == 1 ? 4 : (kind == 2 ? 8 : 15));
-    const int nq = kind == 0 ? 4 : (kind == 1 ? 4 : 7);
-    for (int i = 0; i < 8; ++i) s_q[k][i] = i < nq ? P22[off + i] : 0.f;
-    s_kind[k] = kind;
-  }
-  __syncthreads();
   const int n = blockIdx.x * 256 + t;
-  float cnt[PC_MAXEPS] = {0, 0, 0, 0};
+  float px = 0.f, py = 0.f, pz = 0.f;
   if (n < N) {
     const float *p = P + ((size_t)b * N + n) * 3;
-    const float px = p[0], py = p[1], pz = p[2];
-    float best = INFINITY;
-    for (int k = 0; k < K; ++k) {
-      const cpfn_f32x4 q0 = cpfn_lds_read4(&s_q[k][0]), q1 = cpfn_lds_read4(&s_q[k][4]);   // never a 96-bit LDS read
-      const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-      best = fminf(best, sqrt_safe_f(residue_value(s_kind[k], q, px, py, pz)));
-    }
-    for (int i = 0; i < PC_MAXEPS; ++i) cnt[i] = (i < n_eps && best < eps.e[i]) ? 1.f : 0.f;
+    px = p[0]; py = p[1]; pz = p[2];
   }
+  float best = INFINITY;
+  for (int k0 = 0; k0 < K; k0 += 64) {          // slot parameters through LDS, 64 slots at a time (any K)
+    const int kw = min(64, K - k0);
+    __syncthreads();
+    if (t < kw) {
+      const int k = k0 + t;
+      const long long m = match[(size_t)b * K + k], ty = slot_type[(size_t)b * K + k];
+      const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
+      const float *P22 = params + ((size_t)b * K + m) * 22;
+      const int off = kind == 0 ? 0 : (kind == 1 ? 4 : (kind == 2 ? 8 : 15));
+      const int nq = kind == 0 ? 4 : (kind == 1 ? 4 : 7);
+      for (int i = 0; i < 8; ++i) s_q[t][i] = i < nq ? P22[off + i] : 0.f;
+      s_kind[t] = kind;
+    }
+    __syncthreads();
+    if (n < N)
+      for (int k = 0; k < kw; ++k) {
+        const cpfn_f32x4 q0 = cpfn_lds_read4(&s_q[k][0]), q1 = cpfn_lds_read4(&s_q[k][4]);   // never a 96-bit LDS read
+        const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        best = fminf(best, sqrt_safe_f(residue_value(s_kind[k], q, px, py, pz)));
+      }
+  }
+  float cnt[PC_MAXEPS] = {0, 0, 0, 0};
+  if (n < N)
+    for (int i = 0; i < PC_MAXEPS; ++i) cnt[i] = (i < n_eps && best < eps.e[i]) ? 1.f : 0.f;
   for (int i = 0; i < PC_MAXEPS; ++i)
     for (int msk = 32; msk >= 1; msk >>= 1) cnt[i] += __shfl_xor(cnt[i], msk, 64);
   if ((t & 63) == 0)
@@ -776,11 +801,16 @@ extern "C" int cpfn_seg_stats_chunks(int B, int N) {
 
 extern "C" int cpfn_seg_stats_fwd(const float *W, const int64_t *Igt, int B, int N, int K, float *workspace, float *S,
                                   void *stream) {
-  if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !W || !Igt || !workspace || !S) return CPFN_EINVAL;
+  if (B <= 0 || N <= 0 || K <= 0 || K > 1024 || !W || !Igt || !workspace || !S) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   int ppb;
   const int chunks = loss_chunks(B, N, &ppb);
-  seg_stats_fwd_kernel<<<dim3(chunks, B), LP_THREADS, 0, st>>>(W, (const long long *)Igt, N, K, ppb, workspace);
+  if (K <= MAXK) {
+    seg_stats_fwd_kernel<false><<<dim3(chunks, B), LP_THREADS, 0, st>>>(W, (const long long *)Igt, N, K, ppb, workspace);
+  } else {        // evaluation-sized label sets: one 32 x 32 tile of S per workgroup
+    const int kt = (K + MAXK - 1) / MAXK;
+    seg_stats_fwd_kernel<true><<<dim3(chunks, B, kt * kt), LP_THREADS, 0, st>>>(W, (const long long *)Igt, N, K, ppb, workspace);
+  }
   const long long total = (long long)B * (K + 2) * K;
   chunk_sum_f32_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, (K + 2) * K, total, S);
   return cpfn_launch_status();
@@ -836,7 +866,7 @@ extern "C" int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, 
 extern "C" int cpfn_p_coverage(const float *P, const float *params22, const int64_t *match, const int64_t *slot_type, int B,
                                int N, int K, const int *type_ids, const float *eps, int n_eps, float *workspace, float *out,
                                void *stream) {
-  if (B <= 0 || N <= 0 || K <= 0 || K > 64 || n_eps <= 0 || n_eps > PC_MAXEPS || !P || !params22 || !match || !slot_type ||
+  if (B <= 0 || N <= 0 || K <= 0 || n_eps <= 0 || n_eps > PC_MAXEPS || !P || !params22 || !match || !slot_type ||
       !type_ids || !eps || !workspace || !out)
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;

@@ -2,6 +2,11 @@
 //
 // Both evaluate the reference's CPU distance (modules/geometry_utils.py:4-23) bit for
 // bit: D = ((-2*dot) + |q|²) + |p|² with dot an fma chain over x, y, z.
+// The DIRECT instantiations follow the reference's CUDA route instead (`fast=True`): the
+// distance is (q-p)² summed over x, y, z (ball_query_gpu.cu:29-30, interpolate_gpu.cu:34),
+// the ball is `d2 < radius*radius` in fp32 (:21, :31).  nvcc contracts a*a + b*b + c*c into
+// an fma chain by default (-fmad=true); that is what is spelled here.  No CUDA build of the
+// reference can run in this image, so the DIRECT route is NOT pinned bit for bit.
 //
 // ball_query : one 64-lane wave per query.  The wave strides over the cloud 64 points
 //              at a time in index order; `__ballot` + popcount-of-lower-lanes gives each
@@ -15,6 +20,12 @@ namespace {
 
 constexpr int BQ_WAVES = 4;
 
+__device__ __forceinline__ float direct_sqdist(float qx, float qy, float qz, float x, float y, float z) {
+  const float dx = __fsub_rn(qx, x), dy = __fsub_rn(qy, y), dz = __fsub_rn(qz, z);
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
+
+template <bool DIRECT>
 __global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, int B, int N, int S, float thr, int K,
     int *__restrict__ idx_out) {
@@ -29,14 +40,18 @@ __global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
   const float qn = cpfn_sqnorm3(qx, qy, qz);
 
   int cnt = 0;
-  int first = N;  // what the reference's sort-based code pads with when nothing is kept
+  int first = DIRECT ? 0 : N;  // empty ball: the CPU route's sort-based code pads with N, the CUDA route's output stays 0
   for (int base = 0; base < N && cnt < K; base += CPFN_WAVE) {
     const int n = base + lane;
     bool keep = false;
     if (n < N) {
       const float x = p[3 * n], y = p[3 * n + 1], z = p[3 * n + 2];
-      const float d = cpfn_pair_sqdist(qx, qy, qz, qn, x, y, z, cpfn_sqnorm3(x, y, z));
-      keep = !(d > thr);
+      if (DIRECT) {
+        keep = direct_sqdist(qx, qy, qz, x, y, z) < thr;
+      } else {
+        const float d = cpfn_pair_sqdist(qx, qy, qz, qn, x, y, z, cpfn_sqnorm3(x, y, z));
+        keep = !(d > thr);
+      }
     }
     const unsigned long long mask = __ballot(keep);
     if (mask) {
@@ -53,9 +68,11 @@ __global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 1024;
 
+template <bool DIRECT>
 __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__restrict__ unknown,
                                                               const float *__restrict__ known, int N, int M,
-                                                              float *__restrict__ dist2, int *__restrict__ idx) {
+                                                              float *__restrict__ dist2, int *__restrict__ idx,
+                                                              int sqrt_out) {
   __shared__ float4 s_known[NN_TILE];
   const int b = blockIdx.y;
   const int i = blockIdx.x * NN_THREADS + threadIdx.x;
@@ -67,7 +84,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
   }
   const float un = cpfn_sqnorm3(ux, uy, uz);
   float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
-  int i0 = M, i1 = M, i2 = M;
+  int i0 = DIRECT ? 0 : M, i1 = i0, i2 = i0;      // (interpolate_gpu.cu:29: the CUDA route starts from index 0)
   for (int base = 0; base < M; base += NN_TILE) {
     const int cntk = min(NN_TILE, M - base);
     __syncthreads();
@@ -77,8 +94,9 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
     }
     __syncthreads();
     for (int j = 0; j < cntk; ++j) {
-      const float4 k4 = s_known[j];
-      const float d = cpfn_pair_sqdist(ux, uy, uz, un, k4.x, k4.y, k4.z, k4.w);
+      const cpfn_f32x4 k4 = cpfn_lds_read4((const float *)&s_known[j]);   // (the DIRECT variant uses 3 of the 4 floats)
+      const float d = DIRECT ? direct_sqdist(ux, uy, uz, k4.x, k4.y, k4.z)
+                             : cpfn_pair_sqdist(ux, uy, uz, un, k4.x, k4.y, k4.z, k4.w);
       const int jj = base + j;
       if (d < d2) {
         if (d < d1) {
@@ -97,6 +115,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
   if (i < N) {
     float *od = dist2 + ((size_t)b * N + i) * 3;
     int *oi = idx + ((size_t)b * N + i) * 3;
+    if (sqrt_out) { d0 = __fsqrt_rn(d0); d1 = __fsqrt_rn(d1); d2 = __fsqrt_rn(d2); }   // geometry_utils.py:184
     od[0] = d0; od[1] = d1; od[2] = d2;
     oi[0] = i0; oi[1] = i1; oi[2] = i2;
   }
@@ -137,8 +156,18 @@ extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, in
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
-  ball_query_kernel<<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+  ball_query_kernel<false><<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
       xyz, new_xyz, B, N, S, thr, K, idx_out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, int B, int N, int S, float radius, int K,
+                                      int *idx_out, void *stream) {
+  if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
+  const long long Q = (long long)B * S;
+  if (Q == 0) return 0;
+  ball_query_kernel<true><<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+      xyz, new_xyz, B, N, S, radius * radius, K, idx_out);
   return cpfn_launch_status();
 }
 
@@ -147,7 +176,16 @@ extern "C" int cpfn_three_nn(const float *unknown, const float *known, int B, in
   if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist2 || !idx) return CPFN_EINVAL;
   if (B == 0 || N == 0) return 0;
   dim3 grid(cpfn_cdiv(N, NN_THREADS), B);
-  three_nn_kernel<<<grid, NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M, dist2, idx);
+  three_nn_kernel<false><<<grid, NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M, dist2, idx, 0);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_three_nn_direct(const float *unknown, const float *known, int B, int N, int M, int sqrt_out,
+                                    float *dist, int *idx, void *stream) {
+  if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist || !idx) return CPFN_EINVAL;
+  if (B == 0 || N == 0) return 0;
+  dim3 grid(cpfn_cdiv(N, NN_THREADS), B);
+  three_nn_kernel<true><<<grid, NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M, dist, idx, sqrt_out);
   return cpfn_launch_status();
 }
 

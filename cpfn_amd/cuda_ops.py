@@ -8,11 +8,20 @@ Two deliberate differences, both so that results equal the reference's *CPU* rou
 (the parity target, BASELINE.json): `farthest_point_sampling` takes an optional
 `start_idx` (the CPU route starts from a random index, the CUDA kernel from 0) and
 does not skip near-origin points unless `cuda_compat=True`; `three_nn` and
-`ball_query` use the expanded ‖q‖²+‖p‖²−2q·p distance the CPU route uses.
+`ball_query` use the expanded ‖q‖²+‖p‖²−2q·p distance the CPU route uses unless
+`cuda_compat=True` (then: the CUDA kernels' direct (q−p)² distance, `d2 < r*r`).
+`cuda_compat` defaults to the process-wide switch `cpfn_amd.cuda_ops.CUDA_ROUTE`
+(environment CPFN_CUDA_ROUTE=1), off unless asked for.
 """
+import os
+
 import torch
 
 from . import ops
+
+# Process-wide default of `cuda_compat`: reproduce what the reference's compiled CUDA extension returns
+# (`fast=True`) instead of its CPU route.  Checkpoints trained by the reference on a GPU saw these semantics.
+CUDA_ROUTE = os.environ.get("CPFN_CUDA_ROUTE", "0") == "1"
 
 
 def gather_points(points, idx):
@@ -25,16 +34,20 @@ def gather_points_grad(grad_out, idx, n):
     return ops.group_bwd(grad_out, idx, n)
 
 
-def farthest_point_sampling(points, nsamples, start_idx=None, cuda_compat=False):
+def farthest_point_sampling(points, nsamples, start_idx=None, cuda_compat=None):
     """points [b,n,3] f32 -> [b,nsamples] i32   (sampling.cpp:64-86)."""
+    cuda_compat = CUDA_ROUTE if cuda_compat is None else cuda_compat
     if start_idx is not None:
         start_idx = start_idx.to(device=points.device, dtype=torch.int32).contiguous()
     return ops.fps(points, nsamples, start_idx, skip_near_origin=cuda_compat)
 
 
-def three_nn(unknowns, knows):
-    """unknown [b,n,3], known [b,m,3] -> [dist2 [b,n,3] f32, idx [b,n,3] i32]   (interpolate.cpp)."""
-    d, i = ops.three_nn(unknowns, knows)
+def three_nn(unknowns, knows, cuda_compat=None):
+    """unknown [b,n,3], known [b,m,3] -> [dist2 [b,n,3] f32, idx [b,n,3] i32]   (interpolate.cpp).
+    Squared distances on both routes, as the bound function returns them (the sqrt of the CUDA route is
+    taken by the Python wrapper, modules/geometry_utils.py:184)."""
+    cuda_compat = CUDA_ROUTE if cuda_compat is None else cuda_compat
+    d, i = ops.three_nn(unknowns, knows, cuda_route=cuda_compat)
     return [d, i]
 
 
@@ -48,9 +61,10 @@ def three_weighted_sum_grad(grad_out, idx, weight, m):
     return ops.three_interp_bwd(grad_out, idx, weight, m)
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
+def ball_query(new_xyz, xyz, radius, nsample, cuda_compat=None):
     """new_xyz [b,m,3], xyz [b,n,3] -> [b,m,nsample] i32   (ball_query.cpp)."""
-    return ops.ball_query(new_xyz, xyz, radius, nsample)
+    cuda_compat = CUDA_ROUTE if cuda_compat is None else cuda_compat
+    return ops.ball_query(new_xyz, xyz, radius, nsample, cuda_route=cuda_compat)
 
 
 def group_points(points, idx):

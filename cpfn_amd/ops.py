@@ -49,22 +49,29 @@ def fps(xyz, num_samples, start=None, skip_near_origin=False):
     return out
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
+def ball_query(new_xyz, xyz, radius, nsample, cuda_route=False):
     """new_xyz [B,S,3], xyz [B,N,3] -> idx [B,S,K] i32 (argument order of the
-    reference's cuda_ops.ball_query, ball_query.cpp)."""
+    reference's cuda_ops.ball_query, ball_query.cpp).  cuda_route: the CUDA kernel's direct
+    (q-p)^2 < radius*radius test (ball_query_gpu.cu:21-31) instead of the CPU route's expanded distance."""
     _chk(new_xyz, "new_xyz", torch.float32)
     _chk(xyz, "xyz", torch.float32)
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]
     out = torch.empty(B, S, int(nsample), dtype=torch.int32, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _l.check(_l.lib().cpfn_ball_query(_ptr(xyz), _ptr(new_xyz), B, N, S, ball_query_threshold(radius),
-                                          int(nsample), _ptr(out), _stream()), "cpfn_ball_query")
+        if cuda_route:
+            _l.check(_l.lib().cpfn_ball_query_direct(_ptr(xyz), _ptr(new_xyz), B, N, S, float(radius), int(nsample),
+                                                     _ptr(out), _stream()), "cpfn_ball_query_direct")
+        else:
+            _l.check(_l.lib().cpfn_ball_query(_ptr(xyz), _ptr(new_xyz), B, N, S, ball_query_threshold(radius),
+                                              int(nsample), _ptr(out), _stream()), "cpfn_ball_query")
     return out
 
 
-def three_nn(unknown, known):
-    """unknown [B,N,3] queries, known [B,M,3] -> (dist2 [B,N,3] f32, idx [B,N,3] i32)."""
+def three_nn(unknown, known, cuda_route=False, sqrt=False):
+    """unknown [B,N,3] queries, known [B,M,3] -> (dist2 [B,N,3] f32, idx [B,N,3] i32).
+    cuda_route: the CUDA kernel's direct distance (interpolate_gpu.cu:34); sqrt (cuda_route only): the square
+    roots, which is what the reference's fast=True wrapper returns (modules/geometry_utils.py:184)."""
     _chk(unknown, "unknown", torch.float32)
     _chk(known, "known", torch.float32)
     B, N, _ = unknown.shape
@@ -72,8 +79,14 @@ def three_nn(unknown, known):
     d = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
     i = torch.empty(B, N, 3, dtype=torch.int32, device=unknown.device)
     with torch.cuda.device(unknown.device):
-        _l.check(_l.lib().cpfn_three_nn(_ptr(unknown), _ptr(known), B, N, M, _ptr(d), _ptr(i), _stream()),
-                 "cpfn_three_nn")
+        if cuda_route:
+            _l.check(_l.lib().cpfn_three_nn_direct(_ptr(unknown), _ptr(known), B, N, M, 1 if sqrt else 0, _ptr(d), _ptr(i),
+                                                   _stream()), "cpfn_three_nn_direct")
+        else:
+            if sqrt:
+                raise RuntimeError("sqrt distances exist on the CUDA route only")
+            _l.check(_l.lib().cpfn_three_nn(_ptr(unknown), _ptr(known), B, N, M, _ptr(d), _ptr(i), _stream()),
+                     "cpfn_three_nn")
     return d, i
 
 

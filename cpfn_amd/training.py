@@ -56,6 +56,7 @@ class FlatGradBucket:
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._has_grad = set()            # indices of the parameters whose flat slice holds a gradient of an earlier step
         self.zero()
 
     def zero(self):
@@ -66,13 +67,21 @@ class FlatGradBucket:
     def collect(self, check=False):
         """Call after the backward pass: pack the fresh gradients into the flat buffer.  Parameters that
         received no gradient (conv biases in front of a training-mode BatchNorm) keep a zero slice and
-        `.grad = None`, which the optimizer skips — identical to a zero update.
+        `.grad = None`, which the optimizer skips — identical to a zero update.  A parameter that HAD a gradient in
+        an earlier step and has none now (a loss multiplier switched off, an unused head) gets its slice cleared,
+        so neither the flat optimizer nor the all-reduce ever sees a stale gradient.
         check=True (GPU): the packing copy also scans what it copies for NaN / inf (cpfn_multi_copy_checked) and the
         per-workgroup flags are returned as (flags int32 tensor, count) for FlatAdam.step(nf_flags=...); None when
         nothing had to be copied or the scan could not ride along."""
         src, dst, who = [], [], []
-        for p, v in zip(self.params, self.views):
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if p.grad is None:
+                if i in self._has_grad:
+                    v.zero_()
+                    self._has_grad.discard(i)
+                continue
+            self._has_grad.add(i)
+            if p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
                 who.append(p)
@@ -127,7 +136,8 @@ class SPFNTrainer:
     """Holds the optimizer state and the schedule bookkeeping of the reference's epoch loop."""
 
     def __init__(self, module, batch_size=16, init_learning_rate=1e-3, decay_step=200000, decay_rate=0.7,
-                 bn_decay_step=200000, multipliers=None, classes=None, fused_adam=None, use_graphs=False):
+                 bn_decay_step=200000, multipliers=None, classes=None, fused_adam=None, use_graphs=False,
+                 require_graphs=False):
         self.module = module
         self.batch_size = batch_size
         self.init_learning_rate, self.decay_step, self.decay_rate = init_learning_rate, decay_step, decay_rate
@@ -139,6 +149,7 @@ class SPFNTrainer:
         self.bucket = FlatGradBucket(module)
         on_gpu = self.bucket.flat.is_cuda
         self.use_graphs = bool(use_graphs) and on_gpu
+        self.require_graphs = bool(require_graphs)    # a failed capture raises instead of degrading to eager launches
         # GPU: Adam as one kernel over flat buffers (optim.FlatAdam; lr / step count / skip flag on the device, so
         # the LR staircase needs no re-capture).  `fused_adam=False` keeps torch.optim.Adam (also used on CPU).
         if on_gpu and fused_adam is not False:
@@ -152,13 +163,28 @@ class SPFNTrainer:
         self._graph, self._graph_warm = None, 0
         self._gstream, self._in_gstream, self._gside = None, False, None
         self.global_step = 0
+        # Like the reference (training_utils.py:100, 111-114) the momentum is only WRITTEN when the staircase value
+        # changes: until the first change (step 12500 at batch 16) the BatchNorm layers keep their constructor
+        # momentum (nn default 0.1), although the schedule's value is 0.5.
         self._bn_momentum = get_batch_norm_decay(0, batch_size, bn_decay_step)
         self._lr = get_learning_rate(init_learning_rate, 0, batch_size, decay_step, decay_rate)
-        update_momentum(module, self._bn_momentum)
-        self.skipped_steps = 0
+        self._host_skipped = 0            # steps skipped on the host path (one sync per step, like the reference)
+        self._skipped_dev = None          # device-side counter of the capturable / graph paths (survives re-captures)
         self.fused_losses = True      # HIP loss kernels when the model exposes its packed fp32 heads
         module.return_point_features = False    # the step consumes the heads only (no [B,128,N] fp32 conversion)
         self._side, self._prefetched = None, None
+
+    @property
+    def skipped_steps(self):
+        """Steps whose optimizer update was skipped because a gradient was NaN / inf (training_utils.py:151-158).
+        Reading it synchronises with the device when the capturable / graph path keeps the count there."""
+        dev = 0 if self._skipped_dev is None else int(round(float(self._skipped_dev)))
+        return self._host_skipped + dev
+
+    def _skip_counter(self, device):
+        if self._skipped_dev is None:
+            self._skipped_dev = torch.zeros((), dtype=torch.float32, device=device)
+        return self._skipped_dev
 
     def _schedules(self):
         m = get_batch_norm_decay(self.global_step, self.batch_size, self.bn_decay_step)
@@ -177,6 +203,13 @@ class SPFNTrainer:
             self._lr = lr
 
     # ---- geometry prefetch: FPS / ball query / 3-NN depend on coordinates only -----------------
+    @staticmethod
+    def _batch_key(P):
+        """Identity of a batch's coordinates for the geometry hand-off: storage address AND the tensor's in-place
+        version counter, so a caller that refills an announced buffer in place gets fresh geometry (recomputed)
+        instead of the indices of the old contents.  `next_batch` must hold its final contents when announced."""
+        return (P.data_ptr(), P._version)
+
     def prefetch(self, batch, fps_start=None):
         """Compute the next batch's index tensors on a side stream (overlaps with whatever the
         main stream is doing, typically the current step's backward pass: FPS alone is 0.7 ms of
@@ -192,11 +225,11 @@ class SPFNTrainer:
             geom = self.module.compute_geometry(P, fps_start)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._prefetched = (P.data_ptr(), geom, ev)
+        self._prefetched = (self._batch_key(P), geom, ev)
 
     def _take_prefetched(self, P):
         pf, self._prefetched = self._prefetched, None
-        if pf is None or pf[0] != P.data_ptr():
+        if pf is None or pf[0] != self._batch_key(P):
             return None
         _, geom, ev = pf
         main = torch.cuda.current_stream(P.device)
@@ -344,7 +377,7 @@ class SPFNTrainer:
               "start_host": [torch.zeros(2, B, dtype=torch.int32).pin_memory() for _ in range(2)],
               "start_done": [torch.cuda.Event(), torch.cuda.Event()], "start_turn": 0,
               "match": torch.zeros(B, K, dtype=torch.long, device=dev),
-              "skipped": torch.zeros((), dtype=torch.float32, device=dev)}
+              "skipped": self._skip_counter(dev)}
         st["start1"], st["start2"] = st["start_dev"][0], st["start_dev"][1]
         st["unit"] = torch.ones((), dtype=torch.float32, device=dev)      # d total / d total, allocated outside the graph
         sb = st["batch"]
@@ -481,8 +514,8 @@ class SPFNTrainer:
             geom = self._take_prefetched(batch["P"])
             if geom is not None:
                 self._copy_all(st["geomB"], self._flatten_geom(geom))
-                st["geom_ready_for"] = batch["P"].data_ptr()
-        if st["geom_ready_for"] != batch["P"].data_ptr():      # not announced one step ahead: do it now
+                st["geom_ready_for"] = self._batch_key(batch["P"])
+        if st["geom_ready_for"] != self._batch_key(batch["P"]):      # not announced one step ahead: do it now
             self._draw_starts(st, B, N)
             st["g0"].replay()
         # inputs of the geometry branch: the NEXT batch's FPS seeds (its coordinates were copied above)
@@ -492,7 +525,7 @@ class SPFNTrainer:
         if st["single"]:
             if announce:
                 self._draw_starts(st, B, N)
-            st["geom_ready_for"] = next_batch["P"].data_ptr() if announce else None
+            st["geom_ready_for"] = self._batch_key(next_batch["P"]) if announce else None
             st["g"].replay()                                   # the whole step: no host synchronisation
             if st["world"] > 1:
                 self.bucket.all_reduce_mean()
@@ -504,7 +537,7 @@ class SPFNTrainer:
         st["g1b"].replay()                                     # fits: GPU work for the time of the host round trip
         if announce:
             self._draw_starts(st, B, N)
-        st["geom_ready_for"] = next_batch["P"].data_ptr() if announce else None
+        st["geom_ready_for"] = self._batch_key(next_batch["P"]) if announce else None
         st["cost_ready"].synchronize()                         # the step's one host sync (waits for G1, not G1b)
         fl.hungarian_host(st["cost_host"], st["match"].shape[1], out=st["match_host"])
         st["match"].copy_(st["match_host"], non_blocking=True)
@@ -539,6 +572,8 @@ class SPFNTrainer:
                 try:
                     self._graph = self._capture(batch)
                 except Exception as e:          # capture is an optimisation: fall back to eager launches
+                    if self.require_graphs:     # ... unless the caller asked for the replayed step (bench.py does)
+                        raise
                     import warnings
                     warnings.warn("hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e))
                     self.use_graphs = False
@@ -553,12 +588,11 @@ class SPFNTrainer:
         out[0].backward()
         self.bucket.collect()
         self.bucket.all_reduce_mean()
-        if self.use_graphs:                            # capturable optimizer: skip decided on the device
-            self.optimizer.found_inf = self.bucket.nonfinite_flag()
-            self.optimizer.step()
+        if self.use_graphs:                            # capturable optimizer: skip decided (and counted) on the device
+            self._checked_optimizer_step(self._skip_counter(self.bucket.flat.device))
         elif bool(self.bucket.finite()):               # single host sync (reference: 148)
             self.optimizer.step()
         else:
-            self.skipped_steps += 1
+            self._host_skipped += 1
         self.global_step += 1
         return tuple(o.detach() for o in out)     # do not keep the autograd graph alive across steps

@@ -75,6 +75,20 @@ CPFN_API int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int 
 CPFN_API int cpfn_three_nn(const float *unknown, const float *known, int B, int N, int M,
                   float *dist2, int *idx, void *stream);
 
+/* CUDA-route twins (the reference's `fast=True` results; opt-in, see DESIGN.md "CUDA route").
+ * cpfn_ball_query_direct: ball_query_gpu.cu:9-44 — d2 = (q-p)^2 summed over x,y,z, kept iff
+ * d2 < radius*radius (fp32), first K in index order, padded with the first; an empty ball
+ * leaves index 0 (the reference's zero-initialised output, ball_query.cpp).
+ * cpfn_three_nn_direct: interpolate_gpu.cu:9-59 — the same direct distance, strict '<'
+ * insertion from index 0; sqrt_out != 0 returns the square roots, which is what the
+ * reference's Python wrapper hands on (modules/geometry_utils.py:184).
+ * nvcc's default fma contraction of the three-term sum is assumed; not pinned bit for bit
+ * (no CUDA build of the reference can run next to this library). */
+CPFN_API int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, int B, int N, int S,
+                                    float radius, int K, int *idx_out, void *stream);
+CPFN_API int cpfn_three_nn_direct(const float *unknown, const float *known, int B, int N, int M,
+                                  int sqrt_out, float *dist, int *idx, void *stream);
+
 /* pairwise_squared_distance (modules/geometry_utils.py:4-23), materialised:
  * src[B,N,3], dst[B,M,3] -> out[B,N,M].  API parity only; N, B <= 65535. */
 CPFN_API int cpfn_pairwise_sqdist(const float *src, const float *dst, int B, int N, int M,
@@ -330,7 +344,9 @@ CPFN_API int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long
                                float *workspace, float *dW, void *stream);
 
 /* ------------------------------------------------------------------ loss-side fusions
- * (the callers on the far side of the fitters.)  K <= 32. */
+ * (the callers on the far side of the fitters.)  K <= 32 for the training-side
+ * kernels (head_post, seg_stats_bwd, hungarian_match); cpfn_seg_stats_fwd and cpfn_p_coverage, which the evaluation
+ * metrics also run on merged label sets (evaluation_localSPFN.py:129-131), take any K. */
 
 /* Heads post-processing: Y[B,N,7+K] fp32 (3 normal, 4 type logits, K membership logits) ->
  * Xn[B,N,3] = normalize (Utils/training_utils.py:141), Wsm[B,N,K] = softmax (:142),
@@ -352,7 +368,8 @@ CPFN_API int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t 
                                 const float *gloss, int gloss_planar, int B, int N, int K, float *gY, void *stream);
 /* Label-segmented membership sums, shared by the Hungarian cost matrix and the relaxed-IoU loss
  * (SPFN/losses_implementation.py:19-24, 77-90):  S[B,K+2,K]: rows l<K = sum of W rows with label l,
- * row K = column sums of W, row K+1 = number of points per label.
+ * row K = column sums of W, row K+1 = number of points per label.  fwd: any K <= 1024 (K > 32: one 32 x 32 tile
+ * of S per workgroup); bwd: K <= 32.
  * workspace: B * cpfn_seg_stats_chunks(B,N) * (K+2)*K floats. */
 CPFN_API int cpfn_seg_stats_chunks(int B, int N);
 CPFN_API int cpfn_seg_stats_fwd(const float *W, const int64_t *Igt, int B, int N, int K, float *workspace,
@@ -384,7 +401,7 @@ CPFN_API int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, in
  * points of cloud b whose smallest residue over the K instance slots is below eps[i]; slot k uses the
  * parameters of prediction match[b,k] (params22 in the cpfn_fit_pack_fwd layout) evaluated as primitive
  * type slot_type[b,k]; residue = sqrt(|r| + 1e-10) of the fitters' compute_residue_single.
- * type_ids (HOST, 4 ints) = ids of plane, sphere, cylinder, cone; eps (HOST) n_eps <= 4 thresholds; K <= 64.
+ * type_ids (HOST, 4 ints) = ids of plane, sphere, cylinder, cone; eps (HOST) n_eps <= 4 thresholds; any K.
  * workspace: B * ceil(N/256) * n_eps floats. */
 CPFN_API int cpfn_p_coverage(const float *P, const float *params22, const int64_t *match,
                              const int64_t *slot_type, int B, int N, int K, const int *type_ids,

@@ -267,3 +267,100 @@ int orc_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------
+ * CUDA-ROUTE restatements (the reference's `fast=True` compiled ops).  PARITY UNPINNED: the
+ * reference's CUDA extension cannot be built or run in this image, so nothing below has been
+ * checked against it.  They restate the published kernels scalar-wise and serve as the checker
+ * of the product's opt-in CUDA-route mode (tests/test_gpu_cuda_route.py).  nvcc contracts
+ * a*a + b*b + c*c to an fma chain by default (-fmad=true); that rounding is assumed here. */
+static inline float direct_sqdist(float qx, float qy, float qz, float x, float y, float z) {
+  float dx = qx - x, dy = qy - y, dz = qz - z;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+/* ball_query_gpu.cu:9-44: d2 < radius*radius (fp32), first K in index order, the first hit
+ * fills every slot; an empty ball leaves the zero-initialised output (ball_query.cpp). */
+void orc_ball_query_direct(const float *xyz, const float *new_xyz, int B, int N, int S,
+                           float radius, int K, int64_t *idx) {
+  const float r2 = radius * radius;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b) {
+    for (int s = 0; s < S; ++s) {
+      const float *p = xyz + (size_t)b * N * 3;
+      const float *q = new_xyz + ((size_t)b * S + s) * 3;
+      int64_t *o = idx + ((size_t)b * S + s) * K;
+      for (int k = 0; k < K; ++k) o[k] = 0;
+      int cnt = 0;
+      for (int n = 0; n < N && cnt < K; ++n) {
+        float d2 = direct_sqdist(q[0], q[1], q[2], p[3 * n], p[3 * n + 1], p[3 * n + 2]);
+        if (d2 < r2) {
+          if (cnt == 0)
+            for (int l = 0; l < K; ++l) o[l] = n;
+          o[cnt++] = n;
+        }
+      }
+    }
+  }
+}
+
+/* interpolate_gpu.cu:9-59 + modules/geometry_utils.py:184: direct distance, strict '<'
+ * three-deep insertion starting from (1e40, index 0); sqrt_out != 0 -> sqrt of the result. */
+void orc_three_nn_direct(const float *unknown, const float *known, int B, int N, int M,
+                         int sqrt_out, float *dist, int64_t *idx) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b) {
+    for (int j = 0; j < N; ++j) {
+      const float *u = unknown + ((size_t)b * N + j) * 3;
+      const float *kn = known + (size_t)b * M * 3;
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int64_t i1 = 0, i2 = 0, i3 = 0;
+      for (int k = 0; k < M; ++k) {
+        float d = direct_sqdist(u[0], u[1], u[2], kn[3 * k], kn[3 * k + 1], kn[3 * k + 2]);
+        if (d < best1) {
+          best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = k;
+        } else if (d < best2) {
+          best3 = best2; i3 = i2; best2 = d; i2 = k;
+        } else if (d < best3) {
+          best3 = d; i3 = k;
+        }
+      }
+      float *od = dist + ((size_t)b * N + j) * 3;
+      int64_t *oi = idx + ((size_t)b * N + j) * 3;
+      float f1 = (float)best1, f2 = (float)best2, f3 = (float)best3;
+      if (sqrt_out) { f1 = sqrtf(f1); f2 = sqrtf(f2); f3 = sqrtf(f3); }
+      od[0] = f1; od[1] = f2; od[2] = f3;
+      oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    }
+  }
+}
+
+/* sampling_gpu.cu:63-159: start at index 0; points with |p|^2 <= 1e-3 never take part; the
+ * running minimum and the arg-max as in the CPU route (ties: lowest index here — the CUDA
+ * kernel's tie order depends on its block size and is not reproduced). */
+void orc_fps_cuda(const float *xyz, int B, int N, int S, int64_t *idx_out) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b) {
+    const float *p = xyz + (size_t)b * N * 3;
+    float *mind = (float *)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    for (int k = 0; k < N; ++k) mind[k] = sqnorm3(p[3 * k], p[3 * k + 1], p[3 * k + 2]) <= 1e-3f ? -1.0f : 1e10f;
+    int64_t far = 0;
+    for (int i = 0; i < S; ++i) {
+      idx_out[(size_t)b * S + i] = far;
+      float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
+      float best = -1.0f;
+      int64_t besti = 0;
+      for (int k = 0; k < N; ++k) {
+        if (mind[k] < 0.0f) continue;
+        float dx = p[3 * k] - fx, dy = p[3 * k + 1] - fy, dz = p[3 * k + 2] - fz;
+        float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+        float d = xx + yy;
+        d = d + zz;
+        if (d < mind[k]) mind[k] = d;
+        if (mind[k] > best) { best = mind[k]; besti = k; }
+      }
+      far = besti;
+    }
+    free(mind);
+  }
+}

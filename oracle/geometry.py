@@ -155,3 +155,36 @@ def group_points_grad(grad_out, idx, N):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+# ---------------------------------------------------------------- CUDA route (PARITY UNPINNED)
+# Restatements of the reference's compiled `fast=True` kernels; they cannot be checked against
+# a CUDA build here (see the header of that section in cpfn_oracle.c).
+def ball_query_cuda(radius, num_samples, xyz, new_xyz):
+    """cuda_ops/src/ball_query_gpu.cu:9-44.  xyz [B,N,3], new_xyz [B,S,3] -> [B,S,K] int64."""
+    xyz, new_xyz = _f(xyz), _f(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    out = np.empty((B, S, num_samples), np.int64)
+    lib().orc_ball_query_direct(_pf(xyz), _pf(new_xyz), B, N, S, ctypes.c_float(radius), int(num_samples), _pi(out))
+    return out
+
+
+def three_nn_cuda(unknown, known, sqrt=True):
+    """cuda_ops/src/interpolate_gpu.cu:9-59 (+ the sqrt of modules/geometry_utils.py:184)."""
+    unknown, known = _f(unknown), _f(known)
+    B, N, _ = unknown.shape
+    M = known.shape[1]
+    d = np.empty((B, N, 3), np.float32)
+    i = np.empty((B, N, 3), np.int64)
+    lib().orc_three_nn_direct(_pf(unknown), _pf(known), B, N, M, 1 if sqrt else 0, _pf(d), _pi(i))
+    return d, i
+
+
+def farthest_point_sample_cuda(xyz, num_point):
+    """cuda_ops/src/sampling_gpu.cu:63-159: start 0, near-origin points skipped."""
+    xyz = _f(xyz)
+    B, N, _ = xyz.shape
+    out = np.empty((B, num_point), np.int64)
+    lib().orc_fps_cuda(_pf(xyz), B, N, int(num_point), _pi(out))
+    return out

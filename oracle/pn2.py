@@ -131,14 +131,22 @@ def pointnet2_forward(state, x, fps_starts, training=True, dropout_mask=None):
 
 
 def training_step_losses(state, batch, fps_starts, classes=("sphere", "plane", "cylinder", "cone"),
-                         dropout_mask=None, match=None):
+                         dropout_mask=None, match=None, multipliers=None, return_aux=False):
     """Forward + all losses of spfn_train_val_epoch (Utils/training_utils.py:140-146).
-    `batch` carries the tensors of cpfn_amd.synthetic.training_batch()."""
-    heads, _, _, _ = pointnet2_forward(state, batch["P"], fps_starts, True, dropout_mask)
+    `batch` carries the tensors of cpfn_amd.synthetic.training_batch().  `multipliers`: the six loss multipliers
+    of the config (default all 1.0 = GlobalSPFN; LocalSPFN switches residue / parameter off,
+    Configs/config_localSPFN.yml:10-11).  return_aux: also the index tensors of the forward pass and the heads."""
+    heads, _, _, aux = pointnet2_forward(state, batch["P"], fps_starts, True, dropout_mask)
     X, T, W = heads
     X = F.normalize(X, p=2, dim=2, eps=1e-12)                                          # :141
     W = torch.softmax(W, dim=2)                                                         # :142
     gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"],
           "cone_axis": batch["cone_axis_gt"]}
-    return ospfn.compute_all_losses(batch["P"], W, batch["I_gt"], X, batch["X_gt"], T, batch["T_gt"],
-                                    gt, batch["points_per_instance"], classes=classes, match=match)
+    out = ospfn.compute_all_losses(batch["P"], W, batch["I_gt"], X, batch["X_gt"], T, batch["T_gt"],
+                                   gt, batch["points_per_instance"], classes=classes, match=match,
+                                   multipliers=multipliers)
+    if return_aux:
+        aux = dict(aux)
+        aux["heads"] = (X, T, W)
+        return out, aux
+    return out

@@ -11,6 +11,29 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
+def per_instance_rel(a, b, floor=1e-3):
+    """Per-instance relative error ‖a_bk − b_bk‖ / max(‖b_bk‖, floor) -> [B,K] (vector parameters: Euclidean norm
+    over the last axis; scalar parameters [B,K]: absolute value).  Unlike `rel_err`, one large-magnitude instance
+    cannot hide a wrong small one.  `floor` keeps instances whose true value is ~0 (a plane through the origin) from
+    dividing by nothing: below it the error is measured in absolute units of `floor`."""
+    a, b = a.double(), b.double()
+    if a.dim() == 2:
+        a, b = a.unsqueeze(-1), b.unsqueeze(-1)
+    return (a - b).norm(dim=-1) / b.norm(dim=-1).clamp_min(floor)
+
+
+def plane_eigen_gap(P, W):
+    """(λ1 − λ0) / λ2 of every instance's weighted covariance (fp64, CPU): how well the TLS normal is determined.
+    Printed next to a failing instance: the reference's own fp32 result moves by ~1e-7 / gap."""
+    P, W = P.double().cpu(), W.double().cpu()
+    Ws = W.sum(1).clamp_min(1e-10)                                     # [B,K]
+    mu = torch.einsum("bnk,bnc->bkc", W, P) / Ws.unsqueeze(-1)
+    d = P.unsqueeze(1) - mu.unsqueeze(2)                               # [B,K,N,3]
+    C = torch.einsum("bnk,bknc,bknd->bkcd", W, d, d)
+    ev = torch.linalg.eigvalsh(C)
+    return (ev[..., 1] - ev[..., 0]) / ev[..., 2].clamp_min(1e-300)
+
+
 def align_signs(mine, ref):
     """Plane normal / cylinder axis come out of an SVD and are defined up to a sign per
     instance (the plane offset flips with its normal).  Flip `mine` onto `ref`."""

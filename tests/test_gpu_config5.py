@@ -1,0 +1,139 @@
+"""GPU: BASELINE.json configs[4] at its real size on one GPU ("replicas only": clouds and patches are independent,
+SURVEY §8e) — the cascaded evaluation of evaluation_globalSPFN.py:62-64 (GlobalSPFN on the FULL-resolution cloud,
+batch 1, eval mode) followed by evaluation_localSPFN.py:95-110 (32 patches x 8192 points through LocalSPFN, then
+similarity_soft / get_point_final on its memberships), every stage against the oracle:
+
+  * 131072-point forward: FPS (streaming kernel), ball query and 3-NN indices / weights BIT-EXACT vs oracle/geometry;
+    bf16 heads vs the fp32 compute mode of the same network;
+  * 32 x 8192 LocalSPFN eval forward (K = 21): geometry bit-exact vs the oracle, bf16 vs fp32 heads;
+  * similarity_soft on those memberships vs the float64 oracle (sparse form of the same matrix), get_point_final vs
+    the oracle; the evaluation metrics on the merged (K = 49) membership matrix vs oracle/metrics.
+
+The greedy label solver between similarity_soft and get_point_final is numba host code in the reference and out of
+scope; a deterministic stand-in labelling keeps the data flowing."""
+import numpy as np
+import pytest
+import torch
+
+from cpfn_amd import synthetic
+from oracle import geometry as og
+from oracle import merging as omg
+from oracle import metrics as om
+
+pytestmark = pytest.mark.gpu
+N_HI, NB, NPP, K_GLOBAL, K_LOCAL = 131072, 32, 8192, 28, 21
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _net(K, seed):
+    from cpfn_amd.PointNet2 import pn2_network
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, K])
+    m.load_state_dict(synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(output_sizes=(3, 4, K)), seed=seed),
+                      strict=True)
+    m.dropout_p = 0.0                 # (the reference's dropout stays on in eval mode; neutralised to compare modes)
+    return m.to(dev()).eval()
+
+
+def _geometry_vs_oracle(m, xyz, starts):
+    f1 = og.farthest_point_sample(xyz, 512, starts[0].numpy())
+    assert np.array_equal(m.aux_sa1["fps_idx"].cpu().numpy(), f1.astype(np.int32)), "sa1 FPS"
+    l1 = np.take_along_axis(xyz, f1[:, :, None], axis=1)
+    assert np.array_equal(m.aux_sa1["ball_idx"].cpu().numpy(), og.ball_query(0.2, 64, xyz, l1).astype(np.int32)), "sa1 ball"
+    f2 = og.farthest_point_sample(l1, 128, starts[1].numpy())
+    assert np.array_equal(m.aux_sa2["fps_idx"].cpu().numpy(), f2.astype(np.int32)), "sa2 FPS"
+    d, i = og.three_nn(xyz, l1)
+    assert np.array_equal(m.aux_sfp3["nn_idx"].cpu().numpy(), i.astype(np.int32)), "sfp3 3-NN"
+    assert np.array_equal(m.aux_sfp3["nn_w"].cpu().numpy().view(np.uint32), og.three_weights(d).view(np.uint32))
+
+
+def _both_modes(m, P, starts):
+    with torch.no_grad():
+        m.set_compute_dtype(torch.float32)
+        ref = [t.clone() for t in m(P, fps_start=starts)[:3]]
+        m.set_compute_dtype(torch.bfloat16)
+        out = m(P, fps_start=starts)
+    for name, a, b in zip("XTW", out[:3], ref):
+        e = float((a - b).norm() / b.norm())
+        print("bf16 vs fp32 head %s: rel L2 %.2e" % (name, e))
+        assert torch.isfinite(a).all() and e < 5e-2, (name, e)
+    return out
+
+
+def test_cascaded_eval_131072_points():
+    from cpfn_amd.SPFN import metric_implementation as mi
+    from cpfn_amd.Utils import merging_utils as mu
+    cloud = synthetic.primitive_cloud(1, N_HI, n_prims=12, noise=0.002, seed=9)
+    P = cloud["P"].to(dev())
+    # ---------------- stage 1: GlobalSPFN on the full-resolution cloud, batch 1 (evaluation_globalSPFN.py:62-64)
+    g_net = _net(K_GLOBAL, seed=0)
+    starts = (torch.tensor([12345]), torch.tensor([77]))
+    out = _both_modes(g_net, P, starts)
+    _geometry_vs_oracle(g_net, cloud["P"].numpy(), starts)
+    assert out[3].shape == (1, 1024, 1) and out[4].shape == (1, 128, N_HI)
+    Xg = torch.nn.functional.normalize(out[0], p=2, dim=2, eps=1e-12)
+    Wg = torch.softmax(out[2], dim=2)                                              # [1,N,28]
+    spfn_labels = torch.nn.functional.one_hot(Wg[0].argmax(1), K_GLOBAL)           # [N,28] long, as the data loader stores it
+    # ---------------- stage 2: 32 patches x 8192 points (nearest neighbours of 32 FPS centres), LocalSPFN eval
+    centres = P[0, g_net.aux_sa1["fps_idx"][0, :NB].long()]                       # [32,3]
+    d2 = ((P[0].unsqueeze(0) - centres.unsqueeze(1)) ** 2).sum(-1)                # [32,N]
+    patch_indices = d2.topk(NPP, dim=1, largest=False)[1]                         # [32,8192] (a set per patch)
+    patches = P[0][patch_indices]                                                 # [32,8192,3]
+    patches = patches - patches.mean(1, keepdim=True)
+    patches = (patches / patches.norm(dim=2).max(dim=1)[0].view(NB, 1, 1)).contiguous()
+    l_net = _net(K_LOCAL, seed=3)
+    g = torch.Generator().manual_seed(4)
+    lstarts = (torch.randint(0, NPP, (NB,), generator=g), torch.randint(0, 512, (NB,), generator=g))
+    lout = _both_modes(l_net, patches, lstarts)
+    _geometry_vs_oracle(l_net, patches.cpu().numpy(), lstarts)
+    Wl = torch.softmax(lout[2], dim=2)                                             # [32,8192,21]
+    # ---------------- stage 3: merging (evaluation_localSPFN.py:101-110)
+    sim = mu.similarity_soft(spfn_labels, Wl, patch_indices)
+    C = NB * K_LOCAL + K_GLOBAL
+    assert sim.shape == (C, C)
+    want = omg.similarity_soft_sparse(spfn_labels.cpu().numpy(), Wl.cpu().numpy(), patch_indices.cpu().numpy())
+    scale = np.abs(want).max()
+    err = np.abs(sim.cpu().numpy() - want).max() / scale
+    print("similarity_soft vs float64 oracle: max err / max %.2e" % err)
+    assert err < 2e-5
+    # stand-in for the host solver: every local column joins the global label it overlaps most, global columns keep theirs
+    labels = torch.cat([sim[:NB * K_LOCAL, NB * K_LOCAL:].argmax(1), torch.arange(K_GLOBAL, device=dev())])
+    M = torch.zeros(N_HI, C, device=dev())
+    for b in range(NB):
+        M[patch_indices[b], b * K_LOCAL:(b + 1) * K_LOCAL] = Wl[b]
+    M[:, NB * K_LOCAL:] = spfn_labels.float()
+    flag = M[:, :NB * K_LOCAL].sum(1) > 0
+    M[flag, NB * K_LOCAL:] = 0                                                    # evaluation_localSPFN.py:107-109
+    W_fusion = mu.get_point_final(M, labels)
+    wf = omg.get_point_final(M.cpu().numpy(), labels.cpu().numpy())
+    np.testing.assert_allclose(W_fusion.cpu().numpy(), wf, rtol=1e-5, atol=1e-6)
+    # ---------------- stage 4: metrics on a merged label set wider than 32 columns (local + global = 49)
+    Kf = K_LOCAL + K_GLOBAL
+    Wf = torch.zeros(1, N_HI, Kf, device=dev())
+    Wf[0, :, :K_GLOBAL] = W_fusion
+    Wf[0, :, K_GLOBAL:] = 1e-3 * torch.rand(N_HI, K_LOCAL, device=dev())
+    I_gt = cloud["I_gt"].to(dev())
+    T_gt = torch.zeros(1, Kf, dtype=torch.long, device=dev())
+    T_gt[:, :12] = cloud["T_gt"].to(dev())
+    ppi = torch.zeros(1, Kf, 512, 3, device=dev())
+    for k in range(12):
+        idx = (I_gt[0] == k).nonzero().squeeze(1)[:512]
+        ppi[0, k, :idx.numel()] = P[0, idx]
+        ppi[0, k, idx.numel():] = P[0, idx[0]]
+    gen = torch.Generator().manual_seed(8)
+    gt = {k: torch.nn.functional.normalize(torch.randn(1, Kf, 3, generator=gen), dim=2).to(dev())
+          for k in ("plane_normal", "cylinder_axis", "cone_axis")}
+    T = out[1]
+    CLASSES = ["sphere", "plane", "cylinder", "cone"]
+    res = mi.compute_all_metrics(P, Xg, cloud["X_gt"].to(dev()), Wf, I_gt, T, T_gt, ppi, gt, list_epsilon=[0.01, 0.02],
+                                 classes=CLASSES)
+    c = lambda t: t.detach().float().cpu()
+    ref = om.compute_all_metrics(c(P), c(Xg), cloud["X_gt"], c(Wf), cloud["I_gt"], c(T), c(T_gt), c(ppi),
+                                 {k: c(v) for k, v in gt.items()}, list_epsilon=[0.01, 0.02], classes=CLASSES)
+    assert np.array_equal(res[10].cpu().numpy(), ref["T_instance"].numpy())
+    for name, a, b in (("mIoU", res[0], ref["mIoU"]), ("type", res[1], ref["type_accuracy"]), ("normal", res[2], ref["normal_difference"]),
+                       ("mean_res", res[4], ref["mean_residual"])):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=2e-3, atol=1e-5, err_msg=name)
+    np.testing.assert_allclose(torch.stack(res[7]).cpu().numpy(), ref["P_coverage"].numpy(), atol=20.0 / N_HI)

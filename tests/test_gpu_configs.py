@@ -41,6 +41,65 @@ def test_local_spfn_training_step():
     assert np.isfinite(float(out[0])) and float(out[0]) < first
 
 
+LOCAL_MULT = dict(miou=1.0, normal=1.0, type=1.0, parameter=0.0, residue=0.0, total=1.0)     # config_localSPFN.yml:6-11
+
+
+def test_local_spfn_step_matches_reference(golden):
+    """BASELINE.json configs[2] against the imported reference's LocalSPFN step (step_local_2x1024.npz: K = 21,
+    fitter losses off): fp32 compute mode with the op-by-op losses AND with the fused loss kernels — six losses, the
+    matching, per-parameter gradient norms; then the bf16 product mode within its stated tolerance."""
+    from cpfn_amd.PointNet2 import pn2_network
+    from cpfn_amd.SPFN import fused_losses, losses_implementation as li
+    g = golden("step_local_2x1024.npz")
+    batch = {k: v.to(dev()) for k, v in
+             synthetic.training_batch(2, N=1024, n_max_instances=21, n_prims=6, n_inst_points=64, seed=71).items()}
+    starts = (torch.from_numpy(g["fps_start1"]), torch.from_numpy(g["fps_start2"]))
+    names = [str(n) for n in g["names"]]
+    classes = ["sphere", "plane", "cylinder", "cone"]
+
+    def model():
+        m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 21])
+        m.load_state_dict(synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(output_sizes=(3, 4, 21)), seed=3),
+                          strict=True)
+        m.dropout_p = 0.0
+        return m.to(dev()).train()
+
+    def grad_norms(m):
+        params = dict(m.named_parameters())
+        return np.array([float(params[n].grad.norm()) for n in names])
+
+    scale = g["grad_norm"].max()
+    for fused in (False, True):
+        m = model()
+        X, T, W, _, _ = m(batch["P"], fps_start=starts)
+        if fused:
+            out = fused_losses.fused_losses(batch["P"], torch.cat([X, T, W], 2), batch, LOCAL_MULT, classes)
+        else:
+            gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"], "cone_axis": batch["cone_axis_gt"]}
+            Wn = torch.softmax(W, dim=2)
+            assert np.array_equal(li.hungarian_matching(Wn, batch["I_gt"]).cpu().numpy(), g["match"].astype(np.int64))
+            out = li.compute_all_losses(batch["P"], Wn, batch["I_gt"], torch.nn.functional.normalize(X, p=2, dim=2, eps=1e-12),
+                                        batch["X_gt"], T, batch["T_gt"], gt, batch["points_per_instance"], 1.0, 1.0, 1.0, 0.0,
+                                        0.0, 1.0, False, mode_seg="mIoU", classes=classes)
+        np.testing.assert_allclose([float(v) for v in out[:6]], g["losses"], rtol=2e-3, atol=1e-4)
+        assert float(out[4]) == 0.0 and float(out[5]) == 0.0
+        out[0].backward()
+        gn = grad_norms(m)
+        bad = np.abs(gn - g["grad_norm"]) > 2e-2 * g["grad_norm"] + 1e-4 * scale
+        assert not bad.any(), (fused, [(names[i], gn[i], g["grad_norm"][i]) for i in np.nonzero(bad)[0]])
+    # product mode: bf16 MLP stacks + fused losses.  Stated tolerance: losses 3 %, the flat gradient 10 % in L2
+    # (bf16 activations flip ~0.3 % of the ReLU masks / arg-maxes: DESIGN.md "Numerics").
+    m = model().set_compute_dtype(torch.bfloat16)
+    m(batch["P"], fps_start=starts)
+    out = fused_losses.fused_losses(batch["P"], m.heads_packed, batch, LOCAL_MULT, classes)
+    np.testing.assert_allclose([float(v) for v in out[:4]], g["losses"][:4], rtol=3e-2, atol=1e-3)
+    out[0].backward()
+    gn = grad_norms(m)
+    rel = np.linalg.norm(gn - g["grad_norm"]) / np.linalg.norm(g["grad_norm"])
+    print("bf16 LocalSPFN step: losses", [float(v) for v in out[:4]], "grad-norm vector rel err %.3f" % rel)
+    assert rel < 0.1, rel
+
+
 def test_eval_forward_large_cloud_streaming_fps():
     from cpfn_amd.PointNet2 import pn2_network
     torch.manual_seed(1)

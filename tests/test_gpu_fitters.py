@@ -1,12 +1,14 @@
 """GPU parity of the fused SPFN fitters (HIP moment kernels + per-instance algebra) against
 the golden fixtures of the imported reference and against the oracle.
-Tolerance: 1e-4 relative (max|a-b| / max|b| per tensor), sign-invariant where the
-reference's SVD leaves the sign free — BASELINE.json north_star."""
+Tolerance: 1e-4 relative PER INSTANCE (‖a_bk − b_bk‖ / max(‖b_bk‖, 1e-3) for every [b,k] of every
+parameter, helpers.per_instance_rel) and per tensor (max|a-b| / max|b|), sign-invariant where the
+reference's SVD leaves the sign free — BASELINE.json north_star.  Gradients: per instance column
+for dL/dW, per cloud for dL/dX."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import PARAM_KEYS, align_signs, rel_err, sign_invariant_loss
+from helpers import PARAM_KEYS, align_signs, per_instance_rel, plane_eigen_gap, rel_err, sign_invariant_loss
 from oracle import spfn as ospfn
 
 pytestmark = pytest.mark.gpu
@@ -37,11 +39,23 @@ def _check_case(g):
     mine, (gW, gX) = _run_product(P, W, X, coef)
     ref = {k: torch.from_numpy(g["out_" + k]) for k in PARAM_KEYS}
     aligned = align_signs(mine, ref)
+    worst = {}
     for k in PARAM_KEYS:
         assert mine[k].dtype == torch.float32
         assert rel_err(aligned[k], ref[k]) < TOL, (k, rel_err(aligned[k], ref[k]))
-    assert rel_err(gW, torch.from_numpy(g["gW"])) < TOL
-    assert rel_err(gX, torch.from_numpy(g["gX"])) < TOL
+        e = per_instance_rel(aligned[k], ref[k])                       # [B,K]: EVERY instance of the fixture
+        worst[k] = float(e.max())
+        if not bool((e < TOL).all()):
+            gap = plane_eigen_gap(P, W)
+            bad = [(int(b), int(i), float(e[b, i]), float(gap[b, i])) for b, i in (e >= TOL).nonzero()]
+            raise AssertionError("%s: instances (b, k, rel err, plane eigen-gap) over %g: %s" % (k, TOL, bad))
+    print("per-instance max rel err:", {k: "%.1e" % v for k, v in worst.items()})
+    rW, rX = torch.from_numpy(g["gW"]), torch.from_numpy(g["gX"])
+    assert rel_err(gW, rW) < TOL
+    assert rel_err(gX, rX) < TOL
+    eW = (gW.double() - rW.double()).norm(dim=1) / rW.double().norm(dim=1).clamp_min(1e-12)       # per (cloud, instance) column
+    eX = (gX.double() - rX.double()).norm(dim=(1, 2)) / rX.double().norm(dim=(1, 2))                # per cloud
+    assert float(eW.max()) < TOL and float(eX.max()) < TOL, (float(eW.max()), float(eX.max()))
 
 
 def test_golden_selftest_recipe(golden):
@@ -68,12 +82,25 @@ def test_full_size_vs_oracle():
     ref64 = ospfn.compute_parameters(P.double(), W.double(), X.double())
     aligned = align_signs(mine, ref)
     aligned64 = align_signs({k: v.double() for k, v in mine.items()}, ref64)
+    ref_noise = align_signs({k: v.double() for k, v in ref.items()}, ref64)
+    gap = None
     for k in PARAM_KEYS:
-        # the product accumulates in fp64, so it must sit at least as close to the fp64 arbiter
-        # as to the fp32 restatement; either way within the 1e-4 budget on real instances
-        e32, e64 = rel_err(aligned[k][:, :10], ref[k][:, :10]), rel_err(aligned64[k][:, :10], ref64[k][:, :10])
-        assert min(e32, e64) < TOL, (k, e32, e64)
         assert torch.isfinite(mine[k]).all(), k
+        # EVERY instance (all 28 columns, both clouds) against the fp32 restatement of the reference, per instance.
+        e32 = per_instance_rel(aligned[k], ref[k])
+        bad = (e32 >= TOL).nonzero()
+        # An instance may only miss the fp32 oracle if that is the reference's own fp32 rounding noise: the fp32 oracle
+        # itself is then further than TOL/4 from the fp64 evaluation of the same formulas on that instance, while the
+        # product (fp64 moment accumulation) sits within TOL of the fp64 evaluation.  Justified per instance, printed
+        # with the eigen-gap; anything else fails.
+        e64 = per_instance_rel(aligned64[k], ref64[k])
+        noise = per_instance_rel(ref_noise[k], ref64[k])
+        for b, i in bad:
+            gap = plane_eigen_gap(P, W) if gap is None else gap
+            info = (k, int(b), int(i), float(e32[b, i]), float(e64[b, i]), float(noise[b, i]), float(gap[b, i]))
+            assert float(e64[b, i]) < TOL and float(noise[b, i]) > TOL / 4, \
+                "(param, b, k, err vs fp32 oracle, err vs fp64 oracle, fp32-oracle noise, plane eigen-gap) = %s" % (info,)
+            print("instance accepted on fp32-reference noise:", info)
 
 
 def test_reference_shaped_helpers_vs_oracle():

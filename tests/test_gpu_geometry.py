@@ -244,3 +244,27 @@ def test_inverse_index_adjoints_vs_oracle():
     wantgg = og.group_points_grad(np.ascontiguousarray(gx.float().numpy().reshape(B, S, K, 128)[..., :C].transpose(0, 3, 1, 2)), idx, M).transpose(0, 2, 1)
     gotg = f2.grad.float().cpu().numpy()
     assert np.abs(gotg - wantgg).max() <= 1e-2 * np.abs(wantgg).max()
+
+
+def test_pairwise_squared_distance_matches_reference(golden):
+    """§8 a6: the MATERIALISED distance matrix (modules/geometry_utils.py:4-23) bit for bit against the imported
+    reference's own output (fixture `pdist`: 37 FPS centres x the first 257 points), through the C ABI and through
+    the drop-in `pairwise_squared_distance` ([B,3,N] channel-major arguments)."""
+    from cpfn_amd import cuda_ops, ops
+    from cpfn_amd.PointNet2.pointnet2_ops.modules import geometry_utils as gu
+    g = golden("geometry_ragged.npz")
+    xyz = T(g["xyz"])
+    ctr = ops.gather_rows(xyz, T(g["fps_idx"], torch.int32))                 # [3,37,3]
+    sub = xyz[:, :257].contiguous()
+    got = ops.pairwise_sqdist(ctr, sub)
+    assert got.shape == (3, 37, 257) and got.dtype == torch.float32
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), g["pdist"].view(np.uint32))
+    got2 = gu.pairwise_squared_distance(ctr.transpose(1, 2), sub.transpose(1, 2))
+    assert np.array_equal(got2.cpu().numpy().view(np.uint32), g["pdist"].view(np.uint32))
+    # and against the oracle on a full 8192 x 512 matrix of another cloud
+    g8 = golden("geometry_8192.npz")
+    x8 = T(g8["xyz"][:1])
+    l1 = ops.gather_rows(x8, T(g8["fps1_idx"][:1], torch.int32))
+    full = ops.pairwise_sqdist(l1, x8).cpu().numpy()
+    want = og.pairwise_squared_distance(l1.cpu().numpy(), g8["xyz"][:1])
+    assert np.array_equal(full.view(np.uint32), want.view(np.uint32))

@@ -61,6 +61,43 @@ def test_all_metrics_match_oracle_at_8192():
     _check(out, {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in ref.items() if k != "params"}, 256, N)
 
 
+@pytest.mark.parametrize("K,n_prims", [(49, 40), (70, 33)])
+def test_all_metrics_more_than_32_instances_vs_oracle(K, n_prims):
+    """Evaluation on a MERGED label set (evaluation_localSPFN.py:129-131 hands compute_all_metrics a W_fusion with
+    >= 28 columns and no upper bound; 21 local + 28 global = 49): more instance columns AND more GT labels than the
+    32-wide tile of the training-side kernels — tiled segmented sums, host assignment, untiled fits, K-looped P
+    coverage — against the oracle."""
+    from cpfn_amd.SPFN import metric_implementation as mi
+    B, N = 2, 8192
+    batch = synthetic.training_batch(B, N=N, n_max_instances=K, n_prims=n_prims, n_inst_points=128, seed=K)
+    g = torch.Generator().manual_seed(K)
+    lab = batch["I_gt"].clamp(min=0)
+    logits = torch.randn(B, N, K, generator=g)
+    logits.scatter_add_(2, lab.unsqueeze(2), torch.full((B, N, 1), 3.0))
+    W = torch.softmax(logits, dim=2)
+    X = torch.nn.functional.normalize(batch["X_gt"] + 0.3 * torch.randn(B, N, 3, generator=g), dim=2)
+    T = torch.randn(B, N, 4, generator=g)
+    T.scatter_add_(2, torch.gather(batch["T_gt"], 1, lab).unsqueeze(2), torch.full((B, N, 1), 0.7))
+    gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"], "cone_axis": batch["cone_axis_gt"]}
+    ref = om.compute_all_metrics(batch["P"], X, batch["X_gt"], W, batch["I_gt"], T, batch["T_gt"],
+                                 batch["points_per_instance"], gt, list_epsilon=[0.01, 0.03], classes=CLASSES)
+    d = lambda v: v.to(dev())
+    out = mi.compute_all_metrics(d(batch["P"]), d(X), d(batch["X_gt"]), d(W), d(batch["I_gt"]), d(T), d(batch["T_gt"]),
+                                 d(batch["points_per_instance"]), {k: d(v) for k, v in gt.items()},
+                                 list_epsilon=[0.01, 0.03], classes=CLASSES)
+    match, mask = mi.hungarian_matching(out[8], d(batch["I_gt"]))
+    assert np.array_equal(match.cpu().numpy(), ref["matching"].numpy())
+    assert int(mask.sum()) == B * n_prims
+    _check(out, {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in ref.items() if k != "params"}, 128, N)
+    # the tiled segmented sums themselves against a dense one-hot contraction
+    from cpfn_amd.SPFN import fused_losses as fl
+    S = fl.SegStats.apply(d(W), d(batch["I_gt"])).cpu()
+    oh = torch.nn.functional.one_hot(lab, K).to(W.dtype) * (batch["I_gt"] >= 0).unsqueeze(2)
+    np.testing.assert_allclose(S[:, :K].numpy(), (oh.transpose(1, 2) @ W).numpy(), rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(S[:, K].numpy(), W.sum(1).numpy(), rtol=2e-5, atol=1e-4)
+    assert np.array_equal(S[:, K + 1].numpy(), oh.sum(1).numpy())
+
+
 def test_p_coverage_kernel_vs_expanded_formula():
     """cpfn_p_coverage against the reference-shaped expansion (get_residual_loss on P broadcast to [B,K,N,3])."""
     from cpfn_amd.SPFN import metric_implementation as mi

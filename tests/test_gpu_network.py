@@ -73,6 +73,43 @@ def test_training_step_matches_reference(golden):
     assert not bad.any(), [(names[i], gn[i], g["grad_norm"][i]) for i in np.nonzero(bad)[0]]
 
 
+def test_fused_losses_match_reference_fixture(golden):
+    """§8 f1 pinned to the REFERENCE, not to the sibling path: the fused HIP loss section (csrc/losses.hip +
+    the fitter chain) is fed the reference network's raw heads of losses_2x1024.npz and must reproduce the
+    reference's six losses, its Hungarian matching and dL/d(heads) (SPFN/losses_implementation.py:675-720 behind
+    Utils/training_utils.py:141-146); the op-by-op twin is held to the same fixture."""
+    from cpfn_amd.SPFN import fused_losses, losses_implementation as li
+    g = golden("losses_2x1024.npz")
+    batch = {k: v.to(dev()) for k, v in synthetic.training_batch(2, N=1024, n_prims=5, n_inst_points=64, seed=51).items()}
+    classes = ["sphere", "plane", "cylinder", "cone"]
+    mult = dict(miou=1.0, normal=1.0, type=1.0, parameter=1.0, residue=1.0, total=1.0)
+    gY = torch.from_numpy(g["gY"]).to(dev())
+    Ya = torch.from_numpy(g["Y"]).to(dev()).requires_grad_(True)
+    out = fused_losses.fused_losses(batch["P"], Ya, batch, mult, classes)
+    np.testing.assert_allclose([float(v) for v in out[:6]], g["losses"], rtol=1e-4, atol=1e-6)
+    out[0].backward()
+    err = float((Ya.grad - gY).norm() / gY.norm())
+    assert err < 1e-3, err
+    # per-head blocks separately (normals | type logits | membership logits): none may hide behind the largest
+    for lo, hi in ((0, 3), (3, 7), (7, 35)):
+        e = float((Ya.grad[..., lo:hi] - gY[..., lo:hi]).norm() / gY[..., lo:hi].norm())
+        assert e < 1e-3, (lo, hi, e)
+    W = torch.softmax(Ya.detach()[..., 7:], dim=2)
+    S = fused_losses.SegStats.apply(W, batch["I_gt"])
+    assert np.array_equal(fused_losses.hungarian_device(S, fused_losses.count_gt(batch["I_gt"])).cpu().numpy(),
+                          g["match"].astype(np.int64))
+    Yb = torch.from_numpy(g["Y"]).to(dev()).requires_grad_(True)
+    X = torch.nn.functional.normalize(Yb[..., :3], p=2, dim=2, eps=1e-12)
+    Wb = torch.softmax(Yb[..., 7:], dim=2)
+    gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"], "cone_axis": batch["cone_axis_gt"]}
+    out_r = li.compute_all_losses(batch["P"], Wb, batch["I_gt"], X, batch["X_gt"], Yb[..., 3:7], batch["T_gt"], gt,
+                                  batch["points_per_instance"], 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, False, mode_seg="mIoU",
+                                  classes=classes)
+    np.testing.assert_allclose([float(v) for v in out_r[:6]], g["losses"], rtol=1e-4, atol=1e-6)
+    out_r[0].backward()
+    assert float((Yb.grad - gY).norm() / gY.norm()) < 1e-3
+
+
 def test_fused_losses_match_reference_shaped_losses():
     """The fused HIP loss section (csrc/losses.hip) against the op-by-op
     `losses_implementation.compute_all_losses` on the same packed heads: six scalars and the

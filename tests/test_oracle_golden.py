@@ -203,3 +203,62 @@ def test_merging_oracle_matches_reference_fixture(golden):
     np.testing.assert_array_equal(M, g["point2primitive"])
     fin = om.get_point_final(g["point2primitive"], g["merged_labels"])
     np.testing.assert_allclose(fin, g["point_final"], rtol=1e-5, atol=1e-7)
+
+
+def test_loss_section_on_reference_heads(golden):
+    """oracle/spfn.py's loss section fed the reference network's raw heads (losses_2x1024.npz): six losses, the
+    matching and dL/d(heads) as the reference's compute_all_losses + autograd produced them."""
+    g = golden("losses_2x1024.npz")
+    batch = synthetic.training_batch(2, N=1024, n_prims=5, n_inst_points=64, seed=51)
+    Y = torch.from_numpy(g["Y"]).requires_grad_(True)
+    X = torch.nn.functional.normalize(Y[..., :3], p=2, dim=2, eps=1e-12)
+    W = torch.softmax(Y[..., 7:], dim=2)
+    gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"], "cone_axis": batch["cone_axis_gt"]}
+    assert np.array_equal(ospfn.hungarian_matching(W.detach(), batch["I_gt"]).numpy(), g["match"].astype(np.int64))
+    out = ospfn.compute_all_losses(batch["P"], W, batch["I_gt"], X, batch["X_gt"], Y[..., 3:7], batch["T_gt"], gt,
+                                   batch["points_per_instance"])
+    np.testing.assert_allclose([float(v) for v in out[:6]], g["losses"], rtol=2e-5, atol=1e-6)
+    out[0].backward()
+    err = float((Y.grad - torch.from_numpy(g["gY"])).norm() / torch.from_numpy(g["gY"]).norm())
+    assert err < 1e-4, err
+
+
+def test_local_spfn_step(golden):
+    """BASELINE.json configs[2] in small: the LocalSPFN step (K = 21, residue / parameter multipliers 0 as in
+    Configs/config_localSPFN.yml:10-11) of the oracle against the imported reference's."""
+    g = golden("step_local_2x1024.npz")
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(output_sizes=(3, 4, 21)), seed=3)
+    batch = synthetic.training_batch(2, N=1024, n_max_instances=21, n_prims=6, n_inst_points=64, seed=71)
+    st = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+          for k, v in state.items()}
+    mult = dict(normal=1.0, type=1.0, miou=1.0, residue=0.0, parameter=0.0, total=1.0)
+    out, aux = opn2.training_step_losses(st, batch, (g["fps_start1"], g["fps_start2"]), multipliers=mult, return_aux=True)
+    np.testing.assert_allclose([float(v) for v in out[:6]], g["losses"], rtol=2e-5, atol=1e-6)
+    assert out[6] is None and float(out[4]) == 0.0 and float(out[5]) == 0.0        # fitters never called
+    assert np.array_equal(ospfn.hungarian_matching(aux["heads"][2].detach(), batch["I_gt"]).numpy(),
+                          g["match"].astype(np.int64))
+    out[0].backward()
+    names = [str(n) for n in g["names"]]
+    gn = np.array([float(st[n].grad.norm()) for n in names])
+    assert np.all(np.abs(gn - g["grad_norm"]) <= 1e-3 * g["grad_norm"] + 1e-5 * g["grad_norm"].max())
+
+
+def test_cuda_route_restatement_differs_where_the_routes_differ(golden):
+    """The CUDA-route restatements (oracle, PARITY UNPINNED) against the CPU-route ones on the reference-pinned
+    inputs: 3-NN picks the same neighbours away from ties and returns sqrt of (nearly) the same squared distances;
+    ball query agrees except for points within rounding of the radius; FPS differs (start 0, near-origin skip)."""
+    g = golden("geometry_8192.npz")
+    xyz = g["xyz"]
+    l1 = np.take_along_axis(xyz, g["fps1_idx"].astype(np.int64)[:, :, None], axis=1)
+    d_cpu, i_cpu = og.three_nn(xyz, l1)
+    d_cuda, i_cuda = og.three_nn_cuda(xyz, l1, sqrt=True)
+    assert (i_cpu != i_cuda).mean() < 1e-3
+    np.testing.assert_allclose(d_cuda ** 2, np.maximum(d_cpu, 0), rtol=1e-3, atol=1e-6)
+    b_cpu = og.ball_query(0.2, 64, xyz, l1)
+    b_cuda = og.ball_query_cuda(0.2, 64, xyz, l1)
+    assert (b_cpu != b_cuda).mean() < 1e-3
+    f = og.farthest_point_sample_cuda(xyz, 512)
+    assert (f[:, 0] == 0).all() or (np.sum(xyz[:, 0] ** 2, -1) <= 1e-3).any()
+    near = (np.sum(xyz ** 2, -1) <= 1e-3)
+    for b in range(xyz.shape[0]):
+        assert not near[b, f[b, 1:]].any()
