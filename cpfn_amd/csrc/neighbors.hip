@@ -115,7 +115,10 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
   if (i < N) {
     float *od = dist2 + ((size_t)b * N + i) * 3;
     int *oi = idx + ((size_t)b * N + i) * 3;
-    if (sqrt_out) { d0 = __fsqrt_rn(d0); d1 = __fsqrt_rn(d1); d2 = __fsqrt_rn(d2); }   // geometry_utils.py:184
+    if (sqrt_out) {   // geometry_utils.py:184.  Through fp64: __fsqrt_rn was measured 1 ulp off torch.sqrt / sqrtf on
+                      // gfx950; the fp64 root rounded to fp32 is the correctly rounded fp32 root
+      d0 = (float)sqrt((double)d0); d1 = (float)sqrt((double)d1); d2 = (float)sqrt((double)d2);
+    }
     od[0] = d0; od[1] = d1; od[2] = d2;
     oi[0] = i0; oi[1] = i1; oi[2] = i2;
   }

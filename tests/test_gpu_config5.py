@@ -110,11 +110,14 @@ def test_cascaded_eval_131072_points():
     wf = omg.get_point_final(M.cpu().numpy(), labels.cpu().numpy())
     np.testing.assert_allclose(W_fusion.cpu().numpy(), wf, rtol=1e-5, atol=1e-6)
     # ---------------- stage 4: metrics on a merged label set wider than 32 columns (local + global = 49)
+    # (the networks are untrained: their merged memberships cut the cloud into arbitrary blobs whose cone / cylinder fits
+    #  are ill-conditioned — the fp32 oracle itself moves by several per cent against its fp64 run there.  The GT labels
+    #  are mixed in so that the hard instances are the cloud's real primitives and the comparison means something.)
     Kf = K_LOCAL + K_GLOBAL
-    Wf = torch.zeros(1, N_HI, Kf, device=dev())
-    Wf[0, :, :K_GLOBAL] = W_fusion
-    Wf[0, :, K_GLOBAL:] = 1e-3 * torch.rand(N_HI, K_LOCAL, device=dev())
     I_gt = cloud["I_gt"].to(dev())
+    Wf = torch.zeros(1, N_HI, Kf, device=dev())
+    Wf[0, :, :K_GLOBAL] = W_fusion + 2.0 * torch.nn.functional.one_hot(I_gt[0], K_GLOBAL)
+    Wf[0, :, K_GLOBAL:] = 1e-3 * torch.rand(N_HI, K_LOCAL, device=dev())
     T_gt = torch.zeros(1, Kf, dtype=torch.long, device=dev())
     T_gt[:, :12] = cloud["T_gt"].to(dev())
     ppi = torch.zeros(1, Kf, 512, 3, device=dev())
@@ -129,11 +132,17 @@ def test_cascaded_eval_131072_points():
     CLASSES = ["sphere", "plane", "cylinder", "cone"]
     res = mi.compute_all_metrics(P, Xg, cloud["X_gt"].to(dev()), Wf, I_gt, T, T_gt, ppi, gt, list_epsilon=[0.01, 0.02],
                                  classes=CLASSES)
-    c = lambda t: t.detach().float().cpu()
+    c = lambda t: (t.detach().float() if t.dtype.is_floating_point else t.detach()).cpu()
     ref = om.compute_all_metrics(c(P), c(Xg), cloud["X_gt"], c(Wf), cloud["I_gt"], c(T), c(T_gt), c(ppi),
                                  {k: c(v) for k, v in gt.items()}, list_epsilon=[0.01, 0.02], classes=CLASSES)
     assert np.array_equal(res[10].cpu().numpy(), ref["T_instance"].numpy())
+    # (axis difference is left out HERE: its denominator sums the axis loss over ALL K slots, metric_implementation.py:183,
+    #  and 37 of the 49 hard instances of this cloud are empty — their "axes" are eigenvectors of a zero matrix, arbitrary
+    #  in the reference too.  It is asserted where every slot is populated: tests/test_gpu_metrics.py.)
+    print("metric axis     product %.6f oracle %.6f (not asserted: empty slots)" % (float(res[3]), float(ref["axis_difference"])))
     for name, a, b in (("mIoU", res[0], ref["mIoU"]), ("type", res[1], ref["type_accuracy"]), ("normal", res[2], ref["normal_difference"]),
-                       ("mean_res", res[4], ref["mean_residual"])):
+                       ("mean_res", res[4], ref["mean_residual"]), ("std_res", res[5], ref["std_residual"])):
+        print("metric %-8s product %.6f oracle %.6f" % (name, float(a), float(b)))
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=2e-3, atol=1e-5, err_msg=name)
+    np.testing.assert_allclose(torch.stack(res[6]).cpu().numpy(), ref["Sk_coverage"].numpy(), atol=3.0 / 512)
     np.testing.assert_allclose(torch.stack(res[7]).cpu().numpy(), ref["P_coverage"].numpy(), atol=20.0 / N_HI)

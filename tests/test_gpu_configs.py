@@ -66,7 +66,9 @@ def test_local_spfn_step_matches_reference(golden):
 
     def grad_norms(m):
         params = dict(m.named_parameters())
-        return np.array([float(params[n].grad.norm()) for n in names])
+        # (bf16 mode: a conv bias in front of a training-mode BatchNorm gets no gradient — exactly 0 instead of the
+        #  reference's rounding noise)
+        return np.array([0.0 if params[n].grad is None else float(params[n].grad.norm()) for n in names])
 
     scale = g["grad_norm"].max()
     for fused in (False, True):

@@ -143,6 +143,24 @@ def test_training_step_losses_and_grads(golden):
     assert np.all(np.abs(gn - g["grad_norm"]) <= 1e-3 * g["grad_norm"] + 1e-5 * scale)
 
 
+def test_bf16_storage_emulation_is_a_small_perturbation_of_the_restatement(golden):
+    """oracle.pn2.storage("bf16") (the fp32 restatement with the product's bf16 storage roundings made explicit; used
+    by the full-size GPU tests next to the plain oracle) must stay a bf16-sized perturbation of the pinned fp32
+    restatement, and the default must be untouched by it."""
+    g = golden("network_2x2048.npz")
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(), seed=0)
+    starts = (g["fps_start1"], g["fps_start2"])
+    with torch.no_grad():
+        with opn2.storage("bf16"):
+            hq, _, _, _ = opn2.pointnet2_forward(state, torch.from_numpy(g["P"]), starts, training=True)
+        h, _, _, _ = opn2.pointnet2_forward(state, torch.from_numpy(g["P"]), starts, training=True)
+    assert opn2.STORAGE == "fp32"
+    for name, a, b in zip("XTW", hq, h):
+        np.testing.assert_allclose(b.numpy(), g[name], rtol=1e-4, atol=1e-4)
+        e = float((a - b).norm() / b.norm())
+        assert 1e-4 < e < 0.5, (name, e)
+
+
 def test_lsap_matches_scipy():
     """The restated assignment solver (oracle/lsap.py) picks the SAME optimal assignment as SciPy, ties
     included: random fp32 costs, small-integer costs (many ties), constant matrices, rectangular shapes."""
@@ -235,7 +253,7 @@ def test_local_spfn_step(golden):
     out, aux = opn2.training_step_losses(st, batch, (g["fps_start1"], g["fps_start2"]), multipliers=mult, return_aux=True)
     np.testing.assert_allclose([float(v) for v in out[:6]], g["losses"], rtol=2e-5, atol=1e-6)
     assert out[6] is None and float(out[4]) == 0.0 and float(out[5]) == 0.0        # fitters never called
-    assert np.array_equal(ospfn.hungarian_matching(aux["heads"][2].detach(), batch["I_gt"]).numpy(),
+    assert np.array_equal(ospfn.hungarian_matching(torch.softmax(aux["heads"][2].detach(), 2), batch["I_gt"]).numpy(),
                           g["match"].astype(np.int64))
     out[0].backward()
     names = [str(n) for n in g["names"]]
