@@ -20,39 +20,6 @@ from . import spfn as ospfn
 
 BN_EPS = 1e-5
 
-# ---------------------------------------------------------------------------------------------------
-# STORAGE = "bf16": NOT the reference's arithmetic.  The same fp32 restatement with the product's bf16 STORAGE
-# roundings made explicit (GEMM operands, the stored pre-BatchNorm outputs, the stored activations and interpolated
-# rows are rounded to bf16, straight-through for autograd; accumulation, statistics and normalisation stay fp32).
-# The full-size bench-mode tests use it next to the plain fp32 oracle to separate "the kernels compute something
-# else" from "bf16 storage moved the result": training-mode BatchNorm amplifies a 0.2 % storage rounding to tens of
-# per cent at the heads of a randomly initialised network (the sfp1 layer normalises per-cloud constants over 16
-# clouds), so the fp32 oracle alone cannot pin the bf16 product path tighter than that.
-STORAGE = "fp32"
-
-
-def _q(t):
-    """bf16 storage rounding, straight-through (identity when STORAGE == "fp32")."""
-    if STORAGE != "bf16":
-        return t
-    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
-
-
-class storage:
-    """Context manager: `with pn2.storage("bf16"): ...`."""
-
-    def __init__(self, mode):
-        self.mode = mode
-
-    def __enter__(self):
-        global STORAGE
-        self.prev, STORAGE = STORAGE, self.mode
-
-    def __exit__(self, *a):
-        global STORAGE
-        STORAGE = self.prev
-        return False
-
 
 def _np_bn3(pos_bcn):
     """[B,3,N] torch -> [B,N,3] contiguous numpy."""
@@ -67,24 +34,17 @@ def _gather(points, idx):
     return torch.gather(points, 2, flat).reshape(B, C, *idx.shape[1:])
 
 
-def _mlp(state, conv_fmt, bn_fmt, n_layers, x, training, conv, first_fp32=False):
+def _mlp(state, conv_fmt, bn_fmt, n_layers, x, training, conv):
     """Shared 1x1-conv + BatchNorm(batch statistics) + ReLU stack
-    (pointset_abstraction.py:70-73, pointset_feature_propagation.py:49-51).
-    first_fp32 (STORAGE == "bf16" only): the first layer reads fp32 coordinates with fp32 weights (sa1)."""
+    (pointset_abstraction.py:70-73, pointset_feature_propagation.py:49-51)."""
     for j in range(n_layers):
         w, b = state[conv_fmt % j + ".weight"], state[conv_fmt % j + ".bias"]
-        if first_fp32 and j == 0:
-            x = conv(x, w, b)
-        else:
-            x = conv(_q(x), _q(w), b)
-        x = _q(x)                                   # the stored pre-BatchNorm output
+        x = conv(x, w, b)
         rm, rv = state.get(bn_fmt % j + ".running_mean"), state.get(bn_fmt % j + ".running_var")
         x = F.batch_norm(x, None if training else rm, None if training else rv,
                          state[bn_fmt % j + ".weight"], state[bn_fmt % j + ".bias"],
                          training=training, eps=BN_EPS)
         x = F.relu(x)
-        if j < n_layers - 1:
-            x = _q(x)
     return x
 
 
@@ -118,8 +78,8 @@ def set_abstraction(state, name, pos, feats, num_points, radius, num_samples, st
             g = torch.cat([_gather(feats, grp), g], dim=1)                  # :66 feats FIRST
         aux = {"fps_idx": sel, "ball_idx": grp}
     g = _mlp(state, conv_fmt, bn_fmt, _count(state, conv_fmt), g, training,
-             lambda x, w, b: F.conv2d(x, w, b), first_fp32=feats is None and num_points is not None)
-    return new_pos, _q(g.max(dim=3)[0]), aux                                # :74
+             lambda x, w, b: F.conv2d(x, w, b))
+    return new_pos, g.max(dim=3)[0], aux                                    # :74
 
 
 def feature_propagation(state, name, pos1, pos2, feats1, feats2, training=True):
@@ -133,13 +93,13 @@ def feature_propagation(state, name, pos1, pos2, feats1, feats2, training=True):
         d, i = torch.from_numpy(d), torch.from_numpy(i)
         recip = 1.0 / (d + 1e-8)                                            # :40
         w = recip / recip.sum(dim=2, keepdim=True)                          # :41-42
-        interp = _q((_gather(feats2, i) * w.unsqueeze(1)).sum(-1))          # :44
+        interp = (_gather(feats2, i) * w.unsqueeze(1)).sum(-1)              # :44
         aux = {"nn_idx": i, "nn_w": w}
     x = interp if feats1 is None else torch.cat([feats1, interp], dim=1)    # :45-48
     conv_fmt, bn_fmt = name + ".mlp_convs.%d", name + ".mlp_bns.%d"
     x = _mlp(state, conv_fmt, bn_fmt, _count(state, conv_fmt), x, training,
              lambda x, w, b: F.conv1d(x, w, b))
-    return _q(x), aux
+    return x, aux
 
 
 def pointnet2_forward(state, x, fps_starts, training=True, dropout_mask=None):
@@ -155,17 +115,16 @@ def pointnet2_forward(state, x, fps_starts, training=True, dropout_mask=None):
     l4, _ = feature_propagation(state, "sfp1", l2_pos, None, l2_f, l3_f, training)
     l5, a5 = feature_propagation(state, "sfp2", l1_pos, l2_pos, l1_f, l4, training)
     l6, a6 = feature_propagation(state, "sfp3", pos, l1_pos, None, l5, training)
-    feat = _q(F.conv1d(_q(l6), _q(state["fc1.weight"]), state["fc1.bias"]))           # :60
+    feat = F.conv1d(l6, state["fc1.weight"], state["fc1.bias"])                       # :60
     feat = F.relu(F.batch_norm(feat, None if training else state["bn1.running_mean"],
                                None if training else state["bn1.running_var"],
                                state["bn1.weight"], state["bn1.bias"], training=training, eps=BN_EPS))
     if dropout_mask is not None:
         feat = feat * dropout_mask                                                      # :63
-    feat = _q(feat)
     heads = []
     j = 0
     while "fc2.%d.weight" % j in state:
-        heads.append(F.conv1d(feat, _q(state["fc2.%d.weight" % j]), state["fc2.%d.bias" % j]).transpose(1, 2))
+        heads.append(F.conv1d(feat, state["fc2.%d.weight" % j], state["fc2.%d.bias" % j]).transpose(1, 2))
         j += 1
     aux = {"sa1": a1, "sa2": a2, "sfp2": a5, "sfp3": a6}
     return heads, l3_f, feat, aux

@@ -133,8 +133,16 @@ def test_cascaded_eval_131072_points():
     res = mi.compute_all_metrics(P, Xg, cloud["X_gt"].to(dev()), Wf, I_gt, T, T_gt, ppi, gt, list_epsilon=[0.01, 0.02],
                                  classes=CLASSES)
     c = lambda t: (t.detach().float() if t.dtype.is_floating_point else t.detach()).cpu()
-    ref = om.compute_all_metrics(c(P), c(Xg), cloud["X_gt"], c(Wf), cloud["I_gt"], c(T), c(T_gt), c(ppi),
-                                 {k: c(v) for k, v in gt.items()}, list_epsilon=[0.01, 0.02], classes=CLASSES)
+    # The arbiter at this size is the float64 evaluation of the oracle's formulas: over 131072 points the fp32
+    # restatement's own summation error shows in the residual statistics (its mean residual sits ~1 % from its fp64 run,
+    # printed below), while the product accumulates the fit moments in fp64.
+    d = lambda t: t.double() if t.dtype.is_floating_point else t
+    ref32 = om.compute_all_metrics(c(P), c(Xg), cloud["X_gt"], c(Wf), cloud["I_gt"], c(T), c(T_gt), c(ppi),
+                                   {k: c(v) for k, v in gt.items()}, list_epsilon=[0.01, 0.02], classes=CLASSES)
+    ref = om.compute_all_metrics(d(c(P)), d(c(Xg)), d(cloud["X_gt"]), d(c(Wf)), cloud["I_gt"], d(c(T)), c(T_gt), d(c(ppi)),
+                                 {k: d(c(v)) for k, v in gt.items()}, list_epsilon=[0.01, 0.02], classes=CLASSES)
+    print("fp32 oracle vs fp64 oracle: mean_res %.6f / %.6f, std_res %.6f / %.6f" % (
+        float(ref32["mean_residual"]), float(ref["mean_residual"]), float(ref32["std_residual"]), float(ref["std_residual"])))
     assert np.array_equal(res[10].cpu().numpy(), ref["T_instance"].numpy())
     # (axis difference is left out HERE: its denominator sums the axis loss over ALL K slots, metric_implementation.py:183,
     #  and 37 of the 49 hard instances of this cloud are empty — their "axes" are eigenvectors of a zero matrix, arbitrary
@@ -143,6 +151,6 @@ def test_cascaded_eval_131072_points():
     for name, a, b in (("mIoU", res[0], ref["mIoU"]), ("type", res[1], ref["type_accuracy"]), ("normal", res[2], ref["normal_difference"]),
                        ("mean_res", res[4], ref["mean_residual"]), ("std_res", res[5], ref["std_residual"])):
         print("metric %-8s product %.6f oracle %.6f" % (name, float(a), float(b)))
-        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=2e-3, atol=1e-5, err_msg=name)
-    np.testing.assert_allclose(torch.stack(res[6]).cpu().numpy(), ref["Sk_coverage"].numpy(), atol=3.0 / 512)
-    np.testing.assert_allclose(torch.stack(res[7]).cpu().numpy(), ref["P_coverage"].numpy(), atol=20.0 / N_HI)
+        np.testing.assert_allclose(a.cpu().numpy(), b.float().numpy(), rtol=2e-3, atol=1e-5, err_msg=name)
+    np.testing.assert_allclose(torch.stack(res[6]).cpu().numpy(), ref["Sk_coverage"].float().numpy(), atol=3.0 / 512)
+    np.testing.assert_allclose(torch.stack(res[7]).cpu().numpy(), ref["P_coverage"].float().numpy(), atol=20.0 / N_HI)

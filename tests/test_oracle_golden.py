@@ -143,24 +143,6 @@ def test_training_step_losses_and_grads(golden):
     assert np.all(np.abs(gn - g["grad_norm"]) <= 1e-3 * g["grad_norm"] + 1e-5 * scale)
 
 
-def test_bf16_storage_emulation_is_a_small_perturbation_of_the_restatement(golden):
-    """oracle.pn2.storage("bf16") (the fp32 restatement with the product's bf16 storage roundings made explicit; used
-    by the full-size GPU tests next to the plain oracle) must stay a bf16-sized perturbation of the pinned fp32
-    restatement, and the default must be untouched by it."""
-    g = golden("network_2x2048.npz")
-    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(), seed=0)
-    starts = (g["fps_start1"], g["fps_start2"])
-    with torch.no_grad():
-        with opn2.storage("bf16"):
-            hq, _, _, _ = opn2.pointnet2_forward(state, torch.from_numpy(g["P"]), starts, training=True)
-        h, _, _, _ = opn2.pointnet2_forward(state, torch.from_numpy(g["P"]), starts, training=True)
-    assert opn2.STORAGE == "fp32"
-    for name, a, b in zip("XTW", hq, h):
-        np.testing.assert_allclose(b.numpy(), g[name], rtol=1e-4, atol=1e-4)
-        e = float((a - b).norm() / b.norm())
-        assert 1e-4 < e < 0.5, (name, e)
-
-
 def test_lsap_matches_scipy():
     """The restated assignment solver (oracle/lsap.py) picks the SAME optimal assignment as SciPy, ties
     included: random fp32 costs, small-integer costs (many ties), constant matrices, rectangular shapes."""
