@@ -5,21 +5,24 @@ all-reduce, non-finite guard, Adam) on synthetic 8192-point clouds, 16 clouds pe
 (BASELINE.json configs[1]; configs[3] is the same per-GPU work on 8 GPUs -> weak scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 launches its own N ranks (one process per GPU, RCCL over xGMI) unless it already runs under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE in the environment).
 Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region.
-`roofline` is measured live with HIP events around the dominant entry point of
-libcpfn_hip.so; `cpu_baseline` times the oracle (a port of the reference's CPU path) on the
-host cores of this box, rank 0, N=1 only.
+
+`roofline` describes the dominant kernel family (the bf16 MFMA GEMM behind every 1x1 convolution): its launches time
+THEMSELVES inside the replayed graphs of the timed region (device wall clock, cpfn_mlp_gemm_set_probe), because a
+hipGraph replay cannot be bracketed kernel by kernel with host-side events; the HIP-event figure of eager re-runs and
+the rocprofv3 trace (profiles/) are the cross-checks.  `cpu_baseline` times the oracle (a port of the reference's CPU
+path) on the host cores of this box, rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,61 +32,16 @@ N_POINTS = 8192
 N_INSTANCES = 28
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
-# Dominant kernel family of the step (profiles/r01_*_kernel_stats.csv; DESIGN.md "Measurement"):
-# the bf16 MFMA GEMM behind every 1x1 convolution, forward and data-gradient (31 launches per
+# Dominant kernel family of the step (profiles/r02_rooflines.json; DESIGN.md "Measurement"):
+# the bf16 MFMA GEMM behind every 1x1 convolution, forward and data-gradient (34 launches per
 # step).  Arithmetic intensity is 32-128 FLOP/B (K, N <= 256 for the layers that carry the
 # bytes), far left of the ~300 FLOP/B bf16 ridge, so the bound is HBM.  The algorithmic bytes
 # of each launch (read A[P,K] and W[N,K] once, write Y[P,N] once) are summed by the caller
-# (cpfn_amd/fused_mlp.py:gemm) while the timed region runs.
+# (cpfn_amd/fused_mlp.py:gemm).
 ROOFLINE_SYMBOL = "cpfn_mlp_gemm"
 
 
-def cpu_baseline():
-    """Reference CPU path (oracle port): one GlobalSPFN training step (forward, all losses incl. the four
-    fitters, backward, Adam) on a bounded sample.  torch-CPU does not scale to the 256 hardware threads of
-    the GPU box (128 threads is 10x SLOWER than 16), so a short sweep picks the best thread count and the
-    baseline is timed there — `cores` is the number of threads actually used."""
-    import numpy as np
-    from cpfn_amd import synthetic
-    from oracle import pn2 as opn2
-    Bc = 4
-    prev_threads = torch.get_num_threads()
-    torch.manual_seed(0)
-    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(), seed=0)
-    st = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
-          for k, v in state.items()}
-    leaves = [v for v in st.values() if v.requires_grad]
-    opt = torch.optim.Adam(leaves, lr=1e-3)
-    batch = synthetic.training_batch(Bc, N_POINTS, N_INSTANCES, seed=123)
-
-    def one_step(it):
-        starts = (np.random.RandomState(it).randint(0, N_POINTS, Bc), np.random.RandomState(it + 1).randint(0, 512, Bc))
-        t0 = time.time()
-        opt.zero_grad()
-        out = opn2.training_step_losses(st, batch, starts)
-        out[0].backward()
-        opt.step()
-        return time.time() - t0
-
-    ncpu = os.cpu_count() or 8
-    best_nt, best_t = None, None
-    for nt in [n for n in (8, 16, 32, 64) if n <= ncpu] or [ncpu]:
-        torch.set_num_threads(nt)
-        one_step(0)
-        t = min(one_step(1), one_step(2))
-        if best_t is None or t < best_t:
-            best_nt, best_t = nt, t
-    torch.set_num_threads(best_nt)
-    times = [one_step(10 + i) for i in range(6)]
-    torch.set_num_threads(prev_threads)
-    mean = sum(times) / len(times)
-    return {"value": Bc / mean, "unit": "point-clouds/s", "cores": best_nt, "kind": "port",
-            "sample": "%d timed GlobalSPFN training steps (fwd+losses+bwd+Adam) of %dx%d pts at the best of "
-                      "8/16/32/64 threads (%d; host has %d hardware threads), oracle/ (torch-CPU + C geometry), "
-                      "mean %.3f s/step" % (len(times), Bc, N_POINTS, best_nt, ncpu, mean)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -94,7 +52,108 @@ def main():
     ap.add_argument("--workload", default="global", choices=["global", "local"],
                     help="global (default) = BASELINE.json configs[1], the config the metric is quoted on; local = "
                          "configs[2] (LocalSPFN: 32 patches/GPU, 21 instances, fitter losses off) as an extra data point")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as CHILD processes — before anything
+    in this process has touched the GPU (the parent never does) — and exit with their worst exit code."""
+    import torch
+    visible = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
+    if visible < args.gpus:
+        sys.stderr.write("bench.py: %d GPUs requested, %d visible\n" % (args.gpus, visible))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    sys.exit(max(abs(c) for c in codes))
+
+
+def cpu_baseline():
+    """Reference CPU path (oracle port) on this box's host cores, as BASELINE.md §2 / SURVEY §8d prescribe: config 1
+    (GlobalSPFN forward, one 8192-point cloud, no_grad) and config 2's training step (forward, all losses incl. the four
+    fitters, backward, Adam) at 16 x 8192, 1 warm-up + 3 timed iterations each.  torch-CPU does not scale to the 256
+    hardware threads of the GPU box (128 threads is ~10x SLOWER than 16), so a short sweep on 4 x 8192 picks the thread
+    count the headline baseline is timed at (`cores` = threads actually used); the all-physical-cores figure is reported
+    next to it."""
+    import numpy as np
+    import torch
+    from cpfn_amd import synthetic
+    from oracle import pn2 as opn2
+    prev_threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(), seed=0)
+    st = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+          for k, v in state.items()}
+    leaves = [v for v in st.values() if v.requires_grad]
+    opt = torch.optim.Adam(leaves, lr=1e-3)
+    batches = {b: synthetic.training_batch(b, N_POINTS, N_INSTANCES, seed=123) for b in (1, 4, 16)}
+
+    def one_step(bc, it):
+        starts = (np.random.RandomState(it).randint(0, N_POINTS, bc), np.random.RandomState(it + 1).randint(0, 512, bc))
+        t0 = time.time()
+        opt.zero_grad()
+        out = opn2.training_step_losses(st, batches[bc], starts)
+        out[0].backward()
+        opt.step()
+        return time.time() - t0
+
+    def one_forward(it):
+        starts = (np.random.RandomState(it).randint(0, N_POINTS, 1), np.random.RandomState(it + 1).randint(0, 512, 1))
+        t0 = time.time()
+        with torch.no_grad():
+            opn2.pointnet2_forward(state, batches[1]["P"], starts, training=False)
+        return time.time() - t0
+
+    ncpu = os.cpu_count() or 8
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or ncpu
+    except Exception:
+        physical = ncpu
+    best_nt, best_t = None, None
+    for nt in [n for n in (8, 16, 32, 64) if n <= ncpu] or [ncpu]:
+        torch.set_num_threads(nt)
+        one_step(4, 0)
+        t = min(one_step(4, 1), one_step(4, 2))
+        if best_t is None or t < best_t:
+            best_nt, best_t = nt, t
+    torch.set_num_threads(best_nt)
+    one_step(16, 9)                                                  # warm-up
+    t2 = [one_step(16, 10 + i) for i in range(3)]
+    one_forward(20)
+    t1 = [one_forward(21 + i) for i in range(3)]
+    # all physical cores: one warm-up + one timed step on 4 x 8192 (at ~10x slower this is the bounded sample)
+    torch.set_num_threads(physical)
+    one_step(4, 30)
+    t_all = one_step(4, 31)
+    torch.set_num_threads(prev_threads)
+    m2, m1 = sum(t2) / len(t2), sum(t1) / len(t1)
+    return {"value": 16 / m2, "unit": "point-clouds/s", "cores": best_nt, "kind": "port",
+            "sample": "config 2: %d timed GlobalSPFN training steps (fwd+losses+bwd+Adam) of 16x%d pts after 1 warm-up, at the "
+                      "best of 8/16/32/64 threads (%d; host has %d hardware threads / %d physical cores), oracle/ (torch-CPU + C "
+                      "geometry), mean %.3f s/step" % (len(t2), N_POINTS, best_nt, ncpu, physical, m2),
+            "config1": {"value": 1 / m1, "unit": "point-clouds/s", "cores": best_nt,
+                        "sample": "GlobalSPFN forward, 1x%d pts, no_grad, eval statistics: %d timed after 1 warm-up, mean %.3f s"
+                                  % (N_POINTS, len(t1), m1)},
+            "all_physical_cores": {"value": 4 / t_all, "unit": "point-clouds/s", "cores": physical,
+                                   "sample": "1 timed training step of 4x%d pts after 1 warm-up with torch.set_num_threads(%d): "
+                                             "%.3f s" % (N_POINTS, physical, t_all)}}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                        # never returns
+    import torch
+    import torch.distributed as dist
     global BATCH_PER_GPU, N_INSTANCES
     mult = None
     if args.workload == "local":                        # Configs/config_localSPFN.yml:10-11, training_SPFN.py:69-71
@@ -105,11 +164,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node == --gpus)\n" % (args.gpus, world))
+        sys.exit(2)
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -119,13 +183,16 @@ def main():
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
         fitter_factory.register_primitives(training.GLOBAL_SPFN_CLASSES)
-    lib.lib()                                           # fail loudly if the HIP library is missing
+    h = lib.lib()                                       # fail loudly if the HIP library is missing
 
     torch.manual_seed(0)                                # default PyTorch init, identical on every rank
     model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, N_INSTANCES]).to(dev)
     model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     training.broadcast_parameters(model)
-    trainer = training.SPFNTrainer(model, batch_size=BATCH_PER_GPU * world, use_graphs=not args.no_graphs, multipliers=mult)
+    # require_graphs: a failed capture raises (exit code != 0) instead of degrading to eager launches — a host-bound eager
+    # number can never be recorded as the headline
+    trainer = training.SPFNTrainer(model, batch_size=BATCH_PER_GPU * world, use_graphs=not args.no_graphs,
+                                   require_graphs=not args.no_graphs, multipliers=mult)
     batch = {k: v.to(dev) for k, v in
              synthetic.training_batch(BATCH_PER_GPU, N_POINTS, N_INSTANCES, seed=1000 + rank).items()}
     torch.manual_seed(1234 + rank)                      # per-rank FPS starts / dropout masks
@@ -136,40 +203,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The GEMM family's timing probe is installed BEFORE the graph is captured, so the captured launches carry it.
+    PROBE_SLOTS, PROBE_WG = 128, 2048
+    probe = torch.zeros(PROBE_SLOTS, 2 + 2 * PROBE_WG, dtype=torch.int64, device=dev)
+    lib.check(h.cpfn_mlp_gemm_set_probe(probe.data_ptr(), PROBE_SLOTS, PROBE_WG), "cpfn_mlp_gemm_set_probe")
     # Each step also prefetches the NEXT step's geometry (FPS / ball query / 3-NN with fresh random
     # FPS starts) on a side stream: one geometry pass per step, software-pipelined across steps.
     for _ in range(args.warmup):
         trainer.step(batch, next_batch=batch)
-    lib.time_symbols([ROOFLINE_SYMBOL])
+    if not args.no_graphs and args.dtype == "bf16" and trainer._graph is None and args.warmup >= 3:
+        sys.stderr.write("bench.py: the step was not captured as a hipGraph after %d warm-up steps\n" % args.warmup)
+        sys.exit(3)
+    # algorithmic bytes of ONE step, per entry point (every operand read once, every result written once): one eager
+    # step with the byte census on (same launches as the replayed graph)
+    sync()
+    lib.byte_census(True)
+    trainer.step(batch, force_eager=True)
+    census = lib.byte_census(False)
+    sync()
+    probe.zero_()                                       # only the launches of the timed region will be in it afterwards
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.step(batch, next_batch=batch)
     sync()
     elapsed = time.perf_counter() - t0
-    calls, kernel_ms = lib.timed_report()[ROOFLINE_SYMBOL]
-    roof_bytes = lib.timed_bytes(ROOFLINE_SYMBOL)
-    roof_mode = "events around every launch inside the timed region"
-    if calls == 0:
-        # hipGraph replay: the launches of the timed region are graph nodes and cannot be bracketed one
-        # by one, so the same step is re-run eagerly right here (same process, same tensors, same
-        # stream) with an event pair around every launch of the kernel family.  rocprofv3 (which does
-        # see the kernels inside a replay) gives the same per-launch durations: profiles/README.md.
-        # Launched one by one the host is slower than the GPU (5.5 ms vs 2.5 ms per step), and an event pair would
-        # also time the GPU waiting for the next launch.  A spin kernel queued first holds the stream back until the
-        # host has queued the whole step, so every pair brackets a kernel executing back to back like in the replay.
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); torch.cuda._sleep(2_000_000); e1.record(); sync()
-        spin = int(2_000_000 * 8.0 / max(e0.elapsed_time(e1), 1e-3))      # ~8 ms of spinning
-        lib.time_symbols([ROOFLINE_SYMBOL])
-        for _ in range(3):
-            torch.cuda._sleep(spin)
-            trainer.step(batch, force_eager=True)
-        sync()
-        calls, kernel_ms = lib.timed_report()[ROOFLINE_SYMBOL]
-        roof_bytes = lib.timed_bytes(ROOFLINE_SYMBOL)
-        roof_mode = ("events around every launch in 3 eager re-runs of the step right after the timed region, each queued "
-                     "behind a spin kernel so that the launches execute back to back (graph replays are not bracketable)")
+    # every slot written during the timed region: a replayed graph rewrites the slots its launches were given at capture
+    # time, so the buffer now holds the launches of the LAST replayed step (eager mode: the last PROBE_SLOTS launches)
+    pr = probe.cpu().numpy()
+    probe_ticks, probe_launches = 0, 0
+    for slot in pr:
+        nwg = int(slot[0])
+        if nwg > 0:
+            tt = slot[2:2 + 2 * nwg].reshape(nwg, 2)
+            probe_ticks += int(tt[:, 1].max() - tt[:, 0].min())
+            probe_launches += 1
+    lib.check(h.cpfn_mlp_gemm_set_probe(None, 0, 0), "cpfn_mlp_gemm_set_probe")
+    # cross-check: HIP events around every launch of the family in eager re-runs of the same step, each queued behind a
+    # spin kernel so that the bracketed launches execute back to back (the pair still contains the dispatch gap)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(2_000_000); e1.record(); sync()
+    spin = int(2_000_000 * 8.0 / max(e0.elapsed_time(e1), 1e-3))      # ~8 ms of spinning
+    lib.time_symbols([ROOFLINE_SYMBOL])
+    for _ in range(3):
+        torch.cuda._sleep(spin)
+        trainer.step(batch, force_eager=True)
+    sync()
+    ev_calls, ev_ms = lib.timed_report()[ROOFLINE_SYMBOL]
     lib.time_symbols([])
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -178,17 +258,31 @@ def main():
 
     if rank == 0:
         clouds = BATCH_PER_GPU * world * args.steps
-        per_launch_s = kernel_ms / max(calls, 1) / 1e3
-        bytes_per_launch = roof_bytes / max(calls, 1)
+        wall_khz = float(h.cpfn_wall_clock_khz(local_rank))     # ticks of s_memrealtime (hipDeviceAttributeWallClockRate)
+        if not wall_khz > 0:
+            sys.stderr.write("bench.py: the device's wall-clock rate is unknown\n")
+            sys.exit(4)
+        launches_per_step, bytes_per_step = census.get(ROOFLINE_SYMBOL, (0, 0))
+        if probe_launches > 0:                           # graph replays (or eager steps) of the timed region, timed by the kernels
+            per_launch_s = probe_ticks / (wall_khz * 1e3) / probe_launches
+            roof_mode = ("device wall-clock timestamps (start, end per workgroup; duration = max end - min start) stored by the "
+                         "kernels themselves inside the timed region: the %d launches of its last replayed step (a hipGraph "
+                         "replay cannot be bracketed kernel by kernel with host events)" % probe_launches)
+        else:
+            per_launch_s = ev_ms / max(ev_calls, 1) / 1e3
+            roof_mode = "HIP events around every launch in 3 eager re-runs of the step (probe counters empty)"
+        bytes_per_launch = bytes_per_step / max(launches_per_step, 1)
         achieved = bytes_per_launch / per_launch_s / 1e9
+        step_bytes = sum(b for _, b in census.values())
+        ms_per_step = 1e3 * elapsed / args.steps
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_mlp_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_mlp_gemm_traffic.json")
         if os.path.exists(tpath):                       # PMC pass (rocprofv3 --pmc), see profiles/README.md
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         line = {
             "metric": "point-clouds/sec (8192 pts, %sSPFN fwd+bwd)" % ("Global" if args.workload == "global" else "Local"),
             "value": clouds / elapsed, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("GlobalSPFN training step (fwd + 5 losses incl. fitters + bwd + Adam), "
                                     "%d clouds/GPU x %d pts, %d instances, 4 primitive types" if args.workload == "global" else
@@ -198,12 +292,20 @@ def main():
                        "global_batch": BATCH_PER_GPU * world, "points": N_POINTS,
                        "parallelism": "dp%d" % world, "loss_last": float(out[0]),
                        "launch": ("eager" if trainer._graph is None else
-                                  "hipGraph replay (1 graph/step, device-side assignment)" if trainer._graph.get("single")
+                                  ("hipGraph replay (1 graph/step, device-side assignment%s)" % (
+                                      "" if world == 1 else ", RCCL all-reduce + Adam inside the graph" if trainer._graph.get("exchange_in_graph")
+                                      else ", RCCL all-reduce + Adam after the graph")) if trainer._graph.get("single")
                                   else "hipGraph replay (3 graphs/step around the host-side assignment)")},
             "roofline": {"bound": "hbm", "kernel": ROOFLINE_SYMBOL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": calls, "avg_launch_us": 1e6 * per_launch_s,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "measured": roof_mode},
+                         "launches": probe_launches or ev_calls, "avg_launch_us": 1e6 * per_launch_s,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "measured": roof_mode,
+                         "wall_clock_khz": wall_khz,
+                         "event_cross_check_us": 1e3 * ev_ms / max(ev_calls, 1),
+                         # the whole step against the same roofline: algorithmic bytes of EVERY kernel of one step
+                         # (each operand read once, each result written once) over the measured step time
+                         "step_bytes": step_bytes, "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_kernels_with_bytes": len(census)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

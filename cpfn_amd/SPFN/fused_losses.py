@@ -60,6 +60,7 @@ class HeadPost(torch.autograd.Function):
         with torch.cuda.device(dev):
             _l.check(h.cpfn_head_post_fwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), B, N, K, _ptr(Xn), _ptr(W), _ptr(ws),
                                           _ptr(stats), _ptr(seg_ws), _ptr(S), _stream()), "cpfn_head_post_fwd")
+        _l.add_bytes("cpfn_head_post_fwd", 4 * B * N * (C + 3 + 3 + K) + 8 * B * N + 8 * B * K)
         ctx.save_for_backward(Yc, Xg, Ig, Tg, W, stats)
         if with_seg:
             if S is None:
@@ -89,6 +90,8 @@ class HeadPost(torch.autograd.Function):
             _l.check(_l.lib().cpfn_head_post_bwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), _ptr(W), _ptr(stats), _ptr(gXn),
                                                  _ptr(gW), _ptr(gl), 1 if planar else 0, B, N, C - 7, _ptr(gY), _stream()),
                      "cpfn_head_post_bwd")
+        _l.add_bytes("cpfn_head_post_bwd", 4 * B * N * (2 * C + 3 + (C - 7) + (3 if gXn is not None else 0) + (C - 7 if gW is not None else 0))
+                     + 8 * B * N)
         return gY, None, None, None, None
 
 
@@ -108,6 +111,7 @@ class SegStats(torch.autograd.Function):
         S = torch.empty(B, K + 2, K, dtype=torch.float32, device=W.device)
         with torch.cuda.device(W.device):
             _l.check(h.cpfn_seg_stats_fwd(_ptr(Wc), _ptr(Ig), B, N, K, _ptr(ws), _ptr(S), _stream()), "cpfn_seg_stats_fwd")
+        _l.add_bytes("cpfn_seg_stats_fwd", 4 * B * N * K + 8 * B * N + 4 * B * (K + 2) * K)
         return S
 
     @staticmethod
@@ -118,6 +122,7 @@ class SegStats(torch.autograd.Function):
         dW = torch.empty(B, N, K, dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
             _l.check(_l.lib().cpfn_seg_stats_bwd(_ptr(g), _ptr(Ig), B, N, K, _ptr(dW), _stream()), "cpfn_seg_stats_bwd")
+        _l.add_bytes("cpfn_seg_stats_bwd", 4 * B * N * K + 8 * B * N + 4 * B * (K + 2) * K)
         return dW, None, None
 
 
@@ -135,6 +140,7 @@ class ResidueLoss(torch.autograd.Function):
             _l.check(_l.lib().cpfn_residue_fwd(_ptr(pc), _ptr(mc), _ptr(tc), _ptr(pts.contiguous().float()),
                                                _ptr(gt_axes.contiguous().float()), B, K, NP, ids, _ptr(out), _ptr(dout),
                                                _stream()), "cpfn_residue_fwd")
+        _l.add_bytes("cpfn_residue_fwd", 12 * B * K * NP + 4 * B * K * (22 + 9 + 2 + 10) + 16 * B * K)
         ctx.save_for_backward(dout, mc, tc)
         ctx.type_ids = tuple(type_ids)
         return out

@@ -150,6 +150,10 @@ class FitParams(torch.autograd.Function):
             _l.check(h.cpfn_cone_pass_fwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), B, N, K, _ptr(ws), _ptr(sums),
                                           st), "cpfn_cone_pass_fwd")
             _l.check(h.cpfn_fit_pack_fwd(_ptr(alg), _ptr(sums), _ptr(M), G, _ptr(params), st), "cpfn_fit_pack_fwd")
+        _l.add_bytes("cpfn_fit_moments_fwd", 4 * B * N * (6 + K) + 8 * (chunks + 1) * B * K * SLOTS)
+        _l.add_bytes("cpfn_fit_algebra_fwd", 8 * G * (SLOTS + 21) + 24 * G)
+        _l.add_bytes("cpfn_cone_pass_fwd", 4 * B * N * (3 + K) + 24 * G + 16 * (chunks + 1) * G)
+        _l.add_bytes("cpfn_fit_pack_fwd", 8 * G * (21 + 2 + SLOTS) + 88 * G)
         ctx.save_for_backward(P, X, W, M, cone_in, sums)
         return params
 
@@ -180,4 +184,8 @@ class FitParams(torch.autograd.Function):
             _l.check(h.cpfn_fit_algebra_bwd(_ptr(M), _ptr(g_alg), _ptr(gA0), G, None, _ptr(gM32), st), "cpfn_fit_algebra_bwd")
             _l.check(h.cpfn_fit_moments_bwd(_ptr(P), _ptr(X), _ptr(W), _ptr(gM32), B, N, K, _ptr(dWc), _ptr(dW), _ptr(dX), st),
                      "cpfn_fit_moments_bwd")
+        _l.add_bytes("cpfn_fit_pack_bwd", 88 * G + 8 * G * (2 + SLOTS + 21 + 1) + 4 * G)
+        _l.add_bytes("cpfn_cone_pass_bwd", 4 * B * N * (3 + 2 * K) + 28 * G + 48 * (chunks + 1) * G)
+        _l.add_bytes("cpfn_fit_algebra_bwd", 8 * G * (SLOTS + 22) + 4 * G * SLOTS)
+        _l.add_bytes("cpfn_fit_moments_bwd", 4 * B * N * (6 + 2 * K) + 4 * G * SLOTS + 4 * B * N * (K + 3))
         return None, dX, dW

@@ -45,6 +45,7 @@ def _scatter_bf16(g, ldg, idx, w, T, B, R, M, C):
     with torch.cuda.device(g.device):
         _l.check(_l.lib().cpfn_scatter_rows_bf16(_ptr(g), ldg, _ptr(idx), _ptr(w), T, B, R, M, C, _ptr(out), _stream()),
                  "cpfn_scatter_rows_bf16")
+    _l.add_bytes("cpfn_scatter_rows_bf16", 2 * B * R * C + 4 * B * R * T + 8 * B * M * C)
     return out
 
 
@@ -54,6 +55,9 @@ def _csr_sum_bf16(g, ldg, inv, w, T, B, R, M, C):
     with torch.cuda.device(g.device):
         _l.check(_l.lib().cpfn_csr_gather_sum_bf16(_ptr(g), ldg, _ptr(inv[0]), _ptr(inv[1]), _ptr(w), T, B, R, M, C, _ptr(out),
                                                    _stream()), "cpfn_csr_gather_sum_bf16")
+    # compulsory: every source row once, the inverse index (+ weights), one bf16 row per target (the kernel re-reads a
+    # source row once per (target, entry) pair it appears in: T times — that shows as traffic above this figure)
+    _l.add_bytes("cpfn_csr_gather_sum_bf16", 2 * B * R * C + 4 * B * R * T * (2 if w is not None else 1) + 4 * B * (M + 1) + 2 * B * M * C)
     return out
 
 
@@ -70,6 +74,7 @@ class InterpRowsBf16(torch.autograd.Function):
         with torch.cuda.device(f.device):
             _l.check(_l.lib().cpfn_interp_rows_bf16(_ptr(f), _ptr(idx), _ptr(w), B, M, N, C, _ptr(out), _stream()),
                      "cpfn_interp_rows_bf16")
+        _l.add_bytes("cpfn_interp_rows_bf16", 2 * B * M * C + 24 * B * N + 2 * B * N * C)
         ctx.save_for_backward(idx, w)
         ctx.inv = None if inv_off is None else (inv_off, inv_ent)
         ctx.dims = (B, M, N, C)
@@ -98,6 +103,7 @@ class GroupConcat(torch.autograd.Function):
         with torch.cuda.device(f.device):
             _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
                                                      _stream()), "cpfn_group_concat_bf16")
+        _l.add_bytes("cpfn_group_concat_bf16", 2 * B * N * C + 16 * B * R + 2 * B * R * cpad)
         ctx.save_for_backward(idx)
         ctx.inv = None if inv_off is None else (inv_off, inv_ent)
         ctx.dims = (B, N, R, C, cpad)
@@ -124,6 +130,7 @@ class ConcatPosFeats(torch.autograd.Function):
         with torch.cuda.device(feats_rows.device):
             _l.check(_l.lib().cpfn_concat_pos_feats_bf16(_ptr(xyz_rows.contiguous().float()), _ptr(feats_rows.contiguous()),
                                                          R, C, cpad, _ptr(out), _stream()), "cpfn_concat_pos_feats_bf16")
+            _l.add_bytes("cpfn_concat_pos_feats_bf16", 12 * R + 2 * R * C + 2 * R * cpad)
         ctx.C = C
         return out
 

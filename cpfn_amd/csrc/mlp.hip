@@ -42,6 +42,45 @@ __device__ __forceinline__ bf16x8 bn_relu_frag(bf16x8 v, const float *sc, const 
   return __builtin_bit_cast(bf16x8, o);
 }
 
+// ---- in-kernel timing probe of the GEMM family (bench.py's roofline leg) -----------------------------------------
+// A replayed hipGraph cannot be bracketed per kernel with host-side events, so when a probe is installed
+// (cpfn_mlp_gemm_set_probe) every launch of the family times ITSELF with the device's constant-rate wall clock
+// (s_memrealtime, 100 MHz): every workgroup stores its own (start, end) pair into the launch's slot of the probe
+// buffer — plain 16-byte stores, no atomics (a first version folded the times into one counter with two device-scope
+// atomics per workgroup: ~18 us per launch of pure atomic latency, the step went from 2.4 to 3.0 ms) — and the host
+// takes max(end) - min(start) per slot afterwards.  A launch captured into a graph keeps the slot it was given at
+// capture time, so after a run of replays the buffer holds the LAST replay's launches.  No probe (the default): the
+// argument is NULL and the cost is one uniform branch.
+struct GemmProbeSlot {
+  unsigned long long nwg, pad;                 // header: workgroups of the launch that wrote this slot
+  unsigned long long t[1][2];                  // [workgroup][start, end] (max_wg entries)
+};
+struct GemmProbeState {
+  unsigned long long *buf = nullptr;           // slots x (2 + 2 max_wg) u64
+  int slots = 0, max_wg = 0;
+  unsigned next = 0;                           // launches handed a slot so far
+};
+GemmProbeState g_probe_state;
+// slot of the launch being issued (NULL: probe off or grid too large for a slot)
+static inline unsigned long long *probe_slot(dim3 grid) {
+  GemmProbeState &p = g_probe_state;
+  if (!p.buf || (long long)grid.x * grid.y * grid.z > p.max_wg) return nullptr;
+  return p.buf + (size_t)(p.next++ % (unsigned)p.slots) * (2 + 2 * (size_t)p.max_wg);
+}
+__device__ __forceinline__ unsigned long long probe_begin(const unsigned long long *slot) {
+  return slot ? (unsigned long long)wall_clock64() : 0ull;
+}
+__device__ __forceinline__ void probe_end(unsigned long long *slot, unsigned long long t0) {
+  if (!slot) return;
+  __syncthreads();                // every wave of the workgroup has issued its last store
+  if (threadIdx.x == 0) {
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+    *(u64x2 *)&slot[2 + 2 * (size_t)wg] = (u64x2){t0, (unsigned long long)wall_clock64()};
+    if (wg == 0) slot[0] = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
+  }
+}
+
 constexpr int G_THREADS = 256;
 constexpr int G_ROWS = 128;   // points per workgroup tile (4 waves x 32)
 constexpr int G_KC = 128;     // K chunk staged in LDS
@@ -275,8 +314,9 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
     const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr,
-    const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */) {
+    const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */, unsigned long long *probe = nullptr) {
   constexpr int NT = BN / 16, K = 32 * KS, CPR = BN / 8;
+  const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
   __shared__ __attribute__((aligned(16))) unsigned short s_o[4][32 * G_LDO];
   __shared__ __attribute__((aligned(16))) float s_red[4][2][BN];
@@ -340,6 +380,7 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
       stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c] = s;
     }
   }
+  probe_end(probe, probe_t0);
 }
 
 // ---- generic kernel: K chunks of 128 through a DOUBLE-BUFFERED LDS weight panel.
@@ -426,8 +467,9 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
     const unsigned short *__restrict__ A, int lda, const int *__restrict__ gidx,
     const unsigned short *__restrict__ W, int w_trans, int P, int K, int N, void *__restrict__ Y, int ldy, int y_f32,
     int n_store, const float *__restrict__ bias, float *__restrict__ stats_partial, int tiles_per_wg,
-    const float *__restrict__ a_scale, const float *__restrict__ a_shift) {
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe) {
   constexpr int NT = BN / 16;
+  const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ __attribute__((aligned(16))) unsigned short s_w[2][BN * G_LDW];
   __shared__ float s_red[4][2][BN];
   __shared__ __attribute__((aligned(16))) float s_ss[2][G_SS_MAX];
@@ -571,6 +613,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
       if (n0 + c2 < N) stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c2] = s;
     }
   }
+  probe_end(probe, probe_t0);
 }
 
 template <int LD>
@@ -612,8 +655,9 @@ template <int RT, bool STATS, bool WT>
 __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
     const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
     int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
-    const float *__restrict__ a_scale, const float *__restrict__ a_shift) {
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe) {
   constexpr int TT = RT / 16, D = SP_DEPTH, LDT = 64 + 8;
+  const unsigned long long probe_t0 = probe_begin(probe);
   constexpr int RAW_TILE = 4 * 32 * LDT * 2, RAW_RED = 4 * 4 * TT * 64 * 16;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW_TILE > RAW_RED ? RAW_TILE : RAW_RED];
   __shared__ __attribute__((aligned(16))) float s_ss[2][SP_SS_MAX];
@@ -741,6 +785,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
       *(f32x4 *)&stats_partial[((size_t)blockIdx.x * 2 + 1) * N + n] = sq;
     }
   }
+  probe_end(probe, probe_t0);
 }
 
 // ---------------------------------------------------------------- BatchNorm finalize (forward)
@@ -1473,6 +1518,17 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   return (int)((tiles + tpw - 1) / tpw);
 }
 
+extern "C" int cpfn_mlp_gemm_set_probe(void *buf, int slots, int max_wg) {
+  // buf: slots * (2 + 2 * max_wg) u64 of device memory, zero-filled by the caller (or NULL: probe off).  Applies to
+  // every cpfn_mlp_gemm launch issued (or captured into a graph) from now on; launch i gets slot i % slots.
+  if (buf && (slots <= 0 || max_wg <= 0)) return CPFN_EINVAL;
+  g_probe_state.buf = (unsigned long long *)buf;
+  g_probe_state.slots = buf ? slots : 0;
+  g_probe_state.max_wg = buf ? max_wg : 0;
+  g_probe_state.next = 0;
+  return 0;
+}
+
 static inline bool gemm_stream_k(long long P, int K) {
   // whole-K panel in LDS: K <= 256.  K = 192 / 256 only for the long layers: with few row tiles the 50-68 KB panel
   // (cold in a real step, unlike in a micro-benchmark loop) costs more than the generic kernel's 128-wide K chunks
@@ -1507,10 +1563,10 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
     const int a_bytes = (int)(((P - 1) * lda + K) * 2);
 #define CPFN_SMALLP(RT_)                                                                                              \
   do {                                                                                                                \
-    if (stats_partial && w_trans) mlp_gemm_smallp_kernel<RT_, true, true><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift);  \
-    else if (stats_partial) mlp_gemm_smallp_kernel<RT_, true, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift);       \
-    else if (w_trans) mlp_gemm_smallp_kernel<RT_, false, true><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, nullptr, a_scale, a_shift);                  \
-    else mlp_gemm_smallp_kernel<RT_, false, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, nullptr, a_scale, a_shift);                             \
+    if (stats_partial && w_trans) mlp_gemm_smallp_kernel<RT_, true, true><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift, probe_slot(grid));  \
+    else if (stats_partial) mlp_gemm_smallp_kernel<RT_, true, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift, probe_slot(grid));       \
+    else if (w_trans) mlp_gemm_smallp_kernel<RT_, false, true><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, nullptr, a_scale, a_shift, probe_slot(grid));                  \
+    else mlp_gemm_smallp_kernel<RT_, false, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, nullptr, a_scale, a_shift, probe_slot(grid));                             \
   } while (0)
     if (sp_rows(P, N) == 32) CPFN_SMALLP(32); else CPFN_SMALLP(64);
 #undef CPFN_SMALLP
@@ -1527,13 +1583,13 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   do {                                                                                                               \
     dim3 grid(gx, N / BN_);                                                                                          \
     if (bwd_y)                                                                                                       \
-      mlp_gemm_stream_kernel<BN_, KS_, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift, (const unsigned short *)bwd_y); \
+      mlp_gemm_stream_kernel<BN_, KS_, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift, (const unsigned short *)bwd_y, probe_slot(grid)); \
     else if (stats_partial && a_scale)                                                                               \
-      mlp_gemm_stream_kernel<BN_, (KS_ <= 4 ? KS_ : 4), true, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift); \
+      mlp_gemm_stream_kernel<BN_, (KS_ <= 4 ? KS_ : 4), true, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, a_scale, a_shift, nullptr, probe_slot(grid)); \
     else if (stats_partial)                                                                                          \
-      mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw); \
+      mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, stats_partial, tpw, nullptr, nullptr, nullptr, probe_slot(grid)); \
     else                                                                                                             \
-      mlp_gemm_stream_kernel<BN_, KS_, false><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, nullptr, tpw);      \
+      mlp_gemm_stream_kernel<BN_, KS_, false><<<grid, G_THREADS, 0, st>>>(a, lda, w, w_trans, (int)P, N, y, ldy, nullptr, tpw, nullptr, nullptr, nullptr, probe_slot(grid));      \
   } while (0)
     if (N % 128 == 0) {
       switch (K) { case 64: CPFN_STREAM(128, 2); break; case 128: CPFN_STREAM(128, 4); break;
@@ -1550,15 +1606,15 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   if (wide) {
     dim3 grid(gx, N / 128);
     if (stats_partial)
-      mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw, a_scale, a_shift);
+      mlp_gemm_kernel<128, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw, a_scale, a_shift, probe_slot(grid));
     else
-      mlp_gemm_kernel<128, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw, a_scale, a_shift);
+      mlp_gemm_kernel<128, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw, a_scale, a_shift, probe_slot(grid));
   } else {
     dim3 grid(gx, N / 64);
     if (stats_partial)
-      mlp_gemm_kernel<64, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw, a_scale, a_shift);
+      mlp_gemm_kernel<64, true><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, stats_partial, tpw, a_scale, a_shift, probe_slot(grid));
     else
-      mlp_gemm_kernel<64, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw, a_scale, a_shift);
+      mlp_gemm_kernel<64, false><<<grid, G_THREADS, 0, st>>>(a, lda, gidx, w, w_trans, (int)P, K, N, Y, ldy, y_f32, n_store, bias, nullptr, tpw, a_scale, a_shift, probe_slot(grid));
   }
   return cpfn_launch_status();
 }

@@ -87,6 +87,7 @@ def bn_finalize(part, nblk, N, count, gamma, beta, conv_bias, eps, momentum, rm,
     _check(_l.lib().cpfn_bn_finalize(_ptr(part), nblk, N, float(count), _ptr(gamma), _ptr(beta), _ptr(conv_bias),
                                      float(eps), float(momentum), _ptr(rm), _ptr(rv), _ptr(out[0]), _ptr(out[1]),
                                      _ptr(out[2]), _ptr(out[3]), _stream()), "cpfn_bn_finalize")
+    _l.add_bytes("cpfn_bn_finalize", 8 * nblk * N + 40 * N)
     return out
 
 
@@ -96,11 +97,13 @@ def bn_relu_apply(Y, scale, shift, dropout=None):
     if dropout is None:
         _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), None, 0, 0.0,
                                            None, _stream()), "cpfn_bn_relu_apply")
+        _l.add_bytes("cpfn_bn_relu_apply", 4 * Y.numel())
         return out
     p, counter, base = dropout
     seed = torch.empty(1, dtype=torch.int64, device=Y.device)
     _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), _ptr(counter),
                                        int(base) & 0xFFFFFFFFFFFFFFFF, float(p), _ptr(seed), _stream()), "cpfn_bn_relu_apply")
+    _l.add_bytes("cpfn_bn_relu_apply", 4 * Y.numel())
     if _defer_counters is not None:
         _defer_counters.append(counter)      # advanced with the BatchNorm counters at the end of the forward pass
     else:
@@ -116,6 +119,7 @@ def bn_relu_maxpool(Y, scale, shift, Kn):
     yarg = torch.empty(G, C, dtype=BF16, device=Y.device)
     _check(_l.lib().cpfn_bn_relu_maxpool(_ptr(Y), _ptr(scale), _ptr(shift), G, Kn, C, _ptr(out), _ptr(arg), _ptr(yarg),
                                          _stream()), "cpfn_bn_relu_maxpool")
+    _l.add_bytes("cpfn_bn_relu_maxpool", 2 * Y.numel() + 5 * G * C)
     return out, arg, yarg
 
 
@@ -141,6 +145,7 @@ def _flush_reductions():
     dev = todo[0][0].device
     with torch.cuda.device(dev):
         _check(_l.lib().cpfn_multi_split_reduce(arr, len(todo), _stream()), "cpfn_multi_split_reduce")
+    _l.add_bytes("cpfn_multi_split_reduce", sum(4 * n * (splits + 1) for _, _, n, splits, _, _ in todo))
 
 
 def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0):
@@ -240,6 +245,7 @@ def refresh_weight_panels(params):
         _cast_cache[key] = arr
     with torch.cuda.device(dev):
         _check(_l.lib().cpfn_multi_cast(arr, len(jobs), _stream()), "cpfn_multi_cast")
+    _l.add_bytes("cpfn_multi_cast", sum(6 * r * c for _, _, r, c, _, _ in jobs))
     for ent in ents:
         ent[2] = _refresh_epoch[0]
     for ent in packed:
@@ -320,6 +326,7 @@ class _FusedStack(torch.autograd.Function):
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                     _check(h.cpfn_smallk_fwd(_ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
                            "cpfn_smallk_fwd")
+                    _l.add_bytes("cpfn_smallk_fwd", 4 * P * KS + 2 * P * N + 8 * nblk * N)
                     Wb = None
                 else:
                     Kp = a.shape[1]
@@ -388,12 +395,15 @@ class _FusedStack(torch.autograd.Function):
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                     _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, None, _ptr(part),
                                               None, 0.0, _stream()), "cpfn_bn_relu_bwd")
+                    _l.add_bytes("cpfn_bn_relu_bwd", 4 * G * N + 8 * nblk * N)
                     _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
+                    _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                     Gy = torch.empty(P, N, dtype=BF16, device=dev)
                     _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
                                                     _ptr(coef), G, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
+                    _l.add_bytes("cpfn_bn_pool_bwd_apply", 4 * P * N + 5 * G * N)
                 else:
                     nblk = h.cpfn_bn_bwd_blocks(P)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
@@ -411,15 +421,19 @@ class _FusedStack(torch.autograd.Function):
                     else:
                         _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None if nostore else _ptr(Gy),
                                                   _ptr(part), _ptr(dseed), dp, _stream()), "cpfn_bn_relu_bwd")
+                        _l.add_bytes("cpfn_bn_relu_bwd", (4 if nostore else 6) * P * N + 8 * nblk * N)
                     _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
+                    _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                     if nostore:
                         _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
                                                    _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
+                        _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
                     else:       # (the stored g_z already carries the dropout mask)
                         _check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), None, None, P, N, _ptr(Gy), None, 0.0, _stream()),
                                "cpfn_bn_bwd_apply")
+                        _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
                 grads[3 * li + 1] = dgb[0]
                 grads[3 * li + 2] = dgb[1]
                 wshape = L.weight.shape
@@ -429,6 +443,7 @@ class _FusedStack(torch.autograd.Function):
                     ws = torch.empty(nb * N * KS, dtype=torch.float32, device=dev)
                     dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
                     _check(h.cpfn_smallk_wgrad(_ptr(Gy), _ptr(a_in), KS, P, N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad")
+                    _l.add_bytes("cpfn_smallk_wgrad", 2 * P * N + 4 * P * KS + 8 * nb * N * KS)
                     grads[0] = dW.reshape(wshape)
                 else:
                     Kp = a_in.shape[1]
@@ -437,6 +452,7 @@ class _FusedStack(torch.autograd.Function):
                     _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
                                             None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
                                             _ptr(ws), None, _stream()), "cpfn_mlp_wgrad")
+                    _l.add_bytes("cpfn_mlp_wgrad", 2 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
                     # the split partials are finished by ONE launch at the end of the backward pass; a zero-padded K
                     # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
                     dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
@@ -540,11 +556,13 @@ class _Linear(torch.autograd.Function):
         with torch.cuda.device(a.device):
             _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), _ptr(gbias), _ptr(gb) if fused_pad else None, _stream()),
                    "cpfn_colsum_f32")
+            _l.add_bytes("cpfn_colsum_f32", 4 * P * N + (2 * P * Np if fused_pad else 0))
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
             dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
             _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), _ptr(dW), _stream()),
                    "cpfn_mlp_wgrad")
+            _l.add_bytes("cpfn_mlp_wgrad", 2 * P * Np + 2 * P * K + 8 * splits * Np * K)
             ga, _, _ = gemm(gb, Wb, w_trans=True)
         gw, gbs, o = [], [], 0
         for n, shp in zip(ctx.sizes, ctx.wshapes):

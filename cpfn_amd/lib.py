@@ -67,6 +67,8 @@ SIGNATURES = {
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
+    "cpfn_mlp_gemm_set_probe": [_vp, _i, _i],
+    "cpfn_wall_clock_khz": [_i],
     "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_bn_relu_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp, ctypes.c_uint64, _f, _vp, _vp],
     "cpfn_bn_relu_maxpool": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -103,6 +105,7 @@ _timed = {}
 
 
 _bytes = {}
+_census = None      # {symbol: [launches, algorithmic bytes]} while a byte census is running
 
 
 def time_symbols(names):
@@ -115,13 +118,29 @@ def time_symbols(names):
 
 
 def add_bytes(name, nbytes):
-    """Callers that know a launch's ALGORITHMIC traffic report it here while timing is on."""
+    """Callers that know a launch's ALGORITHMIC traffic (every operand read once, every result written once) report
+    it here; counted only while timing of that symbol or a byte census is on."""
     if name in _bytes:
         _bytes[name] += int(nbytes)
+    if _census is not None:
+        ent = _census.setdefault(name, [0, 0])
+        ent[0] += 1
+        ent[1] += int(nbytes)
 
 
 def timed_bytes(name):
     return _bytes.get(name, 0)
+
+
+def byte_census(on):
+    """Start (True) / stop (False) counting the algorithmic bytes of every instrumented entry point.
+    Stop returns {symbol: (launches, bytes)}."""
+    global _census
+    if on:
+        _census = {}
+        return None
+    out, _census = _census, None
+    return {k: tuple(v) for k, v in (out or {}).items()}
 
 
 def timed_report():

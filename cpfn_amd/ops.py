@@ -46,6 +46,7 @@ def fps(xyz, num_samples, start=None, skip_near_origin=False):
     with torch.cuda.device(xyz.device):
         _l.check(_l.lib().cpfn_fps(_ptr(xyz), B, N, int(num_samples), _ptr(start),
                                    1 if skip_near_origin else 0, _ptr(out), _ptr(scratch), _stream()), "cpfn_fps")
+    _l.add_bytes("cpfn_fps", 12 * B * N + 4 * B * int(num_samples))
     return out
 
 
@@ -65,6 +66,7 @@ def ball_query(new_xyz, xyz, radius, nsample, cuda_route=False):
         else:
             _l.check(_l.lib().cpfn_ball_query(_ptr(xyz), _ptr(new_xyz), B, N, S, ball_query_threshold(radius),
                                               int(nsample), _ptr(out), _stream()), "cpfn_ball_query")
+    _l.add_bytes("cpfn_ball_query", 12 * B * (N + S) + 4 * B * S * int(nsample))
     return out
 
 
@@ -87,6 +89,7 @@ def three_nn(unknown, known, cuda_route=False, sqrt=False):
                 raise RuntimeError("sqrt distances exist on the CUDA route only")
             _l.check(_l.lib().cpfn_three_nn(_ptr(unknown), _ptr(known), B, N, M, _ptr(d), _ptr(i), _stream()),
                      "cpfn_three_nn")
+    _l.add_bytes("cpfn_three_nn", 12 * B * (N + M) + 24 * B * N)
     return d, i
 
 
@@ -107,6 +110,7 @@ def three_weights(dist):
     w = torch.empty_like(dist)
     with torch.cuda.device(dist.device):
         _l.check(_l.lib().cpfn_three_weights(_ptr(dist), dist.numel() // 3, _ptr(w), _stream()), "cpfn_three_weights")
+    _l.add_bytes("cpfn_three_weights", 8 * dist.numel())
     return w
 
 
@@ -169,6 +173,7 @@ def gather_rows(rows, idx):
     with torch.cuda.device(rows.device):
         _l.check(_l.lib().cpfn_gather_rows(_ptr(rows), _ptr(idx), B, N, R, C * rows.element_size(), _ptr(out),
                                            _stream()), "cpfn_gather_rows")
+    _l.add_bytes("cpfn_gather_rows", rows.element_size() * (B * N * C + B * R * C) + 4 * B * R)
     return out
 
 
@@ -194,6 +199,7 @@ def group_xyz_centered(xyz, new_xyz, idx):
     with torch.cuda.device(xyz.device):
         _l.check(_l.lib().cpfn_group_xyz_centered(_ptr(xyz), _ptr(new_xyz), _ptr(idx), B, N, S, K, _ptr(out),
                                                   _stream()), "cpfn_group_xyz_centered")
+    _l.add_bytes("cpfn_group_xyz_centered", 12 * B * (N + S) + 16 * B * S * K)
     return out
 
 
@@ -229,4 +235,5 @@ def csr_build(idx, M):
     ent = torch.empty(B, E, dtype=torch.int32, device=idx.device)
     with torch.cuda.device(idx.device):
         _l.check(_l.lib().cpfn_csr_build(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _stream()), "cpfn_csr_build")
+    _l.add_bytes("cpfn_csr_build", 8 * B * E + 4 * B * (M + 1))
     return off, ent

@@ -76,6 +76,7 @@ class FlatAdam(torch.optim.Optimizer):
                                       float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows), _ptr(self.found_inf),
                                       _ptr(self._coef), _ptr(nf_ws), nf_count, _ptr(skipped), _stream()),
                      "cpfn_adam_flat")
+        _l.add_bytes("cpfn_adam_flat", 28 * self.flat_p.numel() + (4 * grads.numel() if check_gradients and nf_flags is None else 0))
 
     def state_dict(self):
         return {"flat": {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,

@@ -5,6 +5,8 @@ fitters), backward, non-finite-gradient guard, Adam — plus what the reference 
 data-parallel training, one process per GPU, with ONE flat fp32 gradient bucket
 all-reduced over RCCL (xGMI) per step.
 """
+import os
+
 import numpy as np
 
 import torch
@@ -101,9 +103,15 @@ class FlatGradBucket:
         return flags
 
     def all_reduce_mean(self):
+        """The step's one exchange: mean of the flat gradient over the ranks.  RCCL (backend "nccl"): ONE collective
+        with the averaging done inside it (ncclAvg) — no scaling launch, capturable in the step's graph.  Other
+        backends (gloo on CPU): sum + divide."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+            if self.flat.is_cuda and dist.get_backend() == "nccl":
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.flat.div_(dist.get_world_size())
 
     def finite(self):
         """One fused reduction instead of the reference's per-parameter isinf/isnan scan
@@ -161,6 +169,7 @@ class SPFNTrainer:
         else:
             self.optimizer = torch.optim.Adam(module.parameters(), lr=init_learning_rate)
         self._graph, self._graph_warm = None, 0
+        self._exchange_in_graph = os.environ.get("CPFN_EXCHANGE_IN_GRAPH", "1") != "0"
         self._gstream, self._in_gstream, self._gside = None, False, None
         self.global_step = 0
         # Like the reference (training_utils.py:100, 111-114) the momentum is only WRITTEN when the staircase value
@@ -332,6 +341,7 @@ class SPFNTrainer:
             return None
         arr = (_D * len(fast))(*fast)
         h = _l.lib()
+        _l.add_bytes("cpfn_multi_copy", 2 * sum(f.bytes for f in fast))
         with torch.cuda.device(dst[0].device):
             stream = torch.cuda.current_stream().cuda_stream
             if flags is not None and slow == 0 and all(t.dtype == torch.float32 for t in src):
@@ -361,7 +371,10 @@ class SPFNTrainer:
             out[lvl] = d
         return out
 
-    def _capture(self, batch):
+    def _capture(self, batch, exchange_in_graph=True):
+        """exchange_in_graph (data parallel only): capture the RCCL all-reduce and the optimizer inside the step's
+        graph; False = the graph ends after the gradient packing and the exchange + optimizer follow as eager
+        launches (what step() falls back to if the collective cannot be captured on this stack)."""
         from .SPFN import fused_losses as fl
         # The parameters' AccumulateGrad nodes were created by the eager warm-up steps on the default stream and are
         # reused while capturing on the capture stream: autograd warns about that on every backward pass although the
@@ -437,9 +450,15 @@ class SPFNTrainer:
                 nf = self.bucket.collect(check=world == 1)
                 if world == 1:
                     self._checked_optimizer_step(st["skipped"], nf)
+                elif exchange_in_graph:
+                    # data parallel: the gradient exchange (one RCCL all-reduce with in-collective averaging over the
+                    # 5.6 MB flat bucket) and the optimizer are nodes of the SAME graph: still one replay per step
+                    self.bucket.all_reduce_mean()
+                    self._checked_optimizer_step(st["skipped"])
                 st["out"] = tuple(o.detach() for o in out)
                 self._gstream.wait_stream(self._gside)              # join
             st["g"] = g
+            st["exchange_in_graph"] = world > 1 and exchange_in_graph
             st["geom_ready_for"] = None
             return st
         # ---- CPFN_HOST_ASSIGNMENT=1: SciPy on the host like the reference; graphs split at that round trip
@@ -527,7 +546,7 @@ class SPFNTrainer:
                 self._draw_starts(st, B, N)
             st["geom_ready_for"] = self._batch_key(next_batch["P"]) if announce else None
             st["g"].replay()                                   # the whole step: no host synchronisation
-            if st["world"] > 1:
+            if st["world"] > 1 and not st["exchange_in_graph"]:
                 self.bucket.all_reduce_mean()
                 self._checked_optimizer_step(st["skipped"])
             self.global_step += 1
@@ -570,7 +589,20 @@ class SPFNTrainer:
         if self.use_graphs and not force_eager and fps_start is None and batch["P"].is_cuda:
             if self._graph is None and self._graph_warm >= 2:
                 try:
-                    self._graph = self._capture(batch)
+                    try:
+                        self._graph = self._capture(batch, exchange_in_graph=self._exchange_in_graph)
+                    except Exception as e:
+                        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+                        if world == 1 or not self._exchange_in_graph:
+                            raise
+                        # the collective could not be captured on this stack: keep the replayed step, with the
+                        # exchange + optimizer as eager launches after it (still no host synchronisation)
+                        import warnings
+                        warnings.warn("RCCL all-reduce not capturable here (%s: %s); exchange stays outside the graph"
+                                      % (type(e).__name__, e))
+                        torch.cuda.synchronize()
+                        self._exchange_in_graph = False
+                        self._graph = self._capture(batch, exchange_in_graph=False)
                 except Exception as e:          # capture is an optimisation: fall back to eager launches
                     if self.require_graphs:     # ... unless the caller asked for the replayed step (bench.py does)
                         raise

@@ -274,6 +274,15 @@ CPFN_API int cpfn_mlp_gemm_blocks(long long P, int N);
  * g_z = g_a*[a_scale*y + a_shift > 0], the layout cpfn_bn_relu_bwd writes — so cpfn_bn_relu_bwd is not needed for
  * it.  Only where cpfn_mlp_gemm_can_fuse_bwd_stats(P,K,N) returns 1 (the streaming kernel). */
 CPFN_API int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N);
+/* Timing probe of the GEMM family (measurement only; bench.py's roofline leg).  buf = slots * (2 + 2*max_wg) u64 of
+ * zero-filled device memory, or NULL to switch the probe off (default).  While installed, launch i of cpfn_mlp_gemm
+ * — including launches captured into a hipGraph, which host-side events cannot bracket one by one — writes into slot
+ * i % slots: [0] = its number of workgroups, [2 + 2w], [3 + 2w] = start / end of workgroup w in ticks of the device's
+ * constant-rate wall clock (hipDeviceAttributeWallClockRate, 100 MHz on gfx950); plain stores, no atomics.  The
+ * launch's duration is max(end) - min(start).  A captured launch keeps its slot across replays. */
+CPFN_API int cpfn_mlp_gemm_set_probe(void *buf, int slots, int max_wg);
+/* Rate in kHz of the device wall clock the probe's ticks are counted in (hipDeviceAttributeWallClockRate); <= 0 on error. */
+CPFN_API int cpfn_wall_clock_khz(int device);
 CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
                            float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,

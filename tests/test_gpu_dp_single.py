@@ -1,6 +1,6 @@
 """GPU: the data-parallel launch path of the graph-replayed trainer on ONE device — an RCCL process group
-of size 1 with the world size spoofed to 2, so the 'all-reduce outside the graphs + eager capturable Adam'
-branch of SPFNTrainer runs for real (a true multi-GPU run needs a multi-GPU node; the driver does that
+of size 1 with the world size spoofed to 2, so the data-parallel branch of SPFNTrainer (RCCL all-reduce with
+in-collective averaging + the flat optimizer captured INSIDE the step's graph) runs for real (a true multi-GPU run needs a multi-GPU node; the driver does that
 with bench.py).  Runs in a subprocess so the process group does not leak into other tests."""
 import os
 import subprocess
@@ -21,5 +21,17 @@ def test_graph_trainer_with_rccl_group():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("graph captured")][-1]
     assert "graph captured: True" in line and "world in graph: 2" in line and "skipped 0.0" in line, line
+    assert "exchange in graph: True" in line, line + r.stderr[-1500:]
     first, last = [float(x) for x in line.split("loss")[1].split("skipped")[0].replace("->", " ").split()]
     assert last < 0.75 * first, line
+
+
+@pytest.mark.timeout(300)
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` launches its own ranks; asking for more GPUs than the box has must fail loudly instead
+    of reporting a 1-GPU number under another name."""
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "2", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and "GPUs requested" in r.stderr and not r.stdout.strip(), (r.returncode, r.stdout, r.stderr)

@@ -1,17 +1,28 @@
 #!/bin/bash
 # Everything profiles/ is refreshed from, in one gpurun call (run on the GPU box from the repo root):
-#   bash tools/collect_profiles.sh   ->  gpurun_out/collect/{stats,fetch,write}/..., bench_n1.json, bench_n1_eager.json
+#   bash tools/collect_profiles.sh [tag]  ->  gpurun_out/collect/... and profiles/<tag>_*
+# Counter passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa tracing), eager launches.
+tag=${1:-r02}
 repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
-out=gpurun_out/collect
-mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline > $out/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o f -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-graphs > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o w -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-graphs > $out/write.log 2>&1
-python3 tools/pmc_traffic.py $out/fetch $out/write > $out/mlp_gemm_traffic.json 2> $out/traffic.err
-cp $out/mlp_gemm_traffic.json profiles/r01_mlp_gemm_traffic.json     # bench.py reads the traffic figure from here
-python3 bench.py --steps 300 --warmup 30 2> $out/bench.err | tail -1 > $out/bench_n1.json
-python3 bench.py --steps 50 --warmup 10 --no-graphs --no-cpu-baseline 2> $out/bench_eager.err | tail -1 > $out/bench_n1_eager.json
-rm -f $out/fetch/*kernel_trace.csv $out/write/*kernel_trace.csv
-ls -la $out $out/stats | head -30
+mkdir -p gpurun_out/collect
+B="bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/collect/stats -o s -- python3 $B --steps 10 --warmup 5 > gpurun_out/collect/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/fetch -o f -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/write -o w -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/collect/mfma -o m -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/mfma.log 2>&1
+python3 $B --steps 5 --warmup 5 --census-out gpurun_out/collect/census.json > gpurun_out/collect/census.log 2>&1
+python3 tools/rooflines.py --trace gpurun_out/collect/stats --fetch gpurun_out/collect/fetch --write gpurun_out/collect/write \
+    --mfma gpurun_out/collect/mfma --census gpurun_out/collect/census.json \
+    --traffic-out profiles/${tag}_mlp_gemm_traffic.json > profiles/${tag}_rooflines.json 2> gpurun_out/collect/rooflines.err
+python3 tools/replay_breakdown.py $(find gpurun_out/collect/stats -name '*kernel_trace.csv' | head -1) > profiles/${tag}_replayed_step_breakdown.txt 2> gpurun_out/collect/breakdown.err
+cp $(find gpurun_out/collect/stats -name '*kernel_stats.csv' | head -1) profiles/${tag}_graph_kernel_stats.csv
+python3 bench.py --steps 300 --warmup 30 2> gpurun_out/collect/bench.err | tail -1 > profiles/${tag}_bench_n1.json
+python3 bench.py --steps 50 --warmup 10 --no-graphs --no-cpu-baseline 2> gpurun_out/collect/bench_eager.err | tail -1 > profiles/${tag}_bench_n1_eager.json
+python3 bench.py --steps 100 --warmup 10 --workload local 2> gpurun_out/collect/bench_local.err | tail -1 > profiles/${tag}_bench_local_n1.json
+# the traces are large: only the summaries travel back (gpurun merges <= 64 MiB)
+find gpurun_out/collect -name '*kernel_trace.csv' -size +8M -delete
+find gpurun_out/collect -name '*.db' -delete
+find gpurun_out/collect -name '*counter_collection.csv' -size +8M -delete
+tail -3 gpurun_out/collect/rooflines.err gpurun_out/collect/breakdown.err; ls -la profiles | tail -12; head -c 1200 profiles/${tag}_rooflines.json
