@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--workload", default="global", choices=["global", "local"],
                     help="global (default) = BASELINE.json configs[1], the config the metric is quoted on; local = "
                          "configs[2] (LocalSPFN: 32 patches/GPU, 21 instances, fitter losses off) as an extra data point")
+    ap.add_argument("--census-out", default=None, help="write the per-entry-point algorithmic bytes of one step (JSON)")
     return ap.parse_args()
 
 
@@ -220,6 +221,8 @@ def main():
     lib.byte_census(True)
     trainer.step(batch, force_eager=True)
     census = lib.byte_census(False)
+    if args.census_out and rank == 0:
+        json.dump({k: list(v) for k, v in census.items()}, open(args.census_out, "w"), indent=1)
     sync()
     probe.zero_()                                       # only the launches of the timed region will be in it afterwards
     sync()

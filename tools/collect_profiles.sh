@@ -25,4 +25,4 @@ python3 bench.py --steps 100 --warmup 10 --workload local 2> gpurun_out/collect/
 find gpurun_out/collect -name '*kernel_trace.csv' -size +8M -delete
 find gpurun_out/collect -name '*.db' -delete
 find gpurun_out/collect -name '*counter_collection.csv' -size +8M -delete
-tail -3 gpurun_out/collect/rooflines.err gpurun_out/collect/breakdown.err; ls -la profiles | tail -12; head -c 1200 profiles/${tag}_rooflines.json
+tail -n 3 gpurun_out/collect/rooflines.err; tail -n 3 gpurun_out/collect/breakdown.err; ls -la profiles | tail -12; head -c 1200 profiles/${tag}_rooflines.json
