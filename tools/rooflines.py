@@ -37,6 +37,7 @@ ENTRY = {
     "gather_rows_kernel": "cpfn_gather_rows", "group_xyz_centered_kernel": "cpfn_group_xyz_centered",
 }
 HBM_PEAK = 8.0e12
+CLOCK_HZ, N_SIMD = 2.4e9, 1024
 
 
 def base(name):
@@ -103,12 +104,12 @@ def main():
             e["hbm_write"] += 1024.0 * w[0] / max(w[1], 1) * n
             e["pmc_launches"] += f[1]
         if k in mf:
-            g = lambda c: mf[k].get(c, [0.0, 0])
-            e["mfma_busy"] += g("SQ_VALU_MFMA_BUSY_CYCLES")[0]
-            e["sq_busy"] += g("SQ_BUSY_CYCLES")[0]
-            e["mops"] += g("SQ_INSTS_VALU_MFMA_MOPS_BF16")[0]
-            e["valu_active"] += g("SQ_ACTIVE_INST_VALU")[0]
-            e["wave_cycles"] += g("SQ_WAVE_CYCLES")[0]
+            g = lambda c: mf[k].get(c, [0.0, 0])[0] / max(mf[k].get(c, [0.0, 0])[1], 1) * n      # per step
+            e["mfma_busy"] += g("SQ_VALU_MFMA_BUSY_CYCLES")
+            e["sq_busy"] += g("SQ_BUSY_CYCLES")
+            e["mops"] += g("SQ_INSTS_VALU_MFMA_MOPS_BF16")
+            e["valu_active"] += g("SQ_ACTIVE_INST_VALU")
+            e["wave_cycles"] += g("SQ_WAVE_CYCLES")
     table, tot_alg, tot_us, tot_traffic = [], 0.0, 0.0, 0.0
     for key, e in fam.items():
         alg = census.get(key, [0, 0])
@@ -127,9 +128,17 @@ def main():
             if alg[1]:
                 row["traffic_over_algorithmic"] = round((e["hbm_read"] + e["hbm_write"]) / alg[1], 3)
         if e["sq_busy"]:
-            row["mfma_busy_over_sq_busy"] = round(e["mfma_busy"] / e["sq_busy"], 4)
+            # matrix-core utilisation: cycles a SIMD's MFMA pipe was busy, summed over the chip, against the kernel time
+            # x 1024 SIMDs x the shader clock (nominal 2.4 GHz; the clock under load is not read here)
+            simd_cycles = e["us_per_step"] * 1e-6 * CLOCK_HZ * N_SIMD
+            row["mfma_busy_cycles_per_step"] = round(e["mfma_busy"])
+            row["mfma_utilisation"] = round(e["mfma_busy"] / simd_cycles, 4)
+            # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles per wave: the share of a resident wave's time in
+            # which it issues vector-ALU instructions
             row["valu_active_over_wave_cycles"] = round(e["valu_active"] / e["wave_cycles"], 4) if e["wave_cycles"] else None
-            row["mfma_mops_bf16"] = e["mops"]
+            row["mfma_mops_bf16_per_step"] = round(e["mops"])
+            # achieved matrix throughput from the op counter: MOPS counts 512 FLOP units
+            row["mfma_TFLOPs"] = round(e["mops"] * 512 / (e["us_per_step"] * 1e-6) / 1e12, 1)
         tot_us += e["us_per_step"]
         table.append(row)
     out = {"what": "one replayed GlobalSPFN training step, 16 x 8192 points, bf16 (bench.py defaults), MI355X",
@@ -139,7 +148,7 @@ def main():
            "step_frac_of_hbm_peak_traffic": round(tot_traffic / (wall_us * 1e-6) / HBM_PEAK, 3),
            "notes": "us from the rocprofv3 kernel trace of replayed steps; traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB counters, "
                     "FETCH doubled on gfx950) from eager counter passes; algorithmic bytes = every operand read once, every result "
-                    "written once (bench.py --census-out); mfma_busy_over_sq_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES",
+                    "written once (bench.py --census-out); mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs)",
            "families": table}
     print(json.dumps(out, indent=1))
     if args.traffic_out and "cpfn_mlp_gemm" in fam:
