@@ -78,6 +78,92 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
         torch.testing.assert_close(v, sd[0][k], rtol=2e-4, atol=2e-6)
 
 
+# ---- the REAL network: PointNet2 (fp32 compute mode) + SPFNTrainer + FlatGradBucket on two gloo ranks ------------------
+# The device kernels of the geometry path are replaced by oracle-backed CPU stand-ins for the duration of the test
+# (tests/cpu_standins.py: test infrastructure); everything else — module tree, per-replica BatchNorm, flat bucket, the
+# one all-reduce per step, Adam — is the product's host code.
+def _real_batch(rank, step):
+    return synthetic.training_batch(2, N=1024, n_max_instances=21, n_prims=5, n_inst_points=32, seed=100 * step + rank)
+
+
+def _real_starts(rank, step):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return (torch.randint(0, 1024, (2,), generator=g), torch.randint(0, 512, (2,), generator=g))
+
+
+def _real_model():
+    from cpfn_amd.PointNet2 import pn2_network
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 21])
+    m.load_state_dict(synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(output_sizes=(3, 4, 21)), seed=5), strict=True)
+    m.dropout_p = 0.0
+    return m
+
+
+def _real_worker(rank, world, port, out_dir):
+    import cpu_standins
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)      # (same summation order as the in-process emulation: the Hungarian matching of a randomly
+    #                                initialised network is discontinuous in rounding noise)
+    with cpu_standins.installed():
+        model = _real_model()
+        if rank != 0:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(1.0)               # a different start on rank 1: the broadcast must undo it
+        training.broadcast_parameters(model)
+        tr = training.SPFNTrainer(model, batch_size=2 * world, multipliers=LOCAL_MULT, fused_adam=False)
+        for step in range(2):
+            out = tr.step(_real_batch(rank, step), fps_start=_real_starts(rank, step))
+            assert all(torch.isfinite(v) for v in out)
+        assert tr.skipped_steps == 0
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "real%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_data_parallel_real_pointnet2(tmp_path):
+    """Two gloo ranks train the real PointNet2 for two steps; checked against an in-process emulation of the same
+    semantics: one model copy per rank (its own BatchNorm statistics: per-replica BN, as SURVEY 8e prescribes), gradients
+    averaged over the copies, one Adam step each."""
+    import copy
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_standins
+    world = 2
+    mp.spawn(_real_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sd = [torch.load(os.path.join(str(tmp_path), "real%d.pt" % r)) for r in range(world)]
+    param_keys = [k for k, _ in _real_model().named_parameters()]
+    for k in param_keys:
+        assert torch.equal(sd[0][k], sd[1][k]), "replicas diverged: %s" % k
+    assert any(not torch.equal(sd[0][k], sd[1][k]) for k in sd[0] if "running_mean" in k)      # BatchNorm stays per replica
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    with cpu_standins.installed():
+        copies = [_real_model() for _ in range(world)]
+        trainers = [training.SPFNTrainer(m, batch_size=2 * world, multipliers=LOCAL_MULT, fused_adam=False) for m in copies]
+        for step in range(2):
+            grads = []
+            for r, (m, tr) in enumerate(zip(copies, trainers)):
+                m.train()
+                tr.bucket.zero()
+                tr.losses(_real_batch(r, step), _real_starts(r, step))[0].backward()
+                tr.bucket.collect()
+                grads.append(tr.bucket.flat.clone())
+            mean = sum(grads) / world
+            for tr in trainers:
+                tr.bucket.flat.copy_(mean)
+                tr.optimizer.step()
+    torch.set_num_threads(prev_threads)
+    for r in range(world):
+        ref = copies[r].state_dict()
+        for k in param_keys:
+            torch.testing.assert_close(sd[r][k], ref[k], rtol=1e-4, atol=1e-6, msg=lambda m, k=k: "%s: %s" % (k, m))
+        for k in ref:
+            if "running" in k:
+                torch.testing.assert_close(sd[r][k], ref[k], rtol=1e-4, atol=1e-6)
+
+
 def test_schedules_match_reference_formulas():
     # Utils/training_utils.py:9-30 with the GlobalSPFN config (bs 16, steps of 200000 samples)
     assert training.get_batch_norm_decay(0, 16, 200000) == 0.5
