@@ -150,6 +150,94 @@ __global__ __launch_bounds__(NT) void fps_streaming_kernel(const float *__restri
   }
 }
 
+// Large clouds (8192 < N <= 524288: the 131072-point evaluation clouds of the cascade), SEVERAL workgroups per cloud.
+// The streaming kernel above runs a cloud on ONE compute unit: 131072 points cost ~24 us per sample there (12.4 ms for
+// 512 samples — 71 % of the GlobalSPFN evaluation forward).  Here G = N / (256 * PPT) workgroups share a cloud: every
+// lane keeps PPT points and their min-distances in registers exactly like the resident kernel, a workgroup reduces to one
+// 64-bit key, and the G keys of a sample are exchanged through G 8-byte slots in global memory (double-buffered by
+// sample parity): one agent-scope 8-byte store per workgroup and sample, G lanes of every workgroup poll the slots
+// (agent-scope 8-byte loads) until each carries the sample's tag.  The whole hand-off is the 8-byte word itself —
+//     key = dist bits << 32 | (0xFFFFF - index) << 12 | ((sample + 1) & 0xFFF)
+// — so no payload has to be ordered behind a flag (8-byte stores / loads are single-copy atomic), ties still go to the
+// lowest index, and a stale slot (tag of another sample) can never be taken for a fresh one: S <= 4094, slots zeroed by
+// a memset node in front of the launch.  All workgroups of a cloud must be resident together (they spin on each other):
+// the launcher only takes this path while B * G <= 1024 (256 CUs x >= 4 such workgroups), cloud-major block order; a
+// bounded spin (~1 s) turns a violated assumption into -1 indices instead of a hung GPU.
+// Same arithmetic, same tie-break as the other two kernels: bit-identical selections.
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict__ xyz, int N, int S,
+                                                         const int *__restrict__ start, int flags,
+                                                         int *__restrict__ idx_out, unsigned long long *__restrict__ slots) {
+  constexpr int NT = 256, NW = 4;
+  __shared__ unsigned long long s_key[2][NW];
+  __shared__ unsigned s_far;
+  const int G = gridDim.x, wg = blockIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x, lane = t & (CPFN_WAVE - 1), wave = t / CPFN_WAVE;
+  const float *p = xyz + (size_t)b * N * 3;
+  int *out = idx_out + (size_t)b * S;
+  unsigned long long *sl = slots + (size_t)b * 2 * G;
+  const int base = wg * NT * PPT;
+  float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int k = base + t + j * NT;
+    float x = 0.f, y = 0.f, z = 0.f, m = -1.0f;      // m < 0 marks "not a candidate"
+    if (k < N) {
+      x = p[3 * k]; y = p[3 * k + 1]; z = p[3 * k + 2];
+      m = 1e10f;
+      if ((flags & CPFN_FPS_SKIP_NEAR_ORIGIN) && cpfn_sqnorm3(x, y, z) <= 1e-3f) m = -1.0f;
+    }
+    px[j] = x; py[j] = y; pz[j] = z; md[j] = m;
+  }
+  unsigned far = start ? (unsigned)start[b] : 0u;
+  bool dead = false;
+  for (int i = 0; i < S; ++i) {
+    if (wg == 0 && t == 0) out[i] = dead ? -1 : (int)far;
+    const float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
+    float best = -1.0f;
+    unsigned besti = 0xFFFFFu;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const float dx = __fsub_rn(px[j], fx), dy = __fsub_rn(py[j], fy), dz = __fsub_rn(pz[j], fz);
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      float m = md[j];
+      m = d < m ? d : m;
+      md[j] = m;
+      if (m > best) { best = m; besti = (unsigned)(base + t + j * NT); }
+    }
+    // key without the tag: candidates compare by (distance, lowest index); "no candidate" = 0
+    unsigned long long key = best < 0.f ? 0ull : (((unsigned long long)__float_as_uint(best) << 32) |
+                                                   ((unsigned long long)(0xFFFFFu - besti) << 12));
+    key = wave_max_key(key);
+    if (lane == 0) s_key[i & 1][wave] = key;
+    __syncthreads();
+    const unsigned tag = (unsigned)(i + 1) & 0xFFFu;
+    if (t == 0) {
+      unsigned long long k4 = s_key[i & 1][0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) k4 = s_key[i & 1][w] > k4 ? s_key[i & 1][w] : k4;
+      __hip_atomic_store(&sl[(i & 1) * G + wg], k4 | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave == 0) {       // G <= 64 lanes poll one slot each until it carries this sample's tag
+      unsigned long long k = 0ull;
+      if (lane < G) {
+        unsigned spins = 0;
+        do {
+          k = __hip_atomic_load(&sl[(i & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > (1u << 24)) { k = ~0ull; break; }          // ~1 s: a sibling workgroup never arrived
+        } while ((unsigned)(k & 0xFFFull) != tag);
+      }
+      const bool timeout = __ballot(k == ~0ull) != 0ull;
+      k = (lane < G && !timeout) ? (k & ~0xFFFull) : 0ull;
+      k = wave_max_key(k);
+      if (lane == 0) s_far = timeout ? 0xFFFFFFFFu : (k ? 0xFFFFFu - (unsigned)((k >> 12) & 0xFFFFFull) : 0u);
+    }
+    __syncthreads();
+    const unsigned nf = s_far;
+    if (nf == 0xFFFFFFFFu) { dead = true; far = 0u; } else far = nf;
+  }
+}
+
 }  // namespace
 
 extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out,
@@ -165,7 +253,23 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
     fps_resident_kernel<1024, 8><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out);
   } else {
     if (!scratch) return CPFN_EINVAL;
-    fps_streaming_kernel<1024><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out, scratch);
+    // several workgroups per cloud while all of them can be resident together and the key layout holds
+    // (index < 2^20, sample tag < 4095); slots = the first B * 2 * G 8-byte words of the scratch row buffer
+    int ppt = 8;
+    while (ppt < 32 && (N + 256 * ppt - 1) / (256 * ppt) > 64) ppt *= 2;
+    const int G = (N + 256 * ppt - 1) / (256 * ppt);
+    if (G <= 64 && (long long)B * G <= 1024 && B <= 65535 && S <= 4094 && N <= (1 << 20) &&
+        (size_t)B * 2 * G * 8 <= (size_t)B * N * 4 && ((uintptr_t)scratch & 7) == 0) {
+      hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * 2 * G * 8, st);
+      if (e != hipSuccess) return (int)e;
+      unsigned long long *slots = (unsigned long long *)scratch;
+      const dim3 grid(G, B);
+      if (ppt == 8) fps_shared_kernel<8><<<grid, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, slots);
+      else if (ppt == 16) fps_shared_kernel<16><<<grid, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, slots);
+      else fps_shared_kernel<32><<<grid, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, slots);
+    } else {
+      fps_streaming_kernel<1024><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out, scratch);
+    }
   }
   return cpfn_launch_status();
 }

@@ -49,8 +49,14 @@ CPFN_API const char *cpfn_build_info(void);
  * unfused fp32, ties go to the lowest index.  idx_out[B,S].
  * flags bit0 = 1 additionally ignores points with |p|^2 <= 1e-3 like the CUDA
  * kernel does (sampling_gpu.cu:90-91).
- * scratch: B*N floats, only touched when N > CPFN_FPS_MAX_RESIDENT (may be NULL
- * otherwise); the reference allocates the same [B,N] `tmp` itself (sampling.cpp:73). */
+ * scratch: B*N floats (8-byte aligned), only touched when N > CPFN_FPS_MAX_RESIDENT (may be NULL
+ * otherwise); the reference allocates the same [B,N] `tmp` itself (sampling.cpp:73).
+ * Three kernels: N <= 8192: one workgroup per cloud, distances in registers, cloud mirrored in LDS;
+ * 8192 < N <= 524288 (while B * ceil(N / 2048..8192) <= 1024 and S <= 4094): ceil(N / (256*PPT)) workgroups per
+ * cloud, PPT = 8|16|32 points per lane in registers, one 8-byte key per workgroup and sample exchanged through
+ * the first words of `scratch` (zeroed by a memset node in front of the launch; bounded spin: a sibling workgroup
+ * that never arrives yields -1 indices, not a hang); otherwise one workgroup per cloud streaming the distances
+ * through `scratch`.  All three select identical indices. */
 #define CPFN_FPS_MAX_RESIDENT 8192
 #define CPFN_FPS_SKIP_NEAR_ORIGIN 1
 CPFN_API int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, int flags,

@@ -92,6 +92,29 @@ def test_fps_sizes_vs_oracle(B, N, S):
     assert np.array_equal(got, og.farthest_point_sample(xyz, S, start).astype(np.int32))
 
 
+@pytest.mark.parametrize("B,N,S,dup", [(1, 8193, 64, False), (3, 20000, 200, True), (2, 131072, 512, False), (16, 131072, 32, False),
+                                         (1, 150001, 100, True), (1, 300000, 64, False), (1, 524288, 40, False),
+                                         (20, 131072, 16, False), (1, 600000, 20, False)])
+def test_fps_large_clouds_multi_workgroup(B, N, S, dup):
+    """N > 8192: several workgroups per cloud exchanging one 8-byte key per sample (fps_shared_kernel, 8 / 16 / 32 points
+    per lane), and its fall-backs to the one-workgroup streaming kernel (B * G > 1024 resident workgroups, N > 524288) —
+    all bit-identical to the oracle, duplicated points (exact ties: lowest index wins) included; also the CUDA-route
+    flag (near-origin points skipped) on the multi-workgroup path."""
+    from cpfn_amd import cuda_ops
+    rng = np.random.default_rng(N + S)
+    xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    if dup:
+        xyz[:, N // 2:N // 2 + 500] = xyz[:, 100:600]
+    start = rng.integers(0, N, B)
+    got = cuda_ops.farthest_point_sampling(T(xyz), S, start_idx=T(start), cuda_compat=False).cpu().numpy()
+    assert got.min() >= 0
+    assert np.array_equal(got, og.farthest_point_sample(xyz, S, start).astype(np.int32))
+    if B == 3:
+        xyz[:, 50:90] *= 0.01
+        got = cuda_ops.farthest_point_sampling(T(xyz), S, cuda_compat=True).cpu().numpy()
+        assert np.array_equal(got, og.farthest_point_sample_cuda(xyz, S).astype(np.int32))
+
+
 def test_fps_ties_and_default_start():
     from cpfn_amd import cuda_ops
     # a lattice has many exactly equal distances: the lowest index must win each tie
