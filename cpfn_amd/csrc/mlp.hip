@@ -1792,7 +1792,7 @@ extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long
 
 extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C, float *workspace,
                                  float *dW, void *stream) {
-  if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !Gy || !X || !workspace || !dW)
+  if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !Gy || !X || !workspace)
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = cpfn_bn_bwd_blocks(P);
@@ -1805,17 +1805,17 @@ extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long lo
     default: smallk_wgrad_kernel<4><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
   }
   const long long n = (long long)C * KS;
-  launch_split_reduce(workspace, nblk, n, dW, st);
+  if (dW) launch_split_reduce(workspace, nblk, n, dW, st);    // NULL: the caller batches it (cpfn_multi_split_reduce)
   return cpfn_launch_status();
 }
 
 extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *pad_bf16,
                                void *stream) {
-  if (P <= 0 || C <= 0 || C > 64 || !X || !workspace || !out) return CPFN_EINVAL;
+  if (P <= 0 || C <= 0 || C > 64 || !X || !workspace) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (int)((P + CS_ROWS - 1) / CS_ROWS);
   colsum_f32_kernel<<<nblk, 256, 0, st>>>(X, P, C, workspace, (unsigned short *)pad_bf16);
-  launch_split_reduce(workspace, nblk, C, out, st);
+  if (out) launch_split_reduce(workspace, nblk, C, out, st);  // NULL: the caller batches it (cpfn_multi_split_reduce)
   return cpfn_launch_status();
 }
 

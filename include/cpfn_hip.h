@@ -347,7 +347,9 @@ CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, con
                             float *dW, void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
  * workspace: ceil(P/256)*C floats.  pad_bf16 (optional): [P,64] bf16, receives the rows of X converted to bf16
- * and zero-padded to 64 columns in the same pass (the gradient operand of the heads' GEMMs). */
+ * and zero-padded to 64 columns in the same pass (the gradient operand of the heads' GEMMs).
+ * out == NULL: only the per-block partials are left in workspace (ceil(P/256) rows of C floats) for the caller
+ * to finish with cpfn_multi_split_reduce; the same holds for dW == NULL in cpfn_mlp_wgrad / cpfn_smallk_wgrad. */
 CPFN_API int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *pad_bf16,
                              void *stream);
 /* fp32 first layer with K = KS <= 4 inputs (sa1: relative xyz stay fp32):
