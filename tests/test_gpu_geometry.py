@@ -291,3 +291,38 @@ def test_pairwise_squared_distance_matches_reference(golden):
     full = ops.pairwise_sqdist(l1, x8).cpu().numpy()
     want = og.pairwise_squared_distance(l1.cpu().numpy(), g8["xyz"][:1])
     assert np.array_equal(full.view(np.uint32), want.view(np.uint32))
+
+
+def test_random_shapes_sweep_vs_oracle():
+    """60 random configurations (ragged sizes from 1 point up, duplicated points = exact distance ties, radii from
+    "nothing in the ball" to "everything", M < 3 known points for the 3-NN, K larger than the cloud): FPS, ball query,
+    3-NN indices and squared distances, interpolation weights — all bit-identical to the oracle."""
+    from cpfn_amd import cuda_ops, ops
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        B = int(rng.integers(1, 4))
+        N = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 127, 300, 1000, 2049, 5000]))
+        S = int(rng.integers(1, min(N, 600) + 1))
+        K = int(rng.choice([1, 3, 16, 64, 100]))
+        r = float(rng.choice([0.01, 0.1, 0.2, 0.4, 0.9, 3.0]))
+        xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+        if N > 10 and trial % 3 == 0:
+            xyz[:, N // 2:N // 2 + N // 10] = xyz[:, :N // 10]                     # exact duplicates
+        if trial % 7 == 0:
+            xyz = np.round(xyz * 4) / 4                                           # lattice: many equal distances
+        start = rng.integers(0, N, B)
+        tag = (trial, B, N, S, K, r)
+        sel = cuda_ops.farthest_point_sampling(T(xyz), S, start_idx=T(start))
+        want = og.farthest_point_sample(xyz, S, start)
+        assert np.array_equal(sel.cpu().numpy(), want.astype(np.int32)), ("fps", tag)
+        ctr = np.take_along_axis(xyz, want[:, :, None], axis=1)
+        got = cuda_ops.ball_query(T(ctr), T(xyz), r, K).cpu().numpy()
+        assert np.array_equal(got, og.ball_query(r, K, xyz, ctr).astype(np.int32)), ("ball", tag)
+        d, i = cuda_ops.three_nn(T(xyz), T(ctr))
+        od, oi = og.three_nn(xyz, ctr)
+        if S >= 3:
+            assert np.array_equal(i.cpu().numpy(), oi.astype(np.int32)), ("3nn idx", tag)
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32)), ("3nn dist", tag)
+            assert np.array_equal(ops.three_weights(d).cpu().numpy().view(np.uint32), og.three_weights(od).view(np.uint32)), ("w", tag)
+        else:       # fewer than 3 known points: the first S slots are defined (the reference's sort would fail here)
+            assert np.array_equal(i.cpu().numpy()[..., :S], oi.astype(np.int32)[..., :S]), ("3nn idx", tag)
