@@ -16,6 +16,7 @@
 // All reductions (statistics, weight gradients) go through per-workgroup partial buffers that
 // a second tiny kernel sums in a fixed order: bitwise reproducible, no float atomics.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -1512,7 +1513,13 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   if (P > 0 && P <= SP_MAX_ROWS) return (int)((P + sp_rows(P, N) - 1) / sp_rows(P, N));   // small-P kernel: one per row tile
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
   const int ny = (N + 127) / 128 > 0 ? (N + 127) / 128 : 1;
-  long long tpw = tiles * ny / 512;  // aim for ~512 workgroups (256 and 1024 measured: within 4 % / 10 % slower)
+  // Workgroups per launch: at most ~448 (CPFN_GEMM_WGS overrides it for experiments).  Stand-alone, 512 (one round of
+  // two per CU) was the optimum; inside the step the next batch's FPS holds 16 of the 256 CUs for the whole forward
+  // pass (its 96 KB of LDS leaves no room for a 75 KB GEMM workgroup next to it), so 512 workgroups run as a round of
+  // 480 plus a straggler round.  Measured on the replayed step (same box, A/B): 512 -> 2.435 ms, 480 / 448 / 400 ->
+  // 2.404-2.414, 342 -> 2.419, 256 -> 2.440, 1024 -> 2.516.
+  static const int target = getenv("CPFN_GEMM_WGS") && atoi(getenv("CPFN_GEMM_WGS")) > 0 ? atoi(getenv("CPFN_GEMM_WGS")) : 448;
+  long long tpw = (tiles * ny + target - 1) / target;
   if (tpw < 1) tpw = 1;
   if (tpw > 16) tpw = 16;
   return (int)((tiles + tpw - 1) / tpw);
