@@ -573,6 +573,12 @@ class SPFNTrainer:
         `next_batch`: if given, its geometry is prefetched on a side stream during this step's backward."""
         self.module.train()
         self._schedules()
+        if self.use_graphs and batch["T_gt"].shape[1] > 32:
+            # the fused loss kernels (and with them the captured step) take at most 32 instance columns; wider label
+            # sets run eagerly on the op-by-op losses (HIP fitters, stock reductions)
+            if self.require_graphs:
+                raise RuntimeError("graph replay supports at most 32 instance columns (got %d)" % batch["T_gt"].shape[1])
+            force_eager = True
         if self.use_graphs and not force_eager and fps_start is None and batch["P"].is_cuda and not self._in_gstream:
             if self._gstream is None:
                 self._gstream = torch.cuda.Stream(device=batch["P"].device)

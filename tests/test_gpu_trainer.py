@@ -6,6 +6,7 @@ trajectories differ at the 1 % level after a few Adam steps because of that nois
 import contextlib
 import io
 
+import numpy as np
 import pytest
 import torch
 
@@ -114,3 +115,25 @@ def test_training_convergence_matches_fp32_reference_path():
         assert abs(first - first32) < 0.03 * first32, (graphs, first, first32)
         # (dropout masks and the atomics order differ per mode: trajectories agree to ~10 %, not bitwise)
         assert last < 0.7 * first and abs(last - last32) < 0.25 * last32, (graphs, last, last32)
+
+
+def test_more_than_32_instance_columns_train_eagerly():
+    """K = 40 instance columns (beyond the fused loss kernels' 32-wide tile): the trainer runs the op-by-op losses on the
+    HIP fitters, eagerly even when graphs were asked for; asking to REQUIRE graphs fails loudly."""
+    from cpfn_amd import training
+    from cpfn_amd.PointNet2 import pn2_network
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    batch = {k: v.to(dev) for k, v in synthetic.training_batch(2, N=2048, n_max_instances=40, n_prims=34, n_inst_points=64, seed=3).items()}
+    for graphs in (False, True):
+        model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 40]).to(dev)
+        model.set_compute_dtype(torch.bfloat16)
+        tr = training.SPFNTrainer(model, batch_size=2, use_graphs=graphs)
+        hist = [float(tr.step(batch, next_batch=batch)[0]) for _ in range(6)]
+        assert tr._graph is None and tr.skipped_steps == 0
+        assert all(np.isfinite(hist)) and hist[-1] < hist[0]
+    model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 40]).to(dev)
+    model.set_compute_dtype(torch.bfloat16)
+    tr = training.SPFNTrainer(model, batch_size=2, use_graphs=True, require_graphs=True)
+    with pytest.raises(RuntimeError, match="at most 32 instance columns"):
+        tr.step(batch)
