@@ -135,3 +135,40 @@ def test_moment_linearity_and_determinism():
     torch.testing.assert_close(M1 + M2, M12, rtol=1e-6, atol=1e-4)   # W1+W2 itself is rounded to fp32
     # slot 0 is ΣW
     torch.testing.assert_close(M1[..., 0], W1.double().sum(1), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("B,N,n_prims,K", [(1, 300, 2, 2), (3, 1000, 5, 7), (2, 5000, 9, 12), (1, 8192, 10, 33), (1, 4097, 12, 64)])
+def test_shape_sweep_vs_oracle(B, N, n_prims, K):
+    """Ragged sizes and instance counts from 2 to 64 (the moment kernels' limit): points on real primitives with peaky
+    memberships for the first n_prims columns, background-level memberships for the rest.  Every instance of every
+    parameter within 1e-4 (per instance) of the fp32 oracle, or — where that is the fp32 oracle's own rounding noise
+    against its fp64 run — of the fp64 oracle; gradients of the sign-invariant loss against the fp64 oracle."""
+    from cpfn_amd import synthetic
+    d = synthetic.primitive_cloud(B, N, n_prims=n_prims, noise=0.003, seed=N + K)
+    g = torch.Generator().manual_seed(K)
+    logits = torch.randn(B, N, K, generator=g) * 0.3
+    logits.scatter_add_(2, d["I_gt"].unsqueeze(2), torch.full((B, N, 1), 7.0))
+    W = torch.softmax(logits, dim=2)
+    X = torch.nn.functional.normalize(d["X_gt"] + 0.05 * torch.randn(B, N, 3, generator=g), dim=2)
+    P = d["P"]
+    coef = {"plane_normal_outer": torch.randn(B, K, 3, 3, generator=g), "plane_cn": torch.randn(B, K, 3, generator=g),
+            "cylinder_axis_outer": torch.randn(B, K, 3, 3, generator=g)}
+    for k in PARAM_KEYS:
+        if k not in ("plane_normal", "plane_center", "cylinder_axis"):
+            coef[k] = torch.randn((B, K) if k.endswith("squared") or k == "cone_half_angle" else (B, K, 3), generator=g)
+    mine, (gW, gX) = _run_product(P, W, X, coef)
+    ref = ospfn.compute_parameters(P, W, X)
+    W64, X64 = W.double().requires_grad_(True), X.double().requires_grad_(True)
+    ref64 = ospfn.compute_parameters(P.double(), W64, X64)
+    sign_invariant_loss(ref64, {k: v.double() for k, v in coef.items()}).backward()
+    ref64 = {k: v.detach() for k, v in ref64.items()}
+    a32 = align_signs(mine, ref)
+    a64 = align_signs({k: v.double() for k, v in mine.items()}, ref64)
+    noise = align_signs({k: v.double() for k, v in ref.items()}, ref64)
+    for k in PARAM_KEYS:
+        e32, e64, en = per_instance_rel(a32[k], ref[k]), per_instance_rel(a64[k], ref64[k]), per_instance_rel(noise[k], ref64[k])
+        ok = (e32 < TOL) | ((e64 < TOL) & (en > TOL / 4))
+        assert bool(ok.all()), (k, [(int(b), int(i), float(e32[b, i]), float(e64[b, i]), float(en[b, i])) for b, i in (~ok).nonzero()])
+    eW = (gW.double() - W64.grad).norm(dim=1) / W64.grad.norm(dim=1).clamp_min(1e-12)
+    eX = (gX.double() - X64.grad).norm(dim=(1, 2)) / X64.grad.norm(dim=(1, 2))
+    assert float(eW.max()) < 5e-4 and float(eX.max()) < 5e-4, (float(eW.max()), float(eX.max()))
