@@ -36,6 +36,7 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "libcpfn_oracle" not in src, f
+                assert "cpu_standins" not in src, f          # (the CPU stand-ins of the gloo tests are test infrastructure too)
 
 
 def test_bad_arguments_raise_runtime_error():
