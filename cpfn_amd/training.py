@@ -595,20 +595,33 @@ class SPFNTrainer:
         if self.use_graphs and not force_eager and fps_start is None and batch["P"].is_cuda:
             if self._graph is None and self._graph_warm >= 2:
                 try:
-                    try:
+                    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+                    if world == 1 or not self._exchange_in_graph:
                         self._graph = self._capture(batch, exchange_in_graph=self._exchange_in_graph)
-                    except Exception as e:
-                        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-                        if world == 1 or not self._exchange_in_graph:
-                            raise
-                        # the collective could not be captured on this stack: keep the replayed step, with the
-                        # exchange + optimizer as eager launches after it (still no host synchronisation)
-                        import warnings
-                        warnings.warn("RCCL all-reduce not capturable here (%s: %s); exchange stays outside the graph"
-                                      % (type(e).__name__, e))
-                        torch.cuda.synchronize()
-                        self._exchange_in_graph = False
-                        self._graph = self._capture(batch, exchange_in_graph=False)
+                    else:
+                        # Data parallel: try the step WITH the collective inside the graph; all ranks must end up with
+                        # the same layout (a rank replaying the all-reduce while another issues it eagerly is still a
+                        # matching collective, but a rank whose capture failed must not leave the others waiting), so
+                        # the outcome is agreed on with one tiny all-reduce before anybody replays.
+                        graph, err = None, None
+                        try:
+                            graph = self._capture(batch, exchange_in_graph=True)
+                        except Exception as e:
+                            err = e
+                            torch.cuda.synchronize()
+                        ok = torch.tensor([0.0 if graph is None else 1.0], device=batch["P"].device)
+                        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                        if float(ok) < 1.0:
+                            # the collective could not be captured on (some rank of) this stack: keep the replayed step,
+                            # with the exchange + optimizer as eager launches after it (still no host synchronisation)
+                            import warnings
+                            warnings.warn("RCCL all-reduce not capturable on every rank (%s); exchange stays outside the graph"
+                                          % (("%s: %s" % (type(err).__name__, err)) if err is not None else "another rank failed"))
+                            self._exchange_in_graph = False
+                            graph = None
+                            torch.cuda.synchronize()
+                            graph = self._capture(batch, exchange_in_graph=False)
+                        self._graph = graph
                 except Exception as e:          # capture is an optimisation: fall back to eager launches
                     if self.require_graphs:     # ... unless the caller asked for the replayed step (bench.py does)
                         raise
