@@ -61,10 +61,11 @@ class PointNet2(torch.nn.Module):
         cr = bool(_co.CUDA_ROUTE) if cuda_route is None else bool(cuda_route)
         xyz = x[:, :, :self.dim_pos].contiguous().float()
         s1, s2 = fps_start if fps_start is not None else (None, None)
-        g1 = self.sa1.compute_geometry(xyz, s1, cr)
-        g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr)
-        return {"sa1": g1, "sa2": g2, "sfp2": self.sfp2.compute_geometry(g1["new_xyz"], g2["new_xyz"], cr),
-                "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"], cr)}
+        inv = self.training           # the inverse indices serve the backward adjoints only
+        g1 = self.sa1.compute_geometry(xyz, s1, cr, inv)
+        g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr, inv)
+        return {"sa1": g1, "sa2": g2, "sfp2": self.sfp2.compute_geometry(g1["new_xyz"], g2["new_xyz"], cr, inv),
+                "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"], cr, inv)}
 
     def forward(self, x, glob_features=None, loc_features=None, fast=True, fps_start=None, geometry=None):
         """`fast`: the reference switches between its compiled CUDA ops (default) and its PyTorch CPU route, which

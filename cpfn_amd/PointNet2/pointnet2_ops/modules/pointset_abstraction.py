@@ -38,7 +38,7 @@ class PointsetAbstraction(nn.Module):
             self.bn_blocks.append(bns)
 
     # ---------------------------------------------------------------- native layout
-    def compute_geometry(self, xyz, start_idx=None, cuda_route=False):
+    def compute_geometry(self, xyz, start_idx=None, cuda_route=False, need_inverse=True):
         """Everything of this level that depends only on coordinates (no weights, no gradients):
         FPS indices, sampled centres, ball-query neighbours and the centred neighbour coordinates.
         Can be run ahead of time on a side stream (PointNet2.compute_geometry).
@@ -58,7 +58,7 @@ class PointsetAbstraction(nn.Module):
             nbr = ops.ball_query(new_xyz, xyz, r, k, cuda_route=cuda_route)               # [B,S,K] i32
             scales.append((nbr, ops.group_xyz_centered(xyz, new_xyz, nbr)))               # rel [B,S,K,3] fp32
         out = {"fps_idx": sel, "new_xyz": new_xyz, "scales": scales}
-        if self.has_feats and N <= 2048 and len(scales) == 1:
+        if need_inverse and self.has_feats and N <= 2048 and len(scales) == 1:
             # inverse of the neighbour index: atomic-free, deterministic adjoint of the feature gather
             out["inv"] = ops.csr_build(scales[0][0], N)
         return out
@@ -79,7 +79,7 @@ class PointsetAbstraction(nn.Module):
             groups = [(g.reshape(B * N, -1), None, 1, N)] * len(self.mlp_list)
         else:
             if geom is None:
-                geom = self.compute_geometry(xyz, start_idx, cuda_route)
+                geom = self.compute_geometry(xyz, start_idx, cuda_route, need_inverse=self.training and torch.is_grad_enabled())
             new_xyz = geom["new_xyz"]
             aux["fps_idx"] = geom["fps_idx"]
             groups = []

@@ -23,14 +23,15 @@ class PointsetFeaturePropagation(nn.Module):
             c_in = c_out
 
     @staticmethod
-    def compute_geometry(xyz1, xyz2, cuda_route=False):
+    def compute_geometry(xyz1, xyz2, cuda_route=False, need_inverse=True):
         """3-NN indices and inverse-distance weights (coordinates only; prefetchable).
         cuda_route: what the reference's `fast=True` gives — direct distances and their SQUARE ROOTS
         (geometry_utils.py:184), so the weights are 1/(d + 1e-8) instead of the CPU route's 1/(d² + 1e-8)."""
         d2, nn_idx = ops.three_nn(xyz1, xyz2, cuda_route=cuda_route, sqrt=cuda_route)   # CPU route: squared distances
         out = {"nn_idx": nn_idx, "nn_w": ops.three_weights(d2)}             # 1/(d+1e-8), normalised (ref :40-42)
-        if xyz2.shape[1] <= 2048:
-            out["inv"] = ops.csr_build(nn_idx, xyz2.shape[1])               # for the atomic-free interpolation adjoint
+        if need_inverse and xyz2.shape[1] <= 2048:                          # (evaluation never runs the adjoint: one
+            out["inv"] = ops.csr_build(nn_idx, xyz2.shape[1])               #  393216-entry sort per 131072-point cloud, 3.2 ms)
+        #                                                                     for the atomic-free interpolation adjoint
         return out
 
     def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None, cuda_route=False):
@@ -42,7 +43,7 @@ class PointsetFeaturePropagation(nn.Module):
             interp = feats2.expand(B, N, feats2.shape[2])                  # broadcast the global vector (ref :33-34)
         else:
             if geom is None:
-                geom = self.compute_geometry(xyz1, xyz2, cuda_route)
+                geom = self.compute_geometry(xyz1, xyz2, cuda_route, need_inverse=self.training and torch.is_grad_enabled())
             interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"], geom.get("inv"))
             aux = geom
         x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)

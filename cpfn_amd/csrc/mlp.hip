@@ -844,6 +844,22 @@ __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restri
   }
 }
 
+// Evaluation mode (running statistics): z = gamma (y + b - rm) / sqrt(rv + eps) + beta as scale / shift of the
+// bias-free GEMM output, in the 4 x C layout bn_finalize leaves (scale, shift, "mean" = rm - b, rstd) — one launch
+// instead of the eight framework kernels per layer the expression costs as tensor ops (17 layers per forward pass).
+__global__ void bn_eval_affine_kernel(const float *__restrict__ gamma, const float *__restrict__ beta,
+                                      const float *__restrict__ conv_bias, const float *__restrict__ rm,
+                                      const float *__restrict__ rv, float eps, int C, float *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.0f / sqrtf(rv[c] + eps);
+  const float b = conv_bias ? conv_bias[c] : 0.f, sc = gamma[c] * rstd;
+  out[c] = sc;
+  out[C + c] = beta[c] + (b - rm[c]) * sc;
+  out[2 * C + c] = rm[c] - b;
+  out[3 * C + c] = rstd;
+}
+
 // ---------------------------------------------------------------- normalise + ReLU (+ max-pool)
 // out[p,c] = relu(scale[c]·y[p,c] + shift[c]); 8 channels (16 B) per lane.
 // ---- dropout fused into the BatchNorm apply passes (the reference applies F.dropout(p = 0.5) to the fc1
@@ -1634,6 +1650,14 @@ extern "C" int cpfn_bn_finalize(const float *partial, int nblk, int N, float cou
   bn_finalize_kernel<<<cpfn_cdiv(N, 16), RTPB, 0, (hipStream_t)stream>>>(partial, nblk, N, count, gamma, beta, conv_bias,
                                                                         eps, momentum, running_mean, running_var,
                                                                         scale, shift, mean, rstd);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_eval_affine(const float *gamma, const float *beta, const float *conv_bias, const float *running_mean,
+                                   const float *running_var, float eps, int C, float *out4C, void *stream) {
+  if (C <= 0 || !gamma || !beta || !running_mean || !running_var || !out4C) return CPFN_EINVAL;
+  bn_eval_affine_kernel<<<cpfn_cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(gamma, beta, conv_bias, running_mean, running_var, eps, C,
+                                                                             out4C);
   return cpfn_launch_status();
 }
 

@@ -338,11 +338,11 @@ class _FusedStack(torch.autograd.Function):
                 if L.training:
                     st = bn_finalize(part, nblk, N, P, L.gamma.detach(), L.beta.detach(),
                                      None if L.bias is None else L.bias.detach(), L.eps, L.momentum, L.rm, L.rv)
-                else:   # running statistics (eval): z = γ (y + b − rm)/sqrt(rv+eps) + β
-                    rstd = torch.rsqrt(L.rv + L.eps)
-                    sc = L.gamma.detach() * rstd
-                    b = 0.0 if L.bias is None else L.bias.detach()
-                    st = torch.stack([sc, L.beta.detach() + (b - L.rm) * sc, L.rm - b, rstd]).float().contiguous()
+                else:   # running statistics (eval): z = γ (y + b − rm)/sqrt(rv+eps) + β, one launch
+                    st = torch.empty(4, N, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_bn_eval_affine(_ptr(L.gamma.detach()), _ptr(L.beta.detach()),
+                                                 None if L.bias is None else _ptr(L.bias.detach()), _ptr(L.rm), _ptr(L.rv),
+                                                 float(L.eps), N, _ptr(st), _stream()), "cpfn_bn_eval_affine")
                 last = li == len(layers) - 1
                 if last and pool_k:
                     out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)

@@ -299,6 +299,11 @@ CPFN_API int cpfn_bn_finalize(const float *partial, int nblk, int N, float count
                               const float *beta, const float *conv_bias, float eps, float momentum,
                               float *running_mean, float *running_var, float *scale, float *shift,
                               float *mean, float *rstd, void *stream);
+/* Evaluation-mode BatchNorm (running statistics; torch.nn.functional.batch_norm with training=False) as the
+ * scale / shift of the bias-free GEMM output: out4C = [scale | shift | running_mean - conv_bias | rstd], C floats each —
+ * the layout cpfn_bn_finalize writes.  conv_bias may be NULL. */
+CPFN_API int cpfn_bn_eval_affine(const float *gamma, const float *beta, const float *conv_bias, const float *running_mean,
+                                 const float *running_var, float eps, int C, float *out4C, void *stream);
 /* out = relu(scale*y + shift), bf16 [P,C].
  * Fused dropout (optional; the reference's always-on F.dropout on the fc1 features, PointNet2/pn2_network.py:63):
  * with drop_counter non-NULL (a device int64 the caller advances once per forward pass) the output is multiplied by

@@ -154,3 +154,30 @@ def test_cascaded_eval_131072_points():
         np.testing.assert_allclose(a.cpu().numpy(), b.float().numpy(), rtol=2e-3, atol=1e-5, err_msg=name)
     np.testing.assert_allclose(torch.stack(res[6]).cpu().numpy(), ref["Sk_coverage"].float().numpy(), atol=3.0 / 512)
     np.testing.assert_allclose(torch.stack(res[7]).cpu().numpy(), ref["P_coverage"].float().numpy(), atol=20.0 / N_HI)
+
+
+def test_graphed_evaluation_forward_matches_eager():
+    """cpfn_amd.inference.GraphedForward: the evaluation forward of a 131072-point cloud (batch 1) and of 32 x 8192
+    patches replayed as one hipGraph — bit-identical to the eager forward, same FPS points for the same seed."""
+    from cpfn_amd.inference import GraphedForward
+    for K, shape, seed in ((K_GLOBAL, (1, N_HI), 0), (K_LOCAL, (NB, NPP), 3)):
+        m = _net(K, seed=seed).set_compute_dtype(torch.bfloat16)
+        P = synthetic.primitive_cloud(shape[0], shape[1], n_prims=8, seed=11)["P"].to(dev())
+        gf = GraphedForward(m)
+        with torch.no_grad():
+            torch.manual_seed(5)
+            want = [t.clone() for t in m(P)]
+            fps_eager = m.aux_sa1["fps_idx"].clone()
+            for rep in range(2):                     # capture, then a pure replay
+                torch.manual_seed(5)
+                got = gf(P)
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b)
+                assert torch.equal(m.aux_sa1["fps_idx"], fps_eager)
+            got2 = gf(P, fps_start=(torch.zeros(shape[0], dtype=torch.long), torch.ones(shape[0], dtype=torch.long)))
+            want2 = m(P, fps_start=(torch.zeros(shape[0], dtype=torch.long), torch.ones(shape[0], dtype=torch.long)))
+            for a, b in zip(got2, want2):
+                assert torch.equal(a, b)
+    m.train()
+    with pytest.raises(RuntimeError, match="evaluation-mode"):
+        gf(P)

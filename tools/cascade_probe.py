@@ -41,6 +41,9 @@ with torch.no_grad():
     t, _ = timed(lambda: ops.ball_query(ctr, P, 0.2, 64)); print("ball query 512 x 131072                            %8.3f ms" % t)
     t, _ = timed(lambda: ops.three_nn(P, ctr)); print("3-NN 131072 x 512                                  %8.3f ms" % t)
     t, out = timed(lambda: g(P, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("GlobalSPFN eval forward, 1 x 131072               %8.3f ms" % t)
+    from cpfn_amd.inference import GraphedForward
+    gg = GraphedForward(g)
+    t, _ = timed(lambda: gg(P, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("  ... replayed as one hipGraph (GraphedForward)       %8.3f ms" % t)
     centres = P[0, g.aux_sa1["fps_idx"][0, :NB].long()]
     d2 = ((P[0].unsqueeze(0) - centres.unsqueeze(1)) ** 2).sum(-1)
     pidx = d2.topk(NPP, dim=1, largest=False)[1]
@@ -49,6 +52,8 @@ with torch.no_grad():
     patches = (patches / patches.norm(dim=2).max(dim=1)[0].view(NB, 1, 1)).contiguous()
     st = (torch.zeros(NB, dtype=torch.long), torch.zeros(NB, dtype=torch.long))
     t, lout = timed(lambda: l(patches, fps_start=st)); print("LocalSPFN eval forward, 32 x 8192                  %8.3f ms" % t)
+    gl = GraphedForward(l)
+    t, _ = timed(lambda: gl(patches, fps_start=st)); print("  ... replayed as one hipGraph (GraphedForward)       %8.3f ms" % t)
     Wg, Wl = torch.softmax(out[2], 2), torch.softmax(lout[2], 2)
     labels = torch.nn.functional.one_hot(Wg[0].argmax(1), 28)
     t, sim = timed(lambda: mu.similarity_soft(labels, Wl, pidx)); print("similarity_soft (700 x 700)                        %8.3f ms" % t)
