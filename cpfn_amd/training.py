@@ -596,6 +596,10 @@ class SPFNTrainer:
             if self._graph is None and self._graph_warm >= 2:
                 try:
                     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+                    if world > 1 and dist.get_backend() != "nccl":
+                        # only RCCL's collectives can be stream-captured (gloo synchronises the stream: attempting it
+                        # invalidates the capture and leaves the stream unusable)
+                        self._exchange_in_graph = False
                     if world == 1 or not self._exchange_in_graph:
                         self._graph = self._capture(batch, exchange_in_graph=self._exchange_in_graph)
                     else:

@@ -38,3 +38,18 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "2", "--warmup", "3"],
                        capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and "GPUs requested" in r.stderr and not r.stdout.strip(), (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.timeout(600)
+def test_two_real_ranks_on_one_gpu_gloo():
+    """World size 2 for real on a one-GPU box: two processes, both on GPU 0, gloo collective on device tensors (RCCL
+    refuses two ranks on one device) — the bf16 graph trainer with the exchange + optimizer after the graph (gloo
+    cannot be captured).  Replicas bit-identical after 12 steps from different initial weights, training progresses."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_two_ranks_one_gpu.py")], capture_output=True,
+                       text=True, env=env, timeout=540)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("replicas identical")][-1]
+    assert "replicas identical: True" in line and "graph: True" in line and "skipped: 0" in line, line
+    v = [float(x) for x in line.replace("->", " ").split() if x.replace(".", "").isdigit() and "." in x]
+    assert v[1] < 0.85 * v[0] and v[3] < 0.85 * v[2], line
