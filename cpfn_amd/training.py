@@ -371,6 +371,42 @@ class SPFNTrainer:
             out[lvl] = d
         return out
 
+    @staticmethod
+    def _probe_exchange_capture(dev):
+        """Can this stack capture the gradient exchange?  Only RCCL's collectives can be stream-captured (gloo
+        synchronises the stream: attempting it invalidates the capture and leaves the stream unusable), and even there
+        it is tried on a THROW-AWAY stream first: a tiny averaging all-reduce is captured, replayed and its result
+        checked, and the ranks agree on the verdict — so a stack that cannot do it never touches the step's own capture
+        stream, and every rank takes the same layout."""
+        if dist.get_backend() != "nccl":
+            return False
+        ok = 1.0
+        try:
+            rank = dist.get_rank()
+            probe = torch.full((1024,), float(rank), dtype=torch.float32, device=dev)
+            ref = probe.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.AVG)                    # eager: the expected result (and the communicator
+            #                                                               is set up outside any capture)
+            stream = torch.cuda.Stream(device=dev)
+            stream.wait_stream(torch.cuda.current_stream(dev))
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(stream):
+                with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG)
+                probe.fill_(float(rank))
+                g.replay()
+            stream.synchronize()
+            if not torch.equal(probe, ref):
+                ok = 0.0
+        except Exception:
+            ok = 0.0
+        flag = torch.tensor([ok], device=dev)
+        try:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        except Exception:
+            return False
+        return float(flag) >= 1.0
+
     def _capture(self, batch, exchange_in_graph=True):
         """exchange_in_graph (data parallel only): capture the RCCL all-reduce and the optimizer inside the step's
         graph; False = the graph ends after the gradient packing and the exchange + optimizer follow as eager
@@ -596,9 +632,7 @@ class SPFNTrainer:
             if self._graph is None and self._graph_warm >= 2:
                 try:
                     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-                    if world > 1 and dist.get_backend() != "nccl":
-                        # only RCCL's collectives can be stream-captured (gloo synchronises the stream: attempting it
-                        # invalidates the capture and leaves the stream unusable)
+                    if world > 1 and self._exchange_in_graph and not self._probe_exchange_capture(batch["P"].device):
                         self._exchange_in_graph = False
                     if world == 1 or not self._exchange_in_graph:
                         self._graph = self._capture(batch, exchange_in_graph=self._exchange_in_graph)
