@@ -314,6 +314,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
+        sync()                                          # nothing outstanding when the process group goes away
         dist.destroy_process_group()
 
 

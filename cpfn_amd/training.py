@@ -133,6 +133,18 @@ class FlatGradBucket:
         return flag
 
 
+def _quiesce_collectives(dev):
+    """Before a stream capture in a multi-rank process: let the process group's watchdog thread retire every finished
+    collective.  It polls the completion events of outstanding work from ITS thread (hipEventQuery, every 100 ms); a
+    query that lands while this thread is capturing was seen to fail on this stack even in thread-local capture mode
+    (ProcessGroupNCCL::WorkNCCL::finishedGPUExecutionInternal -> process abort, about 1 run in 5 when an eager all-reduce
+    had been issued just before the capture).  After a device synchronisation and 0.25 s the watchdog's list is empty,
+    and nothing is added to it while capturing (captured collectives are not tracked by the watchdog)."""
+    import time
+    torch.cuda.synchronize(dev)
+    time.sleep(0.25)
+
+
 def broadcast_parameters(module, src=0):
     """Identical replicas at start: rank-0 state to everyone (parameters and BN buffers)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -382,11 +394,13 @@ class SPFNTrainer:
             return False
         ok = 1.0
         try:
+            _quiesce_collectives(dev)
             rank = dist.get_rank()
             probe = torch.full((1024,), float(rank), dtype=torch.float32, device=dev)
             ref = probe.clone()
             dist.all_reduce(ref, op=dist.ReduceOp.AVG)                    # eager: the expected result (and the communicator
             #                                                               is set up outside any capture)
+            _quiesce_collectives(dev)
             stream = torch.cuda.Stream(device=dev)
             stream.wait_stream(torch.cuda.current_stream(dev))
             g = torch.cuda.CUDAGraph()
@@ -440,6 +454,8 @@ class SPFNTrainer:
                 sb[k] = stacked[i]
             sb["gt_axes"] = stacked
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1 and batch["P"].is_cuda:
+            _quiesce_collectives(dev)
         starts = (st["start1"], st["start2"])
         # static geometry buffers (shapes from one eager pass)
         g_example = self.module.compute_geometry(sb["P"], starts)

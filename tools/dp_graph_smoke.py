@@ -22,4 +22,4 @@ for i in range(30):
     hist.append(float(tr.step(batch, next_batch=batch)[0]))
 torch.cuda.synchronize()
 print('graph captured:', tr._graph is not None, 'world in graph:', tr._graph['world'], 'exchange in graph:', tr._graph.get('exchange_in_graph'), 'loss', round(hist[0], 3), '->', round(hist[-1], 3), 'skipped', float(tr._graph['skipped']))
-dist.barrier(); dist.destroy_process_group()
+torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()
