@@ -151,6 +151,8 @@ def cpu_baseline():
 
 def main():
     args = parse_args()
+    if args.dtype == "fp32":
+        args.no_graphs = True       # the fp32 parity mode runs PyTorch MLPs and the op-by-op losses (host-side assignment): eager only
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                        # never returns
     import torch
@@ -275,6 +277,8 @@ def main():
             per_launch_s = ev_ms / max(ev_calls, 1) / 1e3
             roof_mode = "HIP events around every launch in 3 eager re-runs of the step (probe counters empty)"
         bytes_per_launch = bytes_per_step / max(launches_per_step, 1)
+        if not per_launch_s > 0:        # (--dtype fp32: the MLPs are PyTorch ops, the roofline kernel family never runs)
+            per_launch_s, roof_mode = float("inf"), "the roofline kernel family was not launched in this mode"
         achieved = bytes_per_launch / per_launch_s / 1e9
         step_bytes = sum(b for _, b in census.values())
         ms_per_step = 1e3 * elapsed / args.steps
