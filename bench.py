@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--workload", default="global", choices=["global", "local"],
                     help="global (default) = BASELINE.json configs[1], the config the metric is quoted on; local = "
                          "configs[2] (LocalSPFN: 32 patches/GPU, 21 instances, fitter losses off) as an extra data point")
+    ap.add_argument("--probe-dump", default=None, help="write the per-launch probe records of the last replayed step (JSON)")
     ap.add_argument("--census-out", default=None, help="write the per-entry-point algorithmic bytes of one step (JSON)")
     return ap.parse_args()
 
@@ -231,6 +232,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = trainer.step(batch, next_batch=batch)
+    enqueue_s = time.perf_counter() - t0                # host time to ISSUE the timed steps (before waiting for them)
     sync()
     elapsed = time.perf_counter() - t0
     # every slot written during the timed region: a replayed graph rewrites the slots its launches were given at capture
@@ -244,6 +246,61 @@ def main():
             probe_ticks += int(tt[:, 1].max() - tt[:, 0].min())
             probe_launches += 1
     lib.check(h.cpfn_mlp_gemm_set_probe(None, 0, 0), "cpfn_mlp_gemm_set_probe")
+    if os.environ.get("CPFN_STEP_STAMPS") == "1" and rank == 0 and getattr(trainer, "_graph", None):
+        sv = trainer._graph.get("stamps")
+        sys.stderr.write("host issued the %d timed steps in %.1f ms; they took %.1f ms\n" % (args.steps, 1e3 * enqueue_s, 1e3 * elapsed))
+        if sv is not None:      # [step start, geometry branch end, main chain end, after the join] of the last replayed step
+            sv = sv.cpu().numpy()
+            sys.stderr.write("step stamps (us from the step's first node): geometry branch ends %.1f, main chain ends %.1f, joined %.1f\n"
+                             % tuple((int(sv[i]) - int(sv[0])) / 100.0 for i in (1, 2, 3)))
+            sys.stderr.write("   previous replay's join -> this replay's first node: %.1f us\n" % ((int(sv[0]) - int(sv[4])) / 100.0))
+            starts = [int(sl[2:2 + 2 * int(sl[0])].reshape(-1, 2)[:, 0].min()) for sl in pr if int(sl[0]) > 0]
+            ends = [int(sl[2:2 + 2 * int(sl[0])].reshape(-1, 2)[:, 1].max()) for sl in pr if int(sl[0]) > 0]
+            if starts:
+                sys.stderr.write("   probed launches of that step: first starts %.1f, last ends %.1f\n"
+                                 % ((min(starts) - int(sv[0])) / 100.0, (max(ends) - int(sv[0])) / 100.0))
+    if args.probe_dump and rank == 0:        # debugging (tools/dbg/probe_timeline.py; CPFN_PROBE_ALL=1 adds the weight gradients)
+        # mean over 40 replays (each the third of three back-to-back steps, then a sync to read the buffers): single steps
+        # differ by tens of microseconds.  Offsets from the step's first node when CPFN_STEP_STAMPS=1, else from the
+        # first probed launch.
+        import numpy as np
+        acc, reps = None, 40
+        sv_t = trainer._graph.get("stamps") if getattr(trainer, "_graph", None) else None
+        marks = np.zeros(4)
+        for _ in range(reps):
+            for _ in range(3):
+                trainer.step(batch, next_batch=batch)
+            sync()
+            q = probe.cpu().numpy()
+            recs = []
+            for slot in q:
+                nwg = int(slot[0])
+                if nwg > 0:
+                    tt = slot[2:2 + 2 * nwg].reshape(nwg, 2)
+                    recs.append((int(tt[:, 0].min()), int(tt[:, 1].max()), int(slot[1]), nwg, float((tt[:, 1] - tt[:, 0]).mean()),
+                                 int(tt[:, 0].max())))
+            recs.sort()
+            base = recs[0][0]
+            if sv_t is not None:
+                svn = sv_t.cpu().numpy()
+                base = int(svn[0])
+                marks += np.array([int(svn[1]) - base, int(svn[2]) - base, int(svn[3]) - base, base - int(svn[4])]) / reps
+            a = np.array([[r[0] - base, r[1] - base, r[4], r[5] - r[0]] for r in recs], dtype=np.float64)
+            acc = a if acc is None else acc + a
+        acc /= reps
+        dump = [{"kind": r[2], "nwg": r[3], "start": acc[i, 0], "end": acc[i, 1], "wg_mean": acc[i, 2], "last_start": acc[i, 0] + acc[i, 3]}
+                for i, r in enumerate(recs)]
+        # per-workgroup start offsets of the one-pass backward launches in the LAST of those replays
+        late = []
+        for slot in q:
+            nwg = int(slot[0])
+            if nwg > 0 and int(slot[1]) in (4, 5):
+                tt = slot[2:2 + 2 * nwg].reshape(nwg, 2)
+                late.append({"kind": int(slot[1]), "start": int(tt[:, 0].min()) - base, "nwg": nwg,
+                             "wg_start_offsets": sorted((tt[:, 0] - tt[:, 0].min()).tolist())[-40:],
+                             "wg_durations": [int(np.percentile(tt[:, 1] - tt[:, 0], q_)) for q_ in (0, 50, 100)]})
+        json.dump({"late_starts": sorted(late, key=lambda d: d["start"]), "launches": dump, "stamps": None if sv_t is None else
+                   {"geometry_end": marks[0], "main_end": marks[1], "joined": marks[2], "gap_before": marks[3]}}, open(args.probe_dump, "w"))
     # cross-check: HIP events around every launch of the family in eager re-runs of the same step, each queued behind a
     # spin kernel so that the bracketed launches execute back to back (the pair still contains the dispatch gap)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -7,6 +7,7 @@
 // small gathered-from tensor left to L2.  Adjoints use fp32 atomics exactly like the
 // reference's kernels (group_points_gpu.cu:60, interpolate_gpu.cu:139-141).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -245,17 +246,22 @@ __global__ __launch_bounds__(TPB) void scatter_rows_lds_kernel(const unsigned sh
 // source entries e = r*T + t that reference it.  The adjoint is then a gather-and-sum per target row:
 // no atomics, fixed order, bitwise reproducible.
 constexpr int CSR_MAXM = 2048;
-constexpr int CSR_LDS_E = 32768;   // entries per cloud that fit the LDS staging slab (128 KB)
+constexpr int CSR_LDS_E = 32768;   // entries per cloud that fit the LDS staging slab (64 KB of 16-bit entry numbers)
+// The slab holds entry numbers e < E <= 32768 as 16-bit values: with 32-bit ones the kernel held 128 + 16 KB of a
+// CU's 160 KB for its whole 150-330 us on the geometry branch, and no main-stream workgroup that needs more than
+// 16 KB of LDS could be placed on those 16 CUs meanwhile (measured with the in-kernel probe: a 256-workgroup,
+// 60 KB launch of the backward pass ran in two rounds whenever it met this kernel).
 template <bool LDS_SLAB>
 __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ idx, int E, int M,
                                                         int *__restrict__ offsets, int *__restrict__ entries) {
   __shared__ int s_cnt[CSR_MAXM + 1];
   __shared__ int s_cur[CSR_MAXM];
-  extern __shared__ int s_ent[];
+  extern __shared__ unsigned short s_ent[];
+  typedef typename std::conditional<LDS_SLAB, unsigned short, int>::type ent_t;
   const int b = blockIdx.x, t = threadIdx.x;
   const int *ii = idx + (size_t)b * E;
   int *off = offsets + (size_t)b * (M + 1), *gent = entries + (size_t)b * E;
-  int *ent = LDS_SLAB ? s_ent : gent;
+  ent_t *ent = LDS_SLAB ? (ent_t *)s_ent : (ent_t *)gent;
   for (int m = t; m <= M; m += TPB) s_cnt[m] = 0;
   __syncthreads();
   for (int e = t; e < E; e += TPB) {
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
   for (int e = t; e < E; e += TPB) {
     int m = ii[e];
     m = m < 0 ? 0 : (m >= M ? M - 1 : m);
-    ent[atomicAdd(&s_cur[m], 1)] = e;
+    ent[atomicAdd(&s_cur[m], 1)] = (ent_t)e;
   }
   __syncthreads();
   // the fill order above depends on scheduling: sort every list ascending (insertion sort; the lists are
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
   for (int m = t; m < M; m += TPB) {
     const int a = s_cnt[m], z = s_cnt[m + 1];
     for (int i = a + 1; i < z; ++i) {
-      const int v = ent[i];
+      const ent_t v = ent[i];
       int j = i - 1;
       while (j >= a && ent[j] > v) { ent[j + 1] = ent[j]; --j; }
       ent[j + 1] = v;
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
   }
   if (LDS_SLAB) {
     __syncthreads();
-    for (int e = t; e < E; e += TPB) gent[e] = s_ent[e];
+    for (int e = t; e < E; e += TPB) gent[e] = (int)s_ent[e];
   }
 }
 
@@ -707,11 +713,11 @@ extern "C" int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets,
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute((const void *)csr_build_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         CSR_LDS_E * (int)sizeof(int));
+                                         CSR_LDS_E * (int)sizeof(unsigned short));
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    csr_build_kernel<true><<<B, TPB, (size_t)E * sizeof(int), (hipStream_t)stream>>>(idx, E, M, offsets, entries);
+    csr_build_kernel<true><<<B, TPB, (size_t)E * sizeof(unsigned short), (hipStream_t)stream>>>(idx, E, M, offsets, entries);
   } else {
     csr_build_kernel<false><<<B, TPB, 0, (hipStream_t)stream>>>(idx, E, M, offsets, entries);
   }

@@ -71,15 +71,25 @@ static inline unsigned long long *probe_slot(dim3 grid) {
 __device__ __forceinline__ unsigned long long probe_begin(const unsigned long long *slot) {
   return slot ? (unsigned long long)wall_clock64() : 0ull;
 }
-__device__ __forceinline__ void probe_end(unsigned long long *slot, unsigned long long t0) {
+__device__ __forceinline__ void probe_end(unsigned long long *slot, unsigned long long t0, unsigned kind = 1) {
   if (!slot) return;
   __syncthreads();                // every wave of the workgroup has issued its last store
   if (threadIdx.x == 0) {
     const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
     *(u64x2 *)&slot[2 + 2 * (size_t)wg] = (u64x2){t0, (unsigned long long)wall_clock64()};
-    if (wg == 0) slot[0] = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
+    if (wg == 0) {
+      slot[0] = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
+      slot[1] = kind;            // 1 streaming GEMM, 2 generic GEMM, 3 small-P GEMM, 4 weight gradient, 5 one-pass backward
+    }
   }
+}
+// CPFN_PROBE_ALL=1 (debugging: tools/dbg/probe_timeline.py): the weight-gradient kernels take probe slots too, which
+// turns the probe buffer into a timeline of the replayed step with ~70 anchors.  Off: bench.py's roofline leg sees the
+// GEMM family only.
+static inline unsigned long long *probe_slot_all(dim3 grid) {
+  static const int all = [] { const char *e = getenv("CPFN_PROBE_ALL"); return e && e[0] == '1'; }();
+  return all ? probe_slot(grid) : nullptr;
 }
 
 constexpr int G_THREADS = 256;
@@ -114,12 +124,12 @@ __device__ __forceinline__ uint4 rot_u16x8(uint4 v, int r) {
 // w_trans == 1: W is [K,N] row-major (the FORWARD layer's weight used for the data gradient): 16-byte
 //               loads along n, transposed on the way into LDS (8-byte pieces, see below), so no transposed
 //               weight copy has to be materialised per step.
-template <int BN, int LDW = G_LDW>
+template <int BN, int LDW = G_LDW, int NT = G_THREADS>
 __device__ __forceinline__ void fill_w_panel(unsigned short *s_w, const unsigned short *__restrict__ W, int K,
                                              int N, int n0, int kc, int kcn, int w_trans, int t) {
   if (!w_trans) {
     const int cpr = kcn / 8;  // 16-byte chunks per row
-    for (int e = t; e < BN * cpr; e += G_THREADS) {
+    for (int e = t; e < BN * cpr; e += NT) {
       const int r = e / cpr, c = e - r * cpr;
       *(uint4 *)&s_w[r * LDW + c * 8] = *(const uint4 *)&W[(size_t)(n0 + r) * K + kc + c * 8];
     }
@@ -130,7 +140,7 @@ __device__ __forceinline__ void fill_w_panel(unsigned short *s_w, const unsigned
     // is 272 B, so 8 rows apart = 2176 B = 17 x 128 B).  The first version wrote single bf16s with that 16-way
     // conflict: the transposed launches ran 25 us against 17.5 us for the plain ones.
     constexpr int cpn = BN / 8;  // 16-byte chunks along n
-    for (int e = t; e < (kcn / 4) * cpn; e += G_THREADS) {
+    for (int e = t; e < (kcn / 4) * cpn; e += NT) {
       const int k4 = e / cpn, c = e - k4 * cpn;
       uint4 v[4];
 #pragma unroll
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
       if (n0 + c2 < N) stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c2] = s;
     }
   }
-  probe_end(probe, probe_t0);
+  probe_end(probe, probe_t0, 2);
 }
 
 template <int LD>
@@ -786,7 +796,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
       *(f32x4 *)&stats_partial[((size_t)blockIdx.x * 2 + 1) * N + n] = sq;
     }
   }
-  probe_end(probe, probe_t0);
+  probe_end(probe, probe_t0, 3);
 }
 
 // ---------------------------------------------------------------- BatchNorm finalize (forward)
@@ -1205,7 +1215,9 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
                                                         const int *__restrict__ gidx, long long P, int N, int K,
                                                         long long rows_per_split, float *__restrict__ partial,
                                                         const float *__restrict__ a_scale,
-                                                        const float *__restrict__ a_shift) {
+                                                        const float *__restrict__ a_shift,
+                                                        unsigned long long *probe = nullptr) {
+  const unsigned long long probe_t0 = probe_begin(probe);
   constexpr int LDN = TN + 8, LDK = TK + 8;       // LDS row strides (elements)
   constexpr int CG = TN / 64, CA = TK / 64;       // 16-byte chunks per thread and step
   constexpr int MI = TN / 32, MJ = TK / 32;       // MFMA tiles per wave (wave sub-tile = TN/2 x TK/2)
@@ -1220,6 +1232,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
       const int n = n0 + e / TK, k = k0 + e % TK;
       if (n < N && k < K) o[(size_t)n * K + k] = 0.f;
     }
+    probe_end(probe, probe_t0, 4);
     return;
   }
   const int wn = (wave >> 1) * (TN / 2), wk = (wave & 1) * (TK / 2);
@@ -1309,6 +1322,173 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
         const int n = n0 + wn + i * 16 + 4 * (lane >> 4) + r, k = k0 + wk + j * 16 + (lane & 15);
         if (n < N && k < K) o[(size_t)n * K + k] = acc[i][j][r];
       }
+  probe_end(probe, probe_t0, 4);
+}
+
+// ---------------------------------------------------------------- weight gradient + data gradient in one pass
+// A dense 128 -> 128 layer's backward reads its BatchNorm-adjoint gradient g_y twice: mlp_wgrad (g_y^T . A) and the
+// data-gradient GEMM (g_y . W).  Here ONE kernel does both from one read: the 32-row g_y tile that the weight-gradient
+// loop stages in LDS anyway (row-major, so its rows are also MFMA point fragments) is multiplied with the transposed
+// weight panel (35 KB of LDS, filled once per workgroup) and the 32 x 128 slab of the data gradient leaves through an
+// LDS patch one step later as 16-byte row-contiguous stores.  BST: as in the streaming GEMM, pass 1 of the BatchNorm
+// backward of the layer BELOW (sum g_z, sum g_z.y) is taken from the slab being stored and the matching rows of that
+// layer's pre-BN output, requested one step ahead.  Grid (1, 1, splits) like mlp_wgrad_kernel<128,128>; N = K = 128.
+template <bool BST>
+__global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
+    const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
+    const unsigned short *__restrict__ W /* forward weight panel [128][128] bf16 */, long long P, long long rows_per_split,
+    float *__restrict__ partial, unsigned short *__restrict__ Gout, int ldo, const float *__restrict__ a_scale,
+    const float *__restrict__ a_shift, const unsigned short *__restrict__ Yb, const float *__restrict__ b_scale,
+    const float *__restrict__ b_shift, float *__restrict__ stats_partial, unsigned long long *probe = nullptr) {
+  // EIGHT waves: a wave's share of the 128 x 128 dW tile is 32 x 64 (32 accumulator registers) and a thread stages one
+  // 16-byte chunk per tensor and step, which keeps the kernel under 256 registers.  That matters inside the replayed
+  // step: a wave of > 256 registers cannot be placed on a SIMD that hosts a wave of the geometry branch (its registers
+  // sit in the middle of the file), and the first version of this kernel (4 waves, 304 registers) then ran in two
+  // rounds — 52-61 us instead of 36 (in-kernel probe, tools/dbg/probe_timeline.py).
+  const unsigned long long probe_t0 = probe_begin(probe);
+  constexpr int T = 128, LD = T + 8, C8 = T / 8, NT = 512;   // 16 chunks of 8 channels per row, 32 rows per step
+  __shared__ __attribute__((aligned(16))) unsigned short s_g[WG_STEP * LD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[WG_STEP * LD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_o[WG_STEP * LD];
+  __shared__ __attribute__((aligned(16))) unsigned short s_wt[T * G_LDW];
+  static_assert(sizeof(float) * 8 * 2 * T <= sizeof(unsigned short) * WG_STEP * LD, "the statistics reduction reuses s_g");
+  float(*s_red)[2][T] = (float(*)[2][T])s_g;        // cross-wave reduction of the statistics: after the last step only
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lq = lane >> 4;
+  const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
+  float *o = partial + (size_t)blockIdx.z * T * T;
+  if (p0 >= p1) {   // empty split: its partial slab (and its statistics row) must still be zero
+    for (int e = t; e < T * T; e += NT) o[e] = 0.f;
+    if (BST) for (int e = t; e < 2 * T; e += NT) stats_partial[(size_t)blockIdx.z * 2 * T + e] = 0.f;
+    probe_end(probe, probe_t0, 5);
+    return;
+  }
+  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 64;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  // thread t of a step: row t / 16, columns 8 (t % 16) — of the staged tiles AND of the slab that leaves
+  const int crow = t / C8, ccol = (t % C8) * 8;
+  uint4 vg[WG_DEPTH], va[WG_DEPTH];
+  float asc[8], ash[8];
+  if (a_scale) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { asc[j] = a_scale[ccol + j]; ash[j] = a_shift[ccol + j]; }
+  }
+  float bsc[8], bsh[8], st_s[8], st_q[8];
+  if (BST) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bsc[j] = b_scale[ccol + j]; bsh[j] = b_shift[ccol + j]; st_s[j] = 0.f; st_q[j] = 0.f; }
+  }
+  auto issue = [&](int sidx, long long base) {
+    const long long p = min(base + crow, p1 - 1);      // clamped: always a valid row, zeroed at store time
+    vg[sidx] = *(const uint4 *)(Gy + p * ldg + ccol);
+    va[sidx] = *(const uint4 *)(A + p * lda + ccol);
+  };
+  auto stage = [&](int sidx, long long base) {
+    uint4 g4 = vg[sidx], a4 = va[sidx];
+    if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
+    if (base + crow >= p1) { g4 = (uint4){0, 0, 0, 0}; a4 = (uint4){0, 0, 0, 0}; }
+    *(uint4 *)&s_g[crow * LD + ccol] = g4;
+    *(uint4 *)&s_a[crow * LD + ccol] = a4;
+  };
+  // the 32 x 128 data-gradient slab of the PREVIOUS step leaves here (its LDS patch was completed before this step's
+  // first barrier): one 16-byte piece per thread
+  uint4 yb;
+  auto store_prev = [&](long long pbase) {
+    const long long p = pbase + crow;
+    const uint4 v = *(const uint4 *)&s_o[crow * LD + ccol];
+    if (p < p1) {
+      *(uint4 *)(Gout + p * ldo + ccol) = v;
+      if (BST) {
+        const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g0 = __uint_as_float(g4[j] << 16), g1 = __uint_as_float(g4[j] & 0xffff0000u);
+          const float y0 = __uint_as_float(y4[j] << 16), y1 = __uint_as_float(y4[j] & 0xffff0000u);
+          const float z0 = fmaf(bsc[2 * j], y0, bsh[2 * j]) > 0.f ? g0 : 0.f;
+          const float z1 = fmaf(bsc[2 * j + 1], y1, bsh[2 * j + 1]) > 0.f ? g1 : 0.f;
+          st_s[2 * j] += z0; st_s[2 * j + 1] += z1;
+          st_q[2 * j] = fmaf(z0, y0, st_q[2 * j]); st_q[2 * j + 1] = fmaf(z1, y1, st_q[2 * j + 1]);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < WG_DEPTH; ++d) issue(d, p0 + (long long)d * WG_STEP);
+  fill_w_panel<T, G_LDW, NT>(s_wt, W, T, T, 0, 0, T, 1, t);        // s_wt[k_out][n]: the forward weight [n][k] transposed
+  long long prev = -1;
+  for (long long base0 = p0; base0 < p1; base0 += WG_STEP * WG_DEPTH) {
+#pragma unroll
+    for (int d = 0; d < WG_DEPTH; ++d) {
+      const long long base = base0 + (long long)d * WG_STEP;
+      __syncthreads();
+      if (prev >= 0) store_prev(prev);
+      stage(d, base);
+      __syncthreads();
+      issue(d, base + WG_STEP * WG_DEPTH);
+      if (BST) yb = *(const uint4 *)(Yb + min(base + crow, p1 - 1) * ldo + ccol);   // this step's slab, used one step later
+      // ---- weight gradient: transposed fragments of both tiles (as mlp_wgrad_kernel)
+      bf16x8 fg[2], fa[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fg[i] = tr_frag<LD>(s_g, wn + 16 * i, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fa[j] = tr_frag<LD>(s_a, wk + 16 * j, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
+      // ---- data gradient of the same 32 rows: wave w owns output channels 16w .. 16w+15
+      f32x4 ad[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 pf0 = *(const bf16x8 *)&s_g[lr * LD + ks * 32 + 8 * lq];
+        const bf16x8 pf1 = *(const bf16x8 *)&s_g[(16 + lr) * LD + ks * 32 + 8 * lq];
+        const bf16x8 wf = *(const bf16x8 *)&s_wt[(wave * 16 + lr) * G_LDW + ks * 32 + 8 * lq];
+        ad[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[0], 0, 0, 0);
+        ad[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const f32x4 v = ad[tt];
+        const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *(bf16x4 *)&s_o[(tt * 16 + lr) * LD + wave * 16 + 4 * lq] = ov;
+      }
+      prev = base;
+    }
+  }
+  __syncthreads();
+  store_prev(prev);
+  // D[row = n-local 4(lane>>4)+r][col = k-local lane&15]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        o[(size_t)(wn + i * 16 + 4 * (lane >> 4) + r) * T + wk + j * 16 + (lane & 15)] = acc[i][j][r];
+  if (BST) {   // threads that share a column chunk (t % 16): two shuffles inside the wave, then the eight waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int m = 16; m < 64; m <<= 1) { st_s[j] += __shfl_xor(st_s[j], m, 64); st_q[j] += __shfl_xor(st_q[j], m, 64); }
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_red[wave][0][lane * 8 + j] = st_s[j]; s_red[wave][1][lane * 8 + j] = st_q[j]; }
+    }
+    __syncthreads();
+    for (int e = t; e < 2 * T; e += NT) {
+      const int which = e / T, c = e - which * T;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += s_red[w][which][c];
+      stats_partial[((size_t)blockIdx.z * 2 + which) * T + c] = v;
+    }
+  }
+  probe_end(probe, probe_t0, 5);
 }
 
 template <int RS>
@@ -1792,16 +1972,43 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
   wgrad_tile(P, N, K, &TN, &TK);
   if (TN == 128 && TK == 128) {
     dim3 grid(N / 128, (K + 127) / 128, splits);
-    mlp_wgrad_kernel<128, 128><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
+    mlp_wgrad_kernel<128, 128><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift, probe_slot_all(grid));
   } else if (TN == 128) {
     dim3 grid(N / 128, (K + 63) / 64, splits);
-    mlp_wgrad_kernel<128, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
+    mlp_wgrad_kernel<128, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift, probe_slot_all(grid));
   } else {
     dim3 grid(N / 64, (K + 63) / 64, splits);
-    mlp_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift);
+    mlp_wgrad_kernel<64, 64><<<grid, 256, 0, st>>>(g, ldg, a, lda, gidx, P, N, K, rps, workspace, a_scale, a_shift, probe_slot_all(grid));
   }
   const long long n = (long long)N * K;
   if (dW) launch_split_reduce(workspace, splits, n, dW, st);    // NULL: the caller batches it (cpfn_multi_split_reduce)
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
+  return N == 128 && K == 128 && P > SP_MAX_ROWS && P >= 32768;
+}
+
+extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
+                                  const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
+                                  const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                  void *stream) {
+  if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gy || !A || !W || !workspace || !Gout || (ldg & 7) || (lda & 7) || (ldo & 7) ||
+      ldg < N || lda < K || ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)))
+    return CPFN_EINVAL;
+  const int splits = cpfn_mlp_wgrad_splits(P, N, K);
+  long long rps = (P + splits - 1) / splits;
+  rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
+  const dim3 grid(1, 1, splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (bwd_y)
+    mlp_bwd_fused_kernel<true><<<grid, 512, 0, st>>>((const unsigned short *)Gy, ldg, (const unsigned short *)A, lda,
+                                                     (const unsigned short *)W, P, rps, workspace, (unsigned short *)Gout, ldo,
+                                                     a_scale, a_shift, (const unsigned short *)bwd_y, b_scale, b_shift, stats_partial, probe_slot_all(grid));
+  else
+    mlp_bwd_fused_kernel<false><<<grid, 512, 0, st>>>((const unsigned short *)Gy, ldg, (const unsigned short *)A, lda,
+                                                      (const unsigned short *)W, P, rps, workspace, (unsigned short *)Gout, ldo,
+                                                      a_scale, a_shift, nullptr, nullptr, nullptr, nullptr, probe_slot_all(grid));
   return cpfn_launch_status();
 }
 

@@ -35,6 +35,9 @@ BN_NOSTORE = os.environ.get("CPFN_BN_NOSTORE", "1") == "1"
 # the data-gradient GEMM that produces the gradient
 BWD_STATS_FUSED = os.environ.get("CPFN_BWD_STATS_FUSED", "1") != "0"
 BN_APPLY_FUSED = os.environ.get("CPFN_BN_APPLY_FUSED", "1") == "1"
+# dense 128 -> 128 layers with >= 32768 rows: weight gradient + data gradient (+ the BatchNorm-backward reduction of the
+# layer below) as one kernel over one read of G_y (cpfn_mlp_bwd_fused); CPFN_FUSED_BWD=0 keeps the two-kernel pair
+FUSED_BWD = os.environ.get("CPFN_FUSED_BWD", "1") != "0"
 
 
 def _pad_to(n, m):
@@ -451,10 +454,32 @@ class _FusedStack(torch.autograd.Function):
                     Kp = a_in.shape[1]
                     splits = h.cpfn_mlp_wgrad_splits(P, N, Kp)
                     ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
-                    _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
-                                            None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
-                                            _ptr(ws), None, _stream()), "cpfn_mlp_wgrad")
-                    _l.add_bytes("cpfn_mlp_wgrad", 2 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
+                    need_dgrad = li > 0 or ctx.x_needs_grad
+                    one_pass = (FUSED_BWD and need_dgrad and a_in.stride(0) == Kp and h.cpfn_mlp_bwd_fused_ok(P, N, Kp))
+                    if one_pass:
+                        # dense 128 -> 128 layer: weight gradient, data gradient and pass 1 of the BatchNorm backward of
+                        # the layer below from ONE read of G_y (mlp_bwd_fused_kernel)
+                        below = li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None
+                        g = torch.empty(P, Kp, dtype=BF16, device=dev)
+                        if below:
+                            Yp, stp = saved[li - 1][2], saved[li - 1][3]
+                            fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev)
+                        _check(h.cpfn_mlp_bwd_fused(_ptr(Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp,
+                                                    None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
+                                                    _ptr(ws), _ptr(g), Kp, _ptr(Yp) if below else None,
+                                                    _ptr(stp[0]) if below else None, _ptr(stp[1]) if below else None,
+                                                    _ptr(fp_) if below else None, _stream()), "cpfn_mlp_bwd_fused")
+                        _l.add_bytes("cpfn_mlp_bwd_fused", 2 * P * N + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
+                                     + ((2 * P * Kp + 8 * splits * Kp) if below else 0))
+                        if below:
+                            fused_part = (fp_, splits)
+                        if li == 0:
+                            gx = g
+                    else:
+                        _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
+                                                None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
+                                                _ptr(ws), None, _stream()), "cpfn_mlp_wgrad")
+                        _l.add_bytes("cpfn_mlp_wgrad", 2 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
                     # the split partials are finished by ONE launch at the end of the backward pass; a zero-padded K
                     # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
                     dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
@@ -463,7 +488,7 @@ class _FusedStack(torch.autograd.Function):
                     else:
                         _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin)
                     grads[3 * li] = dW.reshape(wshape)
-                    if li > 0 or ctx.x_needs_grad:
+                    if need_dgrad and not one_pass:
                         # G_y [P,N] · W [N,Kp]; where the streaming kernel runs, it also reduces the BatchNorm backward
                         # of the layer below from the gradient it is writing
                         if li > 0 and BN_NOSTORE and can_fuse_bwd_stats(P, N, Kp) and saved[li - 1][5] is None:

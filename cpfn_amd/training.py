@@ -482,11 +482,23 @@ class SPFNTrainer:
         if st["single"]:
             # Device-side assignment (cpfn_hungarian_match): the step has no host round trip and is ONE graph.
             g = torch.cuda.CUDAGraph()
+            stamps = st["stamps"] = (torch.zeros(5, dtype=torch.int64, device=dev)
+                                     if os.environ.get("CPFN_STEP_STAMPS") == "1" else None)
+
+            def stamp(i):       # debugging: device wall-clock readings inside the replayed step
+                if stamps is not None:
+                    from . import lib as _l
+                    _l.check(_l.lib().cpfn_stamp(stamps[i:].data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cpfn_stamp")
+
             with torch.cuda.graph(g, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
+                if stamps is not None:
+                    stamps[4:5].copy_(stamps[3:4])                  # when the PREVIOUS replay was joined
+                stamp(0)
                 self._copy_all(geomA, geomB)
                 self._gside.wait_stream(self._gstream)              # fork (after B was read): next batch's geometry
                 with torch.cuda.stream(self._gside):
                     geometry_into_B(st["P_next"])
+                    stamp(1)
                 self.bucket.zero()
                 self.module(sb["P"], geometry=st["geomA"])
                 if fl.PARALLEL_BRANCHES:
@@ -508,7 +520,9 @@ class SPFNTrainer:
                     self.bucket.all_reduce_mean()
                     self._checked_optimizer_step(st["skipped"])
                 st["out"] = tuple(o.detach() for o in out)
+                stamp(2)
                 self._gstream.wait_stream(self._gside)              # join
+                stamp(3)
             st["g"] = g
             st["exchange_in_graph"] = world > 1 and exchange_in_graph
             st["geom_ready_for"] = None

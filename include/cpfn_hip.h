@@ -289,6 +289,9 @@ CPFN_API int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N);
 CPFN_API int cpfn_mlp_gemm_set_probe(void *buf, int slots, int max_wg);
 /* Rate in kHz of the device wall clock the probe's ticks are counted in (hipDeviceAttributeWallClockRate); <= 0 on error. */
 CPFN_API int cpfn_wall_clock_khz(int device);
+/* One reading of that clock into *dst, issued as a (capturable) 1-thread kernel on `stream`: a time stamp inside a
+ * replayed graph (debugging aid: CPFN_STEP_STAMPS=1). */
+CPFN_API int cpfn_stamp(unsigned long long *dst, void *stream);
 CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
                            float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,
@@ -350,6 +353,18 @@ CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,
                             float *dW, void *stream);
+/* Weight gradient AND data gradient of a dense 128 -> 128 layer from ONE read of its BatchNorm-adjoint gradient
+ * (cpfn_mlp_bwd_fused_ok(P,N,K): N = K = 128, P >= 32768): workspace receives the split partials of
+ * dW = Gy^T . A exactly as cpfn_mlp_wgrad leaves them (cpfn_mlp_wgrad_splits(P,128,128) slabs; finish them with
+ * cpfn_multi_split_reduce), Gout[P,128] (bf16, row stride ldo) = Gy . W with W the FORWARD weight panel [128][128]
+ * bf16.  a_scale / a_shift: as in cpfn_mlp_wgrad.  bwd_y (optional) + b_scale / b_shift + stats_partial
+ * [splits][2][128]: pass 1 of the BatchNorm backward of the layer below, as cpfn_mlp_gemm's bwd_y (one partial row per
+ * split).  Replaces a cpfn_mlp_wgrad + cpfn_mlp_gemm(w_trans) pair. */
+CPFN_API int cpfn_mlp_bwd_fused_ok(long long P, int N, int K);
+CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
+                                const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
+                                const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
  * workspace: ceil(P/256)*C floats.  pad_bf16 (optional): [P,64] bf16, receives the rows of X converted to bf16
  * and zero-padded to 64 columns in the same pass (the gradient operand of the heads' GEMMs).

@@ -299,3 +299,35 @@ def test_bn_backward_reduction_on_the_data_gradient_gemm(name, P, cin, widths, p
     assert _rel(gxa, gxb) < 2e-3, _rel(gxa, gxb)
     for a, b in zip(gra, grb):
         assert (a is None and b is None) or _rel(a, b) < 2e-3
+
+
+@pytest.mark.parametrize("name,P,cin,widths,pool_k", [
+    ("sfp3-like", 40000 + 77, 128, [128, 128, 128], None),
+    ("sa2-like", 2 * 300 * 64, 131, [128, 128, 256], 64),
+    ("fc1-like", 32768, 128, [128], None),
+])
+@pytest.mark.parametrize("stats_fused", [False, True])
+def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_fused, monkeypatch):
+    """cpfn_mlp_bwd_fused (weight gradient + data gradient [+ BatchNorm-backward pass 1 of the layer below] of a dense
+    128 -> 128 layer from one read of G_y) against the cpfn_mlp_wgrad + cpfn_mlp_gemm pair: the same MFMA sequences on
+    the same operands, so bit-identical; with the statistics riding along only their summation order differs."""
+    from cpfn_amd import fused_mlp, lib as _l
+    assert _l.lib().cpfn_mlp_bwd_fused_ok(P, 128, 128) == 1
+    convs, bns = _stack(cin, widths, seed=13)
+    g = torch.Generator().manual_seed(P)
+    x = torch.randn(P, cin, generator=g).to(dev())
+    gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
+    monkeypatch.setattr(fused_mlp, "BWD_STATS_FUSED", stats_fused)
+    res = {}
+    for one_pass in (True, False):
+        monkeypatch.setattr(fused_mlp, "FUSED_BWD", one_pass)
+        _l.byte_census(True)
+        res[one_pass] = _run(x, convs, bns, torch.bfloat16, pool_k, None, gout)
+        census = _l.byte_census(False)
+        assert ("cpfn_mlp_bwd_fused" in census) == one_pass, sorted(census)
+    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
+    same = (lambda a, b: _rel(a, b) < 2e-3) if stats_fused else torch.equal
+    assert torch.equal(ya, yb)
+    assert same(gxa, gxb)
+    for a, b in zip(gra, grb):
+        assert (a is None and b is None) or same(a, b)
