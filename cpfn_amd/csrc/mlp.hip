@@ -1333,13 +1333,18 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 // LDS patch one step later as 16-byte row-contiguous stores.  BST: as in the streaming GEMM, pass 1 of the BatchNorm
 // backward of the layer BELOW (sum g_z, sum g_z.y) is taken from the slab being stored and the matching rows of that
 // layer's pre-BN output, requested one step ahead.  Grid (1, 1, splits) like mlp_wgrad_kernel<128,128>; N = K = 128.
-template <bool BST>
+// APPLY: Gy is the gradient with respect to the layer's ACTIVATED output and the BatchNorm-backward apply pass
+// (g_y = c0 . [scale . y + shift > 0] . g + c1 . y + c2, rounded to bf16 exactly as cpfn_bn_bwd_apply stores it) runs on
+// the staged chunks from the layer's own pre-BN output Yr: g_y is never written to or read from memory.
+template <bool BST, bool APPLY>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
     const unsigned short *__restrict__ W /* forward weight panel [128][128] bf16 */, long long P, long long rows_per_split,
     float *__restrict__ partial, unsigned short *__restrict__ Gout, int ldo, const float *__restrict__ a_scale,
     const float *__restrict__ a_shift, const unsigned short *__restrict__ Yb, const float *__restrict__ b_scale,
-    const float *__restrict__ b_shift, float *__restrict__ stats_partial, unsigned long long *probe = nullptr) {
+    const float *__restrict__ b_shift, float *__restrict__ stats_partial, const unsigned short *__restrict__ Yr,
+    const float *__restrict__ coef /* [3][128] */, const float *__restrict__ y_scale, const float *__restrict__ y_shift,
+    unsigned long long *probe = nullptr) {
   // EIGHT waves: a wave's share of the 128 x 128 dW tile is 32 x 64 (32 accumulator registers) and a thread stages one
   // 16-byte chunk per tensor and step, which keeps the kernel under 256 registers.  That matters inside the replayed
   // step: a wave of > 256 registers cannot be placed on a SIMD that hosts a wave of the geometry branch (its registers
@@ -1370,11 +1375,19 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
   // thread t of a step: row t / 16, columns 8 (t % 16) — of the staged tiles AND of the slab that leaves
   const int crow = t / C8, ccol = (t % C8) * 8;
-  uint4 vg[WG_DEPTH], va[WG_DEPTH];
+  uint4 vg[WG_DEPTH], va[WG_DEPTH], vy[APPLY ? WG_DEPTH : 1];
   float asc[8], ash[8];
   if (a_scale) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { asc[j] = a_scale[ccol + j]; ash[j] = a_shift[ccol + j]; }
+  }
+  // APPLY: the five per-channel vectors wait in LDS and are re-read at every stage (40 registers otherwise: with them
+  // the kernel needs 237, and two such waves plus a 56-register wave of the geometry branch do not fit one SIMD)
+  __shared__ __attribute__((aligned(16))) float s_cf[APPLY ? 5 * T : 4];
+  if (APPLY) {
+    for (int e = t; e < 3 * T; e += NT) s_cf[e] = coef[e];
+    if (t < T) { s_cf[3 * T + t] = y_scale[t]; s_cf[4 * T + t] = y_shift[t]; }
+    // (visible after the first barrier of the step loop)
   }
   float bsc[8], bsh[8], st_s[8], st_q[8];
   if (BST) {
@@ -1385,9 +1398,35 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const long long p = min(base + crow, p1 - 1);      // clamped: always a valid row, zeroed at store time
     vg[sidx] = *(const uint4 *)(Gy + p * ldg + ccol);
     va[sidx] = *(const uint4 *)(A + p * lda + ccol);
+    if (APPLY) vy[sidx] = *(const uint4 *)(Yr + p * ldg + ccol);
   };
   auto stage = [&](int sidx, long long base) {
     uint4 g4 = vg[sidx], a4 = va[sidx];
+    if (APPLY) {     // (the arithmetic of bn_bwd_apply_kernel<true>, element for element)
+      const uint4 y4 = vy[sidx];
+      const unsigned gw[4] = {g4.x, g4.y, g4.z, g4.w}, yw[4] = {y4.x, y4.y, y4.z, y4.w};
+      unsigned ow[4];
+      int zero;                                        // opaque 0: keeps these loop-invariant reads INSIDE the loop
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+      const float *cp = &s_cf[ccol + zero];
+      float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];
+      *(float4 *)&cf0[0] = *(const float4 *)&cp[0];         *(float4 *)&cf0[4] = *(const float4 *)&cp[4];
+      *(float4 *)&cf1[0] = *(const float4 *)&cp[T];         *(float4 *)&cf1[4] = *(const float4 *)&cp[T + 4];
+      *(float4 *)&cf2[0] = *(const float4 *)&cp[2 * T];     *(float4 *)&cf2[4] = *(const float4 *)&cp[2 * T + 4];
+      *(float4 *)&ysc[0] = *(const float4 *)&cp[3 * T];     *(float4 *)&ysc[4] = *(const float4 *)&cp[3 * T + 4];
+      *(float4 *)&ysh[0] = *(const float4 *)&cp[4 * T];     *(float4 *)&ysh[4] = *(const float4 *)&cp[4 * T + 4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
+        float z0 = __uint_as_float(gw[j] << 16), z1 = __uint_as_float(gw[j] & 0xffff0000u);
+        z0 = fmaf(ysc[2 * j], y0, ysh[2 * j]) > 0.f ? z0 : 0.f;
+        z1 = fmaf(ysc[2 * j + 1], y1, ysh[2 * j + 1]) > 0.f ? z1 : 0.f;
+        const unsigned lo = f2bf(fmaf(cf0[2 * j], z0, fmaf(cf1[2 * j], y0, cf2[2 * j])));
+        const unsigned hi = f2bf(fmaf(cf0[2 * j + 1], z1, fmaf(cf1[2 * j + 1], y1, cf2[2 * j + 1])));
+        ow[j] = lo | (hi << 16);
+      }
+      g4 = (uint4){ow[0], ow[1], ow[2], ow[3]};
+    }
     if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
     if (base + crow >= p1) { g4 = (uint4){0, 0, 0, 0}; a4 = (uint4){0, 0, 0, 0}; }
     *(uint4 *)&s_g[crow * LD + ccol] = g4;
@@ -1992,23 +2031,29 @@ extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
 extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
                                   const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
                                   const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                  const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
                                   void *stream) {
   if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gy || !A || !W || !workspace || !Gout || (ldg & 7) || (lda & 7) || (ldo & 7) ||
-      ldg < N || lda < K || ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)))
+      ldg < N || lda < K || ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)) ||
+      (apply_y && (!apply_coef || !y_scale || !y_shift)))
     return CPFN_EINVAL;
   const int splits = cpfn_mlp_wgrad_splits(P, N, K);
   long long rps = (P + splits - 1) / splits;
   rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
   const dim3 grid(1, 1, splits);
   hipStream_t st = (hipStream_t)stream;
-  if (bwd_y)
-    mlp_bwd_fused_kernel<true><<<grid, 512, 0, st>>>((const unsigned short *)Gy, ldg, (const unsigned short *)A, lda,
-                                                     (const unsigned short *)W, P, rps, workspace, (unsigned short *)Gout, ldo,
-                                                     a_scale, a_shift, (const unsigned short *)bwd_y, b_scale, b_shift, stats_partial, probe_slot_all(grid));
-  else
-    mlp_bwd_fused_kernel<false><<<grid, 512, 0, st>>>((const unsigned short *)Gy, ldg, (const unsigned short *)A, lda,
-                                                      (const unsigned short *)W, P, rps, workspace, (unsigned short *)Gout, ldo,
-                                                      a_scale, a_shift, nullptr, nullptr, nullptr, nullptr, probe_slot_all(grid));
+  const unsigned short *g = (const unsigned short *)Gy, *a = (const unsigned short *)A, *w = (const unsigned short *)W,
+                       *yb = (const unsigned short *)bwd_y, *yr = (const unsigned short *)apply_y;
+  unsigned short *go = (unsigned short *)Gout;
+#define CPFN_BWD_FUSED(BST_, APPLY_)                                                                                       \
+  mlp_bwd_fused_kernel<BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, a_scale, a_shift, yb, \
+                                                           b_scale, b_shift, stats_partial, yr, apply_coef, y_scale, y_shift,  \
+                                                           probe_slot_all(grid))
+  if (bwd_y && apply_y) CPFN_BWD_FUSED(true, true);
+  else if (bwd_y) CPFN_BWD_FUSED(true, false);
+  else if (apply_y) CPFN_BWD_FUSED(false, true);
+  else CPFN_BWD_FUSED(false, false);
+#undef CPFN_BWD_FUSED
   return cpfn_launch_status();
 }
 

@@ -38,6 +38,9 @@ BN_APPLY_FUSED = os.environ.get("CPFN_BN_APPLY_FUSED", "1") == "1"
 # dense 128 -> 128 layers with >= 32768 rows: weight gradient + data gradient (+ the BatchNorm-backward reduction of the
 # layer below) as one kernel over one read of G_y (cpfn_mlp_bwd_fused); CPFN_FUSED_BWD=0 keeps the two-kernel pair
 FUSED_BWD = os.environ.get("CPFN_FUSED_BWD", "1") != "0"
+# ... and the BatchNorm-backward apply pass of that layer inside the same kernel (g_y never stored); CPFN_FUSED_BWD_APPLY=0:
+# cpfn_bn_bwd_apply as its own launch
+FUSED_BWD_APPLY = os.environ.get("CPFN_FUSED_BWD_APPLY", "1") != "0"
 
 
 def _pad_to(n, m):
@@ -390,6 +393,11 @@ class _FusedStack(torch.autograd.Function):
                 dgb = torch.empty(2, N, dtype=torch.float32, device=dev)
                 coef = torch.empty(3, N, dtype=torch.float32, device=dev)
                 gamma = L.gamma.detach()
+                # dense 128 -> 128 layer with a data gradient to produce: one kernel for weight gradient + data gradient
+                need_dgrad = li > 0 or ctx.x_needs_grad
+                one_pass = (FUSED_BWD and need_dgrad and not (li == 0 and first_fp32) and a_in.stride(0) == a_in.shape[1]
+                            and bool(h.cpfn_mlp_bwd_fused_ok(P, N, a_in.shape[1])))
+                apply_in_pass = False
                 if arg is not None:
                     G = P // pool_k
                     # only the arg-max row of each group carries gradient: the reduction is the dense one over
@@ -429,7 +437,9 @@ class _FusedStack(torch.autograd.Function):
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    if nostore:
+                    if nostore and one_pass and dseed is None and FUSED_BWD_APPLY:
+                        apply_in_pass = True        # g_y = c0 [z > 0] g + c1 y + c2 is formed on the one-pass kernel's staged chunks
+                    elif nostore:
                         _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
                                                    _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
                         _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
@@ -454,23 +464,25 @@ class _FusedStack(torch.autograd.Function):
                     Kp = a_in.shape[1]
                     splits = h.cpfn_mlp_wgrad_splits(P, N, Kp)
                     ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
-                    need_dgrad = li > 0 or ctx.x_needs_grad
-                    one_pass = (FUSED_BWD and need_dgrad and a_in.stride(0) == Kp and h.cpfn_mlp_bwd_fused_ok(P, N, Kp))
                     if one_pass:
                         # dense 128 -> 128 layer: weight gradient, data gradient and pass 1 of the BatchNorm backward of
                         # the layer below from ONE read of G_y (mlp_bwd_fused_kernel)
                         below = li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None
+                        g_up = g                      # gradient w.r.t. the activated output (apply_in_pass) ...
                         g = torch.empty(P, Kp, dtype=BF16, device=dev)
                         if below:
                             Yp, stp = saved[li - 1][2], saved[li - 1][3]
                             fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev)
-                        _check(h.cpfn_mlp_bwd_fused(_ptr(Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp,
+                        ap = apply_in_pass
+                        _check(h.cpfn_mlp_bwd_fused(_ptr(g_up if ap else Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp,
                                                     None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
                                                     _ptr(ws), _ptr(g), Kp, _ptr(Yp) if below else None,
                                                     _ptr(stp[0]) if below else None, _ptr(stp[1]) if below else None,
-                                                    _ptr(fp_) if below else None, _stream()), "cpfn_mlp_bwd_fused")
+                                                    _ptr(fp_) if below else None, _ptr(Y) if ap else None,
+                                                    _ptr(coef) if ap else None, _ptr(st[0]) if ap else None,
+                                                    _ptr(st[1]) if ap else None, _stream()), "cpfn_mlp_bwd_fused")
                         _l.add_bytes("cpfn_mlp_bwd_fused", 2 * P * N + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
-                                     + ((2 * P * Kp + 8 * splits * Kp) if below else 0))
+                                     + ((2 * P * Kp + 8 * splits * Kp) if below else 0) + (2 * P * N if ap else 0))
                         if below:
                             fused_part = (fp_, splits)
                         if li == 0:

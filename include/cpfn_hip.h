@@ -359,11 +359,15 @@ CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, con
  * cpfn_multi_split_reduce), Gout[P,128] (bf16, row stride ldo) = Gy . W with W the FORWARD weight panel [128][128]
  * bf16.  a_scale / a_shift: as in cpfn_mlp_wgrad.  bwd_y (optional) + b_scale / b_shift + stats_partial
  * [splits][2][128]: pass 1 of the BatchNorm backward of the layer below, as cpfn_mlp_gemm's bwd_y (one partial row per
- * split).  Replaces a cpfn_mlp_wgrad + cpfn_mlp_gemm(w_trans) pair. */
+ * split).  apply_y (optional) + apply_coef [3][128] + y_scale / y_shift: Gy is then the gradient with respect to the
+ * layer's ACTIVATED output and cpfn_bn_bwd_apply's arithmetic (ReLU mask from apply_y = the layer's pre-BN output,
+ * g_y = c0 . g_z + c1 . y + c2, bf16-rounded) runs on the staged chunks: g_y never exists in memory.
+ * Replaces a [cpfn_bn_bwd_apply +] cpfn_mlp_wgrad + cpfn_mlp_gemm(w_trans) sequence, bit for bit. */
 CPFN_API int cpfn_mlp_bwd_fused_ok(long long P, int N, int K);
 CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
                                 const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
                                 const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
                                 void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
  * workspace: ceil(P/256)*C floats.  pad_bf16 (optional): [P,64] bf16, receives the rows of X converted to bf16

@@ -307,7 +307,8 @@ def test_bn_backward_reduction_on_the_data_gradient_gemm(name, P, cin, widths, p
     ("fc1-like", 32768, 128, [128], None),
 ])
 @pytest.mark.parametrize("stats_fused", [False, True])
-def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_fused, monkeypatch):
+@pytest.mark.parametrize("apply_fused", [True, False])
+def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_fused, apply_fused, monkeypatch):
     """cpfn_mlp_bwd_fused (weight gradient + data gradient [+ BatchNorm-backward pass 1 of the layer below] of a dense
     128 -> 128 layer from one read of G_y) against the cpfn_mlp_wgrad + cpfn_mlp_gemm pair: the same MFMA sequences on
     the same operands, so bit-identical; with the statistics riding along only their summation order differs."""
@@ -318,6 +319,7 @@ def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_f
     x = torch.randn(P, cin, generator=g).to(dev())
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
     monkeypatch.setattr(fused_mlp, "BWD_STATS_FUSED", stats_fused)
+    monkeypatch.setattr(fused_mlp, "FUSED_BWD_APPLY", apply_fused)     # the BatchNorm apply pass inside the same kernel
     res = {}
     for one_pass in (True, False):
         monkeypatch.setattr(fused_mlp, "FUSED_BWD", one_pass)
@@ -325,6 +327,9 @@ def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_f
         res[one_pass] = _run(x, convs, bns, torch.bfloat16, pool_k, None, gout)
         census = _l.byte_census(False)
         assert ("cpfn_mlp_bwd_fused" in census) == one_pass, sorted(census)
+        if one_pass and apply_fused and name != "fc1-like":      # every eligible layer lost its stand-alone apply launch
+            n_apply = census.get("cpfn_bn_bwd_apply", (0, 0))[0]
+            assert n_apply < len(widths), (n_apply, sorted(census))
     (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
     same = (lambda a, b: _rel(a, b) < 2e-3) if stats_fused else torch.equal
     assert torch.equal(ya, yb)
