@@ -1326,166 +1326,203 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 }
 
 // ---------------------------------------------------------------- weight gradient + data gradient in one pass
-// A dense 128 -> 128 layer's backward reads its BatchNorm-adjoint gradient g_y twice: mlp_wgrad (g_y^T . A) and the
-// data-gradient GEMM (g_y . W).  Here ONE kernel does both from one read: the 32-row g_y tile that the weight-gradient
-// loop stages in LDS anyway (row-major, so its rows are also MFMA point fragments) is multiplied with the transposed
-// weight panel (35 KB of LDS, filled once per workgroup) and the 32 x 128 slab of the data gradient leaves through an
-// LDS patch one step later as 16-byte row-contiguous stores.  BST: as in the streaming GEMM, pass 1 of the BatchNorm
-// backward of the layer BELOW (sum g_z, sum g_z.y) is taken from the slab being stored and the matching rows of that
-// layer's pre-BN output, requested one step ahead.  Grid (1, 1, splits) like mlp_wgrad_kernel<128,128>; N = K = 128.
-// APPLY: Gy is the gradient with respect to the layer's ACTIVATED output and the BatchNorm-backward apply pass
+// A dense layer's backward reads its BatchNorm-adjoint gradient g_y twice: mlp_wgrad (g_y^T . A) and the data-gradient
+// GEMM (g_y . W).  Here ONE kernel does both from one read: the g_y tile that the weight-gradient loop stages in LDS
+// anyway (row-major, so its rows are also MFMA point fragments) is multiplied with the transposed weight panel (filled
+// once per workgroup) and the STEP x TK slab of the data gradient leaves through an LDS patch one step later as 16-byte
+// row-contiguous stores.  BST: as in the streaming GEMM, pass 1 of the BatchNorm backward of the layer BELOW (sum g_z,
+// sum g_z.y) is taken from the slab being stored and the matching rows of that layer's pre-BN output, requested one step
+// ahead.  APPLY: Gy is the gradient with respect to the layer's ACTIVATED output and the BatchNorm-backward apply pass
 // (g_y = c0 . [scale . y + shift > 0] . g + c1 . y + c2, rounded to bf16 exactly as cpfn_bn_bwd_apply stores it) runs on
 // the staged chunks from the layer's own pre-BN output Yr: g_y is never written to or read from memory.
-template <bool BST, bool APPLY>
+// Shapes <TN, TK, STEP>: <128,128,32>, <64,64,64>, <128,64,64> (layer N -> channels of g_y, K -> channels of its input;
+// STEP rows per step, 128 rows in flight).  Grid (1, 1, splits), the split layout of mlp_wgrad_kernel: same partials,
+// bit for bit.
+// EIGHT waves: for <128,128> a wave's share of the dW tile is 32 x 64 (32 accumulator registers) and a thread stages one
+// 16-byte chunk per tensor and step, which keeps the kernel under 224 registers.  That matters inside the replayed step:
+// a wave of > 256 registers cannot be placed on a SIMD that hosts a wave of the geometry branch, and the first version
+// (4 waves, 304 registers) then ran in two rounds — 52-61 us instead of 36 (in-kernel probe, tools/dbg/probe_timeline.py).
+template <int TN, int TK, int STEP, bool BST, bool APPLY>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
-    const unsigned short *__restrict__ W /* forward weight panel [128][128] bf16 */, long long P, long long rows_per_split,
+    const unsigned short *__restrict__ W /* forward weight panel [TN][TK] bf16 */, long long P, long long rows_per_split,
     float *__restrict__ partial, unsigned short *__restrict__ Gout, int ldo, const float *__restrict__ a_scale,
     const float *__restrict__ a_shift, const unsigned short *__restrict__ Yb, const float *__restrict__ b_scale,
     const float *__restrict__ b_shift, float *__restrict__ stats_partial, const unsigned short *__restrict__ Yr,
-    const float *__restrict__ coef /* [3][128] */, const float *__restrict__ y_scale, const float *__restrict__ y_shift,
+    const float *__restrict__ coef /* [3][TN] */, const float *__restrict__ y_scale, const float *__restrict__ y_shift,
     unsigned long long *probe = nullptr) {
-  // EIGHT waves: a wave's share of the 128 x 128 dW tile is 32 x 64 (32 accumulator registers) and a thread stages one
-  // 16-byte chunk per tensor and step, which keeps the kernel under 256 registers.  That matters inside the replayed
-  // step: a wave of > 256 registers cannot be placed on a SIMD that hosts a wave of the geometry branch (its registers
-  // sit in the middle of the file), and the first version of this kernel (4 waves, 304 registers) then ran in two
-  // rounds — 52-61 us instead of 36 (in-kernel probe, tools/dbg/probe_timeline.py).
   const unsigned long long probe_t0 = probe_begin(probe);
-  constexpr int T = 128, LD = T + 8, C8 = T / 8, NT = 512;   // 16 chunks of 8 channels per row, 32 rows per step
-  __shared__ __attribute__((aligned(16))) unsigned short s_g[WG_STEP * LD];
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[WG_STEP * LD];
-  __shared__ __attribute__((aligned(16))) unsigned short s_o[WG_STEP * LD];
-  __shared__ __attribute__((aligned(16))) unsigned short s_wt[T * G_LDW];
-  static_assert(sizeof(float) * 8 * 2 * T <= sizeof(unsigned short) * WG_STEP * LD, "the statistics reduction reuses s_g");
-  float(*s_red)[2][T] = (float(*)[2][T])s_g;        // cross-wave reduction of the statistics: after the last step only
+  constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP, KSTEPS = STEP / 32;
+  constexpr int CPRG = TN / 8, CPRA = TK / 8;                 // 16-byte chunks per row of the TN- / TK-wide tensors
+  constexpr int NG = STEP * CPRG / NT, NA = STEP * CPRA / NT; // chunks per thread and step
+  constexpr int MI = TN / 64, MJ = TK / 32;                   // dW tiles per wave (waves 4 x 2 over TN x TK)
+  constexpr int CHB = TK / 16;                                // 16-channel blocks of the data-gradient slab
+  static_assert(NG >= 1 && NA >= 1 && STEP * DEPTH == WG_STEP * WG_DEPTH && (STEP / 16) * CHB == 16, "shape");
+  __shared__ __attribute__((aligned(16))) unsigned short s_g[STEP * LDN];
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[STEP * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned short s_o[STEP * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned short s_wt[TK * LDN];
+  static_assert(sizeof(float) * 8 * 2 * TK <= sizeof(unsigned short) * STEP * LDN, "the statistics reduction reuses s_g");
+  float(*s_red)[2][TK] = (float(*)[2][TK])s_g;      // cross-wave reduction of the statistics: after the last step only
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lq = lane >> 4;
   const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
-  float *o = partial + (size_t)blockIdx.z * T * T;
+  float *o = partial + (size_t)blockIdx.z * TN * TK;
   if (p0 >= p1) {   // empty split: its partial slab (and its statistics row) must still be zero
-    for (int e = t; e < T * T; e += NT) o[e] = 0.f;
-    if (BST) for (int e = t; e < 2 * T; e += NT) stats_partial[(size_t)blockIdx.z * 2 * T + e] = 0.f;
+    for (int e = t; e < TN * TK; e += NT) o[e] = 0.f;
+    if (BST) for (int e = t; e < 2 * TK; e += NT) stats_partial[(size_t)blockIdx.z * 2 * TK + e] = 0.f;
     probe_end(probe, probe_t0, 5);
     return;
   }
-  const int wn = (wave >> 1) * 32, wk = (wave & 1) * 64;
-  f32x4 acc[2][4];
+  const int wn = (wave >> 1) * (TN / 4), wk = (wave & 1) * (TK / 2);
+  f32x4 acc[MI][MJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
-  // thread t of a step: row t / 16, columns 8 (t % 16) — of the staged tiles AND of the slab that leaves
-  const int crow = t / C8, ccol = (t % C8) * 8;
-  uint4 vg[WG_DEPTH], va[WG_DEPTH], vy[APPLY ? WG_DEPTH : 1];
+    for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  // chunk i of thread t: row t / CPR + i (NT / CPR), columns 8 (t % CPR) — a thread's columns never change
+  const int grow = t / CPRG, gcol = (t % CPRG) * 8, arow = t / CPRA, acol = (t % CPRA) * 8;
+  uint4 vg[DEPTH][NG], va[DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
   float asc[8], ash[8];
   if (a_scale) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { asc[j] = a_scale[ccol + j]; ash[j] = a_shift[ccol + j]; }
+    for (int j = 0; j < 8; ++j) { asc[j] = a_scale[acol + j]; ash[j] = a_shift[acol + j]; }
   }
   // APPLY: the five per-channel vectors wait in LDS and are re-read at every stage (40 registers otherwise: with them
-  // the kernel needs 237, and two such waves plus a 56-register wave of the geometry branch do not fit one SIMD)
-  __shared__ __attribute__((aligned(16))) float s_cf[APPLY ? 5 * T : 4];
+  // the <128,128> kernel needs 237, and two such waves plus a 56-register wave of the geometry branch do not fit one SIMD)
+  __shared__ __attribute__((aligned(16))) float s_cf[APPLY ? 5 * TN : 4];
   if (APPLY) {
-    for (int e = t; e < 3 * T; e += NT) s_cf[e] = coef[e];
-    if (t < T) { s_cf[3 * T + t] = y_scale[t]; s_cf[4 * T + t] = y_shift[t]; }
+    for (int e = t; e < 3 * TN; e += NT) s_cf[e] = coef[e];
+    if (t < TN) { s_cf[3 * TN + t] = y_scale[t]; s_cf[4 * TN + t] = y_shift[t]; }
     // (visible after the first barrier of the step loop)
   }
   float bsc[8], bsh[8], st_s[8], st_q[8];
   if (BST) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { bsc[j] = b_scale[ccol + j]; bsh[j] = b_shift[ccol + j]; st_s[j] = 0.f; st_q[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { bsc[j] = b_scale[acol + j]; bsh[j] = b_shift[acol + j]; st_s[j] = 0.f; st_q[j] = 0.f; }
   }
   auto issue = [&](int sidx, long long base) {
-    const long long p = min(base + crow, p1 - 1);      // clamped: always a valid row, zeroed at store time
-    vg[sidx] = *(const uint4 *)(Gy + p * ldg + ccol);
-    va[sidx] = *(const uint4 *)(A + p * lda + ccol);
-    if (APPLY) vy[sidx] = *(const uint4 *)(Yr + p * ldg + ccol);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const long long p = min(base + grow + i * (NT / CPRG), p1 - 1);      // clamped: always a valid row, zeroed at store time
+      vg[sidx][i] = *(const uint4 *)(Gy + p * ldg + gcol);
+      if (APPLY) vy[sidx][i] = *(const uint4 *)(Yr + p * ldg + gcol);
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const long long p = min(base + arow + i * (NT / CPRA), p1 - 1);
+      va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
+    }
   };
   auto stage = [&](int sidx, long long base) {
-    uint4 g4 = vg[sidx], a4 = va[sidx];
-    if (APPLY) {     // (the arithmetic of bn_bwd_apply_kernel<true>, element for element)
-      const uint4 y4 = vy[sidx];
-      const unsigned gw[4] = {g4.x, g4.y, g4.z, g4.w}, yw[4] = {y4.x, y4.y, y4.z, y4.w};
-      unsigned ow[4];
+    float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];
+    if (APPLY) {
       int zero;                                        // opaque 0: keeps these loop-invariant reads INSIDE the loop
       asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-      const float *cp = &s_cf[ccol + zero];
-      float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];
-      *(float4 *)&cf0[0] = *(const float4 *)&cp[0];         *(float4 *)&cf0[4] = *(const float4 *)&cp[4];
-      *(float4 *)&cf1[0] = *(const float4 *)&cp[T];         *(float4 *)&cf1[4] = *(const float4 *)&cp[T + 4];
-      *(float4 *)&cf2[0] = *(const float4 *)&cp[2 * T];     *(float4 *)&cf2[4] = *(const float4 *)&cp[2 * T + 4];
-      *(float4 *)&ysc[0] = *(const float4 *)&cp[3 * T];     *(float4 *)&ysc[4] = *(const float4 *)&cp[3 * T + 4];
-      *(float4 *)&ysh[0] = *(const float4 *)&cp[4 * T];     *(float4 *)&ysh[4] = *(const float4 *)&cp[4 * T + 4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
-        float z0 = __uint_as_float(gw[j] << 16), z1 = __uint_as_float(gw[j] & 0xffff0000u);
-        z0 = fmaf(ysc[2 * j], y0, ysh[2 * j]) > 0.f ? z0 : 0.f;
-        z1 = fmaf(ysc[2 * j + 1], y1, ysh[2 * j + 1]) > 0.f ? z1 : 0.f;
-        const unsigned lo = f2bf(fmaf(cf0[2 * j], z0, fmaf(cf1[2 * j], y0, cf2[2 * j])));
-        const unsigned hi = f2bf(fmaf(cf0[2 * j + 1], z1, fmaf(cf1[2 * j + 1], y1, cf2[2 * j + 1])));
-        ow[j] = lo | (hi << 16);
-      }
-      g4 = (uint4){ow[0], ow[1], ow[2], ow[3]};
+      const float *cp = &s_cf[gcol + zero];
+      *(float4 *)&cf0[0] = *(const float4 *)&cp[0];          *(float4 *)&cf0[4] = *(const float4 *)&cp[4];
+      *(float4 *)&cf1[0] = *(const float4 *)&cp[TN];         *(float4 *)&cf1[4] = *(const float4 *)&cp[TN + 4];
+      *(float4 *)&cf2[0] = *(const float4 *)&cp[2 * TN];     *(float4 *)&cf2[4] = *(const float4 *)&cp[2 * TN + 4];
+      *(float4 *)&ysc[0] = *(const float4 *)&cp[3 * TN];     *(float4 *)&ysc[4] = *(const float4 *)&cp[3 * TN + 4];
+      *(float4 *)&ysh[0] = *(const float4 *)&cp[4 * TN];     *(float4 *)&ysh[4] = *(const float4 *)&cp[4 * TN + 4];
     }
-    if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
-    if (base + crow >= p1) { g4 = (uint4){0, 0, 0, 0}; a4 = (uint4){0, 0, 0, 0}; }
-    *(uint4 *)&s_g[crow * LD + ccol] = g4;
-    *(uint4 *)&s_a[crow * LD + ccol] = a4;
-  };
-  // the 32 x 128 data-gradient slab of the PREVIOUS step leaves here (its LDS patch was completed before this step's
-  // first barrier): one 16-byte piece per thread
-  uint4 yb;
-  auto store_prev = [&](long long pbase) {
-    const long long p = pbase + crow;
-    const uint4 v = *(const uint4 *)&s_o[crow * LD + ccol];
-    if (p < p1) {
-      *(uint4 *)(Gout + p * ldo + ccol) = v;
-      if (BST) {
-        const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {yb.x, yb.y, yb.z, yb.w};
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int r = grow + i * (NT / CPRG);
+      uint4 g4 = vg[sidx][i];
+      if (APPLY) {     // (the arithmetic of bn_bwd_apply_kernel<true>, element for element)
+        const uint4 y4 = vy[sidx][i];
+        const unsigned gw[4] = {g4.x, g4.y, g4.z, g4.w}, yw[4] = {y4.x, y4.y, y4.z, y4.w};
+        unsigned ow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float g0 = __uint_as_float(g4[j] << 16), g1 = __uint_as_float(g4[j] & 0xffff0000u);
-          const float y0 = __uint_as_float(y4[j] << 16), y1 = __uint_as_float(y4[j] & 0xffff0000u);
-          const float z0 = fmaf(bsc[2 * j], y0, bsh[2 * j]) > 0.f ? g0 : 0.f;
-          const float z1 = fmaf(bsc[2 * j + 1], y1, bsh[2 * j + 1]) > 0.f ? g1 : 0.f;
-          st_s[2 * j] += z0; st_s[2 * j + 1] += z1;
-          st_q[2 * j] = fmaf(z0, y0, st_q[2 * j]); st_q[2 * j + 1] = fmaf(z1, y1, st_q[2 * j + 1]);
+          const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
+          float z0 = __uint_as_float(gw[j] << 16), z1 = __uint_as_float(gw[j] & 0xffff0000u);
+          z0 = fmaf(ysc[2 * j], y0, ysh[2 * j]) > 0.f ? z0 : 0.f;
+          z1 = fmaf(ysc[2 * j + 1], y1, ysh[2 * j + 1]) > 0.f ? z1 : 0.f;
+          const unsigned lo = f2bf(fmaf(cf0[2 * j], z0, fmaf(cf1[2 * j], y0, cf2[2 * j])));
+          const unsigned hi = f2bf(fmaf(cf0[2 * j + 1], z1, fmaf(cf1[2 * j + 1], y1, cf2[2 * j + 1])));
+          ow[j] = lo | (hi << 16);
+        }
+        g4 = (uint4){ow[0], ow[1], ow[2], ow[3]};
+      }
+      if (base + r >= p1) g4 = (uint4){0, 0, 0, 0};
+      *(uint4 *)&s_g[r * LDN + gcol] = g4;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = arow + i * (NT / CPRA);
+      uint4 a4 = va[sidx][i];
+      if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
+      if (base + r >= p1) a4 = (uint4){0, 0, 0, 0};
+      *(uint4 *)&s_a[r * LDK + acol] = a4;
+    }
+  };
+  // the STEP x TK data-gradient slab of the PREVIOUS step leaves here (its LDS patch was completed before this step's
+  // first barrier): NA 16-byte pieces per thread
+  uint4 yb[NA];
+  auto store_prev = [&](long long pbase) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int r = arow + i * (NT / CPRA);
+      const long long p = pbase + r;
+      const uint4 v = *(const uint4 *)&s_o[r * LDK + acol];
+      if (p < p1) {
+        *(uint4 *)(Gout + p * ldo + acol) = v;
+        if (BST) {
+          const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {yb[i].x, yb[i].y, yb[i].z, yb[i].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float g0 = __uint_as_float(g4[j] << 16), g1 = __uint_as_float(g4[j] & 0xffff0000u);
+            const float y0 = __uint_as_float(y4[j] << 16), y1 = __uint_as_float(y4[j] & 0xffff0000u);
+            const float z0 = fmaf(bsc[2 * j], y0, bsh[2 * j]) > 0.f ? g0 : 0.f;
+            const float z1 = fmaf(bsc[2 * j + 1], y1, bsh[2 * j + 1]) > 0.f ? g1 : 0.f;
+            st_s[2 * j] += z0; st_s[2 * j + 1] += z1;
+            st_q[2 * j] = fmaf(z0, y0, st_q[2 * j]); st_q[2 * j + 1] = fmaf(z1, y1, st_q[2 * j + 1]);
+          }
         }
       }
     }
   };
 #pragma unroll
-  for (int d = 0; d < WG_DEPTH; ++d) issue(d, p0 + (long long)d * WG_STEP);
-  fill_w_panel<T, G_LDW, NT>(s_wt, W, T, T, 0, 0, T, 1, t);        // s_wt[k_out][n]: the forward weight [n][k] transposed
+  for (int d = 0; d < DEPTH; ++d) issue(d, p0 + (long long)d * STEP);
+  fill_w_panel<TK, LDN, NT>(s_wt, W, TN, TK, 0, 0, TN, 1, t);      // s_wt[k_out][n]: the forward weight [n][k] transposed
+  const int cb = wave % CHB, rb0 = (wave / CHB) * 2;               // this wave's two 16 x 16 tiles of the slab
   long long prev = -1;
-  for (long long base0 = p0; base0 < p1; base0 += WG_STEP * WG_DEPTH) {
+  for (long long base0 = p0; base0 < p1; base0 += STEP * DEPTH) {
 #pragma unroll
-    for (int d = 0; d < WG_DEPTH; ++d) {
-      const long long base = base0 + (long long)d * WG_STEP;
+    for (int d = 0; d < DEPTH; ++d) {
+      const long long base = base0 + (long long)d * STEP;
       __syncthreads();
       if (prev >= 0) store_prev(prev);
       stage(d, base);
       __syncthreads();
-      issue(d, base + WG_STEP * WG_DEPTH);
-      if (BST) yb = *(const uint4 *)(Yb + min(base + crow, p1 - 1) * ldo + ccol);   // this step's slab, used one step later
-      // ---- weight gradient: transposed fragments of both tiles (as mlp_wgrad_kernel)
-      bf16x8 fg[2], fa[4];
+      issue(d, base + STEP * DEPTH);
+      if (BST) {       // this step's slab, used one step later
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fg[i] = tr_frag<LD>(s_g, wn + 16 * i, lane);
+        for (int i = 0; i < NA; ++i)
+          yb[i] = *(const uint4 *)(Yb + min(base + arow + i * (NT / CPRA), p1 - 1) * ldo + acol);
+      }
+      // ---- weight gradient: transposed fragments of both tiles (as mlp_wgrad_kernel), 32 rows per MFMA
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fa[j] = tr_frag<LD>(s_a, wk + 16 * j, lane);
+      for (int kk = 0; kk < KSTEPS; ++kk) {
+        bf16x8 fg[MI], fa[MJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i) fg[i] = tr_frag<LDN>(s_g + kk * 32 * LDN, wn + 16 * i, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
-      // ---- data gradient of the same 32 rows: wave w owns output channels 16w .. 16w+15
+        for (int j = 0; j < MJ; ++j) fa[j] = tr_frag<LDK>(s_a + kk * 32 * LDK, wk + 16 * j, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < MJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
+      }
+      // ---- data gradient of the same rows: this wave's output channels 16 cb .. +15 of rows 16 rb0 .. +31
       f32x4 ad[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 pf0 = *(const bf16x8 *)&s_g[lr * LD + ks * 32 + 8 * lq];
-        const bf16x8 pf1 = *(const bf16x8 *)&s_g[(16 + lr) * LD + ks * 32 + 8 * lq];
-        const bf16x8 wf = *(const bf16x8 *)&s_wt[(wave * 16 + lr) * G_LDW + ks * 32 + 8 * lq];
+      for (int ks = 0; ks < TN / 32; ++ks) {
+        const bf16x8 pf0 = *(const bf16x8 *)&s_g[(rb0 * 16 + lr) * LDN + ks * 32 + 8 * lq];
+        const bf16x8 pf1 = *(const bf16x8 *)&s_g[(rb0 * 16 + 16 + lr) * LDN + ks * 32 + 8 * lq];
+        const bf16x8 wf = *(const bf16x8 *)&s_wt[(cb * 16 + lr) * LDN + ks * 32 + 8 * lq];
         ad[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[0], 0, 0, 0);
         ad[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[1], 0, 0, 0);
       }
@@ -1493,7 +1530,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       for (int tt = 0; tt < 2; ++tt) {
         const f32x4 v = ad[tt];
         const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *(bf16x4 *)&s_o[(tt * 16 + lr) * LD + wave * 16 + 4 * lq] = ov;
+        *(bf16x4 *)&s_o[((rb0 + tt) * 16 + lr) * LDK + cb * 16 + 4 * lq] = ov;
       }
       prev = base;
     }
@@ -1502,29 +1539,29 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   store_prev(prev);
   // D[row = n-local 4(lane>>4)+r][col = k-local lane&15]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < MJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        o[(size_t)(wn + i * 16 + 4 * (lane >> 4) + r) * T + wk + j * 16 + (lane & 15)] = acc[i][j][r];
-  if (BST) {   // threads that share a column chunk (t % 16): two shuffles inside the wave, then the eight waves through LDS
+        o[(size_t)(wn + i * 16 + 4 * (lane >> 4) + r) * TK + wk + j * 16 + (lane & 15)] = acc[i][j][r];
+  if (BST) {   // threads that share a column chunk (t % CPRA): shuffles inside the wave, then the eight waves through LDS
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
-      for (int m = 16; m < 64; m <<= 1) { st_s[j] += __shfl_xor(st_s[j], m, 64); st_q[j] += __shfl_xor(st_q[j], m, 64); }
+      for (int m = CPRA; m < 64; m <<= 1) { st_s[j] += __shfl_xor(st_s[j], m, 64); st_q[j] += __shfl_xor(st_q[j], m, 64); }
     }
-    if (lane < 16) {
+    if (lane < CPRA) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s_red[wave][0][lane * 8 + j] = st_s[j]; s_red[wave][1][lane * 8 + j] = st_q[j]; }
     }
     __syncthreads();
-    for (int e = t; e < 2 * T; e += NT) {
-      const int which = e / T, c = e - which * T;
+    for (int e = t; e < 2 * TK; e += NT) {
+      const int which = e / TK, c = e - which * TK;
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += s_red[w][which][c];
-      stats_partial[((size_t)blockIdx.z * 2 + which) * T + c] = v;
+      stats_partial[((size_t)blockIdx.z * 2 + which) * TK + c] = v;
     }
   }
   probe_end(probe, probe_t0, 5);
@@ -2025,7 +2062,8 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
 }
 
 extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
-  return N == 128 && K == 128 && P > SP_MAX_ROWS && P >= 32768;
+  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64);
+  return shape && P > SP_MAX_ROWS && P >= 32768;
 }
 
 extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
@@ -2045,14 +2083,22 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   const unsigned short *g = (const unsigned short *)Gy, *a = (const unsigned short *)A, *w = (const unsigned short *)W,
                        *yb = (const unsigned short *)bwd_y, *yr = (const unsigned short *)apply_y;
   unsigned short *go = (unsigned short *)Gout;
-#define CPFN_BWD_FUSED(BST_, APPLY_)                                                                                       \
-  mlp_bwd_fused_kernel<BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, a_scale, a_shift, yb, \
-                                                           b_scale, b_shift, stats_partial, yr, apply_coef, y_scale, y_shift,  \
-                                                           probe_slot_all(grid))
-  if (bwd_y && apply_y) CPFN_BWD_FUSED(true, true);
-  else if (bwd_y) CPFN_BWD_FUSED(true, false);
-  else if (apply_y) CPFN_BWD_FUSED(false, true);
-  else CPFN_BWD_FUSED(false, false);
+#define CPFN_BWD_FUSED(TN_, TK_, STEP_, BST_, APPLY_)                                                                      \
+  mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
+                                                                            a_scale, a_shift, yb, b_scale, b_shift,       \
+                                                                            stats_partial, yr, apply_coef, y_scale,        \
+                                                                            y_shift, probe_slot_all(grid))
+#define CPFN_BWD_FUSED_SHAPE(TN_, TK_, STEP_)                       \
+  do {                                                              \
+    if (bwd_y && apply_y) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, true);   \
+    else if (bwd_y) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, false);        \
+    else if (apply_y) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, true);      \
+    else CPFN_BWD_FUSED(TN_, TK_, STEP_, false, false);                  \
+  } while (0)
+  if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
+  else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
+  else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
+#undef CPFN_BWD_FUSED_SHAPE
 #undef CPFN_BWD_FUSED
   return cpfn_launch_status();
 }

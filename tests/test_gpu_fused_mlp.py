@@ -305,6 +305,7 @@ def test_bn_backward_reduction_on_the_data_gradient_gemm(name, P, cin, widths, p
     ("sfp3-like", 40000 + 77, 128, [128, 128, 128], None),
     ("sa2-like", 2 * 300 * 64, 131, [128, 128, 256], 64),
     ("fc1-like", 32768, 128, [128], None),
+    ("sa1-like", 40 * 1024 + 16, 64, [64, 64, 128], 16),       # the 64 -> 64 and (pooled) 64 -> 128 shapes, ragged last split
 ])
 @pytest.mark.parametrize("stats_fused", [False, True])
 @pytest.mark.parametrize("apply_fused", [True, False])
@@ -313,7 +314,7 @@ def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_f
     128 -> 128 layer from one read of G_y) against the cpfn_mlp_wgrad + cpfn_mlp_gemm pair: the same MFMA sequences on
     the same operands, so bit-identical; with the statistics riding along only their summation order differs."""
     from cpfn_amd import fused_mlp, lib as _l
-    assert _l.lib().cpfn_mlp_bwd_fused_ok(P, 128, 128) == 1
+    assert _l.lib().cpfn_mlp_bwd_fused_ok(P, 128, 128) == 1 and _l.lib().cpfn_mlp_bwd_fused_ok(P, 64, 64) == 1
     convs, bns = _stack(cin, widths, seed=13)
     g = torch.Generator().manual_seed(P)
     x = torch.randn(P, cin, generator=g).to(dev())

@@ -1,12 +1,11 @@
 """cpfn_mlp_bwd_fused against the cpfn_mlp_wgrad + cpfn_mlp_gemm(w_trans, bwd_stats) pair it replaces: results and time.
-    python tools/bwd_fused_probe.py [P reps]"""
+    python tools/bwd_fused_probe.py [P reps N K]"""
 import os, sys
 import torch
 sys.path.insert(0, os.getcwd())
 from cpfn_amd import fused_mlp, lib as _l
 from cpfn_amd.ops import _ptr, _stream
-P, reps = (int(v) for v in (sys.argv[1:3] + ["131072", "50"][len(sys.argv) - 1:]))
-N = K = 128
+P, reps, N, K = (int(v) for v in (sys.argv[1:5] + ["131072", "50", "128", "128"][len(sys.argv) - 1:]))
 dev = torch.device("cuda:0")
 h = _l.lib()
 torch.manual_seed(0)
@@ -37,7 +36,7 @@ def fused(stats, atr):
     part = torch.empty(splits, 2, K, dtype=torch.float32, device=dev) if stats else None
     _l.check(h.cpfn_mlp_bwd_fused(_ptr(Gy), N, _ptr(A), K, _ptr(Wb), P, N, K, _ptr(asc) if atr else None, _ptr(ash) if atr else None,
                                   _ptr(ws), _ptr(g), K, _ptr(Yp) if stats else None, _ptr(bsc) if stats else None,
-                                  _ptr(bsh) if stats else None, _ptr(part), _stream()), "fused")
+                                  _ptr(bsh) if stats else None, _ptr(part), None, None, None, None, _stream()), "fused")
     return ws, g, None if part is None else part.sum(0)
 
 
