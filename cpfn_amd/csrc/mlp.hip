@@ -1342,16 +1342,28 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 // 16-byte chunk per tensor and step, which keeps the kernel under 224 registers.  That matters inside the replayed step:
 // a wave of > 256 registers cannot be placed on a SIMD that hosts a wave of the geometry branch, and the first version
 // (4 waves, 304 registers) then ran in two rounds — 52-61 us instead of 36 (in-kernel probe, tools/dbg/probe_timeline.py).
-template <int TN, int TK, int STEP, bool BST, bool APPLY>
+struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the staged chunks
+  const unsigned short *Yr;                  // the layer's own pre-BN output [P, TN]
+  const float *coef, *y_scale, *y_shift;     // finalize coefficients [3][TN], forward scale / shift (ReLU mask)
+  const unsigned long long *drop_seed;       // APPLY == 3: dropout on the layer's output (cpfn_bn_bwd_apply's)
+  unsigned thresh16;
+  float inv_keep;
+  const unsigned char *pool_arg;             // APPLY == 2 (max-pooled layer): arg-max row of every (group, channel) ...
+  const unsigned short *pool_yarg;           // ... the pre-BN value there; Gy is then the POOLED gradient [P / pool_k, TN]
+  int pool_k;
+  long long groups;
+};
+
+template <int TN, int TK, int STEP, bool BST, int APPLY>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
     const unsigned short *__restrict__ W /* forward weight panel [TN][TK] bf16 */, long long P, long long rows_per_split,
     float *__restrict__ partial, unsigned short *__restrict__ Gout, int ldo, const float *__restrict__ a_scale,
     const float *__restrict__ a_shift, const unsigned short *__restrict__ Yb, const float *__restrict__ b_scale,
-    const float *__restrict__ b_shift, float *__restrict__ stats_partial, const unsigned short *__restrict__ Yr,
-    const float *__restrict__ coef /* [3][TN] */, const float *__restrict__ y_scale, const float *__restrict__ y_shift,
+    const float *__restrict__ b_shift, float *__restrict__ stats_partial, const BwdApplyArgs ap,
     unsigned long long *probe = nullptr) {
   const unsigned long long probe_t0 = probe_begin(probe);
+  const unsigned short *__restrict__ Yr = ap.Yr;
   constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP, KSTEPS = STEP / 32;
   constexpr int CPRG = TN / 8, CPRA = TK / 8;                 // 16-byte chunks per row of the TN- / TK-wide tensors
   constexpr int NG = STEP * CPRG / NT, NA = STEP * CPRA / NT; // chunks per thread and step
@@ -1381,7 +1393,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
   // chunk i of thread t: row t / CPR + i (NT / CPR), columns 8 (t % CPR) — a thread's columns never change
   const int grow = t / CPRG, gcol = (t % CPRG) * 8, arow = t / CPRA, acol = (t % CPRA) * 8;
-  uint4 vg[DEPTH][NG], va[DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
+  uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
+  uint4 vgp[APPLY == 2 ? DEPTH : 1], vya[APPLY == 2 ? DEPTH : 1];       // pooled gradient / arg-max value of the step's group
+  uint2 var_[APPLY == 2 ? DEPTH : 1];                                    // arg-max row (8 channels, one byte each)
+  static_assert(APPLY != 2 || STEP * DEPTH == 128, "pooled: a step never straddles two groups (pool_k % STEP == 0)");
   float asc[8], ash[8];
   if (a_scale) {
 #pragma unroll
@@ -1391,8 +1406,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // the <128,128> kernel needs 237, and two such waves plus a 56-register wave of the geometry branch do not fit one SIMD)
   __shared__ __attribute__((aligned(16))) float s_cf[APPLY ? 5 * TN : 4];
   if (APPLY) {
-    for (int e = t; e < 3 * TN; e += NT) s_cf[e] = coef[e];
-    if (t < TN) { s_cf[3 * TN + t] = y_scale[t]; s_cf[4 * TN + t] = y_shift[t]; }
+    for (int e = t; e < 3 * TN; e += NT) s_cf[e] = ap.coef[e];
+    if (t < TN) { s_cf[3 * TN + t] = ap.y_scale[t]; s_cf[4 * TN + t] = ap.y_shift[t]; }
     // (visible after the first barrier of the step loop)
   }
   float bsc[8], bsh[8], st_s[8], st_q[8];
@@ -1401,10 +1416,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     for (int j = 0; j < 8; ++j) { bsc[j] = b_scale[acol + j]; bsh[j] = b_shift[acol + j]; st_s[j] = 0.f; st_q[j] = 0.f; }
   }
   auto issue = [&](int sidx, long long base) {
+    if (APPLY == 2) {
+      const long long grp = min(base / ap.pool_k, ap.groups - 1);
+      vgp[sidx] = *(const uint4 *)(Gy + grp * TN + gcol);
+      vya[sidx] = *(const uint4 *)(ap.pool_yarg + grp * TN + gcol);
+      var_[sidx] = *(const uint2 *)(ap.pool_arg + grp * TN + gcol);
+    }
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       const long long p = min(base + grow + i * (NT / CPRG), p1 - 1);      // clamped: always a valid row, zeroed at store time
-      vg[sidx][i] = *(const uint4 *)(Gy + p * ldg + gcol);
+      if (APPLY != 2) vg[sidx][i] = *(const uint4 *)(Gy + p * ldg + gcol);
       if (APPLY) vy[sidx][i] = *(const uint4 *)(Yr + p * ldg + gcol);
     }
 #pragma unroll
@@ -1425,22 +1446,55 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       *(float4 *)&ysc[0] = *(const float4 *)&cp[3 * TN];     *(float4 *)&ysc[4] = *(const float4 *)&cp[3 * TN + 4];
       *(float4 *)&ysh[0] = *(const float4 *)&cp[4 * TN];     *(float4 *)&ysh[4] = *(const float4 *)&cp[4 * TN + 4];
     }
+    float pz[8];          // APPLY == 2: masked pooled gradient and arg-max row of this step's group, per channel
+    int pk[8];
+    if (APPLY == 2) {
+      const unsigned gw[4] = {vgp[sidx].x, vgp[sidx].y, vgp[sidx].z, vgp[sidx].w};
+      const unsigned yw[4] = {vya[sidx].x, vya[sidx].y, vya[sidx].z, vya[sidx].w};
+      const unsigned aw[2] = {var_[sidx].x, var_[sidx].y};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float ya = __uint_as_float((j & 1) ? (yw[j >> 1] & 0xffff0000u) : (yw[j >> 1] << 16));
+        const float gp = __uint_as_float((j & 1) ? (gw[j >> 1] & 0xffff0000u) : (gw[j >> 1] << 16));
+        pz[j] = fmaf(ysc[j], ya, ysh[j]) > 0.f ? gp : 0.f;
+        pk[j] = (int)((aw[j >> 2] >> (8 * (j & 3))) & 0xffu);
+      }
+    }
+    const int kbase = APPLY == 2 ? (int)(base % ap.pool_k) : 0;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       const int r = grow + i * (NT / CPRG);
-      uint4 g4 = vg[sidx][i];
-      if (APPLY) {     // (the arithmetic of bn_bwd_apply_kernel<true>, element for element)
+      uint4 g4 = APPLY == 2 ? (uint4){0, 0, 0, 0} : vg[sidx][i];
+      if (APPLY & 1) {     // (the arithmetic of bn_bwd_apply_kernel<true>, element for element; APPLY == 3: with dropout)
         const uint4 y4 = vy[sidx][i];
         const unsigned gw[4] = {g4.x, g4.y, g4.z, g4.w}, yw[4] = {y4.x, y4.y, y4.z, y4.w};
         unsigned ow[4];
+        float f[8];
+        if (APPLY == 3)
+          dropout_factors(*ap.drop_seed, (unsigned long long)(min(base + r, p1 - 1) * CPRG + (gcol >> 3)), ap.thresh16, ap.inv_keep, f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
           float z0 = __uint_as_float(gw[j] << 16), z1 = __uint_as_float(gw[j] & 0xffff0000u);
+          if (APPLY == 3) { z0 *= f[2 * j]; z1 *= f[2 * j + 1]; }
           z0 = fmaf(ysc[2 * j], y0, ysh[2 * j]) > 0.f ? z0 : 0.f;
           z1 = fmaf(ysc[2 * j + 1], y1, ysh[2 * j + 1]) > 0.f ? z1 : 0.f;
           const unsigned lo = f2bf(fmaf(cf0[2 * j], z0, fmaf(cf1[2 * j], y0, cf2[2 * j])));
           const unsigned hi = f2bf(fmaf(cf0[2 * j + 1], z1, fmaf(cf1[2 * j + 1], y1, cf2[2 * j + 1])));
+          ow[j] = lo | (hi << 16);
+        }
+        g4 = (uint4){ow[0], ow[1], ow[2], ow[3]};
+      }
+      if (APPLY == 2) {     // (the arithmetic of bn_pool_bwd_apply_kernel, element for element)
+        const uint4 y4 = vy[sidx][i];
+        const unsigned yw[4] = {y4.x, y4.y, y4.z, y4.w};
+        const int k = kbase + r;
+        unsigned ow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
+          const unsigned lo = f2bf(fmaf(cf0[2 * j], pk[2 * j] == k ? pz[2 * j] : 0.f, fmaf(cf1[2 * j], y0, cf2[2 * j])));
+          const unsigned hi = f2bf(fmaf(cf0[2 * j + 1], pk[2 * j + 1] == k ? pz[2 * j + 1] : 0.f, fmaf(cf1[2 * j + 1], y1, cf2[2 * j + 1])));
           ow[j] = lo | (hi << 16);
         }
         g4 = (uint4){ow[0], ow[1], ow[2], ow[3]};
@@ -1693,14 +1747,28 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 }
 
 // dW[c,j] = Σ_p Gy[p,c]·X[p,j]: partial[gridDim.x][C][KS]
-template <int KS>
+// APPLY: Gy is the gradient w.r.t. the layer's ACTIVATED output; g_y is formed on the fly from the layer's pre-BN output
+// Yr exactly as cpfn_bn_bwd_apply rounds it to bf16 (so the stand-alone apply pass and the g_y tensor disappear).
+template <int KS, bool APPLY>
 __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short *__restrict__ Gy,
                                                            const float *__restrict__ X, long long P,
-                                                           int C, float *__restrict__ partial, int rpb) {
+                                                           int C, float *__restrict__ partial, int rpb,
+                                                           const unsigned short *__restrict__ Yr = nullptr,
+                                                           const float *__restrict__ coef = nullptr,
+                                                           const float *__restrict__ y_scale = nullptr,
+                                                           const float *__restrict__ y_shift = nullptr) {
   __shared__ float s_red[256][8 * KS + 1];
   const int t = threadIdx.x;
   const int nch = C / 8, rsub = 256 / nch;
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
+  float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];
+  if (APPLY) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cf0[j] = coef[c0 + j]; cf1[j] = coef[C + c0 + j]; cf2[j] = coef[2 * C + c0 + j];
+      ysc[j] = y_scale[c0 + j]; ysh[j] = y_shift[c0 + j];
+    }
+  }
   const long long row0 = (long long)blockIdx.x * rpb;
   float a[8][KS];
 #pragma unroll
@@ -1711,11 +1779,12 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short 
     const long long rend = min(P, row0 + rpb);
     for (long long r = row0 + rs; r < rend; r += 4 * rsub) {      // four rows in flight per lane
       float x[4][KS];
-      uint4 rg[4];
+      uint4 rg[4], ry[APPLY ? 4 : 1];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long rr = min(r + (long long)u * rsub, rend - 1);
         rg[u] = *(const uint4 *)(Gy + rr * C + c0);
+        if (APPLY) ry[u] = *(const uint4 *)(Yr + rr * C + c0);
 #pragma unroll
         for (int q = 0; q < KS; ++q) x[u][q] = X[rr * KS + q];
       }
@@ -1723,9 +1792,15 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short 
       for (int u = 0; u < 4; ++u) {
         const bool live = r + (long long)u * rsub < rend;
         const unsigned short *g = (const unsigned short *)&rg[u];
+        const unsigned short *y = (const unsigned short *)&ry[APPLY ? u : 0];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float gv = live ? bf2f(g[j]) : 0.f;
+          float gv = live ? bf2f(g[j]) : 0.f;
+          if (APPLY) {
+            const float yv = bf2f(y[j]);
+            const float gz = fmaf(ysc[j], yv, ysh[j]) > 0.f ? bf2f(g[j]) : 0.f;
+            gv = live ? bf2f(f2bf(fmaf(cf0[j], gz, fmaf(cf1[j], yv, cf2[j])))) : 0.f;
+          }
 #pragma unroll
           for (int q = 0; q < KS; ++q) a[j][q] = fmaf(gv, x[u][q], a[j][q]);
         }
@@ -2070,10 +2145,15 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
                                   const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
                                   const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
                                   const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
-                                  void *stream) {
+                                  const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
+                                  const void *pool_yarg, int pool_k, void *stream) {
   if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gy || !A || !W || !workspace || !Gout || (ldg & 7) || (lda & 7) || (ldo & 7) ||
       ldg < N || lda < K || ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)) ||
       (apply_y && (!apply_coef || !y_scale || !y_shift)))
+    return CPFN_EINVAL;
+  if ((drop_seed && (!apply_y || pool_k > 0 || !(drop_p >= 0.f && drop_p < 1.f))) || pool_k < 0) return CPFN_EINVAL;
+  const int step = N == 128 && K == 128 ? 32 : 64;
+  if (pool_k > 0 && (!apply_y || !pool_arg || !pool_yarg || pool_k > 255 || pool_k % step || P % pool_k || ldg != N))
     return CPFN_EINVAL;
   const int splits = cpfn_mlp_wgrad_splits(P, N, K);
   long long rps = (P + splits - 1) / splits;
@@ -2081,19 +2161,31 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   const dim3 grid(1, 1, splits);
   hipStream_t st = (hipStream_t)stream;
   const unsigned short *g = (const unsigned short *)Gy, *a = (const unsigned short *)A, *w = (const unsigned short *)W,
-                       *yb = (const unsigned short *)bwd_y, *yr = (const unsigned short *)apply_y;
+                       *yb = (const unsigned short *)bwd_y;
   unsigned short *go = (unsigned short *)Gout;
+  BwdApplyArgs ap;
+  ap.Yr = (const unsigned short *)apply_y; ap.coef = apply_coef; ap.y_scale = y_scale; ap.y_shift = y_shift;
+  ap.drop_seed = drop_seed; ap.thresh16 = dropout_thresh16(drop_seed ? drop_p : 0.f); ap.inv_keep = drop_seed ? 1.f / (1.f - drop_p) : 1.f;
+  ap.pool_arg = pool_arg; ap.pool_yarg = (const unsigned short *)pool_yarg; ap.pool_k = pool_k > 0 ? pool_k : 1;
+  ap.groups = pool_k > 0 ? P / pool_k : 1;
+  const int mode = !apply_y ? 0 : (pool_k > 0 ? 2 : (drop_seed ? 3 : 1));
 #define CPFN_BWD_FUSED(TN_, TK_, STEP_, BST_, APPLY_)                                                                      \
   mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
                                                                             a_scale, a_shift, yb, b_scale, b_shift,       \
-                                                                            stats_partial, yr, apply_coef, y_scale,        \
-                                                                            y_shift, probe_slot_all(grid))
-#define CPFN_BWD_FUSED_SHAPE(TN_, TK_, STEP_)                       \
-  do {                                                              \
-    if (bwd_y && apply_y) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, true);   \
-    else if (bwd_y) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, false);        \
-    else if (apply_y) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, true);      \
-    else CPFN_BWD_FUSED(TN_, TK_, STEP_, false, false);                  \
+                                                                            stats_partial, ap, probe_slot_all(grid))
+#define CPFN_BWD_FUSED_SHAPE(TN_, TK_, STEP_)                                  \
+  do {                                                                         \
+    if (bwd_y) {                                                               \
+      if (mode == 2) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 2);                 \
+      else if (mode == 1) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 1);            \
+      else if (mode == 3) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 3);            \
+      else CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 0);                           \
+    } else {                                                                   \
+      if (mode == 2) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 2);                \
+      else if (mode == 1) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 1);           \
+      else if (mode == 3) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 3);           \
+      else CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 0);                          \
+    }                                                                          \
   } while (0)
   if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
   else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
@@ -2119,23 +2211,42 @@ extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C, float *workspace,
-                                 float *dW, void *stream) {
+static int smallk_wgrad_launch(const void *Gy, const float *X, int KS, long long P, int C, float *workspace, float *dW,
+                               const void *apply_y, const float *coef, const float *y_scale, const float *y_shift,
+                               void *stream) {
   if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !Gy || !X || !workspace)
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = cpfn_bn_bwd_blocks(P);
-  const unsigned short *g = (const unsigned short *)Gy;
+  const unsigned short *g = (const unsigned short *)Gy, *yr = (const unsigned short *)apply_y;
   const int rpb = bn_rows_per_block(P);
+#define CPFN_SMALLK_WGRAD(KS_)                                                                                              \
+  do {                                                                                                                      \
+    if (yr) smallk_wgrad_kernel<KS_, true><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb, yr, coef, y_scale, y_shift);   \
+    else smallk_wgrad_kernel<KS_, false><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb);                                 \
+  } while (0)
   switch (KS) {
-    case 1: smallk_wgrad_kernel<1><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
-    case 2: smallk_wgrad_kernel<2><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
-    case 3: smallk_wgrad_kernel<3><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
-    default: smallk_wgrad_kernel<4><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb); break;
+    case 1: CPFN_SMALLK_WGRAD(1); break;
+    case 2: CPFN_SMALLK_WGRAD(2); break;
+    case 3: CPFN_SMALLK_WGRAD(3); break;
+    default: CPFN_SMALLK_WGRAD(4); break;
   }
+#undef CPFN_SMALLK_WGRAD
   const long long n = (long long)C * KS;
   if (dW) launch_split_reduce(workspace, nblk, n, dW, st);    // NULL: the caller batches it (cpfn_multi_split_reduce)
   return cpfn_launch_status();
+}
+
+extern "C" int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C, float *workspace,
+                                 float *dW, void *stream) {
+  return smallk_wgrad_launch(Gy, X, KS, P, C, workspace, dW, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int cpfn_smallk_wgrad_apply(const void *Gz, const void *Y, const float *coef, const float *y_scale,
+                                       const float *y_shift, const float *X, int KS, long long P, int C, float *workspace,
+                                       float *dW, void *stream) {
+  if (!Y || !coef || !y_scale || !y_shift) return CPFN_EINVAL;
+  return smallk_wgrad_launch(Gz, X, KS, P, C, workspace, dW, Y, coef, y_scale, y_shift, stream);
 }
 
 extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *pad_bf16,

@@ -397,7 +397,7 @@ class _FusedStack(torch.autograd.Function):
                 need_dgrad = li > 0 or ctx.x_needs_grad
                 one_pass = (FUSED_BWD and need_dgrad and not (li == 0 and first_fp32) and a_in.stride(0) == a_in.shape[1]
                             and bool(h.cpfn_mlp_bwd_fused_ok(P, N, a_in.shape[1])))
-                apply_in_pass = False
+                apply_in_pass, pool_in_pass = False, False
                 if arg is not None:
                     G = P // pool_k
                     # only the arg-max row of each group carries gradient: the reduction is the dense one over
@@ -411,10 +411,15 @@ class _FusedStack(torch.autograd.Function):
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    Gy = torch.empty(P, N, dtype=BF16, device=dev)
-                    _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
-                                                    _ptr(coef), G, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
-                    _l.add_bytes("cpfn_bn_pool_bwd_apply", 4 * P * N + 5 * G * N)
+                    step_rows = 32 if (N == 128 and a_in.shape[1] == 128) else 64
+                    if one_pass and FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255:
+                        pool_in_pass = True       # g_y is formed from (pooled gradient, arg-max, y) on the one-pass kernel's chunks
+                        Gy = None
+                    else:
+                        Gy = torch.empty(P, N, dtype=BF16, device=dev)
+                        _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
+                                                        _ptr(coef), G, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
+                        _l.add_bytes("cpfn_bn_pool_bwd_apply", 4 * P * N + 5 * G * N)
                 else:
                     nblk = h.cpfn_bn_bwd_blocks(P)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
@@ -437,8 +442,8 @@ class _FusedStack(torch.autograd.Function):
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    if nostore and one_pass and dseed is None and FUSED_BWD_APPLY:
-                        apply_in_pass = True        # g_y = c0 [z > 0] g + c1 y + c2 is formed on the one-pass kernel's staged chunks
+                    if nostore and FUSED_BWD_APPLY and (one_pass or (li == 0 and first_fp32 and dseed is None)):
+                        apply_in_pass = True        # g_y = c0 [z > 0] g + c1 y + c2 is formed on the consumer's staged chunks
                     elif nostore:
                         _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
                                                    _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
@@ -457,8 +462,13 @@ class _FusedStack(torch.autograd.Function):
                     dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
                     # (its 1024 x 192-float partials are finished right here by the 64-subset reduce: in the batched
                     #  reduction three workgroups would walk 256 splits each — a 20 us tail, measured)
-                    _check(h.cpfn_smallk_wgrad(_ptr(Gy), _ptr(a_in), KS, P, N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad")
-                    _l.add_bytes("cpfn_smallk_wgrad", 2 * P * N + 4 * P * KS + 8 * nb * N * KS)
+                    if apply_in_pass:
+                        _check(h.cpfn_smallk_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in), KS, P, N,
+                                                         _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad_apply")
+                        _l.add_bytes("cpfn_smallk_wgrad_apply", 4 * P * N + 4 * P * KS + 8 * nb * N * KS)
+                    else:
+                        _check(h.cpfn_smallk_wgrad(_ptr(Gy), _ptr(a_in), KS, P, N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad")
+                        _l.add_bytes("cpfn_smallk_wgrad", 2 * P * N + 4 * P * KS + 8 * nb * N * KS)
                     grads[0] = dW.reshape(wshape)
                 else:
                     Kp = a_in.shape[1]
@@ -473,16 +483,23 @@ class _FusedStack(torch.autograd.Function):
                         if below:
                             Yp, stp = saved[li - 1][2], saved[li - 1][3]
                             fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev)
-                        ap = apply_in_pass
+                        ap = apply_in_pass or pool_in_pass
+                        dsd = (ctx.drop_seed if li == len(layers) - 1 else None) if apply_in_pass else None
                         _check(h.cpfn_mlp_bwd_fused(_ptr(g_up if ap else Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp,
                                                     None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
                                                     _ptr(ws), _ptr(g), Kp, _ptr(Yp) if below else None,
                                                     _ptr(stp[0]) if below else None, _ptr(stp[1]) if below else None,
                                                     _ptr(fp_) if below else None, _ptr(Y) if ap else None,
                                                     _ptr(coef) if ap else None, _ptr(st[0]) if ap else None,
-                                                    _ptr(st[1]) if ap else None, _stream()), "cpfn_mlp_bwd_fused")
-                        _l.add_bytes("cpfn_mlp_bwd_fused", 2 * P * N + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
-                                     + ((2 * P * Kp + 8 * splits * Kp) if below else 0) + (2 * P * N if ap else 0))
+                                                    _ptr(st[1]) if ap else None, _ptr(dsd),
+                                                    float(cfg["dropout"][0]) if dsd is not None else 0.0,
+                                                    _ptr(arg) if pool_in_pass else None, _ptr(yarg) if pool_in_pass else None,
+                                                    pool_k if pool_in_pass else 0, _stream()), "cpfn_mlp_bwd_fused")
+                        # g_y (or, folded in: g / the pooled g + y), the input, W, the split partials, the data gradient
+                        gy_bytes = (2 * P * N + (2 * P * N // pool_k + 3 * P * N // pool_k) if pool_in_pass
+                                    else (4 * P * N if apply_in_pass else 2 * P * N))
+                        _l.add_bytes("cpfn_mlp_bwd_fused", gy_bytes + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
+                                     + ((2 * P * Kp + 8 * splits * Kp) if below else 0))
                         if below:
                             fused_part = (fp_, splits)
                         if li == 0:

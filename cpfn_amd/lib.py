@@ -83,10 +83,12 @@ SIGNATURES = {
     "cpfn_multi_split_reduce": [_vp, _i, _vp],
     "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused_ok": [_ll, _i, _i],
-    "cpfn_mlp_bwd_fused": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_bwd_fused": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _vp, _f, _vp, _vp, _i, _vp],
     "cpfn_colsum_f32": [_vp, _ll, _i, _vp, _vp, _vp, _vp],
     "cpfn_smallk_fwd": [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad": [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
+    "cpfn_smallk_wgrad_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
     "cpfn_head_post_chunks": [_i],
     "cpfn_head_post_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_head_post_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],

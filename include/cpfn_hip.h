@@ -354,21 +354,26 @@ CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, con
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,
                             float *dW, void *stream);
 /* Weight gradient AND data gradient of a dense 128 -> 128 layer from ONE read of its BatchNorm-adjoint gradient
- * (cpfn_mlp_bwd_fused_ok(P,N,K): N = K = 128, P >= 32768): workspace receives the split partials of
+ * (cpfn_mlp_bwd_fused_ok(P,N,K): P >= 32768): workspace receives the split partials of
  * dW = Gy^T . A exactly as cpfn_mlp_wgrad leaves them (cpfn_mlp_wgrad_splits(P,128,128) slabs; finish them with
  * cpfn_multi_split_reduce), Gout[P,128] (bf16, row stride ldo) = Gy . W with W the FORWARD weight panel [128][128]
  * bf16.  a_scale / a_shift: as in cpfn_mlp_wgrad.  bwd_y (optional) + b_scale / b_shift + stats_partial
  * [splits][2][128]: pass 1 of the BatchNorm backward of the layer below, as cpfn_mlp_gemm's bwd_y (one partial row per
  * split).  apply_y (optional) + apply_coef [3][128] + y_scale / y_shift: Gy is then the gradient with respect to the
  * layer's ACTIVATED output and cpfn_bn_bwd_apply's arithmetic (ReLU mask from apply_y = the layer's pre-BN output,
- * g_y = c0 . g_z + c1 . y + c2, bf16-rounded) runs on the staged chunks: g_y never exists in memory.
- * Replaces a [cpfn_bn_bwd_apply +] cpfn_mlp_wgrad + cpfn_mlp_gemm(w_trans) sequence, bit for bit. */
+ * g_y = c0 . g_z + c1 . y + c2, bf16-rounded) runs on the staged chunks: g_y never exists in memory.  drop_seed /
+ * drop_p: cpfn_bn_bwd_apply's fused dropout on that gradient.  pool_k > 0 (max-pooled layer, P = groups x pool_k rows,
+ * pool_k a multiple of 64 - 32 for N = K = 128 - and <= 255): Gy is the POOLED gradient [P / pool_k, N] and pool_arg /
+ * pool_yarg are cpfn_bn_relu_maxpool's arg-max rows and values: cpfn_bn_pool_bwd_apply's arithmetic instead.
+ * (N, K) in {(128,128), (64,64), (128,64)}.  Replaces a [cpfn_bn_bwd_apply | cpfn_bn_pool_bwd_apply +] cpfn_mlp_wgrad +
+ * cpfn_mlp_gemm(w_trans) sequence, bit for bit. */
 CPFN_API int cpfn_mlp_bwd_fused_ok(long long P, int N, int K);
 CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
                                 const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
                                 const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
                                 const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
-                                void *stream);
+                                const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
+                                const void *pool_yarg, int pool_k, void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
  * workspace: ceil(P/256)*C floats.  pad_bf16 (optional): [P,64] bf16, receives the rows of X converted to bf16
  * and zero-padded to 64 columns in the same pass (the gradient operand of the heads' GEMMs).
@@ -383,6 +388,11 @@ CPFN_API int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P
                              float *partial, void *stream);
 CPFN_API int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C,
                                float *workspace, float *dW, void *stream);
+/* The same with cpfn_bn_bwd_apply folded in: Gz is the gradient w.r.t. the layer's ACTIVATED output, Y its pre-BN output;
+ * g_y = bf16(coef0 . [y_scale . y + y_shift > 0] . g_z + coef1 . y + coef2) is formed on the operand load and never stored. */
+CPFN_API int cpfn_smallk_wgrad_apply(const void *Gz, const void *Y, const float *coef, const float *y_scale,
+                                     const float *y_shift, const float *X, int KS, long long P, int C, float *workspace,
+                                     float *dW, void *stream);
 
 /* ------------------------------------------------------------------ loss-side fusions
  * (the callers on the far side of the fitters.)  K <= 32 for the training-side

@@ -220,12 +220,13 @@ def test_gemm_every_dispatch_path(P, K, N, w_trans, mode):
         assert e2 <= 2e-5 * float((ref.double() ** 2).sum(0).max()) + 1e-3, e2
 
 
-def test_fused_dropout_mask_statistics_and_backward():
+@pytest.mark.parametrize("P", [20000, 40000])       # 40000 rows: the dropout mask is applied inside cpfn_mlp_bwd_fused
+def test_fused_dropout_mask_statistics_and_backward(P):
     """Dropout fused into the last BatchNorm apply (fc1 of the network): Bernoulli(1-p) mask with 1/(1-p) scaling,
     a fresh mask per forward pass, and a backward pass that applies exactly the forward mask (the mask is
     regenerated from an 8-byte seed, never stored)."""
     from cpfn_amd import fused_mlp
-    P, C = 20000, 128
+    C = 128
     convs, bns = _stack(C, [128], seed=3)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(P, C, generator=g).to(dev()).to(torch.bfloat16)
@@ -306,34 +307,45 @@ def test_bn_backward_reduction_on_the_data_gradient_gemm(name, P, cin, widths, p
     ("sa2-like", 2 * 300 * 64, 131, [128, 128, 256], 64),
     ("fc1-like", 32768, 128, [128], None),
     ("sa1-like", 40 * 1024 + 16, 64, [64, 64, 128], 16),       # the 64 -> 64 and (pooled) 64 -> 128 shapes, ragged last split
+    ("sa1-pool64", 643 * 64, 64, [64, 64, 128], 64),            # pooled top layer: the pooled apply pass inside the kernel
+    ("sa1-xyz", 643 * 64, 3, [64, 64, 128], 64),                # fp32 xyz first layer: apply pass inside its weight gradient
+    ("pool32", 1100 * 32, 128, [128, 128], 32),                 # 128 -> 128 pooled (32-row steps)
 ])
 @pytest.mark.parametrize("stats_fused", [False, True])
-@pytest.mark.parametrize("apply_fused", [True, False])
-def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_fused, apply_fused, monkeypatch):
-    """cpfn_mlp_bwd_fused (weight gradient + data gradient [+ BatchNorm-backward pass 1 of the layer below] of a dense
-    128 -> 128 layer from one read of G_y) against the cpfn_mlp_wgrad + cpfn_mlp_gemm pair: the same MFMA sequences on
-    the same operands, so bit-identical; with the statistics riding along only their summation order differs."""
+@pytest.mark.parametrize("variant", ["one-pass+apply", "one-pass", "apply-only"])
+def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_fused, variant, monkeypatch):
+    """cpfn_mlp_bwd_fused (weight gradient + data gradient [+ BatchNorm-backward pass 1 of the layer below] [+ the
+    BatchNorm-backward apply pass, dense or max-pooled] of a dense layer from one read of its gradient) and
+    cpfn_smallk_wgrad_apply against the separate kernels: the same arithmetic on the same operands, so bit-identical;
+    with the statistics riding along only their summation order differs."""
     from cpfn_amd import fused_mlp, lib as _l
     assert _l.lib().cpfn_mlp_bwd_fused_ok(P, 128, 128) == 1 and _l.lib().cpfn_mlp_bwd_fused_ok(P, 64, 64) == 1
+    use_xyz = cin == 3
     convs, bns = _stack(cin, widths, seed=13)
     g = torch.Generator().manual_seed(P)
-    x = torch.randn(P, cin, generator=g).to(dev())
+    xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev()) if use_xyz else None
+    x = None if use_xyz else torch.randn(P, cin, generator=g).to(dev())
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
     monkeypatch.setattr(fused_mlp, "BWD_STATS_FUSED", stats_fused)
-    monkeypatch.setattr(fused_mlp, "FUSED_BWD_APPLY", apply_fused)     # the BatchNorm apply pass inside the same kernel
     res = {}
-    for one_pass in (True, False):
+    for cfg in (variant, "separate"):
+        one_pass, apply_fused = cfg in ("one-pass+apply", "one-pass"), cfg in ("one-pass+apply", "apply-only")
         monkeypatch.setattr(fused_mlp, "FUSED_BWD", one_pass)
+        monkeypatch.setattr(fused_mlp, "FUSED_BWD_APPLY", apply_fused)
         _l.byte_census(True)
-        res[one_pass] = _run(x, convs, bns, torch.bfloat16, pool_k, None, gout)
+        res[cfg] = _run(x, convs, bns, torch.bfloat16, pool_k, xyz, gout)
         census = _l.byte_census(False)
         assert ("cpfn_mlp_bwd_fused" in census) == one_pass, sorted(census)
-        if one_pass and apply_fused and name != "fc1-like":      # every eligible layer lost its stand-alone apply launch
+        assert ("cpfn_smallk_wgrad_apply" in census) == (apply_fused and use_xyz), sorted(census)
+        if cfg == "one-pass+apply":
             n_apply = census.get("cpfn_bn_bwd_apply", (0, 0))[0]
-            assert n_apply < len(widths), (n_apply, sorted(census))
-    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
+            if name not in ("fc1-like", "sa2-like"):     # every eligible layer lost its stand-alone apply launch
+                assert n_apply < len(widths) - (1 if pool_k else 0), (n_apply, sorted(census))
+            if name in ("sa1-pool64", "sa1-xyz", "pool32"):
+                assert "cpfn_bn_pool_bwd_apply" not in census and "cpfn_bn_bwd_apply" not in census, sorted(census)
+    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[variant], res["separate"]
     same = (lambda a, b: _rel(a, b) < 2e-3) if stats_fused else torch.equal
     assert torch.equal(ya, yb)
-    assert same(gxa, gxb)
+    assert (gxa is None and gxb is None) or same(gxa, gxb)
     for a, b in zip(gra, grb):
         assert (a is None and b is None) or same(a, b)
