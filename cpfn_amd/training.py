@@ -40,6 +40,14 @@ def get_learning_rate(init_learning_rate, global_step, batch_size, decay_step, d
     return init_learning_rate * (decay_rate ** p)
 
 
+# The next batch's geometry runs concurrently with the step.  As a forked branch INSIDE the step's hipGraph it switches
+# the whole replay to a slower dispatch mode on this stack (tools/dbg/graph_gap.py: 150 tiny kernels replay in 238 us as
+# a linear graph and in 414 us with one forked branch: +1.2 us per kernel, the fork itself ~27 us).  Default: TWO linear
+# graphs — the step on the trainer's stream, the geometry on a side stream — ordered by two events per step.
+# CPFN_SPLIT_GRAPHS=0: the single forked graph of round 1.
+SPLIT_GRAPHS = os.environ.get("CPFN_SPLIT_GRAPHS", "1") != "0"
+
+
 class FlatGradBucket:
     """All gradients of a module in one contiguous fp32 buffer, so the data-parallel exchange is a
     single all-reduce.  5.6 MB for GlobalSPFN: latency-bound on xGMI, hence one bucket rather than
@@ -462,6 +470,7 @@ class SPFNTrainer:
         geomB = [t.clone() for t in self._flatten_geom(g_example)]
         geomA = [t.clone() for t in geomB]
         st["geomA"] = self._like_geom(g_example, geomA)
+        st["geomA_flat"] = geomA
         st["geomB"] = geomB
         if self._gside is None:
             self._gside = torch.cuda.Stream(device=dev)
@@ -490,15 +499,29 @@ class SPFNTrainer:
                     from . import lib as _l
                     _l.check(_l.lib().cpfn_stamp(stamps[i:].data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cpfn_stamp")
 
+            split = st["split"] = SPLIT_GRAPHS
+            if split:
+                # the geometry of the NEXT batch as its own linear graph, replayed on the side stream while the step's
+                # graph runs (own memory pool: the two replay concurrently)
+                gs = torch.cuda.CUDAGraph()
+                self._gside.wait_stream(self._gstream)
+                with torch.cuda.graph(gs, stream=self._gside, capture_error_mode="thread_local"):
+                    geometry_into_B(st["P_next"])
+                    stamp(1)
+                self._gstream.wait_stream(self._gside)
+                st["gs"] = gs
+                st["b_read"], st["b_written"] = torch.cuda.Event(), torch.cuda.Event()
+                st["side_pending"] = False
             with torch.cuda.graph(g, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
                 if stamps is not None:
                     stamps[4:5].copy_(stamps[3:4])                  # when the PREVIOUS replay was joined
                 stamp(0)
-                self._copy_all(geomA, geomB)
-                self._gside.wait_stream(self._gstream)              # fork (after B was read): next batch's geometry
-                with torch.cuda.stream(self._gside):
-                    geometry_into_B(st["P_next"])
-                    stamp(1)
+                if not split:
+                    self._copy_all(geomA, geomB)
+                    self._gside.wait_stream(self._gstream)              # fork (after B was read): next batch's geometry
+                    with torch.cuda.stream(self._gside):
+                        geometry_into_B(st["P_next"])
+                        stamp(1)
                 self.bucket.zero()
                 self.module(sb["P"], geometry=st["geomA"])
                 if fl.PARALLEL_BRANCHES:
@@ -521,7 +544,8 @@ class SPFNTrainer:
                     self._checked_optimizer_step(st["skipped"])
                 st["out"] = tuple(o.detach() for o in out)
                 stamp(2)
-                self._gstream.wait_stream(self._gside)              # join
+                if not split:
+                    self._gstream.wait_stream(self._gside)              # join
                 stamp(3)
             st["g"] = g
             st["exchange_in_graph"] = world > 1 and exchange_in_graph
@@ -582,6 +606,11 @@ class SPFNTrainer:
     def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
         st = self._graph
+        if st.get("split", False) and st["single"] and st["side_pending"]:
+            # the side graph of the previous step (reads P_next / the FPS seeds, writes geomB) must be done before
+            # this step overwrites its inputs and reads its result
+            torch.cuda.current_stream(batch["P"].device).wait_event(st["b_written"])
+            st["side_pending"] = False
         # inputs into the static buffers: ONE multi-tensor copy (the batch tensors that are not already the
         # static ones + the next batch's coordinates for the geometry branch of G2)
         dst, src = [], []
@@ -592,9 +621,15 @@ class SPFNTrainer:
         if next_batch is not None and next_batch["P"].data_ptr() != st["P_next"].data_ptr():
             dst.append(st["P_next"])
             src.append(next_batch["P"])
+        B, N, _ = batch["P"].shape
+        split = st.get("split", False) and st["single"]
+        # (two linear graphs: geomA <- geomB is an eager launch in front of the step's graph; when the geometry was
+        #  announced one step ahead — the normal case — it rides on the input copy: one launch per step, not two)
+        merged = split and self._prefetched is None and st["geom_ready_for"] == self._batch_key(batch["P"])
+        if merged:
+            dst, src = dst + st["geomA_flat"], src + st["geomB"]
         if dst:
             self._copy_all(dst, src)
-        B, N, _ = batch["P"].shape
         if self._prefetched is not None:                       # geometry prefetched by an eager (warm-up) step
             geom = self._take_prefetched(batch["P"])
             if geom is not None:
@@ -611,6 +646,19 @@ class SPFNTrainer:
             if announce:
                 self._draw_starts(st, B, N)
             st["geom_ready_for"] = self._batch_key(next_batch["P"]) if announce else None
+            if split:
+                # geomA <- geomB (three small launches), then the side stream may overwrite geomB with the next batch's
+                # geometry while this stream replays the step
+                if not merged:
+                    self._copy_all(st["geomA_flat"], st["geomB"])
+                if announce:
+                    cur = torch.cuda.current_stream(batch["P"].device)
+                    st["b_read"].record(cur)
+                    with torch.cuda.stream(self._gside):
+                        self._gside.wait_event(st["b_read"])
+                        st["gs"].replay()
+                        st["b_written"].record(self._gside)
+                    st["side_pending"] = True
             st["g"].replay()                                   # the whole step: no host synchronisation
             if st["world"] > 1 and not st["exchange_in_graph"]:
                 self.bucket.all_reduce_mean()
@@ -633,6 +681,14 @@ class SPFNTrainer:
         self.global_step += 1
         return st["out"]
 
+    def stream(self, device):
+        """The stream the replayed steps run on.  A training loop that runs under it (`with torch.cuda.stream(...)`)
+        saves the two cross-stream dependencies per step that calling step() from another stream costs (~40 us of idle
+        GPU between consecutive replays, measured with CPFN_STEP_STAMPS)."""
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream(device=device)
+        return self._gstream
+
     def step(self, batch, fps_start=None, next_batch=None, force_eager=False):
         """One optimisation step; returns the 6 loss tensors (still on the device — the
         reference's six `.item()` syncs per step, training_utils.py:169-174, are left to the caller).
@@ -649,14 +705,17 @@ class SPFNTrainer:
             if self._gstream is None:
                 self._gstream = torch.cuda.Stream(device=batch["P"].device)
             cur = torch.cuda.current_stream(batch["P"].device)
-            self._gstream.wait_stream(cur)
+            same = cur == self._gstream          # the caller already runs on the trainer's stream (see stream()): no hops
+            if not same:
+                self._gstream.wait_stream(cur)
             self._in_gstream = True
             try:
                 with torch.cuda.stream(self._gstream):
                     out = self.step(batch, None, next_batch)
             finally:
                 self._in_gstream = False
-            cur.wait_stream(self._gstream)
+            if not same:
+                cur.wait_stream(self._gstream)
             return out
         if self.use_graphs and not force_eager and fps_start is None and batch["P"].is_cuda:
             if self._graph is None and self._graph_warm >= 2:
