@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 // ahead.  APPLY: Gy is the gradient with respect to the layer's ACTIVATED output and the BatchNorm-backward apply pass
 // (g_y = c0 . [scale . y + shift > 0] . g + c1 . y + c2, rounded to bf16 exactly as cpfn_bn_bwd_apply stores it) runs on
 // the staged chunks from the layer's own pre-BN output Yr: g_y is never written to or read from memory.
-// Shapes <TN, TK, STEP>: <128,128,32>, <64,64,64>, <128,64,64> (layer N -> channels of g_y, K -> channels of its input;
+// Shapes <TN, TK, STEP>: <128,128,32>, <256,128,32>, <64,64,64>, <128,64,64> (layer N -> channels of g_y, K -> channels of its input;
 // STEP rows per step, 128 rows in flight).  Grid (1, 1, splits), the split layout of mlp_wgrad_kernel: same partials,
 // bit for bit.
 // EIGHT waves: for <128,128> a wave's share of the dW tile is 32 x 64 (32 accumulator registers) and a thread stages one
@@ -1364,12 +1364,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     unsigned long long *probe = nullptr) {
   const unsigned long long probe_t0 = probe_begin(probe);
   const unsigned short *__restrict__ Yr = ap.Yr;
-  constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP, KSTEPS = STEP / 32;
+  // (rows in flight: 128, and 64 for the 256-wide g_y — the same bytes, half the staging registers)
+  constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP / (TN > 128 ? 2 : 1), KSTEPS = STEP / 32;
   constexpr int CPRG = TN / 8, CPRA = TK / 8;                 // 16-byte chunks per row of the TN- / TK-wide tensors
   constexpr int NG = STEP * CPRG / NT, NA = STEP * CPRA / NT; // chunks per thread and step
   constexpr int MI = TN / 64, MJ = TK / 32;                   // dW tiles per wave (waves 4 x 2 over TN x TK)
   constexpr int CHB = TK / 16;                                // 16-channel blocks of the data-gradient slab
-  static_assert(NG >= 1 && NA >= 1 && STEP * DEPTH == WG_STEP * WG_DEPTH && (STEP / 16) * CHB == 16, "shape");
+  static_assert(NG >= 1 && NA >= 1 && (WG_STEP * WG_DEPTH) % (STEP * DEPTH) == 0 && (STEP / 16) * CHB == 16, "shape");
   __shared__ __attribute__((aligned(16))) unsigned short s_g[STEP * LDN];
   __shared__ __attribute__((aligned(16))) unsigned short s_a[STEP * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short s_o[STEP * LDK];
@@ -1396,7 +1397,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
   uint4 vgp[APPLY == 2 ? DEPTH : 1], vya[APPLY == 2 ? DEPTH : 1];       // pooled gradient / arg-max value of the step's group
   uint2 var_[APPLY == 2 ? DEPTH : 1];                                    // arg-max row (8 channels, one byte each)
-  static_assert(APPLY != 2 || STEP * DEPTH == 128, "pooled: a step never straddles two groups (pool_k % STEP == 0)");
+  // (pooled: a step never straddles two groups — the host checks pool_k % STEP == 0)
   float asc[8], ash[8];
   if (a_scale) {
 #pragma unroll
@@ -2137,7 +2138,7 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
 }
 
 extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
-  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64);
+  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128);
   return shape && P > SP_MAX_ROWS && P >= 32768;
 }
 
@@ -2152,7 +2153,7 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
       (apply_y && (!apply_coef || !y_scale || !y_shift)))
     return CPFN_EINVAL;
   if ((drop_seed && (!apply_y || pool_k > 0 || !(drop_p >= 0.f && drop_p < 1.f))) || pool_k < 0) return CPFN_EINVAL;
-  const int step = N == 128 && K == 128 ? 32 : 64;
+  const int step = K == 128 ? 32 : 64;
   if (pool_k > 0 && (!apply_y || !pool_arg || !pool_yarg || pool_k > 255 || pool_k % step || P % pool_k || ldg != N))
     return CPFN_EINVAL;
   const int splits = cpfn_mlp_wgrad_splits(P, N, K);
@@ -2188,6 +2189,7 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
     }                                                                          \
   } while (0)
   if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
+  else if (N == 256) CPFN_BWD_FUSED_SHAPE(256, 128, 32);
   else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
   else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
 #undef CPFN_BWD_FUSED_SHAPE

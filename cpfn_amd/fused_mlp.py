@@ -411,7 +411,7 @@ class _FusedStack(torch.autograd.Function):
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    step_rows = 32 if (N == 128 and a_in.shape[1] == 128) else 64
+                    step_rows = 32 if a_in.shape[1] == 128 else 64        # rows per step of the one-pass kernel for this shape
                     if one_pass and FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255:
                         pool_in_pass = True       # g_y is formed from (pooled gradient, arg-max, y) on the one-pass kernel's chunks
                         Gy = None

@@ -36,7 +36,8 @@ def fused(stats, atr):
     part = torch.empty(splits, 2, K, dtype=torch.float32, device=dev) if stats else None
     _l.check(h.cpfn_mlp_bwd_fused(_ptr(Gy), N, _ptr(A), K, _ptr(Wb), P, N, K, _ptr(asc) if atr else None, _ptr(ash) if atr else None,
                                   _ptr(ws), _ptr(g), K, _ptr(Yp) if stats else None, _ptr(bsc) if stats else None,
-                                  _ptr(bsh) if stats else None, _ptr(part), None, None, None, None, _stream()), "fused")
+                                  _ptr(bsh) if stats else None, _ptr(part), None, None, None, None, None, 0.0, None, None, 0,
+                                  _stream()), "fused")
     return ws, g, None if part is None else part.sum(0)
 
 
