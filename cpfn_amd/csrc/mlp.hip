@@ -662,20 +662,41 @@ constexpr int SP_DEPTH = 2;   // slots in flight per wave (4 measured slower on 
 // 64-row tiles halve the weight re-reads; 32-row tiles when that would leave fewer than 256 workgroups
 static inline int sp_rows(long long P, int N) { return ((P + 63) / 64) * (N / 64 > 0 ? N / 64 : 1) >= 256 ? 64 : 32; }
 
-template <int RT, bool STATS, bool WT>
+// Data gradient of a small layer with the BatchNorm backward folded in (cpfn_mlp_dgrad_small):
+//   APPLY: A is the gradient w.r.t. the layer's ACTIVATED output and Yr its pre-BN output; the operand fragment becomes
+//          g_y = bf16(c0 [ysc y + ysh > 0] g + c1 y + c2) on the fly (per contraction channel; cpfn_bn_bwd_apply's
+//          arithmetic, so the stand-alone apply launch and the g_y tensor disappear);
+//   BST:   pass 1 of the BatchNorm backward of the layer BELOW from the tile being stored (sum g_z, sum g_z y with the
+//          ReLU mask from that layer's pre-BN output Yb): its stand-alone cpfn_bn_relu_bwd launch disappears.
+struct SmallpBwdArgs {
+  const unsigned short *Yr;                 // APPLY: [P, K] like A
+  const float *coef, *y_scale, *y_shift;    // APPLY: [3][K], [K], [K]
+  const unsigned short *Yb;                 // BST: [P, ldy] like Y
+  const float *b_scale, *b_shift;           // BST: [N]
+};
+
+template <int RT, bool STATS, bool WT, bool APPLY = false, bool BST = false>
 __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
     const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
     int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
-    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe) {
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe,
+    const SmallpBwdArgs bw = SmallpBwdArgs()) {
   constexpr int TT = RT / 16, D = SP_DEPTH, LDT = 64 + 8;
+  static_assert(!(STATS && BST) && (!APPLY || WT) && (!BST || WT), "the backward variants belong to the data gradient");
   const unsigned long long probe_t0 = probe_begin(probe);
   constexpr int RAW_TILE = 4 * 32 * LDT * 2, RAW_RED = 4 * 4 * TT * 64 * 16;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW_TILE > RAW_RED ? RAW_TILE : RAW_RED];
-  __shared__ __attribute__((aligned(16))) float s_ss[2][SP_SS_MAX];
+  __shared__ __attribute__((aligned(16))) float s_ss[APPLY ? 5 : 2][SP_SS_MAX];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * 64, row0 = blockIdx.x * RT;
-  if (a_scale) {
+  if (APPLY) {
+    for (int e = t; e < K; e += 256) {
+      s_ss[0][e] = bw.y_scale[e]; s_ss[1][e] = bw.y_shift[e];
+      s_ss[2][e] = bw.coef[e]; s_ss[3][e] = bw.coef[K + e]; s_ss[4][e] = bw.coef[2 * K + e];
+    }
+    __syncthreads();
+  } else if (a_scale) {
     for (int e = t; e < K; e += 256) { s_ss[0][e] = a_scale[e]; s_ss[1][e] = a_shift[e]; }
     __syncthreads();
   }
@@ -686,6 +707,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
   // with K = 256 that was 4x the traffic, and the kernel was slower than the one it replaces.)
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, N * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(APPLY ? (void *)bw.Yr : (void *)A, 0, a_bytes, 0x00020000);
   unsigned aoff[TT];   // byte offsets
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
@@ -702,12 +724,15 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
   const unsigned wstep = WT ? 32u * N * 2 : 64u;
   unsigned short *tile = (unsigned short *)s_raw + wave * 32 * LDT;   // this wave's [32 k][64 n] slice (WT only)
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (a plain vector type: HIP's uint4 struct blocks SROA here)
-  u32x4 ra[D][TT];
+  u32x4 ra[D][TT], ry[APPLY ? D : 1][TT];
   u32x4 rw[D][4];
   auto issue = [&](int d, int s) __attribute__((always_inline)) {
     const unsigned oob = s < S ? 0u : 0x80000000u;
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) ra[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (aoff[tt] + s * 64) | oob, 0, 0);
+    for (int tt = 0; tt < TT; ++tt) {
+      ra[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (aoff[tt] + s * 64) | oob, 0, 0);
+      if (APPLY) ry[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (aoff[tt] + s * 64) | oob, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) rw[d][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (woff[i] + s * wstep) | oob, 0, 0);
   };
@@ -742,7 +767,34 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(bf16x8, rw[d][i]);
         }
-        if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
+        if (APPLY) {     // g_y from (g, y): bn_bwd_apply_kernel<true>'s arithmetic, element for element
+          float sc[8], sh[8], c0[8], c1[8], c2[8];
+          const int k0 = s * 32 + 8 * lq;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            *(cpfn_f32x4 *)&sc[4 * hh] = *(const cpfn_f32x4 *)&s_ss[0][k0 + 4 * hh];
+            *(cpfn_f32x4 *)&sh[4 * hh] = *(const cpfn_f32x4 *)&s_ss[1][k0 + 4 * hh];
+            *(cpfn_f32x4 *)&c0[4 * hh] = *(const cpfn_f32x4 *)&s_ss[2][k0 + 4 * hh];
+            *(cpfn_f32x4 *)&c1[4 * hh] = *(const cpfn_f32x4 *)&s_ss[3][k0 + 4 * hh];
+            *(cpfn_f32x4 *)&c2[4 * hh] = *(const cpfn_f32x4 *)&s_ss[4][k0 + 4 * hh];
+          }
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) {
+            const u32x4 g4 = ra[d][tt], y4 = ry[d][tt];
+            u32x4 o4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float y0 = __uint_as_float(y4[j] << 16), y1 = __uint_as_float(y4[j] & 0xffff0000u);
+              float z0 = __uint_as_float(g4[j] << 16), z1 = __uint_as_float(g4[j] & 0xffff0000u);
+              z0 = fmaf(sc[2 * j], y0, sh[2 * j]) > 0.f ? z0 : 0.f;
+              z1 = fmaf(sc[2 * j + 1], y1, sh[2 * j + 1]) > 0.f ? z1 : 0.f;
+              const unsigned lo = f2bf(fmaf(c0[2 * j], z0, fmaf(c1[2 * j], y0, c2[2 * j])));
+              const unsigned hi = f2bf(fmaf(c0[2 * j + 1], z1, fmaf(c1[2 * j + 1], y1, c2[2 * j + 1])));
+              o4[j] = lo | (hi << 16);
+            }
+            af[tt] = __builtin_bit_cast(bf16x8, o4);
+          }
+        } else if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
           float sc[8], sh[8];
           const int k0 = s * 32 + 8 * lq;
           *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[0][k0]; *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[0][k0 + 4];
@@ -786,9 +838,19 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
       if (STATS) { sm += v; sq += v * v; }
       bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
       *(bf16x4 *)(Y + (size_t)p * ldy + n) = o;
+      if (BST) {     // (on the ROUNDED gradient, as the stand-alone pass would read it back)
+        const bf16x4 yb = *(const bf16x4 *)(bw.Yb + (size_t)p * ldy + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float yv = (float)yb[r];
+          const float z = fmaf(bw.b_scale[n + r], yv, bw.b_shift[n + r]) > 0.f ? (float)o[r] : 0.f;
+          sm[r] += z;
+          sq[r] = fmaf(z, yv, sq[r]);
+        }
+      }
     }
   }
-  if (STATS) {
+  if (STATS || BST) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
     if (lr == 0) {
@@ -1209,14 +1271,22 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
 constexpr int WG_STEP = 32;       // rows per MFMA step
 constexpr int WG_DEPTH = 4;       // steps in flight
 
-template <int TN, int TK>
+// APPLY (cpfn_mlp_wgrad_apply, 64 x 64 tiles): Gy is the gradient w.r.t. the layer's ACTIVATED output; g_y is formed on the
+// staged chunks from the layer's pre-BN output Yr with cpfn_bn_bwd_apply's arithmetic (see mlp_bwd_fused_kernel).
+struct WgradApplyArgs {
+  const unsigned short *Yr;
+  const float *coef, *y_scale, *y_shift;
+};
+
+template <int TN, int TK, bool APPLY = false>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
                                                         const unsigned short *__restrict__ A, int lda,
                                                         const int *__restrict__ gidx, long long P, int N, int K,
                                                         long long rows_per_split, float *__restrict__ partial,
                                                         const float *__restrict__ a_scale,
                                                         const float *__restrict__ a_shift,
-                                                        unsigned long long *probe = nullptr) {
+                                                        unsigned long long *probe = nullptr,
+                                                        const WgradApplyArgs ap = WgradApplyArgs()) {
   const unsigned long long probe_t0 = probe_begin(probe);
   constexpr int LDN = TN + 8, LDK = TK + 8;       // LDS row strides (elements)
   constexpr int CG = TN / 64, CA = TK / 64;       // 16-byte chunks per thread and step
@@ -1242,7 +1312,16 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
   // chunk c = t + 256 i of a step: row c / (T/8), column 8 (c % (T/8))
-  uint4 vg[WG_DEPTH][CG], va[WG_DEPTH][CA];
+  uint4 vg[WG_DEPTH][CG], va[WG_DEPTH][CA], vy[APPLY ? WG_DEPTH : 1][CG];
+  float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];      // APPLY: a lane's g_y chunk columns never change either
+  if (APPLY) {
+    const int col = n0 + (t % (TN / 8)) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cf0[j] = ap.coef[col + j]; cf1[j] = ap.coef[N + col + j]; cf2[j] = ap.coef[2 * N + col + j];
+      ysc[j] = ap.y_scale[col + j]; ysh[j] = ap.y_shift[col + j];
+    }
+  }
   // optional BatchNorm + ReLU of the PREVIOUS layer on the A operand (a lane's chunk columns never change)
   float asc[CA][8], ash[CA][8];
   if (a_scale) {
@@ -1259,6 +1338,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
       const int c = t + 256 * i;
       const long long p = min(base + c / (TN / 8), p1 - 1);      // clamped: always a valid row, zeroed at store time
       vg[sidx][i] = *(const uint4 *)(Gy + p * ldg + n0 + (c % (TN / 8)) * 8);
+      if (APPLY) vy[sidx][i] = *(const uint4 *)(ap.Yr + p * ldg + n0 + (c % (TN / 8)) * 8);
     }
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
@@ -1274,6 +1354,22 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
     for (int i = 0; i < CG; ++i) {
       const int c = t + 256 * i, r = c / (TN / 8);
       uint4 v = vg[sidx][i];
+      if (APPLY) {
+        const uint4 y4 = vy[sidx][i];
+        const unsigned gw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {y4.x, y4.y, y4.z, y4.w};
+        unsigned ow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
+          float z0 = __uint_as_float(gw[j] << 16), z1 = __uint_as_float(gw[j] & 0xffff0000u);
+          z0 = fmaf(ysc[2 * j], y0, ysh[2 * j]) > 0.f ? z0 : 0.f;
+          z1 = fmaf(ysc[2 * j + 1], y1, ysh[2 * j + 1]) > 0.f ? z1 : 0.f;
+          const unsigned lo = f2bf(fmaf(cf0[2 * j], z0, fmaf(cf1[2 * j], y0, cf2[2 * j])));
+          const unsigned hi = f2bf(fmaf(cf0[2 * j + 1], z1, fmaf(cf1[2 * j + 1], y1, cf2[2 * j + 1])));
+          ow[j] = lo | (hi << 16);
+        }
+        v = (uint4){ow[0], ow[1], ow[2], ow[3]};
+      }
       if (base + r >= p1) v = (uint4){0, 0, 0, 0};
       *(uint4 *)&s_g[r * LDN + (c % (TN / 8)) * 8] = v;
     }
@@ -1873,6 +1969,40 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   return (int)((tiles + tpw - 1) / tpw);
 }
 
+extern "C" int cpfn_mlp_dgrad_small_ok(long long P, int N, int K) {
+  return P > 0 && P <= SP_MAX_ROWS && N > 0 && (N & 31) == 0 && N <= SP_SS_MAX && K > 0 && (K & 63) == 0 &&
+         P * N * 2 < (1LL << 31) && (long long)N * K * 2 < (1LL << 31);
+}
+
+// (declared after cpfn_mlp_gemm_blocks: rows of stats_partial = cpfn_mlp_gemm_blocks(P, K))
+extern "C" int cpfn_mlp_dgrad_small(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
+                                    const float *y_shift, const void *W, long long P, int N, int K, void *Gout, int ldo,
+                                    const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                    void *stream) {
+  if (!cpfn_mlp_dgrad_small_ok(P, N, K) || !Gz || !W || !Gout || (ldo & 3) || ldo < K ||
+      (Yr && (!coef || !y_scale || !y_shift)) || (bwd_y && (!b_scale || !b_shift || !stats_partial)) || (!Yr && !bwd_y))
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  // in the kernel's terms: operand A = Gz [P, N] (contraction over the layer's N output channels), outputs = K channels
+  const int gx = cpfn_mlp_gemm_blocks(P, K);
+  dim3 grid(gx, K / 64);
+  const int a_bytes = (int)(((P - 1) * N + N) * 2);
+  SmallpBwdArgs bw;
+  bw.Yr = (const unsigned short *)Yr; bw.coef = coef; bw.y_scale = y_scale; bw.y_shift = y_shift;
+  bw.Yb = (const unsigned short *)bwd_y; bw.b_scale = b_scale; bw.b_shift = b_shift;
+  const unsigned short *a = (const unsigned short *)Gz, *w = (const unsigned short *)W;
+  unsigned short *y = (unsigned short *)Gout;
+#define CPFN_DGRAD_SMALL(RT_)                                                                                             \
+  do {                                                                                                                    \
+    if (bwd_y && Yr) mlp_gemm_smallp_kernel<RT_, false, true, true, true><<<grid, 256, 0, st>>>(a, N, a_bytes, w, (int)P, N, K, y, ldo, stats_partial, nullptr, nullptr, probe_slot(grid), bw); \
+    else if (bwd_y) mlp_gemm_smallp_kernel<RT_, false, true, false, true><<<grid, 256, 0, st>>>(a, N, a_bytes, w, (int)P, N, K, y, ldo, stats_partial, nullptr, nullptr, probe_slot(grid), bw); \
+    else mlp_gemm_smallp_kernel<RT_, false, true, true, false><<<grid, 256, 0, st>>>(a, N, a_bytes, w, (int)P, N, K, y, ldo, nullptr, nullptr, nullptr, probe_slot(grid), bw);         \
+  } while (0)
+  if (sp_rows(P, K) == 32) CPFN_DGRAD_SMALL(32); else CPFN_DGRAD_SMALL(64);
+#undef CPFN_DGRAD_SMALL
+  return cpfn_launch_status();
+}
+
 extern "C" int cpfn_mlp_gemm_set_probe(void *buf, int slots, int max_wg) {
   // buf: slots * (2 + 2 * max_wg) u64 of device memory, zero-filled by the caller (or NULL: probe off).  Applies to
   // every cpfn_mlp_gemm launch issued (or captured into a graph) from now on; launch i gets slot i % slots.
@@ -2134,6 +2264,33 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
   }
   const long long n = (long long)N * K;
   if (dW) launch_split_reduce(workspace, splits, n, dW, st);    // NULL: the caller batches it (cpfn_multi_split_reduce)
+  return cpfn_launch_status();
+}
+
+// the 64 x 64-tile weight gradient with cpfn_bn_bwd_apply folded in (the layers whose data gradient is cpfn_mlp_dgrad_small)
+extern "C" int cpfn_mlp_wgrad_apply_ok(long long P, int N, int K) {
+  int TN, TK;
+  if (P <= 0 || N <= 0 || K < 8 || (N & 63) || (K & 31)) return 0;
+  wgrad_tile(P, N, K, &TN, &TK);
+  return TN == 64 && TK == 64;
+}
+
+extern "C" int cpfn_mlp_wgrad_apply(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
+                                    const float *y_shift, const void *A, int lda, long long P, int N, int K,
+                                    const float *a_scale, const float *a_shift, float *workspace, float *dW, void *stream) {
+  if (!cpfn_mlp_wgrad_apply_ok(P, N, K) || !Gz || !Yr || !coef || !y_scale || !y_shift || !A || !workspace || (lda & 7) ||
+      (!a_scale != !a_shift))
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = cpfn_mlp_wgrad_splits(P, N, K);
+  long long rps = (P + splits - 1) / splits;
+  rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
+  WgradApplyArgs ap;
+  ap.Yr = (const unsigned short *)Yr; ap.coef = coef; ap.y_scale = y_scale; ap.y_shift = y_shift;
+  dim3 grid(N / 64, (K + 63) / 64, splits);
+  mlp_wgrad_kernel<64, 64, true><<<grid, 256, 0, st>>>((const unsigned short *)Gz, N, (const unsigned short *)A, lda, nullptr, P, N,
+                                                       K, rps, workspace, a_scale, a_shift, probe_slot_all(grid), ap);
+  if (dW) launch_split_reduce(workspace, splits, (long long)N * K, dW, st);
   return cpfn_launch_status();
 }
 

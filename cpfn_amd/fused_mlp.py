@@ -41,6 +41,13 @@ FUSED_BWD = os.environ.get("CPFN_FUSED_BWD", "1") != "0"
 # ... and the BatchNorm-backward apply pass of that layer inside the same kernel (g_y never stored); CPFN_FUSED_BWD_APPLY=0:
 # cpfn_bn_bwd_apply as its own launch
 FUSED_BWD_APPLY = os.environ.get("CPFN_FUSED_BWD_APPLY", "1") != "0"
+# small layers (<= 16384 rows): apply pass inside cpfn_mlp_wgrad_apply / cpfn_mlp_dgrad_small, the reduction of the layer
+# below on that data gradient (5 -> 3 launches per layer); CPFN_SMALL_BWD_FUSED=0: the separate kernels
+SMALL_BWD_FUSED = os.environ.get("CPFN_SMALL_BWD_FUSED", "1") != "0"
+# ... the apply pass of those layers on the operand loads too (cpfn_mlp_wgrad_apply, Yr of cpfn_mlp_dgrad_small).  Off by
+# default: every 64-column block of the data gradient re-forms the whole g_y panel, and the slower kernels cancel the
+# saved launch (A/B on the replayed step: 2.059 vs 2.054-2.071 ms).
+SMALL_BWD_APPLY = os.environ.get("CPFN_SMALL_BWD_APPLY", "0") == "1"
 
 
 def _pad_to(n, m):
@@ -398,6 +405,12 @@ class _FusedStack(torch.autograd.Function):
                 one_pass = (FUSED_BWD and need_dgrad and not (li == 0 and first_fp32) and a_in.stride(0) == a_in.shape[1]
                             and bool(h.cpfn_mlp_bwd_fused_ok(P, N, a_in.shape[1])))
                 apply_in_pass, pool_in_pass = False, False
+                # small dense layer (P <= 16384 rows): the apply pass folded into BOTH of its consumers (64 x 64-tile weight
+                # gradient, small-P data gradient), the reduction of the layer below taken by that data gradient
+                small_pass = (SMALL_BWD_FUSED and not one_pass and arg is None and not (li == 0 and first_fp32)
+                              and bool(h.cpfn_mlp_wgrad_apply_ok(P, N, a_in.shape[1]))
+                              and (not need_dgrad or bool(h.cpfn_mlp_dgrad_small_ok(P, N, a_in.shape[1]))))
+                small_apply = False
                 if arg is not None:
                     G = P // pool_k
                     # only the arg-max row of each group carries gradient: the reduction is the dense one over
@@ -442,7 +455,9 @@ class _FusedStack(torch.autograd.Function):
                                                   1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                            "cpfn_bn_bwd_finalize")
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    if nostore and FUSED_BWD_APPLY and (one_pass or (li == 0 and first_fp32 and dseed is None)):
+                    small_pass = small_pass and nostore and dseed is None
+                    small_apply = small_pass and SMALL_BWD_APPLY and FUSED_BWD_APPLY
+                    if nostore and FUSED_BWD_APPLY and (one_pass or small_apply or (li == 0 and first_fp32 and dseed is None)):
                         apply_in_pass = True        # g_y = c0 [z > 0] g + c1 y + c2 is formed on the consumer's staged chunks
                     elif nostore:
                         _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
@@ -504,6 +519,12 @@ class _FusedStack(torch.autograd.Function):
                             fused_part = (fp_, splits)
                         if li == 0:
                             gx = g
+                    elif small_apply:
+                        _check(h.cpfn_mlp_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in),
+                                                      a_in.stride(0), P, N, Kp, None if a_ss is None else _ptr(a_ss[0]),
+                                                      None if a_ss is None else _ptr(a_ss[1]), _ptr(ws), None, _stream()),
+                               "cpfn_mlp_wgrad_apply")
+                        _l.add_bytes("cpfn_mlp_wgrad_apply", 4 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
                     else:
                         _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
                                                 None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
@@ -517,7 +538,27 @@ class _FusedStack(torch.autograd.Function):
                     else:
                         _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin)
                     grads[3 * li] = dW.reshape(wshape)
-                    if need_dgrad and not one_pass:
+                    below_small = small_pass and li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None
+                    if need_dgrad and small_pass and (small_apply or below_small):
+                        below = below_small
+                        g_up = g if small_apply else Gy
+                        g = torch.empty(P, Kp, dtype=BF16, device=dev)
+                        if below:
+                            Yp, stp = saved[li - 1][2], saved[li - 1][3]
+                            nb_ = h.cpfn_mlp_gemm_blocks(P, Kp)
+                            fp_ = torch.empty(nb_, 2, Kp, dtype=torch.float32, device=dev)
+                        sa = small_apply
+                        _check(h.cpfn_mlp_dgrad_small(_ptr(g_up), _ptr(Y) if sa else None, _ptr(coef) if sa else None,
+                                                      _ptr(st[0]) if sa else None, _ptr(st[1]) if sa else None, _ptr(Wb), P, N, Kp,
+                                                      _ptr(g), Kp, _ptr(Yp) if below else None, _ptr(stp[0]) if below else None,
+                                                      _ptr(stp[1]) if below else None, _ptr(fp_) if below else None, _stream()),
+                               "cpfn_mlp_dgrad_small")
+                        _l.add_bytes("cpfn_mlp_dgrad_small", (4 if small_apply else 2) * P * N + 2 * N * Kp + 2 * P * Kp + ((2 * P * Kp + 8 * nb_ * Kp) if below else 0))
+                        if below:
+                            fused_part = (fp_, nb_)
+                        if li == 0:
+                            gx = g
+                    elif need_dgrad and not one_pass:
                         # G_y [P,N] · W [N,Kp]; where the streaming kernel runs, it also reduces the BatchNorm backward
                         # of the layer below from the gradient it is writing
                         if li > 0 and BN_NOSTORE and can_fuse_bwd_stats(P, N, Kp) and saved[li - 1][5] is None:

@@ -83,6 +83,10 @@ SIGNATURES = {
     "cpfn_multi_split_reduce": [_vp, _i, _vp],
     "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused_ok": [_ll, _i, _i],
+    "cpfn_mlp_wgrad_apply_ok": [_ll, _i, _i],
+    "cpfn_mlp_wgrad_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_dgrad_small_ok": [_ll, _i, _i],
+    "cpfn_mlp_dgrad_small": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _f, _vp, _vp, _i, _vp],
     "cpfn_colsum_f32": [_vp, _ll, _i, _vp, _vp, _vp, _vp],

@@ -353,6 +353,25 @@ CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,
                             float *dW, void *stream);
+/* Small layers (P <= 16384 rows) with cpfn_bn_bwd_apply folded into its two consumers — g_y = bf16(coef0 . [y_scale . y +
+ * y_shift > 0] . g_z + coef1 . y + coef2) is formed on the operand loads from the gradient w.r.t. the ACTIVATED output Gz
+ * [P,N] and the layer's pre-BN output Yr [P,N], never stored:
+ *   cpfn_mlp_wgrad_apply: cpfn_mlp_wgrad (64 x 64 tiles; same split partials in workspace, dW optional);
+ *   cpfn_mlp_dgrad_small: Gout[P,K] (bf16, row stride ldo) = g_y . W with W the FORWARD weight panel [N][K]; bwd_y
+ *     (optional, + b_scale / b_shift [K] + stats_partial [cpfn_mlp_gemm_blocks(P,K)][2][K]): pass 1 of the BatchNorm
+ *     backward of the layer below from the tile being stored (replaces its cpfn_bn_relu_bwd launch).  Yr = NULL: Gz is
+ *     g_y itself (bwd_y is then required).  Measured on the replayed step: the riding reduction pays (one launch less
+ *     per hidden layer), the folded apply pass does NOT for these shapes — every column block of the output re-forms
+ *     the whole operand panel (K / 64 times), and the two kernels lose what the saved launch gains. */
+CPFN_API int cpfn_mlp_wgrad_apply_ok(long long P, int N, int K);
+CPFN_API int cpfn_mlp_wgrad_apply(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
+                                  const float *y_shift, const void *A, int lda, long long P, int N, int K,
+                                  const float *a_scale, const float *a_shift, float *workspace, float *dW, void *stream);
+CPFN_API int cpfn_mlp_dgrad_small_ok(long long P, int N, int K);
+CPFN_API int cpfn_mlp_dgrad_small(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
+                                  const float *y_shift, const void *W, long long P, int N, int K, void *Gout, int ldo,
+                                  const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                  void *stream);
 /* Weight gradient AND data gradient of a dense 128 -> 128 layer from ONE read of its BatchNorm-adjoint gradient
  * (cpfn_mlp_bwd_fused_ok(P,N,K): P >= 32768): workspace receives the split partials of
  * dW = Gy^T . A exactly as cpfn_mlp_wgrad leaves them (cpfn_mlp_wgrad_splits(P,128,128) slabs; finish them with

@@ -351,3 +351,42 @@ def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_f
     assert (gxa is None and gxb is None) or same(gxa, gxb)
     for a, b in zip(gra, grb):
         assert (a is None and b is None) or same(a, b)
+
+
+@pytest.mark.parametrize("name,P,cin,widths,pool_k", [
+    ("sa3-like", 16 * 128, 259, [256, 512, 1024], 128),
+    ("sfp1-like", 2048, 1280, [256, 256], None),
+    ("sfp2-like", 8192 - 40, 384, [256, 128], None),
+    ("ragged", 1000, 384, [256, 128], None),
+])
+@pytest.mark.parametrize("stats_fused", [False, True])
+@pytest.mark.parametrize("apply_fused", [False, True])
+def test_small_layer_backward_fusion(name, P, cin, widths, pool_k, stats_fused, apply_fused, monkeypatch):
+    """Small layers: cpfn_mlp_wgrad_apply + cpfn_mlp_dgrad_small (BatchNorm apply pass on the operand loads, the reduction
+    of the layer below on the stored tile) against bn_bwd_apply + wgrad + GEMM (+ bn_relu_bwd): bit-identical without the
+    riding reduction, same sums in a different order with it."""
+    from cpfn_amd import fused_mlp, lib as _l
+    convs, bns = _stack(cin, widths, seed=17)
+    g = torch.Generator().manual_seed(P)
+    x = torch.randn(P, cin, generator=g).to(dev())
+    gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
+    monkeypatch.setattr(fused_mlp, "BWD_STATS_FUSED", stats_fused)
+    monkeypatch.setattr(fused_mlp, "SMALL_BWD_APPLY", apply_fused)     # (off by default: does not pay on these shapes)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(fused_mlp, "SMALL_BWD_FUSED", fused)
+        _l.byte_census(True)
+        res[fused] = _run(x, convs, bns, torch.bfloat16, pool_k, None, gout)
+        census = _l.byte_census(False)
+        assert ("cpfn_mlp_dgrad_small" in census) == (fused and (apply_fused or stats_fused)), sorted(census)
+        assert ("cpfn_mlp_wgrad_apply" in census) == (fused and apply_fused), sorted(census)
+        if fused and not pool_k:
+            assert ("cpfn_bn_bwd_apply" not in census) == apply_fused, sorted(census)
+            if stats_fused:      # only the top layer still needs its own reduction pass
+                assert census["cpfn_bn_relu_bwd"][0] == 1, census["cpfn_bn_relu_bwd"]
+    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
+    same = (lambda a, b: _rel(a, b) < 2e-3) if stats_fused else torch.equal
+    assert torch.equal(ya, yb)
+    assert same(gxa, gxb)
+    for a, b in zip(gra, grb):
+        assert (a is None and b is None) or same(a, b)
