@@ -20,6 +20,9 @@ from .pointnet2_ops.modules.pointset_feature_propagation import PointsetFeatureP
 # CPFN_FUSED_DROPOUT=0: F.dropout as separate PyTorch kernels (mask tensor) instead of the mask generated inside the
 # BatchNorm apply / backward kernels
 FUSED_DROPOUT = os.environ.get("CPFN_FUSED_DROPOUT", "1") != "0"
+# CPFN_CHAIN_FC1=0: fc1 + bn1 as their own fused stack instead of as the last layer of sfp3's (whose last activation is
+# then materialised, and reduced by its own pass in the backward)
+CHAIN_FC1 = os.environ.get("CPFN_CHAIN_FC1", "1") != "0"
 
 
 class PointNet2(torch.nn.Module):
@@ -79,6 +82,16 @@ class PointNet2(torch.nn.Module):
         with fused_mlp.deferred_bn_counters():
             return self._forward(x, glob_features, loc_features, fps_start, geometry, bool(_co.CUDA_ROUTE and fast))
 
+    def _fused_dropout(self, device):
+        """(p, step counter, base seed) of the dropout fused into fc1's BatchNorm apply (cpfn_amd/fused_mlp.py)."""
+        if self._dropout_counter is None or self._dropout_counter.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("run one eager forward pass before capturing a graph (the dropout step counter "
+                                   "must exist outside the captured region)")
+            self._dropout_counter = torch.zeros(1, dtype=torch.int64, device=device)
+            self._dropout_base = torch.initial_seed() ^ 0x5DEECE66D
+        return (self.dropout_p, self._dropout_counter, self._dropout_base)
+
     def _forward(self, x, glob_features, loc_features, fps_start, geometry, cuda_route=False):
         """`fps_start` = optional (start_sa1 [B], start_sa2 [B]) FPS seeds; by default each SA
         level draws its own from the CPU generator like the reference's CPU route."""
@@ -97,25 +110,30 @@ class PointNet2(torch.nn.Module):
             l3 = torch.cat([l3, loc_features.unsqueeze(1).to(l3.dtype)], dim=2)
         l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3)
         l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"), cr)
-        l6, self.aux_sfp3 = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5, gm.get("sfp3"), cr)
         cd = getattr(self, "compute_dtype", torch.float32)
+        # bf16 HIP path: fc1 + bn1 + relu + dropout run as the last layer of sfp3's fused stack (CPFN_CHAIN_FC1=0: its own stack)
+        chain = (CHAIN_FC1 and cd == torch.bfloat16 and x.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT
+                 and not self.features_extractor and getattr(self.sfp3, "compute_dtype", torch.float32) == torch.bfloat16)
+        feat = None
+        if chain:
+            feat, self.aux_sfp3 = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5, gm.get("sfp3"), cr,
+                                                         tail=([self.fc1], [self.bn1], self._fused_dropout(x.device)))
+            feat = feat.reshape(B * N, -1)
+            l6 = None
+        else:
+            l6, self.aux_sfp3 = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5, gm.get("sfp3"), cr)
         l3_out = l3.transpose(1, 2)                                         # [B,1024(+extra),1]
         if getattr(self, "return_point_features", True) or self.features_extractor:
             l3_out = l3_out.float()            # (a trainer that only consumes the heads skips this conversion too)
         if self.features_extractor:
             feat = mlp.conv_as_linear(l6.reshape(B * N, -1).to(cd), self.fc1).float()
             return l3_out, feat.reshape(B, N, -1).transpose(1, 2)
-        if cd == torch.bfloat16 and l6.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT:
+        if feat is not None:
+            pass
+        elif cd == torch.bfloat16 and l6.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT:
             # fc1 + bn1 + relu + the always-on dropout (ref :60-63) with the mask generated inside the BN apply kernel
             # and regenerated in the backward passes (no mask tensor, no separate dropout kernels)
-            if self._dropout_counter is None or self._dropout_counter.device != l6.device:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("run one eager forward pass before capturing a graph (the dropout step counter "
-                                       "must exist outside the captured region)")
-                self._dropout_counter = torch.zeros(1, dtype=torch.int64, device=l6.device)
-                self._dropout_base = torch.initial_seed() ^ 0x5DEECE66D
-            feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd,
-                                 dropout=(self.dropout_p, self._dropout_counter, self._dropout_base))
+            feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd, dropout=self._fused_dropout(l6.device))
         else:
             feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd)       # fc1 + bn1 + relu (ref :60-62)
             feat = F.dropout(feat, p=self.dropout_p, training=True)                        # always on (ref :63)
