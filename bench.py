@@ -39,6 +39,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # of each launch (read A[P,K] and W[N,K] once, write Y[P,N] once) are summed by the caller
 # (cpfn_amd/fused_mlp.py:gemm).
 ROOFLINE_SYMBOL = "cpfn_mlp_gemm"
+# kernel families that time themselves (in-kernel probe): C-ABI entry points whose algorithmic bytes the census counts
+FAMILIES = {"cpfn_mlp_gemm": ("cpfn_mlp_gemm", "cpfn_mlp_dgrad_small"),
+            "cpfn_mlp_wgrad": ("cpfn_mlp_wgrad", "cpfn_mlp_wgrad_apply"),
+            "cpfn_mlp_bwd_fused": ("cpfn_mlp_bwd_fused",)}
+KIND_FAMILY = {1: "cpfn_mlp_gemm", 2: "cpfn_mlp_gemm", 3: "cpfn_mlp_gemm", 4: "cpfn_mlp_wgrad", 5: "cpfn_mlp_bwd_fused"}
 
 
 def parse_args():
@@ -243,13 +248,17 @@ def main():
     # every slot written during the timed region: a replayed graph rewrites the slots its launches were given at capture
     # time, so the buffer now holds the launches of the LAST replayed step (eager mode: the last PROBE_SLOTS launches)
     pr = probe.cpu().numpy()
-    probe_ticks, probe_launches = 0, 0
+    fam_probe = {f: [0, 0] for f in FAMILIES}            # family -> [launches, ticks] of the last replayed step
     for slot in pr:
         nwg = int(slot[0])
         if nwg > 0:
             tt = slot[2:2 + 2 * nwg].reshape(nwg, 2)
-            probe_ticks += int(tt[:, 1].max() - tt[:, 0].min())
-            probe_launches += 1
+            f = KIND_FAMILY.get(int(slot[1]), ROOFLINE_SYMBOL)
+            fam_probe[f][0] += 1
+            fam_probe[f][1] += int(tt[:, 1].max() - tt[:, 0].min())
+    # the family with the most kernel time in the step is the one the roofline object describes
+    dominant = max(FAMILIES, key=lambda f: fam_probe[f][1]) if any(v[0] for v in fam_probe.values()) else ROOFLINE_SYMBOL
+    probe_launches, probe_ticks = fam_probe[dominant]
     lib.check(h.cpfn_mlp_gemm_set_probe(None, 0, 0), "cpfn_mlp_gemm_set_probe")
     if os.environ.get("CPFN_STEP_STAMPS") == "1" and rank == 0 and getattr(trainer, "_graph", None):
         sv = trainer._graph.get("stamps")
@@ -264,7 +273,7 @@ def main():
             if starts:
                 sys.stderr.write("   probed launches of that step: first starts %.1f, last ends %.1f\n"
                                  % ((min(starts) - int(sv[0])) / 100.0, (max(ends) - int(sv[0])) / 100.0))
-    if args.probe_dump and rank == 0:        # debugging (tools/dbg/probe_timeline.py; CPFN_PROBE_ALL=1 adds the weight gradients)
+    if args.probe_dump and rank == 0:        # debugging (tools/dbg/probe_timeline.py)
         # mean over 40 replays (each the third of three back-to-back steps, then a sync to read the buffers): single steps
         # differ by tens of microseconds.  Offsets from the step's first node when CPFN_STEP_STAMPS=1, else from the
         # first probed launch.
@@ -311,12 +320,14 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); torch.cuda._sleep(2_000_000); e1.record(); sync()
     spin = int(2_000_000 * 8.0 / max(e0.elapsed_time(e1), 1e-3))      # ~8 ms of spinning
-    lib.time_symbols([ROOFLINE_SYMBOL])
+    lib.time_symbols(list(FAMILIES[dominant]))
     for _ in range(3):
         torch.cuda._sleep(spin)
         trainer.step(batch, force_eager=True)
     sync()
-    ev_calls, ev_ms = lib.timed_report()[ROOFLINE_SYMBOL]
+    rep = lib.timed_report()
+    ev_calls = sum(rep.get(k, (0, 0.0))[0] for k in FAMILIES[dominant])
+    ev_ms = sum(rep.get(k, (0, 0.0))[1] for k in FAMILIES[dominant])
     lib.time_symbols([])
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -329,7 +340,16 @@ def main():
         if not wall_khz > 0:
             sys.stderr.write("bench.py: the device's wall-clock rate is unknown\n")
             sys.exit(4)
-        launches_per_step, bytes_per_step = census.get(ROOFLINE_SYMBOL, (0, 0))
+        fam_census = {f: (sum(census.get(k, (0, 0))[0] for k in ks), sum(census.get(k, (0, 0))[1] for k in ks))
+                      for f, ks in FAMILIES.items()}
+        launches_per_step, bytes_per_step = fam_census[dominant]
+        families = {}
+        for f in FAMILIES:
+            n, ticks = fam_probe[f]
+            if n > 0 and fam_census[f][0] > 0:
+                us = ticks / (wall_khz * 1e3) * 1e6
+                families[f] = {"launches": n, "us_per_step": us, "achieved": fam_census[f][1] / (us * 1e-6) / 1e9,
+                               "frac": fam_census[f][1] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if probe_launches > 0:                           # graph replays (or eager steps) of the timed region, timed by the kernels
             per_launch_s = probe_ticks / (wall_khz * 1e3) / probe_launches
             roof_mode = ("device wall-clock timestamps (start, end per workgroup; duration = max end - min start) stored by the "
@@ -345,9 +365,9 @@ def main():
         step_bytes = sum(b for _, b in census.values())
         ms_per_step = 1e3 * elapsed / args.steps
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_mlp_gemm_traffic.json")
-        if os.path.exists(tpath):                       # PMC pass (rocprofv3 --pmc), see profiles/README.md
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        tpath = os.path.join(ROOT, "profiles", "r02_family_traffic.json")
+        if os.path.exists(tpath):                       # PMC passes (rocprofv3 --pmc), see profiles/README.md
+            traffic = json.load(open(tpath)).get(dominant, {}).get("hbm_bytes_per_launch")
         line = {
             "metric": "point-clouds/sec (8192 pts, %sSPFN fwd+bwd)" % ("Global" if args.workload == "global" else "Local"),
             "value": clouds / elapsed, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps,
@@ -365,7 +385,7 @@ def main():
                                       "" if world == 1 else ", RCCL all-reduce + Adam inside the graph" if trainer._graph.get("exchange_in_graph")
                                       else ", RCCL all-reduce + Adam after the graph")) if trainer._graph.get("single")
                                   else "hipGraph replay (3 graphs/step around the host-side assignment)")},
-            "roofline": {"bound": "hbm", "kernel": ROOFLINE_SYMBOL, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": probe_launches or ev_calls, "avg_launch_us": 1e6 * per_launch_s,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "measured": roof_mode,
@@ -374,7 +394,9 @@ def main():
                          # the whole step against the same roofline: algorithmic bytes of EVERY kernel of one step
                          # (each operand read once, each result written once) over the measured step time
                          "step_bytes": step_bytes, "step_frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "step_kernels_with_bytes": len(census)},
+                         "step_kernels_with_bytes": len(census),
+                         # every self-timing family of the step ("kernel" above is the one with the most time)
+                         "families": families},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -84,13 +84,9 @@ __device__ __forceinline__ void probe_end(unsigned long long *slot, unsigned lon
     }
   }
 }
-// CPFN_PROBE_ALL=1 (debugging: tools/dbg/probe_timeline.py): the weight-gradient kernels take probe slots too, which
-// turns the probe buffer into a timeline of the replayed step with ~70 anchors.  Off: bench.py's roofline leg sees the
-// GEMM family only.
-static inline unsigned long long *probe_slot_all(dim3 grid) {
-  static const int all = [] { const char *e = getenv("CPFN_PROBE_ALL"); return e && e[0] == '1'; }();
-  return all ? probe_slot(grid) : nullptr;
-}
+// (the weight-gradient and one-pass backward kernels take probe slots too — kinds 4 and 5 — so that bench.py can name the
+//  family with the most time in the step and tools/dbg/probe_timeline.py has ~50 anchors inside a replayed step)
+static inline unsigned long long *probe_slot_all(dim3 grid) { return probe_slot(grid); }
 
 constexpr int G_THREADS = 256;
 constexpr int G_ROWS = 128;   // points per workgroup tile (4 waves x 32)

@@ -15,7 +15,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_
 python3 $B --steps 5 --warmup 5 --census-out gpurun_out/collect/census.json > gpurun_out/collect/census.log 2>&1
 python3 tools/rooflines.py --trace gpurun_out/collect/stats --fetch gpurun_out/collect/fetch --write gpurun_out/collect/write \
     --mfma gpurun_out/collect/mfma --census gpurun_out/collect/census.json \
-    --traffic-out profiles/${tag}_mlp_gemm_traffic.json > profiles/${tag}_rooflines.json 2> gpurun_out/collect/rooflines.err
+    --traffic-out profiles/${tag}_family_traffic.json > profiles/${tag}_rooflines.json 2> gpurun_out/collect/rooflines.err
 python3 tools/replay_breakdown.py $(find gpurun_out/collect/stats -name '*kernel_trace.csv' | head -1) > profiles/${tag}_replayed_step_breakdown.txt 2> gpurun_out/collect/breakdown.err
 cp $(find gpurun_out/collect/stats -name '*kernel_stats.csv' | head -1) profiles/${tag}_graph_kernel_stats.csv
 python3 bench.py --steps 300 --warmup 30 2> gpurun_out/collect/bench.err | tail -1 > profiles/${tag}_bench_n1.json

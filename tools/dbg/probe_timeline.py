@@ -1,4 +1,4 @@
-"""Timeline of the GEMM-family (+ weight-gradient, CPFN_PROBE_ALL=1) launches inside the LAST replayed step of a
+"""Timeline of the GEMM-family, weight-gradient and one-pass backward launches inside the LAST replayed step of a
 bench.py run, from the in-kernel probe (device wall clock, 100 MHz): `bench.py --probe-dump f.json` -> this script.
 Shows per launch: offset from the first anchor, duration, the time since the previous anchor ENDED (= everything that
 ran in between on the critical path) and how ragged the workgroups were.

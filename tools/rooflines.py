@@ -17,7 +17,8 @@ import argparse, collections, csv, glob, json, re, sys
 # kernel function name -> C-ABI entry point that launches it (one entry point may launch several kernels)
 ENTRY = {
     "mlp_gemm_stream_kernel": "cpfn_mlp_gemm", "mlp_gemm_smallp_kernel": "cpfn_mlp_gemm", "mlp_gemm_kernel": "cpfn_mlp_gemm",
-    "mlp_wgrad_kernel": "cpfn_mlp_wgrad", "multi_split_reduce_kernel": "cpfn_multi_split_reduce",
+    "mlp_wgrad_kernel": "cpfn_mlp_wgrad", "mlp_bwd_fused_kernel": "cpfn_mlp_bwd_fused",
+    "multi_split_reduce_kernel": "cpfn_multi_split_reduce",
     "bn_finalize_kernel": "cpfn_bn_finalize", "bn_bwd_finalize_kernel": "cpfn_bn_bwd_finalize",
     "bn_relu_apply_kernel": "cpfn_bn_relu_apply", "bn_relu_maxpool_kernel": "cpfn_bn_relu_maxpool",
     "bn_relu_bwd_kernel": "cpfn_bn_relu_bwd", "bn_bwd_apply_kernel": "cpfn_bn_bwd_apply",
@@ -36,6 +37,9 @@ ENTRY = {
     "three_nn_kernel": "cpfn_three_nn", "three_weights_kernel": "cpfn_three_weights", "csr_build_kernel": "cpfn_csr_build",
     "gather_rows_kernel": "cpfn_gather_rows", "group_xyz_centered_kernel": "cpfn_group_xyz_centered",
 }
+# entry points that launch a kernel family of another entry point: their algorithmic bytes are added to that family
+CENSUS_MERGE = {"cpfn_mlp_dgrad_small": "cpfn_mlp_gemm", "cpfn_mlp_wgrad_apply": "cpfn_mlp_wgrad",
+                "cpfn_smallk_wgrad_apply": "cpfn_smallk_wgrad"}
 HBM_PEAK = 8.0e12
 CLOCK_HZ, N_SIMD = 2.4e9, 1024
 
@@ -82,13 +86,17 @@ def main():
     for a in ("trace", "fetch", "write", "census"):
         ap.add_argument("--" + a, required=True)
     ap.add_argument("--mfma", default=None)
-    ap.add_argument("--traffic-out", default=None, help="also write the GEMM family's traffic file bench.py reads")
+    ap.add_argument("--traffic-out", default=None, help="also write the per-family traffic file bench.py reads")
     args = ap.parse_args()
     times, wall_us = replayed(args.trace)
     fetch, write = pmc(args.fetch, ["FETCH_SIZE"]), pmc(args.write, ["WRITE_SIZE"])
     mf = pmc(args.mfma, ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_ACTIVE_INST_VALU",
                          "SQ_WAVE_CYCLES"]) if args.mfma else {}
     census = json.load(open(args.census))
+    for k, into in CENSUS_MERGE.items():
+        if k in census:
+            a, b = census.pop(k), census.get(into, [0, 0])
+            census[into] = [a[0] + b[0], a[1] + b[1]]
     fam = collections.OrderedDict()
     for k, (n, us) in sorted(times.items(), key=lambda kv: -kv[1][1]):
         key = ENTRY.get(k, k)
@@ -151,15 +159,16 @@ def main():
                     "written once (bench.py --census-out); mfma_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 2.4 GHz x 1024 SIMDs)",
            "families": table}
     print(json.dumps(out, indent=1))
-    if args.traffic_out and "cpfn_mlp_gemm" in fam:
-        e = fam["cpfn_mlp_gemm"]
-        n = e["launches_per_step"]
-        json.dump({"kernel": "mlp_gemm_* (entry point cpfn_mlp_gemm)", "launches_per_step": n,
-                   "hbm_bytes_per_launch": (e["hbm_read"] + e["hbm_write"]) / n,
-                   "fetch_bytes_per_launch_corrected_x2": e["hbm_read"] / n, "write_bytes_per_launch": e["hbm_write"] / n,
-                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graphs`; FETCH_SIZE "
-                           "doubled per MI355X_MICROARCH.md (gfx950), counters in KiB; tools/rooflines.py"},
-                  open(args.traffic_out, "w"), indent=1)
+    if args.traffic_out:
+        out_t = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --no-graphs`; FETCH_SIZE "
+                         "doubled per MI355X_MICROARCH.md (gfx950), counters in KiB; tools/rooflines.py"}
+        for f in ("cpfn_mlp_gemm", "cpfn_mlp_wgrad", "cpfn_mlp_bwd_fused"):
+            if f in fam and fam[f]["pmc_launches"]:
+                e = fam[f]
+                n = e["launches_per_step"]
+                out_t[f] = {"launches_per_step": n, "hbm_bytes_per_launch": (e["hbm_read"] + e["hbm_write"]) / n,
+                            "fetch_bytes_per_launch_corrected_x2": e["hbm_read"] / n, "write_bytes_per_launch": e["hbm_write"] / n}
+        json.dump(out_t, open(args.traffic_out, "w"), indent=1)
 
 
 if __name__ == "__main__":
