@@ -1427,7 +1427,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 // ahead.  APPLY: Gy is the gradient with respect to the layer's ACTIVATED output and the BatchNorm-backward apply pass
 // (g_y = c0 . [scale . y + shift > 0] . g + c1 . y + c2, rounded to bf16 exactly as cpfn_bn_bwd_apply stores it) runs on
 // the staged chunks from the layer's own pre-BN output Yr: g_y is never written to or read from memory.
-// Shapes <TN, TK, STEP>: <128,128,32>, <256,128,32>, <64,64,64>, <128,64,64> (layer N -> channels of g_y, K -> channels of its input;
+// Shapes <TN, TK, STEP>: <128,128,32>, <256,128,32>, <128,192,32>, <64,64,64>, <128,64,64> (layer N -> channels of g_y, K -> channels of its input;
 // STEP rows per step, 128 rows in flight).  Grid (1, 1, splits), the split layout of mlp_wgrad_kernel: same partials,
 // bit for bit.
 // EIGHT waves: for <128,128> a wave's share of the dW tile is 32 x 64 (32 accumulator registers) and a thread stages one
@@ -1459,15 +1459,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // (rows in flight: 128, and 64 for the 256-wide g_y — the same bytes, half the staging registers)
   constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP / (TN > 128 ? 2 : 1), KSTEPS = STEP / 32;
   constexpr int CPRG = TN / 8, CPRA = TK / 8;                 // 16-byte chunks per row of the TN- / TK-wide tensors
-  constexpr int NG = STEP * CPRG / NT, NA = STEP * CPRA / NT; // chunks per thread and step
+  constexpr int NG = STEP * CPRG / NT;                        // g_y chunks per thread and step
+  // TK-wide tensors (input, data-gradient slab, y of the layer below): RPA rows per pass, TA of the 512 threads busy
+  // (TK = 192: 24 chunks per row -> 16 rows x 24 = 384 threads, two passes per 32-row step)
+  constexpr int RPA = (NT / CPRA >= 64 ? 64 : NT / CPRA >= 32 ? 32 : 16) < STEP ? (NT / CPRA >= 64 ? 64 : NT / CPRA >= 32 ? 32 : 16) : STEP;
+  constexpr int TA = RPA * CPRA, NA = STEP / RPA;
   constexpr int MI = TN / 64, MJ = TK / 32;                   // dW tiles per wave (waves 4 x 2 over TN x TK)
-  constexpr int CHB = TK / 16;                                // 16-channel blocks of the data-gradient slab
-  static_assert(NG >= 1 && NA >= 1 && (WG_STEP * WG_DEPTH) % (STEP * DEPTH) == 0 && (STEP / 16) * CHB == 16, "shape");
+  constexpr int CHB = TK / 16, TPW = (STEP / 16) * CHB / 8;   // 16-channel blocks of the data-gradient slab, its tiles per wave
+  static_assert(NG >= 1 && NA >= 1 && TA <= NT && (WG_STEP * WG_DEPTH) % (STEP * DEPTH) == 0 && (STEP / 16) * CHB == 8 * TPW, "shape");
+  static_assert(!BST || (64 % CPRA == 0), "the riding reduction needs a power-of-two chunk count per row");
   __shared__ __attribute__((aligned(16))) unsigned short s_g[STEP * LDN];
   __shared__ __attribute__((aligned(16))) unsigned short s_a[STEP * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short s_o[STEP * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short s_wt[TK * LDN];
-  static_assert(sizeof(float) * 8 * 2 * TK <= sizeof(unsigned short) * STEP * LDN, "the statistics reduction reuses s_g");
+  static_assert(!BST || sizeof(float) * 8 * 2 * TK <= sizeof(unsigned short) * STEP * LDN, "the statistics reduction reuses s_g");
   float(*s_red)[2][TK] = (float(*)[2][TK])s_g;      // cross-wave reduction of the statistics: after the last step only
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lq = lane >> 4;
   const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
@@ -1485,7 +1490,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
   // chunk i of thread t: row t / CPR + i (NT / CPR), columns 8 (t % CPR) — a thread's columns never change
-  const int grow = t / CPRG, gcol = (t % CPRG) * 8, arow = t / CPRA, acol = (t % CPRA) * 8;
+  const int grow = t / CPRG, gcol = (t % CPRG) * 8, arow = (TA == NT ? t : t % TA) / CPRA, acol = (t % CPRA) * 8;
+  const bool a_live = TA == NT || t < TA;
   uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
   uint4 vgp[APPLY == 2 ? DEPTH : 1], vya[APPLY == 2 ? DEPTH : 1];       // pooled gradient / arg-max value of the step's group
   uint2 var_[APPLY == 2 ? DEPTH : 1];                                    // arg-max row (8 channels, one byte each)
@@ -1521,10 +1527,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       if (APPLY != 2) vg[sidx][i] = *(const uint4 *)(Gy + p * ldg + gcol);
       if (APPLY) vy[sidx][i] = *(const uint4 *)(Yr + p * ldg + gcol);
     }
+    if (a_live) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const long long p = min(base + arow + i * (NT / CPRA), p1 - 1);
-      va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
+      for (int i = 0; i < NA; ++i) {
+        const long long p = min(base + arow + i * RPA, p1 - 1);
+        va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
+      }
     }
   };
   auto stage = [&](int sidx, long long base) {
@@ -1595,22 +1603,25 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       if (base + r >= p1) g4 = (uint4){0, 0, 0, 0};
       *(uint4 *)&s_g[r * LDN + gcol] = g4;
     }
+    if (a_live) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int r = arow + i * (NT / CPRA);
-      uint4 a4 = va[sidx][i];
-      if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
-      if (base + r >= p1) a4 = (uint4){0, 0, 0, 0};
-      *(uint4 *)&s_a[r * LDK + acol] = a4;
+      for (int i = 0; i < NA; ++i) {
+        const int r = arow + i * RPA;
+        uint4 a4 = va[sidx][i];
+        if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
+        if (base + r >= p1) a4 = (uint4){0, 0, 0, 0};
+        *(uint4 *)&s_a[r * LDK + acol] = a4;
+      }
     }
   };
   // the STEP x TK data-gradient slab of the PREVIOUS step leaves here (its LDS patch was completed before this step's
   // first barrier): NA 16-byte pieces per thread
   uint4 yb[NA];
   auto store_prev = [&](long long pbase) {
+    if (!a_live) return;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int r = arow + i * (NT / CPRA);
+      const int r = arow + i * RPA;
       const long long p = pbase + r;
       const uint4 v = *(const uint4 *)&s_o[r * LDK + acol];
       if (p < p1) {
@@ -1633,7 +1644,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue(d, p0 + (long long)d * STEP);
   fill_w_panel<TK, LDN, NT>(s_wt, W, TN, TK, 0, 0, TN, 1, t);      // s_wt[k_out][n]: the forward weight [n][k] transposed
-  const int cb = wave % CHB, rb0 = (wave / CHB) * 2;               // this wave's two 16 x 16 tiles of the slab
   long long prev = -1;
   for (long long base0 = p0; base0 < p1; base0 += STEP * DEPTH) {
 #pragma unroll
@@ -1647,7 +1657,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       if (BST) {       // this step's slab, used one step later
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-          yb[i] = *(const uint4 *)(Yb + min(base + arow + i * (NT / CPRA), p1 - 1) * ldo + acol);
+          yb[i] = *(const uint4 *)(Yb + min(base + arow + i * RPA, p1 - 1) * ldo + acol);
       }
       // ---- weight gradient: transposed fragments of both tiles (as mlp_wgrad_kernel), 32 rows per MFMA
 #pragma unroll
@@ -1663,21 +1673,47 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
           for (int j = 0; j < MJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
       }
-      // ---- data gradient of the same rows: this wave's output channels 16 cb .. +15 of rows 16 rb0 .. +31
-      f32x4 ad[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      if constexpr (CHB == 8 || CHB == 4) {
+        // ---- data gradient of the same rows: this wave's output channels 16 cb .. +15 of rows 16 rb0 .. +31 (two tiles
+        //      that share the weight fragment)
+        const int cb = wave % CHB, rb0 = (wave / CHB) * 2;
+        f32x4 ad[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-      for (int ks = 0; ks < TN / 32; ++ks) {
-        const bf16x8 pf0 = *(const bf16x8 *)&s_g[(rb0 * 16 + lr) * LDN + ks * 32 + 8 * lq];
-        const bf16x8 pf1 = *(const bf16x8 *)&s_g[(rb0 * 16 + 16 + lr) * LDN + ks * 32 + 8 * lq];
-        const bf16x8 wf = *(const bf16x8 *)&s_wt[(cb * 16 + lr) * LDN + ks * 32 + 8 * lq];
-        ad[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[0], 0, 0, 0);
-        ad[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[1], 0, 0, 0);
-      }
+        for (int ks = 0; ks < TN / 32; ++ks) {
+          const bf16x8 pf0 = *(const bf16x8 *)&s_g[(rb0 * 16 + lr) * LDN + ks * 32 + 8 * lq];
+          const bf16x8 pf1 = *(const bf16x8 *)&s_g[(rb0 * 16 + 16 + lr) * LDN + ks * 32 + 8 * lq];
+          const bf16x8 wf = *(const bf16x8 *)&s_wt[(cb * 16 + lr) * LDN + ks * 32 + 8 * lq];
+          ad[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[0], 0, 0, 0);
+          ad[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[1], 0, 0, 0);
+        }
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const f32x4 v = ad[tt];
-        const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        *(bf16x4 *)&s_o[((rb0 + tt) * 16 + lr) * LDK + cb * 16 + 4 * lq] = ov;
+        for (int tt = 0; tt < 2; ++tt) {
+          const f32x4 v = ad[tt];
+          const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          *(bf16x4 *)&s_o[((rb0 + tt) * 16 + lr) * LDK + cb * 16 + 4 * lq] = ov;
+        }
+      } else {
+        // ---- (TK = 192: 2 x 12 tiles of 16 x 16) tile q = wave + 8 i of the slab
+        f32x4 ad[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) ad[i] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < TN / 32; ++ks) {
+#pragma unroll
+          for (int i = 0; i < TPW; ++i) {
+            const int q = wave + 8 * i, cb = q % CHB, rb = q / CHB;
+            const bf16x8 pf = *(const bf16x8 *)&s_g[(rb * 16 + lr) * LDN + ks * 32 + 8 * lq];
+            const bf16x8 wf = *(const bf16x8 *)&s_wt[(cb * 16 + lr) * LDN + ks * 32 + 8 * lq];
+            ad[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf, ad[i], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          const int q = wave + 8 * i, cb = q % CHB, rb = q / CHB;
+          const f32x4 v = ad[i];
+          const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          *(bf16x4 *)&s_o[(rb * 16 + lr) * LDK + cb * 16 + 4 * lq] = ov;
+        }
       }
       prev = base;
     }
@@ -2291,7 +2327,8 @@ extern "C" int cpfn_mlp_wgrad_apply(const void *Gz, const void *Yr, const float 
 }
 
 extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
-  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128);
+  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128) ||
+                     (N == 128 && K == 192);
   return shape && P > SP_MAX_ROWS && P >= 32768;
 }
 
@@ -2306,7 +2343,8 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
       (apply_y && (!apply_coef || !y_scale || !y_shift)))
     return CPFN_EINVAL;
   if ((drop_seed && (!apply_y || pool_k > 0 || !(drop_p >= 0.f && drop_p < 1.f))) || pool_k < 0) return CPFN_EINVAL;
-  const int step = K == 128 ? 32 : 64;
+  const int step = K >= 128 ? 32 : 64;
+  if (K == 192 && (bwd_y || drop_seed || pool_k > 0)) return CPFN_EINVAL;   // (24 chunks per row: plain / dense apply only)
   if (pool_k > 0 && (!apply_y || !pool_arg || !pool_yarg || pool_k > 255 || pool_k % step || P % pool_k || ldg != N))
     return CPFN_EINVAL;
   const int splits = cpfn_mlp_wgrad_splits(P, N, K);
@@ -2343,6 +2381,10 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   } while (0)
   if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
   else if (N == 256) CPFN_BWD_FUSED_SHAPE(256, 128, 32);
+  else if (K == 192) {          // sa2's first layer (131 -> padded 192 input channels): never has a layer below
+    if (mode == 1) CPFN_BWD_FUSED(128, 192, 32, false, 1);
+    else CPFN_BWD_FUSED(128, 192, 32, false, 0);
+  }
   else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
   else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
 #undef CPFN_BWD_FUSED_SHAPE

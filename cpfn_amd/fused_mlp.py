@@ -425,7 +425,7 @@ class _FusedStack(torch.autograd.Function):
                            "cpfn_bn_bwd_finalize")
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                     step_rows = 32 if a_in.shape[1] == 128 else 64        # rows per step of the one-pass kernel for this shape
-                    if one_pass and FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255:
+                    if one_pass and FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255 and a_in.shape[1] != 192:
                         pool_in_pass = True       # g_y is formed from (pooled gradient, arg-max, y) on the one-pass kernel's chunks
                         Gy = None
                     else:
@@ -457,6 +457,8 @@ class _FusedStack(torch.autograd.Function):
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                     small_pass = small_pass and nostore and dseed is None
                     small_apply = small_pass and SMALL_BWD_APPLY and FUSED_BWD_APPLY
+                    if one_pass and a_in.shape[1] == 192 and dseed is not None:
+                        one_pass = False            # (the 192-wide shape has no dropout variant)
                     if nostore and FUSED_BWD_APPLY and (one_pass or small_apply or (li == 0 and first_fp32 and dseed is None)):
                         apply_in_pass = True        # g_y = c0 [z > 0] g + c1 y + c2 is formed on the consumer's staged chunks
                     elif nostore:
@@ -492,7 +494,7 @@ class _FusedStack(torch.autograd.Function):
                     if one_pass:
                         # dense 128 -> 128 layer: weight gradient, data gradient and pass 1 of the BatchNorm backward of
                         # the layer below from ONE read of G_y (mlp_bwd_fused_kernel)
-                        below = li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None
+                        below = li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None and Kp != 192
                         g_up = g                      # gradient w.r.t. the activated output (apply_in_pass) ...
                         g = torch.empty(P, Kp, dtype=BF16, device=dev)
                         if below:

@@ -384,7 +384,7 @@ CPFN_API int cpfn_mlp_dgrad_small(const void *Gz, const void *Yr, const float *c
  * drop_p: cpfn_bn_bwd_apply's fused dropout on that gradient.  pool_k > 0 (max-pooled layer, P = groups x pool_k rows,
  * pool_k a multiple of 64 - 32 for N = K = 128 - and <= 255): Gy is the POOLED gradient [P / pool_k, N] and pool_arg /
  * pool_yarg are cpfn_bn_relu_maxpool's arg-max rows and values: cpfn_bn_pool_bwd_apply's arithmetic instead.
- * (N, K) in {(128,128), (64,64), (128,64)}.  Replaces a [cpfn_bn_bwd_apply | cpfn_bn_pool_bwd_apply +] cpfn_mlp_wgrad +
+ * (N, K) in {(128,128), (256,128), (64,64), (128,64)}, and (128,192) without bwd_y / drop_seed / pool_k.  Replaces a [cpfn_bn_bwd_apply | cpfn_bn_pool_bwd_apply +] cpfn_mlp_wgrad +
  * cpfn_mlp_gemm(w_trans) sequence, bit for bit. */
 CPFN_API int cpfn_mlp_bwd_fused_ok(long long P, int N, int K);
 CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
