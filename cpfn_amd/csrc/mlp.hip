@@ -1750,6 +1750,146 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   probe_end(probe, probe_t0, 5);
 }
 
+// ---------------------------------------------------------------- forward GEMM + statistics, row-streaming form
+// The forward layers at 131072 rows (67-100 MB per launch) ran at 2.7 TB/s in the streaming kernel above: with four waves
+// the epilogue (BatchNorm statistics from the staged tile, BN + ReLU of the previous layer on the operand) is VALU work
+// that nothing overlaps.  This kernel is the data-gradient half of mlp_bwd_fused_kernel turned around: EIGHT waves,
+// 32-row steps through a 4-deep register pipeline -> LDS -> MFMA, the weight panel [NO][KC] in LDS once per workgroup,
+// the 32 x NO output slab leaves one step later as 16-byte row stores, and a thread's statistics cover the one 8-channel
+// chunk it stores (sum y, sum y^2 of the ROUNDED values, as before).  Y is bit-identical to the streaming kernel's (same
+// MFMA order); the per-workgroup partial sums group the rows differently.  <KC, NO>: <128,128>, <192,128>, <128,256>.
+template <int KC, int NO, bool ATR>
+__global__ __launch_bounds__(512) void mlp_fwd_rows_kernel(
+    const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W /* [NO][KC] */, long long P,
+    long long rows_per_wg, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe) {
+  const unsigned long long probe_t0 = probe_begin(probe);
+  constexpr int NT = 512, STEP = 32, DEPTH = 4, LDA_ = KC + 8, LDO = NO + 8;
+  constexpr int CPRA = KC / 8, CPRO = NO / 8;
+  constexpr int RPA = NT / CPRA >= 32 ? 32 : 16, TA = RPA * CPRA, NA = STEP / RPA;   // operand chunks (KC = 192: 384 threads x 2)
+  constexpr int NOC = STEP * CPRO / NT;                                                // output chunks per thread and step
+  constexpr int CHB = NO / 16, TPW = 2 * CHB / 8;                                      // 16 x 16 tiles of the slab per wave
+  static_assert(NOC >= 1 && TA <= NT && NT % CPRO == 0 && CHB % 8 == 0, "shape");
+  __shared__ __attribute__((aligned(16))) unsigned short s_a[STEP * LDA_];
+  __shared__ __attribute__((aligned(16))) unsigned short s_o[STEP * LDO];
+  __shared__ __attribute__((aligned(16))) unsigned short s_w[NO * LDA_];
+  static_assert(sizeof(float) * 8 * 2 * NO <= sizeof(unsigned short) * NO * LDA_, "the statistics reduction reuses s_w");
+  float(*s_red)[2][NO] = (float(*)[2][NO])s_w;        // after the last step only
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lq = lane >> 4;
+  const long long p0 = (long long)blockIdx.x * rows_per_wg, p1 = min(P, p0 + rows_per_wg);
+  const int ocol = (t % CPRO) * 8, orow = t / CPRO;
+  float st_s[8], st_q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
+  if (p0 < p1) {
+    const int arow = (TA == NT ? t : t % TA) / CPRA, acol = (t % CPRA) * 8;
+    const bool a_live = TA == NT || t < TA;
+    uint4 va[DEPTH][NA];
+    float asc[8], ash[8];
+    if (ATR) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { asc[j] = a_scale[acol + j]; ash[j] = a_shift[acol + j]; }
+    }
+    auto issue = [&](int sidx, long long base) {
+      if (a_live) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[sidx][i] = *(const uint4 *)(A + min(base + arow + i * RPA, p1 - 1) * lda + acol);
+      }
+    };
+    auto stage = [&](int sidx, long long base) {
+      if (a_live) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int r = arow + i * RPA;
+          uint4 a4 = va[sidx][i];
+          if (ATR) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
+          if (base + r >= p1) a4 = (uint4){0, 0, 0, 0};
+          *(uint4 *)&s_a[r * LDA_ + acol] = a4;
+        }
+      }
+    };
+    auto store_prev = [&](long long pbase) {
+#pragma unroll
+      for (int i = 0; i < NOC; ++i) {
+        const int r = orow + i * (NT / CPRO);
+        const long long p = pbase + r;
+        const uint4 v = *(const uint4 *)&s_o[r * LDO + ocol];
+        if (p < p1) {
+          *(uint4 *)(Y + p * ldy + ocol) = v;
+          const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float y0 = __uint_as_float(w4[j] << 16), y1 = __uint_as_float(w4[j] & 0xffff0000u);
+            st_s[2 * j] += y0; st_s[2 * j + 1] += y1;
+            st_q[2 * j] = fmaf(y0, y0, st_q[2 * j]); st_q[2 * j + 1] = fmaf(y1, y1, st_q[2 * j + 1]);
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d, p0 + (long long)d * STEP);
+    fill_w_panel<NO, LDA_, NT>(s_w, W, KC, NO, 0, 0, KC, 0, t);
+    long long prev = -1;
+    for (long long base0 = p0; base0 < p1; base0 += STEP * DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const long long base = base0 + (long long)d * STEP;
+        __syncthreads();
+        if (prev >= 0) store_prev(prev);
+        stage(d, base);
+        __syncthreads();
+        issue(d, base + STEP * DEPTH);
+        // wave w: output channels 16 (w + 8 i) .. +15 of both 16-row halves (the two tiles share the weight fragment)
+        f32x4 ad[TPW / 2][2];
+#pragma unroll
+        for (int i = 0; i < TPW / 2; ++i) { ad[i][0] = (f32x4){0, 0, 0, 0}; ad[i][1] = (f32x4){0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KC / 32; ++ks) {
+          const bf16x8 pf0 = *(const bf16x8 *)&s_a[lr * LDA_ + ks * 32 + 8 * lq];
+          const bf16x8 pf1 = *(const bf16x8 *)&s_a[(16 + lr) * LDA_ + ks * 32 + 8 * lq];
+#pragma unroll
+          for (int i = 0; i < TPW / 2; ++i) {
+            const bf16x8 wf = *(const bf16x8 *)&s_w[((wave + 8 * i) * 16 + lr) * LDA_ + ks * 32 + 8 * lq];
+            ad[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[i][0], 0, 0, 0);
+            ad[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[i][1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TPW / 2; ++i)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const f32x4 v = ad[i][tt];
+            const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *(bf16x4 *)&s_o[(tt * 16 + lr) * LDO + (wave + 8 * i) * 16 + 4 * lq] = ov;
+          }
+        prev = base;
+      }
+    }
+    __syncthreads();
+    store_prev(prev);
+  }
+  // threads that share a column chunk (t % CPRO): shuffles inside the wave, then the eight waves through LDS
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int m = CPRO; m < 64; m <<= 1) { st_s[j] += __shfl_xor(st_s[j], m, 64); st_q[j] += __shfl_xor(st_q[j], m, 64); }
+  }
+  __syncthreads();        // every wave is done with the weight panel (s_red reuses it)
+  if (lane < CPRO) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_red[wave][0][lane * 8 + j] = st_s[j]; s_red[wave][1][lane * 8 + j] = st_q[j]; }
+  }
+  __syncthreads();
+  for (int e = t; e < 2 * NO; e += NT) {
+    const int which = e / NO, c = e - which * NO;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += s_red[w][which][c];
+    stats_partial[((size_t)blockIdx.x * 2 + which) * NO + c] = v;
+  }
+  probe_end(probe, probe_t0, 1);
+}
+
 template <int RS>
 __global__ __launch_bounds__(16 * RS) void split_reduce_kernel(const float *__restrict__ partial, int splits, long long n,
                                     float *__restrict__ out) {
@@ -2032,6 +2172,44 @@ extern "C" int cpfn_mlp_dgrad_small(const void *Gz, const void *Yr, const float 
   } while (0)
   if (sp_rows(P, K) == 32) CPFN_DGRAD_SMALL(32); else CPFN_DGRAD_SMALL(64);
 #undef CPFN_DGRAD_SMALL
+  return cpfn_launch_status();
+}
+
+// forward layers of >= 32768 rows in the row-streaming form (mlp_fwd_rows_kernel): 256 workgroups, one statistics row each
+extern "C" int cpfn_mlp_gemm_rows_ok(long long P, int K, int N) {
+  // (192 -> 128 and 128 -> 256 are instantiated and correct, but their 73 / 95 KB of LDS do not fit beside the next
+  //  batch's FPS workgroup (98 KB) that sits on 16 CUs during the whole forward pass: 16 workgroups would wait a round)
+  static const int all = [] { const char *e = getenv("CPFN_FWD_ROWS_ALL"); return e && e[0] == '1'; }();
+  const bool shape = (K == 128 && N == 128) || (all && ((K == 192 && N == 128) || (K == 128 && N == 256)));
+  return shape && P >= 32768 && P <= 2000000000LL;
+}
+
+extern "C" int cpfn_mlp_gemm_rows_blocks(long long P) {
+  long long rows = (P + 255) / 256;
+  rows = ((rows + 127) / 128) * 128;
+  return (int)((P + rows - 1) / rows);
+}
+
+extern "C" int cpfn_mlp_gemm_rows(const void *A, int lda, const void *W, long long P, int K, int N, void *Y, int ldy,
+                                  float *stats_partial, const float *a_scale, const float *a_shift, void *stream) {
+  if (!cpfn_mlp_gemm_rows_ok(P, K, N) || !A || !W || !Y || !stats_partial || lda < K || (lda & 7) || ldy < N || (ldy & 7) ||
+      (!a_scale != !a_shift))
+    return CPFN_EINVAL;
+  long long rows = (P + 255) / 256;
+  rows = ((rows + 127) / 128) * 128;
+  const dim3 grid((unsigned)((P + rows - 1) / rows));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
+  unsigned short *y = (unsigned short *)Y;
+#define CPFN_FWD_ROWS(KC_, NO_)                                                                                          \
+  do {                                                                                                                   \
+    if (a_scale) mlp_fwd_rows_kernel<KC_, NO_, true><<<grid, 512, 0, st>>>(a, lda, w, P, rows, y, ldy, stats_partial, a_scale, a_shift, probe_slot(grid)); \
+    else mlp_fwd_rows_kernel<KC_, NO_, false><<<grid, 512, 0, st>>>(a, lda, w, P, rows, y, ldy, stats_partial, nullptr, nullptr, probe_slot(grid));        \
+  } while (0)
+  if (K == 128 && N == 128) CPFN_FWD_ROWS(128, 128);
+  else if (K == 192) CPFN_FWD_ROWS(192, 128);
+  else CPFN_FWD_ROWS(128, 256);
+#undef CPFN_FWD_ROWS
   return cpfn_launch_status();
 }
 

@@ -44,6 +44,12 @@ FUSED_BWD_APPLY = os.environ.get("CPFN_FUSED_BWD_APPLY", "1") != "0"
 # small layers (<= 16384 rows): apply pass inside cpfn_mlp_wgrad_apply / cpfn_mlp_dgrad_small, the reduction of the layer
 # below on that data gradient (5 -> 3 launches per layer); CPFN_SMALL_BWD_FUSED=0: the separate kernels
 SMALL_BWD_FUSED = os.environ.get("CPFN_SMALL_BWD_FUSED", "1") != "0"
+# CPFN_FWD_ROWS=1: forward 128 -> 128 layers at >= 32768 rows through cpfn_mlp_gemm_rows (8 waves, one row pipeline per
+# workgroup: the data-gradient half of the one-pass backward kernel turned around) instead of the tiled streaming kernel.
+# Bit-identical Y, and 17.6 us per workgroup against 18 us per LAUNCH of the streaming kernel — but off by default: with
+# 256 long workgroups the 16 that share a CU with the next batch's FPS workgroup (16 waves of it) finish at 25 us, and
+# the launch with them (in-kernel probe; 2.06 vs 2.015 ms per step).  The streaming kernel's 342 x 3 short tiles balance.
+FWD_ROWS = os.environ.get("CPFN_FWD_ROWS", "0") == "1"
 # ... the apply pass of those layers on the operand loads too (cpfn_mlp_wgrad_apply, Yr of cpfn_mlp_dgrad_small).  Off by
 # default: every 64-column block of the data gradient re-forms the whole g_y panel, and the slower kernels cancel the
 # saved launch (A/B on the replayed step: 2.059 vs 2.054-2.071 ms).
@@ -78,6 +84,15 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
     if bwd_stats is not None:
         yb, a_scale, a_shift = bwd_stats
         stats = True
+    if (FWD_ROWS and stats and bwd_stats is None and not w_trans and gidx is None and bias is None and not out_f32 and n_store == N
+            and h.cpfn_mlp_gemm_rows_ok(P, K, N)):
+        # forward layer at >= 32768 rows: the row-streaming kernel (same Y bit for bit, 256 statistics rows)
+        nblk = h.cpfn_mlp_gemm_rows_blocks(P)
+        part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
+        _check(h.cpfn_mlp_gemm_rows(_ptr(A), A.stride(0), _ptr(Wb), P, K, N, _ptr(Y), N, _ptr(part), _ptr(a_scale), _ptr(a_shift),
+                                    _stream()), "cpfn_mlp_gemm_rows")
+        _l.add_bytes("cpfn_mlp_gemm_rows", 2 * P * K + 2 * N * K + 2 * P * N + 8 * nblk * N)
+        return Y, part, nblk
     if stats:
         nblk = h.cpfn_mlp_gemm_blocks(P, N)
         part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)

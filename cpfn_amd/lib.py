@@ -82,6 +82,9 @@ SIGNATURES = {
     "cpfn_mlp_wgrad_splits": [_ll, _i, _i],
     "cpfn_multi_split_reduce": [_vp, _i, _vp],
     "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_gemm_rows_ok": [_ll, _i, _i],
+    "cpfn_mlp_gemm_rows_blocks": [_ll],
+    "cpfn_mlp_gemm_rows": [_vp, _i, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused_ok": [_ll, _i, _i],
     "cpfn_mlp_wgrad_apply_ok": [_ll, _i, _i],
     "cpfn_mlp_wgrad_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],

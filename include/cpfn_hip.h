@@ -289,6 +289,13 @@ CPFN_API int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N);
 CPFN_API int cpfn_mlp_gemm_set_probe(void *buf, int slots, int max_wg);
 /* Rate in kHz of the device wall clock the probe's ticks are counted in (hipDeviceAttributeWallClockRate); <= 0 on error. */
 CPFN_API int cpfn_wall_clock_khz(int device);
+/* Forward layers of >= 32768 rows, (K, N) in {(128,128), (192,128), (128,256)}, with BatchNorm statistics — the same
+ * Y (bit for bit) and statistics as cpfn_mlp_gemm(..., stats_partial, a_scale, a_shift), in the row-streaming form
+ * (8 waves, one pipeline over the workgroup's rows); stats_partial has cpfn_mlp_gemm_rows_blocks(P) rows. */
+CPFN_API int cpfn_mlp_gemm_rows_ok(long long P, int K, int N);
+CPFN_API int cpfn_mlp_gemm_rows_blocks(long long P);
+CPFN_API int cpfn_mlp_gemm_rows(const void *A, int lda, const void *W, long long P, int K, int N, void *Y, int ldy,
+                                float *stats_partial, const float *a_scale, const float *a_shift, void *stream);
 /* One reading of that clock into *dst, issued as a (capturable) 1-thread kernel on `stream`: a time stamp inside a
  * replayed graph (debugging aid: CPFN_STEP_STAMPS=1). */
 CPFN_API int cpfn_stamp(unsigned long long *dst, void *stream);

@@ -391,3 +391,32 @@ def test_small_layer_backward_fusion(name, P, cin, widths, pool_k, stats_fused, 
     assert same(gxa, gxb)
     for a, b in zip(gra, grb):
         assert (a is None and b is None) or same(a, b)
+
+
+@pytest.mark.parametrize("P,K,N", [(131072, 128, 128), (40000 + 77, 128, 128), (32768, 128, 128)])
+@pytest.mark.parametrize("atr", [False, True])
+def test_forward_row_streaming_kernel(P, K, N, atr):
+    """cpfn_mlp_gemm_rows (CPFN_FWD_ROWS=1; off by default, see fused_mlp.FWD_ROWS) against cpfn_mlp_gemm with statistics:
+    the same Y bit for bit, the same statistics up to the order of the per-workgroup partial sums."""
+    from cpfn_amd import fused_mlp, lib as _l
+    g = torch.Generator().manual_seed(P + K)
+    A = torch.randn(P, K, generator=g).to(dev()).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(dev()).to(torch.bfloat16)
+    sc = (torch.rand(K, generator=g) + 0.5).to(dev()) if atr else None
+    sh = (torch.randn(K, generator=g) * 0.2).to(dev()) if atr else None
+    res = {}
+    for rows in (True, False):
+        fused_mlp.FWD_ROWS = rows
+        try:
+            _l.byte_census(True)
+            Y, part, nblk = fused_mlp.gemm(A, W, stats=True, a_scale=sc, a_shift=sh)
+            census = _l.byte_census(False)
+        finally:
+            fused_mlp.FWD_ROWS = False
+        assert ("cpfn_mlp_gemm_rows" in census) == rows
+        res[rows] = (Y, part[:nblk].double().sum(0))
+    assert torch.equal(res[True][0], res[False][0])
+    assert _rel(res[True][1], res[False][1]) < 1e-6
+    yf = res[True][0].float()
+    ref = torch.stack([yf.double().sum(0), (yf.double() ** 2).sum(0)])
+    assert _rel(res[True][1], ref) < 1e-5
