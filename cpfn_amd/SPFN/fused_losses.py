@@ -31,6 +31,9 @@ PARALLEL_BRANCHES = os.environ.get("CPFN_PARALLEL_BRANCHES", "0") == "1"
 # CPFN_SEG_FUSED=0: the label-segmented membership sums as their own pass over W (cpfn_seg_stats_fwd) instead of riding
 # on the heads post-processing launch
 SEG_FUSED = os.environ.get("CPFN_SEG_FUSED", "1") != "0"
+# ... and their adjoint added to gW inside cpfn_head_post_bwd (CPFN_SEG_BWD_FUSED=0: cpfn_seg_stats_bwd + the framework's
+# gradient-accumulation add as their own launches)
+SEG_BWD_FUSED = SEG_FUSED and os.environ.get("CPFN_SEG_BWD_FUSED", "1") != "0"
 
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
                 ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
@@ -62,15 +65,21 @@ class HeadPost(torch.autograd.Function):
                                           _ptr(stats), _ptr(seg_ws), _ptr(S), _stream()), "cpfn_head_post_fwd")
         _l.add_bytes("cpfn_head_post_fwd", 4 * B * N * (C + 3 + 3 + K) + 8 * B * N + 8 * B * K)
         ctx.save_for_backward(Yc, Xg, Ig, Tg, W, stats)
+        ctx.set_materialize_grads(False)          # (an unused output costs no zero-fill launch)
         if with_seg:
+            # SEG_BWD_FUSED: S is a DIFFERENTIABLE output of this node — its adjoint (what SegStats.backward computes,
+            # cpfn_seg_stats_bwd) is added to gW inside cpfn_head_post_bwd: one launch instead of three (the adjoint, the
+            # framework's accumulation add of the two [B,N,K] gradients of W, the heads' backward)
             if S is None:
                 S = torch.empty(0, device=dev)
-            ctx.mark_non_differentiable(S)
+                ctx.mark_non_differentiable(S)
+            elif not SEG_BWD_FUSED:
+                ctx.mark_non_differentiable(S)
             return Xn, W, stats[:, 0], stats[:, 1], S
         return Xn, W, stats[:, 0], stats[:, 1]
 
     @staticmethod
-    def backward(ctx, gXn, gW, gnl, gtl, _gS=None):
+    def backward(ctx, gXn, gW, gnl, gtl, gS=None):
         Yc, Xg, Ig, Tg, W, stats = ctx.saved_tensors
         B, N, C = Yc.shape
         dev = Yc.device
@@ -85,11 +94,12 @@ class HeadPost(torch.autograd.Function):
                               gtl if gtl is not None else torch.zeros(B, device=dev)], dim=1).contiguous().float()
         gXn = None if gXn is None else gXn.contiguous().float()
         gW = None if gW is None else gW.contiguous().float()
+        gS = None if gS is None else gS.contiguous().float()
         gY = torch.empty_like(Yc)
         with torch.cuda.device(dev):
             _l.check(_l.lib().cpfn_head_post_bwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), _ptr(W), _ptr(stats), _ptr(gXn),
-                                                 _ptr(gW), _ptr(gl), 1 if planar else 0, B, N, C - 7, _ptr(gY), _stream()),
-                     "cpfn_head_post_bwd")
+                                                 _ptr(gW), _ptr(gl), 1 if planar else 0, B, N, C - 7, _ptr(gY), _ptr(gS),
+                                                 _stream()), "cpfn_head_post_bwd")
         _l.add_bytes("cpfn_head_post_bwd", 4 * B * N * (2 * C + 3 + (C - 7) + (3 if gXn is not None else 0) + (C - 7 if gW is not None else 0))
                      + 8 * B * N)
         return gY, None, None, None, None
@@ -149,7 +159,7 @@ class ResidueLoss(torch.autograd.Function):
     def backward(ctx, g):
         dout, mc, tc = ctx.saved_tensors
         B, K, _ = dout.shape
-        gp = torch.zeros(B, K, 22, dtype=torch.float32, device=dout.device)
+        gp = torch.empty(B, K, 22, dtype=torch.float32, device=dout.device)       # (every element written by the kernel)
         ids = (ctypes.c_int * 4)(*ctx.type_ids)
         with torch.cuda.device(dout.device):
             _l.check(_l.lib().cpfn_residue_bwd(_ptr(g.contiguous().float()), _ptr(dout), _ptr(mc), _ptr(tc), B, K, ids,
@@ -273,6 +283,8 @@ def pre_match(Y, batch):
     """Everything before the host-side assignment: unit normals, memberships, per-cloud normal /
     type losses and the label-segmented sums S.  (Capturable: no host synchronisation.)"""
     Xn, W, nl, tl, S_pre = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"], True)
+    if SEG_BWD_FUSED and S_pre.numel() == W.shape[0] * (W.shape[2] + 2) * W.shape[2]:
+        return Xn, W, nl, tl, S_pre                   # computed AND differentiated by the heads post-processing node
     return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"], S_pre)
 
 
@@ -293,7 +305,8 @@ def match_and_fit(P, Y, batch, multipliers):
         side = _branch_streams[key] = torch.cuda.Stream(device=dev)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        S = SegStats.apply(W, batch["I_gt"], S_pre)
+        S = S_pre if (SEG_BWD_FUSED and S_pre.numel() == W.shape[0] * (W.shape[2] + 2) * W.shape[2]) else \
+            SegStats.apply(W, batch["I_gt"], S_pre)
         n_gt = count_gt(batch["I_gt"])
         match = hungarian_device(S, n_gt)
     W.record_stream(side)                       # produced here, read on the side stream

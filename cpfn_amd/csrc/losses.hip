@@ -154,9 +154,15 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
     const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
     const long long *__restrict__ Tgt, const float *__restrict__ Wsm, const float *__restrict__ stats,
     const float *__restrict__ gXn, const float *__restrict__ gW, const float *__restrict__ gloss, int gl_planar, int N,
-    int K, float *__restrict__ gY) {
+    int K, float *__restrict__ gY, const float *__restrict__ gS) {
+  // gS (optional) [B, K+2, K]: gradient w.r.t. the label-segmented membership sums the forward launch produced; its
+  // adjoint dW[n,k] = gS[K,k] + gS[label(n),k] (seg_stats_bwd_kernel) is added to gW here, so that neither that kernel
+  // nor the framework's gradient-accumulation add of the two [B,N,K] tensors is launched.
   __shared__ float s_row[LP_THREADS * LP_LD];
   __shared__ float s_x[LP_THREADS * 3], s_gx[LP_THREADS * 3];
+  __shared__ float s_gs[(MAXK + 1) * MAXK];
+  if (gS)
+    for (int e = threadIdx.x; e < (K + 1) * K; e += LP_THREADS) s_gs[e] = gS[(size_t)blockIdx.y * (K + 2) * K + e];
   const int b = blockIdx.y, t = threadIdx.x, C = 7 + K;
   const int n0 = blockIdx.x * LP_THREADS;
   const int rows = min(LP_THREADS, N - n0);
@@ -170,14 +176,16 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
   if (live)
     for (int j = 0; j < 7; ++j) y7[j] = s_row[t * LP_LD + j];
   __syncthreads();
-  if (gW) {                                              // soft-max adjoint needs W and gW rows
+  if (gW || gS) {                                        // soft-max adjoint needs W and gW rows
     lp_stage_in(s_row, LP_LD, Wsm + p0 * K, rows, K, t);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) sm[k] = (live && k < K) ? s_row[t * LP_LD + k] : 0.f;
     __syncthreads();
-    lp_stage_in(s_row, LP_LD, gW + p0 * K, rows, K, t);
-    __syncthreads();
+    if (gW) {
+      lp_stage_in(s_row, LP_LD, gW + p0 * K, rows, K, t);
+      __syncthreads();
+    }
   }
   if (live) {
     // normals
@@ -214,10 +222,20 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
   }
   // memberships: soft-max adjoint, written over the gW row in place (columns shift by 7)
   float om[MAXK];
-  if (gW) {
+  if (gW || gS) {
     float dot = 0.f;
+    const long long labw = live ? Igt[p0 + t] : -1;
+    const bool hasl = labw >= 0 && labw < K;
+    const float *gl = s_gs + (hasl ? (int)labw : 0) * K, *ga = s_gs + K * K;
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) { om[k] = (live && k < K) ? s_row[t * LP_LD + k] : 0.f; dot = fmaf(om[k], sm[k], dot); }
+    for (int k = 0; k < MAXK; ++k) {
+      om[k] = (gW && live && k < K) ? s_row[t * LP_LD + k] : 0.f;
+      if (gS && live && k < K) {
+        const float dseg = ga[k] + (hasl ? gl[k] : 0.f);       // (seg_stats_bwd_kernel's value, then the accumulation add)
+        om[k] = gW ? om[k] + dseg : dseg;
+      }
+      dot = fmaf(om[k], sm[k], dot);
+    }
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) om[k] = sm[k] * (om[k] - dot);
   } else {
@@ -445,26 +463,33 @@ __global__ __launch_bounds__(128) void residue_fwd_kernel(const float *__restric
   }
 }
 
-// gparams[b][match][slots] += g_res·d residue + g_par·d axis-loss   (gparams zero-filled by the caller)
+// gparams[b][m][slot] = sum over the GT instances k assigned to prediction m (ascending k) of
+//   g_res . d residue / d slot + g_par . d axis-loss / d slot.
+// One lane per (b, m, slot): every element of gparams is WRITTEN (zeros where nothing arrives), so the caller needs no
+// zero fill, and the sum has a fixed order (was: one lane per (b, k) scattering with float atomics into a zeroed tensor).
 __global__ void residue_bwd_kernel(const float *__restrict__ gout, const float *__restrict__ dout,
                                    const long long *__restrict__ match, const long long *__restrict__ Tgt, int K,
                                    int BK, int tid_plane, int tid_sphere, int tid_cyl, int tid_cone,
                                    float *__restrict__ gparams) {
-  const int bk = blockIdx.x * blockDim.x + threadIdx.x;
-  if (bk >= BK) return;
-  const int b = bk / K;
-  const long long m = match[bk], ty = Tgt[bk];
-  const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
-  float *gp = gparams + ((size_t)b * K + m) * 22;
-  const float gr = gout[bk * 2], ga = gout[bk * 2 + 1];
-  const int off = kind == 0 ? 0 : (kind == 1 ? 4 : (kind == 2 ? 8 : 15));
-  const int nq = kind == 0 ? 4 : (kind == 1 ? 4 : 7);
-  if (gr != 0.f)
-    for (int i = 0; i < nq; ++i) atomicAdd(gp + off + i, gr * dout[bk * 10 + i]);
-  if (ga != 0.f && kind != 1) {
-    const int ao = kind == 0 ? 0 : (kind == 2 ? 8 : 18);
-    for (int i = 0; i < 3; ++i) atomicAdd(gp + ao + i, ga * dout[bk * 10 + 7 + i]);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= BK * 22) return;
+  const int slot = e % 22, bm = e / 22, b = bm / K, m = bm - b * K;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int bk = b * K + k;
+    if (match[bk] != m) continue;
+    const long long ty = Tgt[bk];
+    const int kind = ty == tid_plane ? 0 : (ty == tid_sphere ? 1 : (ty == tid_cyl ? 2 : 3));
+    const float gr = gout[bk * 2], ga = gout[bk * 2 + 1];
+    const int off = kind == 0 ? 0 : (kind == 1 ? 4 : (kind == 2 ? 8 : 15));
+    const int nq = kind == 0 ? 4 : (kind == 1 ? 4 : 7);
+    if (gr != 0.f && slot >= off && slot < off + nq) acc += gr * dout[bk * 10 + slot - off];
+    if (ga != 0.f && kind != 1) {
+      const int ao = kind == 0 ? 0 : (kind == 2 ? 8 : 18);
+      if (slot >= ao && slot < ao + 3) acc += ga * dout[bk * 10 + 7 + slot - ao];
+    }
   }
+  gparams[e] = acc;
 }
 
 inline int loss_chunks(int B, int N, int *ppb) {
@@ -786,11 +811,12 @@ extern "C" int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_
 
 extern "C" int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                   const float *Wsm, const float *stats, const float *gXn, const float *gW,
-                                  const float *gloss, int gloss_planar, int B, int N, int K, float *gY, void *stream) {
+                                  const float *gloss, int gloss_planar, int B, int N, int K, float *gY, const float *gS,
+                                  void *stream) {
   if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !Y || !Xgt || !Igt || !Tgt || !Wsm || !stats || !gloss || !gY)
     return CPFN_EINVAL;
   head_post_bwd_kernel<<<dim3(cpfn_cdiv(N, LP_THREADS), B), LP_THREADS, 0, (hipStream_t)stream>>>(
-      Y, Xgt, (const long long *)Igt, (const long long *)Tgt, Wsm, stats, gXn, gW, gloss, gloss_planar, N, K, gY);
+      Y, Xgt, (const long long *)Igt, (const long long *)Tgt, Wsm, stats, gXn, gW, gloss, gloss_planar, N, K, gY, gS);
   return cpfn_launch_status();
 }
 
@@ -837,7 +863,7 @@ extern "C" int cpfn_residue_fwd(const float *params, const int64_t *match, const
 extern "C" int cpfn_residue_bwd(const float *gout, const float *dout, const int64_t *match, const int64_t *Tgt, int B,
                                 int K, const int *type_ids, float *gparams, void *stream) {
   if (B <= 0 || K <= 0 || !gout || !dout || !match || !Tgt || !type_ids || !gparams) return CPFN_EINVAL;
-  residue_bwd_kernel<<<cpfn_cdiv(B * K, 64), 64, 0, (hipStream_t)stream>>>(gout, dout, (const long long *)match,
+  residue_bwd_kernel<<<cpfn_cdiv(B * K * 22, 256), 256, 0, (hipStream_t)stream>>>(gout, dout, (const long long *)match,
                                                                           (const long long *)Tgt, K, B * K, type_ids[0],
                                                                           type_ids[1], type_ids[2], type_ids[3], gparams);
   return cpfn_launch_status();

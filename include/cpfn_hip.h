@@ -439,10 +439,11 @@ CPFN_API int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t 
                                 float *seg_workspace, float *S, void *stream);
 /* Adjoint: gXn[B,N,3], gW[B,N,K] (either may be NULL), gloss = dL/d(normal, type loss) -> gY.
  * gloss_planar = 0: gloss is [B,2]; 1: [2,B] (the two gradient vectors one after the other, as cpfn_loss_tail leaves
- * them: no interleaving copy). */
+ * them: no interleaving copy).  gS (optional) [B,K+2,K] = gradient w.r.t. the segmented sums cpfn_head_post_fwd
+ * left in S: its adjoint (cpfn_seg_stats_bwd's dW) is added to gW inside this launch. */
 CPFN_API int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                 const float *Wsm, const float *stats, const float *gXn, const float *gW,
-                                const float *gloss, int gloss_planar, int B, int N, int K, float *gY, void *stream);
+                                const float *gloss, int gloss_planar, int B, int N, int K, float *gY, const float *gS, void *stream);
 /* Label-segmented membership sums, shared by the Hungarian cost matrix and the relaxed-IoU loss
  * (SPFN/losses_implementation.py:19-24, 77-90):  S[B,K+2,K]: rows l<K = sum of W rows with label l,
  * row K = column sums of W, row K+1 = number of points per label.  fwd: any K <= 1024 (K > 32: one 32 x 32 tile
@@ -462,7 +463,8 @@ CPFN_API int cpfn_seg_stats_bwd(const float *gS, const int64_t *Igt, int B, int 
 CPFN_API int cpfn_residue_fwd(const float *params, const int64_t *match, const int64_t *Tgt,
                               const float *pts, const float *gt_axes, int B, int K, int NP,
                               const int *type_ids, float *out, float *dout, void *stream);
-/* gparams[B,K,22] (zero-filled by the caller) += gout[B,K,2] . dout, routed through match. */
+/* gparams[B,K,22] = gout[B,K,2] . dout, routed through match (every element written: no zero fill needed; the GT
+ * instances assigned to one prediction are summed in ascending order). */
 CPFN_API int cpfn_residue_bwd(const float *gout, const float *dout, const int64_t *match,
                               const int64_t *Tgt, int B, int K, const int *type_ids, float *gparams,
                               void *stream);
