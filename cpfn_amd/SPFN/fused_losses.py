@@ -60,9 +60,17 @@ class HeadPost(torch.autograd.Function):
         if with_seg and SEG_FUSED and K <= 31:
             seg_ws = torch.empty(B * chunks * (K + 2) * K, dtype=torch.float32, device=dev)
             S = torch.empty(B, K + 2, K, dtype=torch.float32, device=dev)
+        # ... and so does the number of GT instances per cloud (count_gt picks it up: no cpfn_count_labels launch)
+        lab_ws = n_gt = None
+        if with_seg:
+            lab_ws = torch.empty(B * chunks, dtype=torch.int32, device=dev)
+            n_gt = torch.empty(B, dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
             _l.check(h.cpfn_head_post_fwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), B, N, K, _ptr(Xn), _ptr(W), _ptr(ws),
-                                          _ptr(stats), _ptr(seg_ws), _ptr(S), _stream()), "cpfn_head_post_fwd")
+                                          _ptr(stats), _ptr(seg_ws), _ptr(S), _ptr(lab_ws), _ptr(n_gt), _stream()),
+                     "cpfn_head_post_fwd")
+        global _n_gt_of_last_heads_pass
+        _n_gt_of_last_heads_pass = None if n_gt is None else (I_gt.data_ptr(), I_gt._version, tuple(I_gt.shape), n_gt)
         _l.add_bytes("cpfn_head_post_fwd", 4 * B * N * (C + 3 + 3 + K) + 8 * B * N + 8 * B * K)
         ctx.save_for_backward(Yc, Xg, Ig, Tg, W, stats)
         ctx.set_materialize_grads(False)          # (an unused output costs no zero-fill launch)
@@ -220,10 +228,18 @@ class unit_loss_gradient:
         return False
 
 
+_n_gt_of_last_heads_pass = None      # (labels' data_ptr, version, shape, n_gt) left by the last HeadPost.forward
+
+
 def count_gt(I_gt):
-    """[B] int64: number of GT instances per cloud (max label + 1; reference lines 603-606)."""
+    """[B] int64: number of GT instances per cloud (max label + 1; reference lines 603-606).  When the heads
+    post-processing launch has just counted them for the same label tensor, that result is returned."""
     if not I_gt.is_cuda:
         return I_gt.max(dim=1)[0] + 1
+    global _n_gt_of_last_heads_pass
+    c, _n_gt_of_last_heads_pass = _n_gt_of_last_heads_pass, None       # one-shot: a later call counts again
+    if c is not None and c[0] == I_gt.data_ptr() and c[1] == I_gt._version and c[2] == tuple(I_gt.shape):
+        return c[3]
     Ig = I_gt.contiguous()
     n_gt = torch.empty(Ig.shape[0], dtype=torch.int64, device=Ig.device)
     with torch.cuda.device(Ig.device):

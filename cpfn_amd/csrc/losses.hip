@@ -33,10 +33,12 @@ constexpr int LP_LD = 7 + MAXK;   // LDS row stride for the [*, 7+K] rows: 39 fl
 __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
     const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
     const long long *__restrict__ Tgt, int N, int K, float *__restrict__ Xn, float *__restrict__ Wsm,
-    float *__restrict__ partial, float *__restrict__ seg_partial /* optional: [B][chunks][(K+2)*K] */) {
+    float *__restrict__ partial, float *__restrict__ seg_partial /* optional: [B][chunks][(K+2)*K] */,
+    int *__restrict__ lab_partial /* optional: [B][chunks] largest label of the chunk (-1: none) */) {
   __shared__ float s_row[LP_THREADS * LP_LD];
   __shared__ float s_x[LP_THREADS * 3];
   __shared__ float s_red[LP_THREADS / 64][3];
+  __shared__ int s_lmax[LP_THREADS / 64];
   __shared__ float s_seg[LP_THREADS / 64][MAXK][MAXK + 1];     // per-wave segmented sums (seg_partial only)
   __shared__ int s_cnt[MAXK];
   const int b = blockIdx.y, t = threadIdx.x, C = 7 + K;
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
   for (int msk = 32; msk >= 1; msk >>= 1) {
     l_n += __shfl_xor(l_n, msk, 64); l_t += __shfl_xor(l_t, msk, 64); l_c += __shfl_xor(l_c, msk, 64);
   }
-  if ((t & 63) == 0) { s_red[t >> 6][0] = l_n; s_red[t >> 6][1] = l_t; s_red[t >> 6][2] = l_c; }
+  int lmax = seg_lab < 0 ? -1 : seg_lab;
+  for (int msk = 32; msk >= 1; msk >>= 1) lmax = max(lmax, __shfl_xor(lmax, msk, 64));
+  if ((t & 63) == 0) { s_red[t >> 6][0] = l_n; s_red[t >> 6][1] = l_t; s_red[t >> 6][2] = l_c; s_lmax[t >> 6] = lmax; }
   if (seg_partial && seg_lab >= 0 && seg_lab < MAXK) atomicAdd(&s_cnt[seg_lab], 1);   // integer: exact, order-free
   __syncthreads();
   if (seg_partial) {
@@ -129,23 +133,45 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_fwd_kernel(
     for (int w = 0; w < LP_THREADS / 64; ++w) s += s_red[w][t];
     partial[((size_t)b * gridDim.x + blockIdx.x) * 3 + t] = s;
   }
+  if (lab_partial && t == 0) {
+    int m = s_lmax[0];
+    for (int w = 1; w < LP_THREADS / 64; ++w) m = max(m, s_lmax[w]);
+    lab_partial[(size_t)b * gridDim.x + blockIdx.x] = m;
+  }
 }
 
-// out[b] = (normal_loss, type_loss, count): fixed-order sum over chunks
-__global__ void head_post_reduce_kernel(const float *__restrict__ partial, int chunks, int N, int B,
-                                        float *__restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// out[b] = (normal_loss, type_loss, count): fixed-order sum over chunks — and in the same launch the chunk sums of the
+// segmented membership sums (chunk_sum_f32_kernel's job) and the
+// number of GT instances per cloud (largest label + 1: cpfn_count_labels' job): three [B]- / [B,K+2,K]-sized launches
+// after the heads pass became one.  Lanes e < total: S[e]; lanes total .. total + B - 1: one cloud's losses and n_gt.
+__global__ void head_post_finish_kernel(const float *__restrict__ partial, const float *__restrict__ seg_partial,
+                                        const int *__restrict__ lab_partial, int chunks, int N, int B, int per_b,
+                                        long long total, float *__restrict__ out, float *__restrict__ S,
+                                        long long *__restrict__ n_gt) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total) {
+    const long long b = e / per_b, r = e % per_b;
+    float s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < chunks; ++c) s += seg_partial[((size_t)b * chunks + c) * per_b + r];
+    S[e] = s;
+    return;
+  }
+  const int b = (int)(e - total);
   if (b >= B) return;
   double a = 0, c = 0, d = 0;
+  int lm = -1;
 #pragma unroll 8
   for (int i = 0; i < chunks; ++i) {
     a += partial[((size_t)b * chunks + i) * 3];
     c += partial[((size_t)b * chunks + i) * 3 + 1];
     d += partial[((size_t)b * chunks + i) * 3 + 2];
+    if (lab_partial) lm = max(lm, lab_partial[(size_t)b * chunks + i]);
   }
   out[b * 3] = (float)(a / N);
   out[b * 3 + 1] = (float)(c / d);   // 0/0 -> NaN for a cloud with no labelled point, like the reference
   out[b * 3 + 2] = (float)d;
+  if (n_gt) n_gt[b] = (long long)lm + 1;
 }
 
 // gY[P,7+K] from: gXn[P,3] (may be null), gW[P,K] (may be null), gloss[B,2] = dL/d(normal_loss, type_loss)
@@ -793,19 +819,18 @@ extern "C" int cpfn_head_post_chunks(int N) { return cpfn_cdiv(N, LP_THREADS); }
 
 extern "C" int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt, int B,
                                   int N, int K, float *Xn, float *Wsm, float *workspace, float *stats,
-                                  float *seg_workspace, float *S, void *stream) {
+                                  float *seg_workspace, float *S, int *lab_workspace, int64_t *n_gt, void *stream) {
   if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !Y || !Xgt || !Igt || !Tgt || !Xn || !Wsm || !workspace || !stats)
     return CPFN_EINVAL;
   if ((seg_workspace != nullptr) != (S != nullptr) || (S && K >= MAXK)) return CPFN_EINVAL;   // the ones row needs K < 32
+  if ((lab_workspace != nullptr) != (n_gt != nullptr)) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int chunks = cpfn_cdiv(N, LP_THREADS);
   head_post_fwd_kernel<<<dim3(chunks, B), LP_THREADS, 0, st>>>(Y, Xgt, (const long long *)Igt, (const long long *)Tgt, N, K,
-                                                               Xn, Wsm, workspace, seg_workspace);
-  head_post_reduce_kernel<<<cpfn_cdiv(B, 64), 64, 0, st>>>(workspace, chunks, N, B, stats);
-  if (S) {
-    const long long total = (long long)B * (K + 2) * K;
-    chunk_sum_f32_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(seg_workspace, chunks, (K + 2) * K, total, S);
-  }
+                                                               Xn, Wsm, workspace, seg_workspace, lab_workspace);
+  const long long total = S ? (long long)B * (K + 2) * K : 0;
+  head_post_finish_kernel<<<cpfn_cdiv(total + B, 256), 256, 0, st>>>(workspace, seg_workspace, lab_workspace, chunks, N, B,
+                                                                    (K + 2) * K, total, stats, S, (long long *)n_gt);
   return cpfn_launch_status();
 }
 

@@ -432,11 +432,13 @@ CPFN_API int cpfn_smallk_wgrad_apply(const void *Gz, const void *Y, const float 
  * workspace: B * cpfn_head_post_chunks(N) * 3 floats.
  * seg_workspace + S (optional, both or neither; K <= 31): the same launch also leaves the label-segmented sums
  * S[B,K+2,K] of cpfn_seg_stats_fwd, taken from the soft-max rows while they are on chip (fp32 MFMA contraction
- * one-hot(label) x memberships); seg_workspace: B * cpfn_head_post_chunks(N) * (K+2)*K floats. */
+ * one-hot(label) x memberships); seg_workspace: B * cpfn_head_post_chunks(N) * (K+2)*K floats.
+ * lab_workspace (B * chunks ints) + n_gt [B] (optional, both or neither): the number of GT instances per cloud (largest
+ * label + 1, what cpfn_count_labels computes) from the same pass. */
 CPFN_API int cpfn_head_post_chunks(int N);
 CPFN_API int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                 int B, int N, int K, float *Xn, float *Wsm, float *workspace, float *stats,
-                                float *seg_workspace, float *S, void *stream);
+                                float *seg_workspace, float *S, int *lab_workspace, int64_t *n_gt, void *stream);
 /* Adjoint: gXn[B,N,3], gW[B,N,K] (either may be NULL), gloss = dL/d(normal, type loss) -> gY.
  * gloss_planar = 0: gloss is [B,2]; 1: [2,B] (the two gradient vectors one after the other, as cpfn_loss_tail leaves
  * them: no interleaving copy).  gS (optional) [B,K+2,K] = gradient w.r.t. the segmented sums cpfn_head_post_fwd
