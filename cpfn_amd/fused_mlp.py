@@ -395,6 +395,11 @@ class _FusedStack(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        """Per layer, top down: (1) pass 1 of the BatchNorm backward (sum g_z, sum g_z y) — its own launch only where the
+        data gradient of the layer above did not already take it — and the [C]-sized finalize; (2) the apply pass
+        g_y = c0 [z > 0] g + c1 y + c2 — its own launch only where no consumer forms g_y on its operand loads; (3) weight
+        gradient + data gradient by one of three routes (`_plan`): the one-pass kernel (>= 32768 rows, five shapes), the
+        small-layer pair (<= 16384 rows), or cpfn_mlp_wgrad + cpfn_mlp_gemm."""
         h = _l.lib()
         cfg = ctx.cfg
         layers = cfg["layers"]
@@ -406,187 +411,179 @@ class _FusedStack(torch.autograd.Function):
         grads = [None] * (3 * len(layers))
         g = g.contiguous().to(BF16)
         gx = None
-        fused_part = None
+        fused_part = None          # (partials, rows): pass 1 of THIS layer, left by the data gradient of the layer above
+        a_ptrs = lambda a_ss: (None, None) if a_ss is None else (_ptr(a_ss[0]), _ptr(a_ss[1]))
         with torch.cuda.device(dev):
             for li in range(len(layers) - 1, -1, -1):
                 L = layers[li]
                 a_in, a_ss, Y, st, Wb, arg, yarg = saved[li]
                 N = L.cout
+                top = li == len(layers) - 1
+                xyz_layer = li == 0 and first_fp32            # fp32 xyz input (sa1's first layer): no data gradient
+                dseed = ctx.drop_seed if (top and arg is None) else None          # fused dropout on the stack's output
+                dp = float(cfg["dropout"][0]) if dseed is not None else 0.0
+                need_dgrad = (li > 0 or ctx.x_needs_grad) and not xyz_layer
+                below_ok = li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None   # may take pass 1 of layer li-1
+                route, fold_apply, fold_pool = _plan(h, P, N, a_in, pool_k if arg is not None else 0, xyz_layer, need_dgrad,
+                                                     dseed is not None)
                 dgb = torch.empty(2, N, dtype=torch.float32, device=dev)
                 coef = torch.empty(3, N, dtype=torch.float32, device=dev)
-                gamma = L.gamma.detach()
-                # dense 128 -> 128 layer with a data gradient to produce: one kernel for weight gradient + data gradient
-                need_dgrad = li > 0 or ctx.x_needs_grad
-                one_pass = (FUSED_BWD and need_dgrad and not (li == 0 and first_fp32) and a_in.stride(0) == a_in.shape[1]
-                            and bool(h.cpfn_mlp_bwd_fused_ok(P, N, a_in.shape[1])))
-                apply_in_pass, pool_in_pass = False, False
-                # small dense layer (P <= 16384 rows): the apply pass folded into BOTH of its consumers (64 x 64-tile weight
-                # gradient, small-P data gradient), the reduction of the layer below taken by that data gradient
-                small_pass = (SMALL_BWD_FUSED and not one_pass and arg is None and not (li == 0 and first_fp32)
-                              and bool(h.cpfn_mlp_wgrad_apply_ok(P, N, a_in.shape[1]))
-                              and (not need_dgrad or bool(h.cpfn_mlp_dgrad_small_ok(P, N, a_in.shape[1]))))
-                small_apply = False
+                Gy = None
+                # ---- (1) reduction + finalize
                 if arg is not None:
-                    G = P // pool_k
-                    # only the arg-max row of each group carries gradient: the reduction is the dense one over
+                    # max-pooled: only the arg-max row of each group carries gradient — the reduction is the dense one over
                     # the [G, N] pooled gradient and the pre-BN values at the arg-max rows
+                    G = P // pool_k
                     nblk = h.cpfn_bn_bwd_blocks(G)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                     _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, None, _ptr(part),
                                               None, 0.0, _stream()), "cpfn_bn_relu_bwd")
                     _l.add_bytes("cpfn_bn_relu_bwd", 4 * G * N + 8 * nblk * N)
-                    _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
-                                                  1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
-                           "cpfn_bn_bwd_finalize")
-                    _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    step_rows = 32 if a_in.shape[1] == 128 else 64        # rows per step of the one-pass kernel for this shape
-                    if one_pass and FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255 and a_in.shape[1] != 192:
-                        pool_in_pass = True       # g_y is formed from (pooled gradient, arg-max, y) on the one-pass kernel's chunks
-                        Gy = None
-                    else:
-                        Gy = torch.empty(P, N, dtype=BF16, device=dev)
-                        _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
-                                                        _ptr(coef), G, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
-                        _l.add_bytes("cpfn_bn_pool_bwd_apply", 4 * P * N + 5 * G * N)
+                elif fused_part is not None:
+                    part, nblk = fused_part
+                    fused_part = None
                 else:
                     nblk = h.cpfn_bn_bwd_blocks(P)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
-                    Gy = torch.empty(P, N, dtype=BF16, device=dev)
-                    # BN_NOSTORE (default): the reduction pass does not store the masked gradient; the apply pass
-                    # recomputes the ReLU mask from y.  3.57 vs 3.65 ms/step (same box, A/B/A/B); CPFN_BN_NOSTORE=0
-                    # selects the two-pass-over-g_z variant.
-                    nostore = BN_NOSTORE
-                    # fused dropout: the gradient of the stack's output is masked on load (top layer only)
-                    dseed = ctx.drop_seed if li == len(layers) - 1 else None
-                    dp = float(cfg["dropout"][0]) if dseed is not None else 0.0
-                    if fused_part is not None:      # pass 1 rode on the data-gradient GEMM of the layer above
-                        part, nblk = fused_part
-                        fused_part = None
-                    else:
-                        _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None if nostore else _ptr(Gy),
-                                                  _ptr(part), _ptr(dseed), dp, _stream()), "cpfn_bn_relu_bwd")
-                        _l.add_bytes("cpfn_bn_relu_bwd", (4 if nostore else 6) * P * N + 8 * nblk * N)
-                    _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(gamma), _ptr(st[2]), _ptr(st[3]),
-                                                  1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
-                           "cpfn_bn_bwd_finalize")
-                    _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    small_pass = small_pass and nostore and dseed is None
-                    small_apply = small_pass and SMALL_BWD_APPLY and FUSED_BWD_APPLY
-                    if one_pass and a_in.shape[1] == 192 and dseed is not None:
-                        one_pass = False            # (the 192-wide shape has no dropout variant)
-                    if nostore and FUSED_BWD_APPLY and (one_pass or small_apply or (li == 0 and first_fp32 and dseed is None)):
-                        apply_in_pass = True        # g_y = c0 [z > 0] g + c1 y + c2 is formed on the consumer's staged chunks
-                    elif nostore:
-                        _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
-                                                   _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
-                        _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
-                    else:       # (the stored g_z already carries the dropout mask)
-                        _check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), None, None, P, N, _ptr(Gy), None, 0.0, _stream()),
-                               "cpfn_bn_bwd_apply")
-                        _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
+                    if not BN_NOSTORE:              # (CPFN_BN_NOSTORE=0: pass 1 also stores the masked gradient)
+                        Gy = torch.empty(P, N, dtype=BF16, device=dev)
+                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy), _ptr(part), _ptr(dseed), dp,
+                                              _stream()), "cpfn_bn_relu_bwd")
+                    _l.add_bytes("cpfn_bn_relu_bwd", (4 if BN_NOSTORE else 6) * P * N + 8 * nblk * N)
+                _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
+                                              1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
+                       "cpfn_bn_bwd_finalize")
+                _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                 grads[3 * li + 1] = dgb[0]
                 grads[3 * li + 2] = dgb[1]
+                # ---- (2) apply pass, unless a consumer forms g_y itself
+                if arg is not None:
+                    if not fold_pool:
+                        Gy = torch.empty(P, N, dtype=BF16, device=dev)
+                        _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
+                                                        _ptr(coef), P // pool_k, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
+                        _l.add_bytes("cpfn_bn_pool_bwd_apply", 4 * P * N + 5 * (P // pool_k) * N)
+                elif not fold_apply:
+                    if Gy is None:                  # BN_NOSTORE: the mask is recomputed from y, dropout re-applied from its seed
+                        Gy = torch.empty(P, N, dtype=BF16, device=dev)
+                        _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
+                                                   _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
+                    else:                           # (the stored g_z already carries mask and dropout)
+                        _check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), None, None, P, N, _ptr(Gy), None, 0.0, _stream()),
+                               "cpfn_bn_bwd_apply")
+                    _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
+                folded = fold_apply or fold_pool                 # the consumers read (g, Y, coef) instead of Gy
+                # ---- (3) weight gradient (+ data gradient)
                 wshape = L.weight.shape
-                if li == 0 and first_fp32:
+                if xyz_layer:
                     KS = a_in.shape[1]
                     nb = h.cpfn_bn_bwd_blocks(P)
                     ws = torch.empty(nb * N * KS, dtype=torch.float32, device=dev)
                     dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
                     # (its 1024 x 192-float partials are finished right here by the 64-subset reduce: in the batched
                     #  reduction three workgroups would walk 256 splits each — a 20 us tail, measured)
-                    if apply_in_pass:
+                    if folded:
                         _check(h.cpfn_smallk_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in), KS, P, N,
                                                          _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad_apply")
-                        _l.add_bytes("cpfn_smallk_wgrad_apply", 4 * P * N + 4 * P * KS + 8 * nb * N * KS)
                     else:
                         _check(h.cpfn_smallk_wgrad(_ptr(Gy), _ptr(a_in), KS, P, N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad")
-                        _l.add_bytes("cpfn_smallk_wgrad", 2 * P * N + 4 * P * KS + 8 * nb * N * KS)
+                    _l.add_bytes("cpfn_smallk_wgrad_apply" if folded else "cpfn_smallk_wgrad",
+                                 (4 if folded else 2) * P * N + 4 * P * KS + 8 * nb * N * KS)
                     grads[0] = dW.reshape(wshape)
+                    continue
+                Kp = a_in.shape[1]
+                splits = h.cpfn_mlp_wgrad_splits(P, N, Kp)
+                ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
+                asc, ash = a_ptrs(a_ss)
+                g_new = None
+                if route == "one_pass":
+                    # weight gradient, data gradient, (folded) apply pass and pass 1 of the layer below from ONE read of the
+                    # gradient (mlp_bwd_fused_kernel)
+                    below = below_ok and Kp != 192
+                    g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
+                    Yp, stp = (saved[li - 1][2], saved[li - 1][3]) if below else (None, (None, None))
+                    fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev) if below else None
+                    dsd = dseed if fold_apply else None
+                    _check(h.cpfn_mlp_bwd_fused(_ptr(g if folded else Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp, asc, ash,
+                                                _ptr(ws), _ptr(g_new), Kp, _ptr(Yp), _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_),
+                                                _ptr(Y) if folded else None, _ptr(coef) if folded else None,
+                                                _ptr(st[0]) if folded else None, _ptr(st[1]) if folded else None, _ptr(dsd),
+                                                dp if dsd is not None else 0.0, _ptr(arg) if fold_pool else None,
+                                                _ptr(yarg) if fold_pool else None, pool_k if fold_pool else 0, _stream()),
+                           "cpfn_mlp_bwd_fused")
+                    # g_y (or, folded in: g / the pooled g + y), the input, W, the split partials, the data gradient
+                    gy_bytes = (2 * P * N + 5 * P * N // pool_k) if fold_pool else (4 * P * N if fold_apply else 2 * P * N)
+                    _l.add_bytes("cpfn_mlp_bwd_fused", gy_bytes + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
+                                 + ((2 * P * Kp + 8 * splits * Kp) if below else 0))
+                    if below:
+                        fused_part = (fp_, splits)
+                elif folded:                        # small layer, apply pass on the weight gradient's operand load (off by default)
+                    _check(h.cpfn_mlp_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in),
+                                                  a_in.stride(0), P, N, Kp, asc, ash, _ptr(ws), None, _stream()), "cpfn_mlp_wgrad_apply")
+                    _l.add_bytes("cpfn_mlp_wgrad_apply", 4 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
                 else:
-                    Kp = a_in.shape[1]
-                    splits = h.cpfn_mlp_wgrad_splits(P, N, Kp)
-                    ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
-                    if one_pass:
-                        # dense 128 -> 128 layer: weight gradient, data gradient and pass 1 of the BatchNorm backward of
-                        # the layer below from ONE read of G_y (mlp_bwd_fused_kernel)
-                        below = li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None and Kp != 192
-                        g_up = g                      # gradient w.r.t. the activated output (apply_in_pass) ...
-                        g = torch.empty(P, Kp, dtype=BF16, device=dev)
-                        if below:
-                            Yp, stp = saved[li - 1][2], saved[li - 1][3]
-                            fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev)
-                        ap = apply_in_pass or pool_in_pass
-                        dsd = (ctx.drop_seed if li == len(layers) - 1 else None) if apply_in_pass else None
-                        _check(h.cpfn_mlp_bwd_fused(_ptr(g_up if ap else Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp,
-                                                    None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
-                                                    _ptr(ws), _ptr(g), Kp, _ptr(Yp) if below else None,
-                                                    _ptr(stp[0]) if below else None, _ptr(stp[1]) if below else None,
-                                                    _ptr(fp_) if below else None, _ptr(Y) if ap else None,
-                                                    _ptr(coef) if ap else None, _ptr(st[0]) if ap else None,
-                                                    _ptr(st[1]) if ap else None, _ptr(dsd),
-                                                    float(cfg["dropout"][0]) if dsd is not None else 0.0,
-                                                    _ptr(arg) if pool_in_pass else None, _ptr(yarg) if pool_in_pass else None,
-                                                    pool_k if pool_in_pass else 0, _stream()), "cpfn_mlp_bwd_fused")
-                        # g_y (or, folded in: g / the pooled g + y), the input, W, the split partials, the data gradient
-                        gy_bytes = (2 * P * N + (2 * P * N // pool_k + 3 * P * N // pool_k) if pool_in_pass
-                                    else (4 * P * N if apply_in_pass else 2 * P * N))
-                        _l.add_bytes("cpfn_mlp_bwd_fused", gy_bytes + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
-                                     + ((2 * P * Kp + 8 * splits * Kp) if below else 0))
-                        if below:
-                            fused_part = (fp_, splits)
-                        if li == 0:
-                            gx = g
-                    elif small_apply:
-                        _check(h.cpfn_mlp_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in),
-                                                      a_in.stride(0), P, N, Kp, None if a_ss is None else _ptr(a_ss[0]),
-                                                      None if a_ss is None else _ptr(a_ss[1]), _ptr(ws), None, _stream()),
-                               "cpfn_mlp_wgrad_apply")
-                        _l.add_bytes("cpfn_mlp_wgrad_apply", 4 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
+                    _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp, asc, ash, _ptr(ws), None,
+                                            _stream()), "cpfn_mlp_wgrad")
+                    _l.add_bytes("cpfn_mlp_wgrad", 2 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
+                # the split partials are finished by ONE launch at the end of the backward pass; a zero-padded K
+                # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
+                dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
+                if Kp == L.cin:
+                    _defer_reduction(ws, dW, N * Kp, splits)
+                else:
+                    _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin)
+                grads[3 * li] = dW.reshape(wshape)
+                if need_dgrad and route == "small" and (folded or below_ok):
+                    # small-P data gradient with the reduction of the layer below on the stored tile (and, off by default,
+                    # the apply pass on its operand load)
+                    g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
+                    Yp, stp = (saved[li - 1][2], saved[li - 1][3]) if below_ok else (None, (None, None))
+                    nb_ = h.cpfn_mlp_gemm_blocks(P, Kp)
+                    fp_ = torch.empty(nb_, 2, Kp, dtype=torch.float32, device=dev) if below_ok else None
+                    _check(h.cpfn_mlp_dgrad_small(_ptr(g if folded else Gy), _ptr(Y) if folded else None,
+                                                  _ptr(coef) if folded else None, _ptr(st[0]) if folded else None,
+                                                  _ptr(st[1]) if folded else None, _ptr(Wb), P, N, Kp, _ptr(g_new), Kp, _ptr(Yp),
+                                                  _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_), _stream()), "cpfn_mlp_dgrad_small")
+                    _l.add_bytes("cpfn_mlp_dgrad_small", (4 if folded else 2) * P * N + 2 * N * Kp + 2 * P * Kp
+                                 + ((2 * P * Kp + 8 * nb_ * Kp) if below_ok else 0))
+                    if below_ok:
+                        fused_part = (fp_, nb_)
+                elif need_dgrad and g_new is None:
+                    # G_y [P,N] · W [N,Kp]; where the streaming kernel runs, it also reduces the BatchNorm backward
+                    # of the layer below from the gradient it is writing
+                    if li > 0 and BN_NOSTORE and can_fuse_bwd_stats(P, N, Kp) and saved[li - 1][5] is None:
+                        Yp, stp = saved[li - 1][2], saved[li - 1][3]
+                        g_new, fp_, nb_ = gemm(Gy, Wb, w_trans=True, bwd_stats=(Yp, stp[0], stp[1]))
+                        fused_part = (fp_, nb_)
                     else:
-                        _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp,
-                                                None if a_ss is None else _ptr(a_ss[0]), None if a_ss is None else _ptr(a_ss[1]),
-                                                _ptr(ws), None, _stream()), "cpfn_mlp_wgrad")
-                        _l.add_bytes("cpfn_mlp_wgrad", 2 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
-                    # the split partials are finished by ONE launch at the end of the backward pass; a zero-padded K
-                    # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
-                    dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
-                    if Kp == L.cin:
-                        _defer_reduction(ws, dW, N * Kp, splits)
-                    else:
-                        _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin)
-                    grads[3 * li] = dW.reshape(wshape)
-                    below_small = small_pass and li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None
-                    if need_dgrad and small_pass and (small_apply or below_small):
-                        below = below_small
-                        g_up = g if small_apply else Gy
-                        g = torch.empty(P, Kp, dtype=BF16, device=dev)
-                        if below:
-                            Yp, stp = saved[li - 1][2], saved[li - 1][3]
-                            nb_ = h.cpfn_mlp_gemm_blocks(P, Kp)
-                            fp_ = torch.empty(nb_, 2, Kp, dtype=torch.float32, device=dev)
-                        sa = small_apply
-                        _check(h.cpfn_mlp_dgrad_small(_ptr(g_up), _ptr(Y) if sa else None, _ptr(coef) if sa else None,
-                                                      _ptr(st[0]) if sa else None, _ptr(st[1]) if sa else None, _ptr(Wb), P, N, Kp,
-                                                      _ptr(g), Kp, _ptr(Yp) if below else None, _ptr(stp[0]) if below else None,
-                                                      _ptr(stp[1]) if below else None, _ptr(fp_) if below else None, _stream()),
-                               "cpfn_mlp_dgrad_small")
-                        _l.add_bytes("cpfn_mlp_dgrad_small", (4 if small_apply else 2) * P * N + 2 * N * Kp + 2 * P * Kp + ((2 * P * Kp + 8 * nb_ * Kp) if below else 0))
-                        if below:
-                            fused_part = (fp_, nb_)
-                        if li == 0:
-                            gx = g
-                    elif need_dgrad and not one_pass:
-                        # G_y [P,N] · W [N,Kp]; where the streaming kernel runs, it also reduces the BatchNorm backward
-                        # of the layer below from the gradient it is writing
-                        if li > 0 and BN_NOSTORE and can_fuse_bwd_stats(P, N, Kp) and saved[li - 1][5] is None:
-                            Yp, stp = saved[li - 1][2], saved[li - 1][3]
-                            g, fp_, nb_ = gemm(Gy, Wb, w_trans=True, bwd_stats=(Yp, stp[0], stp[1]))
-                            fused_part = (fp_, nb_)
-                        else:
-                            g, _, _ = gemm(Gy, Wb, w_trans=True)
-                        if li == 0:
-                            gx = g
+                        g_new, _, _ = gemm(Gy, Wb, w_trans=True)
+                if g_new is not None:
+                    g = g_new
+                    if li == 0:
+                        gx = g
         return (gx, None) + tuple(grads)
+
+
+def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
+    """Route of one layer's backward and what is folded into its consumers:
+    -> (route, fold_apply, fold_pool); route "one_pass" (cpfn_mlp_bwd_fused), "small" (64 x 64-tile weight gradient + small-P
+    data gradient) or "generic"; fold_apply / fold_pool: the dense / max-pooled BatchNorm apply pass is formed on the
+    consumers' operand loads instead of being launched (g_y is then never stored)."""
+    if xyz_layer:
+        return "generic", bool(FUSED_BWD_APPLY and BN_NOSTORE and not pool_k and not dropout), False
+    Kp = a_in.shape[1]
+    one_pass = (FUSED_BWD and need_dgrad and a_in.stride(0) == Kp and bool(h.cpfn_mlp_bwd_fused_ok(P, N, Kp))
+                and not (Kp == 192 and dropout))                    # (the 192-wide shape has no dropout variant)
+    if one_pass:
+        if pool_k:
+            step_rows = 32 if Kp >= 128 else 64                     # rows per step of the one-pass kernel for this shape
+            return "one_pass", False, bool(FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255 and Kp != 192)
+        return "one_pass", bool(FUSED_BWD_APPLY and BN_NOSTORE), False
+    small = (SMALL_BWD_FUSED and not pool_k and BN_NOSTORE and not dropout and bool(h.cpfn_mlp_wgrad_apply_ok(P, N, Kp))
+             and (not need_dgrad or bool(h.cpfn_mlp_dgrad_small_ok(P, N, Kp))))
+    if small:
+        return "small", bool(SMALL_BWD_APPLY and FUSED_BWD_APPLY), False
+    return "generic", False, False
 
 
 def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None):
