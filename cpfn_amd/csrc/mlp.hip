@@ -889,8 +889,15 @@ __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restri
                                    const float *__restrict__ conv_bias, float eps, float momentum,
                                    float *__restrict__ running_mean, float *__restrict__ running_var,
                                    float *__restrict__ scale, float *__restrict__ shift,
-                                   float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+                                   float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                   long long *__restrict__ counter_a, long long *__restrict__ counter_b) {
   __shared__ double s_acc[RSUB][16][2];
+  // step counters advanced by this launch (the layer's num_batches_tracked; the dropout step counter of a stack whose
+  // output dropout reads it in the NEXT launch): was one multi-tensor add per forward pass
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (counter_a) ++*counter_a;
+    if (counter_b) ++*counter_b;
+  }
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
   double s1, s2;
   partial_sums_16x16(partial, nblk, N, c, r, s_acc, s1, s2);
@@ -2317,11 +2324,12 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
 extern "C" int cpfn_bn_finalize(const float *partial, int nblk, int N, float count, const float *gamma,
                                 const float *beta, const float *conv_bias, float eps, float momentum,
                                 float *running_mean, float *running_var, float *scale, float *shift,
-                                float *mean, float *rstd, void *stream) {
+                                float *mean, float *rstd, int64_t *counter_a, int64_t *counter_b, void *stream) {
   if (nblk <= 0 || N <= 0 || !partial || !gamma || !beta || !scale || !shift || !mean || !rstd) return CPFN_EINVAL;
   bn_finalize_kernel<<<cpfn_cdiv(N, 16), RTPB, 0, (hipStream_t)stream>>>(partial, nblk, N, count, gamma, beta, conv_bias,
                                                                         eps, momentum, running_mean, running_var,
-                                                                        scale, shift, mean, rstd);
+                                                                        scale, shift, mean, rstd, (long long *)counter_a,
+                                                                        (long long *)counter_b);
   return cpfn_launch_status();
 }
 

@@ -109,18 +109,21 @@ def can_fuse_bwd_stats(P, K, N):
     return BWD_STATS_FUSED and bool(_l.lib().cpfn_mlp_gemm_can_fuse_bwd_stats(P, K, N))
 
 
-def bn_finalize(part, nblk, N, count, gamma, beta, conv_bias, eps, momentum, rm, rv):
+def bn_finalize(part, nblk, N, count, gamma, beta, conv_bias, eps, momentum, rm, rv, counters=(None, None)):
+    """counters: up to two int64 step counters the launch advances (num_batches_tracked, a fused dropout's step counter)."""
     dev = part.device
     out = torch.empty(4, N, dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
     _check(_l.lib().cpfn_bn_finalize(_ptr(part), nblk, N, float(count), _ptr(gamma), _ptr(beta), _ptr(conv_bias),
                                      float(eps), float(momentum), _ptr(rm), _ptr(rv), _ptr(out[0]), _ptr(out[1]),
-                                     _ptr(out[2]), _ptr(out[3]), _stream()), "cpfn_bn_finalize")
+                                     _ptr(out[2]), _ptr(out[3]), _ptr(counters[0]), _ptr(counters[1]), _stream()),
+           "cpfn_bn_finalize")
     _l.add_bytes("cpfn_bn_finalize", 8 * nblk * N + 40 * N)
     return out
 
 
-def bn_relu_apply(Y, scale, shift, dropout=None):
-    """dropout = (p, counter int64 device scalar, base seed): fused mask; returns (out, seed tensor for backward)."""
+def bn_relu_apply(Y, scale, shift, dropout=None, counter_advanced=False):
+    """dropout = (p, counter int64 device scalar, base seed): fused mask; returns (out, seed tensor for backward).
+    counter_advanced: the step counter was already advanced for this pass (by the layer's cpfn_bn_finalize launch)."""
     out = torch.empty_like(Y)
     if dropout is None:
         _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), None, 0, 0.0,
@@ -132,7 +135,9 @@ def bn_relu_apply(Y, scale, shift, dropout=None):
     _check(_l.lib().cpfn_bn_relu_apply(_ptr(Y), _ptr(scale), _ptr(shift), Y.shape[0], Y.shape[1], _ptr(out), _ptr(counter),
                                        int(base) & 0xFFFFFFFFFFFFFFFF, float(p), _ptr(seed), _stream()), "cpfn_bn_relu_apply")
     _l.add_bytes("cpfn_bn_relu_apply", 4 * Y.numel())
-    if _defer_counters is not None:
+    if counter_advanced:
+        pass
+    elif _defer_counters is not None:
         _defer_counters.append(counter)      # advanced with the BatchNorm counters at the end of the forward pass
     else:
         counter.add_(1)
@@ -283,7 +288,7 @@ def refresh_weight_panels(params):
 # ------------------------------------------------------------------ the stack
 class _Layer:
     """Plain container of one layer's tensors / hyper-parameters (not a module)."""
-    __slots__ = ("weight", "bias", "gamma", "beta", "rm", "rv", "momentum", "eps", "training", "cin", "cout")
+    __slots__ = ("weight", "bias", "gamma", "beta", "rm", "rv", "momentum", "eps", "training", "cin", "cout", "nbt")
 
 
 def _layers_from_modules(convs, bns):
@@ -297,11 +302,8 @@ def _layers_from_modules(convs, bns):
         L.eps = bn.eps
         L.training = bn.training
         L.cout, L.cin = conv.weight.shape[0], conv.weight.shape[1]
-        if bn.training and bn.num_batches_tracked is not None:
-            if _defer_counters is not None:
-                _defer_counters.append(bn.num_batches_tracked)
-            else:
-                bn.num_batches_tracked.add_(1)
+        # num_batches_tracked of a training-mode layer: advanced by the layer's cpfn_bn_finalize launch (_FusedStack.forward)
+        L.nbt = bn.num_batches_tracked if (bn.training and bn.num_batches_tracked is not None) else None
         out.append(L)
     return out
 
@@ -363,21 +365,25 @@ class _FusedStack(torch.autograd.Function):
                         Y, part, nblk = gemm(a, Wb, stats=True)
                     else:
                         Y, part, nblk = gemm(a, Wb, stats=True, a_scale=a_ss[0], a_shift=a_ss[1])
+                last = li == len(layers) - 1
+                drop_in_finalize = False
                 if L.training:
+                    # (the dropout step counter of the stack's output rides on the same launch: bn_relu_apply reads it next)
+                    drop_in_finalize = last and not pool_k and cfg.get("dropout") is not None
                     st = bn_finalize(part, nblk, N, P, L.gamma.detach(), L.beta.detach(),
-                                     None if L.bias is None else L.bias.detach(), L.eps, L.momentum, L.rm, L.rv)
+                                     None if L.bias is None else L.bias.detach(), L.eps, L.momentum, L.rm, L.rv,
+                                     counters=(L.nbt, cfg["dropout"][1] if drop_in_finalize else None))
                 else:   # running statistics (eval): z = γ (y + b − rm)/sqrt(rv+eps) + β, one launch
                     st = torch.empty(4, N, dtype=torch.float32, device=dev)
                     _check(h.cpfn_bn_eval_affine(_ptr(L.gamma.detach()), _ptr(L.beta.detach()),
                                                  None if L.bias is None else _ptr(L.bias.detach()), _ptr(L.rm), _ptr(L.rv),
                                                  float(L.eps), N, _ptr(st), _stream()), "cpfn_bn_eval_affine")
-                last = li == len(layers) - 1
                 if last and pool_k:
                     out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)
                     saved.append((a, a_ss, Y, st, Wb, arg, yarg))
                 elif last or not BN_APPLY_FUSED:
                     if last and cfg.get("dropout") is not None:
-                        nxt, drop_seed = bn_relu_apply(Y, st[0], st[1], cfg["dropout"])
+                        nxt, drop_seed = bn_relu_apply(Y, st[0], st[1], cfg["dropout"], counter_advanced=drop_in_finalize)
                     else:
                         nxt = bn_relu_apply(Y, st[0], st[1])
                     saved.append((a, a_ss, Y, st, Wb, None, None))

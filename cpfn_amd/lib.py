@@ -70,7 +70,7 @@ SIGNATURES = {
     "cpfn_mlp_gemm_set_probe": [_vp, _i, _i],
     "cpfn_wall_clock_khz": [_i],
     "cpfn_stamp": [_vp, _vp],
-    "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_bn_eval_affine": [_vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _vp],
     "cpfn_bn_relu_apply": [_vp, _vp, _vp, _ll, _i, _vp, _vp, ctypes.c_uint64, _f, _vp, _vp],
     "cpfn_bn_relu_maxpool": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -304,11 +304,12 @@ CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *
                            float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,
                            void *stream);
 /* Batch statistics -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update with
- * torch's momentum / unbiased-variance convention; conv_bias re-enters the running mean). */
+ * torch's momentum / unbiased-variance convention; conv_bias re-enters the running mean).   counter_a / counter_b (optional): int64 step counters this launch advances by one — the BatchNorm
+ * module's num_batches_tracked, and the dropout step counter of a stack whose fused output dropout reads it next. */
 CPFN_API int cpfn_bn_finalize(const float *partial, int nblk, int N, float count, const float *gamma,
                               const float *beta, const float *conv_bias, float eps, float momentum,
                               float *running_mean, float *running_var, float *scale, float *shift,
-                              float *mean, float *rstd, void *stream);
+                              float *mean, float *rstd, int64_t *counter_a, int64_t *counter_b, void *stream);
 /* Evaluation-mode BatchNorm (running statistics; torch.nn.functional.batch_norm with training=False) as the
  * scale / shift of the bias-free GEMM output: out4C = [scale | shift | running_mean - conv_bias | rstd], C floats each —
  * the layout cpfn_bn_finalize writes.  conv_bias may be NULL. */

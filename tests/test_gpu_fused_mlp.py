@@ -102,6 +102,7 @@ def test_fused_stack_matches_fp32_reference(name, P, cin, widths, pool_k, use_xy
     y_ref, gx_ref, gr_ref, st_ref = _run(x, convs, bns, "emulated", pool_k, xyz, gout)
     y, gx, gr, st = _run(x, convs, bns, torch.bfloat16, pool_k, xyz, gout)
     assert y.shape == y_ref.shape
+    assert all(int(bn.num_batches_tracked) == 1 for bn in bns)     # advanced by each layer's finalize launch
     # (1) against true fp32: bf16-level agreement of the forward, gradients same direction
     assert _rel(y, y_32) < 3e-2, ("out vs fp32", _rel(y, y_32))
     # (2) against the rounding-emulated reference: the kernels themselves
