@@ -5,10 +5,15 @@ of the coarse features onto the dense points, skip concatenation, shared MLP.
 Same constructor, parameter names (`mlp_convs.i`, `mlp_bns.i`) and
 `forward(pos1, pos2, feats1, feats2)` contract; `forward_rows` is the native entry.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .... import autograd_ops, mlp, ops
+
+# CPFN_CONCAT_INTERP=0: interpolation (or the broadcast of the global vector) and torch.cat as separate launches
+CONCAT_INTERP = os.environ.get("CPFN_CONCAT_INTERP", "1") != "0"
 
 
 class PointsetFeaturePropagation(nn.Module):
@@ -42,14 +47,21 @@ class PointsetFeaturePropagation(nn.Module):
         never materialised and its BatchNorm-backward reduction rides on the next layer's data gradient."""
         B, N, _ = xyz1.shape
         aux = {}
-        if xyz2 is None:
-            interp = feats2.expand(B, N, feats2.shape[2])                  # broadcast the global vector (ref :33-34)
+        if xyz2 is not None and geom is None:
+            geom = self.compute_geometry(xyz1, xyz2, cuda_route, need_inverse=self.training and torch.is_grad_enabled())
+        idx = None if xyz2 is None else geom["nn_idx"]
+        if CONCAT_INTERP and feats1 is not None and autograd_ops.concat_interp_ok(feats1, feats2, idx):
+            # bf16 HIP path: [feats1 | interpolation (or the broadcast global vector)] written by ONE launch
+            x = autograd_ops.concat_interp(feats1, feats2, idx, None if xyz2 is None else geom["nn_w"],
+                                           None if xyz2 is None else geom.get("inv"))
+            aux = {} if xyz2 is None else geom
         else:
-            if geom is None:
-                geom = self.compute_geometry(xyz1, xyz2, cuda_route, need_inverse=self.training and torch.is_grad_enabled())
-            interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"], geom.get("inv"))
-            aux = geom
-        x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
+            if xyz2 is None:
+                interp = feats2.expand(B, N, feats2.shape[2])                  # broadcast the global vector (ref :33-34)
+            else:
+                interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"], geom.get("inv"))
+                aux = geom
+            x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
         convs, bns, dropout = list(self.mlp_convs), list(self.mlp_bns), None
         if tail is not None:
             convs, bns, dropout = convs + list(tail[0]), bns + list(tail[1]), tail[2]

@@ -139,6 +139,59 @@ class ConcatPosFeats(torch.autograd.Function):
         return None, g[:, 3:3 + ctx.C], None
 
 
+class ConcatInterp(torch.autograd.Function):
+    """[ skip [B,N,C1] | three-NN interpolation of feats [B,M,C2] ] -> bf16 [B,N,C1+C2] in one launch (idx = w = None and
+    M = 1: the global feature vector broadcast to every point).  Adjoint: the skip part is a view of the incoming gradient,
+    the interpolated part goes through the inverse index (or the LDS scatter) straight from the gradient's column block —
+    no slice copy —, the broadcast part is a column sum (cpfn_colsum_rows_bf16)."""
+
+    @staticmethod
+    def forward(ctx, skip, feats, idx, w, inv_off=None, inv_ent=None):
+        B, N, C1 = skip.shape
+        M, C2 = feats.shape[1], feats.shape[2]
+        sk, f = skip.contiguous(), feats.contiguous()
+        out = torch.empty(B, N, C1 + C2, dtype=torch.bfloat16, device=f.device)
+        with torch.cuda.device(f.device):
+            _l.check(_l.lib().cpfn_concat_interp_bf16(_ptr(sk), C1, _ptr(f), _ptr(idx), _ptr(w), B, M, N, C2, _ptr(out), _stream()),
+                     "cpfn_concat_interp_bf16")
+        _l.add_bytes("cpfn_concat_interp_bf16", 2 * B * N * C1 + 2 * B * M * C2 + (24 * B * N if idx is not None else 0)
+                     + 2 * B * N * (C1 + C2))
+        ctx.save_for_backward(idx, w)
+        ctx.inv = None if inv_off is None else (inv_off, inv_ent)
+        ctx.dims = (B, M, N, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, w = ctx.saved_tensors
+        B, M, N, C1, C2 = ctx.dims
+        g = g.contiguous().to(torch.bfloat16)
+        g_skip, g_int = g[:, :, :C1], g[:, :, C1:]            # views: the consumers take the row stride
+        if idx is None:
+            gf = torch.empty(B, 1, C2, dtype=torch.bfloat16, device=g.device)
+            with torch.cuda.device(g.device):
+                _l.check(_l.lib().cpfn_colsum_rows_bf16(_ptr(g_int), C1 + C2, B, N, C2, _ptr(gf), _stream()), "cpfn_colsum_rows_bf16")
+            _l.add_bytes("cpfn_colsum_rows_bf16", 2 * B * N * C2 + 2 * B * C2)
+        elif ctx.inv is not None:
+            gf = _csr_sum_bf16(g_int, C1 + C2, ctx.inv, w, 3, B, N, M, C2)
+        else:
+            gf = _scatter_bf16(g_int, C1 + C2, idx, w, 3, B, N, M, C2).to(torch.bfloat16)
+        return g_skip, gf, None, None, None, None
+
+
+def concat_interp_ok(skip, feats, idx):
+    """The one-launch form needs bf16 rows on the GPU, channel counts in multiples of 8, and (interpolation) <= 1024 coarse
+    points for the LDS scatter fallback / (broadcast) exactly one."""
+    return (skip is not None and feats.is_cuda and skip.dtype == feats.dtype == torch.bfloat16 and skip.shape[2] % 8 == 0
+            and feats.shape[2] % 8 == 0 and ((idx is None and feats.shape[1] == 1) or (idx is not None and feats.shape[1] <= 1024)))
+
+
+def concat_interp(skip, feats, idx=None, w=None, inv=None):
+    if inv is not None:
+        return ConcatInterp.apply(skip, feats, idx, w, inv[0], inv[1])
+    return ConcatInterp.apply(skip, feats, idx, w)
+
+
 def interp_rows(feats, idx, w, inv=None):
     if feats.dtype == torch.bfloat16 and feats.is_cuda and feats.shape[2] % 8 == 0 and feats.shape[1] <= 1024:
         if inv is not None:

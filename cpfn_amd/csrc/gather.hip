@@ -195,6 +195,81 @@ __global__ __launch_bounds__(TPB) void interp_rows_bf16_kernel(const unsigned sh
   *(uint4 *)(out + ((size_t)b * N + n) * C + c0) = *(const uint4 *)o;
 }
 
+// Input rows of a feature-propagation stack in one pass (modules/pointset_feature_propagation.py:33-46):
+//   out[b,n,:] = [ skip[b,n,:C1] | Σ_t w[b,n,t]·feats[b,idx[b,n,t],:C2] ]        (idx == NULL: | feats[b,0,:C2], the
+// broadcast of a global feature vector).  Was: the interpolation (or an expand) + torch.cat = two launches and a
+// [B,N,C2] intermediate; the adjoint of the expand was a 12 us framework reduction (colsum_rows_bf16_kernel below).
+__global__ __launch_bounds__(TPB) void concat_interp_bf16_kernel(const unsigned short *__restrict__ skip, int C1,
+                                                                 const unsigned short *__restrict__ feats,
+                                                                 const int *__restrict__ idx, const float *__restrict__ w,
+                                                                 int M, int N, int C2, unsigned short *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int cpr = (C1 + C2) / 8, cp1 = C1 / 8;
+  const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (e >= (long long)N * cpr) return;
+  const int n = (int)(e / cpr), ch = (int)(e - (long long)n * cpr);
+  unsigned short *o = out + ((size_t)b * N + n) * (C1 + C2) + ch * 8;
+  if (ch < cp1) {
+    *(uint4 *)o = *(const uint4 *)(skip + ((size_t)b * N + n) * C1 + ch * 8);
+    return;
+  }
+  const int c0 = (ch - cp1) * 8;
+  if (!idx) {
+    *(uint4 *)o = *(const uint4 *)(feats + (size_t)b * M * C2 + c0);
+    return;
+  }
+  const int *ii = idx + ((size_t)b * N + n) * 3;
+  const float *ww = w + ((size_t)b * N + n) * 3;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const uint4 r = *(const uint4 *)(feats + ((size_t)b * M + ii[t]) * C2 + c0);
+    const unsigned short *h = (const unsigned short *)&r;
+    const float wt = ww[t];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaf(wt, bf2f_(h[j]), acc[j]);
+  }
+  unsigned short ov[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ov[j] = f2bf_(acc[j]);
+  *(uint4 *)o = *(const uint4 *)ov;
+}
+
+// out[b,c] = Σ_n g[b,n,c] for a column block of a row-major bf16 tensor (row stride ldg): adjoint of the broadcast
+// above.  One lane per (cloud, 8-channel chunk, row subset), fp32 sums, subsets combined in a fixed order through LDS.
+__global__ __launch_bounds__(TPB) void colsum_rows_bf16_kernel(const unsigned short *__restrict__ g, int ldg, int N, int C,
+                                                               unsigned short *__restrict__ out) {
+  __shared__ float s_acc[TPB][9];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int cpr = C / 8;                                   // chunks of the column block
+  const int lanes = min(cpr - (int)blockIdx.x * 32, 32);   // up to 32 chunks per workgroup, 8 row subsets
+  const int ch = t & 31, rs = t >> 5;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ch < lanes) {
+    const unsigned short *src = g + (size_t)b * N * ldg + ((size_t)blockIdx.x * 32 + ch) * 8;
+    for (int n = rs; n < N; n += 8) {
+      const uint4 r = *(const uint4 *)(src + (size_t)n * ldg);
+      const unsigned short *h = (const unsigned short *)&r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += bf2f_(h[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_acc[t][j] = acc[j];
+  __syncthreads();
+  if (rs == 0 && ch < lanes) {
+    unsigned short ov[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += s_acc[q * 32 + ch][j];
+      ov[j] = f2bf_(v);
+    }
+    *(uint4 *)(out + (size_t)b * C + ((size_t)blockIdx.x * 32 + ch) * 8) = *(const uint4 *)ov;
+  }
+}
+
 // Scatter-add of bf16 gradient rows into a SMALL fp32 target [B,M,C] (M <= 1024 rows per cloud):
 //   target[b, idx[b,r,t], c] += w[b,r,t] · g[b,r,c]        (T = 1 with w = NULL: plain gather adjoint)
 // The target slab of a 32-channel chunk lives in LDS (M x 32 fp32 <= 128 KB), every contribution is an
@@ -667,6 +742,27 @@ extern "C" int cpfn_interp_rows_bf16(const void *feats, const int *idx, const fl
   dim3 grid(cpfn_cdiv((long long)N * (C / 8), TPB), B);
   interp_rows_bf16_kernel<<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)feats, idx, w, M, N, C,
                                                                  (unsigned short *)out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_concat_interp_bf16(const void *skip, int C1, const void *feats, const int *idx, const float *w, int B,
+                                       int M, int N, int C2, void *out, void *stream) {
+  if (B < 0 || M <= 0 || N < 0 || C1 < 0 || C2 <= 0 || (C1 & 7) || (C2 & 7) || !feats || !out || (C1 > 0 && !skip) ||
+      (!idx != !w) || (!idx && M != 1))
+    return CPFN_EINVAL;
+  if (B == 0 || N == 0) return 0;
+  dim3 grid(cpfn_cdiv((long long)N * ((C1 + C2) / 8), TPB), B);
+  concat_interp_bf16_kernel<<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)skip, C1, (const unsigned short *)feats,
+                                                                   idx, w, M, N, C2, (unsigned short *)out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_colsum_rows_bf16(const void *g, int ldg, int B, int N, int C, void *out, void *stream) {
+  if (B < 0 || N <= 0 || C <= 0 || (C & 7) || (ldg & 7) || ldg < C || !g || !out) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  static_assert(TPB == 256, "32 chunks x 8 row subsets");
+  colsum_rows_bf16_kernel<<<dim3(cpfn_cdiv(C / 8, 32), B), TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, N, C,
+                                                                                         (unsigned short *)out);
   return cpfn_launch_status();
 }
 

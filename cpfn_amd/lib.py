@@ -34,6 +34,8 @@ SIGNATURES = {
     "cpfn_interp_rows_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_interp_rows_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_interp_rows_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "cpfn_concat_interp_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "cpfn_colsum_rows_bf16": [_vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_scatter_rows_bf16": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_group_concat_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_multi_copy": [_vp, _i, _vp],

@@ -154,6 +154,13 @@ CPFN_API int cpfn_interp_rows_bwd(const float *grad_out, const int *idx, const f
  * (modules/pointset_abstraction.py:62-66). */
 CPFN_API int cpfn_interp_rows_bf16(const void *feats, const int *idx, const float *w, int B, int M, int N,
                                    int C, void *out, void *stream);
+/* Input rows of a feature-propagation stack in one pass (modules/pointset_feature_propagation.py:33-46):
+ * out[B,N,C1+C2] = [ skip[B,N,C1] | three-NN interpolation of feats[B,M,C2] ] — or, with idx = w = NULL and M = 1,
+ * [ skip | feats[b,0,:] broadcast ] (the global feature vector of sfp1).  C1, C2 multiples of 8 (C1 may be 0). */
+CPFN_API int cpfn_concat_interp_bf16(const void *skip, int C1, const void *feats, const int *idx, const float *w, int B,
+                                     int M, int N, int C2, void *out, void *stream);
+/* out[B,C] (bf16) = column sums over the N rows of a column block of g (bf16, row stride ldg): adjoint of that broadcast. */
+CPFN_API int cpfn_colsum_rows_bf16(const void *g, int ldg, int B, int N, int C, void *out, void *stream);
 CPFN_API int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, const float *w, int T, int B,
                                     int R, int M, int C, float *out, void *stream);
 CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const int *idx, int B, int N, int R,

@@ -90,3 +90,42 @@ def test_colsum_with_padded_bf16_copy():
         _call("cpfn_colsum_f32", X.data_ptr(), P, C, ws.data_ptr(), out.data_ptr(), pad.data_ptr(), _stream())
         torch.testing.assert_close(out, X.sum(0), rtol=1e-4, atol=1e-3)
         assert torch.equal(pad[:, :C], X.to(torch.bfloat16)) and bool((pad[:, C:] == 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,B,M,N,C1,C2", [("interp", 3, 128, 512, 128, 256), ("interp", 2, 512, 2000, 64, 128),
+                                               ("broadcast", 4, 1, 128, 256, 1024)])
+def test_concat_interp_matches_interp_plus_cat(mode, B, M, N, C1, C2):
+    """cpfn_concat_interp_bf16 (skip | interpolation or broadcast, one launch) against the two-launch form: forward bit for
+    bit; adjoints equal (interpolation: same inverse-index kernel on a strided view; broadcast: fp32 column sums)."""
+    from cpfn_amd import autograd_ops, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * N + C2)
+    skip = torch.randn(B, N, C1, generator=g).to(dev).to(torch.bfloat16)
+    feats = torch.randn(B, M, C2, generator=g).to(dev).to(torch.bfloat16)
+    gout = torch.randn(B, N, C1 + C2, generator=g).to(dev).to(torch.bfloat16)
+    if mode == "interp":
+        idx = torch.randint(0, M, (B, N, 3), generator=g).to(dev).to(torch.int32)
+        w = torch.rand(B, N, 3, generator=g).to(dev)
+        w = (w / w.sum(2, keepdim=True)).contiguous()
+        inv = ops.csr_build(idx, M)
+    else:
+        idx = w = inv = None
+    res = []
+    for fused in (True, False):
+        s_, f_ = skip.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+        if fused:
+            assert autograd_ops.concat_interp_ok(s_, f_, idx)
+            out = autograd_ops.concat_interp(s_, f_, idx, w, inv)
+        else:
+            it = f_.expand(B, N, C2) if idx is None else autograd_ops.interp_rows(f_, idx, w, inv)
+            out = torch.cat([s_, it], dim=2)
+        out.backward(gout)
+        res.append((out.detach(), s_.grad, f_.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    if mode == "interp":
+        assert torch.equal(res[0][2], res[1][2])
+    else:
+        a, b = res[0][2].float(), res[1][2].float()
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
