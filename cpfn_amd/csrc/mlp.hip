@@ -1451,9 +1451,15 @@ struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the
   const unsigned short *pool_yarg;           // ... the pre-BN value there; Gy is then the POOLED gradient [P / pool_k, TN]
   int pool_k;
   long long groups;
+  const float *xyz, *w0;                     // XYZ: the layer's input is the pre-BN output of an fp32-xyz first layer,
+                                             //      y0 = bf16(W0 [TK][3] . xyz [P][3]): RECOMPUTED here instead of read
 };
 
-template <int TN, int TK, int STEP, bool BST, int APPLY>
+// XYZ (sa1's second layer, TK = 64): both uses of the first layer's pre-BN output y0 — the input operand (before its
+// BN + ReLU transform) and the y of the riding reduction — are recomputed from the 12-byte coordinate row with
+// smallk_fwd_kernel's arithmetic (three fused multiply-adds per channel, rounded to bf16) instead of read: y0 is
+// [524288, 64] bf16 = 67 MB per read, the coordinates 6 MB.
+template <int TN, int TK, int STEP, bool BST, int APPLY, bool XYZ = false>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
     const unsigned short *__restrict__ W /* forward weight panel [TN][TK] bf16 */, long long P, long long rows_per_split,
@@ -1463,7 +1469,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     unsigned long long *probe = nullptr) {
   const unsigned long long probe_t0 = probe_begin(probe);
   const unsigned short *__restrict__ Yr = ap.Yr;
-  // (rows in flight: 128, and 64 for the 256-wide g_y — the same bytes, half the staging registers)
+  // (rows in flight: 128, and 64 for the 256-wide g_y — the same bytes, half the staging registers.  The 64-row-step shapes
+  //  are NOT waiting for memory: taking 134 MB of the 64 -> 64 kernel's reads away (XYZ) saved 2 us of 65, and 256 rows in
+  //  flight instead of 128 made both of them 5 % slower (registers); their apply / statistics / conversion VALU work and
+  //  LDS traffic per row are what a 64-channel row costs.)
   constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP / (TN > 128 ? 2 : 1), KSTEPS = STEP / 32;
   constexpr int CPRG = TN / 8, CPRA = TK / 8;                 // 16-byte chunks per row of the TN- / TK-wide tensors
   constexpr int NG = STEP * CPRG / NT;                        // g_y chunks per thread and step
@@ -1499,7 +1508,27 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // chunk i of thread t: row t / CPR + i (NT / CPR), columns 8 (t % CPR) — a thread's columns never change
   const int grow = t / CPRG, gcol = (t % CPRG) * 8, arow = (TA == NT ? t : t % TA) / CPRA, acol = (t % CPRA) * 8;
   const bool a_live = TA == NT || t < TA;
-  uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
+  uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[XYZ ? 1 : DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
+  static_assert(!XYZ || (BST && TK <= 64), "XYZ: the recomputed tensor is the input AND the y of the riding reduction");
+  float vx[XYZ ? DEPTH : 1][NA][3], xb[XYZ ? NA : 1][3], w0r[XYZ ? 8 : 1][3];   // coordinate rows in flight / of the pending slab
+  if (XYZ) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) w0r[j][q] = ap.w0[(acol + j) * 3 + q];
+  }
+  // y0 chunk (8 channels of one row) from its coordinates: smallk_fwd_kernel's arithmetic
+  auto y0_chunk = [&](const float (&x)[3]) {
+    unsigned short o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v = fmaf(w0r[XYZ ? j : 0][q], x[q], v);
+      o[j] = f2bf(v);
+    }
+    return *(const uint4 *)o;
+  };
   uint4 vgp[APPLY == 2 ? DEPTH : 1], vya[APPLY == 2 ? DEPTH : 1];       // pooled gradient / arg-max value of the step's group
   uint2 var_[APPLY == 2 ? DEPTH : 1];                                    // arg-max row (8 channels, one byte each)
   // (pooled: a step never straddles two groups — the host checks pool_k % STEP == 0)
@@ -1538,7 +1567,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const long long p = min(base + arow + i * RPA, p1 - 1);
-        va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
+        if (XYZ) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) vx[sidx][i][q] = ap.xyz[p * 3 + q];
+        } else {
+          va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
+        }
       }
     }
   };
@@ -1614,7 +1648,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int r = arow + i * RPA;
-        uint4 a4 = va[sidx][i];
+        uint4 a4;
+        if (XYZ) {
+          a4 = y0_chunk(vx[sidx][i]);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) xb[i][q] = vx[sidx][i][q];       // this step's slab is stored one step later
+        } else {
+          a4 = va[sidx][i];
+        }
         if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
         if (base + r >= p1) a4 = (uint4){0, 0, 0, 0};
         *(uint4 *)&s_a[r * LDK + acol] = a4;
@@ -1634,7 +1675,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       if (p < p1) {
         *(uint4 *)(Gout + p * ldo + acol) = v;
         if (BST) {
-          const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {yb[i].x, yb[i].y, yb[i].z, yb[i].w};
+          const uint4 ybv = XYZ ? y0_chunk(xb[XYZ ? i : 0]) : yb[i];
+          const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {ybv.x, ybv.y, ybv.z, ybv.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float g0 = __uint_as_float(g4[j] << 16), g1 = __uint_as_float(g4[j] & 0xffff0000u);
@@ -1661,7 +1703,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       stage(d, base);
       __syncthreads();
       issue(d, base + STEP * DEPTH);
-      if (BST) {       // this step's slab, used one step later
+      if (BST && !XYZ) {       // this step's slab, used one step later
 #pragma unroll
         for (int i = 0; i < NA; ++i)
           yb[i] = *(const uint4 *)(Yb + min(base + arow + i * RPA, p1 - 1) * ldo + acol);
@@ -2025,24 +2067,32 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 // dW[c,j] = Σ_p Gy[p,c]·X[p,j]: partial[gridDim.x][C][KS]
 // APPLY: Gy is the gradient w.r.t. the layer's ACTIVATED output; g_y is formed on the fly from the layer's pre-BN output
 // Yr exactly as cpfn_bn_bwd_apply rounds it to bf16 (so the stand-alone apply pass and the g_y tensor disappear).
-template <int KS, bool APPLY>
+// XYZ (with APPLY): the layer's pre-BN output y is not read but recomputed from the row's coordinates and the layer's own
+// weight W0 [C][KS] (smallk_fwd_kernel's arithmetic, rounded to bf16): 12 bytes instead of 2 C per row.
+template <int KS, bool APPLY, bool XYZ = false>
 __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short *__restrict__ Gy,
                                                            const float *__restrict__ X, long long P,
                                                            int C, float *__restrict__ partial, int rpb,
                                                            const unsigned short *__restrict__ Yr = nullptr,
                                                            const float *__restrict__ coef = nullptr,
                                                            const float *__restrict__ y_scale = nullptr,
-                                                           const float *__restrict__ y_shift = nullptr) {
+                                                           const float *__restrict__ y_shift = nullptr,
+                                                           const float *__restrict__ W0 = nullptr) {
+  static_assert(!XYZ || APPLY, "XYZ is a variant of the folded apply pass");
   __shared__ float s_red[256][8 * KS + 1];
   const int t = threadIdx.x;
   const int nch = C / 8, rsub = 256 / nch;
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
-  float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];
+  float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8], w0r[XYZ ? 8 : 1][KS];
   if (APPLY) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       cf0[j] = coef[c0 + j]; cf1[j] = coef[C + c0 + j]; cf2[j] = coef[2 * C + c0 + j];
       ysc[j] = y_scale[c0 + j]; ysh[j] = y_shift[c0 + j];
+      if (XYZ) {
+#pragma unroll
+        for (int q = 0; q < KS; ++q) w0r[j][q] = W0[(c0 + j) * KS + q];
+      }
     }
   }
   const long long row0 = (long long)blockIdx.x * rpb;
@@ -2060,7 +2110,7 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short 
       for (int u = 0; u < 4; ++u) {
         const long long rr = min(r + (long long)u * rsub, rend - 1);
         rg[u] = *(const uint4 *)(Gy + rr * C + c0);
-        if (APPLY) ry[u] = *(const uint4 *)(Yr + rr * C + c0);
+        if (APPLY && !XYZ) ry[u] = *(const uint4 *)(Yr + rr * C + c0);
 #pragma unroll
         for (int q = 0; q < KS; ++q) x[u][q] = X[rr * KS + q];
       }
@@ -2073,7 +2123,15 @@ __global__ __launch_bounds__(256) void smallk_wgrad_kernel(const unsigned short 
         for (int j = 0; j < 8; ++j) {
           float gv = live ? bf2f(g[j]) : 0.f;
           if (APPLY) {
-            const float yv = bf2f(y[j]);
+            float yv;
+            if (XYZ) {
+              float v = 0.f;
+#pragma unroll
+              for (int q = 0; q < KS; ++q) v = fmaf(w0r[XYZ ? j : 0][q], x[u][q], v);
+              yv = bf2f(f2bf(v));
+            } else {
+              yv = bf2f(y[j]);
+            }
             const float gz = fmaf(ysc[j], yv, ysh[j]) > 0.f ? bf2f(g[j]) : 0.f;
             gv = live ? bf2f(f2bf(fmaf(cf0[j], gz, fmaf(cf1[j], yv, cf2[j])))) : 0.f;
           }
@@ -2546,6 +2604,7 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   ap.drop_seed = drop_seed; ap.thresh16 = dropout_thresh16(drop_seed ? drop_p : 0.f); ap.inv_keep = drop_seed ? 1.f / (1.f - drop_p) : 1.f;
   ap.pool_arg = pool_arg; ap.pool_yarg = (const unsigned short *)pool_yarg; ap.pool_k = pool_k > 0 ? pool_k : 1;
   ap.groups = pool_k > 0 ? P / pool_k : 1;
+  ap.xyz = nullptr; ap.w0 = nullptr;
   const int mode = !apply_y ? 0 : (pool_k > 0 ? 2 : (drop_seed ? 3 : 1));
 #define CPFN_BWD_FUSED(TN_, TK_, STEP_, BST_, APPLY_)                                                                      \
   mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
@@ -2578,6 +2637,32 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   return cpfn_launch_status();
 }
 
+// sa1's second layer (64 -> 64 on the pre-BN output of the fp32-xyz first layer): cpfn_mlp_bwd_fused with that input AND the
+// y of the riding reduction recomputed from the coordinates (apply pass folded in; see mlp_bwd_fused_kernel, XYZ)
+extern "C" int cpfn_mlp_bwd_fused_xyz(const void *Gz, const void *Yr, const float *apply_coef, const float *y_scale,
+                                      const float *y_shift, const float *X, const float *W0, const void *W, long long P,
+                                      const float *a_scale, const float *a_shift, float *workspace, void *Gout,
+                                      float *stats_partial, void *stream) {
+  const int N = 64, K = 64;
+  if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gz || !Yr || !apply_coef || !y_scale || !y_shift || !X || !W0 || !W || !a_scale ||
+      !a_shift || !workspace || !Gout || !stats_partial)
+    return CPFN_EINVAL;
+  const int splits = cpfn_mlp_wgrad_splits(P, N, K);
+  long long rps = (P + splits - 1) / splits;
+  rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
+  const dim3 grid(1, 1, splits);
+  BwdApplyArgs ap;
+  ap.Yr = (const unsigned short *)Yr; ap.coef = apply_coef; ap.y_scale = y_scale; ap.y_shift = y_shift;
+  ap.drop_seed = nullptr; ap.thresh16 = 0; ap.inv_keep = 1.f;
+  ap.pool_arg = nullptr; ap.pool_yarg = nullptr; ap.pool_k = 1; ap.groups = 1;
+  ap.xyz = X; ap.w0 = W0;
+  // (the layer below IS the first layer: its scale / shift are both the operand transform and the reduction's mask)
+  mlp_bwd_fused_kernel<64, 64, 64, true, 1, true><<<grid, 512, 0, (hipStream_t)stream>>>(
+      (const unsigned short *)Gz, N, nullptr, K, (const unsigned short *)W, P, rps, workspace, (unsigned short *)Gout, K, a_scale,
+      a_shift, nullptr, a_scale, a_shift, stats_partial, ap, probe_slot_all(grid));
+  return cpfn_launch_status();
+}
+
 extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P, int C, void *Y, float *partial,
                                void *stream) {
   if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || !partial)
@@ -2596,7 +2681,7 @@ extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long
 
 static int smallk_wgrad_launch(const void *Gy, const float *X, int KS, long long P, int C, float *workspace, float *dW,
                                const void *apply_y, const float *coef, const float *y_scale, const float *y_shift,
-                               void *stream) {
+                               void *stream, const float *W0 = nullptr) {
   if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !Gy || !X || !workspace)
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -2605,7 +2690,8 @@ static int smallk_wgrad_launch(const void *Gy, const float *X, int KS, long long
   const int rpb = bn_rows_per_block(P);
 #define CPFN_SMALLK_WGRAD(KS_)                                                                                              \
   do {                                                                                                                      \
-    if (yr) smallk_wgrad_kernel<KS_, true><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb, yr, coef, y_scale, y_shift);   \
+    if (W0) smallk_wgrad_kernel<KS_, true, true><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb, nullptr, coef, y_scale, y_shift, W0); \
+    else if (yr) smallk_wgrad_kernel<KS_, true><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb, yr, coef, y_scale, y_shift);   \
     else smallk_wgrad_kernel<KS_, false><<<nblk, 256, 0, st>>>(g, X, P, C, workspace, rpb);                                 \
   } while (0)
   switch (KS) {
@@ -2630,6 +2716,14 @@ extern "C" int cpfn_smallk_wgrad_apply(const void *Gz, const void *Y, const floa
                                        float *dW, void *stream) {
   if (!Y || !coef || !y_scale || !y_shift) return CPFN_EINVAL;
   return smallk_wgrad_launch(Gz, X, KS, P, C, workspace, dW, Y, coef, y_scale, y_shift, stream);
+}
+
+// ... with y recomputed from X and the layer's own fp32 weight W0 [C][KS] instead of read (see smallk_wgrad_kernel, XYZ)
+extern "C" int cpfn_smallk_wgrad_apply_xyz(const void *Gz, const float *W0, const float *coef, const float *y_scale,
+                                           const float *y_shift, const float *X, int KS, long long P, int C,
+                                           float *workspace, float *dW, void *stream) {
+  if (!W0 || !coef || !y_scale || !y_shift) return CPFN_EINVAL;
+  return smallk_wgrad_launch(Gz, X, KS, P, C, workspace, dW, nullptr, coef, y_scale, y_shift, stream, W0);
 }
 
 extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *workspace, float *out, void *pad_bf16,

@@ -44,6 +44,9 @@ FUSED_BWD_APPLY = os.environ.get("CPFN_FUSED_BWD_APPLY", "1") != "0"
 # small layers (<= 16384 rows): apply pass inside cpfn_mlp_wgrad_apply / cpfn_mlp_dgrad_small, the reduction of the layer
 # below on that data gradient (5 -> 3 launches per layer); CPFN_SMALL_BWD_FUSED=0: the separate kernels
 SMALL_BWD_FUSED = os.environ.get("CPFN_SMALL_BWD_FUSED", "1") != "0"
+# the backward pass of an fp32-xyz first layer and of the 64 -> 64 layer after it (sa1) recompute the first layer's pre-BN
+# output from the coordinates instead of reading it (3 x 67 MB per step); CPFN_XYZ_RECOMPUTE=0 reads the stored tensor
+XYZ_RECOMPUTE = os.environ.get("CPFN_XYZ_RECOMPUTE", "1") != "0"
 # CPFN_FWD_ROWS=1: forward 128 -> 128 layers at >= 32768 rows through cpfn_mlp_gemm_rows (8 waves, one row pipeline per
 # workgroup: the data-gradient half of the one-pass backward kernel turned around) instead of the tiled streaming kernel.
 # Bit-identical Y, and 17.6 us per workgroup against 18 us per LAUNCH of the streaming kernel — but off by default: with
@@ -357,7 +360,7 @@ class _FusedStack(torch.autograd.Function):
                     _check(h.cpfn_smallk_fwd(_ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
                            "cpfn_smallk_fwd")
                     _l.add_bytes("cpfn_smallk_fwd", 4 * P * KS + 2 * P * N + 8 * nblk * N)
-                    Wb = None
+                    Wb = w32                      # (the backward pass recomputes this layer's output from x and w32)
                 else:
                     Kp = a.shape[1]
                     Wb = bf16_weight(L.weight, N, Kp)
@@ -488,6 +491,13 @@ class _FusedStack(torch.autograd.Function):
                     dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
                     # (its 1024 x 192-float partials are finished right here by the 64-subset reduce: in the batched
                     #  reduction three workgroups would walk 256 splits each — a 20 us tail, measured)
+                    if folded and XYZ_RECOMPUTE and KS == 3:
+                        # ... with y recomputed from the coordinates: 12 bytes per row instead of 2 N
+                        _check(h.cpfn_smallk_wgrad_apply_xyz(_ptr(g), _ptr(Wb), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in), KS, P,
+                                                             N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad_apply_xyz")
+                        _l.add_bytes("cpfn_smallk_wgrad_apply_xyz", 2 * P * N + 4 * P * KS + 8 * nb * N * KS)
+                        grads[0] = dW.reshape(wshape)
+                        continue
                     if folded:
                         _check(h.cpfn_smallk_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in), KS, P, N,
                                                          _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad_apply")
@@ -502,7 +512,20 @@ class _FusedStack(torch.autograd.Function):
                 ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
                 asc, ash = a_ptrs(a_ss)
                 g_new = None
-                if route == "one_pass":
+                xyz_below = (XYZ_RECOMPUTE and li == 1 and first_fp32 and route == "one_pass" and N == 64 and Kp == 64 and fold_apply
+                             and below_ok and a_ss is not None and saved[0][0].shape[1] == 3 and dseed is None)
+                if xyz_below:
+                    # sa1's second layer: its input (the first layer's pre-BN output) and the y of the riding reduction are
+                    # recomputed from the coordinates inside the kernel — that [P,64] tensor is not read by the backward pass
+                    g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
+                    fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_mlp_bwd_fused_xyz(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(saved[0][0]),
+                                                    _ptr(saved[0][4]), _ptr(Wb), P, asc, ash, _ptr(ws), _ptr(g_new), _ptr(fp_),
+                                                    _stream()), "cpfn_mlp_bwd_fused_xyz")
+                    _l.add_bytes("cpfn_mlp_bwd_fused_xyz", 4 * P * N + 2 * 12 * P + 2 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
+                                 + 8 * splits * Kp)
+                    fused_part = (fp_, splits)
+                elif route == "one_pass":
                     # weight gradient, data gradient, (folded) apply pass and pass 1 of the layer below from ONE read of the
                     # gradient (mlp_bwd_fused_kernel)
                     below = below_ok and Kp != 192

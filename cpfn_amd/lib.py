@@ -98,6 +98,8 @@ SIGNATURES = {
     "cpfn_smallk_fwd": [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad": [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
+    "cpfn_smallk_wgrad_apply_xyz": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
+    "cpfn_mlp_bwd_fused_xyz": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_head_post_chunks": [_i],
     "cpfn_head_post_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_head_post_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],

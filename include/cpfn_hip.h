@@ -427,6 +427,19 @@ CPFN_API int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long
 CPFN_API int cpfn_smallk_wgrad_apply(const void *Gz, const void *Y, const float *coef, const float *y_scale,
                                      const float *y_shift, const float *X, int KS, long long P, int C, float *workspace,
                                      float *dW, void *stream);
+/* ... and with the layer's pre-BN output y = bf16(W0 [C][KS] . X) RECOMPUTED from the coordinates (cpfn_smallk_fwd's
+ * arithmetic) instead of read: the backward pass of an fp32-xyz first layer then never touches its [P,C] output. */
+CPFN_API int cpfn_smallk_wgrad_apply_xyz(const void *Gz, const float *W0, const float *coef, const float *y_scale,
+                                         const float *y_shift, const float *X, int KS, long long P, int C,
+                                         float *workspace, float *dW, void *stream);
+/* cpfn_mlp_bwd_fused for the 64 -> 64 layer that FOLLOWS such a first layer (sa1): its input operand (before the BN + ReLU
+ * transform a_scale / a_shift) and the y of the riding reduction are both that first layer's pre-BN output, recomputed
+ * from X [P,3] and W0 [64][3]; apply pass folded in (Gz, Yr, apply_coef, y_scale, y_shift as in cpfn_mlp_bwd_fused);
+ * stats_partial [cpfn_mlp_wgrad_splits(P,64,64)][2][64]. */
+CPFN_API int cpfn_mlp_bwd_fused_xyz(const void *Gz, const void *Yr, const float *apply_coef, const float *y_scale,
+                                    const float *y_shift, const float *X, const float *W0, const void *W, long long P,
+                                    const float *a_scale, const float *a_shift, float *workspace, void *Gout,
+                                    float *stats_partial, void *stream);
 
 /* ------------------------------------------------------------------ loss-side fusions
  * (the callers on the far side of the fitters.)  K <= 32 for the training-side

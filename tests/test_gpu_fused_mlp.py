@@ -337,7 +337,7 @@ def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_f
         res[cfg] = _run(x, convs, bns, torch.bfloat16, pool_k, xyz, gout)
         census = _l.byte_census(False)
         assert ("cpfn_mlp_bwd_fused" in census) == one_pass, sorted(census)
-        assert ("cpfn_smallk_wgrad_apply" in census) == (apply_fused and use_xyz), sorted(census)
+        assert (("cpfn_smallk_wgrad_apply" in census) or ("cpfn_smallk_wgrad_apply_xyz" in census)) == (apply_fused and use_xyz), sorted(census)
         if cfg == "one-pass+apply":
             n_apply = census.get("cpfn_bn_bwd_apply", (0, 0))[0]
             if name != "fc1-like":     # every eligible layer lost its stand-alone apply launch
@@ -421,3 +421,25 @@ def test_forward_row_streaming_kernel(P, K, N, atr):
     yf = res[True][0].float()
     ref = torch.stack([yf.double().sum(0), (yf.double() ** 2).sum(0)])
     assert _rel(res[True][1], ref) < 1e-5
+
+
+@pytest.mark.parametrize("P,widths,pool_k", [(643 * 64, [64, 64, 128], 64), (40000 + 16, [64, 64], None)])
+def test_first_layer_output_recomputed_in_backward(P, widths, pool_k, monkeypatch):
+    """sa1: the fp32-xyz first layer's pre-BN output, recomputed from the coordinates inside cpfn_smallk_wgrad_apply_xyz and
+    cpfn_mlp_bwd_fused_xyz instead of read (three reads of a [P,64] tensor): every gradient bit-identical."""
+    from cpfn_amd import fused_mlp, lib as _l
+    convs, bns = _stack(3, widths, seed=19)
+    g = torch.Generator().manual_seed(P)
+    xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev())
+    gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
+    res = {}
+    for rec in (True, False):
+        monkeypatch.setattr(fused_mlp, "XYZ_RECOMPUTE", rec)
+        _l.byte_census(True)
+        res[rec] = _run(None, convs, bns, torch.bfloat16, pool_k, xyz, gout)
+        census = _l.byte_census(False)
+        assert ("cpfn_mlp_bwd_fused_xyz" in census) == rec and ("cpfn_smallk_wgrad_apply_xyz" in census) == rec, sorted(census)
+    (ya, _, gra, _), (yb, _, grb, _) = res[True], res[False]
+    assert torch.equal(ya, yb)
+    for a, b in zip(gra, grb):
+        assert (a is None and b is None) or torch.equal(a, b)
