@@ -1539,8 +1539,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   }
   // APPLY: the five per-channel vectors wait in LDS and are re-read at every stage (40 registers otherwise: with them
   // the <128,128> kernel needs 237, and two such waves plus a 56-register wave of the geometry branch do not fit one SIMD)
-  __shared__ __attribute__((aligned(16))) float s_cf[APPLY ? 5 * TN : 4];
-  if (APPLY) {
+  // (64-row-step shapes — sa1, after the geometry work has ended, bound by VALU + LDS issue rather than memory — keep them
+  //  in registers: 10 LDS reads per stage less)
+  constexpr bool COEF_REGS = APPLY != 0 && STEP == 64;
+  __shared__ __attribute__((aligned(16))) float s_cf[APPLY && !COEF_REGS ? 5 * TN : 4];
+  float cfr[COEF_REGS ? 5 : 1][8];
+  if (COEF_REGS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cfr[0][j] = ap.coef[gcol + j]; cfr[1][j] = ap.coef[TN + gcol + j]; cfr[2][j] = ap.coef[2 * TN + gcol + j];
+      cfr[COEF_REGS ? 3 : 0][j] = ap.y_scale[gcol + j]; cfr[COEF_REGS ? 4 : 0][j] = ap.y_shift[gcol + j];
+    }
+  } else if (APPLY) {
     for (int e = t; e < 3 * TN; e += NT) s_cf[e] = ap.coef[e];
     if (t < TN) { s_cf[3 * TN + t] = ap.y_scale[t]; s_cf[4 * TN + t] = ap.y_shift[t]; }
     // (visible after the first barrier of the step loop)
@@ -1578,7 +1588,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   };
   auto stage = [&](int sidx, long long base) {
     float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];
-    if (APPLY) {
+    if (APPLY && COEF_REGS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { cf0[j] = cfr[0][j]; cf1[j] = cfr[1][j]; cf2[j] = cfr[2][j]; ysc[j] = cfr[3][j]; ysh[j] = cfr[4][j]; }
+    } else if (APPLY) {
       int zero;                                        // opaque 0: keeps these loop-invariant reads INSIDE the loop
       asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
       const float *cp = &s_cf[gcol + zero];
