@@ -486,7 +486,7 @@ __global__ __launch_bounds__(TPB) void group_concat_bf16_kernel(const unsigned s
 // Up to MC_MAX contiguous buffers copied by ONE launch (16-byte pieces, grid-stride inside each buffer's block
 // range): the trainer's static-buffer hand-overs (geometry set B -> A, a new batch into the input buffers) are
 // ~20 tensors of a few MB each; torch's multi-tensor copy takes ~25 us for them, a memcpy node per tensor more.
-constexpr int MC_MAX = 40;
+constexpr int MC_MAX = 96;   // (2.7 KB of kernel arguments; the ~57 gradient tensors of a step fit one launch — 40 needed two)
 struct McArgs {
   const void *src[MC_MAX];
   void *dst[MC_MAX];
