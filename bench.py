@@ -42,7 +42,7 @@ ROOFLINE_SYMBOL = "cpfn_mlp_gemm"
 # kernel families that time themselves (in-kernel probe): C-ABI entry points whose algorithmic bytes the census counts
 FAMILIES = {"cpfn_mlp_gemm": ("cpfn_mlp_gemm", "cpfn_mlp_dgrad_small"),
             "cpfn_mlp_wgrad": ("cpfn_mlp_wgrad", "cpfn_mlp_wgrad_apply"),
-            "cpfn_mlp_bwd_fused": ("cpfn_mlp_bwd_fused",)}
+            "cpfn_mlp_bwd_fused": ("cpfn_mlp_bwd_fused", "cpfn_mlp_bwd_fused_xyz")}
 KIND_FAMILY = {1: "cpfn_mlp_gemm", 2: "cpfn_mlp_gemm", 3: "cpfn_mlp_gemm", 4: "cpfn_mlp_wgrad", 5: "cpfn_mlp_bwd_fused"}
 
 

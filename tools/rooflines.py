@@ -39,7 +39,8 @@ ENTRY = {
 }
 # entry points that launch a kernel family of another entry point: their algorithmic bytes are added to that family
 CENSUS_MERGE = {"cpfn_mlp_dgrad_small": "cpfn_mlp_gemm", "cpfn_mlp_wgrad_apply": "cpfn_mlp_wgrad",
-                "cpfn_smallk_wgrad_apply": "cpfn_smallk_wgrad"}
+                "cpfn_smallk_wgrad_apply": "cpfn_smallk_wgrad", "cpfn_smallk_wgrad_apply_xyz": "cpfn_smallk_wgrad",
+                "cpfn_mlp_bwd_fused_xyz": "cpfn_mlp_bwd_fused"}
 HBM_PEAK = 8.0e12
 CLOCK_HZ, N_SIMD = 2.4e9, 1024
 
