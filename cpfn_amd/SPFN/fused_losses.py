@@ -257,6 +257,7 @@ def hungarian_cost_pack(S, I_gt, n_gt=None):
     cost = D / den.clamp(min=1e-10)
     if n_gt is None:
         n_gt = count_gt(I_gt)
+    _drop_pending_n_gt()
     return torch.cat([cost.reshape(B, -1), n_gt.unsqueeze(1).to(cost.dtype)], dim=1)
 
 
@@ -278,10 +279,18 @@ def hungarian_from_pack(pack, K):
     return hungarian_host(pack.cpu(), K).to(pack.device)
 
 
+def _drop_pending_n_gt():
+    """The count left by a heads pass belongs to THAT batch's loss computation: any later stage of it drops an unclaimed one,
+    so that it can never answer a count_gt() of a different batch that happens to live at the same address."""
+    global _n_gt_of_last_heads_pass
+    _n_gt_of_last_heads_pass = None
+
+
 def hungarian_device(S, n_gt):
     """The assignment on the device (cpfn_hungarian_match): S [B,K+2,K] from SegStats, n_gt [B] int64 ->
     match [B,K] int64.  Same solver and tie-breaking as the SciPy call of the reference
     (losses_implementation.py:27), no host round trip, capturable."""
+    _drop_pending_n_gt()
     B, K2, K = S.shape
     Sc = S.detach().contiguous().float()
     match = torch.empty(B, K, dtype=torch.long, device=S.device)
@@ -350,6 +359,7 @@ def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=Non
     T_gt = batch["T_gt"]
     if n_gt is None:
         n_gt = count_gt(batch["I_gt"])
+    _drop_pending_n_gt()
     rp = None
     if m["residue"] > 0 or m["parameter"] > 0:
         if params is None:
