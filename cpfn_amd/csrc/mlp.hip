@@ -1982,28 +1982,40 @@ struct MsrArgs {
   long long n[MSR_MAX];
   int splits[MSR_MAX];
   int row_in[MSR_MAX], row_out[MSR_MAX];   // 0, 0: flat; else only the first row_out of every row_in elements are kept
+  int deep[MSR_MAX];           // few outputs, many splits: 16 elements x 16 split-subsets per workgroup instead of 64 x 4
   int block0[MSR_MAX + 1];     // first workgroup of buffer i
   int count;
 };
 __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
-  // 64 consecutive elements x 4 split-subsets per workgroup: 256-byte coalesced rows of the partial buffers
-  __shared__ float s_acc[4][64];
+  // 64 consecutive elements x 4 split-subsets per workgroup: 256-byte coalesced rows of the partial buffers.  "deep"
+  // buffers (the 192 outputs x 1024 partials of the fp32-xyz layer, the 35 x 512 of the heads' bias: three / one workgroup
+  // walking 256 / 128 rows each was a 20 us serial tail of this launch, which is why they had their own launches): 16 x 16.
+  __shared__ float s_acc[16][64];
   int d = 0;
   while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
   const float *__restrict__ partial = a.partial[d];
   const long long n = a.n[d];
   const int splits = a.splits[d];
-  const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
-  const long long e = (long long)(blockIdx.x - a.block0[d]) * 64 + lane;
+  const bool deep = a.deep[d] != 0;
+  const int epw = deep ? 16 : 64, nsub = deep ? 16 : 4;
+  const int lane = deep ? (threadIdx.x & 15) : (threadIdx.x & 63), r = deep ? (threadIdx.x >> 4) : (threadIdx.x >> 6);
+  const long long e = (long long)(blockIdx.x - a.block0[d]) * epw + lane;
   float acc = 0.f;
   if (e < n) {
 #pragma unroll 4
-    for (int i = r; i < splits; i += 4) acc += partial[(size_t)i * n + e];
+    for (int i = r; i < splits; i += nsub) acc += partial[(size_t)i * n + e];
   }
   s_acc[r][lane] = acc;
   __syncthreads();
   if (r == 0 && e < n) {
-    const float v = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+    float v;
+    if (deep) {
+      v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += s_acc[q][lane];
+    } else {
+      v = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+    }
     const int ri = a.row_in[d];
     if (ri == 0) {
       a.out[d][e] = v;
@@ -2762,8 +2774,9 @@ extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count,
           (d.row_in > 0 && (d.row_out == 0 || d.n % d.row_in))) return CPFN_EINVAL;
       a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
       a.row_in[i] = d.row_in; a.row_out[i] = d.row_out;
+      a.deep[i] = d.n <= 1024 && d.splits >= 128;
       a.block0[i] = blocks;
-      blocks += cpfn_cdiv(d.n, 64);
+      blocks += cpfn_cdiv(d.n, a.deep[i] ? 16 : 64);
     }
     a.block0[a.count] = blocks;
     if (blocks) multi_split_reduce_kernel<<<blocks, 256, 0, st>>>(a);

@@ -489,20 +489,21 @@ class _FusedStack(torch.autograd.Function):
                     nb = h.cpfn_bn_bwd_blocks(P)
                     ws = torch.empty(nb * N * KS, dtype=torch.float32, device=dev)
                     dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
-                    # (its 1024 x 192-float partials are finished right here by the 64-subset reduce: in the batched
-                    #  reduction three workgroups would walk 256 splits each — a 20 us tail, measured)
+                    # (its 1024 x 192-float partials join the batched split reduction: that launch walks "deep" buffers
+                    #  with 16 split subsets per 16 outputs)
+                    _defer_reduction(ws, dW, N * KS, nb)
                     if folded and XYZ_RECOMPUTE and KS == 3:
                         # ... with y recomputed from the coordinates: 12 bytes per row instead of 2 N
                         _check(h.cpfn_smallk_wgrad_apply_xyz(_ptr(g), _ptr(Wb), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in), KS, P,
-                                                             N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad_apply_xyz")
+                                                             N, _ptr(ws), None, _stream()), "cpfn_smallk_wgrad_apply_xyz")
                         _l.add_bytes("cpfn_smallk_wgrad_apply_xyz", 2 * P * N + 4 * P * KS + 8 * nb * N * KS)
                         grads[0] = dW.reshape(wshape)
                         continue
                     if folded:
                         _check(h.cpfn_smallk_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in), KS, P, N,
-                                                         _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad_apply")
+                                                         _ptr(ws), None, _stream()), "cpfn_smallk_wgrad_apply")
                     else:
-                        _check(h.cpfn_smallk_wgrad(_ptr(Gy), _ptr(a_in), KS, P, N, _ptr(ws), _ptr(dW), _stream()), "cpfn_smallk_wgrad")
+                        _check(h.cpfn_smallk_wgrad(_ptr(Gy), _ptr(a_in), KS, P, N, _ptr(ws), None, _stream()), "cpfn_smallk_wgrad")
                     _l.add_bytes("cpfn_smallk_wgrad_apply" if folded else "cpfn_smallk_wgrad",
                                  (4 if folded else 2) * P * N + 4 * P * KS + 8 * nb * N * KS)
                     grads[0] = dW.reshape(wshape)
@@ -694,8 +695,10 @@ class _Linear(torch.autograd.Function):
         gbias = torch.empty(N, dtype=torch.float32, device=a.device)
         wsb = torch.empty(((P + 255) // 256) * N, dtype=torch.float32, device=a.device)
         with torch.cuda.device(a.device):
-            _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), _ptr(gbias), _ptr(gb) if fused_pad else None, _stream()),
+            # (its 512 x 35 partials are finished by the batched split reduction at the end of the backward pass)
+            _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), None, _ptr(gb) if fused_pad else None, _stream()),
                    "cpfn_colsum_f32")
+            _defer_reduction(wsb, gbias, N, (P + 255) // 256)
             _l.add_bytes("cpfn_colsum_f32", 4 * P * N + (2 * P * Np if fused_pad else 0))
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
