@@ -147,13 +147,15 @@ class FitParams(torch.autograd.Function):
             st = _stream()
             _l.check(h.cpfn_fit_moments_fwd(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), st), "cpfn_fit_moments_fwd")
             _l.check(h.cpfn_fit_algebra_fwd(_ptr(M), G, _ptr(alg), _ptr(cone_in), st), "cpfn_fit_algebra_fwd")
-            _l.check(h.cpfn_cone_pass_fwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), B, N, K, _ptr(ws), _ptr(sums),
-                                          st), "cpfn_cone_pass_fwd")
-            _l.check(h.cpfn_fit_pack_fwd(_ptr(alg), _ptr(sums), _ptr(M), G, _ptr(params), st), "cpfn_fit_pack_fwd")
+            # (the cone pass leaves its per-chunk partials in ws; the pack launch sums them: 3 launches, not 4)
+            _l.check(h.cpfn_cone_pass_fwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), B, N, K, _ptr(ws), None, st),
+                     "cpfn_cone_pass_fwd")
+            _l.check(h.cpfn_fit_pack_fwd_partials(_ptr(alg), _ptr(ws), B, N, K, _ptr(M), _ptr(sums), _ptr(params), st),
+                     "cpfn_fit_pack_fwd_partials")
         _l.add_bytes("cpfn_fit_moments_fwd", 4 * B * N * (6 + K) + 8 * (chunks + 1) * B * K * SLOTS)
         _l.add_bytes("cpfn_fit_algebra_fwd", 8 * G * (SLOTS + 21) + 24 * G)
         _l.add_bytes("cpfn_cone_pass_fwd", 4 * B * N * (3 + K) + 24 * G + 16 * (chunks + 1) * G)
-        _l.add_bytes("cpfn_fit_pack_fwd", 8 * G * (21 + 2 + SLOTS) + 88 * G)
+        _l.add_bytes("cpfn_fit_pack_fwd_partials", 8 * G * (21 + 2 + SLOTS) + 88 * G)
         ctx.save_for_backward(P, X, W, M, cone_in, sums)
         return params
 

@@ -531,6 +531,34 @@ __global__ void fit_pack_fwd_kernel(const double *__restrict__ alg, const double
   p[21] = (float)(h < PK_LO ? PK_LO : (h > PK_HI ? PK_HI : h));   // NaN stays NaN, like torch.clamp
 }
 
+// The same with the chunk reduction of the cone pass folded in (cpfn_cone_pass_fwd with out = NULL leaves its per-chunk
+// partials [B][chunks][K][2] behind): sums[g] = Σ_c partial — chunk_reduce_kernel's order, so the same bits — is formed
+// here and written out for the backward pass; one launch instead of two.
+__global__ void fit_pack_fwd_partials_kernel(const double *__restrict__ alg, const double *__restrict__ cone_ws, int chunks,
+                                             int K, const double *__restrict__ M, long long G, double *__restrict__ sums,
+                                             float *__restrict__ params) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  const long long b = g / K;
+  const int k = (int)(g - b * K);
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+  for (int c = 0; c < chunks; ++c) {
+    const double *w = cone_ws + ((size_t)b * chunks + c) * K * 2 + k * 2;
+    s0 += w[0];
+    s1 += w[1];
+  }
+  sums[g * 2] = s0;
+  sums[g * 2 + 1] = s1;
+  const double *a = alg + g * 21;
+  float *p = params + g * 22;
+  for (int i = 0; i < 18; ++i) p[i] = (float)a[i];
+  const double sgn = cone_sign(s0);
+  for (int i = 18; i < 21; ++i) p[i] = (float)(a[i] * sgn);
+  const double h = s1 / (M[g * FM_SLOTS] + PK_EPS);
+  p[21] = (float)(h < PK_LO ? PK_LO : (h > PK_HI ? PK_HI : h));   // NaN stays NaN, like torch.clamp
+}
+
 // adjoint: g_alg[G,21] (all columns written), g_acos[G] (fp32, feeds the cone pass adjoint), gA0[G] (slot 0 of M)
 __global__ void fit_pack_bwd_kernel(const float *__restrict__ gparams, const double *__restrict__ sums,
                                     const double *__restrict__ M, long long G, double *__restrict__ g_alg,
@@ -588,14 +616,27 @@ extern "C" int cpfn_fit_moments_bwd(const float *P, const float *X, const float 
 
 extern "C" int cpfn_cone_pass_fwd(const float *P, const float *W, const float *apex, const float *axis, int B,
                                   int N, int K, double *workspace, double *out, void *stream) {
-  if (B < 0 || N <= 0 || K <= 0 || !P || !W || !apex || !axis || !workspace || !out) return CPFN_EINVAL;
+  if (B < 0 || N <= 0 || K <= 0 || !P || !W || !apex || !axis || !workspace) return CPFN_EINVAL;
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int ppb;
   const int chunks = pick_chunks(B, N, &ppb);
   cone_fwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, W, apex, axis, N, K, ppb, workspace);
-  const long long total = (long long)B * K * 2;
-  chunk_reduce_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * 2, total, out);
+  if (out) {       // NULL: the per-chunk partials stay in workspace for cpfn_fit_pack_fwd_partials
+    const long long total = (long long)B * K * 2;
+    chunk_reduce_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * 2, total, out);
+  }
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_fit_pack_fwd_partials(const double *alg, const double *cone_workspace, int B, int N, int K,
+                                          const double *M, double *sums, float *params, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || !alg || !cone_workspace || !M || !sums || !params) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  int ppb;
+  const int chunks = pick_chunks(B, N, &ppb);
+  const long long G = (long long)B * K;
+  fit_pack_fwd_partials_kernel<<<cpfn_cdiv(G, 64), 64, 0, (hipStream_t)stream>>>(alg, cone_workspace, chunks, K, M, G, sums, params);
   return cpfn_launch_status();
 }
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "cpfn_fit_algebra_fwd": [_vp, _i64, _vp, _vp, _vp],
     "cpfn_fit_algebra_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "cpfn_fit_pack_fwd": [_vp, _vp, _vp, _i64, _vp, _vp],
+    "cpfn_fit_pack_fwd_partials": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_fit_pack_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "cpfn_nonfinite_flag": [_vp, _ll, _vp, _vp, _vp],
     "cpfn_adam_flat": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],

@@ -255,6 +255,11 @@ CPFN_API int cpfn_fit_algebra_bwd(const double *M, const double *gout, const dou
  * g_acos[G] fp32 (for cpfn_cone_pass_bwd) and gA0[G] (for cpfn_fit_algebra_bwd). */
 CPFN_API int cpfn_fit_pack_fwd(const double *alg, const double *sums, const double *M, int64_t G,
                                float *params, void *stream);
+/* The same with the cone pass's chunk reduction folded in: cpfn_cone_pass_fwd(..., out = NULL) leaves its per-chunk
+ * partials in its workspace; this launch sums them (same order, same bits), writes sums[B,K,2] for the backward pass and
+ * packs the parameters. */
+CPFN_API int cpfn_fit_pack_fwd_partials(const double *alg, const double *cone_workspace, int B, int N, int K,
+                                        const double *M, double *sums, float *params, void *stream);
 CPFN_API int cpfn_fit_pack_bwd(const float *gparams, const double *sums, const double *M, int64_t G,
                                double *g_alg, float *g_acos, double *gA0, void *stream);
 
