@@ -1484,12 +1484,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   constexpr int CHB = TK / 16, TPW = (STEP / 16) * CHB / 8;   // 16-channel blocks of the data-gradient slab, its tiles per wave
   static_assert(NG >= 1 && NA >= 1 && TA <= NT && (WG_STEP * WG_DEPTH) % (STEP * DEPTH) == 0 && (STEP / 16) * CHB == 8 * TPW, "shape");
   static_assert(!BST || (64 % CPRA == 0), "the riding reduction needs a power-of-two chunk count per row");
-  __shared__ __attribute__((aligned(16))) unsigned short s_g[STEP * LDN];
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[STEP * LDK];
-  __shared__ __attribute__((aligned(16))) unsigned short s_o[STEP * LDK];
+  // DB (the 64-row-step shapes: sa1, bound by VALU + LDS issue rather than memory, and run after the geometry work, so
+  // their LDS footprint is free): the three row tiles are double-buffered by step parity, which leaves ONE barrier per step
+  // (stage -> barrier -> store previous slab / MFMAs) instead of two — the waves may drift a step apart and the VALU-heavy
+  // staging of one overlaps the LDS / MFMA phase of another.
+  constexpr bool DB = STEP == 64;
+  static_assert(!DB || DEPTH % 2 == 0, "the buffer of a step is its pipeline slot's parity");
+  __shared__ __attribute__((aligned(16))) unsigned short s_g2[DB ? 2 : 1][STEP * LDN];
+  __shared__ __attribute__((aligned(16))) unsigned short s_a2[DB ? 2 : 1][STEP * LDK];
+  __shared__ __attribute__((aligned(16))) unsigned short s_o2[DB ? 2 : 1][STEP * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short s_wt[TK * LDN];
   static_assert(!BST || sizeof(float) * 8 * 2 * TK <= sizeof(unsigned short) * STEP * LDN, "the statistics reduction reuses s_g");
-  float(*s_red)[2][TK] = (float(*)[2][TK])s_g;      // cross-wave reduction of the statistics: after the last step only
+  float(*s_red)[2][TK] = (float(*)[2][TK])s_g2[0];  // cross-wave reduction of the statistics: after the last step only
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lq = lane >> 4;
   const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
   float *o = partial + (size_t)blockIdx.z * TN * TK;
@@ -1510,7 +1516,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   const bool a_live = TA == NT || t < TA;
   uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[XYZ ? 1 : DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
   static_assert(!XYZ || (BST && TK <= 64), "XYZ: the recomputed tensor is the input AND the y of the riding reduction");
-  float vx[XYZ ? DEPTH : 1][NA][3], xb[XYZ ? NA : 1][3], w0r[XYZ ? 8 : 1][3];   // coordinate rows in flight / of the pending slab
+  float vx[XYZ ? DEPTH : 1][NA][3], xb[XYZ && DB ? 2 : 1][XYZ ? NA : 1][3], w0r[XYZ ? 8 : 1][3];   // coordinate rows in flight / of the pending slab
   if (XYZ) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -1519,15 +1525,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   }
   // y0 chunk (8 channels of one row) from its coordinates: smallk_fwd_kernel's arithmetic
   auto y0_chunk = [&](const float (&x)[3]) {
-    unsigned short o[8];
+    unsigned ow[4];      // (packed by shifts: reading a uint4 back out of an unsigned short array is type punning)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float v = 0.f;
+    for (int j = 0; j < 4; ++j) {
+      float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) v = fmaf(w0r[XYZ ? j : 0][q], x[q], v);
-      o[j] = f2bf(v);
+      for (int q = 0; q < 3; ++q) {
+        v0 = fmaf(w0r[XYZ ? 2 * j : 0][q], x[q], v0);
+        v1 = fmaf(w0r[XYZ ? 2 * j + 1 : 0][q], x[q], v1);
+      }
+      ow[j] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
     }
-    return *(const uint4 *)o;
+    return (uint4){ow[0], ow[1], ow[2], ow[3]};
   };
   uint4 vgp[APPLY == 2 ? DEPTH : 1], vya[APPLY == 2 ? DEPTH : 1];       // pooled gradient / arg-max value of the step's group
   uint2 var_[APPLY == 2 ? DEPTH : 1];                                    // arg-max row (8 channels, one byte each)
@@ -1586,7 +1595,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       }
     }
   };
-  auto stage = [&](int sidx, long long base) {
+  auto stage = [&](int sidx, long long base, int buf) {
+    unsigned short *s_g = s_g2[buf], *s_a = s_a2[buf];
     float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];
     if (APPLY && COEF_REGS) {
 #pragma unroll
@@ -1665,7 +1675,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
         if (XYZ) {
           a4 = y0_chunk(vx[sidx][i]);
 #pragma unroll
-          for (int q = 0; q < 3; ++q) xb[i][q] = vx[sidx][i][q];       // this step's slab is stored one step later
+          for (int q = 0; q < 3; ++q) xb[XYZ && DB ? buf : 0][i][q] = vx[sidx][i][q];   // this step's slab is stored one step later
         } else {
           a4 = va[sidx][i];
         }
@@ -1678,7 +1688,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // the STEP x TK data-gradient slab of the PREVIOUS step leaves here (its LDS patch was completed before this step's
   // first barrier): NA 16-byte pieces per thread
   uint4 yb[NA];
-  auto store_prev = [&](long long pbase) {
+  auto store_prev = [&](long long pbase, int buf) {
+    const unsigned short *s_o = s_o2[buf];
     if (!a_live) return;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -1688,7 +1699,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       if (p < p1) {
         *(uint4 *)(Gout + p * ldo + acol) = v;
         if (BST) {
-          const uint4 ybv = XYZ ? y0_chunk(xb[XYZ ? i : 0]) : yb[i];
+          const uint4 ybv = XYZ ? y0_chunk(xb[XYZ && DB ? buf : 0][XYZ ? i : 0]) : yb[i];
           const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {ybv.x, ybv.y, ybv.z, ybv.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1711,10 +1722,24 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const long long base = base0 + (long long)d * STEP;
-      __syncthreads();
-      if (prev >= 0) store_prev(prev);
-      stage(d, base);
-      __syncthreads();
+      constexpr int dummy_ = 0; (void)dummy_;
+      const int buf = DB ? (d & 1) : 0;
+      unsigned short *s_g = s_g2[buf], *s_a = s_a2[buf], *s_o = s_o2[buf];
+      if (DB && !XYZ) {
+        stage(d, base, buf);
+        __syncthreads();            // the only barrier of the step (see DB above)
+        if (prev >= 0) store_prev(prev, buf ^ 1);
+      } else {
+        // (XYZ keeps both barriers: with one, this instantiation alone returned run-to-run different weight gradients
+        //  inside a stack — 20 of 20 runs — while stand-alone replays of the same launch were reproducible; the ordering
+        //  argument above holds for it like for the others and its ISA shows the expected barriers and buffer offsets, so
+        //  the cause is not understood.  The other single-barrier instantiations: 120 stack runs and every parity test
+        //  bit-identical to the two-kernel path.)
+        __syncthreads();
+        if (prev >= 0) store_prev(prev, DB ? buf ^ 1 : 0);
+        stage(d, base, buf);
+        __syncthreads();
+      }
       issue(d, base + STEP * DEPTH);
       if (BST && !XYZ) {       // this step's slab, used one step later
 #pragma unroll
@@ -1781,7 +1806,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     }
   }
   __syncthreads();
-  store_prev(prev);
+  store_prev(prev, DB ? (DEPTH - 1) & 1 : 0);
   // D[row = n-local 4(lane>>4)+r][col = k-local lane&15]
 #pragma unroll
   for (int i = 0; i < MI; ++i)

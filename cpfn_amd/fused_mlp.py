@@ -47,6 +47,10 @@ SMALL_BWD_FUSED = os.environ.get("CPFN_SMALL_BWD_FUSED", "1") != "0"
 # the backward pass of an fp32-xyz first layer and of the 64 -> 64 layer after it (sa1) recompute the first layer's pre-BN
 # output from the coordinates instead of reading it (3 x 67 MB per step); CPFN_XYZ_RECOMPUTE=0 reads the stored tensor
 XYZ_RECOMPUTE = os.environ.get("CPFN_XYZ_RECOMPUTE", "1") != "0"
+# ... in the 64 -> 64 layer's one-pass kernel too (cpfn_mlp_bwd_fused_xyz).  Off by default: that shape is bound by VALU +
+# LDS issue, the 134 MB it no longer reads bought 2 us of 65, and the plain instantiation runs with one barrier per step
+# (which this one cannot, see mlp_bwd_fused_kernel) — the plain one is faster.
+XYZ_ONEPASS = os.environ.get("CPFN_XYZ_ONEPASS", "0") == "1"
 # CPFN_FWD_ROWS=1: forward 128 -> 128 layers at >= 32768 rows through cpfn_mlp_gemm_rows (8 waves, one row pipeline per
 # workgroup: the data-gradient half of the one-pass backward kernel turned around) instead of the tiled streaming kernel.
 # Bit-identical Y, and 17.6 us per workgroup against 18 us per LAUNCH of the streaming kernel — but off by default: with
@@ -513,7 +517,7 @@ class _FusedStack(torch.autograd.Function):
                 ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
                 asc, ash = a_ptrs(a_ss)
                 g_new = None
-                xyz_below = (XYZ_RECOMPUTE and li == 1 and first_fp32 and route == "one_pass" and N == 64 and Kp == 64 and fold_apply
+                xyz_below = (XYZ_RECOMPUTE and XYZ_ONEPASS and li == 1 and first_fp32 and route == "one_pass" and N == 64 and Kp == 64 and fold_apply
                              and below_ok and a_ss is not None and saved[0][0].shape[1] == 3 and dseed is None)
                 if xyz_below:
                     # sa1's second layer: its input (the first layer's pre-BN output) and the y of the riding reduction are

@@ -433,13 +433,16 @@ def test_first_layer_output_recomputed_in_backward(P, widths, pool_k, monkeypatc
     xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev())
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
     res = {}
-    for rec in (True, False):
+    for rec, onepass in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(fused_mlp, "XYZ_RECOMPUTE", rec)
+        monkeypatch.setattr(fused_mlp, "XYZ_ONEPASS", onepass)       # (off by default: see fused_mlp.XYZ_ONEPASS)
         _l.byte_census(True)
-        res[rec] = _run(None, convs, bns, torch.bfloat16, pool_k, xyz, gout)
+        res[(rec, onepass)] = [_run(None, convs, bns, torch.bfloat16, pool_k, xyz, gout) for _ in range(3)]
         census = _l.byte_census(False)
-        assert ("cpfn_mlp_bwd_fused_xyz" in census) == rec and ("cpfn_smallk_wgrad_apply_xyz" in census) == rec, sorted(census)
-    (ya, _, gra, _), (yb, _, grb, _) = res[True], res[False]
-    assert torch.equal(ya, yb)
-    for a, b in zip(gra, grb):
-        assert (a is None and b is None) or torch.equal(a, b)
+        assert ("cpfn_mlp_bwd_fused_xyz" in census) == onepass and ("cpfn_smallk_wgrad_apply_xyz" in census) == rec, sorted(census)
+    ref = res[(False, False)][0]
+    for key, runs in res.items():
+        for (ya, _, gra, _) in runs:             # every run of every variant: the same bits
+            assert torch.equal(ya, ref[0]), key
+            for a, b in zip(gra, ref[2]):
+                assert (a is None and b is None) or torch.equal(a, b), key
