@@ -292,8 +292,8 @@ def main():
         sv_t = trainer._graph.get("stamps") if getattr(trainer, "_graph", None) else None
         marks = np.zeros(4)
         for _ in range(reps):
-            for _ in range(3):
-                trainer.step(batch, next_batch=batch)
+            for _ in range(3):      # CPFN_PROBE_NO_ANNOUNCE=1: the step's graph WITHOUT the next batch's geometry beside it
+                trainer.step(batch, next_batch=None if os.environ.get("CPFN_PROBE_NO_ANNOUNCE") == "1" else batch)
             sync()
             q = probe.cpu().numpy()
             recs = []

@@ -33,6 +33,7 @@ PARALLEL_BRANCHES = os.environ.get("CPFN_PARALLEL_BRANCHES", "0") == "1"
 SEG_FUSED = os.environ.get("CPFN_SEG_FUSED", "1") != "0"
 # ... and their adjoint added to gW inside cpfn_head_post_bwd (CPFN_SEG_BWD_FUSED=0: cpfn_seg_stats_bwd + the framework's
 # gradient-accumulation add as their own launches)
+MATCH_RIDES = os.environ.get("CPFN_MATCH_RIDES", "1") != "0"     # the assignment as extra workgroups of the moments launch
 SEG_BWD_FUSED = SEG_FUSED and os.environ.get("CPFN_SEG_BWD_FUSED", "1") != "0"
 
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
@@ -300,6 +301,27 @@ def hungarian_device(S, n_gt):
     return match
 
 
+def fit_params_and_match(P, W, Xn, multipliers, S, n_gt):
+    """fit_params + hungarian_device with the assignment riding on the fits' first launch (cpfn_fit_moments_fwd_match:
+    the two are independent; one launch and the shorter of the two durations less on the chain).  Returns (params, match);
+    falls back to the two separate launches when there are no fits to ride on."""
+    if not MATCH_RIDES or not (multipliers["residue"] > 0 or multipliers["parameter"] > 0):
+        return fit_params(P, W, Xn, multipliers), hungarian_device(S, n_gt)
+    from . import moments as _m
+    _drop_pending_n_gt()
+    B, K2, K = S.shape
+    Sc = S.detach().contiguous().float()
+    match = torch.empty(B, K, dtype=torch.long, device=S.device)
+    _m.set_match_rider(Sc, n_gt.contiguous(), match)
+    try:
+        params = fit_params(P, W, Xn, multipliers)
+    finally:
+        left = _m.pending_match_rider()
+    if left is not None:                 # nobody took it (shapes beyond the fused kernels)
+        match = hungarian_device(S, n_gt)
+    return params, match
+
+
 def hungarian_from_stats(S, I_gt):
     return hungarian_from_pack(hungarian_cost_pack(S, I_gt), S.shape[2])
 
@@ -388,7 +410,7 @@ def fused_losses(P, Y, batch, multipliers, classes):
         return li.compute_all_losses(P, W, batch["I_gt"], X, batch["X_gt"], Y[..., 3:7], batch["T_gt"], gt,
                                      batch["points_per_instance"], m["normal"], m["type"], m["miou"], m["residue"],
                                      m["parameter"], m["total"], False, mode_seg='mIoU', classes=classes)[:6]
-    if HOST_ASSIGNMENT or not PARALLEL_BRANCHES:
+    if HOST_ASSIGNMENT:
         Xn, W, nl, tl, S = pre_match(Y, batch)
         n_gt = count_gt(batch["I_gt"])
         if HOST_ASSIGNMENT:
@@ -396,5 +418,10 @@ def fused_losses(P, Y, batch, multipliers, classes):
         else:
             match = hungarian_device(S, n_gt)
         return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt)
+    if not PARALLEL_BRANCHES:
+        Xn, W, nl, tl, S = pre_match(Y, batch)
+        n_gt = count_gt(batch["I_gt"])
+        params, match = fit_params_and_match(P, W, Xn, multipliers, S, n_gt)
+        return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt, params)
     Xn, W, nl, tl, S, n_gt, match, params = match_and_fit(P, Y, batch, multipliers)
     return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt, params)

@@ -120,6 +120,36 @@ class FitAlgebra(torch.autograd.Function):
         return gM
 
 
+# The assignment of the loss section (fused_losses.hungarian_device) can ride on the next FitParams forward launch: the
+# caller leaves (S [B,K+2,K] fp32 contiguous, n_gt [B] int64, match [B,K] int64 to fill) here; FitParams.forward takes it
+# if the shapes fit (K <= 32), else the caller finds it still pending and solves the assignment with its own launch.
+_match_rider = None
+
+
+def set_match_rider(S, n_gt, match):
+    global _match_rider
+    _match_rider = (S, n_gt, match)
+
+
+def pending_match_rider():
+    """The rider if no FitParams launch took it (and forget it)."""
+    global _match_rider
+    r, _match_rider = _match_rider, None
+    return r
+
+
+def _take_match_rider(B, K):
+    global _match_rider
+    r = _match_rider
+    if r is None:
+        return None
+    S, n_gt, match = r
+    if K > 32 or tuple(S.shape) != (B, K + 2, K) or tuple(match.shape) != (B, K) or not (S.is_contiguous() and S.dtype == torch.float32):
+        return None
+    _match_rider = None
+    return r
+
+
 class FitParams(torch.autograd.Function):
     """(P [B,N,3], X [B,N,3] unit normals, W [B,N,K]) -> params [B,K,22] fp32: all four fits of every instance
     in the layout of include/cpfn_hip.h (cpfn_fit_pack_fwd).  The same kernels as FitMoments -> FitAlgebra ->
@@ -145,7 +175,13 @@ class FitParams(torch.autograd.Function):
         G = B * K
         with torch.cuda.device(dev):
             st = _stream()
-            _l.check(h.cpfn_fit_moments_fwd(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), st), "cpfn_fit_moments_fwd")
+            rider = _take_match_rider(B, K)
+            if rider is not None:       # the loss section's assignment as extra workgroups of the moments launch
+                S, n_gt, match = rider
+                _l.check(h.cpfn_fit_moments_fwd_match(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), _ptr(S), _ptr(n_gt),
+                                                      _ptr(match), st), "cpfn_fit_moments_fwd_match")
+            else:
+                _l.check(h.cpfn_fit_moments_fwd(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), st), "cpfn_fit_moments_fwd")
             _l.check(h.cpfn_fit_algebra_fwd(_ptr(M), G, _ptr(alg), _ptr(cone_in), st), "cpfn_fit_algebra_fwd")
             # (the cone pass leaves its per-chunk partials in ws; the pack launch sums them: 3 launches, not 4)
             _l.check(h.cpfn_cone_pass_fwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), B, N, K, _ptr(ws), None, st),

@@ -24,3 +24,40 @@ extern "C" int cpfn_stamp(unsigned long long *dst, void *stream) {
   stamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(dst);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---------------------------------------------------------------- cross-stream ordering by device flags
+// The replayed training step is two linear graphs on two streams (the step; the next batch's geometry).  Ordering them
+// with events — main: wait(geometry written), record(geometry read); side: wait(read), record(written) — costs ~100 us
+// of a 1.9 ms step on this stack whatever the events' flags (each of the four operations alone is free; the closed
+// cross-queue dependency cycle is not; hipStreamWaitValue32 / WriteValue32 are slower still), while a tiny eager kernel
+// between two replays costs nothing.  So the streams order themselves: a one-lane kernel that polls a 4-byte flag until
+// it has reached `value` (agent-scope acquire loads, s_sleep between them), and a one-lane kernel that stores a value
+// (agent-scope release).  The data handed over is written by kernels that precede the setter on its stream and read by
+// kernels that follow the waiter on its stream: kernel boundaries make it visible, exactly as with an event.
+// A waiter gives up after `timeout_ticks` of the 100 MHz wall clock (the setter never came: a host-side error between the
+// two launches), raises *err and lets its stream continue instead of hanging the GPU.
+namespace {
+__global__ void flag_wait_kernel(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err) {
+  const unsigned long long t0 = (unsigned long long)wall_clock64();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+    if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+      if (err) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+__global__ void flag_set_kernel(unsigned *flag, unsigned value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+}
+extern "C" int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err, void *stream) {
+  if (!flag) return -1;
+  flag_wait_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flag, value, timeout_ticks, err);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int cpfn_flag_set(unsigned *flag, unsigned value, void *stream) {
+  if (!flag) return -1;
+  flag_set_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flag, value);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

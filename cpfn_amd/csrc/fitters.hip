@@ -25,6 +25,7 @@
 // The cone's half-angle needs the fitted apex/axis first, so it is a second pass
 // (`cone_pass_*`) over P and W only (SPFN/cone_fitter.py:25-35).
 #include "common.h"
+#include "lsap.h"
 
 namespace {
 
@@ -68,16 +69,28 @@ constexpr int FM_SUB = 4;              // point subsets of a tile (each handled 
 // of LDS per 8 FMAs (1.09 GB of LDS reads per launch = 14 us at the chip's LDS peak, 45 us measured).  Now a lane owns
 // 8 instances x 4 slots (64 B per 32 FMAs) and the 64 points of a tile are split over four lane groups whose partial
 // sums are added in a fixed order at the end.
+// MATCH: the loss section's assignment (lsap.h: one wave per cloud, a ~40 us latency chain on 16 CUs that does not depend
+// on the fits, nor they on it) rides as workgroup x = 0 of every cloud — one launch and ~25 us of chain less than two
+// launches in a row.
+template <bool MATCH>
 __global__ __launch_bounds__(FM_THREADS) void moments_fwd_kernel(const float *__restrict__ P,
                                                                  const float *__restrict__ X,
                                                                  const float *__restrict__ W, int N, int K,
-                                                                 int pts_per_block, double *__restrict__ partial) {
+                                                                 int pts_per_block, double *__restrict__ partial,
+                                                                 const float *__restrict__ seg_S,
+                                                                 const long long *__restrict__ n_gt,
+                                                                 long long *__restrict__ match) {
+  if (MATCH && blockIdx.x == 0) {
+    if (threadIdx.x >= 64) return;            // (the solver's barriers then count one wave)
+    lsap_one_cloud(seg_S, n_gt, K, match, blockIdx.y, threadIdx.x);
+    return;
+  }
   __shared__ __attribute__((aligned(16))) double s_phi[FM_TILE][FM_LDP];     // 27.6 KB; reused for the final combine
   __shared__ __attribute__((aligned(16))) float s_w[FM_TILE][FM_KB];
   __shared__ __attribute__((aligned(16))) float s_wc[FM_TILE][FM_KB];
   static_assert(FM_THREADS == 4 * FM_TILE && FM_TILE * FM_KB == 8 * FM_THREADS, "staging maps below");
   static_assert(FM_SUB * 16 * FM_SLOTS <= FM_TILE * FM_LDP, "combine buffer (half of the instances at a time)");
-  const int b = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x, t = threadIdx.x;
+  const int b = blockIdx.y, chunk = blockIdx.x - (MATCH ? 1 : 0), nchunks = gridDim.x - (MATCH ? 1 : 0), t = threadIdx.x;
   const int n0 = chunk * pts_per_block;
   const int n1 = min(N, n0 + pts_per_block);
   const int sub = t / 52, r52 = t % 52;       // lane group (points sub, sub+4, ... of a tile) and position in it
@@ -584,17 +597,31 @@ extern "C" int cpfn_fit_num_chunks(int B, int N) {
   return pick_chunks(B, N, &ppb);
 }
 
-extern "C" int cpfn_fit_moments_fwd(const float *P, const float *X, const float *W, int B, int N, int K,
-                                    double *workspace, double *M, void *stream) {
+static int fit_moments_fwd(const float *P, const float *X, const float *W, int B, int N, int K, double *workspace, double *M,
+                           const float *seg_S, const int64_t *n_gt, int64_t *match, void *stream) {
   if (B < 0 || N <= 0 || K <= 0 || !P || !X || !W || !workspace || !M) return CPFN_EINVAL;
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int ppb;
   const int chunks = pick_chunks(B, N, &ppb);
-  moments_fwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, X, W, N, K, ppb, workspace);
+  if (seg_S)
+    moments_fwd_kernel<true><<<dim3(chunks + 1, B), FM_THREADS, 0, st>>>(P, X, W, N, K, ppb, workspace, seg_S, (const long long *)n_gt,
+                                                                         (long long *)match);
+  else
+    moments_fwd_kernel<false><<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, X, W, N, K, ppb, workspace, nullptr, nullptr, nullptr);
   const long long total = (long long)B * K * FM_SLOTS;
   chunk_reduce_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * FM_SLOTS, total, M);
   return cpfn_launch_status();
+}
+extern "C" int cpfn_fit_moments_fwd(const float *P, const float *X, const float *W, int B, int N, int K,
+                                    double *workspace, double *M, void *stream) {
+  return fit_moments_fwd(P, X, W, B, N, K, workspace, M, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int cpfn_fit_moments_fwd_match(const float *P, const float *X, const float *W, int B, int N, int K,
+                                          double *workspace, double *M, const float *S, const int64_t *n_gt, int64_t *match,
+                                          void *stream) {
+  if (!S || !n_gt || !match || K > LSAP_MAXK) return CPFN_EINVAL;
+  return fit_moments_fwd(P, X, W, B, N, K, workspace, M, S, n_gt, match, stream);
 }
 
 extern "C" int cpfn_fit_moments_bwd(const float *P, const float *X, const float *W, const float *G, int B,

@@ -2007,7 +2007,7 @@ struct MsrArgs {
   long long n[MSR_MAX];
   int splits[MSR_MAX];
   int row_in[MSR_MAX], row_out[MSR_MAX];   // 0, 0: flat; else only the first row_out of every row_in elements are kept
-  int deep[MSR_MAX];           // few outputs, many splits: 16 elements x 16 split-subsets per workgroup instead of 64 x 4
+  int deep[MSR_MAX];           // 1: few outputs, many splits: 16 elements x 16 split-subsets per workgroup instead of 64 x 4; 2: wide
   int block0[MSR_MAX + 1];     // first workgroup of buffer i
   int count;
 };
@@ -2015,12 +2015,56 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
   // 64 consecutive elements x 4 split-subsets per workgroup: 256-byte coalesced rows of the partial buffers.  "deep"
   // buffers (the 192 outputs x 1024 partials of the fp32-xyz layer, the 35 x 512 of the heads' bias: three / one workgroup
   // walking 256 / 128 rows each was a 20 us serial tail of this launch, which is why they had their own launches): 16 x 16.
-  __shared__ float s_acc[16][64];
+  // "wide" buffers (mode 2: n % 4 == 0, 16-byte aligned — every large weight matrix): 256 elements x 4 subsets, one
+  // float4 per lane and row and eight rows in flight — the launch reads ~250 MB and was latency-bound with 4-byte loads
+  // (3.7 TB/s).  The order of the additions per element is the same in all three modes' common case (subset r adds rows
+  // r, r + 4, ...; then (s0 + s1) + (s2 + s3)), so mode 2 is bit-identical to mode 0.
+  __shared__ __attribute__((aligned(16))) float s_acc[16][64];
   int d = 0;
   while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
   const float *__restrict__ partial = a.partial[d];
   const long long n = a.n[d];
   const int splits = a.splits[d];
+  if (a.deep[d] == 2) {
+    float4 (*s4)[64] = (float4 (*)[64])s_acc;          // [4 subsets][64 lanes] float4 = 4 KB
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const long long e = ((long long)(blockIdx.x - a.block0[d]) * 64 + lane) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n) {
+      const float *src = partial + e;
+      int i = r;
+      for (; i + 28 < splits; i += 32) {               // eight rows of this subset in flight
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const float4 *)(src + (size_t)(i + 4 * u) * n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      for (; i < splits; i += 4) {
+        const float4 v = *(const float4 *)(src + (size_t)i * n);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    s4[r][lane] = acc;
+    __syncthreads();
+    if (r == 0 && e < n) {
+      const float4 s0 = s4[0][lane], s1 = s4[1][lane], s2 = s4[2][lane], s3 = s4[3][lane];
+      const float v[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                          (s0.w + s1.w) + (s2.w + s3.w)};
+      const int ri = a.row_in[d];
+      if (ri == 0) {
+        *(float4 *)(a.out[d] + e) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long long row = (e + j) / ri;
+          const int col = (int)((e + j) - row * ri);
+          if (col < a.row_out[d]) a.out[d][row * a.row_out[d] + col] = v[j];
+        }
+      }
+    }
+    return;
+  }
   const bool deep = a.deep[d] != 0;
   const int epw = deep ? 16 : 64, nsub = deep ? 16 : 4;
   const int lane = deep ? (threadIdx.x & 15) : (threadIdx.x & 63), r = deep ? (threadIdx.x >> 4) : (threadIdx.x >> 6);
@@ -2800,8 +2844,10 @@ extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count,
       a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
       a.row_in[i] = d.row_in; a.row_out[i] = d.row_out;
       a.deep[i] = d.n <= 1024 && d.splits >= 128;
+      if (!a.deep[i] && d.n >= 4096 && d.n % 4 == 0 && (((uintptr_t)d.partial | (d.row_in == 0 ? (uintptr_t)d.out : 0)) & 15) == 0)
+        a.deep[i] = 2;          // wide: float4 per lane (same order of additions as the 64 x 4 layout)
       a.block0[i] = blocks;
-      blocks += cpfn_cdiv(d.n, a.deep[i] ? 16 : 64);
+      blocks += cpfn_cdiv(d.n, a.deep[i] == 2 ? 256 : a.deep[i] ? 16 : 64);
     }
     a.block0[a.count] = blocks;
     if (blocks) multi_split_reduce_kernel<<<blocks, 256, 0, st>>>(a);

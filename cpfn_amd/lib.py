@@ -48,6 +48,7 @@ SIGNATURES = {
     "cpfn_csr_gather_sum_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_fit_num_chunks": [_i, _i],
     "cpfn_fit_moments_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_fit_moments_fwd_match": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_fit_moments_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_cone_pass_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_cone_pass_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
@@ -70,6 +71,7 @@ SIGNATURES = {
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
+    "cpfn_flag_wait": [_vp, ctypes.c_uint, ctypes.c_uint64, _vp, _vp], "cpfn_flag_set": [_vp, ctypes.c_uint, _vp],
     "cpfn_mlp_gemm_set_probe": [_vp, _i, _i],
     "cpfn_wall_clock_khz": [_i],
     "cpfn_stamp": [_vp, _vp],

@@ -529,8 +529,7 @@ class SPFNTrainer:
                 else:
                     Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
                     n_gt = fl.count_gt(sb["I_gt"])
-                    st["match"] = fl.hungarian_device(S, n_gt)
-                    params = fl.fit_params(sb["P"], W, Xn, self.mult)
+                    params, st["match"] = fl.fit_params_and_match(sb["P"], W, Xn, self.mult, S, n_gt)
                 with fl.unit_loss_gradient():
                     out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
                 out[0].backward(st["unit"])              # (no ones_like fill inside the graph)

@@ -215,6 +215,13 @@ CPFN_API int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets
 CPFN_API int cpfn_fit_num_chunks(int B, int N);
 CPFN_API int cpfn_fit_moments_fwd(const float *P, const float *X, const float *W, int B, int N,
                                   int K, double *workspace, double *M, void *stream);
+/* The same launch with the loss section's assignment riding on it as one extra workgroup per cloud (the fits do not
+ * depend on the assignment, nor it on them; on its own it is a ~40 us one-wave-per-cloud latency chain):
+ * S / n_gt / match as cpfn_hungarian_match (SPFN/losses_implementation.py:10-30), K <= 32.  Same results as the two
+ * separate calls, bit for bit. */
+CPFN_API int cpfn_fit_moments_fwd_match(const float *P, const float *X, const float *W, int B, int N, int K,
+                                        double *workspace, double *M, const float *S, const int64_t *n_gt,
+                                        int64_t *match, void *stream);
 /* Adjoint: G[B,K,52] (fp32) = dL/dM  ->  dW[B,N,K], dX[B,N,3] (both overwritten). K <= 64.
  * dW_add (may be NULL): a [B,N,K] term added into dW (the cone pass's dW), saving a separate pass. */
 CPFN_API int cpfn_fit_moments_bwd(const float *P, const float *X, const float *W, const float *G,
@@ -311,6 +318,12 @@ CPFN_API int cpfn_mlp_gemm_rows(const void *A, int lda, const void *W, long long
 /* One reading of that clock into *dst, issued as a (capturable) 1-thread kernel on `stream`: a time stamp inside a
  * replayed graph (debugging aid: CPFN_STEP_STAMPS=1). */
 CPFN_API int cpfn_stamp(unsigned long long *dst, void *stream);
+/* Cross-stream ordering on ONE GPU by device flags (no reference counterpart: the reference has one stream): a one-lane
+ * kernel on `stream` that polls *flag until (int)(*flag - value) >= 0 — giving up after timeout_ticks of the 100 MHz wall
+ * clock, then OR-ing 1 into *err (may be NULL) — and one that stores `value` to *flag.  Data written by kernels BEFORE the
+ * setter on its stream is visible to kernels AFTER the waiter on its stream (kernel boundaries), as with an event. */
+CPFN_API int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err, void *stream);
+CPFN_API int cpfn_flag_set(unsigned *flag, unsigned value, void *stream);
 CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
                            float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,

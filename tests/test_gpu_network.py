@@ -200,3 +200,17 @@ def test_device_assignment_matches_scipy():
     want_host = fl.hungarian_from_pack(fl.hungarian_cost_pack(S, Id, n_gt), K).cpu().numpy()       # SciPy
     assert np.array_equal(got, want_host)
     assert np.array_equal(got, lsap.hungarian_from_stats(S.cpu().numpy(), n_gt.cpu().numpy()))     # the oracle restatement
+    # the same assignment riding on the fits' first launch (cpfn_fit_moments_fwd_match): identical matching, identical fits
+    P = torch.from_numpy(rng.normal(size=(B, N, 3)).astype(np.float32)).to(dev())
+    Xn = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(B, N, 3)).astype(np.float32)).to(dev()), dim=2)
+    mult = dict(miou=1.0, normal=1.0, type=1.0, parameter=1.0, residue=1.0, total=1.0)
+    params_sep = fl.fit_params(P, Wd, Xn, mult)
+    params, match = fl.fit_params_and_match(P, Wd, Xn, mult, S, n_gt)
+    assert np.array_equal(match.cpu().numpy(), got)
+    assert torch.equal(params, params_sep)
+    from cpfn_amd.SPFN import moments
+    assert moments.pending_match_rider() is None
+    # K beyond the fused kernels: nothing takes the rider, the assignment falls back to its own launch
+    off = dict(mult, residue=0.0, parameter=0.0)
+    params0, match0 = fl.fit_params_and_match(P, Wd, Xn, off, S, n_gt)
+    assert params0 is None and np.array_equal(match0.cpu().numpy(), got)
