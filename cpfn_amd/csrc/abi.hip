@@ -35,13 +35,13 @@ extern "C" int cpfn_stamp(unsigned long long *dst, void *stream) {
 // (agent-scope release).  The data handed over is written by kernels that precede the setter on its stream and read by
 // kernels that follow the waiter on its stream: kernel boundaries make it visible, exactly as with an event.
 // A waiter gives up after `timeout_ticks` of the 100 MHz wall clock (the setter never came: a host-side error between the
-// two launches), raises *err and lets its stream continue instead of hanging the GPU.
+// two launches), sets *err = 1 and lets its stream continue instead of hanging the GPU.
 namespace {
 __global__ void flag_wait_kernel(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err) {
   const unsigned long long t0 = (unsigned long long)wall_clock64();
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
     if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
-      if (err) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (err) *(volatile unsigned *)err = 1u;       // (plain store: err may live in pinned host memory)
       break;
     }
     __builtin_amdgcn_s_sleep(16);

@@ -48,6 +48,9 @@ def get_learning_rate(init_learning_rate, global_step, batch_size, decay_step, d
 SPLIT_GRAPHS = os.environ.get("CPFN_SPLIT_GRAPHS", "1") != "0"
 
 
+FLAG_ORDER = os.environ.get("CPFN_FLAG_ORDER", "1") != "0"      # two replayed graphs ordered by device flags, not events
+
+
 class FlatGradBucket:
     """All gradients of a module in one contiguous fp32 buffer, so the data-parallel exchange is a
     single all-reduce.  5.6 MB for GlobalSPFN: latency-bound on xGMI, hence one bucket rather than
@@ -512,6 +515,16 @@ class SPFNTrainer:
                 st["gs"] = gs
                 st["b_read"], st["b_written"] = torch.cuda.Event(), torch.cuda.Event()
                 st["side_pending"] = False
+                # FLAG_ORDER: the two streams order themselves through two device flags polled / set by one-lane kernels
+                # (include/cpfn_hip.h: cpfn_flag_wait / cpfn_flag_set) instead of two events per step: the closed
+                # cross-queue event cycle (main: wait, record; side: wait, record) costs ~100 us of idle GPU per step on
+                # this stack, a tiny eager kernel between two replays costs nothing (tools/dbg/twin_potential.py).
+                # [0] = step graphs whose geometry hand-off is done ("geomB consumed, next inputs written"),
+                # [1] = side graphs finished.  The waiters give up after 2 s and set flag_err (pinned, polled by the host).
+                if FLAG_ORDER:
+                    st["flags"] = torch.zeros(4, dtype=torch.int32, device=dev)
+                    st["flag_err"] = torch.zeros(4, dtype=torch.int32).pin_memory()
+                    st["n_main"], st["n_side"] = 0, 0
             with torch.cuda.graph(g, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
                 if stamps is not None:
                     stamps[4:5].copy_(stamps[3:4])                  # when the PREVIOUS replay was joined
@@ -605,10 +618,18 @@ class SPFNTrainer:
     def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
         st = self._graph
+        flags = st.get("flags")
+        if flags is not None and int(st["flag_err"][0]) != 0:
+            raise RuntimeError("cpfn_amd: a cross-stream flag wait of the replayed step timed out (the other stream's graph "
+                               "was never launched?); the results of the last steps are invalid")
         if st.get("split", False) and st["single"] and st["side_pending"]:
             # the side graph of the previous step (reads P_next / the FPS seeds, writes geomB) must be done before
             # this step overwrites its inputs and reads its result
-            torch.cuda.current_stream(batch["P"].device).wait_event(st["b_written"])
+            cur = torch.cuda.current_stream(batch["P"].device)
+            if flags is not None:
+                self._flag_wait(st, 1, st["n_side"], cur)
+            else:
+                cur.wait_event(st["b_written"])
             st["side_pending"] = False
         # inputs into the static buffers: ONE multi-tensor copy (the batch tensors that are not already the
         # static ones + the next batch's coordinates for the geometry branch of G2)
@@ -652,13 +673,26 @@ class SPFNTrainer:
                     self._copy_all(st["geomA_flat"], st["geomB"])
                 if announce:
                     cur = torch.cuda.current_stream(batch["P"].device)
-                    st["b_read"].record(cur)
-                    with torch.cuda.stream(self._gside):
-                        self._gside.wait_event(st["b_read"])
-                        st["gs"].replay()
-                        st["b_written"].record(self._gside)
+                    if flags is not None:
+                        from . import lib as _l
+                        h = _l.lib()
+                        with torch.cuda.device(cur.device):
+                            _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), st["n_main"] + 1, cur.cuda_stream), "cpfn_flag_set")
+                            self._flag_wait(st, 0, st["n_main"] + 1, self._gside)
+                            with torch.cuda.stream(self._gside):
+                                st["gs"].replay()
+                            _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), st["n_side"] + 1, self._gside.cuda_stream), "cpfn_flag_set")
+                        st["n_side"] += 1
+                    else:
+                        st["b_read"].record(cur)
+                        with torch.cuda.stream(self._gside):
+                            self._gside.wait_event(st["b_read"])
+                            st["gs"].replay()
+                            st["b_written"].record(self._gside)
                     st["side_pending"] = True
             st["g"].replay()                                   # the whole step: no host synchronisation
+            if flags is not None:
+                st["n_main"] += 1
             if st["world"] > 1 and not st["exchange_in_graph"]:
                 self.bucket.all_reduce_mean()
                 self._checked_optimizer_step(st["skipped"])
@@ -679,6 +713,13 @@ class SPFNTrainer:
             self._checked_optimizer_step(st["skipped"])
         self.global_step += 1
         return st["out"]
+
+    @staticmethod
+    def _flag_wait(st, which, value, stream):
+        from . import lib as _l
+        with torch.cuda.device(stream.device):
+            _l.check(_l.lib().cpfn_flag_wait(st["flags"][which:].data_ptr(), int(value) & 0xffffffff, 200_000_000,
+                                             st["flag_err"].data_ptr(), stream.cuda_stream), "cpfn_flag_wait")
 
     def stream(self, device):
         """The stream the replayed steps run on.  A training loop that runs under it (`with torch.cuda.stream(...)`)

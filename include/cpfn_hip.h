@@ -320,7 +320,7 @@ CPFN_API int cpfn_mlp_gemm_rows(const void *A, int lda, const void *W, long long
 CPFN_API int cpfn_stamp(unsigned long long *dst, void *stream);
 /* Cross-stream ordering on ONE GPU by device flags (no reference counterpart: the reference has one stream): a one-lane
  * kernel on `stream` that polls *flag until (int)(*flag - value) >= 0 — giving up after timeout_ticks of the 100 MHz wall
- * clock, then OR-ing 1 into *err (may be NULL) — and one that stores `value` to *flag.  Data written by kernels BEFORE the
+ * clock, then storing 1 to *err (may be NULL; may be pinned host memory) — and one that stores `value` to *flag.  Data written by kernels BEFORE the
  * setter on its stream is visible to kernels AFTER the waiter on its stream (kernel boundaries), as with an event. */
 CPFN_API int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err, void *stream);
 CPFN_API int cpfn_flag_set(unsigned *flag, unsigned value, void *stream);
