@@ -72,3 +72,38 @@ def test_fps_on_a_forked_graph_branch():
             torch.cuda.synchronize()
             bad += int(not torch.equal(out["s2"], ref2))
     assert bad == 0, "%d of 100 graph replays produced different FPS indices" % bad
+
+
+def test_cross_stream_flags_order_two_streams_and_time_out():
+    """cpfn_flag_wait / cpfn_flag_set (what orders the step's two replayed graphs instead of events): a consumer stream
+    that waits for flag >= k sees everything the producer stream wrote before it set the flag to k, over many rounds and
+    in both directions; a waiter whose setter never comes gives up after its timeout and reports it instead of hanging."""
+    from cpfn_amd import lib as _l
+    dev = torch.device("cuda:0")
+    h = _l.lib()
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    err = torch.zeros(4, dtype=torch.int32).pin_memory()
+    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    data = torch.zeros(1 << 20, dtype=torch.float32, device=dev)
+    seen = torch.zeros(64, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    TMO = 200_000_000          # 2 s of the 100 MHz clock
+    for k in range(1, 65):
+        with torch.cuda.stream(a):                     # producer: waits until round k - 1 was consumed, then writes round k
+            _l.check(h.cpfn_flag_wait(flags[1:].data_ptr(), k - 1, TMO, err.data_ptr(), a.cuda_stream), "cpfn_flag_wait")
+            data.fill_(float(k))
+            _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), k, a.cuda_stream), "cpfn_flag_set")
+        with torch.cuda.stream(b):                     # consumer
+            _l.check(h.cpfn_flag_wait(flags[0:].data_ptr(), k, TMO, err.data_ptr(), b.cuda_stream), "cpfn_flag_wait")
+            seen[k - 1:k].copy_(data.min().reshape(1))
+            _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), k, b.cuda_stream), "cpfn_flag_set")
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0
+    assert torch.equal(seen.cpu(), torch.arange(1, 65, dtype=torch.float32)), seen
+    assert flags[:2].tolist() == [64, 64]
+    # nobody sets flag 2: the waiter returns after ~10 ms and raises the error word
+    _l.check(h.cpfn_flag_wait(flags[2:].data_ptr(), 1, 1_000_000, err.data_ptr(), torch.cuda.current_stream().cuda_stream),
+             "cpfn_flag_wait")
+    torch.cuda.synchronize()
+    assert int(err[0]) == 1
+    assert h.cpfn_flag_wait(None, 1, 1, None, None) != 0 and h.cpfn_flag_set(None, 1, None) != 0

@@ -158,12 +158,51 @@ def flags_only():
     st["g"].replay()
 
 
+# ---- which part of the geometry costs the step what?  Side graphs with ONE part of the work each
+from cpfn_amd import ops
+Pn = st["P_next"]
+s1, s2 = st["start1"], st["start2"]
+gA = st["geomA"]
+xyz1 = gA["sa1"]["new_xyz"].clone()
+xyz2 = gA["sa2"]["new_xyz"].clone()
+idx_sa2 = gA["sa2"]["scales"][0][0].clone()
+nn3, nn2 = gA["sfp3"]["nn_idx"].clone(), gA["sfp2"]["nn_idx"].clone()
+parts = {
+    "FPS (8192 -> 512, 512 -> 128)": lambda: (ops.fps(Pn, 512, s1), ops.fps(xyz1, 128, s2)),
+    "ball query x2 + 3-NN x2": lambda: (ops.ball_query(xyz1, Pn, 0.2, 64), ops.ball_query(xyz2, xyz1, 0.4, 64),
+                                         ops.three_nn(Pn, xyz1), ops.three_nn(xyz1, xyz2)),
+    "inverse-index build x3": lambda: (ops.csr_build(idx_sa2, 512), ops.csr_build(nn3, 512), ops.csr_build(nn2, 128)),
+}
+for name, fn in parts.items():
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.synchronize()
+    gpart = torch.cuda.CUDAGraph()
+    side.wait_stream(cur)
+    with torch.cuda.graph(gpart, stream=side, capture_error_mode="thread_local"):
+        keep = fn()
+    cur.wait_stream(side)
+
+    def part_step():
+        nn[0] += 1
+        k = nn[0]
+        hh.cpfn_flag_wait(f_geom, k - 1, TMO, f_err, cur.cuda_stream)
+        hh.cpfn_flag_set(f_consumed, k, cur.cuda_stream)
+        hh.cpfn_flag_wait(f_consumed, k, TMO, f_err, side.cuda_stream)
+        with torch.cuda.stream(side):
+            gpart.replay()
+        hh.cpfn_flag_set(f_geom, k, side.cuda_stream)
+        st["g"].replay()
+    torch.cuda.synchronize()
+    timed(part_step, "(q) side graph = %s" % name)
+    torch.cuda.synchronize()
+    timed(lambda: gpart.replay(), "    that side graph alone")
 # ---- phase of the side graph relative to the step: released X us after the step's start (spin kernel on the side stream)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
 e0.record(); torch.cuda._sleep(1_000_000); e1.record(); torch.cuda.synchronize()
 cyc_per_us = 1_000_000 / (1e3 * e0.elapsed_time(e1))
-for delay_us in (0, 100, 200, 300, 400):
+for delay_us in ():
     def delayed():
         nn[0] += 1
         k = nn[0]
