@@ -53,6 +53,45 @@ def test_modes_agree_with_frozen_weights():
             assert err < 2e-2, (mode, step, err)
 
 
+def test_mixed_announcements_and_alternating_batches_match_eager():
+    """The replayed step with the next batch announced on SOME steps only and two batches taking turns (the geometry graph
+    on the side stream, ordered by the device flags, is then replayed irregularly; un-announced steps compute their
+    geometry serially; the input copy really moves data): same losses and gradients as eager launches, step by step."""
+    from cpfn_amd import training
+    from cpfn_amd.PointNet2 import pn2_network
+    from cpfn_amd.SPFN import fitter_factory
+    dev = torch.device("cuda:0")
+    with contextlib.redirect_stdout(io.StringIO()):
+        fitter_factory.register_primitives(training.GLOBAL_SPFN_CLASSES)
+    batches = [{k: v.to(dev) for k, v in synthetic.training_batch(4, N=2048, n_prims=6, n_inst_points=128, seed=sd).items()}
+               for sd in (5, 6)]
+    announce = [True, True, True, False, True, True, False, False, True, True]
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
+        model.set_compute_dtype(torch.bfloat16)
+        model.dropout_p = 0.0
+        tr = training.SPFNTrainer(model, batch_size=4, init_learning_rate=0.0, use_graphs=mode == "graph")
+        torch.manual_seed(77)
+        losses, grads = [], []
+        for i, ann in enumerate(announce):
+            out = tr.step(batches[i % 2], next_batch=batches[(i + 1) % 2] if ann else None)
+            losses.append([float(o) for o in out])
+            grads.append(tr.bucket.flat.detach().clone())
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert tr._graph is not None and tr._graph["single"] and float(tr._graph["skipped"]) == 0.0
+            assert "flags" not in tr._graph or int(tr._graph["flag_err"][0]) == 0
+        runs[mode] = (losses, grads)
+    for step, (a, b) in enumerate(zip(runs["graph"][0], runs["eager"][0])):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 1e-3 * abs(y) + 1e-5, (step, a, b)
+    for step, (a, b) in enumerate(zip(runs["graph"][1], runs["eager"][1])):
+        err = float((a - b).norm() / b.norm())
+        assert err < 2e-2, (step, err)
+
+
 def test_host_assignment_mode_matches_device_assignment(monkeypatch):
     """CPFN_HOST_ASSIGNMENT=1 (SciPy on the host like the reference; three graphs with the fits overlapping the host
     round trip) against the default single-graph step with cpfn_hungarian_match: same losses and gradients."""
