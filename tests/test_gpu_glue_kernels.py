@@ -86,7 +86,8 @@ def test_wide_split_reduce_same_addition_order():
     (s0 + s1) + (s2 + s3) — so the result is that sum bit for bit; padded rows are compacted by the same launch."""
     from cpfn_amd import fused_mlp
     g = torch.Generator().manual_seed(5)
-    for n_rows, Kp, cin, splits in [(128, 128, 128, 256), (256, 128, 128, 37), (128, 192, 131, 256), (64, 64, 64, 3)]:
+    for n_rows, Kp, cin, splits in [(128, 128, 128, 256), (256, 128, 128, 37), (128, 192, 131, 256), (64, 64, 64, 3),
+                                    (65, 64, 64, 5), (1030, 4, 4, 33), (67, 64, 35, 9)]:      # (ragged last workgroup)
         ws = torch.randn(splits, n_rows, Kp, generator=g).to(dev())
         out = torch.empty(n_rows, cin, device=dev())
         arr = (fused_mlp._ReduceDesc * 1)(fused_mlp._ReduceDesc(ws.data_ptr(), out.data_ptr(), n_rows * Kp, splits,
