@@ -2296,7 +2296,10 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   static const int target = getenv("CPFN_GEMM_WGS") && atoi(getenv("CPFN_GEMM_WGS")) > 0 ? atoi(getenv("CPFN_GEMM_WGS")) : 448;
   long long tpw = (tiles * ny + target - 1) / target;
   if (tpw < 1) tpw = 1;
-  if (tpw > 16) tpw = 16;
+  // (tiles per workgroup: capped at 64 — at 16 the 1M-row launches of the LocalSPFN step, 32 clouds, fell back to 512
+  //  workgroups = two rounds beside a 32-CU FPS: 2.680 -> 2.650 ms per step)
+  static const int tpw_cap = getenv("CPFN_GEMM_TPW_CAP") && atoi(getenv("CPFN_GEMM_TPW_CAP")) > 0 ? atoi(getenv("CPFN_GEMM_TPW_CAP")) : 64;
+  if (tpw > tpw_cap) tpw = tpw_cap;
   return (int)((tiles + tpw - 1) / tpw);
 }
 
