@@ -93,23 +93,38 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
       s_known[j] = make_float4(x, y, z, cpfn_sqnorm3(x, y, z));
     }
     __syncthreads();
-    for (int j = 0; j < cntk; ++j) {
-      const cpfn_f32x4 k4 = cpfn_lds_read4((const float *)&s_known[j]);   // (the DIRECT variant uses 3 of the 4 floats)
-      const float d = DIRECT ? direct_sqdist(ux, uy, uz, k4.x, k4.y, k4.z)
-                             : cpfn_pair_sqdist(ux, uy, uz, un, k4.x, k4.y, k4.z, k4.w);
-      const int jj = base + j;
-      if (d < d2) {
-        if (d < d1) {
-          d2 = d1; i2 = i1;
-          if (d < d0) {
-            d1 = d0; i1 = i0; d0 = d; i0 = jj;
-          } else {
-            d1 = d; i1 = jj;
-          }
-        } else {
-          d2 = d; i2 = jj;
-        }
+    // four candidates per trip: their LDS reads are issued together (one exposed LDS round trip per FOUR candidates —
+    // the rolled loop waited for every single one: 94 cycles per candidate and wave) and the distances are independent;
+    // the insertions stay sequential and in index order (strict '<': the lower index keeps a tie)
+#define CPFN_NN_INSERT(dv, jv)                                   \
+    do {                                                         \
+      const float d_ = (dv);                                     \
+      const int jj_ = (jv);                                      \
+      if (d_ < d2) {                                             \
+        if (d_ < d1) {                                           \
+          d2 = d1; i2 = i1;                                      \
+          if (d_ < d0) { d1 = d0; i1 = i0; d0 = d_; i0 = jj_; }  \
+          else { d1 = d_; i1 = jj_; }                            \
+        } else { d2 = d_; i2 = jj_; }                            \
+      }                                                          \
+    } while (0)
+#define CPFN_NN_DIST(k4) (DIRECT ? direct_sqdist(ux, uy, uz, (k4).x, (k4).y, (k4).z) \
+                                 : cpfn_pair_sqdist(ux, uy, uz, un, (k4).x, (k4).y, (k4).z, (k4).w))
+    int j = 0;
+    for (; j + 4 <= cntk; j += 4) {
+      const cpfn_f32x4 ka = cpfn_lds_read4((const float *)&s_known[j]), kb = cpfn_lds_read4((const float *)&s_known[j + 1]);
+      const cpfn_f32x4 kc = cpfn_lds_read4((const float *)&s_known[j + 2]), kd = cpfn_lds_read4((const float *)&s_known[j + 3]);
+      const float da = CPFN_NN_DIST(ka), db = CPFN_NN_DIST(kb), dc = CPFN_NN_DIST(kc), dd = CPFN_NN_DIST(kd);
+      if (fminf(fminf(da, db), fminf(dc, dd)) < d2) {       // (NaN distances never enter, as in the rolled loop)
+        CPFN_NN_INSERT(da, base + j);
+        CPFN_NN_INSERT(db, base + j + 1);
+        CPFN_NN_INSERT(dc, base + j + 2);
+        CPFN_NN_INSERT(dd, base + j + 3);
       }
+    }
+    for (; j < cntk; ++j) {
+      const cpfn_f32x4 k4 = cpfn_lds_read4((const float *)&s_known[j]);   // (the DIRECT variant uses 3 of the 4 floats)
+      CPFN_NN_INSERT(CPFN_NN_DIST(k4), base + j);
     }
   }
   if (i < N) {
@@ -123,6 +138,9 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
     oi[0] = i0; oi[1] = i1; oi[2] = i2;
   }
 }
+
+#undef CPFN_NN_INSERT
+#undef CPFN_NN_DIST
 
 __global__ void three_weights_kernel(const float *__restrict__ dist, long long R, float *__restrict__ w) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
