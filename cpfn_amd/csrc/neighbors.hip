@@ -65,6 +65,61 @@ __global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
   for (int k = cnt + lane; k < K; k += CPFN_WAVE) out[k] = first;
 }
 
+// The same query, sixteen per workgroup (sixteen waves, all of one cloud), with the cloud walked through LDS in tiles of
+// 2048 points as (x, y, z, |p|^2): a wave then pays one 16-byte LDS read and the six distance operations per point
+// instead of three global loads, the norm (five operations) and the distance — the wave-per-query kernel above is
+// VALU / issue bound (8192 waves x ~100 trips x ~25 instructions for sa1).  Same arithmetic (the norm is the same
+// cpfn_sqnorm3, computed once per point and tile instead of once per point and query), same index order, same early
+// exit (per wave; the workgroup leaves when all sixteen are done).
+constexpr int BQT_WAVES = 16, BQT_TILE = 2048;
+template <bool DIRECT>
+__global__ __launch_bounds__(BQT_WAVES *CPFN_WAVE) void ball_query_tiled_kernel(
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N, int S, float thr, int K,
+    int *__restrict__ idx_out) {
+  __shared__ float4 s_pts[BQT_TILE];
+  const int t = threadIdx.x, lane = t & (CPFN_WAVE - 1), wave = t / CPFN_WAVE;
+  const int b = blockIdx.y;
+  const int sq = blockIdx.x * BQT_WAVES + wave;          // query of this wave inside cloud b (S % 16 == 0: always valid)
+  const float *p = xyz + (size_t)b * N * 3;
+  const float *c = new_xyz + ((size_t)b * S + sq) * 3;
+  int *out = idx_out + ((size_t)b * S + sq) * K;
+  const float qx = c[0], qy = c[1], qz = c[2];
+  const float qn = cpfn_sqnorm3(qx, qy, qz);
+  int cnt = 0;
+  int first = DIRECT ? 0 : N;
+  for (int tile0 = 0; tile0 < N; tile0 += BQT_TILE) {
+    const int tn = min(BQT_TILE, N - tile0);
+    for (int j = t; j < tn; j += BQT_WAVES * CPFN_WAVE) {
+      const float x = p[3 * (tile0 + j)], y = p[3 * (tile0 + j) + 1], z = p[3 * (tile0 + j) + 2];
+      s_pts[j] = make_float4(x, y, z, cpfn_sqnorm3(x, y, z));
+    }
+    __syncthreads();
+    for (int base = 0; base < tn && cnt < K; base += CPFN_WAVE) {
+      const int j = base + lane, n = tile0 + j;
+      bool keep = false;
+      if (j < tn) {
+        const cpfn_f32x4 k4 = cpfn_lds_read4((const float *)&s_pts[j]);
+        if (DIRECT) {
+          keep = direct_sqdist(qx, qy, qz, k4.x, k4.y, k4.z) < thr;
+        } else {
+          const float d = cpfn_pair_sqdist(qx, qy, qz, qn, k4.x, k4.y, k4.z, k4.w);
+          keep = !(d > thr);
+        }
+      }
+      const unsigned long long mask = __ballot(keep);
+      if (mask) {
+        if (cnt == 0) first = tile0 + base + __builtin_ctzll(mask);
+        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep && pos < K) out[pos] = n;
+        cnt += __popcll(mask);
+      }
+    }
+    if (__syncthreads_or(cnt < K) == 0) break;            // (also the barrier in front of the next tile's fill)
+  }
+  if (cnt > K) cnt = K;
+  for (int k = cnt + lane; k < K; k += CPFN_WAVE) out[k] = first;
+}
+
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 1024;
 
@@ -177,8 +232,12 @@ extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, in
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
-  ball_query_kernel<false><<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
-      xyz, new_xyz, B, N, S, thr, K, idx_out);
+  if (S % BQT_WAVES == 0 && N >= 512)
+    ball_query_tiled_kernel<false><<<dim3(S / BQT_WAVES, B), BQT_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+        xyz, new_xyz, N, S, thr, K, idx_out);
+  else
+    ball_query_kernel<false><<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+        xyz, new_xyz, B, N, S, thr, K, idx_out);
   return cpfn_launch_status();
 }
 
@@ -187,8 +246,12 @@ extern "C" int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, in
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
-  ball_query_kernel<true><<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
-      xyz, new_xyz, B, N, S, radius * radius, K, idx_out);
+  if (S % BQT_WAVES == 0 && N >= 512)
+    ball_query_tiled_kernel<true><<<dim3(S / BQT_WAVES, B), BQT_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+        xyz, new_xyz, N, S, radius * radius, K, idx_out);
+  else
+    ball_query_kernel<true><<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+        xyz, new_xyz, B, N, S, radius * radius, K, idx_out);
   return cpfn_launch_status();
 }
 

@@ -125,7 +125,11 @@ def test_fps_ties_and_default_start():
 
 
 @pytest.mark.parametrize("B,N,S,K,r", [(2, 100, 10, 4, 0.5), (1, 8192, 512, 64, 0.2), (3, 777, 99, 32, 0.3),
-                                       (2, 4096, 64, 128, 1.5), (1, 300, 300, 1, 0.1)])
+                                       (2, 4096, 64, 128, 1.5), (1, 300, 300, 1, 0.1),
+                                       # sixteen queries per workgroup, the cloud through LDS tiles of 2048 points: ragged
+                                       # last tile, balls that never fill (every tile scanned), empty balls (pad = N)
+                                       (3, 5000, 48, 64, 0.2), (2, 2049, 16, 64, 0.02), (16, 512, 128, 64, 0.4),
+                                       (2, 8192, 32, 64, 0.001), (1, 2048, 16, 7, 2.0)])
 def test_ball_query_vs_oracle(B, N, S, K, r):
     from cpfn_amd import cuda_ops
     rng = np.random.default_rng(N + K)
