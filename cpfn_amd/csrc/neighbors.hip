@@ -30,8 +30,9 @@ __global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, int B, int N, int S, float thr, int K,
     int *__restrict__ idx_out) {
   const int lane = threadIdx.x & (CPFN_WAVE - 1);
-  const long long q = (long long)blockIdx.x * BQ_WAVES + (threadIdx.x / CPFN_WAVE);
-  if (q >= (long long)B * S) return;  // wave-uniform
+  // (grid-stride over the queries: the host may launch fewer workgroups than queries / 4 — see cpfn_ball_query)
+  for (long long q = (long long)blockIdx.x * BQ_WAVES + (threadIdx.x / CPFN_WAVE); q < (long long)B * S;
+       q += (long long)gridDim.x * BQ_WAVES) {   // wave-uniform
   const int b = (int)(q / S);
   const float *p = xyz + (size_t)b * N * 3;
   const float *c = new_xyz + (size_t)q * 3;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
   }
   if (cnt > K) cnt = K;
   for (int k = cnt + lane; k < K; k += CPFN_WAVE) out[k] = first;
+  }
 }
 
 // The same query, sixteen per workgroup (sixteen waves, all of one cloud), with the cloud walked through LDS in tiles of
@@ -195,6 +197,88 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
 }
 
 #undef CPFN_NN_INSERT
+
+// The same search with FOUR lanes per query (adjacent lanes; lane s takes candidates s, s + 4, ...): the lane-per-query
+// kernel above runs two waves per SIMD at 16 x 8192 queries and exposes its LDS round trips and branches; this one runs
+// eight.  Each lane keeps its three best by strict '<' (its candidates come in ascending index order), then the four
+// triples of a query are merged in the order (distance, index) — the sequential scan's result exactly: lowest distances,
+// the lower index on a tie.
+template <bool DIRECT>
+__global__ __launch_bounds__(NN_THREADS) void three_nn_quad_kernel(const float *__restrict__ unknown,
+                                                                   const float *__restrict__ known, int N, int M,
+                                                                   float *__restrict__ dist2, int *__restrict__ idx,
+                                                                   int sqrt_out) {
+  __shared__ float4 s_known[NN_TILE];
+  const int b = blockIdx.y;
+  const int sub = threadIdx.x & 3;
+  const int i = blockIdx.x * (NN_THREADS / 4) + (threadIdx.x >> 2);
+  const float *kn = known + (size_t)b * M * 3;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (i < N) {
+    const float *u = unknown + ((size_t)b * N + i) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  const float un = cpfn_sqnorm3(ux, uy, uz);
+  float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+  int i0 = DIRECT ? 0 : M, i1 = i0, i2 = i0;
+  for (int base = 0; base < M; base += NN_TILE) {
+    const int cntk = min(NN_TILE, M - base);
+    __syncthreads();
+    for (int j = threadIdx.x; j < cntk; j += NN_THREADS) {
+      const float x = kn[3 * (base + j)], y = kn[3 * (base + j) + 1], z = kn[3 * (base + j) + 2];
+      s_known[j] = make_float4(x, y, z, cpfn_sqnorm3(x, y, z));
+    }
+    __syncthreads();
+    for (int j = sub; j < cntk; j += 8) {          // two candidates of this lane per trip
+      const cpfn_f32x4 ka = cpfn_lds_read4((const float *)&s_known[j]);
+      const bool two = j + 4 < cntk;
+      const cpfn_f32x4 kb = cpfn_lds_read4((const float *)&s_known[two ? j + 4 : j]);
+      const float da = CPFN_NN_DIST(ka), db = two ? CPFN_NN_DIST(kb) : INFINITY;
+      const int ja = base + j, jb = base + j + 4;
+      if (da < d2) {
+        if (da < d1) {
+          d2 = d1; i2 = i1;
+          if (da < d0) { d1 = d0; i1 = i0; d0 = da; i0 = ja; } else { d1 = da; i1 = ja; }
+        } else { d2 = da; i2 = ja; }
+      }
+      if (db < d2) {
+        if (db < d1) {
+          d2 = d1; i2 = i1;
+          if (db < d0) { d1 = d0; i1 = i0; d0 = db; i0 = jb; } else { d1 = db; i1 = jb; }
+        } else { d2 = db; i2 = jb; }
+      }
+    }
+  }
+  // merge the four lanes of a query: butterfly over the quad (xor 1, xor 2); after it every lane holds the query's result
+#pragma unroll
+  for (int m = 1; m <= 2; m <<= 1) {
+    const float e0 = __shfl_xor(d0, m, 64), e1 = __shfl_xor(d1, m, 64), e2 = __shfl_xor(d2, m, 64);
+    const int f0 = __shfl_xor(i0, m, 64), f1 = __shfl_xor(i1, m, 64), f2 = __shfl_xor(i2, m, 64);
+    const float ed[3] = {e0, e1, e2};
+    const int ei[3] = {f0, f1, f2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float d = ed[q];
+      const int jj = ei[q];
+      // (distance, index) order; an entry equal to one already held (the defaults: +inf with the same index) changes nothing
+      if (d < d2 || (d == d2 && jj < i2)) {
+        if (d < d1 || (d == d1 && jj < i1)) {
+          d2 = d1; i2 = i1;
+          if (d < d0 || (d == d0 && jj < i0)) { d1 = d0; i1 = i0; d0 = d; i0 = jj; } else { d1 = d; i1 = jj; }
+        } else { d2 = d; i2 = jj; }
+      }
+    }
+  }
+  if (i < N && sub == 0) {
+    float *od = dist2 + ((size_t)b * N + i) * 3;
+    int *oi = idx + ((size_t)b * N + i) * 3;
+    if (sqrt_out) {
+      d0 = (float)sqrt((double)d0); d1 = (float)sqrt((double)d1); d2 = (float)sqrt((double)d2);
+    }
+    od[0] = d0; od[1] = d1; od[2] = d2;
+    oi[0] = i0; oi[1] = i1; oi[2] = i2;
+  }
+}
 #undef CPFN_NN_DIST
 
 __global__ void three_weights_kernel(const float *__restrict__ dist, long long R, float *__restrict__ w) {
@@ -227,16 +311,31 @@ __global__ __launch_bounds__(256) void pairwise_sqdist_kernel(const float *__res
 
 }  // namespace
 
+// "Background" geometry (cpfn_set_background_geometry): the call runs on a side stream BESIDE other work (the next batch's
+// geometry beside a training step).  The two fast variants — ball query through LDS tiles (84 -> 50 us for the step's two
+// launches), four lanes per 3-NN query (78 -> 50 us) — then make the step they run beside SLOWER (interleaved A/B on one
+// box: +19 us and +5 us per step): full 1024-thread workgroups / eight waves per SIMD take more from their neighbours than
+// the time they save, and the geometry has 0.4 ms of slack anyway.  Throttling the wave-per-query kernel's grid the other
+// way (1024 / 512 / 256 workgroups) is worse too (+14 / +31 / +45 us).  So: background calls use the wave-per-query and
+// lane-per-query kernels, everything else (evaluation, stand-alone calls: the geometry is on the critical path) the fast ones.
+static bool g_background_geometry = false;
+extern "C" int cpfn_set_background_geometry(int on) {
+  const int was = g_background_geometry ? 1 : 0;
+  g_background_geometry = on != 0;
+  return was;
+}
+static int bq_grid(long long Q) { return cpfn_cdiv(Q, BQ_WAVES); }
+
 extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float thr, int K,
                                int *idx_out, void *stream) {
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
-  if (S % BQT_WAVES == 0 && N >= 512)
+  if (S % BQT_WAVES == 0 && N >= 512 && !g_background_geometry)
     ball_query_tiled_kernel<false><<<dim3(S / BQT_WAVES, B), BQT_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
         xyz, new_xyz, N, S, thr, K, idx_out);
   else
-    ball_query_kernel<false><<<cpfn_cdiv(Q, BQ_WAVES), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+    ball_query_kernel<false><<<bq_grid(Q), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
         xyz, new_xyz, B, N, S, thr, K, idx_out);
   return cpfn_launch_status();
 }
@@ -246,7 +345,7 @@ extern "C" int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, in
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
-  if (S % BQT_WAVES == 0 && N >= 512)
+  if (S % BQT_WAVES == 0 && N >= 512 && !g_background_geometry)
     ball_query_tiled_kernel<true><<<dim3(S / BQT_WAVES, B), BQT_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
         xyz, new_xyz, N, S, radius * radius, K, idx_out);
   else
@@ -259,6 +358,11 @@ extern "C" int cpfn_three_nn(const float *unknown, const float *known, int B, in
                              int *idx, void *stream) {
   if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist2 || !idx) return CPFN_EINVAL;
   if (B == 0 || N == 0) return 0;
+  if (M >= 64 && !g_background_geometry) {
+    three_nn_quad_kernel<false><<<dim3(cpfn_cdiv(N, NN_THREADS / 4), B), NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M,
+                                                                                                      dist2, idx, 0);
+    return cpfn_launch_status();
+  }
   dim3 grid(cpfn_cdiv(N, NN_THREADS), B);
   three_nn_kernel<false><<<grid, NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M, dist2, idx, 0);
   return cpfn_launch_status();
@@ -268,6 +372,11 @@ extern "C" int cpfn_three_nn_direct(const float *unknown, const float *known, in
                                     float *dist, int *idx, void *stream) {
   if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist || !idx) return CPFN_EINVAL;
   if (B == 0 || N == 0) return 0;
+  if (M >= 64 && !g_background_geometry) {
+    three_nn_quad_kernel<true><<<dim3(cpfn_cdiv(N, NN_THREADS / 4), B), NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M,
+                                                                                                     dist, idx, sqrt_out);
+    return cpfn_launch_status();
+  }
   dim3 grid(cpfn_cdiv(N, NN_THREADS), B);
   three_nn_kernel<true><<<grid, NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M, dist, idx, sqrt_out);
   return cpfn_launch_status();

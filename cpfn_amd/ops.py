@@ -29,6 +29,19 @@ def _chk(t, name, dtype):
     return t
 
 
+class background_geometry:
+    """Context: the ball queries / 3-NN searches issued inside run on a side stream beside other work (the next batch's
+    geometry beside a training step) and use the narrower kernels (cpfn_set_background_geometry); same results."""
+
+    def __enter__(self):
+        self._was = _l.lib().cpfn_set_background_geometry(1)
+        return self
+
+    def __exit__(self, *exc):
+        _l.lib().cpfn_set_background_geometry(self._was)
+        return False
+
+
 def ball_query_threshold(radius):
     """f32(radius**2 in double): what `sqrdists > radius ** 2` compares against
     (modules/geometry_utils.py:156)."""

@@ -253,7 +253,8 @@ class SPFNTrainer:
             self._side = torch.cuda.Stream(device=P.device)
         main = torch.cuda.current_stream(P.device)
         self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        from . import ops as _ops
+        with torch.cuda.stream(self._side), _ops.background_geometry():
             geom = self.module.compute_geometry(P, fps_start)
             ev = torch.cuda.Event()
             ev.record(self._side)
@@ -478,8 +479,12 @@ class SPFNTrainer:
         if self._gside is None:
             self._gside = torch.cuda.Stream(device=dev)
 
-        def geometry_into_B(P):
-            fresh = self._flatten_geom(self.module.compute_geometry(P, starts))
+        def geometry_into_B(P, beside=True):
+            # beside: the pass runs on the side stream next to a step -> the narrower kernels (csrc/neighbors.hip)
+            import contextlib
+            from . import ops as _ops
+            with (_ops.background_geometry() if beside else contextlib.nullcontext()):
+                fresh = self._flatten_geom(self.module.compute_geometry(P, starts))
             self._copy_all(geomB, fresh)
 
         # capture on the same side stream the eager warm-up steps ran on, so that the parameters'
@@ -488,7 +493,7 @@ class SPFNTrainer:
         # may touch the HIP API while this thread captures
         g0 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g0, stream=self._gstream, capture_error_mode="thread_local"):
-            geometry_into_B(sb["P"])
+            geometry_into_B(sb["P"], beside=False)
         st["world"], st["g0"] = world, g0
         st["single"] = not fl.HOST_ASSIGNMENT and K <= 32
         if st["single"]:

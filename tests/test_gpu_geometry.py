@@ -136,7 +136,11 @@ def test_ball_query_vs_oracle(B, N, S, K, r):
     xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
     q = xyz[:, rng.permutation(N)[:S]]
     got = cuda_ops.ball_query(T(q), T(xyz), r, K).cpu().numpy()
-    assert np.array_equal(got, og.ball_query(r, K, xyz, q).astype(np.int32))
+    want = og.ball_query(r, K, xyz, q).astype(np.int32)
+    assert np.array_equal(got, want)
+    from cpfn_amd import ops
+    with ops.background_geometry():           # the wave-per-query kernel (what runs beside a training step)
+        assert np.array_equal(cuda_ops.ball_query(T(q), T(xyz), r, K).cpu().numpy(), want)
 
 
 def test_ball_query_no_neighbour_pads_with_N():
@@ -146,7 +150,7 @@ def test_ball_query_no_neighbour_pads_with_N():
     assert np.array_equal(cuda_ops.ball_query(T(q), T(xyz), 0.2, 4).cpu().numpy(), np.full((1, 1, 4), 10))
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 1000, 3), (1, 8192, 512), (2, 333, 1500), (1, 5, 2)])
+@pytest.mark.parametrize("B,N,M", [(2, 1000, 3), (1, 8192, 512), (2, 333, 1500), (1, 5, 2), (3, 70, 64), (2, 513, 1027), (1, 100, 65)])
 def test_three_nn_vs_oracle(B, N, M):
     from cpfn_amd import cuda_ops
     rng = np.random.default_rng(N + M)
@@ -158,6 +162,36 @@ def test_three_nn_vs_oracle(B, N, M):
     od, oi = og.three_nn(u, k)
     assert np.array_equal(i.cpu().numpy(), oi.astype(np.int32))
     assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    from cpfn_amd import ops
+    with ops.background_geometry():           # the lane-per-query kernel (what runs beside a training step)
+        d, i = cuda_ops.three_nn(T(u), T(k))
+    assert np.array_equal(i.cpu().numpy(), oi.astype(np.int32))
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+
+
+def test_three_nn_ties_keep_the_lower_index():
+    """Known points on a lattice, queries at cell centres, edge midpoints and lattice points: many exactly equal distances.
+    The four-lanes-per-query kernel merges its lanes' triples in (distance, index) order — the sequential scan's result."""
+    from cpfn_amd import cuda_ops
+    ax = np.linspace(-1, 1, 9, dtype=np.float32)
+    k = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, -1, 3)          # M = 729
+    rng = np.random.default_rng(7)
+    k = k[:, rng.permutation(k.shape[1])]                                               # ties in arbitrary index order
+    cell = (k[0, rng.integers(0, k.shape[1], 400)] + np.float32(0.125)).astype(np.float32)
+    edge = (k[0, rng.integers(0, k.shape[1], 400)] + np.array([0.125, 0, 0], np.float32)).astype(np.float32)
+    u = np.concatenate([cell, edge, k[0, :224]], 0)[None]
+    od, oi = og.three_nn(u, k)
+    from cpfn_amd import ops
+    import contextlib
+    for ctx in (contextlib.nullcontext(), ops.background_geometry()):
+        with ctx:
+            d, i = cuda_ops.three_nn(T(u), T(k))
+        assert np.array_equal(i.cpu().numpy(), oi.astype(np.int32))
+        assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    # identical known points (every distance ties): indices 0, 1, 2
+    same = np.zeros((1, 100, 3), np.float32)
+    d, i = cuda_ops.three_nn(T(u), T(same))
+    assert np.array_equal(i.cpu().numpy(), np.broadcast_to(np.arange(3, dtype=np.int32), (1, u.shape[1], 3)))
 
 
 def test_points_major_ops_vs_oracle():
