@@ -61,3 +61,15 @@ extern "C" int cpfn_flag_set(unsigned *flag, unsigned value, void *stream) {
   flag_set_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flag, value);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---------------------------------------------------------------- background geometry
+// Set around geometry passes that run on a side stream BESIDE other work (the next batch's FPS / ball query / 3-NN beside
+// a training step): those calls then pick the kernel shapes that disturb their neighbours least instead of the fastest
+// ones (csrc/neighbors.hip, csrc/sampling.hip: measured both ways).
+static bool g_background_geometry = false;
+bool cpfn_background_geometry() { return g_background_geometry; }
+extern "C" int cpfn_set_background_geometry(int on) {
+  const int was = g_background_geometry ? 1 : 0;
+  g_background_geometry = on != 0;
+  return was;
+}

@@ -14,6 +14,8 @@ static inline int cpfn_launch_status() {
 
 static inline int cpfn_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+bool cpfn_background_geometry();      // abi.hip: cpfn_set_background_geometry
+
 // ‖p‖² rounded like torch.sum(p**2, dim=1) on CPU: ((x²+y²)+z²), no contraction.
 __device__ __forceinline__ float cpfn_sqnorm3(float x, float y, float z) {
   return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));

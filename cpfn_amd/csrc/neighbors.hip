@@ -318,12 +318,7 @@ __global__ __launch_bounds__(256) void pairwise_sqdist_kernel(const float *__res
 // the time they save, and the geometry has 0.4 ms of slack anyway.  Throttling the wave-per-query kernel's grid the other
 // way (1024 / 512 / 256 workgroups) is worse too (+14 / +31 / +45 us).  So: background calls use the wave-per-query and
 // lane-per-query kernels, everything else (evaluation, stand-alone calls: the geometry is on the critical path) the fast ones.
-static bool g_background_geometry = false;
-extern "C" int cpfn_set_background_geometry(int on) {
-  const int was = g_background_geometry ? 1 : 0;
-  g_background_geometry = on != 0;
-  return was;
-}
+// (The flag itself lives in abi.hip; FPS uses it too: sampling.hip.)
 static int bq_grid(long long Q) { return cpfn_cdiv(Q, BQ_WAVES); }
 
 extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float thr, int K,
@@ -331,7 +326,7 @@ extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, in
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
-  if (S % BQT_WAVES == 0 && N >= 512 && !g_background_geometry)
+  if (S % BQT_WAVES == 0 && N >= 512 && !cpfn_background_geometry())
     ball_query_tiled_kernel<false><<<dim3(S / BQT_WAVES, B), BQT_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
         xyz, new_xyz, N, S, thr, K, idx_out);
   else
@@ -345,7 +340,7 @@ extern "C" int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, in
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyz || !new_xyz || !idx_out) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
-  if (S % BQT_WAVES == 0 && N >= 512 && !g_background_geometry)
+  if (S % BQT_WAVES == 0 && N >= 512 && !cpfn_background_geometry())
     ball_query_tiled_kernel<true><<<dim3(S / BQT_WAVES, B), BQT_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
         xyz, new_xyz, N, S, radius * radius, K, idx_out);
   else
@@ -358,7 +353,7 @@ extern "C" int cpfn_three_nn(const float *unknown, const float *known, int B, in
                              int *idx, void *stream) {
   if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist2 || !idx) return CPFN_EINVAL;
   if (B == 0 || N == 0) return 0;
-  if (M >= 64 && !g_background_geometry) {
+  if (M >= 64 && !cpfn_background_geometry()) {
     three_nn_quad_kernel<false><<<dim3(cpfn_cdiv(N, NN_THREADS / 4), B), NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M,
                                                                                                       dist2, idx, 0);
     return cpfn_launch_status();
@@ -372,7 +367,7 @@ extern "C" int cpfn_three_nn_direct(const float *unknown, const float *known, in
                                     float *dist, int *idx, void *stream) {
   if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist || !idx) return CPFN_EINVAL;
   if (B == 0 || N == 0) return 0;
-  if (M >= 64 && !g_background_geometry) {
+  if (M >= 64 && !cpfn_background_geometry()) {
     three_nn_quad_kernel<true><<<dim3(cpfn_cdiv(N, NN_THREADS / 4), B), NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M,
                                                                                                      dist, idx, sqrt_out);
     return cpfn_launch_status();

@@ -250,7 +250,15 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
   } else if (N <= 2048) {
     fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out);
   } else if (N <= CPFN_FPS_MAX_RESIDENT) {
-    fps_resident_kernel<1024, 8><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out);
+    // 8192 points on ONE CU either way (a sample is a VALU-throughput phase over the cloud plus two key reductions):
+    // 16 waves x 8 points per lane take 670 us for 512 samples, 8 waves x 16 points 572 us, 4 waves x 32 points 636 us
+    // (one wave per SIMD: no other wave hides a wave's dependent chains), 2 x 64 1003 us (registers spill to AGPRs).
+    // Beside a training step (one workgroup per cloud on 16 CUs for the whole forward pass) the FEWER waves the better
+    // for the step: 1.871 ms with 16 waves, 1.855 with 8, 1.849 with 4 (interleaved A/B on one box each).
+    if (cpfn_background_geometry())
+      fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out);
+    else
+      fps_resident_kernel<512, 16><<<B, 512, 0, st>>>(xyz, N, S, start, flags, idx_out);
   } else {
     if (!scratch) return CPFN_EINVAL;
     // several workgroups per cloud while all of them can be resident together and the key layout holds

@@ -30,8 +30,9 @@ def _chk(t, name, dtype):
 
 
 class background_geometry:
-    """Context: the ball queries / 3-NN searches issued inside run on a side stream beside other work (the next batch's
-    geometry beside a training step) and use the narrower kernels (cpfn_set_background_geometry); same results."""
+    """Context: the FPS / ball-query / 3-NN calls issued inside run on a side stream beside other work (the next batch's
+    geometry beside a training step) and use the kernel shapes that disturb their neighbours least
+    (cpfn_set_background_geometry) instead of the fastest ones; same results, bit for bit."""
 
     def __enter__(self):
         self._was = _l.lib().cpfn_set_background_geometry(1)

@@ -90,8 +90,8 @@ CPFN_API int cpfn_three_nn(const float *unknown, const float *known, int B, int 
  * reference's Python wrapper hands on (modules/geometry_utils.py:184).
  * nvcc's default fma contraction of the three-term sum is assumed; not pinned bit for bit
  * (no CUDA build of the reference can run next to this library). */
-/* on != 0: the following cpfn_ball_query* / cpfn_three_nn* calls run BESIDE other work (a side stream next to a training
- * step) and use the narrower kernels, which disturb their neighbours less; 0 (default): the fastest kernels.  Same
+/* on != 0: the following cpfn_fps / cpfn_ball_query* / cpfn_three_nn* calls run BESIDE other work (a side stream next to a
+ * training step) and use the kernel shapes that disturb their neighbours least; 0 (default): the fastest kernels.  Same
  * results, bit for bit.  Returns the previous setting.  (Process-wide; no reference counterpart.) */
 CPFN_API int cpfn_set_background_geometry(int on);
 CPFN_API int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, int B, int N, int S,

@@ -81,7 +81,7 @@ def test_golden_ragged(golden):
                                rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,N,S", [(1, 64, 64), (3, 65, 7), (2, 513, 100), (2, 2049, 33), (1, 8192, 512),
+@pytest.mark.parametrize("B,N,S", [(1, 64, 64), (3, 65, 7), (2, 513, 100), (2, 2049, 33), (1, 8192, 512), (3, 5000, 77),
                                    (2, 10000, 50), (1, 40000, 64)])
 def test_fps_sizes_vs_oracle(B, N, S):
     from cpfn_amd import cuda_ops
@@ -89,7 +89,11 @@ def test_fps_sizes_vs_oracle(B, N, S):
     xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
     start = rng.integers(0, N, B)
     got = cuda_ops.farthest_point_sampling(T(xyz), S, start_idx=T(start)).cpu().numpy()
-    assert np.array_equal(got, og.farthest_point_sample(xyz, S, start).astype(np.int32))
+    want = og.farthest_point_sample(xyz, S, start).astype(np.int32)
+    assert np.array_equal(got, want)
+    from cpfn_amd import ops
+    with ops.background_geometry():       # the shape used beside a training step (4 waves x 32 points per lane at N > 2048)
+        assert np.array_equal(cuda_ops.farthest_point_sampling(T(xyz), S, start_idx=T(start)).cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("B,N,S,dup", [(1, 8193, 64, False), (3, 20000, 200, True), (2, 131072, 512, False), (16, 131072, 32, False),
