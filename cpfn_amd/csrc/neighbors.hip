@@ -18,21 +18,21 @@
 
 namespace {
 
-constexpr int BQ_WAVES = 4;
+constexpr int BQ_WAVES = 2;     // (beside a training step: 1 / 2 / 4 / 8 waves per workgroup -> 1.846 / 1.844 / 1.852 / 1.849 ms per step)
 
 __device__ __forceinline__ float direct_sqdist(float qx, float qy, float qz, float x, float y, float z) {
   const float dx = __fsub_rn(qx, x), dy = __fsub_rn(qy, y), dz = __fsub_rn(qz, z);
   return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
-template <bool DIRECT>
-__global__ __launch_bounds__(BQ_WAVES *CPFN_WAVE) void ball_query_kernel(
+template <bool DIRECT, int BQW = BQ_WAVES>
+__global__ __launch_bounds__(BQW *CPFN_WAVE) void ball_query_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, int B, int N, int S, float thr, int K,
     int *__restrict__ idx_out) {
   const int lane = threadIdx.x & (CPFN_WAVE - 1);
   // (grid-stride over the queries: the host may launch fewer workgroups than queries / 4 — see cpfn_ball_query)
-  for (long long q = (long long)blockIdx.x * BQ_WAVES + (threadIdx.x / CPFN_WAVE); q < (long long)B * S;
-       q += (long long)gridDim.x * BQ_WAVES) {   // wave-uniform
+  for (long long q = (long long)blockIdx.x * BQW + (threadIdx.x / CPFN_WAVE); q < (long long)B * S;
+       q += (long long)gridDim.x * BQW) {   // wave-uniform
   const int b = (int)(q / S);
   const float *p = xyz + (size_t)b * N * 3;
   const float *c = new_xyz + (size_t)q * 3;
@@ -125,14 +125,14 @@ __global__ __launch_bounds__(BQT_WAVES *CPFN_WAVE) void ball_query_tiled_kernel(
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 1024;
 
-template <bool DIRECT>
-__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__restrict__ unknown,
+template <bool DIRECT, int NNT = NN_THREADS>
+__global__ __launch_bounds__(NNT) void three_nn_kernel(const float *__restrict__ unknown,
                                                               const float *__restrict__ known, int N, int M,
                                                               float *__restrict__ dist2, int *__restrict__ idx,
                                                               int sqrt_out) {
   __shared__ float4 s_known[NN_TILE];
   const int b = blockIdx.y;
-  const int i = blockIdx.x * NN_THREADS + threadIdx.x;
+  const int i = blockIdx.x * NNT + threadIdx.x;
   const float *kn = known + (size_t)b * M * 3;
   float ux = 0.f, uy = 0.f, uz = 0.f;
   if (i < N) {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(const float *__res
   for (int base = 0; base < M; base += NN_TILE) {
     const int cntk = min(NN_TILE, M - base);
     __syncthreads();
-    for (int j = threadIdx.x; j < cntk; j += NN_THREADS) {
+    for (int j = threadIdx.x; j < cntk; j += NNT) {
       const float x = kn[3 * (base + j)], y = kn[3 * (base + j) + 1], z = kn[3 * (base + j) + 2];
       s_known[j] = make_float4(x, y, z, cpfn_sqnorm3(x, y, z));
     }
