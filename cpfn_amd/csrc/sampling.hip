@@ -17,13 +17,35 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    unsigned long long o = cpfn_shfl_xor_u64(k, m);
-    k = o > k ? o : k;
-  }
+// max of a 64-bit key over lanes by DPP row operations (VALU moves, ~8 cycles each) instead of ds_bpermute butterflies
+// (an LDS-pipeline round trip per step: the two key reductions of a sample were ~0.5 us of its ~1.2 us).
+//   quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: every lane of a 16-lane row holds the row's maximum;
+//   row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the wave's maximum.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long key_max_dpp_step(unsigned long long k) {
+  const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+  return o > k ? o : k;
+}
+// every lane of a group of G consecutive lanes (G = 4, 8, 16: aligned) gets the group's maximum
+template <int G>
+__device__ __forceinline__ unsigned long long group_max_key(unsigned long long k) {
+  k = key_max_dpp_step<0xB1, 0xF>(k);
+  k = key_max_dpp_step<0x4E, 0xF>(k);
+  if (G >= 8) k = key_max_dpp_step<0x141, 0xF>(k);
+  if (G >= 16) k = key_max_dpp_step<0x140, 0xF>(k);
   return k;
+}
+// the wave's maximum, wave-uniform (read back from lane 63)
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k) {
+  k = group_max_key<16>(k);
+  k = key_max_dpp_step<0x142, 0xA>(k);
+  k = key_max_dpp_step<0x143, 0xC>(k);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 template <int NT, int PPT>
@@ -63,8 +85,14 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
   for (int i = 0; i < S; ++i) {
     if (t == 0) out[i] = (int)far;
     const float fx = s_x[far], fy = s_y[far], fz = s_z[far];
-    float best = -1.0f;
-    unsigned besti = 0xFFFFFFFFu;
+    // the lane's own arg-max over its PPT points: NCH interleaved running maxima (slot j feeds chain j % NCH), combined at
+    // the end — one chain of PPT dependent compare / select pairs is what a wave waits for when it has a SIMD to itself
+    // (16 or 32 points per lane); ties: the lowest index, as the single chain's strict '>' gave
+    constexpr int NCH = PPT >= 16 ? 4 : 1;
+    float bestc[NCH];
+    unsigned bestic[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { bestc[c] = -1.0f; bestic[c] = 0xFFFFFFFFu; }
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
       const float dx = __fsub_rn(px[j], fx), dy = __fsub_rn(py[j], fy), dz = __fsub_rn(pz[j], fz);
@@ -72,10 +100,16 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       float m = md[j];
       m = d < m ? d : m;  // never true for m = -1 (d >= 0)
       md[j] = m;
-      if (m > best) {
-        best = m;
-        besti = (unsigned)(t + j * NT);
+      if (m > bestc[j % NCH]) {
+        bestc[j % NCH] = m;
+        bestic[j % NCH] = (unsigned)(t + j * NT);
       }
+    }
+    float best = bestc[0];
+    unsigned besti = bestic[0];
+#pragma unroll
+    for (int c = 1; c < NCH; ++c) {
+      if (bestc[c] > best || (bestc[c] == best && bestic[c] < besti)) { best = bestc[c]; besti = bestic[c]; }
     }
     unsigned long long key =
         best < 0.f ? 0ull : (((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(~besti));
@@ -84,10 +118,14 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       if (lane == 0) s_key[i & 1][wave] = key;
       __syncthreads();
       key = s_key[i & 1][lane & (NW - 1)];
+      if (NW >= 4) {
+        key = group_max_key<(NW >= 4 ? NW : 4)>(key);
+      } else {
 #pragma unroll
-      for (int m = NW / 2; m >= 1; m >>= 1) {
-        unsigned long long o = cpfn_shfl_xor_u64(key, m);
-        key = o > key ? o : key;
+        for (int m = NW / 2; m >= 1; m >>= 1) {
+          unsigned long long o = cpfn_shfl_xor_u64(key, m);
+          key = o > key ? o : key;
+        }
       }
     }
     far = key ? ~(unsigned)(key & 0xFFFFFFFFull) : 0u;
@@ -251,8 +289,9 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
     fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out);
   } else if (N <= CPFN_FPS_MAX_RESIDENT) {
     // 8192 points on ONE CU either way (a sample is a VALU-throughput phase over the cloud plus two key reductions):
-    // 16 waves x 8 points per lane take 670 us for 512 samples, 8 waves x 16 points 572 us, 4 waves x 32 points 636 us
-    // (one wave per SIMD: no other wave hides a wave's dependent chains), 2 x 64 1003 us (registers spill to AGPRs).
+    // (with ds_bpermute key reductions) 16 waves x 8 points per lane took 670 us for 512 samples, 8 waves x 16 points 572 us,
+    // 4 waves x 32 points 636 us (one wave per SIMD: no other wave hides a wave's dependent chains), 2 x 64 1003 us
+    // (registers spill to AGPRs); with the DPP reductions 4 x 32 takes 522 us (the step beside it: 1.898 -> 1.868 ms).
     // Beside a training step (one workgroup per cloud on 16 CUs for the whole forward pass) the FEWER waves the better
     // for the step: 1.871 ms with 16 waves, 1.855 with 8, 1.849 with 4 (interleaved A/B on one box each).
     if (cpfn_background_geometry())
