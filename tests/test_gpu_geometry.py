@@ -268,6 +268,40 @@ def test_bf16_row_movers_vs_oracle():
     assert np.abs(gotg - wantgg).max() <= 2e-2 * np.abs(wantgg).max()
 
 
+@pytest.mark.parametrize("kind", ["ball_padded", "one_target", "uniform", "beyond_lds"])
+def test_inverse_index_lists_are_ascending(kind):
+    """cpfn_csr_build = a stable sort of the entries by target, whatever the list lengths: rows padded like a ball query's
+    (a popular target collects hundreds of entries: rank sort, one lane per entry), every entry on ONE target (beyond the
+    rank sort's list limit: insertion sort), uniform targets, and more entries than the LDS slab holds."""
+    from cpfn_amd import ops
+    rng = np.random.default_rng(21)
+    B, M = 3, 512
+    if kind == "ball_padded":
+        R, K = 128, 64
+        idx = np.empty((B, R, K), np.int64)
+        for b in range(B):
+            for r in range(R):
+                n = int(rng.integers(1, K + 1))
+                hit = np.sort(rng.choice(M, n, replace=False))
+                idx[b, r, :n] = hit
+                idx[b, r, n:] = hit[0]
+            idx[b, :40, 5:] = idx[b, :40, :1]            # forty rows padded with the same few targets
+    elif kind == "one_target":
+        idx = np.full((B, 2048, 4), 9, np.int64)
+        idx[1, ::3] = 300
+    elif kind == "uniform":
+        idx = rng.integers(0, M, (B, 8192, 3))
+    else:
+        idx = rng.integers(0, M, (B, 40000, 1))
+        idx[0, :5000] = 17
+    off, ent = ops.csr_build(T(idx, torch.int32), M)
+    off, ent = off.cpu().numpy(), ent.cpu().numpy()
+    for b in range(B):
+        flat = idx[b].reshape(-1)
+        assert np.array_equal(ent[b], np.argsort(flat, kind="stable")), kind
+        assert np.array_equal(off[b], np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=M))]))
+
+
 def test_inverse_index_adjoints_vs_oracle():
     """cpfn_csr_build gives, per target, the ascending list of referencing entries; the atomic-free adjoints
     through it match the oracle's scatter-adds and are bitwise reproducible."""
