@@ -51,6 +51,27 @@ __global__ void flag_set_kernel(unsigned *flag, unsigned value) {
   __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 }
+// flag_set with a small payload: up to 64 ints travel in the launch's arguments and are stored to `dst` BEFORE the flag (the
+// trainer's FPS seeds of the next batch: they were a 128-byte host-to-device copy, i.e. a blit kernel of its own between
+// two replays).  The waiter's stream sees them like everything else written before the flag.
+namespace {
+struct FlagPayload { int v[64]; };
+__global__ void flag_set_payload_kernel(unsigned *flag, unsigned value, int *dst, FlagPayload p, int count) {
+  if ((int)threadIdx.x < count) dst[threadIdx.x] = p.v[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+}
+extern "C" int cpfn_flag_set_payload(unsigned *flag, unsigned value, int *dst, const int *payload, int count, void *stream) {
+  if (!flag || count < 0 || count > 64 || (count > 0 && (!dst || !payload))) return -1;
+  FlagPayload p;
+  for (int i = 0; i < 64; ++i) p.v[i] = i < count ? payload[i] : 0;
+  flag_set_payload_kernel<<<1, 64, 0, (hipStream_t)stream>>>(flag, value, dst, p, count);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 extern "C" int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err, void *stream) {
   if (!flag) return -1;
   flag_wait_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flag, value, timeout_ticks, err);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
     "cpfn_flag_wait": [_vp, ctypes.c_uint, ctypes.c_uint64, _vp, _vp], "cpfn_flag_set": [_vp, ctypes.c_uint, _vp],
+    "cpfn_flag_set_payload": [_vp, ctypes.c_uint, _vp, _vp, _i, _vp],
     "cpfn_mlp_gemm_set_probe": [_vp, _i, _i],
     "cpfn_wall_clock_khz": [_i],
     "cpfn_stamp": [_vp, _vp],

@@ -48,6 +48,7 @@ def get_learning_rate(init_learning_rate, global_step, batch_size, decay_step, d
 SPLIT_GRAPHS = os.environ.get("CPFN_SPLIT_GRAPHS", "1") != "0"
 
 
+SEEDS_AS_PAYLOAD = os.environ.get("CPFN_SEEDS_AS_PAYLOAD", "1") != "0"
 FLAG_ORDER = os.environ.get("CPFN_FLAG_ORDER", "1") != "0"      # two replayed graphs ordered by device flags, not events
 
 
@@ -605,7 +606,7 @@ class SPFNTrainer:
         st["geom_ready_for"] = None
         return st
 
-    def _draw_starts(self, st, B, N):
+    def _draw_starts(self, st, B, N, as_payload=False):
         # the same two CPU-generator draws the eager path makes (geometry_utils.py:92), in the same order.
         # They go through PINNED staging buffers that live as long as the graphs, so the asynchronous copy never
         # reads from a temporary pageable tensor the host may already have reused.  Two buffers take turns and
@@ -617,8 +618,11 @@ class SPFNTrainer:
         done.synchronize()
         host[0].copy_(torch.randint(0, N, (B,), dtype=torch.long))
         host[1].copy_(torch.randint(0, self.module.sa1.num_points, (B,), dtype=torch.long))
+        if as_payload:          # the caller sends them with its flag kernel (cpfn_flag_set_payload): no host-to-device copy
+            return host
         st["start_dev"].copy_(host, non_blocking=True)
         done.record()
+        return None
 
     def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
@@ -668,8 +672,10 @@ class SPFNTrainer:
         #  no FPS seeds are drawn, so the CPU generator is consumed exactly as in eager mode)
         announce = next_batch is not None
         if st["single"]:
+            payload = None
             if announce:
-                self._draw_starts(st, B, N)
+                # (flag ordering: the 2 x B seeds travel in the arguments of the flag kernel that releases the geometry graph)
+                payload = self._draw_starts(st, B, N, as_payload=split and flags is not None and SEEDS_AS_PAYLOAD and 2 * B <= 64)
             st["geom_ready_for"] = self._batch_key(next_batch["P"]) if announce else None
             if split:
                 # geomA <- geomB (three small launches), then the side stream may overwrite geomB with the next batch's
@@ -682,7 +688,11 @@ class SPFNTrainer:
                         from . import lib as _l
                         h = _l.lib()
                         with torch.cuda.device(cur.device):
-                            _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), st["n_main"] + 1, cur.cuda_stream), "cpfn_flag_set")
+                            if payload is not None:
+                                _l.check(h.cpfn_flag_set_payload(flags[0:].data_ptr(), st["n_main"] + 1, st["start_dev"].data_ptr(),
+                                                                 payload.data_ptr(), payload.numel(), cur.cuda_stream), "cpfn_flag_set_payload")
+                            else:
+                                _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), st["n_main"] + 1, cur.cuda_stream), "cpfn_flag_set")
                             self._flag_wait(st, 0, st["n_main"] + 1, self._gside)
                             with torch.cuda.stream(self._gside):
                                 st["gs"].replay()

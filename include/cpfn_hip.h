@@ -328,6 +328,9 @@ CPFN_API int cpfn_stamp(unsigned long long *dst, void *stream);
  * setter on its stream is visible to kernels AFTER the waiter on its stream (kernel boundaries), as with an event. */
 CPFN_API int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err, void *stream);
 CPFN_API int cpfn_flag_set(unsigned *flag, unsigned value, void *stream);
+/* cpfn_flag_set with a payload of count <= 64 ints (HOST pointer: they travel in the launch's arguments) stored to the
+ * device array dst before the flag: small per-step inputs of the waiting stream without a host-to-device copy. */
+CPFN_API int cpfn_flag_set_payload(unsigned *flag, unsigned value, int *dst, const int *payload, int count, void *stream);
 CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *W, int w_trans, long long P,
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
                            float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,
