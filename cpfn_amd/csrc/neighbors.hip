@@ -25,7 +25,16 @@ __device__ __forceinline__ float direct_sqdist(float qx, float qy, float qz, flo
   return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
-template <bool DIRECT, int BQW = BQ_WAVES>
+// PACKED: xyz is [B, N, 4] = (x, y, z, |p|^2) (cpfn_pack_xyzn): one 16-byte load per point and no norm per (point, query)
+// — 6 instead of 11 vector operations per point in the scan of the wave-per-query kernel.
+__global__ void pack_xyzn_kernel(const float *__restrict__ xyz, long long R, float4 *__restrict__ out) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float x = xyz[3 * r], y = xyz[3 * r + 1], z = xyz[3 * r + 2];
+  out[r] = make_float4(x, y, z, cpfn_sqnorm3(x, y, z));
+}
+
+template <bool DIRECT, int BQW = BQ_WAVES, bool PACKED = false>
 __global__ __launch_bounds__(BQW *CPFN_WAVE) void ball_query_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, int B, int N, int S, float thr, int K,
     int *__restrict__ idx_out) {
@@ -34,7 +43,7 @@ __global__ __launch_bounds__(BQW *CPFN_WAVE) void ball_query_kernel(
   for (long long q = (long long)blockIdx.x * BQW + (threadIdx.x / CPFN_WAVE); q < (long long)B * S;
        q += (long long)gridDim.x * BQW) {   // wave-uniform
   const int b = (int)(q / S);
-  const float *p = xyz + (size_t)b * N * 3;
+  const float *p = xyz + (size_t)b * N * (PACKED ? 4 : 3);
   const float *c = new_xyz + (size_t)q * 3;
   int *out = idx_out + (size_t)q * K;
   const float qx = c[0], qy = c[1], qz = c[2];
@@ -46,11 +55,18 @@ __global__ __launch_bounds__(BQW *CPFN_WAVE) void ball_query_kernel(
     const int n = base + lane;
     bool keep = false;
     if (n < N) {
-      const float x = p[3 * n], y = p[3 * n + 1], z = p[3 * n + 2];
+      float x, y, z, pn;
+      if (PACKED) {
+        const float4 v = ((const float4 *)p)[n];
+        x = v.x; y = v.y; z = v.z; pn = v.w;
+      } else {
+        x = p[3 * n]; y = p[3 * n + 1]; z = p[3 * n + 2];
+        pn = DIRECT ? 0.f : cpfn_sqnorm3(x, y, z);
+      }
       if (DIRECT) {
         keep = direct_sqdist(qx, qy, qz, x, y, z) < thr;
       } else {
-        const float d = cpfn_pair_sqdist(qx, qy, qz, qn, x, y, z, cpfn_sqnorm3(x, y, z));
+        const float d = cpfn_pair_sqdist(qx, qy, qz, qn, x, y, z, pn);
         keep = !(d > thr);
       }
     }
@@ -332,6 +348,24 @@ extern "C" int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, in
   else
     ball_query_kernel<false><<<bq_grid(Q), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
         xyz, new_xyz, B, N, S, thr, K, idx_out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_pack_xyzn(const float *xyz, int B, int N, float *out, void *stream) {
+  if (B < 0 || N < 0 || !xyz || !out || ((uintptr_t)out & 15)) return CPFN_EINVAL;
+  const long long R = (long long)B * N;
+  if (R == 0) return 0;
+  pack_xyzn_kernel<<<cpfn_cdiv(R, 256), 256, 0, (hipStream_t)stream>>>(xyz, R, (float4 *)out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_ball_query_packed(const float *xyzn, const float *new_xyz, int B, int N, int S, float thr, int K,
+                                      int *idx_out, void *stream) {
+  if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyzn || !new_xyz || !idx_out || ((uintptr_t)xyzn & 15)) return CPFN_EINVAL;
+  const long long Q = (long long)B * S;
+  if (Q == 0) return 0;
+  ball_query_kernel<false, BQ_WAVES, true><<<bq_grid(Q), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
+      xyzn, new_xyz, B, N, S, thr, K, idx_out);
   return cpfn_launch_status();
 }
 

@@ -4,6 +4,8 @@ cuda_ops/include/utils.h:5-25, become RuntimeErrors here), output allocation wit
 torch (the C ABI never allocates) and launch on torch's current stream.
 """
 import numpy as np
+import os
+
 import torch
 
 from . import lib as _l
@@ -29,6 +31,10 @@ def _chk(t, name, dtype):
     return t
 
 
+BALL_QUERY_PACKED = os.environ.get("CPFN_BALL_QUERY_PACKED", "1") != "0"
+_background = [False]
+
+
 class background_geometry:
     """Context: the FPS / ball-query / 3-NN calls issued inside run on a side stream beside other work (the next batch's
     geometry beside a training step) and use the kernel shapes that disturb their neighbours least
@@ -36,10 +42,12 @@ class background_geometry:
 
     def __enter__(self):
         self._was = _l.lib().cpfn_set_background_geometry(1)
+        self._was_py, _background[0] = _background[0], True
         return self
 
     def __exit__(self, *exc):
         _l.lib().cpfn_set_background_geometry(self._was)
+        _background[0] = self._was_py
         return False
 
 
@@ -77,6 +85,12 @@ def ball_query(new_xyz, xyz, radius, nsample, cuda_route=False):
         if cuda_route:
             _l.check(_l.lib().cpfn_ball_query_direct(_ptr(xyz), _ptr(new_xyz), B, N, S, float(radius), int(nsample),
                                                      _ptr(out), _stream()), "cpfn_ball_query_direct")
+        elif BALL_QUERY_PACKED and _background[0] and N >= 512:
+            # beside a training step: the wave-per-query kernel on the cloud packed with its norms (less work per point)
+            pk = torch.empty(B, N, 4, dtype=torch.float32, device=xyz.device)
+            _l.check(_l.lib().cpfn_pack_xyzn(_ptr(xyz), B, N, _ptr(pk), _stream()), "cpfn_pack_xyzn")
+            _l.check(_l.lib().cpfn_ball_query_packed(_ptr(pk), _ptr(new_xyz), B, N, S, ball_query_threshold(radius),
+                                                     int(nsample), _ptr(out), _stream()), "cpfn_ball_query_packed")
         else:
             _l.check(_l.lib().cpfn_ball_query(_ptr(xyz), _ptr(new_xyz), B, N, S, ball_query_threshold(radius),
                                               int(nsample), _ptr(out), _stream()), "cpfn_ball_query")

@@ -90,6 +90,12 @@ CPFN_API int cpfn_three_nn(const float *unknown, const float *known, int B, int 
  * reference's Python wrapper hands on (modules/geometry_utils.py:184).
  * nvcc's default fma contraction of the three-term sum is assumed; not pinned bit for bit
  * (no CUDA build of the reference can run next to this library). */
+/* cpfn_ball_query on a cloud packed as [B, N, 4] = (x, y, z, |p|^2) by cpfn_pack_xyzn (16-byte aligned): the wave-per-query
+ * scan then costs one 16-byte load and six operations per point instead of three loads, the norm and the distance.  Same
+ * results as cpfn_ball_query, bit for bit (the norm is the same ((x*x + y*y) + z*z), computed once per point). */
+CPFN_API int cpfn_pack_xyzn(const float *xyz, int B, int N, float *out, void *stream);
+CPFN_API int cpfn_ball_query_packed(const float *xyzn, const float *new_xyz, int B, int N, int S, float thr, int K,
+                                    int *idx_out, void *stream);
 /* on != 0: the following cpfn_fps / cpfn_ball_query* / cpfn_three_nn* calls run BESIDE other work (a side stream next to a
  * training step) and use the kernel shapes that disturb their neighbours least; 0 (default): the fastest kernels.  Same
  * results, bit for bit.  Returns the previous setting.  (Process-wide; no reference counterpart.) */
