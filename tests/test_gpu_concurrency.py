@@ -101,6 +101,23 @@ def test_cross_stream_flags_order_two_streams_and_time_out():
     assert int(err[0]) == 0
     assert torch.equal(seen.cpu(), torch.arange(1, 65, dtype=torch.float32)), seen
     assert flags[:2].tolist() == [64, 64]
+    # a setter with a payload (the trainer's FPS seeds): the ints are in place when the waiter's stream goes on
+    import ctypes
+    dst = torch.zeros(64, dtype=torch.int32, device=dev)
+    got = torch.zeros(8, 64, dtype=torch.int32, device=dev)
+    for k in range(65, 73):
+        vals = (ctypes.c_int * 40)(*[k * 1000 + i for i in range(40)])
+        with torch.cuda.stream(a):
+            _l.check(h.cpfn_flag_wait(flags[1:].data_ptr(), k - 1, TMO, err.data_ptr(), a.cuda_stream), "cpfn_flag_wait")
+            _l.check(h.cpfn_flag_set_payload(flags[0:].data_ptr(), k, dst.data_ptr(), vals, 40, a.cuda_stream), "cpfn_flag_set_payload")
+        with torch.cuda.stream(b):
+            _l.check(h.cpfn_flag_wait(flags[0:].data_ptr(), k, TMO, err.data_ptr(), b.cuda_stream), "cpfn_flag_wait")
+            got[k - 65].copy_(dst)
+            _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), k, b.cuda_stream), "cpfn_flag_set")
+    torch.cuda.synchronize()
+    want = torch.tensor([[k * 1000 + i if i < 40 else 0 for i in range(64)] for k in range(65, 73)], dtype=torch.int32)
+    assert torch.equal(got.cpu(), want) and int(err[0]) == 0
+    assert h.cpfn_flag_set_payload(flags.data_ptr(), 1, dst.data_ptr(), vals, 65, None) != 0       # more than 64 ints
     # nobody sets flag 2: the waiter returns after ~10 ms and raises the error word
     _l.check(h.cpfn_flag_wait(flags[2:].data_ptr(), 1, 1_000_000, err.data_ptr(), torch.cuda.current_stream().cuda_stream),
              "cpfn_flag_wait")

@@ -173,6 +173,17 @@ def test_three_nn_vs_oracle(B, N, M):
     assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
 
 
+def test_background_geometry_switch_nests_and_restores():
+    from cpfn_amd import lib as _l, ops
+    h = _l.lib()
+    assert h.cpfn_set_background_geometry(0) == 0
+    with ops.background_geometry():
+        with ops.background_geometry():
+            assert h.cpfn_set_background_geometry(1) == 1
+        assert h.cpfn_set_background_geometry(1) == 1          # the inner context restored "on"
+    assert h.cpfn_set_background_geometry(0) == 0              # the outer one restored "off"
+
+
 def test_three_nn_ties_keep_the_lower_index():
     """Known points on a lattice, queries at cell centres, edge midpoints and lattice points: many exactly equal distances.
     The four-lanes-per-query kernel merges its lanes' triples in (distance, index) order — the sequential scan's result."""
