@@ -49,6 +49,7 @@ SPLIT_GRAPHS = os.environ.get("CPFN_SPLIT_GRAPHS", "1") != "0"
 
 
 SEEDS_AS_PAYLOAD = os.environ.get("CPFN_SEEDS_AS_PAYLOAD", "1") != "0"
+ADOPT_SIDE_OUTPUTS = os.environ.get("CPFN_ADOPT_SIDE_OUTPUTS", "1") != "0"    # the side graph's own outputs are the B set
 FLAG_ORDER = os.environ.get("CPFN_FLAG_ORDER", "1") != "0"      # two replayed graphs ordered by device flags, not events
 
 
@@ -514,10 +515,29 @@ class SPFNTrainer:
                 # graph runs (own memory pool: the two replay concurrently)
                 gs = torch.cuda.CUDAGraph()
                 self._gside.wait_stream(self._gstream)
-                with torch.cuda.graph(gs, stream=self._gside, capture_error_mode="thread_local"):
-                    geometry_into_B(st["P_next"])
-                    stamp(1)
-                self._gstream.wait_stream(self._gside)
+                if ADOPT_SIDE_OUTPUTS:
+                    # the tensors the captured pass allocates have fixed addresses (the graph's private pool): they ARE
+                    # the B set — no 12 MB copy at the end of every side replay.  G0 (the serial pass of an un-announced
+                    # batch) is re-captured so that it fills them.
+                    import contextlib
+                    from . import ops as _ops
+                    with torch.cuda.graph(gs, stream=self._gside, capture_error_mode="thread_local"):
+                        with _ops.background_geometry():
+                            fresh_side = self._flatten_geom(self.module.compute_geometry(st["P_next"], starts))
+                        stamp(1)
+                    self._gstream.wait_stream(self._gside)
+                    assert len(fresh_side) == len(geomB) and all(a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous()
+                                                                 for a, b in zip(fresh_side, geomB))
+                    geomB[:] = fresh_side                       # (st["geomB"] and geometry_into_B see the same list)
+                    g0b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g0b, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
+                        geometry_into_B(sb["P"], beside=False)
+                    st["g0_first"], st["g0"] = g0, g0b          # (the first one owns the pool the step's graph shares)
+                else:
+                    with torch.cuda.graph(gs, stream=self._gside, capture_error_mode="thread_local"):
+                        geometry_into_B(st["P_next"])
+                        stamp(1)
+                    self._gstream.wait_stream(self._gside)
                 st["gs"] = gs
                 st["b_read"], st["b_written"] = torch.cuda.Event(), torch.cuda.Event()
                 st["side_pending"] = False

@@ -173,6 +173,8 @@ parts = {
                                          ops.three_nn(Pn, xyz1), ops.three_nn(xyz1, xyz2)),
     "inverse-index build x3": lambda: (ops.csr_build(idx_sa2, 512), ops.csr_build(nn3, 512), ops.csr_build(nn2, 128)),
 }
+_bg = ops.background_geometry()
+_bg.__enter__()                  # the shapes the trainer's geometry pass uses beside a step
 for name, fn in parts.items():
     with torch.cuda.stream(side):
         fn()
@@ -197,6 +199,7 @@ for name, fn in parts.items():
     timed(part_step, "(q) side graph = %s" % name)
     torch.cuda.synchronize()
     timed(lambda: gpart.replay(), "    that side graph alone")
+_bg.__exit__(None, None, None)
 # ---- phase of the side graph relative to the step: released X us after the step's start (spin kernel on the side stream)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
