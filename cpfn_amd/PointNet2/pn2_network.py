@@ -23,6 +23,7 @@ FUSED_DROPOUT = os.environ.get("CPFN_FUSED_DROPOUT", "1") != "0"
 # CPFN_CHAIN_FC1=0: fc1 + bn1 as their own fused stack instead of as the last layer of sfp3's (whose last activation is
 # then materialised, and reduced by its own pass in the backward)
 CHAIN_FC1 = os.environ.get("CPFN_CHAIN_FC1", "1") != "0"
+SAMPLES_FIRST = os.environ.get("CPFN_SAMPLES_FIRST", "1") != "0"
 
 
 class PointNet2(torch.nn.Module):
@@ -65,8 +66,17 @@ class PointNet2(torch.nn.Module):
         xyz = x[:, :, :self.dim_pos].contiguous().float()
         s1, s2 = fps_start if fps_start is not None else (None, None)
         inv = self.training           # the inverse indices serve the backward adjoints only
-        g1 = self.sa1.compute_geometry(xyz, s1, cr, inv)
-        g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr, inv)
+        if SAMPLES_FIRST:
+            # both levels' FPS chains first (sa2's needs sa1's centres only), then the neighbourhood queries: beside a
+            # training step the chip-wide ball queries then start ~60 us later — in the loss section, where the chip is
+            # nearly idle, instead of beside the last GEMMs of the forward pass (same kernels, same results)
+            a1 = self.sa1.sample(xyz, s1, cr)
+            a2 = self.sa2.sample(a1[1], s2, cr)
+            g1 = self.sa1.neighbours(xyz, a1, cr, inv)
+            g2 = self.sa2.neighbours(a1[1], a2, cr, inv)
+        else:
+            g1 = self.sa1.compute_geometry(xyz, s1, cr, inv)
+            g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr, inv)
         return {"sa1": g1, "sa2": g2, "sfp2": self.sfp2.compute_geometry(g1["new_xyz"], g2["new_xyz"], cr, inv),
                 "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"], cr, inv)}
 

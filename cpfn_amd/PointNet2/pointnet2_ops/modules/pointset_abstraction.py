@@ -43,7 +43,13 @@ class PointsetAbstraction(nn.Module):
         FPS indices, sampled centres, ball-query neighbours and the centred neighbour coordinates.
         Can be run ahead of time on a side stream (PointNet2.compute_geometry).
         cuda_route: the semantics of the reference's compiled CUDA ops (`fast=True`): FPS from index 0 skipping
-        near-origin points (sampling_gpu.cu:76-91), direct-distance ball query (ball_query_gpu.cu:21-31)."""
+        near-origin points (sampling_gpu.cu:76-91), direct-distance ball query (ball_query_gpu.cu:21-31).
+        = sample() + neighbours(); a caller may interleave the two halves of several levels (PointNet2.compute_geometry
+        runs both levels' samplings first)."""
+        return self.neighbours(xyz, self.sample(xyz, start_idx, cuda_route), cuda_route, need_inverse)
+
+    def sample(self, xyz, start_idx=None, cuda_route=False):
+        """FPS + the sampled centres: (fps_idx [B,S] i32, new_xyz [B,S,3])."""
         B, N, _ = xyz.shape
         if cuda_route:          # always from index 0 (sampling_gpu.cu:76-77); a caller's start indices do not apply
             sel = ops.fps(xyz, self.num_points, None, skip_near_origin=True)
@@ -52,7 +58,12 @@ class PointsetAbstraction(nn.Module):
                 start_idx = torch.randint(0, N, (B,), dtype=torch.long)
             start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
             sel = ops.fps(xyz, self.num_points, start_idx)
-        new_xyz = ops.gather_rows(xyz, sel)
+        return sel, ops.gather_rows(xyz, sel)
+
+    def neighbours(self, xyz, sampled, cuda_route=False, need_inverse=True):
+        """Ball-query neighbours, centred neighbour coordinates and the inverse index for sample()'s centres."""
+        B, N, _ = xyz.shape
+        sel, new_xyz = sampled
         scales = []
         for r, k in zip(self.radius_list, self.num_samples_list):
             nbr = ops.ball_query(new_xyz, xyz, r, k, cuda_route=cuda_route)               # [B,S,K] i32
