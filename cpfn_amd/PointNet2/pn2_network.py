@@ -24,6 +24,7 @@ FUSED_DROPOUT = os.environ.get("CPFN_FUSED_DROPOUT", "1") != "0"
 # then materialised, and reduced by its own pass in the backward)
 CHAIN_FC1 = os.environ.get("CPFN_CHAIN_FC1", "1") != "0"
 SAMPLES_FIRST = os.environ.get("CPFN_SAMPLES_FIRST", "1") != "0"
+INVERSE_LAST = os.environ.get("CPFN_INVERSE_LAST", "1") != "0"
 
 
 class PointNet2(torch.nn.Module):
@@ -67,16 +68,28 @@ class PointNet2(torch.nn.Module):
         s1, s2 = fps_start if fps_start is not None else (None, None)
         inv = self.training           # the inverse indices serve the backward adjoints only
         if SAMPLES_FIRST:
-            # both levels' FPS chains first (sa2's needs sa1's centres only), then the neighbourhood queries: beside a
-            # training step the chip-wide ball queries then start ~60 us later — in the loss section, where the chip is
-            # nearly idle, instead of beside the last GEMMs of the forward pass (same kernels, same results)
+            # both levels' FPS chains first (sa2's needs sa1's centres only), then every chip-wide neighbourhood query (ball
+            # queries, 3-NN), the inverse-index builds (one workgroup per cloud, hundreds of microseconds of mostly waiting
+            # lanes) last: beside a training step the wide kernels then land in the loss section, where the chip is nearly
+            # idle, instead of beside the GEMMs of the forward / backward pass (same kernels, same results)
+            from ..ops import csr_build as _csr
             a1 = self.sa1.sample(xyz, s1, cr)
             a2 = self.sa2.sample(a1[1], s2, cr)
-            g1 = self.sa1.neighbours(xyz, a1, cr, inv)
-            g2 = self.sa2.neighbours(a1[1], a2, cr, inv)
-        else:
-            g1 = self.sa1.compute_geometry(xyz, s1, cr, inv)
-            g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr, inv)
+            late = INVERSE_LAST
+            g1 = self.sa1.neighbours(xyz, a1, cr, inv and not late)
+            g2 = self.sa2.neighbours(a1[1], a2, cr, inv and not late)
+            f2 = self.sfp2.compute_geometry(a1[1], a2[1], cr, inv and not late)
+            f3 = self.sfp3.compute_geometry(xyz, a1[1], cr, inv and not late)
+            if inv and late:
+                for g, sa, n_src in ((g1, self.sa1, xyz.shape[1]), (g2, self.sa2, a1[1].shape[1])):
+                    if sa.has_feats and n_src <= 2048 and len(g["scales"]) == 1:
+                        g["inv"] = _csr(g["scales"][0][0], n_src)
+                for f, m in ((f2, a2[1].shape[1]), (f3, a1[1].shape[1])):
+                    if m <= 2048:
+                        f["inv"] = _csr(f["nn_idx"], m)
+            return {"sa1": g1, "sa2": g2, "sfp2": f2, "sfp3": f3}
+        g1 = self.sa1.compute_geometry(xyz, s1, cr, inv)
+        g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr, inv)
         return {"sa1": g1, "sa2": g2, "sfp2": self.sfp2.compute_geometry(g1["new_xyz"], g2["new_xyz"], cr, inv),
                 "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"], cr, inv)}
 
