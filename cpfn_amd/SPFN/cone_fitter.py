@@ -18,3 +18,10 @@ def compute_residue_single(apex, axis, half_angle, p):
     vn = torch.nn.functional.normalize(v, p=2, dim=-1, eps=1e-12)
     alpha = acos_safe(torch.sum(vn * axis, dim=-1))
     return torch.sin(torch.clamp(torch.abs(alpha - half_angle), max=np.pi / 2)) ** 2 * torch.sum(v * v, dim=-1)
+
+
+# Names the device path does not define (host-side GT parsing / JSON export, the TensorFlow twins) come from the
+# reference's own SPFN/cone_fitter.py, found on sys.path (_reference.py): nothing of it is restated here.
+from . import _reference as _ref  # noqa: E402
+
+__getattr__ = _ref.module_fallback("cone_fitter")

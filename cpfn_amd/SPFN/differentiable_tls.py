@@ -92,3 +92,10 @@ def solve_weighted_tls(A, W):
     """A [G,N,3], W [G,N] -> x [G,3]  (reference lines 200-209)."""
     M = _m.FitMoments.apply(A, A, W.unsqueeze(2))            # instance axis of size 1
     return smallest_eigvec(M[:, 0, _m.AXX]).to(A.dtype)      # x⊗x slots: differentiable in A
+
+
+# Names the device path does not define (host-side GT parsing / JSON export, the TensorFlow twins) come from the
+# reference's own SPFN/differentiable_tls.py, found on sys.path (_reference.py): nothing of it is restated here.
+from . import _reference as _ref  # noqa: E402
+
+__getattr__ = _ref.module_fallback("differentiable_tls")

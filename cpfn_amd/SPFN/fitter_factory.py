@@ -1,6 +1,5 @@
-"""Primitive-name <-> id registry (drop-in for SPFN/fitter_factory.py:5-30).  The
-`create_primitive_from_dict` dispatcher builds host-side numpy containers
-(SPFN/primitives.py) and is outside the hot path."""
+"""Primitive-name <-> id registry (drop-in for SPFN/fitter_factory.py:5-30).  The registry is
+this module's own state; the host-side `create_primitive_from_dict` dispatcher is the reference's."""
 from . import cone_fitter, cylinder_fitter, plane_fitter, sphere_fitter  # noqa: F401
 
 primitive_name_to_id_dict = {}
@@ -22,6 +21,9 @@ def register_primitives(primitive_name_list):
     print('Registered ' + ','.join(primitive_name_list))
 
 
-def create_primitive_from_dict(d):
-    raise NotImplementedError("host-side primitive containers are outside the MI355X hot path "
-                              "(SURVEY.md §2 row 8); use the reference's SPFN.primitives")
+# `create_primitive_from_dict` (SPFN/fitter_factory.py:21-30: GT meta dict -> numpy container of SPFN/primitives.py,
+# called by the reference's data loader, Utils/dataset_utils.py:79) is host-side parsing that this package does not
+# rebuild: it resolves to the reference's own function, loaded from the checkout on sys.path (_reference.py).
+from . import _reference as _ref  # noqa: E402
+
+__getattr__ = _ref.module_fallback("fitter_factory")

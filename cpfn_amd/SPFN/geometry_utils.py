@@ -125,3 +125,10 @@ def weighted_sphere_fitting(P, W, division_eps=1e-10):
     c, r2 = fit_sphere(M[..., _m.A0], M[..., _m.AP], sym3(M[..., _m.APP]),
                        M[..., _m.B0], M[..., _m.BP], sym3(M[..., _m.BPP]), T3c)
     return c.to(P.dtype), r2.to(P.dtype)
+
+
+# Names the device path does not define (host-side GT parsing / JSON export, the TensorFlow twins) come from the
+# reference's own SPFN/geometry_utils.py, found on sys.path (_reference.py): nothing of it is restated here.
+from . import _reference as _ref  # noqa: E402
+
+__getattr__ = _ref.module_fallback("geometry_utils")

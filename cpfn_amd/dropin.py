@@ -7,6 +7,14 @@
 
 Call it before the reference's modules are imported (e.g. first line of training_SPFN.py, or a
 `sitecustomize`).  Nothing is copied: the names are aliased in `sys.modules`.
+
+What must be on `sys.path`: this repository's root (for `cpfn_amd`) and the root of the user's reference checkout
+(it is `sys.path[0]` when one of the reference's scripts runs from its directory).  The checkout keeps providing
+everything this package does not replace — `Dataset`, `Utils.*`, `Configs`, and the HOST-SIDE helpers inside the
+replaced `SPFN` package: `SPFN.primitives`, `fitter_factory.create_primitive_from_dict`,
+`*_fitter.extract_parameter_data_as_dict` / `extract_predicted_parameters_as_json` / `create_primitive_from_dict`
+(callers: Utils/dataset_utils.py:79, :112-120, SPFN/metric_implementation.py:593-599) resolve to the reference's own
+files through `cpfn_amd/SPFN/_reference.py`.
 """
 import importlib
 import sys
@@ -41,6 +49,8 @@ def install(compute_dtype=None):
     every PointNet2 built afterwards use the fused bf16 MFMA stacks by default."""
     for ref_name, ours in _ALIASES.items():
         sys.modules[ref_name] = importlib.import_module(ours)
+    from .SPFN import _reference
+    _reference.attach()            # SPFN.primitives & co. of a checkout that is already on sys.path; lazy otherwise
     if compute_dtype is not None:
         from .PointNet2 import pn2_network
         orig = pn2_network.PointNet2.__init__
