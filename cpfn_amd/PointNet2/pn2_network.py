@@ -20,11 +20,6 @@ from .pointnet2_ops.modules.pointset_feature_propagation import PointsetFeatureP
 # CPFN_FUSED_DROPOUT=0: F.dropout as separate PyTorch kernels (mask tensor) instead of the mask generated inside the
 # BatchNorm apply / backward kernels
 FUSED_DROPOUT = os.environ.get("CPFN_FUSED_DROPOUT", "1") != "0"
-# CPFN_CHAIN_FC1=0: fc1 + bn1 as their own fused stack instead of as the last layer of sfp3's (whose last activation is
-# then materialised, and reduced by its own pass in the backward)
-CHAIN_FC1 = os.environ.get("CPFN_CHAIN_FC1", "1") != "0"
-SAMPLES_FIRST = os.environ.get("CPFN_SAMPLES_FIRST", "1") != "0"
-INVERSE_LAST = os.environ.get("CPFN_INVERSE_LAST", "1") != "0"
 
 
 class PointNet2(torch.nn.Module):
@@ -67,31 +62,26 @@ class PointNet2(torch.nn.Module):
         xyz = x[:, :, :self.dim_pos].contiguous().float()
         s1, s2 = fps_start if fps_start is not None else (None, None)
         inv = self.training           # the inverse indices serve the backward adjoints only
-        if SAMPLES_FIRST:
-            # both levels' FPS chains first (sa2's needs sa1's centres only), then every chip-wide neighbourhood query (ball
-            # queries, 3-NN), the inverse-index builds (one workgroup per cloud, hundreds of microseconds of mostly waiting
-            # lanes) last: beside a training step the wide kernels then land in the loss section, where the chip is nearly
-            # idle, instead of beside the GEMMs of the forward / backward pass (same kernels, same results)
-            from ..ops import csr_build as _csr
-            a1 = self.sa1.sample(xyz, s1, cr)
-            a2 = self.sa2.sample(a1[1], s2, cr)
-            late = INVERSE_LAST
-            g1 = self.sa1.neighbours(xyz, a1, cr, inv and not late)
-            g2 = self.sa2.neighbours(a1[1], a2, cr, inv and not late)
-            f2 = self.sfp2.compute_geometry(a1[1], a2[1], cr, inv and not late)
-            f3 = self.sfp3.compute_geometry(xyz, a1[1], cr, inv and not late)
-            if inv and late:
-                for g, sa, n_src in ((g1, self.sa1, xyz.shape[1]), (g2, self.sa2, a1[1].shape[1])):
-                    if sa.has_feats and n_src <= 2048 and len(g["scales"]) == 1:
-                        g["inv"] = _csr(g["scales"][0][0], n_src)
-                for f, m in ((f2, a2[1].shape[1]), (f3, a1[1].shape[1])):
-                    if m <= 2048:
-                        f["inv"] = _csr(f["nn_idx"], m)
-            return {"sa1": g1, "sa2": g2, "sfp2": f2, "sfp3": f3}
-        g1 = self.sa1.compute_geometry(xyz, s1, cr, inv)
-        g2 = self.sa2.compute_geometry(g1["new_xyz"], s2, cr, inv)
-        return {"sa1": g1, "sa2": g2, "sfp2": self.sfp2.compute_geometry(g1["new_xyz"], g2["new_xyz"], cr, inv),
-                "sfp3": self.sfp3.compute_geometry(xyz, g1["new_xyz"], cr, inv)}
+        # both levels' FPS chains first (sa2's needs sa1's centres only), then every chip-wide neighbourhood query (ball
+        # queries, 3-NN), the inverse-index builds (one workgroup per cloud, hundreds of microseconds of mostly waiting
+        # lanes) last: beside a training step the wide kernels then land in the loss section, where the chip is nearly
+        # idle, instead of beside the GEMMs of the forward / backward pass (same kernels, same results; -4 and -9 us per
+        # step against level-by-level order)
+        from ..ops import csr_build as _csr
+        a1 = self.sa1.sample(xyz, s1, cr)
+        a2 = self.sa2.sample(a1[1], s2, cr)
+        g1 = self.sa1.neighbours(xyz, a1, cr, False)
+        g2 = self.sa2.neighbours(a1[1], a2, cr, False)
+        f2 = self.sfp2.compute_geometry(a1[1], a2[1], cr, False)
+        f3 = self.sfp3.compute_geometry(xyz, a1[1], cr, False)
+        if inv:
+            for g, sa, n_src in ((g1, self.sa1, xyz.shape[1]), (g2, self.sa2, a1[1].shape[1])):
+                if sa.has_feats and n_src <= 2048 and len(g["scales"]) == 1:
+                    g["inv"] = _csr(g["scales"][0][0], n_src)
+            for f, m in ((f2, a2[1].shape[1]), (f3, a1[1].shape[1])):
+                if m <= 2048:
+                    f["inv"] = _csr(f["nn_idx"], m)
+        return {"sa1": g1, "sa2": g2, "sfp2": f2, "sfp3": f3}
 
     def forward(self, x, glob_features=None, loc_features=None, fast=True, fps_start=None, geometry=None):
         """`fast`: the reference switches between its compiled CUDA ops (default) and its PyTorch CPU route, which
@@ -134,8 +124,8 @@ class PointNet2(torch.nn.Module):
         l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3)
         l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"), cr)
         cd = getattr(self, "compute_dtype", torch.float32)
-        # bf16 HIP path: fc1 + bn1 + relu + dropout run as the last layer of sfp3's fused stack (CPFN_CHAIN_FC1=0: its own stack)
-        chain = (CHAIN_FC1 and cd == torch.bfloat16 and x.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT
+        # bf16 HIP path: fc1 + bn1 + relu + dropout run as the last layer of sfp3's fused stack
+        chain = (cd == torch.bfloat16 and x.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT
                  and not self.features_extractor and getattr(self.sfp3, "compute_dtype", torch.float32) == torch.bfloat16)
         feat = None
         if chain:

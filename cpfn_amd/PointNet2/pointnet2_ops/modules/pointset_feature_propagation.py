@@ -5,15 +5,11 @@ of the coarse features onto the dense points, skip concatenation, shared MLP.
 Same constructor, parameter names (`mlp_convs.i`, `mlp_bns.i`) and
 `forward(pos1, pos2, feats1, feats2)` contract; `forward_rows` is the native entry.
 """
-import os
 
 import torch
 import torch.nn as nn
 
 from .... import autograd_ops, mlp, ops
-
-# CPFN_CONCAT_INTERP=0: interpolation (or the broadcast of the global vector) and torch.cat as separate launches
-CONCAT_INTERP = os.environ.get("CPFN_CONCAT_INTERP", "1") != "0"
 
 
 class PointsetFeaturePropagation(nn.Module):
@@ -50,7 +46,7 @@ class PointsetFeaturePropagation(nn.Module):
         if xyz2 is not None and geom is None:
             geom = self.compute_geometry(xyz1, xyz2, cuda_route, need_inverse=self.training and torch.is_grad_enabled())
         idx = None if xyz2 is None else geom["nn_idx"]
-        if CONCAT_INTERP and feats1 is not None and autograd_ops.concat_interp_ok(feats1, feats2, idx):
+        if feats1 is not None and autograd_ops.concat_interp_ok(feats1, feats2, idx):
             # bf16 HIP path: [feats1 | interpolation (or the broadcast global vector)] written by ONE launch
             x = autograd_ops.concat_interp(feats1, feats2, idx, None if xyz2 is None else geom["nn_w"],
                                            None if xyz2 is None else geom.get("inv"))

@@ -23,18 +23,11 @@ from . import fitters_common as _fc
 # CPFN_HOST_ASSIGNMENT=1: solve the assignment with SciPy on the host like the reference (one device->host->device
 # round trip per step) instead of cpfn_hungarian_match.
 HOST_ASSIGNMENT = os.environ.get("CPFN_HOST_ASSIGNMENT", "0") == "1"
-# CPFN_PARALLEL_BRANCHES=1: the assignment branch and the fitter branch of the loss section on two streams.  Default off
-# since the segmented sums moved into the heads post-processing launch: the assignment branch is then 45 us of kernels
-# and the fork/join pair (forward AND backward, which autograd replays on the forward's streams) costs more than it
-# hides — 2.40 ms serial against 2.51 ms forked on the same box.  (It paid while seg_stats_fwd, 25-34 us, ran there.)
-PARALLEL_BRANCHES = os.environ.get("CPFN_PARALLEL_BRANCHES", "0") == "1"
-# CPFN_SEG_FUSED=0: the label-segmented membership sums as their own pass over W (cpfn_seg_stats_fwd) instead of riding
-# on the heads post-processing launch
-SEG_FUSED = os.environ.get("CPFN_SEG_FUSED", "1") != "0"
-# ... and their adjoint added to gW inside cpfn_head_post_bwd (CPFN_SEG_BWD_FUSED=0: cpfn_seg_stats_bwd + the framework's
-# gradient-accumulation add as their own launches)
-MATCH_RIDES = os.environ.get("CPFN_MATCH_RIDES", "1") != "0"     # the assignment as extra workgroups of the moments launch
-SEG_BWD_FUSED = SEG_FUSED and os.environ.get("CPFN_SEG_BWD_FUSED", "1") != "0"
+# (Round 2 measured and dropped: the assignment branch and the fitter branch on two forked streams — the fork / join
+#  pair, forward AND backward, costs more than the 45 us it hides: 2.40 ms serial against 2.51 ms forked.)
+# The label-segmented membership sums ride on the heads post-processing launch (K <= 31; wider label sets: SegStats' own
+# pass), their adjoint is added to gW inside cpfn_head_post_bwd, and the assignment rides as extra workgroups on the fits'
+# first launch (cpfn_fit_moments_fwd_match).
 
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
                 ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
@@ -55,10 +48,10 @@ class HeadPost(torch.autograd.Function):
         h = _l.lib()
         chunks = h.cpfn_head_post_chunks(N)
         ws = torch.empty(B * chunks * 3, dtype=torch.float32, device=dev)
-        # the label-segmented membership sums ride on this launch (SEG_FUSED, K <= 31): SegStats then has nothing to
+        # the label-segmented membership sums ride on this launch (K <= 31): SegStats then has nothing to
         # compute in its forward pass
         seg_ws = S = None
-        if with_seg and SEG_FUSED and K <= 31:
+        if with_seg and K <= 31:
             seg_ws = torch.empty(B * chunks * (K + 2) * K, dtype=torch.float32, device=dev)
             S = torch.empty(B, K + 2, K, dtype=torch.float32, device=dev)
         # ... and so does the number of GT instances per cloud (count_gt picks it up: no cpfn_count_labels launch)
@@ -76,13 +69,11 @@ class HeadPost(torch.autograd.Function):
         ctx.save_for_backward(Yc, Xg, Ig, Tg, W, stats)
         ctx.set_materialize_grads(False)          # (an unused output costs no zero-fill launch)
         if with_seg:
-            # SEG_BWD_FUSED: S is a DIFFERENTIABLE output of this node — its adjoint (what SegStats.backward computes,
+            # S is a DIFFERENTIABLE output of this node — its adjoint (what SegStats.backward computes,
             # cpfn_seg_stats_bwd) is added to gW inside cpfn_head_post_bwd: one launch instead of three (the adjoint, the
             # framework's accumulation add of the two [B,N,K] gradients of W, the heads' backward)
             if S is None:
                 S = torch.empty(0, device=dev)
-                ctx.mark_non_differentiable(S)
-            elif not SEG_BWD_FUSED:
                 ctx.mark_non_differentiable(S)
             return Xn, W, stats[:, 0], stats[:, 1], S
         return Xn, W, stats[:, 0], stats[:, 1]
@@ -305,7 +296,7 @@ def fit_params_and_match(P, W, Xn, multipliers, S, n_gt):
     """fit_params + hungarian_device with the assignment riding on the fits' first launch (cpfn_fit_moments_fwd_match:
     the two are independent; one launch and the shorter of the two durations less on the chain).  Returns (params, match);
     falls back to the two separate launches when there are no fits to ride on."""
-    if not MATCH_RIDES or not (multipliers["residue"] > 0 or multipliers["parameter"] > 0):
+    if not (multipliers["residue"] > 0 or multipliers["parameter"] > 0):
         return fit_params(P, W, Xn, multipliers), hungarian_device(S, n_gt)
     from . import moments as _m
     _drop_pending_n_gt()
@@ -330,38 +321,9 @@ def pre_match(Y, batch):
     """Everything before the host-side assignment: unit normals, memberships, per-cloud normal /
     type losses and the label-segmented sums S.  (Capturable: no host synchronisation.)"""
     Xn, W, nl, tl, S_pre = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"], True)
-    if SEG_BWD_FUSED and S_pre.numel() == W.shape[0] * (W.shape[2] + 2) * W.shape[2]:
+    if S_pre.numel() == W.shape[0] * (W.shape[2] + 2) * W.shape[2]:
         return Xn, W, nl, tl, S_pre                   # computed AND differentiated by the heads post-processing node
     return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"], S_pre)
-
-
-_branch_streams = {}
-
-
-def match_and_fit(P, Y, batch, multipliers):
-    """Heads post-processing, then TWO independent branches run side by side: (segmented sums -> assignment) on a
-    forked stream and (the four fits) on the current one — both are a handful of low-occupancy, latency-bound
-    kernels (one wave per cloud / one lane per instance), so they overlap almost for free.  Returns
-    (Xn, W, nl, tl, S, n_gt, match, params).  Capturable (the fork becomes a parallel branch of the graph)."""
-    Xn, W, nl, tl, S_pre = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"], True)
-    dev = W.device
-    cur = torch.cuda.current_stream(dev)
-    key = (dev.index, cur.cuda_stream)
-    side = _branch_streams.get(key)
-    if side is None:
-        side = _branch_streams[key] = torch.cuda.Stream(device=dev)
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        S = S_pre if (SEG_BWD_FUSED and S_pre.numel() == W.shape[0] * (W.shape[2] + 2) * W.shape[2]) else \
-            SegStats.apply(W, batch["I_gt"], S_pre)
-        n_gt = count_gt(batch["I_gt"])
-        match = hungarian_device(S, n_gt)
-    W.record_stream(side)                       # produced here, read on the side stream
-    params = fit_params(P, W, Xn, multipliers)
-    cur.wait_stream(side)
-    for t in (S, n_gt, match):                  # produced on the side stream, read here from now on
-        t.record_stream(cur)
-    return Xn, W, nl, tl, S, n_gt, match, params
 
 
 def fit_params(P, W, Xn, multipliers):
@@ -413,15 +375,9 @@ def fused_losses(P, Y, batch, multipliers, classes):
     if HOST_ASSIGNMENT:
         Xn, W, nl, tl, S = pre_match(Y, batch)
         n_gt = count_gt(batch["I_gt"])
-        if HOST_ASSIGNMENT:
-            match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
-        else:
-            match = hungarian_device(S, n_gt)
+        match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
         return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt)
-    if not PARALLEL_BRANCHES:
-        Xn, W, nl, tl, S = pre_match(Y, batch)
-        n_gt = count_gt(batch["I_gt"])
-        params, match = fit_params_and_match(P, W, Xn, multipliers, S, n_gt)
-        return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt, params)
-    Xn, W, nl, tl, S, n_gt, match, params = match_and_fit(P, Y, batch, multipliers)
+    Xn, W, nl, tl, S = pre_match(Y, batch)
+    n_gt = count_gt(batch["I_gt"])
+    params, match = fit_params_and_match(P, W, Xn, multipliers, S, n_gt)
     return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt, params)

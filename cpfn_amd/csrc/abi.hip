@@ -35,12 +35,17 @@ extern "C" int cpfn_stamp(unsigned long long *dst, void *stream) {
 // (agent-scope release).  The data handed over is written by kernels that precede the setter on its stream and read by
 // kernels that follow the waiter on its stream: kernel boundaries make it visible, exactly as with an event.
 // A waiter gives up after `timeout_ticks` of the 100 MHz wall clock (the setter never came: a host-side error between the
-// two launches), sets *err = 1 and lets its stream continue instead of hanging the GPU.
+// two launches, or the other stream stalled for longer than the caller allowed for), sets *err = 1 (pinned host word the
+// host polls) AND *fault = 1.0f (device word: the trainer hands it to the optimizer as its "skip this step" flag, so that
+// nothing computed after a broken hand-over can reach the weights — the host may already have queued several steps by the
+// time it sees *err), and lets its stream continue instead of hanging the GPU.  Both words are sticky.
 namespace {
-__global__ void flag_wait_kernel(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err) {
+__global__ void flag_wait_kernel(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err,
+                                 float *fault) {
   const unsigned long long t0 = (unsigned long long)wall_clock64();
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
     if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+      if (fault) __hip_atomic_store(fault, 1.0f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (err) *(volatile unsigned *)err = 1u;       // (plain store: err may live in pinned host memory)
       break;
     }
@@ -72,9 +77,10 @@ extern "C" int cpfn_flag_set_payload(unsigned *flag, unsigned value, int *dst, c
   flag_set_payload_kernel<<<1, 64, 0, (hipStream_t)stream>>>(flag, value, dst, p, count);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
-extern "C" int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err, void *stream) {
+extern "C" int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err,
+                              float *fault, void *stream) {
   if (!flag) return -1;
-  flag_wait_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flag, value, timeout_ticks, err);
+  flag_wait_kernel<<<1, 1, 0, (hipStream_t)stream>>>(flag, value, timeout_ticks, err, fault);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 extern "C" int cpfn_flag_set(unsigned *flag, unsigned value, void *stream) {

@@ -658,41 +658,32 @@ constexpr int SP_DEPTH = 2;   // slots in flight per wave (4 measured slower on 
 // 64-row tiles halve the weight re-reads; 32-row tiles when that would leave fewer than 256 workgroups
 static inline int sp_rows(long long P, int N) { return ((P + 63) / 64) * (N / 64 > 0 ? N / 64 : 1) >= 256 ? 64 : 32; }
 
-// Data gradient of a small layer with the BatchNorm backward folded in (cpfn_mlp_dgrad_small):
-//   APPLY: A is the gradient w.r.t. the layer's ACTIVATED output and Yr its pre-BN output; the operand fragment becomes
-//          g_y = bf16(c0 [ysc y + ysh > 0] g + c1 y + c2) on the fly (per contraction channel; cpfn_bn_bwd_apply's
-//          arithmetic, so the stand-alone apply launch and the g_y tensor disappear);
+// Data gradient of a small layer with the reduction of the layer below riding on it (cpfn_mlp_dgrad_small):
 //   BST:   pass 1 of the BatchNorm backward of the layer BELOW from the tile being stored (sum g_z, sum g_z y with the
 //          ReLU mask from that layer's pre-BN output Yb): its stand-alone cpfn_bn_relu_bwd launch disappears.
+// (Round 2 also formed g_y on the operand load here and in the 64 x 64 weight gradient: every 64-column block re-forms the
+//  whole panel, the two kernels got 4-6 us slower each and cancelled the saved launch — removed in round 3.)
 struct SmallpBwdArgs {
-  const unsigned short *Yr;                 // APPLY: [P, K] like A
-  const float *coef, *y_scale, *y_shift;    // APPLY: [3][K], [K], [K]
   const unsigned short *Yb;                 // BST: [P, ldy] like Y
   const float *b_scale, *b_shift;           // BST: [N]
 };
 
-template <int RT, bool STATS, bool WT, bool APPLY = false, bool BST = false>
+template <int RT, bool STATS, bool WT, bool BST = false>
 __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
     const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
     int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
     const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe,
     const SmallpBwdArgs bw = SmallpBwdArgs()) {
   constexpr int TT = RT / 16, D = SP_DEPTH, LDT = 64 + 8;
-  static_assert(!(STATS && BST) && (!APPLY || WT) && (!BST || WT), "the backward variants belong to the data gradient");
+  static_assert(!(STATS && BST) && (!BST || WT), "the riding reduction belongs to the data gradient");
   const unsigned long long probe_t0 = probe_begin(probe);
   constexpr int RAW_TILE = 4 * 32 * LDT * 2, RAW_RED = 4 * 4 * TT * 64 * 16;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW_TILE > RAW_RED ? RAW_TILE : RAW_RED];
-  __shared__ __attribute__((aligned(16))) float s_ss[APPLY ? 5 : 2][SP_SS_MAX];
+  __shared__ __attribute__((aligned(16))) float s_ss[2][SP_SS_MAX];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * 64, row0 = blockIdx.x * RT;
-  if (APPLY) {
-    for (int e = t; e < K; e += 256) {
-      s_ss[0][e] = bw.y_scale[e]; s_ss[1][e] = bw.y_shift[e];
-      s_ss[2][e] = bw.coef[e]; s_ss[3][e] = bw.coef[K + e]; s_ss[4][e] = bw.coef[2 * K + e];
-    }
-    __syncthreads();
-  } else if (a_scale) {
+  if (a_scale) {
     for (int e = t; e < K; e += 256) { s_ss[0][e] = a_scale[e]; s_ss[1][e] = a_shift[e]; }
     __syncthreads();
   }
@@ -703,7 +694,6 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
   // with K = 256 that was 4x the traffic, and the kernel was slower than the one it replaces.)
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, N * K * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(APPLY ? (void *)bw.Yr : (void *)A, 0, a_bytes, 0x00020000);
   unsigned aoff[TT];   // byte offsets
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
@@ -720,15 +710,12 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
   const unsigned wstep = WT ? 32u * N * 2 : 64u;
   unsigned short *tile = (unsigned short *)s_raw + wave * 32 * LDT;   // this wave's [32 k][64 n] slice (WT only)
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // (a plain vector type: HIP's uint4 struct blocks SROA here)
-  u32x4 ra[D][TT], ry[APPLY ? D : 1][TT];
+  u32x4 ra[D][TT];
   u32x4 rw[D][4];
   auto issue = [&](int d, int s) __attribute__((always_inline)) {
     const unsigned oob = s < S ? 0u : 0x80000000u;
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      ra[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (aoff[tt] + s * 64) | oob, 0, 0);
-      if (APPLY) ry[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (aoff[tt] + s * 64) | oob, 0, 0);
-    }
+    for (int tt = 0; tt < TT; ++tt) ra[d][tt] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (aoff[tt] + s * 64) | oob, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) rw[d][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (woff[i] + s * wstep) | oob, 0, 0);
   };
@@ -763,34 +750,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(bf16x8, rw[d][i]);
         }
-        if (APPLY) {     // g_y from (g, y): bn_bwd_apply_kernel<true>'s arithmetic, element for element
-          float sc[8], sh[8], c0[8], c1[8], c2[8];
-          const int k0 = s * 32 + 8 * lq;
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            *(cpfn_f32x4 *)&sc[4 * hh] = *(const cpfn_f32x4 *)&s_ss[0][k0 + 4 * hh];
-            *(cpfn_f32x4 *)&sh[4 * hh] = *(const cpfn_f32x4 *)&s_ss[1][k0 + 4 * hh];
-            *(cpfn_f32x4 *)&c0[4 * hh] = *(const cpfn_f32x4 *)&s_ss[2][k0 + 4 * hh];
-            *(cpfn_f32x4 *)&c1[4 * hh] = *(const cpfn_f32x4 *)&s_ss[3][k0 + 4 * hh];
-            *(cpfn_f32x4 *)&c2[4 * hh] = *(const cpfn_f32x4 *)&s_ss[4][k0 + 4 * hh];
-          }
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt) {
-            const u32x4 g4 = ra[d][tt], y4 = ry[d][tt];
-            u32x4 o4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float y0 = __uint_as_float(y4[j] << 16), y1 = __uint_as_float(y4[j] & 0xffff0000u);
-              float z0 = __uint_as_float(g4[j] << 16), z1 = __uint_as_float(g4[j] & 0xffff0000u);
-              z0 = fmaf(sc[2 * j], y0, sh[2 * j]) > 0.f ? z0 : 0.f;
-              z1 = fmaf(sc[2 * j + 1], y1, sh[2 * j + 1]) > 0.f ? z1 : 0.f;
-              const unsigned lo = f2bf(fmaf(c0[2 * j], z0, fmaf(c1[2 * j], y0, c2[2 * j])));
-              const unsigned hi = f2bf(fmaf(c0[2 * j + 1], z1, fmaf(c1[2 * j + 1], y1, c2[2 * j + 1])));
-              o4[j] = lo | (hi << 16);
-            }
-            af[tt] = __builtin_bit_cast(bf16x8, o4);
-          }
-        } else if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
+        if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
           float sc[8], sh[8];
           const int k0 = s * 32 + 8 * lq;
           *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[0][k0]; *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[0][k0 + 4];
@@ -1274,22 +1234,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const unsigned s
 constexpr int WG_STEP = 32;       // rows per MFMA step
 constexpr int WG_DEPTH = 4;       // steps in flight
 
-// APPLY (cpfn_mlp_wgrad_apply, 64 x 64 tiles): Gy is the gradient w.r.t. the layer's ACTIVATED output; g_y is formed on the
-// staged chunks from the layer's pre-BN output Yr with cpfn_bn_bwd_apply's arithmetic (see mlp_bwd_fused_kernel).
-struct WgradApplyArgs {
-  const unsigned short *Yr;
-  const float *coef, *y_scale, *y_shift;
-};
-
-template <int TN, int TK, bool APPLY = false>
+template <int TN, int TK>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
                                                         const unsigned short *__restrict__ A, int lda,
                                                         const int *__restrict__ gidx, long long P, int N, int K,
                                                         long long rows_per_split, float *__restrict__ partial,
                                                         const float *__restrict__ a_scale,
                                                         const float *__restrict__ a_shift,
-                                                        unsigned long long *probe = nullptr,
-                                                        const WgradApplyArgs ap = WgradApplyArgs()) {
+                                                        unsigned long long *probe = nullptr) {
   const unsigned long long probe_t0 = probe_begin(probe);
   constexpr int LDN = TN + 8, LDK = TK + 8;       // LDS row strides (elements)
   constexpr int CG = TN / 64, CA = TK / 64;       // 16-byte chunks per thread and step
@@ -1315,16 +1267,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
   // chunk c = t + 256 i of a step: row c / (T/8), column 8 (c % (T/8))
-  uint4 vg[WG_DEPTH][CG], va[WG_DEPTH][CA], vy[APPLY ? WG_DEPTH : 1][CG];
-  float cf0[8], cf1[8], cf2[8], ysc[8], ysh[8];      // APPLY: a lane's g_y chunk columns never change either
-  if (APPLY) {
-    const int col = n0 + (t % (TN / 8)) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      cf0[j] = ap.coef[col + j]; cf1[j] = ap.coef[N + col + j]; cf2[j] = ap.coef[2 * N + col + j];
-      ysc[j] = ap.y_scale[col + j]; ysh[j] = ap.y_shift[col + j];
-    }
-  }
+  uint4 vg[WG_DEPTH][CG], va[WG_DEPTH][CA];
   // optional BatchNorm + ReLU of the PREVIOUS layer on the A operand (a lane's chunk columns never change)
   float asc[CA][8], ash[CA][8];
   if (a_scale) {
@@ -1341,7 +1284,6 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
       const int c = t + 256 * i;
       const long long p = min(base + c / (TN / 8), p1 - 1);      // clamped: always a valid row, zeroed at store time
       vg[sidx][i] = *(const uint4 *)(Gy + p * ldg + n0 + (c % (TN / 8)) * 8);
-      if (APPLY) vy[sidx][i] = *(const uint4 *)(ap.Yr + p * ldg + n0 + (c % (TN / 8)) * 8);
     }
 #pragma unroll
     for (int i = 0; i < CA; ++i) {
@@ -1357,22 +1299,6 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
     for (int i = 0; i < CG; ++i) {
       const int c = t + 256 * i, r = c / (TN / 8);
       uint4 v = vg[sidx][i];
-      if (APPLY) {
-        const uint4 y4 = vy[sidx][i];
-        const unsigned gw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {y4.x, y4.y, y4.z, y4.w};
-        unsigned ow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float y0 = __uint_as_float(yw[j] << 16), y1 = __uint_as_float(yw[j] & 0xffff0000u);
-          float z0 = __uint_as_float(gw[j] << 16), z1 = __uint_as_float(gw[j] & 0xffff0000u);
-          z0 = fmaf(ysc[2 * j], y0, ysh[2 * j]) > 0.f ? z0 : 0.f;
-          z1 = fmaf(ysc[2 * j + 1], y1, ysh[2 * j + 1]) > 0.f ? z1 : 0.f;
-          const unsigned lo = f2bf(fmaf(cf0[2 * j], z0, fmaf(cf1[2 * j], y0, cf2[2 * j])));
-          const unsigned hi = f2bf(fmaf(cf0[2 * j + 1], z1, fmaf(cf1[2 * j + 1], y1, cf2[2 * j + 1])));
-          ow[j] = lo | (hi << 16);
-        }
-        v = (uint4){ow[0], ow[1], ow[2], ow[3]};
-      }
       if (base + r >= p1) v = (uint4){0, 0, 0, 0};
       *(uint4 *)&s_g[r * LDN + (c % (TN / 8)) * 8] = v;
     }
@@ -1451,15 +1377,12 @@ struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the
   const unsigned short *pool_yarg;           // ... the pre-BN value there; Gy is then the POOLED gradient [P / pool_k, TN]
   int pool_k;
   long long groups;
-  const float *xyz, *w0;                     // XYZ: the layer's input is the pre-BN output of an fp32-xyz first layer,
-                                             //      y0 = bf16(W0 [TK][3] . xyz [P][3]): RECOMPUTED here instead of read
 };
 
-// XYZ (sa1's second layer, TK = 64): both uses of the first layer's pre-BN output y0 — the input operand (before its
-// BN + ReLU transform) and the y of the riding reduction — are recomputed from the 12-byte coordinate row with
-// smallk_fwd_kernel's arithmetic (three fused multiply-adds per channel, rounded to bf16) instead of read: y0 is
-// [524288, 64] bf16 = 67 MB per read, the coordinates 6 MB.
-template <int TN, int TK, int STEP, bool BST, int APPLY, bool XYZ = false>
+// (Round 2 also had an instantiation that RECOMPUTED sa1's first-layer output from the coordinates inside the 64 -> 64
+//  shape instead of reading it: 134 MB fewer reads bought 2 us of 65 — the shape is bound by VALU + LDS issue — and it was
+//  removed in round 3; the recompute lives on in cpfn_smallk_wgrad_apply_xyz, where it pays.)
+template <int TN, int TK, int STEP, bool BST, int APPLY>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
     const unsigned short *__restrict__ W /* forward weight panel [TN][TK] bf16 */, long long P, long long rows_per_split,
@@ -1470,7 +1393,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   const unsigned long long probe_t0 = probe_begin(probe);
   const unsigned short *__restrict__ Yr = ap.Yr;
   // (rows in flight: 128, and 64 for the 256-wide g_y — the same bytes, half the staging registers.  The 64-row-step shapes
-  //  are NOT waiting for memory: taking 134 MB of the 64 -> 64 kernel's reads away (XYZ) saved 2 us of 65, and 256 rows in
+  //  are NOT waiting for memory: taking 134 MB of the 64 -> 64 kernel's reads away (recomputing them) saved 2 us of 65, and 256 rows in
   //  flight instead of 128 made both of them 5 % slower (registers); their apply / statistics / conversion VALU work and
   //  LDS traffic per row are what a 64-channel row costs.)
   constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP / (TN > 128 ? 2 : 1), KSTEPS = STEP / 32;
@@ -1514,30 +1437,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // chunk i of thread t: row t / CPR + i (NT / CPR), columns 8 (t % CPR) — a thread's columns never change
   const int grow = t / CPRG, gcol = (t % CPRG) * 8, arow = (TA == NT ? t : t % TA) / CPRA, acol = (t % CPRA) * 8;
   const bool a_live = TA == NT || t < TA;
-  uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[XYZ ? 1 : DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
-  static_assert(!XYZ || (BST && TK <= 64), "XYZ: the recomputed tensor is the input AND the y of the riding reduction");
-  float vx[XYZ ? DEPTH : 1][NA][3], xb[XYZ && DB ? 2 : 1][XYZ ? NA : 1][3], w0r[XYZ ? 8 : 1][3];   // coordinate rows in flight / of the pending slab
-  if (XYZ) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) w0r[j][q] = ap.w0[(acol + j) * 3 + q];
-  }
-  // y0 chunk (8 channels of one row) from its coordinates: smallk_fwd_kernel's arithmetic
-  auto y0_chunk = [&](const float (&x)[3]) {
-    unsigned ow[4];      // (packed by shifts: reading a uint4 back out of an unsigned short array is type punning)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        v0 = fmaf(w0r[XYZ ? 2 * j : 0][q], x[q], v0);
-        v1 = fmaf(w0r[XYZ ? 2 * j + 1 : 0][q], x[q], v1);
-      }
-      ow[j] = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-    }
-    return (uint4){ow[0], ow[1], ow[2], ow[3]};
-  };
+  uint4 vg[APPLY == 2 ? 1 : DEPTH][NG], va[DEPTH][NA], vy[APPLY ? DEPTH : 1][NG];
   uint4 vgp[APPLY == 2 ? DEPTH : 1], vya[APPLY == 2 ? DEPTH : 1];       // pooled gradient / arg-max value of the step's group
   uint2 var_[APPLY == 2 ? DEPTH : 1];                                    // arg-max row (8 channels, one byte each)
   // (pooled: a step never straddles two groups — the host checks pool_k % STEP == 0)
@@ -1586,12 +1486,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const long long p = min(base + arow + i * RPA, p1 - 1);
-        if (XYZ) {
-#pragma unroll
-          for (int q = 0; q < 3; ++q) vx[sidx][i][q] = ap.xyz[p * 3 + q];
-        } else {
-          va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
-        }
+        va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
       }
     }
   };
@@ -1671,14 +1566,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int r = arow + i * RPA;
-        uint4 a4;
-        if (XYZ) {
-          a4 = y0_chunk(vx[sidx][i]);
-#pragma unroll
-          for (int q = 0; q < 3; ++q) xb[XYZ && DB ? buf : 0][i][q] = vx[sidx][i][q];   // this step's slab is stored one step later
-        } else {
-          a4 = va[sidx][i];
-        }
+        uint4 a4 = va[sidx][i];
         if (a_scale) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
         if (base + r >= p1) a4 = (uint4){0, 0, 0, 0};
         *(uint4 *)&s_a[r * LDK + acol] = a4;
@@ -1699,7 +1587,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       if (p < p1) {
         *(uint4 *)(Gout + p * ldo + acol) = v;
         if (BST) {
-          const uint4 ybv = XYZ ? y0_chunk(xb[XYZ && DB ? buf : 0][XYZ ? i : 0]) : yb[i];
+          const uint4 ybv = yb[i];
           const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {ybv.x, ybv.y, ybv.z, ybv.w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1725,23 +1613,25 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       constexpr int dummy_ = 0; (void)dummy_;
       const int buf = DB ? (d & 1) : 0;
       unsigned short *s_g = s_g2[buf], *s_a = s_a2[buf], *s_o = s_o2[buf];
-      if (DB && !XYZ) {
+      if (DB) {
+        // ONE barrier per step.  Why that orders every LDS access (tests/test_gpu_concurrency.py replays these shapes
+        // hundreds of times beside the geometry graph and compares bit for bit): step d writes the row tiles of parity
+        // d & 1, the barrier, reads the slab patch of parity (d - 1) & 1 (completed by every wave BEFORE it arrived at this
+        // barrier), then reads the row tiles of parity d & 1 and writes the patch of parity d & 1.  A wave can only be
+        // one barrier ahead of the slowest one, i.e. staging step d + 1 into the OTHER parity while the slowest still
+        // reads step d's tiles; the tiles / patch of parity d & 1 are written again at step d + 2, behind barrier d + 1,
+        // which the slowest wave only reaches after all its reads of step d.
         stage(d, base, buf);
-        __syncthreads();            // the only barrier of the step (see DB above)
+        __syncthreads();
         if (prev >= 0) store_prev(prev, buf ^ 1);
       } else {
-        // (XYZ keeps both barriers: with one, this instantiation alone returned run-to-run different weight gradients
-        //  inside a stack — 20 of 20 runs — while stand-alone replays of the same launch were reproducible; the ordering
-        //  argument above holds for it like for the others and its ISA shows the expected barriers and buffer offsets, so
-        //  the cause is not understood.  The other single-barrier instantiations: 120 stack runs and every parity test
-        //  bit-identical to the two-kernel path.)
         __syncthreads();
         if (prev >= 0) store_prev(prev, DB ? buf ^ 1 : 0);
         stage(d, base, buf);
         __syncthreads();
       }
       issue(d, base + STEP * DEPTH);
-      if (BST && !XYZ) {       // this step's slab, used one step later
+      if (BST) {       // this step's slab, used one step later
 #pragma unroll
         for (int i = 0; i < NA; ++i)
           yb[i] = *(const uint4 *)(Yb + min(base + arow + i * RPA, p1 - 1) * ldo + acol);
@@ -1835,146 +1725,6 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     }
   }
   probe_end(probe, probe_t0, 5);
-}
-
-// ---------------------------------------------------------------- forward GEMM + statistics, row-streaming form
-// The forward layers at 131072 rows (67-100 MB per launch) ran at 2.7 TB/s in the streaming kernel above: with four waves
-// the epilogue (BatchNorm statistics from the staged tile, BN + ReLU of the previous layer on the operand) is VALU work
-// that nothing overlaps.  This kernel is the data-gradient half of mlp_bwd_fused_kernel turned around: EIGHT waves,
-// 32-row steps through a 4-deep register pipeline -> LDS -> MFMA, the weight panel [NO][KC] in LDS once per workgroup,
-// the 32 x NO output slab leaves one step later as 16-byte row stores, and a thread's statistics cover the one 8-channel
-// chunk it stores (sum y, sum y^2 of the ROUNDED values, as before).  Y is bit-identical to the streaming kernel's (same
-// MFMA order); the per-workgroup partial sums group the rows differently.  <KC, NO>: <128,128>, <192,128>, <128,256>.
-template <int KC, int NO, bool ATR>
-__global__ __launch_bounds__(512) void mlp_fwd_rows_kernel(
-    const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W /* [NO][KC] */, long long P,
-    long long rows_per_wg, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
-    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe) {
-  const unsigned long long probe_t0 = probe_begin(probe);
-  constexpr int NT = 512, STEP = 32, DEPTH = 4, LDA_ = KC + 8, LDO = NO + 8;
-  constexpr int CPRA = KC / 8, CPRO = NO / 8;
-  constexpr int RPA = NT / CPRA >= 32 ? 32 : 16, TA = RPA * CPRA, NA = STEP / RPA;   // operand chunks (KC = 192: 384 threads x 2)
-  constexpr int NOC = STEP * CPRO / NT;                                                // output chunks per thread and step
-  constexpr int CHB = NO / 16, TPW = 2 * CHB / 8;                                      // 16 x 16 tiles of the slab per wave
-  static_assert(NOC >= 1 && TA <= NT && NT % CPRO == 0 && CHB % 8 == 0, "shape");
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[STEP * LDA_];
-  __shared__ __attribute__((aligned(16))) unsigned short s_o[STEP * LDO];
-  __shared__ __attribute__((aligned(16))) unsigned short s_w[NO * LDA_];
-  static_assert(sizeof(float) * 8 * 2 * NO <= sizeof(unsigned short) * NO * LDA_, "the statistics reduction reuses s_w");
-  float(*s_red)[2][NO] = (float(*)[2][NO])s_w;        // after the last step only
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lq = lane >> 4;
-  const long long p0 = (long long)blockIdx.x * rows_per_wg, p1 = min(P, p0 + rows_per_wg);
-  const int ocol = (t % CPRO) * 8, orow = t / CPRO;
-  float st_s[8], st_q[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { st_s[j] = 0.f; st_q[j] = 0.f; }
-  if (p0 < p1) {
-    const int arow = (TA == NT ? t : t % TA) / CPRA, acol = (t % CPRA) * 8;
-    const bool a_live = TA == NT || t < TA;
-    uint4 va[DEPTH][NA];
-    float asc[8], ash[8];
-    if (ATR) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { asc[j] = a_scale[acol + j]; ash[j] = a_shift[acol + j]; }
-    }
-    auto issue = [&](int sidx, long long base) {
-      if (a_live) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) va[sidx][i] = *(const uint4 *)(A + min(base + arow + i * RPA, p1 - 1) * lda + acol);
-      }
-    };
-    auto stage = [&](int sidx, long long base) {
-      if (a_live) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          const int r = arow + i * RPA;
-          uint4 a4 = va[sidx][i];
-          if (ATR) a4 = __builtin_bit_cast(uint4, bn_relu_frag(__builtin_bit_cast(bf16x8, a4), asc, ash));
-          if (base + r >= p1) a4 = (uint4){0, 0, 0, 0};
-          *(uint4 *)&s_a[r * LDA_ + acol] = a4;
-        }
-      }
-    };
-    auto store_prev = [&](long long pbase) {
-#pragma unroll
-      for (int i = 0; i < NOC; ++i) {
-        const int r = orow + i * (NT / CPRO);
-        const long long p = pbase + r;
-        const uint4 v = *(const uint4 *)&s_o[r * LDO + ocol];
-        if (p < p1) {
-          *(uint4 *)(Y + p * ldy + ocol) = v;
-          const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float y0 = __uint_as_float(w4[j] << 16), y1 = __uint_as_float(w4[j] & 0xffff0000u);
-            st_s[2 * j] += y0; st_s[2 * j + 1] += y1;
-            st_q[2 * j] = fmaf(y0, y0, st_q[2 * j]); st_q[2 * j + 1] = fmaf(y1, y1, st_q[2 * j + 1]);
-          }
-        }
-      }
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(d, p0 + (long long)d * STEP);
-    fill_w_panel<NO, LDA_, NT>(s_w, W, KC, NO, 0, 0, KC, 0, t);
-    long long prev = -1;
-    for (long long base0 = p0; base0 < p1; base0 += STEP * DEPTH) {
-#pragma unroll
-      for (int d = 0; d < DEPTH; ++d) {
-        const long long base = base0 + (long long)d * STEP;
-        __syncthreads();
-        if (prev >= 0) store_prev(prev);
-        stage(d, base);
-        __syncthreads();
-        issue(d, base + STEP * DEPTH);
-        // wave w: output channels 16 (w + 8 i) .. +15 of both 16-row halves (the two tiles share the weight fragment)
-        f32x4 ad[TPW / 2][2];
-#pragma unroll
-        for (int i = 0; i < TPW / 2; ++i) { ad[i][0] = (f32x4){0, 0, 0, 0}; ad[i][1] = (f32x4){0, 0, 0, 0}; }
-#pragma unroll
-        for (int ks = 0; ks < KC / 32; ++ks) {
-          const bf16x8 pf0 = *(const bf16x8 *)&s_a[lr * LDA_ + ks * 32 + 8 * lq];
-          const bf16x8 pf1 = *(const bf16x8 *)&s_a[(16 + lr) * LDA_ + ks * 32 + 8 * lq];
-#pragma unroll
-          for (int i = 0; i < TPW / 2; ++i) {
-            const bf16x8 wf = *(const bf16x8 *)&s_w[((wave + 8 * i) * 16 + lr) * LDA_ + ks * 32 + 8 * lq];
-            ad[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[i][0], 0, 0, 0);
-            ad[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[i][1], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < TPW / 2; ++i)
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const f32x4 v = ad[i][tt];
-            const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            *(bf16x4 *)&s_o[(tt * 16 + lr) * LDO + (wave + 8 * i) * 16 + 4 * lq] = ov;
-          }
-        prev = base;
-      }
-    }
-    __syncthreads();
-    store_prev(prev);
-  }
-  // threads that share a column chunk (t % CPRO): shuffles inside the wave, then the eight waves through LDS
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-#pragma unroll
-    for (int m = CPRO; m < 64; m <<= 1) { st_s[j] += __shfl_xor(st_s[j], m, 64); st_q[j] += __shfl_xor(st_q[j], m, 64); }
-  }
-  __syncthreads();        // every wave is done with the weight panel (s_red reuses it)
-  if (lane < CPRO) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s_red[wave][0][lane * 8 + j] = st_s[j]; s_red[wave][1][lane * 8 + j] = st_q[j]; }
-  }
-  __syncthreads();
-  for (int e = t; e < 2 * NO; e += NT) {
-    const int which = e / NO, c = e - which * NO;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) v += s_red[w][which][c];
-    stats_partial[((size_t)blockIdx.x * 2 + which) * NO + c] = v;
-  }
-  probe_end(probe, probe_t0, 1);
 }
 
 template <int RS>
@@ -2293,12 +2043,12 @@ extern "C" int cpfn_mlp_gemm_blocks(long long P, int N) {
   // pass (its 96 KB of LDS leaves no room for a 75 KB GEMM workgroup next to it), so 512 workgroups run as a round of
   // 480 plus a straggler round.  Measured on the replayed step (same box, A/B): 512 -> 2.435 ms, 480 / 448 / 400 ->
   // 2.404-2.414, 342 -> 2.419, 256 -> 2.440, 1024 -> 2.516.
-  static const int target = getenv("CPFN_GEMM_WGS") && atoi(getenv("CPFN_GEMM_WGS")) > 0 ? atoi(getenv("CPFN_GEMM_WGS")) : 448;
+  constexpr int target = 448;       // (342 ... 480 measured: no signal)
   long long tpw = (tiles * ny + target - 1) / target;
   if (tpw < 1) tpw = 1;
   // (tiles per workgroup: capped at 64 — at 16 the 1M-row launches of the LocalSPFN step, 32 clouds, fell back to 512
   //  workgroups = two rounds beside a 32-CU FPS: 2.680 -> 2.650 ms per step)
-  static const int tpw_cap = getenv("CPFN_GEMM_TPW_CAP") && atoi(getenv("CPFN_GEMM_TPW_CAP")) > 0 ? atoi(getenv("CPFN_GEMM_TPW_CAP")) : 64;
+  constexpr int tpw_cap = 64;
   if (tpw > tpw_cap) tpw = tpw_cap;
   return (int)((tiles + tpw - 1) / tpw);
 }
@@ -2309,12 +2059,11 @@ extern "C" int cpfn_mlp_dgrad_small_ok(long long P, int N, int K) {
 }
 
 // (declared after cpfn_mlp_gemm_blocks: rows of stats_partial = cpfn_mlp_gemm_blocks(P, K))
-extern "C" int cpfn_mlp_dgrad_small(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
-                                    const float *y_shift, const void *W, long long P, int N, int K, void *Gout, int ldo,
+extern "C" int cpfn_mlp_dgrad_small(const void *Gy, const void *W, long long P, int N, int K, void *Gout, int ldo,
                                     const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
                                     void *stream) {
-  if (!cpfn_mlp_dgrad_small_ok(P, N, K) || !Gz || !W || !Gout || (ldo & 3) || ldo < K ||
-      (Yr && (!coef || !y_scale || !y_shift)) || (bwd_y && (!b_scale || !b_shift || !stats_partial)) || (!Yr && !bwd_y))
+  if (!cpfn_mlp_dgrad_small_ok(P, N, K) || !Gy || !W || !Gout || (ldo & 3) || ldo < K || !bwd_y || !b_scale || !b_shift ||
+      !stats_partial)
     return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   // in the kernel's terms: operand A = Gz [P, N] (contraction over the layer's N output channels), outputs = K channels
@@ -2322,56 +2071,13 @@ extern "C" int cpfn_mlp_dgrad_small(const void *Gz, const void *Yr, const float 
   dim3 grid(gx, K / 64);
   const int a_bytes = (int)(((P - 1) * N + N) * 2);
   SmallpBwdArgs bw;
-  bw.Yr = (const unsigned short *)Yr; bw.coef = coef; bw.y_scale = y_scale; bw.y_shift = y_shift;
   bw.Yb = (const unsigned short *)bwd_y; bw.b_scale = b_scale; bw.b_shift = b_shift;
-  const unsigned short *a = (const unsigned short *)Gz, *w = (const unsigned short *)W;
+  const unsigned short *a = (const unsigned short *)Gy, *w = (const unsigned short *)W;
   unsigned short *y = (unsigned short *)Gout;
 #define CPFN_DGRAD_SMALL(RT_)                                                                                             \
-  do {                                                                                                                    \
-    if (bwd_y && Yr) mlp_gemm_smallp_kernel<RT_, false, true, true, true><<<grid, 256, 0, st>>>(a, N, a_bytes, w, (int)P, N, K, y, ldo, stats_partial, nullptr, nullptr, probe_slot(grid), bw); \
-    else if (bwd_y) mlp_gemm_smallp_kernel<RT_, false, true, false, true><<<grid, 256, 0, st>>>(a, N, a_bytes, w, (int)P, N, K, y, ldo, stats_partial, nullptr, nullptr, probe_slot(grid), bw); \
-    else mlp_gemm_smallp_kernel<RT_, false, true, true, false><<<grid, 256, 0, st>>>(a, N, a_bytes, w, (int)P, N, K, y, ldo, nullptr, nullptr, nullptr, probe_slot(grid), bw);         \
-  } while (0)
+  mlp_gemm_smallp_kernel<RT_, false, true, true><<<grid, 256, 0, st>>>(a, N, a_bytes, w, (int)P, N, K, y, ldo, stats_partial, nullptr, nullptr, probe_slot(grid), bw)
   if (sp_rows(P, K) == 32) CPFN_DGRAD_SMALL(32); else CPFN_DGRAD_SMALL(64);
 #undef CPFN_DGRAD_SMALL
-  return cpfn_launch_status();
-}
-
-// forward layers of >= 32768 rows in the row-streaming form (mlp_fwd_rows_kernel): 256 workgroups, one statistics row each
-extern "C" int cpfn_mlp_gemm_rows_ok(long long P, int K, int N) {
-  // (192 -> 128 and 128 -> 256 are instantiated and correct, but their 73 / 95 KB of LDS do not fit beside the next
-  //  batch's FPS workgroup (98 KB) that sits on 16 CUs during the whole forward pass: 16 workgroups would wait a round)
-  static const int all = [] { const char *e = getenv("CPFN_FWD_ROWS_ALL"); return e && e[0] == '1'; }();
-  const bool shape = (K == 128 && N == 128) || (all && ((K == 192 && N == 128) || (K == 128 && N == 256)));
-  return shape && P >= 32768 && P <= 2000000000LL;
-}
-
-extern "C" int cpfn_mlp_gemm_rows_blocks(long long P) {
-  long long rows = (P + 255) / 256;
-  rows = ((rows + 127) / 128) * 128;
-  return (int)((P + rows - 1) / rows);
-}
-
-extern "C" int cpfn_mlp_gemm_rows(const void *A, int lda, const void *W, long long P, int K, int N, void *Y, int ldy,
-                                  float *stats_partial, const float *a_scale, const float *a_shift, void *stream) {
-  if (!cpfn_mlp_gemm_rows_ok(P, K, N) || !A || !W || !Y || !stats_partial || lda < K || (lda & 7) || ldy < N || (ldy & 7) ||
-      (!a_scale != !a_shift))
-    return CPFN_EINVAL;
-  long long rows = (P + 255) / 256;
-  rows = ((rows + 127) / 128) * 128;
-  const dim3 grid((unsigned)((P + rows - 1) / rows));
-  hipStream_t st = (hipStream_t)stream;
-  const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
-  unsigned short *y = (unsigned short *)Y;
-#define CPFN_FWD_ROWS(KC_, NO_)                                                                                          \
-  do {                                                                                                                   \
-    if (a_scale) mlp_fwd_rows_kernel<KC_, NO_, true><<<grid, 512, 0, st>>>(a, lda, w, P, rows, y, ldy, stats_partial, a_scale, a_shift, probe_slot(grid)); \
-    else mlp_fwd_rows_kernel<KC_, NO_, false><<<grid, 512, 0, st>>>(a, lda, w, P, rows, y, ldy, stats_partial, nullptr, nullptr, probe_slot(grid));        \
-  } while (0)
-  if (K == 128 && N == 128) CPFN_FWD_ROWS(128, 128);
-  else if (K == 192) CPFN_FWD_ROWS(192, 128);
-  else CPFN_FWD_ROWS(128, 256);
-#undef CPFN_FWD_ROWS
   return cpfn_launch_status();
 }
 
@@ -2648,25 +2354,6 @@ extern "C" int cpfn_mlp_wgrad_apply_ok(long long P, int N, int K) {
   return TN == 64 && TK == 64;
 }
 
-extern "C" int cpfn_mlp_wgrad_apply(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
-                                    const float *y_shift, const void *A, int lda, long long P, int N, int K,
-                                    const float *a_scale, const float *a_shift, float *workspace, float *dW, void *stream) {
-  if (!cpfn_mlp_wgrad_apply_ok(P, N, K) || !Gz || !Yr || !coef || !y_scale || !y_shift || !A || !workspace || (lda & 7) ||
-      (!a_scale != !a_shift))
-    return CPFN_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const int splits = cpfn_mlp_wgrad_splits(P, N, K);
-  long long rps = (P + splits - 1) / splits;
-  rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
-  WgradApplyArgs ap;
-  ap.Yr = (const unsigned short *)Yr; ap.coef = coef; ap.y_scale = y_scale; ap.y_shift = y_shift;
-  dim3 grid(N / 64, (K + 63) / 64, splits);
-  mlp_wgrad_kernel<64, 64, true><<<grid, 256, 0, st>>>((const unsigned short *)Gz, N, (const unsigned short *)A, lda, nullptr, P, N,
-                                                       K, rps, workspace, a_scale, a_shift, probe_slot_all(grid), ap);
-  if (dW) launch_split_reduce(workspace, splits, (long long)N * K, dW, st);
-  return cpfn_launch_status();
-}
-
 extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
   const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128) ||
                      (N == 128 && K == 192);
@@ -2683,6 +2370,7 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
       ldg < N || lda < K || ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)) ||
       (apply_y && (!apply_coef || !y_scale || !y_shift)))
     return CPFN_EINVAL;
+  if (apply_y && ldg != N) return CPFN_EINVAL;     // (the kernel walks apply_y with the gradient's row stride)
   if ((drop_seed && (!apply_y || pool_k > 0 || !(drop_p >= 0.f && drop_p < 1.f))) || pool_k < 0) return CPFN_EINVAL;
   const int step = K >= 128 ? 32 : 64;
   if (K == 192 && (bwd_y || drop_seed || pool_k > 0)) return CPFN_EINVAL;   // (24 chunks per row: plain / dense apply only)
@@ -2701,7 +2389,6 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   ap.drop_seed = drop_seed; ap.thresh16 = dropout_thresh16(drop_seed ? drop_p : 0.f); ap.inv_keep = drop_seed ? 1.f / (1.f - drop_p) : 1.f;
   ap.pool_arg = pool_arg; ap.pool_yarg = (const unsigned short *)pool_yarg; ap.pool_k = pool_k > 0 ? pool_k : 1;
   ap.groups = pool_k > 0 ? P / pool_k : 1;
-  ap.xyz = nullptr; ap.w0 = nullptr;
   const int mode = !apply_y ? 0 : (pool_k > 0 ? 2 : (drop_seed ? 3 : 1));
 #define CPFN_BWD_FUSED(TN_, TK_, STEP_, BST_, APPLY_)                                                                      \
   mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
@@ -2731,32 +2418,6 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
 #undef CPFN_BWD_FUSED_SHAPE
 #undef CPFN_BWD_FUSED
-  return cpfn_launch_status();
-}
-
-// sa1's second layer (64 -> 64 on the pre-BN output of the fp32-xyz first layer): cpfn_mlp_bwd_fused with that input AND the
-// y of the riding reduction recomputed from the coordinates (apply pass folded in; see mlp_bwd_fused_kernel, XYZ)
-extern "C" int cpfn_mlp_bwd_fused_xyz(const void *Gz, const void *Yr, const float *apply_coef, const float *y_scale,
-                                      const float *y_shift, const float *X, const float *W0, const void *W, long long P,
-                                      const float *a_scale, const float *a_shift, float *workspace, void *Gout,
-                                      float *stats_partial, void *stream) {
-  const int N = 64, K = 64;
-  if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gz || !Yr || !apply_coef || !y_scale || !y_shift || !X || !W0 || !W || !a_scale ||
-      !a_shift || !workspace || !Gout || !stats_partial)
-    return CPFN_EINVAL;
-  const int splits = cpfn_mlp_wgrad_splits(P, N, K);
-  long long rps = (P + splits - 1) / splits;
-  rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
-  const dim3 grid(1, 1, splits);
-  BwdApplyArgs ap;
-  ap.Yr = (const unsigned short *)Yr; ap.coef = apply_coef; ap.y_scale = y_scale; ap.y_shift = y_shift;
-  ap.drop_seed = nullptr; ap.thresh16 = 0; ap.inv_keep = 1.f;
-  ap.pool_arg = nullptr; ap.pool_yarg = nullptr; ap.pool_k = 1; ap.groups = 1;
-  ap.xyz = X; ap.w0 = W0;
-  // (the layer below IS the first layer: its scale / shift are both the operand transform and the reduction's mask)
-  mlp_bwd_fused_kernel<64, 64, 64, true, 1, true><<<grid, 512, 0, (hipStream_t)stream>>>(
-      (const unsigned short *)Gz, N, nullptr, K, (const unsigned short *)W, P, rps, workspace, (unsigned short *)Gout, K, a_scale,
-      a_shift, nullptr, a_scale, a_shift, stats_partial, ap, probe_slot_all(grid));
   return cpfn_launch_status();
 }
 

@@ -199,9 +199,13 @@ __global__ __launch_bounds__(NT) void fps_streaming_kernel(const float *__restri
 // — so no payload has to be ordered behind a flag (8-byte stores / loads are single-copy atomic), ties still go to the
 // lowest index, and a stale slot (tag of another sample) can never be taken for a fresh one: S <= 4094, slots zeroed by
 // a memset node in front of the launch.  All workgroups of a cloud must be resident together (they spin on each other):
-// the launcher only takes this path while B * G <= 1024 (256 CUs x >= 4 such workgroups), cloud-major block order; a
-// bounded spin (~1 s) turns a violated assumption into -1 indices instead of a hung GPU.
+// the launcher only takes this path while B * G fits the device — hipOccupancyMaxActiveBlocksPerMultiprocessor of the
+// instantiation x the number of compute units, queried once per device — and otherwise falls back to the one-workgroup
+// streaming kernel.  Other kernels on the same CUs only delay a sibling; should one never arrive, a bounded spin
+// (~1 s, once: the sample loop ends there) leaves index 0 (a valid point) in the remaining outputs and counts the cloud in
+// a device-side fault counter that cpfn_fps_faults() reads: a hung GPU and out-of-range indices are both worse.
 // Same arithmetic, same tie-break as the other two kernels: bit-identical selections.
+__device__ unsigned g_fps_faults = 0;
 template <int PPT>
 __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict__ xyz, int N, int S,
                                                          const int *__restrict__ start, int flags,
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
   unsigned far = start ? (unsigned)start[b] : 0u;
   bool dead = false;
   for (int i = 0; i < S; ++i) {
-    if (wg == 0 && t == 0) out[i] = dead ? -1 : (int)far;
+    if (wg == 0 && t == 0) out[i] = (int)far;
     const float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
     float best = -1.0f;
     unsigned besti = 0xFFFFFu;
@@ -272,11 +276,44 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
     }
     __syncthreads();
     const unsigned nf = s_far;
-    if (nf == 0xFFFFFFFFu) { dead = true; far = 0u; } else far = nf;
+    if (nf == 0xFFFFFFFFu) {          // a sibling workgroup never arrived: give up for this cloud (every workgroup of it
+      dead = true;                    // takes this branch at most one spin period later)
+      if (wg == 0 && t == 0) {
+        for (int r = i + 1; r < S; ++r) out[r] = 0;
+        atomicAdd(&g_fps_faults, 1u);
+      }
+      break;
+    }
+    far = nf;
   }
+  (void)dead;
 }
 
 }  // namespace
+
+// Workgroups of fps_shared_kernel<PPT> that can be resident at once on the current device (0: unknown -> do not use it).
+template <int PPT>
+static int fps_shared_capacity() {
+  static int cached[64] = {0};                  // per device ordinal; 0 = not queried yet, -1 = query failed
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cached[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_shared_kernel<PPT>, 256, 0) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
+      cached[dev] = per_cu * cus;
+    else
+      cached[dev] = -1;
+  }
+  return cached[dev] > 0 ? cached[dev] : 0;
+}
+
+// Clouds whose several-workgroups FPS gave up on a sibling since the library was loaded (synchronises the device).
+extern "C" int cpfn_fps_faults(void) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fps_faults), sizeof(n)) != hipSuccess) return -1;
+  return (int)n;
+}
 
 extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out,
                         float *scratch, void *stream) {
@@ -305,7 +342,8 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
     int ppt = 8;
     while (ppt < 32 && (N + 256 * ppt - 1) / (256 * ppt) > 64) ppt *= 2;
     const int G = (N + 256 * ppt - 1) / (256 * ppt);
-    if (G <= 64 && (long long)B * G <= 1024 && B <= 65535 && S <= 4094 && N <= (1 << 20) &&
+    const int capacity = ppt == 8 ? fps_shared_capacity<8>() : ppt == 16 ? fps_shared_capacity<16>() : fps_shared_capacity<32>();
+    if (G <= 64 && (long long)B * G <= capacity && B <= 65535 && S <= 4094 && N <= (1 << 20) &&
         (size_t)B * 2 * G * 8 <= (size_t)B * N * 4 && ((uintptr_t)scratch & 7) == 0) {
       hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * 2 * G * 8, st);
       if (e != hipSuccess) return (int)e;

@@ -19,7 +19,6 @@ re-enters the running mean), so its gradient is exactly zero rather than the ref
 rounding noise.
 """
 import ctypes
-import os
 import weakref
 
 import torch
@@ -28,39 +27,24 @@ from . import lib as _l
 from .ops import _ptr, _stream
 
 BF16 = torch.bfloat16
-BN_NOSTORE = os.environ.get("CPFN_BN_NOSTORE", "1") == "1"
-# BN + ReLU of a hidden layer applied on the operand load of the NEXT layer's GEMM and of its weight gradient
-# (the activated tensor of a hidden layer is then never written or read).  CPFN_BN_APPLY_FUSED=0 materialises it.
-# CPFN_BWD_STATS_FUSED=0: BatchNorm-backward pass 1 always as its own kernel (cpfn_bn_relu_bwd) instead of riding on
-# the data-gradient GEMM that produces the gradient
-BWD_STATS_FUSED = os.environ.get("CPFN_BWD_STATS_FUSED", "1") != "0"
-BN_APPLY_FUSED = os.environ.get("CPFN_BN_APPLY_FUSED", "1") == "1"
-# dense 128 -> 128 layers with >= 32768 rows: weight gradient + data gradient (+ the BatchNorm-backward reduction of the
-# layer below) as one kernel over one read of G_y (cpfn_mlp_bwd_fused); CPFN_FUSED_BWD=0 keeps the two-kernel pair
-FUSED_BWD = os.environ.get("CPFN_FUSED_BWD", "1") != "0"
-# ... and the BatchNorm-backward apply pass of that layer inside the same kernel (g_y never stored); CPFN_FUSED_BWD_APPLY=0:
-# cpfn_bn_bwd_apply as its own launch
-FUSED_BWD_APPLY = os.environ.get("CPFN_FUSED_BWD_APPLY", "1") != "0"
-# small layers (<= 16384 rows): apply pass inside cpfn_mlp_wgrad_apply / cpfn_mlp_dgrad_small, the reduction of the layer
-# below on that data gradient (5 -> 3 launches per layer); CPFN_SMALL_BWD_FUSED=0: the separate kernels
-SMALL_BWD_FUSED = os.environ.get("CPFN_SMALL_BWD_FUSED", "1") != "0"
-# the backward pass of an fp32-xyz first layer and of the 64 -> 64 layer after it (sa1) recompute the first layer's pre-BN
-# output from the coordinates instead of reading it (3 x 67 MB per step); CPFN_XYZ_RECOMPUTE=0 reads the stored tensor
-XYZ_RECOMPUTE = os.environ.get("CPFN_XYZ_RECOMPUTE", "1") != "0"
-# ... in the 64 -> 64 layer's one-pass kernel too (cpfn_mlp_bwd_fused_xyz).  Off by default: that shape is bound by VALU +
-# LDS issue, the 134 MB it no longer reads bought 2 us of 65, and the plain instantiation runs with one barrier per step
-# (which this one cannot, see mlp_bwd_fused_kernel) — the plain one is faster.
-XYZ_ONEPASS = os.environ.get("CPFN_XYZ_ONEPASS", "0") == "1"
-# CPFN_FWD_ROWS=1: forward 128 -> 128 layers at >= 32768 rows through cpfn_mlp_gemm_rows (8 waves, one row pipeline per
-# workgroup: the data-gradient half of the one-pass backward kernel turned around) instead of the tiled streaming kernel.
-# Bit-identical Y, and 17.6 us per workgroup against 18 us per LAUNCH of the streaming kernel — but off by default: with
-# 256 long workgroups the 16 that share a CU with the next batch's FPS workgroup (16 waves of it) finish at 25 us, and
-# the launch with them (in-kernel probe; 2.06 vs 2.015 ms per step).  The streaming kernel's 342 x 3 short tiles balance.
-FWD_ROWS = os.environ.get("CPFN_FWD_ROWS", "0") == "1"
-# ... the apply pass of those layers on the operand loads too (cpfn_mlp_wgrad_apply, Yr of cpfn_mlp_dgrad_small).  Off by
-# default: every 64-column block of the data gradient re-forms the whole g_y panel, and the slower kernels cancel the
-# saved launch (A/B on the replayed step: 2.059 vs 2.054-2.071 ms).
-SMALL_BWD_APPLY = os.environ.get("CPFN_SMALL_BWD_APPLY", "0") == "1"
+# What the backward pass folds where (module attributes, not environment switches: tests/test_gpu_fused_mlp.py flips them to
+# hold every fused route to the kernels it replaces, bit for bit):
+#   BN_APPLY_FUSED    BN + ReLU of a hidden layer applied on the operand load of the NEXT layer's GEMM and of its weight
+#                     gradient (the activated tensor of a hidden layer is never written or read)
+#   BWD_STATS_FUSED   BatchNorm-backward pass 1 rides on the data-gradient GEMM that produces the gradient (False: always its
+#                     own cpfn_bn_relu_bwd launch)
+#   FUSED_BWD         dense layers of >= 32768 rows: weight gradient + data gradient (+ the reduction of the layer below) as
+#                     one kernel over one read of G_y (cpfn_mlp_bwd_fused); False: the two-kernel pair
+#   FUSED_BWD_APPLY   ... and that layer's BatchNorm-backward apply pass inside the same kernel (g_y never stored)
+#   SMALL_BWD_FUSED   small layers (<= 16384 rows): the reduction of the layer below on cpfn_mlp_dgrad_small
+#   XYZ_RECOMPUTE     the weight gradient of an fp32-xyz first layer (sa1) recomputes that layer's pre-BN output from the
+#                     coordinates instead of reading it (67 MB per step)
+BWD_STATS_FUSED = True
+BN_APPLY_FUSED = True
+FUSED_BWD = True
+FUSED_BWD_APPLY = True
+SMALL_BWD_FUSED = True
+XYZ_RECOMPUTE = True
 
 
 def _pad_to(n, m):
@@ -91,15 +75,6 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
     if bwd_stats is not None:
         yb, a_scale, a_shift = bwd_stats
         stats = True
-    if (FWD_ROWS and stats and bwd_stats is None and not w_trans and gidx is None and bias is None and not out_f32 and n_store == N
-            and h.cpfn_mlp_gemm_rows_ok(P, K, N)):
-        # forward layer at >= 32768 rows: the row-streaming kernel (same Y bit for bit, 256 statistics rows)
-        nblk = h.cpfn_mlp_gemm_rows_blocks(P)
-        part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
-        _check(h.cpfn_mlp_gemm_rows(_ptr(A), A.stride(0), _ptr(Wb), P, K, N, _ptr(Y), N, _ptr(part), _ptr(a_scale), _ptr(a_shift),
-                                    _stream()), "cpfn_mlp_gemm_rows")
-        _l.add_bytes("cpfn_mlp_gemm_rows", 2 * P * K + 2 * N * K + 2 * P * N + 8 * nblk * N)
-        return Y, part, nblk
     if stats:
         nblk = h.cpfn_mlp_gemm_blocks(P, N)
         part = torch.empty(nblk, 2, N, dtype=torch.float32, device=A.device)
@@ -188,9 +163,21 @@ def _flush_reductions():
     _l.add_bytes("cpfn_multi_split_reduce", sum(4 * n * (splits + 1) for _, _, n, splits, _, _ in todo))
 
 
-def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0):
+def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0, params=()):
     """Queue `out[n] = sum over splits of ws[splits][n]`; runs at the end of the current backward pass.
-    row_in / row_out: the partial rows have row_in elements of which `out` (compact) keeps the first row_out."""
+    row_in / row_out: the partial rows have row_in elements of which `out` (compact) keeps the first row_out.
+    params: the parameters `out` is the gradient of.  Deferring is only sound when autograd's AccumulateGrad STEALS the
+    returned tensor (p.grad is None and nobody hooks it): it then just keeps the reference and the deferred launch fills
+    it before anybody reads.  With gradient accumulation (p.grad already set), tensor hooks or
+    zero_grad(set_to_none=False) autograd reads / adds the tensor right away — so in those cases the reduction runs
+    immediately (one launch per tensor, as before round 2)."""
+    if any(p is not None and (p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None))
+           for p in params):
+        arr = (_ReduceDesc * 1)(_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits, row_in, row_out))
+        with torch.cuda.device(ws.device):
+            _check(_l.lib().cpfn_multi_split_reduce(arr, 1, _stream()), "cpfn_multi_split_reduce")
+        _l.add_bytes("cpfn_multi_split_reduce", 4 * n * (splits + 1))
+        return
     if not _pending_reduce:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
     _pending_reduce.append((ws, out, n, splits, row_in, row_out))
@@ -436,7 +423,7 @@ class _FusedStack(torch.autograd.Function):
                 dseed = ctx.drop_seed if (top and arg is None) else None          # fused dropout on the stack's output
                 dp = float(cfg["dropout"][0]) if dseed is not None else 0.0
                 need_dgrad = (li > 0 or ctx.x_needs_grad) and not xyz_layer
-                below_ok = li > 0 and BN_NOSTORE and BWD_STATS_FUSED and saved[li - 1][5] is None   # may take pass 1 of layer li-1
+                below_ok = li > 0 and BWD_STATS_FUSED and saved[li - 1][5] is None   # may take pass 1 of layer li-1
                 route, fold_apply, fold_pool = _plan(h, P, N, a_in, pool_k if arg is not None else 0, xyz_layer, need_dgrad,
                                                      dseed is not None)
                 dgb = torch.empty(2, N, dtype=torch.float32, device=dev)
@@ -458,11 +445,10 @@ class _FusedStack(torch.autograd.Function):
                 else:
                     nblk = h.cpfn_bn_bwd_blocks(P)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
-                    if not BN_NOSTORE:              # (CPFN_BN_NOSTORE=0: pass 1 also stores the masked gradient)
-                        Gy = torch.empty(P, N, dtype=BF16, device=dev)
-                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy), _ptr(part), _ptr(dseed), dp,
+                    # (pass 1 does not store the masked gradient: pass 2 recomputes the ReLU mask from y)
+                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None, _ptr(part), _ptr(dseed), dp,
                                               _stream()), "cpfn_bn_relu_bwd")
-                    _l.add_bytes("cpfn_bn_relu_bwd", (4 if BN_NOSTORE else 6) * P * N + 8 * nblk * N)
+                    _l.add_bytes("cpfn_bn_relu_bwd", 4 * P * N + 8 * nblk * N)
                 _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
                                               1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
                        "cpfn_bn_bwd_finalize")
@@ -476,14 +462,10 @@ class _FusedStack(torch.autograd.Function):
                         _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
                                                         _ptr(coef), P // pool_k, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
                         _l.add_bytes("cpfn_bn_pool_bwd_apply", 4 * P * N + 5 * (P // pool_k) * N)
-                elif not fold_apply:
-                    if Gy is None:                  # BN_NOSTORE: the mask is recomputed from y, dropout re-applied from its seed
-                        Gy = torch.empty(P, N, dtype=BF16, device=dev)
-                        _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
-                                                   _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
-                    else:                           # (the stored g_z already carries mask and dropout)
-                        _check(h.cpfn_bn_bwd_apply(_ptr(Gy), _ptr(Y), _ptr(coef), None, None, P, N, _ptr(Gy), None, 0.0, _stream()),
-                               "cpfn_bn_bwd_apply")
+                elif not fold_apply:                # the mask is recomputed from y, dropout re-applied from its seed
+                    Gy = torch.empty(P, N, dtype=BF16, device=dev)
+                    _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),
+                                               _ptr(dseed), dp, _stream()), "cpfn_bn_bwd_apply")
                     _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
                 folded = fold_apply or fold_pool                 # the consumers read (g, Y, coef) instead of Gy
                 # ---- (3) weight gradient (+ data gradient)
@@ -495,7 +477,7 @@ class _FusedStack(torch.autograd.Function):
                     dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
                     # (its 1024 x 192-float partials join the batched split reduction: that launch walks "deep" buffers
                     #  with 16 split subsets per 16 outputs)
-                    _defer_reduction(ws, dW, N * KS, nb)
+                    _defer_reduction(ws, dW, N * KS, nb, params=(L.weight,))
                     if folded and XYZ_RECOMPUTE and KS == 3:
                         # ... with y recomputed from the coordinates: 12 bytes per row instead of 2 N
                         _check(h.cpfn_smallk_wgrad_apply_xyz(_ptr(g), _ptr(Wb), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in), KS, P,
@@ -517,20 +499,7 @@ class _FusedStack(torch.autograd.Function):
                 ws = torch.empty(splits * N * Kp, dtype=torch.float32, device=dev)
                 asc, ash = a_ptrs(a_ss)
                 g_new = None
-                xyz_below = (XYZ_RECOMPUTE and XYZ_ONEPASS and li == 1 and first_fp32 and route == "one_pass" and N == 64 and Kp == 64 and fold_apply
-                             and below_ok and a_ss is not None and saved[0][0].shape[1] == 3 and dseed is None)
-                if xyz_below:
-                    # sa1's second layer: its input (the first layer's pre-BN output) and the y of the riding reduction are
-                    # recomputed from the coordinates inside the kernel — that [P,64] tensor is not read by the backward pass
-                    g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
-                    fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev)
-                    _check(h.cpfn_mlp_bwd_fused_xyz(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(saved[0][0]),
-                                                    _ptr(saved[0][4]), _ptr(Wb), P, asc, ash, _ptr(ws), _ptr(g_new), _ptr(fp_),
-                                                    _stream()), "cpfn_mlp_bwd_fused_xyz")
-                    _l.add_bytes("cpfn_mlp_bwd_fused_xyz", 4 * P * N + 2 * 12 * P + 2 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
-                                 + 8 * splits * Kp)
-                    fused_part = (fp_, splits)
-                elif route == "one_pass":
+                if route == "one_pass":
                     # weight gradient, data gradient, (folded) apply pass and pass 1 of the layer below from ONE read of the
                     # gradient (mlp_bwd_fused_kernel)
                     below = below_ok and Kp != 192
@@ -551,10 +520,6 @@ class _FusedStack(torch.autograd.Function):
                                  + ((2 * P * Kp + 8 * splits * Kp) if below else 0))
                     if below:
                         fused_part = (fp_, splits)
-                elif folded:                        # small layer, apply pass on the weight gradient's operand load (off by default)
-                    _check(h.cpfn_mlp_wgrad_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), _ptr(a_in),
-                                                  a_in.stride(0), P, N, Kp, asc, ash, _ptr(ws), None, _stream()), "cpfn_mlp_wgrad_apply")
-                    _l.add_bytes("cpfn_mlp_wgrad_apply", 4 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
                 else:
                     _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp, asc, ash, _ptr(ws), None,
                                             _stream()), "cpfn_mlp_wgrad")
@@ -563,29 +528,24 @@ class _FusedStack(torch.autograd.Function):
                 # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
                 dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
                 if Kp == L.cin:
-                    _defer_reduction(ws, dW, N * Kp, splits)
+                    _defer_reduction(ws, dW, N * Kp, splits, params=(L.weight,))
                 else:
-                    _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin)
+                    _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin, params=(L.weight,))
                 grads[3 * li] = dW.reshape(wshape)
-                if need_dgrad and route == "small" and (folded or below_ok):
-                    # small-P data gradient with the reduction of the layer below on the stored tile (and, off by default,
-                    # the apply pass on its operand load)
+                if need_dgrad and route == "small" and below_ok:
+                    # small-P data gradient with the reduction of the layer below on the stored tile
                     g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
-                    Yp, stp = (saved[li - 1][2], saved[li - 1][3]) if below_ok else (None, (None, None))
+                    Yp, stp = saved[li - 1][2], saved[li - 1][3]
                     nb_ = h.cpfn_mlp_gemm_blocks(P, Kp)
-                    fp_ = torch.empty(nb_, 2, Kp, dtype=torch.float32, device=dev) if below_ok else None
-                    _check(h.cpfn_mlp_dgrad_small(_ptr(g if folded else Gy), _ptr(Y) if folded else None,
-                                                  _ptr(coef) if folded else None, _ptr(st[0]) if folded else None,
-                                                  _ptr(st[1]) if folded else None, _ptr(Wb), P, N, Kp, _ptr(g_new), Kp, _ptr(Yp),
-                                                  _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_), _stream()), "cpfn_mlp_dgrad_small")
-                    _l.add_bytes("cpfn_mlp_dgrad_small", (4 if folded else 2) * P * N + 2 * N * Kp + 2 * P * Kp
-                                 + ((2 * P * Kp + 8 * nb_ * Kp) if below_ok else 0))
-                    if below_ok:
-                        fused_part = (fp_, nb_)
+                    fp_ = torch.empty(nb_, 2, Kp, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_mlp_dgrad_small(_ptr(Gy), _ptr(Wb), P, N, Kp, _ptr(g_new), Kp, _ptr(Yp), _ptr(stp[0]), _ptr(stp[1]),
+                                                  _ptr(fp_), _stream()), "cpfn_mlp_dgrad_small")
+                    _l.add_bytes("cpfn_mlp_dgrad_small", 2 * P * N + 2 * N * Kp + 2 * P * Kp + 2 * P * Kp + 8 * nb_ * Kp)
+                    fused_part = (fp_, nb_)
                 elif need_dgrad and g_new is None:
                     # G_y [P,N] · W [N,Kp]; where the streaming kernel runs, it also reduces the BatchNorm backward
                     # of the layer below from the gradient it is writing
-                    if li > 0 and BN_NOSTORE and can_fuse_bwd_stats(P, N, Kp) and saved[li - 1][5] is None:
+                    if li > 0 and can_fuse_bwd_stats(P, N, Kp) and saved[li - 1][5] is None:
                         Yp, stp = saved[li - 1][2], saved[li - 1][3]
                         g_new, fp_, nb_ = gemm(Gy, Wb, w_trans=True, bwd_stats=(Yp, stp[0], stp[1]))
                         fused_part = (fp_, nb_)
@@ -604,7 +564,7 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
     data gradient) or "generic"; fold_apply / fold_pool: the dense / max-pooled BatchNorm apply pass is formed on the
     consumers' operand loads instead of being launched (g_y is then never stored)."""
     if xyz_layer:
-        return "generic", bool(FUSED_BWD_APPLY and BN_NOSTORE and not pool_k and not dropout), False
+        return "generic", bool(FUSED_BWD_APPLY and not pool_k and not dropout), False
     Kp = a_in.shape[1]
     one_pass = (FUSED_BWD and need_dgrad and a_in.stride(0) == Kp and bool(h.cpfn_mlp_bwd_fused_ok(P, N, Kp))
                 and not (Kp == 192 and dropout))                    # (the 192-wide shape has no dropout variant)
@@ -612,11 +572,11 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
         if pool_k:
             step_rows = 32 if Kp >= 128 else 64                     # rows per step of the one-pass kernel for this shape
             return "one_pass", False, bool(FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255 and Kp != 192)
-        return "one_pass", bool(FUSED_BWD_APPLY and BN_NOSTORE), False
-    small = (SMALL_BWD_FUSED and not pool_k and BN_NOSTORE and not dropout and bool(h.cpfn_mlp_wgrad_apply_ok(P, N, Kp))
+        return "one_pass", bool(FUSED_BWD_APPLY), False
+    small = (SMALL_BWD_FUSED and not pool_k and not dropout and bool(h.cpfn_mlp_wgrad_apply_ok(P, N, Kp))
              and (not need_dgrad or bool(h.cpfn_mlp_dgrad_small_ok(P, N, Kp))))
     if small:
-        return "small", bool(SMALL_BWD_APPLY and FUSED_BWD_APPLY), False
+        return "small", False, False
     return "generic", False, False
 
 
@@ -679,6 +639,7 @@ class _Linear(torch.autograd.Function):
             Y, _, _ = gemm(a, Wb, bias=bp, out_f32=True, n_store=N)
         ctx.save_for_backward(a, Wb)
         ctx.n = N
+        ctx.heads = tuple(wb)                 # (the parameters themselves: backward asks whether their .grad is free)
         ctx.sizes = [t.shape[0] for t in wb[:nheads]]
         ctx.wshapes = [tuple(t.shape) for t in wb[:nheads]]
         return Y
@@ -702,14 +663,14 @@ class _Linear(torch.autograd.Function):
             # (its 512 x 35 partials are finished by the batched split reduction at the end of the backward pass)
             _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), None, _ptr(gb) if fused_pad else None, _stream()),
                    "cpfn_colsum_f32")
-            _defer_reduction(wsb, gbias, N, (P + 255) // 256)
+            _defer_reduction(wsb, gbias, N, (P + 255) // 256, params=ctx.heads)
             _l.add_bytes("cpfn_colsum_f32", 4 * P * N + (2 * P * Np if fused_pad else 0))
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
             dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
             _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), None, _stream()),
                    "cpfn_mlp_wgrad")
-            _defer_reduction(ws, dW, Np * K, splits)
+            _defer_reduction(ws, dW, Np * K, splits, params=ctx.heads)
             _l.add_bytes("cpfn_mlp_wgrad", 2 * P * Np + 2 * P * K + 8 * splits * Np * K)
             ga, _, _ = gemm(gb, Wb, w_trans=True)
         gw, gbs, o = [], [], 0

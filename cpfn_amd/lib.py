@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcpfn_hip.so")
+ABI_VERSION = 2          # = CPFN_ABI_VERSION of include/cpfn_hip.h; bumped whenever an exported signature changes
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 _ll = ctypes.c_longlong
@@ -18,6 +19,7 @@ SIGNATURES = {
     "cpfn_abi_version": [],
     "cpfn_build_info": [],
     "cpfn_fps": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "cpfn_fps_faults": [],
     "cpfn_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "cpfn_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_ball_query_direct": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
@@ -73,7 +75,7 @@ SIGNATURES = {
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
-    "cpfn_flag_wait": [_vp, ctypes.c_uint, ctypes.c_uint64, _vp, _vp], "cpfn_flag_set": [_vp, ctypes.c_uint, _vp],
+    "cpfn_flag_wait": [_vp, ctypes.c_uint, ctypes.c_uint64, _vp, _vp, _vp], "cpfn_flag_set": [_vp, ctypes.c_uint, _vp],
     "cpfn_flag_set_payload": [_vp, ctypes.c_uint, _vp, _vp, _i, _vp],
     "cpfn_mlp_gemm_set_probe": [_vp, _i, _i],
     "cpfn_wall_clock_khz": [_i],
@@ -90,14 +92,10 @@ SIGNATURES = {
     "cpfn_mlp_wgrad_splits": [_ll, _i, _i],
     "cpfn_multi_split_reduce": [_vp, _i, _vp],
     "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "cpfn_mlp_gemm_rows_ok": [_ll, _i, _i],
-    "cpfn_mlp_gemm_rows_blocks": [_ll],
-    "cpfn_mlp_gemm_rows": [_vp, _i, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused_ok": [_ll, _i, _i],
     "cpfn_mlp_wgrad_apply_ok": [_ll, _i, _i],
-    "cpfn_mlp_wgrad_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_dgrad_small_ok": [_ll, _i, _i],
-    "cpfn_mlp_dgrad_small": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_dgrad_small": [_vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _f, _vp, _vp, _i, _vp],
     "cpfn_colsum_f32": [_vp, _ll, _i, _vp, _vp, _vp, _vp],
@@ -105,7 +103,6 @@ SIGNATURES = {
     "cpfn_smallk_wgrad": [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad_apply_xyz": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
-    "cpfn_mlp_bwd_fused_xyz": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_head_post_chunks": [_i],
     "cpfn_head_post_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_head_post_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
@@ -226,8 +223,9 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so is stale: loud by design
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, ctypes.c_int)
-        if h.cpfn_abi_version() != 1:
-            raise CpfnHipError("libcpfn_hip.so ABI version mismatch")
+        if h.cpfn_abi_version() != ABI_VERSION:
+            raise CpfnHipError("libcpfn_hip.so ABI version %d, this package binds version %d: rebuild it "
+                               "(python -m cpfn_amd.build)" % (h.cpfn_abi_version(), ABI_VERSION))
         _lib = _Proxy(h)
     return _lib
 

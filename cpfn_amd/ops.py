@@ -4,7 +4,6 @@ cuda_ops/include/utils.h:5-25, become RuntimeErrors here), output allocation wit
 torch (the C ABI never allocates) and launch on torch's current stream.
 """
 import numpy as np
-import os
 
 import torch
 
@@ -31,7 +30,6 @@ def _chk(t, name, dtype):
     return t
 
 
-BALL_QUERY_PACKED = os.environ.get("CPFN_BALL_QUERY_PACKED", "1") != "0"
 _background = [False]
 
 
@@ -55,6 +53,15 @@ def ball_query_threshold(radius):
     """f32(radius**2 in double): what `sqrdists > radius ** 2` compares against
     (modules/geometry_utils.py:156)."""
     return float(np.float32(float(radius) ** 2))
+
+
+def fps_faults():
+    """Clouds whose several-workgroups FPS (N > 8192) gave up on a sibling workgroup since the library was loaded (their
+    remaining samples are index 0).  0 in a healthy process; reading it synchronises the device."""
+    n = _l.lib().cpfn_fps_faults()
+    if n < 0:
+        raise RuntimeError("cpfn_fps_faults failed")
+    return n
 
 
 def fps(xyz, num_samples, start=None, skip_near_origin=False):
@@ -85,7 +92,7 @@ def ball_query(new_xyz, xyz, radius, nsample, cuda_route=False):
         if cuda_route:
             _l.check(_l.lib().cpfn_ball_query_direct(_ptr(xyz), _ptr(new_xyz), B, N, S, float(radius), int(nsample),
                                                      _ptr(out), _stream()), "cpfn_ball_query_direct")
-        elif BALL_QUERY_PACKED and _background[0] and N >= 512:
+        elif _background[0] and N >= 512:
             # beside a training step: the wave-per-query kernel on the cloud packed with its norms (less work per point)
             pk = torch.empty(B, N, 4, dtype=torch.float32, device=xyz.device)
             _l.check(_l.lib().cpfn_pack_xyzn(_ptr(xyz), B, N, _ptr(pk), _stream()), "cpfn_pack_xyzn")

@@ -40,17 +40,21 @@ def get_learning_rate(init_learning_rate, global_step, batch_size, decay_step, d
     return init_learning_rate * (decay_rate ** p)
 
 
-# The next batch's geometry runs concurrently with the step.  As a forked branch INSIDE the step's hipGraph it switches
-# the whole replay to a slower dispatch mode on this stack (tools/dbg/graph_gap.py: 150 tiny kernels replay in 238 us as
-# a linear graph and in 414 us with one forked branch: +1.2 us per kernel, the fork itself ~27 us).  Default: TWO linear
-# graphs — the step on the trainer's stream, the geometry on a side stream — ordered by two events per step.
-# CPFN_SPLIT_GRAPHS=0: the single forked graph of round 1.
-SPLIT_GRAPHS = os.environ.get("CPFN_SPLIT_GRAPHS", "1") != "0"
-
-
-SEEDS_AS_PAYLOAD = os.environ.get("CPFN_SEEDS_AS_PAYLOAD", "1") != "0"
-ADOPT_SIDE_OUTPUTS = os.environ.get("CPFN_ADOPT_SIDE_OUTPUTS", "1") != "0"    # the side graph's own outputs are the B set
-FLAG_ORDER = os.environ.get("CPFN_FLAG_ORDER", "1") != "0"      # two replayed graphs ordered by device flags, not events
+# The next batch's geometry runs concurrently with the step as a SECOND linear graph on a side stream (a forked branch
+# inside the step's graph switches the whole replay to a slower dispatch mode on this stack: DESIGN.md §4), and the two
+# graphs order themselves through two device flags polled / set by one-lane kernels (cpfn_flag_wait / cpfn_flag_set) —
+# the closed cross-queue event cycle of two events per step costs ~100 us of idle GPU per step.
+#
+# CPFN_FLAG_TIMEOUT_S: how long a flag waiter polls before it gives up (then: a sticky pinned error word the host checks
+# at every step AND a sticky device word that is the optimizer's skip flag, so that nothing computed after a broken
+# hand-over reaches the weights even though the host may have queued several steps by then).  The waiters only wait long
+# when the OTHER stream is stalled from outside — with the gradient all-reduce inside the step's graph that is any peer
+# stall (a rank-0 checkpoint or evaluation, a data-loader hiccup) — so the default is far above any collective stall
+# for data-parallel runs and short for one GPU (where a timeout can only mean a host-side error between two launches).
+def _flag_timeout_ticks(world):
+    s = os.environ.get("CPFN_FLAG_TIMEOUT_S")
+    seconds = float(s) if s else (10.0 if world == 1 else 1800.0)
+    return int(seconds * 100e6)            # ticks of the 100 MHz device wall clock
 
 
 class FlatGradBucket:
@@ -282,16 +286,18 @@ class SPFNTrainer:
         mark(geom)
         return geom
 
-    def _checked_optimizer_step(self, skipped, nf_flags=None):
+    def _checked_optimizer_step(self, skipped, nf_flags=None, fault=None):
         """Finite check of the flat gradient + optimizer step (skipped on the device when a NaN / inf is found) +
         `skipped` counter.  FlatAdam does all of it in its own launches — two when the scan already rode on the
-        packing copy (nf_flags from FlatGradBucket.collect(check=True)); other optimizers get the flag tensor."""
+        packing copy (nf_flags from FlatGradBucket.collect(check=True)); other optimizers get the flag tensor.
+        fault: 0-dim fp32 device word that also skips the step when non-zero (the flag waiters' sticky time-out word)."""
         from .optim import FlatAdam
         if isinstance(self.optimizer, FlatAdam):
-            self.optimizer.found_inf = None
+            self.optimizer.found_inf = fault
             self.optimizer.step(check_gradients=nf_flags is None, skipped=skipped, nf_flags=nf_flags)
         else:
-            self.optimizer.found_inf = self.bucket.nonfinite_flag()
+            found = self.bucket.nonfinite_flag()
+            self.optimizer.found_inf = found if fault is None else torch.maximum(found, fault)
             self.optimizer.step()
             skipped += self.optimizer.found_inf
 
@@ -317,18 +323,19 @@ class SPFNTrainer:
         return out[:6]
 
     # ---- hipGraph replay of the step -----------------------------------------------------------
-    # At 16 clouds per GPU the step is ~330 launches and host-bound when launched one by one.  With the
+    # At 16 clouds per GPU the step is ~150 launches and host-bound when launched one by one.  With the
     # assignment solved on the device (cpfn_hungarian_match) nothing in the step needs the host, so it is
-    # captured ONCE as a single graph:
-    #   G  = (geometry buffers B -> A) + network forward + heads post-processing + segmented sums + assignment
-    #        + fits + matched losses + full backward + gradient packing + finite flag + Adam
-    #        || forked branch: FPS / ball query / 3-NN / inverse indices of the NEXT batch into buffers B
+    # captured ONCE:
+    #   G  = network forward + heads post-processing + segmented sums + assignment + fits + matched losses
+    #        + full backward + gradient packing (+ finite scan) + [all-reduce] + Adam            (trainer's stream)
+    #   GS = FPS / ball query / 3-NN / inverse indices of the NEXT batch into the geometry buffers B (side stream)
     #   G0 = the geometry pass alone (only replayed when the next batch was not announced)
-    # The geometry of a batch depends on its coordinates only, so computing it one step ahead inside G hides
-    # the 0.7 ms FPS latency chain (16 workgroups) behind the forward and backward passes.
+    # and per step: geomA <- geomB + new inputs (one multi-tensor copy), flag kernels, replay G || GS.
+    # The geometry of a batch depends on its coordinates only, so computing it one step ahead hides the 0.6 ms FPS
+    # latency chain (16 workgroups) behind the forward and backward passes.
     # CPFN_HOST_ASSIGNMENT=1 solves the assignment with SciPy on the host like the reference; the step is then
     # split at that round trip: G1 (forward .. cost matrices -> pinned host memory, event), G1b (the fits, which
-    # do not depend on the assignment, run while the host works), G2 (the rest).
+    # do not depend on the assignment, run while the host works), G2 (the rest, with the geometry as a forked branch).
     @staticmethod
     def _flatten_geom(g):
         out = []
@@ -499,7 +506,9 @@ class SPFNTrainer:
         st["world"], st["g0"] = world, g0
         st["single"] = not fl.HOST_ASSIGNMENT and K <= 32
         if st["single"]:
-            # Device-side assignment (cpfn_hungarian_match): the step has no host round trip and is ONE graph.
+            # Device-side assignment (cpfn_hungarian_match): the step has no host round trip and is ONE linear graph; the
+            # geometry of the NEXT batch is a second linear graph, replayed on the side stream while the step's graph runs
+            # (own memory pool: the two replay concurrently).
             g = torch.cuda.CUDAGraph()
             stamps = st["stamps"] = (torch.zeros(5, dtype=torch.int64, device=dev)
                                      if os.environ.get("CPFN_STEP_STAMPS") == "1" else None)
@@ -509,81 +518,57 @@ class SPFNTrainer:
                     from . import lib as _l
                     _l.check(_l.lib().cpfn_stamp(stamps[i:].data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cpfn_stamp")
 
-            split = st["split"] = SPLIT_GRAPHS
-            if split:
-                # the geometry of the NEXT batch as its own linear graph, replayed on the side stream while the step's
-                # graph runs (own memory pool: the two replay concurrently)
-                gs = torch.cuda.CUDAGraph()
-                self._gside.wait_stream(self._gstream)
-                if ADOPT_SIDE_OUTPUTS:
-                    # the tensors the captured pass allocates have fixed addresses (the graph's private pool): they ARE
-                    # the B set — no 12 MB copy at the end of every side replay.  G0 (the serial pass of an un-announced
-                    # batch) is re-captured so that it fills them.
-                    import contextlib
-                    from . import ops as _ops
-                    with torch.cuda.graph(gs, stream=self._gside, capture_error_mode="thread_local"):
-                        with _ops.background_geometry():
-                            fresh_side = self._flatten_geom(self.module.compute_geometry(st["P_next"], starts))
-                        stamp(1)
-                    self._gstream.wait_stream(self._gside)
-                    assert len(fresh_side) == len(geomB) and all(a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous()
-                                                                 for a, b in zip(fresh_side, geomB))
-                    geomB[:] = fresh_side                       # (st["geomB"] and geometry_into_B see the same list)
-                    g0b = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g0b, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
-                        geometry_into_B(sb["P"], beside=False)
-                    st["g0_first"], st["g0"] = g0, g0b          # (the first one owns the pool the step's graph shares)
-                else:
-                    with torch.cuda.graph(gs, stream=self._gside, capture_error_mode="thread_local"):
-                        geometry_into_B(st["P_next"])
-                        stamp(1)
-                    self._gstream.wait_stream(self._gside)
-                st["gs"] = gs
-                st["b_read"], st["b_written"] = torch.cuda.Event(), torch.cuda.Event()
-                st["side_pending"] = False
-                # FLAG_ORDER: the two streams order themselves through two device flags polled / set by one-lane kernels
-                # (include/cpfn_hip.h: cpfn_flag_wait / cpfn_flag_set) instead of two events per step: the closed
-                # cross-queue event cycle (main: wait, record; side: wait, record) costs ~100 us of idle GPU per step on
-                # this stack, a tiny eager kernel between two replays costs nothing (tools/dbg/twin_potential.py).
-                # [0] = step graphs whose geometry hand-off is done ("geomB consumed, next inputs written"),
-                # [1] = side graphs finished.  The waiters give up after 2 s and set flag_err (pinned, polled by the host).
-                if FLAG_ORDER:
-                    st["flags"] = torch.zeros(4, dtype=torch.int32, device=dev)
-                    st["flag_err"] = torch.zeros(4, dtype=torch.int32).pin_memory()
-                    st["n_main"], st["n_side"] = 0, 0
+            from . import ops as _ops
+            gs = torch.cuda.CUDAGraph()
+            self._gside.wait_stream(self._gstream)
+            # the tensors the captured pass allocates have fixed addresses (the graph's private pool): they ARE the B set —
+            # no 12 MB copy at the end of every side replay.  G0 (the serial pass of an un-announced batch) is
+            # re-captured so that it fills them.
+            with torch.cuda.graph(gs, stream=self._gside, capture_error_mode="thread_local"):
+                with _ops.background_geometry():
+                    fresh_side = self._flatten_geom(self.module.compute_geometry(st["P_next"], starts))
+                stamp(1)
+            self._gstream.wait_stream(self._gside)
+            assert len(fresh_side) == len(geomB) and all(a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous()
+                                                         for a, b in zip(fresh_side, geomB))
+            geomB[:] = fresh_side                       # (st["geomB"] and geometry_into_B see the same list)
+            g0b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0b, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
+                geometry_into_B(sb["P"], beside=False)
+            st["g0_first"], st["g0"] = g0, g0b          # (the first one owns the pool the step's graph shares)
+            st["gs"] = gs
+            st["side_pending"] = False
+            # The two streams' flags: [0] = step graphs whose geometry hand-off is done ("geomB consumed, next inputs
+            # written"), [1] = side graphs finished.  A waiter that gives up (_flag_timeout_ticks) raises flag_err (pinned,
+            # polled by the host at every step) and flag_fault (device): the latter is the optimizer's skip flag inside the
+            # graph, so a step computed from a broken hand-over can never update the weights.
+            st["flags"] = torch.zeros(4, dtype=torch.int32, device=dev)
+            st["flag_err"] = torch.zeros(4, dtype=torch.int32).pin_memory()
+            st["flag_fault"] = torch.zeros((), dtype=torch.float32, device=dev)
+            st["flag_timeout"] = _flag_timeout_ticks(world)
+            st["n_main"], st["n_side"] = 0, 0
             with torch.cuda.graph(g, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
                 if stamps is not None:
-                    stamps[4:5].copy_(stamps[3:4])                  # when the PREVIOUS replay was joined
+                    stamps[4:5].copy_(stamps[3:4])                  # when the PREVIOUS replay ended
                 stamp(0)
-                if not split:
-                    self._copy_all(geomA, geomB)
-                    self._gside.wait_stream(self._gstream)              # fork (after B was read): next batch's geometry
-                    with torch.cuda.stream(self._gside):
-                        geometry_into_B(st["P_next"])
-                        stamp(1)
                 self.bucket.zero()
                 self.module(sb["P"], geometry=st["geomA"])
-                if fl.PARALLEL_BRANCHES:
-                    Xn, W, nl, tl, S, n_gt, st["match"], params = fl.match_and_fit(sb["P"], self.module.heads_packed, sb, self.mult)
-                else:
-                    Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
-                    n_gt = fl.count_gt(sb["I_gt"])
-                    params, st["match"] = fl.fit_params_and_match(sb["P"], W, Xn, self.mult, S, n_gt)
+                Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
+                n_gt = fl.count_gt(sb["I_gt"])
+                params, st["match"] = fl.fit_params_and_match(sb["P"], W, Xn, self.mult, S, n_gt)
                 with fl.unit_loss_gradient():
                     out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
                 out[0].backward(st["unit"])              # (no ones_like fill inside the graph)
                 nf = self.bucket.collect(check=world == 1)
                 if world == 1:
-                    self._checked_optimizer_step(st["skipped"], nf)
+                    self._checked_optimizer_step(st["skipped"], nf, fault=st["flag_fault"])
                 elif exchange_in_graph:
-                    # data parallel: the gradient exchange (one RCCL all-reduce with in-collective averaging over the
-                    # 5.6 MB flat bucket) and the optimizer are nodes of the SAME graph: still one replay per step
+                    # data parallel: the gradient exchange (RCCL, over the 5.6 MB flat bucket) and the optimizer are nodes
+                    # of the SAME graph: still one replay per step
                     self.bucket.all_reduce_mean()
-                    self._checked_optimizer_step(st["skipped"])
+                    self._checked_optimizer_step(st["skipped"], fault=st["flag_fault"])
                 st["out"] = tuple(o.detach() for o in out)
                 stamp(2)
-                if not split:
-                    self._gstream.wait_stream(self._gside)              # join
                 stamp(3)
             st["g"] = g
             st["exchange_in_graph"] = world > 1 and exchange_in_graph
@@ -647,21 +632,19 @@ class SPFNTrainer:
     def _graph_step(self, batch, next_batch=None):
         from .SPFN import fused_losses as fl
         st = self._graph
-        flags = st.get("flags")
-        if flags is not None and int(st["flag_err"][0]) != 0:
-            raise RuntimeError("cpfn_amd: a cross-stream flag wait of the replayed step timed out (the other stream's graph "
-                               "was never launched?); the results of the last steps are invalid")
-        if st.get("split", False) and st["single"] and st["side_pending"]:
+        single = st["single"]
+        if single and int(st["flag_err"][0]) != 0:
+            raise RuntimeError("cpfn_amd: a cross-stream flag wait of the replayed step timed out after %.0f s (the other "
+                               "stream's graph was never launched, or it stalled for longer than CPFN_FLAG_TIMEOUT_S); the "
+                               "optimizer has skipped every step since, the losses of the last steps are invalid"
+                               % (st["flag_timeout"] / 100e6))
+        if single and st["side_pending"]:
             # the side graph of the previous step (reads P_next / the FPS seeds, writes geomB) must be done before
             # this step overwrites its inputs and reads its result
-            cur = torch.cuda.current_stream(batch["P"].device)
-            if flags is not None:
-                self._flag_wait(st, 1, st["n_side"], cur)
-            else:
-                cur.wait_event(st["b_written"])
+            self._flag_wait(st, 1, st["n_side"], torch.cuda.current_stream(batch["P"].device))
             st["side_pending"] = False
         # inputs into the static buffers: ONE multi-tensor copy (the batch tensors that are not already the
-        # static ones + the next batch's coordinates for the geometry branch of G2)
+        # static ones + the next batch's coordinates for the geometry graph)
         dst, src = [], []
         for k, v in batch.items():
             if v.data_ptr() != st["batch"][k].data_ptr():
@@ -671,10 +654,9 @@ class SPFNTrainer:
             dst.append(st["P_next"])
             src.append(next_batch["P"])
         B, N, _ = batch["P"].shape
-        split = st.get("split", False) and st["single"]
-        # (two linear graphs: geomA <- geomB is an eager launch in front of the step's graph; when the geometry was
-        #  announced one step ahead — the normal case — it rides on the input copy: one launch per step, not two)
-        merged = split and self._prefetched is None and st["geom_ready_for"] == self._batch_key(batch["P"])
+        # (geomA <- geomB is an eager launch in front of the step's graph; when the geometry was announced one step
+        #  ahead — the normal case — it rides on the input copy: one launch per step, not two)
+        merged = single and self._prefetched is None and st["geom_ready_for"] == self._batch_key(batch["P"])
         if merged:
             dst, src = dst + st["geomA_flat"], src + st["geomB"]
         if dst:
@@ -687,50 +669,42 @@ class SPFNTrainer:
         if st["geom_ready_for"] != self._batch_key(batch["P"]):      # not announced one step ahead: do it now
             self._draw_starts(st, B, N)
             st["g0"].replay()
-        # inputs of the geometry branch: the NEXT batch's FPS seeds (its coordinates were copied above)
-        # (without an announced next batch the branch recomputes stale inputs; its result is ignored and
-        #  no FPS seeds are drawn, so the CPU generator is consumed exactly as in eager mode)
+        # inputs of the geometry graph: the NEXT batch's FPS seeds (its coordinates were copied above)
+        # (without an announced next batch no geometry graph runs and no FPS seeds are drawn, so the CPU generator is
+        #  consumed exactly as in eager mode)
         announce = next_batch is not None
-        if st["single"]:
-            payload = None
-            if announce:
-                # (flag ordering: the 2 x B seeds travel in the arguments of the flag kernel that releases the geometry graph)
-                payload = self._draw_starts(st, B, N, as_payload=split and flags is not None and SEEDS_AS_PAYLOAD and 2 * B <= 64)
+        if single:
             st["geom_ready_for"] = self._batch_key(next_batch["P"]) if announce else None
-            if split:
-                # geomA <- geomB (three small launches), then the side stream may overwrite geomB with the next batch's
-                # geometry while this stream replays the step
-                if not merged:
-                    self._copy_all(st["geomA_flat"], st["geomB"])
-                if announce:
-                    cur = torch.cuda.current_stream(batch["P"].device)
-                    if flags is not None:
-                        from . import lib as _l
-                        h = _l.lib()
-                        with torch.cuda.device(cur.device):
-                            if payload is not None:
-                                _l.check(h.cpfn_flag_set_payload(flags[0:].data_ptr(), st["n_main"] + 1, st["start_dev"].data_ptr(),
-                                                                 payload.data_ptr(), payload.numel(), cur.cuda_stream), "cpfn_flag_set_payload")
-                            else:
-                                _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), st["n_main"] + 1, cur.cuda_stream), "cpfn_flag_set")
-                            self._flag_wait(st, 0, st["n_main"] + 1, self._gside)
-                            with torch.cuda.stream(self._gside):
-                                st["gs"].replay()
-                            _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), st["n_side"] + 1, self._gside.cuda_stream), "cpfn_flag_set")
-                        st["n_side"] += 1
+            # geomA <- geomB, then the side stream may overwrite geomB with the next batch's geometry while this
+            # stream replays the step
+            if not merged:
+                self._copy_all(st["geomA_flat"], st["geomB"])
+            if announce:
+                from . import lib as _l
+                h = _l.lib()
+                cur = torch.cuda.current_stream(batch["P"].device)
+                flags = st["flags"]
+                # the 2 x B seeds travel in the arguments of the flag kernel that releases the geometry graph (they were a
+                # 128-byte host-to-device copy: a blit kernel of its own between two replays)
+                as_payload = 2 * B <= 64
+                payload = self._draw_starts(st, B, N, as_payload=as_payload)
+                with torch.cuda.device(cur.device):
+                    if as_payload:
+                        _l.check(h.cpfn_flag_set_payload(flags[0:].data_ptr(), st["n_main"] + 1, st["start_dev"].data_ptr(),
+                                                         payload.data_ptr(), payload.numel(), cur.cuda_stream), "cpfn_flag_set_payload")
                     else:
-                        st["b_read"].record(cur)
-                        with torch.cuda.stream(self._gside):
-                            self._gside.wait_event(st["b_read"])
-                            st["gs"].replay()
-                            st["b_written"].record(self._gside)
-                    st["side_pending"] = True
+                        _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), st["n_main"] + 1, cur.cuda_stream), "cpfn_flag_set")
+                    self._flag_wait(st, 0, st["n_main"] + 1, self._gside)
+                    with torch.cuda.stream(self._gside):
+                        st["gs"].replay()
+                    _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), st["n_side"] + 1, self._gside.cuda_stream), "cpfn_flag_set")
+                st["n_side"] += 1
+                st["side_pending"] = True
             st["g"].replay()                                   # the whole step: no host synchronisation
-            if flags is not None:
-                st["n_main"] += 1
+            st["n_main"] += 1
             if st["world"] > 1 and not st["exchange_in_graph"]:
                 self.bucket.all_reduce_mean()
-                self._checked_optimizer_step(st["skipped"])
+                self._checked_optimizer_step(st["skipped"], fault=st["flag_fault"])
             self.global_step += 1
             return st["out"]
         st["g1"].replay()
@@ -753,8 +727,9 @@ class SPFNTrainer:
     def _flag_wait(st, which, value, stream):
         from . import lib as _l
         with torch.cuda.device(stream.device):
-            _l.check(_l.lib().cpfn_flag_wait(st["flags"][which:].data_ptr(), int(value) & 0xffffffff, 200_000_000,
-                                             st["flag_err"].data_ptr(), stream.cuda_stream), "cpfn_flag_wait")
+            _l.check(_l.lib().cpfn_flag_wait(st["flags"][which:].data_ptr(), int(value) & 0xffffffff, st["flag_timeout"],
+                                             st["flag_err"].data_ptr(), st["flag_fault"].data_ptr(), stream.cuda_stream),
+                     "cpfn_flag_wait")
 
     def stream(self, device):
         """The stream the replayed steps run on.  A training loop that runs under it (`with torch.cuda.stream(...)`)

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define CPFN_EINVAL (-22)
-#define CPFN_ABI_VERSION 1
+#define CPFN_ABI_VERSION 2
 
 /* Library / build identification (no GPU needed). */
 CPFN_API int cpfn_abi_version(void);
@@ -52,15 +52,20 @@ CPFN_API const char *cpfn_build_info(void);
  * scratch: B*N floats (8-byte aligned), only touched when N > CPFN_FPS_MAX_RESIDENT (may be NULL
  * otherwise); the reference allocates the same [B,N] `tmp` itself (sampling.cpp:73).
  * Three kernels: N <= 8192: one workgroup per cloud, distances in registers, cloud mirrored in LDS;
- * 8192 < N <= 524288 (while B * ceil(N / 2048..8192) <= 1024 and S <= 4094): ceil(N / (256*PPT)) workgroups per
+ * 8192 < N <= 524288 (while all B * ceil(N / 2048..8192) workgroups can be resident together — occupancy of the kernel x
+ * compute units of the device, queried once — and S <= 4094): ceil(N / (256*PPT)) workgroups per
  * cloud, PPT = 8|16|32 points per lane in registers, one 8-byte key per workgroup and sample exchanged through
  * the first words of `scratch` (zeroed by a memset node in front of the launch; bounded spin: a sibling workgroup
- * that never arrives yields -1 indices, not a hang); otherwise one workgroup per cloud streaming the distances
+ * that never arrives ends the cloud's sampling with index 0 in the remaining outputs and a count in cpfn_fps_faults(),
+ * not a hang); otherwise one workgroup per cloud streaming the distances
  * through `scratch`.  All three select identical indices. */
 #define CPFN_FPS_MAX_RESIDENT 8192
 #define CPFN_FPS_SKIP_NEAR_ORIGIN 1
 CPFN_API int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, int flags,
              int *idx_out, float *scratch, void *stream);
+/* Clouds for which the several-workgroups FPS (8192 < N) gave up waiting for a sibling workgroup since the library was
+ * loaded; their remaining samples are index 0.  0 in a healthy process.  Synchronises the device; < 0 on error. */
+CPFN_API int cpfn_fps_faults(void);
 
 /* Ball query.  Replaces ball_query() (cuda_ops/src/ball_query.cpp, kernel
  * ball_query_gpu.cu:9-44) with the CPU route's arithmetic
@@ -318,21 +323,17 @@ CPFN_API int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N);
 CPFN_API int cpfn_mlp_gemm_set_probe(void *buf, int slots, int max_wg);
 /* Rate in kHz of the device wall clock the probe's ticks are counted in (hipDeviceAttributeWallClockRate); <= 0 on error. */
 CPFN_API int cpfn_wall_clock_khz(int device);
-/* Forward layers of >= 32768 rows, (K, N) in {(128,128), (192,128), (128,256)}, with BatchNorm statistics — the same
- * Y (bit for bit) and statistics as cpfn_mlp_gemm(..., stats_partial, a_scale, a_shift), in the row-streaming form
- * (8 waves, one pipeline over the workgroup's rows); stats_partial has cpfn_mlp_gemm_rows_blocks(P) rows. */
-CPFN_API int cpfn_mlp_gemm_rows_ok(long long P, int K, int N);
-CPFN_API int cpfn_mlp_gemm_rows_blocks(long long P);
-CPFN_API int cpfn_mlp_gemm_rows(const void *A, int lda, const void *W, long long P, int K, int N, void *Y, int ldy,
-                                float *stats_partial, const float *a_scale, const float *a_shift, void *stream);
 /* One reading of that clock into *dst, issued as a (capturable) 1-thread kernel on `stream`: a time stamp inside a
  * replayed graph (debugging aid: CPFN_STEP_STAMPS=1). */
 CPFN_API int cpfn_stamp(unsigned long long *dst, void *stream);
 /* Cross-stream ordering on ONE GPU by device flags (no reference counterpart: the reference has one stream): a one-lane
  * kernel on `stream` that polls *flag until (int)(*flag - value) >= 0 — giving up after timeout_ticks of the 100 MHz wall
- * clock, then storing 1 to *err (may be NULL; may be pinned host memory) — and one that stores `value` to *flag.  Data written by kernels BEFORE the
+ * clock, then storing 1 to *err (may be NULL; may be pinned host memory) and 1.0f to *fault (may be NULL; device memory: a
+ * sticky word the caller passes to cpfn_adam_flat as found_inf, so that no step computed after a broken hand-over updates
+ * the weights) — and one that stores `value` to *flag.  Data written by kernels BEFORE the
  * setter on its stream is visible to kernels AFTER the waiter on its stream (kernel boundaries), as with an event. */
-CPFN_API int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err, void *stream);
+CPFN_API int cpfn_flag_wait(const unsigned *flag, unsigned value, unsigned long long timeout_ticks, unsigned *err,
+                            float *fault, void *stream);
 CPFN_API int cpfn_flag_set(unsigned *flag, unsigned value, void *stream);
 /* cpfn_flag_set with a payload of count <= 64 ints (HOST pointer: they travel in the launch's arguments) stored to the
  * device array dst before the flag: small per-step inputs of the waiting stream without a host-to-device copy. */
@@ -399,23 +400,14 @@ CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,
                             float *dW, void *stream);
-/* Small layers (P <= 16384 rows) with cpfn_bn_bwd_apply folded into its two consumers — g_y = bf16(coef0 . [y_scale . y +
- * y_shift > 0] . g_z + coef1 . y + coef2) is formed on the operand loads from the gradient w.r.t. the ACTIVATED output Gz
- * [P,N] and the layer's pre-BN output Yr [P,N], never stored:
- *   cpfn_mlp_wgrad_apply: cpfn_mlp_wgrad (64 x 64 tiles; same split partials in workspace, dW optional);
- *   cpfn_mlp_dgrad_small: Gout[P,K] (bf16, row stride ldo) = g_y . W with W the FORWARD weight panel [N][K]; bwd_y
- *     (optional, + b_scale / b_shift [K] + stats_partial [cpfn_mlp_gemm_blocks(P,K)][2][K]): pass 1 of the BatchNorm
- *     backward of the layer below from the tile being stored (replaces its cpfn_bn_relu_bwd launch).  Yr = NULL: Gz is
- *     g_y itself (bwd_y is then required).  Measured on the replayed step: the riding reduction pays (one launch less
- *     per hidden layer), the folded apply pass does NOT for these shapes — every column block of the output re-forms
- *     the whole operand panel (K / 64 times), and the two kernels lose what the saved launch gains. */
+/* Small layers (P <= 16384 rows): cpfn_mlp_dgrad_small is the data gradient Gout[P,K] (bf16, row stride ldo) = Gy . W with
+ * W the FORWARD weight panel [N][K], with pass 1 of the BatchNorm backward of the layer BELOW riding on the tile being
+ * stored (bwd_y = that layer's pre-BN output [P,K], b_scale / b_shift [K], stats_partial [cpfn_mlp_gemm_blocks(P,K)][2][K]):
+ * replaces that layer's cpfn_bn_relu_bwd launch.  cpfn_mlp_wgrad_apply_ok: the layer's weight gradient runs on 64 x 64
+ * tiles (the shapes this small-layer route is taken for). */
 CPFN_API int cpfn_mlp_wgrad_apply_ok(long long P, int N, int K);
-CPFN_API int cpfn_mlp_wgrad_apply(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
-                                  const float *y_shift, const void *A, int lda, long long P, int N, int K,
-                                  const float *a_scale, const float *a_shift, float *workspace, float *dW, void *stream);
 CPFN_API int cpfn_mlp_dgrad_small_ok(long long P, int N, int K);
-CPFN_API int cpfn_mlp_dgrad_small(const void *Gz, const void *Yr, const float *coef, const float *y_scale,
-                                  const float *y_shift, const void *W, long long P, int N, int K, void *Gout, int ldo,
+CPFN_API int cpfn_mlp_dgrad_small(const void *Gy, const void *W, long long P, int N, int K, void *Gout, int ldo,
                                   const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
                                   void *stream);
 /* Weight gradient AND data gradient of a dense 128 -> 128 layer from ONE read of its BatchNorm-adjoint gradient
@@ -463,14 +455,6 @@ CPFN_API int cpfn_smallk_wgrad_apply(const void *Gz, const void *Y, const float 
 CPFN_API int cpfn_smallk_wgrad_apply_xyz(const void *Gz, const float *W0, const float *coef, const float *y_scale,
                                          const float *y_shift, const float *X, int KS, long long P, int C,
                                          float *workspace, float *dW, void *stream);
-/* cpfn_mlp_bwd_fused for the 64 -> 64 layer that FOLLOWS such a first layer (sa1): its input operand (before the BN + ReLU
- * transform a_scale / a_shift) and the y of the riding reduction are both that first layer's pre-BN output, recomputed
- * from X [P,3] and W0 [64][3]; apply pass folded in (Gz, Yr, apply_coef, y_scale, y_shift as in cpfn_mlp_bwd_fused);
- * stats_partial [cpfn_mlp_wgrad_splits(P,64,64)][2][64]. */
-CPFN_API int cpfn_mlp_bwd_fused_xyz(const void *Gz, const void *Yr, const float *apply_coef, const float *y_scale,
-                                    const float *y_shift, const float *X, const float *W0, const void *W, long long P,
-                                    const float *a_scale, const float *a_shift, float *workspace, void *Gout,
-                                    float *stats_partial, void *stream);
 
 /* ------------------------------------------------------------------ loss-side fusions
  * (the callers on the far side of the fitters.)  K <= 32 for the training-side

@@ -23,8 +23,24 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(h, n), "symbol %s declared in cpfn_hip.h but not exported" % n
         assert n in lib.SIGNATURES, "symbol %s has no ctypes prototype in cpfn_amd/lib.py" % n
     assert set(lib.SIGNATURES) == set(names)
-    assert lib.lib().cpfn_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "cpfn_hip.h")).read()
+    version = int(re.search(r"#define\s+CPFN_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.lib().cpfn_abi_version() == version == lib.ABI_VERSION
     assert b"gfx950" in lib.lib().cpfn_build_info()
+
+
+def test_ctypes_prototypes_have_the_header_s_argument_counts():
+    """A signature that changes in the header but not in lib.py (or the other way round) is a silent argument mismatch
+    for ctypes: every prototype must at least have the declared number of parameters."""
+    from cpfn_amd import lib
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cpfn_hip.h")).read(), flags=re.S)
+    decls = re.findall(r"CPFN_API\s+[\w\s\*]+?\b(cpfn_\w+)\s*\(([^;]*?)\)\s*;", text)
+    assert len(decls) == len(_declared())
+    for name, params in decls:
+        params = params.strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(lib.SIGNATURES[name]), "%s: header declares %d parameters, lib.py binds %d" % (
+            name, n, len(lib.SIGNATURES[name]))
 
 
 def test_product_never_imports_oracle():

@@ -90,11 +90,11 @@ def test_cross_stream_flags_order_two_streams_and_time_out():
     TMO = 200_000_000          # 2 s of the 100 MHz clock
     for k in range(1, 65):
         with torch.cuda.stream(a):                     # producer: waits until round k - 1 was consumed, then writes round k
-            _l.check(h.cpfn_flag_wait(flags[1:].data_ptr(), k - 1, TMO, err.data_ptr(), a.cuda_stream), "cpfn_flag_wait")
+            _l.check(h.cpfn_flag_wait(flags[1:].data_ptr(), k - 1, TMO, err.data_ptr(), None, a.cuda_stream), "cpfn_flag_wait")
             data.fill_(float(k))
             _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), k, a.cuda_stream), "cpfn_flag_set")
         with torch.cuda.stream(b):                     # consumer
-            _l.check(h.cpfn_flag_wait(flags[0:].data_ptr(), k, TMO, err.data_ptr(), b.cuda_stream), "cpfn_flag_wait")
+            _l.check(h.cpfn_flag_wait(flags[0:].data_ptr(), k, TMO, err.data_ptr(), None, b.cuda_stream), "cpfn_flag_wait")
             seen[k - 1:k].copy_(data.min().reshape(1))
             _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), k, b.cuda_stream), "cpfn_flag_set")
     torch.cuda.synchronize()
@@ -108,10 +108,10 @@ def test_cross_stream_flags_order_two_streams_and_time_out():
     for k in range(65, 73):
         vals = (ctypes.c_int * 40)(*[k * 1000 + i for i in range(40)])
         with torch.cuda.stream(a):
-            _l.check(h.cpfn_flag_wait(flags[1:].data_ptr(), k - 1, TMO, err.data_ptr(), a.cuda_stream), "cpfn_flag_wait")
+            _l.check(h.cpfn_flag_wait(flags[1:].data_ptr(), k - 1, TMO, err.data_ptr(), None, a.cuda_stream), "cpfn_flag_wait")
             _l.check(h.cpfn_flag_set_payload(flags[0:].data_ptr(), k, dst.data_ptr(), vals, 40, a.cuda_stream), "cpfn_flag_set_payload")
         with torch.cuda.stream(b):
-            _l.check(h.cpfn_flag_wait(flags[0:].data_ptr(), k, TMO, err.data_ptr(), b.cuda_stream), "cpfn_flag_wait")
+            _l.check(h.cpfn_flag_wait(flags[0:].data_ptr(), k, TMO, err.data_ptr(), None, b.cuda_stream), "cpfn_flag_wait")
             got[k - 65].copy_(dst)
             _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), k, b.cuda_stream), "cpfn_flag_set")
     torch.cuda.synchronize()
@@ -119,8 +119,9 @@ def test_cross_stream_flags_order_two_streams_and_time_out():
     assert torch.equal(got.cpu(), want) and int(err[0]) == 0
     assert h.cpfn_flag_set_payload(flags.data_ptr(), 1, dst.data_ptr(), vals, 65, None) != 0       # more than 64 ints
     # nobody sets flag 2: the waiter returns after ~10 ms and raises the error word
-    _l.check(h.cpfn_flag_wait(flags[2:].data_ptr(), 1, 1_000_000, err.data_ptr(), torch.cuda.current_stream().cuda_stream),
-             "cpfn_flag_wait")
+    fault = torch.zeros((), dtype=torch.float32, device=dev)
+    _l.check(h.cpfn_flag_wait(flags[2:].data_ptr(), 1, 1_000_000, err.data_ptr(), fault.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream), "cpfn_flag_wait")
     torch.cuda.synchronize()
-    assert int(err[0]) == 1
-    assert h.cpfn_flag_wait(None, 1, 1, None, None) != 0 and h.cpfn_flag_set(None, 1, None) != 0
+    assert int(err[0]) == 1 and float(fault) == 1.0          # host word for the host, device word for the optimizer
+    assert h.cpfn_flag_wait(None, 1, 1, None, None, None) != 0 and h.cpfn_flag_set(None, 1, None) != 0

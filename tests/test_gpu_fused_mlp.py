@@ -362,28 +362,23 @@ def test_one_pass_weight_and_data_gradient(name, P, cin, widths, pool_k, stats_f
     ("ragged", 1000, 384, [256, 128], None),
 ])
 @pytest.mark.parametrize("stats_fused", [False, True])
-@pytest.mark.parametrize("apply_fused", [False, True])
-def test_small_layer_backward_fusion(name, P, cin, widths, pool_k, stats_fused, apply_fused, monkeypatch):
-    """Small layers: cpfn_mlp_wgrad_apply + cpfn_mlp_dgrad_small (BatchNorm apply pass on the operand loads, the reduction
-    of the layer below on the stored tile) against bn_bwd_apply + wgrad + GEMM (+ bn_relu_bwd): bit-identical without the
-    riding reduction, same sums in a different order with it."""
+def test_small_layer_backward_fusion(name, P, cin, widths, pool_k, stats_fused, monkeypatch):
+    """Small layers: cpfn_mlp_dgrad_small (the reduction of the layer below riding on the stored tile of the data gradient)
+    against wgrad + GEMM + bn_relu_bwd: the same gradient bits, the same sums in a different order."""
     from cpfn_amd import fused_mlp, lib as _l
     convs, bns = _stack(cin, widths, seed=17)
     g = torch.Generator().manual_seed(P)
     x = torch.randn(P, cin, generator=g).to(dev())
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
     monkeypatch.setattr(fused_mlp, "BWD_STATS_FUSED", stats_fused)
-    monkeypatch.setattr(fused_mlp, "SMALL_BWD_APPLY", apply_fused)     # (off by default: does not pay on these shapes)
     res = {}
     for fused in (True, False):
         monkeypatch.setattr(fused_mlp, "SMALL_BWD_FUSED", fused)
         _l.byte_census(True)
         res[fused] = _run(x, convs, bns, torch.bfloat16, pool_k, None, gout)
         census = _l.byte_census(False)
-        assert ("cpfn_mlp_dgrad_small" in census) == (fused and (apply_fused or stats_fused)), sorted(census)
-        assert ("cpfn_mlp_wgrad_apply" in census) == (fused and apply_fused), sorted(census)
+        assert ("cpfn_mlp_dgrad_small" in census) == (fused and stats_fused), sorted(census)
         if fused and not pool_k:
-            assert ("cpfn_bn_bwd_apply" not in census) == apply_fused, sorted(census)
             if stats_fused:      # only the top layer still needs its own reduction pass
                 assert census["cpfn_bn_relu_bwd"][0] == 1, census["cpfn_bn_relu_bwd"]
     (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
@@ -394,55 +389,60 @@ def test_small_layer_backward_fusion(name, P, cin, widths, pool_k, stats_fused, 
         assert (a is None and b is None) or same(a, b)
 
 
-@pytest.mark.parametrize("P,K,N", [(131072, 128, 128), (40000 + 77, 128, 128), (32768, 128, 128)])
-@pytest.mark.parametrize("atr", [False, True])
-def test_forward_row_streaming_kernel(P, K, N, atr):
-    """cpfn_mlp_gemm_rows (CPFN_FWD_ROWS=1; off by default, see fused_mlp.FWD_ROWS) against cpfn_mlp_gemm with statistics:
-    the same Y bit for bit, the same statistics up to the order of the per-workgroup partial sums."""
-    from cpfn_amd import fused_mlp, lib as _l
-    g = torch.Generator().manual_seed(P + K)
-    A = torch.randn(P, K, generator=g).to(dev()).to(torch.bfloat16)
-    W = (torch.randn(N, K, generator=g) * 0.1).to(dev()).to(torch.bfloat16)
-    sc = (torch.rand(K, generator=g) + 0.5).to(dev()) if atr else None
-    sh = (torch.randn(K, generator=g) * 0.2).to(dev()) if atr else None
-    res = {}
-    for rows in (True, False):
-        fused_mlp.FWD_ROWS = rows
-        try:
-            _l.byte_census(True)
-            Y, part, nblk = fused_mlp.gemm(A, W, stats=True, a_scale=sc, a_shift=sh)
-            census = _l.byte_census(False)
-        finally:
-            fused_mlp.FWD_ROWS = False
-        assert ("cpfn_mlp_gemm_rows" in census) == rows
-        res[rows] = (Y, part[:nblk].double().sum(0))
-    assert torch.equal(res[True][0], res[False][0])
-    assert _rel(res[True][1], res[False][1]) < 1e-6
-    yf = res[True][0].float()
-    ref = torch.stack([yf.double().sum(0), (yf.double() ** 2).sum(0)])
-    assert _rel(res[True][1], ref) < 1e-5
-
-
 @pytest.mark.parametrize("P,widths,pool_k", [(643 * 64, [64, 64, 128], 64), (40000 + 16, [64, 64], None)])
 def test_first_layer_output_recomputed_in_backward(P, widths, pool_k, monkeypatch):
-    """sa1: the fp32-xyz first layer's pre-BN output, recomputed from the coordinates inside cpfn_smallk_wgrad_apply_xyz and
-    cpfn_mlp_bwd_fused_xyz instead of read (three reads of a [P,64] tensor): every gradient bit-identical."""
+    """sa1: the fp32-xyz first layer's pre-BN output, recomputed from the coordinates inside cpfn_smallk_wgrad_apply_xyz
+    instead of read: every gradient bit-identical, run after run."""
     from cpfn_amd import fused_mlp, lib as _l
     convs, bns = _stack(3, widths, seed=19)
     g = torch.Generator().manual_seed(P)
     xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev())
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
     res = {}
-    for rec, onepass in ((True, True), (True, False), (False, False)):
+    for rec in (True, False):
         monkeypatch.setattr(fused_mlp, "XYZ_RECOMPUTE", rec)
-        monkeypatch.setattr(fused_mlp, "XYZ_ONEPASS", onepass)       # (off by default: see fused_mlp.XYZ_ONEPASS)
         _l.byte_census(True)
-        res[(rec, onepass)] = [_run(None, convs, bns, torch.bfloat16, pool_k, xyz, gout) for _ in range(3)]
+        res[rec] = [_run(None, convs, bns, torch.bfloat16, pool_k, xyz, gout) for _ in range(3)]
         census = _l.byte_census(False)
-        assert ("cpfn_mlp_bwd_fused_xyz" in census) == onepass and ("cpfn_smallk_wgrad_apply_xyz" in census) == rec, sorted(census)
-    ref = res[(False, False)][0]
+        assert ("cpfn_smallk_wgrad_apply_xyz" in census) == rec, sorted(census)
+    ref = res[False][0]
     for key, runs in res.items():
         for (ya, _, gra, _) in runs:             # every run of every variant: the same bits
             assert torch.equal(ya, ref[0]), key
             for a, b in zip(gra, ref[2]):
                 assert (a is None and b is None) or torch.equal(a, b), key
+
+
+def test_gradient_accumulation_over_two_backward_passes():
+    """The weight-gradient split reductions are deferred to the end of a backward pass, which is only sound while
+    AccumulateGrad steals the returned tensor (p.grad is None).  With accumulation (p.grad already set) they must run at
+    once: two identical backward passes without clearing the gradients give exactly twice the gradient, for the stack's
+    weights and for the packed heads (weights and biases)."""
+    from cpfn_amd import fused_mlp, mlp
+    P = 40000
+    convs, bns = _stack(128, [128, 128], seed=23)
+    heads = nn.ModuleList([nn.Conv1d(128, o, 1) for o in (3, 4, 28)]).to(dev())
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(P, 128, generator=g).to(dev())
+    gout = torch.randn(P, 35, generator=g).to(dev())
+    params = list(convs.parameters()) + list(bns.parameters()) + list(heads.parameters())
+
+    def once():
+        feat = mlp.run_stack(x, convs, bns, torch.bfloat16)
+        out = torch.cat(mlp.heads(feat, heads, torch.bfloat16), dim=1)
+        (out.float() * gout).sum().backward()
+
+    for p in params:
+        p.grad = None
+    once()
+    torch.cuda.synchronize()
+    single = [None if p.grad is None else p.grad.clone() for p in params]
+    once()                                    # accumulates into the existing .grad tensors
+    torch.cuda.synchronize()
+    for p, s in zip(params, single):
+        if s is None:
+            assert p.grad is None
+        else:
+            assert torch.isfinite(p.grad).all()
+            assert torch.equal(p.grad, 2 * s)
+    assert not fused_mlp._pending_reduce

@@ -101,7 +101,7 @@ def test_fps_sizes_vs_oracle(B, N, S):
                                          (20, 131072, 16, False), (1, 600000, 20, False)])
 def test_fps_large_clouds_multi_workgroup(B, N, S, dup):
     """N > 8192: several workgroups per cloud exchanging one 8-byte key per sample (fps_shared_kernel, 8 / 16 / 32 points
-    per lane), and its fall-backs to the one-workgroup streaming kernel (B * G > 1024 resident workgroups, N > 524288) —
+    per lane), and its fall-backs to the one-workgroup streaming kernel (more workgroups than the device can hold at once, N > 524288) —
     all bit-identical to the oracle, duplicated points (exact ties: lowest index wins) included; also the CUDA-route
     flag (near-origin points skipped) on the multi-workgroup path."""
     from cpfn_amd import cuda_ops
@@ -113,6 +113,8 @@ def test_fps_large_clouds_multi_workgroup(B, N, S, dup):
     got = cuda_ops.farthest_point_sampling(T(xyz), S, start_idx=T(start), cuda_compat=False).cpu().numpy()
     assert got.min() >= 0
     assert np.array_equal(got, og.farthest_point_sample(xyz, S, start).astype(np.int32))
+    from cpfn_amd import ops
+    assert ops.fps_faults() == 0            # no workgroup ever gave up on a sibling (co-residency derived from occupancy)
     if B == 3:
         xyz[:, 50:90] *= 0.01
         got = cuda_ops.farthest_point_sampling(T(xyz), S, cuda_compat=True).cpu().numpy()

@@ -108,22 +108,6 @@ def test_host_assignment_mode_matches_device_assignment(monkeypatch):
         assert float((a - b).norm() / b.norm()) < 2e-2
 
 
-def test_forked_loss_section_matches_serial(monkeypatch):
-    """CPFN_PARALLEL_BRANCHES=1 (assignment on a forked stream next to the four fits; the default until the segmented
-    sums moved into the heads launch) against the default serial loss section: same losses and gradients."""
-    from cpfn_amd.SPFN import fused_losses as fl
-    assert not fl.PARALLEL_BRANCHES
-    l_s, g_s, tr_s = _run("graph+prefetch", 0.0, steps=6)
-    monkeypatch.setattr(fl, "PARALLEL_BRANCHES", True)
-    l_p, g_p, tr_p = _run("graph+prefetch", 0.0, steps=6)
-    assert tr_p._graph is not None and tr_p._graph["single"]
-    for a, b in zip(l_p, l_s):
-        for x, y in zip(a, b):
-            assert abs(x - y) <= 1e-3 * abs(y) + 1e-5, (a, b)
-    for a, b in zip(g_p, g_s):
-        assert float((a - b).norm() / b.norm()) < 2e-2
-
-
 def _train(dtype, fused_losses, graphs, steps=64):
     from cpfn_amd import training
     from cpfn_amd.PointNet2 import pn2_network
