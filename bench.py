@@ -41,8 +41,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ROOFLINE_SYMBOL = "cpfn_mlp_gemm"
 # kernel families that time themselves (in-kernel probe): C-ABI entry points whose algorithmic bytes the census counts
 FAMILIES = {"cpfn_mlp_gemm": ("cpfn_mlp_gemm", "cpfn_mlp_dgrad_small"),
-            "cpfn_mlp_wgrad": ("cpfn_mlp_wgrad", "cpfn_mlp_wgrad_apply"),
-            "cpfn_mlp_bwd_fused": ("cpfn_mlp_bwd_fused", "cpfn_mlp_bwd_fused_xyz")}
+            "cpfn_mlp_wgrad": ("cpfn_mlp_wgrad",),
+            "cpfn_mlp_bwd_fused": ("cpfn_mlp_bwd_fused",)}
 KIND_FAMILY = {1: "cpfn_mlp_gemm", 2: "cpfn_mlp_gemm", 3: "cpfn_mlp_gemm", 4: "cpfn_mlp_wgrad", 5: "cpfn_mlp_bwd_fused"}
 
 
@@ -58,6 +58,11 @@ def parse_args():
                     help="global (default) = BASELINE.json configs[1], the config the metric is quoted on; local = "
                          "configs[2] (LocalSPFN: 32 patches/GPU, 21 instances, fitter losses off) as an extra data point")
     ap.add_argument("--probe-dump", default=None, help="write the per-launch probe records of the last replayed step (JSON)")
+    ap.add_argument("--probe-no-announce", action="store_true",
+                    help="with --probe-dump: replay the step's graph WITHOUT the next batch's geometry beside it")
+    ap.add_argument("--probe-replays", type=int, default=20,
+                    help="replays sampled after the timed region for the roofline's per-launch time (median over them and "
+                         "the timed region's last step)")
     ap.add_argument("--census-out", default=None, help="write the per-entry-point algorithmic bytes of one step (JSON)")
     return ap.parse_args()
 
@@ -257,15 +262,35 @@ def main():
     elapsed = time.perf_counter() - t0
     # every slot written during the timed region: a replayed graph rewrites the slots its launches were given at capture
     # time, so the buffer now holds the launches of the LAST replayed step (eager mode: the last PROBE_SLOTS launches)
-    pr = probe.cpu().numpy()
-    fam_probe = {f: [0, 0] for f in FAMILIES}            # family -> [launches, ticks] of the last replayed step
-    for slot in pr:
-        nwg = int(slot[0])
-        if nwg > 0:
-            tt = slot[2:2 + 2 * nwg].reshape(nwg, 2)
-            f = KIND_FAMILY.get(int(slot[1]), ROOFLINE_SYMBOL)
-            fam_probe[f][0] += 1
-            fam_probe[f][1] += int(tt[:, 1].max() - tt[:, 0].min())
+    def read_probe():
+        pr_ = probe.cpu().numpy()
+        fam = {f: [0, 0] for f in FAMILIES}              # family -> [launches, ticks] of one replayed step
+        for slot in pr_:
+            nwg = int(slot[0])
+            if nwg > 0:
+                tt = slot[2:2 + 2 * nwg].reshape(nwg, 2)
+                f = KIND_FAMILY.get(int(slot[1]), ROOFLINE_SYMBOL)
+                fam[f][0] += 1
+                fam[f][1] += int(tt[:, 1].max() - tt[:, 0].min())
+        return pr_, fam
+
+    pr, fam_last = read_probe()
+    comm_us = [trainer.comm_us()] if world > 1 else []
+    # ... and single steps differ by +-8 % (0.53-0.61 of peak over round 2's runs): `--probe-replays` more replays of the same
+    # graphs are sampled right after the timed region (each the third of three back-to-back steps, then a sync to read the
+    # buffer: steady state, nothing timed) and the roofline uses the MEDIAN over them and the timed region's last step.
+    samples = [fam_last]
+    if trainer._graph is not None:
+        for _ in range(max(args.probe_replays, 0)):
+            for _ in range(3):
+                trainer.step(batch, next_batch=batch)
+            sync()
+            samples.append(read_probe()[1])
+            if world > 1:
+                comm_us.append(trainer.comm_us())
+    import statistics
+    fam_probe = {f: [fam_last[f][0], int(statistics.median(sm[f][1] for sm in samples))] for f in FAMILIES}
+    fam_range = {f: (min(sm[f][1] for sm in samples), max(sm[f][1] for sm in samples)) for f in FAMILIES}
     # the family with the most kernel time in the step is the one the roofline object describes
     dominant = max(FAMILIES, key=lambda f: fam_probe[f][1]) if any(v[0] for v in fam_probe.values()) else ROOFLINE_SYMBOL
     probe_launches, probe_ticks = fam_probe[dominant]
@@ -292,8 +317,8 @@ def main():
         sv_t = trainer._graph.get("stamps") if getattr(trainer, "_graph", None) else None
         marks = np.zeros(4)
         for _ in range(reps):
-            for _ in range(3):      # CPFN_PROBE_NO_ANNOUNCE=1: the step's graph WITHOUT the next batch's geometry beside it
-                trainer.step(batch, next_batch=None if os.environ.get("CPFN_PROBE_NO_ANNOUNCE") == "1" else batch)
+            for _ in range(3):      # --probe-no-announce: the step's graph WITHOUT the next batch's geometry beside it
+                trainer.step(batch, next_batch=None if args.probe_no_announce else batch)
             sync()
             q = probe.cpu().numpy()
             recs = []
@@ -340,7 +365,15 @@ def main():
     ev_ms = sum(rep.get(k, (0, 0.0))[1] for k in FAMILIES[dominant])
     lib.time_symbols([])
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rank_ms, rank_comm = None, None
     if world > 1:
+        # per-rank step times and exchange times travel to rank 0 (diagnosis of a scaling run: a slow rank shows up as
+        # everybody else's exchange time)
+        mine = torch.tensor([1e3 * elapsed / args.steps, statistics.median([c for c in comm_us if c is not None] or [float("nan")])],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rank_ms, rank_comm = [float(a[0]) for a in allr], [float(a[1]) for a in allr]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -363,8 +396,9 @@ def main():
         if probe_launches > 0:                           # graph replays (or eager steps) of the timed region, timed by the kernels
             per_launch_s = probe_ticks / (wall_khz * 1e3) / probe_launches
             roof_mode = ("device wall-clock timestamps (start, end per workgroup; duration = max end - min start) stored by the "
-                         "kernels themselves inside the timed region: the %d launches of its last replayed step (a hipGraph "
-                         "replay cannot be bracketed kernel by kernel with host events)" % probe_launches)
+                         "kernels themselves: the family's %d launches per replayed step, MEDIAN over the timed region's last "
+                         "step and %d replays of the same graphs sampled right after it (a hipGraph replay cannot be "
+                         "bracketed kernel by kernel with host events)" % (probe_launches, len(samples) - 1))
         else:
             per_launch_s = ev_ms / max(ev_calls, 1) / 1e3
             roof_mode = "HIP events around every launch in 3 eager re-runs of the step (probe counters empty)"
@@ -374,10 +408,14 @@ def main():
         achieved = bytes_per_launch / per_launch_s / 1e9
         step_bytes = sum(b for _, b in census.values())
         ms_per_step = 1e3 * elapsed / args.steps
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_family_traffic.json")
-        if os.path.exists(tpath):                       # PMC passes (rocprofv3 --pmc), see profiles/README.md
-            traffic = json.load(open(tpath)).get(dominant, {}).get("hbm_bytes_per_launch")
+        # HBM traffic per launch from the PMC passes of the newest committed collection (rocprofv3 --pmc cannot run inside
+        # this process; tools/collect_profiles.sh refreshes the file and refuses to finish with one older than the library)
+        import glob
+        traffic, traffic_src = None, None
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_family_traffic.json")))
+        if tfiles:
+            traffic = json.load(open(tfiles[-1])).get(dominant, {}).get("hbm_bytes_per_launch")
+            traffic_src = os.path.relpath(tfiles[-1], ROOT)
         line = {
             "metric": "point-clouds/sec (8192 pts, %sSPFN fwd+bwd)" % ("Global" if args.workload == "global" else "Local"),
             "value": clouds / elapsed, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps,
@@ -396,7 +434,11 @@ def main():
                                       else ", RCCL all-reduce + Adam after the graph")) if trainer._graph.get("single")
                                   else "hipGraph replay (3 graphs/step around the host-side assignment)")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_range": [bytes_per_step / (fam_range[dominant][1] / (wall_khz * 1e3)) / 1e9 / HBM_PEAK_GBS,
+                                        bytes_per_step / (fam_range[dominant][0] / (wall_khz * 1e3)) / 1e9 / HBM_PEAK_GBS]
+                         if fam_range[dominant][0] > 0 else None,
+                         "samples": len(samples),
                          "launches": probe_launches or ev_calls, "avg_launch_us": 1e6 * per_launch_s,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "measured": roof_mode,
                          "wall_clock_khz": wall_khz,
@@ -408,6 +450,16 @@ def main():
                          # every self-timing family of the step ("kernel" above is the one with the most time)
                          "families": families},
         }
+        if world > 1:
+            # what a SCALE run needs to be diagnosable: who was slow, and how long the exchange took on every rank
+            line["config"]["collective"] = ("%s on one flat %d-byte fp32 bucket (CPFN_DP_COLLECTIVE), %s" % (
+                trainer.bucket.collective, 4 * trainer.bucket.flat.numel(),
+                "inside the step's graph" if (trainer._graph or {}).get("exchange_in_graph") else "eager launches after the graph"))
+            line["ms_per_step_ranks"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
+            line["comm_us_per_step"] = {"median_over_ranks": statistics.median(rank_comm), "max": max(rank_comm), "all": rank_comm,
+                                        "measured": "device wall clock between two one-lane stamp kernels around the exchange "
+                                                    "(end of gradient packing -> end of the collective), median over %d "
+                                                    "sampled replays per rank" % len(comm_us)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -51,6 +51,14 @@ def get_learning_rate(init_learning_rate, global_step, batch_size, decay_step, d
 # when the OTHER stream is stalled from outside — with the gradient all-reduce inside the step's graph that is any peer
 # stall (a rank-0 checkpoint or evaluation, a data-loader hiccup) — so the default is far above any collective stall
 # for data-parallel runs and short for one GPU (where a timeout can only mean a host-side error between two launches).
+# CPFN_DP_COLLECTIVE: how the flat gradient bucket is averaged over the ranks.  "all_reduce" (default): ONE collective with
+# in-collective averaging.  "rs_ag": reduce-scatter + all-gather on the same bucket (SURVEY §8e argues that on 7
+# point-to-point xGMI links a direct reduce-scatter / all-gather pair can beat a ring all-reduce of this size; RCCL picks its
+# own algorithm for either, so this is an A/B switch for a SCALE run, reported by bench.py as config.collective).
+DP_COLLECTIVE = os.environ.get("CPFN_DP_COLLECTIVE", "all_reduce")
+_BUCKET_PAD = 3360            # elements; 4 x lcm(1..8): every world size up to 8 (and 10, 12, 14, 15, 16 ...) gets 16-byte-aligned shards
+
+
 def _flag_timeout_ticks(world):
     s = os.environ.get("CPFN_FLAG_TIMEOUT_S")
     seconds = float(s) if s else (10.0 if world == 1 else 1800.0)
@@ -70,7 +78,12 @@ class FlatGradBucket:
         self.params = [p for p in module.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=torch.float32, device=ref.device)
+        # (padded so that the bucket splits into equal shards for the reduce-scatter / all-gather layout; `flat` is the
+        #  unpadded view everybody else uses, the padding stays zero)
+        self.padded = torch.zeros((n + _BUCKET_PAD - 1) // _BUCKET_PAD * _BUCKET_PAD, dtype=torch.float32, device=ref.device)
+        self.flat = self.padded[:n]
+        self._shard = None
+        self.collective = DP_COLLECTIVE if DP_COLLECTIVE in ("all_reduce", "rs_ag") else "all_reduce"
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -124,11 +137,21 @@ class FlatGradBucket:
         with the averaging done inside it (ncclAvg) — no scaling launch, capturable in the step's graph.  Other
         backends (gloo on CPU): sum + divide."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            if self.flat.is_cuda and dist.get_backend() == "nccl":
+            world = dist.get_world_size()
+            avg = self.flat.is_cuda and dist.get_backend() == "nccl"
+            if self.collective == "rs_ag" and self.padded.numel() % world == 0:
+                # reduce-scatter into this rank's shard, all-gather the averaged shards back into the bucket
+                if self._shard is None:
+                    self._shard = torch.empty(self.padded.numel() // world, dtype=torch.float32, device=self.padded.device)
+                dist.reduce_scatter_tensor(self._shard, self.padded, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)
+                if not avg:
+                    self._shard.div_(world)
+                dist.all_gather_into_tensor(self.padded, self._shard)
+            elif avg:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                self.flat.div_(dist.get_world_size())
+                self.flat.div_(world)
 
     def finite(self):
         """One fused reduction instead of the reference's per-parameter isinf/isnan scan
@@ -211,6 +234,7 @@ class SPFNTrainer:
         self.fused_losses = True      # HIP loss kernels when the model exposes its packed fp32 heads
         module.return_point_features = False    # the step consumes the heads only (no [B,128,N] fp32 conversion)
         self._side, self._prefetched = None, None
+        self._comm_stamps = None          # two device wall-clock readings around the gradient exchange (world > 1)
 
     @property
     def skipped_steps(self):
@@ -476,6 +500,8 @@ class SPFNTrainer:
             sb["gt_axes"] = stacked
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if world > 1 and batch["P"].is_cuda:
+            if self._comm_stamps is None:                  # (allocated outside any capture)
+                self._comm_stamps = torch.zeros(2, dtype=torch.int64, device=dev)
             _quiesce_collectives(dev)
         starts = (st["start1"], st["start2"])
         # static geometry buffers (shapes from one eager pass)
@@ -564,8 +590,10 @@ class SPFNTrainer:
                     self._checked_optimizer_step(st["skipped"], nf, fault=st["flag_fault"])
                 elif exchange_in_graph:
                     # data parallel: the gradient exchange (RCCL, over the 5.6 MB flat bucket) and the optimizer are nodes
-                    # of the SAME graph: still one replay per step
-                    self.bucket.all_reduce_mean()
+                    # of the SAME graph: still one replay per step.  Two one-lane stamp kernels bracket it (device wall
+                    # clock): `comm_us()` of the last replayed step, so that a scaling run can tell exchange time from
+                    # everything else (2 x ~3 us on a 1.9 ms chain).
+                    self._exchange_with_stamps(dev)
                     self._checked_optimizer_step(st["skipped"], fault=st["flag_fault"])
                 st["out"] = tuple(o.detach() for o in out)
                 stamp(2)
@@ -703,7 +731,7 @@ class SPFNTrainer:
             st["g"].replay()                                   # the whole step: no host synchronisation
             st["n_main"] += 1
             if st["world"] > 1 and not st["exchange_in_graph"]:
-                self.bucket.all_reduce_mean()
+                self._exchange_with_stamps(batch["P"].device)
                 self._checked_optimizer_step(st["skipped"], fault=st["flag_fault"])
             self.global_step += 1
             return st["out"]
@@ -722,6 +750,28 @@ class SPFNTrainer:
             self._checked_optimizer_step(st["skipped"])
         self.global_step += 1
         return st["out"]
+
+    def _exchange_with_stamps(self, dev):
+        """The step's gradient exchange between two device wall-clock stamps (cpfn_stamp: one-lane kernels, capturable)."""
+        from . import lib as _l
+        if self._comm_stamps is None:
+            self._comm_stamps = torch.zeros(2, dtype=torch.int64, device=dev)
+        h = _l.lib()
+        with torch.cuda.device(dev):
+            _l.check(h.cpfn_stamp(self._comm_stamps[0:].data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cpfn_stamp")
+            self.bucket.all_reduce_mean()
+            _l.check(h.cpfn_stamp(self._comm_stamps[1:].data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "cpfn_stamp")
+
+    def comm_us(self):
+        """Microseconds between the two stamps around the LAST step's gradient exchange (from the end of the gradient
+        packing to the end of the collective on this rank: wire time plus the wait for the slowest peer); None on one GPU.
+        Synchronises with the device."""
+        if self._comm_stamps is None:
+            return None
+        a, b = (int(v) for v in self._comm_stamps.cpu())
+        from . import lib as _l
+        khz = float(_l.lib().cpfn_wall_clock_khz(self._comm_stamps.device.index or 0))
+        return (b - a) / khz * 1e3 if khz > 0 and b >= a else None
 
     @staticmethod
     def _flag_wait(st, which, value, stream):

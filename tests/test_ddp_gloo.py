@@ -47,16 +47,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, collective="all_reduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                 # different init per rank: broadcast must fix it
     model = TinyHeads()
     training.broadcast_parameters(model)
     tr = training.SPFNTrainer(model, batch_size=2 * world, multipliers=LOCAL_MULT, fused_adam=False)
+    tr.bucket.collective = collective             # (what CPFN_DP_COLLECTIVE selects)
+    assert tr.bucket.padded.numel() % world == 0 and tr.bucket.flat.data_ptr() == tr.bucket.padded.data_ptr()
     for step in range(3):
         out = tr.step(_batch(2, seed=10 * step + rank))
     assert tr.skipped_steps == 0 and tr.global_step == 3
+    assert not tr.bucket.padded[tr.bucket.flat.numel():].any()          # the padding never picks anything up
     torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -76,6 +79,25 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
         tr.step(_cat([_batch(2, seed=10 * step + r) for r in range(world)]))
     for k, v in model.state_dict().items():
         torch.testing.assert_close(v, sd[0][k], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.timeout(300)
+def test_reduce_scatter_all_gather_layout_gives_the_same_replicas(tmp_path):
+    """CPFN_DP_COLLECTIVE=rs_ag (reduce-scatter + all-gather on the padded flat bucket) against the default single
+    all-reduce: replicas identical across the ranks in both layouts, and — two ranks: a + b is one rounding either way —
+    identical between the layouts."""
+    world = 2
+    res = {}
+    for mode in ("all_reduce", "rs_ag"):
+        d = tmp_path / mode
+        d.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), str(d), mode), nprocs=world, join=True)
+        sd = [torch.load(os.path.join(str(d), "rank%d.pt" % r)) for r in range(world)]
+        for k in sd[0]:
+            assert torch.equal(sd[0][k], sd[1][k]), "replicas diverged (%s): %s" % (mode, k)
+        res[mode] = sd[0]
+    for k in res["all_reduce"]:
+        assert torch.equal(res["all_reduce"][k], res["rs_ag"][k]), k
 
 
 # ---- the REAL network: PointNet2 (fp32 compute mode) + SPFNTrainer + FlatGradBucket on two gloo ranks ------------------
