@@ -32,15 +32,17 @@ def _unit(v):
 
 def primitive_cloud(B, N, n_prims=10, noise=0.005, seed=0):
     """Points sampled on `n_prims` random planes/spheres/cylinders/cones per cloud,
-    plus Gaussian noise.  Returns dict(P, X_gt, I_gt, T_gt) with
+    plus Gaussian noise.  Returns dict(P, X_gt, I_gt, T_gt, axis) with
     T ids in the reference's config order sphere=0, plane=1, cylinder=2, cone=3
-    (Configs/config_globalSPFN.yml:13-17).  Every label in [0, n_prims) is present.
+    (Configs/config_globalSPFN.yml:13-17) and axis [B,n_prims,3] the primitive's plane normal / cylinder or cone
+    axis (an arbitrary unit vector for spheres).  Every label in [0, n_prims) is present.
     """
     g = _gen(seed)
     P = torch.empty(B, N, 3)
     X = torch.empty(B, N, 3)
     I = torch.empty(B, N, dtype=torch.long)
     T = torch.zeros(B, n_prims, dtype=torch.long)
+    A = torch.zeros(B, n_prims, 3)
     for b in range(B):
         lab = torch.randint(0, n_prims, (N,), generator=g)
         lab[:n_prims] = torch.arange(n_prims)  # gap-free labels
@@ -52,6 +54,7 @@ def primitive_cloud(B, N, n_prims=10, noise=0.005, seed=0):
             T[b, k] = t
             c = torch.rand(3, generator=g) * 1.2 - 0.6
             ax = _unit(torch.randn(3, generator=g))
+            A[b, k] = ax
             e1 = _unit(torch.linalg.cross(ax, _unit(torch.randn(3, generator=g))))
             e2 = torch.linalg.cross(ax, e1)
             u = torch.rand(n, generator=g)
@@ -82,13 +85,15 @@ def primitive_cloud(B, N, n_prims=10, noise=0.005, seed=0):
         P[b] += noise * torch.randn(N, 3, generator=g)
     # normalise like the dataset does
     P = normalise_cloud(P)
-    return {"P": P.contiguous(), "X_gt": X.contiguous(), "I_gt": I, "T_gt": T}
+    return {"P": P.contiguous(), "X_gt": X.contiguous(), "I_gt": I, "T_gt": T, "axis": A}
 
 
 def training_batch(B, N=8192, n_max_instances=28, n_prims=10, n_inst_points=512,
-                   kind="primitives", seed=0):
+                   kind="primitives", seed=0, consistent_axes=False):
     """One batch with every tensor spfn_train_val_epoch moves to the device
-    (Utils/training_utils.py:122-132)."""
+    (Utils/training_utils.py:122-132).  consistent_axes: the three GT axis tensors carry the primitives' own axes
+    (what a data set provides; for runs that TRAIN on the batches) instead of random unit vectors (the default:
+    bench.py, the fixtures and the tests only need the shapes)."""
     g = _gen(seed + 7919)
     if kind == "primitives":
         d = primitive_cloud(B, N, n_prims=n_prims, seed=seed)
@@ -110,6 +115,9 @@ def training_batch(B, N=8192, n_max_instances=28, n_prims=10, n_inst_points=512,
             sel = m[torch.randint(0, m.numel(), (n_inst_points,), generator=g)]
             ppi[b, k] = P[b, sel]
     axes = [_unit(torch.randn(B, n_max_instances, 3, generator=g)) for _ in range(3)]
+    if consistent_axes and kind == "primitives":
+        for a in axes:
+            a[:, :n_prims] = d["axis"]
     return {
         "P": P.contiguous(), "X_gt": X_gt.contiguous(), "points_per_instance": ppi,
         "I_gt": I_gt, "T_gt": T_gt,

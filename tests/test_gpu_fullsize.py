@@ -235,10 +235,58 @@ def _compare(model, tr, batch_cpu, batch, starts, out, cfg, tag):
     S = fused_losses.SegStats.apply(torch.softmax(Ya.detach()[..., 7:], 2), batch["I_gt"])
     match_a = fused_losses.hungarian_device(S, fused_losses.count_gt(batch["I_gt"])).cpu().numpy()
     ra = _report(tag + " (A) fp32 mode vs fp32 oracle", oa, Ya.detach().cpu(), match_a, flat_a, ref, aux, st, model, tr, batch_cpu, K)
+    # ---- (P) what the network itself does to an error of bf16 size: the product's fp32 mode again, with Gaussian noise of the
+    #      size of sa1's bf16 error (measured here: ~0.45 % relative L2) added to sa1's output and NOTHING else changed.
+    #      tools/bf16_stage_probe.py: with every stack after sa1 in fp32 the heads still sit 29 % from the all-fp32 heads — the
+    #      randomly initialised network with batch statistics amplifies a perturbation ~65 x — so the end-to-end deviation of
+    #      the bf16 step is held to THIS run's, not to an absolute figure.
+    l1 = {}
+    orig_rows = model.sa1.forward_rows
+
+    def spy(*a, **k):
+        xyz1, f1, aux1 = orig_rows(*a, **k)
+        if l1.get("noise"):
+            g = torch.Generator(device=f1.device).manual_seed(7)
+            nz = torch.randn(f1.shape, generator=g, device=f1.device, dtype=torch.float32)
+            f1 = (f1.float() + nz * (l1["noise"] * f1.float().norm() / nz.norm())).to(f1.dtype)
+        l1["out"] = f1.detach().float().clone()
+        return xyz1, f1, aux1
+    model.sa1.forward_rows = spy
+    try:
+        with torch.no_grad():
+            model(batch["P"], fps_start=starts)
+            l1_fp32 = l1["out"]
+            model.set_compute_dtype(torch.bfloat16)
+            model(batch["P"], fps_start=starts)
+            e1 = _rel(l1["out"], l1_fp32)
+            model.set_compute_dtype(torch.float32)
+        l1["noise"] = e1
+        for p in model.parameters():
+            p.grad = None
+        X, T, W, _, _ = model(batch["P"], fps_start=starts)
+        Yp = torch.cat([X, T, W], 2)
+        op = fused_losses.fused_losses(batch["P"], Yp, batch, cfg["mult"], tr.classes)
+        op[0].backward()
+    finally:
+        model.sa1.forward_rows = orig_rows
+    flat_p = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in tr.bucket.params]).cpu()
+    S = fused_losses.SegStats.apply(torch.softmax(Yp.detach()[..., 7:], 2), batch["I_gt"])
+    match_p = fused_losses.hungarian_device(S, fused_losses.count_gt(batch["I_gt"])).cpu().numpy()
+    rp = _report(tag + " (P) fp32 mode, sa1 output + %.2e noise, vs fp32 oracle" % e1, op, Yp.detach().cpu(), match_p, flat_p, ref, aux, st,
+                 model, tr, batch_cpu, K)
     model.set_compute_dtype(torch.bfloat16)
+    for p in model.parameters():
+        p.grad = None
     assert _losses_within(ra, 1e-3, 1e-5) and max(ra["head_X"], ra["head_T"], ra["head_W"]) < 1e-3, ra
     assert ra["match"] == 1.0 and ra["grad_rel"] < 2e-2, ra
-    assert _losses_within(rc, 6e-2, 3e-3) and rc["match"] >= 0.5 and rc["grad_cos"] > 0.2, rc
+    # (C) against (P): the bf16 step is as far from the fp32 oracle as an fp32 step whose sa1 output carries one bf16 error
+    assert e1 < 8e-3, e1
+    for k in ("head_X", "head_T", "head_W"):
+        assert rc[k] <= 1.3 * rp[k] + 1e-3, (k, rc[k], rp[k])
+    # (the matching is discrete: one noise draw moves the agreement by ~0.1; config 2 measured 0.64 bf16 / 0.75 noise)
+    assert rc["match"] >= rp["match"] - 0.15 and rc["grad_cos"] >= rp["grad_cos"] - 0.1, (rc, rp)
+    assert rc["grad_rel"] <= 1.3 * rp["grad_rel"] + 1e-2, (rc, rp)
+    assert _losses_within(rc, 6e-2, 3e-3), rc
     # ---- (B) the fused bf16 stacks one by one at bench size
     _teacher_forced_stacks(model, batch, starts, tag)
 

@@ -1,0 +1,133 @@
+"""Does the bf16 step train like the fp32 one?  (VERDICT r2 #2a; the reference trains in fp32, Utils/training_utils.py:140-158)
+
+GlobalSPFN is trained from the same initial weights on the same sequence of structured synthetic batches
+(cpfn_amd.synthetic: points on random planes / spheres / cylinders / cones with noise, GT normals, labels, types and axes)
+  * in the product's bf16 mode (fused MFMA stacks, replayed hipGraph) twice, with two different dropout / FPS seeds
+    — their difference is the run-to-run spread that has nothing to do with precision —
+  * and in its fp32 mode (PyTorch fp32 MLPs, same HIP geometry / fitters / losses, eager),
+and every trained model is evaluated on held-out clouds with the evaluation metrics of the reference
+(`SPFN.metric_implementation.compute_all_metrics`, evaluation_globalSPFN.py:85-104: eval-mode BatchNorm, hard memberships).
+
+    python tools/bf16_vs_fp32_training.py [--steps 2000] [--batch 16] [--points 8192] [--out profiles/r03_bf16_vs_fp32.json]
+
+Prints one JSON object; `compare()` is what tests/test_gpu_trainer.py asserts on a short run.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch                                                    # noqa: E402
+
+CLASSES = ["sphere", "plane", "cylinder", "cone"]               # Configs/config_globalSPFN.yml:13-17
+METRICS = ("mIoU", "type_accuracy", "normal_difference", "axis_difference", "mean_residual", "Sk_coverage_0.02", "P_coverage_0.02")
+
+
+def make_pool(n, B, N, seed0, dev, n_prims=10):
+    from cpfn_amd import synthetic
+    return [{k: v.to(dev) for k, v in synthetic.training_batch(B, N, 28, n_prims=n_prims, n_inst_points=512, seed=seed0 + i,
+                                                                consistent_axes=True).items()} for i in range(n)]
+
+
+def train(mode, seed, steps, pool, dev, log_every=0):
+    from cpfn_amd import training
+    from cpfn_amd.PointNet2 import pn2_network
+    torch.manual_seed(0)                                        # the same initial weights in every run
+    model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
+    model.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    B = pool[0]["P"].shape[0]
+    tr = training.SPFNTrainer(model, batch_size=B, use_graphs=mode == "bf16", classes=CLASSES)
+    torch.manual_seed(seed)                                     # FPS starts and dropout masks of THIS run
+    losses, t0 = [], time.time()
+    ctx = torch.cuda.stream(tr.stream(dev)) if mode == "bf16" else contextlib.nullcontext()
+    with ctx:
+        for s in range(steps):
+            out = tr.step(pool[s % len(pool)], next_batch=pool[(s + 1) % len(pool)])
+            if log_every and (s + 1) % log_every == 0:
+                losses.append([float(v) for v in out])
+    torch.cuda.synchronize(dev)
+    return model, {"seconds": time.time() - t0, "skipped_steps": tr.skipped_steps, "losses_every_%d" % log_every: losses}
+
+
+@torch.no_grad()
+def evaluate(model, held, seed=4321):
+    """Mean of the reference's evaluation metrics over the held-out clouds (evaluation_globalSPFN.py:85-104)."""
+    from cpfn_amd.SPFN import metric_implementation as mi
+    model.eval()
+    torch.manual_seed(seed)                                     # FPS starts (and the always-on dropout, pn2_network.py:63)
+    acc, n = {k: 0.0 for k in METRICS}, 0
+    for b in held:
+        X, T, W, _, _ = model(b["P"])
+        X = X / torch.norm(X, dim=2, keepdim=True)
+        W = torch.softmax(W, dim=2)
+        gt = {"plane_normal": b["plane_n_gt"], "cylinder_axis": b["cylinder_axis_gt"], "cone_axis": b["cone_axis_gt"]}
+        out = mi.compute_all_metrics(b["P"], X.float(), b["X_gt"], W.float(), b["I_gt"], T.float(), b["T_gt"], b["points_per_instance"],
+                                     gt, list_epsilon=[0.01, 0.02], classes=CLASSES)
+        vals = dict(zip(METRICS[:5], out[:5]))
+        vals["Sk_coverage_0.02"], vals["P_coverage_0.02"] = out[6][1], out[7][1]
+        for k in METRICS:
+            acc[k] += float(vals[k].double().sum())
+        n += b["P"].shape[0]
+    model.train()
+    return {k: acc[k] / n for k in METRICS}
+
+
+# |bf16 - fp32| of a metric may not exceed max(SPREAD_FACTOR x |bf16 seed A - bf16 seed B|, its floor)
+SPREAD_FACTOR = 3.0
+FLOORS = {"mIoU": 0.03, "type_accuracy": 0.03, "normal_difference": 0.03, "axis_difference": 0.05, "mean_residual": 0.01,
+          "Sk_coverage_0.02": 0.05, "P_coverage_0.02": 0.05}
+
+
+def compare(res, floor_scale=1.0):
+    """-> {metric: (bf16 A, bf16 B, fp32, |mean(A, B) - fp32|, allowed)}, ok"""
+    a, b, f = res["bf16_seedA"]["metrics"], res["bf16_seedB"]["metrics"], res["fp32_seedA"]["metrics"]
+    table, ok = {}, True
+    for k in METRICS:
+        allowed = max(SPREAD_FACTOR * abs(a[k] - b[k]), floor_scale * FLOORS[k])
+        d = abs(0.5 * (a[k] + b[k]) - f[k])
+        table[k] = {"bf16_A": a[k], "bf16_B": b[k], "fp32": f[k], "abs_diff_bf16mean_fp32": d, "allowed": allowed}
+        ok = ok and d <= allowed
+    return table, ok
+
+
+def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0):
+    from cpfn_amd.SPFN import fitter_factory
+    with contextlib.redirect_stdout(io.StringIO()):
+        fitter_factory.register_primitives(CLASSES)
+    pool = make_pool(n_train, B, N, 50000, dev)
+    held = make_pool(n_held, B, N, 90000, dev)
+    res = {"config": {"steps": steps, "batch": B, "points": N, "train_batches": n_train, "held_out_clouds": n_held * B}}
+    for name, mode, seed in (("bf16_seedA", "bf16", 11), ("bf16_seedB", "bf16", 22), ("fp32_seedA", "fp32", 11)):
+        model, info = train(mode, seed, steps, pool, dev, log_every)
+        info["metrics"] = evaluate(model, held)
+        res[name] = info
+        del model
+        torch.cuda.empty_cache()
+    untrained = __import__("cpfn_amd.PointNet2.pn2_network", fromlist=["x"])
+    torch.manual_seed(0)
+    m0 = untrained.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
+    m0.set_compute_dtype(torch.bfloat16)
+    res["untrained"] = {"metrics": evaluate(m0, held)}
+    res["comparison"], res["ok"] = compare(res, floor_scale)
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--train-batches", type=int, default=64)
+    ap.add_argument("--held-batches", type=int, default=8)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    r = run(a.steps, a.batch, a.points, a.train_batches, a.held_batches, torch.device("cuda:0"), log_every=max(a.steps // 10, 1))
+    txt = json.dumps(r, indent=1)
+    if a.out:
+        open(a.out, "w").write(txt + "\n")
+    print(txt)
