@@ -152,7 +152,7 @@ def _teacher_forced_stacks(model, batch, starts, tag):
     """(B): record every run_stack call of an fp32-mode forward (its inputs at bench size), then run each stack alone
     in bf16 (the fused HIP path), in plain fp32 and in fp32-with-explicit-bf16-roundings on those inputs and one
     random upstream gradient."""
-    from cpfn_amd import mlp
+    from cpfn_amd import fused_mlp, mlp
     from test_gpu_fused_mlp import _emulated_stack
     calls, orig = [], mlp.run_stack
 
@@ -185,23 +185,34 @@ def _teacher_forced_stacks(model, batch, starts, tag):
                 b.running_mean.copy_(rm); b.running_var.copy_(rv); b.num_batches_tracked.copy_(nb)
             xin = None if x is None else x.clone().requires_grad_(True)
             if kind == "emulated":
-                y = _emulated_stack(xin, convs, bns, pool_k, xyz)
+                y = _emulated_stack(xin, convs, bns, pool_k, xyz, pool_arg=kernel_arg.get("arg"))
             else:
                 y = mlp.run_stack(xin, convs, bns, kind, pool_k=pool_k, xyz_rows=xyz)
             (y.float() * gout).sum().backward()
             return y.detach().float(), None if xin is None else xin.grad.float(), [p.grad.clone() for p in params]
+        # the fused path first, with the arg-max rows its max-pool kernel chose recorded for the emulation
+        kernel_arg, orig_pool = {}, fused_mlp.bn_relu_maxpool
+
+        def pool_spy(*a, **k):
+            res = orig_pool(*a, **k)
+            kernel_arg["arg"] = res[1].clone()
+            return res
+        fused_mlp.bn_relu_maxpool = pool_spy
+        try:
+            y16, gx16, gp16 = run(torch.bfloat16)
+        finally:
+            fused_mlp.bn_relu_maxpool = orig_pool
+        assert (pool_k is None) == ("arg" not in kernel_arg)
         y32, gx32, gp32 = run(torch.float32)
         yem, gxem, gpem = run("emulated")
-        y16, gx16, gp16 = run(torch.bfloat16)
         e32, eem = _rel(y16, y32), _rel(y16, yem)
         egx = _rel(gx16[:, :gxem.shape[1]], gxem) if gxem is not None else 0.0
         egp = max(_rel(a, b) for a, b in zip(gp16, gpem))
         print("[%s (B) stack %d: %d rows, %s -> %s%s] fwd vs fp32 %.2e, vs bf16-rounding emulation %.2e | dX %.2e | worst dparam %.2e"
               % (tag, idx, rows, "xyz" if x is None else x.shape[1], widths, " pool %d" % pool_k if pool_k else "", e32, eem, egx, egp))
-        # pooled stacks: bf16 values tie often inside a 64-row group (8 mantissa bits), the kernel takes the first row
-        # of a tie and torch.max any of them; the gradient then lands on another row of the same value — bench-size
-        # groups with padded balls show it more than the small shapes of tests/test_gpu_fused_mlp.py
-        gtol = 0.12 if pool_k else 4e-2
+        # (pooled stacks: the emulation pools the rows the kernel's arg-max chose — see _emulated_stack — so they meet the
+        #  dense stacks' bound: 7.3e-2 / 7.7e-2 for sa2 before, when near-ties inside a 64-row group flipped the arg-max)
+        gtol = 4e-2
         bad.append((idx, e32, eem, egx, egp)) if not (e32 < 3e-2 and eem < 1e-2 and egx < gtol and egp < gtol) else None
     assert not bad, bad
     for p in model.parameters():

@@ -37,7 +37,7 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-12))
 
 
-def _emulated_stack(x, convs, bns, pool_k, xyz_rows):
+def _emulated_stack(x, convs, bns, pool_k, xyz_rows, pool_arg=None):
     """The same op in plain PyTorch fp32 with the fused path's storage roundings made explicit
     (bf16 operands, bf16-stored pre-activations / activations, fp32 statistics), so ReLU masks and
     pooling arg-maxes are decided on the same values — otherwise ~0.3 % of the masks flip and the
@@ -57,7 +57,15 @@ def _emulated_stack(x, convs, bns, pool_k, xyz_rows):
         y = y32 + (r(y32) - y32).detach()                      # stored as bf16, straight-through
         z = (y - mean) * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
         if pool_k and i == len(convs) - 1:
-            z = z.reshape(-1, pool_k, z.shape[1]).max(dim=1)[0]
+            # pool_arg [G,C]: the arg-max rows the KERNEL chose.  Two bf16 pipelines with different fp32 summation orders
+            # round ~1 % of the stored pre-activations to neighbouring bf16 values, and among 64 rows the two largest are
+            # often within one bf16 step: the arg-max then flips to a row with another input, which is a few per cent of a
+            # gradient's L2 norm and says nothing about either pipeline.  Without pool_arg: the first row that attains the
+            # maximum (the kernel's rule for exact ties).
+            zz = z.reshape(-1, pool_k, z.shape[1])
+            if pool_arg is None:
+                pool_arg = (zz == zz.amax(dim=1, keepdim=True)).to(torch.uint8).argmax(dim=1)
+            z = torch.gather(zz, 1, pool_arg.long().unsqueeze(1)).squeeze(1)
         a = F.relu(z)
         a = a + (r(a) - a).detach()
     return a
