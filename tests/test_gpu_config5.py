@@ -3,9 +3,9 @@ SURVEY §8e) — the cascaded evaluation of evaluation_globalSPFN.py:62-64 (Glob
 batch 1, eval mode) followed by evaluation_localSPFN.py:95-110 (32 patches x 8192 points through LocalSPFN, then
 similarity_soft / get_point_final on its memberships), every stage against the oracle:
 
-  * 131072-point forward: FPS (streaming kernel), ball query and 3-NN indices / weights BIT-EXACT vs oracle/geometry;
-    bf16 heads vs the fp32 compute mode of the same network;
-  * 32 x 8192 LocalSPFN eval forward (K = 21): geometry bit-exact vs the oracle, bf16 vs fp32 heads;
+  * 131072-point forward: FPS (several workgroups per cloud), ball query and 3-NN indices / weights BIT-EXACT vs
+    oracle/geometry; the heads of both compute modes vs the oracle's evaluation forward (oracle/pn2.py, training=False);
+  * 32 x 8192 LocalSPFN eval forward (K = 21): geometry bit-exact vs the oracle, heads of both modes vs the oracle;
   * similarity_soft on those memberships vs the float64 oracle (sparse form of the same matrix), get_point_final vs
     the oracle; the evaluation metrics on the merged (K = 49) membership matrix vs oracle/metrics.
 
@@ -50,15 +50,29 @@ def _geometry_vs_oracle(m, xyz, starts):
 
 
 def _both_modes(m, P, starts):
+    """Evaluation-mode forward (running statistics, evaluation_globalSPFN.py:60,85 / evaluation_localSPFN.py:95) in both
+    compute modes of the product against the ORACLE's evaluation forward on the same weights, cloud and FPS seeds:
+    the fp32 mode within 1e-5 relative L2 per head (achieved 2e-7 ... 4e-7: summation order), the bf16 mode within 1e-2
+    (achieved 1e-3 ... 5e-3: with running statistics nothing amplifies the operand rounding)."""
+    from oracle import pn2 as opn2
+    state = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    prev = torch.get_num_threads()
+    torch.set_num_threads(16)
+    try:
+        with torch.no_grad():
+            heads, _, _, _ = opn2.pointnet2_forward(state, P.detach().cpu(), (starts[0].numpy(), starts[1].numpy()), training=False)
+    finally:
+        torch.set_num_threads(prev)
     with torch.no_grad():
         m.set_compute_dtype(torch.float32)
         ref = [t.clone() for t in m(P, fps_start=starts)[:3]]
         m.set_compute_dtype(torch.bfloat16)
         out = m(P, fps_start=starts)
-    for name, a, b in zip("XTW", out[:3], ref):
-        e = float((a - b).norm() / b.norm())
-        print("bf16 vs fp32 head %s: rel L2 %.2e" % (name, e))
-        assert torch.isfinite(a).all() and e < 5e-2, (name, e)
+    for name, a, b, o in zip("XTW", out[:3], ref, heads):
+        o = o.to(a.device)
+        e32, e16, e = float((b - o).norm() / o.norm()), float((a - o).norm() / o.norm()), float((a - b).norm() / b.norm())
+        print("head %s (%d x %d): fp32 mode vs oracle %.2e | bf16 vs oracle %.2e | bf16 vs fp32 mode %.2e" % (name, P.shape[0], P.shape[1], e32, e16, e))
+        assert torch.isfinite(a).all() and e32 < 1e-5 and e16 < 1e-2, (name, e32, e16)
     return out
 
 
