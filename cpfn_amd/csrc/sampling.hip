@@ -3,12 +3,21 @@
 // One workgroup per cloud.  The running min-distance of every point lives in
 // registers (PPT points per lane), the cloud itself is mirrored in LDS (x, y, z planes) so
 // that the coordinates of the newly selected point are three broadcast ds_read_b32
-// away, and the arg-max is a 64-bit key max-reduction:
-//     key = (fp32 bits of distance) << 32 | ~index
-// (distances are >= 0 so their bit patterns order like the floats; ~index makes the
-// LOWEST index win a tie, which is what torch.max returns on CPU).  Per sample: one
-// wave-level butterfly, one LDS slot per wave, ONE workgroup barrier (slots are
-// double-buffered by sample parity), one 16-lane butterfly.
+// away.  A sample is a VALU-issue phase over the lane's points plus an arg-max, and the
+// VALU phase is what bounds it (profiles/r03_fps_latency.md: 8192 points x 13 vector
+// instructions / (4 SIMDs x 16 lanes) = 1664 cycles = 0.69 us of the 1.0-1.1 us per sample
+// of the round-2 kernel), so since round 3
+//   * two points per instruction: the points of a lane sit in registers as pairs and the
+//     eight roundings of a distance are v_pk_add_f32 / v_pk_mul_f32 (same IEEE roundings,
+//     one instruction for two points), the running minimum is v_min_f32;
+//   * the lane keeps only its maximum VALUE (v_max3_f32: half an instruction per point
+//     instead of a compare and two selects per point for a (value, index) pair), the wave
+//     reduces that 32-bit value by DPP row operations, and only then is the index looked
+//     up: the first j whose ballot(md[j] == wave maximum) is non-empty, lowest lane in it —
+//     indices are t + j*NT, so that IS the lowest index (what torch.max returns on a tie);
+//   * across waves as before: a 64-bit key (fp32 bits of the distance) << 32 | ~index per
+//     wave in an LDS slot, ONE workgroup barrier per sample (slots double-buffered by
+//     sample parity), a DPP maximum over the slots.
 //
 // Arithmetic follows the reference's CPU route (modules/geometry_utils.py:88-101)
 // op for op — ((dx*dx + dy*dy) + dz*dz) with every op rounded — so that the selected
@@ -48,11 +57,126 @@ __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long k)
   return ((unsigned long long)hi << 32) | lo;
 }
 
-template <int NT, int PPT>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// max of a float over the wave (values >= 0, or -1 for "no candidate"), wave-uniform: six v_max_f32 with the DPP modifier
+// on their first operand (through __builtin_amdgcn_update_dpp the compiler emits v_mov_b32_dpp + v_max_f32 + their wait
+// states per step: 168 cycles for the six steps, profiles/r03_fps_latency.md).  The s_nop 1 in front of each step is the
+// two wait states a DPP read of a VGPR needs after the VALU write of it.
+__device__ __forceinline__ float wave_max_f32(float v) {
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// v_min_f32 / v_max3_f32 as single instructions: through fminf / fmaxf the compiler first canonicalises every operand it
+// cannot prove to be an arithmetic result (v_max_f32 x, x: one more instruction per point for the min-distances carried
+// around the sample loop).  No NaNs exist here: coordinates are finite, distances >= 0, "not a candidate" is -1.
+__device__ __forceinline__ float v_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float v_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// One sample's pass over a lane's PPT points (pairs in registers): min-distances updated against the new sample
+// (fx, fy, fz), the lane's largest min-distance returned.  d = ((dx*dx + dy*dy) + dz*dz), every operation rounded
+// (the translation unit is compiled with -ffp-contract=off; the packed instructions round like the scalar ones).
+template <int PPT>
+__device__ __forceinline__ float fps_update(const f32x2 (&px)[PPT / 2], const f32x2 (&py)[PPT / 2], const f32x2 (&pz)[PPT / 2],
+                                            f32x2 (&md)[PPT / 2], float fx, float fy, float fz) {
+  const f32x2 f2x = {fx, fx}, f2y = {fy, fy}, f2z = {fz, fz};
+  // (a dependent vector instruction issues ~8-10 cycles after its producer when the wave has nothing else to issue — one
+  //  wave per SIMD at 32 points per lane — so the running maximum is NCH independent chains, combined at the end)
+  constexpr int NCH = PPT >= 16 ? 4 : 1;
+  float lm[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) lm[c] = -1.0f;
+#pragma unroll
+  for (int j = 0; j < PPT / 2; ++j) {
+    const f32x2 dx = px[j] - f2x, dy = py[j] - f2y, dz = pz[j] - f2z;
+    const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+    f32x2 m = md[j];
+    m.x = v_min(m.x, d.x);            // never lowers an m = -1 ("not a candidate"): d >= 0
+    m.y = v_min(m.y, d.y);
+    md[j] = m;
+    lm[j % NCH] = v_max3(lm[j % NCH], m.x, m.y);
+  }
+  float r = lm[0];
+  if (NCH == 4) r = fmaxf(v_max3(lm[0], lm[1], lm[2]), lm[3]);
+  return r;
+}
+
+// Lowest point index of the wave whose min-distance equals the wave's maximum wmax (>= 0).  Slot q of a lane is point
+// base + lane + q * NT, so the lowest index is the lowest slot, then the lowest lane.  Branch-free on the vector side: every
+// lane finds its own first matching slot (one compare + one select per slot, walking the slots downwards); then, because
+// the maximum is almost always attained by ONE lane, a ballot and a readlane finish the job — exact ties across lanes (real:
+// duplicated points) take the DPP minimum over the lanes' candidate indices.  (A first version walked the slots with
+// wave-uniform ballots and an early exit: a vector compare feeding a scalar branch costs ~33 cycles per slot — 1140 cycles
+// for 32 slots, and the waves of a workgroup left that loop at different times: tools/dbg/valu_issue_bench.hip,
+// profiles/r03_fps_latency.md.)
+template <int PPT, int NT>
+__device__ __forceinline__ unsigned fps_first_index(const f32x2 (&md)[PPT / 2], float wmax, unsigned base, int lane) {
+  // Four slots per step: four compares into four DIFFERENT scalar mask registers, then the four selects.  Written through
+  // the compiler, every compare lands in VCC and every select waits for it (v_cmp, s_nop 1, v_cndmask: ~20 cycles per slot
+  // on a wave that has its SIMD to itself — 665 of a sample's 2500 cycles at 32 points per lane).
+  unsigned q = 0xFFFFu;
+#pragma unroll
+  for (int j = PPT / 2 - 2; j >= 0; j -= 2) {
+    asm("v_cmp_eq_f32_e64 s[40:41], %[w], %[m3]\n\t"
+        "v_cmp_eq_f32_e64 s[42:43], %[w], %[m2]\n\t"
+        "v_cmp_eq_f32_e64 s[44:45], %[w], %[m1]\n\t"
+        "v_cmp_eq_f32_e64 s[46:47], %[w], %[m0]\n\t"
+        "v_cndmask_b32_e64 %[q], %[q], %[c3], s[40:41]\n\t"
+        "v_cndmask_b32_e64 %[q], %[q], %[c2], s[42:43]\n\t"
+        "v_cndmask_b32_e64 %[q], %[q], %[c1], s[44:45]\n\t"
+        "v_cndmask_b32_e64 %[q], %[q], %[c0], s[46:47]"
+        : [q] "+v"(q)
+        : [w] "s"(wmax), [m0] "v"(md[j].x), [m1] "v"(md[j].y), [m2] "v"(md[j + 1].x), [m3] "v"(md[j + 1].y),
+          [c0] "n"(2 * j), [c1] "n"(2 * j + 1), [c2] "n"(2 * j + 2), [c3] "n"(2 * j + 3)
+        : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");
+  }
+  const unsigned long long hit = __ballot(q != 0xFFFFu);
+  const int l0 = __builtin_ctzll(hit);
+  unsigned idx = base + (unsigned)__builtin_amdgcn_readlane((int)q, l0) * NT + (unsigned)l0;
+  if (hit & (hit - 1)) {                       // several lanes attain the maximum: the lowest index among them
+    unsigned cand = q != 0xFFFFu ? base + q * NT + (unsigned)lane : 0xFFFFFFFFu;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)cand, m, 64);
+      cand = o < cand ? o : cand;
+    }
+    idx = (unsigned)__builtin_amdgcn_readfirstlane((int)cand);
+  }
+  return idx;
+}
+
+// PROFILE: wave 0 accumulates the shader-clock cycles of a sample's phases into prof[b][0..5] (see fps_stamp below) —
+// a diagnostic instantiation behind cpfn_fps_profile; the product kernels carry no stamp.
+__device__ __forceinline__ unsigned long long fps_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+template <int NT, int PPT, bool PROFILE = false>
 __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restrict__ xyz, int N, int S,
                                                           const int *__restrict__ start, int flags,
-                                                          int *__restrict__ idx_out) {
+                                                          int *__restrict__ idx_out,
+                                                          unsigned long long *__restrict__ prof = nullptr) {
   constexpr int NW = NT / CPFN_WAVE;
+  static_assert(PPT % 2 == 0, "points sit in registers as pairs");
   __shared__ float s_x[NT * PPT], s_y[NT * PPT], s_z[NT * PPT];   // three b32 broadcasts per sample, NOT one float4:
                                                                    // see cpfn_lds_read4 in common.h (ds_read_b96)
   __shared__ unsigned long long s_key[2][NW > 1 ? NW : 1];
@@ -64,7 +188,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
   const float *p = xyz + (size_t)b * N * 3;
   int *out = idx_out + (size_t)b * S;
 
-  float px[PPT], py[PPT], pz[PPT], md[PPT];
+  f32x2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], md[PPT / 2];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int k = t + j * NT;
@@ -76,48 +200,39 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       m = 1e10f;
       if ((flags & CPFN_FPS_SKIP_NEAR_ORIGIN) && cpfn_sqnorm3(x, y, z) <= 1e-3f) m = -1.0f;
     }
-    px[j] = x; py[j] = y; pz[j] = z; md[j] = m;
+    px[j / 2][j & 1] = x; py[j / 2][j & 1] = y; pz[j / 2][j & 1] = z; md[j / 2][j & 1] = m;
     s_x[k] = x; s_y[k] = y; s_z[k] = z;
   }
   __syncthreads();
 
+  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
   unsigned far = start ? (unsigned)start[b] : 0u;
+  float fx = s_x[far], fy = s_y[far], fz = s_z[far];
   for (int i = 0; i < S; ++i) {
+    if (PROFILE) t0 = fps_stamp();
     if (t == 0) out[i] = (int)far;
-    const float fx = s_x[far], fy = s_y[far], fz = s_z[far];
-    // the lane's own arg-max over its PPT points: NCH interleaved running maxima (slot j feeds chain j % NCH), combined at
-    // the end — one chain of PPT dependent compare / select pairs is what a wave waits for when it has a SIMD to itself
-    // (16 or 32 points per lane); ties: the lowest index, as the single chain's strict '>' gave
-    constexpr int NCH = PPT >= 16 ? 4 : 1;
-    float bestc[NCH];
-    unsigned bestic[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) { bestc[c] = -1.0f; bestic[c] = 0xFFFFFFFFu; }
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const float dx = __fsub_rn(px[j], fx), dy = __fsub_rn(py[j], fy), dz = __fsub_rn(pz[j], fz);
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      float m = md[j];
-      m = d < m ? d : m;  // never true for m = -1 (d >= 0)
-      md[j] = m;
-      if (m > bestc[j % NCH]) {
-        bestc[j % NCH] = m;
-        bestic[j % NCH] = (unsigned)(t + j * NT);
-      }
-    }
-    float best = bestc[0];
-    unsigned besti = bestic[0];
-#pragma unroll
-    for (int c = 1; c < NCH; ++c) {
-      if (bestc[c] > best || (bestc[c] == best && bestic[c] < besti)) { best = bestc[c]; besti = bestic[c]; }
-    }
-    unsigned long long key =
-        best < 0.f ? 0ull : (((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(~besti));
-    key = wave_max_key(key);
+    if (NW == 1 && i > 0) { fx = s_x[far]; fy = s_y[far]; fz = s_z[far]; }
+    if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[0] += t1 - t0; t0 = t1; }      // (one wave: broadcast read of the sample)
+    const float lm = fps_update<PPT>(px, py, pz, md, fx, fy, fz);
+    if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[1] += t1 - t0; t0 = t1; }      // distance update + lane maximum
+    const float wmax = wave_max_f32(lm);
+    if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[2] += t1 - t0; t0 = t1; }      // wave maximum (DPP)
+    unsigned long long key = 0ull;
+    if (wmax >= 0.f)
+      key = ((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)(~fps_first_index<PPT, NT>(md, wmax, (unsigned)t - (unsigned)lane, lane));
+    if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[3] += t1 - t0; t0 = t1; }      // index of the maximum (ballots)
     if (NW > 1) {
       if (lane == 0) s_key[i & 1][wave] = key;
       __syncthreads();
+      if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[4] += t1 - t0; t0 = t1; }    // LDS slot + workgroup barrier
       key = s_key[i & 1][lane & (NW - 1)];
+      // Lane w (< NW) holds wave w's candidate: its coordinates are requested from the LDS mirror NOW, while the maximum over
+      // the waves is still being formed, and the winner's are picked with three readlanes — the sample's coordinates used
+      // to be read after the maximum was known: one more LDS round trip (~250 cycles of a 2200-cycle sample) on the chain.
+      const unsigned cand = key ? ~(unsigned)(key & 0xFFFFFFFFull) : 0u;
+      const float cx = s_x[cand], cy = s_y[cand], cz = s_z[cand];
+      // (the maximum over the slots by DPP row operations; reading all NW slots into every lane and taking the maximum in
+      //  registers as a tree was measured slower: 570-680 against 405-435 cycles — 64-bit compare / select pairs wait on VCC)
       if (NW >= 4) {
         key = group_max_key<(NW >= 4 ? NW : 4)>(key);
       } else {
@@ -127,8 +242,20 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
           key = o > key ? o : key;
         }
       }
+      far = key ? ~(unsigned)(key & 0xFFFFFFFFull) : 0u;
+      far = (unsigned)__builtin_amdgcn_readfirstlane((int)far);                   // (every lane holds the maximum)
+      const int w = key ? (int)((far % NT) / CPFN_WAVE) : 0;                      // the wave that owns point `far`; no candidate: any slot reads point 0
+      fx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cx), w));
+      fy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cy), w));
+      fz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cz), w));
+    } else {
+      far = key ? ~(unsigned)(key & 0xFFFFFFFFull) : 0u;
     }
-    far = key ? ~(unsigned)(key & 0xFFFFFFFFull) : 0u;
+    if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[5] += t1 - t0; t0 = t1; }      // slot read + maximum over the waves
+  }
+  if (PROFILE && t == 0 && prof) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) prof[(size_t)b * 6 + q] = acc[q];
   }
 }
 
@@ -219,7 +346,7 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
   int *out = idx_out + (size_t)b * S;
   unsigned long long *sl = slots + (size_t)b * 2 * G;
   const int base = wg * NT * PPT;
-  float px[PPT], py[PPT], pz[PPT], md[PPT];
+  f32x2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], md[PPT / 2];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int k = base + t + j * NT;
@@ -229,28 +356,20 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
       m = 1e10f;
       if ((flags & CPFN_FPS_SKIP_NEAR_ORIGIN) && cpfn_sqnorm3(x, y, z) <= 1e-3f) m = -1.0f;
     }
-    px[j] = x; py[j] = y; pz[j] = z; md[j] = m;
+    px[j / 2][j & 1] = x; py[j / 2][j & 1] = y; pz[j / 2][j & 1] = z; md[j / 2][j & 1] = m;
   }
   unsigned far = start ? (unsigned)start[b] : 0u;
   bool dead = false;
   for (int i = 0; i < S; ++i) {
     if (wg == 0 && t == 0) out[i] = (int)far;
     const float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
-    float best = -1.0f;
-    unsigned besti = 0xFFFFFu;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const float dx = __fsub_rn(px[j], fx), dy = __fsub_rn(py[j], fy), dz = __fsub_rn(pz[j], fz);
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-      float m = md[j];
-      m = d < m ? d : m;
-      md[j] = m;
-      if (m > best) { best = m; besti = (unsigned)(base + t + j * NT); }
-    }
+    const float wmax = wave_max_f32(fps_update<PPT>(px, py, pz, md, fx, fy, fz));
     // key without the tag: candidates compare by (distance, lowest index); "no candidate" = 0
-    unsigned long long key = best < 0.f ? 0ull : (((unsigned long long)__float_as_uint(best) << 32) |
-                                                   ((unsigned long long)(0xFFFFFu - besti) << 12));
-    key = wave_max_key(key);
+    unsigned long long key = 0ull;
+    if (wmax >= 0.f) {
+      const unsigned besti = fps_first_index<PPT, NT>(md, wmax, (unsigned)(base + t - lane), lane);
+      key = ((unsigned long long)__float_as_uint(wmax) << 32) | ((unsigned long long)(0xFFFFFu - besti) << 12);
+    }
     if (lane == 0) s_key[i & 1][wave] = key;
     __syncthreads();
     const unsigned tag = (unsigned)(i + 1) & 0xFFFu;
@@ -356,5 +475,21 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
       fps_streaming_kernel<1024><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out, scratch);
     }
   }
+  return cpfn_launch_status();
+}
+
+// Diagnostic: the resident kernel of shape `variant` (0: 256 threads x 8 points per lane [N <= 2048], 1: 512 x 16, 2: 256 x 32
+// [N <= 8192]) with phase stamps; prof[B][6] = shader-clock cycles summed over the S samples of {sample broadcast read,
+// distance update + lane maximum, wave maximum, index ballots, LDS slot + barrier, slot read + maximum over waves} as
+// wave 0 of each workgroup saw them (every stamp drains the wave's memory counters first and costs ~40 cycles itself:
+// profiles/r03_fps_latency.md subtracts that).  Same indices as cpfn_fps.
+extern "C" int cpfn_fps_profile(const float *xyz, int B, int N, int S, const int *start, int variant, int *idx_out,
+                                unsigned long long *prof, void *stream) {
+  if (B <= 0 || N <= 0 || S <= 0 || !xyz || !idx_out || !prof) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (variant == 0 && N <= 2048) fps_resident_kernel<256, 8, true><<<B, 256, 0, st>>>(xyz, N, S, start, 0, idx_out, prof);
+  else if (variant == 1 && N <= 8192) fps_resident_kernel<512, 16, true><<<B, 512, 0, st>>>(xyz, N, S, start, 0, idx_out, prof);
+  else if (variant == 2 && N <= 8192) fps_resident_kernel<256, 32, true><<<B, 256, 0, st>>>(xyz, N, S, start, 0, idx_out, prof);
+  else return CPFN_EINVAL;
   return cpfn_launch_status();
 }

@@ -20,6 +20,7 @@ SIGNATURES = {
     "cpfn_build_info": [],
     "cpfn_fps": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "cpfn_fps_faults": [],
+    "cpfn_fps_profile": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "cpfn_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "cpfn_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_ball_query_direct": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],

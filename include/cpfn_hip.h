@@ -66,6 +66,12 @@ CPFN_API int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, i
 /* Clouds for which the several-workgroups FPS (8192 < N) gave up waiting for a sibling workgroup since the library was
  * loaded; their remaining samples are index 0.  0 in a healthy process.  Synchronises the device; < 0 on error. */
 CPFN_API int cpfn_fps_faults(void);
+/* Diagnostic twin of cpfn_fps for N <= 8192 (one workgroup per cloud; variant 0: 256 threads x 8 points per lane, N <= 2048;
+ * 1: 512 x 16; 2: 256 x 32): same indices, plus prof[B][6] = shader-clock cycles, summed over the S samples, that wave 0
+ * spent in {sample broadcast read, distance update + lane maximum, wave maximum, index ballots, LDS slot + barrier,
+ * slot read + maximum over waves}.  The latency model of profiles/r03_fps_latency.md is built from it. */
+CPFN_API int cpfn_fps_profile(const float *xyz, int B, int N, int S, const int *start, int variant, int *idx_out,
+                              unsigned long long *prof, void *stream);
 
 /* Ball query.  Replaces ball_query() (cuda_ops/src/ball_query.cpp, kernel
  * ball_query_gpu.cu:9-44) with the CPU route's arithmetic
@@ -493,7 +499,7 @@ CPFN_API int cpfn_seg_stats_fwd(const float *W, const int64_t *Igt, int B, int N
 CPFN_API int cpfn_seg_stats_bwd(const float *gS, const int64_t *Igt, int B, int N, int K, float *dW,
                                 void *stream);
 /* Residue + axis losses of every GT instance against its matched prediction, for the instance's GT
- * type only (SPFN/losses_implementation.py:351-387, 480-497; SPFN/*_fitter.compute_residue_single).
+ * type only (SPFN/losses_implementation.py:351-387, 480-497; SPFN/{plane,sphere,cylinder,cone}_fitter.compute_residue_single).
  * params[B,K,22] = plane n(3) c | sphere c(3) r2 | cylinder a(3) c(3) r2 | cone apex(3) axis(3) half;
  * pts[B,K,NP,3]; gt_axes[3,B,K,3] = GT plane normal / cylinder axis / cone axis;
  * type_ids = HOST array of the ids of (plane, sphere, cylinder, cone).

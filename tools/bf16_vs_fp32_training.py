@@ -2,9 +2,10 @@
 
 GlobalSPFN is trained from the same initial weights on the same sequence of structured synthetic batches
 (cpfn_amd.synthetic: points on random planes / spheres / cylinders / cones with noise, GT normals, labels, types and axes)
-  * in the product's bf16 mode (fused MFMA stacks, replayed hipGraph) twice, with two different dropout / FPS seeds
-    — their difference is the run-to-run spread that has nothing to do with precision —
-  * and in its fp32 mode (PyTorch fp32 MLPs, same HIP geometry / fitters / losses, eager),
+  * in the product's bf16 mode (fused MFMA stacks, replayed hipGraph) twice, with two different dropout / FPS seeds,
+  * and in its fp32 mode (PyTorch fp32 MLPs, same HIP geometry / fitters / losses, eager) twice with the same two seeds
+    — the difference inside a pair is the run-to-run spread that has nothing to do with precision (the fp32 mode is not
+    even reproducible for ONE seed: PyTorch's backward uses atomics) —
 and every trained model is evaluated on held-out clouds with the evaluation metrics of the reference
 (`SPFN.metric_implementation.compute_all_metrics`, evaluation_globalSPFN.py:85-104: eval-mode BatchNorm, hard memberships).
 
@@ -77,7 +78,7 @@ def evaluate(model, held, seed=4321):
     return {k: acc[k] / n for k in METRICS}
 
 
-# |bf16 - fp32| of a metric may not exceed max(SPREAD_FACTOR x |bf16 seed A - bf16 seed B|, its floor)
+# |mean(bf16) - mean(fp32)| of a metric may not exceed max(SPREAD_FACTOR x the larger of the two within-mode differences, its floor)
 SPREAD_FACTOR = 3.0
 FLOORS = {"mIoU": 0.03, "type_accuracy": 0.03, "normal_difference": 0.03, "axis_difference": 0.05, "mean_residual": 0.01,
           "Sk_coverage_0.02": 0.05, "P_coverage_0.02": 0.05}
@@ -85,12 +86,13 @@ FLOORS = {"mIoU": 0.03, "type_accuracy": 0.03, "normal_difference": 0.03, "axis_
 
 def compare(res, floor_scale=1.0):
     """-> {metric: (bf16 A, bf16 B, fp32, |mean(A, B) - fp32|, allowed)}, ok"""
-    a, b, f = res["bf16_seedA"]["metrics"], res["bf16_seedB"]["metrics"], res["fp32_seedA"]["metrics"]
+    a, b = res["bf16_seedA"]["metrics"], res["bf16_seedB"]["metrics"]
+    f, g = res["fp32_seedA"]["metrics"], res["fp32_seedB"]["metrics"]
     table, ok = {}, True
     for k in METRICS:
-        allowed = max(SPREAD_FACTOR * abs(a[k] - b[k]), floor_scale * FLOORS[k])
-        d = abs(0.5 * (a[k] + b[k]) - f[k])
-        table[k] = {"bf16_A": a[k], "bf16_B": b[k], "fp32": f[k], "abs_diff_bf16mean_fp32": d, "allowed": allowed}
+        allowed = max(SPREAD_FACTOR * max(abs(a[k] - b[k]), abs(f[k] - g[k])), floor_scale * FLOORS[k])
+        d = abs(0.5 * (a[k] + b[k]) - 0.5 * (f[k] + g[k]))
+        table[k] = {"bf16_A": a[k], "bf16_B": b[k], "fp32_A": f[k], "fp32_B": g[k], "abs_diff_of_means": d, "allowed": allowed}
         ok = ok and d <= allowed
     return table, ok
 
@@ -102,7 +104,7 @@ def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0):
     pool = make_pool(n_train, B, N, 50000, dev)
     held = make_pool(n_held, B, N, 90000, dev)
     res = {"config": {"steps": steps, "batch": B, "points": N, "train_batches": n_train, "held_out_clouds": n_held * B}}
-    for name, mode, seed in (("bf16_seedA", "bf16", 11), ("bf16_seedB", "bf16", 22), ("fp32_seedA", "fp32", 11)):
+    for name, mode, seed in (("bf16_seedA", "bf16", 11), ("bf16_seedB", "bf16", 22), ("fp32_seedA", "fp32", 11), ("fp32_seedB", "fp32", 22)):
         model, info = train(mode, seed, steps, pool, dev, log_every)
         info["metrics"] = evaluate(model, held)
         res[name] = info
