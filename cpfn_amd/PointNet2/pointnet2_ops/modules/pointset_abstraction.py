@@ -95,13 +95,20 @@ class PointsetAbstraction(nn.Module):
             aux["fps_idx"] = geom["fps_idx"]
             groups = []
             S = self.num_points
-            for (nbr, rel), k in zip(geom["scales"], self.num_samples_list):
+            for (nbr, rel), k, convs_of_scale in zip(geom["scales"], self.num_samples_list, self.conv_blocks):
                 aux["ball_idx"] = nbr
                 if feats is not None:
                     D = feats.shape[2]
                     if cd == torch.bfloat16 and feats.is_cuda and feats.dtype == torch.bfloat16 and D % 8 == 0 and N <= 1024:
                         # gather + centred coordinates + zero padding to the GEMM's K, one kernel (feats FIRST, ref :66)
                         inv = geom.get("inv") or (None, None)
+                        from .... import fused_mlp
+                        if fused_mlp.xyz_tail_ok(B * S * k, D, convs_of_scale[0].weight.shape[0]):
+                            # long layers: the coordinates do not become three bf16 columns of a K = 192 operand — they
+                            # reach the first layer as its fp32 xyz tail (cpfn_mlp_gemm_xyz) and the rows are the gather alone
+                            x = autograd_ops.GroupConcat.apply(feats, None, nbr, D, inv[0], inv[1])
+                            groups.append((x, None, S, k, rel.reshape(B * S * k, 3)))
+                            continue
                         x = autograd_ops.GroupConcat.apply(feats, rel, nbr, (D + 3 + 63) // 64 * 64, inv[0], inv[1])
                     else:
                         gf = autograd_ops.gather_rows(feats, nbr)                         # [B,S,K,D]
@@ -110,8 +117,9 @@ class PointsetAbstraction(nn.Module):
                 else:
                     groups.append((None, rel.reshape(B * S * k, 3), S, k))
         outs = []
-        for (x, xyz_rows, S, k), convs, bns in zip(groups, self.conv_blocks, self.bn_blocks):
-            y = mlp.run_stack(x, convs, bns, cd, pool_k=k, xyz_rows=xyz_rows)             # max over the K neighbours (ref :74)
+        for grp, convs, bns in zip(groups, self.conv_blocks, self.bn_blocks):
+            x, xyz_rows, S, k = grp[:4]
+            y = mlp.run_stack(x, convs, bns, cd, pool_k=k, xyz_rows=xyz_rows, xyz_tail=grp[4] if len(grp) > 4 else None)  # max over the K neighbours (ref :74)
             outs.append(y.reshape(B, S, -1))
         return new_xyz, torch.cat(outs, dim=2) if len(outs) > 1 else outs[0], aux
 

@@ -92,7 +92,8 @@ class InterpRowsBf16(torch.autograd.Function):
 
 class GroupConcat(torch.autograd.Function):
     """Grouped set-abstraction input rows in one pass (modules/pointset_abstraction.py:62-66):
-    out[p] = [feats[b, idx[p], :C] | rel[p, :3] | zeros] as bf16 [B*S*K, Cpad]."""
+    out[p] = [feats[b, idx[p], :C] | rel[p, :3] | zeros] as bf16 [B*S*K, Cpad]; rel None (cpad == C): the gather alone —
+    the coordinates then reach the first layer as its fp32 "xyz tail" (fused_mlp)."""
 
     @staticmethod
     def forward(ctx, feats, rel, idx, cpad, inv_off=None, inv_ent=None):
@@ -101,7 +102,7 @@ class GroupConcat(torch.autograd.Function):
         f = feats.contiguous()
         out = torch.empty(B * R, cpad, dtype=torch.bfloat16, device=f.device)
         with torch.cuda.device(f.device):
-            _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
+            _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), None if rel is None else _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
                                                      _stream()), "cpfn_group_concat_bf16")
         _l.add_bytes("cpfn_group_concat_bf16", 2 * B * N * C + 16 * B * R + 2 * B * R * cpad)
         ctx.save_for_backward(idx)

@@ -555,27 +555,36 @@ struct McvArgs {
   const float *src[MCV_MAX];
   void *dst[MCV_MAX];
   int rows[MCV_MAX], cols[MCV_MAX], ld[MCV_MAX], f32[MCV_MAX];
+  int sld[MCV_MAX];            // row stride of the source (== cols: contiguous; > cols: a column slice of a wider matrix)
   int block0[MCV_MAX + 1];
   int count;
 };
 __global__ __launch_bounds__(TPB) void multi_cast_kernel(McvArgs a) {
   int d = 0;
   while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
-  const int cols = a.cols[d], ld = a.ld[d];
+  const int cols = a.cols[d], ld = a.ld[d], sld = a.sld[d];
   const long long n = (long long)a.rows[d] * cols;
   const long long nb = a.block0[d + 1] - a.block0[d];
   const float *__restrict__ s = a.src[d];
   for (long long e = ((long long)(blockIdx.x - a.block0[d]) * TPB + threadIdx.x) * 4; e < n; e += nb * TPB * 4) {
     float v[4];
-    if (e + 4 <= n && (((uintptr_t)(s + e)) & 15) == 0) {
+    const long long r = e / cols;
+    int c = (int)(e - r * cols);
+    if (sld != cols) {                       // column slice: element by element
+      long long rr = r;
+      int cc = c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = e + j < n ? s[rr * sld + cc] : 0.f;
+        if (++cc == cols) { cc = 0; ++rr; }
+      }
+    } else if (e + 4 <= n && (((uintptr_t)(s + e)) & 15) == 0) {
       const float4 q = *(const float4 *)(s + e);
       v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = e + j < n ? s[e + j] : 0.f;
     }
-    const long long r = e / cols;
-    int c = (int)(e - r * cols);
     long long o = r * ld + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -793,7 +802,8 @@ extern "C" int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, co
 
 extern "C" int cpfn_group_concat_bf16(const void *feats, const float *rel, const int *idx, int B, int N, int R, int C,
                                       int Cpad, void *out, void *stream) {
-  if (B < 0 || N <= 0 || R < 0 || C <= 0 || (C & 7) || (Cpad & 7) || Cpad < C + 8 || !feats || !rel || !idx || !out)
+  // rel == NULL: gather only (Cpad == C: the coordinates travel separately, cpfn_mlp_gemm_xyz)
+  if (B < 0 || N <= 0 || R < 0 || C <= 0 || (C & 7) || (Cpad & 7) || (rel ? Cpad < C + 8 : Cpad != C) || !feats || !idx || !out)
     return CPFN_EINVAL;
   if (B == 0 || R == 0) return 0;
   dim3 grid(cpfn_cdiv(R, 32), B);      // 8 rows x 4 passes per workgroup
@@ -895,8 +905,10 @@ extern "C" int cpfn_multi_cast(const cpfn_cast_desc *descs, int count, void *str
     int blocks = 0;
     for (int i = 0; i < a.count; ++i) {
       const cpfn_cast_desc &d = descs[base + i];
-      if (!d.src || !d.dst || d.rows < 0 || d.cols <= 0 || d.dst_ld < d.cols || ((uintptr_t)d.src & 3)) return CPFN_EINVAL;
+      if (!d.src || !d.dst || d.rows < 0 || d.cols <= 0 || d.dst_ld < d.cols || ((uintptr_t)d.src & 3) ||
+          (d.src_ld != 0 && d.src_ld < d.cols)) return CPFN_EINVAL;
       a.src[i] = d.src; a.dst[i] = d.dst; a.rows[i] = d.rows; a.cols[i] = d.cols; a.ld[i] = d.dst_ld; a.f32[i] = d.dst_f32;
+      a.sld[i] = d.src_ld > 0 ? d.src_ld : d.cols;
       a.block0[i] = blocks;
       long long nb = ((long long)d.rows * d.cols + TPB * 4 - 1) / (TPB * 4);
       if (nb < 1) nb = 1;

@@ -193,12 +193,31 @@ struct StreamBufs {
   unsigned a_tile, y_tile, y_step;       // bytes per 128-row tile of A / Y, bytes between a lane's output pieces
 };
 
-template <int BN, int KS, bool STATS, bool ATR, bool BST>
+// XT ("xyz tail", sa2's first layer: 128 gathered feature channels + the 3 centred coordinates of the neighbour): the
+// coordinates do not travel as three bf16 columns of a K = 192 operand (50 MB instead of 33.5 per launch, > 256
+// registers and 90 KB of LDS: one workgroup per CU) but as an fp32 [P,3] tensor; every lane builds ONE more k-step from the
+// two points it owns — x = hi + lo in bf16, columns [x_hi y_hi z_hi x_lo y_lo z_lo x_hi y_hi | z_hi 0 ...] against the
+// weight columns [w_hi w_hi w_lo] — so the three products are accurate to ~2^-16 and the layer is the K = 128 kernel plus
+// NT x 2 MFMAs.  xt_frag: the lane's 8 k-values of that step (k 0-7 in the lanes lq = 0, k 8-15 in lq = 1, zeros above).
+__device__ __forceinline__ bf16x8 xt_frag(float x, float y, float z, int lq) {
+  const unsigned xh = f2bf(x), yh = f2bf(y), zh = f2bf(z);
+  const unsigned xl = f2bf(x - bf2f((unsigned short)xh)), yl = f2bf(y - bf2f((unsigned short)yh)), zl = f2bf(z - bf2f((unsigned short)zh));
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4w;
+  u32x4w v = {0u, 0u, 0u, 0u};
+  if (lq == 0) v = (u32x4w){xh | (yh << 16), zh | (xl << 16), yl | (zl << 16), xh | (yh << 16)};
+  if (lq == 1) v = (u32x4w){zh, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BN, int KS, bool STATS, bool ATR, bool BST, bool XT = false>
 __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, const StreamBufs &sb, int P, int row0, int next_tile,
                                             int wave, int lane, float (&st_s)[8], float (&st_q)[8],
                                             const float *s_ss /*[2][32*KS]: scale, shift*/,
-                                            const float *s_bs /*[2][BN]: scale, shift of the layer below (BST)*/) {
+                                            const float *s_bs /*[2][BN]: scale, shift of the layer below (BST)*/,
+                                            const unsigned short *s_wx /*XT: [BN][16] bf16*/,
+                                            float (&xz)[2][3] /*XT: xyz of the lane's two points, reloaded for the next tile*/,
+                                            const float *xyz) {
   constexpr int NT = BN / 16;
   constexpr int CPR = BN / 8;  // 16-byte chunks per row
   // the 64-wide variants have the registers to request the pieces of Yb before the MFMAs (the two sa1 data gradients,
@@ -215,6 +234,23 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   f32x4 acc[NT][2];
 #pragma unroll
   for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
+  if (XT) {
+    const bf16x8 x0 = xt_frag(xz[0][0], xz[0][1], xz[0][2], lq), x1 = xt_frag(xz[1][0], xz[1][1], xz[1][2], lq);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 wf = *(const bf16x8 *)&s_wx[(nt * 16 + lr) * 16 + 8 * (lq & 1)];
+      if (lq >= 2) wf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, x0, acc[nt][0], 0, 0, 0);
+      acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, x1, acc[nt][1], 0, 0, 0);
+    }
+    // the next tile's coordinates (clamped rows: a tile past the end is never used)
+    const int pn = (next_tile * G_ROWS) + wave * 32 + lr, pa = min(pn, P - 1), pb = min(pn + 16, P - 1);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { xz[0][q] = xyz[(size_t)pa * 3 + q]; xz[1][q] = xyz[(size_t)pb * 3 + q]; }
+    // (the barrier keeps the K loop's weight-fragment reads from being hoisted up here — with them the kernel spills; placed
+    //  behind the K loop instead, the coordinate k-step measured 32.7 us against 29.0 here; the plain K = 128 kernel: 19.3)
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ATR) {   // BatchNorm + ReLU of the previous layer applied to the operand in place, one k-step at a time
@@ -316,12 +352,13 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   }
 }
 
-template <int BN, int KS, bool STATS, bool ATR = false, bool BST = false>
+template <int BN, int KS, bool STATS, bool ATR = false, bool BST = false, bool XT = false>
 __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void mlp_gemm_stream_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
     const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr,
-    const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */, unsigned long long *probe = nullptr) {
+    const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */, unsigned long long *probe = nullptr,
+    const float *__restrict__ xyz = nullptr /* XT: [P,3] */, const float *__restrict__ wx = nullptr /* XT: [N,3] fp32 */) {
   constexpr int NT = BN / 16, K = 32 * KS, CPR = BN / 8;
   const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
@@ -335,6 +372,19 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     for (int e = t; e < K; e += G_THREADS) { s_ss[e] = a_scale[e]; s_ss[K + e] = a_shift[e]; }
   }
   __shared__ __attribute__((aligned(16))) float s_bs[BST ? 2 * BN : 4];
+  __shared__ __attribute__((aligned(16))) unsigned short s_wx[XT ? BN * 16 : 8];
+  float xz[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  if (XT) {   // weight columns of the extra k-step: [w_hi(3) w_hi(3) w_lo(3) 0 ...] per channel (visible after the W-panel barrier)
+    for (int e = t; e < BN; e += G_THREADS) {
+      const float w0 = wx[(size_t)(n0 + e) * 3], w1 = wx[(size_t)(n0 + e) * 3 + 1], w2 = wx[(size_t)(n0 + e) * 3 + 2];
+      const unsigned short h0 = f2bf(w0), h1 = f2bf(w1), h2 = f2bf(w2);
+      const unsigned short l0 = f2bf(w0 - bf2f(h0)), l1 = f2bf(w1 - bf2f(h1)), l2 = f2bf(w2 - bf2f(h2));
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4w;
+      *(u32x4w *)&s_wx[e * 16] = (u32x4w){(unsigned)h0 | ((unsigned)h1 << 16), (unsigned)h2 | ((unsigned)h0 << 16),
+                                          (unsigned)h1 | ((unsigned)h2 << 16), (unsigned)l0 | ((unsigned)l1 << 16)};
+      *(u32x4w *)&s_wx[e * 16 + 8] = (u32x4w){(unsigned)l2, 0u, 0u, 0u};
+    }
+  }
   float st_s[8], st_q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
@@ -359,12 +409,18 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   if (tile0 < tile_end) {
     bf16x8 a[2][KS];
     stream_load_a<KS>(a, sb.a, sb.aoff, (unsigned)tile0 * sb.a_tile);
+    if (XT) {
+      const int p0 = tile0 * G_ROWS + wave * 32 + lr, pa = min(p0, P - 1), pb = min(p0 + 16, P - 1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { xz[0][q] = xyz[(size_t)pa * 3 + q]; xz[1][q] = xyz[(size_t)pb * 3 + q]; }
+    }
     fill_w_panel<BN, 32 * KS + 8>(s_w, W, K, N, n0, 0, K, w_trans, t);
     __syncthreads();
     for (int tile = tile0; tile < tile_end; ++tile) {
       // the reload inside is unconditional (a tile past the end is out of the buffer's range: zeros, no traffic), so
       // the loop body is straight-line
-      stream_tile<BN, KS, STATS, ATR, BST>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1, wave, lane, st_s, st_q, s_ss, s_bs);
+      stream_tile<BN, KS, STATS, ATR, BST, XT>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1, wave, lane, st_s, st_q, s_ss, s_bs,
+                                               s_wx, xz, xyz);
     }
   }
   if (STATS || BST) {
@@ -825,22 +881,52 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
 // coalesced, and still bitwise reproducible.
 constexpr int RSUB = 64;
 constexpr int RTPB = 16 * RSUB;
+// (Round 3: the RSUB subset sums are added as a fixed TREE — two xor-shuffles inside a wave (its 4 subsets x 16 channels),
+//  one LDS slot per wave and channel, four slots per lane of wave 0 and two more shuffles — instead of by one thread per
+//  channel walking 64 LDS entries with 128 dependent fp64 adds (~1 us of a 5-6 us launch that runs 34 times per step on
+//  the step's chain), and the loads of a thread's up to 8 block rows are all issued before the first add.)
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  const unsigned long long u = cpfn_shfl_xor_u64(__builtin_bit_cast(unsigned long long, v), m);
+  return __builtin_bit_cast(double, u);
+}
 __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ partial, int nblk, int N, int c,
                                                    int r, double (*s_acc)[16][2], double &s1, double &s2) {
   double a1 = 0.0, a2 = 0.0;
   if (c < N) {
-#pragma unroll 4
-    for (int i = r; i < nblk; i += RSUB) {
-      a1 += (double)partial[((size_t)i * 2 + 0) * N + c];
-      a2 += (double)partial[((size_t)i * 2 + 1) * N + c];
+    int i = r;
+    for (; i + 7 * RSUB < nblk; i += 8 * RSUB) {       // eight block rows per trip: sixteen loads in flight
+      float v1[8], v2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v1[u] = partial[((size_t)(i + u * RSUB) * 2 + 0) * N + c];
+        v2[u] = partial[((size_t)(i + u * RSUB) * 2 + 1) * N + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a1 += (double)v1[u]; a2 += (double)v2[u]; }
     }
+    float w1[8], w2[8];                                 // the ragged tail, still issued together
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = i + u * RSUB;
+      w1[u] = k < nblk ? partial[((size_t)k * 2 + 0) * N + c] : 0.f;
+      w2[u] = k < nblk ? partial[((size_t)k * 2 + 1) * N + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a1 += (double)w1[u]; a2 += (double)w2[u]; }
   }
-  s_acc[r][threadIdx.x & 15][0] = a1;
-  s_acc[r][threadIdx.x & 15][1] = a2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  a1 += shfl_xor_f64(a1, 16); a2 += shfl_xor_f64(a2, 16);
+  a1 += shfl_xor_f64(a1, 32); a2 += shfl_xor_f64(a2, 32);
+  if (lane < 16) { s_acc[wave][lane][0] = a1; s_acc[wave][lane][1] = a2; }
   __syncthreads();
   s1 = 0.0; s2 = 0.0;
-  if (r == 0) {
-    for (int q = 0; q < RSUB; ++q) { s1 += s_acc[q][threadIdx.x & 15][0]; s2 += s_acc[q][threadIdx.x & 15][1]; }
+  if (wave == 0) {
+    const int cc = lane & 15, g = lane >> 4;
+    double b1 = (s_acc[g][cc][0] + s_acc[g + 4][cc][0]) + (s_acc[g + 8][cc][0] + s_acc[g + 12][cc][0]);
+    double b2 = (s_acc[g][cc][1] + s_acc[g + 4][cc][1]) + (s_acc[g + 8][cc][1] + s_acc[g + 12][cc][1]);
+    b1 += shfl_xor_f64(b1, 16); b2 += shfl_xor_f64(b2, 16);
+    b1 += shfl_xor_f64(b1, 32); b2 += shfl_xor_f64(b2, 32);
+    s1 = b1; s2 = b2;
   }
 }
 
@@ -851,7 +937,7 @@ __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restri
                                    float *__restrict__ scale, float *__restrict__ shift,
                                    float *__restrict__ mean_out, float *__restrict__ rstd_out,
                                    long long *__restrict__ counter_a, long long *__restrict__ counter_b) {
-  __shared__ double s_acc[RSUB][16][2];
+  __shared__ double s_acc[RTPB / 64][16][2];
   // step counters advanced by this launch (the layer's num_batches_tracked; the dropout step counter of a stack whose
   // output dropout reads it in the NEXT launch): was one multi-tensor add per forward pass
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1119,7 +1205,7 @@ __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__re
                                        const float *__restrict__ gamma, const float *__restrict__ mean,
                                        const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
-  __shared__ double s_acc[RSUB][16][2];
+  __shared__ double s_acc[RTPB / 64][16][2];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
   double s1, s2;
   partial_sums_16x16(partial, nblk, C, c, r, s_acc, s1, s2);
@@ -1360,7 +1446,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
 // ahead.  APPLY: Gy is the gradient with respect to the layer's ACTIVATED output and the BatchNorm-backward apply pass
 // (g_y = c0 . [scale . y + shift > 0] . g + c1 . y + c2, rounded to bf16 exactly as cpfn_bn_bwd_apply stores it) runs on
 // the staged chunks from the layer's own pre-BN output Yr: g_y is never written to or read from memory.
-// Shapes <TN, TK, STEP>: <128,128,32>, <256,128,32>, <128,192,32>, <64,64,64>, <128,64,64> (layer N -> channels of g_y, K -> channels of its input;
+// Shapes <TN, TK, STEP>: <128,128,32>, <256,128,32>, <64,64,64>, <128,64,64> (layer N -> channels of g_y, K -> channels of its input;
 // STEP rows per step, 128 rows in flight).  Grid (1, 1, splits), the split layout of mlp_wgrad_kernel: same partials,
 // bit for bit.
 // EIGHT waves: for <128,128> a wave's share of the dW tile is 32 x 64 (32 accumulator registers) and a thread stages one
@@ -1377,12 +1463,18 @@ struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the
   const unsigned short *pool_yarg;           // ... the pre-BN value there; Gy is then the POOLED gradient [P / pool_k, TN]
   int pool_k;
   long long groups;
+  const float *xt_xyz;                       // XT: [P,3] fp32 coordinates that are three more input channels of the layer
+  float *xt_partial;                         //     [splits][TN][3]: split partials of their weight-gradient columns
 };
 
 // (Round 2 also had an instantiation that RECOMPUTED sa1's first-layer output from the coordinates inside the 64 -> 64
 //  shape instead of reading it: 134 MB fewer reads bought 2 us of 65 — the shape is bound by VALU + LDS issue — and it was
 //  removed in round 3; the recompute lives on in cpfn_smallk_wgrad_apply_xyz, where it pays.)
-template <int TN, int TK, int STEP, bool BST, int APPLY>
+// XT (sa2's first layer, see stream_tile): the layer has three more input channels, the fp32 coordinates xyz [P,3].  They need
+// no data gradient (coordinates are inputs) and their weight-gradient columns dWx [TN,3] = g_y^T . xyz ride along: the
+// 32 x 3 coordinate tile of a step is staged as bf16 beside the input tile and costs the four waves that own wk = 0 MI MFMAs
+// more per step.
+template <int TN, int TK, int STEP, bool BST, int APPLY, bool XT = false>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
     const unsigned short *__restrict__ W /* forward weight panel [TN][TK] bf16 */, long long P, long long rows_per_split,
@@ -1417,13 +1509,25 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   __shared__ __attribute__((aligned(16))) unsigned short s_a2[DB ? 2 : 1][STEP * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short s_o2[DB ? 2 : 1][STEP * LDK];
   __shared__ __attribute__((aligned(16))) unsigned short s_wt[TK * LDN];
+  constexpr int LDX = 16 + 8;
+  __shared__ __attribute__((aligned(16))) unsigned short s_x2[XT ? (DB ? 2 : 1) * STEP * LDX : 8];
+  static_assert(!XT || (STEP * 3 <= NT && MI >= 1), "xyz tail: one float per thread and step");
+  f32x4 accx[XT ? MI : 1];
+#pragma unroll
+  for (int i = 0; i < (XT ? MI : 1); ++i) accx[i] = (f32x4){0, 0, 0, 0};
+  float vxt[XT ? DEPTH : 1];
   static_assert(!BST || sizeof(float) * 8 * 2 * TK <= sizeof(unsigned short) * STEP * LDN, "the statistics reduction reuses s_g");
   float(*s_red)[2][TK] = (float(*)[2][TK])s_g2[0];  // cross-wave reduction of the statistics: after the last step only
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lq = lane >> 4;
   const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
   float *o = partial + (size_t)blockIdx.z * TN * TK;
+  if (XT) {      // columns 3..15 of the coordinate tile stay zero
+    for (int e = t; e < (DB ? 2 : 1) * STEP * LDX; e += NT) s_x2[e] = 0;
+    __syncthreads();
+  }
   if (p0 >= p1) {   // empty split: its partial slab (and its statistics row) must still be zero
     for (int e = t; e < TN * TK; e += NT) o[e] = 0.f;
+    if (XT) for (int e = t; e < TN * 3; e += NT) ap.xt_partial[(size_t)blockIdx.z * TN * 3 + e] = 0.f;
     if (BST) for (int e = t; e < 2 * TK; e += NT) stats_partial[(size_t)blockIdx.z * 2 * TK + e] = 0.f;
     probe_end(probe, probe_t0, 5);
     return;
@@ -1488,6 +1592,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
         const long long p = min(base + arow + i * RPA, p1 - 1);
         va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
       }
+    }
+    if (XT && t < STEP * 3) {              // float t of the step's contiguous 32 x 3 block (rows past the split's end: clamped, zeroed at stage time)
+      const long long p = min(base + t / 3, p1 - 1);
+      vxt[XT ? sidx : 0] = ap.xt_xyz[p * 3 + t % 3];
     }
   };
   auto stage = [&](int sidx, long long base, int buf) {
@@ -1572,6 +1680,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
         *(uint4 *)&s_a[r * LDK + acol] = a4;
       }
     }
+    if (XT && t < STEP * 3) {
+      const int r = t / 3;
+      s_x2[(DB ? buf : 0) * STEP * LDX + r * LDX + t % 3] = base + r >= p1 ? (unsigned short)0 : f2bf(vxt[XT ? sidx : 0]);
+    }
   };
   // the STEP x TK data-gradient slab of the PREVIOUS step leaves here (its LDS patch was completed before this step's
   // first barrier): NA 16-byte pieces per thread
@@ -1649,6 +1761,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
           for (int j = 0; j < MJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fa[j], acc[i][j], 0, 0, 0);
+        if (XT && wk == 0) {         // (wave-uniform) the coordinate columns of the weight gradient
+          const bf16x8 fx = tr_frag<LDX>(s_x2 + (DB ? buf : 0) * STEP * LDX + kk * 32 * LDX, 0, lane);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) accx[XT ? i : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[i], fx, accx[XT ? i : 0], 0, 0, 0);
+        }
       }
       if constexpr (CHB == 8 || CHB == 4) {
         // ---- data gradient of the same rows: this wave's output channels 16 cb .. +15 of rows 16 rb0 .. +31 (two tiles
@@ -1705,6 +1822,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         o[(size_t)(wn + i * 16 + 4 * (lane >> 4) + r) * TK + wk + j * 16 + (lane & 15)] = acc[i][j][r];
+  if (XT && wk == 0 && (lane & 15) < 3) {
+    float *ox = ap.xt_partial + (size_t)blockIdx.z * TN * 3;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ox[(size_t)(wn + i * 16 + 4 * (lane >> 4) + r) * 3 + (lane & 15)] = accx[XT ? i : 0][r];
+  }
   if (BST) {   // threads that share a column chunk (t % CPRA): shuffles inside the wave, then the eight waves through LDS
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1757,6 +1881,7 @@ struct MsrArgs {
   long long n[MSR_MAX];
   int splits[MSR_MAX];
   int row_in[MSR_MAX], row_out[MSR_MAX];   // 0, 0: flat; else only the first row_out of every row_in elements are kept
+  int out_ld[MSR_MAX];                     // ... at row stride out_ld of the output (>= row_out; a slice of a wider matrix)
   int deep[MSR_MAX];           // 1: few outputs, many splits: 16 elements x 16 split-subsets per workgroup instead of 64 x 4; 2: wide
   int block0[MSR_MAX + 1];     // first workgroup of buffer i
   int count;
@@ -1809,7 +1934,7 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
         for (int j = 0; j < 4; ++j) {
           const long long row = (e + j) / ri;
           const int col = (int)((e + j) - row * ri);
-          if (col < a.row_out[d]) a.out[d][row * a.row_out[d] + col] = v[j];
+          if (col < a.row_out[d]) a.out[d][row * a.out_ld[d] + col] = v[j];
         }
       }
     }
@@ -1841,7 +1966,7 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
     } else {           // zero-padded K: drop the padding columns (the caller gets a compact [N, row_out] matrix)
       const long long row = e / ri;
       const int col = (int)(e - row * ri);
-      if (col < a.row_out[d]) a.out[d][row * a.row_out[d] + col] = v;
+      if (col < a.row_out[d]) a.out[d][row * a.out_ld[d] + col] = v;
     }
   }
 }
@@ -2182,6 +2307,28 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
   return cpfn_launch_status();
 }
 
+// Forward layer whose input is [A (K = 128 bf16 channels) | xyz (3 fp32 coordinates)] (sa2's first layer): Y = A . W^T +
+// xyz . Wx^T with the coordinate term as one more k-step built in registers (stream_tile, XT).  Statistics rows as cpfn_mlp_gemm.
+extern "C" int cpfn_mlp_gemm_xyz_ok(long long P, int K, int N) {
+  return K == 128 && N == 128 && P >= 32768 && gemm_stream_k(P, K) && (P + G_ROWS) * 128LL * 2 < (1LL << 32);
+}
+extern "C" int cpfn_mlp_gemm_xyz(const void *A, int lda, const void *W, const float *xyz, const float *Wx, long long P, int K,
+                                 int N, void *Y, int ldy, float *stats_partial, void *stream) {
+  if (!cpfn_mlp_gemm_xyz_ok(P, K, N) || !A || !W || !xyz || !Wx || !Y || lda != K || ldy != N) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = cpfn_mlp_gemm_blocks(P, N);
+  const long long tiles = (P + G_ROWS - 1) / G_ROWS;
+  const int tpw = (int)((tiles + gx - 1) / gx);
+  const dim3 grid(gx, N / 128);
+  const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
+  unsigned short *y = (unsigned short *)Y;
+  if (stats_partial)
+    mlp_gemm_stream_kernel<128, 4, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, stats_partial, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx);
+  else
+    mlp_gemm_stream_kernel<128, 4, false, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, nullptr, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx);
+  return cpfn_launch_status();
+}
+
 extern "C" int cpfn_bn_finalize(const float *partial, int nblk, int N, float count, const float *gamma,
                                 const float *beta, const float *conv_bias, float eps, float momentum,
                                 float *running_mean, float *running_var, float *scale, float *shift,
@@ -2355,8 +2502,7 @@ extern "C" int cpfn_mlp_wgrad_apply_ok(long long P, int N, int K) {
 }
 
 extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
-  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128) ||
-                     (N == 128 && K == 192);
+  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128);
   return shape && P > SP_MAX_ROWS && P >= 32768;
 }
 
@@ -2365,7 +2511,8 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
                                   const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
                                   const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
                                   const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
-                                  const void *pool_yarg, int pool_k, void *stream) {
+                                  const void *pool_yarg, int pool_k, const float *xt_xyz,
+                                  float *xt_partial, void *stream) {
   if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gy || !A || !W || !workspace || !Gout || (ldg & 7) || (lda & 7) || (ldo & 7) ||
       ldg < N || lda < K || ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)) ||
       (apply_y && (!apply_coef || !y_scale || !y_shift)))
@@ -2373,7 +2520,10 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   if (apply_y && ldg != N) return CPFN_EINVAL;     // (the kernel walks apply_y with the gradient's row stride)
   if ((drop_seed && (!apply_y || pool_k > 0 || !(drop_p >= 0.f && drop_p < 1.f))) || pool_k < 0) return CPFN_EINVAL;
   const int step = K >= 128 ? 32 : 64;
-  if (K == 192 && (bwd_y || drop_seed || pool_k > 0)) return CPFN_EINVAL;   // (24 chunks per row: plain / dense apply only)
+  // xyz tail (three fp32 coordinate channels beside the K bf16 ones; sa2's first layer): the 128 -> 128 shape with the dense
+  // apply pass and no layer below
+  if ((!xt_xyz) != (!xt_partial)) return CPFN_EINVAL;
+  if (xt_xyz && !(N == 128 && K == 128 && apply_y && !bwd_y && !drop_seed && pool_k == 0)) return CPFN_EINVAL;
   if (pool_k > 0 && (!apply_y || !pool_arg || !pool_yarg || pool_k > 255 || pool_k % step || P % pool_k || ldg != N))
     return CPFN_EINVAL;
   const int splits = cpfn_mlp_wgrad_splits(P, N, K);
@@ -2389,6 +2539,7 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   ap.drop_seed = drop_seed; ap.thresh16 = dropout_thresh16(drop_seed ? drop_p : 0.f); ap.inv_keep = drop_seed ? 1.f / (1.f - drop_p) : 1.f;
   ap.pool_arg = pool_arg; ap.pool_yarg = (const unsigned short *)pool_yarg; ap.pool_k = pool_k > 0 ? pool_k : 1;
   ap.groups = pool_k > 0 ? P / pool_k : 1;
+  ap.xt_xyz = xt_xyz; ap.xt_partial = xt_partial;
   const int mode = !apply_y ? 0 : (pool_k > 0 ? 2 : (drop_seed ? 3 : 1));
 #define CPFN_BWD_FUSED(TN_, TK_, STEP_, BST_, APPLY_)                                                                      \
   mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
@@ -2408,12 +2559,12 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
       else CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 0);                          \
     }                                                                          \
   } while (0)
-  if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
+  if (xt_xyz)
+    mlp_bwd_fused_kernel<128, 128, 32, false, 1, true><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, a_scale,
+                                                                             a_shift, yb, b_scale, b_shift, stats_partial, ap,
+                                                                             probe_slot_all(grid));
+  else if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
   else if (N == 256) CPFN_BWD_FUSED_SHAPE(256, 128, 32);
-  else if (K == 192) {          // sa2's first layer (131 -> padded 192 input channels): never has a layer below
-    if (mode == 1) CPFN_BWD_FUSED(128, 192, 32, false, 1);
-    else CPFN_BWD_FUSED(128, 192, 32, false, 0);
-  }
   else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
   else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
 #undef CPFN_BWD_FUSED_SHAPE
@@ -2503,10 +2654,11 @@ extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count,
     int blocks = 0;
     for (int i = 0; i < a.count; ++i) {
       const cpfn_reduce_desc &d = descs[base + i];
-      if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0 || d.row_in < 0 || d.row_out < 0 || d.row_out > d.row_in ||
+      if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0 || d.row_in < 0 || d.row_out < 0 || d.row_out > d.row_in || (d.out_ld != 0 && (d.row_in == 0 || d.out_ld < d.row_out)) ||
           (d.row_in > 0 && (d.row_out == 0 || d.n % d.row_in))) return CPFN_EINVAL;
       a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
       a.row_in[i] = d.row_in; a.row_out[i] = d.row_out;
+      a.out_ld[i] = d.out_ld > 0 ? d.out_ld : d.row_out;
       a.deep[i] = d.n <= 1024 && d.splits >= 128;
       if (!a.deep[i] && d.n >= 4096 && d.n % 4 == 0 && (((uintptr_t)d.partial | (d.row_in == 0 ? (uintptr_t)d.out : 0)) & 15) == 0)
         a.deep[i] = 2;          // wide: float4 per lane (same order of additions as the 64 x 4 layout)

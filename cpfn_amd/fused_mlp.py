@@ -45,6 +45,10 @@ FUSED_BWD = True
 FUSED_BWD_APPLY = True
 SMALL_BWD_FUSED = True
 XYZ_RECOMPUTE = True
+#   XYZ_TAIL          sa2's first layer at >= 32768 rows: the centred coordinates reach it as an fp32 [P,3] "tail" beside the
+#                     128 gathered bf16 channels (cpfn_mlp_gemm_xyz; its weight-gradient columns ride on the one-pass kernel)
+#                     instead of as three bf16 columns of a zero-padded K = 192 operand
+XYZ_TAIL = True
 
 
 def _pad_to(n, m):
@@ -85,6 +89,12 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
     _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + Y.element_size() * P * n_store + (8 * nblk * N if stats else 0)
                  + (2 * P * N if yb is not None else 0))
     return Y, part, nblk
+
+
+def xyz_tail_ok(P, D, N):
+    """May a stack's first layer take [D bf16 channels | 3 fp32 coordinates] as the split operand of cpfn_mlp_gemm_xyz?"""
+    return (XYZ_TAIL and FUSED_BWD and FUSED_BWD_APPLY and bool(_l.lib().cpfn_mlp_gemm_xyz_ok(P, D, N))
+            and bool(_l.lib().cpfn_mlp_bwd_fused_ok(P, N, D)))
 
 
 def can_fuse_bwd_stats(P, K, N):
@@ -144,7 +154,7 @@ def bn_relu_maxpool(Y, scale, shift, Kn):
 # engine reaches the end of the backward pass (queue_callback), before anybody can read the gradients.
 class _ReduceDesc(ctypes.Structure):
     _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p), ("n", ctypes.c_longlong), ("splits", ctypes.c_int),
-                ("row_in", ctypes.c_int), ("row_out", ctypes.c_int)]
+                ("row_in", ctypes.c_int), ("row_out", ctypes.c_int), ("out_ld", ctypes.c_int)]
 
 
 _pending_reduce = []
@@ -155,17 +165,18 @@ def _flush_reductions():
     todo, _pending_reduce = _pending_reduce, []
     if not todo:
         return
-    arr = (_ReduceDesc * len(todo))(*[_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits, ri, ro)
-                                      for ws, out, n, splits, ri, ro in todo])
+    arr = (_ReduceDesc * len(todo))(*[_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits, ri, ro, old)
+                                      for ws, out, n, splits, ri, ro, old in todo])
     dev = todo[0][0].device
     with torch.cuda.device(dev):
         _check(_l.lib().cpfn_multi_split_reduce(arr, len(todo), _stream()), "cpfn_multi_split_reduce")
-    _l.add_bytes("cpfn_multi_split_reduce", sum(4 * n * (splits + 1) for _, _, n, splits, _, _ in todo))
+    _l.add_bytes("cpfn_multi_split_reduce", sum(4 * n * (splits + 1) for _, _, n, splits, _, _, _ in todo))
 
 
-def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0, params=()):
+def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0, params=(), out_ld=0):
     """Queue `out[n] = sum over splits of ws[splits][n]`; runs at the end of the current backward pass.
-    row_in / row_out: the partial rows have row_in elements of which `out` (compact) keeps the first row_out.
+    row_in / row_out: the partial rows have row_in elements of which `out` (compact) keeps the first row_out;
+    out_ld: `out` is a column slice of a wider matrix (row stride out_ld).
     params: the parameters `out` is the gradient of.  Deferring is only sound when autograd's AccumulateGrad STEALS the
     returned tensor (p.grad is None and nobody hooks it): it then just keeps the reference and the deferred launch fills
     it before anybody reads.  With gradient accumulation (p.grad already set), tensor hooks or
@@ -173,14 +184,14 @@ def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0, params=()):
     immediately (one launch per tensor, as before round 2)."""
     if any(p is not None and (p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None))
            for p in params):
-        arr = (_ReduceDesc * 1)(_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits, row_in, row_out))
+        arr = (_ReduceDesc * 1)(_ReduceDesc(ws.data_ptr(), out.data_ptr(), n, splits, row_in, row_out, out_ld))
         with torch.cuda.device(ws.device):
             _check(_l.lib().cpfn_multi_split_reduce(arr, 1, _stream()), "cpfn_multi_split_reduce")
         _l.add_bytes("cpfn_multi_split_reduce", 4 * n * (splits + 1))
         return
     if not _pending_reduce:
         torch.autograd.Variable._execution_engine.queue_callback(_flush_reductions)
-    _pending_reduce.append((ws, out, n, splits, row_in, row_out))
+    _pending_reduce.append((ws, out, n, splits, row_in, row_out, out_ld))
 
 
 # ------------------------------------------------------------------ bf16 weight panels
@@ -206,6 +217,23 @@ def bf16_weight(W, rows, cols):
 
 
 _refresh_epoch = [0]
+_xt_cache = {}
+
+
+def xt_panels(W, D):
+    """(bf16 panel [N, D] of W[:, :D], fp32 [N, 3] of W[:, D:D+3]) of a first-layer weight W [N, D+3, ...] whose last three
+    input channels are an fp32 xyz tail; kept across steps and refreshed by refresh_weight_panels() like every other panel."""
+    ent = _xt_cache.get(id(W))
+    if ent is None or ent["ref"]() is not W or ent["Wb"].device != W.device or ent["Wb"].shape[1] != D:
+        N = W.shape[0]
+        ent = {"Wb": torch.empty(N, D, dtype=BF16, device=W.device), "Wx": torch.empty(N, 3, dtype=torch.float32, device=W.device),
+               "ref": weakref.ref(W), "epoch": -1}
+        _xt_cache[id(W)] = ent
+    if ent["epoch"] != _refresh_epoch[0]:          # not covered by this forward pass's refresh_weight_panels()
+        w2 = W.detach().reshape(W.shape[0], -1)
+        ent["Wb"].copy_(w2[:, :D])
+        ent["Wx"].copy_(w2[:, D:D + 3])
+    return ent["Wb"], ent["Wx"]
 
 
 def _foreach_copy_by_dtype(dst, src):
@@ -223,7 +251,7 @@ def _foreach_copy_by_dtype(dst, src):
 
 class _CastDesc(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int),
-                ("dst_ld", ctypes.c_int), ("dst_f32", ctypes.c_int)]
+                ("dst_ld", ctypes.c_int), ("dst_f32", ctypes.c_int), ("src_ld", ctypes.c_int)]
 
 
 _cast_cache = {}
@@ -245,7 +273,19 @@ def refresh_weight_panels(params):
         w2 = W.detach().reshape(W.shape[0], -1)
         if not w2.is_contiguous() or w2.shape[0] > rows or w2.shape[1] > cols:
             continue
-        jobs.append((w2, ent[0], w2.shape[0], w2.shape[1], cols, 0))
+        jobs.append((w2.data_ptr(), ent[0].data_ptr(), w2.shape[0], w2.shape[1], cols, 0, 0))
+        ents.append(ent)
+        dev = W.device
+    for pid, ent in _xt_cache.items():           # split panels of a layer with an xyz tail: [:, :D] -> bf16, [:, D:D+3] -> fp32
+        W = want.get(pid)
+        if W is None or ent["ref"]() is not W or ent["Wb"].device != W.device or not W.is_cuda or W.dtype != torch.float32:
+            continue
+        w2 = W.detach().reshape(W.shape[0], -1)
+        D = ent["Wb"].shape[1]
+        if not w2.is_contiguous() or w2.shape[1] != D + 3:
+            continue
+        jobs.append((w2.data_ptr(), ent["Wb"].data_ptr(), w2.shape[0], D, D, 0, D + 3))
+        jobs.append((w2.data_ptr() + 4 * D, ent["Wx"].data_ptr(), w2.shape[0], 3, 3, 1, D + 3))
         ents.append(ent)
         dev = W.device
     for ent in _packed.values():                 # the packed panels of the heads ride along
@@ -256,25 +296,28 @@ def refresh_weight_panels(params):
         for t, d in zip(ts, ent["dst"]):
             t2 = t.detach().reshape(t.shape[0], -1)
             if t.dim() > 1:
-                jobs.append((t2, d, t2.shape[0], t2.shape[1], ent["Wb"].shape[1], 0))
+                jobs.append((t2.data_ptr(), d.data_ptr(), t2.shape[0], t2.shape[1], ent["Wb"].shape[1], 0, 0))
             else:
-                jobs.append((t2, d, 1, t2.shape[0], t2.shape[0], 1))
+                jobs.append((t2.data_ptr(), d.data_ptr(), 1, t2.shape[0], t2.shape[0], 1, 0))
         packed.append(ent)
         dev = ts[0].device
     if not jobs:
         return
-    key = tuple((s_.data_ptr(), d.data_ptr(), r, c, ld, f) for s_, d, r, c, ld, f in jobs)
+    key = tuple(jobs)
     arr = _cast_cache.get(key)
     if arr is None:
         if len(_cast_cache) > 64:
             _cast_cache.clear()
-        arr = (_CastDesc * len(jobs))(*[_CastDesc(s_.data_ptr(), d.data_ptr(), r, c, ld, f) for s_, d, r, c, ld, f in jobs])
+        arr = (_CastDesc * len(jobs))(*[_CastDesc(*j) for j in jobs])
         _cast_cache[key] = arr
     with torch.cuda.device(dev):
         _check(_l.lib().cpfn_multi_cast(arr, len(jobs), _stream()), "cpfn_multi_cast")
-    _l.add_bytes("cpfn_multi_cast", sum(6 * r * c for _, _, r, c, _, _ in jobs))
+    _l.add_bytes("cpfn_multi_cast", sum(6 * r * c for _, _, r, c, _, _, _ in jobs))
     for ent in ents:
-        ent[2] = _refresh_epoch[0]
+        if isinstance(ent, dict):
+            ent["epoch"] = _refresh_epoch[0]
+        else:
+            ent[2] = _refresh_epoch[0]
     for ent in packed:
         ent["epoch"] = _refresh_epoch[0]
 
@@ -331,6 +374,7 @@ class _FusedStack(torch.autograd.Function):
         layers = cfg["layers"]
         pool_k = cfg.get("pool_k")
         first_fp32 = cfg.get("first_fp32", False)
+        xyz_tail = cfg.get("xyz_tail")
         P = x.shape[0]
         dev = x.device
         saved = []
@@ -352,6 +396,15 @@ class _FusedStack(torch.autograd.Function):
                            "cpfn_smallk_fwd")
                     _l.add_bytes("cpfn_smallk_fwd", 4 * P * KS + 2 * P * N + 8 * nblk * N)
                     Wb = w32                      # (the backward pass recomputes this layer's output from x and w32)
+                elif li == 0 and xyz_tail is not None:
+                    Kp = a.shape[1]
+                    Wb, Wx = xt_panels(L.weight, Kp)
+                    nblk = h.cpfn_mlp_gemm_blocks(P, N)
+                    Y = torch.empty(P, N, dtype=BF16, device=dev)
+                    part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                    _check(h.cpfn_mlp_gemm_xyz(_ptr(a), Kp, _ptr(Wb), _ptr(xyz_tail), _ptr(Wx), P, Kp, N, _ptr(Y), N, _ptr(part), _stream()),
+                           "cpfn_mlp_gemm_xyz")
+                    _l.add_bytes("cpfn_mlp_gemm", 2 * P * Kp + 12 * P + 2 * N * Kp + 12 * N + 2 * P * N + 8 * nblk * N)
                 else:
                     Kp = a.shape[1]
                     Wb = bf16_weight(L.weight, N, Kp)
@@ -405,6 +458,7 @@ class _FusedStack(torch.autograd.Function):
         layers = cfg["layers"]
         pool_k = cfg.get("pool_k")
         first_fp32 = cfg.get("first_fp32", False)
+        xyz_tail = cfg.get("xyz_tail")
         P = ctx.P
         saved = ctx.saved
         dev = g.device
@@ -424,8 +478,11 @@ class _FusedStack(torch.autograd.Function):
                 dp = float(cfg["dropout"][0]) if dseed is not None else 0.0
                 need_dgrad = (li > 0 or ctx.x_needs_grad) and not xyz_layer
                 below_ok = li > 0 and BWD_STATS_FUSED and saved[li - 1][5] is None   # may take pass 1 of layer li-1
-                route, fold_apply, fold_pool = _plan(h, P, N, a_in, pool_k if arg is not None else 0, xyz_layer, need_dgrad,
-                                                     dseed is not None)
+                xt = xyz_tail if li == 0 else None           # the layer's fp32 coordinate channels (sa2's first layer)
+                route, fold_apply, fold_pool = _plan(h, P, N, a_in, pool_k if arg is not None else 0, xyz_layer,
+                                                     need_dgrad or xt is not None, dseed is not None)
+                if xt is not None and not (route == "one_pass" and fold_apply):
+                    raise RuntimeError("a layer with an xyz tail takes the one-pass backward kernel (fused_mlp.xyz_tail_ok)")
                 dgb = torch.empty(2, N, dtype=torch.float32, device=dev)
                 coef = torch.empty(3, N, dtype=torch.float32, device=dev)
                 Gy = None
@@ -507,17 +564,19 @@ class _FusedStack(torch.autograd.Function):
                     Yp, stp = (saved[li - 1][2], saved[li - 1][3]) if below else (None, (None, None))
                     fp_ = torch.empty(splits, 2, Kp, dtype=torch.float32, device=dev) if below else None
                     dsd = dseed if fold_apply else None
+                    ws_x = torch.empty(splits * N * 3, dtype=torch.float32, device=dev) if xt is not None else None
                     _check(h.cpfn_mlp_bwd_fused(_ptr(g if folded else Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp, asc, ash,
                                                 _ptr(ws), _ptr(g_new), Kp, _ptr(Yp), _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_),
                                                 _ptr(Y) if folded else None, _ptr(coef) if folded else None,
                                                 _ptr(st[0]) if folded else None, _ptr(st[1]) if folded else None, _ptr(dsd),
                                                 dp if dsd is not None else 0.0, _ptr(arg) if fold_pool else None,
-                                                _ptr(yarg) if fold_pool else None, pool_k if fold_pool else 0, _stream()),
+                                                _ptr(yarg) if fold_pool else None, pool_k if fold_pool else 0,
+                                                _ptr(xt), _ptr(ws_x), _stream()),
                            "cpfn_mlp_bwd_fused")
                     # g_y (or, folded in: g / the pooled g + y), the input, W, the split partials, the data gradient
                     gy_bytes = (2 * P * N + 5 * P * N // pool_k) if fold_pool else (4 * P * N if fold_apply else 2 * P * N)
                     _l.add_bytes("cpfn_mlp_bwd_fused", gy_bytes + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
-                                 + ((2 * P * Kp + 8 * splits * Kp) if below else 0))
+                                 + ((2 * P * Kp + 8 * splits * Kp) if below else 0) + ((12 * P + 12 * splits * N) if xt is not None else 0))
                     if below:
                         fused_part = (fp_, splits)
                 else:
@@ -527,7 +586,11 @@ class _FusedStack(torch.autograd.Function):
                 # the split partials are finished by ONE launch at the end of the backward pass; a zero-padded K
                 # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
                 dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
-                if Kp == L.cin:
+                if xt is not None:
+                    # one [N, Kp + 3] weight gradient from two partial buffers: the bf16 channels' columns and the coordinates'
+                    _defer_reduction(ws, dW, N * Kp, splits, Kp, Kp, params=(L.weight,), out_ld=L.cin)
+                    _defer_reduction(ws_x, dW[:, Kp:], N * 3, splits, 3, 3, params=(L.weight,), out_ld=L.cin)
+                elif Kp == L.cin:
                     _defer_reduction(ws, dW, N * Kp, splits, params=(L.weight,))
                 else:
                     _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin, params=(L.weight,))
@@ -580,9 +643,10 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
     return "generic", False, False
 
 
-def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None):
+def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None):
     """x: bf16 rows [P, Kpad] (Kpad a multiple of 64, zero-padded beyond the first conv's
-    in_channels) — or fp32 [P, KS<=4] with first_fp32=True.  Returns bf16 [P, C_last], or
+    in_channels) — or fp32 [P, KS<=4] with first_fp32=True; xyz_tail [P,3] fp32: three more input channels of the first
+    layer (behind x's D = Kpad channels) that stay fp32.  Returns bf16 [P, C_last], or
     [P/pool_k, C_last] when pool_k is given (max over each run of pool_k consecutive rows).
     dropout = (p, counter, base_seed): dropout on the stack's output, fused into the last BN apply (no pooling)."""
     layers = _layers_from_modules(convs, bns)
@@ -590,7 +654,11 @@ def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None):
         raise ValueError("dropout cannot be fused into a pooled stack")
     if dropout is not None and not dropout[0] > 0.0:
         dropout = None
-    cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout}
+    if xyz_tail is not None and not (x.dtype == BF16 and layers[0].cin == x.shape[1] + 3 and len(layers) > 1 and
+                                     xyz_tail_ok(x.shape[0], x.shape[1], layers[0].cout)):
+        raise ValueError("xyz_tail: [P, D] bf16 rows + [P, 3] fp32 coordinates into a (D + 3)-channel first layer of a shape "
+                         "fused_mlp.xyz_tail_ok accepts")
+    cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout, "xyz_tail": xyz_tail}
     params = []
     for L in layers:
         params += [L.weight, L.gamma, L.beta]

@@ -76,6 +76,8 @@ SIGNATURES = {
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
+    "cpfn_mlp_gemm_xyz_ok": [_ll, _i, _i],
+    "cpfn_mlp_gemm_xyz": [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp],
     "cpfn_flag_wait": [_vp, ctypes.c_uint, ctypes.c_uint64, _vp, _vp, _vp], "cpfn_flag_set": [_vp, ctypes.c_uint, _vp],
     "cpfn_flag_set_payload": [_vp, ctypes.c_uint, _vp, _vp, _i, _vp],
     "cpfn_mlp_gemm_set_probe": [_vp, _i, _i],
@@ -98,7 +100,7 @@ SIGNATURES = {
     "cpfn_mlp_dgrad_small_ok": [_ll, _i, _i],
     "cpfn_mlp_dgrad_small": [_vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                           _vp, _f, _vp, _vp, _i, _vp],
+                           _vp, _f, _vp, _vp, _i, _vp, _vp, _vp],
     "cpfn_colsum_f32": [_vp, _ll, _i, _vp, _vp, _vp, _vp],
     "cpfn_smallk_fwd": [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad": [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp],

@@ -38,10 +38,13 @@ def shared_mlp(x, convs, bns, dtype=torch.float32):
     return x
 
 
-def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None):
+def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None):
     """Run a whole (conv, bn, relu)* stack on rows and optionally max-pool every `pool_k`
     consecutive rows.  `x` [P, C_in] (any float dtype) — or None with `xyz_rows` [P, 3] fp32
     when the stack's only input is relative coordinates (sa1).
+
+    xyz_tail [P,3] fp32 (bf16 HIP path only): three more input channels of the first layer, BEHIND x's (sa2: gathered
+    features first, then the centred coordinates) — kept in fp32 beside the bf16 rows instead of concatenated.
 
     dtype == torch.bfloat16 on a HIP device: the fused MFMA path (cpfn_amd/fused_mlp.py).
     dtype == torch.float32: plain PyTorch ops — the fp32 reference the fused path is tested
@@ -51,6 +54,8 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
         from . import fused_mlp
         if x is None:
             return fused_mlp.fused_mlp_stack(xyz_rows.float().contiguous(), convs, bns, pool_k=pool_k, first_fp32=True)
+        if xyz_tail is not None:
+            return fused_mlp.fused_mlp_stack(x.contiguous(), convs, bns, pool_k=pool_k, dropout=dropout, xyz_tail=xyz_tail.float().contiguous())
         P, C = x.shape
         Cp = (C + 63) // 64 * 64
         if Cp != C or x.dtype != torch.bfloat16 or not x.is_contiguous():
@@ -61,8 +66,8 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
                 xp[:, :C] = x
             x = xp
         return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout)
-    if dropout is not None:
-        raise ValueError("fused dropout exists on the bf16 HIP path only")
+    if dropout is not None or xyz_tail is not None:
+        raise ValueError("fused dropout / the xyz tail exist on the bf16 HIP path only")
     y = shared_mlp(src, convs, bns, dtype)
     if pool_k:
         y = y.reshape(-1, pool_k, y.shape[1]).max(dim=1)[0]

@@ -184,6 +184,7 @@ CPFN_API int cpfn_concat_interp_bf16(const void *skip, int C1, const void *feats
 CPFN_API int cpfn_colsum_rows_bf16(const void *g, int ldg, int B, int N, int C, void *out, void *stream);
 CPFN_API int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, const float *w, int T, int B,
                                     int R, int M, int C, float *out, void *stream);
+/* (rel == NULL with Cpad == C: the gather alone) */
 CPFN_API int cpfn_group_concat_bf16(const void *feats, const float *rel, const int *idx, int B, int N, int R,
                                     int C, int Cpad, void *out, void *stream);
 
@@ -206,7 +207,8 @@ CPFN_API int cpfn_concat_pos_feats_bf16(const float *xyz, const void *feats, lon
                                         void *stream);
 /* n_gt[b] = max(labels[b, :]) + 1 (SPFN/losses_implementation.py:603-606). */
 CPFN_API int cpfn_count_labels(const int64_t *labels, int B, int N, int64_t *n_gt, void *stream);
-typedef struct { const float *src; void *dst; int rows, cols, dst_ld, dst_f32; } cpfn_cast_desc;
+typedef struct { const float *src; void *dst; int rows, cols, dst_ld, dst_f32;
+                 int src_ld; /* 0 = cols (contiguous source); > cols: a column slice of a wider matrix */ } cpfn_cast_desc;
 CPFN_API int cpfn_multi_cast(const cpfn_cast_desc *descs /* HOST array */, int count, void *stream);
 
 /* Inverse index of a gather (geometry stage): for idx[B,E] with values in [0,M) (M <= 2048) build, per
@@ -319,6 +321,13 @@ CPFN_API int cpfn_mlp_gemm_blocks(long long P, int N);
  * also leaves pass 1 of that layer's BatchNorm backward in stats_partial — per-block sum(g_z), sum(g_z*y) with
  * g_z = g_a*[a_scale*y + a_shift > 0], the layout cpfn_bn_relu_bwd writes — so cpfn_bn_relu_bwd is not needed for
  * it.  Only where cpfn_mlp_gemm_can_fuse_bwd_stats(P,K,N) returns 1 (the streaming kernel). */
+/* sa2's first layer: [A (K = 128 bf16 channels, row stride lda = K) | xyz [P,3] fp32] . [W [N,128] bf16 | Wx [N,3] fp32]^T ->
+ * Y [P,N] bf16 (ldy = N) + the statistics rows of cpfn_mlp_gemm (stats_partial NULL: none).  The coordinate term is one more
+ * MFMA k-step built in registers from x = hi + lo (bf16), accurate to ~2^-16: the K = 128 streaming kernel instead of a K = 192
+ * operand with three bf16 coordinate columns and 61 columns of padding.  cpfn_mlp_gemm_xyz_ok: K = N = 128, P >= 32768. */
+CPFN_API int cpfn_mlp_gemm_xyz_ok(long long P, int K, int N);
+CPFN_API int cpfn_mlp_gemm_xyz(const void *A, int lda, const void *W, const float *xyz, const float *Wx, long long P, int K,
+                               int N, void *Y, int ldy, float *stats_partial, void *stream);
 CPFN_API int cpfn_mlp_gemm_can_fuse_bwd_stats(long long P, int K, int N);
 /* Timing probe of the GEMM family (measurement only; bench.py's roofline leg).  buf = slots * (2 + 2*max_wg) u64 of
  * zero-filled device memory, or NULL to switch the probe off (default).  While installed, launch i of cpfn_mlp_gemm
@@ -399,7 +408,9 @@ CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, co
  * together with those of other layers, by ONE cpfn_multi_split_reduce launch (same fixed summation order). */
 typedef struct { const float *partial; float *out; long long n; int splits;
                  int row_in, row_out; /* 0,0: out[n] flat; else partial rows have row_in elements of which the first
-                                         row_out are kept: out is compact [n/row_in, row_out] (zero-padded K) */
+                                         row_out are kept: out is [n/row_in, row_out] (zero-padded K) ... */
+                 int out_ld;          /* ... at row stride out_ld (0 = row_out: compact; > row_out: a column slice of a wider
+                                         matrix, e.g. the 128 feature columns and the 3 coordinate columns of one [N,131] weight) */
 } cpfn_reduce_desc;
 CPFN_API int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs /* HOST array */, int count, void *stream);
 CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
@@ -428,7 +439,9 @@ CPFN_API int cpfn_mlp_dgrad_small(const void *Gy, const void *W, long long P, in
  * drop_p: cpfn_bn_bwd_apply's fused dropout on that gradient.  pool_k > 0 (max-pooled layer, P = groups x pool_k rows,
  * pool_k a multiple of 64 - 32 for N = K = 128 - and <= 255): Gy is the POOLED gradient [P / pool_k, N] and pool_arg /
  * pool_yarg are cpfn_bn_relu_maxpool's arg-max rows and values: cpfn_bn_pool_bwd_apply's arithmetic instead.
- * (N, K) in {(128,128), (256,128), (64,64), (128,64)}, and (128,192) without bwd_y / drop_seed / pool_k.  Replaces a [cpfn_bn_bwd_apply | cpfn_bn_pool_bwd_apply +] cpfn_mlp_wgrad +
+ * (N, K) in {(128,128), (256,128), (64,64), (128,64)}.  xt_xyz [P,3] fp32 + xt_partial [splits][128][3] (N = K = 128, apply_y,
+ * no bwd_y / drop_seed / pool_k): the layer has three more input channels, the coordinates (cpfn_mlp_gemm_xyz), whose
+ * weight-gradient columns g_y^T . xyz leave as split partials in xt_partial.  Replaces a [cpfn_bn_bwd_apply | cpfn_bn_pool_bwd_apply +] cpfn_mlp_wgrad +
  * cpfn_mlp_gemm(w_trans) sequence, bit for bit. */
 CPFN_API int cpfn_mlp_bwd_fused_ok(long long P, int N, int K);
 CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
@@ -436,7 +449,7 @@ CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda,
                                 const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
                                 const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
                                 const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
-                                const void *pool_yarg, int pool_k, void *stream);
+                                const void *pool_yarg, int pool_k, const float *xt_xyz, float *xt_partial, void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
  * workspace: ceil(P/256)*C floats.  pad_bf16 (optional): [P,64] bf16, receives the rows of X converted to bf16
  * and zero-padded to 64 columns in the same pass (the gradient operand of the heads' GEMMs).
