@@ -881,54 +881,27 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
 // coalesced, and still bitwise reproducible.
 constexpr int RSUB = 64;
 constexpr int RTPB = 16 * RSUB;
-// (Round 3: the RSUB subset sums are added as a fixed TREE — two xor-shuffles inside a wave (its 4 subsets x 16 channels),
-//  one LDS slot per wave and channel, four slots per lane of wave 0 and two more shuffles — instead of by one thread per
-//  channel walking 64 LDS entries with 128 dependent fp64 adds (~1 us of a 5-6 us launch that runs 34 times per step on
-//  the step's chain), and the loads of a thread's up to 8 block rows are all issued before the first add.)
-__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
-  const unsigned long long u = cpfn_shfl_xor_u64(__builtin_bit_cast(unsigned long long, v), m);
-  return __builtin_bit_cast(double, u);
-}
 __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ partial, int nblk, int N, int c,
                                                    int r, double (*s_acc)[16][2], double &s1, double &s2) {
   double a1 = 0.0, a2 = 0.0;
   if (c < N) {
-    int i = r;
-    for (; i + 7 * RSUB < nblk; i += 8 * RSUB) {       // eight block rows per trip: sixteen loads in flight
-      float v1[8], v2[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        v1[u] = partial[((size_t)(i + u * RSUB) * 2 + 0) * N + c];
-        v2[u] = partial[((size_t)(i + u * RSUB) * 2 + 1) * N + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { a1 += (double)v1[u]; a2 += (double)v2[u]; }
+#pragma unroll 4
+    for (int i = r; i < nblk; i += RSUB) {
+      a1 += (double)partial[((size_t)i * 2 + 0) * N + c];
+      a2 += (double)partial[((size_t)i * 2 + 1) * N + c];
     }
-    float w1[8], w2[8];                                 // the ragged tail, still issued together
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = i + u * RSUB;
-      w1[u] = k < nblk ? partial[((size_t)k * 2 + 0) * N + c] : 0.f;
-      w2[u] = k < nblk ? partial[((size_t)k * 2 + 1) * N + c] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { a1 += (double)w1[u]; a2 += (double)w2[u]; }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  a1 += shfl_xor_f64(a1, 16); a2 += shfl_xor_f64(a2, 16);
-  a1 += shfl_xor_f64(a1, 32); a2 += shfl_xor_f64(a2, 32);
-  if (lane < 16) { s_acc[wave][lane][0] = a1; s_acc[wave][lane][1] = a2; }
+  s_acc[r][threadIdx.x & 15][0] = a1;
+  s_acc[r][threadIdx.x & 15][1] = a2;
   __syncthreads();
   s1 = 0.0; s2 = 0.0;
-  if (wave == 0) {
-    const int cc = lane & 15, g = lane >> 4;
-    double b1 = (s_acc[g][cc][0] + s_acc[g + 4][cc][0]) + (s_acc[g + 8][cc][0] + s_acc[g + 12][cc][0]);
-    double b2 = (s_acc[g][cc][1] + s_acc[g + 4][cc][1]) + (s_acc[g + 8][cc][1] + s_acc[g + 12][cc][1]);
-    b1 += shfl_xor_f64(b1, 16); b2 += shfl_xor_f64(b2, 16);
-    b1 += shfl_xor_f64(b1, 32); b2 += shfl_xor_f64(b2, 32);
-    s1 = b1; s2 = b2;
+  if (r == 0) {
+    for (int q = 0; q < RSUB; ++q) { s1 += s_acc[q][threadIdx.x & 15][0]; s2 += s_acc[q][threadIdx.x & 15][1]; }
   }
 }
+// (Round 3 tried the RSUB subset sums as a shuffle / LDS tree with all of a thread's loads issued up front: the same 6 us under
+//  rocprofv3, but +1.7 us per launch INSIDE the replayed step — in-kernel probe, gaps around all 34 finalize launches — i.e.
+//  ~55 us per step slower.  Reverted: what this launch costs is its latency chain, and the plain loop has the shorter one.)
 
 __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restrict__ partial, int nblk, int N, float count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -937,7 +910,7 @@ __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restri
                                    float *__restrict__ scale, float *__restrict__ shift,
                                    float *__restrict__ mean_out, float *__restrict__ rstd_out,
                                    long long *__restrict__ counter_a, long long *__restrict__ counter_b) {
-  __shared__ double s_acc[RTPB / 64][16][2];
+  __shared__ double s_acc[RSUB][16][2];
   // step counters advanced by this launch (the layer's num_batches_tracked; the dropout step counter of a stack whose
   // output dropout reads it in the NEXT launch): was one multi-tensor add per forward pass
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1205,7 +1178,7 @@ __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__re
                                        const float *__restrict__ gamma, const float *__restrict__ mean,
                                        const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
-  __shared__ double s_acc[RTPB / 64][16][2];
+  __shared__ double s_acc[RSUB][16][2];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
   double s1, s2;
   partial_sums_16x16(partial, nblk, C, c, r, s_acc, s1, s2);
