@@ -2,7 +2,7 @@
 # Everything profiles/ is refreshed from, in one gpurun call (run on the GPU box from the repo root):
 #   bash tools/collect_profiles.sh [tag]  ->  gpurun_out/collect/... and profiles/<tag>_*
 # Counter passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa tracing), eager launches.
-tag=${1:-r02}
+tag=${1:-r03}
 repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
@@ -21,8 +21,18 @@ cp $(find gpurun_out/collect/stats -name '*kernel_stats.csv' | head -1) profiles
 python3 bench.py --steps 300 --warmup 30 2> gpurun_out/collect/bench.err | tail -1 > profiles/${tag}_bench_n1.json
 python3 bench.py --steps 50 --warmup 10 --no-graphs --no-cpu-baseline 2> gpurun_out/collect/bench_eager.err | tail -1 > profiles/${tag}_bench_n1_eager.json
 python3 bench.py --steps 100 --warmup 10 --workload local 2> gpurun_out/collect/bench_local.err | tail -1 > profiles/${tag}_bench_local_n1.json
+python3 tools/fps_latency.py gpurun_out/collect/fps_latency_table.md > /dev/null 2> gpurun_out/collect/fps_latency.err
+python3 tools/cascade_probe.py > profiles/${tag}_cascade_probe.txt 2> gpurun_out/collect/cascade.err
+# bench.py reads roofline.traffic from profiles/<tag>_family_traffic.json: a file older than the library it describes is a lie
+if [ ! -s profiles/${tag}_family_traffic.json ] || [ profiles/${tag}_family_traffic.json -ot cpfn_amd/libcpfn_hip.so ]; then
+  echo "collect_profiles: profiles/${tag}_family_traffic.json is missing or older than cpfn_amd/libcpfn_hip.so" >&2
+  stale=1
+fi
 # the traces are large: only the summaries travel back (gpurun merges <= 64 MiB)
 find gpurun_out/collect -name '*kernel_trace.csv' -size +8M -delete
 find gpurun_out/collect -name '*.db' -delete
 find gpurun_out/collect -name '*counter_collection.csv' -size +8M -delete
 tail -n 3 gpurun_out/collect/rooflines.err; tail -n 3 gpurun_out/collect/breakdown.err; ls -la profiles | tail -12; head -c 1200 profiles/${tag}_rooflines.json
+# (gpurun only merges gpurun_out/ back: the judged copies travel through it, then `cp gpurun_out/profiles_<tag>/* profiles/`)
+mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* gpurun_out/collect/fps_latency_table.md gpurun_out/profiles_${tag}/ 2>/dev/null
+[ -z "$stale" ] || exit 1
