@@ -160,6 +160,24 @@ def cpu_baseline():
                                              "%.3f s" % (N_POINTS, physical, t_all)}}
 
 
+def scale_fields(collective, bucket_bytes, in_graph, rank_ms, rank_comm, samples):
+    """What a multi-GPU line carries beyond the single-GPU one, so that a SCALE run is diagnosable: who was slow
+    (`ms_per_step_ranks`), how long the gradient exchange took on every rank (`comm_us_per_step`: device wall clock between two
+    one-lane stamp kernels around it — end of the gradient packing -> end of the collective, i.e. wire time plus the wait for
+    the slowest peer) and which collective layout ran where (`collective`)."""
+    import statistics
+    ok = [c for c in rank_comm if c == c]            # (NaN: a rank without a reading)
+    return {
+        "collective": "%s on one flat %d-byte fp32 bucket (CPFN_DP_COLLECTIVE), %s" % (
+            collective, bucket_bytes, "inside the step's graph" if in_graph else "eager launches after the graph"),
+        "ms_per_step_ranks": {"min": min(rank_ms), "max": max(rank_ms), "all": list(rank_ms)},
+        "comm_us_per_step": {"median_over_ranks": statistics.median(ok) if ok else None, "max": max(ok) if ok else None,
+                             "all": [c if c == c else None for c in rank_comm],
+                             "measured": "device wall clock between two one-lane stamp kernels around the exchange (end of "
+                                         "gradient packing -> end of the collective), median over %d sampled replays per rank" % samples},
+    }
+
+
 def main():
     args = parse_args()
     if args.dtype == "fp32":
@@ -451,15 +469,10 @@ def main():
                          "families": families},
         }
         if world > 1:
-            # what a SCALE run needs to be diagnosable: who was slow, and how long the exchange took on every rank
-            line["config"]["collective"] = ("%s on one flat %d-byte fp32 bucket (CPFN_DP_COLLECTIVE), %s" % (
-                trainer.bucket.collective, 4 * trainer.bucket.flat.numel(),
-                "inside the step's graph" if (trainer._graph or {}).get("exchange_in_graph") else "eager launches after the graph"))
-            line["ms_per_step_ranks"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
-            line["comm_us_per_step"] = {"median_over_ranks": statistics.median(rank_comm), "max": max(rank_comm), "all": rank_comm,
-                                        "measured": "device wall clock between two one-lane stamp kernels around the exchange "
-                                                    "(end of gradient packing -> end of the collective), median over %d "
-                                                    "sampled replays per rank" % len(comm_us)}
+            extra = scale_fields(trainer.bucket.collective, 4 * trainer.bucket.flat.numel(),
+                                 bool((trainer._graph or {}).get("exchange_in_graph")), rank_ms, rank_comm, len(comm_us))
+            line["config"]["collective"] = extra.pop("collective")
+            line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

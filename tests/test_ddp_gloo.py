@@ -214,3 +214,20 @@ def test_flat_bucket_views_and_finite_check():
     assert not bool(b.finite())
     b.zero()
     assert all(p.grad is None for p in model.parameters())
+
+
+def test_bench_scale_fields_shape():
+    """The fields bench.py adds to a multi-GPU line (per-rank step times, stamped exchange times, collective layout) — the
+    assembly is a pure function, so the first SCALE run cannot die in it."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.scale_fields("rs_ag", 5625228, True, [1.81, 1.83, 1.9, 1.82], [41.0, 39.5, float("nan"), 44.0], 21)
+    assert "NaN" not in json.dumps(f) and f["comm_us_per_step"]["all"][2] is None          # strict JSON
+    assert f["ms_per_step_ranks"] == {"min": 1.81, "max": 1.9, "all": [1.81, 1.83, 1.9, 1.82]}
+    assert f["comm_us_per_step"]["median_over_ranks"] == 41.0 and f["comm_us_per_step"]["max"] == 44.0
+    assert "rs_ag" in f["collective"] and "inside the step's graph" in f["collective"]
+    g = bench.scale_fields("all_reduce", 4, False, [2.0], [float("nan")], 1)
+    assert g["comm_us_per_step"]["median_over_ranks"] is None and "after the graph" in g["collective"]

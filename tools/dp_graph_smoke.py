@@ -21,5 +21,8 @@ hist = []
 for i in range(30):
     hist.append(float(tr.step(batch, next_batch=batch)[0]))
 torch.cuda.synchronize()
+c_us = tr.comm_us()
+print('comm_us', c_us)
+assert c_us is not None and 0.0 < c_us < 5000.0, c_us          # the two stamps around the exchange of the last replayed step
 print('graph captured:', tr._graph is not None, 'world in graph:', tr._graph['world'], 'exchange in graph:', tr._graph.get('exchange_in_graph'), 'loss', round(hist[0], 3), '->', round(hist[-1], 3), 'skipped', float(tr._graph['skipped']))
 torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()
