@@ -80,7 +80,7 @@ __device__ __forceinline__ void probe_end(unsigned long long *slot, unsigned lon
     *(u64x2 *)&slot[2 + 2 * (size_t)wg] = (u64x2){t0, (unsigned long long)wall_clock64()};
     if (wg == 0) {
       slot[0] = (unsigned long long)gridDim.x * gridDim.y * gridDim.z;
-      slot[1] = kind;            // 1 streaming GEMM, 2 generic GEMM, 3 small-P GEMM, 4 weight gradient, 5 one-pass backward
+      slot[1] = kind;            // 1 streaming GEMM, 2 generic GEMM, 3 small-P GEMM, 4 weight gradient, 5 one-pass backward, 6 small layer: weight + data gradient
     }
   }
 }
@@ -724,21 +724,28 @@ struct SmallpBwdArgs {
   const float *b_scale, *b_shift;           // BST: [N]
 };
 
-template <int RT, bool STATS, bool WT, bool BST = false>
-__global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
+template <int RT>
+struct SmallpLds {
+  static constexpr int TT = RT / 16, LDT = 64 + 8, RAW_TILE = 4 * 32 * LDT * 2, RAW_RED = 4 * 4 * TT * 64 * 16;
+  __attribute__((aligned(16))) unsigned char raw[RAW_TILE > RAW_RED ? RAW_TILE : RAW_RED];
+  __attribute__((aligned(16))) float ss[2][SP_SS_MAX];
+};
+
+// (body with the workgroup's position as arguments: mlp_gemm_smallp_kernel runs it on its own grid, mlp_bwd_small_kernel on
+//  the tail of a grid whose head is a small layer's weight gradient)
+template <int RT, bool STATS, bool WT, bool BST>
+__device__ __forceinline__ void mlp_gemm_smallp_body(
+    SmallpLds<RT> &lds, int bx, int by,
     const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
     int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
-    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe,
-    const SmallpBwdArgs bw = SmallpBwdArgs()) {
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift, const SmallpBwdArgs &bw) {
   constexpr int TT = RT / 16, D = SP_DEPTH, LDT = 64 + 8;
   static_assert(!(STATS && BST) && (!BST || WT), "the riding reduction belongs to the data gradient");
-  const unsigned long long probe_t0 = probe_begin(probe);
-  constexpr int RAW_TILE = 4 * 32 * LDT * 2, RAW_RED = 4 * 4 * TT * 64 * 16;
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[RAW_TILE > RAW_RED ? RAW_TILE : RAW_RED];
-  __shared__ __attribute__((aligned(16))) float s_ss[2][SP_SS_MAX];
+  unsigned char *s_raw = lds.raw;
+  float (*s_ss)[SP_SS_MAX] = lds.ss;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
-  const int n0 = blockIdx.y * 64, row0 = blockIdx.x * RT;
+  const int n0 = by * 64, row0 = bx * RT;
   if (a_scale) {
     for (int e = t; e < K; e += 256) { s_ss[0][e] = a_scale[e]; s_ss[1][e] = a_shift[e]; }
     __syncthreads();
@@ -866,10 +873,22 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
     if (lr == 0) {
-      *(f32x4 *)&stats_partial[((size_t)blockIdx.x * 2 + 0) * N + n] = sm;
-      *(f32x4 *)&stats_partial[((size_t)blockIdx.x * 2 + 1) * N + n] = sq;
+      *(f32x4 *)&stats_partial[((size_t)bx * 2 + 0) * N + n] = sm;
+      *(f32x4 *)&stats_partial[((size_t)bx * 2 + 1) * N + n] = sq;
     }
   }
+}
+
+template <int RT, bool STATS, bool WT, bool BST = false>
+__global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
+    const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
+    int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe,
+    const SmallpBwdArgs bw = SmallpBwdArgs()) {
+  const unsigned long long probe_t0 = probe_begin(probe);
+  __shared__ SmallpLds<RT> lds;
+  mlp_gemm_smallp_body<RT, STATS, WT, BST>(lds, blockIdx.x, blockIdx.y, A, lda, a_bytes, W, P, K, N, Y, ldy, stats_partial, a_scale,
+                                            a_shift, bw);
   probe_end(probe, probe_t0, 3);
 }
 
@@ -1294,29 +1313,32 @@ constexpr int WG_STEP = 32;       // rows per MFMA step
 constexpr int WG_DEPTH = 4;       // steps in flight
 
 template <int TN, int TK>
-__global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
-                                                        const unsigned short *__restrict__ A, int lda,
-                                                        const int *__restrict__ gidx, long long P, int N, int K,
-                                                        long long rows_per_split, float *__restrict__ partial,
-                                                        const float *__restrict__ a_scale,
-                                                        const float *__restrict__ a_shift,
-                                                        unsigned long long *probe = nullptr) {
-  const unsigned long long probe_t0 = probe_begin(probe);
+struct WgradLds {
+  __attribute__((aligned(16))) unsigned short g[WG_STEP * (TN + 8)];
+  __attribute__((aligned(16))) unsigned short a[WG_STEP * (TK + 8)];
+};
+
+// (body with the workgroup's position as arguments, like mlp_gemm_smallp_body)
+template <int TN, int TK>
+__device__ __forceinline__ void mlp_wgrad_body(WgradLds<TN, TK> &lds, int bx, int by, int bz,
+                                               const unsigned short *__restrict__ Gy, int ldg,
+                                               const unsigned short *__restrict__ A, int lda,
+                                               const int *__restrict__ gidx, long long P, int N, int K,
+                                               long long rows_per_split, float *__restrict__ partial,
+                                               const float *__restrict__ a_scale, const float *__restrict__ a_shift) {
   constexpr int LDN = TN + 8, LDK = TK + 8;       // LDS row strides (elements)
   constexpr int CG = TN / 64, CA = TK / 64;       // 16-byte chunks per thread and step
   constexpr int MI = TN / 32, MJ = TK / 32;       // MFMA tiles per wave (wave sub-tile = TN/2 x TK/2)
-  __shared__ __attribute__((aligned(16))) unsigned short s_g[WG_STEP * LDN];
-  __shared__ __attribute__((aligned(16))) unsigned short s_a[WG_STEP * LDK];
+  unsigned short *s_g = lds.g, *s_a = lds.a;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
-  const long long p0 = (long long)blockIdx.z * rows_per_split, p1 = min(P, p0 + rows_per_split);
+  const int n0 = bx * TN, k0 = by * TK;
+  const long long p0 = (long long)bz * rows_per_split, p1 = min(P, p0 + rows_per_split);
   if (p0 >= p1) {   // empty split: its partial slab must still be zero
-    float *o = partial + (size_t)blockIdx.z * N * K;
+    float *o = partial + (size_t)bz * N * K;
     for (int e = t; e < TN * TK; e += 256) {
       const int n = n0 + e / TK, k = k0 + e % TK;
       if (n < N && k < K) o[(size_t)n * K + k] = 0.f;
     }
-    probe_end(probe, probe_t0, 4);
     return;
   }
   const int wn = (wave >> 1) * (TN / 2), wk = (wave & 1) * (TK / 2);
@@ -1396,7 +1418,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
     }
   }
   // D[row = n-local 4(lane>>4)+r][col = k-local lane&15]
-  float *o = partial + (size_t)blockIdx.z * N * K;
+  float *o = partial + (size_t)bz * N * K;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1406,7 +1428,48 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
         const int n = n0 + wn + i * 16 + 4 * (lane >> 4) + r, k = k0 + wk + j * 16 + (lane & 15);
         if (n < N && k < K) o[(size_t)n * K + k] = acc[i][j][r];
       }
+}
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
+                                                        const unsigned short *__restrict__ A, int lda,
+                                                        const int *__restrict__ gidx, long long P, int N, int K,
+                                                        long long rows_per_split, float *__restrict__ partial,
+                                                        const float *__restrict__ a_scale,
+                                                        const float *__restrict__ a_shift,
+                                                        unsigned long long *probe = nullptr) {
+  const unsigned long long probe_t0 = probe_begin(probe);
+  __shared__ WgradLds<TN, TK> lds;
+  mlp_wgrad_body<TN, TK>(lds, blockIdx.x, blockIdx.y, blockIdx.z, Gy, ldg, A, lda, gidx, P, N, K, rows_per_split, partial, a_scale, a_shift);
   probe_end(probe, probe_t0, 4);
+}
+
+// A SMALL layer's weight gradient and data gradient in ONE launch (cpfn_mlp_bwd_small): both read the same g_y and do not
+// depend on each other, and as two launches of 3-10 us each on the step's chain they cost a kernel boundary (2.5-3 us) plus
+// the shorter of the two durations more than they must — seven times per backward pass (sa3, sfp1, sfp2).  The grid's first
+// nW workgroups are mlp_wgrad_kernel<64,64>'s, the rest mlp_gemm_smallp_kernel<32,false,true,BST>'s; the two bodies share
+// the workgroup's LDS (a union) and — at 32-row tiles — have the same register footprint (116 / 128), so neither loses
+// occupancy.  Same arithmetic, same partial layouts: bit-identical to the two launches.
+struct BwdSmallGrid { int nW, wgx, wgy, dgx; };
+template <bool BST>
+__global__ __launch_bounds__(256) void mlp_bwd_small_kernel(
+    BwdSmallGrid gr, const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda, long long P,
+    int N, int K, long long rows_per_split, float *__restrict__ partial, const float *__restrict__ a_scale,
+    const float *__restrict__ a_shift, const unsigned short *__restrict__ W, int g_bytes, unsigned short *__restrict__ Gout, int ldo,
+    float *__restrict__ stats_partial, const SmallpBwdArgs bw, unsigned long long *probe) {
+  const unsigned long long probe_t0 = probe_begin(probe);
+  __shared__ union U { WgradLds<64, 64> w; SmallpLds<32> d; __device__ U() {} } lds;
+  const int b = blockIdx.x;
+  if (b < gr.nW) {
+    const int bx = b % gr.wgx, r = b / gr.wgx;
+    mlp_wgrad_body<64, 64>(lds.w, bx, r % gr.wgy, r / gr.wgy, Gy, ldg, A, lda, nullptr, P, N, K, rows_per_split, partial, a_scale, a_shift);
+  } else {
+    const int d = b - gr.nW;
+    // in the small-P kernel's terms: operand = g_y [P, N] (contraction over the layer's N output channels), outputs = K channels
+    mlp_gemm_smallp_body<32, false, true, BST>(lds.d, d % gr.dgx, d / gr.dgx, Gy, ldg, g_bytes, W, (int)P, N, K, Gout, ldo, stats_partial,
+                                               nullptr, nullptr, bw);
+  }
+  probe_end(probe, probe_t0, 6);
 }
 
 // ---------------------------------------------------------------- weight gradient + data gradient in one pass
@@ -2463,6 +2526,42 @@ extern "C" int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, c
   }
   const long long n = (long long)N * K;
   if (dW) launch_split_reduce(workspace, splits, n, dW, st);    // NULL: the caller batches it (cpfn_multi_split_reduce)
+  return cpfn_launch_status();
+}
+
+// Weight gradient + data gradient of a small layer as ONE launch (mlp_bwd_small_kernel): workspace as cpfn_mlp_wgrad leaves it
+// (cpfn_mlp_wgrad_splits(P,N,K) slabs), Gout [P,K] = Gy . W (W: the FORWARD panel [N][K]); bwd_y (optional, + b_scale / b_shift +
+// stats_partial [cpfn_mlp_bwd_small_blocks(P)][2][K]): pass 1 of the BatchNorm backward of the layer below on the stored tile.
+extern "C" int cpfn_mlp_bwd_small_ok(long long P, int N, int K) {
+  return cpfn_mlp_wgrad_apply_ok(P, N, K) && cpfn_mlp_dgrad_small_ok(P, N, K);
+}
+extern "C" int cpfn_mlp_bwd_small_blocks(long long P) { return (int)((P + 31) / 32); }
+extern "C" int cpfn_mlp_bwd_small(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
+                                  const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
+                                  const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                  void *stream) {
+  if (!cpfn_mlp_bwd_small_ok(P, N, K) || !Gy || !A || !W || !workspace || !Gout || ldg != N || (lda & 7) || lda < K || (ldo & 3) ||
+      ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)))
+    return CPFN_EINVAL;
+  const int splits = cpfn_mlp_wgrad_splits(P, N, K);
+  long long rps = (P + splits - 1) / splits;
+  rps = ((rps + WG_STEP * WG_DEPTH - 1) / (WG_STEP * WG_DEPTH)) * (WG_STEP * WG_DEPTH);
+  BwdSmallGrid gr;
+  gr.wgx = N / 64; gr.wgy = (K + 63) / 64; gr.nW = gr.wgx * gr.wgy * splits;
+  gr.dgx = cpfn_mlp_bwd_small_blocks(P);
+  const dim3 grid(gr.nW + gr.dgx * (K / 64));
+  SmallpBwdArgs bw;
+  bw.Yb = (const unsigned short *)bwd_y; bw.b_scale = b_scale; bw.b_shift = b_shift;
+  const int g_bytes = (int)(((P - 1) * N + N) * 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (bwd_y)
+    mlp_bwd_small_kernel<true><<<grid, 256, 0, st>>>(gr, (const unsigned short *)Gy, ldg, (const unsigned short *)A, lda, P, N, K, rps,
+                                                     workspace, a_scale, a_shift, (const unsigned short *)W, g_bytes,
+                                                     (unsigned short *)Gout, ldo, stats_partial, bw, probe_slot_all(grid));
+  else
+    mlp_bwd_small_kernel<false><<<grid, 256, 0, st>>>(gr, (const unsigned short *)Gy, ldg, (const unsigned short *)A, lda, P, N, K, rps,
+                                                      workspace, a_scale, a_shift, (const unsigned short *)W, g_bytes,
+                                                      (unsigned short *)Gout, ldo, nullptr, bw, probe_slot_all(grid));
   return cpfn_launch_status();
 }
 

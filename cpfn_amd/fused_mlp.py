@@ -49,6 +49,8 @@ XYZ_RECOMPUTE = True
 #                     128 gathered bf16 channels (cpfn_mlp_gemm_xyz; its weight-gradient columns ride on the one-pass kernel)
 #                     instead of as three bf16 columns of a zero-padded K = 192 operand
 XYZ_TAIL = True
+#   SMALL_BWD_MERGED  a small layer's weight gradient and data gradient as ONE launch (cpfn_mlp_bwd_small); False: two launches
+SMALL_BWD_MERGED = True
 
 
 def _pad_to(n, m):
@@ -579,6 +581,21 @@ class _FusedStack(torch.autograd.Function):
                                  + ((2 * P * Kp + 8 * splits * Kp) if below else 0) + ((12 * P + 12 * splits * N) if xt is not None else 0))
                     if below:
                         fused_part = (fp_, splits)
+                elif (SMALL_BWD_MERGED and SMALL_BWD_FUSED and route in ("small", "generic") and need_dgrad and Gy is not None and
+                      Gy.stride(0) == N and bool(h.cpfn_mlp_bwd_small_ok(P, N, Kp))):
+                    # small layer: weight gradient AND data gradient (with pass 1 of the layer below riding on it where there
+                    # is one) as one launch — the two only share their operand g_y
+                    g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
+                    Yp, stp = (saved[li - 1][2], saved[li - 1][3]) if below_ok else (None, (None, None))
+                    nb_ = h.cpfn_mlp_bwd_small_blocks(P)
+                    fp_ = torch.empty(nb_, 2, Kp, dtype=torch.float32, device=dev) if below_ok else None
+                    _check(h.cpfn_mlp_bwd_small(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), _ptr(Wb), P, N, Kp, asc, ash, _ptr(ws),
+                                                _ptr(g_new), Kp, _ptr(Yp), _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_), _stream()),
+                           "cpfn_mlp_bwd_small")
+                    _l.add_bytes("cpfn_mlp_bwd_small", 4 * P * N + 2 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp + 2 * P * Kp
+                                 + ((2 * P * Kp + 8 * nb_ * Kp) if below_ok else 0))
+                    if below_ok:
+                        fused_part = (fp_, nb_)
                 else:
                     _check(h.cpfn_mlp_wgrad(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), None, P, N, Kp, asc, ash, _ptr(ws), None,
                                             _stream()), "cpfn_mlp_wgrad")
@@ -595,7 +612,9 @@ class _FusedStack(torch.autograd.Function):
                 else:
                     _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin, params=(L.weight,))
                 grads[3 * li] = dW.reshape(wshape)
-                if need_dgrad and route == "small" and below_ok:
+                if g_new is not None:
+                    pass                            # (the one-pass / merged launch above produced the data gradient)
+                elif need_dgrad and route == "small" and below_ok:
                     # small-P data gradient with the reduction of the layer below on the stored tile
                     g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
                     Yp, stp = saved[li - 1][2], saved[li - 1][3]

@@ -97,6 +97,9 @@ SIGNATURES = {
     "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused_ok": [_ll, _i, _i],
     "cpfn_mlp_wgrad_apply_ok": [_ll, _i, _i],
+    "cpfn_mlp_bwd_small_ok": [_ll, _i, _i],
+    "cpfn_mlp_bwd_small_blocks": [_ll],
+    "cpfn_mlp_bwd_small": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_dgrad_small_ok": [_ll, _i, _i],
     "cpfn_mlp_dgrad_small": [_vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

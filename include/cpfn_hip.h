@@ -423,6 +423,14 @@ CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, con
  * replaces that layer's cpfn_bn_relu_bwd launch.  cpfn_mlp_wgrad_apply_ok: the layer's weight gradient runs on 64 x 64
  * tiles (the shapes this small-layer route is taken for). */
 CPFN_API int cpfn_mlp_wgrad_apply_ok(long long P, int N, int K);
+/* ... and the two as ONE launch (the grid's head is cpfn_mlp_wgrad's 64 x 64 tiles, its tail the data gradient on 32-row
+ * tiles): same workspace / Gout / statistics, bit for bit; bwd_y optional; stats_partial has cpfn_mlp_bwd_small_blocks(P) rows. */
+CPFN_API int cpfn_mlp_bwd_small_ok(long long P, int N, int K);
+CPFN_API int cpfn_mlp_bwd_small_blocks(long long P);
+CPFN_API int cpfn_mlp_bwd_small(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
+                                const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
+                                const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                void *stream);
 CPFN_API int cpfn_mlp_dgrad_small_ok(long long P, int N, int K);
 CPFN_API int cpfn_mlp_dgrad_small(const void *Gy, const void *W, long long P, int N, int K, void *Gout, int ldo,
                                   const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,

@@ -382,17 +382,35 @@ def test_small_layer_backward_fusion(name, P, cin, widths, pool_k, stats_fused, 
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
     monkeypatch.setattr(fused_mlp, "BWD_STATS_FUSED", stats_fused)
     res = {}
-    for fused in (True, False):
-        monkeypatch.setattr(fused_mlp, "SMALL_BWD_FUSED", fused)
+    for fused in ("merged", True, False):
+        monkeypatch.setattr(fused_mlp, "SMALL_BWD_FUSED", bool(fused))
+        monkeypatch.setattr(fused_mlp, "SMALL_BWD_MERGED", fused == "merged")
         _l.byte_census(True)
         res[fused] = _run(x, convs, bns, torch.bfloat16, pool_k, None, gout)
         census = _l.byte_census(False)
+        if fused == "merged":
+            # round 3: weight gradient + data gradient of EVERY layer of a small stack as one launch each (the pooled top layer
+            # included: its data gradient then also carries the reduction of the layer below)
+            # (sa3's 512 -> 1024 top layer keeps 128 x 128 weight-gradient tiles and with them its own two launches)
+            n_merged = len(widths) - (1 if widths[-1] >= 1024 else 0)
+            assert census["cpfn_mlp_bwd_small"][0] == n_merged and "cpfn_mlp_dgrad_small" not in census, sorted(census)
+            assert census.get("cpfn_mlp_wgrad", (0, 0))[0] == len(widths) - n_merged
+            if stats_fused:          # only the top layer (and the layer below an unmerged one) needs its own reduction pass
+                assert census["cpfn_bn_relu_bwd"][0] == 1 + (len(widths) - n_merged), census["cpfn_bn_relu_bwd"]
+            continue
         assert ("cpfn_mlp_dgrad_small" in census) == (fused and stats_fused), sorted(census)
         if fused and not pool_k:
             if stats_fused:      # only the top layer still needs its own reduction pass
                 assert census["cpfn_bn_relu_bwd"][0] == 1, census["cpfn_bn_relu_bwd"]
-    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
     same = (lambda a, b: _rel(a, b) < 2e-3) if stats_fused else torch.equal
+    (ym, gxm, grm, _), (yf, gxf, grf, _) = res["merged"], res[True]
+    # the merged launch runs the two launches' bodies: the same bits — except that a riding reduction sums its 32-row tiles
+    # (the two-launch form: 64-row tiles where there are enough rows) in another order
+    same_m = same
+    assert torch.equal(ym, yf) and same_m(gxm, gxf)
+    for a_, b_ in zip(grm, grf):
+        assert (a_ is None and b_ is None) or same_m(a_, b_)
+    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
     assert torch.equal(ya, yb)
     assert same(gxa, gxb)
     for a, b in zip(gra, grb):
