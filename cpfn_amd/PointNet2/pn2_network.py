@@ -91,9 +91,16 @@ class PointNet2(torch.nn.Module):
         the CUDA route's semantics — what a checkpoint trained by the reference on a GPU saw."""
         from .. import cuda_ops as _co, fused_mlp
         if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda:
-            fused_mlp.refresh_weight_panels(self.parameters())     # one multi-tensor fp32 -> bf16 conversion
-        with fused_mlp.deferred_bn_counters():
-            return self._forward(x, glob_features, loc_features, fps_start, geometry, bool(_co.CUDA_ROUTE and fast))
+            # one multi-tensor fp32 -> bf16 conversion; when sa1's input is coordinates only, its fp32 first layer is the
+            # forward pass's first launch and the conversion rides on it (cpfn_smallk_fwd_cast)
+            first_is_xyz = (not self.sa1.has_feats and not self.sa1.group_all and
+                            getattr(self.sa1, "compute_dtype", torch.float32) == torch.bfloat16)
+            fused_mlp.refresh_weight_panels(self.parameters(), defer=first_is_xyz)
+        try:
+            with fused_mlp.deferred_bn_counters():
+                return self._forward(x, glob_features, loc_features, fps_start, geometry, bool(_co.CUDA_ROUTE and fast))
+        finally:
+            fused_mlp.flush_pending_cast()       # (never leave a refresh queued behind an exception or an unusual model)
 
     def _fused_dropout(self, device):
         """(p, step counter, base seed) of the dropout fused into fc1's BatchNorm apply (cpfn_amd/fused_mlp.py)."""

@@ -2012,15 +2012,13 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
 // bf16 output + Σy, Σy² partials.  One lane per (row-sub, 8-channel chunk).
 constexpr int KS_MAX = 4;
 template <int KS>
-__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ X,
-                                                         const float *__restrict__ W, long long P, int C,
-                                                         unsigned short *__restrict__ Y,
-                                                         float *__restrict__ partial, int rpb) {
+__device__ __forceinline__ void smallk_fwd_body(int bx, const float *__restrict__ X, const float *__restrict__ W, long long P, int C,
+                                                unsigned short *__restrict__ Y, float *__restrict__ partial, int rpb) {
   __shared__ float s_red[2][256][8 + 1];
   const int t = threadIdx.x;
   const int nch = C / 8, rsub = 256 / nch;  // C <= 2048, power of two
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
-  const long long row0 = (long long)blockIdx.x * rpb;
+  const long long row0 = (long long)bx * rpb;
   float w[8][KS];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -2065,8 +2063,26 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
     const int which = o / (8 * nch), rem = o - which * 8 * nch, chn = rem >> 3, j = rem & 7;
     float s = 0.f;
     for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + chn][j];
-    partial[((size_t)blockIdx.x * 2 + which) * C + rem] = s;
+    partial[((size_t)bx * 2 + which) * C + rem] = s;
   }
+}
+template <int KS>
+__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ X,
+                                                         const float *__restrict__ W, long long P, int C,
+                                                         unsigned short *__restrict__ Y,
+                                                         float *__restrict__ partial, int rpb) {
+  smallk_fwd_body<KS>((int)blockIdx.x, X, W, P, C, Y, partial, rpb);
+}
+// The same launch with the step's bf16 weight-panel refresh (cpfn_multi_cast) as its first workgroups: sa1's first layer reads
+// the fp32 weight itself, so the two are independent — and both sit at the very start of the step's chain, where the refresh
+// alone was a ~7 us launch of pure latency (cpfn_smallk_fwd_cast).
+#include "cast_body.h"
+template <int KS>
+__global__ __launch_bounds__(256) void smallk_fwd_cast_kernel(McvArgs cast, int cast_blocks, const float *__restrict__ X,
+                                                              const float *__restrict__ W, long long P, int C,
+                                                              unsigned short *__restrict__ Y, float *__restrict__ partial, int rpb) {
+  if ((int)blockIdx.x < cast_blocks) multi_cast_body<256>(cast, (int)blockIdx.x);
+  else smallk_fwd_body<KS>((int)blockIdx.x - cast_blocks, X, W, P, C, Y, partial, rpb);
 }
 
 // dW[c,j] = Σ_p Gy[p,c]·X[p,j]: partial[gridDim.x][C][KS]
@@ -2641,6 +2657,21 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
 #undef CPFN_BWD_FUSED_SHAPE
 #undef CPFN_BWD_FUSED
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_smallk_fwd_cast(const cpfn_cast_desc *casts, int n_casts, const float *X, int KS, const float *W, long long P,
+                                    int C, void *Y, float *partial, void *stream) {
+  if (P <= 0 || KS != 3 || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || !partial || n_casts <= 0 ||
+      n_casts > MCV_MAX || !casts)
+    return CPFN_EINVAL;
+  McvArgs a;
+  int cast_blocks = 0;
+  const int rc = mcv_fill(casts, n_casts, a, &cast_blocks);
+  if (rc) return rc;
+  const int nblk = cpfn_bn_bwd_blocks(P), rpb = bn_rows_per_block(P);
+  smallk_fwd_cast_kernel<3><<<cast_blocks + nblk, 256, 0, (hipStream_t)stream>>>(a, cast_blocks, X, W, P, C, (unsigned short *)Y,
+                                                                                 partial, rpb);
   return cpfn_launch_status();
 }
 

@@ -259,12 +259,27 @@ class _CastDesc(ctypes.Structure):
 _cast_cache = {}
 
 
-def refresh_weight_panels(params):
+_pending_cast = None          # (descriptor array, count, device) of a refresh that waits to ride on sa1's first layer
+
+
+def flush_pending_cast():
+    """Launch a deferred weight-panel refresh on its own (whoever needs the panels first calls this)."""
+    global _pending_cast
+    pc, _pending_cast = _pending_cast, None
+    if pc is not None:
+        arr, n, dev = pc
+        with torch.cuda.device(dev):
+            _check(_l.lib().cpfn_multi_cast(arr, n, _stream()), "cpfn_multi_cast")
+
+
+def refresh_weight_panels(params, defer=False):
     """Refresh the bf16 panels of all `params` (nn.Parameters that already have one) — plain, zero-padded and the
     packed heads panel with its fp32 bias vector — with ONE launch (cpfn_multi_cast) instead of one conversion
     kernel per layer (~25 launches, 0.1 ms per step).  Called at the start of a forward pass; bf16_weight() and
     _packed_heads() then return the panels as they are until the next call.  Panels that do not exist yet are left
     to their first use."""
+    global _pending_cast
+    flush_pending_cast()
     _refresh_epoch[0] += 1
     want = {id(p): p for p in params}
     jobs, ents, packed, dev = [], [], [], None
@@ -312,8 +327,13 @@ def refresh_weight_panels(params):
             _cast_cache.clear()
         arr = (_CastDesc * len(jobs))(*[_CastDesc(*j) for j in jobs])
         _cast_cache[key] = arr
-    with torch.cuda.device(dev):
-        _check(_l.lib().cpfn_multi_cast(arr, len(jobs), _stream()), "cpfn_multi_cast")
+    # defer: the caller's next launch is an fp32-xyz first layer (sa1), which reads the fp32 weights themselves — the refresh
+    # then rides on that launch (cpfn_smallk_fwd_cast) instead of being one of its own at the head of the step's chain
+    if defer and len(jobs) <= 64:
+        _pending_cast = (arr, len(jobs), dev)
+    else:
+        with torch.cuda.device(dev):
+            _check(_l.lib().cpfn_multi_cast(arr, len(jobs), _stream()), "cpfn_multi_cast")
     _l.add_bytes("cpfn_multi_cast", sum(6 * r * c for _, _, r, c, _, _, _ in jobs))
     for ent in ents:
         if isinstance(ent, dict):
@@ -377,6 +397,8 @@ class _FusedStack(torch.autograd.Function):
         pool_k = cfg.get("pool_k")
         first_fp32 = cfg.get("first_fp32", False)
         xyz_tail = cfg.get("xyz_tail")
+        if not first_fp32:
+            flush_pending_cast()             # (a deferred panel refresh only waits for an fp32-xyz first layer)
         P = x.shape[0]
         dev = x.device
         saved = []
@@ -394,8 +416,16 @@ class _FusedStack(torch.autograd.Function):
                     nblk = h.cpfn_bn_bwd_blocks(P)
                     Y = torch.empty(P, N, dtype=BF16, device=dev)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
-                    _check(h.cpfn_smallk_fwd(_ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
-                           "cpfn_smallk_fwd")
+                    global _pending_cast
+                    pc = _pending_cast
+                    if pc is not None and KS == 3 and pc[2] == dev:
+                        _pending_cast = None          # the step's weight-panel refresh as the first workgroups of this launch
+                        _check(h.cpfn_smallk_fwd_cast(pc[0], pc[1], _ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
+                               "cpfn_smallk_fwd_cast")
+                    else:
+                        flush_pending_cast()
+                        _check(h.cpfn_smallk_fwd(_ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
+                               "cpfn_smallk_fwd")
                     _l.add_bytes("cpfn_smallk_fwd", 4 * P * KS + 2 * P * N + 8 * nblk * N)
                     Wb = w32                      # (the backward pass recomputes this layer's output from x and w32)
                 elif li == 0 and xyz_tail is not None:
@@ -722,6 +752,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, Wb, bp, N, nheads, *wb):
+        flush_pending_cast()
         with torch.cuda.device(a.device):
             Y, _, _ = gemm(a, Wb, bias=bp, out_f32=True, n_store=N)
         ctx.save_for_backward(a, Wb)

@@ -106,6 +106,7 @@ SIGNATURES = {
                            _vp, _f, _vp, _vp, _i, _vp, _vp, _vp],
     "cpfn_colsum_f32": [_vp, _ll, _i, _vp, _vp, _vp, _vp],
     "cpfn_smallk_fwd": [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
+    "cpfn_smallk_fwd_cast": [_vp, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad": [_vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
     "cpfn_smallk_wgrad_apply_xyz": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],

@@ -470,6 +470,10 @@ CPFN_API int cpfn_colsum_f32(const float *X, long long P, int C, float *workspac
  * (workspace: cpfn_bn_bwd_blocks(P)*C*KS floats). */
 CPFN_API int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P, int C, void *Y,
                              float *partial, void *stream);
+/* cpfn_smallk_fwd (KS = 3) and cpfn_multi_cast (n_casts <= 64 descriptors) as ONE launch: the step's weight-panel refresh rides as
+ * the first workgroups of sa1's first layer, which reads the fp32 weight itself and does not depend on it. */
+CPFN_API int cpfn_smallk_fwd_cast(const cpfn_cast_desc *casts /* HOST array */, int n_casts, const float *X, int KS, const float *W,
+                                  long long P, int C, void *Y, float *partial, void *stream);
 CPFN_API int cpfn_smallk_wgrad(const void *Gy, const float *X, int KS, long long P, int C,
                                float *workspace, float *dW, void *stream);
 /* The same with cpfn_bn_bwd_apply folded in: Gz is the gradient w.r.t. the layer's ACTIVATED output, Y its pre-BN output;
