@@ -29,6 +29,8 @@ HOST_ASSIGNMENT = os.environ.get("CPFN_HOST_ASSIGNMENT", "0") == "1"
 # pass), their adjoint is added to gW inside cpfn_head_post_bwd, and the assignment rides as extra workgroups on the fits'
 # first launch (cpfn_fit_moments_fwd_match).
 
+HEADS_HINT = True        # (module attribute for tests: False = the heads' backward makes its own pass over gY, cpfn_colsum_f32)
+
 PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), ("sphere_radius_squared", 1),
                 ("cylinder_axis", 3), ("cylinder_center", 3), ("cylinder_radius_squared", 1),
                 ("cone_apex", 3), ("cone_axis", 3), ("cone_half_angle", 1))
@@ -96,10 +98,19 @@ class HeadPost(torch.autograd.Function):
         gW = None if gW is None else gW.contiguous().float()
         gS = None if gS is None else gS.contiguous().float()
         gY = torch.empty_like(Yc)
+        # what the fc2 heads' backward makes of gY first — its rows as zero-padded bf16 (the operand of their two GEMMs) and the
+        # per-256-row column sums (their bias gradient) — leaves this launch too, from the tile while it is in LDS, and is handed
+        # to fused_mlp._Linear.backward keyed by gY's address (no cpfn_colsum_f32 launch, no second pass over gY)
+        gb = csp = None
+        if HEADS_HINT and N % 256 == 0 and C <= 64:
+            from .. import fused_mlp
+            gb = torch.empty(B * N, 64, dtype=torch.bfloat16, device=dev)
+            csp = torch.empty((B * N // 256) * C, dtype=torch.float32, device=dev)
+            fused_mlp.heads_grad_hint = (gY.data_ptr(), B * N, C, gb, csp)
         with torch.cuda.device(dev):
             _l.check(_l.lib().cpfn_head_post_bwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), _ptr(W), _ptr(stats), _ptr(gXn),
                                                  _ptr(gW), _ptr(gl), 1 if planar else 0, B, N, C - 7, _ptr(gY), _ptr(gS),
-                                                 _stream()), "cpfn_head_post_bwd")
+                                                 _ptr(gb), _ptr(csp), _stream()), "cpfn_head_post_bwd")
         _l.add_bytes("cpfn_head_post_bwd", 4 * B * N * (2 * C + 3 + (C - 7) + (3 if gXn is not None else 0) + (C - 7 if gW is not None else 0))
                      + 8 * B * N)
         return gY, None, None, None, None

@@ -181,7 +181,12 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
     const float *__restrict__ Y, const float *__restrict__ Xgt, const long long *__restrict__ Igt,
     const long long *__restrict__ Tgt, const float *__restrict__ Wsm, const float *__restrict__ stats,
     const float *__restrict__ gXn, const float *__restrict__ gW, const float *__restrict__ gloss, int gl_planar, int N,
-    int K, float *__restrict__ gY, const float *__restrict__ gS) {
+    int K, float *__restrict__ gY, const float *__restrict__ gS, unsigned short *__restrict__ pad_bf16 = nullptr,
+    float *__restrict__ colsum_partial = nullptr) {
+  // pad_bf16 [B*N, 64] + colsum_partial [B*N/256][7+K] (optional; N % 256 == 0): what cpfn_colsum_f32 makes of gY for the fc2 heads'
+  // backward — the rows converted to bf16 and zero-padded to 64 columns (the gradient operand of their two GEMMs) and the
+  // per-256-row column sums (their bias gradient, finished by the batched split reduction) — taken from the tile while it is
+  // in LDS: that launch (11 us on the step's chain, a second pass over gY) is then not made.  Same order of additions.
   // gS (optional) [B, K+2, K]: gradient w.r.t. the label-segmented membership sums the forward launch produced; its
   // adjoint dW[n,k] = gS[K,k] + gS[label(n),k] (seg_stats_bwd_kernel) is added to gW here, so that neither that kernel
   // nor the framework's gradient-accumulation add of the two [B,N,K] tensors is launched.
@@ -279,6 +284,31 @@ __global__ __launch_bounds__(LP_THREADS) void head_post_bwd_kernel(
   }
   __syncthreads();
   lp_stage_out(s_row, LP_LD, gY + p0 * C, rows, C, t);
+  if (pad_bf16) {
+    // 16-byte chunk e of the tile's rows x 8 chunks: row e / 8, columns 8 (e % 8) .. + 7 (zeros beyond C): coalesced
+    for (int e = t; e < rows * 8; e += LP_THREADS) {
+      const int r = e >> 3, c0 = (e & 7) * 8;
+      unsigned w4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = c0 + 2 * j < C ? s_row[r * LP_LD + c0 + 2 * j] : 0.f;
+        const float hi = c0 + 2 * j + 1 < C ? s_row[r * LP_LD + c0 + 2 * j + 1] : 0.f;
+        w4[j] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+      }
+      *(uint4 *)(pad_bf16 + (p0 + r) * 64 + c0) = (uint4){w4[0], w4[1], w4[2], w4[3]};
+    }
+  }
+  if (colsum_partial) {
+    // colsum_f32_kernel's order: lane (column c, subset rs) adds the rows = rs (mod 4) in ascending order, then ((s0 + s1) + s2) + s3
+    __shared__ float s_cs[4][64];
+    const int c = t & 63, rs = t >> 6;
+    float a = 0.f;
+    if (c < C)
+      for (int r = rs; r < rows; r += 4) a += s_row[r * LP_LD + c];
+    s_cs[rs][c] = a;
+    __syncthreads();
+    if (t < C) colsum_partial[((size_t)b * gridDim.x + blockIdx.x) * C + t] = s_cs[0][t] + s_cs[1][t] + s_cs[2][t] + s_cs[3][t];
+  }
 }
 
 // ------------------------------------------------------------------------------------ seg_stats
@@ -756,11 +786,13 @@ extern "C" int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_
 extern "C" int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                   const float *Wsm, const float *stats, const float *gXn, const float *gW,
                                   const float *gloss, int gloss_planar, int B, int N, int K, float *gY, const float *gS,
-                                  void *stream) {
+                                  void *pad_bf16, float *colsum_partial, void *stream) {
   if (B <= 0 || N <= 0 || K <= 0 || K > MAXK || !Y || !Xgt || !Igt || !Tgt || !Wsm || !stats || !gloss || !gY)
     return CPFN_EINVAL;
+  if ((pad_bf16 || colsum_partial) && (N % LP_THREADS || 7 + K > 64 || !pad_bf16 || !colsum_partial)) return CPFN_EINVAL;
   head_post_bwd_kernel<<<dim3(cpfn_cdiv(N, LP_THREADS), B), LP_THREADS, 0, (hipStream_t)stream>>>(
-      Y, Xgt, (const long long *)Igt, (const long long *)Tgt, Wsm, stats, gXn, gW, gloss, gloss_planar, N, K, gY, gS);
+      Y, Xgt, (const long long *)Igt, (const long long *)Tgt, Wsm, stats, gXn, gW, gloss, gloss_planar, N, K, gY, gS,
+      (unsigned short *)pad_bf16, colsum_partial);
   return cpfn_launch_status();
 }
 

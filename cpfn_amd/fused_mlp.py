@@ -746,6 +746,11 @@ def _packed_heads(weights, biases):
     return ent["Wb"], ent["bp"], ent["N"]
 
 
+# (gY address, rows, columns, bf16 rows padded to 64 columns, per-256-row column sums): left by the loss section's heads
+# post-processing backward (SPFN/fused_losses.HeadPost) for the gradient tensor it returns; one-shot
+heads_grad_hint = None
+
+
 class _Linear(torch.autograd.Function):
     """Y = A·Wᵀ + b with bf16 operands and fp32 output (the fc2 heads; no batch-norm).  Wb / bp: the packed padded
     panel of _packed_heads; the heads' own parameters come in as *wb so that their gradients are routed back."""
@@ -768,21 +773,29 @@ class _Linear(torch.autograd.Function):
         h = _l.lib()
         N, P, K = ctx.n, a.shape[0], a.shape[1]
         Np = Wb.shape[0]
+        global heads_grad_hint
+        hint, heads_grad_hint = heads_grad_hint, None
         gc = g.contiguous().float()
         fused_pad = Np == 64
-        gb = torch.empty(P, Np, dtype=BF16, device=a.device) if fused_pad else torch.zeros(P, Np, dtype=BF16, device=a.device)
-        if not fused_pad:
-            gb[:, :N] = g
-        # bias gradient = column sums of g (torch's strided reduce: 0.66 ms, rocBLAS gemv: 0.8 ms for [131072,35]);
-        # the same pass writes the padded bf16 operand of the two GEMMs below
         gbias = torch.empty(N, dtype=torch.float32, device=a.device)
-        wsb = torch.empty(((P + 255) // 256) * N, dtype=torch.float32, device=a.device)
+        if (hint is not None and fused_pad and hint[0] == gc.data_ptr() and hint[1] == P and hint[2] == N and
+                hint[3].device == a.device):
+            # the producer of g (the heads post-processing backward) already left the padded bf16 rows and the column sums
+            gb, wsb = hint[3], hint[4]
+        else:
+            gb = torch.empty(P, Np, dtype=BF16, device=a.device) if fused_pad else torch.zeros(P, Np, dtype=BF16, device=a.device)
+            if not fused_pad:
+                gb[:, :N] = g
+            # bias gradient = column sums of g (torch's strided reduce: 0.66 ms, rocBLAS gemv: 0.8 ms for [131072,35]);
+            # the same pass writes the padded bf16 operand of the two GEMMs below
+            wsb = torch.empty(((P + 255) // 256) * N, dtype=torch.float32, device=a.device)
+            with torch.cuda.device(a.device):
+                _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), None, _ptr(gb) if fused_pad else None, _stream()),
+                       "cpfn_colsum_f32")
+            _l.add_bytes("cpfn_colsum_f32", 4 * P * N + (2 * P * Np if fused_pad else 0))
         with torch.cuda.device(a.device):
             # (its 512 x 35 partials are finished by the batched split reduction at the end of the backward pass)
-            _check(h.cpfn_colsum_f32(_ptr(gc), P, N, _ptr(wsb), None, _ptr(gb) if fused_pad else None, _stream()),
-                   "cpfn_colsum_f32")
             _defer_reduction(wsb, gbias, N, (P + 255) // 256, params=ctx.heads)
-            _l.add_bytes("cpfn_colsum_f32", 4 * P * N + (2 * P * Np if fused_pad else 0))
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
             dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)

@@ -112,7 +112,7 @@ SIGNATURES = {
     "cpfn_smallk_wgrad_apply_xyz": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp],
     "cpfn_head_post_chunks": [_i],
     "cpfn_head_post_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "cpfn_head_post_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_head_post_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_seg_stats_chunks": [_i, _i],
     "cpfn_seg_stats_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_seg_stats_bwd": [_vp, _vp, _i, _i, _i, _vp, _vp],

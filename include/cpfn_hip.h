@@ -510,9 +510,12 @@ CPFN_API int cpfn_head_post_fwd(const float *Y, const float *Xgt, const int64_t 
  * gloss_planar = 0: gloss is [B,2]; 1: [2,B] (the two gradient vectors one after the other, as cpfn_loss_tail leaves
  * them: no interleaving copy).  gS (optional) [B,K+2,K] = gradient w.r.t. the segmented sums cpfn_head_post_fwd
  * left in S: its adjoint (cpfn_seg_stats_bwd's dW) is added to gW inside this launch. */
+/* (pad_bf16 [B*N,64] bf16 + colsum_partial [B*N/256][7+K], optional, N % 256 == 0: what cpfn_colsum_f32 would make of gY for the
+ * heads' backward, produced from the tile in the same pass) */
 CPFN_API int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t *Igt, const int64_t *Tgt,
                                 const float *Wsm, const float *stats, const float *gXn, const float *gW,
-                                const float *gloss, int gloss_planar, int B, int N, int K, float *gY, const float *gS, void *stream);
+                                const float *gloss, int gloss_planar, int B, int N, int K, float *gY, const float *gS, void *pad_bf16, float *colsum_partial,
+                                void *stream);
 /* Label-segmented membership sums, shared by the Hungarian cost matrix and the relaxed-IoU loss
  * (SPFN/losses_implementation.py:19-24, 77-90):  S[B,K+2,K]: rows l<K = sum of W rows with label l,
  * row K = column sums of W, row K+1 = number of points per label.  fwd: any K <= 1024 (K > 32: one 32 x 32 tile

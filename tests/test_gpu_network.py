@@ -214,3 +214,32 @@ def test_device_assignment_matches_scipy():
     off = dict(mult, residue=0.0, parameter=0.0)
     params0, match0 = fl.fit_params_and_match(P, Wd, Xn, off, S, n_gt)
     assert params0 is None and np.array_equal(match0.cpu().numpy(), got)
+
+
+def test_heads_gradient_hint_is_bit_identical_to_the_colsum_launch(monkeypatch):
+    """The heads post-processing backward (cpfn_head_post_bwd) also leaves what the fc2 heads' backward makes of its result
+    first — zero-padded bf16 rows and per-256-row column sums — so that cpfn_colsum_f32 is not launched: every parameter
+    gradient of a training step must have the same bits with and without that hand-over."""
+    from cpfn_amd import lib as _l, synthetic, training
+    from cpfn_amd.PointNet2 import pn2_network
+    from cpfn_amd.SPFN import fused_losses as fl
+    dev = torch.device("cuda:0")
+    batch = {k: v.to(dev) for k, v in synthetic.training_batch(2, N=2048, n_prims=6, n_inst_points=128, seed=3).items()}
+    starts = (torch.tensor([5, 17]), torch.tensor([1, 300]))
+    res = {}
+    for hint in (True, False):
+        monkeypatch.setattr(fl, "HEADS_HINT", hint)
+        torch.manual_seed(0)
+        model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
+        model.set_compute_dtype(torch.bfloat16)
+        model.dropout_p = 0.0
+        tr = training.SPFNTrainer(model, batch_size=2)
+        tr.bucket.zero()
+        _l.byte_census(True)
+        out = tr.losses(batch, fps_start=starts)
+        out[0].backward()
+        census = _l.byte_census(False)
+        assert ("cpfn_colsum_f32" in census) == (not hint), sorted(census)
+        res[hint] = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+    for a, b in zip(res[True], res[False]):
+        assert (a is None and b is None) or torch.equal(a, b)
