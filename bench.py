@@ -41,9 +41,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ROOFLINE_SYMBOL = "cpfn_mlp_gemm"
 # kernel families that time themselves (in-kernel probe): C-ABI entry points whose algorithmic bytes the census counts
 FAMILIES = {"cpfn_mlp_gemm": ("cpfn_mlp_gemm", "cpfn_mlp_dgrad_small"),
-            "cpfn_mlp_wgrad": ("cpfn_mlp_wgrad",),
+            "cpfn_mlp_wgrad": ("cpfn_mlp_wgrad", "cpfn_mlp_bwd_small"),      # (small layers: weight + data gradient in one launch)
             "cpfn_mlp_bwd_fused": ("cpfn_mlp_bwd_fused",)}
-KIND_FAMILY = {1: "cpfn_mlp_gemm", 2: "cpfn_mlp_gemm", 3: "cpfn_mlp_gemm", 4: "cpfn_mlp_wgrad", 5: "cpfn_mlp_bwd_fused"}
+KIND_FAMILY = {1: "cpfn_mlp_gemm", 2: "cpfn_mlp_gemm", 3: "cpfn_mlp_gemm", 4: "cpfn_mlp_wgrad", 5: "cpfn_mlp_bwd_fused", 6: "cpfn_mlp_wgrad"}
 
 
 def parse_args():

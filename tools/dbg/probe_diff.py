@@ -1,7 +1,7 @@
 """Two probe dumps (bench.py --probe-dump) side by side, launches matched by order: duration and the time since the
 previous probed launch ended, and their differences.   python tools/dbg/probe_diff.py a.json b.json"""
 import json, sys
-KIND = {1: "stream", 2: "generic", 3: "smallp", 4: "wgrad", 5: "onepass"}
+KIND = {1: "stream", 2: "generic", 3: "smallp", 4: "wgrad", 5: "onepass", 6: "small-bwd"}
 a, b = (json.load(open(p))["launches"] for p in sys.argv[1:3])
 assert len(a) == len(b), (len(a), len(b))
 pa = pb = None

@@ -4,7 +4,7 @@ Shows per launch: offset from the first anchor, duration, the time since the pre
 ran in between on the critical path) and how ragged the workgroups were.
     python tools/dbg/probe_timeline.py a.json [b.json]      (two files: side by side, matching launches by order)"""
 import json, sys
-KIND = {1: "stream", 2: "generic", 3: "smallp", 4: "wgrad", 5: "onepass"}
+KIND = {1: "stream", 2: "generic", 3: "smallp", 4: "wgrad", 5: "onepass", 6: "small-bwd"}
 
 
 def load(p):

@@ -17,12 +17,12 @@ import argparse, collections, csv, glob, json, re, sys
 # kernel function name -> C-ABI entry point that launches it (one entry point may launch several kernels)
 ENTRY = {
     "mlp_gemm_stream_kernel": "cpfn_mlp_gemm", "mlp_gemm_smallp_kernel": "cpfn_mlp_gemm", "mlp_gemm_kernel": "cpfn_mlp_gemm",
-    "mlp_wgrad_kernel": "cpfn_mlp_wgrad", "mlp_bwd_fused_kernel": "cpfn_mlp_bwd_fused",
+    "mlp_wgrad_kernel": "cpfn_mlp_wgrad", "mlp_bwd_fused_kernel": "cpfn_mlp_bwd_fused", "mlp_bwd_small_kernel": "cpfn_mlp_bwd_small",
     "multi_split_reduce_kernel": "cpfn_multi_split_reduce",
     "bn_finalize_kernel": "cpfn_bn_finalize", "bn_bwd_finalize_kernel": "cpfn_bn_bwd_finalize",
     "bn_relu_apply_kernel": "cpfn_bn_relu_apply", "bn_relu_maxpool_kernel": "cpfn_bn_relu_maxpool",
     "bn_relu_bwd_kernel": "cpfn_bn_relu_bwd", "bn_bwd_apply_kernel": "cpfn_bn_bwd_apply",
-    "bn_pool_bwd_apply_kernel": "cpfn_bn_pool_bwd_apply", "smallk_fwd_kernel": "cpfn_smallk_fwd",
+    "bn_pool_bwd_apply_kernel": "cpfn_bn_pool_bwd_apply", "smallk_fwd_kernel": "cpfn_smallk_fwd", "smallk_fwd_cast_kernel": "cpfn_smallk_fwd",
     "smallk_wgrad_kernel": "cpfn_smallk_wgrad", "colsum_f32_kernel": "cpfn_colsum_f32",
     "csr_gather_sum_kernel": "cpfn_csr_gather_sum_bf16", "group_concat_bf16_kernel": "cpfn_group_concat_bf16",
     "interp_rows_bf16_kernel": "cpfn_interp_rows_bf16", "concat_pos_feats_kernel": "cpfn_concat_pos_feats_bf16",
