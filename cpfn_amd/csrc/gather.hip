@@ -386,11 +386,14 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
 }
 
 // out[b,m,:] = Σ_{e in list(m)} w[b,e] · g[b, e / T, :]      (w may be NULL), bf16 in / bf16 out.
-// CS_LANES lanes share one (target row, 8-channel chunk): lane q takes entries q, q+CS_LANES, ... of the list, two
-// at a time, and the partial sums are combined by a fixed butterfly.  The kernel is a chain of dependent loads
-// (offsets -> entry -> row), so its time is (entries per lane) x latency: 16 lanes instead of 4 took the sa2 /
-// sfp3 adjoints from 45 us to ~20 us.
-constexpr int CS_LANES = 16;
+// CS_LANES lanes share one (target row, 8-channel chunk): lane q takes entries q, q+CS_LANES, ... of the list,
+// CS_UNROLL at a time, and the partial sums are combined by a fixed butterfly.  The kernel is a chain of dependent loads
+// (offsets -> entry -> row), so its time is (trips per lane) x latency: 32 entries per trip instead of 8 took the sa2 /
+// sfp3 adjoints from 45 us to ~20 us.  Round 3: those 32 as 8 lanes x 4 instead of 16 lanes x 2 — a wave is then 8 chunks
+// (128 contiguous bytes = whole cache lines) of 8 rows per load instead of 4 chunks (half lines) of 16 rows: the measured HBM
+// traffic of the three launches was 1.94 x their bytes.
+constexpr int CS_LANES = 8;
+constexpr int CS_UNROLL = 4;
 __global__ __launch_bounds__(TPB) void csr_gather_sum_kernel(const unsigned short *__restrict__ g, int ldg,
                                                              const int *__restrict__ offsets,
                                                              const int *__restrict__ entries,
@@ -410,22 +413,22 @@ __global__ __launch_bounds__(TPB) void csr_gather_sum_kernel(const unsigned shor
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const int i1 = live ? off[m + 1] : 0;
   int i = (live ? off[m] : 0) + q;
-  for (; i + CS_LANES < i1; i += 2 * CS_LANES) {
-    const int e0 = ent[i], e1 = ent[i + CS_LANES];
-    const float w0 = wb ? wb[e0] : 1.f, w1 = wb ? wb[e1] : 1.f;
-    const uint4 r0 = *(const uint4 *)(gb + (size_t)(e0 / T) * ldg);
-    const uint4 r1 = *(const uint4 *)(gb + (size_t)(e1 / T) * ldg);
-    const unsigned short *h0 = (const unsigned short *)&r0, *h1 = (const unsigned short *)&r1;
+  for (; i < i1; i += CS_UNROLL * CS_LANES) {
+    int e[CS_UNROLL];
+    float wv[CS_UNROLL];
+    uint4 r[CS_UNROLL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w1, bf2f_(h1[j]), fmaf(w0, bf2f_(h0[j]), acc[j]));
-  }
-  if (i < i1) {
-    const int e0 = ent[i];
-    const float w0 = wb ? wb[e0] : 1.f;
-    const uint4 r0 = *(const uint4 *)(gb + (size_t)(e0 / T) * ldg);
-    const unsigned short *h0 = (const unsigned short *)&r0;
+    for (int u = 0; u < CS_UNROLL; ++u) e[u] = ent[min(i + u * CS_LANES, i1 - 1)];     // (past the end: clamped, weight 0)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w0, bf2f_(h0[j]), acc[j]);
+    for (int u = 0; u < CS_UNROLL; ++u) wv[u] = i + u * CS_LANES < i1 ? (wb ? wb[e[u]] : 1.f) : 0.f;
+#pragma unroll
+    for (int u = 0; u < CS_UNROLL; ++u) r[u] = *(const uint4 *)(gb + (size_t)(e[u] / T) * ldg);
+#pragma unroll
+    for (int u = 0; u < CS_UNROLL; ++u) {
+      const unsigned short *h = (const unsigned short *)&r[u];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv[u], bf2f_(h[j]), acc[j]);
+    }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
