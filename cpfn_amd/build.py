@@ -74,9 +74,10 @@ def _compile(src, flags, force):
 # them when three of four floats of a 16-byte LDS element are used; the device assembly kept by
 # -save-temps is scanned after every compile so that a new one cannot slip in.
 _BANNED_ISA = re.compile(r"\bds_(read|write|load|store)_b96\b")
-# Scratch (private segment) is banned too, except where it is known and accepted: a dynamically indexed local
-# array silently moves to scratch memory and cost the Adam kernel 25 us per launch.
-_SCRATCH_OK = ("fit_algebra_fwd_kernel", "fit_algebra_bwd_kernel")
+# Scratch (private segment) is banned too: a dynamically indexed local array silently moves to scratch memory — it cost
+# the Adam kernel 25 us per launch, and the fitters' algebra 44 MB of HBM writes per backward launch until round 3 made its
+# last three run-time indices (Jacobi's (p, q), the eigenvalue sort's permutation, the plane frame's `pick`) static.
+_SCRATCH_OK = ()
 _KERNEL_META = re.compile(r"\.name:\s+(\S+)\s*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)")
 
 

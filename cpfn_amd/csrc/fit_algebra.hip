@@ -55,6 +55,7 @@ __device__ void jacobi3(const double s[6], double lam[3], double V[3][3]) {
     const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
     const double diag = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
     if (off <= 1e-300 || off <= 1e-22 * diag) break;
+#pragma unroll          // (p, q must be compile-time: a[][] / v[][] indexed by a loop variable live in scratch memory)
     for (int pq = 0; pq < 3; ++pq) {
       const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
       const double apq = a[p][q];
@@ -67,14 +68,21 @@ __device__ void jacobi3(const double s[6], double lam[3], double V[3][3]) {
       for (int r = 0; r < 3; ++r) { const double x = v[r][p], y = v[r][q]; v[r][p] = c * x - sn * y; v[r][q] = sn * x + c * y; }
     }
   }
-  int o[3] = {0, 1, 2};
+  // ascending eigenvalues: the three compare-exchanges of a bubble sort, the eigenvector columns swapped along (statically
+  // indexed: a permutation table would put v[][] in scratch memory)
   double e[3] = {a[0][0], a[1][1], a[2][2]};
-  if (e[0] > e[1]) { double te = e[0]; e[0] = e[1]; e[1] = te; int ti = o[0]; o[0] = o[1]; o[1] = ti; }
-  if (e[1] > e[2]) { double te = e[1]; e[1] = e[2]; e[2] = te; int ti = o[1]; o[1] = o[2]; o[2] = ti; }
-  if (e[0] > e[1]) { double te = e[0]; e[0] = e[1]; e[1] = te; int ti = o[0]; o[0] = o[1]; o[1] = ti; }
+#define CPFN_JACOBI_CSWAP(i, j)                                                              \
+  if (e[i] > e[j]) {                                                                         \
+    const double te = e[i]; e[i] = e[j]; e[j] = te;                                          \
+    for (int r = 0; r < 3; ++r) { const double tv = v[r][i]; v[r][i] = v[r][j]; v[r][j] = tv; } \
+  }
+  CPFN_JACOBI_CSWAP(0, 1)
+  CPFN_JACOBI_CSWAP(1, 2)
+  CPFN_JACOBI_CSWAP(0, 1)
+#undef CPFN_JACOBI_CSWAP
   for (int i = 0; i < 3; ++i) {
     lam[i] = e[i];
-    for (int r = 0; r < 3; ++r) V[r][i] = v[r][o[i]];
+    for (int r = 0; r < 3; ++r) V[r][i] = v[r][i];
   }
 }
 
@@ -212,17 +220,24 @@ __device__ void fit_all(const T *M, T *out) {
     T n[3];
     smallest_eigvec(Sxx, n);
     // compute_consistent_plane_frame (geometry_utils.py:8-27): y = normalise(n x e_i) of largest norm
-    T cand[3][3] = {{T(0.0), n[2], -n[1]}, {-n[2], T(0.0), n[0]}, {n[1], -n[0], T(0.0)}};
+    // candidates n x e_i = (0, n2, -n1), (-n2, 0, n0), (n1, -n0, 0); the first of largest norm wins.  Written without a
+    // [3][3] table: indexed by the run-time `pick`, the table lives in scratch memory (160 B per lane).
+    const double n0v = val(n[0]), n1v = val(n[1]), n2v = val(n[2]);
+    const double nn0 = sqrt(0.0 * 0.0 + n2v * n2v + n1v * n1v), nn1 = sqrt(n2v * n2v + 0.0 * 0.0 + n0v * n0v),
+                 nn2 = sqrt(n1v * n1v + n0v * n0v + 0.0 * 0.0);
     int pick = 0;
-    double best = -1.0;
-    for (int i = 0; i < 3; ++i) {
-      const double nn = sqrt(val(cand[i][0]) * val(cand[i][0]) + val(cand[i][1]) * val(cand[i][1]) + val(cand[i][2]) * val(cand[i][2]));
-      if (nn > best) { best = nn; pick = i; }
-    }
-    T yn = tsqrt(cand[pick][0] * cand[pick][0] + cand[pick][1] * cand[pick][1] + cand[pick][2] * cand[pick][2]);
+    double best = nn0;                 // (NaN norms: no candidate beats -1 in the table form either; pick stays 0)
+    if (!(nn0 > -1.0)) best = -1.0;
+    if (nn1 > best) { best = nn1; pick = 1; }
+    if (nn2 > best) { best = nn2; pick = 2; }
+    T cp[3];
+    if (pick == 0) { cp[0] = T(0.0); cp[1] = n[2]; cp[2] = -n[1]; }
+    else if (pick == 1) { cp[0] = -n[2]; cp[1] = T(0.0); cp[2] = n[0]; }
+    else { cp[0] = n[1]; cp[1] = -n[0]; cp[2] = T(0.0); }
+    T yn = tsqrt(cp[0] * cp[0] + cp[1] * cp[1] + cp[2] * cp[2]);
     yn = clamp_min(yn, 1e-12);
     T ey[3], ex[3];
-    for (int i = 0; i < 3; ++i) ey[i] = cand[pick][i] / yn;
+    for (int i = 0; i < 3; ++i) ey[i] = cp[i] / yn;
     ex[0] = ey[1] * n[2] - ey[2] * n[1];
     ex[1] = ey[2] * n[0] - ey[0] * n[2];
     ex[2] = ey[0] * n[1] - ey[1] * n[0];
@@ -270,13 +285,22 @@ __device__ void fit_all(const T *M, T *out) {
 
 constexpr int PART_LO[4] = {0, 4, 8, 15}, PART_HI[4] = {4, 8, 15, 21};
 
-template <typename T>
-__device__ __forceinline__ void fit_part(int part, const T *m, T *o) {   // wave-uniform `part`
+// fit PART and hand its outputs to `sink(i, o_i)` with COMPILE-TIME i (an o[] indexed by a run-time part range lives in
+// scratch memory: 496 B per lane, 44 MB of HBM writes per backward launch in round 2's counters)
+template <typename T, int PART, typename Sink>
+__device__ __forceinline__ void fit_one(const T *m, Sink &&sink) {
+  T o[NO];
+  fit_all<T, PART>(m, o);
+#pragma unroll
+  for (int i = PART_LO[PART]; i < PART_HI[PART]; ++i) sink(i, o[i]);
+}
+template <typename T, typename Sink>
+__device__ __forceinline__ void fit_part(int part, const T *m, Sink &&sink) {   // wave-uniform `part`
   switch (part) {
-    case 0: fit_all<T, 0>(m, o); break;
-    case 1: fit_all<T, 1>(m, o); break;
-    case 2: fit_all<T, 2>(m, o); break;
-    default: fit_all<T, 3>(m, o); break;
+    case 0: fit_one<T, 0>(m, sink); break;
+    case 1: fit_one<T, 1>(m, sink); break;
+    case 2: fit_one<T, 2>(m, sink); break;
+    default: fit_one<T, 3>(m, sink); break;
   }
 }
 
@@ -286,12 +310,13 @@ __global__ __launch_bounds__(256) void fit_algebra_fwd_kernel(const double *__re
   const int part = threadIdx.x >> 6;
   const long long g = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
   if (g >= G) return;
-  double m[NM], o[NO];
+  double m[NM];
   for (int i = 0; i < NM; ++i) m[i] = M[g * NM + i];
-  fit_part<double>(part, m, o);
-  for (int i = PART_LO[part]; i < PART_HI[part]; ++i) out[g * NO + i] = o[i];
-  if (apex_axis32 && part == 3)   // fp32 copy of the cone pass's inputs: apex[G,3] then axis[G,3]
-    for (int i = 0; i < 3; ++i) { apex_axis32[g * 3 + i] = (float)o[15 + i]; apex_axis32[(G + g) * 3 + i] = (float)o[18 + i]; }
+  fit_part<double>(part, m, [&](int i, double oi) {
+    out[g * NO + i] = oi;
+    if (apex_axis32 && i >= 15)   // fp32 copy of the cone pass's inputs: apex[G,3] then axis[G,3]
+      apex_axis32[(i >= 18 ? (G + g) * 3 + (i - 18) : g * 3 + (i - 15))] = (float)oi;
+  });
 }
 
 // one workgroup per instance, 4 waves: wave p, lane d < 52 computes the part-p share of dL/dM[g,d] by forward-mode
@@ -305,10 +330,9 @@ __global__ __launch_bounds__(256) void fit_algebra_bwd_kernel(const double *__re
   const int part = threadIdx.x >> 6, d = threadIdx.x & 63;
   double acc = 0.0;
   if (d < NM) {
-    Dual m[NM], o[NO];
+    Dual m[NM];
     for (int i = 0; i < NM; ++i) m[i] = Dual(M[g * NM + i], i == d ? 1.0 : 0.0);
-    fit_part<Dual>(part, m, o);
-    for (int i = PART_LO[part]; i < PART_HI[part]; ++i) acc += gout[g * NO + i] * o[i].d;
+    fit_part<Dual>(part, m, [&](int i, Dual oi) { acc += gout[g * NO + i] * oi.d; });
   }
   s_share[part][d] = acc;
   __syncthreads();
