@@ -5,6 +5,9 @@ from .. import lib as _l
 from ..ops import _chk, _ptr, _stream
 
 SLOTS = 52
+# FitParams.backward as 3 launches (cpfn_fit_params_bwd_cone / _algebra, cpfn_fit_moments_bwd) instead of 5; False: the
+# separate pack adjoint and chunk reduction (kept for the bit-identity test)
+PARAMS_BWD_FUSED = True
 # slot map of include/cpfn_hip.h
 A0, AP, APP, AX, AXX = 0, slice(1, 4), slice(4, 10), slice(10, 13), slice(13, 19)
 B0, BP, BPP, BPPP, BXX, BXPX = 20, slice(21, 24), slice(24, 30), slice(30, 40), slice(40, 46), slice(46, 49)
@@ -203,9 +206,6 @@ class FitParams(torch.autograd.Function):
         G = B * K
         h = _l.lib()
         gp = g.contiguous().float()
-        g_alg = torch.empty(B, K, 21, dtype=torch.float64, device=dev)
-        g_acos = torch.empty(B, K, dtype=torch.float32, device=dev)
-        gA0 = torch.empty(B, K, dtype=torch.float64, device=dev)
         chunks = h.cpfn_fit_num_chunks(B, N)
         ws = torch.empty(chunks * B * K * 6, dtype=torch.float64, device=dev)
         dWc = torch.empty_like(W)
@@ -214,16 +214,28 @@ class FitParams(torch.autograd.Function):
         dX = torch.empty_like(X)
         with torch.cuda.device(dev):
             st = _stream()
-            _l.check(h.cpfn_fit_pack_bwd(_ptr(gp), _ptr(sums), _ptr(M), G, _ptr(g_alg), _ptr(g_acos), _ptr(gA0), st),
-                     "cpfn_fit_pack_bwd")
-            # cone pass adjoint: dW term, and d(apex, axis) accumulated into columns 15..20 of g_alg
-            _l.check(h.cpfn_cone_pass_bwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), _ptr(g_acos), B, N, K, _ptr(dWc),
-                                          _ptr(ws), g_alg.data_ptr() + 15 * 8, 21, 1, st), "cpfn_cone_pass_bwd")
-            _l.check(h.cpfn_fit_algebra_bwd(_ptr(M), _ptr(g_alg), _ptr(gA0), G, None, _ptr(gM32), st), "cpfn_fit_algebra_bwd")
+            if PARAMS_BWD_FUSED:
+                # three launches: the cone pass adjoint derives g_acos from gp itself, the algebra adjoint sums the cone
+                # pass's per-chunk partials of d(apex, axis) into its own copy of the algebra's adjoint
+                _l.check(h.cpfn_fit_params_bwd_cone(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), _ptr(gp), _ptr(sums),
+                                                    _ptr(M), B, N, K, _ptr(dWc), _ptr(ws), st), "cpfn_fit_params_bwd_cone")
+                _l.check(h.cpfn_fit_params_bwd_algebra(_ptr(M), _ptr(gp), _ptr(sums), _ptr(ws), chunks, B, K, _ptr(gM32), st),
+                         "cpfn_fit_params_bwd_algebra")
+            else:
+                g_alg = torch.empty(B, K, 21, dtype=torch.float64, device=dev)
+                g_acos = torch.empty(B, K, dtype=torch.float32, device=dev)
+                gA0 = torch.empty(B, K, dtype=torch.float64, device=dev)
+                _l.check(h.cpfn_fit_pack_bwd(_ptr(gp), _ptr(sums), _ptr(M), G, _ptr(g_alg), _ptr(g_acos), _ptr(gA0), st),
+                         "cpfn_fit_pack_bwd")
+                # cone pass adjoint: dW term, and d(apex, axis) accumulated into columns 15..20 of g_alg
+                _l.check(h.cpfn_cone_pass_bwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), _ptr(g_acos), B, N, K,
+                                              _ptr(dWc), _ptr(ws), g_alg.data_ptr() + 15 * 8, 21, 1, st), "cpfn_cone_pass_bwd")
+                _l.check(h.cpfn_fit_algebra_bwd(_ptr(M), _ptr(g_alg), _ptr(gA0), G, None, _ptr(gM32), st), "cpfn_fit_algebra_bwd")
             _l.check(h.cpfn_fit_moments_bwd(_ptr(P), _ptr(X), _ptr(W), _ptr(gM32), B, N, K, _ptr(dWc), _ptr(dW), _ptr(dX), st),
                      "cpfn_fit_moments_bwd")
-        _l.add_bytes("cpfn_fit_pack_bwd", 88 * G + 8 * G * (2 + SLOTS + 21 + 1) + 4 * G)
+        if not PARAMS_BWD_FUSED:
+            _l.add_bytes("cpfn_fit_pack_bwd", 88 * G + 8 * G * (2 + SLOTS + 21 + 1) + 4 * G)
         _l.add_bytes("cpfn_cone_pass_bwd", 4 * B * N * (3 + 2 * K) + 28 * G + 48 * (chunks + 1) * G)
-        _l.add_bytes("cpfn_fit_algebra_bwd", 8 * G * (SLOTS + 22) + 4 * G * SLOTS)
+        _l.add_bytes("cpfn_fit_algebra_bwd", 8 * G * (SLOTS + 22) + 4 * G * SLOTS + 48 * chunks * G)
         _l.add_bytes("cpfn_fit_moments_bwd", 4 * B * N * (6 + 2 * K) + 4 * G * SLOTS + 4 * B * N * (K + 3))
         return None, dX, dW

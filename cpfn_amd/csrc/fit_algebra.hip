@@ -18,6 +18,7 @@
 // collapse to the last column).  Value-only decisions (condition-number masks, the frame's
 // arg-max, clamps) carry zero tangent exactly like the reference's detach()/argmax/clamp.
 #include "common.h"
+#include "fit_pack.h"
 
 namespace {
 
@@ -344,7 +345,67 @@ __global__ __launch_bounds__(256) void fit_algebra_bwd_kernel(const double *__re
   }
 }
 
+// The same inside the packed-parameter backward: the workgroup of instance g first forms its own gout[21] and gA0 from the
+// packed parameters' adjoint (fit_pack_bwd_kernel's rules) and the cone pass's per-chunk partials of d(apex, axis), summed
+// in chunk order like chunk_reduce_strided_kernel did — two [B,K]-sized launches of the loss section's backward chain less,
+// the same bits.
+constexpr int FA_MAXCHUNKS = 64;
+__global__ __launch_bounds__(256) void fit_params_bwd_algebra_kernel(const double *__restrict__ M,
+                                                                     const float *__restrict__ gparams,
+                                                                     const double *__restrict__ sums,
+                                                                     const double *__restrict__ cone_ws, int nchunks, int K,
+                                                                     float *__restrict__ gM32) {
+  __shared__ double s_share[4][64];
+  __shared__ double s_cone[FA_MAXCHUNKS][6];
+  __shared__ double s_g[NO + 1];
+  const long long g = blockIdx.x;
+  const int b = (int)(g / K), k = (int)(g - (long long)b * K);
+  const int t = threadIdx.x;
+  for (int e = t; e < nchunks * 6; e += 256) {
+    const int c = e / 6, j = e - c * 6;
+    s_cone[c][j] = cone_ws[(((size_t)b * nchunks + c) * K + k) * 6 + j];
+  }
+  __syncthreads();
+  if (t < NO) {
+    const double gp = (double)gparams[g * 22 + t];
+    double v = t < 18 ? gp : gp * cone_sign(sums[g * 2]);
+    if (t >= 15) {
+      double sc = 0.0;
+      for (int c = 0; c < nchunks; ++c) sc += s_cone[c][t - 15];
+      v = v + sc;
+    }
+    s_g[t] = v;
+  } else if (t == NO) {
+    s_g[NO] = pack_half_angle_adjoint((double)gparams[g * 22 + 21], sums[g * 2 + 1], M[g * NM]).gA0;
+  }
+  __syncthreads();
+  const int part = t >> 6, d = t & 63;
+  double acc = 0.0;
+  if (d < NM) {
+    Dual m[NM];
+    for (int i = 0; i < NM; ++i) m[i] = Dual(M[g * NM + i], i == d ? 1.0 : 0.0);
+    fit_part<Dual>(part, m, [&](int i, Dual oi) { acc += s_g[i] * oi.d; });
+  }
+  s_share[part][d] = acc;
+  __syncthreads();
+  if (part == 0 && d < NM) {
+    double tot = ((s_share[0][d] + s_share[1][d]) + s_share[2][d]) + s_share[3][d];
+    if (d == 0) tot += s_g[NO];
+    gM32[g * NM + d] = (float)tot;
+  }
+}
+
 }  // namespace
+
+extern "C" int cpfn_fit_params_bwd_algebra(const double *M, const float *gparams, const double *sums, const double *cone_workspace,
+                                           int chunks, int B, int K, float *gM32, void *stream) {
+  if (B < 0 || K <= 0 || chunks <= 0 || chunks > FA_MAXCHUNKS || !M || !gparams || !sums || !cone_workspace || !gM32)
+    return CPFN_EINVAL;
+  if (B == 0) return 0;
+  fit_params_bwd_algebra_kernel<<<(unsigned)B * K, 256, 0, (hipStream_t)stream>>>(M, gparams, sums, cone_workspace, chunks, K,
+                                                                               gM32);
+  return cpfn_launch_status();
+}
 
 extern "C" int cpfn_fit_algebra_fwd(const double *M, int64_t G, double *out, float *apex_axis32, void *stream) {
   if (G < 0 || !M || !out) return CPFN_EINVAL;

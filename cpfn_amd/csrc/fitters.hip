@@ -26,6 +26,7 @@
 // (`cone_pass_*`) over P and W only (SPFN/cone_fitter.py:25-35).
 #include "common.h"
 #include "lsap.h"
+#include "fit_pack.h"
 
 namespace {
 
@@ -406,7 +407,10 @@ __global__ __launch_bounds__(FM_THREADS) void cone_bwd_kernel(const float *__res
                                                               const float *__restrict__ axis,
                                                               const float *__restrict__ g_acos, int N, int K,
                                                               int pts_per_block, float *__restrict__ dW,
-                                                              double *__restrict__ partial) {
+                                                              double *__restrict__ partial,
+                                                              const float *__restrict__ gparams /* or NULL */,
+                                                              const double *__restrict__ sums,
+                                                              const double *__restrict__ M) {
   __shared__ float s_p[FM_TILE][3];
   __shared__ float s_w[FM_TILE][FM_KB];
   __shared__ double s_red[CP_SUB][FM_KB][6];
@@ -418,7 +422,10 @@ __global__ __launch_bounds__(FM_THREADS) void cone_bwd_kernel(const float *__res
     float ap[3] = {0, 0, 0}, ax[3] = {0, 0, 0}, g = 0.f;
     if (k < K) {
       for (int j = 0; j < 3; ++j) { ap[j] = apex[((size_t)b * K + k) * 3 + j]; ax[j] = axis[((size_t)b * K + k) * 3 + j]; }
-      g = g_acos[(size_t)b * K + k];
+      const size_t gi = (size_t)b * K + k;
+      // (gparams given: the packed parameters' adjoint comes in as it is and fit_pack_bwd's half-angle rule runs here)
+      g = gparams ? (float)pack_half_angle_adjoint((double)gparams[gi * 22 + 21], sums[gi * 2 + 1], M[gi * FM_SLOTS]).g_acos
+                  : g_acos[gi];
     }
     double acc[6] = {0, 0, 0, 0, 0, 0};  // d apex (3), d axis (3)
     for (int base = n0; base < n1; base += FM_TILE) {
@@ -527,10 +534,7 @@ inline int pick_chunks(int B, int N, int *pts_per_block) {
 // axis(3) half-angle — the layout the residue / axis losses read.  Columns 0..17 are the algebra's;
 // the cone axis is flipped to sgn = sign(Σ W·(axis·v̂)) with sign(0) -> +1 (cone_fitter.py:28-31) and the
 // half angle is Σ W·acos / (Σ W + 1e-10) clamped to [1e-3, π/2 − 1e-3] (cone_fitter.py:33-35).
-constexpr double PK_LO = 1e-3, PK_HI = 1.5707963267948966 - 1e-3, PK_EPS = 1e-10;
-
-__device__ __forceinline__ double cone_sign(double s0) { return s0 > 0.0 ? 1.0 : (s0 < 0.0 ? -1.0 : (s0 == 0.0 ? 1.0 : s0)); }
-
+// (constants and the sign rule: fit_pack.h)
 __global__ void fit_pack_fwd_kernel(const double *__restrict__ alg, const double *__restrict__ sums,
                                     const double *__restrict__ M, long long G, float *__restrict__ params) {
   const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -583,11 +587,9 @@ __global__ void fit_pack_bwd_kernel(const float *__restrict__ gparams, const dou
   for (int i = 0; i < 18; ++i) ga[i] = (double)gp[i];
   const double sgn = cone_sign(sums[g * 2]);
   for (int i = 18; i < 21; ++i) ga[i] = (double)gp[i] * sgn;
-  const double den = M[g * FM_SLOTS] + PK_EPS, s1 = sums[g * 2 + 1];
-  const double h = s1 / den;
-  const double gh = (h >= PK_LO && h <= PK_HI) ? (double)gp[21] : 0.0;   // clamp's adjoint
-  g_acos[g] = (float)(gh / den);
-  gA0[g] = -gh * s1 / (den * den);
+  const PackAdj a = pack_half_angle_adjoint((double)gp[21], sums[g * 2 + 1], M[g * FM_SLOTS]);
+  g_acos[g] = (float)a.g_acos;
+  gA0[g] = a.gA0;
 }
 
 }  // namespace
@@ -676,10 +678,26 @@ extern "C" int cpfn_cone_pass_bwd(const float *P, const float *W, const float *a
   hipStream_t st = (hipStream_t)stream;
   int ppb;
   const int chunks = pick_chunks(B, N, &ppb);
-  cone_bwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, W, apex, axis, g_acos, N, K, ppb, dW, workspace);
+  cone_bwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, W, apex, axis, g_acos, N, K, ppb, dW, workspace, nullptr, nullptr,
+                                                          nullptr);
   const long long total = (long long)B * K * 6;
   chunk_reduce_strided_kernel<<<cpfn_cdiv(total, 256), 256, 0, st>>>(workspace, chunks, K * 6, total, 6, ld, accumulate,
                                                                      d_apex_axis);
+  return cpfn_launch_status();
+}
+
+// The cone pass adjoint inside the packed-parameter backward (cpfn_fit_params_bwd_*): g_acos is derived from the packed
+// parameters' adjoint here (no cpfn_fit_pack_bwd launch) and the per-chunk partials of d(apex, axis) stay in `workspace`
+// (chunks * B * K * 6 doubles) for cpfn_fit_params_bwd_algebra to sum (no chunk reduction launch).
+extern "C" int cpfn_fit_params_bwd_cone(const float *P, const float *W, const float *apex, const float *axis,
+                                        const float *gparams, const double *sums, const double *M, int B, int N, int K,
+                                        float *dW, double *workspace, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || !P || !W || !apex || !axis || !gparams || !sums || !M || !dW || !workspace) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  int ppb;
+  const int chunks = pick_chunks(B, N, &ppb);
+  cone_bwd_kernel<<<dim3(chunks, B), FM_THREADS, 0, (hipStream_t)stream>>>(P, W, apex, axis, nullptr, N, K, ppb, dW, workspace,
+                                                                           gparams, sums, M);
   return cpfn_launch_status();
 }
 

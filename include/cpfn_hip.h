@@ -285,6 +285,17 @@ CPFN_API int cpfn_fit_algebra_bwd(const double *M, const double *gout, const dou
  * g_acos[G] fp32 (for cpfn_cone_pass_bwd) and gA0[G] (for cpfn_fit_algebra_bwd). */
 CPFN_API int cpfn_fit_pack_fwd(const double *alg, const double *sums, const double *M, int64_t G,
                                float *params, void *stream);
+/* Backward of the packed parameters as three launches instead of five (cone pass adjoint, algebra adjoint, then
+ * cpfn_fit_moments_bwd): _cone derives g_acos from gparams[G,22] itself (cpfn_fit_pack_bwd's rule) and leaves the per-chunk
+ * partials of d(apex, axis) in workspace (cpfn_fit_num_chunks * B * K * 6 doubles); _algebra sums them in chunk order
+ * into columns 15..20 of the algebra adjoint it forms from gparams (no g_alg / gA0 tensors) and returns gM32[G,52].
+ * Same bits as cpfn_fit_pack_bwd + cpfn_cone_pass_bwd(ld = 21, accumulate) + cpfn_fit_algebra_bwd. */
+CPFN_API int cpfn_fit_params_bwd_cone(const float *P, const float *W, const float *apex, const float *axis,
+                                      const float *gparams, const double *sums, const double *M, int B, int N,
+                                      int K, float *dW, double *workspace, void *stream);
+CPFN_API int cpfn_fit_params_bwd_algebra(const double *M, const float *gparams, const double *sums,
+                                         const double *cone_workspace, int chunks, int B, int K, float *gM32,
+                                         void *stream);
 /* The same with the cone pass's chunk reduction folded in: cpfn_cone_pass_fwd(..., out = NULL) leaves its per-chunk
  * partials in its workspace; this launch sums them (same order, same bits), writes sums[B,K,2] for the backward pass and
  * packs the parameters. */

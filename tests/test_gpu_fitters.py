@@ -137,6 +137,34 @@ def test_moment_linearity_and_determinism():
     torch.testing.assert_close(M1[..., 0], W1.double().sum(1), rtol=1e-12, atol=1e-9)
 
 
+@pytest.mark.parametrize("B,N,K", [(16, 8192, 28), (3, 1000, 7), (2, 4097, 21)])
+def test_packed_parameters_backward_in_three_launches(B, N, K, monkeypatch):
+    """FitParams.backward through cpfn_fit_params_bwd_cone / _algebra (g_acos, the algebra's adjoint and the chunk sums of
+    the cone pass's d(apex, axis) formed inside the two launches) against cpfn_fit_pack_bwd + cpfn_cone_pass_bwd +
+    chunk reduction + cpfn_fit_algebra_bwd: the same bits."""
+    from cpfn_amd import lib as _l
+    from cpfn_amd.SPFN import moments, fitters_common as fc
+    g = torch.Generator().manual_seed(B * N + K)
+    P = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(dev())
+    X = torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=2).to(dev())
+    logits = (torch.randn(B, N, K, generator=g) * 2).to(dev())
+    gp = torch.randn(B, K, 22, generator=g).to(dev())
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(moments, "PARAMS_BWD_FUSED", fused)
+        W = torch.softmax(logits, 2).requires_grad_(True)
+        Xr = X.clone().requires_grad_(True)
+        _l.byte_census(True)
+        params = fc.fit_params(P, W, Xr)
+        params.backward(gp)
+        census = _l.byte_census(False)
+        assert ("cpfn_fit_pack_bwd" in census) == (not fused), sorted(census)
+        res[fused] = (params.detach(), W.grad, Xr.grad)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert float(res[True][1].abs().max()) > 0 and bool(torch.isfinite(res[True][1]).all())
+
+
 @pytest.mark.parametrize("B,N,n_prims,K", [(1, 300, 2, 2), (3, 1000, 5, 7), (2, 5000, 9, 12), (1, 8192, 10, 33), (1, 4097, 12, 64)])
 def test_shape_sweep_vs_oracle(B, N, n_prims, K):
     """Ragged sizes and instance counts from 2 to 64 (the moment kernels' limit): points on real primitives with peaky

@@ -26,7 +26,7 @@ ENTRY = {
     "smallk_wgrad_kernel": "cpfn_smallk_wgrad", "colsum_f32_kernel": "cpfn_colsum_f32",
     "csr_gather_sum_kernel": "cpfn_csr_gather_sum_bf16", "group_concat_bf16_kernel": "cpfn_group_concat_bf16",
     "interp_rows_bf16_kernel": "cpfn_interp_rows_bf16", "concat_pos_feats_kernel": "cpfn_concat_pos_feats_bf16",
-    "moments_fwd_kernel": "cpfn_fit_moments_fwd", "moments_bwd_kernel": "cpfn_fit_moments_bwd",
+    "moments_fwd_kernel": "cpfn_fit_moments_fwd", "fit_params_bwd_algebra_kernel": "cpfn_fit_algebra_bwd", "moments_bwd_kernel": "cpfn_fit_moments_bwd",
     "cone_fwd_kernel": "cpfn_cone_pass_fwd", "cone_bwd_kernel": "cpfn_cone_pass_bwd",
     "fit_algebra_fwd_kernel": "cpfn_fit_algebra_fwd", "fit_algebra_bwd_kernel": "cpfn_fit_algebra_bwd",
     "fit_pack_fwd_kernel": "cpfn_fit_pack_fwd", "fit_pack_bwd_kernel": "cpfn_fit_pack_bwd",
