@@ -8,6 +8,8 @@ SLOTS = 52
 # FitParams.backward as 3 launches (cpfn_fit_params_bwd_cone / _algebra, cpfn_fit_moments_bwd) instead of 5; False: the
 # separate pack adjoint and chunk reduction (kept for the bit-identity test)
 PARAMS_BWD_FUSED = True
+# FitParams.forward: the moments' chunk reduction folded into the algebra launch (cpfn_fit_moments_algebra_fwd)
+PARAMS_FWD_FUSED = True
 # slot map of include/cpfn_hip.h
 A0, AP, APP, AX, AXX = 0, slice(1, 4), slice(4, 10), slice(10, 13), slice(13, 19)
 B0, BP, BPP, BPPP, BXX, BXPX = 20, slice(21, 24), slice(24, 30), slice(30, 40), slice(40, 46), slice(46, 49)
@@ -178,14 +180,19 @@ class FitParams(torch.autograd.Function):
         G = B * K
         with torch.cuda.device(dev):
             st = _stream()
-            rider = _take_match_rider(B, K)
-            if rider is not None:       # the loss section's assignment as extra workgroups of the moments launch
-                S, n_gt, match = rider
-                _l.check(h.cpfn_fit_moments_fwd_match(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), _ptr(S), _ptr(n_gt),
-                                                      _ptr(match), st), "cpfn_fit_moments_fwd_match")
+            rider = _take_match_rider(B, K)      # the loss section's assignment as extra workgroups of the moments launch
+            S, n_gt, match = rider if rider is not None else (None, None, None)
+            if PARAMS_FWD_FUSED:        # the moments' chunk reduction inside the algebra launch
+                _l.check(h.cpfn_fit_moments_algebra_fwd(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), _ptr(alg),
+                                                        _ptr(cone_in), _ptr(S), _ptr(n_gt), _ptr(match), st),
+                         "cpfn_fit_moments_algebra_fwd")
             else:
-                _l.check(h.cpfn_fit_moments_fwd(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), st), "cpfn_fit_moments_fwd")
-            _l.check(h.cpfn_fit_algebra_fwd(_ptr(M), G, _ptr(alg), _ptr(cone_in), st), "cpfn_fit_algebra_fwd")
+                if rider is not None:
+                    _l.check(h.cpfn_fit_moments_fwd_match(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), _ptr(S),
+                                                          _ptr(n_gt), _ptr(match), st), "cpfn_fit_moments_fwd_match")
+                else:
+                    _l.check(h.cpfn_fit_moments_fwd(_ptr(P), _ptr(X), _ptr(W), B, N, K, _ptr(ws), _ptr(M), st), "cpfn_fit_moments_fwd")
+                _l.check(h.cpfn_fit_algebra_fwd(_ptr(M), G, _ptr(alg), _ptr(cone_in), st), "cpfn_fit_algebra_fwd")
             # (the cone pass leaves its per-chunk partials in ws; the pack launch sums them: 3 launches, not 4)
             _l.check(h.cpfn_cone_pass_fwd(_ptr(P), _ptr(W), _ptr(cone_in[0]), _ptr(cone_in[1]), B, N, K, _ptr(ws), None, st),
                      "cpfn_cone_pass_fwd")

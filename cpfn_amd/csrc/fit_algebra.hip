@@ -19,6 +19,7 @@
 // arg-max, clamps) carry zero tangent exactly like the reference's detach()/argmax/clamp.
 #include "common.h"
 #include "fit_pack.h"
+#include "fit_internal.h"
 
 namespace {
 
@@ -320,6 +321,45 @@ __global__ __launch_bounds__(256) void fit_algebra_fwd_kernel(const double *__re
   });
 }
 
+// The chunk reduction of the moments pass and the algebra in ONE launch (the packed-parameter path): a workgroup owns
+// FR_INST instances; its 256 lanes first sum the per-chunk partials of those instances' 52 moments in chunk order (the
+// bits of chunk_reduce_kernel; 16 loads in flight per lane), leave M in global memory and in LDS, and then wave p, lane
+// l < FR_INST fits primitive type p of instance l.  The separate reduction was a 5 us launch plus its boundary, and 64
+// instances per wave made the Jacobi sweeps of all of them wait for the slowest.
+constexpr int FR_INST = 4;
+__global__ __launch_bounds__(256) void reduce_algebra_fwd_kernel(const double *__restrict__ partial, int nchunks, int K,
+                                                                 long long G, double *__restrict__ Mout,
+                                                                 double *__restrict__ out, float *__restrict__ apex_axis32) {
+  __shared__ double s_M[FR_INST][NM];
+  const int t = threadIdx.x;
+  const long long g0 = (long long)blockIdx.x * FR_INST;
+  if (t < FR_INST * NM) {
+    const int l = t / NM, slot = t - l * NM;
+    const long long g = g0 + l;
+    if (g < G) {
+      const long long b = g / K;
+      const size_t per_b = (size_t)K * NM;
+      const double *src = partial + (size_t)b * nchunks * per_b + (size_t)(g - b * K) * NM + slot;
+      double s = 0.0;
+#pragma unroll 16
+      for (int c = 0; c < nchunks; ++c) s += src[(size_t)c * per_b];
+      s_M[l][slot] = s;
+      Mout[g * NM + slot] = s;
+    }
+  }
+  __syncthreads();
+  const int part = t >> 6, l = t & 63;
+  const long long g = g0 + l;
+  if (l >= FR_INST || g >= G) return;
+  double m[NM];
+  for (int i = 0; i < NM; ++i) m[i] = s_M[l][i];
+  fit_part<double>(part, m, [&](int i, double oi) {
+    out[g * NO + i] = oi;
+    if (apex_axis32 && i >= 15)   // fp32 copy of the cone pass's inputs: apex[G,3] then axis[G,3]
+      apex_axis32[(i >= 18 ? (G + g) * 3 + (i - 18) : g * 3 + (i - 15))] = (float)oi;
+  });
+}
+
 // one workgroup per instance, 4 waves: wave p, lane d < 52 computes the part-p share of dL/dM[g,d] by forward-mode
 // AD through fit p; the four shares are added in a fixed order
 __global__ __launch_bounds__(256) void fit_algebra_bwd_kernel(const double *__restrict__ M,
@@ -396,6 +436,13 @@ __global__ __launch_bounds__(256) void fit_params_bwd_algebra_kernel(const doubl
 }
 
 }  // namespace
+
+int cpfn_launch_reduce_algebra_fwd(const double *partial, int chunks, int B, int K, double *M, double *out, float *apex_axis32,
+                                   hipStream_t stream) {
+  const long long G = (long long)B * K;
+  reduce_algebra_fwd_kernel<<<(unsigned)cpfn_cdiv(G, FR_INST), 256, 0, stream>>>(partial, chunks, K, G, M, out, apex_axis32);
+  return cpfn_launch_status();
+}
 
 extern "C" int cpfn_fit_params_bwd_algebra(const double *M, const float *gparams, const double *sums, const double *cone_workspace,
                                            int chunks, int B, int K, float *gM32, void *stream) {

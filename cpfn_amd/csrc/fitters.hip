@@ -27,6 +27,7 @@
 #include "common.h"
 #include "lsap.h"
 #include "fit_pack.h"
+#include "fit_internal.h"
 
 namespace {
 
@@ -624,6 +625,26 @@ extern "C" int cpfn_fit_moments_fwd_match(const float *P, const float *X, const 
                                           void *stream) {
   if (!S || !n_gt || !match || K > LSAP_MAXK) return CPFN_EINVAL;
   return fit_moments_fwd(P, X, W, B, N, K, workspace, M, S, n_gt, match, stream);
+}
+
+// The moments pass (with the assignment riding on it when S is given) followed by ONE launch that sums the per-chunk
+// partials and runs the per-instance algebra (cpfn_fit_moments_fwd[_match] + cpfn_fit_algebra_fwd, a launch less; same
+// bits).  alg[B*K,21]; apex_axis32 as in cpfn_fit_algebra_fwd.
+extern "C" int cpfn_fit_moments_algebra_fwd(const float *P, const float *X, const float *W, int B, int N, int K,
+                                            double *workspace, double *M, double *alg, float *apex_axis32, const float *S,
+                                            const int64_t *n_gt, int64_t *match, void *stream) {
+  if (B < 0 || N <= 0 || K <= 0 || !P || !X || !W || !workspace || !M || !alg) return CPFN_EINVAL;
+  if (S && (!n_gt || !match || K > LSAP_MAXK)) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int ppb;
+  const int chunks = pick_chunks(B, N, &ppb);
+  if (S)
+    moments_fwd_kernel<true><<<dim3(chunks + 1, B), FM_THREADS, 0, st>>>(P, X, W, N, K, ppb, workspace, S, (const long long *)n_gt,
+                                                                         (long long *)match);
+  else
+    moments_fwd_kernel<false><<<dim3(chunks, B), FM_THREADS, 0, st>>>(P, X, W, N, K, ppb, workspace, nullptr, nullptr, nullptr);
+  return cpfn_launch_reduce_algebra_fwd(workspace, chunks, B, K, M, alg, apex_axis32, st);
 }
 
 extern "C" int cpfn_fit_moments_bwd(const float *P, const float *X, const float *W, const float *G, int B,

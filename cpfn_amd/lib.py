@@ -59,6 +59,7 @@ SIGNATURES = {
     "cpfn_cone_pass_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "cpfn_fit_algebra_fwd": [_vp, _i64, _vp, _vp, _vp],
     "cpfn_fit_algebra_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "cpfn_fit_moments_algebra_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_fit_params_bwd_cone": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_fit_params_bwd_algebra": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "cpfn_fit_pack_fwd": [_vp, _vp, _vp, _i64, _vp, _vp],

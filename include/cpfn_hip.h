@@ -285,6 +285,11 @@ CPFN_API int cpfn_fit_algebra_bwd(const double *M, const double *gout, const dou
  * g_acos[G] fp32 (for cpfn_cone_pass_bwd) and gA0[G] (for cpfn_fit_algebra_bwd). */
 CPFN_API int cpfn_fit_pack_fwd(const double *alg, const double *sums, const double *M, int64_t G,
                                float *params, void *stream);
+/* cpfn_fit_moments_fwd (or _fwd_match when S is not NULL) + cpfn_fit_algebra_fwd with the chunk reduction of the first
+ * folded into the second: two launches instead of three, the same M[B*K,52], alg[B*K,21] and apex_axis32. */
+CPFN_API int cpfn_fit_moments_algebra_fwd(const float *P, const float *X, const float *W, int B, int N, int K,
+                                          double *workspace, double *M, double *alg, float *apex_axis32,
+                                          const float *S, const int64_t *n_gt, int64_t *match, void *stream);
 /* Backward of the packed parameters as three launches instead of five (cone pass adjoint, algebra adjoint, then
  * cpfn_fit_moments_bwd): _cone derives g_acos from gparams[G,22] itself (cpfn_fit_pack_bwd's rule) and leaves the per-chunk
  * partials of d(apex, axis) in workspace (cpfn_fit_num_chunks * B * K * 6 doubles); _algebra sums them in chunk order

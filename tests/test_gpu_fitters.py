@@ -152,6 +152,7 @@ def test_packed_parameters_backward_in_three_launches(B, N, K, monkeypatch):
     res = {}
     for fused in (True, False):
         monkeypatch.setattr(moments, "PARAMS_BWD_FUSED", fused)
+        monkeypatch.setattr(moments, "PARAMS_FWD_FUSED", fused)      # (+ the forward's chunk reduction inside the algebra launch)
         W = torch.softmax(logits, 2).requires_grad_(True)
         Xr = X.clone().requires_grad_(True)
         _l.byte_census(True)
