@@ -216,6 +216,27 @@ def test_device_assignment_matches_scipy():
     assert params0 is None and np.array_equal(match0.cpu().numpy(), got)
 
 
+def test_device_assignment_gives_up_on_non_finite_costs():
+    """NaN / inf in the segmented sums (SciPy raises "matrix contains invalid numeric entries"): the device solver must not
+    spin or read outside its tables — it returns the identity for that cloud's GT rows, and solves the other clouds."""
+    from cpfn_amd.SPFN import fused_losses as fl
+    rng = np.random.default_rng(9)
+    B, N, K = 4, 512, 28
+    I = rng.integers(0, K, (B, N))
+    I[:, :K] = np.arange(K)
+    W = rng.random((B, N, K)).astype(np.float32)
+    W /= W.sum(2, keepdims=True)
+    Wd, Id = torch.from_numpy(W).to(dev()), torch.from_numpy(I).to(dev())
+    S = fl.SegStats.apply(Wd, Id).clone()
+    n_gt = fl.count_gt(Id)
+    good = fl.hungarian_device(S, n_gt).cpu().numpy()
+    S[1, 3, 5] = float("nan")
+    S[2, 0, 0] = float("inf")
+    got = fl.hungarian_device(S, n_gt).cpu().numpy()
+    assert np.array_equal(got[0], good[0]) and np.array_equal(got[3], good[3])
+    assert np.array_equal(got[1], np.arange(K)) and np.array_equal(got[2], np.arange(K))
+
+
 def test_heads_gradient_hint_is_bit_identical_to_the_colsum_launch(monkeypatch):
     """The heads post-processing backward (cpfn_head_post_bwd) also leaves what the fc2 heads' backward makes of its result
     first — zero-padded bf16 rows and per-256-row column sums — so that cpfn_colsum_f32 is not launched: every parameter
