@@ -25,7 +25,7 @@ def hungarian_matching(W_pred, I_gt):
     B, N, K = W_pred.shape
     S = _fl.SegStats.apply(W_pred.detach().float(), I_gt)
     n_gt = _fl.count_gt(I_gt)
-    if _fl.HOST_ASSIGNMENT or K > 32:
+    if _fl.HOST_ASSIGNMENT or K > 64:       # (the device solver: one lane per column)
         match = _fl.hungarian_from_pack(_fl.hungarian_cost_pack(S, I_gt, n_gt), K)
     else:
         match = _fl.hungarian_device(S, n_gt)

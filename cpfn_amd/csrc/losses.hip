@@ -667,7 +667,8 @@ __global__ void p_coverage_reduce_kernel(const float *__restrict__ partial, int 
 // (solver: lsap.h)
 __global__ __launch_bounds__(64) void lsap_kernel(const float *__restrict__ S, const long long *__restrict__ n_gt, int K,
                                                   long long *__restrict__ match) {
-  lsap_one_cloud(S, n_gt, K, match, blockIdx.x, threadIdx.x);
+  if (K <= LSAP_MAXK) lsap_one_cloud<LSAP_MAXK>(S, n_gt, K, match, blockIdx.x, threadIdx.x);
+  else lsap_one_cloud<LSAP_WIDE_MAXK>(S, n_gt, K, match, blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ loss tail
@@ -859,7 +860,7 @@ extern "C" int cpfn_loss_tail(const float *S, const float *rp, const float *nl, 
 }
 
 extern "C" int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, int K, int64_t *match, void *stream) {
-  if (B < 0 || K <= 0 || K > MAXK || !S || !n_gt || !match) return CPFN_EINVAL;
+  if (B < 0 || K <= 0 || K > LSAP_WIDE_MAXK || !S || !n_gt || !match) return CPFN_EINVAL;
   if (B == 0) return 0;
   lsap_kernel<<<B, 64, 0, (hipStream_t)stream>>>(S, (const long long *)n_gt, K, (long long *)match);
   return cpfn_launch_status();

@@ -4,7 +4,8 @@
 #include "common.h"
 
 namespace {
-constexpr int LSAP_MAXK = 32;      // instances per cloud (28 global / 21 local)
+constexpr int LSAP_MAXK = 32;      // instances per cloud of the fused loss kernels and of the solver riding on the fits (28 global / 21 local)
+constexpr int LSAP_WIDE_MAXK = 64; // ... of the solver as its own launch (one lane per column): merged label sets of the evaluation cascade
 
 // Cost as the reference builds it in fp32: D / clamp(cnt + col - D, 1e-10), negated for maximisation.
 //
@@ -53,9 +54,10 @@ __device__ __forceinline__ int lsap_wave_max_i32(int x) {
 
 // One cloud, ONE wave (lanes 0..63 of the calling workgroup; every other wave of it must have left before the call: the
 // workgroup barrier inside then counts this wave alone).
+template <int MAXK = LSAP_MAXK>
 __device__ __forceinline__ void lsap_one_cloud(const float *__restrict__ S, const long long *__restrict__ n_gt, int K,
                                                long long *__restrict__ match, int b, int lane) {
-  constexpr int MAXK = LSAP_MAXK;
+  static_assert(MAXK <= 64, "one lane per column");
   __shared__ double s_cost[MAXK][MAXK + 1];
   const int nc = K;
   long long nn = n_gt[b];

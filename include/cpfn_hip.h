@@ -561,7 +561,8 @@ CPFN_API int cpfn_residue_bwd(const float *gout, const float *dout, const int64_
  * SPFN/losses_implementation.py:10-30, scipy.optimize.linear_sum_assignment(-cost) per cloud):
  * S[B,K+2,K] from cpfn_seg_stats_fwd, n_gt[B] = number of GT instances -> match[B,K] int64 (zeros
  * beyond n_gt).  Same solver as SciPy 1.15 (Crouse's shortest augmenting path, fp64), same tie
- * breaking, hence the same matching.  K <= 32.  Costs must be finite (SciPy raises on NaN/inf). */
+ * breaking, hence the same matching.  K <= 64 (one lane per column; merged label sets of the evaluation
+ * cascade).  Non-finite costs (SciPy raises): the cloud's rows get the identity. */
 CPFN_API int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, int K, int64_t *match,
                                   void *stream);
 /* Evaluation metric "P coverage" (SPFN/metric_implementation.py:409-415): out[b, i] = fraction of the N
