@@ -245,6 +245,30 @@ def test_device_assignment_on_merged_label_sets(K):
     assert np.array_equal(got, lsap.hungarian_from_stats(S.cpu().numpy(), n_gt.cpu().numpy()))
 
 
+@pytest.mark.parametrize("K,levels", [(28, 3), (28, 0), (64, 2), (7, 2)])
+def test_device_assignment_many_random_and_tie_heavy_problems(K, levels):
+    """256 assignment problems per case straight on the segmented sums S (no point clouds): random counts, quantised to a
+    few integer levels so that equal costs abound (levels > 0), random numbers of GT instances — against the oracle's
+    restatement of SciPy's solver (pinned against SciPy itself in the CPU suite), which must agree on EVERY optimal
+    assignment it picks, ties included."""
+    from cpfn_amd.SPFN import fused_losses as fl
+    from oracle import lsap
+    rng = np.random.default_rng(100 * K + levels)
+    B = 256
+    S = np.zeros((B, K + 2, K), dtype=np.float32)
+    n_gt = rng.integers(0, K + 1, B).astype(np.int64)
+    n_gt[:8] = K
+    for b in range(B):
+        D = rng.random((K, K)) * 50 if levels == 0 else rng.integers(0, levels + 1, (K, K)) * 10.0
+        S[b, :K] = D                                   # sum_n [I = l] W[n, k]
+        S[b, K] = D.sum(0) + rng.integers(0, 3, K) * (10.0 if levels else 1.0)   # sum_n W[n, k]  (>= the labelled part)
+        S[b, K + 1] = np.maximum(D.sum(1) / 10.0, 1.0).round()                    # points per label
+    Sd = torch.from_numpy(S).to(dev())
+    got = fl.hungarian_device(Sd, torch.from_numpy(n_gt).to(dev())).cpu().numpy()
+    want = lsap.hungarian_from_stats(S, n_gt)
+    assert np.array_equal(got, want), int((got != want).any(1).sum())
+
+
 def test_device_assignment_gives_up_on_non_finite_costs():
     """NaN / inf in the segmented sums (SciPy raises "matrix contains invalid numeric entries"): the device solver must not
     spin or read outside its tables — it returns the identity for that cloud's GT rows, and solves the other clouds."""
