@@ -341,6 +341,31 @@ __device__ __forceinline__ ConeTerm cone_term(const float *p, const float *apex,
   return r;
 }
 
+// A 64-point tile of coordinates and memberships on its way to LDS: requested into registers one tile AHEAD (round 3; the
+// first version loaded straight into LDS between two barriers, i.e. one exposed global latency per tile, four per workgroup).
+struct ConeStage { float p, w[FM_TILE * FM_KB / FM_THREADS]; };
+__device__ __forceinline__ void cone_fetch(ConeStage &st, const float *__restrict__ P, const float *__restrict__ W, int b, int N,
+                                           int K, int kb, int base, int n1, int t) {
+  st.p = 0.f;
+  if (t < FM_TILE * 3) {
+    const int i = t / 3, c = t % 3;
+    if (base + i < n1) st.p = P[((size_t)b * N + base + i) * 3 + c];
+  }
+#pragma unroll
+  for (int u = 0; u < FM_TILE * FM_KB / FM_THREADS; ++u) {
+    const int e = t + u * FM_THREADS, i = e / FM_KB, k2 = kb + e % FM_KB;
+    st.w[u] = (base + i < n1 && k2 < K) ? W[((size_t)b * N + base + i) * K + k2] : 0.f;
+  }
+}
+__device__ __forceinline__ void cone_store(const ConeStage &st, float (*s_p)[3], float (*s_w)[FM_KB], int t) {
+  if (t < FM_TILE * 3) s_p[t / 3][t % 3] = st.p;
+#pragma unroll
+  for (int u = 0; u < FM_TILE * FM_KB / FM_THREADS; ++u) {
+    const int e = t + u * FM_THREADS;
+    s_w[e / FM_KB][e % FM_KB] = st.w[u];
+  }
+}
+
 template <int NV>
 __device__ __forceinline__ void cone_block_reduce(double (*s_red)[FM_KB][NV], const double *v, int sub, int kk,
                                                   int k, int K, double *out_row) {
@@ -374,17 +399,13 @@ __global__ __launch_bounds__(FM_THREADS) void cone_fwd_kernel(const float *__res
       for (int j = 0; j < 3; ++j) { ap[j] = apex[((size_t)b * K + k) * 3 + j]; ax[j] = axis[((size_t)b * K + k) * 3 + j]; }
     }
     double acc[2] = {0.0, 0.0};  // Σ w·dot, Σ w·acos(clamp|dot|)
+    ConeStage stg;
+    cone_fetch(stg, P, W, b, N, K, kb, n0, n1, t);
     for (int base = n0; base < n1; base += FM_TILE) {
       __syncthreads();
-      if (t < FM_TILE * 3) {
-        const int i = t / 3, c = t % 3;
-        s_p[i][c] = (base + i < n1) ? P[((size_t)b * N + base + i) * 3 + c] : 0.f;
-      }
-      for (int e = t; e < FM_TILE * FM_KB; e += FM_THREADS) {
-        const int i = e / FM_KB, k2 = kb + e % FM_KB;
-        s_w[i][e % FM_KB] = (base + i < n1 && k2 < K) ? W[((size_t)b * N + base + i) * K + k2] : 0.f;
-      }
+      cone_store(stg, s_p, s_w, t);
       __syncthreads();
+      if (base + FM_TILE < n1) cone_fetch(stg, P, W, b, N, K, kb, base + FM_TILE, n1, t);   // in flight during this tile's loop
       float a0 = 0.f, a1 = 0.f;
       for (int i = sub; i < FM_TILE; i += CP_SUB) {
         const ConeTerm r = cone_term(s_p[i], ap, ax);
@@ -429,17 +450,13 @@ __global__ __launch_bounds__(FM_THREADS) void cone_bwd_kernel(const float *__res
                   : g_acos[gi];
     }
     double acc[6] = {0, 0, 0, 0, 0, 0};  // d apex (3), d axis (3)
+    ConeStage stg;
+    cone_fetch(stg, P, W, b, N, K, kb, n0, n1, t);
     for (int base = n0; base < n1; base += FM_TILE) {
       __syncthreads();
-      if (t < FM_TILE * 3) {
-        const int i = t / 3, c = t % 3;
-        s_p[i][c] = (base + i < n1) ? P[((size_t)b * N + base + i) * 3 + c] : 0.f;
-      }
-      for (int e = t; e < FM_TILE * FM_KB; e += FM_THREADS) {
-        const int i = e / FM_KB, k2 = kb + e % FM_KB;
-        s_w[i][e % FM_KB] = (base + i < n1 && k2 < K) ? W[((size_t)b * N + base + i) * K + k2] : 0.f;
-      }
+      cone_store(stg, s_p, s_w, t);
       __syncthreads();
+      if (base + FM_TILE < n1) cone_fetch(stg, P, W, b, N, K, kb, base + FM_TILE, n1, t);   // in flight during this tile's loop
       float f[6] = {0, 0, 0, 0, 0, 0};
       for (int i = sub; i < FM_TILE; i += CP_SUB) {
         const int n = base + i;
