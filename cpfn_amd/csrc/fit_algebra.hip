@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void fit_algebra_fwd_kernel(const double *__re
 
 // The chunk reduction of the moments pass and the algebra in ONE launch (the packed-parameter path): a workgroup owns
 // FR_INST instances; its 256 lanes first sum the per-chunk partials of those instances' 52 moments in chunk order (the
-// bits of chunk_reduce_kernel; 16 loads in flight per lane), leave M in global memory and in LDS, and then wave p, lane
+// bits of chunk_reduce_kernel; 32 loads in flight per lane), leave M in global memory and in LDS, and then wave p, lane
 // l < FR_INST fits primitive type p of instance l.  The separate reduction was a 5 us launch plus its boundary, and 64
 // instances per wave made the Jacobi sweeps of all of them wait for the slowest.
 constexpr int FR_INST = 4;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void reduce_algebra_fwd_kernel(const double *_
       const size_t per_b = (size_t)K * NM;
       const double *src = partial + (size_t)b * nchunks * per_b + (size_t)(g - b * K) * NM + slot;
       double s = 0.0;
-#pragma unroll 16
+#pragma unroll 32
       for (int c = 0; c < nchunks; ++c) s += src[(size_t)c * per_b];
       s_M[l][slot] = s;
       Mout[g * NM + slot] = s;

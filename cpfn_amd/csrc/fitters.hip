@@ -577,7 +577,7 @@ __global__ void fit_pack_fwd_partials_kernel(const double *__restrict__ alg, con
   const long long b = g / K;
   const int k = (int)(g - b * K);
   double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
+#pragma unroll 32          // (all of a 16 x 8192 step's 32 chunks in flight at once: the loop is load latency per trip)
   for (int c = 0; c < chunks; ++c) {
     const double *w = cone_ws + ((size_t)b * chunks + c) * K * 2 + k * 2;
     s0 += w[0];

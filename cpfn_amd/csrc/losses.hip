@@ -153,7 +153,7 @@ __global__ void head_post_finish_kernel(const float *__restrict__ partial, const
   if (e < total) {
     const long long b = e / per_b, r = e % per_b;
     float s = 0.f;
-#pragma unroll 8
+#pragma unroll 32
     for (int c = 0; c < chunks; ++c) s += seg_partial[((size_t)b * chunks + c) * per_b + r];
     S[e] = s;
     return;
