@@ -1806,21 +1806,26 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       if constexpr (CHB == 8 || CHB == 4) {
         // ---- data gradient of the same rows: this wave's output channels 16 cb .. +15 of rows 16 rb0 .. +31 (two tiles
         //      that share the weight fragment)
-        const int cb = wave % CHB, rb0 = (wave / CHB) * 2;
-        f32x4 ad[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        //      (the 8 waves cover CHB column blocks x 8 / CHB row-tile pairs per trip: one trip for 32 x 128 and 64 x 64,
+        //       two for the heads' 64-row step of 128 channels)
+        const int cb = wave % CHB;
 #pragma unroll
-        for (int ks = 0; ks < TN / 32; ++ks) {
-          const bf16x8 pf0 = *(const bf16x8 *)&s_g[(rb0 * 16 + lr) * LDN + ks * 32 + 8 * lq];
-          const bf16x8 pf1 = *(const bf16x8 *)&s_g[(rb0 * 16 + 16 + lr) * LDN + ks * 32 + 8 * lq];
-          const bf16x8 wf = *(const bf16x8 *)&s_wt[(cb * 16 + lr) * LDN + ks * 32 + 8 * lq];
-          ad[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[0], 0, 0, 0);
-          ad[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[1], 0, 0, 0);
-        }
+        for (int rb0 = (wave / CHB) * 2; rb0 < STEP / 16; rb0 += (8 / CHB) * 2) {
+          f32x4 ad[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const f32x4 v = ad[tt];
-          const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-          *(bf16x4 *)&s_o[((rb0 + tt) * 16 + lr) * LDK + cb * 16 + 4 * lq] = ov;
+          for (int ks = 0; ks < TN / 32; ++ks) {
+            const bf16x8 pf0 = *(const bf16x8 *)&s_g[(rb0 * 16 + lr) * LDN + ks * 32 + 8 * lq];
+            const bf16x8 pf1 = *(const bf16x8 *)&s_g[(rb0 * 16 + 16 + lr) * LDN + ks * 32 + 8 * lq];
+            const bf16x8 wf = *(const bf16x8 *)&s_wt[(cb * 16 + lr) * LDN + ks * 32 + 8 * lq];
+            ad[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf0, ad[0], 0, 0, 0);
+            ad[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, pf1, ad[1], 0, 0, 0);
+          }
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const f32x4 v = ad[tt];
+            const bf16x4 ov = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *(bf16x4 *)&s_o[((rb0 + tt) * 16 + lr) * LDK + cb * 16 + 4 * lq] = ov;
+          }
         }
       } else {
         // ---- (TK = 192: 2 x 12 tiles of 16 x 16) tile q = wave + 8 i of the slab
@@ -2590,7 +2595,8 @@ extern "C" int cpfn_mlp_wgrad_apply_ok(long long P, int N, int K) {
 }
 
 extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
-  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128);
+  const bool shape = (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 128 && K == 64) || (N == 256 && K == 128) ||
+                     (N == 64 && K == 128);      // (64 <- 128: the fc2 heads, padded to 64 outputs; linear: no apply pass)
   return shape && P > SP_MAX_ROWS && P >= 32768;
 }
 
@@ -2607,7 +2613,7 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
     return CPFN_EINVAL;
   if (apply_y && ldg != N) return CPFN_EINVAL;     // (the kernel walks apply_y with the gradient's row stride)
   if ((drop_seed && (!apply_y || pool_k > 0 || !(drop_p >= 0.f && drop_p < 1.f))) || pool_k < 0) return CPFN_EINVAL;
-  const int step = K >= 128 ? 32 : 64;
+  const int step = (K >= 128 && N != 64) ? 32 : 64;
   // xyz tail (three fp32 coordinate channels beside the K bf16 ones; sa2's first layer): the 128 -> 128 shape with the dense
   // apply pass and no layer below
   if ((!xt_xyz) != (!xt_partial)) return CPFN_EINVAL;
@@ -2653,7 +2659,10 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
                                                                              probe_slot_all(grid));
   else if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
   else if (N == 256) CPFN_BWD_FUSED_SHAPE(256, 128, 32);
-  else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
+  else if (N == 64 && K == 128) {
+    if (bwd_y || mode != 0) return CPFN_EINVAL;          // (heads: plain linear layer, nothing rides)
+    CPFN_BWD_FUSED(64, 128, 64, false, 0);
+  } else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
   else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
 #undef CPFN_BWD_FUSED_SHAPE
 #undef CPFN_BWD_FUSED

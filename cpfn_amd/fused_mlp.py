@@ -51,6 +51,8 @@ XYZ_RECOMPUTE = True
 XYZ_TAIL = True
 #   SMALL_BWD_MERGED  a small layer's weight gradient and data gradient as ONE launch (cpfn_mlp_bwd_small); False: two launches
 SMALL_BWD_MERGED = True
+#   HEADS_ONE_PASS    the packed fc2 heads' weight gradient and data gradient as one launch (cpfn_mlp_bwd_fused, 64 <- 128)
+HEADS_ONE_PASS = True
 
 
 def _pad_to(n, m):
@@ -799,11 +801,20 @@ class _Linear(torch.autograd.Function):
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
             dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
-            _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), None, _stream()),
-                   "cpfn_mlp_wgrad")
+            if HEADS_ONE_PASS and FUSED_BWD and Np == 64 and h.cpfn_mlp_bwd_fused_ok(P, Np, K):
+                # weight gradient and data gradient of the packed heads in ONE pass over their gradient rows (the one-pass
+                # kernel's 64 <- 128 shape, linear: nothing to apply, nothing rides)
+                ga = torch.empty(P, K, dtype=BF16, device=a.device)
+                _check(h.cpfn_mlp_bwd_fused(_ptr(gb), Np, _ptr(a), a.stride(0), _ptr(Wb), P, Np, K, None, None, _ptr(ws), _ptr(ga), K,
+                                            None, None, None, None, None, None, None, None, None, 0.0, None, None, 0, None, None,
+                                            _stream()), "cpfn_mlp_bwd_fused")
+                _l.add_bytes("cpfn_mlp_bwd_fused", 2 * P * Np + 4 * P * K + 4 * splits * Np * K + 2 * Np * K)
+            else:
+                _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), None, _stream()),
+                       "cpfn_mlp_wgrad")
+                _l.add_bytes("cpfn_mlp_wgrad", 2 * P * Np + 2 * P * K + 8 * splits * Np * K)
+                ga, _, _ = gemm(gb, Wb, w_trans=True)
             _defer_reduction(ws, dW, Np * K, splits, params=ctx.heads)
-            _l.add_bytes("cpfn_mlp_wgrad", 2 * P * Np + 2 * P * K + 8 * splits * Np * K)
-            ga, _, _ = gemm(gb, Wb, w_trans=True)
         gw, gbs, o = [], [], 0
         for n, shp in zip(ctx.sizes, ctx.wshapes):
             gw.append(dW[o:o + n].reshape(shp))

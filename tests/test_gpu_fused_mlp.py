@@ -185,6 +185,35 @@ def test_heads_linear():
     assert _rel(f2.grad, gx_ref) < 3e-2
 
 
+@pytest.mark.parametrize("P", [131072, 40000 + 8])
+def test_heads_backward_in_one_pass(P, monkeypatch):
+    """The packed heads' backward through the one-pass kernel's 64 <- 128 shape (weight gradient partials and data gradient
+    from ONE pass over the gradient rows) against cpfn_mlp_wgrad + the transposed GEMM: the same bits."""
+    from cpfn_amd import fused_mlp, lib as _l
+    torch.manual_seed(2)
+    ws = [torch.nn.Parameter(torch.randn(n, 128, 1, device=dev()) * 0.1) for n in (3, 4, 28)]
+    bs = [torch.nn.Parameter(torch.randn(n, device=dev()) * 0.1) for n in (3, 4, 28)]
+    g = torch.Generator().manual_seed(P)
+    feat = torch.randn(P, 128, generator=g).to(dev()).to(torch.bfloat16)
+    gout = torch.randn(P, 35, generator=g).to(dev())
+    res = {}
+    for one in (True, False):
+        monkeypatch.setattr(fused_mlp, "HEADS_ONE_PASS", one)
+        for q in ws + bs:
+            q.grad = None
+        f = feat.clone().requires_grad_(True)
+        _l.byte_census(True)
+        outs = fused_mlp.linear_heads(f, ws, bs)
+        (torch.cat(outs, 1) * gout).sum().backward()
+        census = _l.byte_census(False)
+        assert ("cpfn_mlp_bwd_fused" in census) == one and ("cpfn_mlp_wgrad" in census) == (not one), sorted(census)
+        torch.cuda.synchronize()
+        res[one] = (f.grad.clone(), [q.grad.clone() for q in ws + bs])
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("P,K,N", [
     (1, 32, 64), (31, 96, 64), (33, 320, 320), (2048, 1280, 256), (2048, 512, 1024), (4096, 64, 128), (4097, 256, 128),
     (8192, 384, 256), (16384, 128, 64), (16385, 128, 128), (5000, 1056, 192), (40000, 320, 128), (33000, 256, 256),
