@@ -1510,7 +1510,7 @@ struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the
 // no data gradient (coordinates are inputs) and their weight-gradient columns dWx [TN,3] = g_y^T . xyz ride along: the
 // 32 x 3 coordinate tile of a step is staged as bf16 beside the input tile and costs the four waves that own wk = 0 MI MFMAs
 // more per step.
-template <int TN, int TK, int STEP, bool BST, int APPLY, bool XT = false>
+template <int TN, int TK, int STEP, bool BST, int APPLY, bool XT = false, bool BDROP = false>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
     const unsigned short *__restrict__ W /* forward weight panel [TN][TK] bf16 */, long long P, long long rows_per_split,
@@ -1520,6 +1520,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     unsigned long long *probe = nullptr) {
   const unsigned long long probe_t0 = probe_begin(probe);
   const unsigned short *__restrict__ Yr = ap.Yr;
+  // BDROP (with BST, no apply pass: the fc2 heads): the layer BELOW ends in the fused dropout, i.e. the slab leaving here is the
+  // gradient w.r.t. the DROPPED activation — the riding reduction scales it by the mask recomputed from the 8-byte seed, as
+  // bn_relu_bwd_kernel<true> does (that launch, 15 us on the fc1 features, is then not made).
+  static_assert(!BDROP || (BST && APPLY == 0), "the layer below's dropout belongs to the riding reduction of a linear layer");
+  const unsigned long long bdrop_seed = BDROP ? *ap.drop_seed : 0ull;
   // (rows in flight: 128, and 64 for the 256-wide g_y — the same bytes, half the staging registers.  The 64-row-step shapes
   //  are NOT waiting for memory: taking 134 MB of the 64 -> 64 kernel's reads away (recomputing them) saved 2 us of 65, and 256 rows in
   //  flight instead of 128 made both of them 5 % slower (registers); their apply / statistics / conversion VALU work and
@@ -1737,9 +1742,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
         if (BST) {
           const uint4 ybv = yb[i];
           const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {ybv.x, ybv.y, ybv.z, ybv.w};
+          float df[8];
+          if (BDROP) dropout_factors(bdrop_seed, (unsigned long long)((p * ldo + acol) >> 3), ap.thresh16, ap.inv_keep, df);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float g0 = __uint_as_float(g4[j] << 16), g1 = __uint_as_float(g4[j] & 0xffff0000u);
+            float g0 = __uint_as_float(g4[j] << 16), g1 = __uint_as_float(g4[j] & 0xffff0000u);
+            if (BDROP) { g0 *= df[2 * j]; g1 *= df[2 * j + 1]; }
             const float y0 = __uint_as_float(y4[j] << 16), y1 = __uint_as_float(y4[j] & 0xffff0000u);
             const float z0 = fmaf(bsc[2 * j], y0, bsh[2 * j]) > 0.f ? g0 : 0.f;
             const float z1 = fmaf(bsc[2 * j + 1], y1, bsh[2 * j + 1]) > 0.f ? g1 : 0.f;
@@ -2612,7 +2620,11 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
       (apply_y && (!apply_coef || !y_scale || !y_shift)))
     return CPFN_EINVAL;
   if (apply_y && ldg != N) return CPFN_EINVAL;     // (the kernel walks apply_y with the gradient's row stride)
-  if ((drop_seed && (!apply_y || pool_k > 0 || !(drop_p >= 0.f && drop_p < 1.f))) || pool_k < 0) return CPFN_EINVAL;
+  // drop_seed: with apply_y the layer's OWN fused dropout (fc1); without it — the 64 <- 128 heads shape only, with bwd_y — the
+  // dropout of the layer BELOW, whose output feeds this linear layer (its mask scales the riding reduction)
+  const bool below_drop = drop_seed && !apply_y && bwd_y && N == 64 && K == 128;
+  if ((drop_seed && !below_drop && (!apply_y || pool_k > 0)) || (drop_seed && !(drop_p >= 0.f && drop_p < 1.f)) || pool_k < 0)
+    return CPFN_EINVAL;
   const int step = (K >= 128 && N != 64) ? 32 : 64;
   // xyz tail (three fp32 coordinate channels beside the K bf16 ones; sa2's first layer): the 128 -> 128 shape with the dense
   // apply pass and no layer below
@@ -2660,8 +2672,13 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   else if (N == 128 && K == 128) CPFN_BWD_FUSED_SHAPE(128, 128, 32);
   else if (N == 256) CPFN_BWD_FUSED_SHAPE(256, 128, 32);
   else if (N == 64 && K == 128) {
-    if (bwd_y || mode != 0) return CPFN_EINVAL;          // (heads: plain linear layer, nothing rides)
-    CPFN_BWD_FUSED(64, 128, 64, false, 0);
+    if (mode != 0 || (bwd_y && !below_drop)) return CPFN_EINVAL;     // (heads: linear; what may ride is fc1's dropped reduction)
+    if (bwd_y)
+      mlp_bwd_fused_kernel<64, 128, 64, true, 0, false, true><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo,
+                                                                                a_scale, a_shift, yb, b_scale, b_shift,
+                                                                                stats_partial, ap, probe_slot_all(grid));
+    else
+      CPFN_BWD_FUSED(64, 128, 64, false, 0);
   } else if (N == 64 && K == 64) CPFN_BWD_FUSED_SHAPE(64, 64, 64);
   else CPFN_BWD_FUSED_SHAPE(128, 64, 64);
 #undef CPFN_BWD_FUSED_SHAPE

@@ -53,6 +53,10 @@ XYZ_TAIL = True
 SMALL_BWD_MERGED = True
 #   HEADS_ONE_PASS    the packed fc2 heads' weight gradient and data gradient as one launch (cpfn_mlp_bwd_fused, 64 <- 128)
 HEADS_ONE_PASS = True
+#   HEADS_RIDE        ... and that launch also takes pass 1 of the BatchNorm backward of the stack that feeds the heads (fc1, whose
+#                     output ends in the fused dropout: the mask is recomputed on the data-gradient slab) — no cpfn_bn_relu_bwd
+#                     launch on the fc1 features
+HEADS_RIDE = True
 
 
 def _pad_to(n, m):
@@ -478,6 +482,12 @@ class _FusedStack(torch.autograd.Function):
         ctx.P = P
         ctx.drop_seed = drop_seed
         ctx.x_needs_grad = ctx.needs_input_grad[0]
+        global top_ride_offer, top_ride_result
+        top_ride_offer = top_ride_result = None
+        if (HEADS_RIDE and HEADS_ONE_PASS and BWD_STATS_FUSED and drop_seed is not None and not pool_k
+                and any(ctx.needs_input_grad)):
+            # the consumer of `out` (the packed heads) may take pass 1 of this stack's top layer on its data gradient
+            top_ride_offer = (out.data_ptr(), P, layers[-1].cout, saved[-1][2], saved[-1][3], drop_seed, float(cfg["dropout"][0]))
         return out
 
     @staticmethod
@@ -500,6 +510,10 @@ class _FusedStack(torch.autograd.Function):
         g = g.contiguous().to(BF16)
         gx = None
         fused_part = None          # (partials, rows): pass 1 of THIS layer, left by the data gradient of the layer above
+        global top_ride_result
+        ride, top_ride_result = top_ride_result, None
+        if ride is not None and ride[0] == g.data_ptr() and ctx.drop_seed is not None and not pool_k:
+            fused_part = (ride[1], ride[2])    # ... or, for the top layer, by the heads' one-pass launch (HEADS_RIDE)
         a_ptrs = lambda a_ss: (None, None) if a_ss is None else (_ptr(a_ss[0]), _ptr(a_ss[1]))
         with torch.cuda.device(dev):
             for li in range(len(layers) - 1, -1, -1):
@@ -751,6 +765,8 @@ def _packed_heads(weights, biases):
 # (gY address, rows, columns, bf16 rows padded to 64 columns, per-256-row column sums): left by the loss section's heads
 # post-processing backward (SPFN/fused_losses.HeadPost) for the gradient tensor it returns; one-shot
 heads_grad_hint = None
+top_ride_offer = None        # set by a stack whose output ends in the fused dropout: (out ptr, P, N, Y, st, seed, p)
+top_ride_result = None       # set by _Linear.backward when it took the offer: (ga ptr, partials, rows)
 
 
 class _Linear(torch.autograd.Function):
@@ -805,10 +821,18 @@ class _Linear(torch.autograd.Function):
                 # weight gradient and data gradient of the packed heads in ONE pass over their gradient rows (the one-pass
                 # kernel's 64 <- 128 shape, linear: nothing to apply, nothing rides)
                 ga = torch.empty(P, K, dtype=BF16, device=a.device)
+                global top_ride_offer, top_ride_result
+                offer, top_ride_offer = top_ride_offer, None
+                ride = (offer is not None and offer[0] == a.data_ptr() and offer[1] == P and offer[2] == K and a.stride(0) == K)
+                Yt, stt, dseed, dp = (offer[3], offer[4], offer[5], offer[6]) if ride else (None, (None, None), None, 0.0)
+                fp_ = torch.empty(splits, 2, K, dtype=torch.float32, device=a.device) if ride else None
                 _check(h.cpfn_mlp_bwd_fused(_ptr(gb), Np, _ptr(a), a.stride(0), _ptr(Wb), P, Np, K, None, None, _ptr(ws), _ptr(ga), K,
-                                            None, None, None, None, None, None, None, None, None, 0.0, None, None, 0, None, None,
-                                            _stream()), "cpfn_mlp_bwd_fused")
-                _l.add_bytes("cpfn_mlp_bwd_fused", 2 * P * Np + 4 * P * K + 4 * splits * Np * K + 2 * Np * K)
+                                            _ptr(Yt), _ptr(stt[0]), _ptr(stt[1]), _ptr(fp_), None, None, None, None, _ptr(dseed), dp,
+                                            None, None, 0, None, None, _stream()), "cpfn_mlp_bwd_fused")
+                _l.add_bytes("cpfn_mlp_bwd_fused", 2 * P * Np + 4 * P * K + 4 * splits * Np * K + 2 * Np * K
+                             + ((2 * P * K + 8 * splits * K) if ride else 0))
+                if ride:
+                    top_ride_result = (ga.data_ptr(), fp_, splits)
             else:
                 _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), None, _stream()),
                        "cpfn_mlp_wgrad")

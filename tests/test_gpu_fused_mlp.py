@@ -185,6 +185,44 @@ def test_heads_linear():
     assert _rel(f2.grad, gx_ref) < 3e-2
 
 
+@pytest.mark.parametrize("P", [131072, 40000 + 24])
+def test_heads_one_pass_takes_the_dropout_stack_s_reduction(P, monkeypatch):
+    """fc1 (BatchNorm + ReLU + fused dropout) followed by the packed heads: with HEADS_RIDE the heads' one-pass backward also
+    leaves pass 1 of fc1's BatchNorm backward — mask recomputed from the seed on the data-gradient slab — and
+    cpfn_bn_relu_bwd is not launched: the same data-gradient bits, the same sums in another order."""
+    from cpfn_amd import fused_mlp, lib as _l
+    C = 128
+    convs, bns = _stack(C, [128], seed=5)
+    torch.manual_seed(11)
+    heads_w = [torch.nn.Parameter(torch.randn(n, C, 1, device=dev()) * 0.1) for n in (3, 4, 28)]
+    heads_b = [torch.nn.Parameter(torch.randn(n, device=dev()) * 0.1) for n in (3, 4, 28)]
+    g = torch.Generator().manual_seed(P)
+    x = torch.randn(P, C, generator=g).to(dev()).to(torch.bfloat16)
+    gout = torch.randn(P, 35, generator=g).to(dev())
+    res = {}
+    for ride in (True, False):
+        monkeypatch.setattr(fused_mlp, "HEADS_RIDE", ride)
+        params = [q for q in list(convs.parameters()) + list(bns.parameters()) + heads_w + heads_b]
+        for q in params:
+            q.grad = None
+        counter = torch.zeros(1, dtype=torch.int64, device=dev())      # same counter, same seed: the same mask both times
+        xin = x.clone().requires_grad_(True)
+        _l.byte_census(True)
+        feats = fused_mlp.fused_mlp_stack(xin, convs, bns, dropout=(0.5, counter, 77))
+        outs = fused_mlp.linear_heads(feats, heads_w, heads_b)
+        (torch.cat(outs, 1) * gout).sum().backward()
+        census = _l.byte_census(False)
+        assert ("cpfn_bn_relu_bwd" in census) == (not ride), sorted(census)
+        assert fused_mlp.top_ride_offer is None and fused_mlp.top_ride_result is None
+        res[ride] = (feats.detach().clone(), xin.grad.float().clone(), [q.grad.clone() for q in params if q.grad is not None])
+    (fa, gxa, gpa), (fb, gxb, gpb) = res[True], res[False]
+    assert torch.equal(fa, fb)
+    assert _rel(gxa, gxb) < 2e-3, _rel(gxa, gxb)
+    assert len(gpa) == len(gpb)
+    for a, b in zip(gpa, gpb):
+        assert _rel(a, b) < 2e-3, _rel(a, b)
+
+
 @pytest.mark.parametrize("P", [131072, 40000 + 8])
 def test_heads_backward_in_one_pass(P, monkeypatch):
     """The packed heads' backward through the one-pass kernel's 64 <- 128 shape (weight gradient partials and data gradient
