@@ -536,6 +536,11 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
   __shared__ __attribute__((aligned(16))) unsigned short s_w[2][BN * G_LDW];
   __shared__ float s_red[4][2][BN];
   __shared__ __attribute__((aligned(16))) float s_ss[2][G_SS_MAX];
+  // DENSE fp32 output (the packed heads: ldy == n_store <= 64, one column block): the tile's rows are contiguous in memory, so
+  // it leaves through LDS as 16-byte pieces of ONE contiguous block instead of 16-byte pieces at a 140-byte row stride
+  __shared__ __attribute__((aligned(16))) float s_of[BN == 64 && !STATS ? G_ROWS * 64 : 4];
+  const bool dense_out = BN == 64 && !STATS && y_f32 && n_store == ldy && n_store <= 64 && gridDim.y == 1 &&
+                         ((unsigned long long)Y & 15ull) == 0;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
@@ -630,7 +635,12 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
             for (int r = 0; r < 4; ++r) v[r] += (n + r < N) ? bias[n + r] : 0.f;
           }
           if (STATS && valid) { s1[nt] += v; s2[nt] += v * v; }
-          if (valid) {
+          if (dense_out) {
+            float *so = s_of + (wave * 32 + tt * 16 + lr) * n_store + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < n_store) so[r] = v[r];
+          } else if (valid) {
             if (y_f32) {
               float *o = (float *)Y + (size_t)p * ldy + n;
               if (n + 3 < n_store) {
@@ -653,6 +663,14 @@ __global__ __launch_bounds__(G_THREADS) void mlp_gemm_kernel(
             }
           }
         }
+      }
+      if (dense_out) {
+        __syncthreads();
+        const int nrows = min(G_ROWS, P - row0), nel = nrows * n_store;
+        float *dst = (float *)Y + (size_t)row0 * n_store;            // (row0 * n_store * 4 B = a multiple of 16 B: 128-row tiles)
+        for (int e = 4 * t; e + 3 < nel; e += 4 * G_THREADS) *(cpfn_f32x4 *)(dst + e) = *(const cpfn_f32x4 *)(s_of + e);
+        if (t < (nel & 3)) dst[(nel & ~3) + t] = s_of[(nel & ~3) + t];
+        __syncthreads();                                             // (the next tile's epilogue overwrites s_of)
       }
     }
     c = nc;
