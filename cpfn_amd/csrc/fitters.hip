@@ -262,7 +262,6 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
                                                                  const float *__restrict__ G, int N, int K,
                                                                  const float *__restrict__ dW_add,
                                                                  float *__restrict__ dW, float *__restrict__ dX) {
-  __shared__ __attribute__((aligned(16))) float s_g[FM_MAXK][FM_SLOTS];   // rows are 208 B: 16-byte aligned
   __shared__ float s_p[FM_THREADS * 3], s_x[FM_THREADS * 3];
   extern __shared__ float s_dyn[];                   // W tile, then (in place) the dW tile; dW_add tile
   const int b = blockIdx.y, t = threadIdx.x;
@@ -270,7 +269,6 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
   const size_t p0 = (size_t)b * N + n0;
   const int ld = K | 1;
   float *s_w = s_dyn, *s_add = s_dyn + FM_THREADS * ld;
-  for (int e = t; e < K * FM_SLOTS; e += FM_THREADS) s_g[e / FM_SLOTS][e % FM_SLOTS] = G[(size_t)b * K * FM_SLOTS + e];
   cpfn_rows_to_lds<FM_THREADS>(s_p, 3, P + p0 * 3, rows, 3, t);
   cpfn_rows_to_lds<FM_THREADS>(s_x, 3, X + p0 * 3, rows, 3, t);
   cpfn_rows_to_lds<FM_THREADS>(s_w, ld, W + p0 * K, rows, K, t);
@@ -284,13 +282,15 @@ __global__ __launch_bounds__(FM_THREADS) void moments_bwd_kernel(const float *__
     float *wrow = s_w + t * ld;
     const float *arow = s_add + t * ld;
     for (int k = 0; k < K; ++k) {
-      // the 52-slot row as 13 un-narrowable 16-byte LDS reads (cpfn_lds_read4: the compiler would turn two of them
-      // into the banned ds_read_b96 because slots 19 and 49..51 are padding)
+      // the 52-slot row of instance k is the same for every lane: read straight from memory, it arrives by SCALAR loads
+      // (s_load_dwordx16: the FMAs below take it as scalar operands).  Round 3; before, G[b] was staged in LDS and every
+      // lane read the row back with 13 16-byte LDS reads per instance — 364 LDS instructions per wave, the bulk of the
+      // kernel's time (25.4 -> 20.2 us stand-alone, same bits).
       float g[FM_SLOTS];
+      {
+        const float *grow = G + ((size_t)b * K + k) * FM_SLOTS;
 #pragma unroll
-      for (int q = 0; q < FM_SLOTS / 4; ++q) {
-        const cpfn_f32x4 v = cpfn_lds_read4(&s_g[k][4 * q]);
-        g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        for (int m = 0; m < FM_SLOTS; ++m) g[m] = grow[m];
       }
       float ga = 0.f, gB = 0.f;
 #pragma unroll
