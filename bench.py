@@ -244,6 +244,15 @@ def main():
     PROBE_SLOTS, PROBE_WG = 128, 2048
     probe = torch.zeros(PROBE_SLOTS, 2 + 2 * PROBE_WG, dtype=torch.int64, device=dev)
     lib.check(h.cpfn_mlp_gemm_set_probe(probe.data_ptr(), PROBE_SLOTS, PROBE_WG), "cpfn_mlp_gemm_set_probe")
+    # algorithmic bytes of ONE step, per entry point (every operand read once, every result written once): one eager
+    # step with the byte census on (same launches as the replayed graph).  It runs BEFORE the warm-up steps (round 3): between
+    # them and the timed region it was 5 ms of host-bound eager launches plus a device synchronisation right in front of the
+    # clock, and the first replays after it ran slower — +21 us per step on the driver's 20-step run against a 300-step one.
+    lib.byte_census(True)
+    trainer.step(batch, force_eager=True)
+    census = lib.byte_census(False)
+    if args.census_out and rank == 0:
+        json.dump({k: list(v) for k, v in census.items()}, open(args.census_out, "w"), indent=1)
     # Each step also prefetches the NEXT step's geometry (FPS / ball query / 3-NN with fresh random
     # FPS starts) on a side stream: one geometry pass per step, software-pipelined across steps.
     for _ in range(args.warmup):
@@ -258,17 +267,6 @@ def main():
         if trainer._graph is None:
             sys.stderr.write("bench.py: the step was not captured as a hipGraph after %d warm-up steps\n" % (args.warmup + extra_warmup))
             sys.exit(3)
-    # algorithmic bytes of ONE step, per entry point (every operand read once, every result written once): one eager
-    # step with the byte census on (same launches as the replayed graph)
-    sync()
-    lib.byte_census(True)
-    trainer.step(batch, force_eager=True)
-    census = lib.byte_census(False)
-    # the instrumentation step above announced no next batch: one untimed step re-primes the geometry pipeline (otherwise
-    # the FIRST timed step computes its geometry serially: 1.4 ms, +3.5 % on a 20-step run)
-    trainer.step(batch, next_batch=batch)
-    if args.census_out and rank == 0:
-        json.dump({k: list(v) for k, v in census.items()}, open(args.census_out, "w"), indent=1)
     sync()
     probe.zero_()                                       # only the launches of the timed region will be in it afterwards
     sync()
