@@ -55,6 +55,14 @@ def get_learning_rate(init_learning_rate, global_step, batch_size, decay_step, d
 # in-collective averaging.  "rs_ag": reduce-scatter + all-gather on the same bucket (SURVEY §8e argues that on 7
 # point-to-point xGMI links a direct reduce-scatter / all-gather pair can beat a ring all-reduce of this size; RCCL picks its
 # own algorithm for either, so this is an A/B switch for a SCALE run, reported by bench.py as config.collective).
+
+class _CopyDesc(__import__("ctypes").Structure):
+    _fields_ = [("src", __import__("ctypes").c_void_p), ("dst", __import__("ctypes").c_void_p),
+                ("bytes", __import__("ctypes").c_longlong)]
+
+
+_copy_desc_cache = {}
+
 DP_COLLECTIVE = os.environ.get("CPFN_DP_COLLECTIVE", "all_reduce")
 _BUCKET_PAD = 3360            # elements; 4 x lcm(1..8): every world size up to 8 (and 10, 12, 14, 15, 16 ...) gets 16-byte-aligned shards
 
@@ -380,11 +388,18 @@ class SPFNTrainer:
         """One launch for a whole set of device-to-device copies (cpfn_multi_copy); tensors that are not contiguous
         (or oddly aligned) go through torch.  flags (int32 device tensor): fp32 copies with the finite scan riding
         along; returns (flags, count) when every tensor went through the checked launch, else None."""
-        import ctypes
         from . import lib as _l
-
-        class _D(ctypes.Structure):
-            _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
+        _D = _CopyDesc
+        # (the same tensors are copied step after step: the descriptor array of a set of (source, destination, strides) is
+        #  built once — the checks and the ctypes construction were ~60 us of host time per step)
+        key = tuple((d.data_ptr(), t.data_ptr(), d.numel(), d.stride(), t.stride(), d.dtype, t.dtype) for d, t in zip(dst, src))
+        ent = _copy_desc_cache.get(key)
+        if ent is not None and flags is None:
+            arr, n_fast, nbytes = ent
+            _l.add_bytes("cpfn_multi_copy", 2 * nbytes)
+            with torch.cuda.device(dst[0].device):
+                _l.check(_l.lib().cpfn_multi_copy(arr, n_fast, torch.cuda.current_stream().cuda_stream), "cpfn_multi_copy")
+            return None
         fast, slow = [], 0
         for d, t in zip(dst, src):
             if (d.is_cuda and t.is_cuda and d.is_contiguous() and t.is_contiguous() and d.dtype == t.dtype
@@ -398,6 +413,10 @@ class SPFNTrainer:
             return None
         arr = (_D * len(fast))(*fast)
         h = _l.lib()
+        if slow == 0 and flags is None:
+            if len(_copy_desc_cache) > 64:
+                _copy_desc_cache.clear()
+            _copy_desc_cache[key] = (arr, len(fast), sum(f.bytes for f in fast))
         _l.add_bytes("cpfn_multi_copy", 2 * sum(f.bytes for f in fast))
         with torch.cuda.device(dst[0].device):
             stream = torch.cuda.current_stream().cuda_stream
@@ -793,11 +812,24 @@ class SPFNTrainer:
             self._gstream = torch.cuda.Stream(device=device)
         return self._gstream
 
+    def _all_training(self):
+        mods = self.__dict__.get("_mods")
+        if mods is None:
+            mods = self._mods = list(self.module.modules())
+        for m in mods:
+            if not m.training:
+                return False
+        return True
+
     def step(self, batch, fps_start=None, next_batch=None, force_eager=False):
         """One optimisation step; returns the 6 loss tensors (still on the device — the
         reference's six `.item()` syncs per step, training_utils.py:169-174, are left to the caller).
         `next_batch`: if given, its geometry is prefetched on a side stream during this step's backward."""
-        self.module.train()
+        # (nn.Module.train() walks all ~60 submodules through __setattr__: ~0.1 ms of host time per call, twice per step with
+        #  the re-entry on the trainer's stream — exposed whenever the GPU is idle, e.g. on the first step after a sync.  The
+        #  walk only happens when some module is NOT in training mode.)
+        if not self._all_training():
+            self.module.train()
         self._schedules()
         if self.use_graphs and batch["T_gt"].shape[1] > 32:
             # the fused loss kernels (and with them the captured step) take at most 32 instance columns; wider label
