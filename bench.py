@@ -63,6 +63,10 @@ def parse_args():
     ap.add_argument("--probe-replays", type=int, default=20,
                     help="replays sampled after the timed region for the roofline's per-launch time (median over them and "
                          "the timed region's last step)")
+    ap.add_argument("--no-routes", action="store_true",
+                    help="skip the two extra data points `routes.epoch` / `routes.zero_edit` (the reference's own epoch-loop "
+                         "signature on the replayed step with host->device input hand-over, and the eager zero-edit loop)")
+    ap.add_argument("--route-steps", type=int, default=240, help="batches of the timed `routes.epoch` epoch")
     ap.add_argument("--census-out", default=None, help="write the per-entry-point algorithmic bytes of one step (JSON)")
     return ap.parse_args()
 
@@ -158,6 +162,149 @@ def cpu_baseline():
             "all_physical_cores": {"value": 4 / t_all, "unit": "point-clouds/s", "cores": physical,
                                    "sample": "1 timed training step of 4x%d pts after 1 warm-up with torch.set_num_threads(%d): "
                                              "%.3f s" % (N_POINTS, physical, t_all)}}
+
+
+class _RouteConf:
+    """The getters `spfn_train_val_epoch` reads, with the values of Configs/config_globalSPFN.yml:2-18."""
+    def get_batch_size(self): return BATCH_PER_GPU
+    def get_bn_decay_step(self): return 200000
+    def get_decay_step(self): return 200000
+    def get_decay_rate(self): return 0.7
+    def get_init_learning_rate(self): return 1e-3
+    def get_miou_loss_multiplier(self): return 1.0
+    def get_normal_loss_multiplier(self): return 1.0
+    def get_type_loss_multiplier(self): return 1.0
+    def get_parameter_loss_multiplier(self): return 1.0
+    def get_residue_loss_multiplier(self): return 1.0
+    def get_total_loss_multiplier(self): return 1.0
+    def get_list_of_primitives(self): return ['sphere', 'plane', 'cylinder', 'cone']
+
+
+class _RouteArgs:
+    network = 'GlobalSPFN'
+
+
+class _RouteVisualiser:
+    """Stands in for Utils/training_visualisation.Visualiser (visdom): keeps the sliding window like log_loss does."""
+    def __init__(self):
+        self.hist, self.steps = {}, 0
+
+    def log_loss(self, value, name):
+        self.hist[name] = (self.hist.get(name, []) + [value])[-50:]
+
+    def update(self):
+        self.steps += 1
+
+
+_ROUTE_ORDER = ("P", "X_gt", "points_per_instance", "I_gt", "T_gt", "plane_n_gt", "cylinder_axis_gt", "cone_axis_gt")
+
+
+def _route_loader(n_distinct, n_batches, rank):
+    """An in-memory "data loader": n_distinct different synthetic batches as tuples of PINNED CPU tensors (what
+    DataLoader(pin_memory=True) hands to the loop, training_SPFN.py:78), cycled to n_batches — consecutive steps never see the
+    same bytes, and nothing is on the device before the loop copies it there."""
+    from cpfn_amd import synthetic
+    base = [synthetic.training_batch(BATCH_PER_GPU, N_POINTS, N_INSTANCES, seed=2000 + 17 * i + rank) for i in range(n_distinct)]
+    pinned = [tuple(b[k].pin_memory() for k in _ROUTE_ORDER) for b in base]
+    return [pinned[i % n_distinct] for i in range(n_batches)]
+
+
+def _zero_edit_epoch(loader, model, optimizer, visualiser, conf, dev):
+    """What an UNCHANGED training_SPFN.py gets behind `dropin.install(compute_dtype=bf16)` without `fast_epoch`: the reference's
+    own loop (Utils/training_utils.py:84-176) calling the eager modules — restated here in its call sequence because the
+    reference's file does not travel to the GPU box: blocking .to(device) of the eight tensors, module forward, normalise /
+    soft-max, op-by-op compute_all_losses (host SciPy assignment), backward, the per-parameter isinf / isnan scan, torch Adam,
+    seven .item() reads and six log_loss calls per batch."""
+    import torch
+    from cpfn_amd.SPFN import losses_implementation as li
+    total = 0.0
+    model.train()
+    for data in loader:
+        optimizer.zero_grad()
+        P, X_gt, ppi = (data[i].type(torch.FloatTensor).to(dev) for i in (0, 1, 2))
+        I_gt, T_gt = (data[i].type(torch.LongTensor).to(dev) for i in (3, 4))
+        gt = {k: data[i].type(torch.FloatTensor).to(dev) for k, i in (("plane_normal", 5), ("cylinder_axis", 6), ("cone_axis", 7))}
+        X, T, W, _, _ = model(P, glob_features=None, loc_features=None)
+        X = torch.nn.functional.normalize(X, p=2, dim=2, eps=1e-12)
+        W = torch.softmax(W, dim=2)
+        out = li.compute_all_losses(P, W, I_gt, X, X_gt, T, T_gt, gt, ppi, conf.get_normal_loss_multiplier(),
+                                    conf.get_type_loss_multiplier(), conf.get_miou_loss_multiplier(),
+                                    conf.get_residue_loss_multiplier(), conf.get_parameter_loss_multiplier(),
+                                    conf.get_total_loss_multiplier(), False, mode_seg='mIoU', classes=conf.get_list_of_primitives())
+        total += P.shape[0] * out[0].item()
+        out[0].backward()
+        bad = False
+        for p in model.parameters():
+            if p.requires_grad and p.grad is not None and (torch.any(torch.isinf(p.grad)) or torch.any(torch.isnan(p.grad))):
+                bad = True
+                break
+        if not bad:
+            optimizer.step()
+        for v, name in zip(out[:6], ("loss", "normal_loss", "type_loss", "miou_loss", "residue_loss", "parameter_loss")):
+            visualiser.log_loss(v.item(), 'train_%s' % name)
+        visualiser.update()
+    return total
+
+
+def measure_routes(args, dev, rank, headline_ms):
+    """Two extra data points beside the headline: the step as a user of the reference reaches it.
+    `epoch`: cpfn_amd.training.spfn_train_val_epoch — the reference's own epoch-loop signature on the replayed step — over an
+    in-memory loader of distinct pinned host batches, host->device copies INCLUDED, a whole epoch timed from the call to its
+    return (the return value needs the last loss on the host).  `zero_edit`: the reference's loop on the eager modules."""
+    import contextlib
+    import torch
+    from cpfn_amd import training
+    from cpfn_amd.PointNet2 import pn2_network
+    conf, out = _RouteConf(), {}
+    n_distinct = 16
+    loader = _route_loader(n_distinct, max(args.route_steps, 8), rank)
+
+    def fresh():
+        torch.manual_seed(0)
+        m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, N_INSTANCES]).to(dev)
+        m.set_compute_dtype(torch.bfloat16)
+        return m, torch.optim.Adam(m.parameters(), lr=conf.get_init_learning_rate())
+
+    with contextlib.redirect_stdout(sys.stderr):
+        # ---- epoch: a short first epoch captures the graphs (as the first minutes of a real run would), the second is timed
+        model, opt = fresh()
+        vis = _RouteVisualiser()
+        gs, _ = training.spfn_train_val_epoch(loader[:8], model, 0, opt, 0, vis, _RouteArgs(), conf, dev, network_mode='train')
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        gs, tot = training.spfn_train_val_epoch(loader, model, 1, opt, gs, vis, _RouteArgs(), conf, dev, network_mode='train')
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        runner = model.__dict__["_cpfn_epoch_runner"]
+        ms = 1e3 * el / len(loader)
+        out["epoch"] = {"route": "epoch", "value": BATCH_PER_GPU * len(loader) / el, "unit": "point-clouds/s", "ms_per_step": ms,
+                        "steps": len(loader), "vs_headline": headline_ms / ms,
+                        "what": "cpfn_amd.training.spfn_train_val_epoch(dataloader, spfn_module, epoch, optimizer, global_step, "
+                                "visualiser, args, conf, device, 'train') = the signature of Utils/training_utils.py:84-176 "
+                                "(dropin.install(fast_epoch=True)), one whole epoch from call to return over an in-memory loader of "
+                                "%d distinct pinned host batches cycled to %d (16x8192 pts, 6.5 MB each): host->device copies, "
+                                "look-ahead, deferred logging and the final loss read INCLUDED; graphs captured by a short epoch "
+                                "before it" % (n_distinct, len(loader)),
+                        "launch": "hipGraph replay" if runner.trainer._graph is not None else "eager",
+                        "skipped_steps": runner.trainer.skipped_steps, "epoch_loss_sum": tot, "visualiser_updates": vis.steps}
+        del model, opt, runner
+        # ---- zero_edit
+        model, opt = fresh()
+        vis = _RouteVisualiser()
+        _zero_edit_epoch(loader[:3], model, opt, vis, conf, dev)
+        torch.cuda.synchronize(dev)
+        n = 30
+        t0 = time.perf_counter()
+        _zero_edit_epoch(loader[3:3 + n], model, opt, vis, conf, dev)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        out["zero_edit"] = {"route": "zero_edit", "value": BATCH_PER_GPU * n / el, "unit": "point-clouds/s",
+                            "ms_per_step": 1e3 * el / n, "steps": n, "vs_headline": headline_ms / (1e3 * el / n),
+                            "what": "the reference's loop (call sequence of Utils/training_utils.py:84-176, restated in bench.py) on "
+                                    "the eager modules: what an unchanged training_SPFN.py gets from dropin.install(compute_dtype="
+                                    "bf16) WITHOUT fast_epoch — blocking .to(device), op-by-op losses with the host assignment, "
+                                    "per-parameter isinf/isnan scan, torch.optim.Adam, 7 .item() per batch; host-bound"}
+    return out
 
 
 def scale_fields(collective, bucket_bytes, in_graph, rank_ms, rank_comm, samples):
@@ -471,6 +618,9 @@ def main():
                                  bool((trainer._graph or {}).get("exchange_in_graph")), rank_ms, rank_comm, len(comm_us))
             line["config"]["collective"] = extra.pop("collective")
             line.update(extra)
+        if world == 1 and not args.no_routes and args.workload == "global" and args.dtype == "bf16" and not args.no_graphs:
+            del trainer, model                         # (its graphs' pools go back before the routes build theirs)
+            line["routes"] = measure_routes(args, dev, rank, ms_per_step)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

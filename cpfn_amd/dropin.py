@@ -44,11 +44,16 @@ _ALIASES = {
 }
 
 
-def install(compute_dtype=None):
+def install(compute_dtype=None, fast_epoch=False):
     """Alias the reference's module names.  `compute_dtype=torch.bfloat16` additionally makes
-    every PointNet2 built afterwards use the fused bf16 MFMA stacks by default."""
+    every PointNet2 built afterwards use the fused bf16 MFMA stacks by default.
+    `fast_epoch=True`: `Utils.training_utils.spfn_train_val_epoch` (the loop training_SPFN.py:105-108 calls) resolves to
+    the replayed-step epoch loop (cpfn_amd/epoch.py: one graph replay per batch, pinned look-ahead input staging, deferred
+    logging, same signature / return / prints); every other name of `Utils.training_utils` stays the reference's own."""
     for ref_name, ours in _ALIASES.items():
         sys.modules[ref_name] = importlib.import_module(ours)
+    if fast_epoch:
+        sys.modules["Utils.training_utils"] = importlib.import_module("cpfn_amd.Utils.training_utils")
     from .SPFN import _reference
     _reference.attach()            # SPFN.primitives & co. of a checkout that is already on sys.path; lazy otherwise
     if compute_dtype is not None:

@@ -333,11 +333,20 @@ class SPFNTrainer:
             self.optimizer.step()
             skipped += self.optimizer.found_inf
 
-    def losses(self, batch, fps_start=None):
-        """Forward + losses (training_utils.py:140-146).  Returns the reference's 6 scalars."""
+    @staticmethod
+    def _feature_kwargs(batch):
+        """LocalSPFN's extra inputs (training_utils.py:136-137), for a network built with use_glob_features / use_loc_features."""
+        return {k: batch[k] for k in ("glob_features", "loc_features") if k in batch}
+
+    def losses(self, batch, fps_start=None, geometry=False):
+        """Forward + losses (training_utils.py:140-146).  Returns the reference's 6 scalars.
+        geometry: the batch's index tensors if the caller already holds them (None = compute them in the forward pass);
+        by default whatever `prefetch` left for this batch."""
         P = batch["P"]
-        geom = self._take_prefetched(P) if fps_start is None else None
-        kw = {"geometry": geom} if geom is not None else {}
+        if geometry is False:
+            geometry = self._take_prefetched(P) if fps_start is None else None
+        kw = {"geometry": geometry} if geometry is not None else {}
+        kw.update(self._feature_kwargs(batch))
         X, T, W, _, _ = self.module(P, fps_start=fps_start, **kw)
         packed = getattr(self.module, "heads_packed", None)
         if self.fused_losses and packed is not None and len(self.classes) == 4 and T.shape[2] == 4:
@@ -353,6 +362,17 @@ class SPFNTrainer:
             m["normal"], m["type"], m["miou"], m["residue"], m["parameter"], m["total"], False,
             mode_seg='mIoU', classes=self.classes)
         return out[:6]
+
+    def eval_losses(self, batch, next_batch=None):
+        """The validation pass of the reference's epoch loop (`network_mode='val'`, training_utils.py:104-105, 140-147 under
+        the caller's `torch.no_grad()`): forward + the six losses in whatever mode the module is in, nothing back-propagated,
+        no optimizer.  `next_batch`: its FPS / ball query / 3-NN run on the side stream beside this batch's forward pass."""
+        with torch.no_grad():
+            geom = self._take_prefetched(batch["P"])
+            if next_batch is not None:
+                self.prefetch(next_batch)
+            out = self.losses(batch, geometry=geom)
+        return tuple(o.detach() for o in out)
 
     # ---- hipGraph replay of the step -----------------------------------------------------------
     # At 16 clouds per GPU the step is ~150 launches and host-bound when launched one by one.  With the
@@ -597,7 +617,7 @@ class SPFNTrainer:
                     stamps[4:5].copy_(stamps[3:4])                  # when the PREVIOUS replay ended
                 stamp(0)
                 self.bucket.zero()
-                self.module(sb["P"], geometry=st["geomA"])
+                self.module(sb["P"], geometry=st["geomA"], **self._feature_kwargs(sb))
                 Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
                 n_gt = fl.count_gt(sb["I_gt"])
                 params, st["match"] = fl.fit_params_and_match(sb["P"], W, Xn, self.mult, S, n_gt)
@@ -628,7 +648,7 @@ class SPFNTrainer:
         with torch.cuda.graph(g1, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
             self._copy_all(geomA, geomB)
             self.bucket.zero()
-            self.module(sb["P"], geometry=st["geomA"])
+            self.module(sb["P"], geometry=st["geomA"], **self._feature_kwargs(sb))
             st["pre"] = fl.pre_match(self.module.heads_packed, sb)
             st["n_gt"] = fl.count_gt(sb["I_gt"])
             st["cost_pack"] = fl.hungarian_cost_pack(st["pre"][4].detach(), sb["I_gt"], st["n_gt"])   # device part, in-graph
@@ -813,10 +833,9 @@ class SPFNTrainer:
         return self._gstream
 
     def _all_training(self):
-        mods = self.__dict__.get("_mods")
-        if mods is None:
-            mods = self._mods = list(self.module.modules())
-        for m in mods:
+        # (walks the module tree every step — ~60 attribute reads, 10 us — instead of caching the list: a submodule added or
+        #  swapped after the first step must be seen)
+        for m in self.module.modules():
             if not m.training:
                 return False
         return True
@@ -910,3 +929,13 @@ class SPFNTrainer:
             self._host_skipped += 1
         self.global_step += 1
         return tuple(o.detach() for o in out)     # do not keep the autograd graph alive across steps
+
+
+
+def __getattr__(name):
+    # the reference's epoch loop on this trainer (same signature as Utils/training_utils.py:84-176) lives in cpfn_amd/epoch.py,
+    # which imports this module: resolved on first use
+    if name in ("spfn_train_val_epoch", "EpochRunner"):
+        from . import epoch
+        return getattr(epoch, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

@@ -1,0 +1,164 @@
+"""GPU: `cpfn_amd.training.spfn_train_val_epoch` (the reference's epoch loop, Utils/training_utils.py:84-176, on the replayed
+step) against `SPFNTrainer.step` / `eval_losses` called by hand on the same batches already resident on the device: the
+look-ahead staging (pinned and pageable host tensors, dtype casts, three rotating slots, copy stream), the announcement of
+the next batch, the ragged last batch, a BatchNorm-momentum change inside an epoch (re-capture) and the deferred logging
+must not change a single loss value."""
+import contextlib
+import io
+
+import pytest
+import torch
+
+from cpfn_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+B, N, K = 4, 2048, 28
+
+
+class Conf:
+    def get_batch_size(self): return B
+    def get_bn_decay_step(self): return 20          # momentum 0.5 -> 0.25 at step 5: inside the first epoch
+    def get_decay_step(self): return 12             # learning rate x 0.7 at step 3
+    def get_decay_rate(self): return 0.7
+    def get_init_learning_rate(self): return 1e-3
+    def get_miou_loss_multiplier(self): return 1.0
+    def get_normal_loss_multiplier(self): return 1.0
+    def get_type_loss_multiplier(self): return 1.0
+    def get_parameter_loss_multiplier(self): return 1.0
+    def get_residue_loss_multiplier(self): return 1.0
+    def get_total_loss_multiplier(self): return 1.0
+    def get_list_of_primitives(self): return ['sphere', 'plane', 'cylinder', 'cone']
+
+
+class Args:
+    network = 'GlobalSPFN'
+
+
+class Visualiser:
+    def __init__(self):
+        self.calls = []
+
+    def log_loss(self, value, name):
+        self.calls.append((name, value))
+
+    def update(self):
+        self.calls.append(("update",))
+
+
+ORDER = ("P", "X_gt", "points_per_instance", "I_gt", "T_gt", "plane_n_gt", "cylinder_axis_gt", "cone_axis_gt")
+
+
+def _host_batches(n, seed0, ragged_last):
+    out = []
+    for i in range(n):
+        b = synthetic.training_batch(B // 2 if (ragged_last and i == n - 1) else B, N=N, n_max_instances=K, n_prims=6,
+                                     n_inst_points=128, seed=seed0 + i)
+        out.append(b)
+    return out
+
+
+def _as_loader(batches):
+    """Tuples like the reference's DataLoader yields; every second batch pinned (DataLoader(pin_memory=True)), the others
+    pageable, P in double / I_gt in int32 on some (the loop casts with .type(FloatTensor) / .type(LongTensor))."""
+    out = []
+    for i, b in enumerate(batches):
+        t = [b[k].clone() for k in ORDER]
+        if i % 3 == 1:
+            t[0], t[3] = t[0].double(), t[3].int()
+        if i % 2 == 0:
+            t = [x.pin_memory() for x in t]
+        out.append(tuple(t))
+    return out
+
+
+def _model(dev):
+    from cpfn_amd import training
+    from cpfn_amd.PointNet2 import pn2_network
+    from cpfn_amd.SPFN import fitter_factory
+    with contextlib.redirect_stdout(io.StringIO()):
+        fitter_factory.register_primitives(training.GLOBAL_SPFN_CLASSES)
+    torch.manual_seed(0)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, K]).to(dev)
+    m.set_compute_dtype(torch.bfloat16)
+    return m
+
+
+def test_epoch_function_equals_trainer_steps_by_hand():
+    from cpfn_amd import training
+    dev = torch.device("cuda:0")
+    conf = Conf()
+    train_b, val_b = _host_batches(9, 300, True), _host_batches(2, 400, False)
+
+    # ---- by hand: the trainer on device-resident batches --------------------------------------------------------------
+    model = _model(dev)
+    tr = training.SPFNTrainer(model, batch_size=B, init_learning_rate=conf.get_init_learning_rate(), decay_step=conf.get_decay_step(),
+                              decay_rate=conf.get_decay_rate(), bn_decay_step=conf.get_bn_decay_step(), use_graphs=True)
+    tb = [{k: v.to(dev) for k, v in b.items()} for b in train_b]
+    vb = [{k: v.to(dev) for k, v in b.items()} for b in val_b]
+    torch.manual_seed(77)
+    hand = []
+    with torch.cuda.stream(tr.stream(dev)):
+        model.train()
+        for i, b in enumerate(tb):
+            ragged = b["P"].shape[0] != B
+            nxt = tb[i + 1] if i + 1 < len(tb) and tb[i + 1]["P"].shape == b["P"].shape and not ragged else None
+            hand.append([float(o) for o in tr.step(b, next_batch=nxt, force_eager=ragged)])
+        assert tr._graph is not None
+        model.eval()
+        for i, b in enumerate(vb):
+            hand.append([float(o) for o in tr.eval_losses(b, next_batch=vb[i + 1] if i + 1 < len(vb) else None)])
+    torch.cuda.synchronize()
+    w_hand = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    assert tr.skipped_steps == 0
+
+    # ---- the epoch function on host batches --------------------------------------------------------------------------
+    model2 = _model(dev)
+    opt = torch.optim.Adam(model2.parameters(), lr=conf.get_init_learning_rate())
+    vis = Visualiser()
+    torch.manual_seed(77)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gs, tot_train = training.spfn_train_val_epoch(_as_loader(train_b), model2, 0, opt, 0, vis, Args(), conf, dev, network_mode='train')
+        with torch.no_grad():
+            gs2, tot_val = training.spfn_train_val_epoch(_as_loader(val_b), model2, 0, opt, gs, vis, Args(), conf, dev, network_mode='val')
+    torch.cuda.synchronize()
+    runner = model2.__dict__["_cpfn_epoch_runner"]
+    assert runner.trainer._graph is not None and runner.trainer.skipped_steps == 0
+    assert gs == len(train_b) and gs2 == gs
+    logged = [c for c in vis.calls if len(c) > 1]
+    names = [n for n, _ in logged]
+    assert names[:6] == ['train_loss', 'train_normal_loss', 'train_type_loss', 'train_miou_loss', 'train_residue_loss', 'train_parameter_loss']
+    assert names[-6:] == ['val_loss', 'val_normal_loss', 'val_type_loss', 'val_miou_loss', 'val_residue_loss', 'val_parameter_loss']
+    assert sum(1 for c in vis.calls if c == ("update",)) == len(train_b) + len(val_b)
+    vals = [v for _, v in logged]
+    epoch_rows = [vals[6 * i:6 * i + 6] for i in range(len(train_b) + len(val_b))]
+    for i, (a, b) in enumerate(zip(epoch_rows, hand)):
+        assert a == b, (i, a, b)                                    # bit for bit: the same kernels on the same bytes
+    sizes = [b["P"].shape[0] for b in train_b]
+    assert tot_train == pytest.approx(sum(s * r[0] for s, r in zip(sizes, hand[:len(train_b)])), rel=1e-12)
+    assert tot_val == pytest.approx(sum(B * r[0] for r in hand[len(train_b):]), rel=1e-12)
+    for k, v in model2.state_dict().items():
+        assert torch.equal(v, w_hand[k]), k
+    # the staircases reached the module, the flat optimizer and the caller's optimizer
+    assert model2.bn1.momentum == 0.25 and model2.sa1.bn_blocks[0][0].momentum == 0.25
+    assert opt.param_groups[0]['lr'] == pytest.approx(1e-3 * 0.7 ** 2)
+    # ... whose state ARE the flat moments (what optimizer.state_dict() would save)
+    p0 = next(model2.parameters())
+    assert float(opt.state[p0]["step"]) == len(train_b) and opt.state[p0]["exp_avg"].abs().sum() > 0
+    assert "[train][Epoch 0 - Iteration 0]" in buf.getvalue() and "Parameter Loss" in buf.getvalue()
+
+
+def test_epoch_function_fp32_model_runs_eagerly():
+    """An fp32 model (dropin.install() without compute_dtype) takes the same function: eager trainer steps with the staging and
+    the deferred logging."""
+    from cpfn_amd import training
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    model.set_compute_dtype(torch.float32)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    vis = Visualiser()
+    with contextlib.redirect_stdout(io.StringIO()):
+        gs, tot = training.spfn_train_val_epoch(_as_loader(_host_batches(3, 500, False)), model, 0, opt, 0, vis, Args(), Conf(), dev)
+    assert gs == 3 and tot == tot and tot > 0
+    assert model.__dict__["_cpfn_epoch_runner"].trainer._graph is None
