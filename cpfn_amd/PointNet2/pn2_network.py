@@ -135,9 +135,14 @@ class PointNet2(torch.nn.Module):
         chain = (cd == torch.bfloat16 and x.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT
                  and not self.features_extractor and getattr(self.sfp3, "compute_dtype", torch.float32) == torch.bfloat16)
         feat = None
+        # side results between the backward nodes of THIS forward pass (fc1's stack <-> packed heads <-> loss section)
+        ho = self.handover = None
+        if cd == torch.bfloat16 and x.is_cuda:
+            from .. import fused_mlp
+            ho = self.handover = fused_mlp.HandOver()
         if chain:
             feat, self.aux_sfp3 = self.sfp3.forward_rows(xyz, l1_xyz, feats0, l5, gm.get("sfp3"), cr,
-                                                         tail=([self.fc1], [self.bn1], self._fused_dropout(x.device)))
+                                                         tail=([self.fc1], [self.bn1], self._fused_dropout(x.device), ho))
             feat = feat.reshape(B * N, -1)
             l6 = None
         else:
@@ -153,11 +158,12 @@ class PointNet2(torch.nn.Module):
         elif cd == torch.bfloat16 and l6.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT:
             # fc1 + bn1 + relu + the always-on dropout (ref :60-63) with the mask generated inside the BN apply kernel
             # and regenerated in the backward passes (no mask tensor, no separate dropout kernels)
-            feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd, dropout=self._fused_dropout(l6.device))
+            feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd, dropout=self._fused_dropout(l6.device),
+                                 handover=ho)
         else:
             feat = mlp.run_stack(l6.reshape(B * N, -1), [self.fc1], [self.bn1], cd)       # fc1 + bn1 + relu (ref :60-62)
             feat = F.dropout(feat, p=self.dropout_p, training=True)                        # always on (ref :63)
-        results = [r.reshape(B, N, -1) for r in mlp.heads(feat, self.fc2, cd)]
+        results = [r.reshape(B, N, -1) for r in mlp.heads(feat, self.fc2, cd, handover=ho)]
         self.heads_packed = None
         if cd == torch.bfloat16 and feat.is_cuda:
             from .. import fused_mlp

@@ -38,7 +38,7 @@ class PointsetFeaturePropagation(nn.Module):
     def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None, cuda_route=False, tail=None):
         """xyz1 [B,N,3] dense, xyz2 [B,S,3] coarse or None, feats1 [B,N,D1] or None,
         feats2 [B,S,D2] -> [B,N,D'].
-        tail = (convs, bns, dropout) (bf16 HIP path only): more (conv, bn, relu) layers run as part of the SAME fused stack
+        tail = (convs, bns, dropout[, handover]) (bf16 HIP path only): more (conv, bn, relu) layers run as part of the SAME fused stack
         — the caller's next per-point layers (GlobalSPFN's fc1 + bn1 + dropout): the stack's own last activation is then
         never materialised and its BatchNorm-backward reduction rides on the next layer's data gradient."""
         B, N, _ = xyz1.shape
@@ -58,10 +58,12 @@ class PointsetFeaturePropagation(nn.Module):
                 interp = autograd_ops.interp_rows(feats2, geom["nn_idx"], geom["nn_w"], geom.get("inv"))
                 aux = geom
             x = interp if feats1 is None else torch.cat([feats1.to(interp.dtype), interp], dim=2)   # feats1 FIRST (ref :46)
-        convs, bns, dropout = list(self.mlp_convs), list(self.mlp_bns), None
+        convs, bns, dropout, handover = list(self.mlp_convs), list(self.mlp_bns), None, None
         if tail is not None:
             convs, bns, dropout = convs + list(tail[0]), bns + list(tail[1]), tail[2]
-        y = mlp.run_stack(x.reshape(B * N, -1), convs, bns, getattr(self, "compute_dtype", torch.float32), dropout=dropout)
+            handover = tail[3] if len(tail) > 3 else None
+        y = mlp.run_stack(x.reshape(B * N, -1), convs, bns, getattr(self, "compute_dtype", torch.float32), dropout=dropout,
+                          handover=handover)
         return y.reshape(B, N, -1), aux
 
     def forward(self, pos1, pos2, feats1, feats2, fast=True):

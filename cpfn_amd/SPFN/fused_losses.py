@@ -38,7 +38,8 @@ PARAM_LAYOUT = (("plane_normal", 3), ("plane_center", 1), ("sphere_center", 3), 
 
 class HeadPost(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, Y, X_gt, I_gt, T_gt, with_seg=False):
+    def forward(ctx, Y, X_gt, I_gt, T_gt, with_seg=False, handover=None):
+        ctx.handover = handover
         B, N, C = Y.shape
         K = C - 7
         Yc = Y.detach().contiguous().float()
@@ -100,20 +101,21 @@ class HeadPost(torch.autograd.Function):
         gY = torch.empty_like(Yc)
         # what the fc2 heads' backward makes of gY first — its rows as zero-padded bf16 (the operand of their two GEMMs) and the
         # per-256-row column sums (their bias gradient) — leaves this launch too, from the tile while it is in LDS, and is handed
-        # to fused_mlp._Linear.backward keyed by gY's address (no cpfn_colsum_f32 launch, no second pass over gY)
+        # to fused_mlp._Linear.backward through the forward pass's HandOver, for exactly this tensor (no cpfn_colsum_f32 launch,
+        # no second pass over gY)
         gb = csp = None
-        if HEADS_HINT and N % 256 == 0 and C <= 64:
-            from .. import fused_mlp
+        ho = ctx.handover
+        if HEADS_HINT and ho is not None and N % 256 == 0 and C <= 64:
             gb = torch.empty(B * N, 64, dtype=torch.bfloat16, device=dev)
             csp = torch.empty((B * N // 256) * C, dtype=torch.float32, device=dev)
-            fused_mlp.heads_grad_hint = (gY.data_ptr(), B * N, C, gb, csp)
+            ho.heads_hint = (gY.data_ptr(), gY._version, B * N, C, gb, csp)
         with torch.cuda.device(dev):
             _l.check(_l.lib().cpfn_head_post_bwd(_ptr(Yc), _ptr(Xg), _ptr(Ig), _ptr(Tg), _ptr(W), _ptr(stats), _ptr(gXn),
                                                  _ptr(gW), _ptr(gl), 1 if planar else 0, B, N, C - 7, _ptr(gY), _ptr(gS),
                                                  _ptr(gb), _ptr(csp), _stream()), "cpfn_head_post_bwd")
         _l.add_bytes("cpfn_head_post_bwd", 4 * B * N * (2 * C + 3 + (C - 7) + (3 if gXn is not None else 0) + (C - 7 if gW is not None else 0))
                      + 8 * B * N)
-        return gY, None, None, None, None
+        return gY, None, None, None, None, None
 
 
 class SegStats(torch.autograd.Function):
@@ -328,10 +330,12 @@ def hungarian_from_stats(S, I_gt):
     return hungarian_from_pack(hungarian_cost_pack(S, I_gt), S.shape[2])
 
 
-def pre_match(Y, batch):
+def pre_match(Y, batch, handover=None):
     """Everything before the host-side assignment: unit normals, memberships, per-cloud normal /
-    type losses and the label-segmented sums S.  (Capturable: no host synchronisation.)"""
-    Xn, W, nl, tl, S_pre = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"], True)
+    type losses and the label-segmented sums S.  (Capturable: no host synchronisation.)
+    handover: the fused_mlp.HandOver of the forward pass that produced Y (the model's `handover` attribute): the heads'
+    backward then gets its padded gradient rows / column sums from this section's backward launch."""
+    Xn, W, nl, tl, S_pre = HeadPost.apply(Y, batch["X_gt"], batch["I_gt"], batch["T_gt"], True, handover)
     if S_pre.numel() == W.shape[0] * (W.shape[2] + 2) * W.shape[2]:
         return Xn, W, nl, tl, S_pre                   # computed AND differentiated by the heads post-processing node
     return Xn, W, nl, tl, SegStats.apply(W, batch["I_gt"], S_pre)
@@ -369,7 +373,7 @@ def post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt=Non
     return total, parts[0], parts[1], parts[2], parts[3], parts[4]
 
 
-def fused_losses(P, Y, batch, multipliers, classes):
+def fused_losses(P, Y, batch, multipliers, classes, handover=None):
     """P [B,N,3]; Y [B,N,7+K] = packed fp32 heads (normal | type logits | membership logits).
     Returns the reference's (total, normal, type, miou, residue, parameter) scalars.
     More than 32 instance columns (beyond the fused kernels' tile): the op-by-op twin
@@ -384,11 +388,11 @@ def fused_losses(P, Y, batch, multipliers, classes):
                                      batch["points_per_instance"], m["normal"], m["type"], m["miou"], m["residue"],
                                      m["parameter"], m["total"], False, mode_seg='mIoU', classes=classes)[:6]
     if HOST_ASSIGNMENT:
-        Xn, W, nl, tl, S = pre_match(Y, batch)
+        Xn, W, nl, tl, S = pre_match(Y, batch, handover)
         n_gt = count_gt(batch["I_gt"])
         match = hungarian_from_pack(hungarian_cost_pack(S.detach(), batch["I_gt"], n_gt), S.shape[2])
         return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt)
-    Xn, W, nl, tl, S = pre_match(Y, batch)
+    Xn, W, nl, tl, S = pre_match(Y, batch, handover)
     n_gt = count_gt(batch["I_gt"])
     params, match = fit_params_and_match(P, W, Xn, multipliers, S, n_gt)
     return post_match(P, Xn, W, nl, tl, S, match, batch, multipliers, classes, n_gt, params)

@@ -482,12 +482,13 @@ class _FusedStack(torch.autograd.Function):
         ctx.P = P
         ctx.drop_seed = drop_seed
         ctx.x_needs_grad = ctx.needs_input_grad[0]
-        global top_ride_offer, top_ride_result
-        top_ride_offer = top_ride_result = None
-        if (HEADS_RIDE and HEADS_ONE_PASS and BWD_STATS_FUSED and drop_seed is not None and not pool_k
-                and any(ctx.needs_input_grad)):
-            # the consumer of `out` (the packed heads) may take pass 1 of this stack's top layer on its data gradient
-            top_ride_offer = (out.data_ptr(), P, layers[-1].cout, saved[-1][2], saved[-1][3], drop_seed, float(cfg["dropout"][0]))
+        ho = ctx.handover = cfg.get("handover")
+        if ho is not None:
+            ho.top_offer = ho.top_result = None
+            if (HEADS_RIDE and HEADS_ONE_PASS and BWD_STATS_FUSED and drop_seed is not None and not pool_k
+                    and any(ctx.needs_input_grad)):
+                # the consumer of `out` (the packed heads) may take pass 1 of this stack's top layer on its data gradient
+                ho.top_offer = (out.data_ptr(), P, layers[-1].cout, saved[-1][2], saved[-1][3], drop_seed, float(cfg["dropout"][0]))
         return out
 
     @staticmethod
@@ -507,13 +508,19 @@ class _FusedStack(torch.autograd.Function):
         saved = ctx.saved
         dev = g.device
         grads = [None] * (3 * len(layers))
+        g_in = g
         g = g.contiguous().to(BF16)
         gx = None
         fused_part = None          # (partials, rows): pass 1 of THIS layer, left by the data gradient of the layer above
-        global top_ride_result
-        ride, top_ride_result = top_ride_result, None
-        if ride is not None and ride[0] == g.data_ptr() and ctx.drop_seed is not None and not pool_k:
-            fused_part = (ride[1], ride[2])    # ... or, for the top layer, by the heads' one-pass launch (HEADS_RIDE)
+        ho = ctx.handover
+        ride = None
+        if ho is not None:
+            ride, ho.top_result = ho.top_result, None
+        # (the result belongs to the gradient tensor the heads' backward returned: same storage AND same in-place version — a
+        #  second consumer of the stack's output makes autograd add its gradient INTO that tensor when it arrives second)
+        if (ride is not None and ride[0] == g_in.data_ptr() and ride[1] == g_in._version and ctx.drop_seed is not None
+                and not pool_k):
+            fused_part = (ride[2], ride[3])    # ... or, for the top layer, by the heads' one-pass launch (HEADS_RIDE)
         a_ptrs = lambda a_ss: (None, None) if a_ss is None else (_ptr(a_ss[0]), _ptr(a_ss[1]))
         with torch.cuda.device(dev):
             for li in range(len(layers) - 1, -1, -1):
@@ -708,12 +715,13 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
     return "generic", False, False
 
 
-def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None):
+def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None, handover=None):
     """x: bf16 rows [P, Kpad] (Kpad a multiple of 64, zero-padded beyond the first conv's
     in_channels) — or fp32 [P, KS<=4] with first_fp32=True; xyz_tail [P,3] fp32: three more input channels of the first
     layer (behind x's D = Kpad channels) that stay fp32.  Returns bf16 [P, C_last], or
     [P/pool_k, C_last] when pool_k is given (max over each run of pool_k consecutive rows).
-    dropout = (p, counter, base_seed): dropout on the stack's output, fused into the last BN apply (no pooling)."""
+    dropout = (p, counter, base_seed): dropout on the stack's output, fused into the last BN apply (no pooling).
+    handover: the HandOver of this forward pass (side results between this stack's and its consumer's backward nodes)."""
     layers = _layers_from_modules(convs, bns)
     if dropout is not None and pool_k:
         raise ValueError("dropout cannot be fused into a pooled stack")
@@ -723,7 +731,8 @@ def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, 
                                      xyz_tail_ok(x.shape[0], x.shape[1], layers[0].cout)):
         raise ValueError("xyz_tail: [P, D] bf16 rows + [P, 3] fp32 coordinates into a (D + 3)-channel first layer of a shape "
                          "fused_mlp.xyz_tail_ok accepts")
-    cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout, "xyz_tail": xyz_tail}
+    cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout, "xyz_tail": xyz_tail,
+           "handover": handover}
     params = []
     for L in layers:
         params += [L.weight, L.gamma, L.beta]
@@ -762,11 +771,24 @@ def _packed_heads(weights, biases):
     return ent["Wb"], ent["bp"], ent["N"]
 
 
-# (gY address, rows, columns, bf16 rows padded to 64 columns, per-256-row column sums): left by the loss section's heads
-# post-processing backward (SPFN/fused_losses.HeadPost) for the gradient tensor it returns; one-shot
-heads_grad_hint = None
-top_ride_offer = None        # set by a stack whose output ends in the fused dropout: (out ptr, P, N, Y, st, seed, p)
-top_ride_result = None       # set by _Linear.backward when it took the offer: (ga ptr, partials, rows)
+class HandOver:
+    """Side results one backward node leaves for the NEXT one, owned by ONE forward pass of ONE model (PointNet2 makes a
+    fresh one per forward; round 3 kept these in module globals keyed by addresses, so two models trained interleaved in one
+    process could cross wires):
+      top_offer   set by a stack whose output ends in the fused dropout: (out address, P, N, Y, st, seed, p) — the packed
+                  heads' one-pass backward may take pass 1 of that stack's top BatchNorm on its data-gradient slab;
+      top_result  set by _Linear.backward when it took the offer: (ga address, ga version, partials, rows);
+      heads_hint  set by the loss section's heads post-processing backward (SPFN/fused_losses.HeadPost) for the gradient
+                  tensor it returns: (gY address, gY version, rows, columns, bf16 rows padded to 64 columns, per-256-row
+                  column sums).
+    Every entry is one-shot and is only honoured for the very tensor it was made for: same address (all parties belong to
+    one forward pass, whose tensors are alive between producer and consumer, so an address cannot be recycled in between) AND
+    same in-place version — autograd's input buffer adds a second incoming gradient INTO the first when nobody else holds
+    it, which keeps the address and bumps the version.  No tensor is referenced (no cycles through autograd nodes)."""
+    __slots__ = ("top_offer", "top_result", "heads_hint")
+
+    def __init__(self):
+        self.top_offer = self.top_result = self.heads_hint = None
 
 
 class _Linear(torch.autograd.Function):
@@ -774,8 +796,9 @@ class _Linear(torch.autograd.Function):
     panel of _packed_heads; the heads' own parameters come in as *wb so that their gradients are routed back."""
 
     @staticmethod
-    def forward(ctx, a, Wb, bp, N, nheads, *wb):
+    def forward(ctx, a, Wb, bp, N, nheads, handover, *wb):
         flush_pending_cast()
+        ctx.handover = handover
         with torch.cuda.device(a.device):
             Y, _, _ = gemm(a, Wb, bias=bp, out_f32=True, n_store=N)
         ctx.save_for_backward(a, Wb)
@@ -791,15 +814,17 @@ class _Linear(torch.autograd.Function):
         h = _l.lib()
         N, P, K = ctx.n, a.shape[0], a.shape[1]
         Np = Wb.shape[0]
-        global heads_grad_hint
-        hint, heads_grad_hint = heads_grad_hint, None
+        ho = ctx.handover
+        hint = None
+        if ho is not None:
+            hint, ho.heads_hint = ho.heads_hint, None
         gc = g.contiguous().float()
         fused_pad = Np == 64
         gbias = torch.empty(N, dtype=torch.float32, device=a.device)
-        if (hint is not None and fused_pad and hint[0] == gc.data_ptr() and hint[1] == P and hint[2] == N and
-                hint[3].device == a.device):
+        if (hint is not None and fused_pad and hint[0] == gc.data_ptr() and hint[1] == gc._version and hint[2] == P
+                and hint[3] == N and hint[4].device == a.device):
             # the producer of g (the heads post-processing backward) already left the padded bf16 rows and the column sums
-            gb, wsb = hint[3], hint[4]
+            gb, wsb = hint[4], hint[5]
         else:
             gb = torch.empty(P, Np, dtype=BF16, device=a.device) if fused_pad else torch.zeros(P, Np, dtype=BF16, device=a.device)
             if not fused_pad:
@@ -821,9 +846,11 @@ class _Linear(torch.autograd.Function):
                 # weight gradient and data gradient of the packed heads in ONE pass over their gradient rows (the one-pass
                 # kernel's 64 <- 128 shape, linear: nothing to apply, nothing rides)
                 ga = torch.empty(P, K, dtype=BF16, device=a.device)
-                global top_ride_offer, top_ride_result
-                offer, top_ride_offer = top_ride_offer, None
-                ride = (offer is not None and offer[0] == a.data_ptr() and offer[1] == P and offer[2] == K and a.stride(0) == K)
+                offer = None
+                if ho is not None:
+                    offer, ho.top_offer = ho.top_offer, None
+                ride = (offer is not None and offer[0] == a.data_ptr() and offer[1] == P and offer[2] == K
+                        and a.stride(0) == K)
                 Yt, stt, dseed, dp = (offer[3], offer[4], offer[5], offer[6]) if ride else (None, (None, None), None, 0.0)
                 fp_ = torch.empty(splits, 2, K, dtype=torch.float32, device=a.device) if ride else None
                 _check(h.cpfn_mlp_bwd_fused(_ptr(gb), Np, _ptr(a), a.stride(0), _ptr(Wb), P, Np, K, None, None, _ptr(ws), _ptr(ga), K,
@@ -832,7 +859,7 @@ class _Linear(torch.autograd.Function):
                 _l.add_bytes("cpfn_mlp_bwd_fused", 2 * P * Np + 4 * P * K + 4 * splits * Np * K + 2 * Np * K
                              + ((2 * P * K + 8 * splits * K) if ride else 0))
                 if ride:
-                    top_ride_result = (ga.data_ptr(), fp_, splits)
+                    ho.top_result = (ga.data_ptr(), ga._version, fp_, splits)
             else:
                 _check(h.cpfn_mlp_wgrad(_ptr(gb), Np, _ptr(a), a.stride(0), None, P, Np, K, None, None, _ptr(ws), None, _stream()),
                        "cpfn_mlp_wgrad")
@@ -844,14 +871,15 @@ class _Linear(torch.autograd.Function):
             gw.append(dW[o:o + n].reshape(shp))
             gbs.append(gbias[o:o + n])
             o += n
-        return (ga, None, None, None, None) + tuple(gw) + tuple(gbs)
+        return (ga, None, None, None, None, None) + tuple(gw) + tuple(gbs)
 
 
-def linear_heads(a, weights, biases):
-    """a bf16 [P,K]; several (weight [o_i,K,1], bias [o_i]) heads computed as ONE GEMM."""
+def linear_heads(a, weights, biases, handover=None):
+    """a bf16 [P,K]; several (weight [o_i,K,1], bias [o_i]) heads computed as ONE GEMM.
+    handover: the HandOver of this forward pass (None: no side results are exchanged with the neighbouring backward nodes)."""
     weights, biases = list(weights), list(biases)
     Wb, bp, N = _packed_heads(weights, biases)
-    Y = _Linear.apply(a, Wb, bp, N, len(weights), *weights, *biases)
+    Y = _Linear.apply(a, Wb, bp, N, len(weights), handover, *weights, *biases)
     linear_heads.last_packed = Y          # [P, sum(o_i)] fp32, for consumers that want the heads fused
     outs, o = [], 0
     for w in weights:

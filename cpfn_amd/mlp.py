@@ -38,7 +38,7 @@ def shared_mlp(x, convs, bns, dtype=torch.float32):
     return x
 
 
-def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None):
+def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None):
     """Run a whole (conv, bn, relu)* stack on rows and optionally max-pool every `pool_k`
     consecutive rows.  `x` [P, C_in] (any float dtype) — or None with `xyz_rows` [P, 3] fp32
     when the stack's only input is relative coordinates (sa1).
@@ -65,7 +65,7 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
             else:
                 xp[:, :C] = x
             x = xp
-        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout)
+        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout, handover=handover)
     if dropout is not None or xyz_tail is not None:
         raise ValueError("fused dropout / the xyz tail exist on the bf16 HIP path only")
     y = shared_mlp(src, convs, bns, dtype)
@@ -74,10 +74,10 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
     return y
 
 
-def heads(feat, head_convs, dtype=torch.float32):
+def heads(feat, head_convs, dtype=torch.float32, handover=None):
     """fc2 heads on rows [P,128] -> list of fp32 [P, o_i]."""
     if dtype == torch.bfloat16 and feat.is_cuda:
         from . import fused_mlp
         return fused_mlp.linear_heads(feat.to(torch.bfloat16).contiguous(), [h.weight for h in head_convs],
-                                      [h.bias for h in head_convs])
+                                      [h.bias for h in head_convs], handover=handover)
     return [conv_as_linear(feat.to(dtype), h).float() for h in head_convs]

@@ -64,6 +64,25 @@ def fps_faults():
     return n
 
 
+_fps_faults_seen = 0
+
+
+def check_fps_faults(where):
+    """Raise if the several-workgroups FPS has given up on a sibling since the last check: the samples of such a cloud are
+    index 0 from there on — plausible-looking, degenerate geometry.  Called where the host synchronises anyway (the end of
+    `compute_all_metrics`, `get_point_final`, the epoch loop's periodic loss read)."""
+    global _fps_faults_seen
+    if torch.cuda.is_current_stream_capturing():
+        return
+    n = fps_faults()
+    if n > _fps_faults_seen:
+        new, _fps_faults_seen = n - _fps_faults_seen, n
+        raise RuntimeError("cpfn_amd: farthest-point sampling of %d cloud(s) gave up on a sibling workgroup before %s (the "
+                           "workgroups of one cloud were not co-resident); their remaining samples are index 0 — results "
+                           "since the last check are invalid" % (new, where))
+
+
+
 def fps(xyz, num_samples, start=None, skip_near_origin=False):
     """xyz [B,N,3] f32, start [B] i32 or None (-> index 0) -> idx [B,S] i32."""
     _chk(xyz, "xyz", torch.float32)

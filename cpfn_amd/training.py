@@ -88,8 +88,13 @@ class FlatGradBucket:
         ref = self.params[0]
         # (padded so that the bucket splits into equal shards for the reduce-scatter / all-gather layout; `flat` is the
         #  unpadded view everybody else uses, the padding stays zero)
-        self.padded = torch.zeros((n + _BUCKET_PAD - 1) // _BUCKET_PAD * _BUCKET_PAD, dtype=torch.float32, device=ref.device)
+        #  ... except its first element, the FAULT SLOT: under data parallelism a rank's sticky "a cross-stream flag wait timed
+        #  out" word is packed there by the gradient-packing launch and rides on the same collective, so that every rank skips
+        #  the optimizer step when ANY rank faulted — a per-rank skip would let the replicas diverge)
+        self.padded = torch.zeros((n + 1 + _BUCKET_PAD - 1) // _BUCKET_PAD * _BUCKET_PAD, dtype=torch.float32, device=ref.device)
         self.flat = self.padded[:n]
+        self.fault_slot = self.padded[n:n + 1]
+        self._exchanged = self.padded[:n + 1]          # what the all-reduce layout moves: gradients + fault slot
         self._shard = None
         self.collective = DP_COLLECTIVE if DP_COLLECTIVE in ("all_reduce", "rs_ag") else "all_reduce"
         self.views, off = [], 0
@@ -104,7 +109,7 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
-    def collect(self, check=False):
+    def collect(self, check=False, fault=None):
         """Call after the backward pass: pack the fresh gradients into the flat buffer.  Parameters that
         received no gradient (conv biases in front of a training-mode BatchNorm) keep a zero slice and
         `.grad = None`, which the optimizer skips — identical to a zero update.  A parameter that HAD a gradient in
@@ -112,7 +117,8 @@ class FlatGradBucket:
         so neither the flat optimizer nor the all-reduce ever sees a stale gradient.
         check=True (GPU): the packing copy also scans what it copies for NaN / inf (cpfn_multi_copy_checked) and the
         per-workgroup flags are returned as (flags int32 tensor, count) for FlatAdam.step(nf_flags=...); None when
-        nothing had to be copied or the scan could not ride along."""
+        nothing had to be copied or the scan could not ride along.
+        fault (data parallel): this rank's 0-dim fp32 fault word; the same launch copies it into the bucket's fault slot."""
         src, dst, who = [], [], []
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             if p.grad is None:
@@ -126,6 +132,9 @@ class FlatGradBucket:
                 dst.append(v)
                 who.append(p)
         flags = None
+        if fault is not None:
+            src.append(fault.reshape(1))
+            dst.append(self.fault_slot)
         if src:
             if self.flat.is_cuda:
                 if check:
@@ -156,10 +165,10 @@ class FlatGradBucket:
                     self._shard.div_(world)
                 dist.all_gather_into_tensor(self.padded, self._shard)
             elif avg:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+                dist.all_reduce(self._exchanged, op=dist.ReduceOp.AVG)
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                self.flat.div_(world)
+                dist.all_reduce(self._exchanged, op=dist.ReduceOp.SUM)
+                self._exchanged.div_(world)
 
     def finite(self):
         """One fused reduction instead of the reference's per-parameter isinf/isnan scan
@@ -351,7 +360,8 @@ class SPFNTrainer:
         packed = getattr(self.module, "heads_packed", None)
         if self.fused_losses and packed is not None and len(self.classes) == 4 and T.shape[2] == 4:
             from .SPFN import fused_losses
-            return fused_losses.fused_losses(P, packed, batch, self.mult, self.classes)
+            return fused_losses.fused_losses(P, packed, batch, self.mult, self.classes,
+                                             handover=getattr(self.module, "handover", None))
         X = torch.nn.functional.normalize(X, p=2, dim=2, eps=1e-12)
         W = torch.softmax(W, dim=2)
         gt = {'plane_normal': batch["plane_n_gt"], 'cylinder_axis': batch["cylinder_axis_gt"],
@@ -618,13 +628,13 @@ class SPFNTrainer:
                 stamp(0)
                 self.bucket.zero()
                 self.module(sb["P"], geometry=st["geomA"], **self._feature_kwargs(sb))
-                Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb)
+                Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb, getattr(self.module, "handover", None))
                 n_gt = fl.count_gt(sb["I_gt"])
                 params, st["match"] = fl.fit_params_and_match(sb["P"], W, Xn, self.mult, S, n_gt)
                 with fl.unit_loss_gradient():
                     out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
                 out[0].backward(st["unit"])              # (no ones_like fill inside the graph)
-                nf = self.bucket.collect(check=world == 1)
+                nf = self.bucket.collect(check=world == 1, fault=st["flag_fault"] if world > 1 else None)
                 if world == 1:
                     self._checked_optimizer_step(st["skipped"], nf, fault=st["flag_fault"])
                 elif exchange_in_graph:
@@ -633,7 +643,9 @@ class SPFNTrainer:
                     # clock): `comm_us()` of the last replayed step, so that a scaling run can tell exchange time from
                     # everything else (2 x ~3 us on a 1.9 ms chain).
                     self._exchange_with_stamps(dev)
-                    self._checked_optimizer_step(st["skipped"], fault=st["flag_fault"])
+                    # (the fault word every rank packed into the bucket's fault slot came back averaged: non-zero on EVERY rank
+                    #  when any rank's flag wait timed out — all replicas skip together)
+                    self._checked_optimizer_step(st["skipped"], fault=self.bucket.fault_slot.reshape(()))
                 st["out"] = tuple(o.detach() for o in out)
                 stamp(2)
                 stamp(3)
@@ -649,7 +661,7 @@ class SPFNTrainer:
             self._copy_all(geomA, geomB)
             self.bucket.zero()
             self.module(sb["P"], geometry=st["geomA"], **self._feature_kwargs(sb))
-            st["pre"] = fl.pre_match(self.module.heads_packed, sb)
+            st["pre"] = fl.pre_match(self.module.heads_packed, sb, getattr(self.module, "handover", None))
             st["n_gt"] = fl.count_gt(sb["I_gt"])
             st["cost_pack"] = fl.hungarian_cost_pack(st["pre"][4].detach(), sb["I_gt"], st["n_gt"])   # device part, in-graph
             st["cost_host"].copy_(st["cost_pack"], non_blocking=True)          # D2H node at the end of G1
@@ -701,6 +713,14 @@ class SPFNTrainer:
         st = self._graph
         single = st["single"]
         if single and int(st["flag_err"][0]) != 0:
+            if st["world"] > 1:
+                # the peers would sit in the next step's in-graph collective until the RCCL time-out: take the group down
+                abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+                try:
+                    if abort is not None:
+                        abort()
+                except Exception:
+                    pass
             raise RuntimeError("cpfn_amd: a cross-stream flag wait of the replayed step timed out after %.0f s (the other "
                                "stream's graph was never launched, or it stalled for longer than CPFN_FLAG_TIMEOUT_S); the "
                                "optimizer has skipped every step since, the losses of the last steps are invalid"
@@ -775,7 +795,7 @@ class SPFNTrainer:
             st["n_main"] += 1
             if st["world"] > 1 and not st["exchange_in_graph"]:
                 self._exchange_with_stamps(batch["P"].device)
-                self._checked_optimizer_step(st["skipped"], fault=st["flag_fault"])
+                self._checked_optimizer_step(st["skipped"], fault=self.bucket.fault_slot.reshape(()))
             self.global_step += 1
             return st["out"]
         st["g1"].replay()

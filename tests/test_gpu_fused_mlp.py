@@ -208,12 +208,13 @@ def test_heads_one_pass_takes_the_dropout_stack_s_reduction(P, monkeypatch):
         counter = torch.zeros(1, dtype=torch.int64, device=dev())      # same counter, same seed: the same mask both times
         xin = x.clone().requires_grad_(True)
         _l.byte_census(True)
-        feats = fused_mlp.fused_mlp_stack(xin, convs, bns, dropout=(0.5, counter, 77))
-        outs = fused_mlp.linear_heads(feats, heads_w, heads_b)
+        ho = fused_mlp.HandOver()
+        feats = fused_mlp.fused_mlp_stack(xin, convs, bns, dropout=(0.5, counter, 77), handover=ho)
+        outs = fused_mlp.linear_heads(feats, heads_w, heads_b, handover=ho)
         (torch.cat(outs, 1) * gout).sum().backward()
         census = _l.byte_census(False)
         assert ("cpfn_bn_relu_bwd" in census) == (not ride), sorted(census)
-        assert fused_mlp.top_ride_offer is None and fused_mlp.top_ride_result is None
+        assert ho.top_offer is None and ho.top_result is None and ho.heads_hint is None
         res[ride] = (feats.detach().clone(), xin.grad.float().clone(), [q.grad.clone() for q in params if q.grad is not None])
     (fa, gxa, gpa), (fb, gxb, gpb) = res[True], res[False]
     assert torch.equal(fa, fb)

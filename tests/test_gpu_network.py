@@ -317,3 +317,107 @@ def test_heads_gradient_hint_is_bit_identical_to_the_colsum_launch(monkeypatch):
         res[hint] = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
     for a, b in zip(res[True], res[False]):
         assert (a is None and b is None) or torch.equal(a, b)
+
+
+def _step_grads(model, batch, starts, aux=None, mult=None):
+    """One forward + losses + backward of the trainer's eager path; aux(model outputs) -> extra scalar added to the total."""
+    from cpfn_amd import training
+    tr = training.SPFNTrainer(model, batch_size=batch["P"].shape[0], multipliers=mult)
+    model.return_point_features = True
+    tr.bucket.zero()
+    out = tr.losses(batch, fps_start=starts)
+    total = out[0]
+    if aux is not None:
+        total = total + aux(model)
+    total.backward()
+    return [None if p.grad is None else p.grad.clone() for p in model.parameters()], [float(o) for o in out]
+
+
+def _fresh_model(K, seed=0):
+    from cpfn_amd.PointNet2 import pn2_network
+    torch.manual_seed(seed)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, K]).to(torch.device("cuda:0"))
+    m.set_compute_dtype(torch.bfloat16)
+    return m
+
+
+@pytest.mark.parametrize("which", ["heads", "features"])
+def test_hand_overs_are_dropped_when_a_second_consumer_adds_to_the_gradient(which, monkeypatch):
+    """the side results one backward node hands to the next (padded gradient rows + column sums of the
+    packed heads; fc1's BatchNorm pass-1 partials) are computed from ONE incoming gradient.  With a second consumer of the
+    packed heads (an auxiliary loss on their slices) or of fc1's output (the per-point features), autograd adds the second
+    gradient into the first tensor in place — same address — and a hand-over keyed by the address alone would silently drop
+    it.  The hand-over also carries the tensor's in-place version: the result must equal the run with the hand-overs off."""
+    from cpfn_amd import fused_mlp, synthetic
+    from cpfn_amd.SPFN import fused_losses as fl
+    dev = torch.device("cuda:0")
+    batch = {k: v.to(dev) for k, v in synthetic.training_batch(2, N=2048, n_prims=6, n_inst_points=128, seed=3).items()}
+    starts = (torch.tensor([5, 17]), torch.tensor([1, 300]))
+    if which == "heads":
+        aux = lambda m: (m.heads_packed[..., :7] ** 2).sum() * 1e-3 + m.heads_packed[..., 7:].abs().sum() * 1e-4
+    else:
+        aux = None        # (set below: needs the model's outputs)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(fl, "HEADS_HINT", on)
+        monkeypatch.setattr(fused_mlp, "HEADS_RIDE", on)
+        model = _fresh_model(28)
+        torch.manual_seed(5)                       # dropout base seed: the same mask both times
+        if which == "features":
+            outs = {}
+            orig = model._forward
+
+            def keep(*a, _o=orig, _d=outs, **k):
+                r = _o(*a, **k)
+                _d["feat"] = r[4]
+                return r
+            model._forward = keep
+            aux = lambda m, _d=outs: (_d["feat"].float() ** 2).sum() * 1e-3
+        res[on] = _step_grads(model, batch, starts, aux)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    # ... and the auxiliary gradient is really in there (the test would not see a dropped one otherwise)
+    model = _fresh_model(28)
+    torch.manual_seed(5)
+    plain, _ = _step_grads(model, batch, starts, None)
+    assert any(a is not None and not torch.equal(a, b) for a, b in zip(res[True][0], plain))
+
+
+def test_two_models_with_interleaved_backward_passes_match_their_solo_runs():
+    """VERDICT r3 #8a: the hand-over state between backward nodes is owned by the forward pass of ONE model (fused_mlp.HandOver),
+    not by the module: GlobalSPFN (K = 28) and LocalSPFN (K = 21) run forward, forward, backward, backward in one process and
+    both get the gradients of their solo runs, bit for bit (same launches: nothing falls back because of the other model)."""
+    from cpfn_amd import lib as _l, synthetic
+    dev = torch.device("cuda:0")
+    starts = (torch.tensor([5, 17]), torch.tensor([1, 300]))
+    local_mult = dict(miou=1.0, normal=1.0, type=1.0, parameter=0.0, residue=0.0, total=1.0)
+    cfgs = {"g": (28, None, synthetic.training_batch(2, N=2048, n_max_instances=28, n_prims=6, n_inst_points=128, seed=3)),
+            "l": (21, local_mult, synthetic.training_batch(2, N=2048, n_max_instances=21, n_prims=5, n_inst_points=128, seed=4))}
+    cfgs = {k: (K, m, {kk: v.to(dev) for kk, v in b.items()}) for k, (K, m, b) in cfgs.items()}
+    solo, census_solo = {}, {}
+    for name, (K, mult, batch) in cfgs.items():
+        model = _fresh_model(K, seed=1)
+        torch.manual_seed(9)
+        _l.byte_census(True)
+        solo[name] = _step_grads(model, batch, starts, None, mult)
+        census_solo[name] = {k: v[0] for k, v in _l.byte_census(False).items()}
+    from cpfn_amd import training
+    models = {n: _fresh_model(K, seed=1) for n, (K, _, _) in cfgs.items()}
+    trs, totals = {}, {}
+    _l.byte_census(True)
+    for n, (K, mult, batch) in cfgs.items():                     # forward g, forward l
+        torch.manual_seed(9)
+        trs[n] = training.SPFNTrainer(models[n], batch_size=2, multipliers=mult)
+        models[n].return_point_features = True
+        trs[n].bucket.zero()
+        totals[n] = trs[n].losses(batch, fps_start=starts)[0]
+    for n in ("g", "l"):                                        # backward g, backward l (the other model's forward lies between)
+        totals[n].backward()
+    census = {k: v[0] for k, v in _l.byte_census(False).items()}
+    for n in cfgs:
+        got = [None if p.grad is None else p.grad for p in models[n].parameters()]
+        for a, b in zip(got, solo[n][0]):
+            assert (a is None and b is None) or torch.equal(a, b), n
+    # the same launches as the two solo runs together: no hand-over was refused
+    both = {k: census_solo["g"].get(k, 0) + census_solo["l"].get(k, 0) for k in set(census_solo["g"]) | set(census_solo["l"])}
+    assert census == both, sorted((k, census.get(k), both.get(k)) for k in set(census) | set(both) if census.get(k) != both.get(k))
