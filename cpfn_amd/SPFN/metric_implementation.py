@@ -1,11 +1,21 @@
 """Evaluation metrics of SPFN (drop-in names for SPFN/metric_implementation.py).
 
-Same functions, arguments and return values as the reference, evaluated on the device with the kernels of
-the training path: the assignment runs on the device (cpfn_hungarian_match on the label-segmented sums), the
-four fits are one fused pass (`losses_implementation.compute_parameters`), and P coverage — the one
-heavy metric: every point of the cloud against every instance slot — is one streaming kernel
-(cpfn_p_coverage) instead of `[B,K,N,3]` / `[B,K,N,4]` expansions (77 MB per 131072-point cloud at K = 49).
-The `[B,K]`-sized bookkeeping stays stock PyTorch, as in the reference.
+Same functions, arguments and return values as the reference, evaluated on the device.  `compute_all_metrics`
+(reference :485-514) is a chain of ten launches (csrc/metrics.hip + the training path's kernels), not ~200 framework
+launches on [B,N,K] / [B,K,N',4] expansions:
+
+  cpfn_metrics_points     one pass over the points: hard one-hot W, the (GT label x predicted label) histogram that is the
+                          assignment's cost input for one-hot memberships, per-instance types, the normal difference
+  cpfn_hungarian_match    the assignment on the device (K <= 64; SciPy on the host beyond, as in the reference)
+  FitParams               the four fits of every instance (moments -> algebra -> cone pass -> pack: 4 launches)
+  cpfn_metrics_tail       matched IoU, type accuracy, axis difference and the per-instance residue statistics (mean, std,
+                          Sk coverage), reduced to the per-cloud figures
+  cpfn_p_coverage         every point of the cloud against every instance slot (2 launches)
+
+Label sets of different widths (K predictions vs K_gt ground-truth slots, :487-492, :505-508) are handled INSIDE the
+kernels — a slot beyond either table reads as zeros — so nothing is padded with concatenations.  The stand-alone helpers
+(`compute_type_accuracy`, `compute_Sk_coverage`, ...) keep the reference's names and results for callers that use them one
+by one; they are written on one shared masked-mean helper.
 """
 import ctypes
 
@@ -17,6 +27,7 @@ from . import fused_losses as _fl
 from . import losses_implementation
 
 PARAM_ORDER = [k for k, _ in _fl.PARAM_LAYOUT]
+_CANON = ("plane", "sphere", "cylinder", "cone")         # order of the kernels' type-id argument
 
 
 def hungarian_matching(W_pred, I_gt):
@@ -25,12 +36,25 @@ def hungarian_matching(W_pred, I_gt):
     B, N, K = W_pred.shape
     S = _fl.SegStats.apply(W_pred.detach().float(), I_gt)
     n_gt = _fl.count_gt(I_gt)
+    match = _assign(S, I_gt, n_gt)
+    return match, _slot_mask(n_gt, K)
+
+
+def _assign(S, I_gt, n_gt):
+    K = S.shape[2]
     if _fl.HOST_ASSIGNMENT or K > 64:       # (the device solver: one lane per column)
-        match = _fl.hungarian_from_pack(_fl.hungarian_cost_pack(S, I_gt, n_gt), K)
-    else:
-        match = _fl.hungarian_device(S, n_gt)
-    mask = torch.arange(K, device=W_pred.device).unsqueeze(0) < n_gt.unsqueeze(1)
-    return match, mask
+        return _fl.hungarian_from_pack(_fl.hungarian_cost_pack(S, I_gt, n_gt), K)
+    return _fl.hungarian_device(S, n_gt)
+
+
+def _slot_mask(n_gt, K):
+    return torch.arange(K, device=n_gt.device).unsqueeze(0) < n_gt.unsqueeze(1)
+
+
+def _instance_mean(per_slot, mask):
+    """Average of a [B,K] quantity over the slots that hold a GT instance."""
+    m = mask.to(per_slot.dtype)
+    return (per_slot * m).sum(dim=1) / m.sum(dim=1)
 
 
 def hard_W_encoding(W):
@@ -48,7 +72,7 @@ def sqrt_safe(x):
 
 
 def get_residual_loss(parameters, matching_indices, points_per_instance, T, classes=['plane', 'sphere', 'cylinder', 'cone']):
-    """sqrt_safe of the per-point residue of the primitive type T[b,k], matched prediction (reference lines 69-75)."""
+    """sqrt_safe of the per-point residue of the primitive type T[b,k], matched prediction (reference lines 76-81)."""
     B, K, Np, _ = points_per_instance.shape
     _, per_point = losses_implementation.compute_residue_loss(parameters, matching_indices, points_per_instance,
                                                               torch.gather(T, 1, matching_indices), classes=classes)
@@ -61,36 +85,39 @@ def acos_safe(x):
 
 
 def compute_segmentation_iou(W, I_gt, matching_indices, mask):
-    mIoU = 1 - losses_implementation.compute_miou_loss(W, I_gt, matching_indices)[0]
-    return torch.sum(mask * mIoU, dim=1) / torch.sum(mask, dim=1)
+    """(reference lines 119-121)"""
+    iou_loss, _ = losses_implementation.compute_miou_loss(W, I_gt, matching_indices)
+    return _instance_mean(1 - iou_loss, mask)
 
 
 def compute_type_accuracy(T, T_gt, matching_indices, mask):
-    T_reordered = torch.gather(T, 1, matching_indices)
-    return torch.sum(mask * (T_reordered == T_gt), dim=1) / torch.sum(mask, dim=1)
+    """(reference lines 142-144)"""
+    return _instance_mean((T.gather(1, matching_indices) == T_gt).to(torch.float32), mask)
 
 
 def compute_normal_difference(X, X_gt):
-    return torch.mean(acos_safe(torch.abs(torch.sum(X * X_gt, dim=2))), dim=1)
+    """(reference lines 170-172)"""
+    return acos_safe((X * X_gt).sum(dim=2).abs()).mean(dim=1)
 
 
 def compute_axis_difference(predicted_parameters, gt_parameters, matching_indices, T, T_gt, mask,
                             classes=['plane', 'sphere', 'cylinder', 'cone'], div_eps=1e-10):
-    mask = mask * (T == T_gt).float()
-    parameter_loss = losses_implementation.compute_parameter_loss(predicted_parameters, gt_parameters, matching_indices,
-                                                                  T_gt, is_eval=True, classes=classes)
-    return torch.sum(mask * parameter_loss, dim=1) / torch.clamp(torch.sum(parameter_loss, dim=1), min=div_eps, max=None)
+    """Angle between matched and GT axis, counted where the slot's OWN predicted type equals the GT type and normalised by
+    the sum of the angles over all slots (the reference's definition, lines 189-193)."""
+    angle = losses_implementation.compute_parameter_loss(predicted_parameters, gt_parameters, matching_indices, T_gt,
+                                                         is_eval=True, classes=classes)
+    counted = mask.to(angle.dtype) * (T == T_gt).to(angle.dtype)
+    return (counted * angle).sum(dim=1) / angle.sum(dim=1).clamp(min=div_eps)
 
 
 def compute_meanstd_Sk_residual(residue_loss, mask):
-    mean_residual = torch.sum(mask * torch.mean(residue_loss, dim=2), dim=1) / torch.sum(mask, dim=1)
-    std_residual = torch.sum(mask * torch.std(residue_loss, dim=2), dim=1) / torch.sum(mask, dim=1)
-    return mean_residual, std_residual
+    """(reference lines 257-260; torch.std: unbiased)"""
+    return _instance_mean(residue_loss.mean(dim=2), mask), _instance_mean(residue_loss.std(dim=2), mask)
 
 
 def compute_Sk_coverage(residue_loss, epsilon, mask):
-    residue_loss = torch.mean((residue_loss < epsilon).float(), dim=2)
-    return torch.sum(mask * residue_loss, dim=1) / torch.sum(mask, dim=1)
+    """(reference lines 332-335)"""
+    return _instance_mean((residue_loss < epsilon).to(torch.float32).mean(dim=2), mask)
 
 
 def pack_parameters(predicted_parameters):
@@ -100,25 +127,40 @@ def pack_parameters(predicted_parameters):
     return torch.cat(cols, dim=-1).float().contiguous()
 
 
-def compute_P_coverages(P, T, matching_indices, predicted_parameters, list_epsilon, classes=['plane', 'sphere', 'cylinder', 'cone']):
-    """P coverage for up to four epsilons in ONE pass over the cloud -> [n_eps, B] (cpfn_p_coverage)."""
+def unpack_parameters(params22):
+    """[B,K,22] (cpfn_fit_pack_fwd layout) -> dict of the 10 fitted tensors, as views."""
+    out, o = {}, 0
+    for key, width in _fl.PARAM_LAYOUT:
+        out[key] = params22[..., o:o + width] if width > 1 else params22[..., o]
+        o += width
+    return out
+
+
+def _type_ids(classes):
+    return (ctypes.c_int * 4)(*[classes.index(c) if c in classes else -1 for c in _CANON])
+
+
+def _p_coverage(P, params22, matching_indices, slot_type, list_epsilon, classes):
     B, N, _ = P.shape
-    K = T.shape[1]
-    if not P.is_cuda:
-        raise RuntimeError("compute_P_coverage: CPU not supported")
-    params = pack_parameters(predicted_parameters)
-    slot_type = torch.gather(T, 1, matching_indices).contiguous()          # reference line 412: gather(T, 1, matching)
+    K = slot_type.shape[1]
     n_eps = len(list_epsilon)
     h = _l.lib()
     ws = torch.empty(B * ((N + 255) // 256) * n_eps, dtype=torch.float32, device=P.device)
     out = torch.empty(B, n_eps, dtype=torch.float32, device=P.device)
-    ids = (ctypes.c_int * 4)(*[classes.index(c) for c in ("plane", "sphere", "cylinder", "cone")])
     eps = (ctypes.c_float * n_eps)(*[float(e) for e in list_epsilon])
     with torch.cuda.device(P.device):
-        _l.check(h.cpfn_p_coverage(_ptr(P.contiguous().float()), _ptr(params), _ptr(matching_indices.contiguous()),
-                                   _ptr(slot_type), B, N, K, ids, eps, n_eps, _ptr(ws), _ptr(out), _stream()),
-                 "cpfn_p_coverage")
-    return out.t()
+        _l.check(h.cpfn_p_coverage(_ptr(P), _ptr(params22), _ptr(matching_indices), _ptr(slot_type), B, N, K, _type_ids(classes),
+                                   eps, n_eps, _ptr(ws), _ptr(out), _stream()), "cpfn_p_coverage")
+    return out
+
+
+def compute_P_coverages(P, T, matching_indices, predicted_parameters, list_epsilon, classes=['plane', 'sphere', 'cylinder', 'cone']):
+    """P coverage for up to four epsilons in ONE pass over the cloud -> [n_eps, B] (cpfn_p_coverage)."""
+    if not P.is_cuda:
+        raise RuntimeError("compute_P_coverage: CPU not supported")
+    slot_type = torch.gather(T, 1, matching_indices).contiguous()          # reference line 412: gather(T, 1, matching)
+    return _p_coverage(P.contiguous().float(), pack_parameters(predicted_parameters), matching_indices.contiguous(), slot_type,
+                       list_epsilon, classes).t()
 
 
 def compute_P_coverage(P, T, matching_indices, predicted_parameters, epsilon, classes=['plane', 'sphere', 'cylinder', 'cone']):
@@ -126,39 +168,73 @@ def compute_P_coverage(P, T, matching_indices, predicted_parameters, epsilon, cl
     return compute_P_coverages(P, T, matching_indices, predicted_parameters, [epsilon], classes)[0]
 
 
+FUSED_MAX_K = 128         # label-set width up to which the point pass keeps its histogram on chip (cpfn_metrics_points)
+
+
 def compute_all_metrics(P, X, X_gt, W, I_gt, T, T_gt, points_per_instance, gt_parameters, list_epsilon=[0.01, 0.02],
                         classes=['plane', 'sphere', 'cylinder', 'cone']):
     """Same 11-tuple as the reference (lines 485-514): mIoU, type accuracy, normal difference, axis difference,
-    mean / std Sk residual, Sk coverage per epsilon, P coverage per epsilon, hard W, fitted parameters, instance types."""
-    W = hard_W_encoding(W)
-    T = get_instance_type(T, W)
-    diff = T.size(1) - T_gt.size(1)
-    if diff > 0:
-        T_gt = torch.cat((T_gt, torch.zeros_like(T_gt[:, 0:1]).expand(-1, diff)), dim=1)
-    elif diff < 0:
-        W = torch.cat((W, torch.zeros_like(W[:, :, 0:1]).expand(-1, -1, -diff)), dim=2)
-        T = torch.cat((T, torch.zeros_like(T[:, 0:1]).expand(-1, -diff)), dim=1)
-    matching_indices, mask = hungarian_matching(W, I_gt)
-    mask = mask.float()
-    mIoU = compute_segmentation_iou(W, I_gt, matching_indices, mask)
-    type_accuracy = compute_type_accuracy(T, T_gt, matching_indices, mask)
-    normal_difference = compute_normal_difference(X, X_gt)
-    predicted_parameters = losses_implementation.compute_parameters(P, W, X)
-    if diff > 0:
-        gt_parameters = dict(gt_parameters)
-        for key in ('plane_normal', 'cylinder_axis', 'cone_axis'):
-            g = gt_parameters[key]
-            gt_parameters[key] = torch.cat((g, torch.zeros_like(g[:, 0:1]).expand(-1, diff, 3)), dim=1)
-        points_per_instance = torch.cat((points_per_instance, torch.zeros_like(points_per_instance[:, 0:1]).expand(
-            -1, diff, points_per_instance.shape[2], 3)), dim=1)
-    axis_difference = compute_axis_difference(predicted_parameters, gt_parameters, matching_indices, T, T_gt, mask, classes=classes)
-    residue_loss = get_residual_loss(predicted_parameters, matching_indices, points_per_instance, T_gt, classes=classes)
-    mean_residual, std_residual = compute_meanstd_Sk_residual(residue_loss, mask)
-    Sk_coverage = [compute_Sk_coverage(residue_loss, epsilon, mask) for epsilon in list_epsilon]
-    pc = compute_P_coverages(P, T, matching_indices, predicted_parameters, list_epsilon, classes=classes)
-    P_coverage = [pc[i] for i in range(len(list_epsilon))]
-    return (mIoU, type_accuracy, normal_difference, axis_difference, mean_residual, std_residual, Sk_coverage, P_coverage,
-            W, predicted_parameters, T)
+    mean / std Sk residual, Sk coverage per epsilon, P coverage per epsilon, hard W, fitted parameters, instance types —
+    the last three Kp = max(K, K_gt) wide, like the reference's padded ones."""
+    if not P.is_cuda:
+        raise RuntimeError("compute_all_metrics: CPU not supported (cpfn_amd runs on the HIP path only)")
+    B, N, K = W.shape
+    Kgt, Np = T_gt.shape[1], points_per_instance.shape[2]
+    Kp, NT = max(K, Kgt), T.shape[2]
+    dev = P.device
+    f32 = lambda t: t.contiguous().float()
+    P, X, X_gt, W, T = f32(P), f32(X), f32(X_gt), f32(W), f32(T)
+    I_gt, T_gt = I_gt.contiguous().long(), T_gt.contiguous().long()
+    h = _l.lib()
+    hardW = torch.empty(B, N, Kp, dtype=torch.float32, device=dev)
+    head = torch.empty(B, 1, dtype=torch.float32, device=dev)                 # normal difference
+    if Kp <= FUSED_MAX_K and NT <= 8:
+        S = torch.empty(B, Kp + 2, Kp, dtype=torch.float32, device=dev)
+        n_gt = torch.empty(B, dtype=torch.int64, device=dev)
+        T_inst = torch.empty(B, Kp, dtype=torch.int64, device=dev)
+        ws = torch.empty(h.cpfn_metrics_workspace(B, N, Kp, NT), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _l.check(h.cpfn_metrics_points(_ptr(W), _ptr(T), _ptr(X), _ptr(X_gt), _ptr(I_gt), B, N, K, Kp, NT, _ptr(hardW), _ptr(ws),
+                                           _ptr(S), _ptr(n_gt), _ptr(T_inst), _ptr(head), _stream()), "cpfn_metrics_points")
+    else:               # label sets wider than the on-chip histogram: the same quantities from the generic kernels
+        hardW.zero_()
+        hardW[:, :, :K] = hard_W_encoding(W)
+        T_inst = torch.zeros(B, Kp, dtype=torch.int64, device=dev)
+        T_inst[:, :K] = get_instance_type(T, hardW[:, :, :K])
+        S = _fl.SegStats.apply(hardW, I_gt)
+        n_gt = _fl.count_gt(I_gt)
+        head[:, 0] = compute_normal_difference(X, X_gt)
+    match = _assign(S, I_gt, n_gt)
+    with torch.no_grad():
+        params22 = _fitters_packed(P, hardW, X)
+    n_eps = len(list_epsilon)
+    tail = torch.empty(B, 5 + min(n_eps, 4), dtype=torch.float32, device=dev)
+    slot_type = torch.empty(B, Kp, dtype=torch.int64, device=dev)
+    axes = [f32(gt_parameters[k]) for k in ('plane_normal', 'cylinder_axis', 'cone_axis')]
+    ppi = f32(points_per_instance)
+    Sk, Pc = [], []
+    for e0 in range(0, max(n_eps, 1), 4):                                     # (the kernels take four thresholds at a time)
+        eps = [float(e) for e in list_epsilon[e0:e0 + 4]]
+        ceps = (ctypes.c_float * max(len(eps), 1))(*eps)
+        if e0 > 0:
+            tail = torch.empty(B, 5 + len(eps), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _l.check(h.cpfn_metrics_tail(_ptr(S), _ptr(match), _ptr(n_gt), _ptr(T_inst), _ptr(T_gt), _ptr(params22), _ptr(ppi),
+                                         _ptr(axes[0]), _ptr(axes[1]), _ptr(axes[2]), B, Kp, Kgt, Np, _type_ids(classes), ceps,
+                                         len(eps), _ptr(tail), _ptr(slot_type), _stream()), "cpfn_metrics_tail")
+        if e0 == 0:
+            first = tail
+        if eps:
+            Sk += [tail[:, 5 + i] for i in range(len(eps))]
+            pc = _p_coverage(P, params22, match, slot_type, eps, classes)
+            Pc += [pc[:, i] for i in range(len(eps))]
+    return (first[:, 0], first[:, 1], head[:, 0], first[:, 2], first[:, 3], first[:, 4], Sk, Pc, hardW,
+            unpack_parameters(params22), T_inst)
+
+
+def _fitters_packed(P, W, X):
+    from . import fitters_common as _fc
+    return _fc.fit_params(P, W, X)
 
 
 # Names the device path does not define (host-side GT parsing / JSON export, the TensorFlow twins) come from the

@@ -31,6 +31,7 @@ SOURCES = {
     "mlp.hip": [],
     "losses.hip": [],
     "merging.hip": [],
+    "metrics.hip": [],
     "optim.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",

@@ -13,6 +13,7 @@
 // All reductions use per-block partials summed in a fixed order (no float atomics in forward passes).
 #include "common.h"
 #include "lsap.h"
+#include "residue.h"
 
 namespace {
 
@@ -566,33 +567,7 @@ inline int loss_chunks(int B, int N, int *ppb) {
 // four residue formulas for every (k, n) ([B,K,N,4]: 77 MB at one 131072-point cloud with K = 49); here one lane
 // per point walks the K slots with the slot parameters in LDS.
 // residue value only (no tangents): the same formulas as residue_of above
-__device__ inline float sqrt_safe_f(float x) { return sqrtf(fabsf(x) + 1e-10f); }   // metric_implementation.py:65-66
-__device__ inline float residue_value(int kind, const float *q, float px, float py, float pz) {
-  if (kind == 0) {
-    const float e = px * q[0] + py * q[1] + pz * q[2] - q[3];
-    return e * e;
-  } else if (kind == 1) {
-    const float dx = px - q[0], dy = py - q[1], dz = pz - q[2];
-    const float e = sqrt_safe_f(dx * dx + dy * dy + dz * dz) - sqrt_safe_f(q[3]);
-    return e * e;
-  } else if (kind == 2) {
-    const float dx = px - q[3], dy = py - q[4], dz = pz - q[5];
-    const float al = dx * q[0] + dy * q[1] + dz * q[2];
-    const float e = sqrt_safe_f(dx * dx + dy * dy + dz * dz - al * al) - sqrt_safe_f(q[6]);
-    return e * e;
-  } else {
-    const float vx = px - q[0], vy = py - q[1], vz = pz - q[2];
-    const float n2 = vx * vx + vy * vy + vz * vz;
-    const float inv = 1.f / fmaxf(sqrtf(n2), 1e-12f);
-    float c = (vx * q[3] + vy * q[4] + vz * q[5]) * inv;
-    const float lim = 1.0f - 1e-6f;
-    c = fminf(fmaxf(c, -lim), lim);
-    const float ad = fabsf(acosf(c) - q[6]);
-    const float sn = sinf(fminf(ad, 1.57079632679f));
-    return sn * sn * n2;
-  }
-}
-
+// (sqrt_safe_f, residue_value: residue.h — shared with the evaluation tail, metrics.hip)
 constexpr int PC_MAXEPS = 4;
 struct PcEps { float e[PC_MAXEPS]; };
 // partial[b][chunk][n_eps] = number of points of the chunk with min_k sqrt_safe(residue) < eps

@@ -71,6 +71,9 @@ SIGNATURES = {
     "cpfn_nonfinite_partial": [_vp, _ll, _vp, _vp],
     "cpfn_hungarian_match": [_vp, _vp, _i, _i, _vp, _vp],
     "cpfn_p_coverage": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "cpfn_metrics_workspace": [_i, _i, _i, _i],
+    "cpfn_metrics_points": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_metrics_tail": [_vp] * 10 + [_i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "cpfn_loss_tail": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_eigh3": [_vp, _i64, _vp, _vp, _vp],
     "cpfn_similarity_soft_workspace": [_i, _i, _i, _i, _i],
@@ -122,7 +125,8 @@ SIGNATURES = {
     "cpfn_residue_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_residue_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
 }
-_RESTYPES = {"cpfn_build_info": ctypes.c_char_p, "cpfn_similarity_soft_workspace": ctypes.c_longlong}
+_RESTYPES = {"cpfn_build_info": ctypes.c_char_p, "cpfn_similarity_soft_workspace": ctypes.c_longlong,
+             "cpfn_metrics_workspace": ctypes.c_longlong}
 
 _lib = None
 _raw = None

@@ -574,6 +574,34 @@ CPFN_API int cpfn_hungarian_match(const float *S, const int64_t *n_gt, int B, in
 CPFN_API int cpfn_p_coverage(const float *P, const float *params22, const int64_t *match,
                              const int64_t *slot_type, int B, int N, int K, const int *type_ids,
                              const float *eps, int n_eps, float *workspace, float *out, void *stream);
+/* Evaluation metrics (SPFN/metric_implementation.py:485-514, compute_all_metrics) around the assignment and the fits.
+ * cpfn_metrics_points — one pass over the points (replaces hard_W_encoding :33-37, get_instance_type :52-55, the cost
+ * inputs of hungarian_matching :19-25 and compute_normal_difference): W[B,N,K] soft memberships, T[B,N,n_types] per-point
+ * type scores, X / Xgt [B,N,3] unit normals, Igt[B,N] (gap-free labels, -1 = background) ->
+ *   hardW[B,N,Kp]  one-hot of the arg-max membership (first index on ties), zero columns K..Kp-1 (Kp >= K: the label sets
+ *                  padded to a common width like :487-492),
+ *   S[B,Kp+2,Kp]   the segmented sums of hardW in cpfn_seg_stats_fwd's layout — for one-hot rows a joint histogram,
+ *                  counted in integers (exact),
+ *   n_gt[B]        largest GT label + 1,  T_inst[B,Kp]  arg-max over types of (hardW^T T),  normal_diff[B] = mean acos|x.x_gt|.
+ * Kp <= 128, n_types <= 8.  workspace: cpfn_metrics_workspace(B, N, Kp, n_types) bytes (zeroed by the call itself). */
+CPFN_API long long cpfn_metrics_workspace(int B, int N, int Kp, int n_types);
+CPFN_API int cpfn_metrics_points(const float *W, const float *T, const float *X, const float *Xgt, const int64_t *Igt,
+                                 int B, int N, int K, int Kp, int n_types, float *hardW, void *workspace, float *S,
+                                 int64_t *n_gt, int64_t *T_inst, float *normal_diff, void *stream);
+/* cpfn_metrics_tail — everything of compute_all_metrics behind the assignment and the fits that is [B,K]- or
+ * [B,K,N']-sized (compute_segmentation_iou, compute_type_accuracy, compute_axis_difference, get_residual_loss :76-81,
+ * compute_meanstd_Sk_residual, compute_Sk_coverage) in ONE launch: match[B,Kp] from cpfn_hungarian_match, params22[B,Kp,22]
+ * from cpfn_fit_pack_fwd, T_gt[B,Kgt], ppi[B,Kgt,Np,3] points per GT instance, axis_*[B,Kgt,3] GT axes (slots beyond Kgt
+ * count as zero axes / zero points, the reference's padding :505-508) ->
+ *   out[B, 5 + n_eps] = mIoU, type accuracy, axis difference, mean residual, std residual (unbiased over the Np points,
+ *                        averaged over the n_gt instances), Sk coverage per eps;
+ *   slot_type[B,Kp]   = T_inst[b, match[b,k]]  (what cpfn_p_coverage evaluates slot k as, :412).
+ * type_ids (HOST, 4 ints) = ids of plane, sphere, cylinder, cone; eps (HOST) n_eps <= 4.  Kp <= 1024, Np >= 2. */
+CPFN_API int cpfn_metrics_tail(const float *S, const int64_t *match, const int64_t *n_gt, const int64_t *T_inst,
+                               const int64_t *T_gt, const float *params22, const float *ppi, const float *axis_plane,
+                               const float *axis_cylinder, const float *axis_cone, int B, int Kp, int Kgt, int Np,
+                               const int *type_ids, const float *eps, int n_eps, float *out, int64_t *slot_type,
+                               void *stream);
 /* The [B,K]-sized tail of compute_all_losses (SPFN/losses_implementation.py:77-90, 603-606, 633-673)
  * in one launch: relaxed IoU of the matched pairs from S[B,K+2,K] (cpfn_seg_stats_fwd), masked means
  * over the n_gt[b] existing instances of that and of rp[B,K,2] (cpfn_residue_fwd; may be NULL), batch

@@ -3,6 +3,11 @@ reference, imported here on CPU with the harness shims of make_golden.py, on a s
 predictions are a noisy copy of the ground truth.
 
     cd tests/golden && python make_golden_metrics.py      # needs /root/reference; writes metrics_2x2048.npz
+                                                          # and metrics_padded_2x1024.npz
+
+The second file holds the two PADDING branches of compute_all_metrics (reference lines 487-492, 505-508): more GT slots than
+prediction columns (W / T padded) and more prediction columns than GT slots (T_gt, the GT axes and points_per_instance
+padded; the reference hard-codes 512 points per instance there).
 """
 import os
 import sys
@@ -17,10 +22,10 @@ sys.path.insert(0, ROOT)
 CLASSES = ["plane", "sphere", "cylinder", "cone"]
 
 
-def make_inputs():
+def make_inputs(N=2048, K=28, Kgt=28, n_prims=6, seed=77):
     from cpfn_amd import synthetic
-    B, N, K = 2, 2048, 28
-    batch = synthetic.training_batch(B, N=N, n_prims=6, n_inst_points=512, seed=77)
+    B = 2
+    batch = synthetic.training_batch(B, N=N, n_max_instances=Kgt, n_prims=n_prims, n_inst_points=512, seed=seed)
     g = torch.Generator().manual_seed(5)
     I = batch["I_gt"]
     logits = torch.randn(B, N, K, generator=g)
@@ -37,10 +42,8 @@ def make_inputs():
                 points_per_instance=batch["points_per_instance"], **{"gt_" + k: v for k, v in gt.items()})
 
 
-def main():
-    import_reference()
+def run_reference(d):
     from SPFN import metric_implementation as mi
-    d = make_inputs()
     gt = {k[3:]: v.clone() for k, v in d.items() if k.startswith("gt_")}
     with torch.no_grad():
         out = mi.compute_all_metrics(d["P"], d["X"], d["X_gt"], d["W"], d["I_gt"], d["T"], d["T_gt"],
@@ -52,10 +55,26 @@ def main():
                   axis_difference=axis_diff.numpy(), mean_residual=mean_res.numpy(), std_residual=std_res.numpy(),
                   Sk_coverage=np.stack([s.numpy() for s in Sk]), P_coverage=np.stack([p.numpy() for p in Pc]),
                   T_instance=Tinst.numpy(), matching=match.numpy(), mask=mask.numpy(), epsilons=np.array([0.01, 0.02]))
+    arrays["W_hard"] = Wh.numpy()
+    arrays.update({"param_" + k: v.numpy() for k, v in params.items()})
     for k in ("mIoU", "type_accuracy", "normal_difference", "axis_difference", "mean_residual", "std_residual",
               "Sk_coverage", "P_coverage"):
         print(k, arrays[k])
-    save("metrics_2x2048.npz", **arrays)
+    return arrays
+
+
+def main():
+    import_reference()
+    a = run_reference(make_inputs())
+    for k in [k for k in a if k == "W_hard" or k.startswith("param_")]:       # (the first fixture keeps its round-2 contents)
+        del a[k]
+    save("metrics_2x2048.npz", **a)
+    padded = {}
+    # K = 12 predictions against 16 GT slots (6 of them used); K = 20 predictions against 12 GT slots (7 used)
+    for tag, kw in (("few_", dict(N=1024, K=12, Kgt=16, n_prims=6, seed=78)), ("many_", dict(N=1024, K=20, Kgt=12, n_prims=7, seed=79))):
+        a = run_reference(make_inputs(**kw))
+        padded.update({tag + k: v for k, v in a.items()})
+    save("metrics_padded_2x1024.npz", **padded)
 
 
 if __name__ == "__main__":

@@ -39,6 +39,31 @@ def test_all_metrics_match_reference_fixture(golden):
     _check(out, g, 512, 2048)
 
 
+@pytest.mark.parametrize("tag", ["few_", "many_"])
+def test_all_metrics_padding_branches_match_reference_fixture(golden, tag):
+    """Fewer / more prediction columns than GT slots (reference :487-492, :505-508; handled inside the kernels here, nothing is
+    concatenated) against the reference's own outputs, including the hard W, the fitted parameters and the instance types of
+    the widened label set."""
+    from cpfn_amd.SPFN import metric_implementation as mi
+    from helpers import PARAM_KEYS, per_instance_rel
+    g = {k[len(tag):]: v for k, v in golden("metrics_padded_2x1024.npz").items() if k.startswith(tag)}
+    t = lambda k: torch.from_numpy(g[k]).to(dev())
+    gt = {k: t("gt_" + k) for k in ("plane_normal", "cylinder_axis", "cone_axis")}
+    out = mi.compute_all_metrics(t("P"), t("X"), t("X_gt"), t("W"), t("I_gt"), t("T"), t("T_gt"), t("points_per_instance"),
+                                 gt, list_epsilon=[float(e) for e in g["epsilons"]], classes=CLASSES)
+    _check(out, g, 512, 1024)
+    assert np.array_equal(out[8].cpu().numpy(), g["W_hard"])
+    # fitted parameters of the columns that own points (an empty column's fit is the guards' output: not compared)
+    used = torch.from_numpy(g["W_hard"]).sum(1) > 8
+    for k in PARAM_KEYS:
+        a, b = out[9][k].cpu(), torch.from_numpy(g["param_" + k])
+        if k in ("plane_normal", "cylinder_axis"):
+            a = a * torch.sign((a * b).sum(-1, keepdim=True))
+        if k == "plane_center":
+            a = a * torch.sign((out[9]["plane_normal"].cpu() * torch.from_numpy(g["param_plane_normal"])).sum(-1))
+        assert float(per_instance_rel(a, b)[used].max()) < 2e-3, k
+
+
 def test_all_metrics_match_oracle_at_8192():
     from cpfn_amd.SPFN import metric_implementation as mi
     B, N, K = 3, 8192, 28

@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/) against the fixtures produced by the imported
 reference (tests/golden/make_golden.py).  This is what pins the oracle."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import geometry as og
@@ -186,6 +187,25 @@ def test_metrics_oracle_matches_reference_fixture(golden):
     # coverages are counts of points under a threshold: allow a handful of points to sit on the boundary
     np.testing.assert_allclose(out["Sk_coverage"].numpy(), g["Sk_coverage"], atol=3.0 / 512)
     np.testing.assert_allclose(out["P_coverage"].numpy(), g["P_coverage"], atol=3.0 / 2048)
+
+
+@pytest.mark.parametrize("tag,n_pts", [("few_", 1024), ("many_", 1024)])
+def test_metrics_oracle_padding_branches_match_reference_fixture(golden, tag, n_pts):
+    """The two padding branches of compute_all_metrics (reference :487-492, :505-508): fewer / more prediction columns
+    than GT slots, against the reference's own outputs."""
+    from oracle import metrics as om
+    g = {k[len(tag):]: v for k, v in golden("metrics_padded_2x1024.npz").items() if k.startswith(tag)}
+    t = lambda k: torch.from_numpy(g[k])
+    gt = {k: t("gt_" + k) for k in ("plane_normal", "cylinder_axis", "cone_axis")}
+    out = om.compute_all_metrics(t("P"), t("X"), t("X_gt"), t("W"), t("I_gt"), t("T"), t("T_gt"), t("points_per_instance"),
+                                 gt, list_epsilon=[float(e) for e in g["epsilons"]])
+    assert np.array_equal(out["matching"].numpy(), g["matching"])
+    assert np.array_equal(out["T_instance"].numpy(), g["T_instance"])
+    assert np.array_equal(out["W_hard"].numpy(), g["W_hard"])
+    for k in ("mIoU", "type_accuracy", "normal_difference", "axis_difference", "mean_residual", "std_residual"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=2e-4, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(out["Sk_coverage"].numpy(), g["Sk_coverage"], atol=3.0 / 512)
+    np.testing.assert_allclose(out["P_coverage"].numpy(), g["P_coverage"], atol=3.0 / n_pts)
 
 
 def test_merging_oracle_matches_reference_fixture(golden):
