@@ -2,14 +2,17 @@
 
 GlobalSPFN is trained from the same initial weights on the same sequence of structured synthetic batches
 (cpfn_amd.synthetic: points on random planes / spheres / cylinders / cones with noise, GT normals, labels, types and axes)
-  * in the product's bf16 mode (fused MFMA stacks, replayed hipGraph) twice, with two different dropout / FPS seeds,
-  * and in its fp32 mode (PyTorch fp32 MLPs, same HIP geometry / fitters / losses, eager) twice with the same two seeds
-    — the difference inside a pair is the run-to-run spread that has nothing to do with precision (the fp32 mode is not
+  * in the product's bf16 mode (fused MFMA stacks, replayed hipGraph) with n different dropout / FPS seeds (default 5),
+  * and in its fp32 mode (PyTorch fp32 MLPs, same HIP geometry / fitters / losses, eager) with the same n seeds
+    — the spread inside a mode is the run-to-run variation that has nothing to do with precision (the fp32 mode is not
     even reproducible for ONE seed: PyTorch's backward uses atomics) —
 and every trained model is evaluated on held-out clouds with the evaluation metrics of the reference
-(`SPFN.metric_implementation.compute_all_metrics`, evaluation_globalSPFN.py:85-104: eval-mode BatchNorm, hard memberships).
+(`SPFN.metric_implementation.compute_all_metrics`, evaluation_globalSPFN.py:85-104: eval-mode BatchNorm, hard memberships),
+in the mode it was trained in AND in both compute modes (same weights, same running statistics), so that "training in bf16
+differs" and "evaluating in bf16 differs" can be told apart.  Per metric: mean +- sd per mode, difference of the means against
+2 pooled standard deviations, Welch's t.
 
-    python tools/bf16_vs_fp32_training.py [--steps 2000] [--batch 16] [--points 8192] [--out profiles/r03_bf16_vs_fp32.json]
+    python tools/bf16_vs_fp32_training.py [--steps 2000] [--seeds 5] [--out profiles/r04_bf16_vs_fp32.json]
 
 Prints one JSON object; `compare()` is what tests/test_gpu_trainer.py asserts on a short run.
 """
@@ -78,44 +81,75 @@ def evaluate(model, held, seed=4321):
     return {k: acc[k] / n for k in METRICS}
 
 
-# |mean(bf16) - mean(fp32)| of a metric may not exceed max(SPREAD_FACTOR x the larger of the two within-mode differences, its floor)
-SPREAD_FACTOR = 3.0
+# Two-sample comparison per metric over n seeds per mode: |mean(bf16) - mean(fp32)| may not exceed
+# max(BAND_SD x pooled standard deviation, floor), pooled sd = sqrt((sd_bf16^2 + sd_fp32^2) / 2) (sample sd, n - 1).
+BAND_SD = 2.0
 FLOORS = {"mIoU": 0.03, "type_accuracy": 0.03, "normal_difference": 0.03, "axis_difference": 0.05, "mean_residual": 0.01,
           "Sk_coverage_0.02": 0.05, "P_coverage_0.02": 0.05}
+SEEDS = (11, 22, 33, 44, 55)
 
 
-def compare(res, floor_scale=1.0):
-    """-> {metric: (bf16 A, bf16 B, fp32, |mean(A, B) - fp32|, allowed)}, ok"""
-    a, b = res["bf16_seedA"]["metrics"], res["bf16_seedB"]["metrics"]
-    f, g = res["fp32_seedA"]["metrics"], res["fp32_seedB"]["metrics"]
+def _mean_sd(v):
+    n = len(v)
+    m = sum(v) / n
+    return m, (sum((x - m) ** 2 for x in v) / (n - 1)) ** 0.5 if n > 1 else 0.0
+
+
+def compare(res, floor_scale=1.0, eval_mode="own"):
+    """Per metric: mean and sample sd of the bf16-trained and the fp32-trained models (each evaluated in `eval_mode`: "own" =
+    the mode it was trained in, "bf16" / "fp32" = all models in that one mode), their difference, the pooled sd, Welch's t,
+    the allowed band.  -> table, ok"""
+    key = {"own": "metrics", "bf16": "metrics_eval_bf16", "fp32": "metrics_eval_fp32"}[eval_mode]
+    runs = {m: [v for k, v in sorted(res.items()) if k.startswith(m + "_seed")] for m in ("bf16", "fp32")}
     table, ok = {}, True
     for k in METRICS:
-        allowed = max(SPREAD_FACTOR * max(abs(a[k] - b[k]), abs(f[k] - g[k])), floor_scale * FLOORS[k])
-        d = abs(0.5 * (a[k] + b[k]) - 0.5 * (f[k] + g[k]))
-        table[k] = {"bf16_A": a[k], "bf16_B": b[k], "fp32_A": f[k], "fp32_B": g[k], "abs_diff_of_means": d, "allowed": allowed}
+        b = [r[key][k] for r in runs["bf16"]]
+        f = [r[key][k] for r in runs["fp32"]]
+        (mb, sb), (mf, sf) = _mean_sd(b), _mean_sd(f)
+        pooled = ((sb * sb + sf * sf) / 2) ** 0.5
+        se = (sb * sb / len(b) + sf * sf / len(f)) ** 0.5
+        allowed = max(BAND_SD * pooled, floor_scale * FLOORS[k])
+        d = abs(mb - mf)
+        table[k] = {"bf16": b, "fp32": f, "bf16_mean": mb, "bf16_sd": sb, "fp32_mean": mf, "fp32_sd": sf,
+                    "abs_diff_of_means": d, "pooled_sd": pooled, "welch_t": (mb - mf) / se if se > 0 else 0.0,
+                    "allowed": allowed, "within_band": d <= allowed}
         ok = ok and d <= allowed
     return table, ok
 
 
-def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0):
+def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0, seeds=SEEDS[:2], both_eval_modes=False):
     from cpfn_amd.SPFN import fitter_factory
     with contextlib.redirect_stdout(io.StringIO()):
         fitter_factory.register_primitives(CLASSES)
     pool = make_pool(n_train, B, N, 50000, dev)
     held = make_pool(n_held, B, N, 90000, dev)
-    res = {"config": {"steps": steps, "batch": B, "points": N, "train_batches": n_train, "held_out_clouds": n_held * B}}
-    for name, mode, seed in (("bf16_seedA", "bf16", 11), ("bf16_seedB", "bf16", 22), ("fp32_seedA", "fp32", 11), ("fp32_seedB", "fp32", 22)):
-        model, info = train(mode, seed, steps, pool, dev, log_every)
-        info["metrics"] = evaluate(model, held)
-        res[name] = info
-        del model
-        torch.cuda.empty_cache()
+    res = {"config": {"steps": steps, "batch": B, "points": N, "train_batches": n_train, "held_out_clouds": n_held * B,
+                      "seeds": list(seeds), "band": "max(%g x pooled sd, %g x floor)" % (BAND_SD, floor_scale)}}
+    for mode in ("bf16", "fp32"):
+        for seed in seeds:
+            model, info = train(mode, seed, steps, pool, dev, log_every)
+            info["metrics"] = evaluate(model, held)
+            if both_eval_modes:
+                # the SAME trained weights and running statistics evaluated in both compute modes: separates "training in bf16
+                # differs" from "evaluating in bf16 differs"
+                for em, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+                    model.set_compute_dtype(dt)
+                    info["metrics_eval_" + em] = evaluate(model, held)
+            res["%s_seed%d" % (mode, seed)] = info
+            del model
+            torch.cuda.empty_cache()
     untrained = __import__("cpfn_amd.PointNet2.pn2_network", fromlist=["x"])
     torch.manual_seed(0)
     m0 = untrained.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
     m0.set_compute_dtype(torch.bfloat16)
     res["untrained"] = {"metrics": evaluate(m0, held)}
     res["comparison"], res["ok"] = compare(res, floor_scale)
+    if both_eval_modes:
+        for em in ("bf16", "fp32"):
+            res["comparison_all_evaluated_in_" + em], res["ok_all_evaluated_in_" + em] = compare(res, floor_scale, em)
+        # evaluation-mode effect on identical weights: mean over all models of (metric in bf16 eval - metric in fp32 eval)
+        allr = [v for k, v in res.items() if "_seed" in k]
+        res["eval_mode_effect"] = {k: _mean_sd([r["metrics_eval_bf16"][k] - r["metrics_eval_fp32"][k] for r in allr]) for k in METRICS}
     return res
 
 
@@ -126,10 +160,12 @@ if __name__ == "__main__":
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--train-batches", type=int, default=64)
     ap.add_argument("--held-batches", type=int, default=8)
+    ap.add_argument("--seeds", type=int, default=5, help="runs per mode (bf16 and fp32 each)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
-    r = run(a.steps, a.batch, a.points, a.train_batches, a.held_batches, torch.device("cuda:0"), log_every=max(a.steps // 10, 1))
+    r = run(a.steps, a.batch, a.points, a.train_batches, a.held_batches, torch.device("cuda:0"), log_every=max(a.steps // 10, 1),
+            seeds=[11 * (i + 1) for i in range(a.seeds)], both_eval_modes=True)
     txt = json.dumps(r, indent=1)
     if a.out:
         open(a.out, "w").write(txt + "\n")
-    print(txt)
+    print(json.dumps({k: v for k, v in r.items() if "_seed" not in k}, indent=1))
