@@ -71,11 +71,36 @@ def parse_args():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT touching the HIP runtime (the parent of a self-launched run only waits for
+    its ranks and should not hold a GPU context): the KFD topology lists one node per agent, GPUs are the ones with SIMDs, and
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow them; None when /sys tells nothing."""
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(nodes):
+            props = dict(l.split()[:2] for l in open(os.path.join(nodes, d, "properties")) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    if n == 0:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script as CHILD processes — before anything
     in this process has touched the GPU (the parent never does) — and exit with their worst exit code."""
-    import torch
-    visible = torch.cuda.device_count()            # (counting devices does not initialise the GPU)
+    visible = visible_gpus()
+    if visible is None:                              # (no KFD topology in /sys: ask the runtime)
+        import torch
+        visible = torch.cuda.device_count()
     if visible < args.gpus:
         sys.stderr.write("bench.py: %d GPUs requested, %d visible\n" % (args.gpus, visible))
         sys.exit(2)

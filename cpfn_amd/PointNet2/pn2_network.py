@@ -90,7 +90,20 @@ class PointNet2(torch.nn.Module):
         parity target); with the process-wide opt-in `cuda_ops.CUDA_ROUTE` (CPFN_CUDA_ROUTE=1) `fast=True` selects
         the CUDA route's semantics — what a checkpoint trained by the reference on a GPU saw."""
         from .. import cuda_ops as _co, fused_mlp
-        if getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda:
+        bf16 = getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda
+        # An evaluation forward under no_grad (evaluation_globalSPFN.py:85, evaluation_localSPFN.py:95 call the module directly)
+        # is ~100 launches whose host cost exceeds their run time: it is captured once per input shape and replayed as one
+        # hipGraph (inference.GraphedForward; bit-identical, same CPU-generator draws for the FPS starts; outputs are copies).
+        # `model.auto_graph = False` opts out.
+        if (bf16 and not self.training and not torch.is_grad_enabled() and geometry is None and getattr(self, "auto_graph", True)
+                and (fast or not _co.CUDA_ROUTE) and not self.__dict__.get("_graph_busy")
+                and not torch.cuda.is_current_stream_capturing()):
+            auto = self.__dict__.get("_auto_graph")
+            if auto is None:
+                from ..inference import GraphedForward
+                auto = self.__dict__["_auto_graph"] = GraphedForward(self, max_shapes=4, clone_outputs=True)
+            return auto(x, glob_features=glob_features, loc_features=loc_features, fps_start=fps_start)
+        if bf16:
             # one multi-tensor fp32 -> bf16 conversion; when sa1's input is coordinates only, its fp32 first layer is the
             # forward pass's first launch and the conversion rides on it (cpfn_smallk_fwd_cast)
             first_is_xyz = (not self.sa1.has_feats and not self.sa1.group_all and

@@ -178,6 +178,8 @@ def compute_all_metrics(P, X, X_gt, W, I_gt, T, T_gt, points_per_instance, gt_pa
     the last three Kp = max(K, K_gt) wide, like the reference's padded ones."""
     if not P.is_cuda:
         raise RuntimeError("compute_all_metrics: CPU not supported (cpfn_amd runs on the HIP path only)")
+    from .. import ops as _ops
+    _ops.check_fps_faults("compute_all_metrics")             # (degenerate sampling upstream must not become a metric)
     B, N, K = W.shape
     Kgt, Np = T_gt.shape[1], points_per_instance.shape[2]
     Kp, NT = max(K, Kgt), T.shape[2]

@@ -57,6 +57,8 @@ def get_point_final(point2primitive_prediction, output_labels_heuristic):
     if lab.numel() != C:
         raise RuntimeError("get_point_final: one label per column expected")
     G = int(lab.max()) + 1                                   # (:57 builds torch.eye(max+1): the same host read)
+    from ..ops import check_fps_faults
+    check_fps_faults("get_point_final")
     ws = torch.empty(C + 2 * G + 2, dtype=torch.int32, device=dev)
     out = torch.empty(N, G, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

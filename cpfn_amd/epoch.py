@@ -199,6 +199,9 @@ class EpochRunner:
             self.ring_host[:pending].copy_(self.ring[:pending], non_blocking=on_gpu)
             if on_gpu:
                 torch.cuda.current_stream(self.device).synchronize()
+            if on_gpu:
+                from . import ops as _ops
+                _ops.check_fps_faults("this point of the epoch")
             rows = self.ring_host[:pending].tolist()
             for b, row in zip(sizes, rows):
                 total += b * row[0]                                                   # (:147)

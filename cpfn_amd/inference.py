@@ -13,11 +13,25 @@ import torch
 class GraphedForward:
     """model: a cpfn_amd PointNet2 in eval mode on a HIP device.  `__call__(x [B,N,C], glob_features=None,
     loc_features=None, fps_start=None)` -> the model's output list (tensors owned by the graph: copy what must
-    outlive the next call)."""
+    outlive the next call — or construct with clone_outputs=True).
 
-    def __init__(self, model):
+    max_shapes: graphs kept (least recently used out first).  A captured graph reads the parameters and BatchNorm buffers
+    where they lay at capture time; the storage addresses are part of a graph's key, so a model whose tensors moved
+    (`.to()`, an optimizer that re-points them) is captured again instead of replaying on stale memory.
+
+    `PointNet2.forward` uses one of these by itself for evaluation-mode forwards under `torch.no_grad()` (max_shapes=4,
+    clone_outputs=True; `model.auto_graph = False` opts out), so that the reference's evaluation scripts
+    (evaluation_globalSPFN.py:85, evaluation_localSPFN.py:95) get the replayed forward unedited."""
+
+    def __init__(self, model, max_shapes=None, clone_outputs=False):
         self.model = model
         self._graphs = {}
+        self.max_shapes = max_shapes
+        self.clone_outputs = clone_outputs
+
+    def _storage_key(self):
+        m = self.model
+        return hash(tuple(t.data_ptr() for t in m.parameters()) + tuple(t.data_ptr() for t in m.buffers()))
 
     def _capture(self, x, glob, loc):
         m = self.model
@@ -37,6 +51,7 @@ class GraphedForward:
                 st["out"] = m(st["x"], glob_features=st["glob"], loc_features=st["loc"], fps_start=starts)
         torch.cuda.current_stream(dev).wait_stream(stream)
         st["g"], st["stream"] = g, stream
+        st["aux"] = {k: getattr(m, k) for k in ("aux_sa1", "aux_sa2", "aux_sfp3", "heads_packed") if hasattr(m, k)}
         return st
 
     @torch.no_grad()
@@ -46,12 +61,21 @@ class GraphedForward:
             raise RuntimeError("GraphedForward replays an evaluation-mode forward: call model.eval() first")
         if not x.is_cuda:
             raise RuntimeError("GraphedForward: CPU not supported")
+        from . import cuda_ops as _co, ops as _ops
+        _ops.check_fps_faults("this evaluation forward")       # (a pinned host word: no synchronisation)
         key = (tuple(x.shape), x.dtype, None if glob_features is None else tuple(glob_features.shape),
                None if loc_features is None else tuple(loc_features.shape), getattr(m, "compute_dtype", torch.float32),
-               float(m.dropout_p))
-        st = self._graphs.get(key)
+               float(m.dropout_p), bool(_co.CUDA_ROUTE), self._storage_key())
+        st = self._graphs.pop(key, None)
         if st is None:
-            st = self._graphs[key] = self._capture(x, glob_features, loc_features)
+            m.__dict__["_graph_busy"] = True         # (the warm-up and the captured forward call the model itself: no nesting)
+            try:
+                st = self._capture(x, glob_features, loc_features)
+            finally:
+                m.__dict__["_graph_busy"] = False
+            if self.max_shapes and len(self._graphs) >= self.max_shapes:
+                self._graphs.pop(next(iter(self._graphs)))          # least recently used
+        self._graphs[key] = st                                       # (re-inserted: most recently used last)
         B, N, _ = x.shape
         k = st["turn"]
         st["turn"] = 1 - k
@@ -75,4 +99,9 @@ class GraphedForward:
                 st["loc"].copy_(loc_features, non_blocking=True)
             st["g"].replay()
         cur.wait_stream(st["stream"])
+        # the module's aux_* attributes (index tensors of the forward pass) are the graph's too: put this graph's back
+        for k, v in st["aux"].items():
+            setattr(m, k, v)
+        if self.clone_outputs:
+            return type(st["out"])(o.clone() for o in st["out"])
         return st["out"]

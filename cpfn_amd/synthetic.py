@@ -125,10 +125,13 @@ def training_batch(B, N=8192, n_max_instances=28, n_prims=10, n_inst_points=512,
     }
 
 
-def pointnet2_state_shapes(output_sizes=(3, 4, 28)):
-    """state_dict keys -> shapes of the reference's PointNet2(dim_input=3, dim_pos=3)
-    (PointNet2/pn2_network.py:11-36), in construction order."""
+def pointnet2_state_shapes(output_sizes=(3, 4, 28), use_glob_features=False, use_loc_features=False,
+                           features_extractor=False):
+    """state_dict keys -> shapes of the reference's PointNet2(dim_input=3, dim_pos=3, ...)
+    (PointNet2/pn2_network.py:11-36), in construction order.  use_glob_features / use_loc_features widen sfp1's first
+    layer by 1024 / 128 channels (:22-27); features_extractor drops bn1 and the heads (:31-36)."""
     shapes = {}
+    extra = (1024 if use_glob_features else 0) + (128 if use_loc_features else 0)
 
     for name, cin, mlp in (("sa1", 3, (64, 64, 128)), ("sa2", 131, (128, 128, 256)),
                            ("sa3", 259, (256, 512, 1024))):
@@ -148,7 +151,7 @@ def pointnet2_state_shapes(output_sizes=(3, 4, 28)):
             shapes[bn + ".running_mean"] = (co,)
             shapes[bn + ".running_var"] = (co,)
             shapes[bn + ".num_batches_tracked"] = ()
-    for name, cin, mlp in (("sfp1", 1280, (256, 256)), ("sfp2", 384, (256, 128)),
+    for name, cin, mlp in (("sfp1", 1280 + extra, (256, 256)), ("sfp2", 384, (256, 128)),
                            ("sfp3", 128, (128, 128, 128))):
         c = cin
         pairs = []
@@ -167,6 +170,8 @@ def pointnet2_state_shapes(output_sizes=(3, 4, 28)):
             shapes[bn + ".num_batches_tracked"] = ()
     shapes["fc1.weight"] = (128, 128, 1)
     shapes["fc1.bias"] = (128,)
+    if features_extractor:
+        return shapes
     for k in ("weight", "bias", "running_mean", "running_var"):
         shapes["bn1." + k] = (128,)
     shapes["bn1.num_batches_tracked"] = ()

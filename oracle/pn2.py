@@ -102,20 +102,30 @@ def feature_propagation(state, name, pos1, pos2, feats1, feats2, training=True):
     return x, aux
 
 
-def pointnet2_forward(state, x, fps_starts, training=True, dropout_mask=None):
-    """PointNet2.forward (PointNet2/pn2_network.py:38-73) for dim_input == dim_pos == 3,
-    no glob/loc features.  x [B,N,3]; fps_starts = (start_sa1 [B], start_sa2 [B]).
+def pointnet2_forward(state, x, fps_starts, training=True, dropout_mask=None, glob_features=None, loc_features=None):
+    """PointNet2.forward (PointNet2/pn2_network.py:38-73) for dim_input == dim_pos == 3.
+    x [B,N,3]; fps_starts = (start_sa1 [B], start_sa2 [B]).
     `dropout_mask` [B,128,N] multiplies the fc1 activations (the reference applies
     F.dropout(p=0.5) unconditionally, :63); None = dropout neutralised.
-    Returns ([heads...], l3_feats [B,1024,1], output_feat [B,128,N], aux)."""
+    glob_features [B,1024] / loc_features [B,128]: the use_glob_features / use_loc_features variant (:51-54) — the state's
+    sfp1 is then 1024 / 128 channels wider (:22-27).  A state without `bn1.*` is the features_extractor variant (:31, :70-71):
+    returns ([], l3_feats, fc1 output, aux).
+    Returns ([heads...], l3_feats [B,1024(+extra),1], output_feat [B,128,N], aux)."""
     pos = x.transpose(2, 1)
     l1_pos, l1_f, a1 = set_abstraction(state, "sa1", pos, None, 512, 0.2, 64, fps_starts[0], training)
     l2_pos, l2_f, a2 = set_abstraction(state, "sa2", l1_pos, l1_f, 128, 0.4, 64, fps_starts[1], training)
     _, l3_f, _ = set_abstraction(state, "sa3", l2_pos, l2_f, None, None, None, None, training)
+    if glob_features is not None:
+        l3_f = torch.cat([l3_f, glob_features.unsqueeze(2)], dim=1)                     # :51-52
+    if loc_features is not None:
+        l3_f = torch.cat([l3_f, loc_features.unsqueeze(2)], dim=1)                      # :53-54
     l4, _ = feature_propagation(state, "sfp1", l2_pos, None, l2_f, l3_f, training)
     l5, a5 = feature_propagation(state, "sfp2", l1_pos, l2_pos, l1_f, l4, training)
     l6, a6 = feature_propagation(state, "sfp3", pos, l1_pos, None, l5, training)
     feat = F.conv1d(l6, state["fc1.weight"], state["fc1.bias"])                       # :60
+    aux = {"sa1": a1, "sa2": a2, "sfp2": a5, "sfp3": a6}
+    if "bn1.weight" not in state:                                                       # features_extractor (:70-71)
+        return [], l3_f, feat, aux
     feat = F.relu(F.batch_norm(feat, None if training else state["bn1.running_mean"],
                                None if training else state["bn1.running_var"],
                                state["bn1.weight"], state["bn1.bias"], training=training, eps=BN_EPS))
@@ -126,8 +136,16 @@ def pointnet2_forward(state, x, fps_starts, training=True, dropout_mask=None):
     while "fc2.%d.weight" % j in state:
         heads.append(F.conv1d(feat, state["fc2.%d.weight" % j], state["fc2.%d.bias" % j]).transpose(1, 2))
         j += 1
-    aux = {"sa1": a1, "sa2": a2, "sfp2": a5, "sfp3": a6}
     return heads, l3_f, feat, aux
+
+
+def patch_selection_loss(state, points, labels, fps_starts, training=True):
+    """Forward + loss of patch_selection_train_val_epoch (Utils/training_utils.py:62-68): cross-entropy of the two-class
+    heat-map logits [B,N,2] against labels [B,N].  Returns (loss, logits)."""
+    heads, _, _, _ = pointnet2_forward(state, points, fps_starts, training)
+    logits = heads[0]
+    B, N, _ = logits.shape
+    return F.cross_entropy(logits.contiguous().view(B * N, 2), labels.view(B * N)), logits
 
 
 def training_step_losses(state, batch, fps_starts, classes=("sphere", "plane", "cylinder", "cone"),

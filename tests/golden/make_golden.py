@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference); the GPU box never
 sees the reference, only the .npz files this script writes.  The fixtures are
 data — seeded inputs and the reference's outputs on them — never reference code.
 
-    python tests/golden/make_golden.py [--only geometry|fitters|network|step|losses|step_local]
+    python tests/golden/make_golden.py [--only geometry|fitters|network|step|losses|step_local|variants]
 
 Harness-side shims (the reference files are untouched):
   * torch.solve was removed from torch>=2        (call site SPFN/geometry_utils.py:140)
@@ -152,6 +152,9 @@ def main():
     if args.only in (None, "step_local"):
         from make_golden_spfn import make_step_local
         make_step_local(pn2_network, pn2_geo, losses)
+    if args.only in (None, "variants"):
+        from make_golden_spfn import make_variants
+        make_variants(pn2_network)
 
 
 if __name__ == "__main__":

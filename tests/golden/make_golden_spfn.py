@@ -288,3 +288,73 @@ def make_step_local(pn2_network, pn2_geo, losses):
     og = np.array([float(st[n].grad.norm()) for n in names])
     rel = np.abs(og - gnorm) / np.maximum(gnorm, 1e-12)
     print("  [step_local] grad-norm rel err: max %.2e median %.2e" % (rel.max(), np.median(rel)))
+
+
+# --------------------------------------------------------------------------- the other network variants (config 5)
+def make_variants(pn2_network):
+    """The three PointNet2 variants BASELINE.json configs[4] runs beside GlobalSPFN / LocalSPFN, on a 2 x 2048 cloud:
+      ps_  PatchSelection (output_sizes=[2]; training_PatchSelection.py:55, evaluation_PatchSelection.py:45): heat-map logits
+           in training and in evaluation mode, and one cross-entropy training step of Utils/training_utils.py:62-75 (loss,
+           per-parameter gradient norms, the first entries of every gradient);
+      fe_  features_extractor=True (pn2_network.py:31-36, 70-71): (l3_feats, output_feat);
+      gl_  use_glob_features=True, use_loc_features=True (pn2_network.py:22-27, 51-54) with seeded feature inputs.
+    Dropout neutralised; weights = cpfn_amd.synthetic.synthetic_state_dict of the variant's shapes."""
+    from cpfn_amd import synthetic
+    out = {}
+    cloud = synthetic.primitive_cloud(2, 2048, n_prims=6, seed=32)
+    P = cloud["P"]
+    sub = np.arange(0, 2048, 8)
+    out.update(P=P.numpy(), sub=sub)
+
+    def fwd(model, seed, **kw):
+        B, N, _ = P.shape
+        torch.manual_seed(seed)
+        s1 = torch.randint(0, N, (B,), dtype=torch.long)
+        s2 = torch.randint(0, 512, (B,), dtype=torch.long)
+        torch.manual_seed(seed)
+        with _no_dropout():
+            r = model(P, fast=False, **kw)
+        return r, (s1, s2)
+
+    # ---- PatchSelection
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([2]), seed=1)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2])
+    m.load_state_dict(state, strict=True)
+    m.train()
+    labels = (cloud["I_gt"] % 2).long()                                      # [2,2048] in {0,1}
+    (heat, l3, feat), st = fwd(m, 43)
+    loss = torch.nn.functional.cross_entropy(heat.contiguous().view(-1, 2), labels.view(-1))     # training_utils.py:66-68
+    loss.backward()
+    names = [n for n, _ in m.named_parameters()]
+    out.update(ps_fps_start1=st[0].numpy(), ps_fps_start2=st[1].numpy(), ps_heat=heat.detach().numpy(), ps_labels=labels.numpy(),
+               ps_l3=l3.detach().numpy()[:, :, 0], ps_feat_sub=feat.detach().numpy()[:, :, sub], ps_loss=np.float64(loss.item()),
+               ps_grad_norm=np.array([float(p.grad.norm()) for _, p in m.named_parameters()], np.float64),
+               ps_grad_head=np.stack([np.resize(p.grad.flatten()[:8].numpy(), 8) for _, p in m.named_parameters()]),
+               ps_names=np.array(names))
+    m.zero_grad()
+    m.load_state_dict(state, strict=True)                                    # (the training pass moved the running statistics)
+    m.eval()
+    with torch.no_grad():
+        (heat_e, _, _), st_e = fwd(m, 44)
+    out.update(ps_eval_fps_start1=st_e[0].numpy(), ps_eval_fps_start2=st_e[1].numpy(), ps_eval_heat=heat_e.numpy())
+    print("  [variants] PatchSelection loss %.6f, heat range %.3f .. %.3f" % (loss.item(), float(heat.min()), float(heat.max())))
+    # ---- features extractor
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([2], features_extractor=True), seed=2)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2], features_extractor=True)
+    m.load_state_dict(state, strict=True)
+    m.train()
+    with torch.no_grad():
+        (l3, feat), st = fwd(m, 45)
+    out.update(fe_fps_start1=st[0].numpy(), fe_fps_start2=st[1].numpy(), fe_l3=l3.numpy()[:, :, 0], fe_feat_sub=feat.numpy()[:, :, sub])
+    # ---- LocalSPFN with global + local feature inputs
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([3, 4, 21], True, True), seed=3)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 21], use_glob_features=True, use_loc_features=True)
+    m.load_state_dict(state, strict=True)
+    m.train()
+    g = torch.Generator().manual_seed(46)
+    glob, loc = torch.randn(2, 1024, generator=g), torch.randn(2, 128, generator=g)
+    with torch.no_grad():
+        (X, T, W, l3, feat), st = fwd(m, 47, glob_features=glob, loc_features=loc)
+    out.update(gl_fps_start1=st[0].numpy(), gl_fps_start2=st[1].numpy(), gl_glob=glob.numpy(), gl_loc=loc.numpy(), gl_X=X.numpy(),
+               gl_T=T.numpy(), gl_W=W.numpy(), gl_l3=l3.numpy()[:, :, 0], gl_feat_sub=feat.numpy()[:, :, sub])
+    save("network_variants_2x2048.npz", **out)

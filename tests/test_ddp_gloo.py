@@ -100,6 +100,29 @@ def test_reduce_scatter_all_gather_layout_gives_the_same_replicas(tmp_path):
         assert torch.equal(res["all_reduce"][k], res["rs_ag"][k]), k
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [3, 4])
+def test_reduce_scatter_all_gather_layout_at_three_and_four_ranks(tmp_path, world):
+    """The flat bucket is padded to multiples of 3360 elements (+ the fault slot) so that it splits into 16-byte-aligned
+    shards for EVERY world size up to 8; round 3 only ran two ranks.  Three and four gloo ranks, both collective layouts:
+    replicas bit-identical across the ranks, the two layouts equal up to the order of the cross-rank additions."""
+    res = {}
+    for mode in ("all_reduce", "rs_ag"):
+        d = tmp_path / mode
+        d.mkdir()
+        mp.spawn(_worker, args=(world, _free_port(), str(d), mode), nprocs=world, join=True)
+        sd = [torch.load(os.path.join(str(d), "rank%d.pt" % r)) for r in range(world)]
+        for r in range(1, world):
+            for k in sd[0]:
+                assert torch.equal(sd[0][k], sd[r][k]), "replicas diverged (%s, rank %d): %s" % (mode, r, k)
+        res[mode] = sd[0]
+    for k in res["all_reduce"]:
+        torch.testing.assert_close(res["all_reduce"][k], res["rs_ag"][k], rtol=1e-5, atol=1e-7)
+    b = training.FlatGradBucket(TinyHeads())
+    assert all(b.padded.numel() % w == 0 and (b.padded.numel() // w * 4) % 16 == 0 for w in range(1, 9))
+    assert b.fault_slot.data_ptr() == b.flat.data_ptr() + 4 * b.flat.numel() and b.padded.numel() > b.flat.numel()
+
+
 # ---- the REAL network: PointNet2 (fp32 compute mode) + SPFNTrainer + FlatGradBucket on two gloo ranks ------------------
 # The device kernels of the geometry path are replaced by oracle-backed CPU stand-ins for the duration of the test
 # (tests/cpu_standins.py: test infrastructure); everything else — module tree, per-replica BatchNorm, flat bucket, the

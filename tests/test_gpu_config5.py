@@ -3,6 +3,8 @@ SURVEY §8e) — the cascaded evaluation of evaluation_globalSPFN.py:62-64 (Glob
 batch 1, eval mode) followed by evaluation_localSPFN.py:95-110 (32 patches x 8192 points through LocalSPFN, then
 similarity_soft / get_point_final on its memberships), every stage against the oracle:
 
+  * PatchSelection (output_sizes=[2], evaluation_PatchSelection.py:45-65) on 16 x 8192 low-resolution clouds: geometry bit-exact,
+    heat-map logits of both compute modes vs the oracle; its hottest points are the patch centres of the local stage;
   * 131072-point forward: FPS (several workgroups per cloud), ball query and 3-NN indices / weights BIT-EXACT vs
     oracle/geometry; the heads of both compute modes vs the oracle's evaluation forward (oracle/pn2.py, training=False);
   * 32 x 8192 LocalSPFN eval forward (K = 21): geometry bit-exact vs the oracle, heads of both modes vs the oracle;
@@ -28,10 +30,11 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _net(K, seed):
+def _net(K, seed, sizes=None):
     from cpfn_amd.PointNet2 import pn2_network
-    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, K])
-    m.load_state_dict(synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(output_sizes=(3, 4, K)), seed=seed),
+    sizes = [3, 4, K] if sizes is None else list(sizes)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=sizes)
+    m.load_state_dict(synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes(output_sizes=tuple(sizes)), seed=seed),
                       strict=True)
     m.dropout_p = 0.0                 # (the reference's dropout stays on in eval mode; neutralised to compare modes)
     return m.to(dev()).eval()
@@ -65,10 +68,10 @@ def _both_modes(m, P, starts):
         torch.set_num_threads(prev)
     with torch.no_grad():
         m.set_compute_dtype(torch.float32)
-        ref = [t.clone() for t in m(P, fps_start=starts)[:3]]
+        ref = [t.clone() for t in m(P, fps_start=starts)[:len(heads)]]
         m.set_compute_dtype(torch.bfloat16)
         out = m(P, fps_start=starts)
-    for name, a, b, o in zip("XTW", out[:3], ref, heads):
+    for name, a, b, o in zip("XTW" if len(heads) == 3 else "H", out[:len(heads)], ref, heads):
         o = o.to(a.device)
         e32, e16, e = float((b - o).norm() / o.norm()), float((a - o).norm() / o.norm()), float((a - b).norm() / b.norm())
         print("head %s (%d x %d): fp32 mode vs oracle %.2e | bf16 vs oracle %.2e | bf16 vs fp32 mode %.2e" % (name, P.shape[0], P.shape[1], e32, e16, e))
@@ -90,8 +93,19 @@ def test_cascaded_eval_131072_points():
     Xg = torch.nn.functional.normalize(out[0], p=2, dim=2, eps=1e-12)
     Wg = torch.softmax(out[2], dim=2)                                              # [1,N,28]
     spfn_labels = torch.nn.functional.one_hot(Wg[0].argmax(1), K_GLOBAL)           # [N,28] long, as the data loader stores it
-    # ---------------- stage 2: 32 patches x 8192 points (nearest neighbours of 32 FPS centres), LocalSPFN eval
-    centres = P[0, g_net.aux_sa1["fps_idx"][0, :NB].long()]                       # [32,3]
+    # ---------------- stage 0: PatchSelection (evaluation_PatchSelection.py:45-65): the heat-map network on a batch of
+    # 16 low-resolution clouds x 8192 points — cloud 0 is the 8192-point subsample of the cloud above — both compute modes
+    # against the oracle; its 32 hottest points are the patch centres of stage 2
+    P_lo = torch.cat([P[:, ::N_HI // NPP], synthetic.primitive_cloud(15, NPP, n_prims=9, seed=21)["P"].to(dev())], 0).contiguous()
+    ps_net = _net(None, seed=1, sizes=[2])
+    gps = torch.Generator().manual_seed(6)
+    pstarts = (torch.randint(0, NPP, (16,), generator=gps), torch.randint(0, 512, (16,), generator=gps))
+    heat = _both_modes(ps_net, P_lo, pstarts)[0]                                  # [16,8192,2] logits
+    _geometry_vs_oracle(ps_net, P_lo.cpu().numpy(), pstarts)
+    assert heat.shape == (16, NPP, 2)
+    hot = (heat[0, :, 1] - heat[0, :, 0]).topk(NB)[1]                             # points the network rates "small primitive" most
+    # ---------------- stage 2: 32 patches x 8192 points (nearest neighbours of the 32 selected centres), LocalSPFN eval
+    centres = P_lo[0, hot]                                                        # [32,3]
     d2 = ((P[0].unsqueeze(0) - centres.unsqueeze(1)) ** 2).sum(-1)                # [32,N]
     patch_indices = d2.topk(NPP, dim=1, largest=False)[1]                         # [32,8192] (a set per patch)
     patches = P[0][patch_indices]                                                 # [32,8192,3]
@@ -179,9 +193,24 @@ def test_graphed_evaluation_forward_matches_eager():
         P = synthetic.primitive_cloud(shape[0], shape[1], n_prims=8, seed=11)["P"].to(dev())
         gf = GraphedForward(m)
         with torch.no_grad():
+            m.auto_graph = False                     # the plain eager forward is the reference point
             torch.manual_seed(5)
             want = [t.clone() for t in m(P)]
             fps_eager = m.aux_sa1["fps_idx"].clone()
+            m.auto_graph = True
+            # ... the module itself replays a graph for an evaluation forward under no_grad (what the reference's unedited
+            # evaluation scripts call, evaluation_globalSPFN.py:85): same bits, outputs that do not alias the graph's buffers
+            for rep in range(2):
+                torch.manual_seed(5)
+                auto = m(P)
+                assert "_auto_graph" in m.__dict__ and len(m.__dict__["_auto_graph"]._graphs) == 1
+                for a, b in zip(auto, want):
+                    assert torch.equal(a, b)
+                assert torch.equal(m.aux_sa1["fps_idx"], fps_eager)
+            keep = auto[2].clone()
+            torch.manual_seed(6)
+            m(P)                                     # a second call must not overwrite what the first returned
+            assert torch.equal(auto[2], keep)
             for rep in range(2):                     # capture, then a pure replay
                 torch.manual_seed(5)
                 got = gf(P)
@@ -189,6 +218,7 @@ def test_graphed_evaluation_forward_matches_eager():
                     assert torch.equal(a, b)
                 assert torch.equal(m.aux_sa1["fps_idx"], fps_eager)
             got2 = gf(P, fps_start=(torch.zeros(shape[0], dtype=torch.long), torch.ones(shape[0], dtype=torch.long)))
+            m.auto_graph = False
             want2 = m(P, fps_start=(torch.zeros(shape[0], dtype=torch.long), torch.ones(shape[0], dtype=torch.long)))
             for a, b in zip(got2, want2):
                 assert torch.equal(a, b)

@@ -148,3 +148,109 @@ def test_patch_selection_and_feature_extractor_variants():
     out = gl(P, glob_features=torch.randn(2, 1024, device=dev()), loc_features=torch.randn(2, 128, device=dev()))
     assert out[2].shape == (2, 1024, 21) and out[3].shape == (2, 1024 + 1024 + 128, 1)
     assert gl.sfp1.mlp_convs[0].weight.shape[1] == 1024 + 1024 + 128 + 256
+
+
+# ---- the network variants of config 5, pinned to the reference -------------------------------------------
+def _variant(kind):
+    from cpfn_amd.PointNet2 import pn2_network
+    if kind == "ps":
+        m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2])
+        state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([2]), seed=1)
+    elif kind == "fe":
+        m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2], features_extractor=True)
+        state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([2], features_extractor=True), seed=2)
+    else:
+        m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 21], use_glob_features=True, use_loc_features=True)
+        state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([3, 4, 21], True, True), seed=3)
+    m.load_state_dict(state, strict=True)
+    m.dropout_p = 0.0
+    return m.to(dev()).train(), state
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+def test_patch_selection_network_matches_reference_fixture(golden):
+    """PointNet2(output_sizes=[2]) — the heat-map network of training_PatchSelection.py:55 / evaluation_PatchSelection.py:45 —
+    against the reference's own outputs (tests/golden/make_golden_spfn.py::make_variants): heat-map logits in training and in
+    evaluation mode, and one cross-entropy step of Utils/training_utils.py:62-75 (loss and per-parameter gradient norms) in
+    the fp32 compute mode at 2e-3; the bf16 mode against the same fixture at the fused stacks' bounds."""
+    g = golden("network_variants_2x2048.npz")
+    P = torch.from_numpy(g["P"]).to(dev())
+    labels = torch.from_numpy(g["ps_labels"]).to(dev())
+    starts = (torch.from_numpy(g["ps_fps_start1"]), torch.from_numpy(g["ps_fps_start2"]))
+    m, state = _variant("ps")
+    heat, l3, feat = m(P, fps_start=starts)
+    np.testing.assert_allclose(heat.detach().cpu().numpy(), g["ps_heat"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(l3.detach().cpu().numpy()[:, :, 0], g["ps_l3"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(feat.detach().cpu().numpy()[:, :, g["sub"]], g["ps_feat_sub"], rtol=2e-3, atol=2e-3)
+    loss = torch.nn.functional.cross_entropy(heat.contiguous().view(-1, 2), labels.view(-1))       # training_utils.py:66-68
+    assert abs(float(loss) - float(g["ps_loss"])) < 2e-3 * float(g["ps_loss"])
+    loss.backward()
+    names = [str(n) for n in g["ps_names"]]
+    params = dict(m.named_parameters())
+    big = g["ps_grad_norm"] > 1e-6
+    gn = np.array([0.0 if params[n].grad is None else float(params[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(gn[big], g["ps_grad_norm"][big], rtol=2e-2)
+    for i, n in enumerate(names):
+        if big[i]:
+            got = params[n].grad.flatten()[:8].cpu().numpy()
+            np.testing.assert_allclose(got, g["ps_grad_head"][i][:got.size], rtol=5e-2, atol=2e-2 * float(g["ps_grad_norm"][i]), err_msg=n)
+    # evaluation mode (evaluation_PatchSelection.py:49): running statistics
+    m, state = _variant("ps")
+    m.eval()
+    est = (torch.from_numpy(g["ps_eval_fps_start1"]), torch.from_numpy(g["ps_eval_fps_start2"]))
+    with torch.no_grad():
+        heat_e = m(P, fps_start=est)[0]
+        np.testing.assert_allclose(heat_e.cpu().numpy(), g["ps_eval_heat"], rtol=2e-3, atol=2e-3)
+        # ... and the same prediction: which points are selected (:65)
+        assert float((heat_e.argmax(2).cpu() == torch.from_numpy(g["ps_eval_heat"]).argmax(2)).float().mean()) > 0.999
+        m.set_compute_dtype(torch.bfloat16)
+        heat_b = m(P, fps_start=est)[0]
+    e_eval = _rel(heat_b.cpu(), torch.from_numpy(g["ps_eval_heat"]))
+    m, state = _variant("ps")
+    m.set_compute_dtype(torch.bfloat16)
+    heat_t = m(P, fps_start=starts)[0]
+    e_train = _rel(heat_t.detach().cpu(), torch.from_numpy(g["ps_heat"]))
+    loss_b = torch.nn.functional.cross_entropy(heat_t.contiguous().view(-1, 2), labels.view(-1))
+    loss_b.backward()
+    gb = np.array([0.0 if params_b.grad is None else float(params_b.grad.norm()) for params_b in (dict(m.named_parameters())[n] for n in names)])
+    e_grad = float(np.abs(gb[big] - g["ps_grad_norm"][big]).max() / g["ps_grad_norm"][big].max())
+    print("PatchSelection bf16 vs reference: heat eval %.2e, heat train %.2e, loss %.5f / %.5f, grad norms %.2e"
+          % (e_eval, e_train, float(loss_b), float(g["ps_loss"]), e_grad))
+    assert e_eval < 1e-2 and e_train < 5e-2 and abs(float(loss_b) - float(g["ps_loss"])) < 2e-2 * float(g["ps_loss"]) and e_grad < 1e-1
+
+
+def test_feature_extractor_and_feature_input_variants_match_reference_fixture(golden):
+    """features_extractor=True (pn2_network.py:31-36, 70-71) and use_glob_features / use_loc_features with seeded feature inputs
+    (:22-27, :51-54) against the reference's own outputs: fp32 mode at 2e-3, bf16 mode at the fused stacks' bounds."""
+    g = golden("network_variants_2x2048.npz")
+    P = torch.from_numpy(g["P"]).to(dev())
+    sub = g["sub"]
+    m, _ = _variant("fe")
+    starts = (torch.from_numpy(g["fe_fps_start1"]), torch.from_numpy(g["fe_fps_start2"]))
+    with torch.no_grad():
+        l3, feat = m(P, fps_start=starts)
+        np.testing.assert_allclose(l3.cpu().numpy()[:, :, 0], g["fe_l3"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(feat.cpu().numpy()[:, :, sub], g["fe_feat_sub"], rtol=2e-3, atol=2e-3)
+        m.set_compute_dtype(torch.bfloat16)
+        l3b, featb = m(P, fps_start=starts)
+    e = (_rel(l3b.cpu()[:, :, 0], torch.from_numpy(g["fe_l3"])), _rel(featb.cpu()[:, :, sub], torch.from_numpy(g["fe_feat_sub"])))
+    print("features extractor bf16 vs reference: l3 %.2e, features %.2e" % e)
+    assert e[0] < 3e-2 and e[1] < 5e-2
+    m, _ = _variant("gl")
+    starts = (torch.from_numpy(g["gl_fps_start1"]), torch.from_numpy(g["gl_fps_start2"]))
+    glob, loc = torch.from_numpy(g["gl_glob"]).to(dev()), torch.from_numpy(g["gl_loc"]).to(dev())
+    with torch.no_grad():
+        X, T, W, l3, feat = m(P, glob_features=glob, loc_features=loc, fps_start=starts)
+        for name, a in (("gl_X", X), ("gl_T", T), ("gl_W", W)):
+            np.testing.assert_allclose(a.cpu().numpy(), g[name], rtol=2e-3, atol=2e-3, err_msg=name)
+        assert l3.shape == (2, 1024 + 1024 + 128, 1)
+        np.testing.assert_allclose(l3.cpu().numpy()[:, :, 0], g["gl_l3"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(feat.cpu().numpy()[:, :, sub], g["gl_feat_sub"], rtol=2e-3, atol=2e-3)
+        m.set_compute_dtype(torch.bfloat16)
+        out = m(P, glob_features=glob, loc_features=loc, fps_start=starts)
+    e = [_rel(a.cpu(), torch.from_numpy(g[n])) for n, a in (("gl_X", out[0]), ("gl_T", out[1]), ("gl_W", out[2]))]
+    print("glob + loc features bf16 vs reference: heads %s" % ["%.2e" % v for v in e])
+    assert max(e) < 5e-2

@@ -208,6 +208,48 @@ def test_metrics_oracle_padding_branches_match_reference_fixture(golden, tag, n_
     np.testing.assert_allclose(out["P_coverage"].numpy(), g["P_coverage"], atol=3.0 / n_pts)
 
 
+def test_network_variants_oracle_matches_reference_fixture(golden):
+    """oracle/pn2.py on the PatchSelection / features-extractor / glob+loc-features variants of the network
+    (tests/golden/make_golden_spfn.py::make_variants ran the reference itself): forward bit-for-bit-close, and the
+    cross-entropy step of Utils/training_utils.py:62-75 with its per-parameter gradients."""
+    g = golden("network_variants_2x2048.npz")
+    P = torch.from_numpy(g["P"])
+    sub = g["sub"]
+    st = lambda tag: (g[tag + "fps_start1"], g[tag + "fps_start2"])
+    # PatchSelection, training mode + one backward pass
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([2]), seed=1)
+    leaves = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in state.items()}
+    loss, heat = opn2.patch_selection_loss(leaves, P, torch.from_numpy(g["ps_labels"]), st("ps_"))
+    np.testing.assert_allclose(heat.detach().numpy(), g["ps_heat"], rtol=1e-4, atol=2e-5)
+    assert abs(float(loss) - float(g["ps_loss"])) < 1e-5
+    loss.backward()
+    names = [str(n) for n in g["ps_names"]]
+    gn = np.array([float(leaves[n].grad.norm()) for n in names])
+    big = g["ps_grad_norm"] > 1e-6                 # (conv biases in front of a batch-norm: exactly cancelling, ~1e-9 noise)
+    np.testing.assert_allclose(gn[big], g["ps_grad_norm"][big], rtol=2e-3)
+    # ... evaluation mode (evaluation_PatchSelection.py:49: running statistics)
+    with torch.no_grad():
+        heads, _, _, _ = opn2.pointnet2_forward(state, P, st("ps_eval_"), training=False)
+    np.testing.assert_allclose(heads[0].numpy(), g["ps_eval_heat"], rtol=1e-4, atol=2e-5)
+    # features extractor
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([2], features_extractor=True), seed=2)
+    with torch.no_grad():
+        heads, l3, feat, _ = opn2.pointnet2_forward(state, P, st("fe_"), training=True)
+    assert heads == []
+    np.testing.assert_allclose(l3.numpy()[:, :, 0], g["fe_l3"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(feat.numpy()[:, :, sub], g["fe_feat_sub"], rtol=1e-4, atol=2e-5)
+    # global + local feature inputs
+    state = synthetic.synthetic_state_dict(synthetic.pointnet2_state_shapes([3, 4, 21], True, True), seed=3)
+    with torch.no_grad():
+        heads, l3, feat, _ = opn2.pointnet2_forward(state, P, st("gl_"), training=True, glob_features=torch.from_numpy(g["gl_glob"]),
+                                                    loc_features=torch.from_numpy(g["gl_loc"]))
+    for name, a in (("gl_X", heads[0]), ("gl_T", heads[1]), ("gl_W", heads[2])):
+        np.testing.assert_allclose(a.numpy(), g[name], rtol=1e-4, atol=2e-5, err_msg=name)
+    assert l3.shape[1] == 1024 + 1024 + 128
+    np.testing.assert_allclose(l3.numpy()[:, :, 0], g["gl_l3"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(feat.numpy()[:, :, sub], g["gl_feat_sub"], rtol=1e-4, atol=2e-5)
+
+
 def test_merging_oracle_matches_reference_fixture(golden):
     """oracle/merging.py against the reference's similarity_soft / get_point_final (fixture generated by running
     those two functions of Utils/merging_utils.py)."""

@@ -40,7 +40,10 @@ with torch.no_grad():
     ctr = ops.gather_rows(P, sel)
     t, _ = timed(lambda: ops.ball_query(ctr, P, 0.2, 64)); print("ball query 512 x 131072                            %8.3f ms" % t)
     t, _ = timed(lambda: ops.three_nn(P, ctr)); print("3-NN 131072 x 512                                  %8.3f ms" % t)
-    t, out = timed(lambda: g(P, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("GlobalSPFN eval forward, 1 x 131072               %8.3f ms" % t)
+    g.auto_graph = False
+    t, out = timed(lambda: g(P, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("GlobalSPFN eval forward, 1 x 131072, eager launches %7.3f ms" % t)
+    g.auto_graph = True
+    t, out = timed(lambda: g(P, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("  ... the unedited call model(P): auto-replayed graph %6.3f ms" % t)
     from cpfn_amd.inference import GraphedForward
     gg = GraphedForward(g)
     t, _ = timed(lambda: gg(P, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("  ... replayed as one hipGraph (GraphedForward)       %8.3f ms" % t)
@@ -51,7 +54,10 @@ with torch.no_grad():
     patches = patches - patches.mean(1, keepdim=True)
     patches = (patches / patches.norm(dim=2).max(dim=1)[0].view(NB, 1, 1)).contiguous()
     st = (torch.zeros(NB, dtype=torch.long), torch.zeros(NB, dtype=torch.long))
-    t, lout = timed(lambda: l(patches, fps_start=st)); print("LocalSPFN eval forward, 32 x 8192                  %8.3f ms" % t)
+    l.auto_graph = False
+    t, lout = timed(lambda: l(patches, fps_start=st)); print("LocalSPFN eval forward, 32 x 8192, eager launches  %8.3f ms" % t)
+    l.auto_graph = True
+    t, lout = timed(lambda: l(patches, fps_start=st)); print("  ... the unedited call model(P): auto-replayed graph %6.3f ms" % t)
     gl = GraphedForward(l)
     t, _ = timed(lambda: gl(patches, fps_start=st)); print("  ... replayed as one hipGraph (GraphedForward)       %8.3f ms" % t)
     Wg, Wl = torch.softmax(out[2], 2), torch.softmax(lout[2], 2)
