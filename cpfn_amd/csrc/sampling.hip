@@ -332,43 +332,30 @@ __global__ __launch_bounds__(NT) void fps_streaming_kernel(const float *__restri
 // (~1 s, once: the sample loop ends there) leaves index 0 (a valid point) in the remaining outputs and counts the cloud in
 // a device-side fault counter that cpfn_fps_faults() reads: a hung GPU and out-of-range indices are both worse.
 // Same arithmetic, same tie-break as the other two kernels: bit-identical selections.
-constexpr int FPS_XCD_DEFAULT = 0;
 __device__ unsigned g_fps_faults = 0;
-// Round 4: the winner's COORDINATES ride with the key.  Round 3's exchange was store key -> poll keys -> dependent global load
-// of the winner's coordinates p[3 * far] (1.65 of a sample's 2.54 us, profiles/r03_fps_latency.md).  Now a workgroup publishes
-// FOUR tagged 8-byte granules per sample — its key and the x, y, z of its own best point (read from an LDS mirror of the
-// workgroup's points, like the resident kernel) as (float bits << 32 | tag) — by four lanes at once; the four waves poll one
-// granule kind each (G lanes per wave), so everything a workgroup needs for the next sample arrives in ONE round trip and the
-// winner's coordinates are picked from LDS.  Double buffering by sample parity stays safe: a workgroup publishes sample i + 1
-// only after ALL its waves have finished polling sample i (the barrier behind the polls), so nobody can overwrite parity p
-// (sample i + 2) while somebody still polls sample i.
-// xcd_remap: the G workgroups of a cloud get linear block ids that are congruent modulo 8, i.e. the same XCD under the
-// dispatcher's round-robin placement, so that the exchange stays inside one L2 (speed only: the protocol is agent-scope).
+// Round 4, measured on one box (tools/dbg/fps_shared_time.py, 131072 -> 512, B = 1): what the exchange costs grows with the
+// number of PARTICIPANTS, not with the bytes: 64 workgroups x 8 points per lane 1.41 ms, 32 x 16: 1.24 ms, 16 x 32: 1.00 ms
+// (512 threads x 16: 1.04, 1024 x 8: 1.10; 8 workgroups of 512 x 32: 1.25 — the per-sample pass over 16384 points then costs
+// more than the lighter exchange saves).  The launcher therefore always takes 32 points per lane.  NOT adopted: the winner's
+// coordinates riding with the key as three more tagged 8-byte granules per workgroup (read from an LDS mirror, published by
+// four lanes at once, one granule kind polled per wave, so that the dependent p[3 * far] load after the exchange disappears):
+// 1.57 / 1.49 / 1.39 ms at 8 / 16 / 32 points per lane against 1.41 / 1.24 / 1.00 — four times the polling traffic on the
+// same few cache lines slows every workgroup's round trip by more than the L2-hit load of the coordinates cost; and with
+// the workgroups of a cloud placed on ONE XCD (linear block ids congruent modulo 8) 2.99 ms at 64 workgroups (two per CU on
+// 32 CUs: the per-sample pass doubles), 1.25 ms at 32.  Both removed.
 template <int PPT>
-__global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict__ xyz, int B, int N, int S, int G,
-                                                         const int *__restrict__ start, int flags, int xcd_remap,
+__global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict__ xyz, int N, int S,
+                                                         const int *__restrict__ start, int flags,
                                                          int *__restrict__ idx_out, unsigned long long *__restrict__ slots,
                                                          unsigned *__restrict__ host_faults) {
   constexpr int NT = 256, NW = 4;
-  __shared__ float s_x[NT * PPT], s_y[NT * PPT], s_z[NT * PPT];     // mirror of this workgroup's points (x / y / z planes)
   __shared__ unsigned long long s_key[2][NW];
-  __shared__ float s_cand[2][NW][3];
-  __shared__ float s_g[2][3][64];               // the G workgroups' candidate coordinates of a sample (by sample parity)
-  __shared__ unsigned s_far[2], s_win[2], s_dead;
-  int wg, b;
-  if (xcd_remap) {
-    const int id = blockIdx.x, slot = id >> 3;
-    b = (slot / G) * 8 + (id & 7);
-    wg = slot % G;
-    if (b >= B) return;
-  } else {
-    wg = blockIdx.x % G;
-    b = blockIdx.x / G;
-  }
+  __shared__ unsigned s_far;
+  const int G = gridDim.x, wg = blockIdx.x, b = blockIdx.y;
   const int t = threadIdx.x, lane = t & (CPFN_WAVE - 1), wave = t / CPFN_WAVE;
   const float *p = xyz + (size_t)b * N * 3;
   int *out = idx_out + (size_t)b * S;
-  unsigned long long *sl = slots + (size_t)b * 8 * G;          // [parity][granule kind][workgroup]
+  unsigned long long *sl = slots + (size_t)b * 2 * G;
   const int base = wg * NT * PPT;
   f32x2 px[PPT / 2], py[PPT / 2], pz[PPT / 2], md[PPT / 2];
 #pragma unroll
@@ -381,65 +368,46 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
       if ((flags & CPFN_FPS_SKIP_NEAR_ORIGIN) && cpfn_sqnorm3(x, y, z) <= 1e-3f) m = -1.0f;
     }
     px[j / 2][j & 1] = x; py[j / 2][j & 1] = y; pz[j / 2][j & 1] = z; md[j / 2][j & 1] = m;
-    s_x[t + j * NT] = x; s_y[t + j * NT] = y; s_z[t + j * NT] = z;
   }
   unsigned far = start ? (unsigned)start[b] : 0u;
-  float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
-  if (t == 0) s_dead = 0u;
-  __syncthreads();
+  bool dead = false;
   for (int i = 0; i < S; ++i) {
     if (wg == 0 && t == 0) out[i] = (int)far;
+    const float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
     const float wmax = wave_max_f32(fps_update<PPT>(px, py, pz, md, fx, fy, fz));
     // key without the tag: candidates compare by (distance, lowest index); "no candidate" = 0
     unsigned long long key = 0ull;
-    unsigned besti = (unsigned)base;
     if (wmax >= 0.f) {
-      besti = fps_first_index<PPT, NT>(md, wmax, (unsigned)(base + t - lane), lane);
+      const unsigned besti = fps_first_index<PPT, NT>(md, wmax, (unsigned)(base + t - lane), lane);
       key = ((unsigned long long)__float_as_uint(wmax) << 32) | ((unsigned long long)(0xFFFFFu - besti) << 12);
-    }
-    if (lane < 3) {                                   // the wave's candidate: its coordinates from the LDS mirror
-      const float *pl = lane == 0 ? s_x : (lane == 1 ? s_y : s_z);
-      s_cand[i & 1][wave][lane] = pl[besti - base];
     }
     if (lane == 0) s_key[i & 1][wave] = key;
     __syncthreads();
     const unsigned tag = (unsigned)(i + 1) & 0xFFFu;
-    if (t < 4) {                                      // four lanes publish the workgroup's four granules at once
+    if (t == 0) {
       unsigned long long k4 = s_key[i & 1][0];
-      int wb = 0;
 #pragma unroll
-      for (int w = 1; w < NW; ++w)
-        if (s_key[i & 1][w] > k4) { k4 = s_key[i & 1][w]; wb = w; }
-      const unsigned long long v = t == 0 ? k4 : ((unsigned long long)__float_as_uint(s_cand[i & 1][wb][t - 1]) << 32);
-      __hip_atomic_store(&sl[((i & 1) * 4 + t) * G + wg], v | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 1; w < NW; ++w) k4 = s_key[i & 1][w] > k4 ? s_key[i & 1][w] : k4;
+      __hip_atomic_store(&sl[(i & 1) * G + wg], k4 | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    {                 // wave w polls granule kind w of all G workgroups (G <= 64 lanes) until each carries this sample's tag
+    if (wave == 0) {       // G <= 64 lanes poll one slot each until it carries this sample's tag
       unsigned long long k = 0ull;
       if (lane < G) {
         unsigned spins = 0;
-        const unsigned long long *src = &sl[((i & 1) * 4 + wave) * G + lane];
         do {
-          k = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          k = __hip_atomic_load(&sl[(i & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (++spins > (1u << 24)) { k = ~0ull; break; }          // ~1 s: a sibling workgroup never arrived
         } while ((unsigned)(k & 0xFFFull) != tag);
       }
       const bool timeout = __ballot(k == ~0ull) != 0ull;
-      if (timeout && lane == 0) s_dead = 1u;                     // (any wave's time-out ends the cloud's sampling)
-      if (wave == 0) {
-        k = (lane < G && !timeout) ? (k & ~0xFFFull) : 0ull;
-        k = wave_max_key(k);
-        if (lane == 0) {
-          const unsigned nf = k ? 0xFFFFFu - (unsigned)((k >> 12) & 0xFFFFFull) : 0u;
-          s_far[i & 1] = nf;
-          s_win[i & 1] = nf / (unsigned)(NT * PPT);
-        }
-      } else if (lane < G) {
-        s_g[i & 1][wave - 1][lane] = __uint_as_float((unsigned)(k >> 32));
-      }
+      k = (lane < G && !timeout) ? (k & ~0xFFFull) : 0ull;
+      k = wave_max_key(k);
+      if (lane == 0) s_far = timeout ? 0xFFFFFFFFu : (k ? 0xFFFFFu - (unsigned)((k >> 12) & 0xFFFFFull) : 0u);
     }
     __syncthreads();
-    if (s_dead) {                     // a sibling workgroup never arrived: give up for this cloud (every workgroup of it
-                                      // takes this branch at most one spin period later)
+    const unsigned nf = s_far;
+    if (nf == 0xFFFFFFFFu) {          // a sibling workgroup never arrived: give up for this cloud (every workgroup of it
+      dead = true;                    // takes this branch at most one spin period later)
       if (wg == 0 && t == 0) {
         for (int r = i + 1; r < S; ++r) out[r] = 0;
         atomicAdd(&g_fps_faults, 1u);
@@ -447,12 +415,9 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
       }
       break;
     }
-    const unsigned nf = s_far[i & 1];
     far = nf;
-    // (the parity's results are rewritten two samples on, behind two more barriers: no third barrier per sample)
-    const unsigned w = s_win[i & 1] < (unsigned)G ? s_win[i & 1] : 0u;
-    fx = s_g[i & 1][0][w]; fy = s_g[i & 1][1][w]; fz = s_g[i & 1][2][w];
   }
+  (void)dead;
 }
 
 }  // namespace
@@ -530,17 +495,14 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
     if (!scratch) return CPFN_EINVAL;
     // several workgroups per cloud while all of them can be resident together and the key layout holds
     // (index < 2^20, sample tag < 4095); slots = the first B * 2 * G 8-byte words of the scratch row buffer
-    int ppt = 8;
-    while (ppt < 32 && (N + 256 * ppt - 1) / (256 * ppt) > 64) ppt *= 2;
+    // 32 points per lane: as few workgroups per cloud as the registers allow (see fps_shared_kernel: the exchange costs by
+    // participant) — 16 for the 131072-point clouds of the evaluation cascade, 64 at 524288 points
+    const int ppt = 32;
     const int G = (N + 256 * ppt - 1) / (256 * ppt);
-    const int capacity = ppt == 8 ? fps_shared_capacity<8>() : ppt == 16 ? fps_shared_capacity<16>() : fps_shared_capacity<32>();
-    // CPFN_FPS_XCD (experiment switch): 1 = the workgroups of a cloud share one XCD (round-robin placement by linear block id)
-    static const int xcd_env = [] { const char *e = getenv("CPFN_FPS_XCD"); return e ? atoi(e) : FPS_XCD_DEFAULT; }();
-    // ... which holds 1/8 of the chip: all G workgroups of ceil(B / 8) clouds must be resident on one XCD's compute units
-    const bool xcd = xcd_env != 0 && (long long)((B + 7) / 8) * G <= capacity / 8;
+    const int capacity = fps_shared_capacity<32>();
     if (G <= 64 && (long long)B * G <= capacity && B <= 65535 && S <= 4094 && N <= (1 << 20) &&
-        (size_t)B * 8 * G * 8 <= (size_t)B * N * 4 && ((uintptr_t)scratch & 7) == 0) {
-      hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * 8 * G * 8, st);
+        (size_t)B * 2 * G * 8 <= (size_t)B * N * 4 && ((uintptr_t)scratch & 7) == 0) {
+      hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * 2 * G * 8, st);
       if (e != hipSuccess) return (int)e;
       unsigned long long *slots = (unsigned long long *)scratch;
       unsigned *hf = nullptr;
@@ -548,10 +510,7 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
       if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
       static bool have_hf = false;
       if (have_hf || cs == hipStreamCaptureStatusNone) { fps_host_faults(&hf); have_hf = true; }   // (first use allocates: not inside a capture)
-      const int blocks = xcd ? ((B + 7) / 8) * 8 * G : B * G;
-      if (ppt == 8) fps_shared_kernel<8><<<blocks, 256, 0, st>>>(xyz, B, N, S, G, start, flags, xcd, idx_out, slots, hf);
-      else if (ppt == 16) fps_shared_kernel<16><<<blocks, 256, 0, st>>>(xyz, B, N, S, G, start, flags, xcd, idx_out, slots, hf);
-      else fps_shared_kernel<32><<<blocks, 256, 0, st>>>(xyz, B, N, S, G, start, flags, xcd, idx_out, slots, hf);
+      fps_shared_kernel<32><<<dim3(G, B), 256, 0, st>>>(xyz, N, S, start, flags, idx_out, slots, hf);
     } else {
       fps_streaming_kernel<1024><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out, scratch);
     }

@@ -190,7 +190,10 @@ def test_patch_selection_network_matches_reference_fixture(golden):
     loss.backward()
     names = [str(n) for n in g["ps_names"]]
     params = dict(m.named_parameters())
-    big = g["ps_grad_norm"] > 1e-6
+    # (a conv bias in front of a training-mode BatchNorm cancels exactly: the reference's gradient for it is rounding noise,
+    #  <= 3e-4 here, the product's is exactly zero — DESIGN.md §5 "deliberate deviation")
+    big = g["ps_grad_norm"] > 2e-3
+    assert all(n.endswith(".bias") for n, b in zip(names, big) if not b)
     gn = np.array([0.0 if params[n].grad is None else float(params[n].grad.norm()) for n in names])
     np.testing.assert_allclose(gn[big], g["ps_grad_norm"][big], rtol=2e-2)
     for i, n in enumerate(names):
