@@ -28,7 +28,10 @@ SOURCES = {
     "gather.hip": ["-ffp-contract=off"],
     "fitters.hip": [],
     "fit_algebra.hip": ["-ffp-contract=off"],
-    "mlp.hip": [],
+    "mlp_fwd.hip": [],
+    "mlp_small.hip": [],
+    "mlp_bwd_fused.hip": [],
+    "bn.hip": [],
     "losses.hip": [],
     "merging.hip": [],
     "metrics.hip": [],
@@ -109,7 +112,7 @@ def _check_isa(src):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = {s: f for s, f in SOURCES.items() if os.path.exists(os.path.join(CSRC, s))}
-    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         res = list(ex.map(lambda kv: _compile(kv[0], kv[1], force), srcs.items()))
     objs = [o for o, _ in res]
     if force or any(c for _, c in res) or _stale(SO, objs):

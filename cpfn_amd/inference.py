@@ -103,5 +103,20 @@ class GraphedForward:
         for k, v in st["aux"].items():
             setattr(m, k, v)
         if self.clone_outputs:
-            return type(st["out"])(o.clone() for o in st["out"])
+            return self._clones(st["out"])
         return st["out"]
+
+    @staticmethod
+    def _clones(out):
+        """Copies of the graph's outputs that keep their view structure: outputs that share a storage (the three heads are
+        slices of one packed [rows, 35] tensor) are copied ONCE and re-sliced."""
+        copies, res = {}, []
+        for o in out:
+            stg = o.untyped_storage()
+            key = stg.data_ptr()
+            if key not in copies:
+                whole = torch.empty(0, dtype=o.dtype, device=o.device).set_(stg, 0, (stg.nbytes() // o.element_size(),), (1,))
+                copies[key] = (whole.clone(), o.dtype)
+            c, dt = copies[key]
+            res.append(torch.as_strided(c, o.size(), o.stride(), o.storage_offset()) if dt == o.dtype else o.clone())
+        return type(out)(res)

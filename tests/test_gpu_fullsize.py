@@ -297,6 +297,11 @@ def _compare(model, tr, batch_cpu, batch, starts, out, cfg, tag):
         assert rc[k] <= 1.3 * rp[k] + 1e-3, (k, rc[k], rp[k])
     # (the matching is discrete: one noise draw moves the agreement by ~0.1; config 2 measured 0.64 bf16 / 0.75 noise)
     assert rc["match"] >= rp["match"] - 0.15 and rc["grad_cos"] >= rp["grad_cos"] - 0.1, (rc, rp)
+    # ... and loose ABSOLUTE floors beside the relative bounds: the reference point itself must be sane — a noise
+    # run that had drifted to cosine ~0 / agreement ~0 would let a broken bf16 backward pass (measured: noise run cosine 0.22,
+    # agreement 0.75; bf16 graph 0.32 / 0.64 at config 2)
+    assert rp["grad_cos"] > 0.12 and rp["match"] >= 0.5 and max(rp["head_X"], rp["head_T"], rp["head_W"]) < 0.5, rp
+    assert rc["grad_cos"] > 0.1 and rc["match"] >= 0.4, rc
     assert rc["grad_rel"] <= 1.3 * rp["grad_rel"] + 1e-2, (rc, rp)
     assert _losses_within(rc, 6e-2, 3e-3), rc
     # ---- (B) the fused bf16 stacks one by one at bench size

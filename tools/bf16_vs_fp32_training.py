@@ -99,7 +99,7 @@ def compare(res, floor_scale=1.0, eval_mode="own"):
     """Per metric: mean and sample sd of the bf16-trained and the fp32-trained models (each evaluated in `eval_mode`: "own" =
     the mode it was trained in, "bf16" / "fp32" = all models in that one mode), their difference, the pooled sd, Welch's t,
     the allowed band.  -> table, ok"""
-    key = {"own": "metrics", "bf16": "metrics_eval_bf16", "fp32": "metrics_eval_fp32"}[eval_mode]
+    key = {"own": "metrics", "bf16": "metrics_eval_bf16", "fp32": "metrics_eval_fp32", "train_set": "metrics_train_set"}[eval_mode]
     runs = {m: [v for k, v in sorted(res.items()) if k.startswith(m + "_seed")] for m in ("bf16", "fp32")}
     table, ok = {}, True
     for k in METRICS:
@@ -130,6 +130,10 @@ def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0, seeds=S
             model, info = train(mode, seed, steps, pool, dev, log_every)
             info["metrics"] = evaluate(model, held)
             if both_eval_modes:
+                # ... and on clouds it was TRAINED on: an advantage that exists on held-out clouds only is generalisation
+                # (rounding noise as a regulariser), not a better fit
+                info["metrics_train_set"] = evaluate(model, pool[:n_held])
+            if both_eval_modes:
                 # the SAME trained weights and running statistics evaluated in both compute modes: separates "training in bf16
                 # differs" from "evaluating in bf16 differs"
                 for em, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
@@ -147,6 +151,7 @@ def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0, seeds=S
     if both_eval_modes:
         for em in ("bf16", "fp32"):
             res["comparison_all_evaluated_in_" + em], res["ok_all_evaluated_in_" + em] = compare(res, floor_scale, em)
+        res["comparison_on_training_clouds"], res["ok_on_training_clouds"] = compare(res, floor_scale, "train_set")
         # evaluation-mode effect on identical weights: mean over all models of (metric in bf16 eval - metric in fp32 eval)
         allr = [v for k, v in res.items() if "_seed" in k]
         res["eval_mode_effect"] = {k: _mean_sd([r["metrics_eval_bf16"][k] - r["metrics_eval_fp32"][k] for r in allr]) for k in METRICS}
