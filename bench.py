@@ -604,6 +604,17 @@ def main():
         if tfiles:
             traffic = json.load(open(tfiles[-1])).get(dominant, {}).get("hbm_bytes_per_launch")
             traffic_src = os.path.relpath(tfiles[-1], ROOT)
+        # ... and the same family's fraction under rocprofv3 (the profiler stretches short kernels: a few per cent lower), from
+        # the newest committed collection, so that the two figures sit in one line
+        rocprof_frac, rocprof_src = None, None
+        rfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_rooflines.json")))
+        if rfiles:
+            try:
+                fam = [f for f in json.load(open(rfiles[-1])).get("families", []) if f.get("family") == dominant]
+                if fam:
+                    rocprof_frac, rocprof_src = fam[0].get("frac_of_hbm_peak"), os.path.relpath(rfiles[-1], ROOT)
+            except (ValueError, OSError):
+                pass
         line = {
             "metric": "point-clouds/sec (8192 pts, %sSPFN fwd+bwd)" % ("Global" if args.workload == "global" else "Local"),
             "value": clouds / elapsed, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps,
@@ -627,6 +638,7 @@ def main():
                                         bytes_per_step / (fam_range[dominant][0] / (wall_khz * 1e3)) / 1e9 / HBM_PEAK_GBS]
                          if fam_range[dominant][0] > 0 else None,
                          "samples": len(samples),
+                         "rocprof_frac": rocprof_frac, "rocprof_source": rocprof_src,
                          "launches": probe_launches or ev_calls, "avg_launch_us": 1e6 * per_launch_s,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "measured": roof_mode,
                          "wall_clock_khz": wall_khz,
@@ -642,6 +654,10 @@ def main():
             extra = scale_fields(trainer.bucket.collective, 4 * trainer.bucket.flat.numel(),
                                  bool((trainer._graph or {}).get("exchange_in_graph")), rank_ms, rank_comm, len(comm_us))
             line["config"]["collective"] = extra.pop("collective")
+            # the exchange sits between the gradient packing and Adam and overlaps with nothing of its own step (only the next
+            # batch's geometry graph runs beside it): at 5.6 MB it is latency-bound, and a second stream would cost two
+            # cross-stream graph edges (~19 us each on this stack) to hide ~30-50 us of wire time
+            line["exchange_overlap"] = False
             line.update(extra)
         if world == 1 and not args.no_routes and args.workload == "global" and args.dtype == "bf16" and not args.no_graphs:
             del trainer, model                         # (its graphs' pools go back before the routes build theirs)

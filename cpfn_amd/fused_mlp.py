@@ -1,4 +1,4 @@
-"""Fused per-point MLP stacks on the HIP kernels of cpfn_amd/csrc/mlp.hip.
+"""Fused per-point MLP stacks on the HIP kernels of cpfn_amd/csrc/{mlp_fwd,mlp_small,mlp_bwd_fused,bn}.hip.
 
 One `torch.autograd.Function` per stack of (1x1 conv -> BatchNorm -> ReLU) layers,
 optionally ending in the max over the K neighbours of a set-abstraction group.  Forward

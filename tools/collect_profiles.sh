@@ -2,7 +2,7 @@
 # Everything profiles/ is refreshed from, in one gpurun call (run on the GPU box from the repo root):
 #   bash tools/collect_profiles.sh [tag]  ->  gpurun_out/collect/... and profiles/<tag>_*
 # Counter passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa tracing), eager launches.
-tag=${1:-r03}
+tag=${1:-r04}
 repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"

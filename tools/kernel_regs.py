@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Register / LDS / scratch footprint of every kernel of one csrc/*.hip file (compiles it to /tmp with -save-temps
-and reads the code-object metadata): `python tools/kernel_regs.py mlp.hip [filter]`.  Occupancy on CDNA4: a wave's
+and reads the code-object metadata): `python tools/kernel_regs.py mlp_fwd.hip [filter]`.  Occupancy on CDNA4: a wave's
 VGPRs + AGPRs come out of one 512-entry file per SIMD lane, so > 256 means ONE wave per SIMD."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
