@@ -7,7 +7,7 @@ repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
 mkdir -p gpurun_out/collect
-B="bench.py --no-cpu-baseline"
+B="bench.py --no-cpu-baseline --no-routes"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/collect/stats -o s -- python3 $B --steps 10 --warmup 5 > gpurun_out/collect/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/fetch -o f -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/write -o w -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/write.log 2>&1
@@ -19,8 +19,8 @@ python3 tools/rooflines.py --trace gpurun_out/collect/stats --fetch gpurun_out/c
 python3 tools/replay_breakdown.py $(find gpurun_out/collect/stats -name '*kernel_trace.csv' | head -1) > profiles/${tag}_replayed_step_breakdown.txt 2> gpurun_out/collect/breakdown.err
 cp $(find gpurun_out/collect/stats -name '*kernel_stats.csv' | head -1) profiles/${tag}_graph_kernel_stats.csv
 python3 bench.py --steps 300 --warmup 30 2> gpurun_out/collect/bench.err | tail -1 > profiles/${tag}_bench_n1.json
-python3 bench.py --steps 50 --warmup 10 --no-graphs --no-cpu-baseline 2> gpurun_out/collect/bench_eager.err | tail -1 > profiles/${tag}_bench_n1_eager.json
-python3 bench.py --steps 100 --warmup 10 --workload local 2> gpurun_out/collect/bench_local.err | tail -1 > profiles/${tag}_bench_local_n1.json
+python3 bench.py --steps 50 --warmup 10 --no-graphs --no-cpu-baseline --no-routes 2> gpurun_out/collect/bench_eager.err | tail -1 > profiles/${tag}_bench_n1_eager.json
+python3 bench.py --steps 100 --warmup 10 --workload local --no-routes 2> gpurun_out/collect/bench_local.err | tail -1 > profiles/${tag}_bench_local_n1.json
 python3 tools/fps_latency.py gpurun_out/collect/fps_latency_table.md > /dev/null 2> gpurun_out/collect/fps_latency.err
 python3 tools/cascade_probe.py > profiles/${tag}_cascade_probe.txt 2> gpurun_out/collect/cascade.err
 # bench.py reads roofline.traffic from profiles/<tag>_family_traffic.json: a file older than the library it describes is a lie
