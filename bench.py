@@ -67,6 +67,9 @@ def parse_args():
                     help="skip the two extra data points `routes.epoch` / `routes.zero_edit` (the reference's own epoch-loop "
                          "signature on the replayed step with host->device input hand-over, and the eager zero-edit loop)")
     ap.add_argument("--route-steps", type=int, default=240, help="batches of the timed `routes.epoch` epoch")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic live (two rocprofv3 --pmc child runs in front of the benchmark, ~40 s); "
+                         "quote the newest committed profiles/r*_family_traffic.json instead")
     ap.add_argument("--census-out", default=None, help="write the per-entry-point algorithmic bytes of one step (JSON)")
     return ap.parse_args()
 
@@ -332,6 +335,57 @@ def measure_routes(args, dev, rank, headline_ms):
     return out
 
 
+# kernels of the three self-timing families, for the PMC passes of measure_traffic()
+FAMILY_KERNELS = {"cpfn_mlp_gemm": ("mlp_gemm_stream_kernel", "mlp_gemm_smallp_kernel", "mlp_gemm_kernel"),
+                  "cpfn_mlp_wgrad": ("mlp_wgrad_kernel", "mlp_bwd_small_kernel"),
+                  "cpfn_mlp_bwd_fused": ("mlp_bwd_fused_kernel",)}
+
+
+def measure_traffic():
+    """roofline.traffic measured by THIS run: HBM bytes per launch of the three self-timing kernel
+    families from the PMC counters, collected as MI355X_MICROARCH.md prescribes — one counter per pass (FETCH_SIZE, WRITE_SIZE),
+    `rocprofv3 --pmc <C> --kernel-trace` only, KiB units, FETCH_SIZE doubled on gfx950 — over child runs of this script with
+    eager launches (a replayed graph's dispatches carry no per-kernel counters; the same kernels run in both).  Called BEFORE
+    this process touches the GPU (a GPU-initialised process must not spawn programs on this pool).  -> {family: bytes per
+    launch} or None (no rocprofv3, a failed pass: the caller falls back to the committed collection and says so)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    me = os.path.abspath(__file__)
+    sums = {f: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]} for f in FAMILY_KERNELS}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--",
+                   sys.executable, me, "--no-cpu-baseline", "--no-routes", "--no-traffic", "--no-graphs", "--steps", "3",
+                   "--warmup", "3", "--probe-replays", "0"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, timeout=420)
+            except (OSError, subprocess.TimeoutExpired):
+                return None
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"]
+                for fam, kernels in FAMILY_KERNELS.items():
+                    if any(k in name for k in kernels):
+                        sums[fam][counter][0] += float(row["Counter_Value"])
+                        sums[fam][counter][1] += 1
+    res = {}
+    for fam, c in sums.items():
+        if c["FETCH_SIZE"][1] and c["WRITE_SIZE"][1]:
+            res[fam] = 2.0 * 1024.0 * c["FETCH_SIZE"][0] / c["FETCH_SIZE"][1] + 1024.0 * c["WRITE_SIZE"][0] / c["WRITE_SIZE"][1]
+    return res or None
+
+
 def scale_fields(collective, bucket_bytes, in_graph, rank_ms, rank_comm, samples):
     """What a multi-GPU line carries beyond the single-GPU one, so that a SCALE run is diagnosable: who was slow
     (`ms_per_step_ranks`), how long the gradient exchange took on every rank (`comm_us_per_step`: device wall clock between two
@@ -356,6 +410,10 @@ def main():
         args.no_graphs = True       # the fp32 parity mode runs PyTorch MLPs and the op-by-op losses (host-side assignment): eager only
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)                                        # never returns
+    live_traffic = None
+    if (args.gpus == 1 and not args.no_traffic and not args.no_graphs and args.dtype == "bf16" and args.workload == "global"
+            and int(os.environ.get("WORLD_SIZE", "1")) == 1):
+        live_traffic = measure_traffic()                         # (before this process initialises the GPU)
     import torch
     import torch.distributed as dist
     global BATCH_PER_GPU, N_INSTANCES
@@ -601,9 +659,13 @@ def main():
         import glob
         traffic, traffic_src = None, None
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_family_traffic.json")))
-        if tfiles:
+        if live_traffic and dominant in live_traffic:
+            traffic = live_traffic[dominant]
+            traffic_src = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over "
+                           "eager child runs of bench.py, KiB counters, FETCH_SIZE doubled (gfx950)")
+        elif tfiles:
             traffic = json.load(open(tfiles[-1])).get(dominant, {}).get("hbm_bytes_per_launch")
-            traffic_src = os.path.relpath(tfiles[-1], ROOT)
+            traffic_src = os.path.relpath(tfiles[-1], ROOT) + (" (a tracked collection: the live PMC passes were switched off or failed)")
         # ... and the same family's fraction under rocprofv3 (the profiler stretches short kernels: a few per cent lower), from
         # the newest committed collection, so that the two figures sit in one line
         rocprof_frac, rocprof_src = None, None

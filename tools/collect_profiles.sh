@@ -7,7 +7,7 @@ repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
 mkdir -p gpurun_out/collect
-B="bench.py --no-cpu-baseline --no-routes"
+B="bench.py --no-cpu-baseline --no-routes --no-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/collect/stats -o s -- python3 $B --steps 10 --warmup 5 > gpurun_out/collect/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/fetch -o f -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/write -o w -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/write.log 2>&1
