@@ -64,6 +64,7 @@ class _CopyDesc(__import__("ctypes").Structure):
 _copy_desc_cache = {}
 
 DP_COLLECTIVE = os.environ.get("CPFN_DP_COLLECTIVE", "all_reduce")
+_SIDE_GRAPH_FIRST = os.environ.get("CPFN_SIDE_GRAPH_FIRST", "0") == "1"
 _BUCKET_PAD = 3360            # elements; 4 x lcm(1..8): every world size up to 8 (and 10, 12, 14, 15, 16 ...) gets 16-byte-aligned shards
 
 
@@ -782,12 +783,19 @@ class SPFNTrainer:
                     else:
                         _l.check(h.cpfn_flag_set(flags[0:].data_ptr(), st["n_main"] + 1, cur.cuda_stream), "cpfn_flag_set")
                     # the step's own graph is submitted BEFORE the side stream's launches: from an idle GPU (the first step after
-                    # a synchronisation) the device then waits for one graph launch less (~0.1 ms of host time)
-                    st["g"].replay()                           # the whole step: no host synchronisation
+                    # a synchronisation) the device then waits for one graph launch less (~0.1 ms of host time).
+                    # CPFN_SIDE_GRAPH_FIRST=1 (profiling only): under rocprofv3 a graph launch costs the host > 1 ms, the side
+                    # graph submitted second then trails the step by most of its length, lands on the last backward launches
+                    # (csr_build holds 80 KB of LDS per CU) and on the NEXT step's waiter — per-kernel times of a trace taken that
+                    # way describe the profiler, not the step (profiles/README.md, round 4).
+                    if not _SIDE_GRAPH_FIRST:
+                        st["g"].replay()                       # the whole step: no host synchronisation
                     self._flag_wait(st, 0, st["n_main"] + 1, self._gside)
                     with torch.cuda.stream(self._gside):
                         st["gs"].replay()
                     _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), st["n_side"] + 1, self._gside.cuda_stream), "cpfn_flag_set")
+                    if _SIDE_GRAPH_FIRST:
+                        st["g"].replay()
                 st["n_side"] += 1
                 st["side_pending"] = True
             else:

@@ -8,7 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 cd "$repo"
 mkdir -p gpurun_out/collect
 B="bench.py --no-cpu-baseline --no-routes --no-traffic"
+# (CPFN_SIDE_GRAPH_FIRST=1: under the profiler a graph launch costs the host > 1 ms; with the step's graph submitted first the side
+#  graph trails it by most of a step and the trace describes the profiler — cpfn_amd/training.py, profiles/README.md)
+export CPFN_SIDE_GRAPH_FIRST=1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/collect/stats -o s -- python3 $B --steps 10 --warmup 5 > gpurun_out/collect/stats.log 2>&1
+unset CPFN_SIDE_GRAPH_FIRST
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/fetch -o f -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/collect/write -o w -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/collect/mfma -o m -- python3 $B --steps 3 --warmup 3 --no-graphs > gpurun_out/collect/mfma.log 2>&1
