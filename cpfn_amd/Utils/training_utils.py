@@ -1,9 +1,9 @@
-"""`Utils.training_utils` behind `cpfn_amd.dropin.install(fast_epoch=True)`: `spfn_train_val_epoch` is the replayed-step
-epoch loop of cpfn_amd/epoch.py (same signature and return as Utils/training_utils.py:84-176); EVERY other name —
-`patch_selection_train_val_epoch`, `get_batch_norm_decay`, `update_momentum`, `get_learning_rate` — is the reference's own,
-looked up in the user's checkout (`Utils/training_utils.py` on sys.path), unchanged.
+"""`Utils.training_utils` behind `cpfn_amd.dropin.install(fast_epoch=True)`: `spfn_train_val_epoch` and
+`patch_selection_train_val_epoch` are the replayed-step epoch loops of cpfn_amd/epoch.py (same signatures and returns as
+Utils/training_utils.py:84-176 and :33-82); EVERY other name — `get_batch_norm_decay`, `update_momentum`,
+`get_learning_rate` — is the reference's own, looked up in the user's checkout (`Utils/training_utils.py` on sys.path), unchanged.
 """
-from ..epoch import spfn_train_val_epoch  # noqa: F401
+from ..epoch import patch_selection_train_val_epoch, spfn_train_val_epoch  # noqa: F401
 
 _reference_module = None
 

@@ -17,6 +17,11 @@ What differs is WHEN the host touches the device:
                                                          at the end of the epoch, then the deferred log_loss / update
                                                          calls in their original order and the same `total_loss_` sum
 
+`patch_selection_train_val_epoch` (Utils/training_utils.py:33-82, the loop of training_PatchSelection.py:79-86) is the same
+machinery on `PatchSelectionTrainer`: two tensors per batch (points, per-point labels), one loss (cross-entropy of the two-class
+heat map), one `visualiser.log_loss` per batch, the one-line print of :70 — and the reference's quirk that the module is put in
+training mode whatever `network_mode` says (:50: the validation pass runs on batch statistics and moves the running ones).
+
 `network_mode='val'`: forward + losses under `no_grad` in evaluation mode (running statistics; dropout stays on as in
 pn2_network.py:63), the next batch's geometry prefetched on the side stream; nothing is back-propagated, `global_step` is
 returned unchanged.
@@ -33,6 +38,7 @@ _FIELDS = ((0, "P", _F), (1, "X_gt", _F), (2, "points_per_instance", _F), (3, "I
            (5, "plane_n_gt", _F), (6, "cylinder_axis_gt", _F), (7, "cone_axis_gt", _F))
 _LOCAL_FIELDS = ((8, "glob_features", _F), (9, "loc_features", _F))
 _LOG_NAMES = ("loss", "normal_loss", "type_loss", "miou_loss", "residue_loss", "parameter_loss")
+_PS_FIELDS = ((0, "P", _F), (1, "labels", _L))                 # patch_selection_train_val_epoch, :57-60
 LOG_EVERY = 100                # the reference prints the six losses at every 100th batch (:87, :167-174)
 
 
@@ -98,19 +104,25 @@ class EpochRunner:
     """What persists between two calls of `spfn_train_val_epoch` for one network: the trainer (optimizer state, captured
     graphs), the staging buffers and the loss ring.  Kept on the module as `_cpfn_epoch_runner`."""
 
-    def __init__(self, spfn_module, optimizer, conf, device):
+    def __init__(self, spfn_module, optimizer, conf, device, kind="spfn"):
         g = optimizer.param_groups[0]
         lr0 = g["lr"]
+        self.kind = kind
         self.device = torch.device(device)
         on_gpu = self.device.type == "cuda"
         bf16 = getattr(spfn_module, "compute_dtype", torch.float32) == torch.bfloat16
-        mult = dict(miou=conf.get_miou_loss_multiplier(), normal=conf.get_normal_loss_multiplier(),
-                    type=conf.get_type_loss_multiplier(), parameter=conf.get_parameter_loss_multiplier(),
-                    residue=conf.get_residue_loss_multiplier(), total=conf.get_total_loss_multiplier())
-        self.trainer = _tr.SPFNTrainer(spfn_module, batch_size=conf.get_batch_size(),
-                                       init_learning_rate=conf.get_init_learning_rate(), decay_step=conf.get_decay_step(),
-                                       decay_rate=conf.get_decay_rate(), bn_decay_step=conf.get_bn_decay_step(),
-                                       multipliers=mult, classes=conf.get_list_of_primitives(), use_graphs=on_gpu and bf16)
+        common = dict(batch_size=conf.get_batch_size(), init_learning_rate=conf.get_init_learning_rate(),
+                      decay_step=conf.get_decay_step(), decay_rate=conf.get_decay_rate(), bn_decay_step=conf.get_bn_decay_step(),
+                      use_graphs=on_gpu and bf16)
+        if kind == "patch_selection":
+            self.trainer = _tr.PatchSelectionTrainer(spfn_module, **common)
+            self.n_losses = 1
+        else:
+            mult = dict(miou=conf.get_miou_loss_multiplier(), normal=conf.get_normal_loss_multiplier(),
+                        type=conf.get_type_loss_multiplier(), parameter=conf.get_parameter_loss_multiplier(),
+                        residue=conf.get_residue_loss_multiplier(), total=conf.get_total_loss_multiplier())
+            self.trainer = _tr.SPFNTrainer(spfn_module, multipliers=mult, classes=conf.get_list_of_primitives(), **common)
+            self.n_losses = 6
         self.optimizer = optimizer
         self._adopt_optimizer(optimizer, float(lr0))
         self.staging = _Staging(self.device) if on_gpu else None
@@ -150,6 +162,8 @@ class EpochRunner:
 
     # ---- one epoch ----------------------------------------------------------------------------------------------
     def _fields(self, data, local):
+        if self.kind == "patch_selection":
+            return [(k, data[i], dt) for i, k, dt in _PS_FIELDS]
         f = [(k, data[i], dt) for i, k, dt in _FIELDS]
         m = self.trainer.module
         if local and (getattr(m, "use_glob_features", False) or getattr(m, "use_loc_features", False)):
@@ -164,19 +178,20 @@ class EpochRunner:
             return None, {k: t.to(dt) for k, t, dt in f}
         return self.staging.put(f)
 
-    @staticmethod
-    def _loss_vector(out):
-        """The step's six scalars as one [6] tensor.  The fused loss tail writes them side by side in one buffer: then this
-        is a view (no launch); otherwise (op-by-op losses) they are stacked."""
+    def _loss_vector(self, out):
+        """The step's loss scalars as one [6] tensor (unused entries stay zero).  The fused loss tail writes the six side by
+        side in one buffer: then this is a view (no launch); otherwise (op-by-op losses, one-loss objectives) they are stacked."""
         o0 = out[0]
-        try:
-            base = o0.untyped_storage().data_ptr()
-            if all(o.dtype == torch.float32 and o.dim() == 0 and o.untyped_storage().data_ptr() == base and
-                   o.storage_offset() == o0.storage_offset() + i for i, o in enumerate(out[:6])):
-                return torch.as_strided(o0.detach(), (6,), (1,))
-        except RuntimeError:
-            pass
-        return torch.stack([o.detach().reshape(()).float() for o in out[:6]])
+        if len(out) >= 6:
+            try:
+                base = o0.untyped_storage().data_ptr()
+                if all(o.dtype == torch.float32 and o.dim() == 0 and o.untyped_storage().data_ptr() == base and
+                       o.storage_offset() == o0.storage_offset() + i for i, o in enumerate(out[:6])):
+                    return torch.as_strided(o0.detach(), (6,), (1,))
+            except RuntimeError:
+                pass
+        v = [o.detach().reshape(()).float() for o in out[:6]]
+        return torch.stack(v + [torch.zeros_like(v[0])] * (6 - len(v)))
 
     def run(self, dataloader, epoch, global_step, visualiser, args, network_mode):
         tr, mod = self.trainer, self.trainer.module
@@ -188,7 +203,9 @@ class EpochRunner:
         tr.global_step = int(global_step)
         tr._bn_momentum = _tr.get_batch_norm_decay(global_step, B_full, tr.bn_decay_step)
         tr._lr = _tr.get_learning_rate(tr.init_learning_rate, global_step, B_full, tr.decay_step, tr.decay_rate)
-        mod.train() if train else mod.eval()
+        ps = self.kind == "patch_selection"
+        # (patch_selection_train_val_epoch puts the module in training mode whatever the mode says, :45-50)
+        mod.train() if (train or ps) else mod.eval()
         total, pending, sizes = 0.0, 0, []
         on_gpu = self.staging is not None
 
@@ -204,9 +221,9 @@ class EpochRunner:
                 _ops.check_fps_faults("this point of the epoch")
             rows = self.ring_host[:pending].tolist()
             for b, row in zip(sizes, rows):
-                total += b * row[0]                                                   # (:147)
-                for v, name in zip(row, _LOG_NAMES):
-                    visualiser.log_loss(v, '%s_%s' % (network_mode, name))          # (:176-181)
+                total += b * row[0]                                                   # (:147; :69)
+                for v, name in zip(row[:self.n_losses], _LOG_NAMES):
+                    visualiser.log_loss(v, '%s_%s' % (network_mode, name))          # (:176-181; :80)
                 visualiser.update()
             pending = 0
             del sizes[:]
@@ -219,7 +236,7 @@ class EpochRunner:
             batch_id = 0
             while cur is not None:
                 nxt = self._stage(next(it, None), local)
-                if batch_id % LOG_EVERY == 0:
+                if batch_id % LOG_EVERY == 0 and not ps:
                     print('[%s][Epoch %d - Iteration %d]' % (network_mode, epoch, batch_id))
                 slot, batch = cur
                 if on_gpu:
@@ -248,7 +265,9 @@ class EpochRunner:
                     self.staging.consumed(slot, torch.cuda.current_stream(self.device))
                 if batch_id % LOG_EVERY == 0 or pending >= LOG_EVERY:
                     row = flush()
-                    if batch_id % LOG_EVERY == 0:
+                    if batch_id % LOG_EVERY == 0 and ps:
+                        print('[%s][Epoch %d - Iteration %d] Loss: %f' % (network_mode, epoch, batch_id, row[0]))      # (:70)
+                    elif batch_id % LOG_EVERY == 0:
                         for label, v in zip(('Loss Value: ', 'Normal Loss', 'Type Loss', 'mIoU Loss', 'Residue Loss',
                                              'Parameter Loss'), row):
                             print(label, v)
@@ -266,24 +285,37 @@ class _Null:
         return False
 
 
-def spfn_train_val_epoch(dataloader, spfn_module, epoch, optimizer, global_step, visualiser, args, conf, device,
-                         network_mode='train'):
-    """Drop-in for Utils/training_utils.py:84-176 (see the module docstring).  `optimizer` must be the
-    `torch.optim.Adam` over `spfn_module.parameters()` that training_SPFN.py:90 builds; anything else runs the
-    reference's own loop."""
+def _epoch(kind, ref_name, dataloader, module, epoch, optimizer, global_step, visualiser, args, conf, device, network_mode):
     assert network_mode in ['train', 'val']
-    runner = spfn_module.__dict__.get("_cpfn_epoch_runner")
-    if runner is None or runner.optimizer is not optimizer:
+    runner = module.__dict__.get("_cpfn_epoch_runner")
+    if runner is None or runner.optimizer is not optimizer or runner.kind != kind:
         if not isinstance(optimizer, torch.optim.Adam) or len(optimizer.param_groups) != 1 or \
                 optimizer.param_groups[0].get("amsgrad") or optimizer.param_groups[0].get("maximize"):
             from .Utils import training_utils as _tu
             warnings.warn("cpfn_amd: the fast epoch loop takes a plain torch.optim.Adam with one parameter group; running "
                           "the reference's own loop with this optimizer")
-            return _tu._load_reference_module().spfn_train_val_epoch(dataloader, spfn_module, epoch, optimizer, global_step,
-                                                                     visualiser, args, conf, device, network_mode)
-        runner = EpochRunner(spfn_module, optimizer, conf, device)
-        spfn_module.__dict__["_cpfn_epoch_runner"] = runner
+            return getattr(_tu._load_reference_module(), ref_name)(dataloader, module, epoch, optimizer, global_step, visualiser,
+                                                                  args, conf, device, network_mode)
+        runner = EpochRunner(module, optimizer, conf, device, kind)
+        module.__dict__["_cpfn_epoch_runner"] = runner
     if network_mode == 'val':
         with torch.no_grad():
             return runner.run(dataloader, epoch, global_step, visualiser, args, network_mode)
     return runner.run(dataloader, epoch, global_step, visualiser, args, network_mode)
+
+
+def spfn_train_val_epoch(dataloader, spfn_module, epoch, optimizer, global_step, visualiser, args, conf, device,
+                         network_mode='train'):
+    """Drop-in for Utils/training_utils.py:84-176 (see the module docstring).  `optimizer` must be the
+    `torch.optim.Adam` over `spfn_module.parameters()` that training_SPFN.py:90 builds; anything else runs the
+    reference's own loop."""
+    return _epoch("spfn", "spfn_train_val_epoch", dataloader, spfn_module, epoch, optimizer, global_step, visualiser, args, conf,
+                  device, network_mode)
+
+
+def patch_selection_train_val_epoch(dataloader, patchselec_module, epoch, optimizer, global_step, visualiser, args, conf, device,
+                                    network_mode='train'):
+    """Drop-in for Utils/training_utils.py:33-82 (training_PatchSelection.py:79-86): same arguments, return, print and
+    visualiser calls, on the replayed step of `PatchSelectionTrainer`."""
+    return _epoch("patch_selection", "patch_selection_train_val_epoch", dataloader, patchselec_module, epoch, optimizer,
+                  global_step, visualiser, args, conf, device, network_mode)

@@ -385,6 +385,23 @@ class SPFNTrainer:
             out = self.losses(batch, geometry=geom)
         return tuple(o.detach() for o in out)
 
+    def _single_graph(self, K):
+        """Can the step be ONE graph?  (SPFN: the assignment on the device, at most 32 instance columns.)"""
+        from .SPFN import fused_losses as fl
+        return not fl.HOST_ASSIGNMENT and K <= 32
+
+    def _graph_losses(self, sb, st):
+        """The loss section inside the captured step, after the network's forward pass on the static batch `sb`: heads
+        post-processing + segmented sums -> assignment + fits -> matched losses (everything capturable, nothing on the host).
+        Returns the tuple whose first entry is back-propagated.  Other objectives on the same network (PatchSelectionTrainer)
+        override this and `losses`."""
+        from .SPFN import fused_losses as fl
+        Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb, getattr(self.module, "handover", None))
+        n_gt = fl.count_gt(sb["I_gt"])
+        params, st["match"] = fl.fit_params_and_match(sb["P"], W, Xn, self.mult, S, n_gt)
+        with fl.unit_loss_gradient():
+            return fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
+
     # ---- hipGraph replay of the step -----------------------------------------------------------
     # At 16 clouds per GPU the step is ~150 launches and host-bound when launched one by one.  With the
     # assignment solved on the device (cpfn_hungarian_match) nothing in the step needs the host, so it is
@@ -528,7 +545,7 @@ class SPFNTrainer:
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         dev = batch["P"].device
         B, N, _ = batch["P"].shape
-        K = batch["T_gt"].shape[1]
+        K = batch["T_gt"].shape[1] if "T_gt" in batch else 0
         st = {"batch": {k: v.clone() for k, v in batch.items()},
               "P_next": batch["P"].clone(),
               "start_dev": torch.zeros(2, B, dtype=torch.int32, device=dev),
@@ -580,7 +597,7 @@ class SPFNTrainer:
         with torch.cuda.graph(g0, stream=self._gstream, capture_error_mode="thread_local"):
             geometry_into_B(sb["P"], beside=False)
         st["world"], st["g0"] = world, g0
-        st["single"] = not fl.HOST_ASSIGNMENT and K <= 32
+        st["single"] = self._single_graph(K)
         if st["single"]:
             # Device-side assignment (cpfn_hungarian_match): the step has no host round trip and is ONE linear graph; the
             # geometry of the NEXT batch is a second linear graph, replayed on the side stream while the step's graph runs
@@ -629,11 +646,7 @@ class SPFNTrainer:
                 stamp(0)
                 self.bucket.zero()
                 self.module(sb["P"], geometry=st["geomA"], **self._feature_kwargs(sb))
-                Xn, W, nl, tl, S = fl.pre_match(self.module.heads_packed, sb, getattr(self.module, "handover", None))
-                n_gt = fl.count_gt(sb["I_gt"])
-                params, st["match"] = fl.fit_params_and_match(sb["P"], W, Xn, self.mult, S, n_gt)
-                with fl.unit_loss_gradient():
-                    out = fl.post_match(sb["P"], Xn, W, nl, tl, S, st["match"], sb, self.mult, self.classes, n_gt, params)
+                out = self._graph_losses(sb, st)
                 out[0].backward(st["unit"])              # (no ones_like fill inside the graph)
                 nf = self.bucket.collect(check=world == 1, fault=st["flag_fault"] if world > 1 else None)
                 if world == 1:
@@ -878,7 +891,7 @@ class SPFNTrainer:
         if not self._all_training():
             self.module.train()
         self._schedules()
-        if self.use_graphs and batch["T_gt"].shape[1] > 32:
+        if self.use_graphs and "T_gt" in batch and batch["T_gt"].shape[1] > 32:
             # the fused loss kernels (and with them the captured step) take at most 32 instance columns; wider label
             # sets run eagerly on the op-by-op losses (HIP fitters, stock reductions)
             if self.require_graphs:
@@ -960,10 +973,43 @@ class SPFNTrainer:
 
 
 
+
+class PatchSelectionTrainer(SPFNTrainer):
+    """The same step machinery for the OTHER objective trained on this network: PatchSelection
+    (`PointNet2(output_sizes=[2])`, training_PatchSelection.py:55) — the two-class heat map with a cross-entropy against
+    per-point labels (`patch_selection_train_val_epoch`, Utils/training_utils.py:62-75).  batch = {"P": [B,N,3] fp32,
+    "labels": [B,N] int64}; `step` / `eval_losses` return a 1-tuple (the loss).  The loss itself is two stock kernels
+    (log-soft-max + NLL over [B*N, 2]) inside the replayed graph; forward, backward, geometry look-ahead, gradient bucket and
+    Adam are the SPFN trainer's.  Unlike the reference's loop (which steps unconditionally, :72-74) a step with non-finite
+    gradients is skipped on the device."""
+
+    def _single_graph(self, K):
+        return True
+
+    def _cross_entropy(self, batch):
+        heat = self._heat
+        B, N, _ = heat.shape
+        return torch.nn.functional.cross_entropy(heat.contiguous().view(B * N, 2), batch["labels"].view(B * N))    # (:66-68)
+
+    def losses(self, batch, fps_start=None, geometry=False):
+        P = batch["P"]
+        if geometry is False:
+            geometry = self._take_prefetched(P) if fps_start is None else None
+        kw = {"geometry": geometry} if geometry is not None else {}
+        self._heat = self.module(P, fps_start=fps_start, **kw)[0]
+        return (self._cross_entropy(batch),)
+
+    def _graph_losses(self, sb, st):
+        self._heat = self.module.heads_packed if self.module.heads_packed is not None else None
+        if self._heat is None or self._heat.shape[2] != 2:
+            raise RuntimeError("PatchSelectionTrainer: a PointNet2(output_sizes=[2]) in the bf16 compute mode is expected")
+        return (self._cross_entropy(sb),)
+
+
 def __getattr__(name):
     # the reference's epoch loop on this trainer (same signature as Utils/training_utils.py:84-176) lives in cpfn_amd/epoch.py,
     # which imports this module: resolved on first use
-    if name in ("spfn_train_val_epoch", "EpochRunner"):
+    if name in ("spfn_train_val_epoch", "patch_selection_train_val_epoch", "EpochRunner"):
         from . import epoch
         return getattr(epoch, name)
     raise AttributeError("module %r has no attribute %r" % (__name__, name))

@@ -178,8 +178,10 @@ def test_other_optimizers_fall_back_to_the_reference_loop(tmp_path):
         sgd = torch.optim.SGD(model.parameters(), lr=0.1)
         with pytest.warns(UserWarning, match="plain torch.optim.Adam"):
             assert training.spfn_train_val_epoch([], model, 0, sgd, 0, Visualiser(), Args(), Conf(), 'cpu') == 'the reference loop'
-        assert tu.patch_selection_train_val_epoch() == 'patch selection of the reference'
-        assert tu.spfn_train_val_epoch.__module__ == "cpfn_amd.epoch"
+        with pytest.warns(UserWarning, match="plain torch.optim.Adam"):
+            assert training.patch_selection_train_val_epoch([], model, 0, sgd, 0, Visualiser(), Args(), Conf(), 'cpu') == \
+                'patch selection of the reference'
+        assert tu.spfn_train_val_epoch.__module__ == tu.patch_selection_train_val_epoch.__module__ == "cpfn_amd.epoch"
     finally:
         sys.path.remove(str(tmp_path))
         tu._reference_module = None
@@ -203,8 +205,8 @@ def test_fast_epoch_dropin_against_the_reference_s_own_function():
         assert training_utils.spfn_train_val_epoch.__module__ == "cpfn_amd.epoch"
         ref = tu._load_reference_module()
         assert os.path.samefile(ref.__file__, os.path.join(REF, "Utils", "training_utils.py"))
-        assert training_utils.patch_selection_train_val_epoch is ref.patch_selection_train_val_epoch
-        assert training_utils.get_batch_norm_decay is ref.get_batch_norm_decay
+        assert training_utils.patch_selection_train_val_epoch.__module__ == "cpfn_amd.epoch"
+        assert training_utils.get_batch_norm_decay is ref.get_batch_norm_decay and training_utils.update_momentum is ref.update_momentum
         ours = _run(lambda dl, m, e, o, g, v, c, mode: training_utils.spfn_train_val_epoch(dl, m, e, o, g, v, Args(), c, 'cpu', network_mode=mode))
         theirs = _run(lambda dl, m, e, o, g, v, c, mode: ref.spfn_train_val_epoch(dl, m, e, o, g, v, Args(), c, torch.device('cpu'), network_mode=mode))
         _assert_same(ours, theirs)
@@ -218,3 +220,116 @@ def test_fast_epoch_dropin_against_the_reference_s_own_function():
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
+
+
+# ---- the PatchSelection loop (Utils/training_utils.py:33-82) ----------------------------------------------------------------
+class TinyHeat(torch.nn.Module):
+    """PointNet2(output_sizes=[2])'s forward contract: points [B,N,3] -> [heat-map logits [B,N,2], l3, features]."""
+
+    def __init__(self):
+        super().__init__()
+        self.body = torch.nn.Linear(3, 16)
+        self.bn = torch.nn.BatchNorm1d(16)
+        self.head = torch.nn.Linear(16, 2)
+
+    def forward(self, P, glob_features=None, loc_features=None, fps_start=None, geometry=None):
+        B, N, _ = P.shape
+        f = torch.tanh(self.bn(self.body(P).reshape(B * N, -1))).reshape(B, N, -1)
+        return [self.head(f), None, None]
+
+
+def _ps_loader(n_batches, ragged=True):
+    out = []
+    for i in range(n_batches):
+        b = synthetic.training_batch(2 if not (ragged and i == n_batches - 1) else 1, N=128, n_max_instances=21, n_prims=4,
+                                     n_inst_points=8, seed=70 + i)
+        out.append((b["P"].double(), (b["I_gt"] % 2).int(), torch.arange(128)))          # (points, labels, shuffled indices)
+    return out
+
+
+def _restated_patch_selection_loop(loader, model, epoch, optimizer, global_step, vis, conf, mode):
+    """The sequence of Utils/training_utils.py:33-82 stated plainly (incl. its quirk: training mode in every mode, :45-50)."""
+    from cpfn_amd import training as tr
+    bs = conf.get_batch_size()
+    old_m = tr.get_batch_norm_decay(global_step, bs, conf.get_bn_decay_step())
+    old_lr = tr.get_learning_rate(conf.get_init_learning_rate(), global_step, bs, conf.get_decay_step(), conf.get_decay_rate())
+    total = 0
+    model.train()
+    for i, d in enumerate(loader):
+        optimizer.zero_grad()
+        m = tr.get_batch_norm_decay(global_step, bs, conf.get_bn_decay_step())
+        if m != old_m:
+            tr.update_momentum(model, m)
+            old_m = m
+        lr = tr.get_learning_rate(conf.get_init_learning_rate(), global_step, bs, conf.get_decay_step(), conf.get_decay_rate())
+        if lr != old_lr:
+            for g in optimizer.param_groups:
+                g['lr'] = lr
+            old_lr = lr
+        pts, lab = d[0].float(), d[1].long()
+        B, N, _ = pts.shape
+        loss = torch.nn.functional.cross_entropy(model(pts)[0].contiguous().view(B * N, 2), lab.view(B * N))
+        total += B * loss.item()
+        if i % 100 == 0:
+            print('[%s][Epoch %d - Iteration %d] Loss: %f' % (mode, epoch, i, loss.item()))
+        if mode == 'train':
+            loss.backward()
+            optimizer.step()
+            global_step += 1
+        vis.log_loss(loss.item(), '%s_loss' % mode)
+        vis.update()
+    return global_step, total
+
+
+def _run_ps(fn, epochs=2):
+    torch.manual_seed(3)
+    model = TinyHeat()
+    conf = Conf()
+    opt = torch.optim.Adam(model.parameters(), lr=conf.get_init_learning_rate())
+    vis = Visualiser()
+    gs, log, buf = 0, [], io.StringIO()
+    with redirect_stdout(buf):
+        for e in range(epochs):
+            gs, tot = fn(_ps_loader(5), model, e, opt, gs, vis, conf, 'train')
+            log.append((gs, tot))
+            with torch.no_grad():
+                log.append(fn(_ps_loader(3, ragged=False), model, e, opt, gs, vis, conf, 'val'))
+    return model, opt, vis, log, buf.getvalue()
+
+
+def _assert_same_ps(a, b):
+    (ma, oa, va, la, pa), (mb, ob, vb, lb, pb) = a, b
+    assert [g for g, _ in la] == [g for g, _ in lb] and la == pytest.approx(lb, rel=1e-6)
+    assert [c[0] for c in va.calls] == [c[0] for c in vb.calls]
+    assert [c[1] for c in va.calls if len(c) > 1] == pytest.approx([c[1] for c in vb.calls if len(c) > 1], rel=1e-5)
+    la_, lb_ = pa.splitlines(), pb.splitlines()
+    assert len(la_) == len(lb_) == 4 and [l.rsplit(' ', 1)[0] for l in la_] == [l.rsplit(' ', 1)[0] for l in lb_]
+    assert [float(l.rsplit(' ', 1)[1]) for l in la_] == pytest.approx([float(l.rsplit(' ', 1)[1]) for l in lb_], rel=1e-4)
+    for (k, x), (_, y) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-7, msg=k)        # incl. the running statistics the val pass moved
+    assert ma.training and mb.training                                        # (:50: training mode even after a 'val' call)
+
+
+def test_patch_selection_epoch_loop_matches_the_reference_s_sequence():
+    from cpfn_amd import training
+    fast = lambda dl, m, e, o, g, v, c, mode: training.patch_selection_train_val_epoch(dl, m, e, o, g, v, Args(), c, 'cpu', network_mode=mode)
+    a = _run_ps(fast)
+    b = _run_ps(_restated_patch_selection_loop)
+    _assert_same_ps(a, b)
+    assert a[3][0][0] == 5 and a[3][1][0] == 5 and a[3][2][0] == 10
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="build container only: needs the reference checkout")
+def test_patch_selection_epoch_against_the_reference_s_own_function():
+    import cpfn_amd.Utils.training_utils as tu
+    from cpfn_amd import training
+    sys.path.insert(0, REF)
+    tu._reference_module = None
+    try:
+        ref = tu._load_reference_module()
+        ours = _run_ps(lambda dl, m, e, o, g, v, c, mode: training.patch_selection_train_val_epoch(dl, m, e, o, g, v, Args(), c, 'cpu', network_mode=mode))
+        theirs = _run_ps(lambda dl, m, e, o, g, v, c, mode: ref.patch_selection_train_val_epoch(dl, m, e, o, g, v, Args(), c, torch.device('cpu'), network_mode=mode))
+        _assert_same_ps(ours, theirs)
+    finally:
+        sys.path.remove(REF)
+        tu._reference_module = None

@@ -162,3 +162,83 @@ def test_epoch_function_fp32_model_runs_eagerly():
         gs, tot = training.spfn_train_val_epoch(_as_loader(_host_batches(3, 500, False)), model, 0, opt, 0, vis, Args(), Conf(), dev)
     assert gs == 3 and tot == tot and tot > 0
     assert model.__dict__["_cpfn_epoch_runner"].trainer._graph is None
+
+
+# ---- PatchSelection (Utils/training_utils.py:33-82; training_PatchSelection.py:79-86) ----------------------------------------------
+class PsConf(Conf):
+    def get_bn_decay_step(self): return 24          # momentum 0.5 -> 0.25 at step 6
+    def get_decay_step(self): return 16             # learning rate x 0.7 at step 4
+
+
+def _ps_batches(n, seed0, ragged_last):
+    out = []
+    for i in range(n):
+        c = synthetic.primitive_cloud(B // 2 if (ragged_last and i == n - 1) else B, N, n_prims=6, seed=seed0 + i)
+        out.append({"P": c["P"], "labels": (c["I_gt"] % 2).long()})
+    return out
+
+
+def _ps_model(dev):
+    from cpfn_amd.PointNet2 import pn2_network
+    torch.manual_seed(0)
+    m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2]).to(dev)
+    m.set_compute_dtype(torch.bfloat16)
+    return m
+
+
+def test_patch_selection_epoch_equals_trainer_steps_by_hand():
+    """`patch_selection_train_val_epoch` (the reference's signature) on the replayed PatchSelectionTrainer step against the same
+    trainer driven by hand on device-resident batches: every loss and every weight bit for bit, through a re-capture (momentum
+    change) and the ragged last batch; the validation call runs in TRAINING mode like the reference's (:45-50) and moves the
+    running statistics; the training reduces the loss."""
+    from cpfn_amd import training
+    dev = torch.device("cuda:0")
+    conf = PsConf()
+    train_b, val_b = _ps_batches(10, 600, True), _ps_batches(2, 700, False)
+    model = _ps_model(dev)
+    tr = training.PatchSelectionTrainer(model, batch_size=B, init_learning_rate=conf.get_init_learning_rate(),
+                                        decay_step=conf.get_decay_step(), decay_rate=conf.get_decay_rate(),
+                                        bn_decay_step=conf.get_bn_decay_step(), use_graphs=True)
+    tb = [{k: v.to(dev) for k, v in b.items()} for b in train_b]
+    vb = [{k: v.to(dev) for k, v in b.items()} for b in val_b]
+    torch.manual_seed(78)
+    hand = []
+    with torch.cuda.stream(tr.stream(dev)):
+        model.train()
+        for i, b in enumerate(tb):
+            ragged = b["P"].shape[0] != B
+            nxt = tb[i + 1] if i + 1 < len(tb) and tb[i + 1]["P"].shape == b["P"].shape and not ragged else None
+            hand.append(float(tr.step(b, next_batch=nxt, force_eager=ragged)[0]))
+        assert tr._graph is not None and tr._graph["single"]
+        rm_before = model.bn1.running_mean.clone()
+        for i, b in enumerate(vb):
+            hand.append(float(tr.eval_losses(b, next_batch=vb[i + 1] if i + 1 < len(vb) else None)[0]))
+        assert not torch.equal(model.bn1.running_mean, rm_before)            # the "validation" pass ran on batch statistics
+    torch.cuda.synchronize()
+    w_hand = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    assert tr.skipped_steps == 0 and hand[8] < 0.9 * hand[0], hand
+
+    model2 = _ps_model(dev)
+    opt = torch.optim.Adam(model2.parameters(), lr=conf.get_init_learning_rate())
+    vis = Visualiser()
+    torch.manual_seed(78)
+    loader = lambda bs: [(b["P"].clone().pin_memory() if i % 2 else b["P"].double(), b["labels"].int() if i % 3 == 0 else b["labels"],
+                          torch.arange(N)) for i, b in enumerate(bs)]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        gs, tot = training.patch_selection_train_val_epoch(loader(train_b), model2, 0, opt, 0, vis, Args(), conf, dev, network_mode='train')
+        with torch.no_grad():
+            gs2, tot_v = training.patch_selection_train_val_epoch(loader(val_b), model2, 0, opt, gs, vis, Args(), conf, dev, network_mode='val')
+    torch.cuda.synchronize()
+    assert gs == len(train_b) and gs2 == gs and model2.training
+    logged = [c for c in vis.calls if len(c) > 1]
+    assert [n for n, _ in logged] == ['train_loss'] * len(train_b) + ['val_loss'] * len(val_b)
+    assert [v for _, v in logged] == hand
+    sizes = [b["P"].shape[0] for b in train_b]
+    assert tot == pytest.approx(sum(s * l for s, l in zip(sizes, hand)), rel=1e-12)
+    assert tot_v == pytest.approx(sum(B * l for l in hand[len(train_b):]), rel=1e-12)
+    for k, v in model2.state_dict().items():
+        assert torch.equal(v, w_hand[k]), k
+    lines = buf.getvalue().splitlines()
+    assert lines[0].startswith("[train][Epoch 0 - Iteration 0] Loss: ") and lines[-1].startswith("[val][Epoch 0 - Iteration 0] Loss: ")
+    assert model2.bn1.momentum == 0.25 and opt.param_groups[0]['lr'] == pytest.approx(1e-3 * 0.7 ** 2)
