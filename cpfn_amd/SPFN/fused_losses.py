@@ -221,6 +221,47 @@ class LossTail(torch.autograd.Function):
                 f[nS + nR + B:], None, None, None)
 
 
+class HeatCrossEntropy(torch.autograd.Function):
+    """The PatchSelection objective (Utils/training_utils.py:66-68): mean two-class cross-entropy of the heat-map logits
+    Y [B,N,2] (the packed fp32 heads) against labels [B,N], with d loss / d Y formed in the same launch (cpfn_ce2) and, for the
+    heads' backward, its padded bf16 rows / column sums handed over like HeadPost does."""
+
+    @staticmethod
+    def forward(ctx, Y, labels, handover=None):
+        B, N, C = Y.shape
+        if C != 2:
+            raise RuntimeError("HeatCrossEntropy: two-class logits expected")
+        Yc = Y.detach().contiguous().float()
+        lab = labels.contiguous().long()
+        P = B * N
+        dev = Y.device
+        h = _l.lib()
+        ws = torch.empty(h.cpfn_ce2_blocks(P), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dY = torch.empty_like(Yc)
+        gb = csp = None
+        if HEADS_HINT and handover is not None and P % 256 == 0:
+            gb = torch.empty(P, 64, dtype=torch.bfloat16, device=dev)
+            csp = torch.empty((P // 256) * 2, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _l.check(h.cpfn_ce2(_ptr(Yc), _ptr(lab), P, _ptr(ws), _ptr(loss), _ptr(dY), _ptr(gb), _ptr(csp), _stream()), "cpfn_ce2")
+        _l.add_bytes("cpfn_ce2", 4 * P * 4 + 8 * P + (128 * P if gb is not None else 0))
+        ctx.save_for_backward(dY)
+        ctx.hint = (handover, P, gb, csp)
+        ctx.unit_grad = LossTail.unit_grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dY,) = ctx.saved_tensors
+        ho, P, gb, csp = ctx.hint
+        if not ctx.unit_grad:                 # (a caller that scales the loss: the hint describes the unscaled gradient)
+            return dY * g, None, None
+        if ho is not None and gb is not None:
+            ho.heads_hint = (dY.data_ptr(), dY._version, P, 2, gb, csp)
+        return dY, None, None
+
+
 class unit_loss_gradient:
     """Context manager for a trainer that back-propagates the plain total (`total.backward()`): LossTail then
     hands its stored gradients on as they are instead of multiplying them by the incoming 1.0."""

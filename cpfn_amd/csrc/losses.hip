@@ -738,6 +738,63 @@ __global__ __launch_bounds__(256) void loss_tail_kernel(const float *__restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------ two-class cross-entropy (PatchSelection)
+// loss = mean_p (logsumexp(y_p) - y_p[label_p]) over P rows of two logits — F.cross_entropy of
+// patch_selection_train_val_epoch (Utils/training_utils.py:66-68) — and, in the same pass, d loss / d y = (softmax - onehot) / P.
+// As stock ops this was ~8 launches around a [131072, 2] tensor, among them torch's one-workgroup mean reduction: ~200 us of a
+// 1.6 ms step.  Like cpfn_head_post_bwd the pass also leaves what the heads' backward makes of that gradient first: the rows as
+// zero-padded bf16 [P, 64] and the per-256-row column sums in colsum_f32_kernel's order (bit-identical to that launch).
+__global__ __launch_bounds__(256) void ce2_kernel(const float *__restrict__ logits, const long long *__restrict__ labels,
+                                                  long long P, float inv_P, float *__restrict__ partial,
+                                                  float *__restrict__ dlogits, unsigned short *__restrict__ pad_bf16,
+                                                  float *__restrict__ colsum_partial) {
+  __shared__ float s_g[256][2];
+  __shared__ float s_l[4], s_cs[4][2];
+  const int t = threadIdx.x;
+  const long long p0 = (long long)blockIdx.x * 256, row = p0 + t;
+  const int rows = (int)min(256ll, P - p0);
+  float li = 0.f, g0 = 0.f, g1 = 0.f;
+  if (t < rows) {
+    const float2 y = ((const float2 *)logits)[row];
+    const bool one = labels[row] != 0;
+    const float m = fmaxf(y.x, y.y), e0 = expf(y.x - m), e1 = expf(y.y - m), sum = e0 + e1;
+    li = (m + logf(sum)) - (one ? y.y : y.x);
+    g0 = (e0 / sum - (one ? 0.f : 1.f)) * inv_P;
+    g1 = (e1 / sum - (one ? 1.f : 0.f)) * inv_P;
+    ((float2 *)dlogits)[row] = (float2){g0, g1};
+  }
+  s_g[t][0] = g0; s_g[t][1] = g1;
+  for (int msk = 32; msk >= 1; msk >>= 1) li += __shfl_xor(li, msk, 64);
+  if ((t & 63) == 0) s_l[t >> 6] = li;
+  __syncthreads();
+  if (t == 0) partial[blockIdx.x] = ((s_l[0] + s_l[1]) + s_l[2]) + s_l[3];
+  if (pad_bf16)
+    for (int e = t; e < rows * 8; e += 256) {
+      const int r = e >> 3;
+      unsigned w0 = 0u;
+      if ((e & 7) == 0)
+        w0 = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)s_g[r][0]) |
+             ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)s_g[r][1]) << 16);
+      *(uint4 *)(pad_bf16 + (p0 + r) * 64 + (e & 7) * 8) = (uint4){w0, 0u, 0u, 0u};
+    }
+  if (colsum_partial) {
+    const int c = t & 63, rs = t >> 6;
+    if (c < 2) {
+      float a = 0.f;
+      for (int r = rs; r < rows; r += 4) a += s_g[r][c];
+      s_cs[rs][c] = a;
+    }
+    __syncthreads();
+    if (t < 2) colsum_partial[(size_t)blockIdx.x * 2 + t] = ((s_cs[0][t] + s_cs[1][t]) + s_cs[2][t]) + s_cs[3][t];
+  }
+}
+
+__global__ void ce2_finish_kernel(const float *__restrict__ partial, int nblk, float inv_P, float *__restrict__ loss) {
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += (double)partial[i];
+  *loss = (float)(s * (double)inv_P);
+}
+
 }  // namespace
 
 extern "C" int cpfn_head_post_chunks(int N) { return cpfn_cdiv(N, LP_THREADS); }
@@ -854,5 +911,21 @@ extern "C" int cpfn_p_coverage(const float *P, const float *params22, const int6
   p_coverage_kernel<<<dim3(chunks, B), 256, 0, st>>>(P, params22, (const long long *)match, (const long long *)slot_type, N, K,
                                                      type_ids[0], type_ids[1], type_ids[2], pe, n_eps, workspace);
   p_coverage_reduce_kernel<<<cpfn_cdiv(B * n_eps, 64), 64, 0, st>>>(workspace, chunks, n_eps, N, B * n_eps, out);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_ce2_blocks(long long P) { return P > 0 ? (int)((P + 255) / 256) : 0; }
+
+extern "C" int cpfn_ce2(const float *logits, const int64_t *labels, long long P, float *workspace, float *loss, float *dlogits,
+                        void *pad_bf16, float *colsum_partial, void *stream) {
+  if (P <= 0 || P > 2000000000LL || !logits || !labels || !workspace || !loss || !dlogits || (!pad_bf16 != !colsum_partial) ||
+      (pad_bf16 && P % 256))
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = cpfn_ce2_blocks(P);
+  const float inv_P = 1.0f / (float)P;
+  ce2_kernel<<<nblk, 256, 0, st>>>(logits, (const long long *)labels, P, inv_P, workspace, dlogits, (unsigned short *)pad_bf16,
+                                   colsum_partial);
+  ce2_finish_kernel<<<1, 1, 0, st>>>(workspace, nblk, inv_P, loss);
   return cpfn_launch_status();
 }

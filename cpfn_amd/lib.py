@@ -71,6 +71,8 @@ SIGNATURES = {
     "cpfn_nonfinite_partial": [_vp, _ll, _vp, _vp],
     "cpfn_hungarian_match": [_vp, _vp, _i, _i, _vp, _vp],
     "cpfn_p_coverage": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "cpfn_ce2_blocks": [_ll],
+    "cpfn_ce2": [_vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_metrics_workspace": [_i, _i, _i, _i],
     "cpfn_metrics_points": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_metrics_tail": [_vp] * 10 + [_i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],

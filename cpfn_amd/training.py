@@ -989,6 +989,13 @@ class PatchSelectionTrainer(SPFNTrainer):
     def _cross_entropy(self, batch):
         heat = self._heat
         B, N, _ = heat.shape
+        packed = getattr(self.module, "heads_packed", None)
+        if heat.is_cuda and packed is not None and packed.shape[2] == 2:
+            # the fused pass (cpfn_ce2): loss, its gradient and the heads' padded gradient rows / column sums in one launch,
+            # instead of ~8 stock kernels around a [B*N, 2] tensor (torch's mean reduction alone is one workgroup)
+            from .SPFN import fused_losses as fl
+            with fl.unit_loss_gradient():
+                return fl.HeatCrossEntropy.apply(packed, batch["labels"], getattr(self.module, "handover", None))
         return torch.nn.functional.cross_entropy(heat.contiguous().view(B * N, 2), batch["labels"].view(B * N))    # (:66-68)
 
     def losses(self, batch, fps_start=None, geometry=False):

@@ -532,6 +532,14 @@ CPFN_API int cpfn_head_post_bwd(const float *Y, const float *Xgt, const int64_t 
                                 const float *Wsm, const float *stats, const float *gXn, const float *gW,
                                 const float *gloss, int gloss_planar, int B, int N, int K, float *gY, const float *gS, void *pad_bf16, float *colsum_partial,
                                 void *stream);
+/* The PatchSelection objective (Utils/training_utils.py:66-68: F.cross_entropy of the [B*N, 2] heat-map logits against
+ * per-point labels, mean reduction) and its gradient in one pass: logits[P,2] fp32, labels[P] int64 (0 / non-zero) ->
+ * loss[1] = mean_p (logsumexp - logit of the label), dlogits[P,2] = (softmax - onehot) / P.  Optionally (both or neither;
+ * P % 256 == 0) what the fc2 heads' backward makes of dlogits first, as cpfn_head_post_bwd leaves it: pad_bf16[P,64] zero-padded
+ * bf16 rows and colsum_partial[P/256][2] column sums in cpfn_colsum_f32's order.  workspace: cpfn_ce2_blocks(P) floats. */
+CPFN_API int cpfn_ce2_blocks(long long P);
+CPFN_API int cpfn_ce2(const float *logits, const int64_t *labels, long long P, float *workspace, float *loss, float *dlogits,
+                      void *pad_bf16, float *colsum_partial, void *stream);
 /* Label-segmented membership sums, shared by the Hungarian cost matrix and the relaxed-IoU loss
  * (SPFN/losses_implementation.py:19-24, 77-90):  S[B,K+2,K]: rows l<K = sum of W rows with label l,
  * row K = column sums of W, row K+1 = number of points per label.  fwd: any K <= 1024 (K > 32: one 32 x 32 tile

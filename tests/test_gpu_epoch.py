@@ -250,3 +250,42 @@ def test_patch_selection_epoch_equals_trainer_steps_by_hand():
     lines = buf.getvalue().splitlines()
     assert lines[0].startswith("[train][Epoch 0 - Iteration 0] Loss: ") and lines[-1].startswith("[val][Epoch 0 - Iteration 0] Loss: ")
     assert model2.bn1.momentum == 0.25 and opt.param_groups[0]['lr'] == pytest.approx(1e-3 * 0.7 ** 2)
+
+
+def test_heat_cross_entropy_matches_torch_and_its_hint_is_bit_identical(monkeypatch):
+    """cpfn_ce2 (loss + gradient + the heads' padded gradient rows / column sums in one launch) against F.cross_entropy
+    (Utils/training_utils.py:66-68), and a whole PatchSelection step with / without the hand-over to the heads' backward."""
+    from cpfn_amd import lib as _l, training
+    from cpfn_amd.SPFN import fused_losses as fl
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for P_ in (256 * 512, 1000):                                   # (a ragged size: no hint, partial last block)
+        Y = (torch.randn(1, P_, 2, generator=g) * 3).to(dev).requires_grad_(True)
+        lab = torch.randint(0, 2, (1, P_), generator=g).to(dev)
+        with fl.unit_loss_gradient():
+            loss = fl.HeatCrossEntropy.apply(Y, lab, None)
+        loss.backward()
+        Yt = Y.detach().clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(Yt.view(P_, 2), lab.view(P_))
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+        assert float((Y.grad - Yt.grad).abs().max()) < 1e-6 * float(Yt.grad.abs().max()) + 1e-12
+    c = synthetic.primitive_cloud(B, N, n_prims=6, seed=9)
+    batch = {"P": c["P"].to(dev), "labels": (c["I_gt"] % 2).long().to(dev)}
+    starts = (torch.arange(B), torch.arange(B) + 3)
+    res = {}
+    for hint in (True, False):
+        monkeypatch.setattr(fl, "HEADS_HINT", hint)
+        model = _ps_model(dev)
+        model.dropout_p = 0.0
+        tr = training.PatchSelectionTrainer(model, batch_size=B)
+        tr.bucket.zero()
+        _l.byte_census(True)
+        out = tr.losses(batch, fps_start=starts)
+        out[0].backward()
+        census = _l.byte_census(False)
+        assert "cpfn_ce2" in census and ("cpfn_colsum_f32" in census) == (not hint), sorted(census)
+        res[hint] = (float(out[0]), [None if p.grad is None else p.grad.clone() for p in model.parameters()])
+    assert res[True][0] == res[False][0]
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a is None and b is None) or torch.equal(a, b)
