@@ -101,7 +101,7 @@ class PointNet2(torch.nn.Module):
             auto = self.__dict__.get("_auto_graph")
             if auto is None:
                 from ..inference import GraphedForward
-                auto = self.__dict__["_auto_graph"] = GraphedForward(self, max_shapes=4, clone_outputs=True)
+                auto = self.__dict__["_auto_graph"] = GraphedForward(self, max_shapes=4, clone_outputs=True, weak=True)
             return auto(x, glob_features=glob_features, loc_features=loc_features, fps_start=fps_start)
         if bf16:
             # one multi-tensor fp32 -> bf16 conversion; when sa1's input is coordinates only, its fp32 first layer is the

@@ -23,11 +23,17 @@ class GraphedForward:
     clone_outputs=True; `model.auto_graph = False` opts out), so that the reference's evaluation scripts
     (evaluation_globalSPFN.py:85, evaluation_localSPFN.py:95) get the replayed forward unedited."""
 
-    def __init__(self, model, max_shapes=None, clone_outputs=False):
-        self.model = model
+    def __init__(self, model, max_shapes=None, clone_outputs=False, weak=False):
+        # weak: the instance the model keeps for itself (PointNet2.forward's auto replay) must not keep the model alive
+        import weakref
+        self._model_ref = weakref.ref(model) if weak else (lambda m=model: m)
         self._graphs = {}
         self.max_shapes = max_shapes
         self.clone_outputs = clone_outputs
+
+    @property
+    def model(self):
+        return self._model_ref()
 
     def _storage_key(self):
         m = self.model
@@ -44,10 +50,11 @@ class GraphedForward:
         starts = (st["start_dev"][0], st["start_dev"][1])
         stream = torch.cuda.Stream(device=dev)
         stream.wait_stream(torch.cuda.current_stream(dev))
+        from .training import capture_guard
         with torch.cuda.stream(stream), torch.no_grad():
             m(st["x"], glob_features=st["glob"], loc_features=st["loc"], fps_start=starts)     # warm-up: lazily created state
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+            with capture_guard(), torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                 st["out"] = m(st["x"], glob_features=st["glob"], loc_features=st["loc"], fps_start=starts)
         torch.cuda.current_stream(dev).wait_stream(stream)
         st["g"], st["stream"] = g, stream

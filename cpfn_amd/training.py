@@ -191,6 +191,28 @@ class FlatGradBucket:
         return flag
 
 
+class capture_guard:
+    """No Python garbage collection inside a stream capture.  A dead reference cycle that owns device-side objects — a model
+    with the trainer / epoch runner / auto-replay state hanging off it holds hipGraphs, pinned buffers, events — is destroyed
+    whenever the cyclic collector happens to run; if that is in the middle of a capture, the destructors' HIP calls abort the
+    process (seen as "Fatal Python error: Aborted ... Garbage-collecting" in a capture that followed the epoch tests).  torch < 2.10
+    ran gc.collect() at the start of every `torch.cuda.graph`; 2.10 does not (`torch.compiler.config.force_cudagraph_gc`).  So:
+    collect BEFORE the capture, keep the collector off DURING it."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def _quiesce_collectives(dev):
     """Before a stream capture in a multi-rank process: let the process group's watchdog thread retire every finished
     collective.  It polls the completion events of outstanding work from ITS thread (hipEventQuery, every 100 ms); a
@@ -378,6 +400,15 @@ class SPFNTrainer:
         """The validation pass of the reference's epoch loop (`network_mode='val'`, training_utils.py:104-105, 140-147 under
         the caller's `torch.no_grad()`): forward + the six losses in whatever mode the module is in, nothing back-propagated,
         no optimizer.  `next_batch`: its FPS / ball query / 3-NN run on the side stream beside this batch's forward pass."""
+        st = self._graph
+        if (self.use_graphs and st is not None and st.get("single") and self._gstream is not None and batch["P"].is_cuda
+                and torch.cuda.current_stream(batch["P"].device) == self._gstream and self._prefetched is None
+                and set(batch) >= {k for k in st["batch"] if k != "gt_axes"}
+                and all(batch[k].shape == st["batch"][k].shape for k in st["batch"] if k != "gt_axes")
+                and (next_batch is None or next_batch["P"].shape == st["P_next"].shape)):
+            # the replayed form: the step's static inputs, geometry hand-over and side graph, with the validation twin of the
+            # step's graph in place of the step (same FPS-seed draws as the eager form: one pair per announced batch)
+            return self._graph_step(batch, next_batch, val=True)
         with torch.no_grad():
             geom = self._take_prefetched(batch["P"])
             if next_batch is not None:
@@ -516,7 +547,7 @@ class SPFNTrainer:
             stream = torch.cuda.Stream(device=dev)
             stream.wait_stream(torch.cuda.current_stream(dev))
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(stream):
+            with torch.cuda.stream(stream), capture_guard():
                 with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
                     dist.all_reduce(probe, op=dist.ReduceOp.AVG)
                 probe.fill_(float(rank))
@@ -534,6 +565,10 @@ class SPFNTrainer:
         return float(flag) >= 1.0
 
     def _capture(self, batch, exchange_in_graph=True):
+        with capture_guard():
+            return self._capture_impl(batch, exchange_in_graph)
+
+    def _capture_impl(self, batch, exchange_in_graph=True):
         """exchange_in_graph (data parallel only): capture the RCCL all-reduce and the optimizer inside the step's
         graph; False = the graph ends after the gradient packing and the exchange + optimizer follow as eager
         launches (what step() falls back to if the collective cannot be captured on this stack)."""
@@ -722,10 +757,30 @@ class SPFNTrainer:
         done.record()
         return None
 
-    def _graph_step(self, batch, next_batch=None):
+    def _val_graph(self, st):
+        """The validation twin of the step's graph: forward + loss section under no_grad in the module's CURRENT mode (evaluation
+        mode for `spfn_train_val_epoch(..., 'val')`; training mode for the PatchSelection loop's quirk), on the same static
+        inputs and geometry set A, sharing the step graph's memory pool.  Captured on first use, one per mode."""
+        key = bool(self.module.training)
+        ent = st.setdefault("val", {}).get(key)
+        if ent is None:
+            dev = st["batch"]["P"].device
+            if st["world"] > 1:
+                _quiesce_collectives(dev)
+            gv = torch.cuda.CUDAGraph()
+            sb = st["batch"]
+            with torch.no_grad(), capture_guard():
+                with torch.cuda.graph(gv, pool=st.get("g0_first", st["g0"]).pool(), stream=self._gstream, capture_error_mode="thread_local"):
+                    self.module(sb["P"], geometry=st["geomA"], **self._feature_kwargs(sb))
+                    out = self._graph_losses(sb, {})
+            ent = st["val"][key] = (gv, tuple(o.detach() for o in out))
+        return ent
+
+    def _graph_step(self, batch, next_batch=None, val=False):
         from .SPFN import fused_losses as fl
         st = self._graph
         single = st["single"]
+        main_graph, main_out = (st.get("g"), None) if not val else self._val_graph(st)
         if single and int(st["flag_err"][0]) != 0:
             if st["world"] > 1:
                 # the peers would sit in the next step's in-graph collective until the RCCL time-out: take the group down
@@ -802,18 +857,20 @@ class SPFNTrainer:
                     # (csr_build holds 80 KB of LDS per CU) and on the NEXT step's waiter — per-kernel times of a trace taken that
                     # way describe the profiler, not the step (profiles/README.md, round 4).
                     if not _SIDE_GRAPH_FIRST:
-                        st["g"].replay()                       # the whole step: no host synchronisation
+                        main_graph.replay()                    # the whole step: no host synchronisation
                     self._flag_wait(st, 0, st["n_main"] + 1, self._gside)
                     with torch.cuda.stream(self._gside):
                         st["gs"].replay()
                     _l.check(h.cpfn_flag_set(flags[1:].data_ptr(), st["n_side"] + 1, self._gside.cuda_stream), "cpfn_flag_set")
                     if _SIDE_GRAPH_FIRST:
-                        st["g"].replay()
+                        main_graph.replay()
                 st["n_side"] += 1
                 st["side_pending"] = True
             else:
-                st["g"].replay()                               # the whole step: no host synchronisation
+                main_graph.replay()                            # the whole step: no host synchronisation
             st["n_main"] += 1
+            if val:                                            # (no backward pass, no exchange, no optimizer, no step count)
+                return main_out
             if st["world"] > 1 and not st["exchange_in_graph"]:
                 self._exchange_with_stamps(batch["P"].device)
                 self._checked_optimizer_step(st["skipped"], fault=self.bucket.fault_slot.reshape(()))

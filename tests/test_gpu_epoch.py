@@ -125,6 +125,8 @@ def test_epoch_function_equals_trainer_steps_by_hand():
     torch.cuda.synchronize()
     runner = model2.__dict__["_cpfn_epoch_runner"]
     assert runner.trainer._graph is not None and runner.trainer.skipped_steps == 0
+    # the validation pass was replayed too (the evaluation-mode twin of the step's graph), by hand and inside the epoch function
+    assert False in runner.trainer._graph.get("val", {}) and False in tr._graph.get("val", {})
     assert gs == len(train_b) and gs2 == gs
     logged = [c for c in vis.calls if len(c) > 1]
     names = [n for n, _ in logged]
@@ -239,6 +241,7 @@ def test_patch_selection_epoch_equals_trainer_steps_by_hand():
             gs2, tot_v = training.patch_selection_train_val_epoch(loader(val_b), model2, 0, opt, gs, vis, Args(), conf, dev, network_mode='val')
     torch.cuda.synchronize()
     assert gs == len(train_b) and gs2 == gs and model2.training
+    assert True in model2.__dict__["_cpfn_epoch_runner"].trainer._graph.get("val", {})       # (training-mode twin: the quirk)
     logged = [c for c in vis.calls if len(c) > 1]
     assert [n for n, _ in logged] == ['train_loss'] * len(train_b) + ['val_loss'] * len(val_b)
     assert [v for _, v in logged] == hand
@@ -289,3 +292,27 @@ def test_heat_cross_entropy_matches_torch_and_its_hint_is_bit_identical(monkeypa
     assert res[True][0] == res[False][0]
     for a, b in zip(res[True][1], res[False][1]):
         assert (a is None and b is None) or torch.equal(a, b)
+
+
+def test_replayed_validation_pass_agrees_with_the_eager_one():
+    """`eval_losses` replays the validation twin of the step's graph when the trainer has one; called from another stream (or
+    before any training step) it runs eager launches.  Same weights, same batches, dropout off: the two forms differ only in the
+    FPS seeds they draw (order of the CPU-generator draws), i.e. by sampling noise."""
+    from cpfn_amd import training
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    model.dropout_p = 0.0
+    tr = training.SPFNTrainer(model, batch_size=B, init_learning_rate=0.0, use_graphs=True)
+    batches = [{k: v.to(dev) for k, v in b.items()} for b in _host_batches(4, 800, False)]
+    with torch.cuda.stream(tr.stream(dev)):
+        for i in range(4):
+            tr.step(batches[i], next_batch=batches[(i + 1) % 4])
+        model.eval()
+        replayed = [[float(o) for o in tr.eval_losses(batches[i], next_batch=batches[i + 1] if i < 3 else None)] for i in range(4)]
+        assert False in tr._graph["val"]
+    torch.cuda.synchronize()
+    eager = [[float(o) for o in tr.eval_losses(batches[i])] for i in range(4)]          # (default stream: eager launches)
+    for a, b in zip(replayed, eager):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 0.08 * abs(y) + 2e-3, (a, b)
+    assert tr.global_step == 4
