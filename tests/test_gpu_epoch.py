@@ -316,3 +316,36 @@ def test_replayed_validation_pass_agrees_with_the_eager_one():
         for x, y in zip(a, b):
             assert abs(x - y) <= 0.08 * abs(y) + 2e-3, (a, b)
     assert tr.global_step == 4
+
+
+class _CloudSet(torch.utils.data.Dataset):
+    """A stand-in for Dataset_GlobalSPFN: one cloud per item, the eight arrays in the order the loop reads them (numpy, like
+    the reference's h5 reader)."""
+
+    def __init__(self, n):
+        b = synthetic.training_batch(n, N=N, n_max_instances=K, n_prims=6, n_inst_points=128, seed=900)
+        self.items = [tuple(b[k][i].numpy() for k in ORDER) for i in range(n)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def test_epoch_function_over_a_real_dataloader():
+    """`torch.utils.data.DataLoader(..., num_workers=2, pin_memory=True)` as training_SPFN.py:78 builds it: the default collate
+    hands the loop a LIST of pinned tensors per batch (copied from where they lie), the last batch is ragged (drop_last=False)."""
+    from cpfn_amd import training
+    dev = torch.device("cuda:0")
+    loader = torch.utils.data.DataLoader(_CloudSet(4 * 7 + 2), batch_size=B, num_workers=2, pin_memory=True, shuffle=False)
+    model = _model(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    vis = Visualiser()
+    with contextlib.redirect_stdout(io.StringIO()):
+        gs, tot = training.spfn_train_val_epoch(loader, model, 0, opt, 0, vis, Args(), Conf(), dev)
+        gs, tot2 = training.spfn_train_val_epoch(loader, model, 1, opt, gs, vis, Args(), Conf(), dev)
+    runner = model.__dict__["_cpfn_epoch_runner"]
+    assert gs == 16 and runner.trainer._graph is not None and runner.trainer.skipped_steps == 0
+    assert tot == tot and tot2 == tot2 and tot2 < tot                       # finite, and the second pass over the data is better
+    assert sum(1 for c in vis.calls if c == ("update",)) == 16
