@@ -333,3 +333,21 @@ def test_patch_selection_epoch_against_the_reference_s_own_function():
     finally:
         sys.path.remove(REF)
         tu._reference_module = None
+
+
+def test_epoch_loop_edge_cases():
+    """An empty loader, a one-batch loader and a validation call before any training step."""
+    from cpfn_amd import training
+    torch.manual_seed(0)
+    model, conf, vis = Tiny(), Conf(), Visualiser()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        assert training.spfn_train_val_epoch([], model, 0, opt, 7, vis, Args(), conf, 'cpu') == (7, 0.0)
+        with torch.no_grad():
+            gs, tot = training.spfn_train_val_epoch(_loader(1, ragged=False), model, 0, opt, 7, vis, Args(), conf, 'cpu', network_mode='val')
+        assert gs == 7 and tot > 0 and not model.training
+        gs, tot = training.spfn_train_val_epoch(iter(_loader(1, ragged=False)), model, 1, opt, 7, vis, Args(), conf, 'cpu')      # (any iterable)
+        assert gs == 8 and model.training
+    assert vis.calls.count(("update",)) == 2
+    assert buf.getvalue().count("[train][Epoch 1 - Iteration 0]") == 1 and buf.getvalue().count("[val][Epoch 0 - Iteration 0]") == 1

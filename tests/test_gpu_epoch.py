@@ -342,9 +342,12 @@ def test_epoch_function_over_a_real_dataloader():
     model = _model(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     vis = Visualiser()
+    class Flat(Conf):                                 # (no staircase change in these 16 steps: the graph stays)
+        def get_bn_decay_step(self): return 10 ** 6
+        def get_decay_step(self): return 10 ** 6
     with contextlib.redirect_stdout(io.StringIO()):
-        gs, tot = training.spfn_train_val_epoch(loader, model, 0, opt, 0, vis, Args(), Conf(), dev)
-        gs, tot2 = training.spfn_train_val_epoch(loader, model, 1, opt, gs, vis, Args(), Conf(), dev)
+        gs, tot = training.spfn_train_val_epoch(loader, model, 0, opt, 0, vis, Args(), Flat(), dev)
+        gs, tot2 = training.spfn_train_val_epoch(loader, model, 1, opt, gs, vis, Args(), Flat(), dev)
     runner = model.__dict__["_cpfn_epoch_runner"]
     assert gs == 16 and runner.trainer._graph is not None and runner.trainer.skipped_steps == 0
     assert tot == tot and tot2 == tot2 and tot2 < tot                       # finite, and the second pass over the data is better
