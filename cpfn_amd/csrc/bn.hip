@@ -292,77 +292,6 @@ __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__re
   coef[2 * C + c] = (float)c3;
 }
 
-// Finalize + apply of a SMALL layer's BatchNorm backward as ONE launch (round 4).  The two were a [C]-sized launch (~3 us inside a
-// replay) plus a kernel boundary in front of an apply pass over a few MB, for each of the six small layers of a step (sa3, sfp1,
-// sfp2).  Here a workgroup is bn_bwd_finalize_kernel's — 16 channels x 64 block-subsets, the same fixed-order sums, so the
-// coefficients have the same bits — and then streams the apply pass for ITS 16 channels over its row range (grid.y ranges of
-// <= 2048 rows: every range finalizes redundantly — a latency chain that runs in parallel, nblk x 128 bytes from L2 — and range 0
-// writes dgamma / dbeta / coef).  1024 lanes = 512 rows x two 16-byte chunks per pass, the loads of four passes issued before
-// the first use.  Arithmetic of bn_bwd_apply_kernel<true>: same bits in g_y.
-__global__ __launch_bounds__(RTPB) void bn_bwd_finalize_apply_kernel(
-    const float *__restrict__ partial, int nblk, int C, float count, const float *__restrict__ gamma,
-    const float *__restrict__ mean, const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
-    float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/, const unsigned short *__restrict__ Gz,
-    const unsigned short *__restrict__ Yr, const float *__restrict__ scale, const float *__restrict__ shift, int P,
-    int rows_per_range, unsigned short *__restrict__ Gy) {
-  __shared__ double s_acc[RSUB][16][2];
-  __shared__ float s_c[5][16];                       // s, c2, c3, scale, shift of the workgroup's 16 channels
-  const int t = threadIdx.x, cl = t & 15, cb = blockIdx.x * 16, c = cb + cl, r = t >> 4;
-  double s1, s2;
-  partial_sums_16x16(partial, nblk, C, c, r, s_acc, s1, s2);
-  if (r == 0) {
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    if (c < C) {
-      const double m = mean[c], rs = rstd[c];
-      const double dg = rs * (s2 - m * s1);
-      const double sg = (double)gamma[c] * rs;
-      const double c2 = training ? -sg * dg * rs / count : 0.0;
-      const double c3 = training ? -sg * s1 / count - c2 * m : 0.0;
-      v0 = (float)sg; v1 = (float)c2; v2 = (float)c3;
-      if (blockIdx.y == 0) {
-        dgamma[c] = (float)dg;
-        dbeta[c] = (float)s1;
-        coef[c] = v0; coef[C + c] = v1; coef[2 * C + c] = v2;
-      }
-    }
-    s_c[0][cl] = v0; s_c[1][cl] = v1; s_c[2][cl] = v2;
-    s_c[3][cl] = c < C ? scale[c] : 0.f;
-    s_c[4][cl] = c < C ? shift[c] : 0.f;
-  }
-  __syncthreads();
-  const int chunk = t & 1, c0 = chunk * 8;             // lane: row (t >> 1) of a 512-row pass, channels cb + c0 .. + 7
-  if (cb + c0 >= C) return;
-  const int p_begin = blockIdx.y * rows_per_range, p_end = min(P, p_begin + rows_per_range);
-  float k0[8], k1[8], k2[8], ksc[8], ksh[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { k0[j] = s_c[0][c0 + j]; k1[j] = s_c[1][c0 + j]; k2[j] = s_c[2][c0 + j]; ksc[j] = s_c[3][c0 + j]; ksh[j] = s_c[4][c0 + j]; }
-  for (int p0 = p_begin + (t >> 1); p0 < p_end; p0 += 4 * 512) {
-    uint4 rg[4], ry[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = p0 + u * 512;
-      const size_t off = (size_t)(p < p_end ? p : p_begin) * C + cb + c0;
-      rg[u] = *(const uint4 *)(Gz + off);
-      ry[u] = *(const uint4 *)(Yr + off);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = p0 + u * 512;
-      if (p >= p_end) break;
-      const unsigned short *g = (const unsigned short *)&rg[u], *y = (const unsigned short *)&ry[u];
-      unsigned short o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float yv = bf2f(y[j]);
-        float gz = bf2f(g[j]);
-        gz = fmaf(ksc[j], yv, ksh[j]) > 0.f ? gz : 0.f;
-        o[j] = f2bf(fmaf(k0[j], gz, fmaf(k1[j], yv, k2[j])));
-      }
-      *(uint4 *)(Gy + (size_t)p * C + cb + c0) = *(const uint4 *)o;
-    }
-  }
-}
-
 // g_y[p,c] = s·g_z + c2·y + c3   (dense).  Gy may alias Gz.
 // With scale/shift given, Gz is really g_a and the ReLU mask [scale·y+shift > 0] is recomputed here, so the
 // reduction pass (bn_relu_bwd) does not have to write the masked gradient at all.
@@ -853,22 +782,6 @@ extern "C" int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float
   if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef) return CPFN_EINVAL;
   bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 16), RTPB, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
                                                                             training, dgamma, dbeta, coef);
-  return cpfn_launch_status();
-}
-
-extern "C" int cpfn_bn_bwd_finalize_apply_ok(long long P, int C) { return P > 0 && P <= 16384 && C > 0 && (C & 15) == 0; }
-
-extern "C" int cpfn_bn_bwd_finalize_apply(const float *partial, int nblk, int C, float count, const float *gamma,
-                                          const float *mean, const float *rstd, int training, float *dgamma, float *dbeta,
-                                          float *coef, const void *Gz, const void *Y, const float *scale, const float *shift,
-                                          long long P, void *Gy, void *stream) {
-  if (nblk <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef || !Gz || !Y || !scale || !shift || !Gy ||
-      !cpfn_bn_bwd_finalize_apply_ok(P, C))
-    return CPFN_EINVAL;
-  const int ranges = cpfn_cdiv(P, 2048), rows = cpfn_cdiv(cpfn_cdiv(P, ranges), 512) * 512;
-  bn_bwd_finalize_apply_kernel<<<dim3(C / 16, cpfn_cdiv(P, rows)), RTPB, 0, (hipStream_t)stream>>>(
-      partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef, (const unsigned short *)Gz,
-      (const unsigned short *)Y, scale, shift, (int)P, rows, (unsigned short *)Gy);
   return cpfn_launch_status();
 }
 

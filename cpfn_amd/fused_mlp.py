@@ -57,8 +57,6 @@ HEADS_ONE_PASS = True
 #                     output ends in the fused dropout: the mask is recomputed on the data-gradient slab) — no cpfn_bn_relu_bwd
 #                     launch on the fc1 features
 HEADS_RIDE = True
-# finalize + apply pass of a small layer's BatchNorm backward as ONE launch (cpfn_bn_bwd_finalize_apply; round 4)
-BN_BWD_MERGED = True
 
 
 def _pad_to(n, m):
@@ -563,22 +561,10 @@ class _FusedStack(torch.autograd.Function):
                     _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None, _ptr(part), _ptr(dseed), dp,
                                               _stream()), "cpfn_bn_relu_bwd")
                     _l.add_bytes("cpfn_bn_relu_bwd", 4 * P * N + 8 * nblk * N)
-                # (small dense layer whose apply pass is its own launch: finalize + apply in one, same bits)
-                merged = (BN_BWD_MERGED and arg is None and not fold_apply and dseed is None
-                          and bool(h.cpfn_bn_bwd_finalize_apply_ok(P, N)))
-                if merged:
-                    Gy = torch.empty(P, N, dtype=BF16, device=dev)
-                    _check(h.cpfn_bn_bwd_finalize_apply(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]),
-                                                        _ptr(st[3]), 1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef),
-                                                        _ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, _ptr(Gy), _stream()),
-                           "cpfn_bn_bwd_finalize_apply")
-                    _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
-                    _l.add_bytes("cpfn_bn_bwd_apply", 6 * P * N)
-                else:
-                    _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
-                                                  1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
-                           "cpfn_bn_bwd_finalize")
-                    _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
+                _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
+                                              1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
+                       "cpfn_bn_bwd_finalize")
+                _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                 grads[3 * li + 1] = dgb[0]
                 grads[3 * li + 2] = dgb[1]
                 # ---- (2) apply pass, unless a consumer forms g_y itself
@@ -588,8 +574,6 @@ class _FusedStack(torch.autograd.Function):
                         _check(h.cpfn_bn_pool_bwd_apply(_ptr(g), _ptr(arg), _ptr(yarg), _ptr(Y), _ptr(st[0]), _ptr(st[1]),
                                                         _ptr(coef), P // pool_k, pool_k, N, _ptr(Gy), _stream()), "cpfn_bn_pool_bwd_apply")
                         _l.add_bytes("cpfn_bn_pool_bwd_apply", 4 * P * N + 5 * (P // pool_k) * N)
-                elif merged:
-                    pass                            # (g_y left by the merged launch above)
                 elif not fold_apply:                # the mask is recomputed from y, dropout re-applied from its seed
                     Gy = torch.empty(P, N, dtype=BF16, device=dev)
                     _check(h.cpfn_bn_bwd_apply(_ptr(g), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]), P, N, _ptr(Gy),

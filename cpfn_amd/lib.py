@@ -99,8 +99,6 @@ SIGNATURES = {
     "cpfn_bn_relu_bwd": [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _f, _vp],
     "cpfn_bn_bwd_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "cpfn_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _f, _vp],
-    "cpfn_bn_bwd_finalize_apply_ok": [_ll, _i],
-    "cpfn_bn_bwd_finalize_apply": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "cpfn_bn_pool_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "cpfn_mlp_wgrad_splits": [_ll, _i, _i],
     "cpfn_multi_split_reduce": [_vp, _i, _vp],

@@ -415,13 +415,6 @@ CPFN_API int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float c
 CPFN_API int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, const float *scale,
                                const float *shift, long long P, int C, void *Gy,
                                const unsigned long long *drop_seed /* NULL: no dropout */, float drop_p, void *stream);
-/* cpfn_bn_bwd_finalize + cpfn_bn_bwd_apply (ReLU mask recomputed from Y, no dropout) as ONE launch for a small layer
- * (cpfn_bn_bwd_finalize_apply_ok: P <= 16384 rows, C % 16 == 0): same dgamma / dbeta / coef and the same g_y, bit for bit. */
-CPFN_API int cpfn_bn_bwd_finalize_apply_ok(long long P, int C);
-CPFN_API int cpfn_bn_bwd_finalize_apply(const float *partial, int nblk, int C, float count, const float *gamma,
-                                        const float *mean, const float *rstd, int training, float *dgamma, float *dbeta,
-                                        float *coef, const void *Gz, const void *Y, const float *scale, const float *shift,
-                                        long long P, void *Gy, void *stream);
 CPFN_API int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, const void *yarg,
                                     const void *Y, const float *scale, const float *shift,
                                     const float *coef, int G, int Kn, int C, void *Gy, void *stream);

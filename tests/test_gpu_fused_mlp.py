@@ -598,26 +598,3 @@ def test_xyz_tail_first_layer_against_the_concatenated_operand(P, pool_k):
         assert _rel(a, b) < tol
     y2, gx2, gp2, _ = run("tail")
     assert torch.equal(y2, yt) and torch.equal(gx2, gxt) and all(torch.equal(a, b) for a, b in zip(gp2, gpt))
-
-
-@pytest.mark.parametrize("name,P,cin,widths", [("sa3-like dense", 2048, 256, [256, 512]), ("sfp1", 2048, 1280, [256, 256]),
-                                               ("sfp2", 8192, 384, [256, 128]), ("ragged", 3000, 128, [128, 64, 64])])
-def test_small_layer_bn_backward_finalize_and_apply_in_one_launch(name, P, cin, widths, monkeypatch):
-    """Round 4: cpfn_bn_bwd_finalize_apply against cpfn_bn_bwd_finalize + cpfn_bn_bwd_apply on the small layers' route: every
-    gradient bit for bit, one launch per layer instead of two."""
-    from cpfn_amd import fused_mlp, lib as _l
-    convs, bns = _stack(cin, widths, seed=23)
-    g = torch.Generator().manual_seed(P + 1)
-    x = torch.randn(P, cin, generator=g).to(dev())
-    gout = torch.randn(P, widths[-1], generator=g).to(dev())
-    res = {}
-    for merged in (True, False):
-        monkeypatch.setattr(fused_mlp, "BN_BWD_MERGED", merged)
-        _l.byte_census(True)
-        res[merged] = _run(x, convs, bns, torch.bfloat16, None, None, gout)
-        census = _l.byte_census(False)
-        assert census["cpfn_bn_bwd_finalize"][0] == len(widths) and census["cpfn_bn_bwd_apply"][0] == len(widths), sorted(census)
-    (ya, gxa, gra, _), (yb, gxb, grb, _) = res[True], res[False]
-    assert torch.equal(ya, yb) and torch.equal(gxa, gxb)
-    for a, b in zip(gra, grb):
-        assert (a is None and b is None) or torch.equal(a, b)
