@@ -365,7 +365,7 @@ def measure_traffic():
                    "--warmup", "3", "--probe-replays", "0"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                                   stderr=subprocess.DEVNULL, timeout=420)
+                                   stderr=subprocess.DEVNULL, timeout=180)
             except (OSError, subprocess.TimeoutExpired):
                 return None
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)

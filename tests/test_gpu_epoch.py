@@ -352,3 +352,51 @@ def test_epoch_function_over_a_real_dataloader():
     assert gs == 16 and runner.trainer._graph is not None and runner.trainer.skipped_steps == 0
     assert tot == tot and tot2 == tot2 and tot2 < tot                       # finite, and the second pass over the data is better
     assert sum(1 for c in vis.calls if c == ("update",)) == 16
+
+
+def test_local_spfn_with_feature_inputs_through_the_epoch_function():
+    """`args.network == 'LocalSPFN'` with a network built with use_glob_features / use_loc_features (pn2_network.py:22-27, 51-54):
+    data[8] / data[9] (Utils/training_utils.py:136-137) are staged with the batch, enter the captured step as static inputs and
+    change the result; a network built WITHOUT them ignores them like the reference's (training_SPFN.py:69-71)."""
+    from cpfn_amd import training
+    from cpfn_amd.PointNet2 import pn2_network
+    dev = torch.device("cuda:0")
+
+    class LocalArgs:
+        network = 'LocalSPFN'
+
+    class LocalConf(Conf):
+        def get_bn_decay_step(self): return 10 ** 6
+        def get_decay_step(self): return 10 ** 6
+        def get_parameter_loss_multiplier(self): return 0.0      # Configs/config_localSPFN.yml:10-11
+        def get_residue_loss_multiplier(self): return 0.0
+
+    g = torch.Generator().manual_seed(1)
+    host = _host_batches(5, 950, False)
+    feats = [(torch.randn(B, 1024, generator=g), torch.randn(B, 128, generator=g)) for _ in host]
+
+    def loader(scale):
+        return [tuple(b[k] for k in ORDER) + (f[0] * scale, f[1] * scale) for b, f in zip(host, feats)]
+
+    def run(use, scale):
+        torch.manual_seed(0)
+        m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, K], use_glob_features=use, use_loc_features=use).to(dev)
+        m.set_compute_dtype(torch.bfloat16)
+        m.dropout_p = 0.0
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        vis = Visualiser()
+        torch.manual_seed(5)
+        with contextlib.redirect_stdout(io.StringIO()):
+            gs, tot = training.spfn_train_val_epoch(loader(scale), m, 0, opt, 0, vis, LocalArgs(), LocalConf(), dev)
+        tr = m.__dict__["_cpfn_epoch_runner"].trainer
+        assert gs == 5 and tr._graph is not None and tr.skipped_steps == 0
+        assert ("glob_features" in tr._graph["batch"]) == use
+        return tot, [c[1] for c in vis.calls if c[0] == "train_loss"]
+
+    t1, l1 = run(True, 1.0)
+    t2, l2 = run(True, 3.0)
+    assert l1 != l2 and all(v == v for v in l1 + l2)               # the feature inputs reach the network inside the replayed graph
+    t3, l3 = run(False, 1.0)
+    t4, l4 = run(False, 3.0)
+    assert l3 == l4                                                 # ... and are ignored by a network built without them
+    assert t1 == t1 and t2 == t2 and t3 == t4
