@@ -139,3 +139,42 @@ def test_p_coverage_kernel_vs_expanded_formula():
     want = np.stack([(rmin < e).float().mean(1).cpu().numpy() for e in eps])
     np.testing.assert_allclose(got, want, atol=3.0 / N)
     assert mi.compute_P_coverage(batch["P"], T, match, params, 0.02, classes=CLASSES).shape == (B,)
+
+
+def _metrics_case(B, N, K, n_prims, seed, background=0.0):
+    batch = synthetic.training_batch(B, N=N, n_max_instances=K, n_prims=n_prims, n_inst_points=128, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    I = batch["I_gt"].clone()
+    if background > 0:
+        I[torch.rand(B, N, generator=g) < background] = -1            # unlabelled points (the reference's "may contain -1's")
+        I[:, :n_prims] = torch.arange(n_prims)                         # (every label still present: gap-free)
+    lab = I.clamp(min=0)
+    logits = torch.randn(B, N, K, generator=g)
+    logits.scatter_add_(2, lab.unsqueeze(2), torch.full((B, N, 1), 3.0))
+    W = torch.softmax(logits, dim=2)
+    X = torch.nn.functional.normalize(batch["X_gt"] + 0.3 * torch.randn(B, N, 3, generator=g), dim=2)
+    T = torch.randn(B, N, 4, generator=g)
+    T.scatter_add_(2, torch.gather(batch["T_gt"], 1, lab).unsqueeze(2), torch.full((B, N, 1), 0.7))
+    gt = {"plane_normal": batch["plane_n_gt"], "cylinder_axis": batch["cylinder_axis_gt"], "cone_axis": batch["cone_axis_gt"]}
+    return batch, I, W, X, T, gt
+
+
+@pytest.mark.parametrize("case", ["background", "wide"])
+def test_all_metrics_background_labels_and_label_sets_wider_than_the_on_chip_histogram(case):
+    """(background) I_gt with -1 entries (metric_implementation.py:12: "may contain -1's"): such points count in the column sums
+    of the assignment's cost but in no GT row; (wide) K = 140 > 128: the point pass falls back to the generic kernels
+    (arg-max / one-hot / SegStats / host assignment), the tail and P-coverage kernels are the same."""
+    from cpfn_amd.SPFN import metric_implementation as mi
+    B, N = 2, 4096
+    K, n_prims, bg = (28, 8, 0.2) if case == "background" else (140, 30, 0.0)
+    batch, I, W, X, T, gt = _metrics_case(B, N, K, n_prims, seed=41 + K, background=bg)
+    ref = om.compute_all_metrics(batch["P"], X, batch["X_gt"], W, I, T, batch["T_gt"], batch["points_per_instance"], gt,
+                                 list_epsilon=[0.01, 0.03], classes=CLASSES)
+    d = lambda v: v.to(dev())
+    out = mi.compute_all_metrics(d(batch["P"]), d(X), d(batch["X_gt"]), d(W), d(I), d(T), d(batch["T_gt"]),
+                                 d(batch["points_per_instance"]), {k: d(v) for k, v in gt.items()}, list_epsilon=[0.01, 0.03],
+                                 classes=CLASSES)
+    assert out[8].shape == (B, N, K) and np.array_equal(out[8].cpu().numpy(), ref["W_hard"].numpy())
+    match, mask = mi.hungarian_matching(out[8], d(I))
+    assert np.array_equal(match.cpu().numpy(), ref["matching"].numpy()) and int(mask.sum()) == B * n_prims
+    _check(out, {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in ref.items() if k != "params"}, 128, N)
