@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Times the stages of BASELINE.json configs[4] on ONE GPU (replicas only: clouds and patches are independent):
-GlobalSPFN eval forward on one 131072-point cloud (batch 1, evaluation_globalSPFN.py:62-64), its geometry kernels one by
+PatchSelection on the 8192-point low-resolution cloud (evaluation_PatchSelection.py:65), GlobalSPFN eval forward on one
+131072-point cloud (batch 1, evaluation_globalSPFN.py:62-64), its geometry kernels one by
 one, the LocalSPFN eval forward on 32 patches x 8192 points (evaluation_localSPFN.py:95), similarity_soft /
 get_point_final, and compute_all_metrics on the merged 49-column label set.  HIP events, median of 5."""
 import os, sys
@@ -34,9 +35,17 @@ g.dropout_p = 0.0
 l = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 21]).to(dev).eval()
 l.set_compute_dtype(torch.bfloat16)
 l.dropout_p = 0.0
+ps = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2]).to(dev).eval()
+ps.set_compute_dtype(torch.bfloat16)
+ps.dropout_p = 0.0
 start = torch.zeros(1, dtype=torch.int32, device=dev)
 with torch.no_grad():
-    t, sel = timed(lambda: ops.fps(P, 512, start)); print("FPS 131072 -> 512 (64 workgroups per cloud)         %8.3f ms" % t)
+    P_lo = P[:, ::N // NPP].contiguous()                       # the low-resolution cloud PatchSelection looks at (evaluation_PatchSelection.py:65)
+    ps.auto_graph = False
+    t, _ = timed(lambda: ps(P_lo, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("PatchSelection eval forward, 1 x 8192, eager launches %6.3f ms" % t)
+    ps.auto_graph = True
+    t, heat = timed(lambda: ps(P_lo, fps_start=(torch.tensor([0]), torch.tensor([0])))); print("  ... the unedited call model(P): auto-replayed graph  %6.3f ms" % t)
+    t, sel = timed(lambda: ops.fps(P, 512, start)); print("FPS 131072 -> 512 (16 workgroups per cloud)         %8.3f ms" % t)
     ctr = ops.gather_rows(P, sel)
     t, _ = timed(lambda: ops.ball_query(ctr, P, 0.2, 64)); print("ball query 512 x 131072                            %8.3f ms" % t)
     t, _ = timed(lambda: ops.three_nn(P, ctr)); print("3-NN 131072 x 512                                  %8.3f ms" % t)
