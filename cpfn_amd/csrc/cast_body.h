@@ -1,6 +1,6 @@
 // fp32 matrices -> bf16 (or fp32) panels with a row stride, up to MCV_MAX of them per launch: the per-step refresh of every
 // bf16 weight panel of the network.  Shared by cpfn_multi_cast (gather.hip) and by the launch that runs it beside sa1's fp32
-// first layer (mlp.hip: cpfn_smallk_fwd_cast).
+// first layer (bn.hip: cpfn_smallk_fwd_cast).
 #pragma once
 #include "common.h"
 
