@@ -249,7 +249,8 @@ class EpochRunner:
                     lr_before = tr._lr
                     # the epoch's ragged last batch runs as eager launches; the batch in front of it does not announce it
                     # (the replayed graphs' static buffers have the full batch's shapes)
-                    ragged = tr.use_graphs and B_cur != B_full
+                    ragged = tr.use_graphs and (B_cur != B_full or (tr._graph is not None and any(
+                        k in tr._graph["batch"] and tr._graph["batch"][k].shape != v.shape for k, v in batch.items())))
                     announce = nxt is not None and not ragged and nxt[1]["P"].shape == batch["P"].shape
                     out = tr.step(batch, next_batch=nxt[1] if announce else None, force_eager=ragged)
                     if tr._lr != lr_before:                                 # the caller's optimizer shows the staircase (:119-121)
