@@ -1,0 +1,33 @@
+"""Soak of the epoch route: several epochs of spfn_train_val_epoch (train + val) over distinct pinned host batches; watches the
+step time per epoch, device / pinned memory and the skip / fault counters."""
+import os, sys, time, io, contextlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+import torch
+from cpfn_amd import ops, training
+from cpfn_amd.PointNet2 import pn2_network
+from cpfn_amd.SPFN import fitter_factory
+dev = torch.device("cuda:0")
+with contextlib.redirect_stdout(io.StringIO()):
+    fitter_factory.register_primitives(training.GLOBAL_SPFN_CLASSES)
+n_epochs, n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 6, int(sys.argv[2]) if len(sys.argv) > 2 else 500
+loader = bench._route_loader(16, n_batches, 0)
+val_loader = bench._route_loader(4, 20, 1)
+torch.manual_seed(0)
+m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev).set_compute_dtype(torch.bfloat16)
+opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+vis, conf, gs = bench._RouteVisualiser(), bench._RouteConf(), 0
+for e in range(n_epochs):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        gs, tot = training.spfn_train_val_epoch(loader, m, e, opt, gs, vis, bench._RouteArgs(), conf, dev, network_mode='train')
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+        _, vtot = training.spfn_train_val_epoch(val_loader, m, e, opt, gs, vis, bench._RouteArgs(), conf, dev, network_mode='val')
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    tr = m.__dict__["_cpfn_epoch_runner"].trainer
+    print("epoch %d: train %.3f ms/step (mean loss %.4f), val %.3f ms/step (mean loss %.4f), skipped %d, fps faults %d, device %.1f MB, reserved %.1f MB"
+          % (e, 1e3 * (t1 - t0) / n_batches, tot / (16 * n_batches), 1e3 * (t2 - t1) / 20, vtot / (16 * 20), tr.skipped_steps, ops.fps_faults(),
+             torch.cuda.memory_allocated() / 1e6, torch.cuda.memory_reserved() / 1e6), flush=True)
