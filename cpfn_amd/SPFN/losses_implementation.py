@@ -41,6 +41,17 @@ def compute_miou_loss(W, I_gt, matching_indices, div_eps=1e-10):
     """-> (1 − relaxed IoU [B,K], 1 − intersection/N [B,K])   (reference lines 77-90)."""
     B, N, K = W.shape
     n_labels = matching_indices.shape[1]
+    if W.is_cuda and n_labels == K and W.dtype == torch.float32 and (K <= 32 or not (W.requires_grad and torch.is_grad_enabled())):
+        # The three sums this function needs per (GT label k, matched column) — intersection, points with label k, column sum —
+        # are entries of the label-segmented sums S[B,K+2,K] (cpfn_seg_stats_fwd: one pass over W, differentiable for K <= 32)
+        # instead of [B,N,K] gathers / one-hot scatters (the evaluation scripts call this on 131072 x 49 memberships,
+        # evaluation_localSPFN.py:145-146).
+        from . import fused_losses as _fl
+        S = _fl.SegStats.apply(W, I_gt)
+        m = matching_indices.clamp(0, K - 1)
+        dot = torch.gather(S[:, :K], 2, m.unsqueeze(2)).squeeze(2)
+        den = S[:, K + 1] + torch.gather(S[:, K], 1, m) - dot
+        return 1.0 - dot / (den + div_eps), 1 - dot / N
     W_reordered = torch.gather(W, 2, matching_indices.unsqueeze(1).expand(B, N, n_labels))
     lab = torch.where(I_gt < 0, torch.full_like(I_gt, n_labels + 1), I_gt)
     W_gt = torch.zeros(B, N, n_labels + 2, dtype=W.dtype, device=W.device).scatter_(2, lab.unsqueeze(2), 1.0)
