@@ -41,7 +41,7 @@ __global__ void phase_kernel(float *records, int rec, int nread, int phase, int 
 __device__ __forceinline__ void grid_barrier(unsigned *xcc_cnt, unsigned *top, unsigned *xcc_gen, unsigned phase, unsigned per_xcc) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    __atomic_thread_fence(__ATOMIC_RELEASE);                                   // agent scope: my records become visible
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                         // my records become visible to the other XCDs
     const int x = blockIdx.x & 7;
     const unsigned a = __hip_atomic_fetch_add(&xcc_cnt[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     if (a == per_xcc * phase) {
@@ -53,7 +53,7 @@ __device__ __forceinline__ void grid_barrier(unsigned *xcc_cnt, unsigned *top, u
       for (unsigned spin = 0; __hip_atomic_load(&xcc_gen[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase && spin < (1u << 22); ++spin)
         __builtin_amdgcn_s_sleep(1);
     }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
