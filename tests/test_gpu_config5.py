@@ -211,6 +211,21 @@ def test_graphed_evaluation_forward_matches_eager():
             torch.manual_seed(6)
             m(P)                                     # a second call must not overwrite what the first returned
             assert torch.equal(auto[2], keep)
+            # weights updated IN PLACE (an optimizer step between two evaluations) are seen by the replayed graph: it reads the
+            # parameters where they lie and refreshes its bf16 panels inside the graph
+            m.fc2[0].weight.mul_(1.5)
+            m.sa1.bn_blocks[0][0].running_mean.add_(0.01)
+            torch.manual_seed(7)
+            after = m(P)
+            m.auto_graph = False
+            torch.manual_seed(7)
+            after_eager = m(P)
+            m.auto_graph = True
+            assert not torch.equal(after[0], auto[0])
+            for a, b in zip(after, after_eager):
+                assert torch.equal(a, b)
+            m.fc2[0].weight.div_(1.5)
+            m.sa1.bn_blocks[0][0].running_mean.sub_(0.01)
             for rep in range(2):                     # capture, then a pure replay
                 torch.manual_seed(5)
                 got = gf(P)
