@@ -16,8 +16,24 @@ __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ par
                                                    int r, double (*s_acc)[16][2], double &s1, double &s2) {
   double a1 = 0.0, a2 = 0.0;
   if (c < N) {
+    // (the step's launches leave at most 512 partial rows: a subset's <= 8 rows are requested together — as a loop unrolled by
+    //  four, the 342-448 rows of the large layers took two memory round trips — and added in the same order)
+    int i = r;
+    if (nblk <= 8 * RSUB) {
+      float p1[8], p2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ii = r + j * RSUB, ic = ii < nblk ? ii : r < nblk ? r : 0;
+        p1[j] = partial[((size_t)ic * 2 + 0) * N + c];
+        p2[j] = partial[((size_t)ic * 2 + 1) * N + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (r + j * RSUB < nblk) { a1 += (double)p1[j]; a2 += (double)p2[j]; }
+      i = nblk;
+    }
 #pragma unroll 4
-    for (int i = r; i < nblk; i += RSUB) {
+    for (; i < nblk; i += RSUB) {
       a1 += (double)partial[((size_t)i * 2 + 0) * N + c];
       a2 += (double)partial[((size_t)i * 2 + 1) * N + c];
     }
@@ -27,7 +43,15 @@ __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ par
   __syncthreads();
   s1 = 0.0; s2 = 0.0;
   if (r == 0) {
-    for (int q = 0; q < RSUB; ++q) { s1 += s_acc[q][threadIdx.x & 15][0]; s2 += s_acc[q][threadIdx.x & 15][1]; }
+    // same order of additions as a plain loop over q, but the LDS reads of eight subsets are issued before the first add (round 4:
+    // as a plain loop this tail was 64 dependent read -> add steps on the critical path of all 34 finalize launches of a step)
+    for (int q0 = 0; q0 < RSUB; q0 += 8) {
+      double v1[8], v2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v1[j] = s_acc[q0 + j][threadIdx.x & 15][0]; v2[j] = s_acc[q0 + j][threadIdx.x & 15][1]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1 += v1[j]; s2 += v2[j]; }
+    }
   }
 }
 // (Round 3 tried the RSUB subset sums as a shuffle / LDS tree with all of a thread's loads issued up front: the same 6 us under
@@ -49,6 +73,13 @@ __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restri
     if (counter_b) ++*counter_b;
   }
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
+  // (the per-channel parameters are requested BEFORE the reduction: their latency then overlaps the partials' instead of
+  //  following the sums on this launch's chain)
+  float g_ = 0.f, b_ = 0.f, cb_ = 0.f, rm_ = 0.f, rv_ = 0.f;
+  if (r == 0 && c < N) {
+    g_ = gamma[c]; b_ = beta[c];
+    if (running_mean) { cb_ = conv_bias ? conv_bias[c] : 0.f; rm_ = running_mean[c]; rv_ = running_var[c]; }
+  }
   double s1, s2;
   partial_sums_16x16(partial, nblk, N, c, r, s_acc, s1, s2);
   if (r != 0 || c >= N) return;
@@ -56,16 +87,15 @@ __global__ __launch_bounds__(RTPB) void bn_finalize_kernel(const float *__restri
   double var = s2 / count - mean * mean;
   var = var > 0.0 ? var : 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * rstd;
+  const float sc = g_ * rstd;
   scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
+  shift[c] = b_ - (float)mean * sc;
   mean_out[c] = (float)mean;
   rstd_out[c] = rstd;
   if (running_mean) {
-    const float b = conv_bias ? conv_bias[c] : 0.f;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mean + b);
+    running_mean[c] = (1.f - momentum) * rm_ + momentum * ((float)mean + cb_);
     const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_var[c] = (1.f - momentum) * rv_ + momentum * (float)unbiased;
   }
 }
 
@@ -277,14 +307,16 @@ __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__re
                                        float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
   __shared__ double s_acc[RSUB][16][2];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
+  float m_ = 0.f, rs_ = 0.f, g_ = 0.f;                  // (requested before the reduction, like bn_finalize_kernel's)
+  if (r == 0 && c < C) { m_ = mean[c]; rs_ = rstd[c]; g_ = gamma[c]; }
   double s1, s2;
   partial_sums_16x16(partial, nblk, C, c, r, s_acc, s1, s2);
   if (r != 0 || c >= C) return;
-  const double m = mean[c], rs = rstd[c];
+  const double m = m_, rs = rs_;
   const double dg = rs * (s2 - m * s1);
   dgamma[c] = (float)dg;
   dbeta[c] = (float)s1;
-  const double s = (double)gamma[c] * rs;
+  const double s = (double)g_ * rs;
   const double c2 = training ? -s * dg * rs / count : 0.0;
   const double c3 = training ? -s * s1 / count - c2 * m : 0.0;
   coef[c] = (float)s;
