@@ -16,24 +16,10 @@ __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ par
                                                    int r, double (*s_acc)[16][2], double &s1, double &s2) {
   double a1 = 0.0, a2 = 0.0;
   if (c < N) {
-    // (the step's launches leave at most 512 partial rows: a subset's <= 8 rows are requested together — as a loop unrolled by
-    //  four, the 342-448 rows of the large layers took two memory round trips — and added in the same order)
-    int i = r;
-    if (nblk <= 8 * RSUB) {
-      float p1[8], p2[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ii = r + j * RSUB, ic = ii < nblk ? ii : r < nblk ? r : 0;
-        p1[j] = partial[((size_t)ic * 2 + 0) * N + c];
-        p2[j] = partial[((size_t)ic * 2 + 1) * N + c];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (r + j * RSUB < nblk) { a1 += (double)p1[j]; a2 += (double)p2[j]; }
-      i = nblk;
-    }
+    // (measured and not kept: a subset's <= 8 partial rows all requested before the first addition — +8 us per step on the
+    //  same box, three-way A/B; the large layers' 342-448 rows are 6-7 iterations of this loop)
 #pragma unroll 4
-    for (; i < nblk; i += RSUB) {
+    for (int i = r; i < nblk; i += RSUB) {
       a1 += (double)partial[((size_t)i * 2 + 0) * N + c];
       a2 += (double)partial[((size_t)i * 2 + 1) * N + c];
     }
