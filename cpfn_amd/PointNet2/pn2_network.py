@@ -12,7 +12,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from .. import mlp
+from .. import autograd_ops, mlp
 from .pointnet2_ops.modules.pointset_abstraction import PointsetAbstraction
 from .pointnet2_ops.modules.pointset_feature_propagation import PointsetFeaturePropagation
 
@@ -135,14 +135,17 @@ class PointNet2(torch.nn.Module):
         gm = geometry if geometry is not None else {}
         cr = cuda_route
         l1_xyz, l1, self.aux_sa1 = self.sa1.forward_rows(xyz, feats0, s1, gm.get("sa1"), cr)
-        l2_xyz, l2, self.aux_sa2 = self.sa2.forward_rows(l1_xyz, l1, s2, gm.get("sa2"), cr)
+        # sa1's features have two consumers, sa2's grouping and sfp2's skip: their two gradients are added inside the grouping
+        # adjoint's launch instead of by a framework add between the two backward nodes (autograd_ops.SkipJoin)
+        join1 = autograd_ops.SkipJoin() if (l1.is_cuda and l1.dtype == torch.bfloat16 and torch.is_grad_enabled()) else None
+        l2_xyz, l2, self.aux_sa2 = self.sa2.forward_rows(l1_xyz, l1, s2, gm.get("sa2"), cr, join=join1)
         _, l3, _ = self.sa3.forward_rows(l2_xyz, l2)                       # [B,1,1024]
         if self.use_glob_features:
             l3 = torch.cat([l3, glob_features.unsqueeze(1).to(l3.dtype)], dim=2)
         if self.use_loc_features:
             l3 = torch.cat([l3, loc_features.unsqueeze(1).to(l3.dtype)], dim=2)
         l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3)
-        l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"), cr)
+        l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"), cr, join=join1)
         cd = getattr(self, "compute_dtype", torch.float32)
         # bf16 HIP path: fc1 + bn1 + relu + dropout run as the last layer of sfp3's fused stack
         chain = (cd == torch.bfloat16 and x.is_cuda and self.dropout_p > 0.0 and FUSED_DROPOUT

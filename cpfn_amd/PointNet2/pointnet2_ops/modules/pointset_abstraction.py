@@ -74,8 +74,9 @@ class PointsetAbstraction(nn.Module):
             out["inv"] = ops.csr_build(scales[0][0], N)
         return out
 
-    def forward_rows(self, xyz, feats, start_idx=None, geom=None, cuda_route=False):
-        """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux)."""
+    def forward_rows(self, xyz, feats, start_idx=None, geom=None, cuda_route=False, join=None):
+        """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux).
+        join: an autograd_ops.SkipJoin shared with the OTHER consumer of `feats` (a later feature-propagation level's skip)."""
         B, N, _ = xyz.shape
         aux = {}
         cd = getattr(self, "compute_dtype", torch.float32)
@@ -106,10 +107,10 @@ class PointsetAbstraction(nn.Module):
                         if fused_mlp.xyz_tail_ok(B * S * k, D, convs_of_scale[0].weight.shape[0]):
                             # long layers: the coordinates do not become three bf16 columns of a K = 192 operand — they
                             # reach the first layer as its fp32 xyz tail (cpfn_mlp_gemm_xyz) and the rows are the gather alone
-                            x = autograd_ops.GroupConcat.apply(feats, None, nbr, D, inv[0], inv[1])
+                            x = autograd_ops.GroupConcat.apply(feats, None, nbr, D, inv[0], inv[1], join)
                             groups.append((x, None, S, k, rel.reshape(B * S * k, 3)))
                             continue
-                        x = autograd_ops.GroupConcat.apply(feats, rel, nbr, (D + 3 + 63) // 64 * 64, inv[0], inv[1])
+                        x = autograd_ops.GroupConcat.apply(feats, rel, nbr, (D + 3 + 63) // 64 * 64, inv[0], inv[1], join)
                     else:
                         gf = autograd_ops.gather_rows(feats, nbr)                         # [B,S,K,D]
                         x = torch.cat([gf, rel.to(gf.dtype)], dim=3).reshape(B * S * k, -1)

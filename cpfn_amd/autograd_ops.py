@@ -49,16 +49,52 @@ def _scatter_bf16(g, ldg, idx, w, T, B, R, M, C):
     return out
 
 
-def _csr_sum_bf16(g, ldg, inv, w, T, B, R, M, C):
-    """Atomic-free adjoint through the inverse index `inv` = (offsets, entries): bf16 [B,M,C]."""
+def _csr_sum_bf16(g, ldg, inv, w, T, B, R, M, C, addend=None, ld_add=0):
+    """Atomic-free adjoint through the inverse index `inv` = (offsets, entries): bf16 [B,M,C].
+    addend (bf16 rows [B*M, ld_add]): the other gradient of a two-consumer tensor, added in the same launch (SkipJoin)."""
     out = torch.empty(B, M, C, dtype=torch.bfloat16, device=g.device)
     with torch.cuda.device(g.device):
-        _l.check(_l.lib().cpfn_csr_gather_sum_bf16(_ptr(g), ldg, _ptr(inv[0]), _ptr(inv[1]), _ptr(w), T, B, R, M, C, _ptr(out),
-                                                   _stream()), "cpfn_csr_gather_sum_bf16")
+        if addend is None:
+            _l.check(_l.lib().cpfn_csr_gather_sum_bf16(_ptr(g), ldg, _ptr(inv[0]), _ptr(inv[1]), _ptr(w), T, B, R, M, C, _ptr(out),
+                                                       _stream()), "cpfn_csr_gather_sum_bf16")
+        else:
+            _l.check(_l.lib().cpfn_csr_gather_sum_add_bf16(_ptr(g), ldg, _ptr(inv[0]), _ptr(inv[1]), _ptr(w), T, B, R, M, C,
+                                                           _ptr(addend), ld_add, _ptr(out), _stream()), "cpfn_csr_gather_sum_add_bf16")
     # compulsory: every source row once, the inverse index (+ weights), one bf16 row per target (the kernel re-reads a
     # source row once per (target, entry) pair it appears in: T times — that shows as traffic above this figure)
-    _l.add_bytes("cpfn_csr_gather_sum_bf16", 2 * B * R * C + 4 * B * R * T * (2 if w is not None else 1) + 4 * B * (M + 1) + 2 * B * M * C)
+    _l.add_bytes("cpfn_csr_gather_sum_bf16", 2 * B * R * C + 4 * B * R * T * (2 if w is not None else 1) + 4 * B * (M + 1) + 2 * B * M * C
+                 + (2 * B * M * C if addend is not None else 0))
     return out
+
+
+# A tensor with two consumers inside ONE forward pass gets its two gradients added by autograd's input buffer: a framework
+# bf16 add (5 us + a kernel boundary on the step's chain) between the two backward nodes.  Where the network's topology fixes
+# the order of those nodes — sa1's features feed sa2's grouping (GroupConcat) and sfp2's skip concatenation (ConcatInterp),
+# PointNet2/pn2_network.py:45-46,55, and sa2 is an ancestor of sfp2: ConcatInterp's backward always runs first — the first
+# node hands its gradient to the second through a SkipJoin (an object of that one forward pass, like fused_mlp.HandOver) and
+# returns None; the second adds it inside its own launch with the framework add's roundings (cpfn_csr_gather_sum_add_bf16:
+# bit-identical gradients, tests/test_gpu_network.py).  Armed only when both nodes saw the SAME tensor (address, in-place
+# version, shape); a gradient handed over and never picked up — a partial backward pass that stops above sa2 — raises at the
+# end of that backward pass instead of being lost.
+SKIP_JOIN = True
+
+
+class SkipJoin:
+    __slots__ = ("src", "armed", "addend")
+
+    def __init__(self):
+        self.src, self.armed, self.addend = None, False, None
+
+    @staticmethod
+    def key(t):
+        return (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+    def _unclaimed(self):
+        if self.addend is not None:
+            self.addend = None
+            raise RuntimeError("cpfn_amd: a skip connection's gradient was handed to the grouping adjoint (autograd_ops.SkipJoin) "
+                               "but that node did not run in this backward pass; set cpfn_amd.autograd_ops.SKIP_JOIN = False "
+                               "for partial backward passes")
 
 
 class InterpRowsBf16(torch.autograd.Function):
@@ -96,10 +132,14 @@ class GroupConcat(torch.autograd.Function):
     the coordinates then reach the first layer as its fp32 "xyz tail" (fused_mlp)."""
 
     @staticmethod
-    def forward(ctx, feats, rel, idx, cpad, inv_off=None, inv_ent=None):
+    def forward(ctx, feats, rel, idx, cpad, inv_off=None, inv_ent=None, join=None):
         B, N, C = feats.shape
         R = idx[0].numel()
         f = feats.contiguous()
+        ctx.join = None
+        if join is not None and SKIP_JOIN and inv_off is not None:
+            join.src, join.armed, join.addend = SkipJoin.key(f), False, None
+            ctx.join = join
         out = torch.empty(B * R, cpad, dtype=torch.bfloat16, device=f.device)
         with torch.cuda.device(f.device):
             _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), None if rel is None else _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
@@ -116,8 +156,13 @@ class GroupConcat(torch.autograd.Function):
         B, N, R, C, cpad = ctx.dims
         g = g.contiguous().to(torch.bfloat16)
         if ctx.inv is not None:
-            return _csr_sum_bf16(g, cpad, ctx.inv, None, 1, B, R, N, C), None, None, None, None, None
-        return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None, None, None
+            addend, ld_add = None, 0
+            j = ctx.join
+            if j is not None and j.addend is not None:
+                addend, ld_add = j.addend
+                j.addend = None
+            return _csr_sum_bf16(g, cpad, ctx.inv, None, 1, B, R, N, C, addend, ld_add), None, None, None, None, None, None
+        return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None, None, None, None
 
 
 class ConcatPosFeats(torch.autograd.Function):
@@ -147,10 +192,14 @@ class ConcatInterp(torch.autograd.Function):
     no slice copy —, the broadcast part is a column sum (cpfn_colsum_rows_bf16)."""
 
     @staticmethod
-    def forward(ctx, skip, feats, idx, w, inv_off=None, inv_ent=None):
+    def forward(ctx, skip, feats, idx, w, inv_off=None, inv_ent=None, join=None):
         B, N, C1 = skip.shape
         M, C2 = feats.shape[1], feats.shape[2]
         sk, f = skip.contiguous(), feats.contiguous()
+        ctx.join = None
+        if join is not None and SKIP_JOIN and join.src is not None and join.src == SkipJoin.key(sk) and (C1 + C2) % 8 == 0:
+            join.armed = True
+            ctx.join = join
         out = torch.empty(B, N, C1 + C2, dtype=torch.bfloat16, device=f.device)
         with torch.cuda.device(f.device):
             _l.check(_l.lib().cpfn_concat_interp_bf16(_ptr(sk), C1, _ptr(f), _ptr(idx), _ptr(w), B, M, N, C2, _ptr(out), _stream()),
@@ -168,6 +217,12 @@ class ConcatInterp(torch.autograd.Function):
         B, M, N, C1, C2 = ctx.dims
         g = g.contiguous().to(torch.bfloat16)
         g_skip, g_int = g[:, :, :C1], g[:, :, C1:]            # views: the consumers take the row stride
+        j = ctx.join
+        if j is not None and j.armed and ctx.needs_input_grad[0]:
+            # the skip tensor's other consumer (an ancestor: its backward node runs later) adds this gradient in its own launch
+            j.addend = (g, C1 + C2)
+            torch.autograd.Variable._execution_engine.queue_callback(j._unclaimed)
+            g_skip = None
         if idx is None:
             gf = torch.empty(B, 1, C2, dtype=torch.bfloat16, device=g.device)
             with torch.cuda.device(g.device):
@@ -177,7 +232,7 @@ class ConcatInterp(torch.autograd.Function):
             gf = _csr_sum_bf16(g_int, C1 + C2, ctx.inv, w, 3, B, N, M, C2)
         else:
             gf = _scatter_bf16(g_int, C1 + C2, idx, w, 3, B, N, M, C2).to(torch.bfloat16)
-        return g_skip, gf, None, None, None, None
+        return g_skip, gf, None, None, None, None, None
 
 
 def concat_interp_ok(skip, feats, idx):
@@ -187,10 +242,10 @@ def concat_interp_ok(skip, feats, idx):
             and feats.shape[2] % 8 == 0 and ((idx is None and feats.shape[1] == 1) or (idx is not None and feats.shape[1] <= 1024)))
 
 
-def concat_interp(skip, feats, idx=None, w=None, inv=None):
+def concat_interp(skip, feats, idx=None, w=None, inv=None, join=None):
     if inv is not None:
-        return ConcatInterp.apply(skip, feats, idx, w, inv[0], inv[1])
-    return ConcatInterp.apply(skip, feats, idx, w)
+        return ConcatInterp.apply(skip, feats, idx, w, inv[0], inv[1], join)
+    return ConcatInterp.apply(skip, feats, idx, w, None, None, join)
 
 
 def interp_rows(feats, idx, w, inv=None):

@@ -394,10 +394,15 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
 // traffic of the three launches was 1.94 x their bytes.
 constexpr int CS_LANES = 8;
 constexpr int CS_UNROLL = 4;
+// ADD (round 4): out = bf16(bf16(sum) + addend[b, m, :]) — the OTHER gradient of a tensor with two consumers (sa2's grouping and
+// sfp2's skip concatenation both read sa1's features) arrives as `addend` (bf16, row stride ld_add) and is added here with the
+// roundings of the framework's bf16 add that autograd's input buffer launched between the two backward nodes (5 us + a boundary).
+template <bool ADD>
 __global__ __launch_bounds__(TPB) void csr_gather_sum_kernel(const unsigned short *__restrict__ g, int ldg,
                                                              const int *__restrict__ offsets,
                                                              const int *__restrict__ entries,
                                                              const float *__restrict__ w, int T, int R, int M, int C,
+                                                             const unsigned short *__restrict__ addend, int ld_add,
                                                              unsigned short *__restrict__ out) {
   const int b = blockIdx.y;
   const int cpr = C / 8;
@@ -411,6 +416,8 @@ __global__ __launch_bounds__(TPB) void csr_gather_sum_kernel(const unsigned shor
   const float *wb = w ? w + (size_t)b * R * T : nullptr;
   const unsigned short *gb = g + (size_t)b * R * ldg + c0;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint4 add4 = make_uint4(0, 0, 0, 0);
+  if (ADD && live && q == 0) add4 = *(const uint4 *)(addend + ((size_t)b * M + m) * ld_add + c0);   // (in flight during the loop)
   const int i1 = live ? off[m + 1] : 0;
   int i = (live ? off[m] : 0) + q;
   for (; i < i1; i += CS_UNROLL * CS_LANES) {
@@ -436,8 +443,9 @@ __global__ __launch_bounds__(TPB) void csr_gather_sum_kernel(const unsigned shor
     for (int msk = 1; msk < CS_LANES; msk <<= 1) acc[j] += __shfl_xor(acc[j], msk);
   if (live && q == 0) {
     unsigned short o[8];
+    const unsigned short *ah = (const unsigned short *)&add4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = f2bf_(acc[j]);
+    for (int j = 0; j < 8; ++j) o[j] = ADD ? f2bf_(bf2f_(f2bf_(acc[j])) + bf2f_(ah[j])) : f2bf_(acc[j]);
     *(uint4 *)(out + ((size_t)b * M + m) * C + c0) = *(const uint4 *)o;
   }
 }
@@ -788,15 +796,27 @@ extern "C" int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets,
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets, const int *entries, const float *w,
-                                        int T, int B, int R, int M, int C, void *out, void *stream) {
-  if (B < 0 || R < 0 || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || ldg < C || T < 1 || !g || !offsets || !entries || !out)
+extern "C" int cpfn_csr_gather_sum_add_bf16(const void *g, int ldg, const int *offsets, const int *entries, const float *w,
+                                            int T, int B, int R, int M, int C, const void *addend, int ld_add, void *out,
+                                            void *stream) {
+  if (B < 0 || R < 0 || M <= 0 || C <= 0 || (C & 7) || (ldg & 7) || ldg < C || T < 1 || !g || !offsets || !entries || !out ||
+      (addend && ((ld_add & 7) || ld_add < C || ((uintptr_t)addend & 15))))
     return CPFN_EINVAL;
   if (B == 0) return 0;
   dim3 grid(cpfn_cdiv((long long)M * (C / 8) * CS_LANES, TPB), B);
-  csr_gather_sum_kernel<<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, offsets, entries, w, T, R, M,
-                                                               C, (unsigned short *)out);
+  if (addend)
+    csr_gather_sum_kernel<true><<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, offsets, entries, w, T, R, M,
+                                                                       C, (const unsigned short *)addend, ld_add,
+                                                                       (unsigned short *)out);
+  else
+    csr_gather_sum_kernel<false><<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, offsets, entries, w, T, R,
+                                                                        M, C, nullptr, 0, (unsigned short *)out);
   return cpfn_launch_status();
+}
+
+extern "C" int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets, const int *entries, const float *w,
+                                        int T, int B, int R, int M, int C, void *out, void *stream) {
+  return cpfn_csr_gather_sum_add_bf16(g, ldg, offsets, entries, w, T, B, R, M, C, nullptr, 0, out, stream);
 }
 
 static int multi_copy_impl(const cpfn_copy_desc *descs, int count, unsigned *flags, int flags_capacity, bool launch,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "cpfn_count_labels": [_vp, _i, _i, _vp, _vp],
     "cpfn_csr_build": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_csr_gather_sum_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "cpfn_csr_gather_sum_add_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     "cpfn_fit_num_chunks": [_i, _i],
     "cpfn_fit_moments_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_fit_moments_fwd_match": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],

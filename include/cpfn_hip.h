@@ -220,6 +220,12 @@ CPFN_API int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets, i
 CPFN_API int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets, const int *entries,
                                       const float *w, int T, int B, int R, int M, int C, void *out,
                                       void *stream);
+/* The same with the OTHER gradient of a two-consumer tensor added in: out = bf16(bf16(sum) + addend[b,m,:]) (addend bf16 with row
+ * stride ld_add, 16-byte aligned; NULL: the plain adjoint) — the roundings of the framework's bf16 add that autograd would launch
+ * between the two backward nodes (PointNet2/pn2_network.py:45-46,55: l1_feats feeds sa2 AND sfp2). */
+CPFN_API int cpfn_csr_gather_sum_add_bf16(const void *g, int ldg, const int *offsets, const int *entries,
+                                          const float *w, int T, int B, int R, int M, int C, const void *addend,
+                                          int ld_add, void *out, void *stream);
 
 /* ------------------------------------------------------------------ SPFN fitters
  * One pass over P[B,N,3], X[B,N,3] (unit normals), W[B,N,K] (soft memberships) yields every

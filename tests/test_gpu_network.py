@@ -421,3 +421,58 @@ def test_two_models_with_interleaved_backward_passes_match_their_solo_runs():
     # the same launches as the two solo runs together: no hand-over was refused
     both = {k: census_solo["g"].get(k, 0) + census_solo["l"].get(k, 0) for k in set(census_solo["g"]) | set(census_solo["l"])}
     assert census == both, sorted((k, census.get(k), both.get(k)) for k in set(census) | set(both) if census.get(k) != both.get(k))
+
+
+def test_skip_join_gives_the_gradients_of_the_framework_add(monkeypatch):
+    """sa1's features feed sa2's grouping AND sfp2's skip concatenation (PointNet2/pn2_network.py:45-46,55): autograd adds
+    their two gradients with a framework bf16 add between the two backward nodes.  autograd_ops.SkipJoin hands the skip's
+    gradient to the grouping adjoint instead, which adds it inside its own launch with the same roundings: every parameter
+    gradient of a training step must have the same bits both ways, and the framework add must be gone."""
+    from cpfn_amd import autograd_ops, lib as _l, synthetic
+    dev = torch.device("cuda:0")
+    batch = {k: v.to(dev) for k, v in synthetic.training_batch(2, N=2048, n_prims=6, n_inst_points=128, seed=3).items()}
+    starts = (torch.tensor([5, 17]), torch.tensor([1, 300]))
+    res, adds = {}, {}
+    for on in (True, False):
+        monkeypatch.setattr(autograd_ops, "SKIP_JOIN", on)
+        model = _fresh_model(28)
+        torch.manual_seed(5)
+        n_add = [0]
+
+        class Count(torch.utils._python_dispatch.TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                if func in (torch.ops.aten.add.Tensor, torch.ops.aten.add_.Tensor) and args[0].dtype == torch.bfloat16:
+                    n_add[0] += 1
+                return func(*args, **(kwargs or {}))
+        with Count():
+            res[on] = _step_grads(model, batch, starts, None)
+        adds[on] = n_add[0]
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    assert res[True][1] == res[False][1]
+    assert adds[True] == adds[False] - 1, adds
+
+
+def test_skip_join_raises_when_the_grouping_adjoint_never_runs():
+    """A gradient handed over and never picked up (a backward pass that stops above sa2's grouping) must not be lost silently."""
+    from cpfn_amd import autograd_ops
+    dev = torch.device("cuda:0")
+    B, N, C, S, k = 2, 512, 128, 128, 16
+    feats = torch.randn(B, N, C, device=dev).to(torch.bfloat16).requires_grad_(True)
+    idx = torch.randint(0, N, (B, S, k), device=dev, dtype=torch.int32)
+    from cpfn_amd import ops
+    inv = ops.csr_build(idx, N)
+    coarse = torch.randn(B, 1, 64, device=dev).to(torch.bfloat16).requires_grad_(True)
+    join = autograd_ops.SkipJoin()
+    f = feats * 1.0
+    grouped = autograd_ops.GroupConcat.apply(f, None, idx, C, inv[0], inv[1], join)
+    cat = autograd_ops.concat_interp(f, coarse, None, None, None, join)
+    assert join.armed
+    # complete backward pass: both nodes run, the sum arrives
+    (grouped.float().sum() + cat.float().sum()).backward(retain_graph=True)
+    ref = torch.autograd.grad(grouped.float().sum(), feats, retain_graph=True)[0].float() + 1.0
+    assert torch.allclose(feats.grad.float(), ref, atol=0.51, rtol=1e-2)
+    # partial backward pass: only the concatenation's branch
+    with pytest.raises(RuntimeError, match="SkipJoin"):
+        torch.autograd.grad(cat.float().sum(), feats, retain_graph=True)
+    assert join.addend is None
