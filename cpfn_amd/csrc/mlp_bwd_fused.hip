@@ -260,7 +260,21 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   };
   // the STEP x TK data-gradient slab of the PREVIOUS step leaves here (its LDS patch was completed before this step's
   // first barrier): NA 16-byte pieces per thread
+  // yb: the rows of the layer below's pre-BN output that match the slab of step d, which leaves at step d + 1.  They are requested
+  // IN FRONT of step d's prefetch.  (Until round 4 they were requested
+  // BEHIND the prefetch of step d + DEPTH: memory returns a wave's loads in order, so waiting for them half a step later drained
+  // the whole prefetch pipeline once per step — the four steps of rows in flight had half a step to arrive.  An ablation
+  // without the riding reduction ran 37 % faster for 19 % fewer bytes.  A second register set, requested a whole step ahead, is
+  // 6 % faster still when the kernel runs alone on HBM-resident operands and LOSES inside the step: 4-8 registers more per wave
+  // are what a one-pass launch cannot afford beside the geometry work)
   uint4 yb[NA];
+  auto issue_yb = [&](long long base) {
+    if (BST) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        yb[i] = *(const uint4 *)(Yb + min(base + arow + i * RPA, p1 - 1) * ldo + acol);
+    }
+  };
   auto store_prev = [&](long long pbase, int buf) {
     const unsigned short *s_o = s_o2[buf];
     if (!a_live) return;
@@ -318,12 +332,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
         stage(d, base, buf);
         __syncthreads();
       }
+      // (requested HERE, not right behind store_prev a staging phase earlier: the longer live range costs registers, and the
+      //  step beside the geometry work 30 us — same-box three-way comparison)
+      issue_yb(base);
       issue(d, base + STEP * DEPTH);
-      if (BST) {       // this step's slab, used one step later
-#pragma unroll
-        for (int i = 0; i < NA; ++i)
-          yb[i] = *(const uint4 *)(Yb + min(base + arow + i * RPA, p1 - 1) * ldo + acol);
-      }
       // ---- weight gradient: transposed fragments of both tiles (as mlp_wgrad_kernel), 32 rows per MFMA
 #pragma unroll
       for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -486,17 +498,19 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
                                                                             a_scale, a_shift, yb, b_scale, b_shift,       \
                                                                             stats_partial, ap, probe_slot_all(grid))
+  // (mode 3 — the layer's own fused dropout — is instantiated for the 128 -> 128 shape only: fc1 is the one layer that ends in it)
+  if (mode == 3 && !(N == 128 && K == 128)) return CPFN_EINVAL;
 #define CPFN_BWD_FUSED_SHAPE(TN_, TK_, STEP_)                                  \
   do {                                                                         \
     if (bwd_y) {                                                               \
       if (mode == 2) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 2);                 \
       else if (mode == 1) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 1);            \
-      else if (mode == 3) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 3);            \
+      else if (mode == 3) { if constexpr (TN_ == 128 && TK_ == 128) CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 3); }  \
       else CPFN_BWD_FUSED(TN_, TK_, STEP_, true, 0);                           \
     } else {                                                                   \
       if (mode == 2) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 2);                \
       else if (mode == 1) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 1);           \
-      else if (mode == 3) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 3);           \
+      else if (mode == 3) { if constexpr (TN_ == 128 && TK_ == 128) CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 3); } \
       else CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 0);                          \
     }                                                                          \
   } while (0)

@@ -707,7 +707,8 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
         if pool_k:
             step_rows = 32 if Kp >= 128 else 64                     # rows per step of the one-pass kernel for this shape
             return "one_pass", False, bool(FUSED_BWD_APPLY and pool_k % step_rows == 0 and pool_k <= 255 and Kp != 192)
-        return "one_pass", bool(FUSED_BWD_APPLY), False
+        # (the dropout form of the apply pass exists for the 128 -> 128 shape only: fc1 is the one layer that ends in the fused dropout)
+        return "one_pass", bool(FUSED_BWD_APPLY and (not dropout or (N == 128 and Kp == 128))), False
     small = (SMALL_BWD_FUSED and not pool_k and not dropout and bool(h.cpfn_mlp_wgrad_apply_ok(P, N, Kp))
              and (not need_dgrad or bool(h.cpfn_mlp_dgrad_small_ok(P, N, Kp))))
     if small:
