@@ -57,11 +57,15 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // bn_relu_bwd_kernel<true> does (that launch, 15 us on the fc1 features, is then not made).
   static_assert(!BDROP || (BST && APPLY == 0), "the layer below's dropout belongs to the riding reduction of a linear layer");
   const unsigned long long bdrop_seed = BDROP ? *ap.drop_seed : 0ull;
-  // (rows in flight: 128, and 64 for the 256-wide g_y — the same bytes, half the staging registers.  The 64-row-step shapes
+  // DEPTH = 2 steps of rows in flight for every shape (round 4; the 32-row-step shapes of 128 channels had four).  The riding
+  // reduction's rows (yb below) are consumed a step after they are requested, and loads return in order: whatever was requested
+  // before them — all but the newest prefetch — has to be there by then, so slots three and four never were in flight when it
+  // mattered; without them the 128 -> 128 instantiation needs 164 registers instead of 206 and the step is 7 us faster (same box).
+  // (rows in flight: 64 for the 32-row steps, 128 for the 64-row steps.  The 64-row-step shapes
   //  are NOT waiting for memory: taking 134 MB of the 64 -> 64 kernel's reads away (recomputing them) saved 2 us of 65, and 256 rows in
   //  flight instead of 128 made both of them 5 % slower (registers); their apply / statistics / conversion VALU work and
   //  LDS traffic per row are what a 64-channel row costs.)
-  constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = (WG_STEP * WG_DEPTH) / STEP / (TN > 128 ? 2 : 1), KSTEPS = STEP / 32;
+  constexpr int NT = 512, LDN = TN + 8, LDK = TK + 8, DEPTH = 2, KSTEPS = STEP / 32;
   constexpr int CPRG = TN / 8, CPRA = TK / 8;                 // 16-byte chunks per row of the TN- / TK-wide tensors
   constexpr int NG = STEP * CPRG / NT;                        // g_y chunks per thread and step
   // TK-wide tensors (input, data-gradient slab, y of the layer below): RPA rows per pass, TA of the 512 threads busy
