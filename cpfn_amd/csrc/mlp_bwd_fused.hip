@@ -2,6 +2,10 @@
 // the BatchNorm-backward reduction of the layer below).  See mlp_fwd.hip for the data layout.
 #include "mlp_common.h"
 
+#ifndef CPFN_BWD_COEF32
+#define CPFN_BWD_COEF32 1
+#endif
+
 namespace {
 
 // ---------------------------------------------------------------- weight gradient + data gradient in one pass
@@ -131,10 +135,16 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // the <128,128> kernel needs 237, and two such waves plus a 56-register wave of the geometry branch do not fit one SIMD)
   // (64-row-step shapes — sa1, after the geometry work has ended, bound by VALU + LDS issue rather than memory — keep them
   //  in registers: 10 LDS reads per stage less)
-  constexpr bool COEF_REGS = APPLY != 0 && STEP == 64;
-  __shared__ __attribute__((aligned(16))) float s_cf[APPLY && !COEF_REGS ? 5 * TN : 4];
+  // (round 4: with two steps of rows in flight the dense 128 -> 128 apply instantiation has the registers too — 164 + 40 —; its
+  //  vectors go through LDS once, COEF_VIA_LDS: forty 4-byte global loads per lane in the prologue cost more than they saved)
+  constexpr bool COEF_VIA_LDS = CPFN_BWD_COEF32 && APPLY == 1 && STEP == 32 && TN <= 128;
+  constexpr bool COEF_REGS = APPLY != 0 && (STEP == 64 || COEF_VIA_LDS);
+  __shared__ __attribute__((aligned(16))) float s_cf[APPLY && (!COEF_REGS || COEF_VIA_LDS) ? 5 * TN : 4];
   float cfr[COEF_REGS ? 5 : 1][8];
-  if (COEF_REGS) {
+  if (COEF_VIA_LDS) {
+    for (int e = t; e < 3 * TN; e += NT) s_cf[e] = ap.coef[e];
+    if (t < TN) { s_cf[3 * TN + t] = ap.y_scale[t]; s_cf[4 * TN + t] = ap.y_shift[t]; }
+  } else if (COEF_REGS) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       cfr[0][j] = ap.coef[gcol + j]; cfr[1][j] = ap.coef[TN + gcol + j]; cfr[2][j] = ap.coef[2 * TN + gcol + j];
@@ -311,6 +321,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue(d, p0 + (long long)d * STEP);
   fill_w_panel<TK, LDN, NT>(s_wt, W, TN, TK, 0, 0, TN, 1, t);      // s_wt[k_out][n]: the forward weight [n][k] transposed
+  if (COEF_VIA_LDS) {
+    __syncthreads();
+#pragma unroll
+    for (int v5 = 0; v5 < 5; ++v5) {
+      *(float4 *)&cfr[COEF_REGS ? v5 : 0][0] = *(const float4 *)&s_cf[v5 * TN + gcol];
+      *(float4 *)&cfr[COEF_REGS ? v5 : 0][4] = *(const float4 *)&s_cf[v5 * TN + gcol + 4];
+    }
+  }
   long long prev = -1;
   for (long long base0 = p0; base0 < p1; base0 += STEP * DEPTH) {
 #pragma unroll
