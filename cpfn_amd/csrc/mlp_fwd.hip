@@ -41,11 +41,15 @@ __device__ __forceinline__ void stream_load_a(bf16x8 (&af)[2][KS], __amdgpu_buff
 }
 
 
+#ifndef CPFN_STREAM_TWOBUF
+#define CPFN_STREAM_TWOBUF 1
+#endif
 struct StreamBufs {
   __amdgpu_buffer_rsrc_t a, y, yb;       // operand rows, output rows, (BST) pre-BN output of the layer below
   unsigned aoff[2];                      // lane byte offset of its two operand rows inside a tile
   unsigned yoff;                         // lane byte offset of its first output piece inside a tile
   unsigned a_tile, y_tile, y_step;       // bytes per 128-row tile of A / Y, bytes between a lane's output pieces
+  unsigned a_oob;                        // an offset past the end of A (lane offsets added to it do not wrap: the host's 2^32 bound)
 };
 
 // XT ("xyz tail", sa2's first layer: 128 gathered feature channels + the 3 centred coordinates of the neighbour): the
@@ -99,7 +103,7 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
       acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, x1, acc[nt][1], 0, 0, 0);
     }
     // the next tile's coordinates (clamped rows: a tile past the end is never used)
-    const int pn = (next_tile * G_ROWS) + wave * 32 + lr, pa = min(pn, P - 1), pb = min(pn + 16, P - 1);
+    const int pn = (max(next_tile, 0) * G_ROWS) + wave * 32 + lr, pa = min(pn, P - 1), pb = min(pn + 16, P - 1);   // (no next tile: any valid rows)
 #pragma unroll
     for (int q = 0; q < 3; ++q) { xz[0][q] = xyz[(size_t)pa * 3 + q]; xz[1][q] = xyz[(size_t)pb * 3 + q]; }
     // (the barrier keeps the K loop's weight-fragment reads from being hoisted up here — with them the kernel spills; placed
@@ -132,7 +136,9 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   // requested before the MFMAs of tile t): 268 registers for the plain 128-wide variant and 454-490 with the
   // statistics — one wave per SIMD, so a CU held ONE workgroup and its load / compute / store phases overlapped
   // with nothing.  Occupancy, not a deeper per-wave pipeline, is what hides the latency here.
-  stream_load_a<KS>(af, sb.a, sb.aoff, (unsigned)next_tile * sb.a_tile);
+  // (a next tile that is not this workgroup's — next_tile < 0 — is requested past the end of the buffer: zeros, no traffic;
+  //  until round 4 every workgroup also fetched the first tile of its neighbour: 1.17 x the launch's bytes in the counters)
+  stream_load_a<KS>(af, sb.a, sb.aoff, next_tile < 0 ? sb.a_oob : (unsigned)next_tile * sb.a_tile);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   sb.aoff[1] = sb.aoff[0] + 16u * lda * 2u;
   sb.yoff = ((unsigned)(wave * 32 + lane / CPR) * ldy + n0 + (lane % CPR) * 8) * 2u;
   sb.a_tile = (unsigned)G_ROWS * lda * 2u;
+  sb.a_oob = ((unsigned)(P - 1) * lda + K) * 2u;
   sb.y_tile = (unsigned)G_ROWS * ldy * 2u;
   sb.y_step = (unsigned)(64 / CPR) * ldy * 2u;
   const int ntiles = (P + G_ROWS - 1) / G_ROWS;
@@ -271,11 +278,28 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     }
     fill_w_panel<BN, 32 * KS + 8>(s_w, W, K, N, n0, 0, K, w_trans, t);
     __syncthreads();
+    // TWO operand buffers for the operand-transform instantiations (every hidden layer's forward launch; round 4): with one,
+    // the rows of tile t + 1 are requested after the MFMAs of tile t and have its epilogue (~1.5 us) to arrive — less than a
+    // loaded memory round trip, so each of a workgroup's ~3 tiles exposed part of its latency (the plain kernel without its
+    // stores: 10.8 us for 33.5 MB of loads).  With two, tile t + 2 is requested after the MFMAs of tile t and has a whole tile.
+    // Round 1 had two buffers at 268-490 registers (64 running sums of the statistics); now the pair costs 32 of ~180.
+    constexpr bool TWOBUF = CPFN_STREAM_TWOBUF && ATR && !XT && !BST;
+    if (TWOBUF) {
+      bf16x8 b[2][KS];
+      stream_load_a<KS>(b, sb.a, sb.aoff, tile0 + 1 < tile_end ? (unsigned)(tile0 + 1) * sb.a_tile : sb.a_oob);
+      for (int tile = tile0; tile < tile_end; tile += 2) {
+        stream_tile<BN, KS, STATS, ATR, BST, XT>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 2 < tile_end ? tile + 2 : -1, wave, lane,
+                                                 st_s, st_q, s_ss, s_bs, s_wx, xz, xyz);
+        if (tile + 1 < tile_end)
+          stream_tile<BN, KS, STATS, ATR, BST, XT>(b, s_w, s_o[wave], sb, P, (tile + 1) * G_ROWS, tile + 3 < tile_end ? tile + 3 : -1, wave,
+                                                   lane, st_s, st_q, s_ss, s_bs, s_wx, xz, xyz);
+      }
+    } else
     for (int tile = tile0; tile < tile_end; ++tile) {
       // the reload inside is unconditional (a tile past the end is out of the buffer's range: zeros, no traffic), so
       // the loop body is straight-line
-      stream_tile<BN, KS, STATS, ATR, BST, XT>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1, wave, lane, st_s, st_q, s_ss, s_bs,
-                                               s_wx, xz, xyz);
+      stream_tile<BN, KS, STATS, ATR, BST, XT>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1 < tile_end ? tile + 1 : -1, wave, lane,
+                                               st_s, st_q, s_ss, s_bs, s_wx, xz, xyz);
     }
   }
   if (STATS || BST) {
