@@ -52,13 +52,11 @@ class PointsetAbstraction(nn.Module):
         """FPS + the sampled centres: (fps_idx [B,S] i32, new_xyz [B,S,3])."""
         B, N, _ = xyz.shape
         if cuda_route:          # always from index 0 (sampling_gpu.cu:76-77); a caller's start indices do not apply
-            sel = ops.fps(xyz, self.num_points, None, skip_near_origin=True)
-        else:
-            if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
-                start_idx = torch.randint(0, N, (B,), dtype=torch.long)
-            start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
-            sel = ops.fps(xyz, self.num_points, start_idx)
-        return sel, ops.gather_rows(xyz, sel)
+            return ops.fps_centres(xyz, self.num_points, None, skip_near_origin=True)
+        if start_idx is None:   # the reference's CPU route draws the start here (geometry_utils.py:92)
+            start_idx = torch.randint(0, N, (B,), dtype=torch.long)
+        start_idx = start_idx.to(device=xyz.device, dtype=torch.int32)
+        return ops.fps_centres(xyz, self.num_points, start_idx)      # (indices + the centres themselves: one launch)
 
     def neighbours(self, xyz, sampled, cuda_route=False, need_inverse=True):
         """Ball-query neighbours, centred neighbour coordinates and the inverse index for sample()'s centres."""

@@ -28,8 +28,9 @@ class PointsetFeaturePropagation(nn.Module):
         """3-NN indices and inverse-distance weights (coordinates only; prefetchable).
         cuda_route: what the reference's `fast=True` gives — direct distances and their SQUARE ROOTS
         (geometry_utils.py:184), so the weights are 1/(d + 1e-8) instead of the CPU route's 1/(d² + 1e-8)."""
-        d2, nn_idx = ops.three_nn(xyz1, xyz2, cuda_route=cuda_route, sqrt=cuda_route)   # CPU route: squared distances
-        out = {"nn_idx": nn_idx, "nn_w": ops.three_weights(d2)}             # 1/(d+1e-8), normalised (ref :40-42)
+        # CPU route: squared distances; the weights 1/(d+1e-8), normalised (ref :40-42), leave the same launch
+        _, nn_idx, nn_w = ops.three_nn_weights(xyz1, xyz2, cuda_route=cuda_route, sqrt=cuda_route)
+        out = {"nn_idx": nn_idx, "nn_w": nn_w}
         if need_inverse and xyz2.shape[1] <= 2048:                          # (evaluation never runs the adjoint: one
             out["inv"] = ops.csr_build(nn_idx, xyz2.shape[1])               #  393216-entry sort per 131072-point cloud, 3.2 ms)
         #                                                                     for the atomic-free interpolation adjoint

@@ -145,7 +145,7 @@ template <bool DIRECT, int NNT = NN_THREADS>
 __global__ __launch_bounds__(NNT) void three_nn_kernel(const float *__restrict__ unknown,
                                                               const float *__restrict__ known, int N, int M,
                                                               float *__restrict__ dist2, int *__restrict__ idx,
-                                                              int sqrt_out) {
+                                                              int sqrt_out, float *__restrict__ w_out = nullptr) {
   __shared__ float4 s_known[NN_TILE];
   const int b = blockIdx.y;
   const int i = blockIdx.x * NNT + threadIdx.x;
@@ -209,6 +209,12 @@ __global__ __launch_bounds__(NNT) void three_nn_kernel(const float *__restrict__
     }
     od[0] = d0; od[1] = d1; od[2] = d2;
     oi[0] = i0; oi[1] = i1; oi[2] = i2;
+    if (w_out) {      // three_weights_kernel's arithmetic on the three distances just stored (one launch less per interpolation)
+      const float a = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f)), bq = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f)), c = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+      const float sm = __fadd_rn(__fadd_rn(a, bq), c);
+      float *ow = w_out + ((size_t)b * N + i) * 3;
+      ow[0] = __fdiv_rn(a, sm); ow[1] = __fdiv_rn(bq, sm); ow[2] = __fdiv_rn(c, sm);
+    }
   }
 }
 
@@ -223,7 +229,7 @@ template <bool DIRECT>
 __global__ __launch_bounds__(NN_THREADS) void three_nn_quad_kernel(const float *__restrict__ unknown,
                                                                    const float *__restrict__ known, int N, int M,
                                                                    float *__restrict__ dist2, int *__restrict__ idx,
-                                                                   int sqrt_out) {
+                                                                   int sqrt_out, float *__restrict__ w_out = nullptr) {
   __shared__ float4 s_known[NN_TILE];
   const int b = blockIdx.y;
   const int sub = threadIdx.x & 3;
@@ -293,6 +299,12 @@ __global__ __launch_bounds__(NN_THREADS) void three_nn_quad_kernel(const float *
     }
     od[0] = d0; od[1] = d1; od[2] = d2;
     oi[0] = i0; oi[1] = i1; oi[2] = i2;
+    if (w_out) {      // three_weights_kernel's arithmetic on the three distances just stored (one launch less per interpolation)
+      const float a = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f)), bq = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f)), c = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+      const float sm = __fadd_rn(__fadd_rn(a, bq), c);
+      float *ow = w_out + ((size_t)b * N + i) * 3;
+      ow[0] = __fdiv_rn(a, sm); ow[1] = __fdiv_rn(bq, sm); ow[2] = __fdiv_rn(c, sm);
+    }
   }
 }
 #undef CPFN_NN_DIST
@@ -383,18 +395,26 @@ extern "C" int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, in
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_three_nn(const float *unknown, const float *known, int B, int N, int M, float *dist2,
-                             int *idx, void *stream) {
+extern "C" int cpfn_three_nn_weights(const float *unknown, const float *known, int B, int N, int M, int direct, int sqrt_out,
+                                     float *dist2, int *idx, float *w, void *stream) {
   if (B < 0 || N < 0 || M < 0 || !unknown || !known || !dist2 || !idx) return CPFN_EINVAL;
   if (B == 0 || N == 0) return 0;
-  if (M >= 64 && !cpfn_background_geometry()) {
-    three_nn_quad_kernel<false><<<dim3(cpfn_cdiv(N, NN_THREADS / 4), B), NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M,
-                                                                                                      dist2, idx, 0);
-    return cpfn_launch_status();
+  hipStream_t st = (hipStream_t)stream;
+  const bool quad = M >= 64 && !cpfn_background_geometry();
+  const dim3 grid(cpfn_cdiv(N, quad ? NN_THREADS / 4 : NN_THREADS), B);
+  if (direct) {
+    if (quad) three_nn_quad_kernel<true><<<grid, NN_THREADS, 0, st>>>(unknown, known, N, M, dist2, idx, sqrt_out, w);
+    else three_nn_kernel<true><<<grid, NN_THREADS, 0, st>>>(unknown, known, N, M, dist2, idx, sqrt_out, w);
+  } else {
+    if (quad) three_nn_quad_kernel<false><<<grid, NN_THREADS, 0, st>>>(unknown, known, N, M, dist2, idx, 0, w);
+    else three_nn_kernel<false><<<grid, NN_THREADS, 0, st>>>(unknown, known, N, M, dist2, idx, 0, w);
   }
-  dim3 grid(cpfn_cdiv(N, NN_THREADS), B);
-  three_nn_kernel<false><<<grid, NN_THREADS, 0, (hipStream_t)stream>>>(unknown, known, N, M, dist2, idx, 0);
   return cpfn_launch_status();
+}
+
+extern "C" int cpfn_three_nn(const float *unknown, const float *known, int B, int N, int M, float *dist2,
+                             int *idx, void *stream) {
+  return cpfn_three_nn_weights(unknown, known, B, N, M, 0, 0, dist2, idx, nullptr, stream);
 }
 
 extern "C" int cpfn_three_nn_direct(const float *unknown, const float *known, int B, int N, int M, int sqrt_out,

@@ -174,7 +174,8 @@ template <int NT, int PPT, bool PROFILE = false>
 __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restrict__ xyz, int N, int S,
                                                           const int *__restrict__ start, int flags,
                                                           int *__restrict__ idx_out,
-                                                          unsigned long long *__restrict__ prof = nullptr) {
+                                                          unsigned long long *__restrict__ prof = nullptr,
+                                                          float *__restrict__ centres = nullptr /* [B,S,3]: xyz[idx_out] */) {
   constexpr int NW = NT / CPFN_WAVE;
   static_assert(PPT % 2 == 0, "points sit in registers as pairs");
   __shared__ float s_x[NT * PPT], s_y[NT * PPT], s_z[NT * PPT];   // three b32 broadcasts per sample, NOT one float4:
@@ -212,6 +213,10 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
     if (PROFILE) t0 = fps_stamp();
     if (t == 0) out[i] = (int)far;
     if (NW == 1 && i > 0) { fx = s_x[far]; fy = s_y[far]; fz = s_z[far]; }
+    if (centres && t == 0) {          // the sampled centre itself (what a gather of xyz by idx_out would read: one launch less per level)
+      float *c = centres + ((size_t)b * S + i) * 3;
+      c[0] = fx; c[1] = fy; c[2] = fz;
+    }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[0] += t1 - t0; t0 = t1; }      // (one wave: broadcast read of the sample)
     const float lm = fps_update<PPT>(px, py, pz, md, fx, fy, fz);
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[1] += t1 - t0; t0 = t1; }      // distance update + lane maximum
@@ -471,15 +476,30 @@ extern "C" int cpfn_fps_faults(void) {
   return (int)n;
 }
 
+static int fps_launch(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out, float *scratch,
+                      float *centres, hipStream_t st);
+
 extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out,
                         float *scratch, void *stream) {
+  return fps_launch(xyz, B, N, S, start, flags, idx_out, scratch, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cpfn_fps_max_resident(void) { return CPFN_FPS_MAX_RESIDENT; }
+
+extern "C" int cpfn_fps_centres(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out,
+                                float *centres, void *stream) {
+  if (N > CPFN_FPS_MAX_RESIDENT || !centres) return CPFN_EINVAL;      // (the one-workgroup-per-cloud kernels only)
+  return fps_launch(xyz, B, N, S, start, flags, idx_out, nullptr, centres, (hipStream_t)stream);
+}
+
+static int fps_launch(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out, float *scratch,
+                      float *centres, hipStream_t st) {
   if (B < 0 || N <= 0 || S < 0 || !xyz || (!idx_out && B * S > 0)) return CPFN_EINVAL;
   if (B == 0 || S == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   if (N <= 512) {
-    fps_resident_kernel<64, 8><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out);
+    fps_resident_kernel<64, 8><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
   } else if (N <= 2048) {
-    fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out);
+    fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
   } else if (N <= CPFN_FPS_MAX_RESIDENT) {
     // 8192 points on ONE CU either way (a sample is a VALU-throughput phase over the cloud plus two key reductions):
     // (with ds_bpermute key reductions) 16 waves x 8 points per lane took 670 us for 512 samples, 8 waves x 16 points 572 us,
@@ -488,9 +508,9 @@ extern "C" int cpfn_fps(const float *xyz, int B, int N, int S, const int *start,
     // Beside a training step (one workgroup per cloud on 16 CUs for the whole forward pass) the FEWER waves the better
     // for the step: 1.871 ms with 16 waves, 1.855 with 8, 1.849 with 4 (interleaved A/B on one box each).
     if (cpfn_background_geometry())
-      fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out);
+      fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
     else
-      fps_resident_kernel<512, 16><<<B, 512, 0, st>>>(xyz, N, S, start, flags, idx_out);
+      fps_resident_kernel<512, 16><<<B, 512, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
   } else {
     if (!scratch) return CPFN_EINVAL;
     // several workgroups per cloud while all of them can be resident together and the key layout holds

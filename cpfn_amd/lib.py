@@ -19,10 +19,13 @@ SIGNATURES = {
     "cpfn_abi_version": [],
     "cpfn_build_info": [],
     "cpfn_fps": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "cpfn_fps_centres": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "cpfn_fps_max_resident": [],
     "cpfn_fps_faults": [],
     "cpfn_fps_profile": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "cpfn_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "cpfn_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_three_nn_weights": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_ball_query_direct": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "cpfn_set_background_geometry": [_i],
     "cpfn_pack_xyzn": [_vp, _i, _i, _vp, _vp], "cpfn_ball_query_packed": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],

@@ -98,6 +98,26 @@ def fps(xyz, num_samples, start=None, skip_near_origin=False):
     return out
 
 
+def fps_centres(xyz, num_samples, start=None, skip_near_origin=False):
+    """fps + the sampled centres xyz[b, idx] (what select_point_subset gathers right after the sampling,
+    pointset_abstraction.py:50) -> (idx [B,S] i32, centres [B,S,3] f32).  One launch for clouds the one-workgroup-per-cloud
+    kernels take (N <= 8192: they hold every sample's coordinates anyway); sampling + gather_rows beyond."""
+    _chk(xyz, "xyz", torch.float32)
+    B, N, _ = xyz.shape
+    if N > _l.lib().cpfn_fps_max_resident():
+        idx = fps(xyz, num_samples, start, skip_near_origin)
+        return idx, gather_rows(xyz, idx)
+    if start is not None:
+        _chk(start, "start", torch.int32)
+    out = torch.empty(B, num_samples, dtype=torch.int32, device=xyz.device)
+    ctr = torch.empty(B, num_samples, 3, dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        _l.check(_l.lib().cpfn_fps_centres(_ptr(xyz), B, N, int(num_samples), _ptr(start), 1 if skip_near_origin else 0, _ptr(out),
+                                           _ptr(ctr), _stream()), "cpfn_fps_centres")
+    _l.add_bytes("cpfn_fps", 12 * B * N + 16 * B * int(num_samples))
+    return out, ctr
+
+
 def ball_query(new_xyz, xyz, radius, nsample, cuda_route=False):
     """new_xyz [B,S,3], xyz [B,N,3] -> idx [B,S,K] i32 (argument order of the
     reference's cuda_ops.ball_query, ball_query.cpp).  cuda_route: the CUDA kernel's direct
@@ -145,6 +165,24 @@ def three_nn(unknown, known, cuda_route=False, sqrt=False):
                      "cpfn_three_nn")
     _l.add_bytes("cpfn_three_nn", 12 * B * (N + M) + 24 * B * N)
     return d, i
+
+
+def three_nn_weights(unknown, known, cuda_route=False, sqrt=False):
+    """three_nn + three_weights of the distances it returns in ONE launch -> (dist [B,N,3], idx [B,N,3] i32, w [B,N,3])."""
+    _chk(unknown, "unknown", torch.float32)
+    _chk(known, "known", torch.float32)
+    if sqrt and not cuda_route:
+        raise RuntimeError("sqrt distances exist on the CUDA route only")
+    B, N, _ = unknown.shape
+    M = known.shape[1]
+    d = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
+    i = torch.empty(B, N, 3, dtype=torch.int32, device=unknown.device)
+    w = torch.empty(B, N, 3, dtype=torch.float32, device=unknown.device)
+    with torch.cuda.device(unknown.device):
+        _l.check(_l.lib().cpfn_three_nn_weights(_ptr(unknown), _ptr(known), B, N, M, 1 if cuda_route else 0, 1 if sqrt else 0,
+                                                _ptr(d), _ptr(i), _ptr(w), _stream()), "cpfn_three_nn_weights")
+    _l.add_bytes("cpfn_three_nn", 12 * B * (N + M) + 36 * B * N)
+    return d, i, w
 
 
 def pairwise_sqdist(src, dst):

@@ -63,6 +63,12 @@ CPFN_API const char *cpfn_build_info(void);
 #define CPFN_FPS_SKIP_NEAR_ORIGIN 1
 CPFN_API int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, int flags,
              int *idx_out, float *scratch, void *stream);
+/* cpfn_fps for N <= cpfn_fps_max_resident() that also writes the sampled centres, centres[B,S,3] = xyz[b, idx_out[b,s], :] — what
+ * select_point_subset (modules/geometry_utils.py:26-44) gathers right after the sampling (pointset_abstraction.py:50): one launch less
+ * per set-abstraction level. */
+CPFN_API int cpfn_fps_centres(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out,
+                              float *centres, void *stream);
+CPFN_API int cpfn_fps_max_resident(void);
 /* Clouds for which the several-workgroups FPS (8192 < N) gave up waiting for a sibling workgroup since the library was
  * loaded; their remaining samples are index 0.  0 in a healthy process.  Synchronises the device; < 0 on error. */
 CPFN_API int cpfn_fps_faults(void);
@@ -91,6 +97,10 @@ CPFN_API int cpfn_ball_query(const float *xyz, const float *new_xyz, int B, int 
  * M < 3 leaves +inf / M in the unused slots. */
 CPFN_API int cpfn_three_nn(const float *unknown, const float *known, int B, int N, int M,
                   float *dist2, int *idx, void *stream);
+/* cpfn_three_nn (direct == 0) / cpfn_three_nn_direct (direct != 0) and, when w is not NULL, cpfn_three_weights on the distances
+ * they return, in the same launch (pointset_feature_propagation.py:38-42). */
+CPFN_API int cpfn_three_nn_weights(const float *unknown, const float *known, int B, int N, int M, int direct, int sqrt_out,
+                                   float *dist2, int *idx, float *w, void *stream);
 
 /* CUDA-route twins (the reference's `fast=True` results; opt-in, see DESIGN.md "CUDA route").
  * cpfn_ball_query_direct: ball_query_gpu.cu:9-44 — d2 = (q-p)^2 summed over x,y,z, kept iff

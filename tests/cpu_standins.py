@@ -43,6 +43,16 @@ def gather_rows(rows, idx):
     return out.reshape(tuple(idx.shape) + (C,))
 
 
+def fps_centres(xyz, num_samples, start=None, skip_near_origin=False):
+    idx = fps(xyz, num_samples, start, skip_near_origin)
+    return idx, gather_rows(xyz, idx)
+
+
+def three_nn_weights(unknown, known, cuda_route=False, sqrt=False):
+    d, i = three_nn(unknown, known, cuda_route, sqrt)
+    return d, i, three_weights(d)
+
+
 def scatter_add_rows(grad_out, idx, N):
     B, C = grad_out.shape[0], grad_out.shape[-1]
     flat = idx.reshape(B, -1).long()
@@ -69,7 +79,7 @@ def csr_build(idx, M):
     return torch.zeros(B, M + 1, dtype=torch.int32), torch.zeros(B, idx[0].numel(), dtype=torch.int32)
 
 
-_NAMES = ("fps", "ball_query", "three_nn", "three_weights", "gather_rows", "scatter_add_rows", "group_xyz_centered",
+_NAMES = ("fps", "fps_centres", "ball_query", "three_nn", "three_nn_weights", "three_weights", "gather_rows", "scatter_add_rows", "group_xyz_centered",
           "interp_rows_fwd", "interp_rows_bwd", "csr_build")
 
 

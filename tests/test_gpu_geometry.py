@@ -415,3 +415,48 @@ def test_random_shapes_sweep_vs_oracle():
             assert np.array_equal(ops.three_weights(d).cpu().numpy().view(np.uint32), og.three_weights(od).view(np.uint32)), ("w", tag)
         else:       # fewer than 3 known points: the first S slots are defined (the reference's sort would fail here)
             assert np.array_equal(i.cpu().numpy()[..., :S], oi.astype(np.int32)[..., :S]), ("3nn idx", tag)
+
+
+@pytest.mark.parametrize("B,N,S", [(3, 300, 64), (2, 2048, 512), (2, 8192, 512), (1, 5000, 37)])
+@pytest.mark.parametrize("background", [False, True])
+def test_fps_centres_equals_sampling_then_gather(B, N, S, background):
+    """cpfn_fps_centres: the sampling kernels also write the centres they hold anyway — bit for bit what cpfn_fps followed by
+    a gather of xyz gives (pointset_abstraction.py:49-50), in both kernel shapes (critical path / beside a training step)."""
+    from cpfn_amd import ops
+    g = torch.Generator().manual_seed(N + S)
+    xyz = torch.randn(B, N, 3, generator=g).cuda()
+    start = torch.randint(0, N, (B,), generator=g).to(torch.int32).cuda()
+    import contextlib
+    with (ops.background_geometry() if background else contextlib.nullcontext()):
+        idx0 = ops.fps(xyz, S, start)
+        idx1, ctr = ops.fps_centres(xyz, S, start)
+        idx2, ctr2 = ops.fps_centres(xyz, S, None, skip_near_origin=True)
+        idx3 = ops.fps(xyz, S, None, skip_near_origin=True)
+    assert torch.equal(idx0, idx1) and torch.equal(idx2, idx3)
+    assert torch.equal(ctr, ops.gather_rows(xyz, idx0)) and torch.equal(ctr2, ops.gather_rows(xyz, idx3))
+
+
+def test_fps_centres_on_large_clouds_falls_back_to_two_launches():
+    from cpfn_amd import ops
+    g = torch.Generator().manual_seed(1)
+    xyz = torch.randn(1, 20000, 3, generator=g).cuda()
+    start = torch.tensor([7], dtype=torch.int32).cuda()
+    idx, ctr = ops.fps_centres(xyz, 64, start)
+    assert torch.equal(idx, ops.fps(xyz, 64, start)) and torch.equal(ctr, ops.gather_rows(xyz, idx))
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 8192, 512), (3, 512, 128), (2, 1000, 37), (1, 131, 3)])
+@pytest.mark.parametrize("background", [False, True])
+@pytest.mark.parametrize("cuda_route", [False, True])
+def test_three_nn_weights_equals_three_nn_then_three_weights(B, N, M, background, cuda_route):
+    """cpfn_three_nn_weights: distances, indices AND the normalised inverse-distance weights (pointset_feature_propagation.py:38-42)
+    from one launch, bit for bit what the two launches give — lane-per-query and four-lanes-per-query kernels, both routes."""
+    from cpfn_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + M)
+    u, k = torch.randn(B, N, 3, generator=g).cuda(), torch.randn(B, M, 3, generator=g).cuda()
+    import contextlib
+    with (ops.background_geometry() if background else contextlib.nullcontext()):
+        d0, i0 = ops.three_nn(u, k, cuda_route=cuda_route, sqrt=cuda_route)
+        w0 = ops.three_weights(d0)
+        d1, i1, w1 = ops.three_nn_weights(u, k, cuda_route=cuda_route, sqrt=cuda_route)
+    assert torch.equal(d0, d1) and torch.equal(i0, i1) and torch.equal(w0, w1)
