@@ -64,8 +64,8 @@ class PointsetAbstraction(nn.Module):
         sel, new_xyz = sampled
         scales = []
         for r, k in zip(self.radius_list, self.num_samples_list):
-            nbr = ops.ball_query(new_xyz, xyz, r, k, cuda_route=cuda_route)               # [B,S,K] i32
-            scales.append((nbr, ops.group_xyz_centered(xyz, new_xyz, nbr)))               # rel [B,S,K,3] fp32
+            # neighbours [B,S,K] i32 and their centred coordinates rel [B,S,K,3] fp32 (one launch beside a training step)
+            scales.append(ops.ball_query_rel(new_xyz, xyz, r, k, cuda_route=cuda_route))
         out = {"fps_idx": sel, "new_xyz": new_xyz, "scales": scales}
         if need_inverse and self.has_feats and N <= 2048 and len(scales) == 1:
             # inverse of the neighbour index: atomic-free, deterministic adjoint of the feature gather

@@ -37,7 +37,7 @@ __global__ void pack_xyzn_kernel(const float *__restrict__ xyz, long long R, flo
 template <bool DIRECT, int BQW = BQ_WAVES, bool PACKED = false>
 __global__ __launch_bounds__(BQW *CPFN_WAVE) void ball_query_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, int B, int N, int S, float thr, int K,
-    int *__restrict__ idx_out) {
+    int *__restrict__ idx_out, float *__restrict__ rel_out = nullptr /* [B,S,K,3]: xyz[idx] - centre (group_xyz_centered) */) {
   const int lane = threadIdx.x & (CPFN_WAVE - 1);
   // (grid-stride over the queries: the host may launch fewer workgroups than queries / 4 — see cpfn_ball_query)
   for (long long q = (long long)blockIdx.x * BQW + (threadIdx.x / CPFN_WAVE); q < (long long)B * S;
@@ -54,8 +54,9 @@ __global__ __launch_bounds__(BQW *CPFN_WAVE) void ball_query_kernel(
   for (int base = 0; base < N && cnt < K; base += CPFN_WAVE) {
     const int n = base + lane;
     bool keep = false;
+    float x = 0.f, y = 0.f, z = 0.f;
     if (n < N) {
-      float x, y, z, pn;
+      float pn;
       if (PACKED) {
         const float4 v = ((const float4 *)p)[n];
         x = v.x; y = v.y; z = v.z; pn = v.w;
@@ -74,11 +75,28 @@ __global__ __launch_bounds__(BQW *CPFN_WAVE) void ball_query_kernel(
     if (mask) {
       if (cnt == 0) first = base + __builtin_ctzll(mask);
       const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-      if (keep && pos < K) out[pos] = n;
+      if (keep && pos < K) {
+        out[pos] = n;
+        if (rel_out) {           // the kept neighbour's centred coordinates: the lane holds them (group_xyz_centered's subtraction)
+          float *r = rel_out + ((size_t)q * K + pos) * 3;
+          r[0] = __fsub_rn(x, qx); r[1] = __fsub_rn(y, qy); r[2] = __fsub_rn(z, qz);
+        }
+      }
       cnt += __popcll(mask);
     }
   }
   if (cnt > K) cnt = K;
+  if (rel_out && cnt + lane < K) {           // padding slots: the first kept neighbour again (an empty ball: index N, read as N - 1)
+    const int fi = first < 0 ? 0 : (first >= N ? N - 1 : first);
+    float x, y, z;
+    if (PACKED) { const float4 v = ((const float4 *)p)[fi]; x = v.x; y = v.y; z = v.z; }
+    else { x = p[3 * fi]; y = p[3 * fi + 1]; z = p[3 * fi + 2]; }
+    const float rx = __fsub_rn(x, qx), ry = __fsub_rn(y, qy), rz = __fsub_rn(z, qz);
+    for (int k = cnt + lane; k < K; k += CPFN_WAVE) {
+      float *r = rel_out + ((size_t)q * K + k) * 3;
+      r[0] = rx; r[1] = ry; r[2] = rz;
+    }
+  }
   for (int k = cnt + lane; k < K; k += CPFN_WAVE) out[k] = first;
   }
 }
@@ -371,14 +389,19 @@ extern "C" int cpfn_pack_xyzn(const float *xyz, int B, int N, float *out, void *
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_ball_query_packed(const float *xyzn, const float *new_xyz, int B, int N, int S, float thr, int K,
-                                      int *idx_out, void *stream) {
+extern "C" int cpfn_ball_query_packed_rel(const float *xyzn, const float *new_xyz, int B, int N, int S, float thr, int K,
+                                          int *idx_out, float *rel_out, void *stream) {
   if (B < 0 || N <= 0 || S < 0 || K <= 0 || !xyzn || !new_xyz || !idx_out || ((uintptr_t)xyzn & 15)) return CPFN_EINVAL;
   const long long Q = (long long)B * S;
   if (Q == 0) return 0;
   ball_query_kernel<false, BQ_WAVES, true><<<bq_grid(Q), BQ_WAVES * CPFN_WAVE, 0, (hipStream_t)stream>>>(
-      xyzn, new_xyz, B, N, S, thr, K, idx_out);
+      xyzn, new_xyz, B, N, S, thr, K, idx_out, rel_out);
   return cpfn_launch_status();
+}
+
+extern "C" int cpfn_ball_query_packed(const float *xyzn, const float *new_xyz, int B, int N, int S, float thr, int K,
+                                      int *idx_out, void *stream) {
+  return cpfn_ball_query_packed_rel(xyzn, new_xyz, B, N, S, thr, K, idx_out, nullptr, stream);
 }
 
 extern "C" int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, int B, int N, int S, float radius, int K,

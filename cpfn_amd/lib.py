@@ -29,6 +29,7 @@ SIGNATURES = {
     "cpfn_ball_query_direct": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "cpfn_set_background_geometry": [_i],
     "cpfn_pack_xyzn": [_vp, _i, _i, _vp, _vp], "cpfn_ball_query_packed": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "cpfn_ball_query_packed_rel": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "cpfn_three_nn_direct": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "cpfn_pairwise_sqdist": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "cpfn_three_weights": [_vp, _i64, _vp, _vp],

@@ -118,6 +118,28 @@ def fps_centres(xyz, num_samples, start=None, skip_near_origin=False):
     return out, ctr
 
 
+def ball_query_rel(new_xyz, xyz, radius, nsample, cuda_route=False):
+    """ball_query + group_xyz_centered -> (idx [B,S,K] i32, rel [B,S,K,3] f32 = xyz[idx] - new_xyz).  Beside a training step
+    (background_geometry; the wave-per-query kernel on the packed cloud) ONE launch: a lane that keeps a neighbour holds its
+    coordinates."""
+    _chk(new_xyz, "new_xyz", torch.float32)
+    _chk(xyz, "xyz", torch.float32)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    if cuda_route or not (_background[0] and N >= 512):
+        idx = ball_query(new_xyz, xyz, radius, nsample, cuda_route=cuda_route)
+        return idx, group_xyz_centered(xyz, new_xyz, idx)
+    out = torch.empty(B, S, int(nsample), dtype=torch.int32, device=xyz.device)
+    rel = torch.empty(B, S, int(nsample), 3, dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        packed = torch.empty(B, N, 4, dtype=torch.float32, device=xyz.device)
+        _l.check(_l.lib().cpfn_pack_xyzn(_ptr(xyz), B, N, _ptr(packed), _stream()), "cpfn_pack_xyzn")
+        _l.check(_l.lib().cpfn_ball_query_packed_rel(_ptr(packed), _ptr(new_xyz), B, N, S, ball_query_threshold(radius),
+                                                     int(nsample), _ptr(out), _ptr(rel), _stream()), "cpfn_ball_query_packed_rel")
+    _l.add_bytes("cpfn_ball_query", 12 * B * (N + S) + 16 * B * S * int(nsample))
+    return out, rel
+
+
 def ball_query(new_xyz, xyz, radius, nsample, cuda_route=False):
     """new_xyz [B,S,3], xyz [B,N,3] -> idx [B,S,K] i32 (argument order of the
     reference's cuda_ops.ball_query, ball_query.cpp).  cuda_route: the CUDA kernel's direct

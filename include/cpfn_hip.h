@@ -117,6 +117,10 @@ CPFN_API int cpfn_three_nn_weights(const float *unknown, const float *known, int
 CPFN_API int cpfn_pack_xyzn(const float *xyz, int B, int N, float *out, void *stream);
 CPFN_API int cpfn_ball_query_packed(const float *xyzn, const float *new_xyz, int B, int N, int S, float thr, int K,
                                     int *idx_out, void *stream);
+/* ... and, when rel_out is not NULL, the centred coordinates of the neighbours it returns, rel_out[B,S,K,3] = xyz[idx] - new_xyz
+ * (cpfn_group_xyz_centered; pointset_abstraction.py:62-63) from the same launch. */
+CPFN_API int cpfn_ball_query_packed_rel(const float *xyzn, const float *new_xyz, int B, int N, int S, float thr, int K,
+                                        int *idx_out, float *rel_out, void *stream);
 /* on != 0: the following cpfn_fps / cpfn_ball_query* / cpfn_three_nn* calls run BESIDE other work (a side stream next to a
  * training step) and use the kernel shapes that disturb their neighbours least; 0 (default): the fastest kernels.  Same
  * results, bit for bit.  Returns the previous setting.  (Process-wide; no reference counterpart.) */

@@ -48,6 +48,11 @@ def fps_centres(xyz, num_samples, start=None, skip_near_origin=False):
     return idx, gather_rows(xyz, idx)
 
 
+def ball_query_rel(new_xyz, xyz, radius, nsample, cuda_route=False):
+    idx = ball_query(new_xyz, xyz, radius, nsample, cuda_route)
+    return idx, group_xyz_centered(xyz, new_xyz, idx)
+
+
 def three_nn_weights(unknown, known, cuda_route=False, sqrt=False):
     d, i = three_nn(unknown, known, cuda_route, sqrt)
     return d, i, three_weights(d)
@@ -79,7 +84,7 @@ def csr_build(idx, M):
     return torch.zeros(B, M + 1, dtype=torch.int32), torch.zeros(B, idx[0].numel(), dtype=torch.int32)
 
 
-_NAMES = ("fps", "fps_centres", "ball_query", "three_nn", "three_nn_weights", "three_weights", "gather_rows", "scatter_add_rows", "group_xyz_centered",
+_NAMES = ("fps", "fps_centres", "ball_query", "ball_query_rel", "three_nn", "three_nn_weights", "three_weights", "gather_rows", "scatter_add_rows", "group_xyz_centered",
           "interp_rows_fwd", "interp_rows_bwd", "csr_build")
 
 

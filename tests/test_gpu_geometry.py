@@ -460,3 +460,22 @@ def test_three_nn_weights_equals_three_nn_then_three_weights(B, N, M, background
         w0 = ops.three_weights(d0)
         d1, i1, w1 = ops.three_nn_weights(u, k, cuda_route=cuda_route, sqrt=cuda_route)
     assert torch.equal(d0, d1) and torch.equal(i0, i1) and torch.equal(w0, w1)
+
+
+@pytest.mark.parametrize("B,N,S,K,r", [(2, 8192, 512, 64, 0.2), (3, 512, 128, 64, 0.4), (2, 777, 99, 32, 0.3), (1, 600, 40, 16, 0.01)])
+@pytest.mark.parametrize("background", [False, True])
+def test_ball_query_rel_equals_ball_query_then_centred_grouping(B, N, S, K, r, background):
+    """ball_query_rel: neighbours AND their centred coordinates (pointset_abstraction.py:59-63) — beside a training step from ONE
+    launch, bit for bit what ball_query + group_xyz_centered give;
+    padded slots and empty balls (radius 0.01) included."""
+    from cpfn_amd import ops
+    import contextlib
+    g = torch.Generator().manual_seed(N + K)
+    xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1).cuda()
+    start = torch.randint(0, N, (B,), generator=g).to(torch.int32).cuda()
+    with (ops.background_geometry() if background else contextlib.nullcontext()):
+        sel, ctr = ops.fps_centres(xyz, S, start)
+        idx0 = ops.ball_query(ctr, xyz, r, K)
+        rel0 = ops.group_xyz_centered(xyz, ctr, idx0)
+        idx1, rel1 = ops.ball_query_rel(ctr, xyz, r, K)
+    assert torch.equal(idx0, idx1) and torch.equal(rel0, rel1)
