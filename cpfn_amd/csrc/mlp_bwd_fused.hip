@@ -80,11 +80,14 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   constexpr int CHB = TK / 16, TPW = (STEP / 16) * CHB / 8;   // 16-channel blocks of the data-gradient slab, its tiles per wave
   static_assert(NG >= 1 && NA >= 1 && TA <= NT && (WG_STEP * WG_DEPTH) % (STEP * DEPTH) == 0 && (STEP / 16) * CHB == 8 * TPW, "shape");
   static_assert(!BST || (64 % CPRA == 0), "the riding reduction needs a power-of-two chunk count per row");
-  // DB (the 64-row-step shapes: sa1, bound by VALU + LDS issue rather than memory, and run after the geometry work, so
-  // their LDS footprint is free): the three row tiles are double-buffered by step parity, which leaves ONE barrier per step
+  // DB (the 64-row-step shapes: sa1, run after the geometry work, so their LDS footprint is free): the three row tiles are
+  // double-buffered by step parity, which leaves ONE barrier per step
   // (stage -> barrier -> store previous slab / MFMAs) instead of two — the waves may drift a step apart and the VALU-heavy
   // staging of one overlaps the LDS / MFMA phase of another.
-  constexpr bool DB = STEP == 64;
+  // (round 4: the 128 -> 128 shapes too.  Round 2 measured nothing for them — their steps were then paced by the drained prefetch
+  //  pipeline, §9 — and their 87-90 KB would not have fitted beside the inverse-index build's 80 KB of that time (64 KB now); with
+  //  the drain gone: 34.5 -> 32.5 us stand-alone, -9 us per step.  The 256-channel shape stays at two barriers: 141 KB.)
+  constexpr bool DB = STEP == 64 || (STEP == 32 && TN == 128 && TK == 128);
   static_assert(!DB || DEPTH % 2 == 0, "the buffer of a step is its pipeline slot's parity");
   __shared__ __attribute__((aligned(16))) unsigned short s_g2[DB ? 2 : 1][STEP * LDN];
   __shared__ __attribute__((aligned(16))) unsigned short s_a2[DB ? 2 : 1][STEP * LDK];
