@@ -16,8 +16,10 @@ __device__ __forceinline__ void partial_sums_16x16(const float *__restrict__ par
                                                    int r, double (*s_acc)[16][2], double &s1, double &s2) {
   double a1 = 0.0, a2 = 0.0;
   if (c < N) {
-    // (measured and not kept: a subset's <= 8 partial rows all requested before the first addition — +8 us per step on the
-    //  same box, three-way A/B; the large layers' 342-448 rows are 6-7 iterations of this loop)
+    // (measured and not kept, twice: a subset's <= 8 partial rows all requested before the first addition — with clamped row
+    //  numbers +8 us per step, with masked loads (no traffic for rows that do not exist) +31 us, same-box A/B both; the large
+    //  layers' 342-448 rows are 6-7 iterations of this loop, a batch of four and a remainder loop that takes a round trip per
+    //  row, and that is the faster form)
 #pragma unroll 4
     for (int i = r; i < nblk; i += RSUB) {
       a1 += (double)partial[((size_t)i * 2 + 0) * N + c];
