@@ -129,7 +129,9 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
     }
     // keep the k-steps apart: left alone the scheduler hoists all 32 weight-fragment reads (and the operand
     // transform of every k-step) in front of the first MFMA, which costs >100 registers
-    if (ATR) __builtin_amdgcn_sched_barrier(0);
+    // (round 4: for every instantiation — the plain ones sat at 254 registers, two of their workgroups filled a CU's register
+    //  file and nothing of the next batch's geometry could share a SIMD with them; fenced: 94-170.  GlobalSPFN step +-0, LocalSPFN -6 us)
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ONE operand buffer: the next tile's rows are requested as soon as the MFMAs have consumed this one's, and fly
   // during the epilogue below (statistics, LDS staging, stores).  The first version kept two buffers (tile t+1
