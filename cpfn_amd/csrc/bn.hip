@@ -289,10 +289,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DROP ? 3 : 
 
 // dβ = Σg_z, dγ = rstd·(Σg_z·y − mean·Σg_z);  g_y = s·g_z + c2·y + c3 with
 // s = γ·rstd, c2 = −s·dγ·rstd/count, c3 = −s·dβ/count − c2·mean  (training-mode batch norm).
-__global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
-                                       const float *__restrict__ gamma, const float *__restrict__ mean,
-                                       const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const float *__restrict__ partial, int nblk, int C, float count,
+                                                     const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
+                                                     float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
   __shared__ double s_acc[RSUB][16][2];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
   float m_ = 0.f, rs_ = 0.f, g_ = 0.f;                  // (requested before the reduction, like bn_finalize_kernel's)
@@ -310,6 +310,12 @@ __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__re
   coef[c] = (float)s;
   coef[C + c] = (float)c2;
   coef[2 * C + c] = (float)c3;
+}
+__global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
+                                       const float *__restrict__ gamma, const float *__restrict__ mean,
+                                       const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
+  bn_bwd_finalize_body(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef);
 }
 
 // g_y[p,c] = s·g_z + c2·y + c3   (dense).  Gy may alias Gz.
@@ -425,18 +431,23 @@ __global__ __launch_bounds__(16 * RS) void split_reduce_kernel(const float *__re
 // whole backward pass leave their split partials behind and are finished together at its end (19 launches of
 // ~7 us each, all latency, become one).  blockIdx -> (buffer, 64-element group) through prefix sums.
 constexpr int MSR_MAX = 32;
-struct MsrArgs {
-  const float *partial[MSR_MAX];
-  float *out[MSR_MAX];
-  long long n[MSR_MAX];
-  int splits[MSR_MAX];
-  int row_in[MSR_MAX], row_out[MSR_MAX];   // 0, 0: flat; else only the first row_out of every row_in elements are kept
-  int out_ld[MSR_MAX];                     // ... at row stride out_ld of the output (>= row_out; a slice of a wider matrix)
-  int deep[MSR_MAX];           // 1: few outputs, many splits: 16 elements x 16 split-subsets per workgroup instead of 64 x 4; 2: wide
-  int block0[MSR_MAX + 1];     // first workgroup of buffer i
+constexpr int MSR_RIDE_MAX = 6;      // buffers that may ride on one bn_bwd_finalize launch (bn_bwd_finalize_ride_kernel)
+template <int MAXB>
+struct MsrArgsT {
+  const float *partial[MAXB];
+  float *out[MAXB];
+  long long n[MAXB];
+  int splits[MAXB];
+  int row_in[MAXB], row_out[MAXB];   // 0, 0: flat; else only the first row_out of every row_in elements are kept
+  int out_ld[MAXB];                  // ... at row stride out_ld of the output (>= row_out; a slice of a wider matrix)
+  int deep[MAXB];              // 1: few outputs, many splits: 16 elements x 16 split-subsets per workgroup instead of 64 x 4; 2: wide
+  int block0[MAXB + 1];        // first workgroup of buffer i
   int count;
 };
-__global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
+typedef MsrArgsT<MSR_MAX> MsrArgs;
+// (the body of multi_split_reduce_kernel for workgroup `bid` of the launch described by `a`; 256 lanes)
+template <class ARGS>
+__device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
   // 64 consecutive elements x 4 split-subsets per workgroup: 256-byte coalesced rows of the partial buffers.  "deep"
   // buffers (the 192 outputs x 1024 partials of the fp32-xyz layer, the 35 x 512 of the heads' bias: three / one workgroup
   // walking 256 / 128 rows each was a 20 us serial tail of this launch, which is why they had their own launches): 16 x 16.
@@ -446,14 +457,14 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
   // r, r + 4, ...; then (s0 + s1) + (s2 + s3)), so mode 2 is bit-identical to mode 0.
   __shared__ __attribute__((aligned(16))) float s_acc[16][64];
   int d = 0;
-  while (d + 1 < a.count && (int)blockIdx.x >= a.block0[d + 1]) ++d;
+  while (d + 1 < a.count && bid >= a.block0[d + 1]) ++d;
   const float *__restrict__ partial = a.partial[d];
   const long long n = a.n[d];
   const int splits = a.splits[d];
   if (a.deep[d] == 2) {
     float4 (*s4)[64] = (float4 (*)[64])s_acc;          // [4 subsets][64 lanes] float4 = 4 KB
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
-    const long long e = ((long long)(blockIdx.x - a.block0[d]) * 64 + lane) * 4;
+    const long long e = ((long long)(bid - a.block0[d]) * 64 + lane) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e < n) {
       const float *src = partial + e;
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
   const bool deep = a.deep[d] != 0;
   const int epw = deep ? 16 : 64, nsub = deep ? 16 : 4;
   const int lane = deep ? (threadIdx.x & 15) : (threadIdx.x & 63), r = deep ? (threadIdx.x >> 4) : (threadIdx.x >> 6);
-  const long long e = (long long)(blockIdx.x - a.block0[d]) * epw + lane;
+  const long long e = (long long)(bid - a.block0[d]) * epw + lane;
   float acc = 0.f;
   if (e < n) {
 #pragma unroll 4
@@ -519,6 +530,26 @@ __global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) {
       if (col < a.row_out[d]) a.out[d][row * a.out_ld[d] + col] = v;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) { msr_body(a, (int)blockIdx.x); }
+
+// bn_bwd_finalize with split reductions RIDING on it (round 4).  The 17 finalize launches of a backward pass are eight-odd
+// workgroups each on an otherwise idle chip, and the weight-gradient partials of the layer ABOVE were written by the launch before
+// them: reduced here, as further workgroups of the same launch (the first 256 lanes of a 1024-lane workgroup run msr_body), they are
+// read while they are still in the infinity cache instead of ~250 MB from HBM in one launch at the end of the pass.
+typedef MsrArgsT<MSR_RIDE_MAX> MsrRideArgs;
+__global__ __launch_bounds__(RTPB) void bn_bwd_finalize_ride_kernel(const float *__restrict__ partial, int nblk, int C, float count,
+                                                                    const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                                    const float *__restrict__ rstd, int training,
+                                                                    float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                                    float *__restrict__ coef, int nfin, MsrRideArgs a) {
+  if ((int)blockIdx.x >= nfin) {
+    if (threadIdx.x >= 256) return;           // (waves that have ended do not count at the body's barrier)
+    msr_body(a, (int)blockIdx.x - nfin);
+    return;
+  }
+  bn_bwd_finalize_body(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef);
 }
 
 // ---------------------------------------------------------------- fp32 small-K first layer (sa1: K = 3)
@@ -928,28 +959,53 @@ extern "C" int cpfn_colsum_f32(const float *X, long long P, int C, float *worksp
   return cpfn_launch_status();
 }
 
+template <class ARGS>
+static int msr_fill(ARGS &a, const cpfn_reduce_desc *descs, int count, int *blocks_out) {
+  a.count = count;
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    const cpfn_reduce_desc &d = descs[i];
+    if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0 || d.row_in < 0 || d.row_out < 0 || d.row_out > d.row_in || (d.out_ld != 0 && (d.row_in == 0 || d.out_ld < d.row_out)) ||
+        (d.row_in > 0 && (d.row_out == 0 || d.n % d.row_in))) return CPFN_EINVAL;
+    a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
+    a.row_in[i] = d.row_in; a.row_out[i] = d.row_out;
+    a.out_ld[i] = d.out_ld > 0 ? d.out_ld : d.row_out;
+    a.deep[i] = d.n <= 1024 && d.splits >= 128;
+    if (!a.deep[i] && d.n >= 4096 && d.n % 4 == 0 && (((uintptr_t)d.partial | (d.row_in == 0 ? (uintptr_t)d.out : 0)) & 15) == 0)
+      a.deep[i] = 2;          // wide: float4 per lane (same order of additions as the 64 x 4 layout)
+    a.block0[i] = blocks;
+    blocks += cpfn_cdiv(d.n, a.deep[i] == 2 ? 256 : a.deep[i] ? 16 : 64);
+  }
+  a.block0[count] = blocks;
+  *blocks_out = blocks;
+  return 0;
+}
+
 extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count, void *stream) {
   if (count < 0 || (count > 0 && !descs)) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < count; base += MSR_MAX) {
     MsrArgs a;
-    a.count = count - base < MSR_MAX ? count - base : MSR_MAX;
     int blocks = 0;
-    for (int i = 0; i < a.count; ++i) {
-      const cpfn_reduce_desc &d = descs[base + i];
-      if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0 || d.row_in < 0 || d.row_out < 0 || d.row_out > d.row_in || (d.out_ld != 0 && (d.row_in == 0 || d.out_ld < d.row_out)) ||
-          (d.row_in > 0 && (d.row_out == 0 || d.n % d.row_in))) return CPFN_EINVAL;
-      a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
-      a.row_in[i] = d.row_in; a.row_out[i] = d.row_out;
-      a.out_ld[i] = d.out_ld > 0 ? d.out_ld : d.row_out;
-      a.deep[i] = d.n <= 1024 && d.splits >= 128;
-      if (!a.deep[i] && d.n >= 4096 && d.n % 4 == 0 && (((uintptr_t)d.partial | (d.row_in == 0 ? (uintptr_t)d.out : 0)) & 15) == 0)
-        a.deep[i] = 2;          // wide: float4 per lane (same order of additions as the 64 x 4 layout)
-      a.block0[i] = blocks;
-      blocks += cpfn_cdiv(d.n, a.deep[i] == 2 ? 256 : a.deep[i] ? 16 : 64);
-    }
-    a.block0[a.count] = blocks;
+    const int rc = msr_fill(a, descs + base, count - base < MSR_MAX ? count - base : MSR_MAX, &blocks);
+    if (rc) return rc;
     if (blocks) multi_split_reduce_kernel<<<blocks, 256, 0, st>>>(a);
   }
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_bwd_finalize_ride(const float *partial, int nblk, int C, float count, const float *gamma, const float *mean,
+                                         const float *rstd, int training, float *dgamma, float *dbeta, float *coef,
+                                         const cpfn_reduce_desc *descs, int ndesc, void *stream) {
+  if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef || ndesc < 0 || ndesc > MSR_RIDE_MAX ||
+      (ndesc > 0 && !descs))
+    return CPFN_EINVAL;
+  MsrRideArgs a;
+  int blocks = 0;
+  const int rc = msr_fill(a, descs, ndesc, &blocks);
+  if (rc) return rc;
+  const int nfin = cpfn_cdiv(C, 16);
+  bn_bwd_finalize_ride_kernel<<<nfin + blocks, RTPB, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd, training,
+                                                                              dgamma, dbeta, coef, nfin, a);
   return cpfn_launch_status();
 }

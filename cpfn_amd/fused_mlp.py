@@ -181,6 +181,17 @@ def _flush_reductions():
     _l.add_bytes("cpfn_multi_split_reduce", sum(4 * n * (splits + 1) for _, _, n, splits, _, _, _ in todo))
 
 
+# REDUCE_RIDE: queued reductions do not all wait for the end of the pass — every bn_bwd_finalize launch of the backward pass takes
+# along what has been queued by then (cpfn_bn_bwd_finalize_ride); the end-of-pass launch finishes the rest.  Same arithmetic.
+REDUCE_RIDE = True
+
+
+def _take_pending_reductions(max_n):
+    global _pending_reduce
+    take, _pending_reduce = _pending_reduce[:max_n], _pending_reduce[max_n:]
+    return take
+
+
 def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0, params=(), out_ld=0):
     """Queue `out[n] = sum over splits of ws[splits][n]`; runs at the end of the current backward pass.
     row_in / row_out: the partial rows have row_in elements of which `out` (compact) keeps the first row_out;
@@ -561,9 +572,20 @@ class _FusedStack(torch.autograd.Function):
                     _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(Y), _ptr(st[0]), _ptr(st[1]), P, N, None, _ptr(part), _ptr(dseed), dp,
                                               _stream()), "cpfn_bn_relu_bwd")
                     _l.add_bytes("cpfn_bn_relu_bwd", 4 * P * N + 8 * nblk * N)
-                _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
-                                              1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
-                       "cpfn_bn_bwd_finalize")
+                riders = _take_pending_reductions(6) if REDUCE_RIDE else []
+                if riders:
+                    # the weight-gradient partials queued so far (the launch before this one wrote them) are reduced by further
+                    # workgroups of the finalize launch: read out of the infinity cache now instead of from HBM at the end of the pass
+                    arr = (_ReduceDesc * len(riders))(*[_ReduceDesc(ws_.data_ptr(), out_.data_ptr(), n_, sp_, ri_, ro_, old_)
+                                                        for ws_, out_, n_, sp_, ri_, ro_, old_ in riders])
+                    _check(h.cpfn_bn_bwd_finalize_ride(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
+                                                       1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), arr, len(riders),
+                                                       _stream()), "cpfn_bn_bwd_finalize_ride")
+                    _l.add_bytes("cpfn_multi_split_reduce", sum(4 * n_ * (sp_ + 1) for _, _, n_, sp_, _, _, _ in riders))
+                else:
+                    _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
+                                                  1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
+                           "cpfn_bn_bwd_finalize")
                 _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                 grads[3 * li + 1] = dgb[0]
                 grads[3 * li + 2] = dgb[1]

@@ -449,6 +449,11 @@ typedef struct { const float *partial; float *out; long long n; int splits;
                                          matrix, e.g. the 128 feature columns and the 3 coordinate columns of one [N,131] weight) */
 } cpfn_reduce_desc;
 CPFN_API int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs /* HOST array */, int count, void *stream);
+/* cpfn_bn_bwd_finalize with up to 6 such reductions riding on the same launch as further workgroups (the weight-gradient partials
+ * the launch before it left: read while still in the infinity cache instead of at the end of the backward pass). */
+CPFN_API int cpfn_bn_bwd_finalize_ride(const float *partial, int nblk, int C, float count, const float *gamma, const float *mean,
+                                       const float *rstd, int training, float *dgamma, float *dbeta, float *coef,
+                                       const cpfn_reduce_desc *descs /* HOST array */, int ndesc, void *stream);
 CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,

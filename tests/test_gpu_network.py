@@ -476,3 +476,41 @@ def test_skip_join_raises_when_the_grouping_adjoint_never_runs():
     with pytest.raises(RuntimeError, match="SkipJoin"):
         torch.autograd.grad(cat.float().sum(), feats, retain_graph=True)
     assert join.addend is None
+
+
+def test_split_reductions_riding_on_the_finalize_launches_are_bit_identical(monkeypatch):
+    """fused_mlp.REDUCE_RIDE: the queued weight-gradient split reductions leave with the bn_bwd_finalize launches of the backward
+    pass (cpfn_bn_bwd_finalize_ride) instead of all waiting for its end — the same arithmetic per buffer: every parameter gradient
+    of a training step must have the same bits both ways, and most of the reduction must really have moved."""
+    from cpfn_amd import fused_mlp, lib as _l, synthetic
+    dev = torch.device("cuda:0")
+    batch = {k: v.to(dev) for k, v in synthetic.training_batch(2, N=2048, n_prims=6, n_inst_points=128, seed=3).items()}
+    starts = (torch.tensor([5, 17]), torch.tensor([1, 300]))
+    h = _l.lib()
+    seen = {"ride": 0, "riders": 0, "tail": 0}
+    o_ride, o_tail = h.cpfn_bn_bwd_finalize_ride, h.cpfn_multi_split_reduce
+
+    def spy_ride(*a):
+        seen["ride"] += 1
+        seen["riders"] += a[12]
+        return o_ride(*a)
+
+    def spy_tail(*a):
+        seen["tail"] += a[1]
+        return o_tail(*a)
+    monkeypatch.setattr(h, "cpfn_bn_bwd_finalize_ride", spy_ride)
+    monkeypatch.setattr(h, "cpfn_multi_split_reduce", spy_tail)
+    res, counts = {}, {}
+    for on in (True, False):
+        monkeypatch.setattr(fused_mlp, "REDUCE_RIDE", on)
+        for k in seen:
+            seen[k] = 0
+        model = _fresh_model(28)
+        torch.manual_seed(5)
+        res[on] = _step_grads(model, batch, starts, None)
+        counts[on] = dict(seen)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    assert counts[False]["ride"] == 0 and counts[False]["tail"] >= 15, counts
+    assert counts[True]["riders"] + counts[True]["tail"] == counts[False]["tail"], counts      # every buffer reduced exactly once
+    assert counts[True]["riders"] >= 12 and counts[True]["tail"] <= 6, counts
