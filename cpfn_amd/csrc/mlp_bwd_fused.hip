@@ -156,7 +156,8 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   } else if (APPLY) {
     for (int e = t; e < 3 * TN; e += NT) s_cf[e] = ap.coef[e];
     if (t < TN) { s_cf[3 * TN + t] = ap.y_scale[t]; s_cf[4 * TN + t] = ap.y_shift[t]; }
-    // (visible after the first barrier of the step loop)
+    // (visible after the first barrier of the step loop — two-barrier shapes; the one-barrier shapes STAGE before their first
+    //  barrier and get one of their own below)
   }
   float bsc[8], bsh[8], st_s[8], st_q[8];
   if (BST) {
@@ -324,6 +325,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) issue(d, p0 + (long long)d * STEP);
   fill_w_panel<TK, LDN, NT>(s_wt, W, TN, TK, 0, 0, TN, 1, t);      // s_wt[k_out][n]: the forward weight [n][k] transposed
+  // One-barrier (DB) shapes whose apply pass reads its per-channel vectors from LDS at every stage — fc1's dropout instantiation and
+  // the pooled 128 -> 128 one since the 128-channel shapes are double-buffered — stage step 0 BEFORE the loop's first barrier: the
+  // vectors written above by other lanes must be visible first.  (Found by tests/test_gpu_fused_mlp.py failing once in ~15 runs
+  // after the shapes became one-barrier: a first stage that read the vectors early.)
+  if (DB && APPLY && !COEF_REGS) __syncthreads();
   if (COEF_VIA_LDS) {
     __syncthreads();
 #pragma unroll
