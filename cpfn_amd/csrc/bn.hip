@@ -461,6 +461,51 @@ __device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
   const float *__restrict__ partial = a.partial[d];
   const long long n = a.n[d];
   const int splits = a.splits[d];
+  if (a.deep[d] == 4) {
+    // "wide-deep" (round 4, large buffers with >= 64 partial rows): 64 elements (16 lanes x float4: 256-byte runs) x 16 subsets
+    // per workgroup — a lane adds 16 of 256 rows (two batches of eight loads) instead of 64 (eight batches): four times the
+    // workgroups and a quarter of the dependent round trips per lane.  What mattered when the reductions began to ride on the
+    // finalize launches of the backward pass: a rider should be done when the finalize workgroups are.
+    float4 (*s4)[16] = (float4 (*)[16])s_acc;          // [16 subsets][16 lanes] float4 = 4 KB
+    const int lane = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const long long e = ((long long)(bid - a.block0[d]) * 16 + lane) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < n) {
+      const float *src = partial + e;
+      int i = r;
+      for (; i + 112 < splits; i += 128) {             // eight rows of this subset in flight
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const float4 *)(src + (size_t)(i + 16 * u) * n);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      }
+      for (; i < splits; i += 16) {
+        const float4 v = *(const float4 *)(src + (size_t)i * n);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    s4[r][lane] = acc;
+    __syncthreads();
+    if (r == 0 && e < n) {
+      float4 t4 = s4[0][lane];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) { const float4 u4 = s4[q][lane]; t4.x += u4.x; t4.y += u4.y; t4.z += u4.z; t4.w += u4.w; }
+      const float v[4] = {t4.x, t4.y, t4.z, t4.w};
+      const int ri = a.row_in[d];
+      if (ri == 0) {
+        *(float4 *)(a.out[d] + e) = t4;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const long long row = (e + j) / ri;
+          const int col = (int)((e + j) - row * ri);
+          if (col < a.row_out[d]) a.out[d][row * a.out_ld[d] + col] = v[j];
+        }
+      }
+    }
+    return;
+  }
   if (a.deep[d] == 2) {
     float4 (*s4)[64] = (float4 (*)[64])s_acc;          // [4 subsets][64 lanes] float4 = 4 KB
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
@@ -972,9 +1017,9 @@ static int msr_fill(ARGS &a, const cpfn_reduce_desc *descs, int count, int *bloc
     a.out_ld[i] = d.out_ld > 0 ? d.out_ld : d.row_out;
     a.deep[i] = d.n <= 1024 && d.splits >= 128;
     if (!a.deep[i] && d.n >= 4096 && d.n % 4 == 0 && (((uintptr_t)d.partial | (d.row_in == 0 ? (uintptr_t)d.out : 0)) & 15) == 0)
-      a.deep[i] = 2;          // wide: float4 per lane (same order of additions as the 64 x 4 layout)
+      a.deep[i] = d.splits >= 64 ? 4 : 2;   // wide (float4 per lane; 2: the 64 x 4 layout's order of additions) / wide-deep (4: 16 subsets)
     a.block0[i] = blocks;
-    blocks += cpfn_cdiv(d.n, a.deep[i] == 2 ? 256 : a.deep[i] ? 16 : 64);
+    blocks += cpfn_cdiv(d.n, a.deep[i] == 2 ? 256 : a.deep[i] == 4 ? 64 : a.deep[i] ? 16 : 64);
   }
   a.block0[count] = blocks;
   *blocks_out = blocks;
