@@ -454,7 +454,8 @@ __device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
   // "wide" buffers (mode 2: n % 4 == 0, 16-byte aligned — every large weight matrix): 256 elements x 4 subsets, one
   // float4 per lane and row and eight rows in flight — the launch reads ~250 MB and was latency-bound with 4-byte loads
   // (3.7 TB/s).  The order of the additions per element is the same in all three modes' common case (subset r adds rows
-  // r, r + 4, ...; then (s0 + s1) + (s2 + s3)), so mode 2 is bit-identical to mode 0.
+  // r, r + 4, ...; then (s0 + s1) + (s2 + s3)), so mode 2 is bit-identical to mode 0.  Mode 4 (round 4, below) has its own fixed order:
+  // 16 subsets.  Which mode a buffer takes depends on its size and row count only, so a gradient has the same bits on every path.
   __shared__ __attribute__((aligned(16))) float s_acc[16][64];
   int d = 0;
   while (d + 1 < a.count && bid >= a.block0[d + 1]) ++d;

@@ -80,26 +80,35 @@ def test_compacting_split_reduce():
     torch.testing.assert_close(out_f, flat.sum(0), rtol=1e-5, atol=1e-5)
 
 
-def test_wide_split_reduce_same_addition_order():
-    """Large buffers take the float4 layout (256 elements x 4 split-subsets per workgroup, eight rows in flight): the
-    additions per element happen in the order of the 64 x 4 layout — subset r adds rows r, r + 4, ... one by one, then
-    (s0 + s1) + (s2 + s3) — so the result is that sum bit for bit; padded rows are compacted by the same launch."""
+def test_wide_split_reduce_fixed_addition_orders():
+    """Large buffers take a float4 layout with a FIXED order of additions per element (bitwise reproducible, checked here against
+    the same order spelled out in torch): fewer than 64 partial rows — 256 elements x 4 split-subsets per workgroup, the order of
+    the 64 x 4 layout: subset r adds rows r, r + 4, ... one by one, then (s0 + s1) + (s2 + s3); 64 rows or more (round 4) —
+    64 elements x 16 subsets: subset r adds rows r, r + 16, ..., then s0 + s1 + ... + s15 in that order.  Padded rows are
+    compacted by the same launch."""
     from cpfn_amd import fused_mlp
     g = torch.Generator().manual_seed(5)
     for n_rows, Kp, cin, splits in [(128, 128, 128, 256), (256, 128, 128, 37), (128, 192, 131, 256), (64, 64, 64, 3),
-                                    (65, 64, 64, 5), (1030, 4, 4, 33), (67, 64, 35, 9)]:      # (ragged last workgroup)
+                                    (65, 64, 64, 5), (1030, 4, 4, 33), (67, 64, 35, 9), (128, 64, 64, 64), (100, 128, 128, 100)]:
         ws = torch.randn(splits, n_rows, Kp, generator=g).to(dev())
         out = torch.empty(n_rows, cin, device=dev())
         arr = (fused_mlp._ReduceDesc * 1)(fused_mlp._ReduceDesc(ws.data_ptr(), out.data_ptr(), n_rows * Kp, splits,
                                                                  0 if cin == Kp else Kp, 0 if cin == Kp else cin))
         _call("cpfn_multi_split_reduce", arr, 1, _stream())
+        wide_deep = splits >= 64 and n_rows * Kp >= 4096 and (n_rows * Kp) % 4 == 0
+        nsub = 16 if wide_deep else 4
         sub = []
-        for r in range(4):
+        for r in range(nsub):
             acc = torch.zeros(n_rows, Kp, device=dev())
-            for i in range(r, splits, 4):
+            for i in range(r, splits, nsub):
                 acc = acc + ws[i]
             sub.append(acc)
-        want = (sub[0] + sub[1]) + (sub[2] + sub[3])
+        if wide_deep:
+            want = sub[0]
+            for q in range(1, 16):
+                want = want + sub[q]
+        else:
+            want = (sub[0] + sub[1]) + (sub[2] + sub[3])
         assert torch.equal(out, want[:, :cin]), (n_rows, Kp, cin, splits)
 
 
