@@ -139,8 +139,9 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // (64-row-step shapes — sa1, after the geometry work has ended, bound by VALU + LDS issue rather than memory — keep them
   //  in registers: 10 LDS reads per stage less)
   // (round 4: with two steps of rows in flight the dense 128 -> 128 apply instantiation has the registers too — 164 + 40 —; its
-  //  vectors go through LDS once, COEF_VIA_LDS: forty 4-byte global loads per lane in the prologue cost more than they saved)
-  constexpr bool COEF_VIA_LDS = CPFN_BWD_COEF32 && APPLY == 1 && STEP == 32 && TN <= 128;
+  //  vectors go through LDS once, COEF_VIA_LDS: forty 4-byte global loads per lane in the prologue cost more than they saved;
+  //  fc1's dropout instantiation too: 214 registers, -1 us)
+  constexpr bool COEF_VIA_LDS = CPFN_BWD_COEF32 && (APPLY == 1 || APPLY == 3) && STEP == 32 && TN <= 128;
   constexpr bool COEF_REGS = APPLY != 0 && (STEP == 64 || COEF_VIA_LDS);
   __shared__ __attribute__((aligned(16))) float s_cf[APPLY && (!COEF_REGS || COEF_VIA_LDS) ? 5 * TN : 4];
   float cfr[COEF_REGS ? 5 : 1][8];
