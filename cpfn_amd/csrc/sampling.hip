@@ -91,9 +91,51 @@ __device__ __forceinline__ float v_max3(float a, float b, float c) {
 // One sample's pass over a lane's PPT points (pairs in registers): min-distances updated against the new sample
 // (fx, fy, fz), the lane's largest min-distance returned.  d = ((dx*dx + dy*dy) + dz*dz), every operation rounded
 // (the translation unit is compiled with -ffp-contract=off; the packed instructions round like the scalar ones).
-template <int PPT>
+//
+// PK = false — the instantiations that run BESIDE a training step (the next batch's geometry on the side stream): one point per
+// instruction, no packed fp32.  Round 4 found run-to-run different samples in ~1 of 100 twelve-step runs of tests/test_gpu_epoch.py's
+// configuration, and followed them into this function: with v_pk_add_f32 / v_pk_mul_f32 here, a lane of a wave's LAST row (lanes
+// 48-63) now and then kept its min-distance un-updated for one sample while the step's graph ran on the other stream — caught in the
+// act by an in-kernel invariant (the sample's own min-distance must be 0 after the update: 10-25 violations per 300 runs, always
+// lanes 48-63, EXEC full, the sample's coordinates right; tools/dbg/step_repro.py, tools/dbg/fps_event.py).  Not a wait-state
+// problem of this wave (eight s_nop around the consumer made it MORE frequent), not LDS read widths, not stale input, none of the
+// hand-written reductions (compiler-scheduled C versions of them failed alike); the same kernel alone, or beside the MLP backward
+// stacks (tests/test_gpu_concurrency.py: 7e8 packed instructions), never showed it.  With the eight roundings as single
+// v_sub / v_mul / v_add: 0 violations, 0 of 250 runs differ.  The aggressor inside the step was not identified; until it is, no
+// kernel that has to be bit-exact beside other work keeps long-running packed-fp32 chains (the stand-alone instantiations — evaluation,
+// the parity tests — do: same roundings, half the VALU issue).
+template <int PPT, bool PK = true>
 __device__ __forceinline__ float fps_update(const f32x2 (&px)[PPT / 2], const f32x2 (&py)[PPT / 2], const f32x2 (&pz)[PPT / 2],
                                             f32x2 (&md)[PPT / 2], float fx, float fy, float fz) {
+  if (!PK) {
+    constexpr int NCH1 = PPT >= 16 ? 4 : 1;
+    float lm1[NCH1];
+#pragma unroll
+    for (int c = 0; c < NCH1; ++c) lm1[c] = -1.0f;
+#pragma unroll
+    for (int j = 0; j < PPT / 2; ++j) {
+      float m2[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // (inline assembly, one rounding each: left to the compiler, the vectoriser pairs them up into the packed forms again)
+        float dx, dy, dz, xx, yy, zz, d;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dx) : "v"(px[j][h]), "v"(fx));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dy) : "v"(py[j][h]), "v"(fy));
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dz) : "v"(pz[j][h]), "v"(fz));
+        asm("v_mul_f32 %0, %1, %1" : "=v"(xx) : "v"(dx));
+        asm("v_mul_f32 %0, %1, %1" : "=v"(yy) : "v"(dy));
+        asm("v_mul_f32 %0, %1, %1" : "=v"(zz) : "v"(dz));
+        asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(xx), "v"(yy));
+        asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(d), "v"(zz));
+        m2[h] = v_min(md[j][h], d);
+      }
+      md[j] = (f32x2){m2[0], m2[1]};
+      lm1[j % NCH1] = v_max3(lm1[j % NCH1], m2[0], m2[1]);
+    }
+    float r1 = lm1[0];
+    if (NCH1 == 4) r1 = fmaxf(v_max3(lm1[0], lm1[1], lm1[2]), lm1[3]);
+    return r1;
+  }
   const f32x2 f2x = {fx, fx}, f2y = {fy, fy}, f2z = {fz, fz};
   // (a dependent vector instruction issues ~8-10 cycles after its producer when the wave has nothing else to issue — one
   //  wave per SIMD at 32 points per lane — so the running maximum is NCH independent chains, combined at the end)
@@ -170,7 +212,7 @@ __device__ __forceinline__ unsigned long long fps_stamp() {
   return t;
 }
 
-template <int NT, int PPT, bool PROFILE = false>
+template <int NT, int PPT, bool PROFILE = false, bool PK = true>
 __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restrict__ xyz, int N, int S,
                                                           const int *__restrict__ start, int flags,
                                                           int *__restrict__ idx_out,
@@ -220,7 +262,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       c[0] = fx; c[1] = fy; c[2] = fz;
     }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[0] += t1 - t0; t0 = t1; }      // (one wave: broadcast read of the sample)
-    const float lm = fps_update<PPT>(px, py, pz, md, fx, fy, fz);
+    const float lm = fps_update<PPT, PK>(px, py, pz, md, fx, fy, fz);
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[1] += t1 - t0; t0 = t1; }      // distance update + lane maximum
     const float wmax = wave_max_f32(lm);
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[2] += t1 - t0; t0 = t1; }      // wave maximum (DPP)
@@ -498,10 +540,14 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
                       float *centres, hipStream_t st) {
   if (B < 0 || N <= 0 || S < 0 || !xyz || (!idx_out && B * S > 0)) return CPFN_EINVAL;
   if (B == 0 || S == 0) return 0;
+  // (beside a training step — cpfn_background_geometry() — the instantiations without packed fp32: see fps_update)
+  const bool beside = cpfn_background_geometry();
   if (N <= 512) {
-    fps_resident_kernel<64, 8><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    if (beside) fps_resident_kernel<64, 8, false, false><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    else fps_resident_kernel<64, 8><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
   } else if (N <= 2048) {
-    fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    if (beside) fps_resident_kernel<256, 8, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    else fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
   } else if (N <= CPFN_FPS_MAX_RESIDENT) {
     // 8192 points on ONE CU either way (a sample is a VALU-throughput phase over the cloud plus two key reductions):
     // (with ds_bpermute key reductions) 16 waves x 8 points per lane took 670 us for 512 samples, 8 waves x 16 points 572 us,
@@ -509,8 +555,8 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
     // (registers spill to AGPRs); with the DPP reductions 4 x 32 takes 522 us (the step beside it: 1.898 -> 1.868 ms).
     // Beside a training step (one workgroup per cloud on 16 CUs for the whole forward pass) the FEWER waves the better
     // for the step: 1.871 ms with 16 waves, 1.855 with 8, 1.849 with 4 (interleaved A/B on one box each).
-    if (cpfn_background_geometry())
-      fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    if (beside)
+      fps_resident_kernel<256, 32, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
     else
       fps_resident_kernel<512, 16><<<B, 512, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
   } else {

@@ -132,6 +132,9 @@ def test_cross_stream_flags_order_two_streams_and_time_out():
     ("sfp3-like: <128,128,32> x 2 (one barrier per step since round 4)", 131072, [128, 128, 128], None, False, False),
     ("fc1-like: <128,128,32> with the fused dropout on top (its apply pass reads its vectors from LDS at every stage)", 131072,
      [128, 128], None, False, True),
+    ("sa2-like at the smallest row count the one-pass kernel takes: <128,128,32> with the fp32 coordinate tail, <128,128,32>, pooled "
+     "<256,128,32>; four steps per split", 32768, [128, 128, 256], 64, "tail", False),
+    ("sfp3-like, four steps per split", 32768, [128, 128, 128], None, False, False),
 ])
 def test_one_pass_backward_is_bitwise_reproducible_beside_the_geometry_graph(name, P, widths, pool_k, xyz, dropout):
     """VERDICT r2 #6.  The 64-row-step shapes of mlp_bwd_fused_kernel (sa1, 524288 rows) run with ONE barrier per step on
@@ -145,7 +148,9 @@ def test_one_pass_backward_is_bitwise_reproducible_beside_the_geometry_graph(nam
     from cpfn_amd.PointNet2 import pn2_network
     from test_gpu_fused_mlp import _stack
     dev = torch.device("cuda:0")
-    convs, bns = _stack(3 if xyz else 128, widths, seed=29)
+    tail_mode = xyz == "tail"                # sa2: 128 gathered bf16 channels + the centred coordinates kept in fp32 beside them
+    xyz = xyz is True
+    convs, bns = _stack(3 if xyz else (131 if tail_mode else 128), widths, seed=29)
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev) if xyz else torch.randn(P, 128, generator=g).to(dev).requires_grad_(True)
     gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev)
@@ -153,7 +158,9 @@ def test_one_pass_backward_is_bitwise_reproducible_beside_the_geometry_graph(nam
     # (round 4 made the 128-channel shapes one-barrier too; the dropout instantiation then staged its first step before anything
     #  ordered the per-channel vectors other lanes had written to LDS — one wrong step in ~15 runs of tests/test_gpu_fused_mlp.py)
     drop = (0.5, torch.zeros(1, dtype=torch.int64, device=dev), 1234567) if dropout else None
-    y = mlp.run_stack(None if xyz else x, convs, bns, torch.bfloat16, pool_k=pool_k, xyz_rows=x if xyz else None, dropout=drop)
+    tail = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev) if tail_mode else None
+    y = mlp.run_stack(None if xyz else (x.to(torch.bfloat16) if tail_mode else x), convs, bns, torch.bfloat16, pool_k=pool_k,
+                      xyz_rows=x if xyz else None, dropout=drop, xyz_tail=tail)
     loss = (y.float() * gout).sum()
 
     # the geometry pass of a 16 x 8192 batch as a graph on a side stream, in the shapes it has beside a training step
@@ -176,6 +183,18 @@ def test_one_pass_backward_is_bitwise_reproducible_beside_the_geometry_graph(nam
     torch.cuda.synchronize()
     ref_fps = geom["sa1"]["fps_idx"].clone()
     assert int(ref_fps.min()) >= 0 and int(ref_fps.max()) < 8192
+
+    def flat(d, pre=""):                     # every tensor the geometry pass hands to the step, by name
+        out = []
+        for k, v in (d.items() if isinstance(d, dict) else enumerate(d)):
+            if torch.is_tensor(v):
+                out.append((pre + str(k), v))
+            elif isinstance(v, (dict, list, tuple)):
+                out += flat(v, pre + str(k) + ".")
+        return out
+    geo = flat(geom)
+    geo_ref = [t.clone() for _, t in geo]
+    geo_bad = torch.zeros(len(geo), dtype=torch.int32, device=dev)
 
     def backward():
         for p in params:
@@ -201,6 +220,10 @@ def test_one_pass_backward_is_bitwise_reproducible_beside_the_geometry_graph(nam
                 gg.replay()
                 gg.replay()
         got = backward()
+        if i % 4 == 3:                      # the victims' side: every geometry output of the replays that ran beside these passes
+            torch.cuda.current_stream().wait_stream(side)
+            geo_bad += torch.stack([(a != b).any() for (_, a), b in zip(geo, geo_ref)]).int()
+            side.wait_stream(torch.cuda.current_stream())
         same = torch.stack([(a == b).all() for a, b in zip(got, ref)]).all()      # (device-side: no sync per repetition)
         bad = bad + (~same).int() if i else (~same).int()
         if i % 100 == 99:
@@ -209,4 +232,45 @@ def test_one_pass_backward_is_bitwise_reproducible_beside_the_geometry_graph(nam
     torch.cuda.synchronize()
     assert int(bad) == 0, "%s: %d of %d backward passes beside the geometry graph returned different bits" % (name, int(bad), REPS)
     assert bad_fps == 0
+    assert int(geo_bad.sum()) == 0, {n: int(c) for (n, _), c in zip(geo, geo_bad.tolist()) if c}
     assert not fused_mlp._pending_reduce
+
+
+def test_replayed_training_runs_sample_the_same_points():
+    """Round 4: two identical replayed training runs parted in ~1 of 100 twelve-step runs of this configuration — the sampling kernel
+    of the NEXT batch's geometry, beside the step's graph, inserted one bogus sample (a lane of a wave's last row kept its min-distance
+    un-updated for one sample; packed fp32 in the distance update, csrc/sampling.hip fps_update).  40 short runs of the PatchSelection
+    trainer on the same device-resident batches: the sampled indices, centres and neighbour tables every step reads, and every loss,
+    must be the first run's.  (The build before the fix fails this ~70 % of the time; tools/dbg/step_repro.py is the long form.)"""
+    from cpfn_amd import synthetic, training
+    from cpfn_amd.PointNet2 import pn2_network
+    dev = torch.device("cuda:0")
+    B, N, steps = 4, 2048, 12
+    bs = []
+    for i in range(steps):
+        c = synthetic.primitive_cloud(B, N, n_prims=6, seed=600 + i)
+        bs.append({"P": c["P"].to(dev), "labels": (c["I_gt"] % 2).long().to(dev)})
+
+    def run():
+        torch.manual_seed(0)
+        m = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[2]).to(dev)
+        m.set_compute_dtype(torch.bfloat16)
+        tr = training.PatchSelectionTrainer(m, batch_size=B, use_graphs=True)
+        torch.manual_seed(78)
+        rec = []
+        with torch.cuda.stream(tr.stream(dev)):
+            m.train()
+            for i, b in enumerate(bs):
+                out = tr.step(b, next_batch=bs[i + 1] if i + 1 < steps else None)
+                st = tr._graph
+                rec.append([out[0].detach().clone().reshape(1)] + ([t.clone() for t in st["geomA_flat"]] if st else []))
+        torch.cuda.synchronize()
+        assert tr._graph is not None and tr.skipped_steps == 0
+        return rec
+
+    ref = run()
+    for r in range(40):
+        got = run()
+        for s_, (a, b) in enumerate(zip(ref, got)):
+            diff = [j for j, (x, y) in enumerate(zip(a, b)) if not torch.equal(x, y)]
+            assert not diff, "run %d, step %d: tensors %s (0 = loss, 1.. = the geometry set the step read) differ from the first run's" % (r, s_, diff)

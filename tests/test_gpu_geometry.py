@@ -92,7 +92,8 @@ def test_fps_sizes_vs_oracle(B, N, S):
     want = og.farthest_point_sample(xyz, S, start).astype(np.int32)
     assert np.array_equal(got, want)
     from cpfn_amd import ops
-    with ops.background_geometry():       # the shape used beside a training step (4 waves x 32 points per lane at N > 2048)
+    with ops.background_geometry():       # the instantiations used beside a training step: 4 waves x 32 points per lane at N > 2048,
+        #                                   and no packed fp32 at any size (csrc/sampling.hip, fps_update)
         assert np.array_equal(cuda_ops.farthest_point_sampling(T(xyz), S, start_idx=T(start)).cpu().numpy(), want)
 
 
