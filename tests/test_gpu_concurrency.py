@@ -51,6 +51,35 @@ def test_fps_is_immune_to_a_neighbouring_lds_heavy_kernel():
     assert bad == 0, "%d of 100 overlapped FPS runs differ from the quiet run" % bad
 
 
+def test_sampling_of_small_clouds_beside_the_weight_gradient_kernel():
+    """Round 4.  The SAME neighbour disturbs something else than LDS reads: while mlp_wgrad runs on the other stream, packed-fp32
+    arithmetic (v_pk_add_f32 / v_pk_mul_f32) of a co-resident wave now and then loses the write of its last row (lanes 48-63).  The
+    sampling kernel of 513-2048-point clouds (4 waves x 8 points per lane: the one shape that leaves room for a weight-gradient wave
+    on its SIMDs) then kept a min-distance un-updated and inserted a bogus sample: 1027 of 19264 launches beside mlp_wgrad differed
+    from the quiet run, 0 beside every other kernel of a backward pass (tools/dbg/pk_aggressor.py).  The instantiations used beside a
+    training step (ops.background_geometry) carry no packed fp32 (csrc/sampling.hip, fps_update): every launch here must sample
+    the quiet run's points."""
+    ops, P1, P2, start, wgrad = _setup()
+    g = torch.Generator().manual_seed(11)
+    clouds = (torch.rand(4, 2048, 3, generator=g) * 2 - 1).cuda()
+    st = torch.randint(0, 2048, (4,), generator=g).to(torch.int32).cuda()
+    with ops.background_geometry():
+        ref = ops.fps(clouds, 512, st).clone()
+    assert torch.equal(ref, ops.fps(clouds, 512, st))                    # (the stand-alone, packed instantiation: same points)
+    side = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int32, device=clouds.device)
+    for _ in range(150):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with ops.background_geometry():
+                for _ in range(16):
+                    bad += (ops.fps(clouds, 512, st) != ref).any().int()
+        wgrad(60)
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(bad) == 0, "%d of 2400 sampling launches beside the weight-gradient kernel differ from the quiet run" % int(bad)
+
+
 def test_fps_on_a_forked_graph_branch():
     ops, P1, P2, start, wgrad = _setup()
     ref2 = ops.fps(P2, 128, start)
