@@ -23,6 +23,9 @@
 // op for op — ((dx*dx + dy*dy) + dz*dz) with every op rounded — so that the selected
 // indices are identical to it, not merely close.
 #include "common.h"
+#include <cstdlib>
+
+constexpr int CPFN_LDS_BYTES_PER_CU = 160 * 1024;      // gfx950
 
 namespace {
 
@@ -92,18 +95,21 @@ __device__ __forceinline__ float v_max3(float a, float b, float c) {
 // (fx, fy, fz), the lane's largest min-distance returned.  d = ((dx*dx + dy*dy) + dz*dz), every operation rounded
 // (the translation unit is compiled with -ffp-contract=off; the packed instructions round like the scalar ones).
 //
-// PK = false — the instantiations that run BESIDE a training step (the next batch's geometry on the side stream): one point per
-// instruction, no packed fp32.  Round 4 found run-to-run different samples in ~1 of 100 twelve-step runs of tests/test_gpu_epoch.py's
-// configuration, and followed them into this function: with v_pk_add_f32 / v_pk_mul_f32 here, a lane of a wave's LAST row (lanes
-// 48-63) now and then kept its min-distance un-updated for one sample while the step's graph ran on the other stream — caught in the
-// act by an in-kernel invariant (the sample's own min-distance must be 0 after the update: 10-25 violations per 300 runs, always
-// lanes 48-63, EXEC full, the sample's coordinates right; tools/dbg/step_repro.py, tools/dbg/fps_event.py).  Not a wait-state
-// problem of this wave (eight s_nop around the consumer made it MORE frequent), not LDS read widths, not stale input, none of the
-// hand-written reductions (compiler-scheduled C versions of them failed alike); the same kernel alone, or beside the MLP backward
-// stacks (tests/test_gpu_concurrency.py: 7e8 packed instructions), never showed it.  With the eight roundings as single
-// v_sub / v_mul / v_add: 0 violations, 0 of 250 runs differ.  The aggressor inside the step was not identified; until it is, no
-// kernel that has to be bit-exact beside other work keeps long-running packed-fp32 chains (the stand-alone instantiations — evaluation,
-// the parity tests — do: same roundings, half the VALU issue).
+// PK = false — one point per instruction, no packed fp32: the 64- and 256-lane instantiations used BESIDE a training step (the next
+// batch's geometry on the side stream).  Round 4 found run-to-run different samples in ~1 of 100 twelve-step runs of
+// tests/test_gpu_epoch.py's configuration and followed them into this function.  With v_pk_add_f32 / v_pk_mul_f32 here, a lane of a
+// wave's LAST row (lanes 48-63) now and then kept its min-distance un-updated for one sample — caught in the act by an in-kernel
+// invariant (the sample's own min-distance must be 0 after the update; EXEC full, the sample's coordinates right) — whenever a
+// workgroup of a WEIGHT-GRADIENT kernel shared the compute unit: mlp_wgrad, the one-pass backward kernels, the small-layer backward
+// kernels (the kernels that read their operands transposed out of LDS, ds_read_b64_tr_b16 — the same neighbour next to which
+// ds_read_b96 returned wrong data in round 1, common.h).  tools/dbg/pk_aggressor.py, packed 4 x 8 instantiation on a side stream,
+// one candidate looping on the main stream: 1027 of 19264 launches differ beside mlp_wgrad; 0 beside the forward / data-gradient
+// GEMMs, the BatchNorm passes (fp64 sums included), the split reduction, the optimizer, copies, a spinning flag waiter.  Not a
+// wait-state problem of this wave (eight s_nop around the consumer made it MORE frequent), not LDS read widths, not stale input,
+// none of the hand-written reductions (compiler-scheduled C versions failed alike).  With the eight roundings as single
+// v_sub / v_mul / v_add: 0 violations, 0 of 250 runs differ.  The 8192-point shape keeps the packed form behind a structural
+// guard (fps_launch: its workgroup claims the compute unit's whole LDS); stand-alone launches (evaluation, the parity tests: nothing
+// else runs) keep it too: same roundings, half the VALU issue.
 template <int PPT, bool PK = true>
 __device__ __forceinline__ float fps_update(const f32x2 (&px)[PPT / 2], const f32x2 (&py)[PPT / 2], const f32x2 (&pz)[PPT / 2],
                                             f32x2 (&md)[PPT / 2], float fx, float fy, float fz) {
@@ -555,9 +561,34 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
     // (registers spill to AGPRs); with the DPP reductions 4 x 32 takes 522 us (the step beside it: 1.898 -> 1.868 ms).
     // Beside a training step (one workgroup per cloud on 16 CUs for the whole forward pass) the FEWER waves the better
     // for the step: 1.871 ms with 16 waves, 1.855 with 8, 1.849 with 4 (interleaved A/B on one box each).
-    if (beside)
-      fps_resident_kernel<256, 32, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
-    else
+    if (beside) {
+      // The 8192-point shape keeps its packed arithmetic beside a step, behind a structural guard instead: its workgroup claims
+      // the compute unit's WHOLE LDS (96 KB mirror + dynamic padding to 160 KB), so that no workgroup that uses LDS — every kernel
+      // of the disturbing kind does: their transposed operand reads are LDS reads — can be resident on the same compute unit.
+      // (Unpadded, a 64 x 64 weight-gradient workgroup — 9 KB of LDS, 116 registers — fits beside it; the 128-channel ones never
+      //  did: 252 + 257 registers.  The one-point-per-instruction form costs this shape 116 us per launch: +48 us per step and
+      //  the dominant kernel 0.72 -> 0.63 of peak, because the longer chain then overlaps the backward pass.)
+      //  CPFN_FPS_BESIDE_MODE (debugging): 0 = the form without packed fp32, 2 = packed without the LDS claim.
+      static const int mode = getenv("CPFN_FPS_BESIDE_MODE") ? atoi(getenv("CPFN_FPS_BESIDE_MODE")) : 1;
+      static int pad = -2;                       // -2: not asked yet, -1: the claim is not available
+      if (pad == -2) {
+        hipFuncAttributes a;
+        pad = -1;
+        if (hipFuncGetAttributes(&a, (const void *)fps_resident_kernel<256, 32>) == hipSuccess) {
+          const int p = CPFN_LDS_BYTES_PER_CU - (int)a.sharedSizeBytes;
+          if (p >= 0 && hipFuncSetAttribute((const void *)fps_resident_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, p) ==
+                            hipSuccess)
+            pad = p;
+        }
+        (void)hipGetLastError();
+      }
+      if (mode == 2)
+        fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+      else if (mode == 1 && pad >= 0)
+        fps_resident_kernel<256, 32><<<B, 256, pad, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+      else
+        fps_resident_kernel<256, 32, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    } else
       fps_resident_kernel<512, 16><<<B, 512, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
   } else {
     if (!scratch) return CPFN_EINVAL;

@@ -80,6 +80,40 @@ def test_sampling_of_small_clouds_beside_the_weight_gradient_kernel():
     assert int(bad) == 0, "%d of 2400 sampling launches beside the weight-gradient kernel differ from the quiet run" % int(bad)
 
 
+def test_sampling_of_large_clouds_beside_small_weight_gradient_workgroups():
+    """... and the 8192-point shape (4 waves x 32 points per lane, 96 KB LDS mirror), which keeps its packed arithmetic beside a step:
+    its workgroup claims the compute unit's whole LDS, so no LDS-using workgroup — every kernel of the disturbing kind — can share the
+    compute unit.  The neighbour here is the one that WOULD fit beside the unpadded kernel: the 64 x 64 weight-gradient kernel
+    (9 KB of LDS, 116 registers).  CPFN_FPS_BESIDE_MODE=2 (packed, no claim) is the debugging form of this test."""
+    from cpfn_amd import lib as _l, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(12)
+    clouds = (torch.rand(16, 8192, 3, generator=g) * 2 - 1).to(dev)
+    st = torch.randint(0, 8192, (16,), generator=g).to(torch.int32).to(dev)
+    ref = ops.fps(clouds, 512, st).clone()                               # (stand-alone instantiation, quiet)
+    h = _l.lib()
+    Y = torch.randn(131072, 64, generator=g).to(dev).to(torch.bfloat16)
+    splits = h.cpfn_mlp_wgrad_splits(131072, 64, 64)
+    ws = torch.empty(splits * 64 * 64, device=dev)
+
+    def wgrad64(n):
+        for _ in range(n):
+            assert h.cpfn_mlp_wgrad(Y.data_ptr(), 64, Y.data_ptr(), 64, None, 131072, 64, 64, None, None, ws.data_ptr(), None,
+                                    torch.cuda.current_stream().cuda_stream) == 0
+    side = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int32, device=dev)
+    for _ in range(60):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with ops.background_geometry():
+                for _ in range(4):
+                    bad += (ops.fps(clouds, 512, st) != ref).any().int()
+        wgrad64(150)
+        torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(bad) == 0, "%d of 240 sampling launches (16 clouds each) beside the 64 x 64 weight-gradient kernel differ" % int(bad)
+
+
 def test_fps_on_a_forked_graph_branch():
     ops, P1, P2, start, wgrad = _setup()
     ref2 = ops.fps(P2, 128, start)
