@@ -63,3 +63,22 @@ def test_bad_arguments_raise_runtime_error():
         cuda_ops.farthest_point_sampling(torch.zeros(1, 8, 3), 2)
     with pytest.raises(RuntimeError, match="CPU not supported"):
         cuda_ops.ball_query(torch.zeros(1, 2, 3), torch.zeros(1, 8, 3), 0.2, 4)
+
+
+def test_build_rejects_packed_fp32_beside_a_step_and_96_bit_lds_reads():
+    """cpfn_amd/build.py scans the device assembly of every compile (two hardware interactions found next to the
+    weight-gradient kernels).  The patterns, on synthetic assembly: a 96-bit DS read anywhere; packed fp32 in ANY kernel of
+    neighbors.hip and in the sampling instantiations meant to be free of it — and not in the stand-alone ones."""
+    from cpfn_amd import build as b
+    assert b._BANNED_ISA.search("\tds_read_b96 v[0:2], v3\n") and not b._BANNED_ISA.search("\tds_read_b128 v[0:3], v4\n")
+    beside = "_ZN12_GLOBAL__N_119fps_resident_kernelILi256ELi8ELb0ELb0EEEvPKfiiPKiiPiPyPf"
+    alone = "_ZN12_GLOBAL__N_119fps_resident_kernelILi256ELi8ELb0ELb1EEEvPKfiiPKiiPiPyPf"
+    text = ("%s: ; @x\n\tv_sub_f32_e32 v1, v2, v3\n\tv_pk_mul_f32 v[0:1], v[2:3], v[2:3]\n.Lfunc_end0:\n"
+            "%s: ; @y\n\tv_pk_add_f32 v[0:1], v[2:3], v[4:5]\n\tv_pk_mov_b32 v[0:1], v[2:3], v[4:5]\n.Lfunc_end1:\n" % (beside, alone))
+    bodies = dict(b._KERNEL_BODY.findall(text))
+    assert set(bodies) == {beside, alone}
+    sel = b._NO_PACKED["sampling.hip"]
+    assert sel(beside) and not sel(alone)
+    assert len(b._PACKED_F32.findall(bodies[beside])) == 1 and len(b._PACKED_F32.findall(bodies[alone])) == 1   # (v_pk_mov is not arithmetic)
+    assert b._NO_PACKED["neighbors.hip"]("anything")
+    assert "-fno-slp-vectorize" in b.SOURCES["neighbors.hip"] and "-fno-slp-vectorize" in b.SOURCES["sampling.hip"]
