@@ -5,7 +5,11 @@ Regression test for a hardware interaction found in round 1: `ds_read_b96` (what
 floats of a float4 in LDS) returned wrong data now and then while a workgroup of another kernel on the same
 CU was writing LDS heavily.  Furthest-point sampling next to the weight-gradient kernel picked a spurious point
 in 195 of 200 runs; with b32 / b128 reads: 0 of 200.  (cpfn_amd/csrc/common.h, cpfn_lds_read4; the build rejects
-96-bit DS instructions.)"""
+96-bit DS instructions.)
+
+Round 4 found a second one with the same neighbour: packed fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32) of a wave that shares
+its compute unit with a weight-gradient workgroup now and then loses the write of its last 16-lane row — the sampling kernel
+inserted a bogus sample (tests below: small clouds, large clouds, 40 replayed training runs)."""
 import numpy as np
 import pytest
 import torch
