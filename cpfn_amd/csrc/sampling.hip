@@ -22,6 +22,10 @@
 // Arithmetic follows the reference's CPU route (modules/geometry_utils.py:88-101)
 // op for op — ((dx*dx + dy*dy) + dz*dz) with every op rounded — so that the selected
 // indices are identical to it, not merely close.
+//
+// Beside a training step (cpfn_set_background_geometry) the instantiations differ: no packed fp32 at 64 / 256 lanes x 8 points, and
+// the 8192-point shape claims its compute unit's whole LDS — a co-resident weight-gradient workgroup makes packed fp32 lose a
+// row now and then (round 4; fps_update and fps_launch below).
 #include "common.h"
 #include <cstdlib>
 
