@@ -2,7 +2,9 @@
 round 4 — the sample's own min-distance must be 0 after the distance update, counted in g_fps_dbg / cpfn_dbg_fps_read; a scratch
 tree, not the product.)  The packed instantiation (ops.fps OUTSIDE background_geometry) loops on a side stream while ONE candidate
 loops on the main stream; per candidate: invariant violations and launches whose indices differ from the quiet run's.
-    python tools/dbg/pk_aggressor.py [seconds per candidate]"""
+    python tools/dbg/pk_aggressor.py [seconds per candidate] [stacks | kernels | ablate]
+(stacks: one MLP stack's forward + backward at a time; kernels: one backward kernel at a time; ablate: a tools/dbg/fps_ablate.py build,
+the real kernel beside mlp_wgrad under one run-time ablation mask at a time)"""
 import ctypes
 import os
 import sys
@@ -154,6 +156,40 @@ def main():
         cands = (("bn_relu_bwd (pass 1 reduction)", k_relu_bwd), ("bn_bwd_finalize (fp64 sums)", k_finalize), ("bn_bwd_apply", k_apply),
                  ("mlp_wgrad", k_wgrad), ("multi_split_reduce", k_reduce), ("data-gradient GEMM (w_trans)", k_dgrad),
                  ("forward GEMM with statistics", k_fwd_gemm))
+    elif len(sys.argv) > 2 and sys.argv[2] == "ablate":
+        # ---- "ablate" mode (a tools/dbg/fps_ablate.py build): the real packed kernel beside mlp_wgrad, one ablation mask at a time
+        P_, N_ = 131072, 128
+        gk = torch.Generator().manual_seed(7)
+        Gy_ = torch.randn(P_, N_, generator=gk).to(dev).to(torch.bfloat16)
+        splits = h.cpfn_mlp_wgrad_splits(P_, N_, N_)
+        ws = torch.empty(splits * N_ * N_, device=dev)
+
+        def k_wgrad():
+            for _ in range(40):
+                _l.check(h.cpfn_mlp_wgrad(Gy_.data_ptr(), N_, Gy_.data_ptr(), N_, None, P_, N_, N_, None, None, ws.data_ptr(), None,
+                                          torch.cuda.current_stream().cuda_stream), "wgrad")
+        h.cpfn_dbg_fps_abl.argtypes = [ctypes.c_int]
+        side = torch.cuda.Stream()
+        for mask in (0, 1, 2, 4, 8, 16, 32, 64, 2 | 4, 8 | 16, 1 | 2 | 4 | 8 | 16, 127):
+            h.cpfn_dbg_fps_abl(mask)
+            torch.cuda.synchronize()
+            ref_m = ops.fps(xyz, 512, start).clone()               # quiet run under this mask (masks 1 and 32 change what is written)
+            h.cpfn_dbg_fps_read(buf, 1)
+            t0, launches, bad = time.time(), 0, torch.zeros((), dtype=torch.int32, device=dev)
+            while time.time() - t0 < secs:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(16):
+                        bad += (ops.fps(xyz, 512, start) != ref_m).any().int()
+                        launches += 1
+                k_wgrad()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+            h.cpfn_dbg_fps_read(buf, 0)
+            print("mask %3d: %6d sampling launches, %4d with different indices%s, %4d invariant violations" %
+                  (mask, launches, int(bad), " (not meaningful: nothing / a schedule is written)" if mask & 33 else "", buf[8]), flush=True)
+        h.cpfn_dbg_fps_abl(0)
+        return
     else:
         cands = None
     side = torch.cuda.Stream()
