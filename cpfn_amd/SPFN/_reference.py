@@ -119,12 +119,29 @@ def _publish_unoverridden():
             setattr(pkg, name, mod)
 
 
+# What may fall through to the reference's own file: host-side GT parsing / JSON export and the TensorFlow twins of its
+# self-checks.  Everything else a module of this package does not define RAISES: a compute function of the reference that
+# silently ran op by op from the reference's file (`guarded_matrix_solve_ls`, whose reference body calls the removed
+# `torch.solve`) is worse than an error that names it.
+PASS_THROUGH = ("create_primitive_from_dict", "creates_json", "batched_gather")
+PASS_THROUGH_PREFIXES = ("extract_",)
+PASS_THROUGH_SUFFIXES = ("_tensorflow",)
+
+
+def passes_through(name):
+    return name in PASS_THROUGH or name.startswith(PASS_THROUGH_PREFIXES) or name.endswith(PASS_THROUGH_SUFFIXES)
+
+
 def module_fallback(module_name):
-    """A module-level `__getattr__` for `cpfn_amd/SPFN/<module_name>.py`: names the device path does not define
-    come from the reference's same-named file."""
+    """A module-level `__getattr__` for `cpfn_amd/SPFN/<module_name>.py`: host-side helper names (`passes_through`) the
+    device path does not define come from the reference's same-named file; any other name raises."""
     def __getattr__(name):
         if name.startswith("__"):
             raise AttributeError(name)
+        if not passes_through(name):
+            raise AttributeError("%s.%s has no %r: only host-side helpers (create_primitive_from_dict, extract_*, creates_json, "
+                                 "batched_gather, *_tensorflow) are passed through to the reference's SPFN/%s.py; a compute "
+                                 "function must be defined on the device path" % (_PKG, module_name, name, module_name))
         try:
             ref = reference_module(module_name)
         except ImportError as e:

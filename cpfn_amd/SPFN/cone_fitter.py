@@ -3,7 +3,12 @@ import numpy as np
 import torch
 
 from . import fitters_common as _fc
-from .plane_fitter import acos_safe, compute_parameter_loss  # noqa: F401 (reference lines 9-10, 105-115)
+from . import plane_fitter as _plane
+
+
+def acos_safe(x):
+    """acos clamped to ±(1 − 1e-6)   (reference lines 9-10)."""
+    return _plane.acos_safe(x)
 
 
 def compute_parameters(P, W, X, div_eps=1e-10):
@@ -18,6 +23,11 @@ def compute_residue_single(apex, axis, half_angle, p):
     vn = torch.nn.functional.normalize(v, p=2, dim=-1, eps=1e-12)
     alpha = acos_safe(torch.sum(vn * axis, dim=-1))
     return torch.sin(torch.clamp(torch.abs(alpha - half_angle), max=np.pi / 2)) ** 2 * torch.sum(v * v, dim=-1)
+
+
+def compute_parameter_loss(predicted_axis, gt_axis, matching_indices, angle_diff):
+    """1 − |axis_pred·axis_gt| (or its angle) of the matched instances   (reference lines 138-148: the plane's loss on the axis)."""
+    return _plane.compute_parameter_loss(predicted_axis, gt_axis, matching_indices, angle_diff)
 
 
 # Names the device path does not define (host-side GT parsing / JSON export, the TensorFlow twins) come from the

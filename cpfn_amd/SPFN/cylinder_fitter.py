@@ -2,7 +2,7 @@
 import torch
 
 from . import fitters_common as _fc
-from .plane_fitter import compute_parameter_loss  # same loss on the axis (reference lines 91-101)
+from . import plane_fitter as _plane
 
 
 def compute_parameters(P, W, X):
@@ -21,6 +21,16 @@ def compute_residue_single(axis, center, radius_squared, p):
     d2 = torch.sum(d ** 2, dim=-1)
     along = torch.sum(d * axis, dim=-1)
     return (sqrt_safe(d2 - along ** 2) - sqrt_safe(radius_squared)) ** 2
+
+
+def acos_safe(x):
+    """acos clamped to ±(1 − 1e-6)   (reference lines 126-127)."""
+    return _plane.acos_safe(x)
+
+
+def compute_parameter_loss(predicted_axis, gt_axis, matching_indices, angle_diff):
+    """1 − |axis_pred·axis_gt| (or its angle) of the matched instances   (reference lines 129-139: the plane's loss on the axis)."""
+    return _plane.compute_parameter_loss(predicted_axis, gt_axis, matching_indices, angle_diff)
 
 
 # Names the device path does not define (host-side GT parsing / JSON export, the TensorFlow twins) come from the

@@ -35,10 +35,13 @@ def centred_scatter(S0, S1, S2, mean):
     return S2 - o(mean, S1) - o(S1, mean) + S0[..., None, None] * o(mean, mean)
 
 
-def _cond_mask(AtA):
+def _cond_mask(AtA, cap=COND_CAP):
     """mask = s_max / s_min < 1e5 on the detached singular values (reference lines 132-134)."""
     D = AtA.shape[-1]
     A = AtA.detach()
+    if D not in (2, 3):                      # (the fitters only use D = 2, 3; any other width through the library routine)
+        s = torch.linalg.svdvals(A)
+        return ((s[..., 0] / s[..., -1]) < cap).to(AtA.dtype)
     if D == 3:
         lam, _ = _m.eigh3(to6(A))
         s = lam.abs()
@@ -47,12 +50,14 @@ def _cond_mask(AtA):
         a, b, c = A[..., 0, 0], A[..., 0, 1], A[..., 1, 1]
         mid, rad = 0.5 * (a + c), torch.sqrt((0.5 * (a - c)) ** 2 + b * b)
         smax, smin = torch.maximum((mid + rad).abs(), (mid - rad).abs()), torch.minimum((mid + rad).abs(), (mid - rad).abs())
-    return ((smax / smin) < COND_CAP).to(AtA.dtype)
+    return ((smax / smin) < cap).to(AtA.dtype)
 
 
 def _solve_small(A, b):
     """Closed-form solve of [...,D,D] x = [...,D] for D in (2, 3) (adjugate / determinant)."""
     D = A.shape[-1]
+    if D not in (2, 3):
+        return torch.linalg.solve(A, b.unsqueeze(-1)).squeeze(-1)
     if D == 2:
         det = A[..., 0, 0] * A[..., 1, 1] - A[..., 0, 1] * A[..., 1, 0]
         x0 = (A[..., 1, 1] * b[..., 0] - A[..., 0, 1] * b[..., 1]) / det
@@ -65,11 +70,26 @@ def _solve_small(A, b):
     return torch.stack([(c0 * b).sum(-1), (c1 * b).sum(-1), (c2 * b).sum(-1)], -1) / det.unsqueeze(-1)
 
 
-def guarded_solve_normal_equations(AtA, Atb):
+def guarded_solve_normal_equations(AtA, Atb, condition_number_cap=COND_CAP, ls_l2_regularizer=RIDGE):
     """(AtA·mask + 1e-8 I) x = Atb·mask   (reference lines 134-140)."""
-    mask = _cond_mask(AtA)
+    mask = _cond_mask(AtA, condition_number_cap)
     eye = torch.eye(AtA.shape[-1], dtype=AtA.dtype, device=AtA.device)
-    return _solve_small(AtA * mask[..., None, None] + RIDGE * eye, Atb * mask[..., None])
+    return _solve_small(AtA * mask[..., None, None] + ls_l2_regularizer * eye, Atb * mask[..., None])
+
+
+def guarded_matrix_solve_ls(A, b, W, condition_number_cap=1e5, sqrt_eps=1e-10, ls_l2_regularizer=1e-8):
+    """Weighted least squares ‖√W (A x − b)‖² with the reference's guards   (reference lines 121-142, same signature):
+    A [G,N,D], b [G,N,1], W [G,N] -> x [G,D].  Row weights clamp(W, sqrt_eps) (the square of the reference's
+    √clamp(W)); the D x D normal equations are accumulated in fp64 and go through `guarded_solve_normal_equations` —
+    the condition-number cap on the detached singular values and the ridge — which is what the sphere / circle / apex
+    fits of this package use on their fused moments.  The reference's body calls `torch.solve`, removed from PyTorch."""
+    if not A.is_cuda:
+        raise RuntimeError("guarded_matrix_solve_ls: CPU not supported (cpfn_amd runs on the device path only)")
+    w = W.clamp(min=sqrt_eps).unsqueeze(2).double()
+    Ad = A.double()
+    Aw = (Ad * w).transpose(1, 2)                                  # [G,D,N]
+    x = guarded_solve_normal_equations(Aw @ Ad, (Aw @ b.double()).squeeze(2), condition_number_cap, ls_l2_regularizer)
+    return x.to(A.dtype)
 
 
 def fit_plane(S0, S1, S2):

@@ -44,16 +44,30 @@ _ALIASES = {
 }
 
 
-def install(compute_dtype=None, fast_epoch=False):
+# the caller harness (training_SPFN.py:14 `from Utils import training_utils`), aliased unless install(fast_epoch=False)
+_EPOCH_ALIASES = {"Utils.training_utils": "cpfn_amd.Utils.training_utils"}
+
+
+def alias_names():
+    """Every module name install() may bind (tests snapshot / restore these)."""
+    return sorted(list(_ALIASES) + list(_EPOCH_ALIASES))
+
+
+def install(compute_dtype=None, fast_epoch=True):
     """Alias the reference's module names.  `compute_dtype=torch.bfloat16` additionally makes
     every PointNet2 built afterwards use the fused bf16 MFMA stacks by default.
-    `fast_epoch=True`: `Utils.training_utils.spfn_train_val_epoch` (the loop training_SPFN.py:105-108 calls) resolves to
-    the replayed-step epoch loop (cpfn_amd/epoch.py: one graph replay per batch, pinned look-ahead input staging, deferred
-    logging, same signature / return / prints); every other name of `Utils.training_utils` stays the reference's own."""
+    `fast_epoch` (default since round 5: the unchanged script should get the replayed step, not 0.13 x of it):
+    `Utils.training_utils.spfn_train_val_epoch` / `patch_selection_train_val_epoch` (the loops training_SPFN.py:105-108 and
+    training_PatchSelection.py:79-86 call) resolve to the replayed-step epoch loops (cpfn_amd/epoch.py: one graph replay per
+    batch, pinned look-ahead input staging, deferred logging, same signature / return / prints) — WHEN the caller's optimizer
+    is the plain `torch.optim.Adam` those scripts build; with any other optimizer the same call runs the reference's own loop
+    (decided per call, with a warning).  Every other name of `Utils.training_utils` stays the reference's own.
+    `fast_epoch=False` leaves `Utils.training_utils` alone: the reference's loop on the eager modules."""
     for ref_name, ours in _ALIASES.items():
         sys.modules[ref_name] = importlib.import_module(ours)
     if fast_epoch:
-        sys.modules["Utils.training_utils"] = importlib.import_module("cpfn_amd.Utils.training_utils")
+        for ref_name, ours in _EPOCH_ALIASES.items():
+            sys.modules[ref_name] = importlib.import_module(ours)
     from .SPFN import _reference
     _reference.attach()            # SPFN.primitives & co. of a checkout that is already on sys.path; lazy otherwise
     if compute_dtype is not None:
@@ -64,4 +78,4 @@ def install(compute_dtype=None, fast_epoch=False):
             orig(self, *a, **k)
             self.set_compute_dtype(compute_dtype)
         pn2_network.PointNet2.__init__ = patched
-    return sorted(_ALIASES)
+    return sorted(list(_ALIASES) + (list(_EPOCH_ALIASES) if fast_epoch else []))

@@ -288,6 +288,42 @@ class SPFNTrainer:
             self._skipped_dev = torch.zeros((), dtype=torch.float32, device=device)
         return self._skipped_dev
 
+    # ---- the rank's FAULT WORD (data parallel) --------------------------------------------------------------------------
+    # One sticky 0-dim fp32 word per rank: non-zero = "what this rank computed may be wrong" (a cross-stream flag wait of the
+    # replayed step timed out; `raise_fault()` for anything the caller finds — an FPS fault count, a failed loader).  The
+    # gradient-packing launch copies it into the flat bucket's fault slot, it rides on the step's ONE collective (any rank's 1
+    # makes the reduced slot non-zero everywhere) and the reduced value is the optimizer's skip flag: every replica skips the
+    # same step, so the weights stay identical.  Then the raising rank errors (taking the process group down where torch can)
+    # and its peers error too instead of waiting in the next collective.
+    def fault_word(self, device):
+        if getattr(self, "_fault", None) is None or self._fault.device != torch.device(device):
+            self._fault = torch.zeros((), dtype=torch.float32, device=device)
+            self._fault_raised = None
+        return self._fault
+
+    def raise_fault(self, reason="fault raised by the caller"):
+        """Mark this rank's next step as not to be applied — on EVERY rank.  The step that carries the word still runs (its
+        collective must match the peers'), skips the optimizer everywhere, and then raises."""
+        dev = self.bucket.flat.device
+        self.fault_word(dev).fill_(1.0)
+        self._fault_raised = str(reason)
+
+    def _after_exchange_fault_check(self):
+        """Host side of the fault word on the paths that read the device anyway (eager launches): after the exchange the
+        bucket's fault slot is the ranks' mean."""
+        if float(self.bucket.fault_slot) == 0.0:
+            return
+        if getattr(self, "_fault_raised", None) is not None:
+            abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+            try:
+                if abort is not None:
+                    abort()
+            except Exception:
+                pass
+            raise RuntimeError("cpfn_amd: this rank raised its fault word (%s); every rank skipped the optimizer step" % self._fault_raised)
+        raise RuntimeError("cpfn_amd: a PEER rank raised its fault word; every rank skipped the optimizer step (this rank's "
+                           "replica is intact: restart from it)")
+
     def _schedules(self):
         m = get_batch_norm_decay(self.global_step, self.batch_size, self.bn_decay_step)
         if m != self._bn_momentum:
@@ -672,7 +708,7 @@ class SPFNTrainer:
             # graph, so a step computed from a broken hand-over can never update the weights.
             st["flags"] = torch.zeros(4, dtype=torch.int32, device=dev)
             st["flag_err"] = torch.zeros(4, dtype=torch.int32).pin_memory()
-            st["flag_fault"] = torch.zeros((), dtype=torch.float32, device=dev)
+            st["flag_fault"] = self.fault_word(dev)            # (the rank's one fault word: raise_fault() sets the same tensor)
             st["flag_timeout"] = _flag_timeout_ticks(world)
             st["n_main"], st["n_side"] = 0, 0
             with torch.cuda.graph(g, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
@@ -875,6 +911,10 @@ class SPFNTrainer:
                 self._exchange_with_stamps(batch["P"].device)
                 self._checked_optimizer_step(st["skipped"], fault=self.bucket.fault_slot.reshape(()))
             self.global_step += 1
+            if st["world"] > 1 and getattr(self, "_fault_raised", None) is not None:
+                # raise_fault(): the replay just issued carries the word through the collective (every rank skips); now stop
+                torch.cuda.current_stream(batch["P"].device).synchronize()
+                self._after_exchange_fault_check()
             return st["out"]
         st["g1"].replay()
         st["cost_ready"].record()                              # the cost matrices are in pinned host memory after this
@@ -1017,15 +1057,19 @@ class SPFNTrainer:
         if next_batch is not None:
             self.prefetch(next_batch)
         out[0].backward()
-        self.bucket.collect()
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.bucket.collect(fault=self.fault_word(self.bucket.flat.device) if world > 1 else None)
         self.bucket.all_reduce_mean()
+        reduced_fault = self.bucket.fault_slot.reshape(()) if world > 1 else None
         if self.use_graphs:                            # capturable optimizer: skip decided (and counted) on the device
-            self._checked_optimizer_step(self._skip_counter(self.bucket.flat.device))
-        elif bool(self.bucket.finite()):               # single host sync (reference: 148)
+            self._checked_optimizer_step(self._skip_counter(self.bucket.flat.device), fault=reduced_fault)
+        elif bool(self.bucket.finite()) and (reduced_fault is None or float(reduced_fault) == 0.0):   # host sync (reference: 148)
             self.optimizer.step()
         else:
             self._host_skipped += 1
         self.global_step += 1
+        if world > 1 and not self.use_graphs:
+            self._after_exchange_fault_check()
         return tuple(o.detach() for o in out)     # do not keep the autograd graph alive across steps
 
 

@@ -123,6 +123,55 @@ def test_reduce_scatter_all_gather_layout_at_three_and_four_ranks(tmp_path, worl
     assert b.fault_slot.data_ptr() == b.flat.data_ptr() + 4 * b.flat.numel() and b.padded.numel() > b.flat.numel()
 
 
+def _fault_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    model = TinyHeads()
+    training.broadcast_parameters(model)
+    tr = training.SPFNTrainer(model, batch_size=2 * world, multipliers=LOCAL_MULT, fused_adam=False)
+    snap = lambda: {k: v.clone() for k, v in model.state_dict().items()}
+    for step in range(2):
+        tr.step(_batch(2, seed=10 * step + rank))
+    before = snap()
+    moments_before = [v.clone() for st_ in tr.optimizer.state.values() for v in st_.values() if torch.is_tensor(v)]
+    if rank == 1:
+        tr.raise_fault("injected by the test on step 3")
+    err = None
+    try:
+        tr.step(_batch(2, seed=20 + rank))                       # step 3: the fault word rides on the all-reduce
+    except RuntimeError as e:
+        err = str(e)
+    after = snap()
+    moments_after = [v.clone() for st_ in tr.optimizer.state.values() for v in st_.values() if torch.is_tensor(v)]
+    torch.save({"before": before, "after": after, "err": err, "skipped": tr.skipped_steps, "fault_slot": float(tr.bucket.fault_slot),
+                "moments_equal": all(torch.equal(a, b) for a, b in zip(moments_before, moments_after)),
+                "grad_norm": float(tr.bucket.flat.norm())}, os.path.join(out_dir, "rank%d.pt" % rank))
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_s_fault_skips_the_step_on_every_rank_and_both_fail_fast(tmp_path):
+    """VERDICT r4 #8 / ADVICE r3: the fault slot's BEHAVIOUR, not its layout.  Rank 1 raises its fault word before step 3; the word
+    rides on the step's one all-reduce in the bucket's fault slot; BOTH ranks skip the optimizer on that step (weights and Adam
+    moments bit-identical before / after, on both ranks, replicas still equal), the raising rank errors with its reason and the
+    peer errors too — at once, not after a collective time-out (the test's own time-out would catch a hang)."""
+    world = 2
+    mp.spawn(_fault_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % k)) for k in range(world)]
+    for k in range(world):
+        assert r[k]["skipped"] == 1 and r[k]["fault_slot"] == 0.5 and r[k]["moments_equal"], (k, r[k]["skipped"], r[k]["fault_slot"])
+        assert r[k]["grad_norm"] > 0                               # a real averaged gradient WAS there to be applied
+        for name in r[k]["before"]:
+            assert torch.equal(r[k]["before"][name], r[k]["after"][name]), "rank %d applied the step: %s" % (k, name)
+            assert torch.equal(r[0]["after"][name], r[k]["after"][name]), "replicas diverged: %s" % name
+    assert r[1]["err"] is not None and "this rank raised its fault word (injected by the test on step 3)" in r[1]["err"]
+    assert r[0]["err"] is not None and "PEER rank raised its fault word" in r[0]["err"]
+
+
 # ---- the REAL network: PointNet2 (fp32 compute mode) + SPFNTrainer + FlatGradBucket on two gloo ranks ------------------
 # The device kernels of the geometry path are replaced by oracle-backed CPU stand-ins for the duration of the test
 # (tests/cpu_standins.py: test infrastructure); everything else — module tree, per-replica BatchNorm, flat bucket, the

@@ -5,7 +5,7 @@ import sys
 
 def test_install_aliases_reference_import_paths():
     import cpfn_amd.dropin as d
-    saved = {k: sys.modules.get(k) for k in d._ALIASES}
+    saved = {k: sys.modules.get(k) for k in d.alias_names()}
     try:
         d.install()
         from PointNet2 import pn2_network
@@ -35,6 +35,12 @@ def test_install_aliases_reference_import_paths():
         fitter_factory.register_primitives(["sphere", "plane", "cylinder", "cone"])
         assert fitter_factory.primitive_name_to_id("cylinder") == 2
         assert fitter_factory.get_n_registered_primitives() == 4
+        # the caller harness: bound by default (the unchanged script must get the replayed step) ...
+        assert sys.modules["Utils.training_utils"].__name__ == "cpfn_amd.Utils.training_utils"
+        assert sys.modules["Utils.training_utils"].spfn_train_val_epoch.__module__ == "cpfn_amd.epoch"
+        # ... and left alone on request
+        del sys.modules["Utils.training_utils"]
+        assert "Utils.training_utils" not in d.install(fast_epoch=False) and "Utils.training_utils" not in sys.modules
     finally:
         for k, v in saved.items():
             if v is None:
@@ -64,7 +70,7 @@ def test_merging_utils_alias_keeps_the_host_solver_of_the_reference(tmp_path):
     (tmp_path / "Utils" / "merging_utils.py").write_text(
         "def run_heuristic_solver(*a, **k):\n    return 'host solver of the reference'\n"
         "def similarity_soft(*a):\n    raise AssertionError('must not be reached')\n")
-    saved = {k: sys.modules.get(k) for k in list(d._ALIASES) + ["Utils"]}
+    saved = {k: sys.modules.get(k) for k in d.alias_names() + ["Utils"]}
     sys.path.insert(0, str(tmp_path))
     try:
         d.install()
@@ -101,7 +107,7 @@ def _restore_modules(saved_keys_snapshot):
 
 def _snapshot():
     import cpfn_amd.dropin as d
-    return {k: sys.modules.get(k) for k in list(d._ALIASES) + ["Utils", "Dataset", "SPFN.primitives"]}
+    return {k: sys.modules.get(k) for k in d.alias_names() + ["Utils", "Dataset", "SPFN.primitives"]}
 
 
 FAKE_PRIMITIVES = "class Plane:\n    def __init__(self, n, c):\n        self.n, self.c = n, c\n"
@@ -149,7 +155,12 @@ def test_host_helpers_of_a_fake_reference_tree_resolve_behind_the_alias(tmp_path
         assert sys.modules["SPFN.geometry_utils"].__name__ == "cpfn_amd.SPFN.geometry_utils"
         import pytest
         with pytest.raises(AttributeError, match="neither"):
-            plane_fitter.no_such_name
+            plane_fitter.extract_no_such_name                      # a pass-through NAME neither side defines
+        with pytest.raises(AttributeError, match="only host-side helpers"):
+            plane_fitter.no_such_name                              # anything else is not passed through at all
+        from SPFN import geometry_utils
+        with pytest.raises(AttributeError, match="only host-side helpers"):
+            geometry_utils.host_only_helper                        # ... even if the checkout's file defines it
     finally:
         sys.path.remove(str(tmp_path))
         _restore_modules(saved)
@@ -275,3 +286,40 @@ def test_the_reference_s_own_data_path_runs_behind_the_alias():
         if saved_h5 is None:
             sys.modules.pop("h5py", None)
         _restore_modules(saved)
+
+
+def test_every_reference_function_is_defined_here_or_passed_through_by_name():
+    """walk every top-level `def` / `class` of the reference's SPFN/*.py.  Each is either DEFINED by the same-named
+    module of this package (a `def` of its own, not a fall-through) or is on the pass-through allow-list (host-side GT parsing /
+    JSON export, TensorFlow twins).  A compute function of the reference that silently ran the reference's own op-by-op file would
+    fail here.  Build container only: needs the reference checkout."""
+    import ast
+    import importlib
+    import os
+    import pytest
+    from cpfn_amd.SPFN import _reference as r
+    ref_dir = os.path.join(REFERENCE, "SPFN")
+    if not os.path.isdir(ref_dir):
+        pytest.skip("no reference checkout (GPU box)")
+    ours_dir = os.path.dirname(r.__file__)
+    checked = 0
+    for f in sorted(os.listdir(ref_dir)):
+        name = f[:-3]
+        if not f.endswith(".py") or name == "__init__" or not r.overridden(name):
+            continue                                            # (`primitives`: not overridden, the reference's file IS the module)
+        tree = ast.parse(open(os.path.join(ref_dir, f)).read())
+        ref_defs = [n.name for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))]
+        own = ast.parse(open(os.path.join(ours_dir, f)).read())
+        own_defs = {n.name for n in own.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))}
+        mod = importlib.import_module("cpfn_amd.SPFN." + name)
+        for d in ref_defs:
+            checked += 1
+            if r.passes_through(d):
+                continue
+            assert d in own_defs, "SPFN/%s.py:%s is neither defined in cpfn_amd/SPFN/%s nor on the pass-through list" % (name, d, f)
+            assert getattr(mod, d).__module__.startswith("cpfn_amd."), (name, d)
+    assert checked > 100
+    # the allow-list is narrow: none of the reference's compute functions match it
+    for d in ("guarded_matrix_solve_ls", "compute_parameter_loss", "acos_safe", "compute_parameters", "weighted_sphere_fitting",
+              "solve_weighted_tls", "compute_all_losses", "compute_all_metrics", "hungarian_matching"):
+        assert not r.passes_through(d), d

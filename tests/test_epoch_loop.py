@@ -195,11 +195,11 @@ def test_fast_epoch_dropin_against_the_reference_s_own_function():
     calls and weights."""
     import cpfn_amd.dropin as d
     import cpfn_amd.Utils.training_utils as tu
-    saved = {k: sys.modules.get(k) for k in list(d._ALIASES) + ["Utils", "Utils.training_utils", "SPFN.primitives"]}
+    saved = {k: sys.modules.get(k) for k in d.alias_names() + ["Utils", "Utils.training_utils", "SPFN.primitives"]}
     sys.path.insert(0, REF)
     tu._reference_module = None
     try:
-        d.install(fast_epoch=True)
+        d.install()                                    # (fast_epoch is the default since round 5)
         from Utils import training_utils
         assert training_utils is tu
         assert training_utils.spfn_train_val_epoch.__module__ == "cpfn_amd.epoch"

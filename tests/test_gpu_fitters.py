@@ -121,6 +121,57 @@ def test_reference_shaped_helpers_vs_oracle():
     assert rel_err(ctr.cpu(), ctr_r[:, 0]) < TOL and rel_err(r2.cpu(), r2_r[:, 0]) < TOL
 
 
+def test_guarded_matrix_solve_ls_on_the_selftest_sphere_problem(golden):
+    """`SPFN.geometry_utils.guarded_matrix_solve_ls` exists on the device path with the reference's signature
+    (SPFN/geometry_utils.py:121-142) — given the (A, b, W) that `weighted_sphere_fitting` builds (:209-220) from the reference's own
+    self-test recipe it returns the fixture's sphere centres (the reference's output) and the oracle's, per instance; its guards
+    (condition-number cap, ridge) answer a rank-deficient problem with 0 like the oracle; gradients flow to A, b and W."""
+    from cpfn_amd.SPFN import geometry_utils
+    g = golden("fitters_selftest")
+    P, W = torch.from_numpy(g["P"]), torch.from_numpy(g["W"])
+    B, N, K = W.shape
+    Wk = W.transpose(1, 2).reshape(B * K, N)                                       # [BK,N]   (sphere_fitter.py:12-13)
+    Pk = P.unsqueeze(1).expand(B, K, N, 3).reshape(B * K, N, 3)
+    den = Wk.sum(1).clamp(min=1e-10)
+    psq = (Pk * Pk).sum(-1)
+    b = ((Wk * psq).sum(1) / den).unsqueeze(1) - psq                               # :213-214
+    A = 2.0 * (((Wk.unsqueeze(2) * Pk).sum(1) / den.unsqueeze(1)).unsqueeze(1) - Pk)   # :215-216
+    x = geometry_utils.guarded_matrix_solve_ls(A.to(dev()), b.unsqueeze(2).to(dev()), Wk.to(dev())).cpu()
+    assert x.dtype == torch.float32 and x.shape == (B * K, 3)
+    ref = torch.from_numpy(g["out_sphere_center"]).reshape(B * K, 3)
+    xo = ospfn.guarded_matrix_solve_ls(A.view(B, K, N, 3), b.view(B, K, N), Wk.view(B, K, N)).reshape(B * K, 3)
+    for want in (ref, xo):
+        e = (x - want).norm(dim=-1) / want.norm(dim=-1).clamp(min=1e-3)
+        assert float(e.max()) < TOL, float(e.max())
+    # the guards: two identical columns -> condition number over the cap -> mask 0 -> x = 0 (ridge only), as in the oracle
+    A2 = A.clone()
+    A2[:, :, 1] = A2[:, :, 0]
+    x2 = geometry_utils.guarded_matrix_solve_ls(A2.to(dev()), b.unsqueeze(2).to(dev()), Wk.to(dev())).cpu()
+    xo2 = ospfn.guarded_matrix_solve_ls(A2.view(B, K, N, 3), b.view(B, K, N), Wk.view(B, K, N)).reshape(B * K, 3)
+    assert float(x2.abs().max()) == 0.0 and float(xo2.abs().max()) == 0.0
+    # D = 2 (the cylinder's circle fit) against the oracle
+    x3 = geometry_utils.guarded_matrix_solve_ls(A[:, :, :2].contiguous().to(dev()), b.unsqueeze(2).to(dev()), Wk.to(dev())).cpu()
+    xo3 = ospfn.guarded_matrix_solve_ls(A.view(B, K, N, 3)[..., :2], b.view(B, K, N), Wk.view(B, K, N)).reshape(B * K, 2)
+    assert rel_err(x3, xo3) < TOL
+    # differentiable in all three arguments, gradients against the oracle's autograd
+    Ad, bd, Wd = (t.to(dev()).requires_grad_(True) for t in (A, b.unsqueeze(2), Wk))
+    geometry_utils.guarded_matrix_solve_ls(Ad, bd, Wd).square().sum().backward()
+    Ao, bo, Wo = (t.clone().requires_grad_(True) for t in (A.view(B, K, N, 3), b.view(B, K, N), Wk.view(B, K, N)))
+    ospfn.guarded_matrix_solve_ls(Ao, bo, Wo).square().sum().backward()
+    assert rel_err(Ad.grad.cpu().view(B, K, N, 3), Ao.grad) < 1e-3
+    assert rel_err(bd.grad.cpu().view(B, K, N), bo.grad) < 1e-3
+    assert rel_err(Wd.grad.cpu().view(B, K, N), Wo.grad) < 1e-3
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        geometry_utils.guarded_matrix_solve_ls(A, b.unsqueeze(2), Wk)
+    from cpfn_amd.SPFN import cone_fitter, cylinder_fitter, plane_fitter
+    for m in (cylinder_fitter, cone_fitter):                                        # own `def`s now, not fall-throughs
+        assert m.acos_safe.__module__ == m.__name__ and m.compute_parameter_loss.__module__ == m.__name__
+        pn, gn = torch.randn(2, 5, 3, device=dev()), torch.randn(2, 4, 3, device=dev())
+        mi = torch.randint(0, 5, (2, 4), device=dev())
+        for ad in (False, True):
+            assert torch.equal(m.compute_parameter_loss(pn, gn, mi, ad), plane_fitter.compute_parameter_loss(pn, gn, mi, ad))
+
+
 def test_moment_linearity_and_determinism():
     """Size-independent properties at the full benchmark size (B=16, N=8192, K=28):
     moments are linear in W, and two runs are bitwise identical (no atomics)."""

@@ -156,21 +156,26 @@ def main():
         cands = (("bn_relu_bwd (pass 1 reduction)", k_relu_bwd), ("bn_bwd_finalize (fp64 sums)", k_finalize), ("bn_bwd_apply", k_apply),
                  ("mlp_wgrad", k_wgrad), ("multi_split_reduce", k_reduce), ("data-gradient GEMM (w_trans)", k_dgrad),
                  ("forward GEMM with statistics", k_fwd_gemm))
-    elif len(sys.argv) > 2 and sys.argv[2] == "ablate":
+    elif len(sys.argv) > 2 and sys.argv[2] in ("ablate", "ablate0", "diag"):
         # ---- "ablate" mode (a tools/dbg/fps_ablate.py build): the real packed kernel beside mlp_wgrad, one ablation mask at a time
-        P_, N_ = 131072, 128
+        # (the "kernels" mode's aggressor, the one round 4 found: 8192 rows, 128 -> 128 = the 64 x 64-tile weight-gradient kernel,
+        #  9 KB of LDS and 116 registers, which FITS beside a sampling workgroup.  Round 5's first run used 131072 rows: the
+        #  128 x 128-tile kernel, 252 registers at 8 waves — it cannot share a compute unit with anything, and nothing failed.)
+        P_, N_ = int(os.environ.get("PK_ROWS", "8192")), 128
         gk = torch.Generator().manual_seed(7)
         Gy_ = torch.randn(P_, N_, generator=gk).to(dev).to(torch.bfloat16)
         splits = h.cpfn_mlp_wgrad_splits(P_, N_, N_)
         ws = torch.empty(splits * N_ * N_, device=dev)
 
         def k_wgrad():
-            for _ in range(40):
+            for _ in range(60):
                 _l.check(h.cpfn_mlp_wgrad(Gy_.data_ptr(), N_, Gy_.data_ptr(), N_, None, P_, N_, N_, None, None, ws.data_ptr(), None,
                                           torch.cuda.current_stream().cuda_stream), "wgrad")
         h.cpfn_dbg_fps_abl.argtypes = [ctypes.c_int]
         side = torch.cuda.Stream()
-        for mask in (0, 1, 2, 4, 8, 16, 32, 64, 2 | 4, 8 | 16, 1 | 2 | 4 | 8 | 16, 127):
+        import struct
+        f32 = lambda v: struct.unpack("f", struct.pack("i", v))[0]
+        for mask in ((0, 1, 2, 4, 8, 16, 32, 64, 2 | 4, 8 | 16, 1 | 2 | 4 | 8 | 16, 127) if sys.argv[2] == "ablate" else (0,)):
             h.cpfn_dbg_fps_abl(mask)
             torch.cuda.synchronize()
             ref_m = ops.fps(xyz, 512, start).clone()               # quiet run under this mask (masks 1 and 32 change what is written)
@@ -188,6 +193,14 @@ def main():
             h.cpfn_dbg_fps_read(buf, 0)
             print("mask %3d: %6d sampling launches, %4d with different indices%s, %4d invariant violations" %
                   (mask, launches, int(bad), " (not meaningful: nothing / a schedule is written)" if mask & 33 else "", buf[8]), flush=True)
+            if sys.argv[2] == "diag":
+                print("  events by 16-lane row %s; packed d == distance to the PREVIOUS sample %d; packed d wrong %d; minimum not applied to a "
+                      "right d %d" % (list(buf[0:4]), buf[4], buf[5], buf[6]))
+                for k in range(min(buf[8], 6)):
+                    r = buf[16 + 8 * k:24 + 8 * k]
+                    print("  sample %4d thread %4d (lane %2d) slot %2d: packed d %.9g (0x%08x) scalar d %.9g (0x%08x) d to previous sample %.9g "
+                          "old min %.9g new min %.9g" % (r[0], r[1], r[1] % 64, r[2], f32(r[3]), r[3] & 0xFFFFFFFF, f32(r[4]), r[4] & 0xFFFFFFFF,
+                                                         f32(r[5]), f32(r[6]), f32(r[7])))
         h.cpfn_dbg_fps_abl(0)
         return
     else:
