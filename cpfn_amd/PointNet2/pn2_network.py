@@ -91,18 +91,28 @@ class PointNet2(torch.nn.Module):
         the CUDA route's semantics — what a checkpoint trained by the reference on a GPU saw."""
         from .. import cuda_ops as _co, fused_mlp
         bf16 = getattr(self, "compute_dtype", torch.float32) == torch.bfloat16 and x.is_cuda
-        # An evaluation forward under no_grad (evaluation_globalSPFN.py:85, evaluation_localSPFN.py:95 call the module directly)
-        # is ~100 launches whose host cost exceeds their run time: it is captured once per input shape and replayed as one
+        # An evaluation forward under no_grad (evaluation_globalSPFN.py:84-85; evaluation_localSPFN.py:95 calls the module with
+        # gradients ENABLED and therefore stays on eager launches: its outputs must carry autograd history) is ~100 launches
+        # whose host cost exceeds their run time: from the SECOND time a shape is seen it is captured once and replayed as one
         # hipGraph (inference.GraphedForward; bit-identical, same CPU-generator draws for the FPS starts; outputs are copies).
+        # The first sighting runs eager launches: a caller whose shapes never repeat (full-resolution clouds with a per-shape N)
+        # then pays one eager forward per call, not a warm-up + a capture + a replay and a churned graph pool (ADVICE r4).
         # `model.auto_graph = False` opts out.
         if (bf16 and not self.training and not torch.is_grad_enabled() and geometry is None and getattr(self, "auto_graph", True)
                 and (fast or not _co.CUDA_ROUTE) and not self.__dict__.get("_graph_busy")
                 and not torch.cuda.is_current_stream_capturing()):
-            auto = self.__dict__.get("_auto_graph")
-            if auto is None:
-                from ..inference import GraphedForward
-                auto = self.__dict__["_auto_graph"] = GraphedForward(self, max_shapes=4, clone_outputs=True, weak=True)
-            return auto(x, glob_features=glob_features, loc_features=loc_features, fps_start=fps_start)
+            seen = self.__dict__.setdefault("_auto_seen", {})
+            skey = (tuple(x.shape), None if glob_features is None else tuple(glob_features.shape),
+                    None if loc_features is None else tuple(loc_features.shape))
+            if skey in seen:
+                auto = self.__dict__.get("_auto_graph")
+                if auto is None:
+                    from ..inference import GraphedForward
+                    auto = self.__dict__["_auto_graph"] = GraphedForward(self, max_shapes=4, clone_outputs=True, weak=True)
+                return auto(x, glob_features=glob_features, loc_features=loc_features, fps_start=fps_start)
+            if len(seen) >= 64:
+                seen.clear()
+            seen[skey] = True
         if bf16:
             # one multi-tensor fp32 -> bf16 conversion; when sa1's input is coordinates only, its fp32 first layer is the
             # forward pass's first launch and the conversion rides on it (cpfn_smallk_fwd_cast)

@@ -230,6 +230,12 @@ def compute_all_metrics(P, X, X_gt, W, I_gt, T, T_gt, points_per_instance, gt_pa
             Sk += [tail[:, 5 + i] for i in range(len(eps))]
             pc = _p_coverage(P, params22, match, slot_type, eps, classes)
             Pc += [pc[:, i] for i in range(len(eps))]
+    # The caller reads these on the host next (evaluation_*.py: `.item()` / `.cpu()` on every entry), so the stream is drained
+    # HERE and the sampling fault word checked behind it: a several-workgroups FPS of the forward pass that was still queued
+    # when this function started cannot hide behind the check at its head any more.
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(dev).synchronize()
+        _ops.check_fps_faults("the end of compute_all_metrics")
     return (first[:, 0], first[:, 1], head[:, 0], first[:, 2], first[:, 3], first[:, 4], Sk, Pc, hardW,
             unpack_parameters(params22), T_inst)
 

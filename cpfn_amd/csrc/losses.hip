@@ -756,11 +756,16 @@ __global__ __launch_bounds__(256) void ce2_kernel(const float *__restrict__ logi
   float li = 0.f, g0 = 0.f, g1 = 0.f;
   if (t < rows) {
     const float2 y = ((const float2 *)logits)[row];
-    const bool one = labels[row] != 0;
+    const long long lab = labels[row];
+    const bool one = lab != 0;
     const float m = fmaxf(y.x, y.y), e0 = expf(y.x - m), e1 = expf(y.y - m), sum = e0 + e1;
     li = (m + logf(sum)) - (one ? y.y : y.x);
     g0 = (e0 / sum - (one ? 0.f : 1.f)) * inv_P;
     g1 = (e1 / sum - (one ? 1.f : 0.f)) * inv_P;
+    // A label outside {0, 1}: F.cross_entropy raises on it (or, for ignore_index = -100, leaves the row out of the mean); a
+    // captured launch cannot raise, so such a row POISONS the loss and its gradient with NaN — the trainer's finite check then
+    // skips the step and the caller sees a NaN loss instead of a row silently counted as class 1.
+    if (lab != 0 && lab != 1) li = g0 = g1 = __builtin_nanf("");
     ((float2 *)dlogits)[row] = (float2){g0, g1};
   }
   s_g[t][0] = g0; s_g[t][1] = g1;

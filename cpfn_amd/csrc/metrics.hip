@@ -9,8 +9,9 @@
 //                           instance the sqrt-safe residues of its N' points against the matched fit (mean, unbiased std,
 //                           coverage per epsilon), reduced to the per-cloud figures — everything that was [B,K]-sized glue.
 //
-// Integer work (histogram, counts, arg-max indices) is exact; float sums are taken in a fixed order (per-block partials,
-// then in chunk order in fp64).
+// Integer work (histogram, counts, arg-max indices) is exact; float sums are taken in a fixed order: the type scores of a
+// block by the lane that owns a (label, type) entry walking the tile's rows in row order (round 5; LDS float atomics before:
+// the order, and with it a near-tie's arg-max, changed from run to run — ADVICE r4), then in chunk order in fp64.
 #include "common.h"
 #include "residue.h"
 
@@ -19,7 +20,8 @@ namespace {
 constexpr int MP_THREADS = 256, MP_TILE = 64, MP_TILES = 4;      // a workgroup = 256 rows as four 64-row tiles
 constexpr int MP_MAXK = 128, MP_MAXT = 8, MT_MAXEPS = 4;
 
-// dynamic LDS: tile [64 * K] floats | labels [64] | hist [(Kp + 2) * Kp] ints | type sums [Kp * NT] floats | 4 floats
+// dynamic LDS: tile [64 * K] floats | labels [64] | hist [(Kp + 2) * Kp] ints | type sums [Kp * NT] floats | 4 floats |
+//              the tile's type rows [64 * NT] floats
 __global__ __launch_bounds__(MP_THREADS) void metrics_points_kernel(
     const float *__restrict__ W, const float *__restrict__ T, const float *__restrict__ X, const float *__restrict__ Xgt,
     const long long *__restrict__ Igt, int N, int K, int Kp, int NT, float *__restrict__ hardW, int *__restrict__ counters,
@@ -30,6 +32,7 @@ __global__ __launch_bounds__(MP_THREADS) void metrics_points_kernel(
   int *s_hist = s_lab + MP_TILE;
   float *s_ts = (float *)(s_hist + (Kp + 2) * Kp);
   float *s_nd = s_ts + Kp * NT;
+  float *s_T = s_nd + 4;
   __shared__ int s_lmax;
   const int b = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
   const int nh = (Kp + 2) * Kp;
@@ -46,6 +49,8 @@ __global__ __launch_bounds__(MP_THREADS) void metrics_points_kernel(
     __syncthreads();
     const float *src = W + ((size_t)b * N + row0) * K;
     for (int e = t; e < rows * K; e += MP_THREADS) s_tile[e] = src[e];
+    const float *srcT = T + ((size_t)b * N + row0) * NT;
+    for (int e = t; e < rows * NT; e += MP_THREADS) s_T[e] = srcT[e];
     __syncthreads();
     // arg-max of a row by four lanes (first index wins a tie, like torch.argmax)
     float bv = -INFINITY;
@@ -71,11 +76,18 @@ __global__ __launch_bounds__(MP_THREADS) void metrics_points_kernel(
         atomicAdd(&s_hist[(Kp + 1) * Kp + (int)g], 1);                     // row Kp + 1: points per GT label
         lmax1 = max(lmax1, (int)g + 1);
       }
-      for (int c = 0; c < NT; ++c) atomicAdd(&s_ts[lab * NT + c], T[n * NT + c]);
       const float d = fabsf(X[n * 3] * Xgt[n * 3] + X[n * 3 + 1] * Xgt[n * 3 + 1] + X[n * 3 + 2] * Xgt[n * 3 + 2]);
       nd += acosf(fminf(fmaxf(d, -1.0f + 1e-6f), 1.0f - 1e-6f));
     }
     __syncthreads();
+    // type scores W^T T of the tile: entry (label k, type c) belongs to ONE lane for the whole launch, which adds the rows that
+    // chose k in row order — a fixed order of additions (no float atomics)
+    for (int e = t; e < Kp * NT; e += MP_THREADS) {
+      const int k = e / NT, c = e - k * NT;
+      float acc = s_ts[e];
+      for (int rr = 0; rr < rows; ++rr) acc += s_lab[rr] == k ? s_T[rr * NT + c] : 0.f;
+      s_ts[e] = acc;
+    }
     float *dst = hardW + ((size_t)b * N + row0) * Kp;
     for (int e = t; e < rows * Kp; e += MP_THREADS) {
       const int rr = e / Kp;
@@ -249,7 +261,17 @@ extern "C" int cpfn_metrics_points(const float *W, const float *T, const float *
   int *counters = (int *)workspace;
   float *partial = (float *)((char *)workspace + ((ints * 4 + 15) / 16) * 16);
   if (hipMemsetAsync(counters, 0, ints * 4, st) != hipSuccess) return (int)hipGetLastError();
-  const size_t lds = sizeof(float) * (MP_TILE * K + Kp * n_types + 4) + sizeof(int) * (MP_TILE + (Kp + 2) * Kp);
+  const size_t lds = sizeof(float) * (MP_TILE * K + Kp * n_types + 4 + MP_TILE * n_types) + sizeof(int) * (MP_TILE + (Kp + 2) * Kp);
+  // Kp = 128 needs 103 KB: past 64 KB a launch needs the kernel's dynamic-LDS limit raised first (as csr_build, moments_bwd and
+  // the sampling kernel's LDS claim do) — label sets of 98..128 columns, which evaluation_localSPFN's merged sets can reach,
+  // would otherwise fail at launch (tests/test_gpu_metrics.py runs K = 100 and K = 128)
+  static size_t lds_allowed = 64 * 1024;
+  if (lds > lds_allowed) {
+    if (hipFuncSetAttribute((const void *)metrics_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) !=
+        hipSuccess)
+      return (int)hipGetLastError();
+    lds_allowed = 160 * 1024 - 64;
+  }
   metrics_points_kernel<<<dim3(chunks, B), MP_THREADS, lds, st>>>(W, T, X, Xgt, (const long long *)Igt, N, K, Kp, n_types, hardW,
                                                                    counters, partial);
   metrics_finish_kernel<<<B, 256, 0, st>>>(counters, partial, chunks, N, Kp, n_types, S, (long long *)n_gt, (long long *)T_inst,

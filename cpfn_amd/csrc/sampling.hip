@@ -23,6 +23,12 @@
 // op for op — ((dx*dx + dy*dy) + dz*dz) with every op rounded — so that the selected
 // indices are identical to it, not merely close.
 //
+// TRIPWIRE (round 5, every instantiation): a sample's own min-distance is 0 after its update, so the next arg-max can only
+// return the SAME point again when every candidate is exhausted (maximum 0).  A repeated point with a positive maximum means the
+// update was lost on the lane that owns the sample — the signature of round 4's packed-fp32 fault — and costs one scalar compare
+// per sample to see: the pass is repeated once (the update is idempotent: min with the same distances; the output stays right) and
+// the workgroup bumps the fault count that cpfn_fps_faults() / ops.check_fps_faults() read (device counter + pinned host word).
+//
 // Beside a training step (cpfn_set_background_geometry) the instantiations differ: no packed fp32 at 64 / 256 lanes x 8 points, and
 // the 8192-point shape claims its compute unit's whole LDS — a co-resident weight-gradient workgroup makes packed fp32 lose a
 // row now and then (round 4; fps_update and fps_launch below).
@@ -31,7 +37,15 @@
 
 constexpr int CPFN_LDS_BYTES_PER_CU = 160 * 1024;      // gfx950
 
+__device__ unsigned g_fps_faults = 0;           // sibling time-outs of the several-workgroups kernel + lost updates (tripwire)
+
 namespace {
+
+// one lane of a workgroup reports a fault: device counter + (when the launcher had one) the pinned host word
+__device__ __forceinline__ void fps_report_fault(unsigned *__restrict__ host_faults) {
+  atomicAdd(&g_fps_faults, 1u);
+  if (host_faults) __hip_atomic_fetch_add(host_faults, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // max of a 64-bit key over lanes by DPP row operations (VALU moves, ~8 cycles each) instead of ds_bpermute butterflies
 // (an LDS-pipeline round trip per step: the two key reductions of a sample were ~0.5 us of its ~1.2 us).
@@ -227,7 +241,8 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
                                                           const int *__restrict__ start, int flags,
                                                           int *__restrict__ idx_out,
                                                           unsigned long long *__restrict__ prof = nullptr,
-                                                          float *__restrict__ centres = nullptr /* [B,S,3]: xyz[idx_out] */) {
+                                                          float *__restrict__ centres = nullptr /* [B,S,3]: xyz[idx_out] */,
+                                                          unsigned *__restrict__ host_faults = nullptr, int dbg_drop = -1) {
   constexpr int NW = NT / CPFN_WAVE;
   static_assert(PPT % 2 == 0, "points sit in registers as pairs");
   __shared__ float s_x[NT * PPT], s_y[NT * PPT], s_z[NT * PPT];   // three b32 broadcasts per sample, NOT one float4:
@@ -263,7 +278,9 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
   unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
   unsigned far = start ? (unsigned)start[b] : 0u;
   float fx = s_x[far], fy = s_y[far], fz = s_z[far];
-  for (int i = 0; i < S; ++i) {
+  bool retried = false;
+  // `it` counts passes (slot parity), `i` samples: a pass whose arg-max returns the point it has just sampled is repeated (tripwire)
+  for (int i = 0, it = 0; i < S; ++it) {
     if (PROFILE) t0 = fps_stamp();
     if (t == 0) out[i] = (int)far;
     if (NW == 1 && i > 0) { fx = s_x[far]; fy = s_y[far]; fz = s_z[far]; }
@@ -272,7 +289,16 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       c[0] = fx; c[1] = fy; c[2] = fz;
     }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[0] += t1 - t0; t0 = t1; }      // (one wave: broadcast read of the sample)
-    const float lm = fps_update<PPT, PK>(px, py, pz, md, fx, fy, fz);
+    float lm;
+    if (dbg_drop >= 0 && i == dbg_drop && !retried && (unsigned)wave == (far % NT) / CPFN_WAVE) {
+      // (test hook, cpfn_fps_debug_drop: the wave that owns sample `dbg_drop` skips its update once — what the hardware fault does
+      //  to a row of lanes — so that the tripwire and its repair can be tested on a box that does not have the fault)
+      lm = -1.0f;
+#pragma unroll
+      for (int j = 0; j < PPT / 2; ++j) lm = v_max3(lm, md[j].x, md[j].y);
+    } else {
+      lm = fps_update<PPT, PK>(px, py, pz, md, fx, fy, fz);
+    }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[1] += t1 - t0; t0 = t1; }      // distance update + lane maximum
     const float wmax = wave_max_f32(lm);
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[2] += t1 - t0; t0 = t1; }      // wave maximum (DPP)
@@ -280,11 +306,12 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
     if (wmax >= 0.f)
       key = ((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)(~fps_first_index<PPT, NT>(md, wmax, (unsigned)t - (unsigned)lane, lane));
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[3] += t1 - t0; t0 = t1; }      // index of the maximum (ballots)
+    const unsigned sampled = far;
     if (NW > 1) {
-      if (lane == 0) s_key[i & 1][wave] = key;
+      if (lane == 0) s_key[it & 1][wave] = key;
       __syncthreads();
       if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[4] += t1 - t0; t0 = t1; }    // LDS slot + workgroup barrier
-      key = s_key[i & 1][lane & (NW - 1)];
+      key = s_key[it & 1][lane & (NW - 1)];
       // Lane w (< NW) holds wave w's candidate: its coordinates are requested from the LDS mirror NOW, while the maximum over
       // the waves is still being formed, and the winner's are picked with three readlanes — the sample's coordinates used
       // to be read after the maximum was known: one more LDS round trip (~250 cycles of a 2200-cycle sample) on the chain.
@@ -311,6 +338,13 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       far = key ? ~(unsigned)(key & 0xFFFFFFFFull) : 0u;
     }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[5] += t1 - t0; t0 = t1; }      // slot read + maximum over the waves
+    // TRIPWIRE: the point just sampled comes back with a positive distance -> its own min-distance was not zeroed (a lost update).
+    // Workgroup-uniform (every wave holds the same key), so every wave repeats the pass together: same f, same i, next parity.
+    const bool lost = !PROFILE && far == sampled && (unsigned)(key >> 32) != 0u;
+    if (lost && t == 0) fps_report_fault(host_faults);
+    if (lost && !retried) { retried = true; continue; }
+    retried = false;
+    ++i;
   }
   if (PROFILE && t == 0 && prof) {
 #pragma unroll
@@ -391,7 +425,6 @@ __global__ __launch_bounds__(NT) void fps_streaming_kernel(const float *__restri
 // (~1 s, once: the sample loop ends there) leaves index 0 (a valid point) in the remaining outputs and counts the cloud in
 // a device-side fault counter that cpfn_fps_faults() reads: a hung GPU and out-of-range indices are both worse.
 // Same arithmetic, same tie-break as the other two kernels: bit-identical selections.
-__device__ unsigned g_fps_faults = 0;
 // Round 4, measured on one box (tools/dbg/fps_shared_time.py, 131072 -> 512, B = 1): what the exchange costs grows with the
 // number of PARTICIPANTS, not with the bytes: 64 workgroups x 8 points per lane 1.41 ms, 32 x 16: 1.24 ms, 16 x 32: 1.00 ms
 // (512 threads x 16: 1.04, 1024 x 8: 1.10; 8 workgroups of 512 x 32: 1.25 — the per-sample pass over 16384 points then costs
@@ -406,10 +439,10 @@ template <int PPT>
 __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict__ xyz, int N, int S,
                                                          const int *__restrict__ start, int flags,
                                                          int *__restrict__ idx_out, unsigned long long *__restrict__ slots,
-                                                         unsigned *__restrict__ host_faults) {
+                                                         unsigned *__restrict__ host_faults, int dbg_drop) {
   constexpr int NT = 256, NW = 4;
   __shared__ unsigned long long s_key[2][NW];
-  __shared__ unsigned s_far;
+  __shared__ unsigned s_far, s_dist;
   const int G = gridDim.x, wg = blockIdx.x, b = blockIdx.y;
   const int t = threadIdx.x, lane = t & (CPFN_WAVE - 1), wave = t / CPFN_WAVE;
   const float *p = xyz + (size_t)b * N * 3;
@@ -429,67 +462,87 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
     px[j / 2][j & 1] = x; py[j / 2][j & 1] = y; pz[j / 2][j & 1] = z; md[j / 2][j & 1] = m;
   }
   unsigned far = start ? (unsigned)start[b] : 0u;
-  bool dead = false;
-  for (int i = 0; i < S; ++i) {
+  bool retried = false;
+  // `it` counts passes (slot parity and tag), `i` samples: see the tripwire at the end of the loop
+  for (int i = 0, it = 0; i < S; ++it) {
     if (wg == 0 && t == 0) out[i] = (int)far;
     const float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
-    const float wmax = wave_max_f32(fps_update<PPT>(px, py, pz, md, fx, fy, fz));
+    float lm;
+    if (dbg_drop >= 0 && i == dbg_drop && !retried && (int)far >= base && (int)far < base + NT * PPT &&
+        (unsigned)wave == ((far - (unsigned)base) % NT) / CPFN_WAVE) {          // (test hook: see fps_resident_kernel)
+      lm = -1.0f;
+#pragma unroll
+      for (int j = 0; j < PPT / 2; ++j) lm = v_max3(lm, md[j].x, md[j].y);
+    } else {
+      lm = fps_update<PPT>(px, py, pz, md, fx, fy, fz);
+    }
+    const float wmax = wave_max_f32(lm);
     // key without the tag: candidates compare by (distance, lowest index); "no candidate" = 0
     unsigned long long key = 0ull;
     if (wmax >= 0.f) {
       const unsigned besti = fps_first_index<PPT, NT>(md, wmax, (unsigned)(base + t - lane), lane);
       key = ((unsigned long long)__float_as_uint(wmax) << 32) | ((unsigned long long)(0xFFFFFu - besti) << 12);
     }
-    if (lane == 0) s_key[i & 1][wave] = key;
+    if (lane == 0) s_key[it & 1][wave] = key;
     __syncthreads();
-    const unsigned tag = (unsigned)(i + 1) & 0xFFFu;
+    const unsigned tag = (unsigned)(it + 1) & 0xFFFu;
     if (t == 0) {
-      unsigned long long k4 = s_key[i & 1][0];
+      unsigned long long k4 = s_key[it & 1][0];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) k4 = s_key[i & 1][w] > k4 ? s_key[i & 1][w] : k4;
-      __hip_atomic_store(&sl[(i & 1) * G + wg], k4 | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 1; w < NW; ++w) k4 = s_key[it & 1][w] > k4 ? s_key[it & 1][w] : k4;
+      __hip_atomic_store(&sl[(it & 1) * G + wg], k4 | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wave == 0) {       // G <= 64 lanes poll one slot each until it carries this sample's tag
+    if (wave == 0) {       // G <= 64 lanes poll one slot each until it carries this pass's tag
       unsigned long long k = 0ull;
       if (lane < G) {
         unsigned spins = 0;
         do {
-          k = __hip_atomic_load(&sl[(i & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          k = __hip_atomic_load(&sl[(it & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (++spins > (1u << 24)) { k = ~0ull; break; }          // ~1 s: a sibling workgroup never arrived
         } while ((unsigned)(k & 0xFFFull) != tag);
       }
       const bool timeout = __ballot(k == ~0ull) != 0ull;
       k = (lane < G && !timeout) ? (k & ~0xFFFull) : 0ull;
       k = wave_max_key(k);
-      if (lane == 0) s_far = timeout ? 0xFFFFFFFFu : (k ? 0xFFFFFu - (unsigned)((k >> 12) & 0xFFFFFull) : 0u);
+      if (lane == 0) {
+        s_far = timeout ? 0xFFFFFFFFu : (k ? 0xFFFFFu - (unsigned)((k >> 12) & 0xFFFFFull) : 0u);
+        s_dist = (unsigned)(k >> 32);
+      }
     }
     __syncthreads();
-    const unsigned nf = s_far;
+    const unsigned nf = s_far, nd = s_dist;
     if (nf == 0xFFFFFFFFu) {          // a sibling workgroup never arrived: give up for this cloud (every workgroup of it
-      dead = true;                    // takes this branch at most one spin period later)
+                                      // takes this branch at most one spin period later)
       if (wg == 0 && t == 0) {
         for (int r = i + 1; r < S; ++r) out[r] = 0;
-        atomicAdd(&g_fps_faults, 1u);
-        if (host_faults) __hip_atomic_fetch_add(host_faults, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        fps_report_fault(host_faults);
       }
       break;
     }
+    // TRIPWIRE (see fps_resident_kernel): every workgroup of the cloud reads the same (nf, nd) and repeats the pass together.  (The
+    // 12-bit tag of a pass only has to differ from what its slot held two passes earlier — it does, modulo 4096 — and from the
+    // memset's zero in the first two passes: repeated passes cannot confuse the exchange.)
+    const bool lost = nf == far && nd != 0u;
+    if (lost && wg == 0 && t == 0) fps_report_fault(host_faults);
     far = nf;
+    if (lost && !retried) { retried = true; continue; }
+    retried = false;
+    ++i;
   }
-  (void)dead;
 }
 
 }  // namespace
 
-// Workgroups of fps_shared_kernel<PPT> that can be resident at once on the current device (0: unknown -> do not use it).
+// Workgroups of fps_shared_kernel<PPT> that can be resident at once on the current device when each is launched with `dyn_lds`
+// bytes of dynamic LDS (0: unknown -> do not use it).
 template <int PPT>
-static int fps_shared_capacity() {
+static int fps_shared_capacity(int dyn_lds) {
   static int cached[64] = {0};                  // per device ordinal; 0 = not queried yet, -1 = query failed
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
   if (cached[dev] == 0) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_shared_kernel<PPT>, 256, 0) == hipSuccess &&
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_shared_kernel<PPT>, 256, dyn_lds) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
       cached[dev] = per_cu * cus;
     else
@@ -520,14 +573,41 @@ static unsigned *fps_host_faults(unsigned **dev_ptr) {
   return host;
 }
 
-// Clouds whose several-workgroups FPS gave up on a sibling since the library was loaded.  Reads a pinned host word (no
-// synchronisation; a fault shows up once its kernel has got that far); without one, the device symbol (synchronises).
+static bool g_fps_have_hf = false, g_fps_launched_without_hf = false;
+
+// Sampling faults since the library was loaded: clouds whose several-workgroups FPS gave up on a sibling + lost updates caught by
+// the tripwire.  Reads a pinned host word (no synchronisation; a fault shows up once its kernel has got that far).  Launches
+// that were issued before the word existed (a first launch inside a stream capture) report to the device counter only: once that
+// has happened — or without a host word at all — the device symbol is read as well (synchronises) and the larger count returned
+// (the freshly allocated host word, 0, used to hide such a graph's faults).
 extern "C" int cpfn_fps_faults(void) {
   const unsigned *h = fps_host_faults(nullptr);
-  if (h) return (int)__atomic_load_n(h, __ATOMIC_RELAXED);
+  unsigned host_n = h ? __atomic_load_n(h, __ATOMIC_RELAXED) : 0u;
+  if (h && !g_fps_launched_without_hf) return (int)host_n;
   unsigned n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fps_faults), sizeof(n)) != hipSuccess) return -1;
-  return (int)n;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fps_faults), sizeof(n)) != hipSuccess) return h ? (int)host_n : -1;
+  return (int)(n > host_n ? n : host_n);
+}
+
+// The whole-LDS claim of a one-workgroup-per-cloud sampling kernel: dynamic padding up to the compute unit's 160 KB, so that no
+// LDS-using workgroup of another kernel can be resident beside it (-1: not available).  Asked once per kernel.
+static int fps_lds_claim(const void *kernel) {
+  static const void *seen[4] = {nullptr, nullptr, nullptr, nullptr};
+  static int pads[4] = {-1, -1, -1, -1};
+  for (int i = 0; i < 4; ++i) {
+    if (seen[i] == kernel) return pads[i];
+    if (!seen[i]) {
+      seen[i] = kernel;
+      hipFuncAttributes a;
+      if (hipFuncGetAttributes(&a, kernel) == hipSuccess) {
+        const int p = CPFN_LDS_BYTES_PER_CU - (int)a.sharedSizeBytes;
+        if (p >= 0 && hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p) == hipSuccess) pads[i] = p;
+      }
+      (void)hipGetLastError();
+      return pads[i];
+    }
+  }
+  return -1;
 }
 
 static int fps_launch(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out, float *scratch,
@@ -546,18 +626,37 @@ extern "C" int cpfn_fps_centres(const float *xyz, int B, int N, int S, const int
   return fps_launch(xyz, B, N, S, start, flags, idx_out, nullptr, centres, (hipStream_t)stream);
 }
 
+static int g_fps_dbg_drop = -1;
+// Test hook: the wave that owns sample `sample` (0-based) skips its distance update once in every sampling launch issued from now on
+// (-1: off) — what round 4's hardware fault does to a row of lanes — so that the tripwire and its repair are testable anywhere.
+extern "C" int cpfn_fps_debug_drop(int sample) {
+  const int was = g_fps_dbg_drop;
+  g_fps_dbg_drop = sample;
+  return was;
+}
+
 static int fps_launch(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out, float *scratch,
                       float *centres, hipStream_t st) {
   if (B < 0 || N <= 0 || S < 0 || !xyz || (!idx_out && B * S > 0)) return CPFN_EINVAL;
   if (B == 0 || S == 0) return 0;
+  // the pinned host word of the fault count (first use allocates: never inside a capture — such a launch reports to the device
+  // counter only, and cpfn_fps_faults() then reads both)
+  unsigned *hf = nullptr;
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+    if (g_fps_have_hf || cs == hipStreamCaptureStatusNone) { fps_host_faults(&hf); g_fps_have_hf = true; }
+    if (!hf) g_fps_launched_without_hf = true;
+  }
+  const int dd = g_fps_dbg_drop;
   // (beside a training step — cpfn_background_geometry() — the instantiations without packed fp32: see fps_update)
   const bool beside = cpfn_background_geometry();
   if (N <= 512) {
-    if (beside) fps_resident_kernel<64, 8, false, false><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
-    else fps_resident_kernel<64, 8><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    if (beside) fps_resident_kernel<64, 8, false, false><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+    else fps_resident_kernel<64, 8><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
   } else if (N <= 2048) {
-    if (beside) fps_resident_kernel<256, 8, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
-    else fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+    if (beside) fps_resident_kernel<256, 8, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+    else fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
   } else if (N <= CPFN_FPS_MAX_RESIDENT) {
     // 8192 points on ONE CU either way (a sample is a VALU-throughput phase over the cloud plus two key reductions):
     // (with ds_bpermute key reductions) 16 waves x 8 points per lane took 670 us for 512 samples, 8 waves x 16 points 572 us,
@@ -574,46 +673,38 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
       //  the dominant kernel 0.72 -> 0.63 of peak, because the longer chain then overlaps the backward pass.)
       //  CPFN_FPS_BESIDE_MODE (debugging): 0 = the form without packed fp32, 2 = packed without the LDS claim.
       static const int mode = getenv("CPFN_FPS_BESIDE_MODE") ? atoi(getenv("CPFN_FPS_BESIDE_MODE")) : 1;
-      static int pad = -2;                       // -2: not asked yet, -1: the claim is not available
-      if (pad == -2) {
-        hipFuncAttributes a;
-        pad = -1;
-        if (hipFuncGetAttributes(&a, (const void *)fps_resident_kernel<256, 32>) == hipSuccess) {
-          const int p = CPFN_LDS_BYTES_PER_CU - (int)a.sharedSizeBytes;
-          if (p >= 0 && hipFuncSetAttribute((const void *)fps_resident_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, p) ==
-                            hipSuccess)
-            pad = p;
-        }
-        (void)hipGetLastError();
-      }
+      const int pad = fps_lds_claim((const void *)fps_resident_kernel<256, 32>);
       if (mode == 2)
-        fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+        fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
       else if (mode == 1 && pad >= 0)
-        fps_resident_kernel<256, 32><<<B, 256, pad, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+        fps_resident_kernel<256, 32><<<B, 256, pad, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
       else
-        fps_resident_kernel<256, 32, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
-    } else
-      fps_resident_kernel<512, 16><<<B, 512, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres);
+        fps_resident_kernel<256, 32, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+    } else {
+      // Stand-alone (evaluation, the parity tests) the packed 8-wave shape — ALSO with its compute unit's LDS claimed whole
+      // (round 5): "nothing else runs" was an assumption about the caller; the claim costs a workgroup that has
+      // its compute unit to itself nothing.
+      const int pad = fps_lds_claim((const void *)fps_resident_kernel<512, 16>);
+      fps_resident_kernel<512, 16><<<B, 512, pad >= 0 ? pad : 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+    }
   } else {
     if (!scratch) return CPFN_EINVAL;
     // several workgroups per cloud while all of them can be resident together and the key layout holds
-    // (index < 2^20, sample tag < 4095); slots = the first B * 2 * G 8-byte words of the scratch row buffer
+    // (index < 2^20); slots = the first B * 2 * G 8-byte words of the scratch row buffer
     // 32 points per lane: as few workgroups per cloud as the registers allow (see fps_shared_kernel: the exchange costs by
     // participant) — 16 for the 131072-point clouds of the evaluation cascade, 64 at 524288 points
     const int ppt = 32;
     const int G = (N + 256 * ppt - 1) / (256 * ppt);
-    const int capacity = fps_shared_capacity<32>();
-    if (G <= 64 && (long long)B * G <= capacity && B <= 65535 && S <= 4094 && N <= (1 << 20) &&
+    // (round 5: each of these workgroups claims its compute unit's whole LDS too — one workgroup per compute unit, nothing that
+    //  uses LDS beside its packed arithmetic; the cascade's shapes need 16-64 of the 256 compute units)
+    const int claim = fps_lds_claim((const void *)fps_shared_kernel<32>);
+    const int capacity = fps_shared_capacity<32>(claim >= 0 ? claim : 0);
+    if (G <= 64 && (long long)B * G <= capacity && B <= 65535 && N <= (1 << 20) &&
         (size_t)B * 2 * G * 8 <= (size_t)B * N * 4 && ((uintptr_t)scratch & 7) == 0) {
       hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * 2 * G * 8, st);
       if (e != hipSuccess) return (int)e;
       unsigned long long *slots = (unsigned long long *)scratch;
-      unsigned *hf = nullptr;
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
-      static bool have_hf = false;
-      if (have_hf || cs == hipStreamCaptureStatusNone) { fps_host_faults(&hf); have_hf = true; }   // (first use allocates: not inside a capture)
-      fps_shared_kernel<32><<<dim3(G, B), 256, 0, st>>>(xyz, N, S, start, flags, idx_out, slots, hf);
+      fps_shared_kernel<32><<<dim3(G, B), 256, claim >= 0 ? claim : 0, st>>>(xyz, N, S, start, flags, idx_out, slots, hf, dd);
     } else {
       fps_streaming_kernel<1024><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out, scratch);
     }

@@ -22,6 +22,7 @@ SIGNATURES = {
     "cpfn_fps_centres": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "cpfn_fps_max_resident": [],
     "cpfn_fps_faults": [],
+    "cpfn_fps_debug_drop": [_i],
     "cpfn_fps_profile": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "cpfn_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "cpfn_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],

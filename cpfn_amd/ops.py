@@ -56,8 +56,9 @@ def ball_query_threshold(radius):
 
 
 def fps_faults():
-    """Clouds whose several-workgroups FPS (N > 8192) gave up on a sibling workgroup since the library was loaded (their
-    remaining samples are index 0).  0 in a healthy process; reading it synchronises the device."""
+    """Sampling faults since the library was loaded (cpfn_fps_faults): clouds whose several-workgroups FPS (N > 8192) gave up on a
+    sibling workgroup (their remaining samples are index 0) + samples whose update was lost on the lane that owns them (the
+    tripwire of csrc/sampling.hip: caught, repeated, counted).  0 in a healthy process; a pinned host word: no synchronisation."""
     n = _l.lib().cpfn_fps_faults()
     if n < 0:
         raise RuntimeError("cpfn_fps_faults failed")
@@ -68,18 +69,22 @@ _fps_faults_seen = 0
 
 
 def check_fps_faults(where):
-    """Raise if the several-workgroups FPS has given up on a sibling since the last check: the samples of such a cloud are
-    index 0 from there on — plausible-looking, degenerate geometry.  Called where the host synchronises anyway (the end of
-    `compute_all_metrics`, `get_point_final`, the epoch loop's periodic loss read)."""
+    """Raise if the sampling kernels have reported a fault since the last check: a several-workgroups FPS that gave up on a sibling
+    (the samples of such a cloud are index 0 from there on — plausible-looking, degenerate geometry), or the tripwire: a sample's
+    own min-distance was not zeroed by its update (a lost update: round 4's packed-fp32 fault; the kernel repeats the pass, but
+    lanes that do not own the sample may have lost theirs unseen).  Called where the host synchronises anyway (the end of
+    `compute_all_metrics`, `get_point_final`, the epoch loop's periodic loss read, the trainer's periodic flag check)."""
     global _fps_faults_seen
     if torch.cuda.is_current_stream_capturing():
         return
     n = fps_faults()
     if n > _fps_faults_seen:
         new, _fps_faults_seen = n - _fps_faults_seen, n
-        raise RuntimeError("cpfn_amd: farthest-point sampling of %d cloud(s) gave up on a sibling workgroup before %s (the "
-                           "workgroups of one cloud were not co-resident); their remaining samples are index 0 — results "
-                           "since the last check are invalid" % (new, where))
+        raise RuntimeError("cpfn_amd: farthest-point sampling reported %d fault(s) before %s: either the workgroups of one large "
+                           "cloud were not co-resident (a sibling never arrived; that cloud's remaining samples are index 0), or a "
+                           "sample's distance update was LOST on the lane that owns it (the tripwire of csrc/sampling.hip: packed "
+                           "fp32 beside a weight-gradient workgroup on some MI355X boxes, DESIGN.md section 4) — results since the "
+                           "last check are suspect" % (new, where))
 
 
 

@@ -830,6 +830,11 @@ class SPFNTrainer:
                                "stream's graph was never launched, or it stalled for longer than CPFN_FLAG_TIMEOUT_S); the "
                                "optimizer has skipped every step since, the losses of the last steps are invalid"
                                % (st["flag_timeout"] / 100e6))
+        if (st["n_main"] & 63) == 0:
+            # the sampling kernels' fault count (a pinned host word: no synchronisation): the several-workgroups time-out and the
+            # tripwire — a sample whose own min-distance was not zeroed, i.e. a lost update beside this very step (VERDICT r4 #1a)
+            from . import ops as _ops
+            _ops.check_fps_faults("training step %d" % self.global_step)
         if single and st["side_pending"]:
             # the side graph of the previous step (reads P_next / the FPS seeds, writes geomB) must be done before
             # this step overwrites its inputs and reads its result

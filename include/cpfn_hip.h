@@ -69,9 +69,17 @@ CPFN_API int cpfn_fps(const float *xyz, int B, int N, int S, const int *start, i
 CPFN_API int cpfn_fps_centres(const float *xyz, int B, int N, int S, const int *start, int flags, int *idx_out,
                               float *centres, void *stream);
 CPFN_API int cpfn_fps_max_resident(void);
-/* Clouds for which the several-workgroups FPS (8192 < N) gave up waiting for a sibling workgroup since the library was
- * loaded; their remaining samples are index 0.  0 in a healthy process.  Synchronises the device; < 0 on error. */
+/* Sampling faults since the library was loaded.  0 in a healthy process; < 0 on error.  Two kinds are counted:
+ * (i) clouds for which the several-workgroups FPS (8192 < N) gave up waiting for a sibling workgroup (their remaining samples
+ * are index 0); (ii) TRIPWIRE, every kernel: a sample whose own min-distance was not zeroed by its update — the arg-max
+ * returned the point just sampled with a positive distance — i.e. a lost update on the lane that owns the sample (round 4's
+ * packed-fp32 fault beside a weight-gradient workgroup).  Such a pass is repeated once (the update is idempotent), so the
+ * indices stay those of modules/geometry_utils.py:88-101; the count says that the hardware / a neighbour misbehaved.
+ * Reads a pinned host word (no synchronisation); the device counter too once a launch had to go without that word. */
 CPFN_API int cpfn_fps_faults(void);
+/* Test hook for the tripwire: in every sampling launch issued from now on the wave that owns sample `sample` (0-based) skips its
+ * distance update once (-1: off).  Returns the previous setting. */
+CPFN_API int cpfn_fps_debug_drop(int sample);
 /* Diagnostic twin of cpfn_fps for N <= 8192 (one workgroup per cloud; variant 0: 256 threads x 8 points per lane, N <= 2048;
  * 1: 512 x 16; 2: 256 x 32): same indices, plus prof[B][6] = shader-clock cycles, summed over the S samples, that wave 0
  * spent in {sample broadcast read, distance update + lane maximum, wave maximum, index ballots, LDS slot + barrier,

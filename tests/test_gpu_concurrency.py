@@ -341,3 +341,81 @@ def test_replayed_training_runs_sample_the_same_points():
         for s_, (a, b) in enumerate(zip(ref, got)):
             diff = [j for j, (x, y) in enumerate(zip(a, b)) if not torch.equal(x, y)]
             assert not diff, "run %d, step %d: tensors %s (0 = loss, 1.. = the geometry set the step read) differ from the first run's" % (r, s_, diff)
+
+
+# ---- round 5: the tripwire (csrc/sampling.hip) ----------------------------------------------------------------------------------
+def _consume_faults(ops):
+    """Faults raised on purpose must not trip a later test's check_fps_faults."""
+    ops._fps_faults_seen = ops.fps_faults()
+
+
+@pytest.mark.parametrize("B,N,S,beside", [(4, 2048, 512, False), (4, 2048, 512, True), (3, 500, 128, False), (3, 500, 128, True),
+                                          (2, 8192, 512, False), (2, 8192, 512, True), (1, 131072, 512, False), (2, 40000, 64, False)])
+def test_tripwire_counts_and_repairs_a_dropped_update(B, N, S, beside):
+    """VERDICT r4 #1a: the own-min-distance invariant lives in the PRODUCT kernels.  A sample's own min-distance is 0 after its update,
+    so an arg-max that returns the point just sampled with a positive distance is a lost update on the owning lane.  The test hook
+    cpfn_fps_debug_drop(s) makes the wave that owns sample s skip its update once — what round 4's fault does to a row of lanes —
+    in every instantiation (packed / one point per instruction, one and several workgroups per cloud): the kernel must (i) count
+    exactly one fault per cloud in cpfn_fps_faults(), visible without a device synchronisation, (ii) repeat the pass, so that the
+    indices are STILL those of the oracle (modules/geometry_utils.py:88-101), and (iii) count nothing when nothing is dropped."""
+    import contextlib
+    from cpfn_amd import lib as _l, ops
+    from oracle import geometry as og
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + B)
+    xyz = (torch.rand(B, N, 3, generator=g) * 2 - 1)
+    start = torch.randint(0, N, (B,), generator=g).to(torch.int32)
+    want = og.farthest_point_sample(xyz.numpy(), S, start.numpy()).astype(np.int32)
+    xd, sd = xyz.to(dev), start.to(dev)
+    h = _l.lib()
+    ctx = ops.background_geometry if beside else contextlib.nullcontext
+    torch.cuda.synchronize()
+    n0 = ops.fps_faults()
+    with ctx():
+        quiet = ops.fps(xd, S, sd)
+    torch.cuda.synchronize()
+    assert np.array_equal(quiet.cpu().numpy(), want)
+    assert ops.fps_faults() == n0, "a healthy launch reported a fault"
+    try:
+        for drop in (0, 7, S - 2):
+            h.cpfn_fps_debug_drop(drop)
+            with ctx():
+                got = ops.fps(xd, S, sd)
+            torch.cuda.synchronize()
+            n1 = ops.fps_faults()
+            assert n1 == n0 + B, "sample %d dropped once per cloud: %d faults counted, %d expected" % (drop, n1 - n0, B)
+            assert np.array_equal(got.cpu().numpy(), want), "the repeated pass did not repair the dropped update (sample %d)" % drop
+            n0 = n1
+        with pytest.raises(RuntimeError, match="fault"):
+            ops.check_fps_faults("the tripwire test")
+    finally:
+        h.cpfn_fps_debug_drop(-1)
+        _consume_faults(ops)
+
+
+def test_tripwire_beside_the_weight_gradient_kernel():
+    """VERDICT r4 #1 "Done": the packed 8192-point shape WITHOUT its guard (CPFN_FPS_BESIDE_MODE=2: no LDS claim) beside mlp_wgrad —
+    on a box that has round 4's fault the indices differ from the quiet run's AND the tripwire has counted (it sees the events whose
+    lost row holds the sample's owner); in the guarded mode (the product's default) nothing differs and nothing is counted.  Round 5
+    found boxes of the pool that do NOT have the fault (profiles/r05_pk_repro.txt): there both modes are clean and the first
+    assertion has nothing to hold.  The launcher reads the mode once per process: two child processes (tools/dbg/pk_repro.py)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode, case in (("2", "beside2"), ("1", "beside1")):
+        env = dict(os.environ, CPFN_FPS_BESIDE_MODE=mode)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "pk_repro.py"), "5", case], capture_output=True,
+                           text=True, cwd=root, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        m = re.search(r"(\d+) sampling launches beside mlp_wgrad,\s+(\d+) with different indices; sampling faults word (\d+)", r.stdout)
+        assert m, r.stdout[-2000:]
+        res[mode] = tuple(int(v) for v in m.groups())
+        print("CPFN_FPS_BESIDE_MODE=%s: %d launches, %d with different indices, %d faults counted" % ((mode,) + res[mode]))
+    assert res["1"][0] > 100 and res["1"][1] == 0 and res["1"][2] == 0, "the guarded mode must be clean: %s" % (res["1"],)
+    if res["2"][1] > 0:
+        assert res["2"][2] >= 1, "indices differed in %d launches and the tripwire counted nothing" % res["2"][1]
+    else:
+        print("this box does not reproduce round 4's fault: unguarded packed fp32 beside mlp_wgrad is clean here")

@@ -200,10 +200,15 @@ def test_graphed_evaluation_forward_matches_eager():
             m.auto_graph = True
             # ... the module itself replays a graph for an evaluation forward under no_grad (what the reference's unedited
             # evaluation scripts call, evaluation_globalSPFN.py:85): same bits, outputs that do not alias the graph's buffers
-            for rep in range(2):
+            # — from the SECOND sighting of a shape on (the first runs eager launches: a shape that never returns must not cost
+            # a warm-up + capture + replay)
+            for rep in range(3):
                 torch.manual_seed(5)
                 auto = m(P)
-                assert "_auto_graph" in m.__dict__ and len(m.__dict__["_auto_graph"]._graphs) == 1
+                if rep == 0:
+                    assert "_auto_graph" not in m.__dict__
+                else:
+                    assert len(m.__dict__["_auto_graph"]._graphs) == 1
                 for a, b in zip(auto, want):
                     assert torch.equal(a, b)
                 assert torch.equal(m.aux_sa1["fps_idx"], fps_eager)

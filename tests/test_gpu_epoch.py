@@ -273,6 +273,16 @@ def test_heat_cross_entropy_matches_torch_and_its_hint_is_bit_identical(monkeypa
         ref.backward()
         assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
         assert float((Y.grad - Yt.grad).abs().max()) < 1e-6 * float(Yt.grad.abs().max()) + 1e-12
+    # labels outside {0, 1} (F.cross_entropy raises / ignores them): the fused pass poisons loss and gradient instead of
+    # counting the row as class 1
+    for bad in (2, -100):
+        Y = (torch.randn(1, 1000, 2, generator=g) * 3).to(dev).requires_grad_(True)
+        lab = torch.randint(0, 2, (1, 1000), generator=g).to(dev)
+        lab[0, 123] = bad
+        with fl.unit_loss_gradient():
+            loss = fl.HeatCrossEntropy.apply(Y, lab, None)
+        loss.backward()
+        assert torch.isnan(loss) and torch.isnan(Y.grad[0, 123]).all() and torch.isfinite(Y.grad[0, :123]).all()
     c = synthetic.primitive_cloud(B, N, n_prims=6, seed=9)
     batch = {"P": c["P"].to(dev), "labels": (c["I_gt"] % 2).long().to(dev)}
     starts = (torch.arange(B), torch.arange(B) + 3)

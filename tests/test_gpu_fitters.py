@@ -127,7 +127,7 @@ def test_guarded_matrix_solve_ls_on_the_selftest_sphere_problem(golden):
     self-test recipe it returns the fixture's sphere centres (the reference's output) and the oracle's, per instance; its guards
     (condition-number cap, ridge) answer a rank-deficient problem with 0 like the oracle; gradients flow to A, b and W."""
     from cpfn_amd.SPFN import geometry_utils
-    g = golden("fitters_selftest")
+    g = golden("fitters_selftest.npz")
     P, W = torch.from_numpy(g["P"]), torch.from_numpy(g["W"])
     B, N, K = W.shape
     Wk = W.transpose(1, 2).reshape(B * K, N)                                       # [BK,N]   (sphere_fitter.py:12-13)

@@ -86,7 +86,7 @@ def test_all_metrics_match_oracle_at_8192():
     _check(out, {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in ref.items() if k != "params"}, 256, N)
 
 
-@pytest.mark.parametrize("K,n_prims", [(49, 40), (70, 33)])
+@pytest.mark.parametrize("K,n_prims", [(49, 40), (70, 33), (100, 60), (128, 90)])      # 100, 128: > 64 KB of LDS
 def test_all_metrics_more_than_32_instances_vs_oracle(K, n_prims):
     """Evaluation on a MERGED label set (evaluation_localSPFN.py:129-131 hands compute_all_metrics a W_fusion with
     >= 28 columns and no upper bound; 21 local + 28 global = 49): more instance columns AND more GT labels than the
@@ -121,6 +121,13 @@ def test_all_metrics_more_than_32_instances_vs_oracle(K, n_prims):
     np.testing.assert_allclose(S[:, :K].numpy(), (oh.transpose(1, 2) @ W).numpy(), rtol=2e-5, atol=1e-4)
     np.testing.assert_allclose(S[:, K].numpy(), W.sum(1).numpy(), rtol=2e-5, atol=1e-4)
     assert np.array_equal(S[:, K + 1].numpy(), oh.sum(1).numpy())
+    # the point pass sums in a fixed order (no float atomics since round 5): a second call gives the same bits
+    out2 = mi.compute_all_metrics(d(batch["P"]), d(X), d(batch["X_gt"]), d(W), d(batch["I_gt"]), d(T), d(batch["T_gt"]),
+                                  d(batch["points_per_instance"]), {k: d(v) for k, v in gt.items()},
+                                  list_epsilon=[0.01, 0.03], classes=CLASSES)
+    for a, b in zip(out[:6], out2[:6]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[10], out2[10]) and torch.equal(out[8], out2[8])
 
 
 def test_p_coverage_kernel_vs_expanded_formula():
