@@ -25,9 +25,12 @@
 //
 // TRIPWIRE (round 5, every instantiation): a sample's own min-distance is 0 after its update, so the next arg-max can only
 // return the SAME point again when every candidate is exhausted (maximum 0).  A repeated point with a positive maximum means the
-// update was lost on the lane that owns the sample — the signature of round 4's packed-fp32 fault — and costs one scalar compare
-// per sample to see: the pass is repeated once (the update is idempotent: min with the same distances; the output stays right) and
-// the workgroup bumps the fault count that cpfn_fps_faults() / ops.check_fps_faults() read (device counter + pinned host word).
+// update was lost on the lane that owns the sample — the signature of round 4's packed-fp32 fault — and costs one compare per
+// sample to see, OFF the sample loop's dependency chain: the workgroup bumps the fault count that cpfn_fps_faults() /
+// ops.check_fps_faults() read (device counter + pinned host word).  Detection only: a first version also repeated the pass (the
+// update is idempotent) — the loop control then hung on two VALU -> SGPR round trips per sample, +4..8 % on every shape and +19 %
+// on the one-wave kernel (same-box A/B against the round-4 tree), for a repair that cannot reach the lanes that do not own the
+// sample anyway.
 //
 // Beside a training step (cpfn_set_background_geometry) the instantiations differ: no packed fp32 at 64 / 256 lanes x 8 points, and
 // the 8192-point shape claims its compute unit's whole LDS — a co-resident weight-gradient workgroup makes packed fp32 lose a
@@ -236,7 +239,7 @@ __device__ __forceinline__ unsigned long long fps_stamp() {
   return t;
 }
 
-template <int NT, int PPT, bool PROFILE = false, bool PK = true>
+template <int NT, int PPT, bool PROFILE = false, bool PK = true, bool DBG = false>
 __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restrict__ xyz, int N, int S,
                                                           const int *__restrict__ start, int flags,
                                                           int *__restrict__ idx_out,
@@ -278,9 +281,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
   unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
   unsigned far = start ? (unsigned)start[b] : 0u;
   float fx = s_x[far], fy = s_y[far], fz = s_z[far];
-  bool retried = false;
-  // `it` counts passes (slot parity), `i` samples: a pass whose arg-max returns the point it has just sampled is repeated (tripwire)
-  for (int i = 0, it = 0; i < S; ++it) {
+  for (int i = 0; i < S; ++i) {
     if (PROFILE) t0 = fps_stamp();
     if (t == 0) out[i] = (int)far;
     if (NW == 1 && i > 0) { fx = s_x[far]; fy = s_y[far]; fz = s_z[far]; }
@@ -289,16 +290,13 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       c[0] = fx; c[1] = fy; c[2] = fz;
     }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[0] += t1 - t0; t0 = t1; }      // (one wave: broadcast read of the sample)
-    float lm;
-    if (dbg_drop >= 0 && i == dbg_drop && !retried && (unsigned)wave == (far % NT) / CPFN_WAVE) {
-      // (test hook, cpfn_fps_debug_drop: the wave that owns sample `dbg_drop` skips its update once — what the hardware fault does
-      //  to a row of lanes — so that the tripwire and its repair can be tested on a box that does not have the fault)
-      lm = -1.0f;
-#pragma unroll
-      for (int j = 0; j < PPT / 2; ++j) lm = v_max3(lm, md[j].x, md[j].y);
-    } else {
-      lm = fps_update<PPT, PK>(px, py, pz, md, fx, fy, fz);
-    }
+    // (test hook, cpfn_fps_debug_drop — the DBG instantiations only, the product kernels carry none of it: the wave that owns
+    //  sample `dbg_drop` loses its update once — what the hardware fault does to a row of lanes — so that the tripwire and its
+    //  repair can be tested on a box that does not have the fault.  The wave measures its distances to a point at infinity
+    //  instead: every min(md, inf) leaves md alone.)
+    const bool drop = DBG && i == dbg_drop && (unsigned)wave == (far % NT) / CPFN_WAVE;
+    const float ux = drop ? __builtin_inff() : fx;
+    const float lm = fps_update<PPT, PK>(px, py, pz, md, ux, fy, fz);
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[1] += t1 - t0; t0 = t1; }      // distance update + lane maximum
     const float wmax = wave_max_f32(lm);
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[2] += t1 - t0; t0 = t1; }      // wave maximum (DPP)
@@ -308,10 +306,10 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[3] += t1 - t0; t0 = t1; }      // index of the maximum (ballots)
     const unsigned sampled = far;
     if (NW > 1) {
-      if (lane == 0) s_key[it & 1][wave] = key;
+      if (lane == 0) s_key[i & 1][wave] = key;
       __syncthreads();
       if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[4] += t1 - t0; t0 = t1; }    // LDS slot + workgroup barrier
-      key = s_key[it & 1][lane & (NW - 1)];
+      key = s_key[i & 1][lane & (NW - 1)];
       // Lane w (< NW) holds wave w's candidate: its coordinates are requested from the LDS mirror NOW, while the maximum over
       // the waves is still being formed, and the winner's are picked with three readlanes — the sample's coordinates used
       // to be read after the maximum was known: one more LDS round trip (~250 cycles of a 2200-cycle sample) on the chain.
@@ -339,12 +337,13 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
     }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[5] += t1 - t0; t0 = t1; }      // slot read + maximum over the waves
     // TRIPWIRE: the point just sampled comes back with a positive distance -> its own min-distance was not zeroed (a lost update).
-    // Workgroup-uniform (every wave holds the same key), so every wave repeats the pass together: same f, same i, next parity.
-    const bool lost = !PROFILE && far == sampled && (unsigned)(key >> 32) != 0u;
-    if (lost && t == 0) fps_report_fault(host_faults);
-    if (lost && !retried) { retried = true; continue; }
-    retried = false;
-    ++i;
+    // Every lane holds the same key; nothing of the loop depends on the outcome (an exec-masked report, normally skipped).
+    // (`far` and `sampled` sit in scalar registers in the several-waves shapes: the common path is one scalar compare and an
+    //  untaken branch; the key is only looked at behind it)
+    if (!PROFILE && __builtin_expect(far == sampled, 0)) {
+      asm volatile("; tripwire: rare path" ::: "memory");      // (keeps the two conditions apart: merged, every sample pays a vector compare + exec mask)
+      if (t == 0 && (unsigned)(key >> 32) != 0u) fps_report_fault(host_faults);
+    }
   }
   if (PROFILE && t == 0 && prof) {
 #pragma unroll
@@ -435,7 +434,7 @@ __global__ __launch_bounds__(NT) void fps_streaming_kernel(const float *__restri
 // same few cache lines slows every workgroup's round trip by more than the L2-hit load of the coordinates cost; and with
 // the workgroups of a cloud placed on ONE XCD (linear block ids congruent modulo 8) 2.99 ms at 64 workgroups (two per CU on
 // 32 CUs: the per-sample pass doubles), 1.25 ms at 32.  Both removed.
-template <int PPT>
+template <int PPT, bool DBG = false>
 __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict__ xyz, int N, int S,
                                                          const int *__restrict__ start, int flags,
                                                          int *__restrict__ idx_out, unsigned long long *__restrict__ slots,
@@ -462,20 +461,12 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
     px[j / 2][j & 1] = x; py[j / 2][j & 1] = y; pz[j / 2][j & 1] = z; md[j / 2][j & 1] = m;
   }
   unsigned far = start ? (unsigned)start[b] : 0u;
-  bool retried = false;
-  // `it` counts passes (slot parity and tag), `i` samples: see the tripwire at the end of the loop
-  for (int i = 0, it = 0; i < S; ++it) {
+  for (int i = 0; i < S; ++i) {
     if (wg == 0 && t == 0) out[i] = (int)far;
     const float fx = p[3 * far], fy = p[3 * far + 1], fz = p[3 * far + 2];
-    float lm;
-    if (dbg_drop >= 0 && i == dbg_drop && !retried && (int)far >= base && (int)far < base + NT * PPT &&
-        (unsigned)wave == ((far - (unsigned)base) % NT) / CPFN_WAVE) {          // (test hook: see fps_resident_kernel)
-      lm = -1.0f;
-#pragma unroll
-      for (int j = 0; j < PPT / 2; ++j) lm = v_max3(lm, md[j].x, md[j].y);
-    } else {
-      lm = fps_update<PPT>(px, py, pz, md, fx, fy, fz);
-    }
+    const bool drop = DBG && i == dbg_drop && (int)far >= base && (int)far < base + NT * PPT &&
+                      (unsigned)wave == ((far - (unsigned)base) % NT) / CPFN_WAVE;          // (test hook: see fps_resident_kernel)
+    const float lm = fps_update<PPT>(px, py, pz, md, drop ? __builtin_inff() : fx, fy, fz);
     const float wmax = wave_max_f32(lm);
     // key without the tag: candidates compare by (distance, lowest index); "no candidate" = 0
     unsigned long long key = 0ull;
@@ -483,21 +474,21 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
       const unsigned besti = fps_first_index<PPT, NT>(md, wmax, (unsigned)(base + t - lane), lane);
       key = ((unsigned long long)__float_as_uint(wmax) << 32) | ((unsigned long long)(0xFFFFFu - besti) << 12);
     }
-    if (lane == 0) s_key[it & 1][wave] = key;
+    if (lane == 0) s_key[i & 1][wave] = key;
     __syncthreads();
-    const unsigned tag = (unsigned)(it + 1) & 0xFFFu;
+    const unsigned tag = (unsigned)(i + 1) & 0xFFFu;
     if (t == 0) {
-      unsigned long long k4 = s_key[it & 1][0];
+      unsigned long long k4 = s_key[i & 1][0];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) k4 = s_key[it & 1][w] > k4 ? s_key[it & 1][w] : k4;
-      __hip_atomic_store(&sl[(it & 1) * G + wg], k4 | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 1; w < NW; ++w) k4 = s_key[i & 1][w] > k4 ? s_key[i & 1][w] : k4;
+      __hip_atomic_store(&sl[(i & 1) * G + wg], k4 | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wave == 0) {       // G <= 64 lanes poll one slot each until it carries this pass's tag
+    if (wave == 0) {       // G <= 64 lanes poll one slot each until it carries this sample's tag
       unsigned long long k = 0ull;
       if (lane < G) {
         unsigned spins = 0;
         do {
-          k = __hip_atomic_load(&sl[(it & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          k = __hip_atomic_load(&sl[(i & 1) * G + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (++spins > (1u << 24)) { k = ~0ull; break; }          // ~1 s: a sibling workgroup never arrived
         } while ((unsigned)(k & 0xFFFull) != tag);
       }
@@ -519,15 +510,12 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
       }
       break;
     }
-    // TRIPWIRE (see fps_resident_kernel): every workgroup of the cloud reads the same (nf, nd) and repeats the pass together.  (The
-    // 12-bit tag of a pass only has to differ from what its slot held two passes earlier — it does, modulo 4096 — and from the
-    // memset's zero in the first two passes: repeated passes cannot confuse the exchange.)
-    const bool lost = nf == far && nd != 0u;
-    if (lost && wg == 0 && t == 0) fps_report_fault(host_faults);
+    // TRIPWIRE (see fps_resident_kernel): the point just sampled comes back with a positive distance
+    if (__builtin_expect(nf == far, 0)) {
+      asm volatile("; tripwire: rare path" ::: "memory");
+      if (wg == 0 && t == 0 && nd != 0u) fps_report_fault(host_faults);
+    }
     far = nf;
-    if (lost && !retried) { retried = true; continue; }
-    retried = false;
-    ++i;
   }
 }
 
@@ -542,7 +530,7 @@ static int fps_shared_capacity(int dyn_lds) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
   if (cached[dev] == 0) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_shared_kernel<PPT>, 256, dyn_lds) == hipSuccess &&
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_shared_kernel<PPT, false>, 256, dyn_lds) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0 && cus > 0)
       cached[dev] = per_cu * cus;
     else
@@ -651,12 +639,18 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
   const int dd = g_fps_dbg_drop;
   // (beside a training step — cpfn_background_geometry() — the instantiations without packed fp32: see fps_update)
   const bool beside = cpfn_background_geometry();
+  // one launch of fps_resident_kernel<NT, PPT, false, PK, DBG> (the DBG twins only while the test hook is armed)
+#define CPFN_FPS_RESIDENT(NT_, PPT_, PK_, LDS_)                                                                                          \
+  do {                                                                                                                                 \
+    if (dd >= 0) fps_resident_kernel<NT_, PPT_, false, PK_, true><<<B, NT_, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd); \
+    else fps_resident_kernel<NT_, PPT_, false, PK_, false><<<B, NT_, LDS_, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, -1); \
+  } while (0)
   if (N <= 512) {
-    if (beside) fps_resident_kernel<64, 8, false, false><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
-    else fps_resident_kernel<64, 8><<<B, 64, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+    if (beside) CPFN_FPS_RESIDENT(64, 8, false, 0);
+    else CPFN_FPS_RESIDENT(64, 8, true, 0);
   } else if (N <= 2048) {
-    if (beside) fps_resident_kernel<256, 8, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
-    else fps_resident_kernel<256, 8><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+    if (beside) CPFN_FPS_RESIDENT(256, 8, false, 0);
+    else CPFN_FPS_RESIDENT(256, 8, true, 0);
   } else if (N <= CPFN_FPS_MAX_RESIDENT) {
     // 8192 points on ONE CU either way (a sample is a VALU-throughput phase over the cloud plus two key reductions):
     // (with ds_bpermute key reductions) 16 waves x 8 points per lane took 670 us for 512 samples, 8 waves x 16 points 572 us,
@@ -673,19 +667,16 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
       //  the dominant kernel 0.72 -> 0.63 of peak, because the longer chain then overlaps the backward pass.)
       //  CPFN_FPS_BESIDE_MODE (debugging): 0 = the form without packed fp32, 2 = packed without the LDS claim.
       static const int mode = getenv("CPFN_FPS_BESIDE_MODE") ? atoi(getenv("CPFN_FPS_BESIDE_MODE")) : 1;
-      const int pad = fps_lds_claim((const void *)fps_resident_kernel<256, 32>);
-      if (mode == 2)
-        fps_resident_kernel<256, 32><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
-      else if (mode == 1 && pad >= 0)
-        fps_resident_kernel<256, 32><<<B, 256, pad, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
-      else
-        fps_resident_kernel<256, 32, false, false><<<B, 256, 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+      const int pad = fps_lds_claim((const void *)fps_resident_kernel<256, 32, false, true, false>);
+      if (mode == 2) CPFN_FPS_RESIDENT(256, 32, true, 0);
+      else if (mode == 1 && pad >= 0) CPFN_FPS_RESIDENT(256, 32, true, pad);
+      else CPFN_FPS_RESIDENT(256, 32, false, 0);
     } else {
       // Stand-alone (evaluation, the parity tests) the packed 8-wave shape — ALSO with its compute unit's LDS claimed whole
       // (round 5): "nothing else runs" was an assumption about the caller; the claim costs a workgroup that has
       // its compute unit to itself nothing.
-      const int pad = fps_lds_claim((const void *)fps_resident_kernel<512, 16>);
-      fps_resident_kernel<512, 16><<<B, 512, pad >= 0 ? pad : 0, st>>>(xyz, N, S, start, flags, idx_out, nullptr, centres, hf, dd);
+      const int pad = fps_lds_claim((const void *)fps_resident_kernel<512, 16, false, true, false>);
+      CPFN_FPS_RESIDENT(512, 16, true, pad >= 0 ? pad : 0);
     }
   } else {
     if (!scratch) return CPFN_EINVAL;
@@ -697,18 +688,20 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
     const int G = (N + 256 * ppt - 1) / (256 * ppt);
     // (round 5: each of these workgroups claims its compute unit's whole LDS too — one workgroup per compute unit, nothing that
     //  uses LDS beside its packed arithmetic; the cascade's shapes need 16-64 of the 256 compute units)
-    const int claim = fps_lds_claim((const void *)fps_shared_kernel<32>);
+    const int claim = fps_lds_claim((const void *)fps_shared_kernel<32, false>);
     const int capacity = fps_shared_capacity<32>(claim >= 0 ? claim : 0);
     if (G <= 64 && (long long)B * G <= capacity && B <= 65535 && N <= (1 << 20) &&
         (size_t)B * 2 * G * 8 <= (size_t)B * N * 4 && ((uintptr_t)scratch & 7) == 0) {
       hipError_t e = hipMemsetAsync(scratch, 0, (size_t)B * 2 * G * 8, st);
       if (e != hipSuccess) return (int)e;
       unsigned long long *slots = (unsigned long long *)scratch;
-      fps_shared_kernel<32><<<dim3(G, B), 256, claim >= 0 ? claim : 0, st>>>(xyz, N, S, start, flags, idx_out, slots, hf, dd);
+      if (dd >= 0) fps_shared_kernel<32, true><<<dim3(G, B), 256, 0, st>>>(xyz, N, S, start, flags, idx_out, slots, hf, dd);
+      else fps_shared_kernel<32, false><<<dim3(G, B), 256, claim >= 0 ? claim : 0, st>>>(xyz, N, S, start, flags, idx_out, slots, hf, -1);
     } else {
       fps_streaming_kernel<1024><<<B, 1024, 0, st>>>(xyz, N, S, start, flags, idx_out, scratch);
     }
   }
+#undef CPFN_FPS_RESIDENT
   return cpfn_launch_status();
 }
 

@@ -58,7 +58,7 @@ def ball_query_threshold(radius):
 def fps_faults():
     """Sampling faults since the library was loaded (cpfn_fps_faults): clouds whose several-workgroups FPS (N > 8192) gave up on a
     sibling workgroup (their remaining samples are index 0) + samples whose update was lost on the lane that owns them (the
-    tripwire of csrc/sampling.hip: caught, repeated, counted).  0 in a healthy process; a pinned host word: no synchronisation."""
+    tripwire of csrc/sampling.hip: caught and counted; that launch's indices are wrong).  0 in a healthy process; a pinned host word: no synchronisation."""
     n = _l.lib().cpfn_fps_faults()
     if n < 0:
         raise RuntimeError("cpfn_fps_faults failed")
@@ -71,8 +71,8 @@ _fps_faults_seen = 0
 def check_fps_faults(where):
     """Raise if the sampling kernels have reported a fault since the last check: a several-workgroups FPS that gave up on a sibling
     (the samples of such a cloud are index 0 from there on — plausible-looking, degenerate geometry), or the tripwire: a sample's
-    own min-distance was not zeroed by its update (a lost update: round 4's packed-fp32 fault; the kernel repeats the pass, but
-    lanes that do not own the sample may have lost theirs unseen).  Called where the host synchronises anyway (the end of
+    own min-distance was not zeroed by its update (a lost update: round 4's packed-fp32 fault; that launch's indices are wrong,
+    and lanes that do not own a sample may have lost theirs unseen).  Called where the host synchronises anyway (the end of
     `compute_all_metrics`, `get_point_final`, the epoch loop's periodic loss read, the trainer's periodic flag check)."""
     global _fps_faults_seen
     if torch.cuda.is_current_stream_capturing():

@@ -73,8 +73,8 @@ CPFN_API int cpfn_fps_max_resident(void);
  * (i) clouds for which the several-workgroups FPS (8192 < N) gave up waiting for a sibling workgroup (their remaining samples
  * are index 0); (ii) TRIPWIRE, every kernel: a sample whose own min-distance was not zeroed by its update — the arg-max
  * returned the point just sampled with a positive distance — i.e. a lost update on the lane that owns the sample (round 4's
- * packed-fp32 fault beside a weight-gradient workgroup).  Such a pass is repeated once (the update is idempotent), so the
- * indices stay those of modules/geometry_utils.py:88-101; the count says that the hardware / a neighbour misbehaved.
+ * packed-fp32 fault beside a weight-gradient workgroup).  Detection only: the indices of such a launch are NOT those of
+ * modules/geometry_utils.py:88-101 any more (the point repeats); the count says that the hardware / a neighbour misbehaved.
  * Reads a pinned host word (no synchronisation); the device counter too once a launch had to go without that word. */
 CPFN_API int cpfn_fps_faults(void);
 /* Test hook for the tripwire: in every sampling launch issued from now on the wave that owns sample `sample` (0-based) skips its

@@ -351,13 +351,14 @@ def _consume_faults(ops):
 
 @pytest.mark.parametrize("B,N,S,beside", [(4, 2048, 512, False), (4, 2048, 512, True), (3, 500, 128, False), (3, 500, 128, True),
                                           (2, 8192, 512, False), (2, 8192, 512, True), (1, 131072, 512, False), (2, 40000, 64, False)])
-def test_tripwire_counts_and_repairs_a_dropped_update(B, N, S, beside):
+def test_tripwire_counts_a_dropped_update(B, N, S, beside):
     """VERDICT r4 #1a: the own-min-distance invariant lives in the PRODUCT kernels.  A sample's own min-distance is 0 after its update,
     so an arg-max that returns the point just sampled with a positive distance is a lost update on the owning lane.  The test hook
     cpfn_fps_debug_drop(s) makes the wave that owns sample s skip its update once — what round 4's fault does to a row of lanes —
-    in every instantiation (packed / one point per instruction, one and several workgroups per cloud): the kernel must (i) count
-    exactly one fault per cloud in cpfn_fps_faults(), visible without a device synchronisation, (ii) repeat the pass, so that the
-    indices are STILL those of the oracle (modules/geometry_utils.py:88-101), and (iii) count nothing when nothing is dropped."""
+    in (debugging twins of) every instantiation (packed / one point per instruction, one and several workgroups per cloud): the
+    kernel must (i) count exactly one fault per cloud in cpfn_fps_faults(), visible without a device synchronisation of the caller's,
+    (ii) show the fault's signature — the dropped sample repeats, everything before it is the oracle's — and (iii) count nothing
+    when nothing is dropped (the product kernels: indices = modules/geometry_utils.py:88-101)."""
     import contextlib
     from cpfn_amd import lib as _l, ops
     from oracle import geometry as og
@@ -377,17 +378,25 @@ def test_tripwire_counts_and_repairs_a_dropped_update(B, N, S, beside):
     assert np.array_equal(quiet.cpu().numpy(), want)
     assert ops.fps_faults() == n0, "a healthy launch reported a fault"
     try:
-        for drop in (0, 7, S - 2):
+        # (not sample 0: every min-distance is still 1e10 then, the arg-max ties inside the wave and picks its lowest index —
+        #  a wrong pick that is not a repeat: the tripwire sees the lost update of the sample's OWNER, which needs a history)
+        for drop in (3, 7, S - 2):
             h.cpfn_fps_debug_drop(drop)
             with ctx():
-                got = ops.fps(xd, S, sd)
+                got = ops.fps(xd, S, sd).cpu().numpy()
             torch.cuda.synchronize()
             n1 = ops.fps_faults()
             assert n1 == n0 + B, "sample %d dropped once per cloud: %d faults counted, %d expected" % (drop, n1 - n0, B)
-            assert np.array_equal(got.cpu().numpy(), want), "the repeated pass did not repair the dropped update (sample %d)" % drop
+            assert np.array_equal(got[:, :drop + 1], want[:, :drop + 1]) and np.array_equal(got[:, drop + 1], got[:, drop]), \
+                "the dropped sample %d did not repeat" % drop
             n0 = n1
         with pytest.raises(RuntimeError, match="fault"):
             ops.check_fps_faults("the tripwire test")
+        h.cpfn_fps_debug_drop(-1)
+        with ctx():
+            again = ops.fps(xd, S, sd)
+        torch.cuda.synchronize()
+        assert np.array_equal(again.cpu().numpy(), want) and ops.fps_faults() == n0
     finally:
         h.cpfn_fps_debug_drop(-1)
         _consume_faults(ops)

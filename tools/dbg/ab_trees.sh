@@ -3,5 +3,5 @@
 other=$1; seq=${2:-"a b b a a b"}
 for v in $seq; do
   if [ $v = a ]; then d=$other; else d=.; fi
-  (cd $d && python3 bench.py --steps ${STEPS:-500} --warmup 20 --no-cpu-baseline --no-routes --no-traffic 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$v', '$d', round(d['ms_per_step'],4), round(d['value'],1))")
+  (cd $d && python3 bench.py --steps ${STEPS:-500} --warmup 20 --no-cpu-baseline --no-routes --no-traffic $(grep -q no-rocprof bench.py && echo --no-rocprof) 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$v', '$d', round(d['ms_per_step'],4), round(d['value'],1))")
 done

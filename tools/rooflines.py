@@ -20,6 +20,7 @@ ENTRY = {
     "mlp_wgrad_kernel": "cpfn_mlp_wgrad", "mlp_bwd_fused_kernel": "cpfn_mlp_bwd_fused", "mlp_bwd_small_kernel": "cpfn_mlp_bwd_small",
     "multi_split_reduce_kernel": "cpfn_multi_split_reduce",
     "bn_finalize_kernel": "cpfn_bn_finalize", "bn_bwd_finalize_kernel": "cpfn_bn_bwd_finalize",
+    "bn_bwd_finalize_ride_kernel": "cpfn_bn_bwd_finalize_ride",
     "bn_relu_apply_kernel": "cpfn_bn_relu_apply", "bn_relu_maxpool_kernel": "cpfn_bn_relu_maxpool",
     "bn_relu_bwd_kernel": "cpfn_bn_relu_bwd", "bn_bwd_apply_kernel": "cpfn_bn_bwd_apply",
     "bn_pool_bwd_apply_kernel": "cpfn_bn_pool_bwd_apply", "smallk_fwd_kernel": "cpfn_smallk_fwd", "smallk_fwd_cast_kernel": "cpfn_smallk_fwd",
