@@ -303,7 +303,10 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       const long long p = pbase + r;
       const uint4 v = *(const uint4 *)&s_o[r * LDK + acol];
       if (p < p1) {
-        *(uint4 *)(Gout + p * ldo + acol) = v;
+        {   // (`nt` store: see stream_tile in mlp_fwd.hip)
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4nt;
+          __builtin_nontemporal_store((u32x4nt){v.x, v.y, v.z, v.w}, (u32x4nt *)(Gout + p * ldo + acol));
+        }
         if (BST) {
           const uint4 ybv = yb[i];
           const unsigned g4[4] = {v.x, v.y, v.z, v.w}, y4[4] = {ybv.x, ybv.y, ybv.z, ybv.w};

@@ -169,7 +169,9 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
     const int r = e / CPR, c = e - r * CPR;
     const int p = row0 + wave * 32 + r;
     const uint4 vv = *(const uint4 *)&s_o[r * G_LDO + c * 8];
-    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){vv.x, vv.y, vv.z, vv.w}, sb.y, sb.yoff + y_tile_off + i * sb.y_step, 0, 0);
+    // (aux = 2: `nt` — the tile is not read again by this kernel; fewer dirty lines for the kernel boundary to write back:
+    //  -4 us per step with the one-pass backward kernel's stores, same-box A/B .tnt, NOTEBOOK round 5)
+    __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){vv.x, vv.y, vv.z, vv.w}, sb.y, sb.yoff + y_tile_off + i * sb.y_step, 0, 2);
     if (p < P) {      // (the store needs no guard: rows past P are out of the buffer's range; the sums do)
       if (BST) {
         // (scale / shift of the lane's chunk come from LDS for every piece: as 16 more live registers they pushed

@@ -26,7 +26,7 @@
 // TRIPWIRE (round 5, every instantiation): a sample's own min-distance is 0 after its update, so the next arg-max can only
 // return the SAME point again when every candidate is exhausted (maximum 0).  A repeated point with a positive maximum means the
 // update was lost on the lane that owns the sample — the signature of round 4's packed-fp32 fault — and costs one compare per
-// sample to see, OFF the sample loop's dependency chain: the workgroup bumps the fault count that cpfn_fps_faults() /
+// sample to see, by the lane that stores the sample's index, OFF the loop's dependency chain: it bumps the fault count that cpfn_fps_faults() /
 // ops.check_fps_faults() read (device counter + pinned host word).  Detection only: a first version also repeated the pass (the
 // update is idempotent) — the loop control then hung on two VALU -> SGPR round trips per sample, +4..8 % on every shape and +19 %
 // on the one-wave kernel (same-box A/B against the round-4 tree), for a repair that cannot reach the lanes that do not own the
@@ -281,9 +281,18 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
   unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, t0 = 0;
   unsigned far = start ? (unsigned)start[b] : 0u;
   float fx = s_x[far], fy = s_y[far], fz = s_z[far];
+  unsigned prev = 0xFFFFFFFFu, kd = 0u;
   for (int i = 0; i < S; ++i) {
     if (PROFILE) t0 = fps_stamp();
-    if (t == 0) out[i] = (int)far;
+    if (t == 0) {
+      out[i] = (int)far;
+      // TRIPWIRE, by the lane that stores the index: the point sampled one pass ago comes back with a positive distance -> its own
+      // min-distance was not zeroed (a lost update).  Placed HERE the check is free (same-box A/B: 464 us against 464 without it at
+      // 8 waves x 16 points, 454 against 480 at 4 x 32; at the loop's tail, behind the cross-wave reduction, it cost 3-4 % — there
+      // the compiler rotated the loop differently and filled the v_readlane wait states with s_nop instead of pointer arithmetic)
+      if (!PROFILE && i > 0 && far == prev && kd != 0u) fps_report_fault(host_faults);
+    }
+    prev = far;
     if (NW == 1 && i > 0) { fx = s_x[far]; fy = s_y[far]; fz = s_z[far]; }
     if (centres && t == 0) {          // the sampled centre itself (what a gather of xyz by idx_out would read: one launch less per level)
       float *c = centres + ((size_t)b * S + i) * 3;
@@ -304,7 +313,6 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
     if (wmax >= 0.f)
       key = ((unsigned long long)__float_as_uint(wmax) << 32) | (unsigned)(~fps_first_index<PPT, NT>(md, wmax, (unsigned)t - (unsigned)lane, lane));
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[3] += t1 - t0; t0 = t1; }      // index of the maximum (ballots)
-    const unsigned sampled = far;
     if (NW > 1) {
       if (lane == 0) s_key[i & 1][wave] = key;
       __syncthreads();
@@ -336,14 +344,7 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       far = key ? ~(unsigned)(key & 0xFFFFFFFFull) : 0u;
     }
     if (PROFILE) { const unsigned long long t1 = fps_stamp(); acc[5] += t1 - t0; t0 = t1; }      // slot read + maximum over the waves
-    // TRIPWIRE: the point just sampled comes back with a positive distance -> its own min-distance was not zeroed (a lost update).
-    // Every lane holds the same key; nothing of the loop depends on the outcome (an exec-masked report, normally skipped).
-    // (`far` and `sampled` sit in scalar registers in the several-waves shapes: the common path is one scalar compare and an
-    //  untaken branch; the key is only looked at behind it)
-    if (!PROFILE && __builtin_expect(far == sampled, 0)) {
-      asm volatile("; tripwire: rare path" ::: "memory");      // (keeps the two conditions apart: merged, every sample pays a vector compare + exec mask)
-      if (t == 0 && (unsigned)(key >> 32) != 0u) fps_report_fault(host_faults);
-    }
+    kd = (unsigned)(key >> 32);            // (distance bits of the key that chose the next sample: the tripwire at the loop's top)
   }
   if (PROFILE && t == 0 && prof) {
 #pragma unroll

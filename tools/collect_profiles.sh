@@ -2,12 +2,12 @@
 # Everything profiles/ is refreshed from, in one gpurun call (run on the GPU box from the repo root):
 #   bash tools/collect_profiles.sh [tag]  ->  gpurun_out/collect/... and profiles/<tag>_*
 # Counter passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa tracing), eager launches.
-tag=${1:-r04}
+tag=${1:-r05}
 repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
 mkdir -p gpurun_out/collect
-B="bench.py --no-cpu-baseline --no-routes --no-traffic"
+B="bench.py --no-cpu-baseline --no-routes --no-traffic --no-rocprof"
 # (CPFN_SIDE_GRAPH_FIRST=1: under the profiler a graph launch costs the host > 1 ms; with the step's graph submitted first the side
 #  graph trails it by most of a step and the trace describes the profiler — cpfn_amd/training.py, profiles/README.md)
 export CPFN_SIDE_GRAPH_FIRST=1
@@ -23,8 +23,8 @@ python3 tools/rooflines.py --trace gpurun_out/collect/stats --fetch gpurun_out/c
 python3 tools/replay_breakdown.py $(find gpurun_out/collect/stats -name '*kernel_trace.csv' | head -1) > profiles/${tag}_replayed_step_breakdown.txt 2> gpurun_out/collect/breakdown.err
 cp $(find gpurun_out/collect/stats -name '*kernel_stats.csv' | head -1) profiles/${tag}_graph_kernel_stats.csv
 python3 bench.py --steps 300 --warmup 30 2> gpurun_out/collect/bench.err | tail -1 > profiles/${tag}_bench_n1.json
-python3 bench.py --steps 50 --warmup 10 --no-graphs --no-cpu-baseline --no-routes 2> gpurun_out/collect/bench_eager.err | tail -1 > profiles/${tag}_bench_n1_eager.json
-python3 bench.py --steps 100 --warmup 10 --workload local --no-routes 2> gpurun_out/collect/bench_local.err | tail -1 > profiles/${tag}_bench_local_n1.json
+python3 bench.py --steps 50 --warmup 10 --no-graphs --no-cpu-baseline --no-routes --no-rocprof 2> gpurun_out/collect/bench_eager.err | tail -1 > profiles/${tag}_bench_n1_eager.json
+python3 bench.py --steps 100 --warmup 10 --workload local --no-routes --no-rocprof 2> gpurun_out/collect/bench_local.err | tail -1 > profiles/${tag}_bench_local_n1.json
 python3 tools/fps_latency.py gpurun_out/collect/fps_latency_table.md > /dev/null 2> gpurun_out/collect/fps_latency.err
 python3 tools/cascade_probe.py > profiles/${tag}_cascade_probe.txt 2> gpurun_out/collect/cascade.err
 # bench.py reads roofline.traffic from profiles/<tag>_family_traffic.json: a file older than the library it describes is a lie

@@ -5,4 +5,4 @@ tag=${1:-run}
 repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o $tag -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-routes --no-traffic > gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o $tag -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-routes --no-traffic --no-rocprof > gpurun_out/prof_$tag.log 2>&1
