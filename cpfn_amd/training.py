@@ -830,7 +830,7 @@ class SPFNTrainer:
                                "stream's graph was never launched, or it stalled for longer than CPFN_FLAG_TIMEOUT_S); the "
                                "optimizer has skipped every step since, the losses of the last steps are invalid"
                                % (st["flag_timeout"] / 100e6))
-        if (st["n_main"] & 63) == 0:
+        if (self.global_step & 63) == 0:
             # the sampling kernels' fault count (a pinned host word: no synchronisation): the several-workgroups time-out and the
             # tripwire — a sample whose own min-distance was not zeroed, i.e. a lost update beside this very step (VERDICT r4 #1a)
             from . import ops as _ops

@@ -324,3 +324,20 @@ def test_cuda_route_restatement_differs_where_the_routes_differ(golden):
     near = (np.sum(xyz ** 2, -1) <= 1e-3)
     for b in range(xyz.shape[0]):
         assert not near[b, f[b, 1:]].any()
+
+
+def test_torch_geometry_restatement_agrees_with_the_c_oracle():
+    """oracle/geometry_torch.py — the reference's CPU geometry route op for op in torch, used by bench.py's
+    `cpu_baseline.reference_like` only — selects the same indices as the C restatement the parity tests use (which the fixtures
+    pin to the reference itself)."""
+    from oracle import geometry_torch as gt
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(-1, 1, (2, 2048, 3)).astype(np.float32)
+    start = rng.integers(0, 2048, 2)
+    sel = og.farthest_point_sample(xyz, 128, start)
+    assert np.array_equal(gt.farthest_point_sample(xyz, 128, start), sel)
+    ctr = np.take_along_axis(xyz, sel[:, :, None], axis=1)
+    assert np.array_equal(gt.ball_query(0.2, 64, xyz, ctr), og.ball_query(0.2, 64, xyz, ctr))
+    d0, i0 = og.three_nn(xyz, ctr)
+    d1, i1 = gt.three_nn(xyz, ctr)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
