@@ -385,6 +385,121 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
   }
 }
 
+// Round 5: the inverse index as a STABLE LSD RADIX SORT of the entries by target — ascending lists by construction, no
+// per-list sort.  The first version above counts, scatters with LDS atomics (order by scheduling) and then sorts every list with one
+// lane per list: a ball query's padded rows give a few targets hundreds of entries, and three launches took 531 us per step with
+// 64-80 KB of LDS per compute unit.  Here: 3 bits of the target per pass (ceil(log2 M) / 3 passes); a wave takes 64 consecutive
+// entries at a time, its rank inside the chunk is a ballot + mbcnt per bucket (lane order = entry order), the rank of the chunk a
+// prefix sum over the [bucket][chunk] table of counts (bucket-major: stable); entries travel packed as (target << 21 | e) between two
+// global buffers (`entries` and a caller-supplied workspace, L2-resident: 96 KB per cloud), the last pass writes plain e into
+// `entries`.  LDS: the table (32 B per chunk) + M counters = 14 KB for the step's largest launch.
+constexpr int CSRX_BITS = 3, CSRX_NB = 1 << CSRX_BITS, CSRX_EBITS = 21, CSRX_MAX_E = 65536;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void csr_build_radix_kernel(const int *__restrict__ idx, int E, int M, int npass,
+                                                             int *__restrict__ offsets, int *__restrict__ entries,
+                                                             int *__restrict__ ws) {
+  constexpr int NW = NT / 64;
+  extern __shared__ int s_dyn[];                   // [CSRX_NB][nch] chunk table | [M + 1] counters
+  __shared__ int s_wsum[NW];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int nch = (E + 63) / 64;
+  int *s_tab = s_dyn, *s_cnt = s_dyn + CSRX_NB * nch;
+  const int *ii = idx + (size_t)b * E;
+  int *off = offsets + (size_t)b * (M + 1);
+  unsigned *bufE = (unsigned *)(entries + (size_t)b * E), *bufW = (unsigned *)(ws + (size_t)b * E);
+  // ---- offsets: histogram of the targets (integer LDS atomics: the COUNTS do not depend on the order) + exclusive scan
+  for (int m = t; m <= M; m += NT) s_cnt[m] = 0;
+  __syncthreads();
+  for (int e = t; e < E; e += NT) {
+    int m = ii[e];
+    m = m < 0 ? 0 : (m >= M ? M - 1 : m);
+    atomicAdd(&s_cnt[m], 1);
+  }
+  __syncthreads();
+  if (t < 64) {
+    const int per = (M + 63) / 64, m0 = t * per, m1 = min(M, m0 + per);
+    int sum = 0;
+    for (int m = m0; m < m1; ++m) sum += s_cnt[m];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (t >= d) incl += o;
+    }
+    int run = incl - sum;
+    for (int m = m0; m < m1; ++m) { const int c = s_cnt[m]; off[m] = run; run += c; }
+    if (t == 63) off[M] = incl;
+  }
+  // ---- the passes
+  const int L = CSRX_NB * nch, per = (L + NT - 1) / NT;
+  for (int p = 0; p < npass; ++p) {
+    const int shift = CSRX_EBITS + p * CSRX_BITS;
+    const bool last = p == npass - 1;
+    // pass p writes dst_p; the last one writes `entries`; they alternate backwards from there
+    unsigned *dst = ((npass - 1 - p) & 1) ? bufW : bufE;
+    const unsigned *src = ((npass - 1 - p) & 1) ? bufE : bufW;           // = dst_{p-1} (unused in pass 0: the keys come from idx)
+    auto fetch = [&](int e) -> unsigned {
+      if (p == 0) {
+        int m = ii[e];
+        m = m < 0 ? 0 : (m >= M ? M - 1 : m);
+        return ((unsigned)m << CSRX_EBITS) | (unsigned)e;
+      }
+      return src[e];
+    };
+    __syncthreads();                                                     // (previous pass's stores / table reads are done)
+    // A: per chunk, the count of every bucket
+    for (int c = wave; c < nch; c += NW) {
+      const int e = c * 64 + lane;
+      const int d = e < E ? (int)((fetch(e) >> shift) & (CSRX_NB - 1)) : CSRX_NB;
+      int mine = 0;
+#pragma unroll
+      for (int q = 0; q < CSRX_NB; ++q) {
+        const unsigned long long mk = __ballot(d == q);
+        if (lane == q) mine = __popcll(mk);
+      }
+      if (lane < CSRX_NB) s_tab[lane * nch + c] = mine;
+    }
+    __syncthreads();
+    // exclusive prefix sum over the table in bucket-major order: every lane sums `per` consecutive entries, then a block scan
+    {
+      const int i0 = min(t * per, L), i1 = min(i0 + per, L);
+      int sum = 0;
+      for (int i = i0; i < i1; ++i) sum += s_tab[i];
+      int incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+      }
+      if (lane == 63) s_wsum[wave] = incl;
+      __syncthreads();
+      int base = 0;
+      for (int w = 0; w < wave; ++w) base += s_wsum[w];
+      int run = base + incl - sum;
+      for (int i = i0; i < i1; ++i) { const int c = s_tab[i]; s_tab[i] = run; run += c; }
+    }
+    __syncthreads();
+    // B: scatter — position = start of (bucket, chunk) + the number of lower lanes of the chunk in the same bucket
+    for (int c = wave; c < nch; c += NW) {
+      const int e = c * 64 + lane;
+      const unsigned v = e < E ? fetch(e) : 0u;
+      const int d = e < E ? (int)((v >> shift) & (CSRX_NB - 1)) : CSRX_NB;
+      int rank = 0;
+#pragma unroll
+      for (int q = 0; q < CSRX_NB; ++q) {
+        const unsigned long long mk = __ballot(d == q);
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (d == q) rank = below;
+      }
+      if (e < E) {
+        const int pos = s_tab[d * nch + c] + rank;
+        dst[pos] = last ? (v & ((1u << CSRX_EBITS) - 1u)) : v;
+      }
+    }
+  }
+}
+
 // out[b,m,:] = Σ_{e in list(m)} w[b,e] · g[b, e / T, :]      (w may be NULL), bf16 in / bf16 out.
 // CS_LANES lanes share one (target row, 8-channel chunk): lane q takes entries q, q+CS_LANES, ... of the list,
 // CS_UNROLL at a time, and the partial sums are combined by a fixed butterfly.  The kernel is a chain of dependent loads
@@ -793,6 +908,25 @@ extern "C" int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets,
   } else {
     csr_build_kernel<false><<<B, TPB, 0, (hipStream_t)stream>>>(idx, E, M, offsets, entries);
   }
+  return cpfn_launch_status();
+}
+
+// cpfn_csr_build with a caller-supplied workspace [B, E] int32: the radix-sort form (E <= 65536); without it, or beyond, the first
+// version.  threads: 0 = the default (256 lanes per cloud), or 512 / 1024.
+extern "C" int cpfn_csr_build_ws(const int *idx, int B, int E, int M, int *offsets, int *entries, int *workspace, int threads,
+                                 void *stream) {
+  if (B < 0 || E < 0 || M <= 0 || M > CSR_MAXM || !idx || !offsets || !entries) return CPFN_EINVAL;
+  if (B == 0) return 0;
+  if (!workspace || E > CSRX_MAX_E || E == 0) return cpfn_csr_build(idx, B, E, M, offsets, entries, stream);
+  int bits = 1;
+  while ((1 << bits) < M) ++bits;
+  const int npass = (bits + CSRX_BITS - 1) / CSRX_BITS;
+  const int nch = (E + 63) / 64;
+  const size_t lds = sizeof(int) * ((size_t)CSRX_NB * nch + M + 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (threads == 1024) csr_build_radix_kernel<1024><<<B, 1024, lds, st>>>(idx, E, M, npass, offsets, entries, workspace);
+  else if (threads == 512) csr_build_radix_kernel<512><<<B, 512, lds, st>>>(idx, E, M, npass, offsets, entries, workspace);
+  else csr_build_radix_kernel<256><<<B, 256, lds, st>>>(idx, E, M, npass, offsets, entries, workspace);
   return cpfn_launch_status();
 }
 

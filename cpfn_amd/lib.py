@@ -55,6 +55,7 @@ SIGNATURES = {
     "cpfn_concat_pos_feats_bf16": [_vp, _vp, _ll, _i, _i, _vp, _vp],
     "cpfn_count_labels": [_vp, _i, _i, _vp, _vp],
     "cpfn_csr_build": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "cpfn_csr_build_ws": [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "cpfn_csr_gather_sum_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_csr_gather_sum_add_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp],
     "cpfn_fit_num_chunks": [_i, _i],

@@ -344,6 +344,11 @@ def interp_rows_bwd(grad_out, idx, w, M):
     return out
 
 
+# the inverse index by a stable radix sort (round 5) / by count + scatter + per-list sort (rounds 1-4; still the route for E > 65536)
+CSR_RADIX = __import__("os").environ.get("CPFN_CSR_RADIX", "1") != "0"
+CSR_THREADS = int(__import__("os").environ.get("CPFN_CSR_THREADS", "0"))
+
+
 def csr_build(idx, M):
     """idx [B, ...] i32 with values in [0, M) -> (offsets [B, M+1] i32, entries [B, E] i32): for every
     target m the ascending list of flattened source positions that reference it."""
@@ -353,6 +358,11 @@ def csr_build(idx, M):
     off = torch.empty(B, M + 1, dtype=torch.int32, device=idx.device)
     ent = torch.empty(B, E, dtype=torch.int32, device=idx.device)
     with torch.cuda.device(idx.device):
-        _l.check(_l.lib().cpfn_csr_build(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _stream()), "cpfn_csr_build")
+        if CSR_RADIX and 0 < E <= 65536:
+            ws = torch.empty(B, E, dtype=torch.int32, device=idx.device)       # (scratch of the radix passes)
+            _l.check(_l.lib().cpfn_csr_build_ws(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _ptr(ws), CSR_THREADS, _stream()),
+                     "cpfn_csr_build_ws")
+        else:
+            _l.check(_l.lib().cpfn_csr_build(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _stream()), "cpfn_csr_build")
     _l.add_bytes("cpfn_csr_build", 8 * B * E + 4 * B * (M + 1))
     return off, ent

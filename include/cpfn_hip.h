@@ -239,6 +239,11 @@ CPFN_API int cpfn_multi_cast(const cpfn_cast_desc *descs /* HOST array */, int c
  * w[b,e] * g[b, e/T, :] (w may be NULL; g bf16 with row stride ldg; out bf16 [B,M,C]) — no atomics,
  * fixed summation order. */
 CPFN_API int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets, int *entries, void *stream);
+/* The same result by a stable radix sort of the entries by target (round 5: ascending by construction, no per-list sort; 3 bits of
+ * the target per pass, ballot ranks inside 64-entry chunks, two global buffers): workspace [B, E] int32 (scratch), E <= 65536;
+ * threads per cloud 0 (= 256), 512 or 1024.  Without a workspace, or beyond that size, cpfn_csr_build. */
+CPFN_API int cpfn_csr_build_ws(const int *idx, int B, int E, int M, int *offsets, int *entries, int *workspace, int threads,
+                               void *stream);
 CPFN_API int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets, const int *entries,
                                       const float *w, int T, int B, int R, int M, int C, void *out,
                                       void *stream);
