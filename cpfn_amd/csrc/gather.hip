@@ -393,7 +393,7 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
 // prefix sum over the [bucket][chunk] table of counts (bucket-major: stable); entries travel packed as (target << 21 | e) between two
 // global buffers (`entries` and a caller-supplied workspace, L2-resident: 96 KB per cloud), the last pass writes plain e into
 // `entries`.  LDS: the table (32 B per chunk) + M counters = 14 KB for the step's largest launch.
-constexpr int CSRX_BITS = 3, CSRX_NB = 1 << CSRX_BITS, CSRX_EBITS = 21, CSRX_MAX_E = 65536;
+constexpr int CSRX_BITS = 3, CSRX_NB = 1 << CSRX_BITS, CSRX_EBITS = 21, CSRX_MAX_E = 32768, CSRX_G = 8;
 
 template <int NT>
 __global__ __launch_bounds__(NT) void csr_build_radix_kernel(const int *__restrict__ idx, int E, int M, int npass,
@@ -448,17 +448,27 @@ __global__ __launch_bounds__(NT) void csr_build_radix_kernel(const int *__restri
       return src[e];
     };
     __syncthreads();                                                     // (previous pass's stores / table reads are done)
-    // A: per chunk, the count of every bucket
-    for (int c = wave; c < nch; c += NW) {
-      const int e = c * 64 + lane;
-      const int d = e < E ? (int)((fetch(e) >> shift) & (CSRX_NB - 1)) : CSRX_NB;
-      int mine = 0;
+    // A: per chunk, the count of every bucket.  A wave takes CSRX_G consecutive chunks per trip and requests all their words before
+    // it looks at the first (one chunk per trip was a chain of dependent L2 round trips: 850 cycles per chunk and phase)
+    for (int c0 = wave * CSRX_G; c0 < nch; c0 += NW * CSRX_G) {
+      unsigned v[CSRX_G];
 #pragma unroll
-      for (int q = 0; q < CSRX_NB; ++q) {
-        const unsigned long long mk = __ballot(d == q);
-        if (lane == q) mine = __popcll(mk);
+      for (int g = 0; g < CSRX_G; ++g) {
+        const int e = (c0 + g) * 64 + lane;
+        v[g] = e < E ? fetch(e) : 0u;
       }
-      if (lane < CSRX_NB) s_tab[lane * nch + c] = mine;
+#pragma unroll
+      for (int g = 0; g < CSRX_G; ++g) {
+        const int c = c0 + g, e = c * 64 + lane;
+        const int d = e < E ? (int)((v[g] >> shift) & (CSRX_NB - 1)) : CSRX_NB;
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < CSRX_NB; ++q) {
+          const unsigned long long mk = __ballot(d == q);
+          if (lane == q) mine = __popcll(mk);
+        }
+        if (lane < CSRX_NB && c < nch) s_tab[lane * nch + c] = mine;
+      }
     }
     __syncthreads();
     // exclusive prefix sum over the table in bucket-major order: every lane sums `per` consecutive entries, then a block scan
@@ -481,20 +491,28 @@ __global__ __launch_bounds__(NT) void csr_build_radix_kernel(const int *__restri
     }
     __syncthreads();
     // B: scatter — position = start of (bucket, chunk) + the number of lower lanes of the chunk in the same bucket
-    for (int c = wave; c < nch; c += NW) {
-      const int e = c * 64 + lane;
-      const unsigned v = e < E ? fetch(e) : 0u;
-      const int d = e < E ? (int)((v >> shift) & (CSRX_NB - 1)) : CSRX_NB;
-      int rank = 0;
+    for (int c0 = wave * CSRX_G; c0 < nch; c0 += NW * CSRX_G) {
+      unsigned v[CSRX_G];
 #pragma unroll
-      for (int q = 0; q < CSRX_NB; ++q) {
-        const unsigned long long mk = __ballot(d == q);
-        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-        if (d == q) rank = below;
+      for (int g = 0; g < CSRX_G; ++g) {
+        const int e = (c0 + g) * 64 + lane;
+        v[g] = e < E ? fetch(e) : 0u;
       }
-      if (e < E) {
-        const int pos = s_tab[d * nch + c] + rank;
-        dst[pos] = last ? (v & ((1u << CSRX_EBITS) - 1u)) : v;
+#pragma unroll
+      for (int g = 0; g < CSRX_G; ++g) {
+        const int c = c0 + g, e = c * 64 + lane;
+        const int d = e < E ? (int)((v[g] >> shift) & (CSRX_NB - 1)) : CSRX_NB;
+        int rank = 0;
+#pragma unroll
+        for (int q = 0; q < CSRX_NB; ++q) {      // (the ranks of phase A kept in LDS as one byte per entry instead: SLOWER, 307 against 248 us)
+          const unsigned long long mk = __ballot(d == q);
+          const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+          if (d == q) rank = below;
+        }
+        if (e < E) {
+          const int pos = s_tab[d * nch + c] + rank;
+          dst[pos] = last ? (v[g] & ((1u << CSRX_EBITS) - 1u)) : v[g];
+        }
       }
     }
   }
@@ -912,7 +930,7 @@ extern "C" int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets,
 }
 
 // cpfn_csr_build with a caller-supplied workspace [B, E] int32: the radix-sort form (E <= 65536); without it, or beyond, the first
-// version.  threads: 0 = the default (256 lanes per cloud), or 512 / 1024.
+// version.  threads: 0 = the default (256 lanes per cloud), or 512 / 1024.  E <= 32768.
 extern "C" int cpfn_csr_build_ws(const int *idx, int B, int E, int M, int *offsets, int *entries, int *workspace, int threads,
                                  void *stream) {
   if (B < 0 || E < 0 || M <= 0 || M > CSR_MAXM || !idx || !offsets || !entries) return CPFN_EINVAL;

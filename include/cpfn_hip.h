@@ -240,7 +240,7 @@ CPFN_API int cpfn_multi_cast(const cpfn_cast_desc *descs /* HOST array */, int c
  * fixed summation order. */
 CPFN_API int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets, int *entries, void *stream);
 /* The same result by a stable radix sort of the entries by target (round 5: ascending by construction, no per-list sort; 3 bits of
- * the target per pass, ballot ranks inside 64-entry chunks, two global buffers): workspace [B, E] int32 (scratch), E <= 65536;
+ * the target per pass, ballot ranks inside 64-entry chunks, two global buffers): workspace [B, E] int32 (scratch), E <= 32768;
  * threads per cloud 0 (= 256), 512 or 1024.  Without a workspace, or beyond that size, cpfn_csr_build. */
 CPFN_API int cpfn_csr_build_ws(const int *idx, int B, int E, int M, int *offsets, int *entries, int *workspace, int threads,
                                void *stream);
