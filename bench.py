@@ -188,17 +188,17 @@ def cpu_baseline():
     torch.set_num_threads(best_nt)
     c_geometry, opn2.og = opn2.og, _gt
     try:
-        one_step(4, 40)
-        t_ref = min(one_step(4, 41), one_step(4, 42))
+        one_step(16, 40)
+        t_ref = min(one_step(16, 41), one_step(16, 42))
     finally:
         opn2.og = c_geometry
     torch.set_num_threads(prev_threads)
     m2, m1 = sum(t2) / len(t2), sum(t1) / len(t1)
     return {"value": 16 / m2, "unit": "point-clouds/s", "cores": best_nt, "kind": "port",
-            "reference_like": {"value": 4 / t_ref, "unit": "point-clouds/s", "cores": best_nt, "kind": "port",
+            "reference_like": {"value": 16 / t_ref, "unit": "point-clouds/s", "cores": best_nt, "kind": "port",
                                "sample": "the same training step with the reference's own CPU GEOMETRY algorithm (torch ops: FPS loop, "
                                          "distance matrices + sorts; oracle/geometry_torch.py) instead of the C restatement: best of 2 "
-                                         "timed steps of 4x%d pts after 1 warm-up, %.3f s" % (N_POINTS, t_ref)},
+                                         "timed steps of 16x%d pts after 1 warm-up, %.3f s" % (N_POINTS, t_ref)},
             "sample": "config 2: %d timed GlobalSPFN training steps (fwd+losses+bwd+Adam) of 16x%d pts after 1 warm-up, at the "
                       "best of 8/16/32/64 threads (%d; host has %d hardware threads / %d physical cores), oracle/ (torch-CPU + C "
                       "geometry), mean %.3f s/step" % (len(t2), N_POINTS, best_nt, ncpu, physical, m2),

@@ -23,10 +23,20 @@ def _bn_rows(y, bn):
                         bn.weight, bn.bias, training, momentum, bn.eps)
 
 
+# Experiment switch (tools/bf16_vs_fp32_training.py --arms fp32r; NOTEBOOK R5.5): the fp32 PyTorch path with the bf16 path's STORAGE
+# roundings — GEMM operands (activations, weights) and the stored pre-BN output rounded to bf16, everything else fp32 — to tell
+# "rounding noise" from "anything else the fused path does differently" when bf16 and fp32 trainings are compared.
+ROUND_STORAGE = False
+
+
+def _r(t):
+    return t.to(torch.bfloat16).to(t.dtype) if ROUND_STORAGE else t
+
+
 def conv_as_linear(x, conv):
     """1x1 Conv1d/Conv2d applied to rows [P, C_in] -> [P, C_out]."""
     w = conv.weight.reshape(conv.weight.shape[0], -1)
-    return F.linear(x, w.to(x.dtype), None if conv.bias is None else conv.bias.to(x.dtype))
+    return _r(F.linear(_r(x), _r(w.to(x.dtype)), None if conv.bias is None else conv.bias.to(x.dtype)))
 
 
 def shared_mlp(x, convs, bns, dtype=torch.float32):

@@ -44,6 +44,8 @@ def train(mode, seed, steps, pool, dev, log_every=0):
     torch.manual_seed(0)                                        # the same initial weights in every run
     model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
     model.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    from cpfn_amd import mlp as _mlp
+    _mlp.ROUND_STORAGE = mode == "fp32r"        # fp32 arithmetic with the bf16 path's storage roundings (round 5)
     B = pool[0]["P"].shape[0]
     tr = training.SPFNTrainer(model, batch_size=B, use_graphs=mode == "bf16", classes=CLASSES)
     torch.manual_seed(seed)                                     # FPS starts and dropout masks of THIS run
@@ -55,6 +57,7 @@ def train(mode, seed, steps, pool, dev, log_every=0):
             if log_every and (s + 1) % log_every == 0:
                 losses.append([float(v) for v in out])
     torch.cuda.synchronize(dev)
+    _mlp.ROUND_STORAGE = False
     return model, {"seconds": time.time() - t0, "skipped_steps": tr.skipped_steps, "losses_every_%d" % log_every: losses}
 
 
@@ -117,7 +120,7 @@ def compare(res, floor_scale=1.0, eval_mode="own"):
     return table, ok
 
 
-def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0, seeds=SEEDS[:2], both_eval_modes=False):
+def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0, seeds=SEEDS[:2], both_eval_modes=False, arms=("bf16", "fp32")):
     from cpfn_amd.SPFN import fitter_factory
     with contextlib.redirect_stdout(io.StringIO()):
         fitter_factory.register_primitives(CLASSES)
@@ -125,7 +128,7 @@ def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0, seeds=S
     held = make_pool(n_held, B, N, 90000, dev)
     res = {"config": {"steps": steps, "batch": B, "points": N, "train_batches": n_train, "held_out_clouds": n_held * B,
                       "seeds": list(seeds), "band": "max(%g x pooled sd, %g x floor)" % (BAND_SD, floor_scale)}}
-    for mode in ("bf16", "fp32"):
+    for mode in arms:
         for seed in seeds:
             model, info = train(mode, seed, steps, pool, dev, log_every)
             info["metrics"] = evaluate(model, held)
@@ -147,6 +150,11 @@ def run(steps, B, N, n_train, n_held, dev, log_every=0, floor_scale=1.0, seeds=S
     m0 = untrained.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
     m0.set_compute_dtype(torch.bfloat16)
     res["untrained"] = {"metrics": evaluate(m0, held)}
+    # per arm: mean and sample sd of every metric (own evaluation mode)
+    res["arms"] = {m: {k: _mean_sd([v["metrics"][k] for kk, v in sorted(res.items()) if kk.startswith(m + "_seed")]) for k in METRICS}
+                   for m in arms}
+    if not ("bf16" in arms and "fp32" in arms):
+        return res
     res["comparison"], res["ok"] = compare(res, floor_scale)
     if both_eval_modes:
         for em in ("bf16", "fp32"):
@@ -167,9 +175,12 @@ if __name__ == "__main__":
     ap.add_argument("--held-batches", type=int, default=8)
     ap.add_argument("--seeds", type=int, default=5, help="runs per mode (bf16 and fp32 each)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--arms", default="bf16,fp32",
+                    help="comma list of bf16 | fp32 | fp32r (fp32 arithmetic with the bf16 path's storage roundings: cpfn_amd.mlp.ROUND_STORAGE)")
     a = ap.parse_args()
+    arms = tuple(a.arms.split(","))
     r = run(a.steps, a.batch, a.points, a.train_batches, a.held_batches, torch.device("cuda:0"), log_every=max(a.steps // 10, 1),
-            seeds=[11 * (i + 1) for i in range(a.seeds)], both_eval_modes=True)
+            seeds=[11 * (i + 1) for i in range(a.seeds)], both_eval_modes="fp32r" not in arms, arms=arms)
     txt = json.dumps(r, indent=1)
     if a.out:
         open(a.out, "w").write(txt + "\n")
