@@ -93,7 +93,9 @@ extern "C" int cpfn_flag_set(unsigned *flag, unsigned value, void *stream) {
 // Set around geometry passes that run on a side stream BESIDE other work (the next batch's FPS / ball query / 3-NN beside
 // a training step): those calls then pick the kernel shapes that disturb their neighbours least instead of the fastest
 // ones (csrc/neighbors.hip, csrc/sampling.hip: measured both ways).
-static bool g_background_geometry = false;
+// Per THREAD since round 5 (as a process-global, two threads capturing at once got each other's setting): the
+// switch is read at launch time by the thread that issues the launch, which is the thread that set it.
+static thread_local bool g_background_geometry = false;
 bool cpfn_background_geometry() { return g_background_geometry; }
 extern "C" int cpfn_set_background_geometry(int on) {
   const int was = g_background_geometry ? 1 : 0;

@@ -131,7 +131,7 @@ CPFN_API int cpfn_ball_query_packed_rel(const float *xyzn, const float *new_xyz,
                                         int *idx_out, float *rel_out, void *stream);
 /* on != 0: the following cpfn_fps / cpfn_ball_query* / cpfn_three_nn* calls run BESIDE other work (a side stream next to a
  * training step) and use the kernel shapes that disturb their neighbours least; 0 (default): the fastest kernels.  Same
- * results, bit for bit.  Returns the previous setting.  (Process-wide; no reference counterpart.) */
+ * results, bit for bit.  Returns the previous setting.  (Per calling thread since round 5; no reference counterpart.) */
 CPFN_API int cpfn_set_background_geometry(int on);
 CPFN_API int cpfn_ball_query_direct(const float *xyz, const float *new_xyz, int B, int N, int S,
                                     float radius, int K, int *idx_out, void *stream);

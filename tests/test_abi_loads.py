@@ -82,3 +82,26 @@ def test_build_rejects_packed_fp32_beside_a_step_and_96_bit_lds_reads():
     assert len(b._PACKED_F32.findall(bodies[beside])) == 1 and len(b._PACKED_F32.findall(bodies[alone])) == 1   # (v_pk_mov is not arithmetic)
     assert b._NO_PACKED["neighbors.hip"]("anything")
     assert "-fno-slp-vectorize" in b.SOURCES["neighbors.hip"] and "-fno-slp-vectorize" in b.SOURCES["sampling.hip"]
+
+
+def test_background_geometry_switch_is_per_thread():
+    """cpfn_set_background_geometry is read at launch time by the launching thread: as a process-global (until round 5) two threads
+    capturing at once got each other's setting (VERDICT r4, weak #1).  Host-side state only: no GPU needed."""
+    import ctypes
+    import threading
+    from cpfn_amd import build
+    h = ctypes.CDLL(build.SO)
+    h.cpfn_set_background_geometry.argtypes = [ctypes.c_int]
+    h.cpfn_set_background_geometry.restype = ctypes.c_int
+    assert h.cpfn_set_background_geometry(1) == 0
+    seen = []
+
+    def other():
+        seen.append(h.cpfn_set_background_geometry(0))          # this thread's own setting: still the default
+        seen.append(h.cpfn_set_background_geometry(1))
+        seen.append(h.cpfn_set_background_geometry(1))
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen == [0, 0, 1]
+    assert h.cpfn_set_background_geometry(0) == 1               # ... and the first thread's is untouched by the other's
