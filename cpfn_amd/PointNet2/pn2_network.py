@@ -74,13 +74,6 @@ class PointNet2(torch.nn.Module):
         g2 = self.sa2.neighbours(a1[1], a2, cr, False)
         f2 = self.sfp2.compute_geometry(a1[1], a2[1], cr, False)
         f3 = self.sfp3.compute_geometry(xyz, a1[1], cr, False)
-        _nd = int(__import__("os").environ.get("CPFN_DBG_SIDE_DUMMIES", "0"))
-        if _nd:        # (experiment, NOTEBOOK R5.6: what does one more CHIP-WIDE launch of trivial work on the side stream cost the step?)
-            from .. import ops as _o
-            if self.__dict__.get("_dbg_dummy") is None or self.__dict__["_dbg_dummy"].device != xyz.device:
-                self.__dict__["_dbg_dummy"] = torch.ones(2048 * 256, 3, device=xyz.device)
-            for _ in range(_nd):
-                self.__dict__["_dbg_keep"] = _o.three_weights(self.__dict__["_dbg_dummy"])
         if inv:
             for g, sa, n_src in ((g1, self.sa1, xyz.shape[1]), (g2, self.sa2, a1[1].shape[1])):
                 if sa.has_feats and n_src <= 2048 and len(g["scales"]) == 1:
