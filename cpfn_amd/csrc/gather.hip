@@ -385,6 +385,85 @@ __global__ __launch_bounds__(TPB) void csr_build_kernel(const int *__restrict__ 
   }
 }
 
+// Round 5, the form the step likes ("ordered"): the first version's count / scan / LDS-atomic scatter — lanes that wait on LDS atomics
+// issue nothing, which is what makes it a cheap neighbour (NOTEBOOK R5.4) — made to deliver ASCENDING lists without a sort phase:
+// every wave owns a contiguous range of the entries and its own row of counters (position = start of the list + what the waves
+// before it hold of that list + arrival order inside the wave), and walks its range in order, 64 entries per instruction.  Inside
+// one ds_add_rtn instruction the hardware serialises the lanes that hit the same counter; on gfx950 it does so in ascending lane
+// order, i.e. in entry order — which no manual promises, so the result is VERIFIED by all lanes (the whole array must be sorted by
+// (target, entry): one compare per adjacent pair) and the first version's insertion sort runs if a single pair is out of order.
+// The per-list sort that cost ~100 us with 80 KB of LDS held is then a ~3 us check.
+template <int NW, bool VERIFY>
+__global__ __launch_bounds__(64 * NW) void csr_build_ordered_kernel(const int *__restrict__ idx, int E, int M,
+                                                                    int *__restrict__ offsets, int *__restrict__ entries,
+                                                                    int *__restrict__ fallbacks) {
+  extern __shared__ int s_dyn2[];                  // [NW][M] counters / running positions | [M + 1] offsets | [E] target << 16 | entry
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int *s_w = s_dyn2, *s_off = s_dyn2 + NW * M;
+  unsigned *s_ent = (unsigned *)(s_off + M + 1);
+  __shared__ int s_bad;
+  const int *ii = idx + (size_t)b * E;
+  int *off = offsets + (size_t)b * (M + 1), *gent = entries + (size_t)b * E;
+  const int per = ((E + NW * 64 - 1) / (NW * 64)) * 64;          // entries per wave, a multiple of 64
+  const int e0 = wave * per, e1 = min(E, e0 + per);
+  for (int i = t; i < NW * M; i += 64 * NW) s_w[i] = 0;
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  for (int e = e0 + lane; e < e1; e += 64) {
+    int m = ii[e];
+    m = m < 0 ? 0 : (m >= M ? M - 1 : m);
+    atomicAdd(&s_w[wave * M + m], 1);
+  }
+  __syncthreads();
+  if (t < 64) {   // exclusive scan of the per-target totals by one wave; the per-wave rows become running positions
+    const int pm = (M + 63) / 64, m0 = t * pm, m1 = min(M, m0 + pm);
+    int sum = 0;
+    for (int m = m0; m < m1; ++m)
+      for (int w = 0; w < NW; ++w) sum += s_w[w * M + m];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (t >= d) incl += o;
+    }
+    int run = incl - sum;
+    for (int m = m0; m < m1; ++m) {
+      s_off[m] = run;
+      for (int w = 0; w < NW; ++w) { const int c = s_w[w * M + m]; s_w[w * M + m] = run; run += c; }
+    }
+    if (t == 63) s_off[M] = incl;
+  }
+  __syncthreads();
+  for (int m = t; m <= M; m += 64 * NW) off[m] = s_off[m];
+  for (int e = e0 + lane; e < e1; e += 64) {          // in order: one instruction = 64 consecutive entries
+    int m = ii[e];
+    m = m < 0 ? 0 : (m >= M ? M - 1 : m);
+    s_ent[atomicAdd(&s_w[wave * M + m], 1)] = ((unsigned)m << 16) | (unsigned)e;
+  }
+  __syncthreads();
+  // verification: sorted by (target, entry)?  (one LDS compare per adjacent pair)
+  if (VERIFY) {
+    int bad = 0;
+    for (int i = t; i + 1 < E; i += 64 * NW) bad |= s_ent[i] >= s_ent[i + 1];
+    if (bad) s_bad = 1;
+    __syncthreads();
+  }
+  if (s_bad) {                                         // (never taken on the hardware seen so far; counted for the tests)
+    if (t == 0 && fallbacks) atomicAdd(fallbacks, 1);
+    for (int m = t; m < M; m += 64 * NW) {
+      const int a = s_off[m], z = s_off[m + 1];
+      for (int i = a + 1; i < z; ++i) {
+        const unsigned v = s_ent[i];
+        int j = i - 1;
+        while (j >= a && s_ent[j] > v) { s_ent[j + 1] = s_ent[j]; --j; }
+        s_ent[j + 1] = v;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < E; e += 64 * NW) gent[e] = (int)(s_ent[e] & 0xffffu);
+}
+
 // Round 5: the inverse index as a STABLE LSD RADIX SORT of the entries by target — ascending lists by construction, no
 // per-list sort.  The first version above counts, scatters with LDS atomics (order by scheduling) and then sorts every list with one
 // lane per list: a ball query's padded rows give a few targets hundreds of entries, and three launches took 531 us per step with
@@ -936,6 +1015,23 @@ extern "C" int cpfn_csr_build_ws(const int *idx, int B, int E, int M, int *offse
   if (B < 0 || E < 0 || M <= 0 || M > CSR_MAXM || !idx || !offsets || !entries) return CPFN_EINVAL;
   if (B == 0) return 0;
   if (!workspace || E > CSRX_MAX_E || E == 0) return cpfn_csr_build(idx, B, E, M, offsets, entries, stream);
+  if (threads < 0) {          // "ordered": per-wave ranges + in-order LDS atomics + verification (the workspace's first word counts fall-backs)
+    constexpr int NW = 4;
+    const size_t lds2 = sizeof(int) * ((size_t)NW * M + M + 1) + sizeof(unsigned) * (size_t)E + 64;
+    if (lds2 <= 150 * 1024 && M <= 65536 && E <= 65536) {
+      static bool attr_set3 = false;
+      if (!attr_set3) {
+        hipError_t e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set3 = true;
+      }
+      if (threads == -2) csr_build_ordered_kernel<NW, false><<<B, 64 * NW, lds2, (hipStream_t)stream>>>(idx, E, M, offsets, entries, workspace);   // (timing experiments only)
+      else csr_build_ordered_kernel<NW, true><<<B, 64 * NW, lds2, (hipStream_t)stream>>>(idx, E, M, offsets, entries, workspace);
+      return cpfn_launch_status();
+    }
+    return cpfn_csr_build(idx, B, E, M, offsets, entries, stream);     // (the one-word workspace is no scratch for the radix passes)
+  }
   int bits = 1;
   while ((1 << bits) < M) ++bits;
   const int npass = (bits + CSRX_BITS - 1) / CSRX_BITS;

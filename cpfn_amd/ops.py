@@ -344,9 +344,33 @@ def interp_rows_bwd(grad_out, idx, w, M):
     return out
 
 
-# the inverse index by a stable radix sort (round 5) / by count + scatter + per-list sort (rounds 1-4; still the route for E > 32768)
+# The inverse index (csrc/gather.hip), three builds of the same ascending lists:
+#   "ordered" (CPFN_CSR_THREADS < 0, the default since round 5): count / scan / in-order LDS-atomic scatter, verified in the kernel;
+#   the stable radix sort (CPFN_CSR_THREADS = 0 | 512 | 1024; also where the ordered form's LDS slab does not fit);
+#   count + scatter + per-list sort (rounds 1-4: CPFN_CSR_RADIX=0, and E > 32768).
+# The step's three launches, stand-alone: 65 us / 106 us / 367 us; the step itself: -5 us / 0 / 0 (NOTEBOOK R5.4, R5.7).
 CSR_RADIX = __import__("os").environ.get("CPFN_CSR_RADIX", "1") != "0"
-CSR_THREADS = int(__import__("os").environ.get("CPFN_CSR_THREADS", "1024"))      # (1024 lanes per cloud: 106 us for the step's three launches, 248 with 256)
+CSR_THREADS = int(__import__("os").environ.get("CPFN_CSR_THREADS", "-1"))
+
+
+def _csr_ordered_fits(E, M):
+    return 4 * (5 * M + 1) + 4 * E + 64 <= 150 * 1024 and M <= 65536 and E <= 65536
+
+
+_CSR_FALLBACKS = {}
+
+
+def _csr_fallback_word(device):
+    w = _CSR_FALLBACKS.get(device)
+    if w is None:
+        w = _CSR_FALLBACKS[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def csr_fallbacks(device=None):
+    """Clouds whose "ordered" inverse index (CPFN_CSR_THREADS < 0) failed its in-kernel verification and was sorted by the
+    fall-back loop — 0 on every MI355X seen so far; the result is ascending either way (csrc/gather.hip)."""
+    return sum(int(w.item()) for d, w in _CSR_FALLBACKS.items() if device is None or d == device)
 
 
 def csr_build(idx, M):
@@ -359,8 +383,13 @@ def csr_build(idx, M):
     ent = torch.empty(B, E, dtype=torch.int32, device=idx.device)
     with torch.cuda.device(idx.device):
         if CSR_RADIX and 0 < E <= 32768:
-            ws = torch.empty(B, E, dtype=torch.int32, device=idx.device)       # (scratch of the radix passes)
-            _l.check(_l.lib().cpfn_csr_build_ws(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _ptr(ws), CSR_THREADS, _stream()),
+            threads = CSR_THREADS
+            if threads < 0 and _csr_ordered_fits(E, int(M)):      # no scratch; the word counts the clouds whose scatter had to be sorted after all
+                ws = _csr_fallback_word(idx.device)
+            else:
+                threads = 1024 if threads < 0 else threads
+                ws = torch.empty(B, E, dtype=torch.int32, device=idx.device)       # (scratch of the radix passes)
+            _l.check(_l.lib().cpfn_csr_build_ws(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _ptr(ws), threads, _stream()),
                      "cpfn_csr_build_ws")
         else:
             _l.check(_l.lib().cpfn_csr_build(_ptr(idx), B, E, int(M), _ptr(off), _ptr(ent), _stream()), "cpfn_csr_build")

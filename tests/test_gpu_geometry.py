@@ -284,12 +284,18 @@ def test_bf16_row_movers_vs_oracle():
     assert np.abs(gotg - wantgg).max() <= 2e-2 * np.abs(wantgg).max()
 
 
-@pytest.mark.parametrize("kind", ["ball_padded", "one_target", "uniform", "beyond_lds"])
-def test_inverse_index_lists_are_ascending(kind):
-    """cpfn_csr_build = a stable sort of the entries by target, whatever the list lengths: rows padded like a ball query's
-    (a popular target collects hundreds of entries: rank sort, one lane per entry), every entry on ONE target (beyond the
-    rank sort's list limit: insertion sort), uniform targets, and more entries than the LDS slab holds."""
+@pytest.mark.parametrize("route", ["ordered", "radix", "sorted_lists"])
+@pytest.mark.parametrize("kind", ["ball_padded", "one_target", "two_alternating", "runs_of_64", "uniform", "beyond_lds"])
+def test_inverse_index_lists_are_ascending(kind, route, monkeypatch):
+    """cpfn_csr_build(_ws) = a stable sort of the entries by target, whatever the list lengths and whichever of the three builds
+    runs (ops.CSR_THREADS / CSR_RADIX): rows padded like a ball query's (a popular target collects hundreds of entries), every
+    entry on ONE target, two targets alternating lane by lane and runs of 64 equal targets (the worst cases of the ordered build's
+    same-counter LDS atomics), uniform targets, and more entries than any LDS slab holds.  The ordered build must not have needed
+    its fall-back sort."""
     from cpfn_amd import ops
+    monkeypatch.setattr(ops, "CSR_THREADS", {"ordered": -1, "radix": 1024, "sorted_lists": 0}[route])
+    monkeypatch.setattr(ops, "CSR_RADIX", route != "sorted_lists")
+    fallbacks0 = ops.csr_fallbacks()
     rng = np.random.default_rng(21)
     B, M = 3, 512
     if kind == "ball_padded":
@@ -305,6 +311,10 @@ def test_inverse_index_lists_are_ascending(kind):
     elif kind == "one_target":
         idx = np.full((B, 2048, 4), 9, np.int64)
         idx[1, ::3] = 300
+    elif kind == "two_alternating":
+        idx = np.tile((np.arange(8192) % 2 * 300).reshape(1, 8192, 1), (B, 1, 1))
+    elif kind == "runs_of_64":
+        idx = np.repeat(rng.integers(0, M, (B, 128)), 64, axis=1).reshape(B, 8192, 1)
     elif kind == "uniform":
         idx = rng.integers(0, M, (B, 8192, 3))
     else:
@@ -316,6 +326,7 @@ def test_inverse_index_lists_are_ascending(kind):
         flat = idx[b].reshape(-1)
         assert np.array_equal(ent[b], np.argsort(flat, kind="stable")), kind
         assert np.array_equal(off[b], np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=M))]))
+    assert ops.csr_fallbacks() == fallbacks0
 
 
 def test_inverse_index_adjoints_vs_oracle():
