@@ -409,6 +409,7 @@ __global__ __launch_bounds__(64 * NW) void csr_build_ordered_kernel(const int *_
   for (int i = t; i < NW * M; i += 64 * NW) s_w[i] = 0;
   if (t == 0) s_bad = 0;
   __syncthreads();
+#pragma unroll 4
   for (int e = e0 + lane; e < e1; e += 64) {
     int m = ii[e];
     m = m < 0 ? 0 : (m >= M ? M - 1 : m);
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(64 * NW) void csr_build_ordered_kernel(const int *_
   }
   __syncthreads();
   for (int m = t; m <= M; m += 64 * NW) off[m] = s_off[m];
+#pragma unroll 4
   for (int e = e0 + lane; e < e1; e += 64) {          // in order: one instruction = 64 consecutive entries
     int m = ii[e];
     m = m < 0 ? 0 : (m >= M ? M - 1 : m);
@@ -1016,18 +1018,23 @@ extern "C" int cpfn_csr_build_ws(const int *idx, int B, int E, int M, int *offse
   if (B == 0) return 0;
   if (!workspace || E > CSRX_MAX_E || E == 0) return cpfn_csr_build(idx, B, E, M, offsets, entries, stream);
   if (threads < 0) {          // "ordered": per-wave ranges + in-order LDS atomics + verification (the workspace's first word counts fall-backs)
-    constexpr int NW = 4;
-    const size_t lds2 = sizeof(int) * ((size_t)NW * M + M + 1) + sizeof(unsigned) * (size_t)E + 64;
+    const int NWr = threads == -8 ? 8 : threads == -16 ? 16 : 4;          // (-8 / -16: timing experiments; 4 waves is what the step likes)
+    const size_t lds2 = sizeof(int) * ((size_t)NWr * M + M + 1) + sizeof(unsigned) * (size_t)E + 64;
     if (lds2 <= 150 * 1024 && M <= 65536 && E <= 65536) {
       static bool attr_set3 = false;
       if (!attr_set3) {
-        hipError_t e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)csr_build_ordered_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set3 = true;
       }
-      if (threads == -2) csr_build_ordered_kernel<NW, false><<<B, 64 * NW, lds2, (hipStream_t)stream>>>(idx, E, M, offsets, entries, workspace);   // (timing experiments only)
-      else csr_build_ordered_kernel<NW, true><<<B, 64 * NW, lds2, (hipStream_t)stream>>>(idx, E, M, offsets, entries, workspace);
+      hipStream_t st = (hipStream_t)stream;
+      if (threads == -2) csr_build_ordered_kernel<4, false><<<B, 256, lds2, st>>>(idx, E, M, offsets, entries, workspace);   // (timing experiments only)
+      else if (NWr == 8) csr_build_ordered_kernel<8, true><<<B, 512, lds2, st>>>(idx, E, M, offsets, entries, workspace);
+      else if (NWr == 16) csr_build_ordered_kernel<16, true><<<B, 1024, lds2, st>>>(idx, E, M, offsets, entries, workspace);
+      else csr_build_ordered_kernel<4, true><<<B, 256, lds2, st>>>(idx, E, M, offsets, entries, workspace);
       return cpfn_launch_status();
     }
     return cpfn_csr_build(idx, B, E, M, offsets, entries, stream);     // (the one-word workspace is no scratch for the radix passes)

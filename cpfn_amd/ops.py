@@ -348,13 +348,15 @@ def interp_rows_bwd(grad_out, idx, w, M):
 #   "ordered" (CPFN_CSR_THREADS < 0, the default since round 5): count / scan / in-order LDS-atomic scatter, verified in the kernel;
 #   the stable radix sort (CPFN_CSR_THREADS = 0 | 512 | 1024; also where the ordered form's LDS slab does not fit);
 #   count + scatter + per-list sort (rounds 1-4: CPFN_CSR_RADIX=0, and E > 32768).
-# The step's three launches, stand-alone: 65 us / 106 us / 367 us; the step itself: -5 us / 0 / 0 (NOTEBOOK R5.4, R5.7).
+# The step's three launches, stand-alone: 47 us (8 waves per cloud) / 106 us / 367 us; the step itself: -20 us / 0 / 0 (NOTEBOOK
+# R5.4, R5.7).
 CSR_RADIX = __import__("os").environ.get("CPFN_CSR_RADIX", "1") != "0"
-CSR_THREADS = int(__import__("os").environ.get("CPFN_CSR_THREADS", "-1"))
+CSR_THREADS = int(__import__("os").environ.get("CPFN_CSR_THREADS", "-8"))      # (ordered: -1 = 4 waves per cloud, -8 = 8, -16 = 16)
 
 
 def _csr_ordered_fits(E, M):
-    return 4 * (5 * M + 1) + 4 * E + 64 <= 150 * 1024 and M <= 65536 and E <= 65536
+    waves = {-8: 8, -16: 16}.get(CSR_THREADS, 4)
+    return 4 * ((waves + 1) * M + 1) + 4 * E + 64 <= 150 * 1024 and M <= 65536 and E <= 65536
 
 
 _CSR_FALLBACKS = {}

@@ -242,11 +242,11 @@ CPFN_API int cpfn_csr_build(const int *idx, int B, int E, int M, int *offsets, i
 /* The same result by a stable radix sort of the entries by target (round 5: ascending by construction, no per-list sort; 3 bits of
  * the target per pass, ballot ranks inside 64-entry chunks, two global buffers): workspace [B, E] int32 (scratch), E <= 32768;
  * threads per cloud 0 (= 256), 512 or 1024.  Without a workspace, or beyond that size, cpfn_csr_build.
- * threads < 0: the "ordered" build — count, scan, then a scatter through LDS atomics in which every wave walks its own contiguous
+ * threads < 0 (-1: 4 waves per cloud, -8: 8 waves, -16: 16 waves): the "ordered" build — count, scan, then a scatter through LDS atomics in which every wave walks its own contiguous
  * range of the entries in order (ascending lists as long as one ds_add_rtn serves its lanes in lane order, which gfx950 does);
  * the kernel verifies the result (one LDS compare per adjacent pair) and sorts the lists itself where the check fails, so the
  * result is the same on any hardware.  workspace is then ONE int32 the caller zeroes once: the number of clouds that needed
- * the sort (0 on every MI355X seen).  Needs 4 (5 M + 1) + 4 E + 64 bytes of LDS <= 150 KB, otherwise cpfn_csr_build runs. */
+ * the sort (0 on every MI355X seen).  Needs 4 ((waves + 1) M + 1) + 4 E + 64 bytes of LDS <= 150 KB, otherwise cpfn_csr_build runs. */
 CPFN_API int cpfn_csr_build_ws(const int *idx, int B, int E, int M, int *offsets, int *entries, int *workspace, int threads,
                                void *stream);
 CPFN_API int cpfn_csr_gather_sum_bf16(const void *g, int ldg, const int *offsets, const int *entries,

@@ -284,7 +284,7 @@ def test_bf16_row_movers_vs_oracle():
     assert np.abs(gotg - wantgg).max() <= 2e-2 * np.abs(wantgg).max()
 
 
-@pytest.mark.parametrize("route", ["ordered", "radix", "sorted_lists"])
+@pytest.mark.parametrize("route", ["ordered", "ordered_4_waves", "ordered_16_waves", "radix", "sorted_lists"])
 @pytest.mark.parametrize("kind", ["ball_padded", "one_target", "two_alternating", "runs_of_64", "uniform", "beyond_lds"])
 def test_inverse_index_lists_are_ascending(kind, route, monkeypatch):
     """cpfn_csr_build(_ws) = a stable sort of the entries by target, whatever the list lengths and whichever of the three builds
@@ -293,7 +293,7 @@ def test_inverse_index_lists_are_ascending(kind, route, monkeypatch):
     same-counter LDS atomics), uniform targets, and more entries than any LDS slab holds.  The ordered build must not have needed
     its fall-back sort."""
     from cpfn_amd import ops
-    monkeypatch.setattr(ops, "CSR_THREADS", {"ordered": -1, "radix": 1024, "sorted_lists": 0}[route])
+    monkeypatch.setattr(ops, "CSR_THREADS", {"ordered": -8, "ordered_4_waves": -1, "ordered_16_waves": -16, "radix": 1024, "sorted_lists": 0}[route])
     monkeypatch.setattr(ops, "CSR_RADIX", route != "sorted_lists")
     fallbacks0 = ops.csr_fallbacks()
     rng = np.random.default_rng(21)

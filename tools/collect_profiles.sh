@@ -28,7 +28,7 @@ python3 bench.py --steps 100 --warmup 10 --workload local --no-routes --no-rocpr
 python3 tools/fps_latency.py gpurun_out/collect/fps_latency_table.md > /dev/null 2> gpurun_out/collect/fps_latency.err
 python3 tools/cascade_probe.py > profiles/${tag}_cascade_probe.txt 2> gpurun_out/collect/cascade.err
 cp gpurun_out/collect/fps_latency_table.md profiles/${tag}_fps_latency_table.md 2>/dev/null
-(CPFN_CSR_RADIX=0 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=1024 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=256 python3 tools/dbg/csr_time.py; python3 tools/dbg/csr_time.py) > profiles/${tag}_csr_time.txt 2> gpurun_out/collect/csr.err
+(CPFN_CSR_RADIX=0 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=1024 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=256 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=-1 python3 tools/dbg/csr_time.py; python3 tools/dbg/csr_time.py) > profiles/${tag}_csr_time.txt 2> gpurun_out/collect/csr.err
 # bench.py reads roofline.traffic from profiles/<tag>_family_traffic.json: a file older than the library it describes is a lie
 if [ ! -s profiles/${tag}_family_traffic.json ] || [ profiles/${tag}_family_traffic.json -ot cpfn_amd/libcpfn_hip.so ]; then
   echo "collect_profiles: profiles/${tag}_family_traffic.json is missing or older than cpfn_amd/libcpfn_hip.so" >&2

@@ -1,4 +1,4 @@
-"""The "ordered" inverse index (CPFN_CSR_THREADS=-1) against numpy's stable argsort on adversarial inputs, and its fall-back count."""
+"""The "ordered" inverse index (CPFN_CSR_THREADS < 0: the default) against numpy's stable argsort on adversarial inputs, and its fall-back count."""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.getcwd())
 from cpfn_amd import ops          # noqa: E402
 
-assert ops.CSR_THREADS < 0, "run with CPFN_CSR_THREADS=-1"
+assert ops.CSR_THREADS < 0, "run with CPFN_CSR_THREADS < 0"
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(5)
 bad = 0

@@ -1,6 +1,6 @@
 """Times cpfn_csr_build on the three shapes of a GlobalSPFN step (16 clouds): sa2's grouping (8192 entries -> 512 targets, ball-query
 rows with padding), sfp2's 3-NN (1536 -> 128), sfp3's 3-NN (24576 -> 512); HIP events, median of 20, launches back to back.
-    CPFN_CSR_RADIX=0|1 CPFN_CSR_THREADS=-1|0|512|1024 python tools/dbg/csr_time.py"""
+    CPFN_CSR_RADIX=0|1 CPFN_CSR_THREADS=-16|-8|-1|0|512|1024 python tools/dbg/csr_time.py"""
 import os
 import sys
 
@@ -37,4 +37,4 @@ for name, idx, M in cases:
     ts.sort()
     tot += ts[len(ts) // 2]
     print("%-32s %8.1f us   (checksum %d)" % (name, ts[len(ts) // 2], int(ent.long().sum() % 1000003)))
-print("sum %.1f us   (CPFN_CSR_RADIX=%s, CPFN_CSR_THREADS=%s)" % (tot, os.environ.get("CPFN_CSR_RADIX", "1"), os.environ.get("CPFN_CSR_THREADS", "-1 (ordered)")))
+print("sum %.1f us   (CPFN_CSR_RADIX=%s, CPFN_CSR_THREADS=%s)" % (tot, os.environ.get("CPFN_CSR_RADIX", "1"), os.environ.get("CPFN_CSR_THREADS", "-8 (ordered, 8 waves)")))
