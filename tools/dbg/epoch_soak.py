@@ -28,6 +28,7 @@ for e in range(n_epochs):
         _, vtot = training.spfn_train_val_epoch(val_loader, m, e, opt, gs, vis, bench._RouteArgs(), conf, dev, network_mode='val')
     torch.cuda.synchronize(); t2 = time.perf_counter()
     tr = m.__dict__["_cpfn_epoch_runner"].trainer
-    print("epoch %d: train %.3f ms/step (mean loss %.4f), val %.3f ms/step (mean loss %.4f), skipped %d, fps faults %d, device %.1f MB, reserved %.1f MB"
+    print("epoch %d: train %.3f ms/step (mean loss %.4f), val %.3f ms/step (mean loss %.4f), skipped %d, fps faults %d, inverse-index fall-backs %d, device %.1f MB, reserved %.1f MB"
           % (e, 1e3 * (t1 - t0) / n_batches, tot / (16 * n_batches), 1e3 * (t2 - t1) / 20, vtot / (16 * 20), tr.skipped_steps, ops.fps_faults(),
+             ops.csr_fallbacks(),
              torch.cuda.memory_allocated() / 1e6, torch.cuda.memory_reserved() / 1e6), flush=True)
