@@ -31,6 +31,12 @@ BATCH_PER_GPU = int(os.environ.get("CPFN_BENCH_BATCH", "16"))   # 16 = BASELINE.
 N_POINTS = 8192
 N_INSTANCES = 28
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# PLUMBING CHECK ONLY: CPFN_BENCH_BACKEND=gloo CPFN_BENCH_SHARE_GPU=1 python bench.py --gpus 2 puts every rank on
+# GPU 0 with gloo as the collective backend (RCCL refuses two ranks on one device), so that the N-rank code of this file — the
+# self-launch, the rank-time all_gather, comm_us_per_step, the fault slot, rs_ag — executes on a one-GPU box.  The line it prints
+# says so (`plumbing_check`); its numbers are two processes time-slicing one GPU and are NOT a scaling measurement.
+BENCH_BACKEND = os.environ.get("CPFN_BENCH_BACKEND", "nccl")
+SHARE_GPU = os.environ.get("CPFN_BENCH_SHARE_GPU", "0") == "1" and BENCH_BACKEND == "gloo"
 
 # Dominant kernel family of the step (profiles/r02_rooflines.json; DESIGN.md "Measurement"):
 # the bf16 MFMA GEMM behind every 1x1 convolution, forward and data-gradient (34 launches per
@@ -107,6 +113,8 @@ def self_launch(args):
     if visible is None:                              # (no KFD topology in /sys: ask the runtime)
         import torch
         visible = torch.cuda.device_count()
+    if SHARE_GPU and visible >= 1:
+        visible = args.gpus                          # (plumbing check: every rank on GPU 0, see SHARE_GPU)
     if visible < args.gpus:
         sys.stderr.write("bench.py: %d GPUs requested, %d visible\n" % (args.gpus, visible))
         sys.exit(2)
@@ -680,6 +688,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if SHARE_GPU:
+        local_rank = 0
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node == --gpus)\n" % (args.gpus, world))
         sys.exit(2)
@@ -689,7 +699,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if BENCH_BACKEND == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -871,6 +884,8 @@ def main():
         # everybody else's exchange time)
         mine = torch.tensor([1e3 * elapsed / args.steps, statistics.median([c for c in comm_us if c is not None] or [float("nan")])],
                             dtype=torch.float64, device=dev)
+        if BENCH_BACKEND == "gloo":
+            mine = mine.cpu()                          # (gloo's device all_gather support differs from release to release)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_ms, rank_comm = [float(a[0]) for a in allr], [float(a[1]) for a in allr]
@@ -971,6 +986,10 @@ def main():
                          "probe_achieved": probe_achieved, "probe_frac": probe_achieved / HBM_PEAK_GBS,
                          "rocprof_families": rocprof_live,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         # what the counters say: measured HBM bytes per launch over the same per-launch duration as `frac`
+                         "traffic_frac": (traffic / (bytes_per_launch / (achieved * 1e9)) / 1e9 / HBM_PEAK_GBS)
+                         if (traffic and achieved > 0 and bytes_per_launch > 0) else None,
+                         "traffic_over_algorithmic": (traffic / bytes_per_launch) if (traffic and bytes_per_launch > 0) else None,
                          "probe_frac_range": [bytes_per_step / (fam_range[dominant][1] / (wall_khz * 1e3)) / 1e9 / HBM_PEAK_GBS,
                                         bytes_per_step / (fam_range[dominant][0] / (wall_khz * 1e3)) / 1e9 / HBM_PEAK_GBS]
                          if fam_range[dominant][0] > 0 else None,
@@ -998,6 +1017,9 @@ def main():
             # cross-stream graph edges (~19 us each on this stack) to hide ~30-50 us of wire time
             line["exchange_overlap"] = False
             line.update(extra)
+            if SHARE_GPU or BENCH_BACKEND != "nccl":
+                line["plumbing_check"] = ("NOT a scaling number: backend %s%s — exercises the N-rank plumbing of bench.py and the "
+                                          "trainer on one GPU" % (BENCH_BACKEND, ", all ranks on GPU 0" if SHARE_GPU else ""))
         if world == 1 and not args.no_routes and args.workload == "global" and args.dtype == "bf16" and not args.no_graphs:
             del trainer, model                         # (its graphs' pools go back before the routes build theirs)
             line["routes"] = measure_routes(args, dev, rank, ms_per_step)

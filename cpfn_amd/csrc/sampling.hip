@@ -37,9 +37,11 @@
 // row now and then (round 4; fps_update and fps_launch below).
 #include "common.h"
 #include <cstdlib>
+#include <mutex>
 
 constexpr int CPFN_LDS_BYTES_PER_CU = 160 * 1024;      // gfx950
 
+constexpr unsigned CPFN_FPS_INIT_DIST_BITS = 0x501502F9u;      // 1e10f, every point's min-distance before the first sample
 __device__ unsigned g_fps_faults = 0;           // sibling time-outs of the several-workgroups kernel + lost updates (tripwire)
 
 namespace {
@@ -290,7 +292,10 @@ __global__ __launch_bounds__(NT) void fps_resident_kernel(const float *__restric
       // min-distance was not zeroed (a lost update).  Placed HERE the check is free (same-box A/B: 464 us against 464 without it at
       // 8 waves x 16 points, 454 against 480 at 4 x 32; at the loop's tail, behind the cross-wave reduction, it cost 3-4 % — there
       // the compiler rotated the loop differently and filled the v_readlane wait states with s_nop instead of pointer arithmetic)
-      if (!PROFILE && i > 0 && far == prev && kd != 0u) fps_report_fault(host_faults);
+      // (kd == the bits of the INITIAL min-distance 1e10f: the point's distance was never lowered at all — an inf / NaN
+      //  coordinate, whose distance to itself is NaN; the reference repeats such a point silently, geometry_utils.py:88-101,
+      //  and so does this kernel: bad input, not a lost update — ADVICE r5)
+      if (!PROFILE && i > 0 && far == prev && kd != 0u && kd != CPFN_FPS_INIT_DIST_BITS) fps_report_fault(host_faults);
     }
     prev = far;
     if (NW == 1 && i > 0) { fx = s_x[far]; fy = s_y[far]; fz = s_z[far]; }
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void fps_shared_kernel(const float *__restrict
     // TRIPWIRE (see fps_resident_kernel): the point just sampled comes back with a positive distance
     if (__builtin_expect(nf == far, 0)) {
       asm volatile("; tripwire: rare path" ::: "memory");
-      if (wg == 0 && t == 0 && nd != 0u) fps_report_fault(host_faults);
+      if (wg == 0 && t == 0 && nd != 0u && nd != CPFN_FPS_INIT_DIST_BITS) fps_report_fault(host_faults);
     }
     far = nf;
   }
@@ -543,11 +548,20 @@ static int fps_shared_capacity(int dyn_lds) {
 // The fault count also lives in a pinned host word the kernel bumps with a system-scope atomic, so that it can be polled
 // without synchronising the device (round 3 read the device symbol: a hipMemcpyFromSymbol, i.e. a device synchronisation,
 // which nobody but a test ever paid for).
-static unsigned *fps_host_faults(unsigned **dev_ptr) {
+// All launcher-side state of this file (the host word, the LDS claims) sits behind ONE mutex: launches may come from several
+// host threads (the epoch loop's staging thread, evaluation beside training) — ADVICE r5.
+static std::mutex g_fps_mu;
+
+static unsigned *fps_host_faults(unsigned **dev_ptr) {      // (g_fps_mu held by the caller)
   static unsigned *host = nullptr, *dev = nullptr;
   static bool tried = false;
   if (!tried) {
     tried = true;
+    // The first launch may sit inside a stream capture (thread-local / global mode: allocations are refused there): the
+    // allocation is not a stream operation, so the capture mode is relaxed around it — the word then exists for EVERY launch and
+    // cpfn_fps_faults() never has to fall back to the synchronising read of the device symbol.
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
     void *h = nullptr, *d = nullptr;
     if (hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped) == hipSuccess && h &&
         hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
@@ -557,12 +571,13 @@ static unsigned *fps_host_faults(unsigned **dev_ptr) {
     } else {
       (void)hipGetLastError();
     }
+    if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
   }
   if (dev_ptr) *dev_ptr = dev;
   return host;
 }
 
-static bool g_fps_have_hf = false, g_fps_launched_without_hf = false;
+static bool g_fps_launched_without_hf = false;
 
 // Sampling faults since the library was loaded: clouds whose several-workgroups FPS gave up on a sibling + lost updates caught by
 // the tripwire.  Reads a pinned host word (no synchronisation; a fault shows up once its kernel has got that far).  Launches
@@ -570,9 +585,15 @@ static bool g_fps_have_hf = false, g_fps_launched_without_hf = false;
 // has happened — or without a host word at all — the device symbol is read as well (synchronises) and the larger count returned
 // (the freshly allocated host word, 0, used to hide such a graph's faults).
 extern "C" int cpfn_fps_faults(void) {
-  const unsigned *h = fps_host_faults(nullptr);
+  const unsigned *h;
+  bool without;
+  {
+    std::lock_guard<std::mutex> lk(g_fps_mu);
+    h = fps_host_faults(nullptr);
+    without = g_fps_launched_without_hf;
+  }
   unsigned host_n = h ? __atomic_load_n(h, __ATOMIC_RELAXED) : 0u;
-  if (h && !g_fps_launched_without_hf) return (int)host_n;
+  if (h && !without) return (int)host_n;
   unsigned n = 0;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fps_faults), sizeof(n)) != hipSuccess) return h ? (int)host_n : -1;
   return (int)(n > host_n ? n : host_n);
@@ -581,12 +602,19 @@ extern "C" int cpfn_fps_faults(void) {
 // The whole-LDS claim of a one-workgroup-per-cloud sampling kernel: dynamic padding up to the compute unit's 160 KB, so that no
 // LDS-using workgroup of another kernel can be resident beside it (-1: not available).  Asked once per kernel.
 static int fps_lds_claim(const void *kernel) {
-  static const void *seen[4] = {nullptr, nullptr, nullptr, nullptr};
-  static int pads[4] = {-1, -1, -1, -1};
+  constexpr int MAX_DEV = 16;
+  static const void *seen_[MAX_DEV][4] = {};
+  static int pads_[MAX_DEV][4];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) { (void)hipGetLastError(); return -1; }
+  std::lock_guard<std::mutex> lk(g_fps_mu);       // (a function attribute belongs to a device: the cache is per device ordinal)
+  const void **seen = seen_[dev];
+  int *pads = pads_[dev];
   for (int i = 0; i < 4; ++i) {
     if (seen[i] == kernel) return pads[i];
     if (!seen[i]) {
       seen[i] = kernel;
+      pads[i] = -1;
       hipFuncAttributes a;
       if (hipFuncGetAttributes(&a, kernel) == hipSuccess) {
         const int p = CPFN_LDS_BYTES_PER_CU - (int)a.sharedSizeBytes;
@@ -634,8 +662,10 @@ static int fps_launch(const float *xyz, int B, int N, int S, const int *start, i
   {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
-    if (g_fps_have_hf || cs == hipStreamCaptureStatusNone) { fps_host_faults(&hf); g_fps_have_hf = true; }
-    if (!hf) g_fps_launched_without_hf = true;
+    (void)cs;
+    std::lock_guard<std::mutex> lk(g_fps_mu);
+    fps_host_faults(&hf);                         // (allocates on first use, also inside a capture: see there)
+    if (!hf) g_fps_launched_without_hf = true;    // no host word on this stack at all: cpfn_fps_faults() reads the device symbol
   }
   const int dd = g_fps_dbg_drop;
   // (beside a training step — cpfn_background_geometry() — the instantiations without packed fp32: see fps_update)

@@ -655,9 +655,12 @@ class _FusedStack(torch.autograd.Function):
                                                 _ptr(xt), _ptr(ws_x), _stream()),
                            "cpfn_mlp_bwd_fused")
                     # g_y (or, folded in: g / the pooled g + y), the input, W, the split partials, the data gradient
+                    # (a buffer counts ONCE per launch: for a hidden layer the pre-BN output of the layer below, which the riding
+                    #  reduction reads, IS this layer's input — the second read hits L2 and is not compulsory traffic)
                     gy_bytes = (2 * P * N + 5 * P * N // pool_k) if fold_pool else (4 * P * N if fold_apply else 2 * P * N)
+                    yp_bytes = 0 if (not below or Yp.data_ptr() == a_in.data_ptr()) else 2 * P * Kp
                     _l.add_bytes("cpfn_mlp_bwd_fused", gy_bytes + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
-                                 + ((2 * P * Kp + 8 * splits * Kp) if below else 0) + ((12 * P + 12 * splits * N) if xt is not None else 0))
+                                 + yp_bytes + (8 * splits * Kp if below else 0) + ((12 * P + 12 * splits * N) if xt is not None else 0))
                     if below:
                         fused_part = (fp_, splits)
                 elif (SMALL_BWD_MERGED and SMALL_BWD_FUSED and route in ("small", "generic") and need_dgrad and Gy is not None and
@@ -671,8 +674,11 @@ class _FusedStack(torch.autograd.Function):
                     _check(h.cpfn_mlp_bwd_small(_ptr(Gy), N, _ptr(a_in), a_in.stride(0), _ptr(Wb), P, N, Kp, asc, ash, _ptr(ws),
                                                 _ptr(g_new), Kp, _ptr(Yp), _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_), _stream()),
                            "cpfn_mlp_bwd_small")
-                    _l.add_bytes("cpfn_mlp_bwd_small", 4 * P * N + 2 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp + 2 * P * Kp
-                                 + ((2 * P * Kp + 8 * nb_ * Kp) if below_ok else 0))
+                    # g_y (read by both halves of the merged launch: counted once), the input, W, the split partials, the data gradient
+                    # (+ the layer below's pre-BN output only where it is not the input itself)
+                    yp_bytes = 0 if (not below_ok or Yp.data_ptr() == a_in.data_ptr()) else 2 * P * Kp
+                    _l.add_bytes("cpfn_mlp_bwd_small", 2 * P * N + 2 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp + 2 * P * Kp
+                                 + yp_bytes + (8 * nb_ * Kp if below_ok else 0))
                     if below_ok:
                         fused_part = (fp_, nb_)
                 else:

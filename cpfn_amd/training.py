@@ -308,21 +308,33 @@ class SPFNTrainer:
         self.fault_word(dev).fill_(1.0)
         self._fault_raised = str(reason)
 
+    @staticmethod
+    def _abort_group():
+        abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+        try:
+            if abort is not None:
+                abort()
+        except Exception:
+            pass
+
+    def _raise_reduced_fault(self, abort_as_peer=False):
+        """The reduced fault slot was non-zero: this rank's own word (the process group goes down where torch can) or a peer's.
+        abort_as_peer: a peer also takes the group down first — the replayed path, where this rank may already have queued later
+        steps whose in-graph collective would wait for the partner that has stopped."""
+        if getattr(self, "_fault_raised", None) is not None:
+            self._abort_group()
+            raise RuntimeError("cpfn_amd: this rank raised its fault word (%s); every rank skipped the optimizer step" % self._fault_raised)
+        if abort_as_peer:
+            self._abort_group()
+        raise RuntimeError("cpfn_amd: a PEER rank raised its fault word; every rank skipped the optimizer step (this rank's "
+                           "replica is intact: restart from it)")
+
     def _after_exchange_fault_check(self):
         """Host side of the fault word on the paths that read the device anyway (eager launches): after the exchange the
         bucket's fault slot is the ranks' mean."""
         if float(self.bucket.fault_slot) == 0.0:
             return
-        if getattr(self, "_fault_raised", None) is not None:
-            abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
-            try:
-                if abort is not None:
-                    abort()
-            except Exception:
-                pass
-            raise RuntimeError("cpfn_amd: this rank raised its fault word (%s); every rank skipped the optimizer step" % self._fault_raised)
-        raise RuntimeError("cpfn_amd: a PEER rank raised its fault word; every rank skipped the optimizer step (this rank's "
-                           "replica is intact: restart from it)")
+        self._raise_reduced_fault()
 
     def _schedules(self):
         m = get_batch_norm_decay(self.global_step, self.batch_size, self.bn_decay_step)
@@ -710,6 +722,7 @@ class SPFNTrainer:
             st["flag_err"] = torch.zeros(4, dtype=torch.int32).pin_memory()
             st["flag_fault"] = self.fault_word(dev)            # (the rank's one fault word: raise_fault() sets the same tensor)
             st["flag_timeout"] = _flag_timeout_ticks(world)
+            st["fault_host"] = torch.zeros(1, dtype=torch.float32).pin_memory()      # the reduced fault slot of the last step (world > 1)
             st["n_main"], st["n_side"] = 0, 0
             with torch.cuda.graph(g, pool=g0.pool(), stream=self._gstream, capture_error_mode="thread_local"):
                 if stamps is not None:
@@ -731,6 +744,8 @@ class SPFNTrainer:
                     # (the fault word every rank packed into the bucket's fault slot came back averaged: non-zero on EVERY rank
                     #  when any rank's flag wait timed out — all replicas skip together)
                     self._checked_optimizer_step(st["skipped"], fault=self.bucket.fault_slot.reshape(()))
+                    # ... and lands in a pinned host word every rank polls at the head of its next steps (one 4-byte copy node)
+                    st["fault_host"].copy_(self.bucket.fault_slot, non_blocking=True)
                 st["out"] = tuple(o.detach() for o in out)
                 stamp(2)
                 stamp(3)
@@ -830,11 +845,23 @@ class SPFNTrainer:
                                "stream's graph was never launched, or it stalled for longer than CPFN_FLAG_TIMEOUT_S); the "
                                "optimizer has skipped every step since, the losses of the last steps are invalid"
                                % (st["flag_timeout"] / 100e6))
+        if single and st["world"] > 1 and float(st["fault_host"][0]) != 0.0:
+            # the REDUCED fault slot of an earlier replayed step (copied to this pinned word by the step itself, right behind the
+            # exchange): some rank raised its fault word, every replica skipped that step — and every rank stops here, the peers
+            # too, instead of replaying into a collective whose partner is gone
+            self._raise_reduced_fault(abort_as_peer=True)
         if (self.global_step & 63) == 0:
             # the sampling kernels' fault count (a pinned host word: no synchronisation): the several-workgroups time-out and the
             # tripwire — a sample whose own min-distance was not zeroed, i.e. a lost update beside this very step (VERDICT r4 #1a)
             from . import ops as _ops
-            _ops.check_fps_faults("training step %d" % self.global_step)
+            try:
+                _ops.check_fps_faults("training step %d" % self.global_step)
+            except RuntimeError as e:
+                if not (single and st["world"] > 1):
+                    raise
+                # data parallel: leaving the loop here would strand the peers in this step's collective — the fault rides on the
+                # rank's fault word instead: the step runs, EVERY rank skips its update, then this rank (and its peers) raise
+                self.raise_fault("sampling fault: %s" % e)
         if single and st["side_pending"]:
             # the side graph of the previous step (reads P_next / the FPS seeds, writes geomB) must be done before
             # this step overwrites its inputs and reads its result
@@ -915,9 +942,11 @@ class SPFNTrainer:
             if st["world"] > 1 and not st["exchange_in_graph"]:
                 self._exchange_with_stamps(batch["P"].device)
                 self._checked_optimizer_step(st["skipped"], fault=self.bucket.fault_slot.reshape(()))
+                st["fault_host"].copy_(self.bucket.fault_slot, non_blocking=True)
             self.global_step += 1
             if st["world"] > 1 and getattr(self, "_fault_raised", None) is not None:
-                # raise_fault(): the replay just issued carries the word through the collective (every rank skips); now stop
+                # raise_fault(): the replay just issued carries the word through the collective (every rank skips); now stop.
+                # (The peers see the same reduced slot in their pinned word at the head of one of their next steps.)
                 torch.cuda.current_stream(batch["P"].device).synchronize()
                 self._after_exchange_fault_check()
             return st["out"]

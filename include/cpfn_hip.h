@@ -75,7 +75,11 @@ CPFN_API int cpfn_fps_max_resident(void);
  * returned the point just sampled with a positive distance — i.e. a lost update on the lane that owns the sample (round 4's
  * packed-fp32 fault beside a weight-gradient workgroup).  Detection only: the indices of such a launch are NOT those of
  * modules/geometry_utils.py:88-101 any more (the point repeats); the count says that the hardware / a neighbour misbehaved.
- * Reads a pinned host word (no synchronisation); the device counter too once a launch had to go without that word. */
+ * A point with an inf / NaN coordinate is NOT counted (its min-distance is never lowered from the initial 1e10 and the point
+ * repeats, exactly as in the reference's loop): bad input, not a fault.
+ * Reads a pinned host word (no synchronisation).  The word is allocated by the first sampling launch — also inside a stream
+ * capture (the capture mode is relaxed around the allocation); only on a stack where it cannot be allocated at all does this
+ * call fall back to reading the device counter, which SYNCHRONISES the device and must not be used while a capture is open. */
 CPFN_API int cpfn_fps_faults(void);
 /* Test hook for the tripwire: in every sampling launch issued from now on the wave that owns sample `sample` (0-based) skips its
  * distance update once (-1: off).  Returns the previous setting. */

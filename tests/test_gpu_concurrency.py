@@ -402,6 +402,33 @@ def test_tripwire_counts_a_dropped_update(B, N, S, beside):
         _consume_faults(ops)
 
 
+@pytest.mark.parametrize("N,S,beside,bad", [(2048, 64, False, float("inf")), (2048, 64, True, float("nan")),
+                                           (8192, 64, False, float("nan")), (8192, 64, True, float("-inf")),
+                                           (40000, 32, False, float("inf"))])
+def test_non_finite_input_is_not_a_fault(N, S, beside, bad):
+    """a point with an inf / NaN coordinate has distance NaN to itself, `dist < distance` never holds for it, its
+    min-distance stays at the initial 1e10 and the reference's loop (modules/geometry_utils.py:94-100) samples it again and again.
+    The kernels do exactly that — same indices as the oracle — and the tripwire must NOT call it a lost update."""
+    import contextlib
+    from cpfn_amd import ops
+    from oracle import geometry as og
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + S)
+    xyz = (torch.rand(2, N, 3, generator=g) * 2 - 1)
+    xyz[0, 5, 1] = bad
+    xyz[1, N - 3, 2] = bad
+    start = torch.tensor([11, 7], dtype=torch.int32)
+    want = og.farthest_point_sample(xyz.numpy(), S, start.numpy()).astype(np.int32)
+    assert (want[0, 1:] == 5).all() and (want[1, 1:] == N - 3).all()          # (the oracle repeats the bad point from sample 1 on)
+    torch.cuda.synchronize()
+    n0 = ops.fps_faults()
+    with (ops.background_geometry() if beside else contextlib.nullcontext()):
+        got = ops.fps(xyz.to(dev), S, start.to(dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert ops.fps_faults() == n0, "bad input was counted as a sampling fault"
+
+
 def test_tripwire_beside_the_weight_gradient_kernel():
     """VERDICT r4 #1 "Done": the packed 8192-point shape WITHOUT its guard (CPFN_FPS_BESIDE_MODE=2: no LDS claim) beside mlp_wgrad —
     on a box that has round 4's fault the indices differ from the quiet run's AND the tripwire has counted (it sees the events whose
