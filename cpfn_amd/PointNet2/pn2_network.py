@@ -120,7 +120,9 @@ class PointNet2(torch.nn.Module):
                             getattr(self.sa1, "compute_dtype", torch.float32) == torch.bfloat16)
             fused_mlp.refresh_weight_panels(self.parameters(), defer=first_is_xyz)
         try:
-            with fused_mlp.deferred_bn_counters():
+            # (seam_pass: the accumulators of this pass's BatchNorm seams — statistics that reach their consumer without a finalize
+            #  launch, csrc/seam.h — are zeroed by ONE fill up front)
+            with fused_mlp.deferred_bn_counters(), fused_mlp.seam_pass(x.device, bf16 and self.training):
                 return self._forward(x, glob_features, loc_features, fps_start, geometry, bool(_co.CUDA_ROUTE and fast))
         finally:
             fused_mlp.flush_pending_cast()       # (never leave a refresh queued behind an exception or an unusual model)

@@ -1,6 +1,7 @@
 // BatchNorm passes of the per-point MLP stacks (finalize, normalise + ReLU (+ max-pool), backward passes), the fixed-order
 // split reductions, the fp32 small-K first layer of sa1 and the column sums of the heads.  See mlp_fwd.hip for the data layout.
 #include "mlp_common.h"
+#include "seam.h"
 
 namespace {
 
@@ -604,9 +605,11 @@ __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_ride_kernel(const float 
 constexpr int KS_MAX = 4;
 template <int KS>
 __device__ __forceinline__ void smallk_fwd_body(int bx, const float *__restrict__ X, const float *__restrict__ W, long long P, int C,
-                                                unsigned short *__restrict__ Y, float *__restrict__ partial, int rpb) {
+                                                unsigned short *__restrict__ Y, float *__restrict__ partial, int rpb,
+                                                const SeamOut &so = SeamOut()) {
   __shared__ float s_red[2][256][8 + 1];
   const int t = threadIdx.x;
+  if (so.acc && bx == 0 && t == 0) seam_counters(so);
   const int nch = C / 8, rsub = 256 / nch;  // C <= 2048, power of two
   const int ch = t % nch, rs = t / nch, c0 = ch * 8;
   const long long row0 = (long long)bx * rpb;
@@ -654,15 +657,16 @@ __device__ __forceinline__ void smallk_fwd_body(int bx, const float *__restrict_
     const int which = o / (8 * nch), rem = o - which * 8 * nch, chn = rem >> 3, j = rem & 7;
     float s = 0.f;
     for (int r = 0; r < rsub; ++r) s += s_red[which][r * nch + chn][j];
-    partial[((size_t)bx * 2 + which) * C + rem] = s;
+    if (so.acc) seam_add(so, C, which, rem, s, (unsigned)bx);          // (no finalize launch behind this layer: seam.h)
+    else partial[((size_t)bx * 2 + which) * C + rem] = s;
   }
 }
 template <int KS>
 __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict__ X,
                                                          const float *__restrict__ W, long long P, int C,
                                                          unsigned short *__restrict__ Y,
-                                                         float *__restrict__ partial, int rpb) {
-  smallk_fwd_body<KS>((int)blockIdx.x, X, W, P, C, Y, partial, rpb);
+                                                         float *__restrict__ partial, int rpb, const SeamOut so = SeamOut()) {
+  smallk_fwd_body<KS>((int)blockIdx.x, X, W, P, C, Y, partial, rpb, so);
 }
 // The same launch with the step's bf16 weight-panel refresh (cpfn_multi_cast) as its first workgroups: sa1's first layer reads
 // the fp32 weight itself, so the two are independent — and both sit at the very start of the step's chain, where the refresh
@@ -671,9 +675,10 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float *__restrict
 template <int KS>
 __global__ __launch_bounds__(256) void smallk_fwd_cast_kernel(McvArgs cast, int cast_blocks, const float *__restrict__ X,
                                                               const float *__restrict__ W, long long P, int C,
-                                                              unsigned short *__restrict__ Y, float *__restrict__ partial, int rpb) {
+                                                              unsigned short *__restrict__ Y, float *__restrict__ partial, int rpb,
+                                                              const SeamOut so = SeamOut()) {
   if ((int)blockIdx.x < cast_blocks) multi_cast_body<256>(cast, (int)blockIdx.x);
-  else smallk_fwd_body<KS>((int)blockIdx.x - cast_blocks, X, W, P, C, Y, partial, rpb);
+  else smallk_fwd_body<KS>((int)blockIdx.x - cast_blocks, X, W, P, C, Y, partial, rpb, so);
 }
 
 // dW[c,j] = Σ_p Gy[p,c]·X[p,j]: partial[gridDim.x][C][KS]
@@ -917,10 +922,10 @@ extern "C" int cpfn_bn_pool_bwd_apply(const void *Gp, const unsigned char *arg, 
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_smallk_fwd_cast(const cpfn_cast_desc *casts, int n_casts, const float *X, int KS, const float *W, long long P,
-                                    int C, void *Y, float *partial, void *stream) {
-  if (P <= 0 || KS != 3 || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || !partial || n_casts <= 0 ||
-      n_casts > MCV_MAX || !casts)
+static int smallk_fwd_cast_launch(const cpfn_cast_desc *casts, int n_casts, const float *X, int KS, const float *W, long long P,
+                                  int C, void *Y, float *partial, const cpfn_seam_out *seam_out, void *stream) {
+  if (P <= 0 || KS != 3 || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || (!partial == !seam_out) || n_casts <= 0 ||
+      n_casts > MCV_MAX || !casts || !seam_out_valid(seam_out))
     return CPFN_EINVAL;
   McvArgs a;
   int cast_blocks = 0;
@@ -928,24 +933,41 @@ extern "C" int cpfn_smallk_fwd_cast(const cpfn_cast_desc *casts, int n_casts, co
   if (rc) return rc;
   const int nblk = cpfn_bn_bwd_blocks(P), rpb = bn_rows_per_block(P);
   smallk_fwd_cast_kernel<3><<<cast_blocks + nblk, 256, 0, (hipStream_t)stream>>>(a, cast_blocks, X, W, P, C, (unsigned short *)Y,
-                                                                                 partial, rpb);
+                                                                                 partial, rpb, seam_out_arg(seam_out));
   return cpfn_launch_status();
 }
+extern "C" int cpfn_smallk_fwd_cast(const cpfn_cast_desc *casts, int n_casts, const float *X, int KS, const float *W, long long P,
+                                    int C, void *Y, float *partial, void *stream) {
+  return smallk_fwd_cast_launch(casts, n_casts, X, KS, W, P, C, Y, partial, nullptr, stream);
+}
 
-extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P, int C, void *Y, float *partial,
-                               void *stream) {
-  if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || !partial)
+static int smallk_fwd_launch(const float *X, int KS, const float *W, long long P, int C, void *Y, float *partial,
+                             const cpfn_seam_out *seam_out, void *stream) {
+  if (P <= 0 || KS <= 0 || KS > KS_MAX || C <= 0 || (C & 7) || !pow2(C / 8) || C / 8 > 256 || !X || !W || !Y || (!partial == !seam_out) ||
+      !seam_out_valid(seam_out))
     return CPFN_EINVAL;
   const int nblk = cpfn_bn_bwd_blocks(P), rpb = bn_rows_per_block(P);
   hipStream_t st = (hipStream_t)stream;
   unsigned short *y = (unsigned short *)Y;
+  const SeamOut so = seam_out_arg(seam_out);
   switch (KS) {
-    case 1: smallk_fwd_kernel<1><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
-    case 2: smallk_fwd_kernel<2><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
-    case 3: smallk_fwd_kernel<3><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
-    default: smallk_fwd_kernel<4><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb); break;
+    case 1: smallk_fwd_kernel<1><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb, so); break;
+    case 2: smallk_fwd_kernel<2><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb, so); break;
+    case 3: smallk_fwd_kernel<3><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb, so); break;
+    default: smallk_fwd_kernel<4><<<nblk, 256, 0, st>>>(X, W, P, C, y, partial, rpb, so); break;
   }
   return cpfn_launch_status();
+}
+extern "C" int cpfn_smallk_fwd(const float *X, int KS, const float *W, long long P, int C, void *Y, float *partial,
+                               void *stream) {
+  return smallk_fwd_launch(X, KS, W, P, C, Y, partial, nullptr, stream);
+}
+// the same layer as the PRODUCER of a BatchNorm seam (seam.h): casts == NULL: plain launch; else the panel refresh rides (KS = 3)
+extern "C" int cpfn_smallk_fwd_seam(const cpfn_cast_desc *casts, int n_casts, const float *X, int KS, const float *W, long long P,
+                                    int C, void *Y, const cpfn_seam_out *out, void *stream) {
+  if (!out) return CPFN_EINVAL;
+  if (casts) return smallk_fwd_cast_launch(casts, n_casts, X, KS, W, P, C, Y, nullptr, out, stream);
+  return smallk_fwd_launch(X, KS, W, P, C, Y, nullptr, out, stream);
 }
 
 static int smallk_wgrad_launch(const void *Gy, const float *X, int KS, long long P, int C, float *workspace, float *dW,

@@ -220,6 +220,6 @@ constexpr int WG_DEPTH = 4;       // steps in flight
 
 int cpfn_smallp_gemm_launch(const unsigned short *a, int lda, const unsigned short *w, int w_trans, long long P, int K, int N,
                             unsigned short *y, int ldy, float *stats_partial, const float *a_scale, const float *a_shift, int gx,
-                            hipStream_t st);
+                            hipStream_t st, const cpfn_seam_out *seam_out = nullptr, const cpfn_seam_in *seam_in = nullptr);
 // out[i] = sum over splits of ws[s][i], fixed order (split_reduce_kernel, bn.hip)
 void cpfn_launch_split_reduce(const float *ws, int splits, long long n, float *out, hipStream_t st);

@@ -18,6 +18,7 @@
 //
 // This file: the forward / data-gradient GEMM kernels of the large layers (streaming kernel, generic kernel) and cpfn_mlp_gemm.
 #include "mlp_common.h"
+#include "seam.h"
 
 GemmProbeState g_probe_state;
 
@@ -223,7 +224,9 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
     const float *__restrict__ a_scale = nullptr, const float *__restrict__ a_shift = nullptr,
     const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */, unsigned long long *probe = nullptr,
-    const float *__restrict__ xyz = nullptr /* XT: [P,3] */, const float *__restrict__ wx = nullptr /* XT: [N,3] fp32 */) {
+    const float *__restrict__ xyz = nullptr /* XT: [P,3] */, const float *__restrict__ wx = nullptr /* XT: [N,3] fp32 */,
+    const SeamOut so = SeamOut() /* STATS: the sums leave as fixed-point atomics instead of partial rows */,
+    const SeamIn si = SeamIn() /* ATR: scale / shift folded from the previous layer's sums (seam.h) */) {
   constexpr int NT = BN / 16, K = 32 * KS, CPR = BN / 8;
   const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
@@ -233,9 +236,10 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = blockIdx.y * BN;
-  if (ATR) {   // visible after the W-panel barrier
+  if (ATR && !si.acc) {   // visible after the W-panel barrier
     for (int e = t; e < K; e += G_THREADS) { s_ss[e] = a_scale[e]; s_ss[K + e] = a_shift[e]; }
   }
+  if (STATS && so.acc && t == 0 && blockIdx.x == 0 && blockIdx.y == 0) seam_counters(so);
   __shared__ __attribute__((aligned(16))) float s_bs[BST ? 2 * BN : 4];
   __shared__ __attribute__((aligned(16))) unsigned short s_wx[XT ? BN * 16 : 8];
   float xz[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
@@ -274,6 +278,11 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   const int tile_end = min(tile0 + tiles_per_wg, ntiles);
   if (tile0 < tile_end) {
     bf16x8 a[2][KS];
+    // (a seam's accumulator words are requested FIRST — K <= 128: one channel per lane of the first two waves — then this
+    //  workgroup's first rows and the weight panel; the fold's arithmetic runs behind the panel fill, when all of it has arrived)
+    SeamFoldRegs fq;
+    const bool folds = ATR && si.acc && t < K;
+    if (folds) seam_fold_issue(si, t, fq);
     stream_load_a<KS>(a, sb.a, sb.aoff, (unsigned)tile0 * sb.a_tile);
     if (XT) {
       const int p0 = tile0 * G_ROWS + wave * 32 + lr, pa = min(p0, P - 1), pb = min(p0 + 16, P - 1);
@@ -281,6 +290,11 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
       for (int q = 0; q < 3; ++q) { xz[0][q] = xyz[(size_t)pa * 3 + q]; xz[1][q] = xyz[(size_t)pb * 3 + q]; }
     }
     fill_w_panel<BN, 32 * KS + 8>(s_w, W, K, N, n0, 0, K, w_trans, t);
+    if (folds) {
+      float sc, sh;
+      seam_fold_finish(si, t, blockIdx.x == 0 && blockIdx.y == 0, fq, sc, sh);
+      s_ss[t] = sc; s_ss[K + t] = sh;
+    }
     __syncthreads();
     // TWO operand buffers for the operand-transform instantiations (every hidden layer's forward launch; round 4): with one,
     // the rows of tile t + 1 are requested after the MFMAs of tile t and have its epilogue (~1.5 us) to arrive — less than a
@@ -323,7 +337,8 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     for (int e = t; e < 2 * BN; e += G_THREADS) {
       const int which = e / BN, c = e - which * BN;
       const float s = s_red[0][which][c] + s_red[1][which][c] + s_red[2][which][c] + s_red[3][which][c];
-      stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c] = s;
+      if (STATS && so.acc) seam_add(so, N, which, n0 + c, s, blockIdx.x);
+      else stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + c] = s;
     }
   }
   probe_end(probe, probe_t0);
@@ -700,9 +715,11 @@ extern "C" int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void
 extern "C" int cpfn_mlp_gemm_xyz_ok(long long P, int K, int N) {
   return K == 128 && N == 128 && P >= 32768 && gemm_stream_k(P, K) && (P + G_ROWS) * 128LL * 2 < (1LL << 32);
 }
-extern "C" int cpfn_mlp_gemm_xyz(const void *A, int lda, const void *W, const float *xyz, const float *Wx, long long P, int K,
-                                 int N, void *Y, int ldy, float *stats_partial, void *stream) {
-  if (!cpfn_mlp_gemm_xyz_ok(P, K, N) || !A || !W || !xyz || !Wx || !Y || lda != K || ldy != N) return CPFN_EINVAL;
+static int gemm_xyz_launch(const void *A, int lda, const void *W, const float *xyz, const float *Wx, long long P, int K,
+                           int N, void *Y, int ldy, float *stats_partial, const cpfn_seam_out *seam_out, void *stream) {
+  if (!cpfn_mlp_gemm_xyz_ok(P, K, N) || !A || !W || !xyz || !Wx || !Y || lda != K || ldy != N || !seam_out_valid(seam_out) ||
+      (seam_out && stats_partial))
+    return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int gx = cpfn_mlp_gemm_blocks(P, N);
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
@@ -710,9 +727,77 @@ extern "C" int cpfn_mlp_gemm_xyz(const void *A, int lda, const void *W, const fl
   const dim3 grid(gx, N / 128);
   const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
   unsigned short *y = (unsigned short *)Y;
-  if (stats_partial)
-    mlp_gemm_stream_kernel<128, 4, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, stats_partial, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx);
+  if (stats_partial || seam_out)
+    mlp_gemm_stream_kernel<128, 4, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, stats_partial, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx, seam_out_arg(seam_out));
   else
     mlp_gemm_stream_kernel<128, 4, false, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, nullptr, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx);
+  return cpfn_launch_status();
+}
+extern "C" int cpfn_mlp_gemm_xyz(const void *A, int lda, const void *W, const float *xyz, const float *Wx, long long P, int K,
+                                 int N, void *Y, int ldy, float *stats_partial, void *stream) {
+  return gemm_xyz_launch(A, lda, W, xyz, Wx, P, K, N, Y, ldy, stats_partial, nullptr, stream);
+}
+extern "C" int cpfn_mlp_gemm_xyz_seam(const void *A, const void *W, const float *xyz, const float *Wx, long long P, int K, int N,
+                                      void *Y, const cpfn_seam_out *out, void *stream) {
+  if (!out) return CPFN_EINVAL;
+  return gemm_xyz_launch(A, K, W, xyz, Wx, P, K, N, Y, N, nullptr, out, stream);
+}
+
+// ---- forward layers with their BatchNorm seams spelled out (seam.h) -------------------------------------------------------
+extern "C" int cpfn_seam_words(int replicas, int C) {
+  return replicas >= 1 && replicas <= 8 && C > 0 ? replicas * 2 * C + 2 : -1;      // sums + the poison word (+ one of padding)
+}
+
+// which of cpfn_mlp_gemm's kernels a forward layer (bf16 rows, lda = K, ldy = N, no gather / bias) takes: 1 small-P, 2 streaming, 0 other
+static int gemm_fwd_route(long long P, int K, int N, bool transform) {
+  if (P <= 0 || K <= 0 || (K & 31) || N <= 0 || (N & 63) || P > 2000000000LL) return 0;
+  if (P <= SP_MAX_ROWS && (N & 3) == 0 && (!transform || K <= SP_SS_MAX) && P * K * 2 < (1LL << 31) && (long long)N * K * 2 < (1LL << 31))
+    return 1;
+  if (gemm_stream_k(P, K) && (K & 7) == 0 && (!transform || K <= 128) && (P + G_ROWS) * (long long)(K > N ? K : N) * 2 < (1LL << 32))
+    return 2;
+  return 0;
+}
+
+extern "C" int cpfn_mlp_gemm_seam_ok(long long P, int K, int N) {
+  return (gemm_fwd_route(P, K, N, false) ? 1 : 0) | (gemm_fwd_route(P, K, N, true) ? 2 : 0);
+}
+
+extern "C" int cpfn_mlp_gemm_seam(const void *A, const void *W, long long P, int K, int N, void *Y, float *stats_partial,
+                                  const cpfn_seam_out *out, const cpfn_seam_in *in, const float *a_scale, const float *a_shift,
+                                  void *stream) {
+  if (!A || !W || !Y || (!stats_partial == !out) || (!a_scale != !a_shift) || (in && a_scale) || !seam_out_valid(out) ||
+      !seam_in_valid(in, K))
+    return CPFN_EINVAL;
+  const bool transform = in || a_scale;
+  const int route = gemm_fwd_route(P, K, N, transform);
+  if (!route) return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = cpfn_mlp_gemm_blocks(P, N);
+  const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
+  unsigned short *y = (unsigned short *)Y;
+  if (route == 1) {
+    if (in && in->replicas > 4) return CPFN_EINVAL;       // (the small-P kernel holds at most four replicas' words per lane)
+    return cpfn_smallp_gemm_launch(a, K, w, 0, P, K, N, y, N, stats_partial, a_scale, a_shift, gx, st, out, in);
+  }
+  const long long tiles = (P + G_ROWS - 1) / G_ROWS;
+  const int tpw = (int)((tiles + gx - 1) / gx);
+  const SeamOut so = seam_out_arg(out);
+  const SeamIn si = seam_in_arg(in);
+#define CPFN_STREAM_SEAM(BN_, KS_)                                                                                     \
+  do {                                                                                                                 \
+    dim3 grid(gx, N / BN_);                                                                                            \
+    if (transform)                                                                                                     \
+      mlp_gemm_stream_kernel<BN_, (KS_ <= 4 ? KS_ : 4), true, true><<<grid, G_THREADS, 0, st>>>(a, K, w, 0, (int)P, N, y, N, stats_partial, tpw, a_scale, a_shift, nullptr, probe_slot(grid), nullptr, nullptr, so, si); \
+    else                                                                                                               \
+      mlp_gemm_stream_kernel<BN_, KS_, true><<<grid, G_THREADS, 0, st>>>(a, K, w, 0, (int)P, N, y, N, stats_partial, tpw, nullptr, nullptr, nullptr, probe_slot(grid), nullptr, nullptr, so, si); \
+  } while (0)
+  if (N % 128 == 0) {
+    switch (K) { case 64: CPFN_STREAM_SEAM(128, 2); break; case 128: CPFN_STREAM_SEAM(128, 4); break;
+                 case 192: CPFN_STREAM_SEAM(128, 6); break; default: CPFN_STREAM_SEAM(128, 8); }
+  } else {
+    switch (K) { case 64: CPFN_STREAM_SEAM(64, 2); break; case 128: CPFN_STREAM_SEAM(64, 4); break;
+                 case 192: CPFN_STREAM_SEAM(64, 6); break; default: CPFN_STREAM_SEAM(64, 8); }
+  }
+#undef CPFN_STREAM_SEAM
   return cpfn_launch_status();
 }

@@ -1,6 +1,7 @@
 // Per-point MLP stacks, small layers (P <= 16384 rows: sa3, sfp1, sfp2) and the stand-alone weight gradient: the split-K
 // small-P GEMM, mlp_wgrad_kernel, and the two of them as ONE launch (mlp_bwd_small_kernel).  See mlp_fwd.hip for the data layout.
 #include "mlp_common.h"
+#include "seam.h"
 
 namespace {
 
@@ -44,7 +45,8 @@ __device__ __forceinline__ void mlp_gemm_smallp_body(
     SmallpLds<RT> &lds, int bx, int by,
     const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
     int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
-    const float *__restrict__ a_scale, const float *__restrict__ a_shift, const SmallpBwdArgs &bw) {
+    const float *__restrict__ a_scale, const float *__restrict__ a_shift, const SmallpBwdArgs &bw,
+    const SeamOut &so = SeamOut(), const SeamIn &si = SeamIn()) {
   constexpr int TT = RT / 16, D = SP_DEPTH, LDT = 64 + 8;
   static_assert(!(STATS && BST) && (!BST || WT), "the riding reduction belongs to the data gradient");
   unsigned char *s_raw = lds.raw;
@@ -52,10 +54,19 @@ __device__ __forceinline__ void mlp_gemm_smallp_body(
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int n0 = by * 64, row0 = bx * RT;
-  if (a_scale) {
+  const bool transform = a_scale || si.acc;
+  // scale / shift of the previous layer: read, or FOLDED from that layer's sums (seam.h: no finalize launch in between) — the
+  // accumulator words are requested here, the arithmetic runs behind the first operand requests (K <= 512: two channels per lane)
+  // (replicas <= 4 on this route — cpfn_mlp_gemm_seam checks — so the words held across the first requests cost 20 registers;
+  //  a second channel per lane, K > 256, is folded in one piece behind them)
+  SeamFoldRegsT<4> fq;
+  if (si.acc) {
+    if (t < K) seam_fold_issue(si, t, fq);
+  } else if (a_scale) {
     for (int e = t; e < K; e += 256) { s_ss[0][e] = a_scale[e]; s_ss[1][e] = a_shift[e]; }
     __syncthreads();
   }
+  if (STATS && so.acc && t == 0 && bx == 0 && by == 0) seam_counters(so);
   const int S = K / 32;
   // Buffer loads (SGPR base + 32-bit lane offset, hardware bounds check): a pipeline slot past the end of K gets an
   // out-of-range offset, which returns zeros WITHOUT touching memory — the loop body stays straight-line (counted
@@ -95,6 +106,16 @@ __device__ __forceinline__ void mlp_gemm_smallp_body(
     for (int tt = 0; tt < TT; ++tt) acc[i][tt] = (f32x4){0, 0, 0, 0};
 #pragma unroll
   for (int d = 0; d < D; ++d) issue(d, wave + 4 * d);
+  if (si.acc) {
+    float sc, sh;
+    if (t < K) { seam_fold_finish(si, t, bx == 0 && by == 0, fq, sc, sh); s_ss[0][t] = sc; s_ss[1][t] = sh; }
+    if (t + 256 < K) {
+      seam_fold_issue(si, t + 256, fq);
+      seam_fold_finish(si, t + 256, bx == 0 && by == 0, fq, sc, sh);
+      s_ss[0][t + 256] = sc; s_ss[1][t + 256] = sh;
+    }
+    __syncthreads();
+  }
   const int cnt = (S + 3) / 4;
   // (one instantiation of the stage body per pipeline slot: the slot index must be a compile-time constant so that
   //  ra / rw stay in registers)
@@ -119,7 +140,7 @@ __device__ __forceinline__ void mlp_gemm_smallp_body(
 #pragma unroll
           for (int i = 0; i < 4; ++i) wf[i] = __builtin_bit_cast(bf16x8, rw[d][i]);
         }
-        if (a_scale) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
+        if (transform) {   // BatchNorm + ReLU of the previous layer applied to the operand on the fly
           float sc[8], sh[8];
           const int k0 = s * 32 + 8 * lq;
           *(cpfn_f32x4 *)&sc[0] = *(const cpfn_f32x4 *)&s_ss[0][k0]; *(cpfn_f32x4 *)&sc[4] = *(const cpfn_f32x4 *)&s_ss[0][k0 + 4];
@@ -179,8 +200,13 @@ __device__ __forceinline__ void mlp_gemm_smallp_body(
 #pragma unroll
     for (int r = 0; r < 4; ++r) { sm[r] = row16_sum(sm[r]); sq[r] = row16_sum(sq[r]); }
     if (lr == 0) {
-      *(f32x4 *)&stats_partial[((size_t)bx * 2 + 0) * N + n] = sm;
-      *(f32x4 *)&stats_partial[((size_t)bx * 2 + 1) * N + n] = sq;
+      if (STATS && so.acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { seam_add(so, N, 0, n + r, sm[r], (unsigned)bx); seam_add(so, N, 1, n + r, sq[r], (unsigned)bx); }
+      } else {
+        *(f32x4 *)&stats_partial[((size_t)bx * 2 + 0) * N + n] = sm;
+        *(f32x4 *)&stats_partial[((size_t)bx * 2 + 1) * N + n] = sq;
+      }
     }
   }
 }
@@ -190,11 +216,11 @@ __global__ __launch_bounds__(256) void mlp_gemm_smallp_kernel(
     const unsigned short *__restrict__ A, int lda, int a_bytes, const unsigned short *__restrict__ W,
     int P, int K, int N, unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial,
     const float *__restrict__ a_scale, const float *__restrict__ a_shift, unsigned long long *probe,
-    const SmallpBwdArgs bw = SmallpBwdArgs()) {
+    const SmallpBwdArgs bw = SmallpBwdArgs(), const SeamOut so = SeamOut(), const SeamIn si = SeamIn()) {
   const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ SmallpLds<RT> lds;
   mlp_gemm_smallp_body<RT, STATS, WT, BST>(lds, blockIdx.x, blockIdx.y, A, lda, a_bytes, W, P, K, N, Y, ldy, stats_partial, a_scale,
-                                            a_shift, bw);
+                                            a_shift, bw, so, si);
   probe_end(probe, probe_t0, 3);
 }
 
@@ -374,9 +400,19 @@ __global__ __launch_bounds__(256) void mlp_bwd_small_kernel(
 
 int cpfn_smallp_gemm_launch(const unsigned short *a, int lda, const unsigned short *w, int w_trans, long long P, int K, int N,
                             unsigned short *y, int ldy, float *stats_partial, const float *a_scale, const float *a_shift, int gx,
-                            hipStream_t st) {
+                            hipStream_t st, const cpfn_seam_out *seam_out, const cpfn_seam_in *seam_in) {
   dim3 grid(gx, N / 64);
   const int a_bytes = (int)(((P - 1) * lda + K) * 2);
+  if (seam_out || seam_in) {      // forward layers only (cpfn_mlp_gemm_seam): statistics on, plain weight layout
+    if (w_trans || (!stats_partial && !seam_out)) return CPFN_EINVAL;
+    const SeamOut so = seam_out_arg(seam_out);
+    const SeamIn si = seam_in_arg(seam_in);
+    if (sp_rows(P, N) == 32)
+      mlp_gemm_smallp_kernel<32, true, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift, probe_slot(grid), SmallpBwdArgs(), so, si);
+    else
+      mlp_gemm_smallp_kernel<64, true, false><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift, probe_slot(grid), SmallpBwdArgs(), so, si);
+    return cpfn_launch_status();
+  }
 #define CPFN_SMALLP(RT_)                                                                                              \
   do {                                                                                                                \
     if (stats_partial && w_trans) mlp_gemm_smallp_kernel<RT_, true, true><<<grid, 256, 0, st>>>(a, lda, a_bytes, w, (int)P, K, N, y, ldy, stats_partial, a_scale, a_shift, probe_slot(grid));  \

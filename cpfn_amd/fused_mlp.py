@@ -59,8 +59,90 @@ HEADS_ONE_PASS = True
 HEADS_RIDE = True
 
 
+#   ATOMIC_SEAMS      a hidden layer's BatchNorm statistics leave its GEMM as fixed-point atomics and are folded into scale / shift
+#                     in the prologue of the NEXT layer's GEMM (csrc/seam.h): no cpfn_bn_finalize launch between the two.  Integer
+#                     sums: bit-reproducible; equal to the ordered fp32 sums to ~1e-7 relative (tests/test_gpu_fused_mlp.py)
+ATOMIC_SEAMS = True
+# fixed point of the sums: value * 2^s in int64.  A partial sum must stay below 2^(50 - s) (2048 of them then fit 63 bits; larger ones
+# poison the seam -> NaN statistics, like an overflow would): s = 24 resolves 6e-8 per partial and takes a workgroup's sum(y^2) up to
+# 6.7e7 (8192 rows of |y| ~ 90); the fp32-xyz first layer of sa1 sees coordinates of a 0.2 ball (|y| ~ 0.05, 512 rows per partial): s = 30.
+SEAM_LOG2_FWD = 24
+SEAM_LOG2_XYZ = 30
+
+
 def _pad_to(n, m):
     return (n + m - 1) // m * m
+
+
+class _SeamOutC(ctypes.Structure):          # cpfn_seam_out (include/cpfn_hip.h)
+    _fields_ = [("acc", ctypes.c_void_p), ("replicas", ctypes.c_int), ("log2_scale", ctypes.c_int),
+                ("counter_a", ctypes.c_void_p), ("counter_b", ctypes.c_void_p)]
+
+
+class _SeamInC(ctypes.Structure):           # cpfn_seam_in
+    _fields_ = [("acc", ctypes.c_void_p), ("replicas", ctypes.c_int), ("log2_scale", ctypes.c_int), ("C", ctypes.c_int),
+                ("count", ctypes.c_float), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("conv_bias", ctypes.c_void_p),
+                ("running_mean", ctypes.c_void_p), ("running_var", ctypes.c_void_p), ("stats", ctypes.c_void_p)]
+
+
+# The seams' accumulators must be ZERO when their producer starts.  One arena per device, zeroed by ONE fill at the start of a
+# network forward pass (`seam_pass`, entered by PointNet2.forward) up to the previous pass's high-water mark; a stack that runs
+# outside such a pass (or finds the arena exhausted) gets a freshly zeroed tensor of its own instead.
+class _SeamArena:
+    def __init__(self, dev):
+        self.buf = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
+        self.off, self.zeroed, self.high, self.active = 0, 0, None, False
+
+
+_arenas = {}
+import os as _os
+_SEAM_NOFILL = _os.environ.get("CPFN_SEAM_NOFILL") == "1"      # timing experiment only (wrong statistics): what the fill launch costs
+
+
+class seam_pass:
+    def __init__(self, device, on=True):
+        self.dev, self.on, self.ar = torch.device(device), bool(on) and ATOMIC_SEAMS, None
+
+    def __enter__(self):
+        if not self.on or self.dev.type != "cuda":
+            return self
+        ar = _arenas.get(self.dev)
+        if ar is None:
+            if torch.cuda.is_current_stream_capturing():
+                return self                  # (never allocate the persistent arena inside a capture: per-seam tensors instead)
+            ar = _arenas[self.dev] = _SeamArena(self.dev)
+        if ar.active:
+            return self                      # nested pass (a second network inside the first): per-seam tensors for the inner one
+        n = ar.buf.numel() if ar.high is None else min(ar.buf.numel(), ar.high)
+        if n and not _SEAM_NOFILL:
+            ar.buf[:n].zero_()
+        ar.off, ar.zeroed, ar.active = 0, n, True
+        self.ar = ar
+        return self
+
+    def __exit__(self, *exc):
+        if self.ar is not None:
+            self.ar.active = False
+            self.ar.high = max(64, _pad_to(self.ar.off, 64))
+        return False
+
+
+def _seam_alloc(dev, words):
+    ar = _arenas.get(dev)
+    if ar is not None and ar.active:
+        if ar.off + words <= ar.zeroed:
+            v = ar.buf[ar.off:ar.off + words]
+            ar.off += _pad_to(words, 2)
+            return v
+        ar.off += _pad_to(words, 2)          # (counted: the next pass zeroes enough for it)
+    return torch.zeros(words, dtype=torch.int64, device=dev)
+
+
+def _seam_replicas(nblk, P):
+    """Copies of a seam's accumulator: ~50 same-address adds per word at most; at most 4 where the consumer is the small-P kernel
+    (P <= 16384 rows: it holds the words in registers across its first requests)."""
+    return (8 if P > 16384 else 4) if nblk > 128 else (4 if nblk > 32 else 1)
 
 
 def _check(status, what):
@@ -97,6 +179,23 @@ def gemm(A, Wb, n_out=None, gidx=None, stats=False, bias=None, out_f32=False, n_
     _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + Y.element_size() * P * n_store + (8 * nblk * N if stats else 0)
                  + (2 * P * N if yb is not None else 0))
     return Y, part, nblk
+
+
+def gemm_seam(A, Wb, part, out_desc, in_desc, a_scale=None, a_shift=None):
+    """A forward layer through cpfn_mlp_gemm_seam: statistics as partial rows (`part` [blocks,2,N]) or into the seam `out_desc`;
+    operand transform from a_scale / a_shift or folded from the previous layer's seam `in_desc` (csrc/seam.h)."""
+    h = _l.lib()
+    P, K = A.shape
+    N = Wb.shape[0]
+    Y = torch.empty(P, N, dtype=BF16, device=A.device)
+    _check(h.cpfn_mlp_gemm_seam(_ptr(A), _ptr(Wb), P, K, N, _ptr(Y), _ptr(part),
+                                ctypes.addressof(out_desc) if out_desc is not None else None,
+                                ctypes.addressof(in_desc) if in_desc is not None else None,
+                                _ptr(a_scale), _ptr(a_shift), _stream()), "cpfn_mlp_gemm_seam")
+    _l.add_bytes("cpfn_mlp_gemm", 2 * P * K + 2 * N * K + 2 * P * N
+                 + (8 * part.shape[0] * N if part is not None else 16 * out_desc.replicas * N)
+                 + (16 * in_desc.replicas * K if in_desc is not None else 0))
+    return Y
 
 
 def xyz_tail_ok(P, D, N):
@@ -423,10 +522,31 @@ class _FusedStack(torch.autograd.Function):
         a_ss = None                      # (scale, shift) when `a` is the previous layer's raw pre-BN output
         out = None
         drop_seed = None
+        seam_prev = None                 # cpfn_seam_in of the previous layer when its statistics left as a seam (nothing finalized them)
         with torch.cuda.device(dev):
             for li, L in enumerate(layers):
                 W = params[3 * li]
                 N = L.cout
+                last = li == len(layers) - 1
+                # ---- may this layer's statistics leave its GEMM as a seam?  Its consumer must be the next layer's GEMM (operand
+                #      transform) and both kernels must have the form (cpfn_mlp_gemm_seam_ok)
+                seam_out = seam_st = None
+                if (ATOMIC_SEAMS and L.training and not last and BN_APPLY_FUSED and layers[li + 1].training is not None
+                        and (h.cpfn_mlp_gemm_seam_ok(P, N, layers[li + 1].cout) & 2)):
+                    if li == 0 and first_fp32:
+                        nblk_s = h.cpfn_bn_bwd_blocks(P) if x.shape[1] <= 4 else 0
+                    elif li == 0 and xyz_tail is not None:
+                        nblk_s = h.cpfn_mlp_gemm_blocks(P, N)
+                    else:
+                        need = 2 if (a_ss is not None or seam_prev is not None) else 1
+                        ok = a.dim() == 2 and a.stride(0) == a.shape[1] and (h.cpfn_mlp_gemm_seam_ok(P, a.shape[1], N) & need)
+                        nblk_s = h.cpfn_mlp_gemm_blocks(P, N) if ok else 0
+                    if nblk_s > 0:
+                        R = _seam_replicas(nblk_s, P)
+                        acc = _seam_alloc(dev, h.cpfn_seam_words(R, N))
+                        seam_out = _SeamOutC(acc.data_ptr(), R, SEAM_LOG2_XYZ if (li == 0 and first_fp32) else SEAM_LOG2_FWD, _ptr(L.nbt), None)
+                        seam_out._keep = acc
+                        seam_st = torch.empty(4, N, dtype=torch.float32, device=dev)       # written by the consumer's first workgroup
                 if li == 0 and first_fp32:
                     KS = x.shape[1]
                     w32 = W.detach().reshape(N, -1).float().contiguous()
@@ -435,7 +555,16 @@ class _FusedStack(torch.autograd.Function):
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                     global _pending_cast
                     pc = _pending_cast
-                    if pc is not None and KS == 3 and pc[2] == dev:
+                    if seam_out is not None:
+                        part = None
+                        if pc is not None and KS == 3 and pc[2] == dev:
+                            _pending_cast = None
+                        else:
+                            flush_pending_cast()
+                            pc = None
+                        _check(h.cpfn_smallk_fwd_seam(pc[0] if pc else None, pc[1] if pc else 0, _ptr(a), KS, _ptr(w32), P, N, _ptr(Y),
+                                                      ctypes.addressof(seam_out), _stream()), "cpfn_smallk_fwd_seam")
+                    elif pc is not None and KS == 3 and pc[2] == dev:
                         _pending_cast = None          # the step's weight-panel refresh as the first workgroups of this launch
                         _check(h.cpfn_smallk_fwd_cast(pc[0], pc[1], _ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
                                "cpfn_smallk_fwd_cast")
@@ -443,27 +572,50 @@ class _FusedStack(torch.autograd.Function):
                         flush_pending_cast()
                         _check(h.cpfn_smallk_fwd(_ptr(a), KS, _ptr(w32), P, N, _ptr(Y), _ptr(part), _stream()),
                                "cpfn_smallk_fwd")
-                    _l.add_bytes("cpfn_smallk_fwd", 4 * P * KS + 2 * P * N + 8 * nblk * N)
+                    _l.add_bytes("cpfn_smallk_fwd", 4 * P * KS + 2 * P * N + (8 * nblk * N if seam_out is None else 16 * seam_out.replicas * N))
                     Wb = w32                      # (the backward pass recomputes this layer's output from x and w32)
                 elif li == 0 and xyz_tail is not None:
                     Kp = a.shape[1]
                     Wb, Wx = xt_panels(L.weight, Kp)
                     nblk = h.cpfn_mlp_gemm_blocks(P, N)
                     Y = torch.empty(P, N, dtype=BF16, device=dev)
-                    part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
-                    _check(h.cpfn_mlp_gemm_xyz(_ptr(a), Kp, _ptr(Wb), _ptr(xyz_tail), _ptr(Wx), P, Kp, N, _ptr(Y), N, _ptr(part), _stream()),
-                           "cpfn_mlp_gemm_xyz")
-                    _l.add_bytes("cpfn_mlp_gemm", 2 * P * Kp + 12 * P + 2 * N * Kp + 12 * N + 2 * P * N + 8 * nblk * N)
+                    if seam_out is not None:
+                        part = None
+                        _check(h.cpfn_mlp_gemm_xyz_seam(_ptr(a), _ptr(Wb), _ptr(xyz_tail), _ptr(Wx), P, Kp, N, _ptr(Y),
+                                                        ctypes.addressof(seam_out), _stream()), "cpfn_mlp_gemm_xyz_seam")
+                    else:
+                        part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                        _check(h.cpfn_mlp_gemm_xyz(_ptr(a), Kp, _ptr(Wb), _ptr(xyz_tail), _ptr(Wx), P, Kp, N, _ptr(Y), N, _ptr(part), _stream()),
+                               "cpfn_mlp_gemm_xyz")
+                    _l.add_bytes("cpfn_mlp_gemm", 2 * P * Kp + 12 * P + 2 * N * Kp + 12 * N + 2 * P * N
+                                 + (8 * nblk * N if seam_out is None else 16 * seam_out.replicas * N))
                 else:
                     Kp = a.shape[1]
                     Wb = bf16_weight(L.weight, N, Kp)
-                    if a_ss is None:
+                    if seam_out is not None or seam_prev is not None:
+                        # (the seam forms of the same kernels: this layer's statistics into its seam and / or the operand transform
+                        #  folded from the previous layer's)
+                        part, nblk = None, 0
+                        if seam_out is None:
+                            nblk = h.cpfn_mlp_gemm_blocks(P, N)
+                            part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                        sc_, sh_ = (a_ss if (a_ss is not None and seam_prev is None) else (None, None))
+                        Y = gemm_seam(a, Wb, part, seam_out, seam_prev, sc_, sh_)
+                    elif a_ss is None:
                         Y, part, nblk = gemm(a, Wb, stats=True)
                     else:
                         Y, part, nblk = gemm(a, Wb, stats=True, a_scale=a_ss[0], a_shift=a_ss[1])
-                last = li == len(layers) - 1
+                seam_prev = None
                 drop_in_finalize = False
-                if L.training:
+                if seam_out is not None:
+                    # no finalize launch: the NEXT layer's GEMM folds the sums; its first workgroup leaves scale / shift / mean /
+                    # rstd in `st` (for the backward pass) and updates the running statistics
+                    st = seam_st
+                    seam_prev = _SeamInC(seam_out.acc, seam_out.replicas, seam_out.log2_scale, N, float(P), float(L.eps), float(L.momentum),
+                                         _ptr(L.gamma.detach()), _ptr(L.beta.detach()),
+                                         None if L.bias is None else _ptr(L.bias.detach()), _ptr(L.rm), _ptr(L.rv), _ptr(st))
+                    seam_prev._keep = (seam_out._keep, st)
+                elif L.training:
                     # (the dropout step counter of the stack's output rides on the same launch: bn_relu_apply reads it next)
                     drop_in_finalize = last and not pool_k and cfg.get("dropout") is not None
                     st = bn_finalize(part, nblk, N, P, L.gamma.detach(), L.beta.detach(),

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcpfn_hip.so")
-ABI_VERSION = 2          # = CPFN_ABI_VERSION of include/cpfn_hip.h; bumped whenever an exported signature changes
+ABI_VERSION = 3          # = CPFN_ABI_VERSION of include/cpfn_hip.h; bumped whenever an exported signature changes
 
 _vp, _i, _f, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 _ll = ctypes.c_longlong
@@ -90,6 +90,11 @@ SIGNATURES = {
     "cpfn_label_pool": [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp],
     "cpfn_mlp_gemm_blocks": [_ll, _i],
     "cpfn_mlp_gemm": [_vp, _i, _vp, _vp, _i, _ll, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_seam_words": [_i, _i],
+    "cpfn_mlp_gemm_seam_ok": [_ll, _i, _i],
+    "cpfn_mlp_gemm_seam": [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_gemm_xyz_seam": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp],
+    "cpfn_smallk_fwd_seam": [_vp, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
     "cpfn_mlp_gemm_xyz_ok": [_ll, _i, _i],
     "cpfn_mlp_gemm_xyz": [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp],

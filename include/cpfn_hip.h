@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define CPFN_EINVAL (-22)
-#define CPFN_ABI_VERSION 2
+#define CPFN_ABI_VERSION 3
 
 /* Library / build identification (no GPU needed). */
 CPFN_API int cpfn_abi_version(void);
@@ -415,6 +415,42 @@ CPFN_API int cpfn_mlp_gemm(const void *A, int lda, const int *gidx, const void *
                            int K, int N, void *Y, int ldy, int y_f32, int n_store, const float *bias,
                            float *stats_partial, const float *a_scale, const float *a_shift, const void *bwd_y,
                            void *stream);
+/* ---- BatchNorm seams without a finalize launch (round 6; no reference counterpart: the reference's batch_norm is one
+ * framework op, modules/pointset_abstraction.py:70-74, pointset_feature_propagation.py:49-51).  The layer's GEMM (the
+ * PRODUCER) adds its per-workgroup sum(y), sum(y^2) as 64-bit fixed-point integers (value * 2^log2_scale, no-return atomics)
+ * into `replicas` copies of a [2][C] accumulator — workgroup w into copy w % replicas — and the NEXT layer's GEMM (the
+ * CONSUMER) folds the copies into scale / shift in every workgroup's prologue: cpfn_bn_finalize is not launched for that
+ * layer.  Integer sums: bit-reproducible.  acc = cpfn_seam_words(replicas, C) int64 words, ZERO before the producer runs
+ * (the last word is a poison flag: a NaN / inf / oversized partial sum makes the consumer see NaN statistics).
+ * One workgroup of the consumer also writes stats[4][C] = scale | shift | mean | rstd (what cpfn_bn_finalize leaves, for
+ * the backward pass) and updates the running statistics; the step counters are advanced by the PRODUCER. */
+typedef struct cpfn_seam_out {
+  long long *acc; int replicas; int log2_scale;
+  long long *counter_a, *counter_b;          /* optional int64 step counters (see cpfn_bn_finalize) */
+} cpfn_seam_out;
+typedef struct cpfn_seam_in {
+  const long long *acc; int replicas; int log2_scale; int C;
+  float count, eps, momentum;
+  const float *gamma, *beta, *conv_bias;     /* conv_bias optional */
+  float *running_mean, *running_var;         /* optional (both or neither) */
+  float *stats;                              /* [4][C], written */
+} cpfn_seam_in;
+CPFN_API int cpfn_seam_words(int replicas, int C);
+/* bit 0: cpfn_mlp_gemm_seam can PRODUCE a seam for a forward layer of this shape (bf16 rows, no gather / bias), bit 1: it can
+ * CONSUME one (operand transform from the previous layer's sums; K = that layer's channels). */
+CPFN_API int cpfn_mlp_gemm_seam_ok(long long P, int K, int N);
+/* Forward layer Y[P,N] = f(A)[P,K] . W[N,K]^T, lda = K, ldy = N, bf16 — cpfn_mlp_gemm with the seams spelled out:
+ * statistics either as partial rows (stats_partial) or into `out`; operand transform f = relu(scale*a + shift) either from
+ * a_scale / a_shift or folded from `in` (NULL / NULL / NULL: plain operand).  Same kernels, same Y bits. */
+CPFN_API int cpfn_mlp_gemm_seam(const void *A, const void *W, long long P, int K, int N, void *Y, float *stats_partial,
+                                const cpfn_seam_out *out, const cpfn_seam_in *in, const float *a_scale, const float *a_shift,
+                                void *stream);
+/* cpfn_mlp_gemm_xyz / cpfn_smallk_fwd(_cast) as producers of a seam (stats_partial / partial replaced by `out`). */
+CPFN_API int cpfn_mlp_gemm_xyz_seam(const void *A, const void *W, const float *xyz, const float *Wx, long long P, int K, int N,
+                                    void *Y, const cpfn_seam_out *out, void *stream);
+CPFN_API int cpfn_smallk_fwd_seam(const cpfn_cast_desc *casts /* HOST array or NULL */, int n_casts, const float *X, int KS,
+                                  const float *W, long long P, int C, void *Y, const cpfn_seam_out *out, void *stream);
+
 /* Batch statistics -> scale = gamma*rstd, shift = beta - mean*scale (+ running-stat update with
  * torch's momentum / unbiased-variance convention; conv_bias re-enters the running mean).   counter_a / counter_b (optional): int64 step counters this launch advances by one — the BatchNorm
  * module's num_batches_tracked, and the dropout step counter of a stack whose fused output dropout reads it next. */

@@ -141,6 +141,9 @@ def test_bn_apply_on_operand_load_is_bit_identical(name, P, cin, widths, pool_k,
     """BN + ReLU of a hidden layer applied on the operand load of the next GEMM and of its weight gradient
     (default) against the variant that materialises the activated tensor: same bits, forward and backward."""
     from cpfn_amd import fused_mlp
+    # (the seams of round 6 replace the ordered fp32 sums of a hidden layer's statistics by fixed-point ones — equal to ~1e-7, not
+    #  bit for bit — and exist only WITH the operand-load apply: this test holds the two apply routes to each other on the ordered sums)
+    monkeypatch.setattr(fused_mlp, "ATOMIC_SEAMS", False)
     convs, bns = _stack(cin, widths, seed=7)
     g = torch.Generator().manual_seed(P)
     xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev()) if use_xyz else None
@@ -160,6 +163,91 @@ def test_bn_apply_on_operand_load_is_bit_identical(name, P, cin, widths, pool_k,
         assert (a is None and b is None) or same(a, b)
     for (rm, rv), (rm_r, rv_r) in zip(sta, stb):
         assert same(rm, rm_r) and same(rv, rv_r)
+
+
+@pytest.mark.parametrize("name,P,cin,widths,pool_k,use_xyz", [
+    ("sa1-like", 2 * 40 * 16, 3, [64, 64, 128], 16, True),
+    ("sa1-size", 40 * 512 * 64, 3, [64, 64, 128], 64, True),          # 1.3 M rows: the streaming kernels, 8 replicas
+    ("sa2-like", 2 * 24 * 64, 131, [128, 128, 256], 64, False),
+    ("sa3-like", 3 * 128, 259, [256, 512, 1024], 128, False),
+    ("sfp-like", 8192, 384, [256, 128], None, False),
+    ("sfp3-like", 40000 + 77, 128, [128, 128, 128, 128], None, False),
+    ("sfp3-size", 131072, 128, [128, 128, 128, 128], None, False),
+])
+def test_atomic_seams_against_the_finalize_launch(name, P, cin, widths, pool_k, use_xyz, monkeypatch):
+    """a hidden layer's BatchNorm statistics as fixed-point atomics folded by the next layer's GEMM (csrc/seam.h)
+    against the partial rows + cpfn_bn_finalize they replace.  (i) the statistics themselves — scale, shift, mean, rstd as the
+    consumer's first workgroup leaves them, running mean / variance — within 1e-6 relative of the ordered sums' (the fixed point
+    resolves 2.4e-7 per partial sum); (ii) outputs and every gradient within a bf16 rounding flip of the other route's (rel-L2
+    < 2e-3: a 1e-7 change of a scale moves a handful of bf16 roundings); (iii) TWO seam runs bit-identical — integer sums;
+    (iv) fewer cpfn_bn_finalize launches, the same step counters."""
+    from cpfn_amd import fused_mlp, lib as _l
+    convs, bns = _stack(cin, widths, seed=11)
+    g = torch.Generator().manual_seed(P + 1)
+    xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev()) if use_xyz else None
+    x = None if use_xyz else torch.randn(P, cin, generator=g).to(dev())
+    gout = torch.randn(P // pool_k if pool_k else P, widths[-1], generator=g).to(dev())
+    res, launches, stats = {}, {}, {}
+    for mode in ("finalize", "seam", "seam2"):
+        monkeypatch.setattr(fused_mlp, "ATOMIC_SEAMS", mode != "finalize")
+        grabbed = []
+        orig = fused_mlp._FusedStack.forward
+
+        def spy(ctx, *a, _orig=orig, _g=grabbed):
+            out = _orig(ctx, *a)
+            _g.append([t[3] for t in ctx.saved])                   # every layer's [4, C] scale | shift | mean | rstd
+            return out
+        monkeypatch.setattr(fused_mlp._FusedStack, "forward", staticmethod(spy))
+        _l.byte_census(True)
+        with fused_mlp.seam_pass(dev(), True):
+            res[mode] = _run(x, convs, bns, torch.bfloat16, pool_k, xyz, gout)
+        launches[mode] = _l.byte_census(False).get("cpfn_bn_finalize", (0, 0))[0]
+        torch.cuda.synchronize()
+        stats[mode] = [t.clone() for t in grabbed[0]]
+        monkeypatch.setattr(fused_mlp._FusedStack, "forward", orig)
+        assert all(int(bn.num_batches_tracked) == 1 for bn in bns), mode
+    assert launches["finalize"] == len(widths) and launches["seam"] == 1, launches      # only the stack's last layer keeps its launch
+    rel = lambda a, b: float(((a.double() - b.double()).abs() / b.double().abs().clamp_min(1e-3)).max())
+    for li, (sa, sb) in enumerate(zip(stats["seam"][:-1], stats["finalize"][:-1])):
+        # (only the FIRST layer sees identical inputs on both routes; behind it the other route's own rounding flips move the sums)
+        tol = 1e-6 if li == 0 else 5e-3
+        d_mean = float(((sa[2].double() - sb[2].double()).abs() * sb[3].double()).max())      # in units of the channel's sigma
+        d_shift = float(((sa[1].double() - sb[1].double()).abs() / (1.0 + sb[1].double().abs())).max())
+        assert d_mean < tol and rel(sa[3], sb[3]) < tol and rel(sa[0], sb[0]) < tol and d_shift < tol, \
+            (li, d_mean, rel(sa[3], sb[3]), rel(sa[0], sb[0]), d_shift)
+    (ya, gxa, gra, sta), (yb, gxb, grb, stb), (yc, gxc, grc, stc) = res["seam"], res["finalize"], res["seam2"]
+    assert _rel(ya, yb) < 2e-3, _rel(ya, yb)
+    assert (gxa is None) or _rel(gxa, gxb) < 5e-3
+    for a, b in zip(gra, grb):
+        assert (a is None and b is None) or _rel(a, b) < 5e-3, _rel(a, b)
+    assert float((sta[0][0] - stb[0][0]).abs().max()) < 1e-6 and rel(sta[0][1], stb[0][1]) < 1e-5   # running statistics, first layer
+    assert torch.equal(ya, yc) and ((gxa is None) or torch.equal(gxa, gxc))
+    for a, c in zip(gra, grc):
+        assert (a is None and c is None) or torch.equal(a, c)
+    for (rm, rv), (rm_c, rv_c) in zip(sta, stc):
+        assert torch.equal(rm, rm_c) and torch.equal(rv, rv_c)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3e22])
+def test_atomic_seam_poison_becomes_nan_statistics(bad, monkeypatch):
+    """A NaN / inf / absurdly large value in a hidden layer's output must reach the consumer as NaN statistics (the fp32 sums would
+    have carried a NaN; an integer cannot): the producer raises the seam's poison word instead of adding an undefined integer, and the
+    consumer then behaves exactly like the finalize route on NaN sums — same running statistics (NaN), same output bits."""
+    from cpfn_amd import fused_mlp, mlp
+    out = {}
+    for seams in (True, False):
+        monkeypatch.setattr(fused_mlp, "ATOMIC_SEAMS", seams)
+        convs, bns = _stack(128, [128, 128], seed=3)
+        x = torch.randn(40000, 128, generator=torch.Generator().manual_seed(5)).to(dev())
+        x[17, 5] = bad
+        with fused_mlp.seam_pass(dev(), True):
+            y = mlp.run_stack(x, convs, bns, torch.bfloat16)
+        torch.cuda.synchronize()
+        out[seams] = (y.detach().float(), bns[0].running_mean.clone(), bns[0].running_var.clone())
+    assert bool(torch.isnan(out[True][1]).all()) and bool(torch.isnan(out[True][2]).all())
+    if bad != bad:          # (a NaN input: the ordered sums are NaN too — identical behaviour down to the output bits)
+        assert bool(torch.isnan(out[False][1]).all())
+        assert torch.equal(out[True][0].nan_to_num(7.0), out[False][0].nan_to_num(7.0))
 
 
 def test_heads_linear():
