@@ -165,6 +165,19 @@ __global__ __launch_bounds__(TPB) void interp_rows_bwd_kernel(const float *__res
 }
 
 // ---------------------------------------------------------------- bf16 row movers of the MLP path
+// XCD-aware (workgroup, cloud) of a (nx, B) grid.  Consecutive workgroup ids go round-robin over the chip's 8 XCDs, each with
+// its own L2: with the plain (blockIdx.x, blockIdx.y = cloud) mapping every cloud's source rows are fetched by all eight — the
+// interpolation adjoint, which reads each gradient row three times (once per neighbour), measured 1.93 x its bytes from HBM,
+// the interpolation itself 1.40 x (round 5 counters).  Here XCD k walks clouds k, k + 8, ... one after the other, so a row's
+// re-reads hit the L2 that fetched it.  (B % 8 != 0: the plain mapping.)
+__device__ __forceinline__ void xcd_cloud_map(int &bx, int &b) {
+  const int nx = (int)gridDim.x, B = (int)gridDim.y;
+  bx = (int)blockIdx.x; b = (int)blockIdx.y;
+  if (B & 7) return;
+  const int L = bx + nx * b, j = L >> 3;
+  b = (L & 7) + 8 * (j / nx);
+  bx = j % nx;
+}
 __device__ __forceinline__ float bf2f_(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 __device__ __forceinline__ unsigned short f2bf_(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
@@ -173,9 +186,10 @@ __global__ __launch_bounds__(TPB) void interp_rows_bf16_kernel(const unsigned sh
                                                                const int *__restrict__ idx,
                                                                const float *__restrict__ w, int M, int N, int C,
                                                                unsigned short *__restrict__ out) {
-  const int b = blockIdx.y;
+  int bx, b;
+  xcd_cloud_map(bx, b);
   const int cpr = C / 8;
-  const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long e = (long long)bx * TPB + threadIdx.x;
   if (e >= (long long)N * cpr) return;
   const int n = (int)(e / cpr), c0 = (int)(e - (long long)n * cpr) * 8;
   const int *ii = idx + ((size_t)b * N + n) * 3;
@@ -203,9 +217,10 @@ __global__ __launch_bounds__(TPB) void concat_interp_bf16_kernel(const unsigned 
                                                                  const unsigned short *__restrict__ feats,
                                                                  const int *__restrict__ idx, const float *__restrict__ w,
                                                                  int M, int N, int C2, unsigned short *__restrict__ out) {
-  const int b = blockIdx.y;
+  int bx, b;
+  xcd_cloud_map(bx, b);
   const int cpr = (C1 + C2) / 8, cp1 = C1 / 8;
-  const long long e = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long e = (long long)bx * TPB + threadIdx.x;
   if (e >= (long long)N * cpr) return;
   const int n = (int)(e / cpr), ch = (int)(e - (long long)n * cpr);
   unsigned short *o = out + ((size_t)b * N + n) * (C1 + C2) + ch * 8;
@@ -618,9 +633,10 @@ __global__ __launch_bounds__(TPB) void csr_gather_sum_kernel(const unsigned shor
                                                              const float *__restrict__ w, int T, int R, int M, int C,
                                                              const unsigned short *__restrict__ addend, int ld_add,
                                                              unsigned short *__restrict__ out) {
-  const int b = blockIdx.y;
+  int bx, b;
+  xcd_cloud_map(bx, b);
   const int cpr = C / 8;
-  const long long xl = (long long)blockIdx.x * TPB + threadIdx.x;
+  const long long xl = (long long)bx * TPB + threadIdx.x;
   const long long x = xl / CS_LANES;
   const int q = (int)(xl % CS_LANES);
   const bool live = x < (long long)M * cpr;
@@ -673,10 +689,11 @@ __global__ __launch_bounds__(TPB) void group_concat_bf16_kernel(const unsigned s
   // 32 chunk lanes x 8 rows per workgroup pass, GC_ROWS passes per workgroup: no integer divisions, one index load
   // per (row, lane) served from L1, and the rows of a pass are independent loads in flight
   constexpr int GC_ROWS = 4;
-  const int b = blockIdx.y;
+  int bx, b;
+  xcd_cloud_map(bx, b);
   const int cpr = Cpad / 8;
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int row0 = blockIdx.x * (8 * GC_ROWS) + ry;
+  const int row0 = bx * (8 * GC_ROWS) + ry;
   int ii[GC_ROWS];
 #pragma unroll
   for (int u = 0; u < GC_ROWS; ++u) {
