@@ -212,6 +212,77 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const unsigned sho
   }
 }
 
+// ---------------------------------------------------------------- max-pool, second half (round 6)
+// The pooled last layer's GEMM left, per wave of 32 rows and channel, the raw y of the wave's winner of max(+-y) and its row
+// inside the group (cpfn_mlp_gemm_pool; +- = the sign of gamma).  Here: the WPG = pool_k / 32 wave results of a group are
+// combined (ascending rows: `>` keeps the first), the affine map goes on the winner only —
+//   out = relu(scale * y + shift), arg = its row, yarg = y —
+// and scale / shift come either from cpfn_bn_finalize's vectors or are folded from the layer's seam (seam.h) by the first lanes
+// of every workgroup: [G, C]-sized work in large workgroups (PF_GROUPS groups x 256 channels each), which is what a seam's
+// consumer has to be.  out has the bits of cpfn_bn_relu_maxpool; arg / yarg name another row only where two DIFFERENT y round
+// to the same z (this takes the first row of the extreme y, that one the first row of the z-tie).  scale == 0 / NaN, or no
+// winner (a group of NaNs): row 0, like that kernel.
+constexpr int PF_GROUPS = 32;
+__global__ __launch_bounds__(256) void bn_pool_finish_kernel(const unsigned short *__restrict__ pmax, const unsigned char *__restrict__ pidx,
+                                                             const unsigned short *__restrict__ Yr, int G, int pool_k, int C,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             const SeamIn si, unsigned short *__restrict__ out,
+                                                             unsigned char *__restrict__ arg, unsigned short *__restrict__ yarg) {
+  __shared__ float s_sc[256], s_sh[256];
+  const int t = threadIdx.x;
+  const int cb = blockIdx.y * 256, nc = min(256, C - cb);        // this workgroup's channels
+  if (t < nc) {
+    float sc, sh;
+    if (si.acc) seam_fold_fwd(si, cb + t, blockIdx.x == 0, sc, sh);
+    else { sc = scale[cb + t]; sh = shift[cb + t]; }
+    s_sc[t] = sc; s_sh[t] = sh;
+  }
+  __syncthreads();
+  const int nch = nc / 8, gsub = 256 / nch;                      // chunk lanes x groups per pass
+  const int ch = t % nch, gs = t / nch, c0 = cb + ch * 8;
+  const int wpg = pool_k / 32;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = s_sc[ch * 8 + j]; sh[j] = s_sh[ch * 8 + j]; }
+  const int g1 = min(G, ((int)blockIdx.x + 1) * PF_GROUPS);
+  for (int g = blockIdx.x * PF_GROUPS + gs; g < g1; g += gsub) {
+    uint4 pv[4];
+    uint2 pi[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (w < wpg) {
+        pv[w] = *(const uint4 *)(pmax + ((size_t)g * wpg + w) * C + c0);
+        pi[w] = *(const uint2 *)(pidx + ((size_t)g * wpg + w) * C + c0);
+      }
+    unsigned short o[8], ya[8];
+    unsigned char ka[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool neg = !(sc[j] >= 0.f) && sc[j] < 0.f;           // (the producer used the sign of gamma = the sign of scale)
+      float best = -INFINITY, ybest = 0.f;
+      int kbest = 255;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w < wpg) {
+          const unsigned short *hv = (const unsigned short *)&pv[w];
+          const unsigned char *hk = (const unsigned char *)&pi[w];
+          const float y = bf2f(hv[j]), v = neg ? -y : y;
+          if (hk[j] != 255 && v > best) { best = v; ybest = y; kbest = hk[j]; }
+        }
+      if (kbest == 255 || !(sc[j] != 0.f)) {                      // no winner, or no ordering: row 0
+        kbest = 0;
+        ybest = bf2f(Yr[(size_t)g * pool_k * C + c0 + j]);
+      }
+      o[j] = f2bf(fmaxf(fmaf(sc[j], ybest, sh[j]), 0.f));
+      ya[j] = f2bf(ybest);
+      ka[j] = (unsigned char)kbest;
+    }
+    *(uint4 *)(out + (size_t)g * C + c0) = *(const uint4 *)o;
+    *(uint4 *)(yarg + (size_t)g * C + c0) = *(const uint4 *)ya;
+    *(uint2 *)(arg + (size_t)g * C + c0) = *(const uint2 *)ka;
+  }
+}
+
 // ---------------------------------------------------------------- BatchNorm backward, pass 1
 template <bool DROP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DROP ? 3 : 4))) void bn_relu_bwd_kernel(const unsigned short *__restrict__ Ga,
@@ -847,6 +918,21 @@ extern "C" int cpfn_bn_relu_maxpool(const void *Y, const float *scale, const flo
   if (G == 0) return 0;
   bn_relu_maxpool_kernel<<<dim3(G, cpfn_cdiv(C / 8, 32)), 256, 0, (hipStream_t)stream>>>((const unsigned short *)Y, scale, shift, Kn, C,
                                                              (unsigned short *)out, arg, (unsigned short *)yarg);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_pool_finish(const void *pmax, const unsigned char *pidx, const void *Y, int G, int pool_k, int C,
+                                   const float *scale, const float *shift, const cpfn_seam_in *in, void *out, unsigned char *arg,
+                                   void *yarg, void *stream) {
+  if (G < 0 || !(pool_k == 32 || pool_k == 64 || pool_k == 128) || C < 64 || (C & 63) || !pmax || !pidx || !Y || !out || !arg || !yarg ||
+      (!in && (!scale || !shift)) || (in && (scale || shift)) || !seam_in_valid(in, C))
+    return CPFN_EINVAL;
+  if (G == 0) return 0;
+  const int nc = C < 256 ? C : 256;
+  if ((nc / 8) & (nc / 8 - 1)) return CPFN_EINVAL;               // chunk lanes: a power of two
+  bn_pool_finish_kernel<<<dim3(cpfn_cdiv(G, PF_GROUPS), cpfn_cdiv(C, 256)), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned short *)pmax, pidx, (const unsigned short *)Y, G, pool_k, C, scale, shift, seam_in_arg(in), (unsigned short *)out,
+      arg, (unsigned short *)yarg);
   return cpfn_launch_status();
 }
 

@@ -69,7 +69,21 @@ __device__ __forceinline__ bf16x8 xt_frag(float x, float y, float z, int lq) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BN, int KS, bool STATS, bool ATR, bool BST, bool XT = false>
+// POOL (the pooled last layer of a set-abstraction stack, round 6): the max over the K neighbours starts in THIS kernel's
+// epilogue.  z = scale*y + shift is monotone in y with the sign of scale = the sign of gamma (rstd > 0) — a parameter, known
+// before the batch statistics are — so max_k z = affine(max_k (+-y)) and the maximum of +-y over a wave's 32 rows can be taken
+// from the tile on its way out, BEFORE anybody knows scale / shift: every wave leaves (raw y of its winner, its row k inside the
+// group) per channel, [P / 32][N], and cpfn_bn_pool_finish combines the pool_k / 32 wave results of a group and applies the
+// affine map to the winner only.  The stand-alone pooling pass (cpfn_bn_relu_maxpool: a second read of the whole [P, N] output,
+// 36 + 24 us per step for sa1 + sa2) is then a [G, N]-sized launch.
+struct PoolOut {
+  unsigned short *pmax;        // [ceil(P / 32)][N] bf16: raw y of the wave's winner
+  unsigned char *pidx;         // [ceil(P / 32)][N]: its row inside the group (0 .. pool_k - 1)
+  const float *gamma;          // [N]: the sign decides between max and min of y
+  int pool_k;                  // 32 | 64 | 128
+};
+
+template <int BN, int KS, bool STATS, bool ATR, bool BST, bool XT = false, bool POOL = false>
 __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned short *s_w,
                                             unsigned short *s_o, const StreamBufs &sb, int P, int row0, int next_tile,
                                             int wave, int lane, float (&st_s)[8], float (&st_q)[8],
@@ -77,7 +91,8 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
                                             const float *s_bs /*[2][BN]: scale, shift of the layer below (BST)*/,
                                             const unsigned short *s_wx /*XT: [BN][16] bf16*/,
                                             float (&xz)[2][3] /*XT: xyz of the lane's two points, reloaded for the next tile*/,
-                                            const float *xyz) {
+                                            const float *xyz, const PoolOut &po = PoolOut(), const unsigned (&smask)[4] = {0u, 0u, 0u, 0u},
+                                            int n0 = 0, int N = 0) {
   constexpr int NT = BN / 16;
   constexpr int CPR = BN / 8;  // 16-byte chunks per row
   // the 64-wide variants have the registers to request the pieces of Yb before the MFMAs (the two sa1 data gradients,
@@ -164,12 +179,28 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
 #pragma unroll
     for (int i = 0; i < 32 * CPR / 64; ++i) yb[i] = __builtin_amdgcn_raw_buffer_load_b128(sb.yb, sb.yoff + y_tile_off + i * sb.y_step, 0, 0);
   }
+  float pb[POOL ? 8 : 1];        // POOL: the lane's running maximum of +-y over the rows it stores (8 channels of one chunk) ...
+  int pk[POOL ? 8 : 1];          // ... and the row (inside its group) that holds it: rows ascend with i, `>` keeps the first
+  if (POOL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pb[j] = -INFINITY; pk[j] = 0x7fffffff; }
+  }
 #pragma unroll
   for (int i = 0; i < 32 * CPR / 64; ++i) {
     const int e = i * 64 + lane;
     const int r = e / CPR, c = e - r * CPR;
     const int p = row0 + wave * 32 + r;
     const uint4 vv = *(const uint4 *)&s_o[r * G_LDO + c * 8];
+    if (POOL && p < P) {
+      const int kg = (row0 + wave * 32 + r) & (po.pool_k - 1);
+      const unsigned w4[4] = {vv.x ^ smask[0], vv.y ^ smask[1], vv.z ^ smask[2], vv.w ^ smask[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = __uint_as_float(w4[j] << 16), v1 = __uint_as_float(w4[j] & 0xffff0000u);
+        if (v0 > pb[2 * j]) { pb[2 * j] = v0; pk[2 * j] = kg; }
+        if (v1 > pb[2 * j + 1]) { pb[2 * j + 1] = v1; pk[2 * j + 1] = kg; }
+      }
+    }
     // (aux = 2: `nt` — the tile is not read again by this kernel; fewer dirty lines for the kernel boundary to write back:
     //  -4 us per step with the one-pass backward kernel's stores, same-box A/B .tnt, NOTEBOOK round 5)
     __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){vv.x, vv.y, vv.z, vv.w}, sb.y, sb.yoff + y_tile_off + i * sb.y_step, 0, 2);
@@ -216,9 +247,37 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
       }
     }
   }
+  if (POOL) {
+    // the lanes that carry the same chunk (lane % CPR; lane / CPR = row subset: higher subset = later rows) -> the wave's winner;
+    // equal values keep the smaller row
+#pragma unroll
+    for (int m = CPR; m < 64; m <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v2 = __shfl_xor(pb[j], m, 64);
+        const int k2 = __shfl_xor(pk[j], m, 64);
+        if (v2 > pb[j] || (v2 == pb[j] && k2 < pk[j])) { pb[j] = v2; pk[j] = k2; }
+      }
+    }
+    const int prow = row0 / 32 + wave;
+    if (lane < CPR && row0 + wave * 32 < P) {
+      // raw y = the winner with its sign restored (an exact bit flip); no winner (every row NaN): k = 255, any value
+      unsigned o[4];
+      unsigned long long kk = 0ull;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned lo = (__float_as_uint(pb[2 * j]) >> 16), hi = (__float_as_uint(pb[2 * j + 1]) & 0xffff0000u);
+        o[j] = (lo | hi) ^ smask[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kk |= (unsigned long long)(pk[j] > 255 ? 255 : pk[j]) << (8 * j);
+      *(uint4 *)&po.pmax[(size_t)prow * N + n0 + lane * 8] = (uint4){o[0], o[1], o[2], o[3]};
+      *(unsigned long long *)&po.pidx[(size_t)prow * N + n0 + lane * 8] = kk;
+    }
+  }
 }
 
-template <int BN, int KS, bool STATS, bool ATR = false, bool BST = false, bool XT = false>
+template <int BN, int KS, bool STATS, bool ATR = false, bool BST = false, bool XT = false, bool POOL = false>
 __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void mlp_gemm_stream_kernel(
     const unsigned short *__restrict__ A, int lda, const unsigned short *__restrict__ W, int w_trans, int P, int N,
     unsigned short *__restrict__ Y, int ldy, float *__restrict__ stats_partial, int tiles_per_wg,
@@ -226,7 +285,8 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     const unsigned short *__restrict__ Yb = nullptr /* BST: [P, ldy] like Y */, unsigned long long *probe = nullptr,
     const float *__restrict__ xyz = nullptr /* XT: [P,3] */, const float *__restrict__ wx = nullptr /* XT: [N,3] fp32 */,
     const SeamOut so = SeamOut() /* STATS: the sums leave as fixed-point atomics instead of partial rows */,
-    const SeamIn si = SeamIn() /* ATR: scale / shift folded from the previous layer's sums (seam.h) */) {
+    const SeamIn si = SeamIn() /* ATR: scale / shift folded from the previous layer's sums (seam.h) */,
+    const PoolOut po = PoolOut() /* POOL: per-wave winners of the max over neighbours */) {
   constexpr int NT = BN / 16, K = 32 * KS, CPR = BN / 8;
   const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
@@ -257,6 +317,13 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   float st_s[8], st_q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+  unsigned smask[4] = {0u, 0u, 0u, 0u};      // POOL: bf16 sign bits of gamma for the channel pairs of the lane's output chunk
+  if (POOL) {
+    const int cc = n0 + (lane % CPR) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      smask[j] = (po.gamma[cc + 2 * j] < 0.f ? 0x8000u : 0u) | (po.gamma[cc + 2 * j + 1] < 0.f ? 0x80000000u : 0u);
+  }
   if (BST) {   // scale / shift of the layer below for this column block (visible after the W-panel barrier)
     for (int e = t; e < BN; e += G_THREADS) { s_bs[e] = a_scale[n0 + e]; s_bs[BN + e] = a_shift[n0 + e]; }
   }
@@ -306,18 +373,18 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
       bf16x8 b[2][KS];
       stream_load_a<KS>(b, sb.a, sb.aoff, tile0 + 1 < tile_end ? (unsigned)(tile0 + 1) * sb.a_tile : sb.a_oob);
       for (int tile = tile0; tile < tile_end; tile += 2) {
-        stream_tile<BN, KS, STATS, ATR, BST, XT>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 2 < tile_end ? tile + 2 : -1, wave, lane,
-                                                 st_s, st_q, s_ss, s_bs, s_wx, xz, xyz);
+        stream_tile<BN, KS, STATS, ATR, BST, XT, POOL>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 2 < tile_end ? tile + 2 : -1, wave, lane,
+                                                       st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N);
         if (tile + 1 < tile_end)
-          stream_tile<BN, KS, STATS, ATR, BST, XT>(b, s_w, s_o[wave], sb, P, (tile + 1) * G_ROWS, tile + 3 < tile_end ? tile + 3 : -1, wave,
-                                                   lane, st_s, st_q, s_ss, s_bs, s_wx, xz, xyz);
+          stream_tile<BN, KS, STATS, ATR, BST, XT, POOL>(b, s_w, s_o[wave], sb, P, (tile + 1) * G_ROWS, tile + 3 < tile_end ? tile + 3 : -1, wave,
+                                                         lane, st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N);
       }
     } else
     for (int tile = tile0; tile < tile_end; ++tile) {
       // the reload inside is unconditional (a tile past the end is out of the buffer's range: zeros, no traffic), so
       // the loop body is straight-line
-      stream_tile<BN, KS, STATS, ATR, BST, XT>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1 < tile_end ? tile + 1 : -1, wave, lane,
-                                               st_s, st_q, s_ss, s_bs, s_wx, xz, xyz);
+      stream_tile<BN, KS, STATS, ATR, BST, XT, POOL>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1 < tile_end ? tile + 1 : -1, wave, lane,
+                                                     st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N);
     }
   }
   if (STATS || BST) {
@@ -799,5 +866,36 @@ extern "C" int cpfn_mlp_gemm_seam(const void *A, const void *W, long long P, int
                  case 192: CPFN_STREAM_SEAM(64, 6); break; default: CPFN_STREAM_SEAM(64, 8); }
   }
 #undef CPFN_STREAM_SEAM
+  return cpfn_launch_status();
+}
+
+// ---- the pooled last layer of a set-abstraction stack: the same forward layer with the max over neighbours started in its
+//      epilogue (stream_tile, POOL).  Streaming kernel with the operand transform only (the layer's input is a hidden layer's
+//      pre-BN output), N % 128 == 0, pool_k in {32, 64, 128} dividing P.
+extern "C" int cpfn_mlp_gemm_pool_ok(long long P, int K, int N, int pool_k) {
+  return gemm_fwd_route(P, K, N, true) == 2 && (N % 128) == 0 && (K == 64 || K == 128) &&
+         (pool_k == 32 || pool_k == 64 || pool_k == 128) && P % pool_k == 0;
+}
+extern "C" int cpfn_mlp_gemm_pool(const void *A, const void *W, long long P, int K, int N, void *Y, float *stats_partial,
+                                  const cpfn_seam_out *out, const cpfn_seam_in *in, const float *a_scale, const float *a_shift,
+                                  int pool_k, const float *gamma, void *pmax, unsigned char *pidx, void *stream) {
+  if (!A || !W || !Y || (!stats_partial == !out) || (!a_scale != !a_shift) || (!in == !a_scale) || !seam_out_valid(out) ||
+      !seam_in_valid(in, K) || !gamma || !pmax || !pidx || !cpfn_mlp_gemm_pool_ok(P, K, N, pool_k))
+    return CPFN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = cpfn_mlp_gemm_blocks(P, N);
+  const long long tiles = (P + G_ROWS - 1) / G_ROWS;
+  const int tpw = (int)((tiles + gx - 1) / gx);
+  const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
+  unsigned short *y = (unsigned short *)Y;
+  PoolOut po;
+  po.pmax = (unsigned short *)pmax; po.pidx = pidx; po.gamma = gamma; po.pool_k = pool_k;
+  const SeamOut so = seam_out_arg(out);
+  const SeamIn si = seam_in_arg(in);
+  dim3 grid(gx, N / 128);
+  if (K == 64)
+    mlp_gemm_stream_kernel<128, 2, true, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, K, w, 0, (int)P, N, y, N, stats_partial, tpw, a_scale, a_shift, nullptr, probe_slot(grid), nullptr, nullptr, so, si, po);
+  else
+    mlp_gemm_stream_kernel<128, 4, true, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, K, w, 0, (int)P, N, y, N, stats_partial, tpw, a_scale, a_shift, nullptr, probe_slot(grid), nullptr, nullptr, so, si, po);
   return cpfn_launch_status();
 }

@@ -63,6 +63,10 @@ HEADS_RIDE = True
 #                     in the prologue of the NEXT layer's GEMM (csrc/seam.h): no cpfn_bn_finalize launch between the two.  Integer
 #                     sums: bit-reproducible; equal to the ordered fp32 sums to ~1e-7 relative (tests/test_gpu_fused_mlp.py)
 ATOMIC_SEAMS = True
+#   POOL_IN_GEMM      the max over the K neighbours of a set-abstraction stack starts in the epilogue of its last layer's GEMM
+#                     (cpfn_mlp_gemm_pool: per-wave winners of max(sign(gamma) * y), taken before the batch statistics exist) and is
+#                     finished by a [G, C]-sized launch (cpfn_bn_pool_finish) instead of a second pass over the [P, C] output
+POOL_IN_GEMM = True
 # fixed point of the sums: value * 2^s in int64.  A partial sum must stay below 2^(50 - s) (2048 of them then fit 63 bits; larger ones
 # poison the seam -> NaN statistics, like an overflow would): s = 24 resolves 6e-8 per partial and takes a workgroup's sum(y^2) up to
 # 6.7e7 (8192 rows of |y| ~ 90); the fp32-xyz first layer of sa1 sees coordinates of a 0.2 ball (|y| ~ 0.05, 512 rows per partial): s = 30.
@@ -252,6 +256,23 @@ def bn_relu_maxpool(Y, scale, shift, Kn):
     _check(_l.lib().cpfn_bn_relu_maxpool(_ptr(Y), _ptr(scale), _ptr(shift), G, Kn, C, _ptr(out), _ptr(arg), _ptr(yarg),
                                          _stream()), "cpfn_bn_relu_maxpool")
     _l.add_bytes("cpfn_bn_relu_maxpool", 2 * Y.numel() + 5 * G * C)
+    return out, arg, yarg
+
+
+def bn_pool_finish(pool_part, Y, st, seam_in, Kn):
+    """Second half of the pooling that cpfn_mlp_gemm_pool started: out / arg / yarg as bn_relu_maxpool returns them.  scale / shift
+    from st (cpfn_bn_finalize's vectors) or, with seam_in (a cpfn_seam_in descriptor), folded from the layer's seam — whose first
+    workgroup then also writes st."""
+    P, C = Y.shape
+    G = P // Kn
+    out = torch.empty(G, C, dtype=BF16, device=Y.device)
+    arg = torch.empty(G, C, dtype=torch.uint8, device=Y.device)
+    yarg = torch.empty(G, C, dtype=BF16, device=Y.device)
+    sc, sh = (None, None) if seam_in is not None else (st[0], st[1])
+    _check(_l.lib().cpfn_bn_pool_finish(_ptr(pool_part[0]), _ptr(pool_part[1]), _ptr(Y), G, Kn, C, _ptr(sc), _ptr(sh),
+                                        ctypes.addressof(seam_in) if seam_in is not None else None, _ptr(out), _ptr(arg), _ptr(yarg),
+                                        _stream()), "cpfn_bn_pool_finish")
+    _l.add_bytes("cpfn_bn_pool_finish", 3 * pool_part[0].shape[0] * C + 5 * G * C)
     return out, arg, yarg
 
 
@@ -531,8 +552,16 @@ class _FusedStack(torch.autograd.Function):
                 # ---- may this layer's statistics leave its GEMM as a seam?  Its consumer must be the next layer's GEMM (operand
                 #      transform) and both kernels must have the form (cpfn_mlp_gemm_seam_ok)
                 seam_out = seam_st = None
-                if (ATOMIC_SEAMS and L.training and not last and BN_APPLY_FUSED and layers[li + 1].training is not None
-                        and (h.cpfn_mlp_gemm_seam_ok(P, N, layers[li + 1].cout) & 2)):
+                # the pooled last layer: pooling started in the GEMM's epilogue, finished by a [G, C]-sized launch
+                pool_fused = bool(POOL_IN_GEMM and last and pool_k and li > 0 and (a_ss is not None or seam_prev is not None)
+                                  and a.dim() == 2 and a.stride(0) == a.shape[1] and h.cpfn_mlp_gemm_pool_ok(P, a.shape[1], N, pool_k))
+                if not (ATOMIC_SEAMS and L.training):
+                    consumer_ok = False
+                elif not last:           # consumer: the next layer's GEMM
+                    consumer_ok = BN_APPLY_FUSED and bool(h.cpfn_mlp_gemm_seam_ok(P, N, layers[li + 1].cout) & 2)
+                else:                    # consumer: cpfn_bn_pool_finish (large workgroups, unlike the stand-alone pooling pass)
+                    consumer_ok = pool_fused
+                if consumer_ok:
                     if li == 0 and first_fp32:
                         nblk_s = h.cpfn_bn_bwd_blocks(P) if x.shape[1] <= 4 else 0
                     elif li == 0 and xyz_tail is not None:
@@ -592,7 +621,25 @@ class _FusedStack(torch.autograd.Function):
                 else:
                     Kp = a.shape[1]
                     Wb = bf16_weight(L.weight, N, Kp)
-                    if seam_out is not None or seam_prev is not None:
+                    pool_part = None
+                    if pool_fused:
+                        part, nblk = None, 0
+                        if seam_out is None:
+                            nblk = h.cpfn_mlp_gemm_blocks(P, N)
+                            part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                        sc_, sh_ = (a_ss if seam_prev is None else (None, None))
+                        Y = torch.empty(P, N, dtype=BF16, device=dev)
+                        nw = (P + 31) // 32
+                        pool_part = (torch.empty(nw, N, dtype=BF16, device=dev), torch.empty(nw, N, dtype=torch.uint8, device=dev))
+                        _check(h.cpfn_mlp_gemm_pool(_ptr(a), _ptr(Wb), P, Kp, N, _ptr(Y), _ptr(part),
+                                                    ctypes.addressof(seam_out) if seam_out is not None else None,
+                                                    ctypes.addressof(seam_prev) if seam_prev is not None else None,
+                                                    _ptr(sc_), _ptr(sh_), pool_k, _ptr(L.gamma.detach()), _ptr(pool_part[0]),
+                                                    _ptr(pool_part[1]), _stream()), "cpfn_mlp_gemm_pool")
+                        _l.add_bytes("cpfn_mlp_gemm", 2 * P * Kp + 2 * N * Kp + 2 * P * N + 3 * nw * N
+                                     + (8 * nblk * N if part is not None else 16 * seam_out.replicas * N)
+                                     + (16 * seam_prev.replicas * Kp if seam_prev is not None else 0))
+                    elif seam_out is not None or seam_prev is not None:
                         # (the seam forms of the same kernels: this layer's statistics into its seam and / or the operand transform
                         #  folded from the previous layer's)
                         part, nblk = None, 0
@@ -627,7 +674,11 @@ class _FusedStack(torch.autograd.Function):
                                                  None if L.bias is None else _ptr(L.bias.detach()), _ptr(L.rm), _ptr(L.rv),
                                                  float(L.eps), N, _ptr(st), _stream()), "cpfn_bn_eval_affine")
                 if last and pool_k:
-                    out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)
+                    if li > 0 and pool_fused:
+                        out, arg, yarg = bn_pool_finish(pool_part, Y, st, seam_prev, pool_k)
+                        seam_prev = None
+                    else:
+                        out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)
                     saved.append((a, a_ss, Y, st, Wb, arg, yarg))
                 elif last or not BN_APPLY_FUSED:
                     if last and cfg.get("dropout") is not None:
@@ -886,7 +937,10 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
         return "generic", bool(FUSED_BWD_APPLY and not pool_k and not dropout), False
     Kp = a_in.shape[1]
     one_pass = (FUSED_BWD and need_dgrad and a_in.stride(0) == Kp and bool(h.cpfn_mlp_bwd_fused_ok(P, N, Kp))
-                and not (Kp == 192 and dropout))                    # (the 192-wide shape has no dropout variant)
+                and not (Kp == 192 and dropout)                     # (the 192-wide shape has no dropout variant)
+                and not (N == 64 and Kp == 128))                    # (64 <- 128 is the packed heads' LINEAR shape: no apply pass, no
+    #                                                                  riding reduction of a plain layer below; found in round 6 by a
+    #                                                                  128 -> 64 -> 128 test stack at 38400 rows)
     if one_pass:
         if pool_k:
             step_rows = 32 if Kp >= 128 else 64                     # rows per step of the one-pass kernel for this shape

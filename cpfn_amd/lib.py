@@ -94,6 +94,9 @@ SIGNATURES = {
     "cpfn_mlp_gemm_seam_ok": [_ll, _i, _i],
     "cpfn_mlp_gemm_seam": [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_gemm_xyz_seam": [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp],
+    "cpfn_mlp_gemm_pool_ok": [_ll, _i, _i, _i],
+    "cpfn_mlp_gemm_pool": [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "cpfn_bn_pool_finish": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_smallk_fwd_seam": [_vp, _i, _vp, _i, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_mlp_gemm_can_fuse_bwd_stats": [_ll, _i, _i],
     "cpfn_mlp_gemm_xyz_ok": [_ll, _i, _i],

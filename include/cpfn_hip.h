@@ -448,6 +448,21 @@ CPFN_API int cpfn_mlp_gemm_seam(const void *A, const void *W, long long P, int K
 /* cpfn_mlp_gemm_xyz / cpfn_smallk_fwd(_cast) as producers of a seam (stats_partial / partial replaced by `out`). */
 CPFN_API int cpfn_mlp_gemm_xyz_seam(const void *A, const void *W, const float *xyz, const float *Wx, long long P, int K, int N,
                                     void *Y, const cpfn_seam_out *out, void *stream);
+/* The pooled last layer of a set-abstraction stack (modules/pointset_abstraction.py:70-77: conv, batch_norm, relu, max over the K
+ * neighbours) WITHOUT a second pass over its [P, N] output: cpfn_mlp_gemm_pool is cpfn_mlp_gemm_seam's streaming kernel with the
+ * operand transform whose epilogue also leaves, per wave of 32 rows and channel, the raw y of the wave's winner of max(sign(gamma)*y)
+ * (pmax [P/32][N] bf16) and its row inside the group (pidx [P/32][N] u8; 255: none) — z = scale*y + shift is monotone in y with the
+ * sign of gamma, so the maximum over neighbours can be taken before the batch statistics exist.  cpfn_bn_pool_finish combines the
+ * pool_k/32 wave results of every group and applies the affine map to the winner: out / arg / yarg as cpfn_bn_relu_maxpool leaves
+ * them (out bit-identical; arg / yarg may name another row of a tie in z between different y), scale / shift from
+ * cpfn_bn_finalize's vectors or folded from the layer's seam `in` (then scale = shift = NULL).  pool_k in {32, 64, 128}. */
+CPFN_API int cpfn_mlp_gemm_pool_ok(long long P, int K, int N, int pool_k);
+CPFN_API int cpfn_mlp_gemm_pool(const void *A, const void *W, long long P, int K, int N, void *Y, float *stats_partial,
+                                const cpfn_seam_out *out, const cpfn_seam_in *in, const float *a_scale, const float *a_shift,
+                                int pool_k, const float *gamma, void *pmax, unsigned char *pidx, void *stream);
+CPFN_API int cpfn_bn_pool_finish(const void *pmax, const unsigned char *pidx, const void *Y, int G, int pool_k, int C,
+                                 const float *scale, const float *shift, const cpfn_seam_in *in, void *out, unsigned char *arg,
+                                 void *yarg, void *stream);
 CPFN_API int cpfn_smallk_fwd_seam(const cpfn_cast_desc *casts /* HOST array or NULL */, int n_casts, const float *X, int KS,
                                   const float *W, long long P, int C, void *Y, const cpfn_seam_out *out, void *stream);
 

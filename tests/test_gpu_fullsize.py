@@ -40,8 +40,14 @@ from oracle import pn2 as opn2
 
 pytestmark = pytest.mark.gpu
 
-GLOBAL = dict(B=16, K=28, mult=dict(miou=1.0, normal=1.0, type=1.0, parameter=1.0, residue=1.0, total=1.0))
-LOCAL = dict(B=32, K=21, mult=dict(miou=1.0, normal=1.0, type=1.0, parameter=0.0, residue=0.0, total=1.0))
+# `c_floor`: absolute bounds on (C), the replayed bf16 step against the fp32 oracle, at TWICE the error achieved on the final build of
+# round 6 (profiles/r06_fullsize_parity.txt: config 2 heads 0.31 / 0.33 / 0.26, agreement 0.66, gradient rel-L2 1.05, cosine 0.33, worst
+# loss 2.3e-2 relative; config 3 heads 0.32 / 0.33 / 0.27, agreement 0.67, gradient 0.80, cosine 0.68): heads rel-L2, 1 - agreement,
+# gradient rel-L2, 1 - cosine (capped at 0.85), worst relative loss error — VERDICT r5 #7
+GLOBAL = dict(B=16, K=28, mult=dict(miou=1.0, normal=1.0, type=1.0, parameter=1.0, residue=1.0, total=1.0),
+              c_floor=dict(head=0.66, match=0.33, grad_rel=2.1, grad_cos=0.15, loss_rel=4.6e-2))
+LOCAL = dict(B=32, K=21, mult=dict(miou=1.0, normal=1.0, type=1.0, parameter=0.0, residue=0.0, total=1.0),
+             c_floor=dict(head=0.66, match=0.34, grad_rel=1.6, grad_cos=0.37, loss_rel=4.6e-2))
 N = 8192
 
 
@@ -192,17 +198,19 @@ def _teacher_forced_stacks(model, batch, starts, tag):
             (y.float() * gout).sum().backward()
             return y.detach().float(), None if xin is None else xin.grad.float(), [p.grad.clone() for p in params]
         # the fused path first, with the arg-max rows its max-pool kernel chose recorded for the emulation
-        kernel_arg, orig_pool = {}, fused_mlp.bn_relu_maxpool
+        # (round 6: the pooling of the large stacks starts in the last GEMM's epilogue and ends in bn_pool_finish)
+        kernel_arg, orig_pool, orig_finish = {}, fused_mlp.bn_relu_maxpool, fused_mlp.bn_pool_finish
 
-        def pool_spy(*a, **k):
-            res = orig_pool(*a, **k)
+        def pool_spy(*a, _f=None, **k):
+            res = _f(*a, **k)
             kernel_arg["arg"] = res[1].clone()
             return res
-        fused_mlp.bn_relu_maxpool = pool_spy
+        fused_mlp.bn_relu_maxpool = lambda *a, **k: pool_spy(*a, _f=orig_pool, **k)
+        fused_mlp.bn_pool_finish = lambda *a, **k: pool_spy(*a, _f=orig_finish, **k)
         try:
             y16, gx16, gp16 = run(torch.bfloat16)
         finally:
-            fused_mlp.bn_relu_maxpool = orig_pool
+            fused_mlp.bn_relu_maxpool, fused_mlp.bn_pool_finish = orig_pool, orig_finish
         assert (pool_k is None) == ("arg" not in kernel_arg)
         y32, gx32, gp32 = run(torch.float32)
         yem, gxem, gpem = run("emulated")
@@ -303,7 +311,10 @@ def _compare(model, tr, batch_cpu, batch, starts, out, cfg, tag):
     assert rp["grad_cos"] > 0.12 and rp["match"] >= 0.5 and max(rp["head_X"], rp["head_T"], rp["head_W"]) < 0.5, rp
     assert rc["grad_cos"] > 0.1 and rc["match"] >= 0.4, rc
     assert rc["grad_rel"] <= 1.3 * rp["grad_rel"] + 1e-2, (rc, rp)
-    assert _losses_within(rc, 6e-2, 3e-3), rc
+    fl = cfg["c_floor"]
+    assert _losses_within(rc, fl["loss_rel"], 3e-3), rc
+    assert max(rc["head_X"], rc["head_T"], rc["head_W"]) < fl["head"] and rc["match"] >= fl["match"], (rc, fl)
+    assert rc["grad_rel"] < fl["grad_rel"] and rc["grad_cos"] > fl["grad_cos"], (rc, fl)
     # ---- (B) the fused bf16 stacks one by one at bench size
     _teacher_forced_stacks(model, batch, starts, tag)
 

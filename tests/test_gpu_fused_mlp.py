@@ -206,7 +206,10 @@ def test_atomic_seams_against_the_finalize_launch(name, P, cin, widths, pool_k, 
         stats[mode] = [t.clone() for t in grabbed[0]]
         monkeypatch.setattr(fused_mlp._FusedStack, "forward", orig)
         assert all(int(bn.num_batches_tracked) == 1 for bn in bns), mode
-    assert launches["finalize"] == len(widths) and launches["seam"] == 1, launches      # only the stack's last layer keeps its launch
+    # only the stack's last layer keeps its launch — unless its pooling starts in the GEMM (large pooled stacks): then the
+    # [G, C]-sized finish launch folds the last seam too
+    pooled_in_gemm = bool(pool_k) and bool(_l.lib().cpfn_mlp_gemm_pool_ok(P, widths[-2], widths[-1], pool_k))
+    assert launches["finalize"] == len(widths) and launches["seam"] == (0 if pooled_in_gemm else 1), launches
     rel = lambda a, b: float(((a.double() - b.double()).abs() / b.double().abs().clamp_min(1e-3)).max())
     for li, (sa, sb) in enumerate(zip(stats["seam"][:-1], stats["finalize"][:-1])):
         # (only the FIRST layer sees identical inputs on both routes; behind it the other route's own rounding flips move the sums)
@@ -248,6 +251,60 @@ def test_atomic_seam_poison_becomes_nan_statistics(bad, monkeypatch):
     if bad != bad:          # (a NaN input: the ordered sums are NaN too — identical behaviour down to the output bits)
         assert bool(torch.isnan(out[False][1]).all())
         assert torch.equal(out[True][0].nan_to_num(7.0), out[False][0].nan_to_num(7.0))
+
+
+@pytest.mark.parametrize("name,P,cin,widths,pool_k,use_xyz", [
+    ("sa1-size", 40 * 512 * 64, 3, [64, 64, 128], 64, True),
+    ("sa1-ragged-tiles", 643 * 64, 3, [64, 64, 128], 64, True),          # 41152 rows: the last 128-row tile holds one group
+    ("sa2-size", 16 * 128 * 64, 131, [128, 128, 256], 64, False),
+    ("pool32", 1300 * 32, 128, [128, 128], 32, False),
+    ("pool128", 300 * 128, 128, [64, 128], 128, False),
+])
+@pytest.mark.parametrize("seams", [True, False])
+def test_pooling_started_in_the_gemm_epilogue(name, P, cin, widths, pool_k, use_xyz, seams, monkeypatch):
+    """Round 6: the max over neighbours of a set-abstraction stack taken from the last GEMM's tile on its way out (per-wave winners
+    of max(sign(gamma) * y), before the batch statistics exist) + the [G, C]-sized cpfn_bn_pool_finish, against the stand-alone
+    cpfn_bn_relu_maxpool pass over the stored output: the SAME pooled output bits (max_k fma(s, y_k, t) = fma(s, max_k +-y_k, t):
+    rounding is monotone; the test stacks have negative gammas), the same arg-max rows except where two different y give the same z,
+    gradients equal up to those rows."""
+    from cpfn_amd import fused_mlp
+    monkeypatch.setattr(fused_mlp, "ATOMIC_SEAMS", seams)
+    convs, bns = _stack(cin, widths, seed=5)
+    g = torch.Generator().manual_seed(P + 3)
+    xyz = (torch.rand(P, 3, generator=g) * 0.4 - 0.2).to(dev()) if use_xyz else None
+    x = None if use_xyz else torch.randn(P, cin, generator=g).to(dev())
+    gout = torch.randn(P // pool_k, widths[-1], generator=g).to(dev())
+    res, args = {}, {}
+    for fused in (True, False):
+        monkeypatch.setattr(fused_mlp, "POOL_IN_GEMM", fused)
+        grabbed = []
+        orig = fused_mlp._FusedStack.forward
+
+        def spy(ctx, *a, _orig=orig, _g=grabbed):
+            out = _orig(ctx, *a)
+            _g.append((ctx.saved[-1][5].clone(), ctx.saved[-1][6].clone()))      # arg, yarg of the pooled layer
+            return out
+        monkeypatch.setattr(fused_mlp._FusedStack, "forward", staticmethod(spy))
+        with fused_mlp.seam_pass(dev(), True):
+            res[fused] = _run(x, convs, bns, torch.bfloat16, pool_k, xyz, gout)
+        monkeypatch.setattr(fused_mlp._FusedStack, "forward", orig)
+        args[fused] = grabbed[0]
+    (ya, gxa, gra, sta), (yb, gxb, grb, stb) = res[True], res[False]
+    # with the seams on, the LAST layer's statistics are fixed-point on one route and ordered sums on the other (the stand-alone
+    # pooling pass cannot consume a seam): ~1e-7 apart, a handful of bf16 roundings; without them: the same bits
+    same_stats = not seams
+    if same_stats:
+        assert torch.equal(ya, yb)
+    else:
+        assert _rel(ya, yb) < 1e-3
+    differ = float((args[True][0] != args[False][0]).float().mean())
+    assert differ < (1e-4 if same_stats else 2e-3), differ
+    if same_stats:
+        sel = args[True][0] == args[False][0]
+        assert torch.equal(args[True][1][sel], args[False][1][sel])
+    for a, b in zip(gra, grb):
+        assert (a is None and b is None) or _rel(a, b) < (2e-3 if same_stats else 5e-3), _rel(a, b)
+    assert (gxa is None) or _rel(gxa, gxb) < 5e-3
 
 
 def test_heads_linear():

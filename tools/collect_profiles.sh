@@ -2,7 +2,7 @@
 # Everything profiles/ is refreshed from, in one gpurun call (run on the GPU box from the repo root):
 #   bash tools/collect_profiles.sh [tag]  ->  gpurun_out/collect/... and profiles/<tag>_*
 # Counter passes are separate runs with --kernel-trace only (never combined with sys/hip/hsa tracing), eager launches.
-tag=${1:-r05}
+tag=${1:-r06}
 repo=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd "$repo"
@@ -29,6 +29,9 @@ python3 tools/fps_latency.py gpurun_out/collect/fps_latency_table.md > /dev/null
 python3 tools/cascade_probe.py > profiles/${tag}_cascade_probe.txt 2> gpurun_out/collect/cascade.err
 cp gpurun_out/collect/fps_latency_table.md profiles/${tag}_fps_latency_table.md 2>/dev/null
 (CPFN_CSR_RADIX=0 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=1024 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=256 python3 tools/dbg/csr_time.py; CPFN_CSR_THREADS=-1 python3 tools/dbg/csr_time.py; python3 tools/dbg/csr_time.py) > profiles/${tag}_csr_time.txt 2> gpurun_out/collect/csr.err
+# what the full-size parity tests ACHIEVED on this build: (A) fp32 mode, (B) every fused stack teacher-forced at bench
+# size, (C) the replayed bf16 step against the fp32 oracle, and the fitters' worst per-instance errors at full size
+python3 -m pytest tests/test_gpu_fullsize.py tests/test_gpu_fitters.py -m gpu -s -q 2>&1 | grep -E "^\[|per-instance|accepted|passed|failed" > profiles/${tag}_fullsize_parity.txt
 # bench.py reads roofline.traffic from profiles/<tag>_family_traffic.json: a file older than the library it describes is a lie
 if [ ! -s profiles/${tag}_family_traffic.json ] || [ profiles/${tag}_family_traffic.json -ot cpfn_amd/libcpfn_hip.so ]; then
   echo "collect_profiles: profiles/${tag}_family_traffic.json is missing or older than cpfn_amd/libcpfn_hip.so" >&2
