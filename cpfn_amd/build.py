@@ -33,7 +33,12 @@ SOURCES = {
     "fit_algebra.hip": ["-ffp-contract=off"],
     "mlp_fwd.hip": [],
     "mlp_small.hip": [],
-    "mlp_bwd_fused.hip": [],
+    # (-fno-slp-vectorize, round 6: with the SLP vectoriser's v_pk_fma_f32 the xyz weight-gradient sums that ride on the 64 <- 64
+    #  one-pass kernel came out DIFFERENT from run to run in a few accumulators — 2e-4 relative, same inputs, one kernel alone on the
+    #  chip, no neighbour: packed fp32 in a kernel whose other waves read their operands transposed out of LDS, the round-4 fault
+    #  inside ONE kernel (tools/dbg/xw_sens3.py).  Without it: bit-identical runs, 2e-8 from an fp64 reference,
+    #  same registers, +2 us per step.  CPFN_BWD_SLP=1 builds the faulty form for the reproducer.)
+    "mlp_bwd_fused.hip": [] if os.environ.get("CPFN_BWD_SLP") == "1" else ["-fno-slp-vectorize"],
     "bn.hip": [],
     "losses.hip": [],
     "merging.hip": [],
@@ -89,6 +94,7 @@ _SCRATCH_OK = ()
 # neighbors.hip, and the sampling instantiations without it (fps_resident_kernel<.., PROFILE = false, PK = false>).
 _PACKED_F32 = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
 _NO_PACKED = {"neighbors.hip": lambda name: True,
+              "mlp_bwd_fused.hip": lambda name: os.environ.get("CPFN_BWD_SLP") != "1",
               "sampling.hip": lambda name: "fps_resident_kernel" in name and "ELb0ELb0EEEv" in name}     # <.., PROFILE = false, PK = false>
 _KERNEL_BODY = re.compile(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", re.M | re.S)
 _KERNEL_META = re.compile(r"\.name:\s+(\S+)\s*\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)")

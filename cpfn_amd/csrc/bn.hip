@@ -513,6 +513,7 @@ struct MsrArgsT {
   int row_in[MAXB], row_out[MAXB];   // 0, 0: flat; else only the first row_out of every row_in elements are kept
   int out_ld[MAXB];                  // ... at row stride out_ld of the output (>= row_out; a slice of a wider matrix)
   int deep[MAXB];              // 1: few outputs, many splits: 16 elements x 16 split-subsets per workgroup instead of 64 x 4; 2: wide
+  const float *coef[MAXB];     // non-NULL: the "xyz weight gradient" form (see msr_body)
   int block0[MAXB + 1];        // first workgroup of buffer i
   int count;
 };
@@ -534,6 +535,37 @@ __device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
   const float *__restrict__ partial = a.partial[d];
   const long long n = a.n[d];
   const int splits = a.splits[d];
+  if (a.coef[d]) {
+    // The weight gradient of an fp32-xyz first layer (sa1) from sums that rode on the one-pass kernel of the layer above
+    // (mlp_bwd_fused_kernel, XW): dW[c][j] = sum_p g_y[p,c] x[p,j] with g_y = c0 g_z + c1 y + c2 is LINEAR in the BatchNorm
+    // coefficients, so the kernel that produces g_z — before the coefficients exist — accumulates S1 = sum g_z x_j, S2 = sum y x_j,
+    // S3 = sum x_j per split and this reduction forms c0[c] S1[c][j] + c1[c] S2[c][j] + c2[c] S3[j]: the layer's stand-alone
+    // weight-gradient launch and the [P, C] gradient tensor it read never exist.  partial [splits][7][C] (rows 0-2 S1, 3-5 S2,
+    // row 6: S3 in its first three entries), C = row_in, out [C][3].  16 outputs x 16 split subsets per workgroup, fixed order.
+    float (*s3)[16][3] = (float (*)[16][3])s_acc;        // [16 subsets][16 lanes][3]
+    const int C = a.row_in[d];
+    const int lane = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const long long e = (long long)(bid - a.block0[d]) * 16 + lane;
+    const int c = (int)(e / 3), j = (int)(e - (long long)c * 3);
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < n) {
+#pragma unroll 4
+      for (int i = r; i < splits; i += 16) {
+        const float *pp = partial + (size_t)i * 7 * C;
+        a1 += pp[j * C + c]; a2 += pp[(3 + j) * C + c]; a3 += pp[6 * C + j];
+      }
+    }
+    s3[r][lane][0] = a1; s3[r][lane][1] = a2; s3[r][lane][2] = a3;
+    __syncthreads();
+    if (r == 0 && e < n) {
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { t1 += s3[q][lane][0]; t2 += s3[q][lane][1]; t3 += s3[q][lane][2]; }
+      const float *cf = a.coef[d];
+      a.out[d][e] = fmaf(cf[c], t1, fmaf(cf[C + c], t2, cf[2 * C + c] * t3));
+    }
+    return;
+  }
   if (a.deep[d] == 4) {
     // "wide-deep" (round 4, large buffers with >= 64 partial rows): 64 elements (16 lanes x float4: 256-byte runs) x 16 subsets
     // per workgroup — a lane adds 16 of 256 rows (two batches of eight loads) instead of 64 (eight batches): four times the
@@ -1120,10 +1152,18 @@ static int msr_fill(ARGS &a, const cpfn_reduce_desc *descs, int count, int *bloc
   for (int i = 0; i < count; ++i) {
     const cpfn_reduce_desc &d = descs[i];
     if (!d.partial || !d.out || d.splits <= 0 || d.n <= 0 || d.row_in < 0 || d.row_out < 0 || d.row_out > d.row_in || (d.out_ld != 0 && (d.row_in == 0 || d.out_ld < d.row_out)) ||
-        (d.row_in > 0 && (d.row_out == 0 || d.n % d.row_in))) return CPFN_EINVAL;
+        (!d.coef && d.row_in > 0 && (d.row_out == 0 || d.n % d.row_in))) return CPFN_EINVAL;
     a.partial[i] = d.partial; a.out[i] = d.out; a.n[i] = d.n; a.splits[i] = d.splits;
     a.row_in[i] = d.row_in; a.row_out[i] = d.row_out;
     a.out_ld[i] = d.out_ld > 0 ? d.out_ld : d.row_out;
+    a.coef[i] = d.coef;
+    if (d.coef) {          // the xyz weight-gradient form: n = 3 C outputs from [splits][7][C] partials (row_in = C)
+      if (d.row_in <= 0 || d.n != 3LL * d.row_in) return CPFN_EINVAL;
+      a.deep[i] = 1;
+      a.block0[i] = blocks;
+      blocks += cpfn_cdiv(d.n, 16);
+      continue;
+    }
     a.deep[i] = d.n <= 1024 && d.splits >= 128;
     if (!a.deep[i] && d.n >= 4096 && d.n % 4 == 0 && (((uintptr_t)d.partial | (d.row_in == 0 ? (uintptr_t)d.out : 0)) & 15) == 0)
       a.deep[i] = d.splits >= 64 ? 4 : 2;   // wide (float4 per lane; 2: the 64 x 4 layout's order of additions) / wide-deep (4: 16 subsets)

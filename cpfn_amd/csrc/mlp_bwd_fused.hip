@@ -37,6 +37,8 @@ struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the
   long long groups;
   const float *xt_xyz;                       // XT: [P,3] fp32 coordinates that are three more input channels of the layer
   float *xt_partial;                         //     [splits][TN][3]: split partials of their weight-gradient columns
+  const float *xw_xyz;                       // XW: [P,3] fp32 coordinates, the ONLY input of the layer below (sa1's first layer) ...
+  float *xw_partial;                         //     [splits][7][TK]: S1 = sum g_z x_j, S2 = sum y x_j (j < 3), S3 = sum x_j — see below
 };
 
 // (Round 2 also had an instantiation that RECOMPUTED sa1's first-layer output from the coordinates inside the 64 -> 64
@@ -46,7 +48,12 @@ struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the
 // no data gradient (coordinates are inputs) and their weight-gradient columns dWx [TN,3] = g_y^T . xyz ride along: the
 // 32 x 3 coordinate tile of a step is staged as bf16 beside the input tile and costs the four waves that own wk = 0 MI MFMAs
 // more per step.
-template <int TN, int TK, int STEP, bool BST, int APPLY, bool XT = false, bool BDROP = false>
+// XW (round 6; with BST): the layer BELOW is an fp32-xyz first layer (sa1: y = W0 . x, three coordinates in, no data gradient).
+// Its weight gradient dW0[c][j] = sum_p g_y[p,c] x[p,j], g_y = c0 g_z + c1 y + c2, is linear in the BatchNorm coefficients — which
+// do not exist yet when this kernel forms g_z — so the riding reduction also accumulates S1 = sum g_z x_j, S2 = sum y x_j and
+// S3 = sum x_j per split; cpfn_multi_split_reduce's coefficient form (bn.hip) finishes c0 S1 + c1 S2 + c2 S3.  With Gout = NULL
+// the slab is not stored either: the 67 MB gradient w.r.t. that layer's output and the 30 us launch that read it are gone.
+template <int TN, int TK, int STEP, bool BST, int APPLY, bool XT = false, bool BDROP = false, bool XW = false>
 __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     const unsigned short *__restrict__ Gy, int ldg, const unsigned short *__restrict__ A, int lda,
     const unsigned short *__restrict__ W /* forward weight panel [TN][TK] bf16 */, long long P, long long rows_per_split,
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // gradient w.r.t. the DROPPED activation — the riding reduction scales it by the mask recomputed from the 8-byte seed, as
   // bn_relu_bwd_kernel<true> does (that launch, 15 us on the fc1 features, is then not made).
   static_assert(!BDROP || (BST && APPLY == 0), "the layer below's dropout belongs to the riding reduction of a linear layer");
+  static_assert(!XW || (BST && !BDROP && !XT), "the xyz weight-gradient sums ride on the reduction of the layer below");
   const unsigned long long bdrop_seed = BDROP ? *ap.drop_seed : 0ull;
   // DEPTH = 2 steps of rows in flight for every shape (round 4; the 32-row-step shapes of 128 channels had four).  The riding
   // reduction's rows (yb below) are consumed a step after they are requested, and loads return in order: whatever was requested
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
     for (int e = t; e < TN * TK; e += NT) o[e] = 0.f;
     if (XT) for (int e = t; e < TN * 3; e += NT) ap.xt_partial[(size_t)blockIdx.z * TN * 3 + e] = 0.f;
     if (BST) for (int e = t; e < 2 * TK; e += NT) stats_partial[(size_t)blockIdx.z * 2 * TK + e] = 0.f;
+    if (XW) for (int e = t; e < 7 * TK; e += NT) ap.xw_partial[(size_t)blockIdx.z * 7 * TK + e] = 0.f;
     probe_end(probe, probe_t0, 5);
     return;
   }
@@ -164,6 +173,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   if (BST) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { bsc[j] = b_scale[acol + j]; bsh[j] = b_shift[acol + j]; st_s[j] = 0.f; st_q[j] = 0.f; }
+  }
+  float xw1[XW ? 8 : 1][3], xw2[XW ? 8 : 1][3], xw3[3] = {0.f, 0.f, 0.f};      // XW: the lane's shares of S1, S2 (its 8 channels), S3
+  if (XW) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { xw1[j][q] = 0.f; xw2[j][q] = 0.f; }
   }
   auto issue = [&](int sidx, long long base) {
     if (APPLY == 2) {
@@ -287,11 +303,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
   // 6 % faster still when the kernel runs alone on HBM-resident operands and LOSES inside the step: 4-8 registers more per wave
   // are what a one-pass launch cannot afford beside the geometry work)
   uint4 yb[NA];
+  float xr[XW ? NA : 1][3];          // XW: the coordinates of the same rows
   auto issue_yb = [&](long long base) {
     if (BST) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i)
-        yb[i] = *(const uint4 *)(Yb + min(base + arow + i * RPA, p1 - 1) * ldo + acol);
+      for (int i = 0; i < NA; ++i) {
+        const long long pr = min(base + arow + i * RPA, p1 - 1);
+        yb[i] = *(const uint4 *)(Yb + pr * ldo + acol);
+        if (XW) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) xr[XW ? i : 0][q] = ap.xw_xyz[pr * 3 + q];
+        }
+      }
     }
   };
   auto store_prev = [&](long long pbase, int buf) {
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       const long long p = pbase + r;
       const uint4 v = *(const uint4 *)&s_o[r * LDK + acol];
       if (p < p1) {
-        {   // (`nt` store: see stream_tile in mlp_fwd.hip)
+        if (!XW || Gout) {   // (`nt` store: see stream_tile in mlp_fwd.hip; XW with Gout = NULL: nobody reads this gradient)
           typedef __attribute__((ext_vector_type(4))) unsigned u32x4nt;
           __builtin_nontemporal_store((u32x4nt){v.x, v.y, v.z, v.w}, (u32x4nt *)(Gout + p * ldo + acol));
         }
@@ -321,6 +344,20 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
             const float z1 = fmaf(bsc[2 * j + 1], y1, bsh[2 * j + 1]) > 0.f ? g1 : 0.f;
             st_s[2 * j] += z0; st_s[2 * j + 1] += z1;
             st_q[2 * j] = fmaf(z0, y0, st_q[2 * j]); st_q[2 * j + 1] = fmaf(z1, y1, st_q[2 * j + 1]);
+            if (XW) {
+#pragma unroll
+              for (int q = 0; q < 3; ++q) {
+                const float xq = xr[XW ? i : 0][q];
+                xw1[XW ? 2 * j : 0][q] = fmaf(z0, xq, xw1[XW ? 2 * j : 0][q]);
+                xw1[XW ? 2 * j + 1 : 0][q] = fmaf(z1, xq, xw1[XW ? 2 * j + 1 : 0][q]);
+                xw2[XW ? 2 * j : 0][q] = fmaf(y0, xq, xw2[XW ? 2 * j : 0][q]);
+                xw2[XW ? 2 * j + 1 : 0][q] = fmaf(y1, xq, xw2[XW ? 2 * j + 1 : 0][q]);
+              }
+            }
+          }
+          if (XW && acol == 0) {           // (every row once: the lane of its first chunk)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xw3[q] += xr[XW ? i : 0][q];
           }
         }
       }
@@ -476,6 +513,55 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
       stats_partial[((size_t)blockIdx.z * 2 + which) * TK + c] = v;
     }
   }
+  if (XW) {
+    // the same two-level sum for S1, S2 (3 x TK values each) and S3 (3 values), one after the other through the same LDS patch
+    static_assert(!XW || sizeof(float) * 8 * 3 * TK <= sizeof(unsigned short) * STEP * LDN, "the XW reduction reuses s_g");
+    float(*s_x)[3][TK] = (float(*)[3][TK])s_g2[0];
+    float *xo = ap.xw_partial + (size_t)blockIdx.z * 7 * TK;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float (&xs)[XW ? 8 : 1][3] = pass == 0 ? xw1 : xw2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int m = CPRA; m < 64; m <<= 1) xs[XW ? j : 0][q] += __shfl_xor(xs[XW ? j : 0][q], m, 64);
+      __syncthreads();
+      if (lane < CPRA) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) s_x[wave][q][lane * 8 + j] = xs[XW ? j : 0][q];
+      }
+      __syncthreads();
+      for (int e = t; e < 3 * TK; e += NT) {
+        const int q = e / TK, c = e - q * TK;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += s_x[w][q][c];
+        xo[(pass * 3 + q) * TK + c] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int m = CPRA; m < 64; m <<= 1) xw3[q] += __shfl_xor(xw3[q], m, 64);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s_x[wave][q][0] = xw3[q];      // (one word per row of the patch: three adjacent words would be a 96-bit DS write, banned)
+    }
+    __syncthreads();
+    if (t < TK) {
+      float v = 0.f;
+      if (t < 3) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += s_x[w][t][0];
+      }
+      xo[6 * TK + t] = v;
+    }
+  }
   probe_end(probe, probe_t0, 5);
 }
 
@@ -490,14 +576,18 @@ extern "C" int cpfn_mlp_bwd_fused_ok(long long P, int N, int K) {
   return shape && P > SP_MAX_ROWS && P >= 32768;
 }
 
-extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
-                                  const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
-                                  const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
-                                  const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
-                                  const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
-                                  const void *pool_yarg, int pool_k, const float *xt_xyz,
-                                  float *xt_partial, void *stream) {
-  if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gy || !A || !W || !workspace || !Gout || (ldg & 7) || (lda & 7) || (ldo & 7) ||
+static int bwd_fused_launch(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
+                            const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
+                            const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                            const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
+                            const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
+                            const void *pool_yarg, int pool_k, const float *xt_xyz,
+                            float *xt_partial, const float *xw_xyz, float *xw_partial, void *stream) {
+  // xw (the xyz weight-gradient sums of the layer below riding on its reduction): the 64 <- 64 shape with the dense apply pass,
+  // sa1's second layer; Gout may then be NULL (nobody needs the gradient w.r.t. the first layer's output)
+  if ((!xw_xyz) != (!xw_partial)) return CPFN_EINVAL;
+  if (xw_xyz && !(N == 64 && K == 64 && bwd_y && apply_y && !drop_seed && pool_k == 0 && !xt_xyz)) return CPFN_EINVAL;
+  if (!cpfn_mlp_bwd_fused_ok(P, N, K) || !Gy || !A || !W || !workspace || (!Gout && !xw_xyz) || (ldg & 7) || (lda & 7) || (ldo & 7) ||
       ldg < N || lda < K || ldo < K || (!a_scale != !a_shift) || (bwd_y && (!b_scale || !b_shift || !stats_partial)) ||
       (apply_y && (!apply_coef || !y_scale || !y_shift)))
     return CPFN_EINVAL;
@@ -528,6 +618,7 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
   ap.pool_arg = pool_arg; ap.pool_yarg = (const unsigned short *)pool_yarg; ap.pool_k = pool_k > 0 ? pool_k : 1;
   ap.groups = pool_k > 0 ? P / pool_k : 1;
   ap.xt_xyz = xt_xyz; ap.xt_partial = xt_partial;
+  ap.xw_xyz = xw_xyz; ap.xw_partial = xw_partial;
   const int mode = !apply_y ? 0 : (pool_k > 0 ? 2 : (drop_seed ? 3 : 1));
 #define CPFN_BWD_FUSED(TN_, TK_, STEP_, BST_, APPLY_)                                                                      \
   mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
@@ -549,7 +640,11 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
       else CPFN_BWD_FUSED(TN_, TK_, STEP_, false, 0);                          \
     }                                                                          \
   } while (0)
-  if (xt_xyz)
+  if (xw_xyz)
+    mlp_bwd_fused_kernel<64, 64, 64, true, 1, false, false, true><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo,
+                                                                                        a_scale, a_shift, yb, b_scale, b_shift,
+                                                                                        stats_partial, ap, probe_slot_all(grid));
+  else if (xt_xyz)
     mlp_bwd_fused_kernel<128, 128, 32, false, 1, true><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, a_scale,
                                                                              a_shift, yb, b_scale, b_shift, stats_partial, ap,
                                                                              probe_slot_all(grid));
@@ -568,4 +663,30 @@ extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int ld
 #undef CPFN_BWD_FUSED_SHAPE
 #undef CPFN_BWD_FUSED
   return cpfn_launch_status();
+}
+
+extern "C" int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda, const void *W, long long P, int N, int K,
+                                  const float *a_scale, const float *a_shift, float *workspace, void *Gout, int ldo,
+                                  const void *bwd_y, const float *b_scale, const float *b_shift, float *stats_partial,
+                                  const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
+                                  const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
+                                  const void *pool_yarg, int pool_k, const float *xt_xyz,
+                                  float *xt_partial, void *stream) {
+  return bwd_fused_launch(Gy, ldg, A, lda, W, P, N, K, a_scale, a_shift, workspace, Gout, ldo, bwd_y, b_scale, b_shift, stats_partial,
+                          apply_y, apply_coef, y_scale, y_shift, drop_seed, drop_p, pool_arg, pool_yarg, pool_k, xt_xyz, xt_partial,
+                          nullptr, nullptr, stream);
+}
+
+// The 64 <- 64 one-pass launch (sa1's second layer) with the weight-gradient sums of the fp32-xyz FIRST layer riding on its
+// reduction of that layer (mlp_bwd_fused_kernel, XW): xw_xyz [P,3] the first layer's input, xw_partial [splits][7][64] (S1, S2, S3;
+// finished by cpfn_multi_split_reduce with cpfn_reduce_desc.coef).  Gout may be NULL: the gradient w.r.t. the first layer's output
+// is then never stored.
+extern "C" int cpfn_mlp_bwd_fused_xw(const void *Gy, const void *A, const void *W, long long P, int N, int K, const float *a_scale,
+                                     const float *a_shift, float *workspace, void *Gout, const void *bwd_y, const float *b_scale,
+                                     const float *b_shift, float *stats_partial, const void *apply_y, const float *apply_coef,
+                                     const float *y_scale, const float *y_shift, const float *xw_xyz, float *xw_partial,
+                                     void *stream) {
+  if (!xw_xyz || !xw_partial) return CPFN_EINVAL;
+  return bwd_fused_launch(Gy, N, A, K, W, P, N, K, a_scale, a_shift, workspace, Gout, K, bwd_y, b_scale, b_shift, stats_partial, apply_y,
+                          apply_coef, y_scale, y_shift, nullptr, 0.f, nullptr, nullptr, 0, nullptr, nullptr, xw_xyz, xw_partial, stream);
 }

@@ -520,6 +520,10 @@ typedef struct { const float *partial; float *out; long long n; int splits;
                                          row_out are kept: out is [n/row_in, row_out] (zero-padded K) ... */
                  int out_ld;          /* ... at row stride out_ld (0 = row_out: compact; > row_out: a column slice of a wider
                                          matrix, e.g. the 128 feature columns and the 3 coordinate columns of one [N,131] weight) */
+                 const float *coef;   /* NULL — or the BatchNorm-backward coefficients [3][C] of an fp32-xyz first layer whose weight
+                                         gradient is formed HERE from sums that rode on the layer above's cpfn_mlp_bwd_fused launch (xw_*):
+                                         partial [splits][7][C] (S1 = sum g_z x_j, S2 = sum y x_j, S3 = sum x_j), row_in = C, n = 3 C,
+                                         out [C][3] = c0 S1 + c1 S2 + c2 S3 */
 } cpfn_reduce_desc;
 CPFN_API int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs /* HOST array */, int count, void *stream);
 /* cpfn_bn_bwd_finalize with up to 6 such reductions riding on the same launch as further workgroups (the weight-gradient partials
@@ -572,6 +576,18 @@ CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda,
                                 const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
                                 const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
                                 const void *pool_yarg, int pool_k, const float *xt_xyz, float *xt_partial, void *stream);
+/* The 64 <- 64 shape of cpfn_mlp_bwd_fused (sa1's second layer: dense apply pass, riding reduction of the layer below) when the
+ * layer BELOW is the fp32-xyz first layer (modules/pointset_abstraction.py:70: the first 1x1 convolution over the centred
+ * coordinates): that layer's weight gradient dW0[c][j] = sum_p g_y[p,c] x[p,j], g_y = c0 g_z + c1 y + c2, is linear in its
+ * BatchNorm-backward coefficients, so its sums S1 = sum g_z x_j, S2 = sum y x_j, S3 = sum x_j ride on this launch
+ * (xw_xyz [P,3], xw_partial [splits][7][64]) and cpfn_multi_split_reduce finishes c0 S1 + c1 S2 + c2 S3 once the coefficients exist
+ * (cpfn_reduce_desc.coef): cpfn_smallk_wgrad_apply_xyz is not launched, and with Gout = NULL the gradient w.r.t. the first layer's
+ * output is never stored.  ldg = N, lda = ldo = K. */
+CPFN_API int cpfn_mlp_bwd_fused_xw(const void *Gy, const void *A, const void *W, long long P, int N, int K, const float *a_scale,
+                                   const float *a_shift, float *workspace, void *Gout, const void *bwd_y, const float *b_scale,
+                                   const float *b_shift, float *stats_partial, const void *apply_y, const float *apply_coef,
+                                   const float *y_scale, const float *y_shift, const float *xw_xyz, float *xw_partial,
+                                   void *stream);
 /* Column sums of a row-major fp32 matrix X[P,C], C <= 64 (bias gradient of the fc2 heads).
  * workspace: ceil(P/256)*C floats.  pad_bf16 (optional): [P,64] bf16, receives the rows of X converted to bf16
  * and zero-padded to 64 columns in the same pass (the gradient operand of the heads' GEMMs).
