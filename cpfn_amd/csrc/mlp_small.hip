@@ -351,6 +351,18 @@ __device__ __forceinline__ void mlp_wgrad_body(WgradLds<TN, TK> &lds, int bx, in
       }
 }
 
+// workgroup `L` of a (gx, gy, gz = splits) weight-gradient grid -> (tile x, tile y, split z) with all tiles of a split on one XCD
+__device__ __forceinline__ void wgrad_xcd_map_linear(int L, int gx, int gy, int gz, int &bx, int &by, int &bz) {
+  const int tiles = gx * gy;
+  if (gz & 7) { bx = L % gx; by = (L / gx) % gy; bz = L / tiles; return; }
+  const int j = L >> 3, t = j % tiles;
+  bz = (L & 7) + 8 * (j / tiles);
+  bx = t % gx; by = t / gx;
+}
+__device__ __forceinline__ void wgrad_xcd_map(int &bx, int &by, int &bz, int gx, int gy, int gz) {
+  wgrad_xcd_map_linear(bx + gx * (by + gy * bz), gx, gy, gz, bx, by, bz);
+}
+
 template <int TN, int TK>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__restrict__ Gy, int ldg,
                                                         const unsigned short *__restrict__ A, int lda,
@@ -361,7 +373,12 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const unsigned short *__
                                                         unsigned long long *probe = nullptr) {
   const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ WgradLds<TN, TK> lds;
-  mlp_wgrad_body<TN, TK>(lds, blockIdx.x, blockIdx.y, blockIdx.z, Gy, ldg, A, lda, gidx, P, N, K, rows_per_split, partial, a_scale, a_shift);
+  // XCD-aware (round 6): the (N / TN) x (K / TK) tiles of one row split read the SAME rows of g_y and of the input; consecutive
+  // workgroup ids go round-robin over the 8 XCDs, so with the plain (x, y, z) order every split's rows were fetched into every L2
+  // (1.64 x the launch's bytes from HBM in round 5's counters).  Here XCD k takes splits k, k + 8, ..., all tiles of a split in a row.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  wgrad_xcd_map(bx, by, bz, (int)gridDim.x, (int)gridDim.y, (int)gridDim.z);
+  mlp_wgrad_body<TN, TK>(lds, bx, by, bz, Gy, ldg, A, lda, gidx, P, N, K, rows_per_split, partial, a_scale, a_shift);
   probe_end(probe, probe_t0, 4);
 }
 
@@ -382,8 +399,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_small_kernel(
   __shared__ union U { WgradLds<64, 64> w; SmallpLds<32> d; __device__ U() {} } lds;
   const int b = blockIdx.x;
   if (b < gr.nW) {
-    const int bx = b % gr.wgx, r = b / gr.wgx;
-    mlp_wgrad_body<64, 64>(lds.w, bx, r % gr.wgy, r / gr.wgy, Gy, ldg, A, lda, nullptr, P, N, K, rows_per_split, partial, a_scale, a_shift);
+    int bx, by, bz;            // (all tiles of a row split on one XCD: see mlp_wgrad_kernel)
+    wgrad_xcd_map_linear(b, gr.wgx, gr.wgy, gr.nW / (gr.wgx * gr.wgy), bx, by, bz);
+    mlp_wgrad_body<64, 64>(lds.w, bx, by, bz, Gy, ldg, A, lda, nullptr, P, N, K, rows_per_split, partial, a_scale, a_shift);
   } else {
     const int d = b - gr.nW;
     // in the small-P kernel's terms: operand = g_y [P, N] (contraction over the layer's N output channels), outputs = K channels
