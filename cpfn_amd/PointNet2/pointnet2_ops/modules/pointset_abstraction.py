@@ -105,8 +105,12 @@ class PointsetAbstraction(nn.Module):
                         if fused_mlp.xyz_tail_ok(B * S * k, D, convs_of_scale[0].weight.shape[0]):
                             # long layers: the coordinates do not become three bf16 columns of a K = 192 operand — they
                             # reach the first layer as its fp32 xyz tail (cpfn_mlp_gemm_xyz) and the rows are the gather alone
-                            x = autograd_ops.GroupConcat.apply(feats, None, nbr, D, inv[0], inv[1], join)
-                            groups.append((x, None, S, k, rel.reshape(B * S * k, 3)))
+                            # (round 6: ... and not even that — the first layer's GEMM and its backward kernel read the rows out of
+                            #  `feats` through `nbr` while loading their operand; `x` only carries the autograd edge)
+                            lazy = fused_mlp.gather_on_load_ok(B, N, S * k, D)
+                            x = autograd_ops.GroupConcat.apply(feats, None, nbr, D, inv[0], inv[1], join, lazy)
+                            groups.append((x, None, S, k, rel.reshape(B * S * k, 3),
+                                           (feats.contiguous().reshape(B * N, D), nbr.reshape(-1), S * k, N) if lazy else None))
                             continue
                         x = autograd_ops.GroupConcat.apply(feats, rel, nbr, (D + 3 + 63) // 64 * 64, inv[0], inv[1], join)
                     else:
@@ -118,7 +122,8 @@ class PointsetAbstraction(nn.Module):
         outs = []
         for grp, convs, bns in zip(groups, self.conv_blocks, self.bn_blocks):
             x, xyz_rows, S, k = grp[:4]
-            y = mlp.run_stack(x, convs, bns, cd, pool_k=k, xyz_rows=xyz_rows, xyz_tail=grp[4] if len(grp) > 4 else None)  # max over the K neighbours (ref :74)
+            y = mlp.run_stack(x, convs, bns, cd, pool_k=k, xyz_rows=xyz_rows, xyz_tail=grp[4] if len(grp) > 4 else None,
+                              gather=grp[5] if len(grp) > 5 else None)  # max over the K neighbours (ref :74)
             outs.append(y.reshape(B, S, -1))
         return new_xyz, torch.cat(outs, dim=2) if len(outs) > 1 else outs[0], aux
 

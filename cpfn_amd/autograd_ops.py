@@ -132,7 +132,10 @@ class GroupConcat(torch.autograd.Function):
     the coordinates then reach the first layer as its fp32 "xyz tail" (fused_mlp)."""
 
     @staticmethod
-    def forward(ctx, feats, rel, idx, cpad, inv_off=None, inv_ent=None, join=None):
+    def forward(ctx, feats, rel, idx, cpad, inv_off=None, inv_ent=None, join=None, lazy=False):
+        """lazy (round 6, rel None): the rows are NOT gathered — the consumer (fused_mlp: cpfn_mlp_gemm_xyz_gather and the backward
+        kernel's twin) reads them out of `feats` through `idx` while loading its operand; the returned tensor is uninitialised
+        storage that only carries the autograd edge (its gradient arrives here as before)."""
         B, N, C = feats.shape
         R = idx[0].numel()
         f = feats.contiguous()
@@ -141,10 +144,11 @@ class GroupConcat(torch.autograd.Function):
             join.src, join.armed, join.addend = SkipJoin.key(f), False, None
             ctx.join = join
         out = torch.empty(B * R, cpad, dtype=torch.bfloat16, device=f.device)
-        with torch.cuda.device(f.device):
-            _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), None if rel is None else _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
-                                                     _stream()), "cpfn_group_concat_bf16")
-        _l.add_bytes("cpfn_group_concat_bf16", 2 * B * N * C + 16 * B * R + 2 * B * R * cpad)
+        if not (lazy and rel is None):
+            with torch.cuda.device(f.device):
+                _l.check(_l.lib().cpfn_group_concat_bf16(_ptr(f), None if rel is None else _ptr(rel.contiguous()), _ptr(idx), B, N, R, C, cpad, _ptr(out),
+                                                         _stream()), "cpfn_group_concat_bf16")
+            _l.add_bytes("cpfn_group_concat_bf16", 2 * B * N * C + 16 * B * R + 2 * B * R * cpad)
         ctx.save_for_backward(idx)
         ctx.inv = None if inv_off is None else (inv_off, inv_ent)
         ctx.dims = (B, N, R, C, cpad)
@@ -161,8 +165,8 @@ class GroupConcat(torch.autograd.Function):
             if j is not None and j.addend is not None:
                 addend, ld_add = j.addend
                 j.addend = None
-            return _csr_sum_bf16(g, cpad, ctx.inv, None, 1, B, R, N, C, addend, ld_add), None, None, None, None, None, None
-        return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None, None, None, None
+            return _csr_sum_bf16(g, cpad, ctx.inv, None, 1, B, R, N, C, addend, ld_add), None, None, None, None, None, None, None
+        return _scatter_bf16(g, cpad, idx, None, 1, B, R, N, C).to(torch.bfloat16), None, None, None, None, None, None, None
 
 
 class ConcatPosFeats(torch.autograd.Function):

@@ -37,6 +37,8 @@ struct BwdApplyArgs {                       // APPLY != 0: what forms g_y on the
   long long groups;
   const float *xt_xyz;                       // XT: [P,3] fp32 coordinates that are three more input channels of the layer
   float *xt_partial;                         //     [splits][TN][3]: split partials of their weight-gradient columns
+  const int *g_idx;                          // XT + gather (round 6): the input rows are A[(p / g_rpc) * g_nsrc + g_idx[p]] — the
+  int g_rpc, g_nsrc;                         //     grouped rows of sa2's first layer read out of the per-cloud table (mlp_fwd.hip, GatherIn)
   const float *xw_xyz;                       // XW: [P,3] fp32 coordinates, the ONLY input of the layer below (sa1's first layer) ...
   float *xw_partial;                         //     [splits][7][TK]: S1 = sum g_z x_j, S2 = sum y x_j (j < 3), S3 = sum x_j — see below
 };
@@ -181,6 +183,11 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
       for (int q = 0; q < 3; ++q) { xw1[j][q] = 0.f; xw2[j][q] = 0.f; }
   }
+  int gnx[XT ? NA : 1];        // XT + gather: table rows of the NEXT issue's input rows (consecutive issues take consecutive steps)
+  if (XT && ap.g_idx) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) gnx[XT ? i : 0] = ap.g_idx[min(p0 + arow + i * RPA, p1 - 1)];
+  }
   auto issue = [&](int sidx, long long base) {
     if (APPLY == 2) {
       const long long grp = min(base / ap.pool_k, ap.groups - 1);
@@ -198,7 +205,13 @@ __global__ __launch_bounds__(512) void mlp_bwd_fused_kernel(
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const long long p = min(base + arow + i * RPA, p1 - 1);
-        va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
+        if (XT && ap.g_idx) {
+          const long long row = (long long)((int)p / ap.g_rpc) * ap.g_nsrc + gnx[XT ? i : 0];
+          va[sidx][i] = *(const uint4 *)(A + row * lda + acol);
+          gnx[XT ? i : 0] = ap.g_idx[min(base + STEP + arow + i * RPA, p1 - 1)];      // for the next issue (base + STEP)
+        } else {
+          va[sidx][i] = *(const uint4 *)(A + p * lda + acol);
+        }
       }
     }
     if (XT && t < STEP * 3) {              // float t of the step's contiguous 32 x 3 block (rows past the split's end: clamped, zeroed at stage time)
@@ -582,7 +595,9 @@ static int bwd_fused_launch(const void *Gy, int ldg, const void *A, int lda, con
                             const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
                             const unsigned long long *drop_seed, float drop_p, const unsigned char *pool_arg,
                             const void *pool_yarg, int pool_k, const float *xt_xyz,
-                            float *xt_partial, const float *xw_xyz, float *xw_partial, void *stream) {
+                            float *xt_partial, const float *xw_xyz, float *xw_partial, void *stream,
+                            const int *g_idx = nullptr, int g_rpc = 0, int g_nsrc = 0) {
+  if (g_idx && (!xt_xyz || g_rpc <= 0 || g_nsrc <= 0 || P % g_rpc)) return CPFN_EINVAL;
   // xw (the xyz weight-gradient sums of the layer below riding on its reduction): the 64 <- 64 shape with the dense apply pass,
   // sa1's second layer; Gout may then be NULL (nobody needs the gradient w.r.t. the first layer's output)
   if ((!xw_xyz) != (!xw_partial)) return CPFN_EINVAL;
@@ -619,6 +634,7 @@ static int bwd_fused_launch(const void *Gy, int ldg, const void *A, int lda, con
   ap.groups = pool_k > 0 ? P / pool_k : 1;
   ap.xt_xyz = xt_xyz; ap.xt_partial = xt_partial;
   ap.xw_xyz = xw_xyz; ap.xw_partial = xw_partial;
+  ap.g_idx = g_idx; ap.g_rpc = g_rpc; ap.g_nsrc = g_nsrc;
   const int mode = !apply_y ? 0 : (pool_k > 0 ? 2 : (drop_seed ? 3 : 1));
 #define CPFN_BWD_FUSED(TN_, TK_, STEP_, BST_, APPLY_)                                                                      \
   mlp_bwd_fused_kernel<TN_, TK_, STEP_, BST_, APPLY_><<<grid, 512, 0, st>>>(g, ldg, a, lda, w, P, rps, workspace, go, ldo, \
@@ -689,4 +705,17 @@ extern "C" int cpfn_mlp_bwd_fused_xw(const void *Gy, const void *A, const void *
   if (!xw_xyz || !xw_partial) return CPFN_EINVAL;
   return bwd_fused_launch(Gy, N, A, K, W, P, N, K, a_scale, a_shift, workspace, Gout, K, bwd_y, b_scale, b_shift, stats_partial, apply_y,
                           apply_coef, y_scale, y_shift, nullptr, 0.f, nullptr, nullptr, 0, nullptr, nullptr, xw_xyz, xw_partial, stream);
+}
+
+// cpfn_mlp_bwd_fused's xyz-tail form (sa2's first layer: 128 <- 128 + 3 coordinates, dense apply pass, no layer below) with the
+// layer's input rows GATHERED from the per-cloud table while loading (cpfn_mlp_gemm_xyz_gather's operand): the [P, 128] grouped
+// copy is not read — it does not exist.  ldg = N = 128, lda = ldo = K = 128.
+extern "C" int cpfn_mlp_bwd_fused_xt_gather(const void *Gy, const void *table, const int *gidx, int rows_per_cloud, int n_src,
+                                            const void *W, long long P, int N, int K, float *workspace, void *Gout,
+                                            const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
+                                            const float *xt_xyz, float *xt_partial, void *stream) {
+  if (!gidx) return CPFN_EINVAL;
+  return bwd_fused_launch(Gy, N, table, K, W, P, N, K, nullptr, nullptr, workspace, Gout, K, nullptr, nullptr, nullptr, nullptr, apply_y,
+                          apply_coef, y_scale, y_shift, nullptr, 0.f, nullptr, nullptr, 0, xt_xyz, xt_partial, nullptr, nullptr, stream,
+                          gidx, rows_per_cloud, n_src);
 }

@@ -45,6 +45,15 @@ __device__ __forceinline__ void stream_load_a(bf16x8 (&af)[2][KS], __amdgpu_buff
 #ifndef CPFN_STREAM_TWOBUF
 #define CPFN_STREAM_TWOBUF 1
 #endif
+// XT + gather (round 6): the rows of the operand are not a [P, K] tensor but a GATHER of a small per-cloud table — sa2's
+// grouped input rows feats[b, idx[b, s, k], :] — taken while loading: cpfn_group_concat_bf16's [P, K] copy (33.5 MB written, then
+// read here and again by the backward kernel) never exists.  rows_per_cloud = S * K rows of the operand per cloud, n_src rows of
+// the table per cloud; a 128-row tile never straddles two clouds (rows_per_cloud % 128 == 0).
+struct GatherIn {
+  const int *idx;              // [P] table row of every operand row (inside its cloud); nullptr: off
+  int rows_per_cloud, n_src;
+};
+
 struct StreamBufs {
   __amdgpu_buffer_rsrc_t a, y, yb;       // operand rows, output rows, (BST) pre-BN output of the layer below
   unsigned aoff[2];                      // lane byte offset of its two operand rows inside a tile
@@ -92,8 +101,9 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
                                             const unsigned short *s_wx /*XT: [BN][16] bf16*/,
                                             float (&xz)[2][3] /*XT: xyz of the lane's two points, reloaded for the next tile*/,
                                             const float *xyz, const PoolOut &po = PoolOut(), const unsigned (&smask)[4] = {0u, 0u, 0u, 0u},
-                                            int n0 = 0, int N = 0) {
+                                            int n0 = 0, int N = 0, const GatherIn &gin = GatherIn(), int lda = 0) {
   constexpr int NT = BN / 16;
+  int gnext[2] = {0, 0};          // XT + gather: table rows of the lane's two operand rows in the NEXT tile
   constexpr int CPR = BN / 8;  // 16-byte chunks per row
   // the 64-wide variants have the registers to request the pieces of Yb before the MFMAs (the two sa1 data gradients,
   // 524288 rows: 47 / 36 us with the loads issued at the epilogue, where their latency is exposed); the 128-wide ones
@@ -122,6 +132,7 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
     const int pn = (max(next_tile, 0) * G_ROWS) + wave * 32 + lr, pa = min(pn, P - 1), pb = min(pn + 16, P - 1);   // (no next tile: any valid rows)
 #pragma unroll
     for (int q = 0; q < 3; ++q) { xz[0][q] = xyz[(size_t)pa * 3 + q]; xz[1][q] = xyz[(size_t)pb * 3 + q]; }
+    if (gin.idx) { gnext[0] = gin.idx[pa]; gnext[1] = gin.idx[pb]; }      // (requested a whole MFMA phase before they are used)
     // (the barrier keeps the K loop's weight-fragment reads from being hoisted up here — with them the kernel spills; placed
     //  behind the K loop instead, the coordinate k-step measured 32.7 us against 29.0 here; the plain K = 128 kernel: 19.3)
     __builtin_amdgcn_sched_barrier(0);
@@ -156,6 +167,12 @@ __device__ __forceinline__ void stream_tile(bf16x8 (&af)[2][KS], const unsigned 
   // with nothing.  Occupancy, not a deeper per-wave pipeline, is what hides the latency here.
   // (a next tile that is not this workgroup's — next_tile < 0 — is requested past the end of the buffer: zeros, no traffic;
   //  until round 4 every workgroup also fetched the first tile of its neighbour: 1.17 x the launch's bytes in the counters)
+  if (XT && gin.idx) {
+    // gathered rows of the next tile: (cloud * n_src + table row) * lda — the tile's cloud is wave-uniform
+    const unsigned cbase = (unsigned)((max(next_tile, 0) * G_ROWS) / gin.rows_per_cloud) * (unsigned)gin.n_src;
+    const unsigned goff[2] = {((cbase + (unsigned)gnext[0]) * (unsigned)lda + 8u * lq) * 2u, ((cbase + (unsigned)gnext[1]) * (unsigned)lda + 8u * lq) * 2u};
+    stream_load_a<KS>(af, sb.a, goff, next_tile < 0 ? sb.a_oob : 0u);
+  } else
   stream_load_a<KS>(af, sb.a, sb.aoff, next_tile < 0 ? sb.a_oob : (unsigned)next_tile * sb.a_tile);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
@@ -286,7 +303,8 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     const float *__restrict__ xyz = nullptr /* XT: [P,3] */, const float *__restrict__ wx = nullptr /* XT: [N,3] fp32 */,
     const SeamOut so = SeamOut() /* STATS: the sums leave as fixed-point atomics instead of partial rows */,
     const SeamIn si = SeamIn() /* ATR: scale / shift folded from the previous layer's sums (seam.h) */,
-    const PoolOut po = PoolOut() /* POOL: per-wave winners of the max over neighbours */) {
+    const PoolOut po = PoolOut() /* POOL: per-wave winners of the max over neighbours */,
+    const GatherIn gin = GatherIn() /* XT: the operand rows are gathered from a per-cloud table A [clouds * n_src, lda] */) {
   constexpr int NT = BN / 16, K = 32 * KS, CPR = BN / 8;
   const unsigned long long probe_t0 = probe_begin(probe);
   __shared__ __attribute__((aligned(16))) unsigned short s_w[BN * (32 * KS + 8)];   // whole-K panel, rows padded by 16 B
@@ -330,14 +348,15 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
   // buffer descriptors: the host guarantees P * max(lda, ldy) * 2 < 2^32
   StreamBufs sb;
   const unsigned y_bytes = ((unsigned)(P - 1) * ldy + N) * 2u;
-  sb.a = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, ((unsigned)(P - 1) * lda + K) * 2u, 0x00020000);
+  const unsigned a_rows = (XT && gin.idx) ? (unsigned)((P + gin.rows_per_cloud - 1) / gin.rows_per_cloud) * (unsigned)gin.n_src : (unsigned)P;
+  sb.a = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, ((a_rows - 1) * lda + K) * 2u, 0x00020000);
   sb.y = __builtin_amdgcn_make_buffer_rsrc((void *)Y, 0, y_bytes, 0x00020000);
   sb.yb = __builtin_amdgcn_make_buffer_rsrc(BST ? (void *)Yb : (void *)Y, 0, y_bytes, 0x00020000);
   sb.aoff[0] = ((unsigned)(wave * 32 + lr) * lda + 8 * lq) * 2u;
   sb.aoff[1] = sb.aoff[0] + 16u * lda * 2u;
   sb.yoff = ((unsigned)(wave * 32 + lane / CPR) * ldy + n0 + (lane % CPR) * 8) * 2u;
   sb.a_tile = (unsigned)G_ROWS * lda * 2u;
-  sb.a_oob = ((unsigned)(P - 1) * lda + K) * 2u;
+  sb.a_oob = ((a_rows - 1) * lda + K) * 2u;
   sb.y_tile = (unsigned)G_ROWS * ldy * 2u;
   sb.y_step = (unsigned)(64 / CPR) * ldy * 2u;
   const int ntiles = (P + G_ROWS - 1) / G_ROWS;
@@ -350,6 +369,13 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
     SeamFoldRegs fq;
     const bool folds = ATR && si.acc && t < K;
     if (folds) seam_fold_issue(si, t, fq);
+    if (XT && gin.idx) {       // (the first tile's table rows: one exposed index round trip per workgroup)
+      const int p0g = tile0 * G_ROWS + wave * 32 + lr;
+      const unsigned cbase = (unsigned)((tile0 * G_ROWS) / gin.rows_per_cloud) * (unsigned)gin.n_src;
+      const unsigned g0 = (unsigned)gin.idx[min(p0g, P - 1)], g1 = (unsigned)gin.idx[min(p0g + 16, P - 1)];
+      const unsigned goff[2] = {((cbase + g0) * (unsigned)lda + 8u * lq) * 2u, ((cbase + g1) * (unsigned)lda + 8u * lq) * 2u};
+      stream_load_a<KS>(a, sb.a, goff, 0u);
+    } else
     stream_load_a<KS>(a, sb.a, sb.aoff, (unsigned)tile0 * sb.a_tile);
     if (XT) {
       const int p0 = tile0 * G_ROWS + wave * 32 + lr, pa = min(p0, P - 1), pb = min(p0 + 16, P - 1);
@@ -374,17 +400,17 @@ __global__ __launch_bounds__(G_THREADS) __attribute__((amdgpu_waves_per_eu(2))) 
       stream_load_a<KS>(b, sb.a, sb.aoff, tile0 + 1 < tile_end ? (unsigned)(tile0 + 1) * sb.a_tile : sb.a_oob);
       for (int tile = tile0; tile < tile_end; tile += 2) {
         stream_tile<BN, KS, STATS, ATR, BST, XT, POOL>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 2 < tile_end ? tile + 2 : -1, wave, lane,
-                                                       st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N);
+                                                       st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N, gin, lda);
         if (tile + 1 < tile_end)
           stream_tile<BN, KS, STATS, ATR, BST, XT, POOL>(b, s_w, s_o[wave], sb, P, (tile + 1) * G_ROWS, tile + 3 < tile_end ? tile + 3 : -1, wave,
-                                                         lane, st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N);
+                                                         lane, st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N, gin, lda);
       }
     } else
     for (int tile = tile0; tile < tile_end; ++tile) {
       // the reload inside is unconditional (a tile past the end is out of the buffer's range: zeros, no traffic), so
       // the loop body is straight-line
       stream_tile<BN, KS, STATS, ATR, BST, XT, POOL>(a, s_w, s_o[wave], sb, P, tile * G_ROWS, tile + 1 < tile_end ? tile + 1 : -1, wave, lane,
-                                                     st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N);
+                                                     st_s, st_q, s_ss, s_bs, s_wx, xz, xyz, po, smask, n0, N, gin, lda);
     }
   }
   if (STATS || BST) {
@@ -783,10 +809,16 @@ extern "C" int cpfn_mlp_gemm_xyz_ok(long long P, int K, int N) {
   return K == 128 && N == 128 && P >= 32768 && gemm_stream_k(P, K) && (P + G_ROWS) * 128LL * 2 < (1LL << 32);
 }
 static int gemm_xyz_launch(const void *A, int lda, const void *W, const float *xyz, const float *Wx, long long P, int K,
-                           int N, void *Y, int ldy, float *stats_partial, const cpfn_seam_out *seam_out, void *stream) {
+                           int N, void *Y, int ldy, float *stats_partial, const cpfn_seam_out *seam_out, void *stream,
+                           const int *gidx = nullptr, int rows_per_cloud = 0, int n_src = 0) {
   if (!cpfn_mlp_gemm_xyz_ok(P, K, N) || !A || !W || !xyz || !Wx || !Y || lda != K || ldy != N || !seam_out_valid(seam_out) ||
       (seam_out && stats_partial))
     return CPFN_EINVAL;
+  if (gidx && (rows_per_cloud <= 0 || (rows_per_cloud % G_ROWS) || n_src <= 0 || P % rows_per_cloud ||
+               (P / rows_per_cloud) * (long long)n_src * lda * 2 >= (1LL << 32)))
+    return CPFN_EINVAL;
+  GatherIn gin;
+  gin.idx = gidx; gin.rows_per_cloud = rows_per_cloud; gin.n_src = n_src;
   hipStream_t st = (hipStream_t)stream;
   const int gx = cpfn_mlp_gemm_blocks(P, N);
   const long long tiles = (P + G_ROWS - 1) / G_ROWS;
@@ -795,9 +827,9 @@ static int gemm_xyz_launch(const void *A, int lda, const void *W, const float *x
   const unsigned short *a = (const unsigned short *)A, *w = (const unsigned short *)W;
   unsigned short *y = (unsigned short *)Y;
   if (stats_partial || seam_out)
-    mlp_gemm_stream_kernel<128, 4, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, stats_partial, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx, seam_out_arg(seam_out));
+    mlp_gemm_stream_kernel<128, 4, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, stats_partial, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx, seam_out_arg(seam_out), SeamIn(), PoolOut(), gin);
   else
-    mlp_gemm_stream_kernel<128, 4, false, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, nullptr, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx);
+    mlp_gemm_stream_kernel<128, 4, false, false, false, true><<<grid, G_THREADS, 0, st>>>(a, lda, w, 0, (int)P, N, y, ldy, nullptr, tpw, nullptr, nullptr, nullptr, probe_slot(grid), xyz, Wx, SeamOut(), SeamIn(), PoolOut(), gin);
   return cpfn_launch_status();
 }
 extern "C" int cpfn_mlp_gemm_xyz(const void *A, int lda, const void *W, const float *xyz, const float *Wx, long long P, int K,
@@ -898,4 +930,13 @@ extern "C" int cpfn_mlp_gemm_pool(const void *A, const void *W, long long P, int
   else
     mlp_gemm_stream_kernel<128, 4, true, true, false, false, true><<<grid, G_THREADS, 0, st>>>(a, K, w, 0, (int)P, N, y, N, stats_partial, tpw, a_scale, a_shift, nullptr, probe_slot(grid), nullptr, nullptr, so, si, po);
   return cpfn_launch_status();
+}
+
+// cpfn_mlp_gemm_xyz(_seam) with the [P, K] operand GATHERED from a per-cloud table while loading (stream_tile, GatherIn):
+// table [P / rows_per_cloud][n_src][K] bf16, gidx [P] int32 (row inside the cloud's table).  Exactly one of stats_partial / out.
+extern "C" int cpfn_mlp_gemm_xyz_gather(const void *table, const int *gidx, int rows_per_cloud, int n_src, const void *W,
+                                        const float *xyz, const float *Wx, long long P, int K, int N, void *Y, float *stats_partial,
+                                        const cpfn_seam_out *out, void *stream) {
+  if (!gidx || (!stats_partial == !out)) return CPFN_EINVAL;
+  return gemm_xyz_launch(table, K, W, xyz, Wx, P, K, N, Y, N, stats_partial, out, stream, gidx, rows_per_cloud, n_src);
 }

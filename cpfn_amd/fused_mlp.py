@@ -71,6 +71,9 @@ ATOMIC_SEAMS = True
 #                     (cpfn_mlp_gemm_pool: per-wave winners of max(sign(gamma) * y), taken before the batch statistics exist) and is
 #                     finished by a [G, C]-sized launch (cpfn_bn_pool_finish) instead of a second pass over the [P, C] output
 POOL_IN_GEMM = True
+#   GATHER_ON_LOAD    sa2's grouped input rows are not materialised: the first layer's GEMM (cpfn_mlp_gemm_xyz_gather) and its one-pass
+#                     backward kernel (cpfn_mlp_bwd_fused_xt_gather) read feats[b, idx[p]] while loading their operand
+GATHER_ON_LOAD = True
 # fixed point of the sums: value * 2^s in int64.  A partial sum must stay below 2^(50 - s) (2048 of them then fit 63 bits; larger ones
 # poison the seam -> NaN statistics, like an overflow would): s = 24 resolves 6e-8 per partial and takes a workgroup's sum(y^2) up to
 # 6.7e7 (8192 rows of |y| ~ 90); the fp32-xyz first layer of sa1 sees coordinates of a 0.2 ball (|y| ~ 0.05, 512 rows per partial): s = 30.
@@ -204,6 +207,12 @@ def gemm_seam(A, Wb, part, out_desc, in_desc, a_scale=None, a_shift=None):
                  + (8 * part.shape[0] * N if part is not None else 16 * out_desc.replicas * N)
                  + (16 * in_desc.replicas * K if in_desc is not None else 0))
     return Y
+
+
+def gather_on_load_ok(B, n_src, rows_per_cloud, D):
+    """May the rows of an xyz-tail first layer be gathered while loading (the lazy form of autograd_ops.GroupConcat)?  128-row
+    tiles must not straddle clouds, 32-bit byte offsets into the table."""
+    return bool(GATHER_ON_LOAD and FUSED_BWD and FUSED_BWD_APPLY and rows_per_cloud % 128 == 0 and B * n_src * D * 2 < (1 << 32))
 
 
 def xyz_tail_ok(P, D, N):
@@ -622,7 +631,15 @@ class _FusedStack(torch.autograd.Function):
                     Wb, Wx = xt_panels(L.weight, Kp)
                     nblk = h.cpfn_mlp_gemm_blocks(P, N)
                     Y = torch.empty(P, N, dtype=BF16, device=dev)
-                    if seam_out is not None:
+                    gat = cfg.get("gather")
+                    if gat is not None:
+                        # the operand rows are read out of the feature table through the neighbour indices (`a` is uninitialised)
+                        part = None if seam_out is not None else torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
+                        _check(h.cpfn_mlp_gemm_xyz_gather(_ptr(gat[0]), _ptr(gat[1]), gat[2], gat[3], _ptr(Wb), _ptr(xyz_tail), _ptr(Wx),
+                                                          P, Kp, N, _ptr(Y), _ptr(part),
+                                                          ctypes.addressof(seam_out) if seam_out is not None else None, _stream()),
+                               "cpfn_mlp_gemm_xyz_gather")
+                    elif seam_out is not None:
                         part = None
                         _check(h.cpfn_mlp_gemm_xyz_seam(_ptr(a), _ptr(Wb), _ptr(xyz_tail), _ptr(Wx), P, Kp, N, _ptr(Y),
                                                         ctypes.addressof(seam_out), _stream()), "cpfn_mlp_gemm_xyz_seam")
@@ -630,8 +647,9 @@ class _FusedStack(torch.autograd.Function):
                         part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                         _check(h.cpfn_mlp_gemm_xyz(_ptr(a), Kp, _ptr(Wb), _ptr(xyz_tail), _ptr(Wx), P, Kp, N, _ptr(Y), N, _ptr(part), _stream()),
                                "cpfn_mlp_gemm_xyz")
-                    _l.add_bytes("cpfn_mlp_gemm", 2 * P * Kp + 12 * P + 2 * N * Kp + 12 * N + 2 * P * N
-                                 + (8 * nblk * N if seam_out is None else 16 * seam_out.replicas * N))
+                    # (gathered operand: the table once + 4 bytes of index per row instead of the [P, K] copy)
+                    _l.add_bytes("cpfn_mlp_gemm", (2 * P * Kp if gat is None else 2 * gat[0].numel() + 4 * P) + 12 * P + 2 * N * Kp + 12 * N
+                                 + 2 * P * N + (8 * nblk * N if seam_out is None else 16 * seam_out.replicas * N))
                 else:
                     Kp = a.shape[1]
                     Wb = bf16_weight(L.weight, N, Kp)
@@ -893,20 +911,28 @@ class _FusedStack(torch.autograd.Function):
                         g = None
                         continue
                     g_new = torch.empty(P, Kp, dtype=BF16, device=dev)
-                    _check(h.cpfn_mlp_bwd_fused(_ptr(g if folded else Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp, asc, ash,
-                                                _ptr(ws), _ptr(g_new), Kp, _ptr(Yp), _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_),
-                                                _ptr(Y) if folded else None, _ptr(coef) if folded else None,
-                                                _ptr(st[0]) if folded else None, _ptr(st[1]) if folded else None, _ptr(dsd),
-                                                dp if dsd is not None else 0.0, _ptr(arg) if fold_pool else None,
-                                                _ptr(yarg) if fold_pool else None, pool_k if fold_pool else 0,
-                                                _ptr(xt), _ptr(ws_x), _stream()),
-                           "cpfn_mlp_bwd_fused")
+                    gat = cfg.get("gather") if xt is not None else None
+                    if gat is not None:
+                        # the layer's input rows come out of the feature table through the neighbour indices, as in the forward pass
+                        _check(h.cpfn_mlp_bwd_fused_xt_gather(_ptr(g), _ptr(gat[0]), _ptr(gat[1]), gat[2], gat[3], _ptr(Wb), P, N, Kp,
+                                                              _ptr(ws), _ptr(g_new), _ptr(Y), _ptr(coef), _ptr(st[0]), _ptr(st[1]),
+                                                              _ptr(xt), _ptr(ws_x), _stream()), "cpfn_mlp_bwd_fused_xt_gather")
+                    else:
+                        _check(h.cpfn_mlp_bwd_fused(_ptr(g if folded else Gy), N, _ptr(a_in), Kp, _ptr(Wb), P, N, Kp, asc, ash,
+                                                    _ptr(ws), _ptr(g_new), Kp, _ptr(Yp), _ptr(stp[0]), _ptr(stp[1]), _ptr(fp_),
+                                                    _ptr(Y) if folded else None, _ptr(coef) if folded else None,
+                                                    _ptr(st[0]) if folded else None, _ptr(st[1]) if folded else None, _ptr(dsd),
+                                                    dp if dsd is not None else 0.0, _ptr(arg) if fold_pool else None,
+                                                    _ptr(yarg) if fold_pool else None, pool_k if fold_pool else 0,
+                                                    _ptr(xt), _ptr(ws_x), _stream()),
+                               "cpfn_mlp_bwd_fused")
                     # g_y (or, folded in: g / the pooled g + y), the input, W, the split partials, the data gradient
                     # (a buffer counts ONCE per launch: for a hidden layer the pre-BN output of the layer below, which the riding
                     #  reduction reads, IS this layer's input — the second read hits L2 and is not compulsory traffic)
                     gy_bytes = (2 * P * N + 5 * P * N // pool_k) if fold_pool else (4 * P * N if fold_apply else 2 * P * N)
                     yp_bytes = 0 if (not below or Yp.data_ptr() == a_in.data_ptr()) else 2 * P * Kp
-                    _l.add_bytes("cpfn_mlp_bwd_fused", gy_bytes + 4 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
+                    a_bytes = 2 * P * Kp if gat is None else 2 * gat[0].numel() + 4 * P      # (gathered input: the table + the indices)
+                    _l.add_bytes("cpfn_mlp_bwd_fused", gy_bytes + a_bytes + 2 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
                                  + yp_bytes + (8 * splits * Kp if below else 0) + ((12 * P + 12 * splits * N) if xt is not None else 0))
                     if below:
                         fused_part = (fp_, splits)
@@ -998,7 +1024,7 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
     return "generic", False, False
 
 
-def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None, handover=None):
+def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None, handover=None, gather=None):
     """x: bf16 rows [P, Kpad] (Kpad a multiple of 64, zero-padded beyond the first conv's
     in_channels) — or fp32 [P, KS<=4] with first_fp32=True; xyz_tail [P,3] fp32: three more input channels of the first
     layer (behind x's D = Kpad channels) that stay fp32.  Returns bf16 [P, C_last], or
@@ -1014,8 +1040,12 @@ def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, 
                                      xyz_tail_ok(x.shape[0], x.shape[1], layers[0].cout)):
         raise ValueError("xyz_tail: [P, D] bf16 rows + [P, 3] fp32 coordinates into a (D + 3)-channel first layer of a shape "
                          "fused_mlp.xyz_tail_ok accepts")
+    if gather is not None and (xyz_tail is None or not gather_on_load_ok(gather[0].shape[0] // gather[3], gather[3], gather[2], x.shape[1])
+                               or x.shape[0] % gather[2] or gather[1].numel() != x.shape[0] or gather[1].dtype != torch.int32):
+        raise ValueError("gather = (table [B*n_src, D] bf16, idx [P] int32, rows per cloud, n_src) belongs to an xyz-tail first layer "
+                         "(fused_mlp.gather_on_load_ok)")
     cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout, "xyz_tail": xyz_tail,
-           "handover": handover}
+           "handover": handover, "gather": gather}
     params = []
     for L in layers:
         params += [L.weight, L.gamma, L.beta]

@@ -128,6 +128,8 @@ SIGNATURES = {
     "cpfn_mlp_dgrad_small": [_vp, _vp, _ll, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp, _f, _vp, _vp, _i, _vp, _vp, _vp],
+    "cpfn_mlp_gemm_xyz_gather": [_vp, _vp, _i, _i, _vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp],
+    "cpfn_mlp_bwd_fused_xt_gather": [_vp, _vp, _vp, _i, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused_xw": [_vp, _vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_colsum_f32": [_vp, _ll, _i, _vp, _vp, _vp, _vp],
     "cpfn_smallk_fwd": [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp],

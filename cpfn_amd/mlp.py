@@ -48,7 +48,7 @@ def shared_mlp(x, convs, bns, dtype=torch.float32):
     return x
 
 
-def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None):
+def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None, gather=None):
     """Run a whole (conv, bn, relu)* stack on rows and optionally max-pool every `pool_k`
     consecutive rows.  `x` [P, C_in] (any float dtype) — or None with `xyz_rows` [P, 3] fp32
     when the stack's only input is relative coordinates (sa1).
@@ -65,7 +65,8 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
         if x is None:
             return fused_mlp.fused_mlp_stack(xyz_rows.float().contiguous(), convs, bns, pool_k=pool_k, first_fp32=True)
         if xyz_tail is not None:
-            return fused_mlp.fused_mlp_stack(x.contiguous(), convs, bns, pool_k=pool_k, dropout=dropout, xyz_tail=xyz_tail.float().contiguous())
+            return fused_mlp.fused_mlp_stack(x.contiguous(), convs, bns, pool_k=pool_k, dropout=dropout, xyz_tail=xyz_tail.float().contiguous(),
+                                             gather=gather)
         P, C = x.shape
         Cp = (C + 63) // 64 * 64
         if Cp != C or x.dtype != torch.bfloat16 or not x.is_contiguous():

@@ -463,6 +463,13 @@ CPFN_API int cpfn_mlp_gemm_pool(const void *A, const void *W, long long P, int K
 CPFN_API int cpfn_bn_pool_finish(const void *pmax, const unsigned char *pidx, const void *Y, int G, int pool_k, int C,
                                  const float *scale, const float *shift, const cpfn_seam_in *in, void *out, unsigned char *arg,
                                  void *yarg, void *stream);
+/* ... and with the [P, K] operand GATHERED while loading (round 6): row p of the operand is table[(p / rows_per_cloud) * n_src +
+ * gidx[p]] — sa2's grouped input rows (modules/pointset_abstraction.py:62-66: select_point_subset of the features) read out of
+ * the [B, n_src, K] feature table, so cpfn_group_concat_bf16's [P, K] copy is neither written nor read.  rows_per_cloud % 128 == 0;
+ * exactly one of stats_partial / out (a seam). */
+CPFN_API int cpfn_mlp_gemm_xyz_gather(const void *table, const int *gidx, int rows_per_cloud, int n_src, const void *W,
+                                      const float *xyz, const float *Wx, long long P, int K, int N, void *Y, float *stats_partial,
+                                      const cpfn_seam_out *out, void *stream);
 CPFN_API int cpfn_smallk_fwd_seam(const cpfn_cast_desc *casts /* HOST array or NULL */, int n_casts, const float *X, int KS,
                                   const float *W, long long P, int C, void *Y, const cpfn_seam_out *out, void *stream);
 
@@ -583,6 +590,12 @@ CPFN_API int cpfn_mlp_bwd_fused(const void *Gy, int ldg, const void *A, int lda,
  * (xw_xyz [P,3], xw_partial [splits][7][64]) and cpfn_multi_split_reduce finishes c0 S1 + c1 S2 + c2 S3 once the coefficients exist
  * (cpfn_reduce_desc.coef): cpfn_smallk_wgrad_apply_xyz is not launched, and with Gout = NULL the gradient w.r.t. the first layer's
  * output is never stored.  ldg = N, lda = ldo = K. */
+/* cpfn_mlp_bwd_fused's xyz-tail form (N = K = 128, dense apply pass, no layer below, xt_xyz / xt_partial as there) with the
+ * layer's input rows gathered from the same table while loading (the operand of cpfn_mlp_gemm_xyz_gather). */
+CPFN_API int cpfn_mlp_bwd_fused_xt_gather(const void *Gy, const void *table, const int *gidx, int rows_per_cloud, int n_src,
+                                          const void *W, long long P, int N, int K, float *workspace, void *Gout,
+                                          const void *apply_y, const float *apply_coef, const float *y_scale, const float *y_shift,
+                                          const float *xt_xyz, float *xt_partial, void *stream);
 CPFN_API int cpfn_mlp_bwd_fused_xw(const void *Gy, const void *A, const void *W, long long P, int N, int K, const float *a_scale,
                                    const float *a_shift, float *workspace, void *Gout, const void *bwd_y, const float *b_scale,
                                    const float *b_shift, float *stats_partial, const void *apply_y, const float *apply_coef,

@@ -700,6 +700,47 @@ def test_xyz_weight_gradient_rides_on_the_layer_above(P, widths, pool_k, monkeyp
     assert _rel(gra[0], gr_ref[0]) < 3e-2, _rel(gra[0], gr_ref[0])
 
 
+@pytest.mark.parametrize("B,n_src,S,k", [(16, 512, 128, 64), (5, 200, 128, 64), (2, 512, 256, 128)])
+def test_grouped_rows_gathered_while_loading(B, n_src, S, k, monkeypatch):
+    """Round 6: sa2's grouped input rows feats[b, idx[b, s, k]] are not materialised — cpfn_mlp_gemm_xyz_gather and
+    cpfn_mlp_bwd_fused_xt_gather read them out of the feature table while loading their operand (autograd_ops.GroupConcat, lazy).
+    Against the materialised gather (cpfn_group_concat_bf16 + the plain kernels): the same operand values in the same MFMA order —
+    outputs, the gradient w.r.t. the feature table and every parameter gradient bit-identical; no cpfn_group_concat_bf16 launch."""
+    from cpfn_amd import autograd_ops, fused_mlp, lib as _l, mlp, ops
+    D, P = 128, B * S * k
+    assert fused_mlp.xyz_tail_ok(P, D, 128)
+    convs, bns = _stack(D + 3, [128, 128, 256], seed=37)
+    g = torch.Generator().manual_seed(P + 5)
+    feats = torch.randn(B, n_src, D, generator=g).to(dev()).to(torch.bfloat16)
+    nbr = torch.randint(0, n_src, (B, S, k), generator=g).to(torch.int32).to(dev())
+    rel = (torch.rand(P, 3, generator=g) * 0.8 - 0.4).to(dev())
+    gout = torch.randn(P // k, 256, generator=g).to(dev())
+    inv = ops.csr_build(nbr.reshape(B, S * k), n_src)
+    params = [p for c in convs for p in (c.weight,)] + [p for b in bns for p in (b.weight, b.bias)]
+    res = {}
+    for lazy in (True, False):
+        monkeypatch.setattr(fused_mlp, "GATHER_ON_LOAD", lazy)
+        for p in params:
+            p.grad = None
+        for bn in bns:
+            bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+        f = feats.clone().requires_grad_(True)
+        ok = fused_mlp.gather_on_load_ok(B, n_src, S * k, D)
+        assert ok == lazy
+        _l.byte_census(True)
+        x = autograd_ops.GroupConcat.apply(f, None, nbr, D, inv[0], inv[1], None, ok)
+        y = mlp.run_stack(x, convs, bns, torch.bfloat16, pool_k=k, xyz_tail=rel,
+                          gather=(f.detach().reshape(B * n_src, D), nbr.reshape(-1), S * k, n_src) if ok else None)
+        (y.float() * gout).sum().backward()
+        census = _l.byte_census(False)
+        assert ("cpfn_group_concat_bf16" in census) == (not lazy), sorted(census)
+        res[lazy] = (y.detach().float(), f.grad.float(), [p.grad.clone() for p in params])
+    (ya, ga, pa), (yb, gb, pb) = res[True], res[False]
+    assert torch.equal(ya, yb) and torch.equal(ga, gb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+
+
 def test_gradient_accumulation_over_two_backward_passes():
     """The weight-gradient split reductions are deferred to the end of a backward pass, which is only sound while
     AccumulateGrad steals the returned tensor (p.grad is None).  With accumulation (p.grad already set) they must run at
