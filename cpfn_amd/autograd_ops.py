@@ -76,7 +76,11 @@ def _csr_sum_bf16(g, ldg, inv, w, T, B, R, M, C, addend=None, ld_add=0):
 # bit-identical gradients, tests/test_gpu_network.py).  Armed only when both nodes saw the SAME tensor (address, in-place
 # version, shape); a gradient handed over and never picked up — a partial backward pass that stops above sa2 — raises at the
 # end of that backward pass instead of being lost.
+# Round 6, the second such tensor: sa2's pooled features feed sa3's input rows (ConcatPosFeats) and sfp1's skip (pn2_network.py:
+# 48-49,56).  There the node that takes the handed-over gradient is the PRODUCER's backward — sa2's fused stack, whose first launch
+# (BatchNorm-backward pass 1 over the pooled gradient) forms the sum on load (cpfn_bn_relu_bwd_join): the step's last framework add.
 SKIP_JOIN = True
+OUTPUT_JOIN = __import__("os").environ.get("CPFN_OUTPUT_JOIN", "1") == "1"      # the round-6 form (sa2's output)
 
 
 class SkipJoin:
@@ -88,6 +92,11 @@ class SkipJoin:
     @staticmethod
     def key(t):
         return (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+
+    @staticmethod
+    def flat_key(t):
+        """(for a producer that sees its output as rows [G, C] while the consumer sees [B, S, C]: same storage, same version)"""
+        return (t.data_ptr(), t._version, t.numel(), t.dtype)
 
     def _unclaimed(self):
         if self.addend is not None:
@@ -201,7 +210,8 @@ class ConcatInterp(torch.autograd.Function):
         M, C2 = feats.shape[1], feats.shape[2]
         sk, f = skip.contiguous(), feats.contiguous()
         ctx.join = None
-        if join is not None and SKIP_JOIN and join.src is not None and join.src == SkipJoin.key(sk) and (C1 + C2) % 8 == 0:
+        if (join is not None and SKIP_JOIN and join.src is not None and join.src in (SkipJoin.key(sk), SkipJoin.flat_key(sk))
+                and (C1 + C2) % 8 == 0):
             join.armed = True
             ctx.join = join
         out = torch.empty(B, N, C1 + C2, dtype=torch.bfloat16, device=f.device)

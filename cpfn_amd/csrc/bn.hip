@@ -284,15 +284,21 @@ __global__ __launch_bounds__(256) void bn_pool_finish_kernel(const unsigned shor
 }
 
 // ---------------------------------------------------------------- BatchNorm backward, pass 1
-template <bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DROP ? 3 : 4))) void bn_relu_bwd_kernel(const unsigned short *__restrict__ Ga,
+// JOIN (round 6): the gradient is the SUM of two row-strided bf16 tensors — the two consumers' gradients of a tensor that autograd's
+// input buffer would have added with a framework kernel between their backward nodes (sa2's pooled features: sa3's input rows,
+// columns 3.. of a wider gradient and therefore only 2-byte aligned, + sfp1's skip columns; autograd_ops.SkipJoin) — formed on
+// load with that add's rounding, bf16(a + b), and left contiguous in Gsum for the apply pass.
+template <bool DROP, bool JOIN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JOIN ? 2 : (DROP ? 3 : 4)))) void bn_relu_bwd_kernel(const unsigned short *__restrict__ Ga,
                                                           const unsigned short *__restrict__ Yr,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, long long P, int C,
                                                           unsigned short *__restrict__ Gz,
                                                           float *__restrict__ partial, int rpb,
                                                           const unsigned long long *__restrict__ drop_seed,
-                                                          unsigned thresh16, float inv_keep) {
+                                                          unsigned thresh16, float inv_keep, int ldg = 0,
+                                                          const unsigned short *__restrict__ Gb = nullptr, int ldb = 0,
+                                                          unsigned short *__restrict__ Gsum = nullptr) {
   __shared__ float s_red[2][256][8 + 1];
   const unsigned long long seed = DROP ? *drop_seed : 0ull;
   const int t = threadIdx.x;
@@ -318,6 +324,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DROP ? 3 : 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const long long rr = min(r + (long long)u * rsub, rend - 1);
+          if (JOIN) {
+            const unsigned short *pa = Ga + rr * ldg + c0;        // (2-byte aligned rows: element loads; Gb's are 16-byte aligned)
+            const uint4 qb = *(const uint4 *)(Gb + rr * ldb + c0);
+            const unsigned wb[4] = {qb.x, qb.y, qb.z, qb.w};
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              w[j] = (unsigned)f2bf(bf2f(pa[2 * j]) + bf2f((unsigned short)(wb[j] & 0xffffu))) |
+                     ((unsigned)f2bf(bf2f(pa[2 * j + 1]) + bf2f((unsigned short)(wb[j] >> 16))) << 16);
+            rg[u] = make_uint4(w[0], w[1], w[2], w[3]);
+          } else
           rg[u] = *(const uint4 *)(Ga + rr * C + c0);
           ry[u] = *(const uint4 *)(Yr + rr * C + c0);
         }
@@ -325,6 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DROP ? 3 : 
         for (int u = 0; u < 4; ++u) {
           const long long rr = r + (long long)u * rsub;
           const bool live = rr < rend;
+          if (JOIN && live) *(uint4 *)(Gsum + rr * C + c0) = rg[u];
           const unsigned short *g = (const unsigned short *)&rg[u], *y = (const unsigned short *)&ry[u];
           unsigned short o[8];
           float f[8];
@@ -993,6 +1011,17 @@ extern "C" int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scal
     bn_relu_bwd_kernel<false><<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
         (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, (unsigned short *)Gz, partial,
         bn_rows_per_block(P), nullptr, 0u, 1.f);
+  return cpfn_launch_status();
+}
+
+extern "C" int cpfn_bn_relu_bwd_join(const void *Ga, int ldg, const void *Gb, int ldb, const void *Y, const float *scale,
+                                     const float *shift, long long P, int C, void *Gsum, float *partial, void *stream) {
+  if (P <= 0 || C <= 0 || (C & 7) || !pow2(C / 8) || !Ga || !Gb || !Y || !scale || !shift || !partial || !Gsum || ldg < C || ldb < C)
+    return CPFN_EINVAL;
+  if (((uintptr_t)Ga & 1) || ((uintptr_t)Gb & 15) || (ldb & 7)) return CPFN_EINVAL;
+  bn_relu_bwd_kernel<false, true><<<cpfn_bn_bwd_blocks(P), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned short *)Ga, (const unsigned short *)Y, scale, shift, P, C, nullptr, partial, bn_rows_per_block(P), nullptr, 0u,
+      1.f, ldg, (const unsigned short *)Gb, ldb, (unsigned short *)Gsum);
   return cpfn_launch_status();
 }
 

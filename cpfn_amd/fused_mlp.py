@@ -755,7 +755,12 @@ class _FusedStack(torch.autograd.Function):
         dev = g.device
         grads = [None] * (3 * len(layers))
         g_in = g
-        g = g.contiguous().to(BF16)
+        joined = None              # (gradient rows, row stride) of the output's other consumer, handed over by its backward node
+        jo = cfg.get("join_out")
+        if jo is not None and jo.addend is not None:
+            joined, jo.addend = jo.addend, None
+        if joined is None:
+            g = g.contiguous().to(BF16)
         gx = None
         fused_part = None          # (partials, rows): pass 1 of THIS layer, left by the data gradient of the layer above
         xw_ride = None             # (partials [splits,7,C], splits): the xyz first layer's weight-gradient sums, left the same way
@@ -795,9 +800,24 @@ class _FusedStack(torch.autograd.Function):
                     G = P // pool_k
                     nblk = h.cpfn_bn_bwd_blocks(G)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
-                    _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, None, _ptr(part),
-                                              None, 0.0, _stream()), "cpfn_bn_relu_bwd")
-                    _l.add_bytes("cpfn_bn_relu_bwd", 4 * G * N + 8 * nblk * N)
+                    pass1_done = False
+                    if joined is not None:
+                        # the two consumers' gradients summed on load (what autograd's input buffer did with a framework add)
+                        gb, ldb = joined
+                        joined = None
+                        if (g.dtype == BF16 and g.dim() == 2 and tuple(g.shape) == (G, N) and g.stride(1) == 1 and g.stride(0) >= N
+                                and gb.dtype == BF16 and gb.is_contiguous() and gb.numel() == G * ldb and ldb >= N):
+                            gsum = torch.empty(G, N, dtype=BF16, device=dev)
+                            _check(h.cpfn_bn_relu_bwd_join(_ptr(g), g.stride(0), _ptr(gb), ldb, _ptr(yarg), _ptr(st[0]), _ptr(st[1]),
+                                                           G, N, _ptr(gsum), _ptr(part), _stream()), "cpfn_bn_relu_bwd_join")
+                            _l.add_bytes("cpfn_bn_relu_bwd", 8 * G * N + 8 * nblk * N)
+                            g, pass1_done = gsum, True
+                        else:
+                            g = (g.to(BF16) + gb.reshape(G, ldb)[:, :N]).contiguous()
+                    if not pass1_done:
+                        _check(h.cpfn_bn_relu_bwd(_ptr(g), _ptr(yarg), _ptr(st[0]), _ptr(st[1]), G, N, None, _ptr(part),
+                                                  None, 0.0, _stream()), "cpfn_bn_relu_bwd")
+                        _l.add_bytes("cpfn_bn_relu_bwd", 4 * G * N + 8 * nblk * N)
                 elif fused_part is not None:
                     part, nblk = fused_part
                     fused_part = None
@@ -1024,7 +1044,8 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
     return "generic", False, False
 
 
-def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None, handover=None, gather=None):
+def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None, handover=None, gather=None,
+                    join_out=None):
     """x: bf16 rows [P, Kpad] (Kpad a multiple of 64, zero-padded beyond the first conv's
     in_channels) — or fp32 [P, KS<=4] with first_fp32=True; xyz_tail [P,3] fp32: three more input channels of the first
     layer (behind x's D = Kpad channels) that stay fp32.  Returns bf16 [P, C_last], or
@@ -1045,11 +1066,16 @@ def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, 
         raise ValueError("gather = (table [B*n_src, D] bf16, idx [P] int32, rows per cloud, n_src) belongs to an xyz-tail first layer "
                          "(fused_mlp.gather_on_load_ok)")
     cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout, "xyz_tail": xyz_tail,
-           "handover": handover, "gather": gather}
+           "handover": handover, "gather": gather, "join_out": join_out if pool_k else None}
     params = []
     for L in layers:
         params += [L.weight, L.gamma, L.beta]
-    return _FusedStack.apply(x, cfg, *params)
+    out = _FusedStack.apply(x, cfg, *params)
+    jo = cfg["join_out"]
+    if jo is not None:
+        # (autograd_ops.SkipJoin: this stack's backward takes the gradient of the output's OTHER consumer in its first launch)
+        jo.src, jo.armed, jo.addend = ((out.data_ptr(), out._version, out.numel(), out.dtype) if out.requires_grad else None), False, None
+    return out
 
 
 # Packed, zero-padded bf16 panel of several heads' weights ([sum(o_i) -> 64k rows, K]) + fp32 bias vector, kept across

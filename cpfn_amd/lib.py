@@ -112,6 +112,7 @@ SIGNATURES = {
     "cpfn_bn_relu_maxpool": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "cpfn_bn_bwd_blocks": [_ll],
     "cpfn_bn_relu_bwd": [_vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp, _f, _vp],
+    "cpfn_bn_relu_bwd_join": [_vp, _i, _vp, _i, _vp, _vp, _vp, _ll, _i, _vp, _vp, _vp],
     "cpfn_bn_bwd_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "cpfn_bn_bwd_finalize_ride": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "cpfn_bn_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp, _f, _vp],

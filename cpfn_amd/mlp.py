@@ -48,13 +48,17 @@ def shared_mlp(x, convs, bns, dtype=torch.float32):
     return x
 
 
-def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None, gather=None):
+def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None, gather=None,
+              join_out=None):
     """Run a whole (conv, bn, relu)* stack on rows and optionally max-pool every `pool_k`
     consecutive rows.  `x` [P, C_in] (any float dtype) — or None with `xyz_rows` [P, 3] fp32
     when the stack's only input is relative coordinates (sa1).
 
     xyz_tail [P,3] fp32 (bf16 HIP path only): three more input channels of the first layer, BEHIND x's (sa2: gathered
     features first, then the centred coordinates) — kept in fp32 beside the bf16 rows instead of concatenated.
+
+    join_out (bf16 HIP path, pooled stacks): an autograd_ops.SkipJoin through which the backward node of the output's OTHER consumer
+    hands its gradient to this stack's backward (ignored elsewhere: the join then never arms).
 
     dtype == torch.bfloat16 on a HIP device: the fused MFMA path (cpfn_amd/fused_mlp.py).
     dtype == torch.float32: plain PyTorch ops — the fp32 reference the fused path is tested
@@ -66,7 +70,7 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
             return fused_mlp.fused_mlp_stack(xyz_rows.float().contiguous(), convs, bns, pool_k=pool_k, first_fp32=True)
         if xyz_tail is not None:
             return fused_mlp.fused_mlp_stack(x.contiguous(), convs, bns, pool_k=pool_k, dropout=dropout, xyz_tail=xyz_tail.float().contiguous(),
-                                             gather=gather)
+                                             gather=gather, join_out=join_out)
         P, C = x.shape
         Cp = (C + 63) // 64 * 64
         if Cp != C or x.dtype != torch.bfloat16 or not x.is_contiguous():
@@ -76,7 +80,7 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
             else:
                 xp[:, :C] = x
             x = xp
-        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout, handover=handover)
+        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout, handover=handover, join_out=join_out)
     if dropout is not None or xyz_tail is not None:
         raise ValueError("fused dropout / the xyz tail exist on the bf16 HIP path only")
     y = shared_mlp(src, convs, bns, dtype)

@@ -506,6 +506,12 @@ CPFN_API int cpfn_bn_bwd_blocks(long long P);
 CPFN_API int cpfn_bn_relu_bwd(const void *Ga, const void *Y, const float *scale, const float *shift,
                               long long P, int C, void *Gz, float *partial,
                               const unsigned long long *drop_seed /* NULL: no dropout */, float drop_p, void *stream);
+/* The same pass on the SUM of two row-strided bf16 gradients (rows of ldg / ldb elements; Ga 2-byte, Gb 16-byte aligned, ldb % 8 == 0): the two consumers'
+ * gradients of one tensor, which autograd (the reference's backward pass: torch's input buffer) adds with a kernel of its own
+ * XX.  Gsum [P][C] receives
+ * bf16(Ga + Gb), the bits of that add, for the apply pass. */
+CPFN_API int cpfn_bn_relu_bwd_join(const void *Ga, int ldg, const void *Gb, int ldb, const void *Y, const float *scale,
+                                   const float *shift, long long P, int C, void *Gsum, float *partial, void *stream);
 /* dgamma, dbeta and coef[3][C] with g_y = coef0*g_z + coef1*y + coef2. */
 CPFN_API int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float count, const float *gamma,
                                   const float *mean, const float *rstd, int training, float *dgamma,

@@ -830,3 +830,40 @@ def test_xyz_tail_first_layer_against_the_concatenated_operand(P, pool_k):
         assert _rel(a, b) < tol
     y2, gx2, gp2, _ = run("tail")
     assert torch.equal(y2, yt) and torch.equal(gx2, gxt) and all(torch.equal(a, b) for a, b in zip(gp2, gpt))
+
+
+@pytest.mark.parametrize("G,N,lda,off,ldb", [(2048, 256, 320, 3, 1280), (100, 64, 64, 0, 64), (4096, 128, 192, 5, 136)])
+def test_pooled_pass1_on_the_sum_of_two_strided_gradients(G, N, lda, off, ldb):
+    """cpfn_bn_relu_bwd_join: BatchNorm-backward pass 1 of a pooled layer on g = bf16(ga + gb), ga a 2-byte-aligned column slice of a
+    wider gradient (sa3's input rows, columns 3..), gb the leading columns of another (sfp1's skip): the sum has the bits of the
+    framework add autograd would have launched, the partial sums the bits of cpfn_bn_relu_bwd on that sum."""
+    from cpfn_amd import lib as _l
+    dev = torch.device("cuda:0")
+    h = _l.lib()
+    gen = torch.Generator(device="cpu").manual_seed(G + N)
+    wide_a = torch.randn(G, lda, generator=gen).to(dev).to(torch.bfloat16)
+    wide_b = torch.randn(G, ldb, generator=gen).to(dev).to(torch.bfloat16)
+    wide_b[3, 1] = float("inf")
+    y = torch.randn(G, N, generator=gen).to(dev).to(torch.bfloat16)
+    scale = (torch.rand(N, generator=gen) - 0.3).to(dev)
+    shift = (torch.randn(N, generator=gen) * 0.2).to(dev)
+    ga = wide_a[:, off:off + N]
+    ref_sum = (ga + wide_b[:, :N]).contiguous()
+    nblk = h.cpfn_bn_bwd_blocks(G)
+    part_ref = torch.empty(nblk, 2, N, device=dev)
+    part = torch.full((nblk, 2, N), -7.0, device=dev)
+    gsum = torch.empty(G, N, dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _l.check(h.cpfn_bn_relu_bwd(ref_sum.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), G, N, None, part_ref.data_ptr(),
+                                None, 0.0, st), "cpfn_bn_relu_bwd")
+    _l.check(h.cpfn_bn_relu_bwd_join(ga.data_ptr(), lda, wide_b.data_ptr(), ldb, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), G, N,
+                                     gsum.data_ptr(), part.data_ptr(), st), "cpfn_bn_relu_bwd_join")
+    assert torch.equal(gsum.view(torch.int16), ref_sum.view(torch.int16))
+    assert torch.equal(part.view(torch.int32), part_ref.view(torch.int32))
+    # refused: an odd address for ga, a misaligned gb, a row stride below the width
+    assert h.cpfn_bn_relu_bwd_join(ga.data_ptr() + 1, lda, wide_b.data_ptr(), ldb, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), G, N,
+                                   gsum.data_ptr(), part.data_ptr(), st) != 0
+    assert h.cpfn_bn_relu_bwd_join(ga.data_ptr(), lda, wide_b.data_ptr() + 2, ldb, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), G, N,
+                                   gsum.data_ptr(), part.data_ptr(), st) != 0
+    assert h.cpfn_bn_relu_bwd_join(ga.data_ptr(), N - 8, wide_b.data_ptr(), ldb, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), G, N,
+                                   gsum.data_ptr(), part.data_ptr(), st) != 0

@@ -427,7 +427,9 @@ def test_skip_join_gives_the_gradients_of_the_framework_add(monkeypatch):
     """sa1's features feed sa2's grouping AND sfp2's skip concatenation (PointNet2/pn2_network.py:45-46,55): autograd adds
     their two gradients with a framework bf16 add between the two backward nodes.  autograd_ops.SkipJoin hands the skip's
     gradient to the grouping adjoint instead, which adds it inside its own launch with the same roundings: every parameter
-    gradient of a training step must have the same bits both ways, and the framework add must be gone."""
+    gradient of a training step must have the same bits both ways, and the framework add must be gone.
+    Round 6: sa2's features (sa3's input rows + sfp1's skip, :48-49,56) the same way — that sum is formed by the first launch of
+    sa2's own backward (cpfn_bn_relu_bwd_join) — so BOTH framework adds of a step are gone."""
     from cpfn_amd import autograd_ops, lib as _l, synthetic
     dev = torch.device("cuda:0")
     batch = {k: v.to(dev) for k, v in synthetic.training_batch(2, N=2048, n_prims=6, n_inst_points=128, seed=3).items()}
@@ -450,7 +452,7 @@ def test_skip_join_gives_the_gradients_of_the_framework_add(monkeypatch):
     for a, b in zip(res[True][0], res[False][0]):
         assert (a is None and b is None) or torch.equal(a, b)
     assert res[True][1] == res[False][1]
-    assert adds[True] == adds[False] - 1, adds
+    assert adds[True] == adds[False] - 2, adds
 
 
 def test_skip_join_raises_when_the_grouping_adjoint_never_runs():
