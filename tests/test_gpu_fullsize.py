@@ -162,7 +162,8 @@ def _teacher_forced_stacks(model, batch, starts, tag):
     from test_gpu_fused_mlp import _emulated_stack
     calls, orig = [], mlp.run_stack
 
-    def spy(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None, gather=None):
+    def spy(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None, gather=None,
+            join_out=None):
         assert xyz_tail is None and gather is None          # (fp32 mode: the grouped rows arrive concatenated)
         calls.append((None if x is None else x.detach().clone(), convs, bns, pool_k, None if xyz_rows is None else xyz_rows.detach().clone()))
         return orig(x, convs, bns, dtype, pool_k=pool_k, xyz_rows=xyz_rows, dropout=dropout)
