@@ -45,6 +45,13 @@ class PointNet2(torch.nn.Module):
             self.bn1 = torch.nn.BatchNorm1d(128)
             self.fc2 = torch.nn.ModuleList(torch.nn.Conv1d(128, o, 1) for o in output_sizes)
 
+    def packed_parameter_groups(self):
+        """Parameters whose gradients the fused path produces as ONE packed block each: the fc2 heads' weights ([sum o_i, 128], in
+        head order) and their biases.  training.FlatGradBucket keeps each group adjacent so that the block is written in place."""
+        if self.features_extractor:
+            return []
+        return [[h.weight for h in self.fc2], [h.bias for h in self.fc2]]
+
     def set_compute_dtype(self, dtype):
         """GEMM operand type of every per-point MLP (torch.bfloat16 on MI355X; fp32 for parity)."""
         self.compute_dtype = dtype

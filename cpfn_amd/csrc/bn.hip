@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JOIN ? 2 : 
 __device__ __forceinline__ void bn_bwd_finalize_body(const float *__restrict__ partial, int nblk, int C, float count,
                                                      const float *__restrict__ gamma, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
-                                                     float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
+                                                     float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/,
+                                                     unsigned *__restrict__ flags = nullptr /* one word: see msr_body_checked */) {
   __shared__ double s_acc[RSUB][16][2];
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), r = threadIdx.x >> 4;
   float m_ = 0.f, rs_ = 0.f, g_ = 0.f;                  // (requested before the reduction, like bn_finalize_kernel's)
@@ -394,6 +395,10 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const float *__restrict__ p
   const double dg = rs * (s2 - m * s1);
   dgamma[c] = (float)dg;
   dbeta[c] = (float)s1;
+  if (flags) {      // (the lanes still here: r == 0 and c < C, all in the first wave; lane 0 always is one of them)
+    const unsigned long long m = __ballot((cpfn_nonfinite((float)dg) | cpfn_nonfinite((float)s1)) != 0);
+    if (threadIdx.x == 0 && m != 0ull) atomicOr(flags, 1u);
+  }
   const double s = (double)g_ * rs;
   const double c2 = training ? -s * dg * rs / count : 0.0;
   const double c3 = training ? -s * s1 / count - c2 * m : 0.0;
@@ -404,8 +409,9 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const float *__restrict__ p
 __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk, int C, float count,
                                        const float *__restrict__ gamma, const float *__restrict__ mean,
                                        const float *__restrict__ rstd, int training, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/) {
-  bn_bwd_finalize_body(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef);
+                                       float *__restrict__ dbeta, float *__restrict__ coef /*[3][C]*/,
+                                       unsigned *__restrict__ flags) {
+  bn_bwd_finalize_body(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef, flags);
 }
 
 // g_y[p,c] = s·g_z + c2·y + c3   (dense).  Gy may alias Gz.
@@ -538,7 +544,9 @@ struct MsrArgsT {
 typedef MsrArgsT<MSR_MAX> MsrArgs;
 // (the body of multi_split_reduce_kernel for workgroup `bid` of the launch described by `a`; 256 lanes)
 template <class ARGS>
-__device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
+__device__ __forceinline__ unsigned msr_body(const ARGS &a, const int bid) {
+  // -> non-zero in the lanes that stored a NaN / inf (all of them lanes of the workgroup's FIRST wave): msr_body_checked below
+  unsigned bad = 0;
   // 64 consecutive elements x 4 split-subsets per workgroup: 256-byte coalesced rows of the partial buffers.  "deep"
   // buffers (the 192 outputs x 1024 partials of the fp32-xyz layer, the 35 x 512 of the heads' bias: three / one workgroup
   // walking 256 / 128 rows each was a 20 us serial tail of this launch, which is why they had their own launches): 16 x 16.
@@ -580,9 +588,11 @@ __device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) { t1 += s3[q][lane][0]; t2 += s3[q][lane][1]; t3 += s3[q][lane][2]; }
       const float *cf = a.coef[d];
-      a.out[d][e] = fmaf(cf[c], t1, fmaf(cf[C + c], t2, cf[2 * C + c] * t3));
+      const float ov = fmaf(cf[c], t1, fmaf(cf[C + c], t2, cf[2 * C + c] * t3));
+      a.out[d][e] = ov;
+      bad |= cpfn_nonfinite(ov);
     }
-    return;
+    return bad;
   }
   if (a.deep[d] == 4) {
     // "wide-deep" (round 4, large buffers with >= 64 partial rows): 64 elements (16 lanes x float4: 256-byte runs) x 16 subsets
@@ -617,17 +627,18 @@ __device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
       const float v[4] = {t4.x, t4.y, t4.z, t4.w};
       const int ri = a.row_in[d];
       if (ri == 0) {
+        bad |= cpfn_nonfinite(v[0]) | cpfn_nonfinite(v[1]) | cpfn_nonfinite(v[2]) | cpfn_nonfinite(v[3]);
         *(float4 *)(a.out[d] + e) = t4;
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const long long row = (e + j) / ri;
           const int col = (int)((e + j) - row * ri);
-          if (col < a.row_out[d]) a.out[d][row * a.out_ld[d] + col] = v[j];
+          if (col < a.row_out[d]) { a.out[d][row * a.out_ld[d] + col] = v[j]; bad |= cpfn_nonfinite(v[j]); }
         }
       }
     }
-    return;
+    return bad;
   }
   if (a.deep[d] == 2) {
     float4 (*s4)[64] = (float4 (*)[64])s_acc;          // [4 subsets][64 lanes] float4 = 4 KB
@@ -657,17 +668,18 @@ __device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
                           (s0.w + s1.w) + (s2.w + s3.w)};
       const int ri = a.row_in[d];
       if (ri == 0) {
+        bad |= cpfn_nonfinite(v[0]) | cpfn_nonfinite(v[1]) | cpfn_nonfinite(v[2]) | cpfn_nonfinite(v[3]);
         *(float4 *)(a.out[d] + e) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const long long row = (e + j) / ri;
           const int col = (int)((e + j) - row * ri);
-          if (col < a.row_out[d]) a.out[d][row * a.out_ld[d] + col] = v[j];
+          if (col < a.row_out[d]) { a.out[d][row * a.out_ld[d] + col] = v[j]; bad |= cpfn_nonfinite(v[j]); }
         }
       }
     }
-    return;
+    return bad;
   }
   const bool deep = a.deep[d] != 0;
   const int epw = deep ? 16 : 64, nsub = deep ? 16 : 4;
@@ -692,15 +704,30 @@ __device__ __forceinline__ void msr_body(const ARGS &a, const int bid) {
     const int ri = a.row_in[d];
     if (ri == 0) {
       a.out[d][e] = v;
+      bad |= cpfn_nonfinite(v);
     } else {           // zero-padded K: drop the padding columns (the caller gets a compact [N, row_out] matrix)
       const long long row = e / ri;
       const int col = (int)(e - row * ri);
-      if (col < a.row_out[d]) a.out[d][row * a.out_ld[d] + col] = v;
+      if (col < a.row_out[d]) { a.out[d][row * a.out_ld[d] + col] = v; bad |= cpfn_nonfinite(v); }
     }
   }
+  return bad;
 }
 
-__global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a) { msr_body(a, (int)blockIdx.x); }
+// flag (nullable): ONE word, OR-ed with 1 by every workgroup that stored a NaN / inf (a no-return atomic, only in that rare case) and
+// cleared by its consumer (cpfn_adam_flat_sticky): the finite check of a training step's gradients rides on the launches that write
+// them (round 6; the gradients land in the flat bucket directly and the packing copy that used to carry the scan is gone)
+template <class ARGS>
+__device__ __forceinline__ void msr_body_checked(const ARGS &a, const int bid, unsigned *__restrict__ flag) {
+  const unsigned bad = msr_body(a, bid);
+  if (flag && threadIdx.x < 64) {
+    const unsigned long long m = __ballot(bad != 0);
+    if (threadIdx.x == 0 && m != 0ull) atomicOr(flag, 1u);
+  }
+}
+__global__ __launch_bounds__(256) void multi_split_reduce_kernel(MsrArgs a, unsigned *__restrict__ flags) {
+  msr_body_checked(a, (int)blockIdx.x, flags);
+}
 
 // bn_bwd_finalize with split reductions RIDING on it (round 4).  The 17 finalize launches of a backward pass are eight-odd
 // workgroups each on an otherwise idle chip, and the weight-gradient partials of the layer ABOVE were written by the launch before
@@ -711,13 +738,14 @@ __global__ __launch_bounds__(RTPB) void bn_bwd_finalize_ride_kernel(const float 
                                                                     const float *__restrict__ gamma, const float *__restrict__ mean,
                                                                     const float *__restrict__ rstd, int training,
                                                                     float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                                    float *__restrict__ coef, int nfin, MsrRideArgs a) {
+                                                                    float *__restrict__ coef, int nfin, MsrRideArgs a,
+                                                                    unsigned *__restrict__ flags) {
   if ((int)blockIdx.x >= nfin) {
     if (threadIdx.x >= 256) return;           // (waves that have ended do not count at the body's barrier)
-    msr_body(a, (int)blockIdx.x - nfin);
+    msr_body_checked(a, (int)blockIdx.x - nfin, flags);
     return;
   }
-  bn_bwd_finalize_body(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef);
+  bn_bwd_finalize_body(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef, flags);
 }
 
 // ---------------------------------------------------------------- fp32 small-K first layer (sa1: K = 3)
@@ -1025,13 +1053,18 @@ extern "C" int cpfn_bn_relu_bwd_join(const void *Ga, int ldg, const void *Gb, in
   return cpfn_launch_status();
 }
 
+extern "C" int cpfn_bn_bwd_finalize_checked(const float *partial, int nblk, int C, float count, const float *gamma,
+                                            const float *mean, const float *rstd, int training, float *dgamma,
+                                            float *dbeta, float *coef, unsigned *flags /* nullable: one word */, void *stream) {
+  if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef) return CPFN_EINVAL;
+  bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 16), RTPB, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
+                                                                            training, dgamma, dbeta, coef, flags);
+  return cpfn_launch_status();
+}
 extern "C" int cpfn_bn_bwd_finalize(const float *partial, int nblk, int C, float count, const float *gamma,
                                     const float *mean, const float *rstd, int training, float *dgamma,
                                     float *dbeta, float *coef, void *stream) {
-  if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef) return CPFN_EINVAL;
-  bn_bwd_finalize_kernel<<<cpfn_cdiv(C, 16), RTPB, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd,
-                                                                            training, dgamma, dbeta, coef);
-  return cpfn_launch_status();
+  return cpfn_bn_bwd_finalize_checked(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef, nullptr, stream);
 }
 
 extern "C" int cpfn_bn_bwd_apply(const void *Gz, const void *Y, const float *coef, const float *scale,
@@ -1204,7 +1237,7 @@ static int msr_fill(ARGS &a, const cpfn_reduce_desc *descs, int count, int *bloc
   return 0;
 }
 
-extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count, void *stream) {
+extern "C" int cpfn_multi_split_reduce_checked(const cpfn_reduce_desc *descs, int count, unsigned *flags, void *stream) {
   if (count < 0 || (count > 0 && !descs)) return CPFN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < count; base += MSR_MAX) {
@@ -1212,14 +1245,16 @@ extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count,
     int blocks = 0;
     const int rc = msr_fill(a, descs + base, count - base < MSR_MAX ? count - base : MSR_MAX, &blocks);
     if (rc) return rc;
-    if (blocks) multi_split_reduce_kernel<<<blocks, 256, 0, st>>>(a);
+    if (blocks) multi_split_reduce_kernel<<<blocks, 256, 0, st>>>(a, flags);
   }
   return cpfn_launch_status();
 }
-
-extern "C" int cpfn_bn_bwd_finalize_ride(const float *partial, int nblk, int C, float count, const float *gamma, const float *mean,
-                                         const float *rstd, int training, float *dgamma, float *dbeta, float *coef,
-                                         const cpfn_reduce_desc *descs, int ndesc, void *stream) {
+extern "C" int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs, int count, void *stream) {
+  return cpfn_multi_split_reduce_checked(descs, count, nullptr, stream);
+}
+extern "C" int cpfn_bn_bwd_finalize_ride_checked(const float *partial, int nblk, int C, float count, const float *gamma,
+                                                 const float *mean, const float *rstd, int training, float *dgamma, float *dbeta,
+                                                 float *coef, const cpfn_reduce_desc *descs, int ndesc, unsigned *flags, void *stream) {
   if (nblk <= 0 || C <= 0 || !partial || !gamma || !mean || !rstd || !dgamma || !dbeta || !coef || ndesc < 0 || ndesc > MSR_RIDE_MAX ||
       (ndesc > 0 && !descs))
     return CPFN_EINVAL;
@@ -1229,6 +1264,13 @@ extern "C" int cpfn_bn_bwd_finalize_ride(const float *partial, int nblk, int C, 
   if (rc) return rc;
   const int nfin = cpfn_cdiv(C, 16);
   bn_bwd_finalize_ride_kernel<<<nfin + blocks, RTPB, 0, (hipStream_t)stream>>>(partial, nblk, C, count, gamma, mean, rstd, training,
-                                                                              dgamma, dbeta, coef, nfin, a);
+                                                                              dgamma, dbeta, coef, nfin, a, flags);
   return cpfn_launch_status();
 }
+extern "C" int cpfn_bn_bwd_finalize_ride(const float *partial, int nblk, int C, float count, const float *gamma, const float *mean,
+                                         const float *rstd, int training, float *dgamma, float *dbeta, float *coef,
+                                         const cpfn_reduce_desc *descs, int ndesc, void *stream) {
+  return cpfn_bn_bwd_finalize_ride_checked(partial, nblk, C, count, gamma, mean, rstd, training, dgamma, dbeta, coef, descs, ndesc,
+                                           nullptr, stream);
+}
+

@@ -17,6 +17,9 @@ static inline int cpfn_cdiv(long long a, long long b) { return (int)((a + b - 1)
 bool cpfn_background_geometry();      // abi.hip: cpfn_set_background_geometry
 
 // ‖p‖² rounded like torch.sum(p**2, dim=1) on CPU: ((x²+y²)+z²), no contraction.
+// 1 if v is NaN or +-inf (exponent all ones): the test of the gradient scans (optim.hip, cpfn_multi_copy_checked)
+__device__ __forceinline__ unsigned cpfn_nonfinite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+
 __device__ __forceinline__ float cpfn_sqnorm3(float x, float y, float z) {
   return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
 }

@@ -14,13 +14,18 @@ namespace {
 // The step is skipped when *found_inf != 0 or any of the nf_count per-block flags of the gradient scan
 // (nonfinite_partial_kernel) is set — the scan's final reduction and the trainer's skipped-step counter ride here
 // instead of being two more launches.
+// n_sticky: the first n_sticky words of nf_partial are not rewritten every step by a scan but OR-ed into by the launches that
+// wrote the gradients (cpfn_multi_split_reduce_checked, cpfn_bn_bwd_finalize(_ride)_checked): read here, then cleared for the next step.
 __global__ __launch_bounds__(64) void adam_prepare_kernel(const float *__restrict__ lr, float beta1, float beta2,
                                                          float *__restrict__ step, double *__restrict__ pows,
                                                          const float *__restrict__ found_inf, float *__restrict__ coef,
-                                                         const unsigned *__restrict__ nf_partial, int nf_count,
-                                                         float *__restrict__ skipped) {
+                                                         unsigned *__restrict__ nf_partial, int nf_count,
+                                                         float *__restrict__ skipped, int n_sticky) {
   unsigned bad = 0;
-  for (int i = threadIdx.x; i < nf_count; i += 64) bad |= nf_partial[i];
+  for (int i = threadIdx.x; i < nf_count; i += 64) {
+    bad |= nf_partial[i];
+    if (i < n_sticky) nf_partial[i] = 0u;
+  }
   const bool skip = __ballot(bad != 0) != 0ull || (found_inf && *found_inf != 0.f);
   if (threadIdx.x != 0) return;
   const double b1t = pows[0] * (double)beta1, b2t = pows[1] * (double)beta2;
@@ -122,16 +127,25 @@ extern "C" int cpfn_nonfinite_flag(const float *x, long long n, unsigned *worksp
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
-                              float beta2, float eps, float weight_decay, float *step, double *pows,
-                              const float *found_inf, float *coef3, const unsigned *nf_partial, int nf_count,
-                              float *skipped, void *stream) {
-  if (n < 0 || !p || !g || !m || !v || !lr || !step || !pows || !coef3 || nf_count < 0 || (nf_count > 0 && !nf_partial))
+extern "C" int cpfn_adam_flat_sticky(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
+                                     float beta2, float eps, float weight_decay, float *step, double *pows,
+                                     const float *found_inf, float *coef3, unsigned *nf_partial, int nf_count, int n_sticky,
+                                     float *skipped, void *stream) {
+  if (n < 0 || !p || !g || !m || !v || !lr || !step || !pows || !coef3 || nf_count < 0 || (nf_count > 0 && !nf_partial) ||
+      n_sticky < 0 || n_sticky > nf_count)
     return CPFN_EINVAL;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CPFN_EINVAL;
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  adam_prepare_kernel<<<1, 64, 0, st>>>(lr, beta1, beta2, step, pows, found_inf, coef3, nf_partial, nf_count, skipped);
+  adam_prepare_kernel<<<1, 64, 0, st>>>(lr, beta1, beta2, step, pows, found_inf, coef3, nf_partial, nf_count, skipped, n_sticky);
   adam_flat_kernel<<<cpfn_cdiv(cpfn_cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, coef3);
   return cpfn_launch_status();
+}
+
+extern "C" int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
+                              float beta2, float eps, float weight_decay, float *step, double *pows,
+                              const float *found_inf, float *coef3, const unsigned *nf_partial, int nf_count,
+                              float *skipped, void *stream) {
+  return cpfn_adam_flat_sticky(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, pows, found_inf, coef3,
+                               (unsigned *)nf_partial, nf_count, 0, skipped, stream);
 }

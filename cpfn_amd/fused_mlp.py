@@ -319,7 +319,7 @@ def _flush_reductions():
     arr = (_ReduceDesc * len(todo))(*[_reduce_desc(e) for e in todo])
     dev = todo[0][0].device
     with torch.cuda.device(dev):
-        _check(_l.lib().cpfn_multi_split_reduce(arr, len(todo), _stream()), "cpfn_multi_split_reduce")
+        _check(_l.lib().cpfn_multi_split_reduce_checked(arr, len(todo), _ptr(_sink_flag()), _stream()), "cpfn_multi_split_reduce")
     _l.add_bytes("cpfn_multi_split_reduce", sum(_reduce_bytes(e) for e in todo))
 
 
@@ -332,6 +332,78 @@ def _take_pending_reductions(max_n):
     global _pending_reduce
     take, _pending_reduce = _pending_reduce[:max_n], _pending_reduce[max_n:]
     return take
+
+
+# ------------------------------------------------------------------ gradients written straight into the trainer's flat bucket
+# (round 6; priced in round 5, VERDICT r5 #5.)  A parameter gradient of the fused path is born in one of three launches: a
+# BatchNorm-backward finalize (dgamma, dbeta), a split reduction riding on one, or the batched reduction at the end of the pass.
+# Between those and the optimizer stood cpfn_multi_copy_checked: ~57 tensors packed into the flat bucket, the finite scan riding
+# on the copy (12.8 us + a kernel boundary at the very end of the step's chain).  While a GradSink is armed — by the trainer, around
+# the backward pass of its own step, where every `.grad` is None and nothing hooks the parameters — those launches write into the
+# bucket's views directly (autograd's AccumulateGrad keeps the returned view as `.grad`: no copy) and OR a NaN / inf they store
+# into ONE device word (`_checked` entries) that the optimizer's prepare kernel reads and clears (cpfn_adam_flat_sticky).
+GRAD_SINK = _os.environ.get("CPFN_GRAD_SINK", "1") == "1"
+_grad_sink = None
+
+
+class GradSink:
+    def __init__(self, params, views, flat, flag=None):
+        self.views = {id(p): v for p, v in zip(params, views)}
+        self.flat = flat                  # the bucket's flat fp32 buffer the views are slices of
+        self.flag = flag                  # int32 [1] device word (None: no finite check rides along)
+        self.covered = set()              # ids of the parameters whose gradient was written in place by a checked launch
+
+    def block(self, params):
+        """One 1-D view over the gradients of `params` if their slices are adjacent in this order, else None."""
+        vs = [self.views.get(id(p)) for p in params]
+        if any(v is None for v in vs):
+            return None
+        esz = self.flat.element_size()
+        for a, b in zip(vs, vs[1:]):
+            if a.data_ptr() + a.numel() * esz != b.data_ptr():
+                return None
+        o = (vs[0].data_ptr() - self.flat.data_ptr()) // esz
+        return self.flat[o:o + sum(v.numel() for v in vs)]
+
+
+class grad_sink:
+    """`with grad_sink(params, views, flat, flag) as s:` around loss.backward(); s.covered afterwards."""
+
+    def __init__(self, params, views, flat, flag=None):
+        self.s = GradSink(params, views, flat, flag) if GRAD_SINK else None
+
+    def __enter__(self):
+        global _grad_sink
+        self.prev, _grad_sink = _grad_sink, self.s
+        return self.s
+
+    def __exit__(self, *exc):
+        global _grad_sink
+        _grad_sink = self.prev
+        return False
+
+
+def _param_free(p):
+    return p.grad is None and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None)
+
+
+def _grad_out(param, shape, device):
+    """fp32 storage for the gradient of `param` in the given (2-D / 1-D) shape: its slice of the armed sink, else a fresh tensor."""
+    s = _grad_sink
+    if s is not None and param is not None and _param_free(param):
+        v = s.views.get(id(param))
+        n = 1
+        for d in shape:
+            n *= d
+        if v is not None and v.numel() == n and v.device == device:
+            s.covered.add(id(param))
+            return v.view(shape)            # (a NEW tensor object: AccumulateGrad only keeps a gradient nobody else references)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _sink_flag():
+    s = _grad_sink
+    return None if s is None else s.flag
 
 
 def _defer_reduction(ws, out, n, splits, row_in=0, row_out=0, params=(), out_ld=0, coef=None):
@@ -790,7 +862,7 @@ class _FusedStack(torch.autograd.Function):
                                                      need_dgrad or xt is not None, dseed is not None)
                 if xt is not None and not (route == "one_pass" and fold_apply):
                     raise RuntimeError("a layer with an xyz tail takes the one-pass backward kernel (fused_mlp.xyz_tail_ok)")
-                dgb = torch.empty(2, N, dtype=torch.float32, device=dev)
+                dgb = (_grad_out(L.gamma, (N,), dev), _grad_out(L.beta, (N,), dev))
                 coef = torch.empty(3, N, dtype=torch.float32, device=dev)
                 Gy = None
                 # ---- (1) reduction + finalize
@@ -833,17 +905,18 @@ class _FusedStack(torch.autograd.Function):
                     # the weight-gradient partials queued so far (the launch before this one wrote them) are reduced by further
                     # workgroups of the finalize launch: read out of the infinity cache now instead of from HBM at the end of the pass
                     arr = (_ReduceDesc * len(riders))(*[_reduce_desc(e_) for e_ in riders])
-                    _check(h.cpfn_bn_bwd_finalize_ride(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
-                                                       1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), arr, len(riders),
-                                                       _stream()), "cpfn_bn_bwd_finalize_ride")
+                    _check(h.cpfn_bn_bwd_finalize_ride_checked(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]),
+                                                               _ptr(st[3]), 1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef),
+                                                               arr, len(riders), _ptr(_sink_flag()), _stream()),
+                           "cpfn_bn_bwd_finalize_ride")
                     # (census: the riders' partial rows are read by THIS launch — booked under its own name since round 5; they sat
                     #  under cpfn_multi_split_reduce, a 10 us launch credited with 239 MB, while the launch that moves them had
                     #  traffic and no algorithmic bytes: VERDICT r4 #2)
                     _l.add_bytes("cpfn_bn_bwd_finalize_ride", sum(_reduce_bytes(e_) for e_ in riders) + 8 * nblk * N + 32 * N)
                 else:
-                    _check(h.cpfn_bn_bwd_finalize(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
-                                                  1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef), _stream()),
-                           "cpfn_bn_bwd_finalize")
+                    _check(h.cpfn_bn_bwd_finalize_checked(_ptr(part), nblk, N, float(P), _ptr(L.gamma.detach()), _ptr(st[2]), _ptr(st[3]),
+                                                          1 if L.training else 0, _ptr(dgb[0]), _ptr(dgb[1]), _ptr(coef),
+                                                          _ptr(_sink_flag()), _stream()), "cpfn_bn_bwd_finalize")
                     _l.add_bytes("cpfn_bn_bwd_finalize", 8 * nblk * N + 32 * N)
                 grads[3 * li + 1] = dgb[0]
                 grads[3 * li + 2] = dgb[1]
@@ -867,7 +940,7 @@ class _FusedStack(torch.autograd.Function):
                     # split reduction at the end of the pass, now that the coefficients exist
                     xw_part, xw_splits = xw_ride
                     xw_ride = None
-                    dW = torch.empty(N, 3, dtype=torch.float32, device=dev)
+                    dW = _grad_out(L.weight, (N, 3), dev)
                     _defer_reduction(xw_part, dW, 3 * N, xw_splits, row_in=N, params=(L.weight,), coef=coef)
                     grads[0] = dW.reshape(wshape)
                     continue
@@ -875,7 +948,7 @@ class _FusedStack(torch.autograd.Function):
                     KS = a_in.shape[1]
                     nb = h.cpfn_bn_bwd_blocks(P)
                     ws = torch.empty(nb * N * KS, dtype=torch.float32, device=dev)
-                    dW = torch.empty(N, KS, dtype=torch.float32, device=dev)
+                    dW = _grad_out(L.weight, (N, KS), dev)
                     # (its 1024 x 192-float partials join the batched split reduction: that launch walks "deep" buffers
                     #  with 16 split subsets per 16 outputs)
                     _defer_reduction(ws, dW, N * KS, nb, params=(L.weight,))
@@ -924,7 +997,7 @@ class _FusedStack(torch.autograd.Function):
                                      + (0 if Yp.data_ptr() == a_in.data_ptr() else 2 * P * Kp) + 8 * splits * Kp + 12 * P + 28 * splits * Kp)
                         fused_part = (fp_, splits)
                         xw_ride = (xw_part, splits)
-                        dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
+                        dW = _grad_out(L.weight, (N, L.cin), dev)
                         _defer_reduction(ws, dW, N * Kp, splits, params=(L.weight,)) if Kp == L.cin else \
                             _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin, params=(L.weight,))
                         grads[3 * li] = dW.reshape(wshape)
@@ -980,7 +1053,7 @@ class _FusedStack(torch.autograd.Function):
                     _l.add_bytes("cpfn_mlp_wgrad", 2 * P * N + 2 * P * Kp + 4 * splits * N * Kp)
                 # the split partials are finished by ONE launch at the end of the backward pass; a zero-padded K
                 # is compacted by that same launch (was: an immediate reduction + a strided slice copy)
-                dW = torch.empty(N, L.cin, dtype=torch.float32, device=dev)
+                dW = _grad_out(L.weight, (N, L.cin), dev)
                 if xt is not None:
                     # one [N, Kp + 3] weight gradient from two partial buffers: the bf16 channels' columns and the coordinates'
                     _defer_reduction(ws, dW, N * Kp, splits, Kp, Kp, params=(L.weight,), out_ld=L.cin)
@@ -1159,7 +1232,18 @@ class _Linear(torch.autograd.Function):
             hint, ho.heads_hint = ho.heads_hint, None
         gc = g.contiguous().float()
         fused_pad = Np == 64
-        gbias = torch.empty(N, dtype=torch.float32, device=a.device)
+        nh = len(ctx.sizes)
+        sink = _grad_sink if all(_param_free(p) for p in ctx.heads) else None
+        # the heads' weight slices / bias slices are adjacent in the trainer's bucket (FlatGradBucket puts packed groups last):
+        # the packed [N, K] gradient and the [N] bias gradient are then written there as two blocks
+        wblk = sink.block(ctx.heads[:nh]) if sink is not None else None
+        bblk = sink.block(ctx.heads[nh:]) if sink is not None else None
+        if wblk is not None and bblk is not None and wblk.numel() == N * K and bblk.numel() == N:
+            for p_ in ctx.heads:
+                sink.covered.add(id(p_))
+        else:
+            wblk = bblk = None
+        gbias = bblk if bblk is not None else torch.empty(N, dtype=torch.float32, device=a.device)
         if (hint is not None and fused_pad and hint[0] == gc.data_ptr() and hint[1] == gc._version and hint[2] == P
                 and hint[3] == N and hint[4].device == a.device):
             # the producer of g (the heads post-processing backward) already left the padded bf16 rows and the column sums
@@ -1180,7 +1264,7 @@ class _Linear(torch.autograd.Function):
             _defer_reduction(wsb, gbias, N, (P + 255) // 256, params=ctx.heads)
             splits = h.cpfn_mlp_wgrad_splits(P, Np, K)
             ws = torch.empty(splits * Np * K, dtype=torch.float32, device=a.device)
-            dW = torch.empty(Np, K, dtype=torch.float32, device=a.device)
+            dW = wblk.view(N, K) if wblk is not None else torch.empty(Np, K, dtype=torch.float32, device=a.device)
             if HEADS_ONE_PASS and FUSED_BWD and Np == 64 and h.cpfn_mlp_bwd_fused_ok(P, Np, K):
                 # weight gradient and data gradient of the packed heads in ONE pass over their gradient rows (the one-pass
                 # kernel's 64 <- 128 shape, linear: nothing to apply, nothing rides)
@@ -1204,7 +1288,10 @@ class _Linear(torch.autograd.Function):
                        "cpfn_mlp_wgrad")
                 _l.add_bytes("cpfn_mlp_wgrad", 2 * P * Np + 2 * P * K + 8 * splits * Np * K)
                 ga, _, _ = gemm(gb, Wb, w_trans=True)
-            _defer_reduction(ws, dW, Np * K, splits, params=ctx.heads)
+            if wblk is not None:      # only the first N of the padded Np rows: one "row" of Np K elements per split, N K of them kept
+                _defer_reduction(ws, dW, Np * K, splits, Np * K, N * K, params=ctx.heads)
+            else:
+                _defer_reduction(ws, dW, Np * K, splits, params=ctx.heads)
         gw, gbs, o = [], [], 0
         for n, shp in zip(ctx.sizes, ctx.wshapes):
             gw.append(dW[o:o + n].reshape(shp))

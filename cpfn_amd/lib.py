@@ -74,6 +74,7 @@ SIGNATURES = {
     "cpfn_fit_pack_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "cpfn_nonfinite_flag": [_vp, _ll, _vp, _vp, _vp],
     "cpfn_adam_flat": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "cpfn_adam_flat_sticky": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "cpfn_nonfinite_blocks": [_ll],
     "cpfn_nonfinite_partial": [_vp, _ll, _vp, _vp],
     "cpfn_hungarian_match": [_vp, _vp, _i, _i, _vp, _vp],
@@ -119,6 +120,9 @@ SIGNATURES = {
     "cpfn_bn_pool_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "cpfn_mlp_wgrad_splits": [_ll, _i, _i],
     "cpfn_multi_split_reduce": [_vp, _i, _vp],
+    "cpfn_multi_split_reduce_checked": [_vp, _i, _vp, _vp],
+    "cpfn_bn_bwd_finalize_checked": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "cpfn_bn_bwd_finalize_ride_checked": [_vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "cpfn_mlp_wgrad": [_vp, _i, _vp, _i, _vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "cpfn_mlp_bwd_fused_ok": [_ll, _i, _i],
     "cpfn_mlp_wgrad_apply_ok": [_ll, _i, _i],

@@ -50,8 +50,9 @@ class FlatAdam(torch.optim.Optimizer):
         """check_gradients: scan the flat gradient for NaN / inf in the same launch sequence and skip the step if any
         is found (the reference's per-parameter isinf/isnan scan, Utils/training_utils.py:151-156) — the scan's final
         reduction and the optional `skipped` device counter (+1 per skipped step) live in the 1-wave prepare kernel.
-        nf_flags = (int32 flags tensor, count): per-workgroup flags of a scan that already happened (the checked packing
-        copy of FlatGradBucket.collect); the step is skipped if any of them is set."""
+        nf_flags = (int32 flags tensor, count[, n_sticky]): per-workgroup flags of a scan that already happened (the checked packing
+        copy of FlatGradBucket.collect); the step is skipped if any of them is set.  The first n_sticky words are OR-ed into by
+        the launches that wrote the gradients (fused_mlp.GradSink) and are cleared by this step's prepare kernel."""
         g = self.param_groups[0]
         lr = g["lr"]
         if not isinstance(lr, torch.Tensor):       # someone assigned a float: mirror it into the device scalar
@@ -63,19 +64,20 @@ class FlatAdam(torch.optim.Optimizer):
         h = _l.lib()
         grads = self.bucket.flat
         with torch.cuda.device(self.flat_p.device):
-            nf_ws, nf_count = None, 0
+            nf_ws, nf_count, n_sticky = None, 0, 0
             if nf_flags is not None:
-                nf_ws, nf_count = nf_flags
+                nf_ws, nf_count = nf_flags[0], nf_flags[1]
+                n_sticky = nf_flags[2] if len(nf_flags) > 2 else 0       # words OR-ed into by the gradients' writers: cleared here
             elif check_gradients:
                 if self._nf_ws is None:
                     self._nf_ws = torch.empty(256, dtype=torch.int32, device=self.flat_p.device)
                 nf_ws, nf_count = self._nf_ws, h.cpfn_nonfinite_blocks(grads.numel())
                 _l.check(h.cpfn_nonfinite_partial(_ptr(grads), grads.numel(), _ptr(nf_ws), _stream()), "cpfn_nonfinite_partial")
-            _l.check(h.cpfn_adam_flat(_ptr(self.flat_p), _ptr(grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                      self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
-                                      float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows), _ptr(self.found_inf),
-                                      _ptr(self._coef), _ptr(nf_ws), nf_count, _ptr(skipped), _stream()),
-                     "cpfn_adam_flat")
+            _l.check(h.cpfn_adam_flat_sticky(_ptr(self.flat_p), _ptr(grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                             self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
+                                             float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows),
+                                             _ptr(self.found_inf), _ptr(self._coef), _ptr(nf_ws), nf_count, n_sticky, _ptr(skipped),
+                                             _stream()), "cpfn_adam_flat")
         _l.add_bytes("cpfn_adam_flat", 28 * self.flat_p.numel() + (4 * grads.numel() if check_gradients and nf_flags is None else 0))
 
     def state_dict(self):

@@ -85,6 +85,14 @@ class FlatGradBucket:
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
+        # parameters whose gradients are produced as ONE packed block (PointNet2.packed_parameter_groups: the fc2 heads' weights,
+        # then their biases) sit adjacent, in that order, at the END of the bucket: the launch that reduces the packed gradient then
+        # writes the bucket directly (fused_mlp.GradSink); behind them nothing needs 16-byte alignment any more
+        groups = module.packed_parameter_groups() if hasattr(module, "packed_parameter_groups") else []
+        moved = [p for g in groups for p in g if p.requires_grad]
+        if moved and len({id(p) for p in moved}) == len(moved) and all(any(p is q for q in self.params) for p in moved):
+            ids = {id(p) for p in moved}
+            self.params = [p for p in self.params if id(p) not in ids] + moved
         n = sum(p.numel() for p in self.params)
         ref = self.params[0]
         # (padded so that the bucket splits into equal shards for the reduce-scatter / all-gather layout; `flat` is the
@@ -110,7 +118,17 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
-    def collect(self, check=False, fault=None):
+    def sink(self, check):
+        """fused_mlp.grad_sink over this bucket for the backward pass of a step (GPU, bf16 fused path): the launches that produce
+        parameter gradients write them into the bucket's views and OR a NaN / inf into `sink_flag` (check=True)."""
+        from . import fused_mlp
+        if self.flat.is_cuda and check and getattr(self, "_sink_flags", None) is None:
+            # word 0: the writers' sticky flag; words 1..: the per-workgroup flags of a checked copy of whatever was not written in place
+            self._sink_flags = torch.zeros(4096, dtype=torch.int32, device=self.flat.device)
+        flag = self._sink_flags[0:1] if (self.flat.is_cuda and check) else None
+        return fused_mlp.grad_sink(self.params, self.views, self.flat, flag)
+
+    def collect(self, check=False, fault=None, sink=None):
         """Call after the backward pass: pack the fresh gradients into the flat buffer.  Parameters that
         received no gradient (conv biases in front of a training-mode BatchNorm) keep a zero slice and
         `.grad = None`, which the optimizer skips — identical to a zero update.  A parameter that HAD a gradient in
@@ -119,8 +137,11 @@ class FlatGradBucket:
         check=True (GPU): the packing copy also scans what it copies for NaN / inf (cpfn_multi_copy_checked) and the
         per-workgroup flags are returned as (flags int32 tensor, count) for FlatAdam.step(nf_flags=...); None when
         nothing had to be copied or the scan could not ride along.
+        sink: the fused_mlp.GradSink that was armed during the backward pass (self.sink(check)): gradients it covered are
+        already in place and checked by the launches that wrote them (its sticky flag word = flags[0]); anything else is
+        copied — and scanned — as before, its flags behind that word.  Returns (flags, count, n_sticky = 1) then.
         fault (data parallel): this rank's 0-dim fp32 fault word; the same launch copies it into the bucket's fault slot."""
-        src, dst, who = [], [], []
+        src, dst, who, in_place = [], [], [], set()
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             if p.grad is None:
                 if i in self._has_grad:
@@ -132,10 +153,28 @@ class FlatGradBucket:
                 src.append(p.grad)
                 dst.append(v)
                 who.append(p)
+            else:
+                in_place.add(id(p))
         flags = None
         if fault is not None:
             src.append(fault.reshape(1))
             dst.append(self.fault_slot)
+        if sink is not None and sink.flag is not None and check and self.flat.is_cuda:
+            # every gradient that is in place must have been written by a checked launch of THIS pass
+            if in_place <= sink.covered:
+                count = 1
+                if src:
+                    if not all(t.dtype == torch.float32 for t in src):
+                        sink = None
+                    else:
+                        got = SPFNTrainer._copy_all(dst, src, flags=self._sink_flags[1:])
+                        if got is None:
+                            sink = None                     # (the scan could not ride on the copy: full scan by the optimizer)
+                        else:
+                            count += got[1]
+                    for p, v in zip(who, dst):
+                        p.grad = v
+                return (self._sink_flags, count, 1) if sink is not None else None
         if src:
             if self.flat.is_cuda:
                 if check:
@@ -731,8 +770,11 @@ class SPFNTrainer:
                 self.bucket.zero()
                 self.module(sb["P"], geometry=st["geomA"], **self._feature_kwargs(sb))
                 out = self._graph_losses(sb, st)
-                out[0].backward(st["unit"])              # (no ones_like fill inside the graph)
-                nf = self.bucket.collect(check=world == 1, fault=st["flag_fault"] if world > 1 else None)
+                # (the launches that produce parameter gradients write them into the flat bucket, finite check included:
+                #  FlatGradBucket.sink — no packing copy on one GPU, a one-word copy of the fault slot under data parallelism)
+                with self.bucket.sink(check=world == 1) as gsink:
+                    out[0].backward(st["unit"])          # (no ones_like fill inside the graph)
+                nf = self.bucket.collect(check=world == 1, fault=st["flag_fault"] if world > 1 else None, sink=gsink)
                 if world == 1:
                     self._checked_optimizer_step(st["skipped"], nf, fault=st["flag_fault"])
                 elif exchange_in_graph:

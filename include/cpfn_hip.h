@@ -544,6 +544,18 @@ CPFN_API int cpfn_multi_split_reduce(const cpfn_reduce_desc *descs /* HOST array
 CPFN_API int cpfn_bn_bwd_finalize_ride(const float *partial, int nblk, int C, float count, const float *gamma, const float *mean,
                                        const float *rstd, int training, float *dgamma, float *dbeta, float *coef,
                                        const cpfn_reduce_desc *descs /* HOST array */, int ndesc, void *stream);
+/* The finite check of a step's gradients riding on the launches that WRITE them (round 6; the reference scans every parameter's
+ * gradient with isinf / isnan after the backward pass, Utils/training_utils.py:151-156): the `_checked` forms OR 1 into ONE device
+ * word `flag` (a no-return atomic, only from a workgroup that stored a NaN / inf); its consumer clears it (cpfn_adam_flat_sticky).
+ * flag == NULL: the plain entries. */
+CPFN_API int cpfn_multi_split_reduce_checked(const cpfn_reduce_desc *descs /* HOST array */, int count, unsigned *flag, void *stream);
+CPFN_API int cpfn_bn_bwd_finalize_checked(const float *partial, int nblk, int C, float count, const float *gamma,
+                                          const float *mean, const float *rstd, int training, float *dgamma,
+                                          float *dbeta, float *coef, unsigned *flag, void *stream);
+CPFN_API int cpfn_bn_bwd_finalize_ride_checked(const float *partial, int nblk, int C, float count, const float *gamma,
+                                               const float *mean, const float *rstd, int training, float *dgamma, float *dbeta,
+                                               float *coef, const cpfn_reduce_desc *descs /* HOST array */, int ndesc,
+                                               unsigned *flag, void *stream);
 CPFN_API int cpfn_mlp_wgrad_splits(long long P, int N, int K);
 CPFN_API int cpfn_mlp_wgrad(const void *Gy, int ldg, const void *A, int lda, const int *gidx, long long P,
                             int N, int K, const float *a_scale, const float *a_shift, float *workspace,
@@ -771,6 +783,12 @@ CPFN_API int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long l
                             const unsigned *nf_partial /* optional: the nf_count per-block flags left by
                             cpfn_nonfinite_partial over g; any set flag skips the step */, int nf_count,
                             float *skipped /* optional device counter, +1 for a skipped step */, void *stream);
+/* The same with the first n_sticky words of nf_partial OR-accumulated by the launches that WROTE the gradients (the `_checked`
+ * reductions / finalizes above) instead of rewritten by a scan: they are read and then CLEARED here for the next step. */
+CPFN_API int cpfn_adam_flat_sticky(float *p, const float *g, float *m, float *v, long long n, const float *lr,
+                                   float beta1, float beta2, float eps, float weight_decay, float *step,
+                                   double *pows, const float *found_inf, float *coef3, unsigned *nf_partial, int nf_count,
+                                   int n_sticky, float *skipped, void *stream);
 /* First half of cpfn_nonfinite_flag: workspace256[i] = 1 if block i of x holds a NaN / inf, for
  * i < cpfn_nonfinite_blocks(n) (<= 256); the reduction is then done by cpfn_adam_flat's prepare kernel. */
 CPFN_API int cpfn_nonfinite_blocks(long long n);

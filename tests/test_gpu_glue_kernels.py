@@ -161,3 +161,67 @@ def test_concat_interp_matches_interp_plus_cat(mode, B, M, N, C1, C2):
     else:
         a, b = res[0][2].float(), res[1][2].float()
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
+
+
+def test_checked_reductions_and_finalize_raise_the_sticky_word_only_for_what_they_store():
+    """cpfn_multi_split_reduce_checked / cpfn_bn_bwd_finalize(_ride)_checked: the finite check of a step's gradients rides on the
+    launches that write them.  One word, OR-ed with 1 by a workgroup that STORED a NaN / inf: every reduction layout (flat, compact,
+    deep, wide, wide-deep, the xyz coefficient form), a NaN in a padding column that is never stored must NOT raise it, and the
+    outputs are those of the plain entries, bit for bit."""
+    from cpfn_amd import fused_mlp, lib as _l
+    h = _l.lib()
+    g = torch.Generator().manual_seed(11)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev())
+    cases = [(96, 192, 131, 7), (128, 128, 128, 256), (256, 128, 128, 37), (30, 16, 16, 200), (1, 35, 35, 512), (64, 8192 // 64, 70, 16)]
+    for poison in (None, "stored", "padding"):
+        for n_rows, Kp, cin, splits in cases:
+            if poison == "padding" and cin == Kp:
+                continue
+            ws = torch.randn(splits, n_rows, Kp, generator=g).to(dev())
+            if poison == "stored":
+                ws[splits // 2, n_rows - 1, cin - 1] = float("inf")
+            elif poison == "padding":
+                ws[splits // 2, 0, Kp - 1] = float("nan")
+            out = torch.empty(n_rows, cin, device=dev())
+            ref = torch.empty(n_rows, cin, device=dev())
+            d = lambda o: (fused_mlp._ReduceDesc * 1)(fused_mlp._ReduceDesc(ws.data_ptr(), o.data_ptr(), n_rows * Kp, splits,
+                                                                           0 if cin == Kp else Kp, 0 if cin == Kp else cin))
+            flag.zero_()
+            _call("cpfn_multi_split_reduce_checked", d(out), 1, flag.data_ptr(), _stream())
+            _call("cpfn_multi_split_reduce", d(ref), 1, _stream())
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+            assert int(flag) == (1 if poison == "stored" else 0), (poison, n_rows, Kp, cin, splits)
+    # the xyz coefficient form: out[c][j] = c0 S1 + c1 S2 + c2 S3
+    C, splits = 64, 40
+    for poison in (False, True):
+        part = torch.randn(splits, 7, C, generator=g).to(dev())
+        coef = torch.randn(3, C, generator=g).to(dev())
+        if poison:
+            part[3, 1, 5] = float("nan")
+        out = torch.empty(C, 3, device=dev())
+        arr = (fused_mlp._ReduceDesc * 1)(fused_mlp._ReduceDesc(part.data_ptr(), out.data_ptr(), 3 * C, splits, C, 0, 0, coef.data_ptr()))
+        flag.zero_()
+        _call("cpfn_multi_split_reduce_checked", arr, 1, flag.data_ptr(), _stream())
+        assert int(flag) == int(poison)
+    # finalize (+ riders): dgamma / dbeta of a layer, one NaN partial
+    for ride in (False, True):
+        for poison in (False, True):
+            C, nblk, P = 128, 37, 4096
+            part = torch.randn(nblk, 2, C, generator=g).to(dev())
+            if poison:
+                part[7, 1, 100] = float("inf")
+            gamma, mean, rstd = (torch.rand(C, generator=g).to(dev()) + 0.5 for _ in range(3))
+            dg, db, coef = torch.empty(C, device=dev()), torch.empty(C, device=dev()), torch.empty(3, C, device=dev())
+            ws = torch.randn(5, 1000, generator=g).to(dev())
+            o2 = torch.empty(1000, device=dev())
+            arr = (fused_mlp._ReduceDesc * 1)(fused_mlp._ReduceDesc(ws.data_ptr(), o2.data_ptr(), 1000, 5, 0, 0))
+            flag.zero_()
+            if ride:
+                _call("cpfn_bn_bwd_finalize_ride_checked", part.data_ptr(), nblk, C, float(P), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                      1, dg.data_ptr(), db.data_ptr(), coef.data_ptr(), arr, 1, flag.data_ptr(), _stream())
+                torch.testing.assert_close(o2, ws.sum(0), rtol=1e-5, atol=1e-5)
+            else:
+                _call("cpfn_bn_bwd_finalize_checked", part.data_ptr(), nblk, C, float(P), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                      1, dg.data_ptr(), db.data_ptr(), coef.data_ptr(), flag.data_ptr(), _stream())
+            assert int(flag) == int(poison), (ride, poison)
+            assert bool(torch.isfinite(dg).all()) == (not poison)

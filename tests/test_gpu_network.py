@@ -490,7 +490,7 @@ def test_split_reductions_riding_on_the_finalize_launches_are_bit_identical(monk
     starts = (torch.tensor([5, 17]), torch.tensor([1, 300]))
     h = _l.lib()
     seen = {"ride": 0, "riders": 0, "tail": 0}
-    o_ride, o_tail = h.cpfn_bn_bwd_finalize_ride, h.cpfn_multi_split_reduce
+    o_ride, o_tail = h.cpfn_bn_bwd_finalize_ride_checked, h.cpfn_multi_split_reduce_checked      # (the entries fused_mlp calls)
 
     def spy_ride(*a):
         seen["ride"] += 1
@@ -500,8 +500,8 @@ def test_split_reductions_riding_on_the_finalize_launches_are_bit_identical(monk
     def spy_tail(*a):
         seen["tail"] += a[1]
         return o_tail(*a)
-    monkeypatch.setattr(h, "cpfn_bn_bwd_finalize_ride", spy_ride)
-    monkeypatch.setattr(h, "cpfn_multi_split_reduce", spy_tail)
+    monkeypatch.setattr(h, "cpfn_bn_bwd_finalize_ride_checked", spy_ride)
+    monkeypatch.setattr(h, "cpfn_multi_split_reduce_checked", spy_tail)
     res, counts = {}, {}
     for on in (True, False):
         monkeypatch.setattr(fused_mlp, "REDUCE_RIDE", on)

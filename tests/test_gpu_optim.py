@@ -114,3 +114,50 @@ def test_checked_packing_copy_feeds_the_optimizer():
         for p, v in zip(bucket.params, bucket.views):
             assert p.grad.data_ptr() == v.data_ptr()
     assert float(skipped) == 3.0
+
+
+def test_gradients_written_in_place_and_the_sticky_word():
+    """FlatGradBucket.sink + collect(sink=...): gradients written into the bucket's views by a checked launch are not copied,
+    whatever else arrived as a fresh tensor still is (and is scanned by that copy); the writers' sticky word is flags[0], read
+    and CLEARED by the optimizer's prepare kernel — a NaN stored in one step skips that step only."""
+    from cpfn_amd import training, fused_mlp, lib as _l
+    from cpfn_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    h = _l.lib()
+    m = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Linear(128, 35), torch.nn.Linear(35, 3)).to(dev)
+    bucket = training.FlatGradBucket(m)
+    opt = FlatAdam(bucket, lr=1e-2)
+    skipped = torch.zeros((), device=dev)
+    params = list(m.parameters())
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(4)
+    for step, (poison_sink, poison_copy) in enumerate([(False, False), (True, False), (False, False), (False, True), (False, False)]):
+        for p in params:
+            p.grad = None
+        with bucket.sink(check=True) as sink:
+            assert sink is not None and sink.flag is not None
+            # parameter 0 (a [128, 64] weight): written in place by a checked split reduction of 9 partial slabs
+            ws = torch.randn(9, 128 * 64, generator=g).to(dev)
+            if poison_sink:
+                ws[4, 77] = float("nan")
+            out = fused_mlp._grad_out(params[0], (128, 64), dev)
+            arr = (fused_mlp._ReduceDesc * 1)(fused_mlp._ReduceDesc(ws.data_ptr(), out.data_ptr(), 128 * 64, 9, 0, 0))
+            _l.check(h.cpfn_multi_split_reduce_checked(arr, 1, sink.flag.data_ptr(), st), "reduce")
+            params[0].grad = out
+            # the others: fresh tensors, as a framework op would leave them
+            for p in params[1:]:
+                p.grad = torch.randn(p.shape, generator=g).to(dev)
+            if poison_copy:
+                params[3].grad.view(-1)[1] = float("inf")
+        nf = bucket.collect(check=True, sink=sink)
+        assert nf is not None and nf[2] == 1 and nf[1] > 1
+        assert params[0].grad.data_ptr() == bucket.views[[id(q) for q in bucket.params].index(id(params[0]))].data_ptr()
+        torch.testing.assert_close(bucket.views[[id(q) for q in bucket.params].index(id(params[0]))].reshape(-1), ws.sum(0),
+                                   rtol=1e-5, atol=1e-5, equal_nan=True)
+        before, steps = opt.flat_p.clone(), float(opt.step_count)
+        opt.step(skipped=skipped, nf_flags=nf)
+        skip = poison_sink or poison_copy
+        assert (float(opt.step_count) == steps) == skip, step
+        assert torch.equal(opt.flat_p, before) == skip, step
+        assert int(bucket._sink_flags[0]) == 0                       # consumed
+    assert float(skipped) == 2.0

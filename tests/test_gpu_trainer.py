@@ -184,3 +184,60 @@ def test_bf16_step_trains_like_the_fp32_step_on_held_out_metrics():
         assert res[run]["skipped_steps"] == 0
         assert res[run]["metrics"]["mIoU"] > 5 * res["untrained"]["metrics"]["mIoU"], (run, res[run]["metrics"])
     assert res["ok"], res["comparison"]
+
+
+def test_replayed_step_writes_its_gradients_straight_into_the_bucket(monkeypatch):
+    """fused_mlp.GradSink (round 6): in the replayed one-GPU step every parameter gradient is written into the flat bucket by the
+    launch that produces it — no packing copy (cpfn_multi_copy_checked is not called during the capture), the finite check rides on
+    those launches — and the bucket holds the same bits as with the sink off; a batch with a NaN coordinate is skipped
+    (weights and moments untouched, the skip counted) and the next clean batch trains again."""
+    from cpfn_amd import training, fused_mlp, lib as _l
+    from cpfn_amd.PointNet2 import pn2_network
+    from cpfn_amd.SPFN import fitter_factory
+    dev = torch.device("cuda:0")
+    with contextlib.redirect_stdout(io.StringIO()):
+        fitter_factory.register_primitives(training.GLOBAL_SPFN_CLASSES)
+    batch = {k: v.to(dev) for k, v in synthetic.training_batch(4, N=2048, n_prims=6, n_inst_points=128, seed=5).items()}
+    h = _l.lib()
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(fused_mlp, "GRAD_SINK", on)
+        torch.manual_seed(0)
+        model = pn2_network.PointNet2(dim_input=3, dim_pos=3, output_sizes=[3, 4, 28]).to(dev)
+        model.set_compute_dtype(torch.bfloat16)
+        model.dropout_p = 0.0
+        tr = training.SPFNTrainer(model, batch_size=4, init_learning_rate=1e-3, use_graphs=True)
+        calls = [0]
+        orig = h.cpfn_multi_copy_checked
+
+        def spy(*a):
+            calls[0] += 1
+            return orig(*a)
+        monkeypatch.setattr(h, "cpfn_multi_copy_checked", spy)
+        torch.manual_seed(77)
+        snaps = []
+        for i in range(6):
+            out = tr.step(batch, next_batch=batch)
+            snaps.append((tr.bucket.flat.detach().clone(), [float(o) for o in out]))
+        torch.cuda.synchronize()
+        monkeypatch.setattr(h, "cpfn_multi_copy_checked", orig)
+        assert tr._graph is not None and tr._graph["single"] and float(tr._graph["skipped"]) == 0.0
+        res[on] = (snaps, calls[0], tr, model)
+    # steps 0-2 ran as eager launches (warm-up + capture), 3-5 replayed: the same gradients and losses either way
+    for (ga, la), (gb, lb) in zip(res[True][0], res[False][0]):
+        # (parameter order inside the bucket is the same in both runs: FlatGradBucket's layout does not depend on the switch)
+        assert torch.equal(ga, gb) and la == lb
+    assert res[False][1] >= 1 and res[True][1] == 0, (res[True][1], res[False][1])
+    # a poisoned batch through the replayed step with the sink on
+    _, _, tr, model = res[True]
+    bad = {k: v.clone() for k, v in batch.items()}
+    bad["P"][1, 100, 2] = float("nan")
+    w0, m0 = tr.optimizer.flat_p.clone(), tr.optimizer.exp_avg.clone()
+    tr.step(bad, next_batch=batch)
+    torch.cuda.synchronize()
+    assert float(tr._graph["skipped"]) == 1.0
+    assert torch.equal(tr.optimizer.flat_p, w0) and torch.equal(tr.optimizer.exp_avg, m0)
+    tr.step(batch, next_batch=batch)
+    torch.cuda.synchronize()
+    assert float(tr._graph["skipped"]) == 1.0 and not torch.equal(tr.optimizer.flat_p, w0)
+    assert bool(torch.isfinite(tr.optimizer.flat_p).all())
