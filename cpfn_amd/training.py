@@ -111,6 +111,9 @@ class FlatGradBucket:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self._has_grad = set()            # indices of the parameters whose flat slice holds a gradient of an earlier step
+        # the gradient sink's flags (allocated HERE, never inside a capture — a torch.zeros there is a fill node of every replay):
+        # word 0 = the writers' sticky flag, words 1.. = the per-workgroup flags of a checked copy of whatever was not written in place
+        self._sink_flags = torch.zeros(4096, dtype=torch.int32, device=ref.device) if ref.is_cuda else None
         self.zero()
 
     def zero(self):
@@ -122,9 +125,6 @@ class FlatGradBucket:
         """fused_mlp.grad_sink over this bucket for the backward pass of a step (GPU, bf16 fused path): the launches that produce
         parameter gradients write them into the bucket's views and OR a NaN / inf into `sink_flag` (check=True)."""
         from . import fused_mlp
-        if self.flat.is_cuda and check and getattr(self, "_sink_flags", None) is None:
-            # word 0: the writers' sticky flag; words 1..: the per-workgroup flags of a checked copy of whatever was not written in place
-            self._sink_flags = torch.zeros(4096, dtype=torch.int32, device=self.flat.device)
         flag = self._sink_flags[0:1] if (self.flat.is_cuda and check) else None
         return fused_mlp.grad_sink(self.params, self.views, self.flat, flag)
 
