@@ -16,12 +16,27 @@ namespace {
 // instead of being two more launches.
 // n_sticky: the first n_sticky words of nf_partial are not rewritten every step by a scan but OR-ed into by the launches that
 // wrote the gradients (cpfn_multi_split_reduce_checked, cpfn_bn_bwd_finalize(_ride)_checked): read here, then cleared for the next step.
+// xw (cpfn_adam_flat_xw): the LAST gradient of a backward pass — the weight gradient [C][3] of an fp32-xyz first layer from sums that
+// rode on the layer above (bn.hip, msr_body's coefficient form): out[c][j] = c0[c] S1[j][c] + c1[c] S2[j][c] + c2[c] S3[j] with
+// S [7][C] already reduced over the splits — is finished HERE, by this wave, with that form's arithmetic, and checked with the rest:
+// it needs the BatchNorm coefficients of the last finalize launch of the pass, so as a reduction it was a launch of its own
+// (12 workgroups, 5.7 us + a kernel boundary) between that finalize and this kernel.
+struct AdamXw { const float *S, *coef; int C; float *out; };
 __global__ __launch_bounds__(64) void adam_prepare_kernel(const float *__restrict__ lr, float beta1, float beta2,
                                                          float *__restrict__ step, double *__restrict__ pows,
                                                          const float *__restrict__ found_inf, float *__restrict__ coef,
                                                          unsigned *__restrict__ nf_partial, int nf_count,
-                                                         float *__restrict__ skipped, int n_sticky) {
+                                                         float *__restrict__ skipped, int n_sticky, const AdamXw xw) {
   unsigned bad = 0;
+  if (xw.out) {
+    const int C = xw.C;
+    for (int e = threadIdx.x; e < 3 * C; e += 64) {
+      const int c = e / 3, j = e - 3 * c;
+      const float v = fmaf(xw.coef[c], xw.S[j * C + c], fmaf(xw.coef[C + c], xw.S[(3 + j) * C + c], xw.coef[2 * C + c] * xw.S[6 * C + j]));
+      xw.out[e] = v;
+      bad |= (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u;
+    }
+  }
   for (int i = threadIdx.x; i < nf_count; i += 64) {
     bad |= nf_partial[i];
     if (i < n_sticky) nf_partial[i] = 0u;
@@ -127,19 +142,30 @@ extern "C" int cpfn_nonfinite_flag(const float *x, long long n, unsigned *worksp
   return cpfn_launch_status();
 }
 
+extern "C" int cpfn_adam_flat_xw(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
+                                 float beta2, float eps, float weight_decay, float *step, double *pows,
+                                 const float *found_inf, float *coef3, unsigned *nf_partial, int nf_count, int n_sticky,
+                                 float *skipped, const float *xw_S, const float *xw_coef, int xw_C, float *xw_out, void *stream) {
+  if (n < 0 || !p || !g || !m || !v || !lr || !step || !pows || !coef3 || nf_count < 0 || (nf_count > 0 && !nf_partial) ||
+      n_sticky < 0 || n_sticky > nf_count)
+    return CPFN_EINVAL;
+  if (xw_out && (!xw_S || !xw_coef || xw_C <= 0)) return CPFN_EINVAL;
+  AdamXw xw;
+  xw.S = xw_S; xw.coef = xw_coef; xw.C = xw_C; xw.out = xw_out;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CPFN_EINVAL;
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  adam_prepare_kernel<<<1, 64, 0, st>>>(lr, beta1, beta2, step, pows, found_inf, coef3, nf_partial, nf_count, skipped, n_sticky, xw);
+  adam_flat_kernel<<<cpfn_cdiv(cpfn_cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, coef3);
+  return cpfn_launch_status();
+}
+
 extern "C" int cpfn_adam_flat_sticky(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,
                                      float beta2, float eps, float weight_decay, float *step, double *pows,
                                      const float *found_inf, float *coef3, unsigned *nf_partial, int nf_count, int n_sticky,
                                      float *skipped, void *stream) {
-  if (n < 0 || !p || !g || !m || !v || !lr || !step || !pows || !coef3 || nf_count < 0 || (nf_count > 0 && !nf_partial) ||
-      n_sticky < 0 || n_sticky > nf_count)
-    return CPFN_EINVAL;
-  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return CPFN_EINVAL;
-  if (n == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  adam_prepare_kernel<<<1, 64, 0, st>>>(lr, beta1, beta2, step, pows, found_inf, coef3, nf_partial, nf_count, skipped, n_sticky);
-  adam_flat_kernel<<<cpfn_cdiv(cpfn_cdiv(n, 4), 256), 256, 0, st>>>(p, g, m, v, n, beta1, beta2, eps, weight_decay, coef3);
-  return cpfn_launch_status();
+  return cpfn_adam_flat_xw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, pows, found_inf, coef3, nf_partial, nf_count,
+                           n_sticky, skipped, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int cpfn_adam_flat(float *p, const float *g, float *m, float *v, long long n, const float *lr, float beta1,

@@ -346,12 +346,20 @@ GRAD_SINK = _os.environ.get("CPFN_GRAD_SINK", "1") == "1"
 _grad_sink = None
 
 
+# XW_IN_PREPARE: ... and the pass's LAST gradient — sa1's first-layer weight gradient in its riding form, which needs the coefficients
+# of the pass's last finalize launch and was therefore the one reduction left for a launch of its own behind it — is finished by the
+# optimizer's 1-wave prepare kernel (cpfn_adam_flat_xw; GradSink.combine), its sums reduced as a rider of that last finalize.
+XW_IN_PREPARE = _os.environ.get("CPFN_XW_IN_PREPARE", "1") == "1"
+
+
 class GradSink:
-    def __init__(self, params, views, flat, flag=None):
+    def __init__(self, params, views, flat, flag=None, combine_ok=False):
         self.views = {id(p): v for p, v in zip(params, views)}
         self.flat = flat                  # the bucket's flat fp32 buffer the views are slices of
         self.flag = flag                  # int32 [1] device word (None: no finite check rides along)
         self.covered = set()              # ids of the parameters whose gradient was written in place by a checked launch
+        self.combine_ok = bool(combine_ok and flag is not None and XW_IN_PREPARE)      # the caller's optimizer step takes `combine`
+        self.combine = None               # (S [7 C], coef [3, C], C, out view [C, 3]): for cpfn_adam_flat_xw
 
     def block(self, params):
         """One 1-D view over the gradients of `params` if their slices are adjacent in this order, else None."""
@@ -369,8 +377,8 @@ class GradSink:
 class grad_sink:
     """`with grad_sink(params, views, flat, flag) as s:` around loss.backward(); s.covered afterwards."""
 
-    def __init__(self, params, views, flat, flag=None):
-        self.s = GradSink(params, views, flat, flag) if GRAD_SINK else None
+    def __init__(self, params, views, flat, flag=None, combine_ok=False):
+        self.s = GradSink(params, views, flat, flag, combine_ok) if GRAD_SINK else None
 
     def __enter__(self):
         global _grad_sink
@@ -938,10 +946,16 @@ class _FusedStack(torch.autograd.Function):
                 if xyz_layer and xw_ride is not None:
                     # the sums rode on the one-pass launch of the layer above (XYZ_WGRAD_RIDE): c0 S1 + c1 S2 + c2 S3 by the batched
                     # split reduction at the end of the pass, now that the coefficients exist
-                    xw_part, xw_splits = xw_ride
+                    xw_part, xw_splits, xw_S = xw_ride
                     xw_ride = None
                     dW = _grad_out(L.weight, (N, 3), dev)
-                    _defer_reduction(xw_part, dW, 3 * N, xw_splits, row_in=N, params=(L.weight,), coef=coef)
+                    if xw_S is not None and _grad_sink is not None and _grad_sink.combine is None and id(L.weight) in _grad_sink.covered:
+                        _grad_sink.combine = (xw_S, coef, N, dW)          # (finished — and checked — by cpfn_adam_flat_xw)
+                    elif xw_S is not None:
+                        # (the sums are reduced already: finish from them — one split — with the same arithmetic)
+                        _defer_reduction(xw_S, dW, 3 * N, 1, row_in=N, params=(L.weight,), coef=coef)
+                    else:
+                        _defer_reduction(xw_part, dW, 3 * N, xw_splits, row_in=N, params=(L.weight,), coef=coef)
                     grads[0] = dW.reshape(wshape)
                     continue
                 if xyz_layer:
@@ -996,7 +1010,14 @@ class _FusedStack(torch.autograd.Function):
                         _l.add_bytes("cpfn_mlp_bwd_fused", 4 * P * N + 2 * P * Kp + 4 * splits * N * Kp + 2 * N * Kp
                                      + (0 if Yp.data_ptr() == a_in.data_ptr() else 2 * P * Kp) + 8 * splits * Kp + 12 * P + 28 * splits * Kp)
                         fused_part = (fp_, splits)
-                        xw_ride = (xw_part, splits)
+                        xw_S = None
+                        if (_grad_sink is not None and _grad_sink.combine_ok and _grad_sink.combine is None
+                                and _param_free(layers[0].weight) and id(layers[0].weight) in _grad_sink.views):
+                            # the riding sums reduced over their splits as a plain rider of the NEXT (= the pass's last) finalize
+                            # launch; c0 S1 + c1 S2 + c2 S3 itself is left to the optimizer's prepare kernel (XW_IN_PREPARE)
+                            xw_S = torch.empty(7 * Kp, dtype=torch.float32, device=dev)
+                            _defer_reduction(xw_part, xw_S, 7 * Kp, splits)
+                        xw_ride = (xw_part, splits, xw_S)
                         dW = _grad_out(L.weight, (N, L.cin), dev)
                         _defer_reduction(ws, dW, N * Kp, splits, params=(L.weight,)) if Kp == L.cin else \
                             _defer_reduction(ws, dW, N * Kp, splits, Kp, L.cin, params=(L.weight,))

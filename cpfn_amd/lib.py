@@ -74,6 +74,7 @@ SIGNATURES = {
     "cpfn_fit_pack_bwd": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp],
     "cpfn_nonfinite_flag": [_vp, _ll, _vp, _vp, _vp],
     "cpfn_adam_flat": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "cpfn_adam_flat_xw": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "cpfn_adam_flat_sticky": [_vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "cpfn_nonfinite_blocks": [_ll],
     "cpfn_nonfinite_partial": [_vp, _ll, _vp, _vp],

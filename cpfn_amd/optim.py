@@ -46,13 +46,15 @@ class FlatAdam(torch.optim.Optimizer):
         self.lr_dev.fill_(float(lr))
 
     @torch.no_grad()
-    def step(self, closure=None, check_gradients=False, skipped=None, nf_flags=None):
+    def step(self, closure=None, check_gradients=False, skipped=None, nf_flags=None, combine=None):
         """check_gradients: scan the flat gradient for NaN / inf in the same launch sequence and skip the step if any
         is found (the reference's per-parameter isinf/isnan scan, Utils/training_utils.py:151-156) — the scan's final
         reduction and the optional `skipped` device counter (+1 per skipped step) live in the 1-wave prepare kernel.
         nf_flags = (int32 flags tensor, count[, n_sticky]): per-workgroup flags of a scan that already happened (the checked packing
         copy of FlatGradBucket.collect); the step is skipped if any of them is set.  The first n_sticky words are OR-ed into by
-        the launches that wrote the gradients (fused_mlp.GradSink) and are cleared by this step's prepare kernel."""
+        the launches that wrote the gradients (fused_mlp.GradSink) and are cleared by this step's prepare kernel.
+        combine = (S [7 C], coef [3, C], C, out [C, 3] — a slice of the flat gradient): the pass's last gradient, finished (and
+        checked) by the prepare kernel (fused_mlp.GradSink.combine, cpfn_adam_flat_xw)."""
         g = self.param_groups[0]
         lr = g["lr"]
         if not isinstance(lr, torch.Tensor):       # someone assigned a float: mirror it into the device scalar
@@ -73,11 +75,12 @@ class FlatAdam(torch.optim.Optimizer):
                     self._nf_ws = torch.empty(256, dtype=torch.int32, device=self.flat_p.device)
                 nf_ws, nf_count = self._nf_ws, h.cpfn_nonfinite_blocks(grads.numel())
                 _l.check(h.cpfn_nonfinite_partial(_ptr(grads), grads.numel(), _ptr(nf_ws), _stream()), "cpfn_nonfinite_partial")
-            _l.check(h.cpfn_adam_flat_sticky(_ptr(self.flat_p), _ptr(grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-                                             self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
-                                             float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows),
-                                             _ptr(self.found_inf), _ptr(self._coef), _ptr(nf_ws), nf_count, n_sticky, _ptr(skipped),
-                                             _stream()), "cpfn_adam_flat")
+            xS, xc, xC, xo = combine if combine is not None else (None, None, 0, None)
+            _l.check(h.cpfn_adam_flat_xw(_ptr(self.flat_p), _ptr(grads), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                         self.flat_p.numel(), _ptr(lr), float(b1), float(b2), float(g["eps"]),
+                                         float(g["weight_decay"]), _ptr(self.step_count), _ptr(self.beta_pows),
+                                         _ptr(self.found_inf), _ptr(self._coef), _ptr(nf_ws), nf_count, n_sticky, _ptr(skipped),
+                                         _ptr(xS), _ptr(xc), int(xC), _ptr(xo), _stream()), "cpfn_adam_flat")
         _l.add_bytes("cpfn_adam_flat", 28 * self.flat_p.numel() + (4 * grads.numel() if check_gradients and nf_flags is None else 0))
 
     def state_dict(self):

@@ -121,12 +121,13 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
 
-    def sink(self, check):
+    def sink(self, check, combine_ok=False):
         """fused_mlp.grad_sink over this bucket for the backward pass of a step (GPU, bf16 fused path): the launches that produce
-        parameter gradients write them into the bucket's views and OR a NaN / inf into `sink_flag` (check=True)."""
+        parameter gradients write them into the bucket's views and OR a NaN / inf into `sink_flag` (check=True).
+        combine_ok: the caller's optimizer step takes GradSink.combine (FlatAdam.step(combine=...))."""
         from . import fused_mlp
         flag = self._sink_flags[0:1] if (self.flat.is_cuda and check) else None
-        return fused_mlp.grad_sink(self.params, self.views, self.flat, flag)
+        return fused_mlp.grad_sink(self.params, self.views, self.flat, flag, combine_ok)
 
     def collect(self, check=False, fault=None, sink=None):
         """Call after the backward pass: pack the fresh gradients into the flat buffer.  Parameters that
@@ -437,7 +438,7 @@ class SPFNTrainer:
         mark(geom)
         return geom
 
-    def _checked_optimizer_step(self, skipped, nf_flags=None, fault=None):
+    def _checked_optimizer_step(self, skipped, nf_flags=None, fault=None, combine=None):
         """Finite check of the flat gradient + optimizer step (skipped on the device when a NaN / inf is found) +
         `skipped` counter.  FlatAdam does all of it in its own launches — two when the scan already rode on the
         packing copy (nf_flags from FlatGradBucket.collect(check=True)); other optimizers get the flag tensor.
@@ -445,8 +446,9 @@ class SPFNTrainer:
         from .optim import FlatAdam
         if isinstance(self.optimizer, FlatAdam):
             self.optimizer.found_inf = fault
-            self.optimizer.step(check_gradients=nf_flags is None, skipped=skipped, nf_flags=nf_flags)
+            self.optimizer.step(check_gradients=nf_flags is None, skipped=skipped, nf_flags=nf_flags, combine=combine)
         else:
+            assert combine is None
             found = self.bucket.nonfinite_flag()
             self.optimizer.found_inf = found if fault is None else torch.maximum(found, fault)
             self.optimizer.step()
@@ -772,11 +774,13 @@ class SPFNTrainer:
                 out = self._graph_losses(sb, st)
                 # (the launches that produce parameter gradients write them into the flat bucket, finite check included:
                 #  FlatGradBucket.sink — no packing copy on one GPU, a one-word copy of the fault slot under data parallelism)
-                with self.bucket.sink(check=world == 1) as gsink:
+                from .optim import FlatAdam as _FA
+                with self.bucket.sink(check=world == 1, combine_ok=world == 1 and isinstance(self.optimizer, _FA)) as gsink:
                     out[0].backward(st["unit"])          # (no ones_like fill inside the graph)
                 nf = self.bucket.collect(check=world == 1, fault=st["flag_fault"] if world > 1 else None, sink=gsink)
                 if world == 1:
-                    self._checked_optimizer_step(st["skipped"], nf, fault=st["flag_fault"])
+                    self._checked_optimizer_step(st["skipped"], nf, fault=st["flag_fault"],
+                                                 combine=None if gsink is None else gsink.combine)
                 elif exchange_in_graph:
                     # data parallel: the gradient exchange (RCCL, over the 5.6 MB flat bucket) and the optimizer are nodes
                     # of the SAME graph: still one replay per step.  Two one-lane stamp kernels bracket it (device wall

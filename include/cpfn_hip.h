@@ -789,6 +789,15 @@ CPFN_API int cpfn_adam_flat_sticky(float *p, const float *g, float *m, float *v,
                                    float beta1, float beta2, float eps, float weight_decay, float *step,
                                    double *pows, const float *found_inf, float *coef3, unsigned *nf_partial, int nf_count,
                                    int n_sticky, float *skipped, void *stream);
+/* ... and with the LAST gradient of the backward pass finished by the prepare kernel: the weight gradient xw_out [C][3] of an fp32-xyz
+ * first layer, c0[c] S1[j][c] + c1[c] S2[j][c] + c2[c] S3[j] from xw_S [7][C] (the sums that rode on the layer above, cpfn_mlp_bwd_fused_xw,
+ * already reduced over their splits) and xw_coef [3][C] (that layer's cpfn_bn_bwd_finalize coefficients) — the arithmetic of
+ * cpfn_multi_split_reduce's coefficient form, checked for NaN / inf with the rest.  xw_out (a slice of g) == NULL: cpfn_adam_flat_sticky. */
+CPFN_API int cpfn_adam_flat_xw(float *p, const float *g, float *m, float *v, long long n, const float *lr,
+                               float beta1, float beta2, float eps, float weight_decay, float *step,
+                               double *pows, const float *found_inf, float *coef3, unsigned *nf_partial, int nf_count,
+                               int n_sticky, float *skipped, const float *xw_S, const float *xw_coef, int xw_C, float *xw_out,
+                               void *stream);
 /* First half of cpfn_nonfinite_flag: workspace256[i] = 1 if block i of x holds a NaN / inf, for
  * i < cpfn_nonfinite_blocks(n) (<= 256); the reduction is then done by cpfn_adam_flat's prepare kernel. */
 CPFN_API int cpfn_nonfinite_blocks(long long n);

@@ -207,13 +207,18 @@ def test_replayed_step_writes_its_gradients_straight_into_the_bucket(monkeypatch
         model.set_compute_dtype(torch.bfloat16)
         model.dropout_p = 0.0
         tr = training.SPFNTrainer(model, batch_size=4, init_learning_rate=1e-3, use_graphs=True)
-        calls = [0]
-        orig = h.cpfn_multi_copy_checked
+        calls, flushes = [0], [0]
+        orig, orig_flush = h.cpfn_multi_copy_checked, h.cpfn_multi_split_reduce_checked
 
         def spy(*a):
             calls[0] += 1
             return orig(*a)
+
+        def spy_flush(*a):
+            flushes[0] += 1 if torch.cuda.is_current_stream_capturing() else 0        # (launches of the captured pass only)
+            return orig_flush(*a)
         monkeypatch.setattr(h, "cpfn_multi_copy_checked", spy)
+        monkeypatch.setattr(h, "cpfn_multi_split_reduce_checked", spy_flush)
         torch.manual_seed(77)
         snaps = []
         for i in range(6):
@@ -221,15 +226,19 @@ def test_replayed_step_writes_its_gradients_straight_into_the_bucket(monkeypatch
             snaps.append((tr.bucket.flat.detach().clone(), [float(o) for o in out]))
         torch.cuda.synchronize()
         monkeypatch.setattr(h, "cpfn_multi_copy_checked", orig)
+        monkeypatch.setattr(h, "cpfn_multi_split_reduce_checked", orig_flush)
         assert tr._graph is not None and tr._graph["single"] and float(tr._graph["skipped"]) == 0.0
-        res[on] = (snaps, calls[0], tr, model)
+        res[on] = (snaps, calls[0], tr, model, flushes[0])
     # steps 0-2 ran as eager launches (warm-up + capture), 3-5 replayed: the same gradients and losses either way
     for (ga, la), (gb, lb) in zip(res[True][0], res[False][0]):
         # (parameter order inside the bucket is the same in both runs: FlatGradBucket's layout does not depend on the switch)
         assert torch.equal(ga, gb) and la == lb
     assert res[False][1] >= 1 and res[True][1] == 0, (res[True][1], res[False][1])
+    # ... and no reduction launch at the end of the captured pass either: its one leftover, sa1's first-layer weight gradient, is
+    # finished by the optimizer's prepare kernel (fused_mlp.XW_IN_PREPARE)
+    assert res[True][4] == 0 and res[False][4] >= 1, (res[True][4], res[False][4])
     # a poisoned batch through the replayed step with the sink on
-    _, _, tr, model = res[True]
+    _, _, tr, model, _ = res[True]
     bad = {k: v.clone() for k, v in batch.items()}
     bad["P"][1, 100, 2] = float("nan")
     w0, m0 = tr.optimizer.flat_p.clone(), tr.optimizer.exp_avg.clone()
