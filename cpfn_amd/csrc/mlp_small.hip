@@ -444,7 +444,10 @@ int cpfn_smallp_gemm_launch(const unsigned short *a, int lda, const unsigned sho
 }
 
 extern "C" int cpfn_mlp_dgrad_small_ok(long long P, int N, int K) {
-  return P > 0 && P <= SP_MAX_ROWS && N > 0 && (N & 31) == 0 && N <= SP_SS_MAX && K > 0 && (K & 63) == 0 &&
+  // (N, the contraction length here, is NOT bounded by SP_SS_MAX: that is the size of the operand transform's scale / shift vectors,
+  //  which a data gradient does not use.  Until round 6 it was, and sa3's 1024 <- 512 layer ran its weight gradient, its data gradient
+  //  and the reduction of the layer below as three launches instead of one.)
+  return P > 0 && P <= SP_MAX_ROWS && N > 0 && (N & 31) == 0 && N <= 4096 && K > 0 && (K & 63) == 0 &&
          P * N * 2 < (1LL << 31) && (long long)N * K * 2 < (1LL << 31);
 }
 

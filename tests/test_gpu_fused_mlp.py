@@ -607,8 +607,9 @@ def test_small_layer_backward_fusion(name, P, cin, widths, pool_k, stats_fused, 
         if fused == "merged":
             # round 3: weight gradient + data gradient of EVERY layer of a small stack as one launch each (the pooled top layer
             # included: its data gradient then also carries the reduction of the layer below)
-            # (sa3's 512 -> 1024 top layer keeps 128 x 128 weight-gradient tiles and with them its own two launches)
-            n_merged = len(widths) - (1 if widths[-1] >= 1024 else 0)
+            # (round 6: sa3's 512 -> 1024 top layer too — cpfn_mlp_dgrad_small_ok bounded the contraction length by the size of the
+            #  operand transform's vectors, which a data gradient does not use; it ran as three launches until then)
+            n_merged = len(widths)
             assert census["cpfn_mlp_bwd_small"][0] == n_merged and "cpfn_mlp_dgrad_small" not in census, sorted(census)
             assert census.get("cpfn_mlp_wgrad", (0, 0))[0] == len(widths) - n_merged
             if stats_fused:          # only the top layer (and the layer below an unmerged one) needs its own reduction pass
