@@ -160,12 +160,17 @@ class PointNet2(torch.nn.Module):
         # ... and so have sa2's (sa3's input rows, sfp1's skip): that sum is formed by sa2's own backward, in its first launch
         join2 = autograd_ops.SkipJoin() if (join1 is not None and autograd_ops.OUTPUT_JOIN) else None
         l2_xyz, l2, self.aux_sa2 = self.sa2.forward_rows(l1_xyz, l1, s2, gm.get("sa2"), cr, join=join1, join_out=join2)
-        _, l3, _ = self.sa3.forward_rows(l2_xyz, l2)                       # [B,1,1024]
+        # (sa3's global vector is read by sfp1's broadcast alone: pass 1 of sa3's last BatchNorm backward rides on that adjoint)
+        ride3 = None
+        if join1 is not None:
+            from .. import fused_mlp
+            ride3 = fused_mlp.TopRide()
+        _, l3, _ = self.sa3.forward_rows(l2_xyz, l2, top_ride=ride3)       # [B,1,1024]
         if self.use_glob_features:
             l3 = torch.cat([l3, glob_features.unsqueeze(1).to(l3.dtype)], dim=2)
         if self.use_loc_features:
             l3 = torch.cat([l3, loc_features.unsqueeze(1).to(l3.dtype)], dim=2)
-        l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3, join=join2)
+        l4, _ = self.sfp1.forward_rows(l2_xyz, None, l2, l3, join=join2, top_ride=ride3)
         l5, _ = self.sfp2.forward_rows(l1_xyz, l2_xyz, l1, l4, gm.get("sfp2"), cr, join=join1)
         cd = getattr(self, "compute_dtype", torch.float32)
         # bf16 HIP path: fc1 + bn1 + relu + dropout run as the last layer of sfp3's fused stack

@@ -72,10 +72,11 @@ class PointsetAbstraction(nn.Module):
             out["inv"] = ops.csr_build(scales[0][0], N)
         return out
 
-    def forward_rows(self, xyz, feats, start_idx=None, geom=None, cuda_route=False, join=None, join_out=None):
+    def forward_rows(self, xyz, feats, start_idx=None, geom=None, cuda_route=False, join=None, join_out=None, top_ride=None):
         """xyz [B,N,3] f32, feats [B,N,D] or None -> (new_xyz [B,S,3] | None, new_feats [B,S,D'], aux).
         join: an autograd_ops.SkipJoin shared with the OTHER consumer of `feats` (a later feature-propagation level's skip).
-        join_out: the same for this level's OUTPUT, where it has two consumers (single-scale levels only)."""
+        join_out: the same for this level's OUTPUT, where it has two consumers (single-scale levels only).
+        top_ride: a fused_mlp.TopRide shared with the consumer whose backward node produces the gradient of this level's output."""
         B, N, _ = xyz.shape
         aux = {}
         cd = getattr(self, "compute_dtype", torch.float32)
@@ -125,7 +126,8 @@ class PointsetAbstraction(nn.Module):
             x, xyz_rows, S, k = grp[:4]
             y = mlp.run_stack(x, convs, bns, cd, pool_k=k, xyz_rows=xyz_rows, xyz_tail=grp[4] if len(grp) > 4 else None,
                               gather=grp[5] if len(grp) > 5 else None,  # max over the K neighbours (ref :74)
-                              join_out=join_out if len(groups) == 1 else None)
+                              join_out=join_out if len(self.conv_blocks) == 1 else None,
+                              top_ride=top_ride if len(self.conv_blocks) == 1 else None)
             outs.append(y.reshape(B, S, -1))
         return new_xyz, torch.cat(outs, dim=2) if len(outs) > 1 else outs[0], aux
 

@@ -36,13 +36,14 @@ class PointsetFeaturePropagation(nn.Module):
         #                                                                     for the atomic-free interpolation adjoint
         return out
 
-    def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None, cuda_route=False, tail=None, join=None):
+    def forward_rows(self, xyz1, xyz2, feats1, feats2, geom=None, cuda_route=False, tail=None, join=None, top_ride=None):
         """xyz1 [B,N,3] dense, xyz2 [B,S,3] coarse or None, feats1 [B,N,D1] or None,
         feats2 [B,S,D2] -> [B,N,D'].
         tail = (convs, bns, dropout[, handover]) (bf16 HIP path only): more (conv, bn, relu) layers run as part of the SAME fused stack
         — the caller's next per-point layers (GlobalSPFN's fc1 + bn1 + dropout): the stack's own last activation is then
         never materialised and its BatchNorm-backward reduction rides on the next layer's data gradient.
-        join: an autograd_ops.SkipJoin shared with the earlier consumer of `feats1` (a set-abstraction level's grouping)."""
+        join: an autograd_ops.SkipJoin shared with the earlier consumer of `feats1` (a set-abstraction level's grouping).
+        top_ride: the fused_mlp.TopRide of the pooled stack that produced `feats2` (the broadcast form: sa3's global vector)."""
         B, N, _ = xyz1.shape
         aux = {}
         if xyz2 is not None and geom is None:
@@ -51,7 +52,7 @@ class PointsetFeaturePropagation(nn.Module):
         if feats1 is not None and autograd_ops.concat_interp_ok(feats1, feats2, idx):
             # bf16 HIP path: [feats1 | interpolation (or the broadcast global vector)] written by ONE launch
             x = autograd_ops.concat_interp(feats1, feats2, idx, None if xyz2 is None else geom["nn_w"],
-                                           None if xyz2 is None else geom.get("inv"), join)
+                                           None if xyz2 is None else geom.get("inv"), join, top_ride if xyz2 is None else None)
             aux = {} if xyz2 is None else geom
         else:
             if xyz2 is None:

@@ -205,7 +205,9 @@ class ConcatInterp(torch.autograd.Function):
     no slice copy —, the broadcast part is a column sum (cpfn_colsum_rows_bf16)."""
 
     @staticmethod
-    def forward(ctx, skip, feats, idx, w, inv_off=None, inv_ent=None, join=None):
+    def forward(ctx, skip, feats, idx, w, inv_off=None, inv_ent=None, join=None, top_ride=None):
+        """top_ride (broadcast form): the fused_mlp.TopRide of the pooled stack that produced `feats` — this node's backward then
+        also leaves BatchNorm-backward pass 1 of that stack's last layer (cpfn_colsum_rows_pass1_bf16)."""
         B, N, C1 = skip.shape
         M, C2 = feats.shape[1], feats.shape[2]
         sk, f = skip.contiguous(), feats.contiguous()
@@ -223,6 +225,8 @@ class ConcatInterp(torch.autograd.Function):
         ctx.save_for_backward(idx, w)
         ctx.inv = None if inv_off is None else (inv_off, inv_ent)
         ctx.dims = (B, M, N, C1, C2)
+        o_ = None if top_ride is None else top_ride.offer
+        ctx.top_ride = top_ride if (o_ is not None and idx is None and o_[0] == f.data_ptr() and o_[1] == B and o_[2] == C2) else None
         return out
 
     @staticmethod
@@ -239,14 +243,22 @@ class ConcatInterp(torch.autograd.Function):
             g_skip = None
         if idx is None:
             gf = torch.empty(B, 1, C2, dtype=torch.bfloat16, device=g.device)
+            tr = ctx.top_ride
             with torch.cuda.device(g.device):
-                _l.check(_l.lib().cpfn_colsum_rows_bf16(_ptr(g_int), C1 + C2, B, N, C2, _ptr(gf), _stream()), "cpfn_colsum_rows_bf16")
+                if tr is not None and tr.offer is not None:
+                    _, _, _, yarg, sc_, sh_ = tr.offer
+                    part = torch.empty(B, 2, C2, dtype=torch.float32, device=g.device)
+                    _l.check(_l.lib().cpfn_colsum_rows_pass1_bf16(_ptr(g_int), C1 + C2, B, N, C2, _ptr(gf), _ptr(yarg), _ptr(sc_),
+                                                                  _ptr(sh_), _ptr(part), _stream()), "cpfn_colsum_rows_pass1_bf16")
+                    tr.result = (gf.data_ptr(), gf._version, part, B)
+                else:
+                    _l.check(_l.lib().cpfn_colsum_rows_bf16(_ptr(g_int), C1 + C2, B, N, C2, _ptr(gf), _stream()), "cpfn_colsum_rows_bf16")
             _l.add_bytes("cpfn_colsum_rows_bf16", 2 * B * N * C2 + 2 * B * C2)
         elif ctx.inv is not None:
             gf = _csr_sum_bf16(g_int, C1 + C2, ctx.inv, w, 3, B, N, M, C2)
         else:
             gf = _scatter_bf16(g_int, C1 + C2, idx, w, 3, B, N, M, C2).to(torch.bfloat16)
-        return g_skip, gf, None, None, None, None, None
+        return g_skip, gf, None, None, None, None, None, None
 
 
 def concat_interp_ok(skip, feats, idx):
@@ -256,10 +268,10 @@ def concat_interp_ok(skip, feats, idx):
             and feats.shape[2] % 8 == 0 and ((idx is None and feats.shape[1] == 1) or (idx is not None and feats.shape[1] <= 1024)))
 
 
-def concat_interp(skip, feats, idx=None, w=None, inv=None, join=None):
+def concat_interp(skip, feats, idx=None, w=None, inv=None, join=None, top_ride=None):
     if inv is not None:
-        return ConcatInterp.apply(skip, feats, idx, w, inv[0], inv[1], join)
-    return ConcatInterp.apply(skip, feats, idx, w, None, None, join)
+        return ConcatInterp.apply(skip, feats, idx, w, inv[0], inv[1], join, top_ride)
+    return ConcatInterp.apply(skip, feats, idx, w, None, None, join, top_ride)
 
 
 def interp_rows(feats, idx, w, inv=None):

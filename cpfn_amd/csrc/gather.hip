@@ -252,8 +252,18 @@ __global__ __launch_bounds__(TPB) void concat_interp_bf16_kernel(const unsigned 
 
 // out[b,c] = Σ_n g[b,n,c] for a column block of a row-major bf16 tensor (row stride ldg): adjoint of the broadcast
 // above.  One lane per (cloud, 8-channel chunk, row subset), fp32 sums, subsets combined in a fixed order through LDS.
+// PASS1 (round 6): `out` [B, C] is the gradient of a max-pooled stack's output (sa3's global feature vector, one row per cloud),
+// so BatchNorm-backward pass 1 of that stack's last layer — sum g_z, sum g_z y over its B rows, g_z = g [scale y + shift > 0] with y
+// the pre-BN value at the arg-max row (bn_relu_bwd_kernel's arithmetic) — is taken from the row while it is being stored: one
+// partial row per cloud, part [B][2][C], for cpfn_bn_bwd_finalize (nblk = B).  The one-workgroup cpfn_bn_relu_bwd launch that read
+// the [B, C] gradient back (6 us + a kernel boundary on the backward chain) is not made.
+template <bool PASS1>
 __global__ __launch_bounds__(TPB) void colsum_rows_bf16_kernel(const unsigned short *__restrict__ g, int ldg, int N, int C,
-                                                               unsigned short *__restrict__ out) {
+                                                               unsigned short *__restrict__ out,
+                                                               const unsigned short *__restrict__ yarg = nullptr,
+                                                               const float *__restrict__ scale = nullptr,
+                                                               const float *__restrict__ shift = nullptr,
+                                                               float *__restrict__ part = nullptr) {
   __shared__ float s_acc[TPB][9];
   const int b = blockIdx.y, t = threadIdx.x;
   const int cpr = C / 8;                                   // chunks of the column block
@@ -281,7 +291,23 @@ __global__ __launch_bounds__(TPB) void colsum_rows_bf16_kernel(const unsigned sh
       for (int q = 0; q < 8; ++q) v += s_acc[q * 32 + ch][j];
       ov[j] = f2bf_(v);
     }
-    *(uint4 *)(out + (size_t)b * C + ((size_t)blockIdx.x * 32 + ch) * 8) = *(const uint4 *)ov;
+    const size_t c0 = ((size_t)blockIdx.x * 32 + ch) * 8;
+    *(uint4 *)(out + (size_t)b * C + c0) = *(const uint4 *)ov;
+    if (PASS1) {
+      const uint4 ry = *(const uint4 *)(yarg + (size_t)b * C + c0);
+      const unsigned short *y = (const unsigned short *)&ry;
+      float z1[8], z2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float yv = bf2f_(y[j]);
+        const float gz = fmaf(scale[c0 + j], yv, shift[c0 + j]) > 0.f ? bf2f_(ov[j]) : 0.f;
+        z1[j] = gz;
+        z2[j] = gz * yv;
+      }
+      float *p1 = part + ((size_t)b * 2 + 0) * C + c0, *p2 = part + ((size_t)b * 2 + 1) * C + c0;
+      *(float4 *)p1 = make_float4(z1[0], z1[1], z1[2], z1[3]); *(float4 *)(p1 + 4) = make_float4(z1[4], z1[5], z1[6], z1[7]);
+      *(float4 *)p2 = make_float4(z2[0], z2[1], z2[2], z2[3]); *(float4 *)(p2 + 4) = make_float4(z2[4], z2[5], z2[6], z2[7]);
+    }
   }
 }
 
@@ -963,13 +989,23 @@ extern "C" int cpfn_concat_interp_bf16(const void *skip, int C1, const void *fea
   return cpfn_launch_status();
 }
 
-extern "C" int cpfn_colsum_rows_bf16(const void *g, int ldg, int B, int N, int C, void *out, void *stream) {
+extern "C" int cpfn_colsum_rows_pass1_bf16(const void *g, int ldg, int B, int N, int C, void *out, const void *yarg, const float *scale,
+                                          const float *shift, float *part, void *stream) {
   if (B < 0 || N <= 0 || C <= 0 || (C & 7) || (ldg & 7) || ldg < C || !g || !out) return CPFN_EINVAL;
+  if (yarg && (!scale || !shift || !part)) return CPFN_EINVAL;
   if (B == 0) return 0;
   static_assert(TPB == 256, "32 chunks x 8 row subsets");
-  colsum_rows_bf16_kernel<<<dim3(cpfn_cdiv(C / 8, 32), B), TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, N, C,
-                                                                                         (unsigned short *)out);
+  const dim3 grid(cpfn_cdiv(C / 8, 32), B);
+  if (yarg)
+    colsum_rows_bf16_kernel<true><<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, N, C, (unsigned short *)out,
+                                                                         (const unsigned short *)yarg, scale, shift, part);
+  else
+    colsum_rows_bf16_kernel<false><<<grid, TPB, 0, (hipStream_t)stream>>>((const unsigned short *)g, ldg, N, C, (unsigned short *)out);
   return cpfn_launch_status();
+}
+
+extern "C" int cpfn_colsum_rows_bf16(const void *g, int ldg, int B, int N, int C, void *out, void *stream) {
+  return cpfn_colsum_rows_pass1_bf16(g, ldg, B, N, C, out, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, const float *w, int T, int B, int R,

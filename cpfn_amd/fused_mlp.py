@@ -792,6 +792,8 @@ class _FusedStack(torch.autograd.Function):
                     else:
                         out, arg, yarg = bn_relu_maxpool(Y, st[0], st[1], pool_k)
                     saved.append((a, a_ss, Y, st, Wb, arg, yarg))
+                    if cfg.get("top_ride") is not None and L.training:
+                        cfg["top_ride"].offer = (out.data_ptr(), P // pool_k, N, yarg, st[0], st[1])
                 elif last or not BN_APPLY_FUSED:
                     if last and cfg.get("dropout") is not None:
                         nxt, drop_seed = bn_relu_apply(Y, st[0], st[1], cfg["dropout"], counter_advanced=drop_in_finalize)
@@ -881,6 +883,12 @@ class _FusedStack(torch.autograd.Function):
                     nblk = h.cpfn_bn_bwd_blocks(G)
                     part = torch.empty(nblk, 2, N, dtype=torch.float32, device=dev)
                     pass1_done = False
+                    tr_ = cfg.get("top_ride")
+                    if tr_ is not None and tr_.result is not None:
+                        res_, tr_.result = tr_.result, None
+                        if (joined is None and res_[0] == g_in.data_ptr() and res_[1] == g_in._version and res_[3] == G
+                                and g.data_ptr() == g_in.data_ptr()):
+                            part, nblk, pass1_done = res_[2], G, True       # (one partial row per row of the pooled gradient)
                     if joined is not None:
                         # the two consumers' gradients summed on load (what autograd's input buffer did with a framework add)
                         gb, ldb = joined
@@ -1139,7 +1147,7 @@ def _plan(h, P, N, a_in, pool_k, xyz_layer, need_dgrad, dropout):
 
 
 def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, xyz_tail=None, handover=None, gather=None,
-                    join_out=None):
+                    join_out=None, top_ride=None):
     """x: bf16 rows [P, Kpad] (Kpad a multiple of 64, zero-padded beyond the first conv's
     in_channels) — or fp32 [P, KS<=4] with first_fp32=True; xyz_tail [P,3] fp32: three more input channels of the first
     layer (behind x's D = Kpad channels) that stay fp32.  Returns bf16 [P, C_last], or
@@ -1160,7 +1168,10 @@ def fused_mlp_stack(x, convs, bns, pool_k=None, first_fp32=False, dropout=None, 
         raise ValueError("gather = (table [B*n_src, D] bf16, idx [P] int32, rows per cloud, n_src) belongs to an xyz-tail first layer "
                          "(fused_mlp.gather_on_load_ok)")
     cfg = {"layers": layers, "pool_k": pool_k, "first_fp32": first_fp32, "dropout": dropout, "xyz_tail": xyz_tail,
-           "handover": handover, "gather": gather, "join_out": join_out if pool_k else None}
+           "handover": handover, "gather": gather, "join_out": join_out if pool_k else None,
+           "top_ride": top_ride if (pool_k and TOP_RIDE) else None}
+    if top_ride is not None:
+        top_ride.offer = top_ride.result = None
     params = []
     for L in layers:
         params += [L.weight, L.gamma, L.beta]
@@ -1202,6 +1213,22 @@ def _packed_heads(weights, biases):
         src = [w.detach().reshape(w.shape[0], -1) for w in weights] + [b.detach() for b in biases]
         _foreach_copy_by_dtype(ent["dst"], src)
     return ent["Wb"], ent["bp"], ent["N"]
+
+
+TOP_RIDE = _os.environ.get("CPFN_TOP_RIDE", "1") == "1"
+
+
+class TopRide:
+    """BatchNorm-backward pass 1 of a POOLED stack's last layer taken by the launch that produces the gradient of its output
+    (round 6: sa3's global feature vector, whose gradient is the column sum of sfp1's broadcast adjoint,
+    cpfn_colsum_rows_pass1_bf16).  An object of one forward pass, like HandOver:
+      offer   set by the stack: (output address, G, N, yarg, scale, shift);
+      result  set by the consumer's backward node: (gradient address, gradient version, partials [G, 2, N], G).
+    Honoured only for the very tensors it was made for (address + in-place version)."""
+    __slots__ = ("offer", "result")
+
+    def __init__(self):
+        self.offer = self.result = None
 
 
 class HandOver:

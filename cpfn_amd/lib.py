@@ -46,6 +46,7 @@ SIGNATURES = {
     "cpfn_interp_rows_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_concat_interp_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "cpfn_colsum_rows_bf16": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "cpfn_colsum_rows_pass1_bf16": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "cpfn_scatter_rows_bf16": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_group_concat_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "cpfn_multi_copy": [_vp, _i, _vp],

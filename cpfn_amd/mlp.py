@@ -49,7 +49,7 @@ def shared_mlp(x, convs, bns, dtype=torch.float32):
 
 
 def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None, gather=None,
-              join_out=None):
+              join_out=None, top_ride=None):
     """Run a whole (conv, bn, relu)* stack on rows and optionally max-pool every `pool_k`
     consecutive rows.  `x` [P, C_in] (any float dtype) — or None with `xyz_rows` [P, 3] fp32
     when the stack's only input is relative coordinates (sa1).
@@ -80,7 +80,8 @@ def run_stack(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dr
             else:
                 xp[:, :C] = x
             x = xp
-        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout, handover=handover, join_out=join_out)
+        return fused_mlp.fused_mlp_stack(x, convs, bns, pool_k=pool_k, dropout=dropout, handover=handover, join_out=join_out,
+                                         top_ride=top_ride)
     if dropout is not None or xyz_tail is not None:
         raise ValueError("fused dropout / the xyz tail exist on the bf16 HIP path only")
     y = shared_mlp(src, convs, bns, dtype)

@@ -208,6 +208,12 @@ CPFN_API int cpfn_concat_interp_bf16(const void *skip, int C1, const void *feats
                                      int M, int N, int C2, void *out, void *stream);
 /* out[B,C] (bf16) = column sums over the N rows of a column block of g (bf16, row stride ldg): adjoint of that broadcast. */
 CPFN_API int cpfn_colsum_rows_bf16(const void *g, int ldg, int B, int N, int C, void *out, void *stream);
+/* ... which IS the gradient of sa3's max-pooled output, one row per cloud (PointNet2/pn2_network.py:49,56): with yarg [B,C] (bf16, the
+ * pre-BN values at the arg-max rows), scale / shift [C] of that stack's last layer, the same launch leaves BatchNorm-backward pass 1
+ * of it as one partial row per cloud, part [B][2][C] (sum g_z, sum g_z y — cpfn_bn_relu_bwd's arithmetic on a single row), for
+ * cpfn_bn_bwd_finalize with nblk = B.  yarg == NULL: the plain entry. */
+CPFN_API int cpfn_colsum_rows_pass1_bf16(const void *g, int ldg, int B, int N, int C, void *out, const void *yarg, const float *scale,
+                                         const float *shift, float *part, void *stream);
 CPFN_API int cpfn_scatter_rows_bf16(const void *g, int ldg, const int *idx, const float *w, int T, int B,
                                     int R, int M, int C, float *out, void *stream);
 /* (rel == NULL with Cpad == C: the gather alone) */

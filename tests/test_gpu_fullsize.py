@@ -163,7 +163,7 @@ def _teacher_forced_stacks(model, batch, starts, tag):
     calls, orig = [], mlp.run_stack
 
     def spy(x, convs, bns, dtype=torch.float32, pool_k=None, xyz_rows=None, dropout=None, xyz_tail=None, handover=None, gather=None,
-            join_out=None):
+            **side_channels):            # (join_out, top_ride, ...: objects of the bf16 path's backward; unused in fp32 mode)
         assert xyz_tail is None and gather is None          # (fp32 mode: the grouped rows arrive concatenated)
         calls.append((None if x is None else x.detach().clone(), convs, bns, pool_k, None if xyz_rows is None else xyz_rows.detach().clone()))
         return orig(x, convs, bns, dtype, pool_k=pool_k, xyz_rows=xyz_rows, dropout=dropout)

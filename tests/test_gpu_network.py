@@ -455,6 +455,59 @@ def test_skip_join_gives_the_gradients_of_the_framework_add(monkeypatch):
     assert adds[True] == adds[False] - 2, adds
 
 
+def test_sa3_pass1_rides_on_the_broadcast_adjoint(monkeypatch):
+    """fused_mlp.TopRide: the gradient of sa3's global feature vector is the column sum of sfp1's broadcast adjoint, one row per
+    cloud; BatchNorm-backward pass 1 of sa3's last layer is taken from those rows as they are stored (cpfn_colsum_rows_pass1_bf16:
+    one partial row per cloud) instead of by a one-workgroup launch that reads them back.  The same sums in another grouping:
+    losses identical, every parameter gradient within the tolerance of the other riding reductions, one cpfn_bn_relu_bwd launch
+    fewer; the kernel itself against cpfn_colsum_rows_bf16 + cpfn_bn_relu_bwd bit for bit."""
+    from cpfn_amd import fused_mlp, lib as _l, synthetic
+    dev = torch.device("cuda:0")
+    h = _l.lib()
+    # kernel level
+    g = torch.Generator().manual_seed(8)
+    B, N, C1, C2 = 5, 128, 256, 1024
+    wide = torch.randn(B, N, C1 + C2, generator=g).to(dev).to(torch.bfloat16)
+    yarg = torch.randn(B, C2, generator=g).to(dev).to(torch.bfloat16)
+    scale, shift = (torch.rand(C2, generator=g) - 0.3).to(dev), (torch.randn(C2, generator=g) * 0.2).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    gcol = wide[:, :, C1:]
+    ref = torch.empty(B, C2, dtype=torch.bfloat16, device=dev)
+    got = torch.empty_like(ref)
+    part = torch.empty(B, 2, C2, device=dev)
+    _l.check(h.cpfn_colsum_rows_bf16(gcol.data_ptr(), C1 + C2, B, N, C2, ref.data_ptr(), st), "colsum")
+    _l.check(h.cpfn_colsum_rows_pass1_bf16(gcol.data_ptr(), C1 + C2, B, N, C2, got.data_ptr(), yarg.data_ptr(), scale.data_ptr(),
+                                           shift.data_ptr(), part.data_ptr(), st), "colsum_pass1")
+    assert torch.equal(got, ref)
+    for b in range(B):            # a single-row cpfn_bn_relu_bwd per cloud is the same arithmetic
+        p1 = torch.empty(h.cpfn_bn_bwd_blocks(1), 2, C2, device=dev)
+        _l.check(h.cpfn_bn_relu_bwd(ref[b:b + 1].data_ptr(), yarg[b:b + 1].data_ptr(), scale.data_ptr(), shift.data_ptr(), 1, C2, None,
+                                    p1.data_ptr(), None, 0.0, st), "bn_relu_bwd")
+        assert torch.equal(part[b], p1[0])
+    # network level
+    batch = {k: v.to(dev) for k, v in synthetic.training_batch(2, N=2048, n_prims=6, n_inst_points=128, seed=3).items()}
+    starts = (torch.tensor([5, 17]), torch.tensor([1, 300]))
+    res, n_pass1 = {}, {}
+    orig = h.cpfn_bn_relu_bwd
+    for on in (True, False):
+        monkeypatch.setattr(fused_mlp, "TOP_RIDE", on)
+        model = _fresh_model(28)
+        torch.manual_seed(5)
+        n = [0]
+
+        def spy(*a):
+            n[0] += 1
+            return orig(*a)
+        monkeypatch.setattr(h, "cpfn_bn_relu_bwd", spy)
+        res[on] = _step_grads(model, batch, starts, None)
+        monkeypatch.setattr(h, "cpfn_bn_relu_bwd", orig)
+        n_pass1[on] = n[0]
+    assert res[True][1] == res[False][1]
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a is None and b is None) or float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)) < 2e-3
+    assert n_pass1[True] == n_pass1[False] - 1, n_pass1
+
+
 def test_skip_join_raises_when_the_grouping_adjoint_never_runs():
     """A gradient handed over and never picked up (a backward pass that stops above sa2's grouping) must not be lost silently."""
     from cpfn_amd import autograd_ops
